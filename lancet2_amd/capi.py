@@ -1,0 +1,126 @@
+"""ctypes view of include/microasm.h (structs + output buffer allocation).
+
+Used by bench.py and tests/ to drive the product library (libmicroasm.so) and -- in tests only --
+the oracle (oracle/liboracle.so exports the same layouts with an ``orc_`` prefix).  This module
+contains NO compute: it only describes memory.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB_PATH = os.path.join(REPO, "lancet2_amd", "libmicroasm.so")
+
+MA_RF_PASS, MA_RF_CASE, MA_RF_REV = 1, 2, 4
+MA_W_NO_HAPLOTYPE, MA_W_HAP_OVERFLOW, MA_W_LEN_OVERFLOW = 1, 2, 4
+MA_W_BFS_LIMIT, MA_W_TABLE_OVERFLOW, MA_W_VAR_OVERFLOW = 8, 16, 32
+MA_MEM_HOST, MA_MEM_DEVICE = 0, 1
+
+
+class Params(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "min_k", "max_k", "k_step", "min_node_cov", "min_anchor_cov", "num_samples",
+        "min_anchor_len", "max_mismatch", "bfs_limit", "band", "min_aln_score",
+        "max_comps", "max_haps", "max_hap_len", "max_runs", "max_vars", "max_alts",
+        "max_allele_bytes", "max_cigar", "case_ctrl_mode")]
+
+
+def default_params(**kw):
+    p = Params(13, 127, 6, 2, 5, 2, 150, 2, 1 << 20, 64, 80, 4, 16, 2048, 256, 64, 4, 4096, 16, 1)
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
+class Batch(C.Structure):
+    _fields_ = [("n_windows", C.c_int32), ("n_reads", C.c_int64),
+                ("ref_bases", C.c_void_p), ("ref_off", C.c_void_p), ("read_win_off", C.c_void_p),
+                ("read_off", C.c_void_p), ("read_bases", C.c_void_p), ("read_quals", C.c_void_p),
+                ("read_qname_id", C.c_void_p), ("read_sample", C.c_void_p), ("read_flags", C.c_void_p)]
+
+
+class GateOut(C.Structure):
+    _fields_ = [("max_approx", C.c_void_p), ("max_exact", C.c_void_p)]
+
+
+class AsmOut(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in (
+        "win_status", "win_k", "win_ncomp", "comp_anchor", "comp_hap0", "comp_nhaps", "comp_cx",
+        "comp_cxf", "hap_len", "hap_nruns", "hap_stats", "hap_bases", "hap_runs")]
+
+
+class VarOut(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in (
+        "win_nvars", "var_comp", "var_pos", "var_ref_start", "var_ref_off", "var_ref_len",
+        "var_nalts", "alt_off", "alt_len", "alt_type", "alt_length", "var_hap_allele",
+        "var_hap_start", "allele_pool")]
+
+
+class GenoOut(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in (
+        "allele_counts", "var_qual", "aln_rec", "aln_cigar", "asg_allele", "asg_score")]
+
+
+BATCH_DTYPES = dict(ref_bases=np.uint8, ref_off=np.uint32, read_win_off=np.uint32,
+                    read_off=np.uint64, read_bases=np.uint8, read_quals=np.uint8,
+                    read_qname_id=np.uint32, read_sample=np.uint8, read_flags=np.uint8)
+
+
+def asm_out_spec(p, n):
+    MC, MH, ML, MR = p.max_comps, p.max_haps, p.max_hap_len, p.max_runs
+    return dict(win_status=(np.uint32, n), win_k=(np.uint32, n), win_ncomp=(np.uint32, n),
+                comp_anchor=(np.uint32, n * MC), comp_hap0=(np.uint32, n * MC),
+                comp_nhaps=(np.uint32, n * MC), comp_cx=(np.uint32, n * MC * 3),
+                comp_cxf=(np.float64, n * MC * 4), hap_len=(np.uint32, n * MH),
+                hap_nruns=(np.uint32, n * MH), hap_stats=(np.float64, n * MH * 6),
+                hap_bases=(np.uint8, n * MH * ML), hap_runs=(np.uint32, n * MH * MR * 2))
+
+
+def var_out_spec(p, n):
+    MH, MV, MA, MP = p.max_haps, p.max_vars, p.max_alts, p.max_allele_bytes
+    return dict(win_nvars=(np.uint32, n), var_comp=(np.uint32, n * MV), var_pos=(np.uint32, n * MV),
+                var_ref_start=(np.uint32, n * MV), var_ref_off=(np.uint32, n * MV),
+                var_ref_len=(np.uint32, n * MV), var_nalts=(np.uint32, n * MV),
+                alt_off=(np.uint32, n * MV * MA), alt_len=(np.uint32, n * MV * MA),
+                alt_type=(np.int32, n * MV * MA), alt_length=(np.int32, n * MV * MA),
+                var_hap_allele=(np.uint8, n * MV * MH), var_hap_start=(np.uint32, n * MV * MH),
+                allele_pool=(np.uint8, n * MP))
+
+
+def geno_out_spec(p, n, n_reads, debug=True):
+    MH, MV, MA, S, MCG = p.max_haps, p.max_vars, p.max_alts, p.num_samples, p.max_cigar
+    spec = dict(allele_counts=(np.uint32, n * MV * S * (MA + 1) * 2), var_qual=(np.float64, n * MV))
+    if debug:
+        spec.update(aln_rec=(np.int32, n_reads * MH * 6), aln_cigar=(np.uint32, n_reads * MH * (1 + MCG)),
+                    asg_allele=(np.uint8, n_reads * MV), asg_score=(np.float64, n_reads * MV))
+    return spec
+
+
+def gate_out_spec(n):
+    return dict(max_approx=(np.uint32, n), max_exact=(np.uint32, n))
+
+
+def alloc_host(spec):
+    return {k: np.zeros(sz, dtype=dt) for k, (dt, sz) in spec.items()}
+
+
+def fill_struct(cls, arrays):
+    """Build a ctypes struct whose pointer fields reference numpy arrays (kept alive by caller)."""
+    s = cls()
+    for name, _ in cls._fields_:
+        a = arrays.get(name) if isinstance(arrays, dict) else None
+        if a is None:
+            continue
+        if isinstance(a, np.ndarray):
+            setattr(s, name, a.ctypes.data)
+        else:  # torch tensor or raw int pointer
+            setattr(s, name, a if isinstance(a, int) else a.data_ptr())
+    return s
+
+
+def make_batch_struct(arrs, n_windows, n_reads):
+    b = fill_struct(Batch, arrs)
+    b.n_windows = n_windows
+    b.n_reads = n_reads
+    return b

@@ -1,0 +1,375 @@
+// ORACLE -- TEST INFRASTRUCTURE ONLY (see common.hpp header).
+// Read <-> haplotype aligner and the CIGAR-based allele-scoring epilogue.
+//
+// PARITY UNPINNED for the aligner: the reference calls minimap2 2.30 (mm_map with
+// k=11,w=5 seeds, a=1 b=4 q=12 e=3 single-affine, bw=10000, zdrop off, end_bonus=10000,
+// best_n=1: caller/genotyper.cpp:89-191, :376-411); its source is not under
+// /root/reference and no reference test pins its output.  What follows is the engine's
+// CANONICAL restatement of that contract (DESIGN.md "read<->haplotype aligner"):
+//   1. nt4 encoding; substitution +1 / -4, any ambiguous base -1 (minimap2 sc_ambi);
+//      a gap of length L costs 12 + 3L.
+//   2. Seed vote: every exact 11-mer shared by read and haplotype votes for its diagonal
+//      d = hap_pos - read_pos; the band centre is the most-voted diagonal (ties: smallest d);
+//      no shared 11-mer => no hit.
+//   3. Banded (|j - i - centre| <= band) overlap alignment: the read is aligned end to end
+//      unless it overhangs a haplotype end, in which case the overhang is soft-clipped
+//      (start cells (0,j) and (i,0); end cells (m,j) and (i,n)).
+//   4. Best end cell: max score, ties -> larger i, then smaller j.  Traceback: diagonal
+//      first, then deletion (E), then insertion (F); inside a gap prefer opening over
+//      extending (left-aligned gaps, ksw2's default).
+//   5. A hit is reported iff score >= 80 (minimap2's default min_dp_max, which the reference
+//      does not override).
+// The scoring epilogue below IS first-party reference code and is restated literally.
+#include "oracle.hpp"
+
+namespace orc {
+
+AlnResult AlignReadToHap(std::string_view read, std::string_view hap, const AlignParams& ap) {
+  AlnResult res;
+  i32 const m = static_cast<i32>(read.size()), n = static_cast<i32>(hap.size());
+  i32 const SK = ap.seed_k;
+  if (m < SK || n < SK) return res;
+  std::vector<u8> q(m), t(n);
+  for (i32 i = 0; i < m; ++i) q[i] = EncodeBase(read[i]);
+  for (i32 j = 0; j < n; ++j) t[j] = EncodeBase(hap[j]);
+
+  // --- seed vote ---
+  auto code_at = [&](const std::vector<u8>& s, i32 p, u32* code) {
+    u32 c = 0;
+    for (i32 x = 0; x < SK; ++x) {
+      if (s[p + x] > 3) return false;
+      c = (c << 2) | s[p + x];
+    }
+    *code = c;
+    return true;
+  };
+  std::unordered_map<u32, std::vector<i32>> index;
+  for (i32 j = 0; j + SK <= n; ++j) {
+    u32 c;
+    if (code_at(t, j, &c)) index[c].push_back(j);
+  }
+  std::vector<i32> votes(static_cast<usize>(m + n + 1), 0);  // diag d -> votes[d + m]
+  for (i32 i = 0; i + SK <= m; ++i) {
+    u32 c;
+    if (!code_at(q, i, &c)) continue;
+    auto it = index.find(c);
+    if (it == index.end()) continue;
+    for (i32 j : it->second) votes[static_cast<usize>(j - i + m)]++;
+  }
+  i32 best_votes = 0, centre = 0;
+  for (i32 d = -m; d <= n; ++d)
+    if (votes[static_cast<usize>(d + m)] > best_votes) {
+      best_votes = votes[static_cast<usize>(d + m)];
+      centre = d;
+    }
+  if (best_votes == 0) return res;
+
+  // --- banded overlap DP ---
+  i32 const B = ap.band, GO = 12, GE = 3;
+  i32 const NEG = -(1 << 28);
+  i32 const Wd = 2 * B + 1;  // band positions t = j - i - centre + B
+  auto IDX = [&](i32 i, i32 tt) { return static_cast<usize>(i) * Wd + tt; };
+  std::vector<i32> H(static_cast<usize>(m + 1) * Wd, NEG), E(H.size(), NEG), F(H.size(), NEG);
+  auto in_band = [&](i32 i, i32 j) {
+    i32 const tt = j - i - centre + B;
+    return tt >= 0 && tt < Wd && j >= 0 && j <= n;
+  };
+  auto getH = [&](i32 i, i32 j) { return in_band(i, j) ? H[IDX(i, j - i - centre + B)] : NEG; };
+  auto getE = [&](i32 i, i32 j) { return in_band(i, j) ? E[IDX(i, j - i - centre + B)] : NEG; };
+  auto getF = [&](i32 i, i32 j) { return in_band(i, j) ? F[IDX(i, j - i - centre + B)] : NEG; };
+  auto sub = [&](i32 i, i32 j) -> i32 {  // 1-based cell (i,j) pairs q[i-1], t[j-1]
+    u8 const a = q[i - 1], b = t[j - 1];
+    if (a > 3 || b > 3) return -1;
+    return a == b ? 1 : -4;
+  };
+  for (i32 i = 0; i <= m; ++i) {
+    for (i32 tt = 0; tt < Wd; ++tt) {
+      i32 const j = i + centre - B + tt;
+      if (j < 0 || j > n) continue;
+      i32 h, e = NEG, f = NEG;
+      if (i == 0 || j == 0) {
+        h = 0;  // free start: read begins inside the haplotype, or overhangs its left end
+      } else {
+        e = std::max(getH(i, j - 1) - (GO + GE), getE(i, j - 1) - GE);
+        f = std::max(getH(i - 1, j) - (GO + GE), getF(i - 1, j) - GE);
+        h = std::max(getH(i - 1, j - 1) + sub(i, j), std::max(e, f));
+      }
+      H[IDX(i, tt)] = h;
+      E[IDX(i, tt)] = e;
+      F[IDX(i, tt)] = f;
+    }
+  }
+  // --- best end cell: (m, j) any j, or (i, n) any i ---
+  i32 best = NEG, bi = -1, bj = -1;
+  auto consider = [&](i32 i, i32 j) {
+    if (!in_band(i, j)) return;
+    i32 const h = getH(i, j);
+    if (h > best || (h == best && (i > bi || (i == bi && j < bj)))) {
+      best = h;
+      bi = i;
+      bj = j;
+    }
+  };
+  for (i32 j = 0; j <= n; ++j) consider(m, j);
+  for (i32 i = 0; i < m; ++i) consider(i, n);
+  if (bi < 0 || best < ap.min_score) return res;
+
+  // --- traceback ---
+  std::vector<char> ops;  // reversed
+  i32 i = bi, j = bj;
+  int state = 0;  // 0 = H, 1 = E (deletion run), 2 = F (insertion run)
+  while (true) {
+    if (state == 0) {
+      if (i == 0 || j == 0) break;
+      i32 const h = getH(i, j);
+      if (h == getH(i - 1, j - 1) + sub(i, j)) {
+        ops.push_back('M');
+        --i;
+        --j;
+      } else if (h == getE(i, j)) {
+        state = 1;
+      } else {
+        state = 2;
+      }
+    } else if (state == 1) {
+      i32 const e = getE(i, j);
+      ops.push_back('D');
+      bool const open = e == getH(i, j - 1) - (GO + GE);
+      --j;
+      if (open) state = 0;
+    } else {
+      i32 const f = getF(i, j);
+      ops.push_back('I');
+      bool const open = f == getH(i - 1, j) - (GO + GE);
+      --i;
+      if (open) state = 0;
+    }
+  }
+  res.hit = true;
+  res.score = best;
+  res.qs = i;
+  res.rs = j;
+  res.qe = bi;
+  res.re = bj;
+  // genotyper.cpp:45-69 BuildCigar: S(qs) + core + S(qlen - qe)
+  if (res.qs > 0) res.cigar.push_back({'S', static_cast<u32>(res.qs)});
+  for (auto it = ops.rbegin(); it != ops.rend(); ++it) {
+    if (!res.cigar.empty() && res.cigar.back().op == *it && *it != 'S') res.cigar.back().len++;
+    else res.cigar.push_back({*it, 1});
+  }
+  if (res.qe < m) res.cigar.push_back({'S', static_cast<u32>(m - res.qe)});
+  return res;
+}
+
+// hts/cigar_utils.h:48-111
+u32 ComputeEditDistance(const std::vector<CigarUnit>& cigar, const std::vector<u8>& q, const u8* t,
+                        usize tlen) {
+  u32 ed = 0;
+  usize qp = 0, tp = 0;
+  for (auto const& u : cigar) {
+    switch (u.op) {
+      case 'M':
+        for (u32 i = 0; i < u.len; ++i, ++qp, ++tp)
+          if (qp < q.size() && tp < tlen && q[qp] != t[tp]) ++ed;
+        break;
+      case '=': qp += u.len; tp += u.len; break;
+      case 'X': ed += u.len; qp += u.len; tp += u.len; break;
+      case 'I': ed += u.len; qp += u.len; break;
+      case 'D': ed += u.len; tp += u.len; break;
+      case 'S': qp += u.len; break;
+      case 'N': tp += u.len; break;
+      default: break;
+    }
+  }
+  return ed;
+}
+
+// hts/cigar_utils.h:113-139
+usize CigarRefPosToQueryPos(const std::vector<CigarUnit>& cigar, usize ref_pos) {
+  usize qp = 0, tp = 0;
+  for (auto const& u : cigar) {
+    switch (u.op) {
+      case 'M': case '=': case 'X':
+        for (u32 i = 0; i < u.len; ++i, ++qp, ++tp)
+          if (tp == ref_pos) return qp;
+        break;
+      case 'I': qp += u.len; break;
+      case 'D': case 'N':
+        for (u32 i = 0; i < u.len; ++i, ++tp)
+          if (tp == ref_pos) return qp;
+        break;
+      case 'S': qp += u.len; break;
+      default: break;
+    }
+  }
+  return qp;
+}
+
+namespace {
+
+constexpr i8 kMatrix[25] = {1, -4, -4, -4, 0, -4, 1, -4, -4, 0, -4, -4, 1, -4, 0,
+                            -4, -4, -4, 1, 0, 0, 0, 0, 0, 0};  // scoring_constants.h:35-41
+
+struct LocalScore { f64 pbq = 0, raw = 0, identity = 0; u8 bq = 0; };
+
+bool ConsumesRef(char op) { return op == 'M' || op == 'D' || op == 'N' || op == '=' || op == 'X'; }
+
+// caller/local_scorer.cpp:166-279
+LocalScore ComputeLocalScore(const std::vector<CigarUnit>& cigar, const std::vector<u8>& qry,
+                             const u8* target, usize tlen, const u8* quals, usize nquals,
+                             i32 aln_start, i32 var_start, i32 var_len) {
+  LocalScore out;
+  if (cigar.empty() || var_len == 0) return out;
+  i32 const var_end = var_start + var_len;
+  f64 pbq = 0.0, raw = 0.0;
+  usize matches = 0, aligned = 0;
+  u8 min_bq = 255;
+  auto in_region = [&](i32 tp) {
+    i32 const a = aln_start + tp;
+    return a >= var_start && a < var_end;
+  };
+  auto track_bq = [&](usize qp) {
+    if (qp < nquals) min_bq = std::min(min_bq, quals[qp]);
+  };
+  i32 tpos = 0;
+  usize qpos = 0;
+  for (auto const& u : cigar) {
+    if (aln_start + tpos >= var_end && ConsumesRef(u.op)) break;
+    switch (u.op) {
+      case 'M': case '=': case 'X':
+        for (u32 i = 0; i < u.len; ++i, ++tpos, ++qpos) {
+          if (!in_region(tpos)) continue;
+          ++aligned;
+          if (!(qpos >= qry.size() || static_cast<usize>(tpos) >= tlen)) {
+            i8 const r = kMatrix[target[tpos] * 5 + qry[qpos]];
+            raw += static_cast<f64>(r);
+            f64 const w = qpos < nquals ? 1.0 - PhredToErrorProb(quals[qpos]) : 1.0;
+            pbq += static_cast<f64>(r) * w;
+            matches += (qry[qpos] == target[tpos]);
+          }
+          track_bq(qpos);
+        }
+        break;
+      case 'I': {
+        bool const inr = in_region(tpos);
+        for (u32 i = 0; i < u.len; ++i, ++qpos) {
+          if (!inr) continue;
+          ++aligned;
+          track_bq(qpos);
+          pbq += 3.0;  // + SCORING_GAP_EXTEND (local_scorer.cpp:228)
+        }
+        break;
+      }
+      case 'D':
+        for (u32 i = 0; i < u.len; ++i, ++tpos)
+          if (in_region(tpos)) {
+            ++aligned;
+            pbq += 3.0;
+          }
+        if (qpos > 0 && qpos - 1 < nquals) min_bq = std::min(min_bq, quals[qpos - 1]);
+        if (qpos < nquals) min_bq = std::min(min_bq, quals[qpos]);
+        break;
+      case 'S': qpos += u.len; break;
+      case 'N': tpos += static_cast<i32>(u.len); break;
+      default: break;
+    }
+  }
+  out.pbq = pbq;
+  out.raw = raw;
+  out.identity = aligned > 0 ? static_cast<f64>(matches) / static_cast<f64>(aligned) : 0.0;
+  out.bq = min_bq == 255 ? 0 : min_bq;
+  return out;
+}
+
+// caller/local_scorer.cpp:290-305
+f64 SoftClipPenalty(const std::vector<CigarUnit>& c) {
+  if (c.empty()) return 0.0;
+  i32 const s5 = c.front().op == 'S' ? static_cast<i32>(c.front().len) : 0;
+  i32 const s3 = (c.size() > 1 && c.back().op == 'S') ? static_cast<i32>(c.back().len) : 0;
+  return static_cast<f64>(s5 + s3) * 4;
+}
+
+}  // namespace
+
+// caller/genotyper.cpp:269-362 + caller/combined_scorer.cpp:24-108
+std::vector<Assignment> AssignReadToAlleles(const Read& rd, const std::vector<std::string>& haps,
+                                            const std::vector<RawVariant>& vars, const AlignParams& ap,
+                                            std::vector<AlnResult>* alns_out) {
+  std::vector<Assignment> out(vars.size());
+  std::vector<AlnResult> alns;
+  for (usize h = 0; h < haps.size(); ++h) {  // AlignToAllHaplotypes (genotyper.cpp:376-411)
+    AlnResult a = AlignReadToHap(rd.seq, haps[h], ap);
+    if (!a.hit) continue;
+    a.hap = static_cast<u32>(h);
+    alns.push_back(std::move(a));
+  }
+  if (alns_out) *alns_out = alns;
+  if (alns.empty()) return out;
+  std::vector<u8> qenc(rd.seq.size());
+  for (usize i = 0; i < rd.seq.size(); ++i) qenc[i] = EncodeBase(rd.seq[i]);
+  std::vector<std::vector<u8>> henc(haps.size());
+  for (usize h = 0; h < haps.size(); ++h) {
+    henc[h].resize(haps[h].size());
+    for (usize i = 0; i < haps[h].size(); ++i) henc[h][i] = EncodeBase(haps[h][i]);
+  }
+  usize const rlen = rd.seq.size();
+  // combined_scorer.cpp:24-38: NM against the REF haplotype; read length when no REF alignment
+  u32 ref_nm = static_cast<u32>(rlen);
+  for (auto const& a : alns) {
+    if (a.hap != 0 || a.rs >= a.re) continue;
+    ref_nm = ComputeEditDistance(a.cigar, qenc, henc[0].data() + a.rs, static_cast<usize>(a.re - a.rs));
+    break;
+  }
+  for (auto const& a : alns) {
+    for (usize v = 0; v < vars.size(); ++v) {
+      auto const& var = vars[v];
+      // ExtractHapBounds (genotyper.cpp:329-352)
+      i32 vstart = 0, vlen = 0;
+      u32 allele = 0;
+      bool have = false;
+      if (a.hap == 0) {
+        vstart = static_cast<i32>(var.ref_start0);
+        vlen = static_cast<i32>(var.ref.size());
+        allele = 0;
+        have = true;
+      } else {
+        for (usize ai = 0; ai < var.alts.size() && !have; ++ai)
+          for (auto const& hs : var.alts[ai].hap_starts)
+            if (hs.first == a.hap) {
+              vstart = static_cast<i32>(hs.second);
+              vlen = static_cast<i32>(var.alts[ai].seq.size());
+              allele = static_cast<u32>(ai + 1);
+              have = true;
+              break;
+            }
+      }
+      if (!have) continue;
+      if (!((vstart + vlen) > a.rs && vstart < a.re)) continue;  // OverlapsAlignment :360-362
+      // ScoreReadAtVariant (combined_scorer.cpp:60-108)
+      usize const alen = static_cast<usize>(a.re - a.rs);
+      const u8* target = henc[a.hap].data() + a.rs;
+      LocalScore const ls = ComputeLocalScore(a.cigar, qenc, target, alen, rd.qual, rlen, a.rs, vstart, vlen);
+      f64 const global_adj = static_cast<f64>(a.score) - SoftClipPenalty(a.cigar);
+      Assignment s;
+      s.valid = true;
+      s.allele = allele;
+      s.global_score = static_cast<i32>(global_adj - ls.raw);
+      s.local_score = ls.pbq;
+      s.local_identity = ls.identity;
+      s.base_qual = ls.bq;
+      s.hap_id = a.hap;
+      s.own_nm = ComputeEditDistance(a.cigar, qenc, target, alen);
+      usize vsa = 0;
+      if (vstart > a.rs) vsa = static_cast<usize>(vstart - a.rs);
+      usize const qp = CigarRefPosToQueryPos(a.cigar, vsa);
+      f64 const rel = rlen > 0 ? static_cast<f64>(qp) / static_cast<f64>(rlen) : 0.5;
+      s.folded_pos = std::min(rel, 1.0 - rel);
+      s.ref_nm = ref_nm;
+      if (out[v].valid && s.Combined() <= out[v].Combined()) continue;  // first wins ties
+      out[v] = s;
+    }
+  }
+  return out;
+}
+
+}  // namespace orc

@@ -1,0 +1,103 @@
+"""Test harness: loads the ORACLE (tests are the only place allowed to) and the product library,
+and runs the batched stage entry points of either through identical numpy buffers."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from lancet2_amd import capi
+
+REPO = capi.REPO
+ORACLE_DIR = os.path.join(REPO, "oracle")
+ORACLE_LIB = os.path.join(ORACLE_DIR, "liboracle.so")
+
+
+def load_oracle():
+    srcs = [os.path.join(ORACLE_DIR, f) for f in os.listdir(ORACLE_DIR) if f.endswith((".cpp", ".hpp"))]
+    if (not os.path.exists(ORACLE_LIB)) or any(os.path.getmtime(s) > os.path.getmtime(ORACLE_LIB) for s in srcs):
+        subprocess.check_call(["make", "-C", ORACLE_DIR, "-s"])
+    lib = C.CDLL(ORACLE_LIB)
+    lib.orc_hamming.restype = C.c_uint64
+    lib.orc_hash64.restype = C.c_uint64
+    lib.orc_phred.restype = C.c_double
+    lib.orc_median_u32.restype = C.c_uint32
+    lib.orc_edit_distance.restype = C.c_uint32
+    lib.orc_refpos_to_qpos.restype = C.c_uint64
+    return lib
+
+
+_ORACLE = None
+
+
+def oracle():
+    global _ORACLE
+    if _ORACLE is None:
+        _ORACLE = load_oracle()
+    return _ORACLE
+
+
+class OracleEngine:
+    """Runs the oracle's batched stages on host numpy arrays."""
+
+    def __init__(self, params):
+        self.p = params
+        self.lib = oracle()
+
+    def gate(self, arrs, n, nr):
+        out = capi.alloc_host(capi.gate_out_spec(n))
+        b = capi.make_batch_struct(arrs, n, nr)
+        rc = self.lib.orc_repeat_gate_batch(C.byref(self.p), C.byref(b), C.byref(capi.fill_struct(capi.GateOut, out)))
+        assert rc == 0
+        return out
+
+    def assemble(self, arrs, n, nr):
+        out = capi.alloc_host(capi.asm_out_spec(self.p, n))
+        b = capi.make_batch_struct(arrs, n, nr)
+        rc = self.lib.orc_assemble_batch(C.byref(self.p), C.byref(b), C.byref(capi.fill_struct(capi.AsmOut, out)))
+        assert rc == 0
+        return out
+
+    def msa(self, arrs, n, nr, asm):
+        out = capi.alloc_host(capi.var_out_spec(self.p, n))
+        b = capi.make_batch_struct(arrs, n, nr)
+        rc = self.lib.orc_msa_batch(C.byref(self.p), C.byref(b), C.byref(capi.fill_struct(capi.AsmOut, asm)),
+                                    C.byref(capi.fill_struct(capi.VarOut, out)))
+        assert rc == 0
+        return out
+
+    def genotype(self, arrs, n, nr, asm, var, debug=True):
+        out = capi.alloc_host(capi.geno_out_spec(self.p, n, nr, debug))
+        b = capi.make_batch_struct(arrs, n, nr)
+        rc = self.lib.orc_genotype_batch(C.byref(self.p), C.byref(b), C.byref(capi.fill_struct(capi.AsmOut, asm)),
+                                         C.byref(capi.fill_struct(capi.VarOut, var)),
+                                         C.byref(capi.fill_struct(capi.GenoOut, out)))
+        assert rc == 0
+        return out
+
+
+def haplotypes_of(p, asm, w):
+    """-> list over components of list of haplotype byte strings."""
+    res = []
+    for c in range(int(asm["win_ncomp"][w])):
+        ci = w * p.max_comps + c
+        hs = []
+        for h in range(int(asm["comp_nhaps"][ci])):
+            hi = w * p.max_haps + int(asm["comp_hap0"][ci]) + h
+            hs.append(bytes(asm["hap_bases"][hi * p.max_hap_len: hi * p.max_hap_len + int(asm["hap_len"][hi])]))
+        res.append(hs)
+    return res
+
+
+def variants_of(p, var, w):
+    res = []
+    pool = var["allele_pool"][w * p.max_allele_bytes:(w + 1) * p.max_allele_bytes]
+    for v in range(int(var["win_nvars"][w])):
+        vi = w * p.max_vars + v
+        ref = bytes(pool[int(var["var_ref_off"][vi]): int(var["var_ref_off"][vi]) + int(var["var_ref_len"][vi])])
+        alts = []
+        for a in range(int(var["var_nalts"][vi])):
+            ai = vi * p.max_alts + a
+            alts.append(bytes(pool[int(var["alt_off"][ai]): int(var["alt_off"][ai]) + int(var["alt_len"][ai])]))
+        res.append((int(var["var_pos"][vi]), ref, tuple(alts)))
+    return res
