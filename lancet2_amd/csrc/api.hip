@@ -1,0 +1,351 @@
+// C-ABI entry points of libmicroasm.so (see include/microasm.h).  No CPU fallback: every entry
+// point fails with MA_ERR_NO_DEVICE when there is no HIP device.
+#include <cstring>
+#include <new>
+
+#include "ma_internal.h"
+
+using namespace ma;
+
+void ma_ctx::tic(const char* name) {
+  if (!timing) return;
+  if (timers_used == timers.size()) {
+    KernelTimer t{name, nullptr, nullptr};
+    (void)hipEventCreate(&t.beg);
+    (void)hipEventCreate(&t.end);
+    timers.push_back(t);
+  }
+  timers[timers_used].name = name;
+  (void)hipEventRecord(timers[timers_used].beg, stream);
+}
+void ma_ctx::toc() {
+  if (!timing) return;
+  (void)hipEventRecord(timers[timers_used].end, stream);
+  timers_used++;
+}
+
+namespace {
+
+struct OutField {
+  size_t offset;   // byte offset of the pointer member inside the out struct
+  size_t bytes;    // payload size
+};
+
+template <class S, class T>
+size_t off_of(T* S::*m) {
+  return reinterpret_cast<size_t>(&(reinterpret_cast<S*>(0)->*m));
+}
+
+std::vector<OutField> gate_fields(const ma_params_t&, int n) {
+  return {{off_of(&ma_gate_out_t::max_approx), 4ull * n}, {off_of(&ma_gate_out_t::max_exact), 4ull * n}};
+}
+std::vector<OutField> asm_fields(const ma_params_t& p, int n) {
+  size_t const N = n, MC = p.max_comps, MH = p.max_haps, ML = p.max_hap_len, MR = p.max_runs;
+  return {{off_of(&ma_asm_out_t::win_status), 4 * N}, {off_of(&ma_asm_out_t::win_k), 4 * N},
+          {off_of(&ma_asm_out_t::win_ncomp), 4 * N}, {off_of(&ma_asm_out_t::comp_anchor), 4 * N * MC},
+          {off_of(&ma_asm_out_t::comp_hap0), 4 * N * MC}, {off_of(&ma_asm_out_t::comp_nhaps), 4 * N * MC},
+          {off_of(&ma_asm_out_t::comp_cx), 4 * N * MC * 3}, {off_of(&ma_asm_out_t::comp_cxf), 8 * N * MC * 4},
+          {off_of(&ma_asm_out_t::hap_len), 4 * N * MH}, {off_of(&ma_asm_out_t::hap_nruns), 4 * N * MH},
+          {off_of(&ma_asm_out_t::hap_stats), 8 * N * MH * 6}, {off_of(&ma_asm_out_t::hap_bases), N * MH * ML},
+          {off_of(&ma_asm_out_t::hap_runs), 4 * N * MH * MR * 2}};
+}
+std::vector<OutField> var_fields(const ma_params_t& p, int n) {
+  size_t const N = n, MH = p.max_haps, MV = p.max_vars, MA = p.max_alts, MP = p.max_allele_bytes;
+  return {{off_of(&ma_var_out_t::win_nvars), 4 * N}, {off_of(&ma_var_out_t::var_comp), 4 * N * MV},
+          {off_of(&ma_var_out_t::var_pos), 4 * N * MV}, {off_of(&ma_var_out_t::var_ref_start), 4 * N * MV},
+          {off_of(&ma_var_out_t::var_ref_off), 4 * N * MV}, {off_of(&ma_var_out_t::var_ref_len), 4 * N * MV},
+          {off_of(&ma_var_out_t::var_nalts), 4 * N * MV}, {off_of(&ma_var_out_t::alt_off), 4 * N * MV * MA},
+          {off_of(&ma_var_out_t::alt_len), 4 * N * MV * MA}, {off_of(&ma_var_out_t::alt_type), 4 * N * MV * MA},
+          {off_of(&ma_var_out_t::alt_length), 4 * N * MV * MA},
+          {off_of(&ma_var_out_t::var_hap_allele), N * MV * MH}, {off_of(&ma_var_out_t::var_hap_start), 4 * N * MV * MH},
+          {off_of(&ma_var_out_t::allele_pool), N * MP}};
+}
+std::vector<OutField> geno_fields(const ma_params_t& p, int n, i64 nr) {
+  size_t const N = n, R = static_cast<size_t>(nr), MH = p.max_haps, MV = p.max_vars, MA = p.max_alts,
+               S = p.num_samples, MCG = p.max_cigar;
+  return {{off_of(&ma_geno_out_t::allele_counts), 4 * N * MV * S * (MA + 1) * 2},
+          {off_of(&ma_geno_out_t::var_qual), 8 * N * MV},
+          {off_of(&ma_geno_out_t::aln_rec), 4 * R * MH * 6},
+          {off_of(&ma_geno_out_t::aln_cigar), 4 * R * MH * (1 + MCG)},
+          {off_of(&ma_geno_out_t::asg_allele), R * MV},
+          {off_of(&ma_geno_out_t::asg_score), 8 * R * MV}};
+}
+
+void*& ptr_at(void* strct, size_t off) { return *reinterpret_cast<void**>(static_cast<char*>(strct) + off); }
+void* ptr_at(const void* strct, size_t off) {
+  return *reinterpret_cast<void* const*>(static_cast<const char*>(strct) + off);
+}
+
+// Device mirror of a caller output struct.  MA_MEM_DEVICE: aliases the caller's pointers.
+// MA_MEM_HOST: one device allocation per non-NULL member; download() copies results back.
+template <class S>
+struct OutMirror {
+  S dev;
+  const S* host = nullptr;
+  std::vector<OutField> fields;
+  std::vector<DevBuf*> bufs;
+  int prepare(ma_ctx* ctx, const S* user, std::vector<OutField> f, size_t stage_base, bool upload) {
+    host = user;
+    fields = std::move(f);
+    std::memset(&dev, 0, sizeof(dev));
+    if (!user) return MA_OK;
+    if (ctx->memspace == MA_MEM_DEVICE) {
+      dev = *user;
+      return MA_OK;
+    }
+    if (ctx->out_stage.size() < stage_base + fields.size()) ctx->out_stage.resize(stage_base + fields.size());
+    for (size_t i = 0; i < fields.size(); ++i) {
+      void* hp = ptr_at(user, fields[i].offset);
+      if (!hp) continue;
+      DevBuf& b = ctx->out_stage[stage_base + i];
+      MA_HIP(ctx, b.reserve(fields[i].bytes));
+      ptr_at(&dev, fields[i].offset) = b.p;
+      if (upload) MA_HIP(ctx, hipMemcpyAsync(b.p, hp, fields[i].bytes, hipMemcpyHostToDevice, ctx->stream));
+    }
+    return MA_OK;
+  }
+  int download(ma_ctx* ctx) {
+    if (!host || ctx->memspace == MA_MEM_DEVICE) return MA_OK;
+    for (auto const& f : fields) {
+      void* hp = ptr_at(host, f.offset);
+      void* dp = ptr_at(&dev, f.offset);
+      if (!hp || !dp) continue;
+      MA_HIP(ctx, hipMemcpyAsync(hp, dp, f.bytes, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    return MA_OK;
+  }
+};
+
+int stage_batch(ma_ctx* ctx, const ma_batch_t* b, DBatch* d) {
+  if (!b || b->n_windows < 0 || b->n_reads < 0) return MA_ERR_ARG;
+  d->n_windows = b->n_windows;
+  d->n_reads = b->n_reads;
+  if (ctx->memspace == MA_MEM_DEVICE) {
+    d->ref_bases = b->ref_bases; d->ref_off = b->ref_off; d->read_win_off = b->read_win_off;
+    d->read_off = b->read_off; d->read_bases = b->read_bases; d->read_quals = b->read_quals;
+    d->read_qname_id = b->read_qname_id; d->read_sample = b->read_sample; d->read_flags = b->read_flags;
+    return MA_OK;
+  }
+  size_t const n = b->n_windows, nr = static_cast<size_t>(b->n_reads);
+  size_t const ref_bytes = n ? b->ref_off[n] : 0;
+  size_t const read_bytes = nr ? b->read_off[nr] : 0;
+  struct Item { const void* src; size_t bytes; size_t pad; const void** dst; };
+  Item items[9] = {
+      {b->ref_bases, ref_bytes, 64, reinterpret_cast<const void**>(&d->ref_bases)},
+      {b->ref_off, 4 * (n + 1), 0, reinterpret_cast<const void**>(&d->ref_off)},
+      {b->read_win_off, 4 * (n + 1), 0, reinterpret_cast<const void**>(&d->read_win_off)},
+      {b->read_off, 8 * (nr + 1), 0, reinterpret_cast<const void**>(&d->read_off)},
+      {b->read_bases, read_bytes, 64, reinterpret_cast<const void**>(&d->read_bases)},
+      {b->read_quals, read_bytes, 64, reinterpret_cast<const void**>(&d->read_quals)},
+      {b->read_qname_id, 4 * nr, 0, reinterpret_cast<const void**>(&d->read_qname_id)},
+      {b->read_sample, nr, 0, reinterpret_cast<const void**>(&d->read_sample)},
+      {b->read_flags, nr, 0, reinterpret_cast<const void**>(&d->read_flags)}};
+  for (int i = 0; i < 9; ++i) {
+    MA_HIP(ctx, ctx->in_stage[i].reserve(items[i].bytes + items[i].pad + 16));
+    if (items[i].bytes)
+      MA_HIP(ctx, hipMemcpyAsync(ctx->in_stage[i].p, items[i].src, items[i].bytes, hipMemcpyHostToDevice, ctx->stream));
+    if (items[i].pad)
+      MA_HIP(ctx, hipMemsetAsync(static_cast<char*>(ctx->in_stage[i].p) + items[i].bytes, 0, items[i].pad, ctx->stream));
+    *items[i].dst = ctx->in_stage[i].p;
+  }
+  return MA_OK;
+}
+
+int check_params(const ma_params_t& p) {
+  if (p.min_k < 5 || p.max_k > 255 || p.min_k > p.max_k || p.k_step <= 0) return MA_ERR_PARAM;
+  if ((p.min_k & 1) == 0 || (p.k_step & 1) != 0) return MA_ERR_PARAM;  // k must stay odd (graph_params.h:11-26)
+  if (p.num_samples < 1 || p.num_samples > 8) return MA_ERR_PARAM;
+  if (p.max_mismatch < 0 || p.max_mismatch > 3) return MA_ERR_PARAM;
+  if (p.max_comps < 1 || p.max_comps > 16 || p.max_haps < 2 || p.max_haps > 32) return MA_ERR_PARAM;
+  if (p.max_hap_len < 256 || p.max_hap_len > 8192 || p.max_runs < 8) return MA_ERR_PARAM;
+  if (p.max_vars < 1 || p.max_alts < 1 || p.max_alts > 15 || p.max_allele_bytes < 64) return MA_ERR_PARAM;
+  if (p.band < 4 || p.band > 128 || p.max_cigar < 4 || p.max_cigar > 64) return MA_ERR_PARAM;
+  if (p.bfs_limit < 1) return MA_ERR_PARAM;
+  return MA_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+void ma_default_params(ma_params_t* p) {
+  std::memset(p, 0, sizeof(*p));
+  p->min_k = 13; p->max_k = 127; p->k_step = 6;        // graph_params.h:11-26
+  p->min_node_cov = 2; p->min_anchor_cov = 5;          // graph_params.h:17-20
+  p->num_samples = 2;
+  p->min_anchor_len = 150;                              // graph.cpp:88
+  p->max_mismatch = 2;                                  // graph.h:129
+  p->bfs_limit = 1 << 20;                               // max_flow.h:69
+  p->band = 64; p->min_aln_score = 80;
+  p->max_comps = 4; p->max_haps = 16; p->max_hap_len = 2048; p->max_runs = 256;
+  p->max_vars = 64; p->max_alts = 4; p->max_allele_bytes = 4096; p->max_cigar = 16;
+  p->case_ctrl_mode = 1;
+}
+
+int ma_create(const ma_params_t* prm, int device, int memspace, ma_ctx_t** out) {
+  if (!prm || !out) return MA_ERR_ARG;
+  *out = nullptr;
+  int rc = check_params(*prm);
+  if (rc != MA_OK) return rc;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) {
+    return MA_ERR_NO_DEVICE;  // the engine has no CPU fallback, by design
+  }
+  if (hipSetDevice(device) != hipSuccess) return MA_ERR_HIP;
+  ma_ctx* c = new (std::nothrow) ma_ctx();
+  if (!c) return MA_ERR_NOMEM;
+  c->prm = *prm;
+  c->device = device;
+  c->memspace = memspace;
+  *out = c;
+  return MA_OK;
+}
+
+void ma_destroy(ma_ctx_t* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  for (auto& b : ctx->in_stage) b.release();
+  for (auto& b : ctx->out_stage) b.release();
+  ctx->ws_build.release(); ctx->ws_nodes.release(); ctx->ws_clean.release();
+  ctx->ws_poa.release(); ctx->ws_aln.release(); ctx->ws_misc.release();
+  for (auto& t : ctx->timers) {
+    (void)hipEventDestroy(t.beg);
+    (void)hipEventDestroy(t.end);
+  }
+  delete ctx;
+}
+
+const char* ma_last_error(const ma_ctx_t* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int ma_set_stream(ma_ctx_t* ctx, void* s) {
+  if (!ctx) return MA_ERR_ARG;
+  ctx->stream = static_cast<hipStream_t>(s);
+  return MA_OK;
+}
+
+int ma_synchronize(ma_ctx_t* ctx) {
+  if (!ctx) return MA_ERR_ARG;
+  MA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return MA_OK;
+}
+
+int ma_last_kernel_times(ma_ctx_t* ctx, const char** names, float* ms, int cap) {
+  if (!ctx) return MA_ERR_ARG;
+  MA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  int n = 0;
+  for (size_t i = 0; i < ctx->timers_used && n < cap; ++i, ++n) {
+    names[n] = ctx->timers[i].name;
+    float t = 0.f;
+    (void)hipEventElapsedTime(&t, ctx->timers[i].beg, ctx->timers[i].end);
+    ms[n] = t;
+  }
+  return n;
+}
+
+#define MA_BEGIN(ctx)                                   \
+  if (!(ctx)) return MA_ERR_ARG;                        \
+  MA_HIP(ctx, hipSetDevice((ctx)->device));             \
+  (ctx)->timers_used = 0;
+
+#define MA_TRY(expr)          \
+  do {                        \
+    int _rc = (expr);         \
+    if (_rc != MA_OK) return _rc; \
+  } while (0)
+
+int ma_repeat_gate_batch(ma_ctx_t* ctx, const ma_batch_t* b, const ma_gate_out_t* out) {
+  MA_BEGIN(ctx);
+  if (!out || !out->max_approx || !out->max_exact) return MA_ERR_ARG;
+  DBatch d;
+  MA_TRY(stage_batch(ctx, b, &d));
+  OutMirror<ma_gate_out_t> g;
+  MA_TRY(g.prepare(ctx, out, gate_fields(ctx->prm, d.n_windows), 0, false));
+  MA_TRY(launch_gate(ctx, d, g.dev.max_approx, g.dev.max_exact));
+  MA_TRY(g.download(ctx));
+  if (ctx->memspace == MA_MEM_HOST) MA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return MA_OK;
+}
+
+int ma_assemble_batch(ma_ctx_t* ctx, const ma_batch_t* b, const ma_asm_out_t* out) {
+  MA_BEGIN(ctx);
+  if (!out) return MA_ERR_ARG;
+  DBatch d;
+  MA_TRY(stage_batch(ctx, b, &d));
+  OutMirror<ma_asm_out_t> a;
+  MA_TRY(a.prepare(ctx, out, asm_fields(ctx->prm, d.n_windows), 2, false));
+  // the k-cascade consumes the gate result; compute it into scratch
+  MA_HIP(ctx, ctx->ws_misc.reserve(8ull * (d.n_windows + 1)));
+  u32* approx = ctx->ws_misc.as<u32>();
+  u32* exact = approx + d.n_windows;
+  MA_TRY(launch_gate(ctx, d, approx, exact));
+  MA_TRY(launch_assemble(ctx, d, a.dev, approx));
+  MA_TRY(a.download(ctx));
+  if (ctx->memspace == MA_MEM_HOST) MA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return MA_OK;
+}
+
+int ma_msa_batch(ma_ctx_t* ctx, const ma_batch_t* b, const ma_asm_out_t* asmb, const ma_var_out_t* out) {
+  MA_BEGIN(ctx);
+  if (!out || !asmb) return MA_ERR_ARG;
+  DBatch d;
+  MA_TRY(stage_batch(ctx, b, &d));
+  OutMirror<ma_asm_out_t> a;
+  MA_TRY(a.prepare(ctx, asmb, asm_fields(ctx->prm, d.n_windows), 2, true));
+  OutMirror<ma_var_out_t> v;
+  MA_TRY(v.prepare(ctx, out, var_fields(ctx->prm, d.n_windows), 16, false));
+  MA_TRY(launch_msa(ctx, d, a.dev, v.dev));
+  MA_TRY(v.download(ctx));
+  // win_status may gain MA_W_VAR_OVERFLOW
+  if (ctx->memspace == MA_MEM_HOST) {
+    MA_HIP(ctx, hipMemcpyAsync(asmb->win_status, a.dev.win_status, 4ull * d.n_windows, hipMemcpyDeviceToHost, ctx->stream));
+    MA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  return MA_OK;
+}
+
+int ma_genotype_batch(ma_ctx_t* ctx, const ma_batch_t* b, const ma_asm_out_t* asmb, const ma_var_out_t* vars,
+                      const ma_geno_out_t* out) {
+  MA_BEGIN(ctx);
+  if (!out || !asmb || !vars) return MA_ERR_ARG;
+  DBatch d;
+  MA_TRY(stage_batch(ctx, b, &d));
+  OutMirror<ma_asm_out_t> a;
+  MA_TRY(a.prepare(ctx, asmb, asm_fields(ctx->prm, d.n_windows), 2, true));
+  OutMirror<ma_var_out_t> v;
+  MA_TRY(v.prepare(ctx, vars, var_fields(ctx->prm, d.n_windows), 16, true));
+  OutMirror<ma_geno_out_t> g;
+  MA_TRY(g.prepare(ctx, out, geno_fields(ctx->prm, d.n_windows, d.n_reads), 32, false));
+  MA_TRY(launch_genotype(ctx, d, a.dev, v.dev, g.dev));
+  MA_TRY(g.download(ctx));
+  if (ctx->memspace == MA_MEM_HOST) MA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return MA_OK;
+}
+
+int ma_process_batch(ma_ctx_t* ctx, const ma_batch_t* b, const ma_gate_out_t* gate, const ma_asm_out_t* asmb,
+                     const ma_var_out_t* vars, const ma_geno_out_t* geno) {
+  MA_BEGIN(ctx);
+  if (!gate || !asmb || !vars || !geno) return MA_ERR_ARG;
+  DBatch d;
+  MA_TRY(stage_batch(ctx, b, &d));
+  OutMirror<ma_gate_out_t> g;
+  MA_TRY(g.prepare(ctx, gate, gate_fields(ctx->prm, d.n_windows), 0, false));
+  OutMirror<ma_asm_out_t> a;
+  MA_TRY(a.prepare(ctx, asmb, asm_fields(ctx->prm, d.n_windows), 2, false));
+  OutMirror<ma_var_out_t> v;
+  MA_TRY(v.prepare(ctx, vars, var_fields(ctx->prm, d.n_windows), 16, false));
+  OutMirror<ma_geno_out_t> q;
+  MA_TRY(q.prepare(ctx, geno, geno_fields(ctx->prm, d.n_windows, d.n_reads), 32, false));
+  MA_TRY(launch_gate(ctx, d, g.dev.max_approx, g.dev.max_exact));
+  MA_TRY(launch_assemble(ctx, d, a.dev, g.dev.max_approx));
+  MA_TRY(launch_msa(ctx, d, a.dev, v.dev));
+  MA_TRY(launch_genotype(ctx, d, a.dev, v.dev, q.dev));
+  MA_TRY(g.download(ctx));
+  MA_TRY(a.download(ctx));
+  MA_TRY(v.download(ctx));
+  MA_TRY(q.download(ctx));
+  if (ctx->memspace == MA_MEM_HOST) MA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return MA_OK;
+}
+
+}  // extern "C"
