@@ -1,0 +1,173 @@
+// Host orchestration of Graph::BuildComponentResults (cbdg/graph.cpp:78-256) over a batch of windows:
+// the k-cascade loop runs on the host, each attempt launching the build passes (build.hip) and the
+// cleaning/enumeration kernel (clean.hip) for the windows that are still unresolved at that k.
+#include <algorithm>
+#include <cstdlib>
+
+#include "graph_ws.h"
+
+namespace ma {
+
+int run_build_pass(ma_ctx* ctx, const DBatch& b, const GraphWs& ws);
+int run_count_inst(ma_ctx* ctx, const DBatch& b, const GraphWs& ws, int win0, int nwin, u32* maxima_dev);
+int run_select_active(ma_ctx* ctx, const GraphWs& ws, int win0, int nwin, const u32* gate_approx, u32* win_k,
+                      u32* active, u32* n_active_dev);
+int run_clean_pass(ma_ctx* ctx, const DBatch& b, const GraphWs& ws, const ma_asm_out_t& out);
+
+namespace {
+
+__global__ void k_init_out(ma_asm_out_t o, u32* win_flags, int n) {
+  int const i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  o.win_status[i] = MA_W_NO_HAPLOTYPE;
+  o.win_k[i] = 0;
+  o.win_ncomp[i] = 0;
+  win_flags[i] = 0;
+}
+
+int ceil_log2(u64 v) {
+  int l = 0;
+  while ((u64(1) << l) < v) ++l;
+  return l;
+}
+
+u64 mod_inverse_pow2(u64 a) {  // a odd: Newton iteration mod 2^64
+  u64 x = a;
+  for (int i = 0; i < 6; ++i) x *= 2 - a * x;
+  return x;
+}
+
+struct Carver {
+  char* base;
+  size_t off = 0;
+  template <class T>
+  T* take(size_t count) {
+    off = (off + 255) & ~size_t(255);
+    T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
+    off += count * sizeof(T);
+    return p;
+  }
+};
+
+}  // namespace
+
+int launch_assemble(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& out, const u32* gate_approx) {
+  int const n = b.n_windows;
+  if (n == 0) return MA_OK;
+  ma_params_t const& P = ctx->prm;
+  int const S = P.num_samples;
+
+  // batch-level scratch: sequence bookkeeping + flags
+  size_t const nseq = static_cast<size_t>(b.n_reads) + n;
+  Carver cm{nullptr};
+  auto carve_misc = [&](Carver& c, GraphWs& ws, u32** win_flags, u32** active, u32** counters) {
+    ws.seq_inst_base = c.take<u32>(nseq + 1);
+    ws.win_ninst = c.take<u32>(n);
+    ws.win_nread_inst = c.take<u32>(n);
+    *win_flags = c.take<u32>(n);
+    *active = c.take<u32>(n);
+    *counters = c.take<u32>(16);
+  };
+  GraphWs ws{};
+  u32 *win_flags = nullptr, *active = nullptr, *counters = nullptr;
+  carve_misc(cm, ws, &win_flags, &active, &counters);
+  MA_HIP(ctx, ctx->ws_nodes.reserve(cm.off + 4096));
+  Carver cm2{static_cast<char*>(ctx->ws_nodes.p)};
+  carve_misc(cm2, ws, &win_flags, &active, &counters);
+  ws.win_flags = win_flags;
+  ws.num_samples = S;
+
+  hipLaunchKernelGGL(k_init_out, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, out, win_flags, n);
+
+  // capacity planning: instance maxima at the smallest k (the largest instance counts)
+  ws.k = P.min_k;
+  MA_TRY_RC(run_count_inst(ctx, b, ws, 0, n, counters));
+  u32 maxima[4] = {0, 0, 0, 0};
+  MA_HIP(ctx, hipMemcpyAsync(maxima, counters, 16, hipMemcpyDeviceToHost, ctx->stream));
+  MA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  u32 const max_inst = std::max<u32>(maxima[0], 1), max_read_inst = std::max<u32>(maxima[1], 1);
+  u32 const max_refk = std::max<u32>(maxima[2], 1);
+
+  ws.tc_log2 = std::max(10, ceil_log2(static_cast<u64>(max_inst) * 4 / 3 + 16));
+  ws.mc_log2 = std::max(10, ceil_log2(static_cast<u64>(max_read_inst) * 4 / 3 + 16));
+  ws.inst_stride = (max_inst + 63) & ~63u;
+  ws.ref_stride = (max_refk + 63) & ~63u;
+  u32 nc = 8192;
+  if (const char* e = getenv("MA_NODE_CAP")) nc = static_cast<u32>(atoi(e));
+  nc = std::max<u32>(nc, 2 * max_refk + 64);
+  if (max_inst > 400000) nc = std::max<u32>(nc, 32768);  // deep panels keep more recurrent-error k-mers
+  ws.nc = nc;
+  u32 ac = 1u << 16;
+  if (const char* e = getenv("MA_ARENA_CAP")) ac = static_cast<u32>(atoi(e));
+  ws.ac = ac;
+
+  // per-window workspace footprint -> chunk size
+  auto carve_ws = [&](Carver& c, GraphWs& g, size_t A) {
+    size_t const tcap = size_t(1) << g.tc_log2, mcap = size_t(1) << g.mc_log2, NC = g.nc;
+    g.tbl_key = c.take<u64>(A * tcap);
+    g.tbl_first = c.take<u32>(A * tcap);
+    g.slot_node = c.take<u32>(A * tcap);
+    g.tbl_cnt = c.take<u32>(A * tcap * (S + 2));
+    g.inst_slot = c.take<u32>(A * g.inst_stride);
+    g.mm_key = c.take<u64>(A * mcap);
+    g.mm_min = c.take<u32>(A * mcap);
+    g.n_nodes = c.take<u32>(A);
+    g.nd_cnt = c.take<u32>(A * NC * S);
+    g.nd_role = c.take<u32>(A * NC * 2);
+    g.nd_src = c.take<u32>(A * NC);
+    g.nd_label = c.take<u8>(A * NC);
+    g.nd_sign = c.take<u8>(A * NC);
+    g.nd_nedge = c.take<u8>(A * NC);
+    g.nd_edge = c.take<u32>(A * NC * kEdgeCap);
+    g.nd_ekey = c.take<u32>(A * NC * kEdgeCap);
+    g.ref_node = c.take<u32>(A * g.ref_stride);
+    g.nd_comp = c.take<u32>(A * NC);
+    g.nd_len = c.take<u32>(A * NC);
+    g.nd_alive = c.take<u8>(A * NC);
+    g.nd_head = c.take<u32>(A * NC);
+    g.nd_tail = c.take<u32>(A * NC);
+    g.sl_next = c.take<u32>(A * NC);
+    g.sl_prev = c.take<u32>(A * NC);
+    g.sl_desc = c.take<u32>(A * NC);
+    g.scratch = c.take<u32>(A * NC * 32);
+    g.arena = c.take<uint4>(A * g.ac);
+  };
+  Carver probe{nullptr};
+  {
+    GraphWs tmp = ws;
+    carve_ws(probe, tmp, 1);
+  }
+  size_t const per_window = probe.off + 4096;
+  size_t budget = size_t(24) << 30;  // workspace budget per chunk
+  if (const char* e = getenv("MA_WS_GB")) budget = static_cast<size_t>(atoi(e)) << 30;
+  int chunk = static_cast<int>(std::max<size_t>(1, std::min<size_t>(n, budget / per_window)));
+  MA_HIP(ctx, ctx->ws_build.reserve(per_window * static_cast<size_t>(chunk)));
+
+  for (int win0 = 0; win0 < n; win0 += chunk) {
+    int const nwin = std::min(chunk, n - win0);
+    Carver cw{static_cast<char*>(ctx->ws_build.p)};
+    carve_ws(cw, ws, static_cast<size_t>(nwin));
+    for (int k = P.min_k; k <= P.max_k; k += P.k_step) {
+      ws.k = k;
+      u64 pk1 = 1;
+      for (int i = 0; i < k - 1; ++i) pk1 *= kHashP;
+      ws.pk1 = pk1;
+      ws.pinv = mod_inverse_pow2(kHashP);
+      MA_TRY_RC(run_select_active(ctx, ws, win0, nwin, gate_approx, out.win_k, active, counters + 8));
+      u32 host_cnt[2] = {0, 0};
+      MA_HIP(ctx, hipMemcpyAsync(host_cnt, counters + 8, 8, hipMemcpyDeviceToHost, ctx->stream));
+      MA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      ws.n_active = static_cast<int>(host_cnt[0]);
+      ws.active = active;
+      if (host_cnt[1] == 0) break;  // every window of the chunk is resolved (graph.cpp:106 loop exit)
+      if (ws.n_active > 0) {
+        MA_TRY_RC(run_count_inst(ctx, b, ws, win0, nwin, counters));
+        MA_TRY_RC(run_build_pass(ctx, b, ws));
+        MA_TRY_RC(run_clean_pass(ctx, b, ws, out));
+      }
+    }
+  }
+  return MA_OK;
+}
+
+}  // namespace ma

@@ -1,0 +1,526 @@
+// Colored de Bruijn graph construction on gfx950 -- replaces Graph::BuildGraph / AddNodes
+// (cbdg/graph.cpp:262-341), the MateMer read-support dedup (cbdg/graph.h:102-117), the first
+// RemoveLowCovNodes(0) pass (graph.cpp:135, :363-390) and produces the compact, canonically ordered
+// node/edge arrays the cleaning kernel (clean.hip) walks.
+//
+// One 256-thread workgroup per window attempt.  Five data-parallel passes over the k-mer INSTANCES of
+// the window (reference k-mers first, then each filter-passing read in collector order -- that
+// sequence-major order is the canonical first-insertion order of DESIGN.md):
+//   k_build_insert  rolling canonical hash (fwd + rev-comp polynomial, fmix64), inward canonical
+//                   compare (kmer.cpp:17-28), open-addressing insert with atomicCAS, atomicMin of the
+//                   first-instance index (= try_emplace keeps the first inserter, graph.cpp:325-326);
+//                   sequential f64 Phred prefix sums per read (graph.cpp:280-304) via two lagged
+//                   accumulators -> error-free bit.
+//   k_mm_insert     (qname, role, node) set with atomicMin of the first error-free instance
+//   k_count         the winning instance increments per-sample / per-role support (node.cpp:18-24)
+//   k_rank          low-coverage pruning + canonical ranking of survivors, node records
+//   k_edges         forward + mirror edge of every (k+1)-mer whose two nodes survive, de-duplicated
+//                   per node with the order key of the first occurrence; k_edge_sort orders them.
+#include "graph_ws.h"
+
+namespace ma {
+
+constexpr int kBT = 256;
+__constant__ u64 c_phred_bits[256] = {
+#include "../../include/ma_phred_lut.inc"
+};
+
+struct SeqInfo {
+  u64 off;   // byte offset in its buffer
+  u32 len;
+  u32 nk;    // number of k-mer instances (0 if len < k+1: SlidingView(seq, k+1) is empty)
+};
+
+__device__ __forceinline__ u32 seq_count(const DBatch& b, int w) {
+  return 1u + (b.read_win_off[w + 1] - b.read_win_off[w]);
+}
+
+// sequence s of window w: s == 0 is the reference, s >= 1 is read (read_win_off[w] + s - 1)
+__device__ __forceinline__ SeqInfo seq_info(const DBatch& b, int w, u32 s, int k) {
+  SeqInfo si;
+  if (s == 0) {
+    si.off = b.ref_off[w];
+    si.len = b.ref_off[w + 1] - b.ref_off[w];
+  } else {
+    u32 const r = b.read_win_off[w] + s - 1;
+    si.off = b.read_off[r];
+    si.len = static_cast<u32>(b.read_off[r + 1] - b.read_off[r]);
+    if (!(b.read_flags[r] & MA_RF_PASS)) si.len = 0;  // graph.cpp:275
+  }
+  si.nk = si.len >= static_cast<u32>(k) + 1 ? si.len - k + 1 : 0;
+  return si;
+}
+
+// block-wide exclusive scan helper over a small per-thread value
+__device__ __forceinline__ u32 block_excl_scan(u32 v, u32* sh, u32* total) {
+  int const t = threadIdx.x;
+  sh[t] = v;
+  __syncthreads();
+  for (int d = 1; d < kBT; d <<= 1) {
+    u32 x = t >= d ? sh[t - d] : 0;
+    __syncthreads();
+    sh[t] += x;
+    __syncthreads();
+  }
+  u32 const incl = sh[t];
+  *total = sh[kBT - 1];
+  __syncthreads();
+  return incl - v;
+}
+
+// ---- per-k instance bookkeeping: seq_inst_base + totals, over ALL windows of the chunk ----
+__global__ __launch_bounds__(kBT) void k_count_inst(DBatch b, GraphWs ws, int win0, int nwin, u32* maxima) {
+  __shared__ u32 sh[kBT];
+  int const w = win0 + blockIdx.x;
+  if (blockIdx.x >= static_cast<u32>(nwin)) return;
+  u32 const ns = seq_count(b, w);
+  u32 const base_idx = b.read_win_off[w] + w;
+  u32 running = 0, read_inst = 0;
+  for (u32 s0 = 0; s0 < ns; s0 += kBT) {
+    u32 const s = s0 + threadIdx.x;
+    u32 nk = 0;
+    if (s < ns) nk = seq_info(b, w, s, ws.k).nk;
+    u32 tot;
+    u32 const ex = block_excl_scan(nk, sh, &tot);
+    if (s < ns) ws.seq_inst_base[base_idx + s] = running + ex;
+    if (s0 == 0) {
+      // the reference contributes sh[0]-lane value; recompute below
+    }
+    running += tot;
+  }
+  if (threadIdx.x == 0) {
+    u32 const refk = seq_info(b, w, 0, ws.k).nk;
+    read_inst = running - refk;
+    ws.win_ninst[w] = running;
+    ws.win_nread_inst[w] = read_inst;
+    atomicMax(&maxima[0], running);
+    atomicMax(&maxima[1], read_inst);
+    atomicMax(&maxima[2], refk);
+  }
+}
+
+// ---- choose the windows that attempt this k (graph.cpp:106-120) ----
+__global__ void k_select_active(GraphWs ws, int win0, int nwin, const u32* gate_approx, u32* win_k, u32* active,
+                                u32* n_active) {
+  int const i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nwin) return;
+  int const w = win0 + i;
+  if (ws.win_flags[w] & 1u) return;           // done at an earlier k
+  atomicAdd(n_active + 1, 1u);                  // still pending
+  win_k[w] = static_cast<u32>(ws.k);            // Graph::CurrentK()
+  if (gate_approx[w] >= static_cast<u32>(ws.k)) return;  // HasExactOrApproxRepeat -> continue
+  u32 const a = atomicAdd(n_active, 1u);
+  active[a] = static_cast<u32>(w);
+}
+
+__device__ __forceinline__ u32 table_insert(u64* keys, u32 mask, u64 id) {
+  u32 slot = static_cast<u32>(id) & mask;
+  for (u32 probe = 0; probe <= mask; ++probe) {
+    u64 cur = keys[slot];
+    if (cur == id) return slot;
+    if (cur == 0) {
+      unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long*>(&keys[slot]), 0ull,
+                                         static_cast<unsigned long long>(id));
+      if (old == 0ull || old == id) return slot;
+    }
+    slot = (slot + 1) & mask;
+  }
+  return kNoNode;
+}
+
+__device__ __forceinline__ u32 table_find(const u64* keys, u32 mask, u64 id) {
+  u32 slot = static_cast<u32>(id) & mask;
+  for (u32 probe = 0; probe <= mask; ++probe) {
+    u64 cur = keys[slot];
+    if (cur == id) return slot;
+    if (cur == 0) return kNoNode;
+    slot = (slot + 1) & mask;
+  }
+  return kNoNode;
+}
+
+// canonical decision of cbdg/kmer.cpp:17-28 on bytes s[0..k)
+__device__ __forceinline__ bool canon_plus(const u8* s, int k) {
+  int const half = (k + 1) / 2;
+  for (int i = 0; i < half; ++i) {
+    signed char const f = static_cast<signed char>(s[i]);
+    signed char const r = static_cast<signed char>(dev_complement(s[k - 1 - i]));
+    if (f < r) return true;
+    if (f > r) return false;
+  }
+  return true;
+}
+
+__global__ __launch_bounds__(kBT) void k_build_insert(DBatch b, GraphWs ws) {
+  int const a = blockIdx.x;
+  int const w = static_cast<int>(ws.active[a]);
+  int const k = ws.k;
+  u32 const mask = (1u << ws.tc_log2) - 1;
+  u64* keys = ws.tbl_key + (static_cast<size_t>(a) << ws.tc_log2);
+  u32* first = ws.tbl_first + (static_cast<size_t>(a) << ws.tc_log2);
+  u32* inst_slot = ws.inst_slot + static_cast<size_t>(a) * ws.inst_stride;
+  u32 const ns = seq_count(b, w);
+  u32 const base_idx = b.read_win_off[w] + w;
+  const f64* phred = reinterpret_cast<const f64*>(c_phred_bits);
+
+  // (A) reference k-mers: one thread per position, direct O(k) hash (no qualities)
+  {
+    SeqInfo const si = seq_info(b, w, 0, k);
+    const u8* s = b.ref_bases + si.off;
+    for (u32 p = threadIdx.x; p < si.nk; p += kBT) {
+      u64 hf = 0, hr = 0, pw = 1;
+      for (int i = 0; i < k; ++i) {
+        hf = hf * kHashP + s[p + i];
+        hr += pw * dev_complement(s[p + i]);
+        pw *= kHashP;
+      }
+      bool const plus = canon_plus(s + p, k);
+      u64 id = dev_fmix64(plus ? hf : hr);
+      id = id ? id : 1;
+      u32 const slot = table_insert(keys, mask, id);
+      u32 const inst = p;  // seq_inst_base of the reference is 0
+      if (slot != kNoNode) atomicMin(&first[slot], inst);
+      inst_slot[inst] = (slot & kInstSlotMask) | (plus ? kInstPlus : 0u);
+    }
+  }
+  // (B) reads: one thread per read, rolling hashes + lagged f64 prefix sums
+  for (u32 s_idx = 1 + threadIdx.x; s_idx < ns; s_idx += kBT) {
+    SeqInfo const si = seq_info(b, w, s_idx, k);
+    if (si.nk == 0) continue;
+    const u8* s = b.read_bases + si.off;
+    const u8* q = b.read_quals + si.off;
+    u32 const ibase = ws.seq_inst_base[base_idx + s_idx];
+    u64 hf = 0, hr = 0, pw = 1;
+    f64 lead = 0.0, lag = 0.0;  // prefix[o+k] and prefix[o] of graph.cpp:283-285
+    for (int i = 0; i < k; ++i) {
+      hf = hf * kHashP + s[i];
+      hr += pw * dev_complement(s[i]);
+      pw *= kHashP;
+      f64 const pe = phred[q[i]];
+      lead = (i == 0) ? pe : lead + pe;
+    }
+    for (u32 o = 0; o < si.nk; ++o) {
+      bool const plus = canon_plus(s + o, k);
+      u64 id = dev_fmix64(plus ? hf : hr);
+      id = id ? id : 1;
+      u32 const slot = table_insert(keys, mask, id);
+      u32 const inst = ibase + o;
+      if (slot != kNoNode) atomicMin(&first[slot], inst);
+      // floor(prefix[o+k] - prefix[o]) == 0  <=>  difference < 1.0 (prefix is non-decreasing)
+      bool const errfree = (lead - lag) < 1.0;
+      inst_slot[inst] = (slot & kInstSlotMask) | (plus ? kInstPlus : 0u) | (errfree ? kInstErrFree : 0u);
+      if (o + 1 < si.nk) {
+        u8 const c_out = s[o], c_in = s[o + k];
+        hf = (hf - ws.pk1 * c_out) * kHashP + c_in;
+        hr = (hr - dev_complement(c_out)) * ws.pinv + ws.pk1 * dev_complement(c_in);
+        f64 const pl = phred[q[o]];
+        lag = (o == 0) ? pl : lag + pl;
+        lead = lead + phred[q[o + k]];
+      }
+    }
+  }
+}
+
+__device__ __forceinline__ u64 mm_key_of(u32 slot, u32 qname, u32 role) {
+  return ((static_cast<u64>(slot) << 33) | (static_cast<u64>(qname) << 1) | role) + 1ull;
+}
+
+__global__ __launch_bounds__(kBT) void k_mm_insert(DBatch b, GraphWs ws) {
+  int const a = blockIdx.x;
+  int const w = static_cast<int>(ws.active[a]);
+  u32 const mask = (1u << ws.mc_log2) - 1;
+  u64* keys = ws.mm_key + (static_cast<size_t>(a) << ws.mc_log2);
+  u32* mins = ws.mm_min + (static_cast<size_t>(a) << ws.mc_log2);
+  const u32* inst_slot = ws.inst_slot + static_cast<size_t>(a) * ws.inst_stride;
+  u32 const ns = seq_count(b, w);
+  u32 const base_idx = b.read_win_off[w] + w;
+  for (u32 s_idx = 1 + threadIdx.x; s_idx < ns; s_idx += kBT) {
+    SeqInfo const si = seq_info(b, w, s_idx, ws.k);
+    if (si.nk == 0) continue;
+    u32 const r = b.read_win_off[w] + s_idx - 1;
+    u32 const qn = b.read_qname_id[r];
+    u32 const role = (b.read_flags[r] & MA_RF_CASE) ? 1u : 0u;
+    u32 const ibase = ws.seq_inst_base[base_idx + s_idx];
+    for (u32 o = 0; o < si.nk; ++o) {
+      u32 const v = inst_slot[ibase + o];
+      if (!(v & kInstErrFree)) continue;
+      u64 const key = mm_key_of(v & kInstSlotMask, qn, role);
+      u32 slot = static_cast<u32>(dev_fmix64(key)) & mask;
+      for (u32 probe = 0; probe <= mask; ++probe) {
+        u64 cur = keys[slot];
+        if (cur != key && cur == 0) {
+          unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long*>(&keys[slot]), 0ull,
+                                             static_cast<unsigned long long>(key));
+          cur = (old == 0ull) ? key : old;
+        }
+        if (cur == key) {
+          atomicMin(&mins[slot], ibase + o);
+          break;
+        }
+        slot = (slot + 1) & mask;
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(kBT) void k_count(DBatch b, GraphWs ws) {
+  int const a = blockIdx.x;
+  int const w = static_cast<int>(ws.active[a]);
+  int const S = ws.num_samples, CW = S + 2;
+  u32 const mask = (1u << ws.mc_log2) - 1;
+  const u64* keys = ws.mm_key + (static_cast<size_t>(a) << ws.mc_log2);
+  const u32* mins = ws.mm_min + (static_cast<size_t>(a) << ws.mc_log2);
+  u32* cnt = ws.tbl_cnt + (static_cast<size_t>(a) << ws.tc_log2) * CW;
+  const u32* inst_slot = ws.inst_slot + static_cast<size_t>(a) * ws.inst_stride;
+  u32 const ns = seq_count(b, w);
+  u32 const base_idx = b.read_win_off[w] + w;
+  for (u32 s_idx = 1 + threadIdx.x; s_idx < ns; s_idx += kBT) {
+    SeqInfo const si = seq_info(b, w, s_idx, ws.k);
+    if (si.nk == 0) continue;
+    u32 const r = b.read_win_off[w] + s_idx - 1;
+    u32 const qn = b.read_qname_id[r];
+    u32 const role = (b.read_flags[r] & MA_RF_CASE) ? 1u : 0u;
+    u32 sample = b.read_sample[r];
+    if (sample >= static_cast<u32>(S)) sample = S - 1;
+    u32 const ibase = ws.seq_inst_base[base_idx + s_idx];
+    for (u32 o = 0; o < si.nk; ++o) {
+      u32 const v = inst_slot[ibase + o];
+      if (!(v & kInstErrFree)) continue;
+      u32 const nslot = v & kInstSlotMask;
+      u64 const key = mm_key_of(nslot, qn, role);
+      u32 slot = static_cast<u32>(dev_fmix64(key)) & mask;
+      for (u32 probe = 0; probe <= mask; ++probe) {
+        u64 const cur = keys[slot];
+        if (cur == key) break;
+        if (cur == 0) {
+          slot = kNoNode;
+          break;
+        }
+        slot = (slot + 1) & mask;
+      }
+      if (slot == kNoNode || mins[slot] != ibase + o) continue;  // a previous (qname, role, kmer) wins
+      atomicAdd(&cnt[static_cast<size_t>(nslot) * CW + sample], 1u);
+      atomicAdd(&cnt[static_cast<size_t>(nslot) * CW + S + role], 1u);
+    }
+  }
+}
+
+// low-coverage pruning (graph.cpp:363-390 with component 0 == everything, no anchors yet) and
+// canonical ranking of the survivors by first-insertion order.
+__global__ __launch_bounds__(kBT) void k_rank(DBatch b, GraphWs ws, u32 min_node_cov) {
+  __shared__ u32 sh[kBT];
+  int const a = blockIdx.x;
+  int const w = static_cast<int>(ws.active[a]);
+  int const S = ws.num_samples, CW = S + 2;
+  u32 const tcap = 1u << ws.tc_log2;
+  const u64* keys = ws.tbl_key + (static_cast<size_t>(a) << ws.tc_log2);
+  u32* first = ws.tbl_first + (static_cast<size_t>(a) << ws.tc_log2);
+  u32* slot_node = ws.slot_node + (static_cast<size_t>(a) << ws.tc_log2);
+  const u32* cnt = ws.tbl_cnt + (static_cast<size_t>(a) << ws.tc_log2) * CW;
+  const u32* inst_slot = ws.inst_slot + static_cast<size_t>(a) * ws.inst_stride;
+  size_t const nb = static_cast<size_t>(a) * ws.nc;
+
+  // 1. survivor flag into bit 31 of tbl_first (set = pruned / empty)
+  for (u32 s = threadIdx.x; s < tcap; s += kBT) {
+    slot_node[s] = kNoNode;
+    if (keys[s] == 0) {
+      first[s] = 0xFFFFFFFFu;
+      continue;
+    }
+    u32 total = 0;
+    bool any = false, all = true;
+    for (int i = 0; i < S; ++i) {
+      u32 const c = cnt[static_cast<size_t>(s) * CW + i];
+      total += c;
+      any |= c > 0;
+      all &= c <= 1;
+    }
+    bool const remove = (any && all) || total < min_node_cov;  // node.cpp:38-42, graph.cpp:374-378
+    if (remove) first[s] |= 0x80000000u;
+  }
+  __syncthreads();
+
+  // 2. canonical ranking: count "first instance of a surviving node" per contiguous block of sequences
+  u32 const ns = seq_count(b, w);
+  u32 const base_idx = b.read_win_off[w] + w;
+  u32 const per = (ns + kBT - 1) / kBT;
+  u32 const s_beg = min(ns, threadIdx.x * per), s_end = min(ns, s_beg + per);
+  u32 mine = 0;
+  for (u32 s = s_beg; s < s_end; ++s) {
+    SeqInfo const si = seq_info(b, w, s, ws.k);
+    u32 const ibase = ws.seq_inst_base[base_idx + s];
+    for (u32 o = 0; o < si.nk; ++o) {
+      u32 const slot = inst_slot[ibase + o] & kInstSlotMask;
+      mine += (first[slot] == ibase + o);
+    }
+  }
+  u32 total;
+  u32 idx = block_excl_scan(mine, sh, &total);
+  if (threadIdx.x == 0) ws.n_nodes[a] = total;
+  if (total >= ws.nc) {  // capacity exceeded: flagged, window fails
+    if (threadIdx.x == 0) atomicOr(&ws.win_flags[w], 4u);
+    return;
+  }
+  for (u32 s = s_beg; s < s_end; ++s) {
+    SeqInfo const si = seq_info(b, w, s, ws.k);
+    u32 const ibase = ws.seq_inst_base[base_idx + s];
+    u32 label = 1;  // Label::REFERENCE
+    u32 srcbit = 0, rel_off = 0;
+    if (s > 0) {
+      u32 const r = b.read_win_off[w] + s - 1;
+      label = (b.read_flags[r] & MA_RF_CASE) ? 4u : 2u;  // Label::CASE / Label::CTRL
+      srcbit = 0x80000000u;
+      rel_off = static_cast<u32>(si.off - b.read_off[b.read_win_off[w]]);
+    }
+    for (u32 o = 0; o < si.nk; ++o) {
+      u32 const v = inst_slot[ibase + o];
+      u32 const slot = v & kInstSlotMask;
+      if (first[slot] != ibase + o) continue;
+      slot_node[slot] = idx;
+      for (int i = 0; i < S; ++i) ws.nd_cnt[(nb + idx) * S + i] = cnt[static_cast<size_t>(slot) * CW + i];
+      ws.nd_role[(nb + idx) * 2 + 0] = cnt[static_cast<size_t>(slot) * CW + S];
+      ws.nd_role[(nb + idx) * 2 + 1] = cnt[static_cast<size_t>(slot) * CW + S + 1];
+      ws.nd_src[nb + idx] = srcbit | (rel_off + o);
+      ws.nd_label[nb + idx] = static_cast<u8>(label);
+      ws.nd_sign[nb + idx] = (v & kInstPlus) ? 1 : 0;
+      ws.nd_nedge[nb + idx] = 0;
+      for (int e = 0; e < kEdgeCap; ++e) {
+        ws.nd_edge[(nb + idx) * kEdgeCap + e] = 0xFFFFFFFFu;
+        ws.nd_ekey[(nb + idx) * kEdgeCap + e] = 0xFFFFFFFFu;
+      }
+      idx++;
+    }
+  }
+  __syncthreads();
+  // 3. mRefNodeIds (graph.cpp:264-267): node of every reference k-mer (kNoNode when pruned)
+  SeqInfo const rsi = seq_info(b, w, 0, ws.k);
+  u32* refn = ws.ref_node + static_cast<size_t>(a) * ws.ref_stride;
+  for (u32 p = threadIdx.x; p < ws.ref_stride; p += kBT)
+    refn[p] = p < rsi.nk ? slot_node[inst_slot[p] & kInstSlotMask] : kNoNode;
+}
+
+__device__ __forceinline__ void edge_insert(GraphWs const& ws, size_t nb, u32 node, u32 val, u32 key, u32* flags) {
+  u32* ed = ws.nd_edge + (nb + node) * kEdgeCap;
+  u32* ek = ws.nd_ekey + (nb + node) * kEdgeCap;
+  for (int e = 0; e < kEdgeCap; ++e) {
+    u32 cur = ed[e];
+    if (cur == 0xFFFFFFFFu) {
+      u32 const old = atomicCAS(&ed[e], 0xFFFFFFFFu, val);
+      cur = (old == 0xFFFFFFFFu) ? val : old;
+    }
+    if (cur == val) {
+      atomicMin(&ek[e], key);
+      return;
+    }
+  }
+  atomicOr(flags, 4u);  // more than kEdgeCap distinct edges at one node
+}
+
+__global__ __launch_bounds__(kBT) void k_edges(DBatch b, GraphWs ws) {
+  int const a = blockIdx.x;
+  int const w = static_cast<int>(ws.active[a]);
+  if (ws.win_flags[w] & 4u) return;
+  const u32* slot_node = ws.slot_node + (static_cast<size_t>(a) << ws.tc_log2);
+  const u32* inst_slot = ws.inst_slot + static_cast<size_t>(a) * ws.inst_stride;
+  size_t const nb = static_cast<size_t>(a) * ws.nc;
+  u32 const ns = seq_count(b, w);
+  u32 const base_idx = b.read_win_off[w] + w;
+  // the reference sequence is long: all threads share it (one (k+1)-mer per thread, strided); every read is
+  // walked by one thread
+  for (u32 s = 0; s < ns; s = (s == 0 ? 1 + threadIdx.x : s + kBT)) {
+    SeqInfo const si = seq_info(b, w, s, ws.k);
+    if (si.nk < 2) continue;
+    u32 const ibase = ws.seq_inst_base[base_idx + s];
+    u32 const o_beg = s == 0 ? threadIdx.x : 0u, o_step = s == 0 ? kBT : 1u, o_end = si.nk - 1;
+    for (u32 o = o_beg; o < o_end; o += o_step) {
+      u32 const na = slot_node[inst_slot[ibase + o] & kInstSlotMask];
+      u32 const nbn = slot_node[inst_slot[ibase + o + 1] & kInstSlotMask];
+      if (na == kNoNode || nbn == kNoNode) continue;
+      // edge kind from the STORED signs of both nodes (graph.cpp:333-336)
+      u32 const sa_minus = ws.nd_sign[nb + na] ? 0u : 1u, sb_minus = ws.nd_sign[nb + nbn] ? 0u : 1u;
+      u32 const fwd = (sa_minus << 1) | sb_minus;                 // MakeFwdEdgeKind(sA, sB)
+      u32 const rev = ((sb_minus ^ 1u) << 1) | (sa_minus ^ 1u);   // RevEdgeKind(fwd) seen from B
+      u32 const key = 2u * (ibase + o);
+      edge_insert(ws, nb, na, (nbn << 2) | fwd, key, &ws.win_flags[w]);
+      edge_insert(ws, nb, nbn, (na << 2) | rev, key + 1u, &ws.win_flags[w]);
+    }
+  }
+}
+
+__global__ __launch_bounds__(kBT) void k_edge_sort(GraphWs ws) {
+  int const a = blockIdx.x;
+  size_t const nb = static_cast<size_t>(a) * ws.nc;
+  u32 const n = min(ws.n_nodes[a], ws.nc);
+  for (u32 i = threadIdx.x; i < n; i += kBT) {
+    u32* ed = ws.nd_edge + (nb + i) * kEdgeCap;
+    u32* ek = ws.nd_ekey + (nb + i) * kEdgeCap;
+    u32 v[kEdgeCap], kk[kEdgeCap];
+    int m = 0;
+    for (int e = 0; e < kEdgeCap; ++e) {
+      if (ed[e] == 0xFFFFFFFFu) break;
+      // insertion sort by first-occurrence key (EmplaceEdge order, node.h:59-64)
+      u32 const cv = ed[e], ck = ek[e];
+      int j = m++;
+      while (j > 0 && kk[j - 1] > ck) {
+        kk[j] = kk[j - 1];
+        v[j] = v[j - 1];
+        --j;
+      }
+      kk[j] = ck;
+      v[j] = cv;
+    }
+    for (int e = 0; e < m; ++e) ed[e] = v[e];
+    ws.nd_nedge[nb + i] = static_cast<u8>(m);
+  }
+}
+
+// ---- host side: one k attempt of the build stage for the active windows ----
+int run_build_pass(ma_ctx* ctx, const DBatch& b, const GraphWs& ws) {
+  if (ws.n_active == 0) return MA_OK;
+  size_t const A = ws.n_active;
+  size_t const tcap = size_t(1) << ws.tc_log2, mcap = size_t(1) << ws.mc_log2;
+  MA_HIP(ctx, hipMemsetAsync(ws.tbl_key, 0, A * tcap * 8, ctx->stream));
+  MA_HIP(ctx, hipMemsetAsync(ws.tbl_first, 0x7F, A * tcap * 4, ctx->stream));  // 0x7F7F7F7F > any instance
+  MA_HIP(ctx, hipMemsetAsync(ws.tbl_cnt, 0, A * tcap * 4 * (ws.num_samples + 2), ctx->stream));
+  MA_HIP(ctx, hipMemsetAsync(ws.mm_key, 0, A * mcap * 8, ctx->stream));
+  MA_HIP(ctx, hipMemsetAsync(ws.mm_min, 0xFF, A * mcap * 4, ctx->stream));
+  ctx->tic("k_build_insert");
+  hipLaunchKernelGGL(k_build_insert, dim3(ws.n_active), dim3(kBT), 0, ctx->stream, b, ws);
+  ctx->toc();
+  ctx->tic("k_mm_insert");
+  hipLaunchKernelGGL(k_mm_insert, dim3(ws.n_active), dim3(kBT), 0, ctx->stream, b, ws);
+  ctx->toc();
+  ctx->tic("k_count");
+  hipLaunchKernelGGL(k_count, dim3(ws.n_active), dim3(kBT), 0, ctx->stream, b, ws);
+  ctx->toc();
+  ctx->tic("k_rank");
+  hipLaunchKernelGGL(k_rank, dim3(ws.n_active), dim3(kBT), 0, ctx->stream, b, ws,
+                     static_cast<u32>(ctx->prm.min_node_cov));
+  ctx->toc();
+  ctx->tic("k_edges");
+  hipLaunchKernelGGL(k_edges, dim3(ws.n_active), dim3(kBT), 0, ctx->stream, b, ws);
+  ctx->toc();
+  ctx->tic("k_edge_sort");
+  hipLaunchKernelGGL(k_edge_sort, dim3(ws.n_active), dim3(kBT), 0, ctx->stream, ws);
+  ctx->toc();
+  MA_HIP(ctx, hipGetLastError());
+  return MA_OK;
+}
+
+int run_count_inst(ma_ctx* ctx, const DBatch& b, const GraphWs& ws, int win0, int nwin, u32* maxima_dev) {
+  MA_HIP(ctx, hipMemsetAsync(maxima_dev, 0, 16, ctx->stream));
+  hipLaunchKernelGGL(k_count_inst, dim3(nwin), dim3(kBT), 0, ctx->stream, b, ws, win0, nwin, maxima_dev);
+  MA_HIP(ctx, hipGetLastError());
+  return MA_OK;
+}
+
+int run_select_active(ma_ctx* ctx, const GraphWs& ws, int win0, int nwin, const u32* gate_approx, u32* win_k,
+                      u32* active, u32* n_active_dev) {
+  MA_HIP(ctx, hipMemsetAsync(n_active_dev, 0, 8, ctx->stream));
+  hipLaunchKernelGGL(k_select_active, dim3((nwin + 255) / 256), dim3(256), 0, ctx->stream, ws, win0, nwin,
+                     gate_approx, win_k, active, n_active_dev);
+  MA_HIP(ctx, hipGetLastError());
+  return MA_OK;
+}
+
+}  // namespace ma

@@ -1,0 +1,958 @@
+// Graph cleaning + haplotype enumeration on gfx950: the per-window serial heart of cbdg --
+// MarkConnectedComponents, FindSource/FindSink, PruneComponent (CompressGraph / RemoveLowCovNodes /
+// RemoveTips), BuildTraversalIndex, HasCycle, ComputeGraphComplexity, MaxFlow::NextPath, BuildHaplotypes
+// (cbdg/graph.cpp:142-235, :392-924; traversal_index.cpp; cycle_finder.cpp; graph_complexity.cpp;
+// max_flow.cpp; path.cpp).
+//
+// One wavefront per window attempt.  The algorithm is order dependent by construction (floor-averaged
+// coverage merges, edge-list order, first-found walks), so it is executed in the CANONICAL order of
+// DESIGN.md by lane 0 of the wave on the compact arrays build.hip produced; node sequences are never
+// materialised during cleaning -- a node is a doubly linked list of SLICES of original k-mers
+// (start, len, revcomp), which reproduces Kmer::Merge's string semantics (kmer.cpp:48-109) exactly,
+// including for the reference's stored-sign edge quirk.  Haplotype bases are spelled from the batch's
+// ref/read bytes only when a walk is emitted.
+#include "graph_ws.h"
+
+namespace ma {
+
+namespace {
+
+constexpr int kMaxWalks = 64;
+constexpr u32 kNoParent = 0xFFFFFFFFu;
+
+struct Win {
+  // inputs
+  const u8* refb;   // window reference bytes
+  const u8* readb;  // first read byte of the window
+  u32 ref_len;
+  int k, S;
+  u32 n;            // number of nodes
+  u32 nc;
+  u32 min_node_cov, min_anchor_cov;
+  // node arrays
+  u32* cnt;
+  u32* role;
+  const u32* src;
+  u8* label;
+  const u8* sign;
+  u8* nedge;
+  u32* edge;
+  u32* comp;
+  u32* len;
+  u8* alive;
+  u32* head;
+  u32* tail;
+  u32* snext;
+  u32* sprev;
+  u32* sdesc;
+  u32* scratch;
+  i64 source, sink;
+  u32 flags;  // bit2: capacity overflow
+};
+
+__device__ __forceinline__ u32 kind_rev(u32 kind) { return (((kind & 1u) ^ 1u) << 1) | (((kind >> 1) & 1u) ^ 1u); }
+__device__ __forceinline__ u32 mirror_of(u32 self, u32 val) { return (self << 2) | kind_rev(val & 3u); }
+
+__device__ u32 nd_total(const Win& g, u32 i) {
+  u32 t = 0;
+  for (int s = 0; s < g.S; ++s) t += g.cnt[i * g.S + s];
+  return t;
+}
+__device__ bool nd_all_singletons(const Win& g, u32 i) {
+  bool any = false, all = true;
+  for (int s = 0; s < g.S; ++s) {
+    u32 const c = g.cnt[i * g.S + s];
+    any |= c > 0;
+    all &= c <= 1;
+  }
+  return any && all;
+}
+// Node::Confidence (node.cpp:59-79)
+__device__ u32 nd_confidence(const Win& g, u32 i) {
+  if (nd_all_singletons(g, i)) return 1;
+  u32 const total = nd_total(g, i);
+  if (total == 0) return 0;
+  int confirming = 0;
+  for (int s = 0; s < g.S; ++s) confirming += g.cnt[i * g.S + s] > 0;
+  f64 const denom = static_cast<f64>(g.S > 1 ? g.S : 1);
+  f64 const concordance = static_cast<f64>(confirming) / denom;
+  u32 const bonus = (g.label[i] & 1u) ? 1u : 0u;
+  return static_cast<u32>(static_cast<f64>(total) * concordance) + bonus;
+}
+
+__device__ void emplace_edge(Win& g, u32 i, u32 val) {  // node.h:59-64
+  u32* e = g.edge + i * kEdgeCap;
+  int const n = g.nedge[i];
+  for (int x = 0; x < n; ++x)
+    if (e[x] == val) return;
+  if (n >= kEdgeCap) {
+    g.flags |= 4u;
+    return;
+  }
+  e[n] = val;
+  g.nedge[i] = static_cast<u8>(n + 1);
+}
+__device__ void erase_edge(Win& g, u32 i, u32 val) {  // node.h:66-71
+  u32* e = g.edge + i * kEdgeCap;
+  int const n = g.nedge[i];
+  for (int x = 0; x < n; ++x)
+    if (e[x] == val) {
+      for (int y = x; y + 1 < n; ++y) e[y] = e[y + 1];
+      g.nedge[i] = static_cast<u8>(n - 1);
+      return;
+    }
+}
+__device__ bool has_self_loop(const Win& g, u32 i) {
+  const u32* e = g.edge + i * kEdgeCap;
+  for (int x = 0; x < g.nedge[i]; ++x)
+    if ((e[x] >> 2) == i) return true;
+  return false;
+}
+// FindEdgesInDirection (node.cpp:118-127): count + first match
+__device__ int edges_in_dir(const Win& g, u32 i, bool dflt, u32* first) {
+  u32 const exp_minus = dflt ? (g.sign[i] ? 0u : 1u) : (g.sign[i] ? 1u : 0u);
+  const u32* e = g.edge + i * kEdgeCap;
+  int c = 0;
+  for (int x = 0; x < g.nedge[i]; ++x)
+    if (((e[x] >> 1) & 1u) == exp_minus) {
+      if (c == 0) *first = e[x];
+      c++;
+    }
+  return c;
+}
+
+// Graph::RemoveNode (graph.cpp:347-361)
+__device__ void remove_node(Win& g, u32 i) {
+  if (!g.alive[i]) return;
+  const u32* e = g.edge + i * kEdgeCap;
+  for (int x = 0; x < g.nedge[i]; ++x) {
+    u32 const d = e[x] >> 2;
+    if (d == i) continue;
+    if (g.alive[d]) erase_edge(g, d, mirror_of(i, e[x]));
+  }
+  g.alive[i] = 0;
+  g.nedge[i] = 0;
+}
+
+// RemoveLowCovNodes (graph.cpp:363-390)
+__device__ void remove_low_cov(Win& g, u32 comp) {
+  u32* rm = g.scratch;
+  u32 nrm = 0;
+  for (u32 i = 0; i < g.n; ++i) {
+    if (!g.alive[i] || g.comp[i] != comp) continue;
+    if (static_cast<i64>(i) == g.source || static_cast<i64>(i) == g.sink) continue;
+    if (nd_all_singletons(g, i) || nd_total(g, i) < g.min_node_cov) rm[nrm++] = i;
+  }
+  for (u32 x = 0; x < nrm; ++x) remove_node(g, rm[x]);
+}
+
+// ---- slice lists: a node's sequence in its stored orientation ----
+__device__ void slices_reverse(Win& g, u32 node) {  // sequence := RevComp(sequence)
+  u32 s = g.head[node];
+  while (s != kNoNode) {
+    u32 const nx = g.snext[s];
+    g.snext[s] = g.sprev[s];
+    g.sprev[s] = nx;
+    u32 const d = g.sdesc[s];
+    u32 const st = d & 0xFFu, ln = (d >> 8) & 0xFFu, rc = (d >> 16) & 1u;
+    g.sdesc[s] = (static_cast<u32>(g.k) - st - ln) | (ln << 8) | ((rc ^ 1u) << 16);
+    s = nx;
+  }
+  u32 const h = g.head[node];
+  g.head[node] = g.tail[node];
+  g.tail[node] = h;
+}
+__device__ void slices_drop_front(Win& g, u32 node, u32 nb) {
+  while (nb > 0) {
+    u32 const s = g.head[node];
+    u32 const d = g.sdesc[s];
+    u32 const st = d & 0xFFu, ln = (d >> 8) & 0xFFu;
+    if (ln <= nb) {
+      nb -= ln;
+      u32 const nx = g.snext[s];
+      g.head[node] = nx;
+      if (nx != kNoNode) g.sprev[nx] = kNoNode; else g.tail[node] = kNoNode;
+    } else {
+      g.sdesc[s] = (st + nb) | ((ln - nb) << 8) | (d & 0x10000u);
+      nb = 0;
+    }
+  }
+}
+__device__ void slices_drop_back(Win& g, u32 node, u32 nb) {
+  while (nb > 0) {
+    u32 const s = g.tail[node];
+    u32 const d = g.sdesc[s];
+    u32 const st = d & 0xFFu, ln = (d >> 8) & 0xFFu;
+    if (ln <= nb) {
+      nb -= ln;
+      u32 const pv = g.sprev[s];
+      g.tail[node] = pv;
+      if (pv != kNoNode) g.snext[pv] = kNoNode; else g.head[node] = kNoNode;
+    } else {
+      g.sdesc[s] = st | ((ln - nb) << 8) | (d & 0x10000u);
+      nb = 0;
+    }
+  }
+}
+
+// Node::Merge (node.cpp:81-112) + Kmer::Merge / MergeCords (kmer.cpp:48-109)
+__device__ void merge_node(Win& g, u32 x, u32 b, u32 kind) {
+  u32 const K1 = static_cast<u32>(g.k) - 1;
+  u32 const blen = g.len[b];
+  bool const append = kind == 0 || kind == 1;  // PLUS_PLUS / PLUS_MINUS append, MINUS_* prepend
+  bool const rc = kind == 1 || kind == 2;      // PLUS_MINUS / MINUS_PLUS use RevComp(other)
+  if (rc) slices_reverse(g, b);
+  if (append) {
+    slices_drop_front(g, b, K1);  // NonOvlSuffix
+    if (g.head[b] != kNoNode) {
+      g.snext[g.tail[x]] = g.head[b];
+      g.sprev[g.head[b]] = g.tail[x];
+      g.tail[x] = g.tail[b];
+    }
+  } else {
+    slices_drop_back(g, b, K1);  // NonOvlPrefix
+    if (g.head[b] != kNoNode) {
+      g.sprev[g.head[x]] = g.tail[b];
+      g.snext[g.tail[b]] = g.head[x];
+      g.head[x] = g.head[b];
+    }
+  }
+  g.head[b] = g.tail[b] = kNoNode;
+  g.len[x] += blen - K1;
+  g.label[x] |= g.label[b];
+  u64 const this_len = g.len[x];  // length AFTER the merge (node.cpp:91)
+  u64 const other_len = blen, total_len = this_len + other_len;
+  for (int s = 0; s < g.S; ++s) {
+    u64 const av = g.cnt[x * g.S + s], bv = g.cnt[b * g.S + s];
+    g.cnt[x * g.S + s] = static_cast<u32>((av * this_len + bv * other_len) / total_len);
+  }
+  for (int r = 0; r < 2; ++r) {
+    u64 const av = g.role[x * 2 + r], bv = g.role[b * 2 + r];
+    g.role[x * 2 + r] = static_cast<u32>((av * this_len + bv * other_len) / total_len);
+  }
+}
+
+// IsPotentialBuddyEdge (graph.cpp:758-799); conn = edge value stored at src
+__device__ bool is_potential_buddy(const Win& g, u32 src, u32 conn) {
+  u32 const nb = conn >> 2;
+  if (g.nedge[src] == 1 && g.nedge[nb] == 1) {
+    if ((g.edge[src * kEdgeCap] >> 2) == nb && (g.edge[nb * kEdgeCap] >> 2) == src) return false;
+  }
+  if (g.nedge[nb] > 2 || g.nedge[nb] == 0 || has_self_loop(g, nb)) return false;
+  u32 const expected = mirror_of(src, conn);  // nbour -> src
+  // direction of nbour whose SrcSign equals the mirror's SrcSign
+  u32 const exp_src_minus = (expected >> 1) & 1u;
+  bool const dir_dflt = (exp_src_minus == 0u) == (g.sign[nb] != 0);
+  u32 f = 0;
+  int const c1 = edges_in_dir(g, nb, dir_dflt, &f);
+  if (c1 != 1 || f != expected) return false;
+  u32 f2 = 0;
+  int const c2 = edges_in_dir(g, nb, !dir_dflt, &f2);
+  if (c2 != 1 || (f2 >> 2) == src) return false;
+  return g.nedge[f2 >> 2] <= 2;
+}
+
+// FindCompressibleEdge (graph.cpp:688-717)
+__device__ bool find_compressible_edge(const Win& g, u32 src, bool dflt, u32* out) {
+  if (g.nedge[src] > 2 || g.nedge[src] == 0 || has_self_loop(g, src)) return false;
+  if (static_cast<i64>(src) == g.source || static_cast<i64>(src) == g.sink) return false;
+  u32 cand = 0;
+  if (edges_in_dir(g, src, dflt, &cand) != 1) return false;
+  u32 const d = cand >> 2;
+  if (static_cast<i64>(d) == g.source || static_cast<i64>(d) == g.sink) return false;
+  if (!is_potential_buddy(g, src, cand)) return false;
+  u32 opp = 0;
+  int const co = edges_in_dir(g, src, !dflt, &opp);
+  if (co == 0) {
+    *out = cand;
+    return true;
+  }
+  if (co > 1) return false;
+  if (!is_potential_buddy(g, src, opp)) return false;
+  *out = cand;
+  return true;
+}
+
+// CompressNode (graph.cpp:600-645)
+__device__ void compress_node(Win& g, u32 nid, bool dflt, u8* absorbed) {
+  u32 s2o = 0;
+  while (find_compressible_edge(g, nid, dflt, &s2o)) {
+    u32 const ob = s2o >> 2, kind = s2o & 3u;
+    merge_node(g, nid, ob, kind);
+    erase_edge(g, nid, s2o);
+    u32 const src_minus = (kind >> 1) & 1u, dst_minus = kind & 1u;
+    u32 const mirror = mirror_of(nid, s2o);
+    int const nob = g.nedge[ob];
+    for (int x = 0; x < nob; ++x) {
+      u32 const o2n = g.edge[ob * kEdgeCap + x];
+      if (o2n == mirror) continue;
+      u32 const nbd = o2n >> 2;
+      u32 const o2n_src_minus = (o2n >> 1) & 1u, o2n_dst_minus = o2n & 1u;
+      u32 const ne_src_minus = (dst_minus != o2n_src_minus) ? (src_minus ^ 1u) : src_minus;
+      u32 const s2n = (nbd << 2) | (ne_src_minus << 1) | o2n_dst_minus;
+      emplace_edge(g, nid, s2n);
+      emplace_edge(g, nbd, mirror_of(nid, s2n));
+      erase_edge(g, nbd, mirror_of(ob, o2n));
+    }
+    absorbed[ob] = 1;
+  }
+}
+
+// CompressGraph (graph.cpp:558-576)
+__device__ void compress_graph(Win& g, u32 comp) {
+  u8* absorbed = reinterpret_cast<u8*>(g.scratch + g.nc);
+  for (u32 i = 0; i < g.n; ++i) absorbed[i] = 0;
+  for (u32 i = 0; i < g.n; ++i) {
+    if (!g.alive[i] || g.comp[i] != comp || absorbed[i]) continue;
+    compress_node(g, i, true, absorbed);
+    compress_node(g, i, false, absorbed);
+  }
+  for (u32 i = 0; i < g.n; ++i)
+    if (absorbed[i]) remove_node(g, i);
+}
+
+// RemoveTips (graph.cpp:801-840)
+__device__ void remove_tips(Win& g, u32 comp) {
+  u32 current = 1;
+  while (current > 0) {
+    u32* rm = g.scratch;
+    u32 nrm = 0;
+    for (u32 i = 0; i < g.n; ++i) {
+      if (!g.alive[i]) continue;
+      bool const anchor = static_cast<i64>(i) == g.source || static_cast<i64>(i) == g.sink;
+      if (g.comp[i] != comp || anchor || g.nedge[i] > 1) continue;
+      u32 const uniq = g.len[i] - static_cast<u32>(g.k) + 1;
+      if (uniq >= static_cast<u32>(g.k)) continue;
+      rm[nrm++] = i;
+    }
+    if (nrm > 0) {
+      for (u32 x = 0; x < nrm; ++x) remove_node(g, rm[x]);
+      compress_graph(g, comp);
+    }
+    current = nrm;
+  }
+}
+
+// ---- sequence spelling ----
+__device__ __forceinline__ u8 canon_base(const Win& g, u32 o, u32 x) {  // x-th base of node o's canonical k-mer
+  u32 const sv = g.src[o];
+  const u8* p = (sv & 0x80000000u) ? g.readb + (sv & 0x7FFFFFFFu) : g.refb + sv;
+  return g.sign[o] ? p[x] : dev_complement(p[g.k - 1 - x]);
+}
+__device__ __forceinline__ u8 slice_base(const Win& g, u32 o, u32 d, u32 j) {  // j-th base of slice (o, d)
+  u32 const st = d & 0xFFu, rc = (d >> 16) & 1u;
+  u32 const pp = st + j;
+  return rc ? dev_complement(canon_base(g, o, g.k - 1 - pp)) : canon_base(g, o, pp);
+}
+// append the oriented sequence of `node` (dflt: stored orientation, else reverse complement) minus its
+// first `skip` bases to out[*pos..], bounded by cap.  Returns false on overflow.
+__device__ bool emit_node_seq(const Win& g, u32 node, bool dflt, u32 skip, u8* out, u32* pos, u32 cap) {
+  bool ok = true;
+  if (dflt) {
+    for (u32 s = g.head[node]; s != kNoNode; s = g.snext[s]) {
+      u32 const d = g.sdesc[s], ln = (d >> 8) & 0xFFu;
+      for (u32 j = 0; j < ln; ++j) {
+        if (skip > 0) {
+          skip--;
+          continue;
+        }
+        if (*pos < cap) out[*pos] = slice_base(g, s, d, j); else ok = false;
+        (*pos)++;
+      }
+    }
+  } else {
+    for (u32 s = g.tail[node]; s != kNoNode; s = g.sprev[s]) {
+      u32 const d = g.sdesc[s], ln = (d >> 8) & 0xFFu;
+      for (u32 j = ln; j-- > 0;) {
+        if (skip > 0) {
+          skip--;
+          continue;
+        }
+        if (*pos < cap) out[*pos] = dev_complement(slice_base(g, s, d, j)); else ok = false;
+        (*pos)++;
+      }
+    }
+  }
+  return ok;
+}
+
+struct OnlineStats {  // base/compute_stats.h:75-125
+  u32 n = 0;
+  f64 m1 = 0.0, m2 = 0.0;
+  __device__ void add(f64 v) {
+    u32 const old_n = n++;
+    f64 const delta = v - m1;
+    f64 const nd = delta / static_cast<f64>(n);
+    m1 += nd;
+    m2 += (delta * nd * static_cast<f64>(old_n));
+  }
+  __device__ f64 variance() const { return n < 2 ? 0.0 : m2 / static_cast<f64>(n - 1); }
+  __device__ f64 sd() const { return sqrt(variance()); }
+};
+
+__device__ void isort_u32(u32* v, u32 n) {
+  for (u32 i = 1; i < n; ++i) {
+    u32 const x = v[i];
+    u32 j = i;
+    while (j > 0 && v[j - 1] > x) {
+      v[j] = v[j - 1];
+      --j;
+    }
+    v[j] = x;
+  }
+}
+__device__ u32 median_sorted(const u32* v, u32 n) {  // compute_stats.h:146-159 on sorted data
+  if (n == 0) return 0;
+  if (n == 1) return v[0];
+  u32 const half = v[n / 2];
+  if (n % 2 == 1) return half;
+  return (half + v[n / 2 - 1]) / 2;
+}
+
+}  // namespace
+
+struct CleanArgs {
+  DBatch b;
+  GraphWs ws;
+  ma_asm_out_t out;
+  ma_params_t prm;
+};
+
+__global__ __launch_bounds__(64) void k_clean(CleanArgs A) {
+  if (threadIdx.x != 0) return;  // canonical serial order: lane 0 drives the window
+  int const a = blockIdx.x;
+  GraphWs const& ws = A.ws;
+  int const w = static_cast<int>(ws.active[a]);
+  ma_params_t const& P = A.prm;
+  size_t const nb = static_cast<size_t>(a) * ws.nc;
+  int const MC = P.max_comps, MH = P.max_haps, ML = P.max_hap_len, MR = P.max_runs;
+
+  if (ws.win_flags[w] & 4u) {  // build-stage capacity overflow: report and stop retrying
+    A.out.win_status[w] = MA_W_TABLE_OVERFLOW | MA_W_NO_HAPLOTYPE;
+    A.out.win_ncomp[w] = 0;
+    atomicOr(&ws.win_flags[w], 1u);
+    return;
+  }
+
+  Win g;
+  g.refb = A.b.ref_bases + A.b.ref_off[w];
+  g.readb = A.b.read_bases + A.b.read_off[A.b.read_win_off[w]];
+  g.ref_len = A.b.ref_off[w + 1] - A.b.ref_off[w];
+  g.k = ws.k;
+  g.S = ws.num_samples;
+  g.n = ws.n_nodes[a];
+  g.nc = ws.nc;
+  g.min_node_cov = P.min_node_cov;
+  g.min_anchor_cov = P.min_anchor_cov;
+  g.cnt = ws.nd_cnt + nb * g.S;
+  g.role = ws.nd_role + nb * 2;
+  g.src = ws.nd_src + nb;
+  g.label = ws.nd_label + nb;
+  g.sign = ws.nd_sign + nb;
+  g.nedge = ws.nd_nedge + nb;
+  g.edge = ws.nd_edge + nb * kEdgeCap;
+  g.comp = ws.nd_comp + nb;
+  g.len = ws.nd_len + nb;
+  g.alive = ws.nd_alive + nb;
+  g.head = ws.nd_head + nb;
+  g.tail = ws.nd_tail + nb;
+  g.snext = ws.sl_next + nb;
+  g.sprev = ws.sl_prev + nb;
+  g.sdesc = ws.sl_desc + nb;
+  g.scratch = ws.scratch + nb * 32;
+  g.source = g.sink = -1;
+  g.flags = 0;
+  u32 const NC = ws.nc;
+  u32 const K = static_cast<u32>(g.k);
+
+  for (u32 i = 0; i < g.n; ++i) {
+    g.comp[i] = 0;
+    g.len[i] = K;
+    g.alive[i] = 1;
+    g.head[i] = g.tail[i] = i;
+    g.snext[i] = g.sprev[i] = kNoNode;
+    g.sdesc[i] = 0u | (K << 8);
+  }
+
+  // ---- MarkConnectedComponents (graph.cpp:392-463): ids in discovery order over canonical order ----
+  u32 ncomp_all = 0;
+  {
+    u32* q = g.scratch;  // FIFO; every node is pushed once per incident edge at most -> bound by visited check
+    for (u32 i = 0; i < g.n; ++i) {
+      if (g.comp[i] != 0) continue;
+      ncomp_all++;
+      u32 qh = 0, qt = 0;
+      q[qt++] = i;
+      g.comp[i] = ncomp_all;
+      while (qh < qt) {
+        u32 const cur = q[qh++];
+        for (int x = 0; x < g.nedge[cur]; ++x) {
+          u32 const d = g.edge[cur * kEdgeCap + x] >> 2;
+          if (g.comp[d] == 0) {
+            g.comp[d] = ncomp_all;
+            q[qt++] = d;
+          }
+        }
+      }
+    }
+  }
+  // component sizes + anchors in one pass (FindSource / FindSink, graph.cpp:469-509): components are
+  // disjoint and pruning one never touches another, so the candidates can be resolved up front.
+  // Candidate = component with source != sink and ref anchor length >= min_anchor_len.
+  const u32* refn = ws.ref_node + static_cast<size_t>(a) * ws.ref_stride;
+  u32 const n_refk = g.ref_len >= K + 1 ? g.ref_len - K + 1 : 0;
+  constexpr int kMaxCand = 16;
+  u32 cand_comp[kMaxCand], cand_size[kMaxCand], cand_src[kMaxCand], cand_snk[kMaxCand];
+  u32 cand_soff[kMaxCand], cand_koff[kMaxCand];
+  int ncand = 0;
+  {
+    // first / last qualifying reference k-mer per component, discovered in reference order
+    u32* first_off = g.scratch;            // [ncomp_all+1]
+    u32* last_off = g.scratch + NC;        // [ncomp_all+1]
+    u32* csize = g.scratch + 2 * NC;       // [ncomp_all+1]
+    for (u32 c = 0; c <= ncomp_all; ++c) {
+      first_off[c] = kNoNode;
+      last_off[c] = kNoNode;
+      csize[c] = 0;
+    }
+    for (u32 i = 0; i < g.n; ++i) csize[g.comp[i]]++;
+    for (u32 r = 0; r < n_refk; ++r) {
+      u32 const nd = refn[r];
+      if (nd == kNoNode) continue;
+      if (nd_total(g, nd) < g.min_anchor_cov) continue;
+      u32 const c = g.comp[nd];
+      if (first_off[c] == kNoNode) first_off[c] = r;
+      last_off[c] = r;
+    }
+    for (u32 c = 1; c <= ncomp_all; ++c) {
+      if (first_off[c] == kNoNode) continue;
+      u32 const so = first_off[c], ko = last_off[c];
+      if (refn[so] == refn[ko]) continue;                        // same node (graph.cpp:160)
+      if (ko - so + K < static_cast<u32>(P.min_anchor_len)) continue;  // graph.cpp:167-173
+      if (ncand < kMaxCand) {
+        cand_comp[ncand] = c;
+        cand_size[ncand] = csize[c];
+        cand_src[ncand] = refn[so];
+        cand_snk[ncand] = refn[ko];
+        cand_soff[ncand] = so;
+        cand_koff[ncand] = ko;
+        ncand++;
+      } else {
+        g.flags |= 4u;
+      }
+    }
+    // stable order: size descending, then component id ascending (canonical form of graph.cpp:441)
+    for (int i = 1; i < ncand; ++i) {
+      int j = i;
+      while (j > 0 && cand_size[j - 1] < cand_size[j]) {
+        u32 t;
+        t = cand_comp[j]; cand_comp[j] = cand_comp[j - 1]; cand_comp[j - 1] = t;
+        t = cand_size[j]; cand_size[j] = cand_size[j - 1]; cand_size[j - 1] = t;
+        t = cand_src[j]; cand_src[j] = cand_src[j - 1]; cand_src[j - 1] = t;
+        t = cand_snk[j]; cand_snk[j] = cand_snk[j - 1]; cand_snk[j - 1] = t;
+        t = cand_soff[j]; cand_soff[j] = cand_soff[j - 1]; cand_soff[j - 1] = t;
+        t = cand_koff[j]; cand_koff[j] = cand_koff[j - 1]; cand_koff[j - 1] = t;
+        --j;
+      }
+    }
+  }
+
+  u32 status = 0;
+  u32 ncomp_out = 0, slot = 0;
+  bool retry = false;
+
+  for (int ci = 0; ci < ncand && !retry; ++ci) {
+    u32 const comp = cand_comp[ci];
+    g.source = cand_src[ci];
+    g.sink = cand_snk[ci];
+    u32 const anchor_len = cand_koff[ci] - cand_soff[ci] + K;
+    const u8* ref_anchor = g.refb + cand_soff[ci];
+
+    // ---- PruneComponent (graph.cpp:515-540) ----
+    compress_graph(g, comp);
+    remove_low_cov(g, comp);
+    compress_graph(g, comp);
+    remove_tips(g, comp);
+    if (g.flags & 4u) break;
+
+    // ---- BuildTraversalIndex (traversal_index.cpp:34-119) ----
+    u32* flat_of = g.scratch + NC;       // node -> flat
+    u32* flat_nodes = g.scratch + 2 * NC;
+    u32* rstart = g.scratch + 3 * NC;    // [2V]
+    u32* rcnt = g.scratch + 5 * NC;      // [2V]
+    u32* adj_state = g.scratch + 7 * NC;   // [E]
+    u32* adj_ord = g.scratch + 11 * NC;    // [E]
+    u32* ord_src = g.scratch + 15 * NC;    // [E] source node of ordinal
+    u32* ord_val = g.scratch + 19 * NC;    // [E] dst<<2|kind of ordinal
+    u8* traversed = reinterpret_cast<u8*>(g.scratch + 23 * NC);  // [E]
+    u8* color = reinterpret_cast<u8*>(g.scratch + 24 * NC);      // [2V]
+    u32* stack = g.scratch + 25 * NC;      // DFS frames (2 u32 each) / walk pool afterwards
+    u32 V = 0, E = 0;
+    for (u32 i = 0; i < g.n; ++i) {
+      flat_of[i] = kNoNode;
+      if (!g.alive[i] || g.comp[i] != comp) continue;
+      flat_of[i] = V;
+      flat_nodes[V++] = i;
+    }
+    for (u32 s = 0; s < 2 * V; ++s) rcnt[s] = 0;
+    for (u32 f = 0; f < V; ++f) {
+      u32 const i = flat_nodes[f];
+      for (int x = 0; x < g.nedge[i]; ++x) {
+        u32 const e = g.edge[i * kEdgeCap + x];
+        if (flat_of[e >> 2] == kNoNode) continue;
+        rcnt[f * 2 + ((e >> 1) & 1u)]++;
+        E++;
+      }
+    }
+    if (E > 4 * NC || 2 * V > 2 * NC) {
+      g.flags |= 4u;
+      break;
+    }
+    {
+      u32 off = 0;
+      for (u32 s = 0; s < 2 * V; ++s) {
+        rstart[s] = off;
+        off += rcnt[s];
+        rcnt[s] = 0;
+      }
+    }
+    {
+      u32 ord = 0;
+      for (u32 f = 0; f < V; ++f) {
+        u32 const i = flat_nodes[f];
+        for (int x = 0; x < g.nedge[i]; ++x) {
+          u32 const e = g.edge[i * kEdgeCap + x];
+          u32 const df = flat_of[e >> 2];
+          if (df == kNoNode) continue;
+          u32 const ss = f * 2 + ((e >> 1) & 1u);
+          u32 const ds = df * 2 + (e & 1u);
+          ord_src[ord] = i;
+          ord_val[ord] = e;
+          adj_state[rstart[ss] + rcnt[ss]] = ds;
+          adj_ord[rstart[ss] + rcnt[ss]] = ord;
+          rcnt[ss]++;
+          ord++;
+        }
+      }
+    }
+    u32 const src_state = flat_of[g.source] * 2 + (g.sign[g.source] ? 0u : 1u);
+    u32 const snk_flat = flat_of[g.sink];
+
+    // ---- HasCycle (cycle_finder.cpp:55-100) ----
+    {
+      for (u32 s = 0; s < 2 * V; ++s) color[s] = 0;
+      u32 sp = 0;
+      color[src_state] = 1;
+      stack[0] = src_state;
+      stack[1] = 0;
+      sp = 1;
+      bool cyc = false;
+      while (sp > 0 && !cyc) {
+        u32 const st = stack[(sp - 1) * 2], pos = stack[(sp - 1) * 2 + 1];
+        if (pos >= rcnt[st]) {
+          color[st] = 2;
+          sp--;
+          continue;
+        }
+        u32 const dsts = adj_state[rstart[st] + pos];
+        stack[(sp - 1) * 2 + 1] = pos + 1;
+        if (color[dsts] == 1) {
+          cyc = true;
+          break;
+        }
+        if (color[dsts] != 0) continue;
+        color[dsts] = 1;
+        stack[sp * 2] = dsts;
+        stack[sp * 2 + 1] = 0;
+        sp++;
+      }
+      if (cyc) {
+        retry = true;
+        break;
+      }
+    }
+
+    // ---- ComputeGraphComplexity (graph_complexity.cpp:16-93) ----
+    u32 cx_cc = 0, cx_bp = 0, cx_maxdeg = 0;
+    f64 cx_unitig = 0.0, cx_cv = 0.0, cx_tip = 0.0;
+    {
+      u32 nn = 0, ne = 0, unitigs = 0;
+      OnlineStats cov, tip, uni;
+      for (u32 f = 0; f < V; ++f) {
+        u32 const i = flat_nodes[f];
+        nn++;
+        u32 d = 0, o = 0;
+        u32 const self_minus = g.sign[i] ? 0u : 1u;
+        for (int x = 0; x < g.nedge[i]; ++x) {
+          if (((g.edge[i * kEdgeCap + x] >> 1) & 1u) == self_minus) d++; else o++;
+        }
+        ne += d + o;
+        u32 const mx = d > o ? d : o;
+        cx_maxdeg = cx_maxdeg > mx ? cx_maxdeg : mx;
+        if (d >= 2 || o >= 2) cx_bp++;
+        if (d == 1 && o == 1) unitigs++;
+        f64 const cv = static_cast<f64>(nd_total(g, i));
+        cov.add(cv);
+        if (d == 0 || o == 0) tip.add(cv); else if (d == 1 && o == 1) uni.add(cv);
+      }
+      ne /= 2;
+      cx_cc = ne >= nn ? ne - nn + 1 : 0;
+      cx_unitig = nn > 0 ? static_cast<f64>(unitigs) / static_cast<f64>(nn) : 0.0;
+      if (cov.n > 0 && cov.m1 > 0.0) cx_cv = cov.sd() / cov.m1;
+      if (tip.n > 0 && uni.n > 0 && uni.m1 > 0.0) cx_tip = tip.m1 / uni.m1;
+    }
+    if (cx_cc >= 50 && cx_bp >= 50) {  // GraphComplexity::IsComplex (graph_complexity.h:112-121)
+      retry = true;
+      break;
+    }
+
+    // ---- BuildHaplotypes: MaxFlow::NextPath loop (max_flow.cpp:162-280, graph.cpp:846-891) ----
+    for (u32 e = 0; e < E; ++e) traversed[e] = 0;
+    uint4* arena = ws.arena + static_cast<size_t>(a) * ws.ac;
+    u32* walk_pool = stack;  // ordinals of accepted walks, back to back
+    u32 walk_pool_cap = 7 * NC, walk_pool_used = 0;
+    u32 walk_off[kMaxWalks], walk_len[kMaxWalks], walk_minw[kMaxWalks];
+    int nwalks = 0;
+    bool hit_limit = false, arena_over = false;
+    while (true) {
+      u32 an = 0, head = 0;
+      // EnqueueOutgoingEdges (max_flow.cpp:235-280): stable sort by dst Confidence desc, new edges first
+      auto enqueue = [&](u32 state, u32 parent, u32 pscore) {
+        u32 const cnt = rcnt[state];
+        if (cnt == 0) return;
+        u32 idx[kEdgeCap], conf[kEdgeCap];
+        u32 const m = cnt < static_cast<u32>(kEdgeCap) ? cnt : static_cast<u32>(kEdgeCap);
+        for (u32 x = 0; x < m; ++x) {
+          u32 const p = rstart[state] + x;
+          u32 const cf = nd_confidence(g, flat_nodes[adj_state[p] >> 1]);
+          u32 j = x;
+          while (j > 0 && conf[j - 1] < cf) {
+            conf[j] = conf[j - 1];
+            idx[j] = idx[j - 1];
+            --j;
+          }
+          conf[j] = cf;
+          idx[j] = p;
+        }
+        for (int pass = 0; pass < 2; ++pass)
+          for (u32 x = 0; x < m; ++x) {
+            u32 const p = idx[x];
+            bool const trav = traversed[adj_ord[p]] != 0;
+            if (trav != (pass == 1)) continue;
+            if (an >= ws.ac) {
+              arena_over = true;
+              return;
+            }
+            arena[an++] = make_uint4(adj_ord[p], adj_state[p], parent, pscore + (trav ? 0u : 1u));
+          }
+      };
+      enqueue(src_state, kNoParent, 0);
+      u32 nvisits = 0;
+      i64 best = -1;
+      while (head < an && !arena_over) {
+        nvisits++;
+        if (nvisits > static_cast<u32>(P.bfs_limit)) {
+          hit_limit = true;
+          break;
+        }
+        u32 const ai = head++;
+        uint4 const wn = arena[ai];
+        if ((wn.y >> 1) == snk_flat) {
+          if (wn.w == 0) continue;
+          best = ai;
+          break;
+        }
+        enqueue(wn.y, ai, wn.w);
+      }
+      if (best < 0) break;
+      // reconstruct (max_flow.cpp:42-54) into the pool, reversed to source->sink order
+      u32 wl = 0;
+      for (u32 i = static_cast<u32>(best); i != kNoParent; i = arena[i].z) wl++;
+      if (nwalks >= kMaxWalks || walk_pool_used + wl > walk_pool_cap) {
+        status |= MA_W_HAP_OVERFLOW;
+        break;
+      }
+      u32 const off = walk_pool_used;
+      {
+        u32 pos = wl;
+        for (u32 i = static_cast<u32>(best); i != kNoParent; i = arena[i].z) {
+          walk_pool[off + --pos] = arena[i].x;
+          traversed[arena[i].x] = 1;
+        }
+      }
+      // MinWeight over the walk's nodes (path.cpp:34-37)
+      u32 mw = nd_confidence(g, ord_src[walk_pool[off]]);
+      for (u32 x = 0; x < wl; ++x) {
+        u32 const cf = nd_confidence(g, ord_val[walk_pool[off + x]] >> 2);
+        mw = mw < cf ? mw : cf;
+      }
+      walk_off[nwalks] = off;
+      walk_len[nwalks] = wl;
+      walk_minw[nwalks] = mw;
+      nwalks++;
+      walk_pool_used += wl;
+    }
+    if (arena_over) status |= MA_W_TABLE_OVERFLOW;
+    if (hit_limit) status |= MA_W_BFS_LIMIT;
+    if (nwalks == 0) continue;  // graph.cpp:225
+
+    // stable sort by MinWeight desc (graph.cpp:876-879)
+    int order[kMaxWalks];
+    for (int i = 0; i < nwalks; ++i) {
+      int j = i;
+      while (j > 0 && walk_minw[order[j - 1]] < walk_minw[i]) {
+        order[j] = order[j - 1];
+        --j;
+      }
+      order[j] = i;
+    }
+    if (static_cast<int>(ncomp_out) >= MC || static_cast<int>(slot) + 1 > MH) {
+      status |= MA_W_HAP_OVERFLOW;
+      break;
+    }
+    size_t const cidx = static_cast<size_t>(w) * MC + ncomp_out;
+    u32 const hap0 = slot;
+    // REF haplotype (graph.cpp:902-924)
+    {
+      u32* confs = g.scratch;  // reuse
+      u32 ncf = 0;
+      for (u32 f = 0; f < V; ++f) {
+        u32 const i = flat_nodes[f];
+        if (g.label[i] & 1u) confs[ncf++] = nd_confidence(g, i);
+      }
+      isort_u32(confs, ncf);
+      u32 const wgt = ncf == 0 ? 1u : median_sorted(confs, ncf);
+      size_t const hi = static_cast<size_t>(w) * MH + slot;
+      u32 len = anchor_len;
+      if (len > static_cast<u32>(ML)) {
+        status |= MA_W_LEN_OVERFLOW;
+        len = ML;
+      }
+      for (u32 x = 0; x < len; ++x) A.out.hap_bases[hi * ML + x] = ref_anchor[x];
+      A.out.hap_len[hi] = len;
+      A.out.hap_nruns[hi] = 1;
+      A.out.hap_runs[(hi * MR) * 2 + 0] = wgt;
+      A.out.hap_runs[(hi * MR) * 2 + 1] = anchor_len;
+      for (int x = 0; x < 6; ++x) A.out.hap_stats[hi * 6 + x] = 0.0;
+      slot++;
+    }
+    f64 max_alt_cv = -1.0;
+    bool has_alt = false;
+    for (int oi = 0; oi < nwalks; ++oi) {
+      int const wi = order[oi];
+      if (static_cast<int>(slot) >= MH) {
+        status |= MA_W_HAP_OVERFLOW;
+        break;
+      }
+      size_t const hi = static_cast<size_t>(w) * MH + slot;
+      u8* hb = A.out.hap_bases + hi * ML;
+      u32* covs = g.scratch;  // node coverages in walk order
+      u32 ncov = 0, pos = 0, nruns = 0;
+      bool ok = true, runs_ok = true;
+      // BuildSequence (max_flow.cpp:64-113)
+      u32 const wl = walk_len[wi];
+      const u32* wo = walk_pool + walk_off[wi];
+      {
+        u32 const e0 = ord_val[wo[0]];
+        u32 const sn = ord_src[wo[0]];
+        bool const dflt = ((e0 >> 1) & 1u) == 0u;  // walk[0].SrcSign() == PLUS
+        u32 const before = pos;
+        ok &= emit_node_seq(g, sn, dflt, 0, hb, &pos, ML);
+        covs[ncov++] = nd_total(g, sn);
+        if (static_cast<int>(nruns) < MR) {
+          A.out.hap_runs[(hi * MR + nruns) * 2 + 0] = nd_confidence(g, sn);
+          A.out.hap_runs[(hi * MR + nruns) * 2 + 1] = pos - before;
+        } else runs_ok = false;
+        nruns++;
+      }
+      for (u32 x = 0; x < wl; ++x) {
+        u32 const e = ord_val[wo[x]];
+        u32 const dn = e >> 2;
+        bool const dflt = (e & 1u) == 0u;  // conn.DstSign() == PLUS
+        u32 const before = pos;
+        ok &= emit_node_seq(g, dn, dflt, K - 1, hb, &pos, ML);
+        covs[ncov++] = nd_total(g, dn);
+        if (static_cast<int>(nruns) < MR) {
+          A.out.hap_runs[(hi * MR + nruns) * 2 + 0] = nd_confidence(g, dn);
+          A.out.hap_runs[(hi * MR + nruns) * 2 + 1] = pos - before;
+        } else runs_ok = false;
+        nruns++;
+      }
+      // dedup by sequence against kept haplotypes of this component and the ref anchor (graph.cpp:883-887)
+      bool dup = false;
+      if (ok) {
+        for (u32 h = hap0; h < slot && !dup; ++h) {
+          size_t const oi2 = static_cast<size_t>(w) * MH + h;
+          if (A.out.hap_len[oi2] != pos) continue;
+          const u8* ob = A.out.hap_bases + oi2 * ML;
+          bool same = true;
+          for (u32 x = 0; x < pos && same; ++x) same = ob[x] == hb[x];
+          dup = same;
+        }
+      }
+      if (dup) continue;
+      if (!ok || !runs_ok) status |= MA_W_LEN_OVERFLOW;
+      A.out.hap_len[hi] = pos < static_cast<u32>(ML) ? pos : static_cast<u32>(ML);
+      A.out.hap_nruns[hi] = nruns < static_cast<u32>(MR) ? nruns : static_cast<u32>(MR);
+      // Path::Finalize (path.cpp:39-70)
+      OnlineStats st;
+      for (u32 x = 0; x < ncov; ++x) st.add(static_cast<f64>(covs[x]));
+      f64 const mean = st.m1, sdv = st.sd();
+      f64 const total = mean * static_cast<f64>(st.n);
+      f64 cv = 0.0, qcv = 0.0;
+      if (mean > 0.0) cv = sdv / mean;
+      isort_u32(covs, ncov);
+      f64 const med = static_cast<f64>(median_sorted(covs, ncov));
+      if (ncov >= 4) {
+        f64 const q1 = static_cast<f64>(covs[ncov / 4]), q3 = static_cast<f64>(covs[(ncov * 3) / 4]);
+        if (q3 + q1 > 0.0) qcv = (q3 - q1) / (q3 + q1);
+      }
+      f64* hs = A.out.hap_stats + hi * 6;
+      hs[0] = mean; hs[1] = med; hs[2] = sdv; hs[3] = cv; hs[4] = qcv; hs[5] = total;
+      max_alt_cv = has_alt ? (max_alt_cv > cv ? max_alt_cv : cv) : cv;
+      has_alt = true;
+      slot++;
+    }
+    A.out.comp_anchor[cidx] = cand_soff[ci];
+    A.out.comp_hap0[cidx] = hap0;
+    A.out.comp_nhaps[cidx] = slot - hap0;
+    A.out.comp_cx[cidx * 3 + 0] = cx_cc;
+    A.out.comp_cx[cidx * 3 + 1] = cx_bp;
+    A.out.comp_cx[cidx * 3 + 2] = cx_maxdeg;
+    A.out.comp_cxf[cidx * 4 + 0] = cx_unitig;
+    A.out.comp_cxf[cidx * 4 + 1] = cx_cv;
+    A.out.comp_cxf[cidx * 4 + 2] = cx_tip;
+    A.out.comp_cxf[cidx * 4 + 3] = has_alt ? max_alt_cv : -1.0;
+    ncomp_out++;
+  }
+
+  if (g.flags & 4u) {
+    A.out.win_status[w] = MA_W_TABLE_OVERFLOW | MA_W_NO_HAPLOTYPE;
+    A.out.win_ncomp[w] = 0;
+    atomicOr(&ws.win_flags[w], 1u);
+    return;
+  }
+  if (retry || ncomp_out == 0) {  // graph.cpp:230-234 / results.empty(): try the next k
+    A.out.win_ncomp[w] = 0;
+    A.out.win_status[w] = MA_W_NO_HAPLOTYPE;
+    return;
+  }
+  u32 nalt = 0;
+  for (u32 c = 0; c < ncomp_out; ++c) nalt += A.out.comp_nhaps[static_cast<size_t>(w) * MC + c] - 1;
+  if (nalt == 0) status |= MA_W_NO_HAPLOTYPE;  // variant_builder.cpp:231-240
+  A.out.win_ncomp[w] = ncomp_out;
+  A.out.win_status[w] = status;
+  atomicOr(&ws.win_flags[w], 1u);
+}
+
+int run_clean_pass(ma_ctx* ctx, const DBatch& b, const GraphWs& ws, const ma_asm_out_t& out) {
+  if (ws.n_active == 0) return MA_OK;
+  CleanArgs args{b, ws, out, ctx->prm};
+  ctx->tic("k_clean");
+  hipLaunchKernelGGL(k_clean, dim3(ws.n_active), dim3(64), 0, ctx->stream, args);
+  ctx->toc();
+  MA_HIP(ctx, hipGetLastError());
+  return MA_OK;
+}
+
+}  // namespace ma

@@ -1,0 +1,97 @@
+// Device workspace of the cbdg assembly stage (build.hip + clean.hip).
+//
+// HBM layout per active window slot `a` (windows of a chunk that attempt the current k):
+//   k-mer table   : tbl_key[a][TC] u64 (0 = empty), tbl_first[a][TC] u32 (first instance),
+//                   tbl_cnt[a][TC][S+2] u32 (per-sample + per-role read support)
+//   instances     : inst_slot[a][IS] u32 = slot | sign<<30 | errfree<<31, sequence-major
+//   mate-mer set  : mm_key[a][MC] u64, mm_min[a][MC] u32        (graph.h:102-117)
+//   compact graph : node arrays [a][NC] in canonical (first-insertion) order, see below
+//   BFS arena     : arena[a][AC] 16 B records                    (max_flow.h:51-63)
+#pragma once
+#include "ma_internal.h"
+
+namespace ma {
+
+constexpr int kEdgeCap = 16;       // edges per node (reference: InlinedVector<Edge, 8>, node.h:42)
+constexpr u32 kNoNode = 0xFFFFFFFFu;
+constexpr u32 kInstErrFree = 1u << 31;
+constexpr u32 kInstPlus = 1u << 30;
+constexpr u32 kInstSlotMask = (1u << 30) - 1;
+constexpr int kMaxSamples = 8;
+
+struct GraphWs {
+  // ---- per k attempt ----
+  int k;
+  u64 pk1;   // P^(k-1) mod 2^64
+  u64 pinv;  // P^-1   mod 2^64
+  int n_active;
+  const u32* active;      // [n_active] global window ids
+  // ---- per batch ----
+  u32* seq_inst_base;     // [n_reads + n_windows]: index read_win_off[w] + w is the ref of window w, reads follow
+  u32* win_ninst;         // [n_windows] total instances of window w at this k
+  u32* win_nread_inst;    // [n_windows] instances that come from reads
+  // table
+  int tc_log2, mc_log2;
+  u32 inst_stride;
+  u64* tbl_key;
+  u32* tbl_first;
+  u32* tbl_cnt;
+  u32* inst_slot;
+  u64* mm_key;
+  u32* mm_min;
+  // compact graph (per active slot, NC nodes)
+  u32 nc;                 // node capacity per window
+  u32* slot_node;         // [a][TC] slot -> node idx (kNoNode if pruned)   (aliases tbl_first after ranking)
+  u32* n_nodes;           // [a]
+  u32* nd_cnt;            // [a][NC][S]
+  u32* nd_role;           // [a][NC][2]
+  u32* nd_src;            // [a][NC] source of the canonical k-mer: bit31 = read buffer (else ref), low bits = byte
+                          //          offset relative to the window's first ref / read byte
+  u8* nd_label;           // [a][NC]
+  u8* nd_sign;            // [a][NC] 1 = PLUS
+  u8* nd_nedge;           // [a][NC]
+  u32* nd_edge;           // [a][NC][kEdgeCap]  dst << 2 | kind
+  u32* nd_ekey;           // [a][NC][kEdgeCap]  insertion-order key (build only)
+  u32* ref_node;          // [a][max_ref_kmers] node idx of each reference k-mer (kNoNode if pruned): mRefNodeIds
+  u32 ref_stride;
+  // clean-stage scratch
+  u32* nd_comp;           // [a][NC]
+  u32* nd_len;            // [a][NC]
+  u8* nd_alive;           // [a][NC]
+  u32* nd_head;           // [a][NC] slice list head / tail (original node ids)
+  u32* nd_tail;
+  u32* sl_next;           // [a][NC]
+  u32* sl_prev;
+  u32* sl_desc;           // [a][NC] start | len << 8 | rc << 16
+  u32* scratch;           // [a][4 * NC] queues / flat indices / sort buffers
+  u32 ac;                 // arena capacity (records)
+  uint4* arena;           // [a][AC]
+  u32* win_flags;         // [n_windows] bit0 done, bit1 retry-at-next-k requested
+  int num_samples;
+};
+
+__device__ __forceinline__ u8 dev_complement(u8 b) {  // base/rev_comp.h:15-31
+  switch (b) {
+    case 'A': return 'T';
+    case 'a': return 't';
+    case 'T': return 'A';
+    case 't': return 'a';
+    case 'C': return 'G';
+    case 'c': return 'g';
+    case 'G': return 'C';
+    case 'g': return 'c';
+    case 'n': return 'n';
+    default: return 'N';
+  }
+}
+
+__device__ __forceinline__ u64 dev_fmix64(u64 x) {
+  x ^= x >> 33;
+  x *= 0xff51afd7ed558ccdULL;
+  x ^= x >> 33;
+  x *= 0xc4ceb9fe1a85ec53ULL;
+  x ^= x >> 33;
+  return x;
+}
+
+}  // namespace ma

@@ -80,6 +80,12 @@ struct ma_ctx {
     }                                                                                  \
   } while (0)
 
+#define MA_TRY_RC(expr)            \
+  do {                             \
+    int _rc = (expr);              \
+    if (_rc != MA_OK) return _rc;  \
+  } while (0)
+
 namespace ma {
 
 // device-side views (all pointers are device pointers)

@@ -9,8 +9,4 @@ int launch_genotype(ma_ctx* ctx, const DBatch&, const ma_asm_out_t&, const ma_va
   ctx->err = "ma_genotype_batch: not implemented yet";
   return MA_ERR_ARG;
 }
-int launch_assemble(ma_ctx* ctx, const DBatch&, const ma_asm_out_t&, const u32*) {
-  ctx->err = "ma_assemble_batch: not implemented yet";
-  return MA_ERR_ARG;
-}
 }  // namespace ma

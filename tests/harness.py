@@ -101,3 +101,36 @@ def variants_of(p, var, w):
             alts.append(bytes(pool[int(var["alt_off"][ai]): int(var["alt_off"][ai]) + int(var["alt_len"][ai])]))
         res.append((int(var["var_pos"][vi]), ref, tuple(alts)))
     return res
+
+
+def compare_asm(p, got, want, n):
+    """Bit-exact comparison of the used part of two ma_asm_out_t buffers; returns list of mismatch strings."""
+    bad = []
+    for name in ("win_status", "win_k", "win_ncomp"):
+        if not np.array_equal(got[name], want[name]):
+            idx = np.nonzero(got[name] != want[name])[0][:5]
+            bad.append(f"{name} differs at windows {idx.tolist()}: got {got[name][idx].tolist()} want {want[name][idx].tolist()}")
+    if bad:
+        return bad
+    MC, MH, ML, MR = p.max_comps, p.max_haps, p.max_hap_len, p.max_runs
+    for w in range(n):
+        for c in range(int(want["win_ncomp"][w])):
+            ci = w * MC + c
+            for name, width in (("comp_anchor", 1), ("comp_hap0", 1), ("comp_nhaps", 1), ("comp_cx", 3), ("comp_cxf", 4)):
+                g, x = got[name][ci * width:(ci + 1) * width], want[name][ci * width:(ci + 1) * width]
+                if not np.array_equal(g.view(np.uint8), x.view(np.uint8)):
+                    bad.append(f"w{w} c{c} {name}: got {g.tolist()} want {x.tolist()}")
+            for h in range(int(want["comp_nhaps"][ci])):
+                hi = w * MH + int(want["comp_hap0"][ci]) + h
+                if got["hap_len"][hi] != want["hap_len"][hi] or got["hap_nruns"][hi] != want["hap_nruns"][hi]:
+                    bad.append(f"w{w} c{c} h{h} len/nruns: got {got['hap_len'][hi]},{got['hap_nruns'][hi]} want {want['hap_len'][hi]},{want['hap_nruns'][hi]}")
+                    continue
+                L, R = int(want["hap_len"][hi]), int(want["hap_nruns"][hi])
+                if not np.array_equal(got["hap_bases"][hi * ML: hi * ML + L], want["hap_bases"][hi * ML: hi * ML + L]):
+                    bad.append(f"w{w} c{c} h{h} bases differ")
+                if not np.array_equal(got["hap_runs"][hi * MR * 2: (hi * MR + R) * 2], want["hap_runs"][hi * MR * 2: (hi * MR + R) * 2]):
+                    bad.append(f"w{w} c{c} h{h} runs differ")
+                gs, xs = got["hap_stats"][hi * 6:(hi + 1) * 6], want["hap_stats"][hi * 6:(hi + 1) * 6]
+                if not np.array_equal(gs.view(np.uint64), xs.view(np.uint64)):
+                    bad.append(f"w{w} c{c} h{h} stats: got {gs.tolist()} want {xs.tolist()}")
+    return bad

@@ -52,3 +52,46 @@ def test_repeat_gate_parity_random(engine):
     got = engine.gate(arrs, n, nr)
     assert np.array_equal(got["max_approx"], want["max_approx"])
     assert np.array_equal(got["max_exact"], want["max_exact"])
+
+
+from harness import compare_asm  # noqa: E402
+
+
+def _asm_parity(params, arrs, n, nr):
+    from lancet2_amd.engine import Engine
+    eng = Engine(params)
+    try:
+        got = eng.assemble(arrs, n, nr)
+    finally:
+        eng.close()
+    want = OracleEngine(params).assemble(arrs, n, nr)
+    bad = compare_asm(params, got, want, n)
+    assert not bad, "\n".join(bad[:20])
+    return got, want
+
+
+@pytest.mark.parametrize("cfg,nwin", [("C1", 4), ("C2", 6), ("C3", 4)])
+def test_assemble_parity_fixed_k25(cfg, nwin):
+    arrs, n, nr = synth.make_config_batch(cfg, nwin)
+    got, want = _asm_parity(capi.default_params(min_k=25, max_k=25), arrs, n, nr)
+    assert (want["win_ncomp"] > 0).sum() >= nwin // 2  # the synthetic windows do assemble
+
+
+def test_assemble_parity_k_cascade():
+    arrs, n, nr = synth.make_config_batch("C2", 6, first_index=40)
+    _asm_parity(capi.default_params(), arrs, n, nr)
+
+
+def test_assemble_parity_three_samples():
+    arrs, n, nr = synth.make_config_batch("C5", 4, first_index=80)
+    _asm_parity(capi.default_params(min_k=25, max_k=25, num_samples=3), arrs, n, nr)
+
+
+def test_assemble_parity_str_and_edge_cases():
+    wins = [synth.make_window(200 + i, W=1001, depths=(30, 30), str_unit=u) for i, u in enumerate([b"CA", b"AAG", b"T"])]
+    wins.append(synth.make_window(210, W=1001, depths=(0, 0)))               # no reads at all
+    wins.append(synth.make_window(211, W=1001, depths=(3, 3)))               # below anchor coverage
+    wins.append(dict(ref=np.frombuffer(b"N" * 400, dtype=np.uint8).copy(), reads=[]))
+    wins.append(synth.make_window(212, W=300, depths=(30, 30)))              # short window
+    arrs, n, nr = synth.pack_batch(wins)
+    _asm_parity(capi.default_params(), arrs, n, nr)
