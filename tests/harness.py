@@ -134,3 +134,28 @@ def compare_asm(p, got, want, n):
                 if not np.array_equal(gs.view(np.uint64), xs.view(np.uint64)):
                     bad.append(f"w{w} c{c} h{h} stats: got {gs.tolist()} want {xs.tolist()}")
     return bad
+
+
+def compare_vars(p, got, want, n):
+    bad = []
+    if not np.array_equal(got["win_nvars"], want["win_nvars"]):
+        return [f"win_nvars got {got['win_nvars'].tolist()} want {want['win_nvars'].tolist()}"]
+    MH, MV, MA, MP = p.max_haps, p.max_vars, p.max_alts, p.max_allele_bytes
+    for w in range(n):
+        nv = int(want["win_nvars"][w])
+        for name, width in (("var_comp", 1), ("var_pos", 1), ("var_ref_start", 1), ("var_ref_off", 1), ("var_ref_len", 1),
+                            ("var_nalts", 1), ("var_hap_allele", MH), ("var_hap_start", MH)):
+            g = got[name][w * MV * width:(w * MV + nv) * width]
+            x = want[name][w * MV * width:(w * MV + nv) * width]
+            if not np.array_equal(g, x):
+                bad.append(f"w{w} {name}: got {g.tolist()} want {x.tolist()}")
+        for v in range(nv):
+            vi = w * MV + v
+            na = int(want["var_nalts"][vi])
+            for name in ("alt_off", "alt_len", "alt_type", "alt_length"):
+                g, x = got[name][vi * MA: vi * MA + na], want[name][vi * MA: vi * MA + na]
+                if not np.array_equal(g, x):
+                    bad.append(f"w{w} v{v} {name}: got {g.tolist()} want {x.tolist()}")
+        if variants_of(p, got, w) != variants_of(p, want, w):
+            bad.append(f"w{w} alleles: got {variants_of(p, got, w)} want {variants_of(p, want, w)}")
+    return bad

@@ -95,3 +95,26 @@ def test_assemble_parity_str_and_edge_cases():
     wins.append(synth.make_window(212, W=300, depths=(30, 30)))              # short window
     arrs, n, nr = synth.pack_batch(wins)
     _asm_parity(capi.default_params(), arrs, n, nr)
+
+
+from harness import compare_vars  # noqa: E402
+
+
+@pytest.mark.parametrize("cfg,nwin,kw", [("C2", 8, {}), ("C3", 4, {}), ("C4", 1, dict(depths=(60, 60))),
+                                          ("C5", 3, dict(num_samples=3))])
+def test_msa_parity(cfg, nwin, kw):
+    from lancet2_amd.engine import Engine
+    ns = kw.pop("num_samples", 2)
+    params = capi.default_params(min_k=25, max_k=25, num_samples=ns)
+    arrs, n, nr = synth.make_config_batch(cfg, nwin, first_index=300, **kw)
+    orc = OracleEngine(params)
+    asm = orc.assemble(arrs, n, nr)
+    want = orc.msa(arrs, n, nr, asm)
+    eng = Engine(params)
+    try:
+        got = eng.msa(arrs, n, nr, asm)
+    finally:
+        eng.close()
+    bad = compare_vars(params, got, want, n)
+    assert not bad, "\n".join(bad[:20])
+    assert want["win_nvars"].sum() > 0
