@@ -1,0 +1,878 @@
+// Read <-> haplotype genotyping on gfx950: batched banded affine-gap alignment with in-kernel
+// traceback, the CIGAR-walk allele-scoring epilogue, evidence de-duplication and site QUAL.
+//
+// Replaces caller::Genotyper::Genotype (caller/genotyper.cpp:224-235): AlignToAllHaplotypes
+// (:376-411, minimap2 2.30 in the reference -- restated as the canonical seed-vote + banded overlap
+// DP of DESIGN.md, parity unpinned), AssignReadToAlleles (:269-362), ScoreReadAtVariant /
+// ComputeLocalScore / ComputeSoftClipPenalty / ComputeEditDistance (caller/combined_scorer.cpp:24-108,
+// caller/local_scorer.cpp:166-305, hts/cigar_utils.h:48-139), AddToTable + VariantSupport::AddEvidence
+// (genotyper.cpp:423-456, caller/variant_support.cpp:24-30) and SomaticLogOddsRatio
+// (caller/variant_call.cpp:316-345).
+//
+// Kernels (HBM traffic per read x haplotype pair: 2 reads of ~150 B + one haplotype segment in, a
+// 4-bit/cell traceback tile out and partially back in, 24 + 4*n_cigar bytes of result):
+//   k_plan       per window: which haplotype slots get aligned, pair counts
+//   k_hap_index  per haplotype slot: 11-mer chained hash index (head/next) in HBM
+//   k_vote       one wave per pair: every shared 11-mer votes for its diagonal in an LDS histogram;
+//                wave arg-max = band centre
+//   k_align      one LANE per pair (inter-task SIMD: all lanes run the same row/band loop, no
+//                cross-lane traffic); (H,F) band rows packed i16x2 in LDS laid out [band][lane]
+//                (conflict-free), haplotype segment packed 4 bit/base in LDS, traceback nibbles
+//                written to HBM coalesced as [row][word][lane]; per-lane traceback -> CIGAR
+//   k_assign     one lane per read: best allele per variant over the haplotypes of each component
+//   k_evidence   first read per (variant, sample, allele, qname) counts, by strand
+//   k_qual       SOLOR site quality
+#include <algorithm>
+#include <cstdlib>
+#include <vector>
+
+#include "ma_internal.h"
+
+namespace ma {
+
+namespace {
+
+constexpr int SK = 11;                 // seed length (minimap2 -k 11 in the reference)
+constexpr int kIdxCap = 4096;          // hash buckets per haplotype index (>= 2 * max_hap_len rounded)
+constexpr i32 GO = 12, GE = 3;         // scoring_constants.h:17-20
+constexpr i32 NEGS = -16000;           // "minus infinity" that survives i16 packing
+__constant__ u64 c_phred_bits_a[256] = {
+#include "../../include/ma_phred_lut.inc"
+};
+
+__constant__ i8 c_score_matrix[25] = {1, -4, -4, -4, 0, -4, 1, -4, -4, 0, -4, -4, 1, -4, 0,
+                                      -4, -4, -4, 1, 0, 0, 0, 0, 0, 0};  // scoring_constants.h:35-41
+
+__device__ __forceinline__ u32 enc_base(u8 c) {  // scoring_constants.h:48-74
+  switch (c) {
+    case 'A': case 'a': return 0;
+    case 'C': case 'c': return 1;
+    case 'G': case 'g': return 2;
+    case 'T': case 't': return 3;
+    default: return 4;
+  }
+}
+
+struct AlnWs {
+  // planning
+  u32* win_slotmask;   // [n] bitmask of haplotype slots to align
+  u64* pair_off;       // [n + 1]
+  u32* counters;       // [8]: 0 max read len
+  // haplotype seed index, per (window, slot)
+  u32 idx_cap;
+  u16* idx_head;       // [n * MH][idx_cap]  (0xFFFF = empty)
+  u16* idx_next;       // [n * MH][max_hap_len]
+  u32* idx_code;       // [n * MH][max_hap_len] (0xFFFFFFFF = no valid 11-mer)
+  // per pair
+  i32* centre;         // [pairs in chunk]
+  u32* tb;             // traceback nibbles
+  u32 tb_words;        // words per row
+  u32 tb_rows;         // rows per pair (max read len + 1)
+  // evidence table per window
+  u32 ev_cap;
+  u64* ev_key;         // [n][ev_cap]
+  u32* ev_min;         // [n][ev_cap]
+  u8* asg_allele;      // [n_reads * MV] (internal copy when the caller passes NULL)
+  i32 band;
+};
+
+struct GArgs {
+  DBatch b;
+  ma_asm_out_t a;
+  ma_var_out_t v;
+  ma_geno_out_t o;
+  AlnWs ws;
+  ma_params_t prm;
+  u64 pair0;     // first global pair index of this chunk
+  u32 npairs;    // pairs in this chunk
+};
+
+__global__ void k_max_reads(DBatch b, u32* out) {
+  int const w = blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= b.n_windows) return;
+  atomicMax(out, b.read_win_off[w + 1] - b.read_win_off[w]);
+}
+
+// ---- planning ----
+__global__ void k_plan(GArgs A) {
+  int const w = blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= A.b.n_windows) return;
+  ma_params_t const& P = A.prm;
+  u32 mask = 0;
+  u32 const nv = A.v.win_nvars[w];
+  if (nv > 0 && !(A.a.win_status[w] & MA_W_NO_HAPLOTYPE)) {
+    for (u32 c = 0; c < A.a.win_ncomp[w]; ++c) {
+      bool has = false;
+      for (u32 x = 0; x < nv && !has; ++x) has = A.v.var_comp[static_cast<size_t>(w) * P.max_vars + x] == c;
+      if (!has) continue;  // variant_builder.cpp:248: components without variants are not genotyped
+      size_t const ci = static_cast<size_t>(w) * P.max_comps + c;
+      for (u32 h = 0; h < A.a.comp_nhaps[ci]; ++h) mask |= 1u << (A.a.comp_hap0[ci] + h);
+    }
+  }
+  A.ws.win_slotmask[w] = mask;
+  u32 const nr = A.b.read_win_off[w + 1] - A.b.read_win_off[w];
+  A.ws.pair_off[w] = static_cast<u64>(nr) * __popc(mask);  // counts; scanned below
+  u32 ml = 0;
+  for (u32 r = A.b.read_win_off[w]; r < A.b.read_win_off[w + 1]; ++r)
+    ml = max(ml, static_cast<u32>(A.b.read_off[r + 1] - A.b.read_off[r]));
+  atomicMax(&A.ws.counters[0], ml);
+  atomicMax(&A.ws.counters[1], nr);
+}
+
+__global__ void k_scan_pairs(u64* pair_off, int n) {  // single block exclusive scan (n <= few 100k)
+  __shared__ u64 carry;
+  __shared__ u64 sh[1024];
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (int base = 0; base < n; base += 1024) {
+    int const i = base + threadIdx.x;
+    u64 const v = i < n ? pair_off[i] : 0;
+    sh[threadIdx.x] = v;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+      u64 const x = threadIdx.x >= static_cast<u32>(d) ? sh[threadIdx.x - d] : 0;
+      __syncthreads();
+      sh[threadIdx.x] += x;
+      __syncthreads();
+    }
+    u64 const incl = sh[threadIdx.x];
+    if (i < n) pair_off[i] = carry + incl - v;
+    __syncthreads();
+    if (threadIdx.x == 1023) carry += incl;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) pair_off[n] = carry;
+}
+
+// pair p -> (window, read, slot)
+struct PairId { int w; u32 r; u32 slot; };
+__device__ PairId pair_decode(GArgs const& A, u64 p) {
+  int lo = 0, hi = A.b.n_windows;  // largest w with pair_off[w] <= p
+  while (hi - lo > 1) {
+    int const mid = (lo + hi) / 2;
+    if (A.ws.pair_off[mid] <= p) lo = mid; else hi = mid;
+  }
+  PairId id;
+  id.w = lo;
+  u64 const local = p - A.ws.pair_off[lo];
+  u32 const nr = A.b.read_win_off[lo + 1] - A.b.read_win_off[lo];
+  u32 const si = static_cast<u32>(local / nr);
+  id.r = A.b.read_win_off[lo] + static_cast<u32>(local % nr);
+  u32 mask = A.ws.win_slotmask[lo];
+  for (u32 x = 0; x < si; ++x) mask &= mask - 1;
+  id.slot = __ffs(mask) - 1;
+  return id;
+}
+
+// ---- haplotype 11-mer index ----
+__global__ __launch_bounds__(256) void k_hap_index(GArgs A) {
+  int const w = blockIdx.x / A.prm.max_haps, slot = blockIdx.x % A.prm.max_haps;
+  if (!(A.ws.win_slotmask[w] & (1u << slot))) return;
+  size_t const hi = static_cast<size_t>(w) * A.prm.max_haps + slot;
+  u32 const n = A.a.hap_len[hi];
+  const u8* hb = A.a.hap_bases + hi * A.prm.max_hap_len;
+  u16* head = A.ws.idx_head + hi * A.ws.idx_cap;
+  u16* next = A.ws.idx_next + hi * A.prm.max_hap_len;
+  u32* code = A.ws.idx_code + hi * A.prm.max_hap_len;
+  for (u32 x = threadIdx.x; x < A.ws.idx_cap; x += 256) head[x] = 0xFFFFu;
+  __syncthreads();
+  for (u32 j = threadIdx.x; j + SK <= n; j += 256) {
+    u32 cd = 0;
+    bool ok = true;
+    for (int x = 0; x < SK; ++x) {
+      u32 const e = enc_base(hb[j + x]);
+      ok &= e < 4;
+      cd = (cd << 2) | (e & 3u);
+    }
+    code[j] = ok ? cd : 0xFFFFFFFFu;
+    if (!ok) continue;
+    u32 const bkt = (cd * 2654435761u) >> (32 - 12);  // idx_cap == 4096
+    // push-front into the bucket chain (order irrelevant: votes commute).  16-bit CAS via 32-bit word.
+    u32* word = reinterpret_cast<u32*>(head) + (bkt >> 1);
+    u32 const shift = (bkt & 1u) * 16u;
+    u32 old = *word;
+    while (true) {
+      u32 const prev16 = (old >> shift) & 0xFFFFu;
+      next[j] = static_cast<u16>(prev16);
+      u32 const nw = (old & ~(0xFFFFu << shift)) | (static_cast<u32>(j) << shift);
+      u32 const seen = atomicCAS(word, old, nw);
+      if (seen == old) break;
+      old = seen;
+    }
+  }
+}
+
+// ---- seed vote: one wave per pair ----
+__global__ __launch_bounds__(256) void k_vote(GArgs A, u32 hist_len) {
+  extern __shared__ u16 lds_hist[];  // [4 waves][hist_len]
+  int const wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  u64 const lp = static_cast<u64>(blockIdx.x) * 4 + wave;
+  if (lp >= A.npairs) return;
+  PairId const id = pair_decode(A, A.pair0 + lp);
+  size_t const hi = static_cast<size_t>(id.w) * A.prm.max_haps + id.slot;
+  i32 const n = static_cast<i32>(A.a.hap_len[hi]);
+  u64 const ro = A.b.read_off[id.r];
+  i32 const m = static_cast<i32>(A.b.read_off[id.r + 1] - ro);
+  const u8* rb = A.b.read_bases + ro;
+  u16* hist = lds_hist + static_cast<size_t>(wave) * hist_len;
+  i32 const nd = m + n + 1;  // diagonals d in [-m, n] -> hist[d + m]
+  for (i32 x = lane; x < nd; x += 64) hist[x] = 0;
+  __builtin_amdgcn_wave_barrier();
+  if (m >= SK && n >= SK) {
+    const u16* head = A.ws.idx_head + hi * A.ws.idx_cap;
+    const u16* next = A.ws.idx_next + hi * A.prm.max_hap_len;
+    const u32* code = A.ws.idx_code + hi * A.prm.max_hap_len;
+    for (i32 i = lane; i + SK <= m; i += 64) {
+      u32 cd = 0;
+      bool ok = true;
+      for (int x = 0; x < SK; ++x) {
+        u32 const e = enc_base(rb[i + x]);
+        ok &= e < 4;
+        cd = (cd << 2) | (e & 3u);
+      }
+      if (!ok) continue;
+      u32 const bkt = (cd * 2654435761u) >> (32 - 12);
+      for (u32 j = head[bkt]; j != 0xFFFFu; j = next[j]) {
+        if (code[j] != cd) continue;
+        i32 const d = static_cast<i32>(j) - i + m;
+        // 16-bit LDS counter: atomic add on the containing 32-bit word
+        atomicAdd(reinterpret_cast<u32*>(hist) + (d >> 1), 1u << ((d & 1) * 16));
+      }
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  // arg-max, ties -> smallest diagonal
+  u32 best = 0;
+  i32 bd = 0x7FFFFFFF;
+  for (i32 x = lane; x < nd; x += 64) {
+    u32 const v = hist[x];
+    if (v > best || (v == best && v > 0 && x < bd)) {
+      best = v;
+      bd = x;
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    u32 const ob = __shfl_down(best, off);
+    i32 const od = __shfl_down(bd, off);
+    if (ob > best || (ob == best && ob > 0 && od < bd)) {
+      best = ob;
+      bd = od;
+    }
+  }
+  if (lane == 0) A.ws.centre[lp] = best == 0 ? 0x7FFFFFFF : (bd - m);
+}
+
+// ---- banded overlap DP + traceback: one lane per pair ----
+__global__ __launch_bounds__(64) void k_align(GArgs A, u32 seg_words) {
+  extern __shared__ u32 lds[];
+  int const lane = threadIdx.x;
+  i32 const B = A.ws.band, WD = 2 * B + 1;
+  u32* HF = lds;                                 // [WD + 1][64] packed (H lo16, F hi16)
+  u32* SEG = lds + static_cast<size_t>(WD + 1) * 64;  // [seg_words][64] haplotype segment, 4 bit/base
+  u64 const lp = static_cast<u64>(blockIdx.x) * 64 + lane;
+  bool const live = lp < A.npairs;
+  PairId id{0, 0, 0};
+  i32 m = 0, n = 0, c = 0;
+  const u8* rb = nullptr;
+  const u8* hb = nullptr;
+  bool active = false;
+  if (live) {
+    id = pair_decode(A, A.pair0 + lp);
+    size_t const hi = static_cast<size_t>(id.w) * A.prm.max_haps + id.slot;
+    n = static_cast<i32>(A.a.hap_len[hi]);
+    hb = A.a.hap_bases + hi * A.prm.max_hap_len;
+    u64 const ro = A.b.read_off[id.r];
+    m = static_cast<i32>(A.b.read_off[id.r + 1] - ro);
+    rb = A.b.read_bases + ro;
+    c = A.ws.centre[lp];
+    active = c != 0x7FFFFFFF && m >= SK && n >= SK && static_cast<u32>(m) + 1 <= A.ws.tb_rows;
+  }
+  i32 const mrows = active ? m : 0;
+  // wave-uniform row count
+  i32 mmax = mrows;
+  for (int off = 32; off > 0; off >>= 1) mmax = max(mmax, __shfl_xor(mmax, off));
+
+  // haplotype segment: bases hap[j0 .. j0 + seglen) with j0 = c - B (0-based base index j-1 for cell j)
+  // cell (i, t) uses hap base index (j - 1) = i + c - B + t - 1  ->  rel = (i - 1) + t  in [0, m + 2B)
+  i32 const j0 = c - B;  // hap base index of rel 0
+  if (active) {
+    i32 const seglen = m + 2 * B + 1;
+    for (i32 wd = 0; wd * 8 < seglen; ++wd) {
+      u32 pk = 0;
+      for (int x = 0; x < 8; ++x) {
+        i32 const hbidx = j0 + wd * 8 + x;
+        u32 const e = (hbidx >= 0 && hbidx < n) ? enc_base(hb[hbidx]) : 4u;
+        pk |= e << (4 * x);
+      }
+      SEG[static_cast<size_t>(wd) * 64 + lane] = pk;
+    }
+    // row 0: H = 0 for 0 <= j <= n, else NEG; F = NEG
+    for (i32 t = 0; t <= WD; ++t) {
+      i32 const j = c - B + t;
+      i32 const h = (t < WD && j >= 0 && j <= n) ? 0 : NEGS;
+      HF[static_cast<size_t>(t) * 64 + lane] = (static_cast<u32>(h) & 0xFFFFu) | (static_cast<u32>(NEGS) << 16);
+    }
+  }
+  size_t const tb_base = static_cast<size_t>(blockIdx.x) * A.ws.tb_rows * A.ws.tb_words * 64;
+  u32* tb = A.ws.tb + tb_base;
+  i32 best = NEGS, bi = -1, bj = -1;
+  if (active) {  // end cells on row 0: (0, n) -- only if m == 0 (never); nothing to do
+  }
+  for (i32 i = 1; i <= mmax; ++i) {
+    if (i <= mrows) {
+      u32 const qi = enc_base(rb[i - 1]);
+      i32 lh = NEGS, le = NEGS;  // H, E of the cell to the left (out of band at t == 0)
+      u32 word = 0;
+      i32 rel = i - 1;
+      u32 segw = SEG[static_cast<size_t>(rel >> 3) * 64 + lane];
+      u32 nxt = HF[lane];  // HF[t] of the previous row, pre-loaded
+      for (i32 t = 0; t < WD; ++t, ++rel) {
+        if ((rel & 7) == 0 && t > 0) segw = SEG[static_cast<size_t>(rel >> 3) * 64 + lane];
+        u32 const cur = nxt;
+        nxt = HF[static_cast<size_t>(t + 1) * 64 + lane];
+        i32 const dh = static_cast<i16>(cur & 0xFFFFu);
+        i32 const uh = static_cast<i16>(nxt & 0xFFFFu), uf = static_cast<i16>(nxt >> 16);
+        i32 const j = i + c - B + t;
+        u32 const tbse = (segw >> (4 * (rel & 7))) & 0xFu;
+        i32 const s = (qi > 3 || tbse > 3) ? -1 : (qi == tbse ? 1 : -4);
+        i32 const eo = lh - (GO + GE), ee = le - GE;
+        i32 const fo = uh - (GO + GE), fe = uf - GE;
+        i32 e = max(eo, ee), f = max(fo, fe);
+        i32 const dg = dh + s;
+        i32 h = max(dg, max(e, f));
+        u32 nib = (dg >= e && dg >= f) ? 0u : (e >= f ? 1u : 2u);
+        nib |= (eo >= ee ? 4u : 0u) | (fo >= fe ? 8u : 0u);
+        if (j <= 0 || j > n) {
+          h = (j == 0) ? 0 : NEGS;
+          e = NEGS;
+          f = NEGS;
+        }
+        // keep "minus infinity" from drifting out of i16 range
+        h = max(h, 2 * NEGS + 1000);
+        f = max(f, 2 * NEGS + 1000);
+        e = max(e, 2 * NEGS + 1000);
+        HF[static_cast<size_t>(t) * 64 + lane] = (static_cast<u32>(h) & 0xFFFFu) | (static_cast<u32>(f) << 16);
+        lh = h;
+        le = e;
+        word |= nib << (4 * (t & 7));
+        if ((t & 7) == 7 || t == WD - 1) {
+          tb[(static_cast<size_t>(i) * A.ws.tb_words + (t >> 3)) * 64 + lane] = word;
+          word = 0;
+        }
+        // end cells: (m, j) for any j, (i, n) for i < m
+        if (j >= 0 && j <= n && (i == mrows || j == n)) {
+          if (h > best || (h == best && (i > bi || (i == bi && j < bj)))) {
+            best = h;
+            bi = i;
+            bj = j;
+          }
+        }
+      }
+    }
+  }
+  if (!live) return;
+  // ---- result record ----
+  int const MH = A.prm.max_haps, MCG = A.prm.max_cigar;
+  size_t const rec = (static_cast<size_t>(id.r) * MH + id.slot);
+  i32* arec = A.o.aln_rec + rec * 6;
+  u32* acig = A.o.aln_cigar + rec * (1 + MCG);
+  bool const hit = active && bi >= 0 && best >= A.prm.min_aln_score;
+  if (!hit) {
+    for (int x = 0; x < 6; ++x) arec[x] = 0;
+    acig[0] = 0;
+    return;
+  }
+  // traceback (rules of oracle/align.cpp: diagonal, then E, then F; prefer opening a gap)
+  u32 ops[64];   // reversed run-length ops, len << 4 | op
+  int nops = 0;
+  u32 total_ops = 0;
+  auto push = [&](u32 op) {
+    if (nops > 0 && (ops[nops - 1] & 0xFu) == op && nops <= 64) {
+      ops[nops - 1] += 16u;
+    } else {
+      total_ops++;
+      if (nops < 64) ops[nops++] = (1u << 4) | op; else nops = 65;  // overflow marker
+    }
+  };
+  i32 i = bi, j = bj;
+  int state = 0;
+  while (true) {
+    if (state == 0 && (i == 0 || j == 0)) break;
+    i32 const t = j - i - c + B;
+    u32 const wv = tb[(static_cast<size_t>(i) * A.ws.tb_words + (t >> 3)) * 64 + lane];
+    u32 const nib = (wv >> (4 * (t & 7))) & 0xFu;
+    if (state == 0) {
+      u32 const src = nib & 3u;
+      if (src == 0) {
+        push(0);
+        --i;
+        --j;
+      } else {
+        state = src == 1 ? 1 : 2;
+      }
+    } else if (state == 1) {
+      push(2);  // D
+      --j;
+      if (nib & 4u) state = 0;
+    } else {
+      push(1);  // I
+      --i;
+      if (nib & 8u) state = 0;
+    }
+  }
+  i32 const qs = i, rs = j, qe = bi, re = bj;
+  arec[0] = 1;
+  arec[1] = best;
+  arec[2] = rs;
+  arec[3] = re;
+  arec[4] = qs;
+  arec[5] = qe;
+  // BuildCigar (genotyper.cpp:45-69): S(qs) + core + S(qlen - qe); ops were collected reversed
+  u32 ncig = 0, widx = 0;
+  auto emit = [&](u32 v) {
+    if (static_cast<int>(widx) < MCG) acig[1 + widx] = v;
+    widx++;
+    ncig++;
+  };
+  if (qs > 0) emit((static_cast<u32>(qs) << 4) | 4u);
+  int const kept = nops > 64 ? 64 : nops;
+  for (int x = kept - 1; x >= 0; --x) emit(ops[x]);
+  if (qe < m) emit((static_cast<u32>(m - qe) << 4) | 4u);
+  acig[0] = (nops > 64) ? (total_ops + (qs > 0) + (qe < m)) : ncig;
+}
+
+// ---- scoring epilogue ----
+struct Cig {
+  const u32* c;
+  u32 n;
+};
+__device__ __forceinline__ u32 cop(u32 v) { return v & 0xFu; }   // 0 M, 1 I, 2 D, 4 S
+__device__ __forceinline__ u32 clen(u32 v) { return v >> 4; }
+
+// hts::ComputeEditDistance (hts/cigar_utils.h:61-111) on encoded query/target
+__device__ u32 edit_distance(Cig cg, const u8* rb, u32 qn, const u8* hb, u32 tn) {
+  u32 ed = 0, qp = 0, tp = 0;
+  for (u32 x = 0; x < cg.n; ++x) {
+    u32 const op = cop(cg.c[x]), len = clen(cg.c[x]);
+    if (op == 0) {
+      for (u32 y = 0; y < len; ++y, ++qp, ++tp)
+        if (qp < qn && tp < tn && enc_base(rb[qp]) != enc_base(hb[tp])) ++ed;
+    } else if (op == 1) {
+      ed += len;
+      qp += len;
+    } else if (op == 2) {
+      ed += len;
+      tp += len;
+    } else if (op == 4) {
+      qp += len;
+    }
+  }
+  return ed;
+}
+// hts::CigarRefPosToQueryPos (hts/cigar_utils.h:113-139)
+__device__ u32 refpos_to_qpos(Cig cg, u32 ref_pos) {
+  u32 qp = 0, tp = 0;
+  for (u32 x = 0; x < cg.n; ++x) {
+    u32 const op = cop(cg.c[x]), len = clen(cg.c[x]);
+    if (op == 0) {
+      for (u32 y = 0; y < len; ++y, ++qp, ++tp)
+        if (tp == ref_pos) return qp;
+    } else if (op == 1 || op == 4) {
+      qp += len;
+    } else if (op == 2) {
+      for (u32 y = 0; y < len; ++y, ++tp)
+        if (tp == ref_pos) return qp;
+    }
+  }
+  return qp;
+}
+
+struct Scored {
+  f64 local_score, local_identity;
+  i32 global_score;
+  u32 allele;
+  __device__ f64 combined() const { return static_cast<f64>(global_score) + local_score * local_identity; }
+};
+
+// ScoreReadAtVariant (combined_scorer.cpp:60-108) restricted to the fields that decide the allele
+__device__ Scored score_at_variant(Cig cg, i32 score, i32 rs, i32 re, const u8* rb, const u8* rq, u32 rlen,
+                                   const u8* hap, i32 vstart, i32 vlen) {
+  const f64* phred = reinterpret_cast<const f64*>(c_phred_bits_a);
+  const i8* kMatrix = c_score_matrix;
+  const u8* target = hap + rs;
+  u32 const tlen = static_cast<u32>(re - rs);
+  f64 pbq = 0.0, raw = 0.0;
+  u32 matches = 0, aligned = 0;
+  if (cg.n > 0 && vlen != 0) {  // ComputeLocalScore (local_scorer.cpp:166-279)
+    i32 const vend = vstart + vlen;
+    i32 tpos = 0;
+    u32 qpos = 0;
+    for (u32 x = 0; x < cg.n; ++x) {
+      u32 const op = cop(cg.c[x]), len = clen(cg.c[x]);
+      bool const cons_ref = op == 0 || op == 2;
+      if (rs + tpos >= vend && cons_ref) break;
+      if (op == 0) {
+        for (u32 y = 0; y < len; ++y, ++tpos, ++qpos) {
+          i32 const ap = rs + tpos;
+          if (!(ap >= vstart && ap < vend)) continue;
+          ++aligned;
+          if (!(qpos >= rlen || static_cast<u32>(tpos) >= tlen)) {
+            u32 const qe = enc_base(rb[qpos]), te = enc_base(target[tpos]);
+            i8 const r = kMatrix[te * 5 + qe];
+            raw += static_cast<f64>(r);
+            f64 const wgt = qpos < rlen ? 1.0 - phred[rq[qpos]] : 1.0;
+            pbq += static_cast<f64>(r) * wgt;
+            matches += (qe == te);
+          }
+        }
+      } else if (op == 1) {
+        i32 const ap = rs + tpos;
+        bool const inr = ap >= vstart && ap < vend;
+        for (u32 y = 0; y < len; ++y, ++qpos) {
+          if (!inr) continue;
+          ++aligned;
+          pbq += 3.0;
+        }
+      } else if (op == 2) {
+        for (u32 y = 0; y < len; ++y, ++tpos) {
+          i32 const ap = rs + tpos;
+          if (ap >= vstart && ap < vend) {
+            ++aligned;
+            pbq += 3.0;
+          }
+        }
+      } else if (op == 4) {
+        qpos += len;
+      }
+    }
+  }
+  f64 const identity = aligned > 0 ? static_cast<f64>(matches) / static_cast<f64>(aligned) : 0.0;
+  // ComputeSoftClipPenalty (local_scorer.cpp:290-305)
+  i32 s5 = 0, s3 = 0;
+  if (cg.n > 0) {
+    if (cop(cg.c[0]) == 4) s5 = static_cast<i32>(clen(cg.c[0]));
+    if (cg.n > 1 && cop(cg.c[cg.n - 1]) == 4) s3 = static_cast<i32>(clen(cg.c[cg.n - 1]));
+  }
+  f64 const sc_pen = static_cast<f64>(s5 + s3) * 4;
+  f64 const global_adj = static_cast<f64>(score) - sc_pen;
+  Scored s;
+  s.global_score = static_cast<i32>(global_adj - raw);
+  s.local_score = pbq;
+  s.local_identity = identity;
+  s.allele = 0;
+  return s;
+}
+
+__device__ __forceinline__ u64 ev_key_of(u32 var, u32 sample, u32 allele, u32 qname) {
+  return ((static_cast<u64>(var) << 44) | (static_cast<u64>(sample) << 40) | (static_cast<u64>(allele) << 33) |
+          (static_cast<u64>(qname) << 1)) + 1ull;
+}
+
+// AssignReadToAlleles (genotyper.cpp:269-321): one lane per read
+__global__ __launch_bounds__(64) void k_assign(GArgs A) {
+  i64 const r = static_cast<i64>(blockIdx.x) * 64 + threadIdx.x;
+  if (r >= A.b.n_reads) return;
+  ma_params_t const& P = A.prm;
+  int const MH = P.max_haps, MV = P.max_vars, MA = P.max_alts, MCG = P.max_cigar, S = P.num_samples;
+  // window of this read
+  int lo = 0, hi = A.b.n_windows;
+  while (hi - lo > 1) {
+    int const mid = (lo + hi) / 2;
+    if (A.b.read_win_off[mid] <= r) lo = mid; else hi = mid;
+  }
+  int const w = lo;
+  u8* asg = A.ws.asg_allele + static_cast<size_t>(r) * MV;
+  for (int v = 0; v < MV; ++v) asg[v] = 255;
+  if (A.o.asg_allele)
+    for (int v = 0; v < MV; ++v) A.o.asg_allele[static_cast<size_t>(r) * MV + v] = 255;
+  if (A.o.asg_score)
+    for (int v = 0; v < MV; ++v) A.o.asg_score[static_cast<size_t>(r) * MV + v] = 0.0;
+  u32 const nv = A.v.win_nvars[w];
+  u32 const mask = A.ws.win_slotmask[w];
+  if (nv == 0 || mask == 0) return;
+  u64 const ro = A.b.read_off[r];
+  u32 const rlen = static_cast<u32>(A.b.read_off[r + 1] - ro);
+  const u8* rb = A.b.read_bases + ro;
+  const u8* rq = A.b.read_quals + ro;
+  u32 sample = A.b.read_sample[r];
+  u32 const qn = A.b.read_qname_id[r];
+  u64* evk = A.ws.ev_key + static_cast<size_t>(w) * A.ws.ev_cap;
+  u32* evm = A.ws.ev_min + static_cast<size_t>(w) * A.ws.ev_cap;
+  u32 const evmask = A.ws.ev_cap - 1;
+
+  for (u32 c = 0; c < A.a.win_ncomp[w]; ++c) {
+    size_t const ci = static_cast<size_t>(w) * P.max_comps + c;
+    u32 const hap0 = A.a.comp_hap0[ci], nh = A.a.comp_nhaps[ci];
+    if (!(mask & (1u << hap0))) continue;
+    for (u32 v = 0; v < nv; ++v) {
+      size_t const vi = static_cast<size_t>(w) * MV + v;
+      if (A.v.var_comp[vi] != c) continue;
+      bool have_best = false;
+      Scored bestsc{};
+      for (u32 h = 0; h < nh; ++h) {  // alignments in haplotype order (all_alns)
+        size_t const rec = static_cast<size_t>(r) * MH + hap0 + h;
+        const i32* ar = A.o.aln_rec + rec * 6;
+        if (!ar[0]) continue;
+        const u32* cgp = A.o.aln_cigar + rec * (1 + MCG);
+        Cig cg{cgp + 1, min(cgp[0], static_cast<u32>(MCG))};
+        // ExtractHapBounds (genotyper.cpp:329-352)
+        i32 vstart, vlen;
+        u32 allele;
+        if (h == 0) {
+          vstart = static_cast<i32>(A.v.var_ref_start[vi]);
+          vlen = static_cast<i32>(A.v.var_ref_len[vi]);
+          allele = 0;
+        } else {
+          u32 const al = A.v.var_hap_allele[vi * MH + h];
+          if (al == 0) continue;  // this haplotype carries the REF allele here: no bounds
+          vstart = static_cast<i32>(A.v.var_hap_start[vi * MH + h]);
+          vlen = static_cast<i32>(A.v.alt_len[vi * MA + (al - 1)]);
+          allele = al;
+        }
+        i32 const rs = ar[2], re = ar[3];
+        if (!((vstart + vlen) > rs && vstart < re)) continue;  // OverlapsAlignment (:360-362)
+        const u8* hap = A.a.hap_bases + (static_cast<size_t>(w) * MH + hap0 + h) * P.max_hap_len;
+        Scored sc = score_at_variant(cg, ar[1], rs, re, rb, rq, rlen, hap, vstart, vlen);
+        sc.allele = allele;
+        if (have_best && sc.combined() <= bestsc.combined()) continue;  // first wins ties
+        bestsc = sc;
+        have_best = true;
+      }
+      if (!have_best) continue;
+      asg[v] = static_cast<u8>(bestsc.allele);
+      if (A.o.asg_allele) A.o.asg_allele[static_cast<size_t>(r) * MV + v] = static_cast<u8>(bestsc.allele);
+      if (A.o.asg_score) A.o.asg_score[static_cast<size_t>(r) * MV + v] = bestsc.combined();
+      if (sample >= static_cast<u32>(S)) continue;
+      // evidence de-duplication: first read (collector order) per (variant, sample, allele, qname)
+      u64 const key = ev_key_of(v, sample, bestsc.allele, qn);
+      u32 slot = static_cast<u32>(key * 0x9E3779B97F4A7C15ULL >> 40) & evmask;
+      for (u32 probe = 0; probe <= evmask; ++probe) {
+        u64 cur = evk[slot];
+        if (cur != key && cur == 0) {
+          unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long*>(&evk[slot]), 0ull,
+                                             static_cast<unsigned long long>(key));
+          cur = old == 0ull ? key : old;
+        }
+        if (cur == key) {
+          atomicMin(&evm[slot], static_cast<u32>(r - A.b.read_win_off[w]));
+          break;
+        }
+        slot = (slot + 1) & evmask;
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(64) void k_evidence(GArgs A) {
+  i64 const r = static_cast<i64>(blockIdx.x) * 64 + threadIdx.x;
+  if (r >= A.b.n_reads) return;
+  ma_params_t const& P = A.prm;
+  int const MV = P.max_vars, NA = P.max_alts + 1, S = P.num_samples;
+  int lo = 0, hi = A.b.n_windows;
+  while (hi - lo > 1) {
+    int const mid = (lo + hi) / 2;
+    if (A.b.read_win_off[mid] <= r) lo = mid; else hi = mid;
+  }
+  int const w = lo;
+  u32 const nv = A.v.win_nvars[w];
+  if (nv == 0) return;
+  const u8* asg = A.ws.asg_allele + static_cast<size_t>(r) * MV;
+  u32 const sample = A.b.read_sample[r];
+  if (sample >= static_cast<u32>(S)) return;
+  u32 const qn = A.b.read_qname_id[r];
+  u32 const rev = (A.b.read_flags[r] & MA_RF_REV) ? 1u : 0u;
+  const u64* evk = A.ws.ev_key + static_cast<size_t>(w) * A.ws.ev_cap;
+  const u32* evm = A.ws.ev_min + static_cast<size_t>(w) * A.ws.ev_cap;
+  u32 const evmask = A.ws.ev_cap - 1;
+  u32 const rloc = static_cast<u32>(r - A.b.read_win_off[w]);
+  for (u32 v = 0; v < nv; ++v) {
+    u32 const al = asg[v];
+    if (al == 255) continue;
+    u64 const key = ev_key_of(v, sample, al, qn);
+    u32 slot = static_cast<u32>(key * 0x9E3779B97F4A7C15ULL >> 40) & evmask;
+    bool win = false;
+    for (u32 probe = 0; probe <= evmask; ++probe) {
+      u64 const cur = evk[slot];
+      if (cur == key) {
+        win = evm[slot] == rloc;
+        break;
+      }
+      if (cur == 0) break;
+      slot = (slot + 1) & evmask;
+    }
+    if (!win) continue;
+    size_t const vi = static_cast<size_t>(w) * MV + v;
+    atomicAdd(&A.o.allele_counts[((vi * S + sample) * NA + al) * 2 + rev], 1u);
+  }
+}
+
+// site quality (variant_call.cpp:289-345): max over case samples with evidence of SOLOR
+__global__ void k_qual(GArgs A) {
+  i64 const idx = static_cast<i64>(blockIdx.x) * blockDim.x + threadIdx.x;
+  ma_params_t const& P = A.prm;
+  int const MV = P.max_vars, NA = P.max_alts + 1, S = P.num_samples;
+  if (idx >= static_cast<i64>(A.b.n_windows) * MV) return;
+  int const w = static_cast<int>(idx / MV), v = static_cast<int>(idx % MV);
+  A.o.var_qual[idx] = 0.0;
+  if (static_cast<u32>(v) >= A.v.win_nvars[w] || !P.case_ctrl_mode) return;
+  // sample roles from the window's reads
+  u32 case_mask = 0;
+  for (u32 r = A.b.read_win_off[w]; r < A.b.read_win_off[w + 1]; ++r)
+    if ((A.b.read_flags[r] & MA_RF_CASE) && A.b.read_sample[r] < static_cast<u32>(S)) case_mask |= 1u << A.b.read_sample[r];
+  const u32* cnt = A.o.allele_counts + static_cast<size_t>(idx) * S * NA * 2;
+  auto cov = [&](int s, bool alt) {
+    u64 t = 0;
+    for (int al = alt ? 1 : 0; al < (alt ? NA : 1); ++al) t += cnt[(s * NA + al) * 2] + cnt[(s * NA + al) * 2 + 1];
+    return t;
+  };
+  f64 sum_alt = 0.0, sum_ref = 0.0, n_ctrl = 0.0;
+  for (int s = 0; s < S; ++s) {
+    if ((case_mask >> s) & 1u) continue;
+    if (cov(s, false) + cov(s, true) == 0) continue;
+    sum_alt += static_cast<f64>(cov(s, true));
+    sum_ref += static_cast<f64>(cov(s, false));
+    n_ctrl += 1.0;
+  }
+  f64 const cc = n_ctrl > 1.0 ? n_ctrl : 1.0;
+  f64 const ctrl_alt = sum_alt / cc + 1.0, ctrl_ref = sum_ref / cc + 1.0;
+  f64 qual = 0.0;
+  for (int s = 0; s < S; ++s) {
+    if (!((case_mask >> s) & 1u)) continue;
+    if (cov(s, false) + cov(s, true) == 0) continue;
+    f64 const case_alt = static_cast<f64>(cov(s, true)) + 1.0, case_ref = static_cast<f64>(cov(s, false)) + 1.0;
+    f64 const lor = log((case_alt * ctrl_ref) / (case_ref * ctrl_alt));
+    qual = qual > lor ? qual : lor;
+  }
+  A.o.var_qual[idx] = qual;
+}
+
+}  // namespace
+
+int launch_genotype(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& a, const ma_var_out_t& v,
+                    const ma_geno_out_t& o_in) {
+  int const n = b.n_windows;
+  if (n == 0) return MA_OK;
+  ma_params_t const& P = ctx->prm;
+  size_t const NR = static_cast<size_t>(b.n_reads);
+  int const MH = P.max_haps, MV = P.max_vars, MCG = P.max_cigar;
+  if (P.max_hap_len + SK > 65000 || P.max_hap_len * 2 > kIdxCap * 2) {
+    ctx->err = "max_hap_len too large for the 16-bit seed index";
+    return MA_ERR_PARAM;
+  }
+  GArgs A{};
+  A.b = b;
+  A.a = a;
+  A.v = v;
+  A.o = o_in;
+  A.prm = P;
+  AlnWs& ws = A.ws;
+  ws.band = P.band;
+  ws.idx_cap = kIdxCap;
+  // evidence table: sized from the largest window (reads x a few variants each); the read count per
+  // window is known from read_win_off only on the device, so a first tiny pass fetches the maxima
+  ws.ev_cap = 8192;
+  {
+    MA_HIP(ctx, ctx->ws_misc.reserve(4096));
+    u32* cnt = ctx->ws_misc.as<u32>();
+    MA_HIP(ctx, hipMemsetAsync(cnt, 0, 16, ctx->stream));
+    hipLaunchKernelGGL(k_max_reads, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, b, cnt);
+    u32 mr = 0;
+    MA_HIP(ctx, hipMemcpyAsync(&mr, cnt, 4, hipMemcpyDeviceToHost, ctx->stream));
+    MA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    u64 want = static_cast<u64>(mr) * 8 + 1024;
+    u32 cap = 8192;
+    while (cap < want && cap < (1u << 24)) cap <<= 1;
+    ws.ev_cap = cap;
+  }
+
+  // fixed-size part of the workspace
+  auto carve_fixed = [&](char* base) -> size_t {
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+      off = (off + 255) & ~size_t(255);
+      char* p = base ? base + off : nullptr;
+      off += bytes;
+      return p;
+    };
+    ws.win_slotmask = reinterpret_cast<u32*>(take(4ull * n));
+    ws.pair_off = reinterpret_cast<u64*>(take(8ull * (n + 1)));
+    ws.counters = reinterpret_cast<u32*>(take(64));
+    ws.idx_head = reinterpret_cast<u16*>(take(2ull * n * MH * kIdxCap));
+    ws.idx_next = reinterpret_cast<u16*>(take(2ull * n * MH * P.max_hap_len));
+    ws.idx_code = reinterpret_cast<u32*>(take(4ull * n * MH * P.max_hap_len));
+    ws.ev_key = reinterpret_cast<u64*>(take(8ull * n * ws.ev_cap));
+    ws.ev_min = reinterpret_cast<u32*>(take(4ull * n * ws.ev_cap));
+    ws.asg_allele = reinterpret_cast<u8*>(take(NR * MV + 16));
+    // internal alignment records when the caller does not want the debug taps
+    if (!o_in.aln_rec) A.o.aln_rec = reinterpret_cast<i32*>(take(4ull * NR * MH * 6));
+    if (!o_in.aln_cigar) A.o.aln_cigar = reinterpret_cast<u32*>(take(4ull * NR * MH * (1 + MCG)));
+    return off;
+  };
+  size_t const fixed = carve_fixed(nullptr);
+  MA_HIP(ctx, ctx->ws_aln.reserve(fixed + 4096));
+  carve_fixed(static_cast<char*>(ctx->ws_aln.p));
+  MA_HIP(ctx, hipMemsetAsync(ws.counters, 0, 64, ctx->stream));
+  MA_HIP(ctx, hipMemsetAsync(ws.ev_key, 0, 8ull * n * ws.ev_cap, ctx->stream));
+  MA_HIP(ctx, hipMemsetAsync(ws.ev_min, 0xFF, 4ull * n * ws.ev_cap, ctx->stream));
+  MA_HIP(ctx, hipMemsetAsync(A.o.allele_counts, 0,
+                             4ull * n * MV * P.num_samples * (P.max_alts + 1) * 2, ctx->stream));
+  MA_HIP(ctx, hipMemsetAsync(A.o.aln_rec, 0, 4ull * NR * MH * 6, ctx->stream));
+  MA_HIP(ctx, hipMemsetAsync(A.o.aln_cigar, 0, 4ull * NR * MH * (1 + MCG), ctx->stream));
+
+  ctx->tic("k_plan");
+  hipLaunchKernelGGL(k_plan, dim3((n + 127) / 128), dim3(128), 0, ctx->stream, A);
+  hipLaunchKernelGGL(k_scan_pairs, dim3(1), dim3(1024), 0, ctx->stream, ws.pair_off, n);
+  ctx->toc();
+  u64 total_pairs = 0;
+  u32 max_read_len = 0;
+  MA_HIP(ctx, hipMemcpyAsync(&total_pairs, ws.pair_off + n, 8, hipMemcpyDeviceToHost, ctx->stream));
+  MA_HIP(ctx, hipMemcpyAsync(&max_read_len, ws.counters, 4, hipMemcpyDeviceToHost, ctx->stream));
+  MA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+
+  if (total_pairs > 0) {
+    ctx->tic("k_hap_index");
+    hipLaunchKernelGGL(k_hap_index, dim3(n * MH), dim3(256), 0, ctx->stream, A);
+    ctx->toc();
+    ws.tb_rows = max_read_len + 1;
+    ws.tb_words = static_cast<u32>((2 * P.band + 1 + 7) / 8);
+    size_t const tb_per_group = static_cast<size_t>(ws.tb_rows) * ws.tb_words * 64 * 4;  // 64 pairs
+    size_t budget = size_t(8) << 30;
+    if (const char* e = getenv("MA_TB_GB")) budget = static_cast<size_t>(atoi(e)) << 30;
+    u64 const groups_total = (total_pairs + 63) / 64;
+    u64 const groups_chunk = std::max<u64>(1, std::min<u64>(groups_total, budget / tb_per_group));
+    MA_HIP(ctx, ctx->ws_misc.reserve(groups_chunk * tb_per_group + groups_chunk * 64 * 4 + 4096));
+    ws.tb = ctx->ws_misc.as<u32>();
+    ws.centre = reinterpret_cast<i32*>(reinterpret_cast<char*>(ctx->ws_misc.p) + groups_chunk * tb_per_group);
+    u32 const hist_len = ((max_read_len + static_cast<u32>(P.max_hap_len) + 2 + 1) & ~1u);
+    u32 const seg_words = (max_read_len + 2 * P.band + 1 + 7) / 8 + 1;
+    size_t const lds_align = (static_cast<size_t>(2 * P.band + 2) * 64 + static_cast<size_t>(seg_words) * 64) * 4;
+    for (u64 g0 = 0; g0 < groups_total; g0 += groups_chunk) {
+      u64 const ng = std::min<u64>(groups_chunk, groups_total - g0);
+      A.pair0 = g0 * 64;
+      A.npairs = static_cast<u32>(std::min<u64>(ng * 64, total_pairs - A.pair0));
+      ctx->tic("k_vote");
+      hipLaunchKernelGGL(k_vote, dim3((A.npairs + 3) / 4), dim3(256), 4ull * hist_len * 2, ctx->stream, A, hist_len);
+      ctx->toc();
+      ctx->tic("k_align");
+      if (lds_align > 65536)
+        MA_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_align),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_align)));
+      hipLaunchKernelGGL(k_align, dim3(static_cast<u32>(ng)), dim3(64), lds_align, ctx->stream, A, seg_words);
+      ctx->toc();
+    }
+  }
+  ctx->tic("k_assign");
+  hipLaunchKernelGGL(k_assign, dim3(static_cast<u32>((NR + 63) / 64)), dim3(64), 0, ctx->stream, A);
+  ctx->toc();
+  ctx->tic("k_evidence");
+  hipLaunchKernelGGL(k_evidence, dim3(static_cast<u32>((NR + 63) / 64)), dim3(64), 0, ctx->stream, A);
+  ctx->toc();
+  ctx->tic("k_qual");
+  hipLaunchKernelGGL(k_qual, dim3(static_cast<u32>((static_cast<size_t>(n) * MV + 255) / 256)), dim3(256), 0,
+                     ctx->stream, A);
+  ctx->toc();
+  MA_HIP(ctx, hipGetLastError());
+  return MA_OK;
+}
+
+}  // namespace ma

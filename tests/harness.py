@@ -159,3 +159,36 @@ def compare_vars(p, got, want, n):
         if variants_of(p, got, w) != variants_of(p, want, w):
             bad.append(f"w{w} alleles: got {variants_of(p, got, w)} want {variants_of(p, want, w)}")
     return bad
+
+
+def compare_geno(p, got, want, n, nr, win_nvars, read_win_off):
+    bad = []
+    MH, MV, MCG = p.max_haps, p.max_vars, p.max_cigar
+    if not np.array_equal(got["aln_rec"], want["aln_rec"]):
+        idx = np.nonzero(got["aln_rec"].reshape(-1, 6) != want["aln_rec"].reshape(-1, 6))[0]
+        for i in np.unique(idx)[:8]:
+            bad.append(f"aln_rec read {i // MH} slot {i % MH}: got {got['aln_rec'].reshape(-1, 6)[i].tolist()} "
+                       f"want {want['aln_rec'].reshape(-1, 6)[i].tolist()}")
+    gc, wc = got["aln_cigar"].reshape(-1, 1 + MCG), want["aln_cigar"].reshape(-1, 1 + MCG)
+    if not np.array_equal(gc[:, 0], wc[:, 0]):
+        bad.append("cigar op counts differ")
+    else:
+        for i in np.nonzero(wc[:, 0])[0]:
+            k = min(int(wc[i, 0]), MCG)
+            if not np.array_equal(gc[i, 1:1 + k], wc[i, 1:1 + k]):
+                bad.append(f"cigar read {i // MH} slot {i % MH}: got {gc[i, 1:1 + k].tolist()} want {wc[i, 1:1 + k].tolist()}")
+                if len(bad) > 10:
+                    break
+    if not np.array_equal(got["asg_allele"], want["asg_allele"]):
+        i = np.nonzero(got["asg_allele"] != want["asg_allele"])[0][:8]
+        bad.append(f"asg_allele differs at {i.tolist()}: got {got['asg_allele'][i].tolist()} want {want['asg_allele'][i].tolist()}")
+    if not np.array_equal(got["asg_score"].view(np.uint64), want["asg_score"].view(np.uint64)):
+        i = np.nonzero(got["asg_score"] != want["asg_score"])[0][:8]
+        bad.append(f"asg_score differs at {i.tolist()}: got {got['asg_score'][i].tolist()} want {want['asg_score'][i].tolist()}")
+    if not np.array_equal(got["allele_counts"], want["allele_counts"]):
+        i = np.nonzero(got["allele_counts"] != want["allele_counts"])[0][:8]
+        bad.append(f"allele_counts differ at {i.tolist()}: got {got['allele_counts'][i].tolist()} want {want['allele_counts'][i].tolist()}")
+    dq = np.abs(got["var_qual"] - want["var_qual"]).max() if len(want["var_qual"]) else 0.0
+    if dq > 1e-9:
+        bad.append(f"var_qual max abs diff {dq}")
+    return bad

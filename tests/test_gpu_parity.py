@@ -118,3 +118,49 @@ def test_msa_parity(cfg, nwin, kw):
     bad = compare_vars(params, got, want, n)
     assert not bad, "\n".join(bad[:20])
     assert want["win_nvars"].sum() > 0
+
+
+from harness import compare_geno  # noqa: E402
+
+
+@pytest.mark.parametrize("cfg,nwin,kw", [("C2", 6, {}), ("C3", 3, {}), ("C4", 1, dict(depths=(60, 60))),
+                                          ("C5", 3, dict(num_samples=3))])
+def test_genotype_parity(cfg, nwin, kw):
+    from lancet2_amd.engine import Engine
+    ns = kw.pop("num_samples", 2)
+    params = capi.default_params(min_k=25, max_k=25, num_samples=ns)
+    arrs, n, nr = synth.make_config_batch(cfg, nwin, first_index=500, **kw)
+    orc = OracleEngine(params)
+    asm = orc.assemble(arrs, n, nr)
+    var = orc.msa(arrs, n, nr, asm)
+    want = orc.genotype(arrs, n, nr, asm, var)
+    eng = Engine(params)
+    try:
+        got = eng.genotype(arrs, n, nr, asm, var)
+    finally:
+        eng.close()
+    bad = compare_geno(params, got, want, n, nr, var["win_nvars"], arrs["read_win_off"])
+    assert not bad, "\n".join(bad[:20])
+    assert want["allele_counts"].sum() > 0 and (want["aln_rec"].reshape(-1, 6)[:, 0] > 0).sum() > 100
+
+
+def test_process_batch_end_to_end():
+    """gate -> assemble -> msa -> genotype chained on the device equals the oracle chain."""
+    from lancet2_amd.engine import Engine
+    params = capi.default_params()
+    arrs, n, nr = synth.make_config_batch("C2", 5, first_index=700)
+    orc = OracleEngine(params)
+    wg = orc.gate(arrs, n, nr)
+    wa = orc.assemble(arrs, n, nr)
+    wv = orc.msa(arrs, n, nr, wa)
+    wq = orc.genotype(arrs, n, nr, wa, wv)
+    eng = Engine(params)
+    try:
+        g, a, v, q = eng.process(arrs, n, nr, debug=True)
+    finally:
+        eng.close()
+    assert np.array_equal(g["max_approx"], wg["max_approx"]) and np.array_equal(g["max_exact"], wg["max_exact"])
+    assert not compare_asm(params, a, wa, n)
+    assert not compare_vars(params, v, wv, n)
+    bad = compare_geno(params, q, wq, n, nr, wv["win_nvars"], arrs["read_win_off"])
+    assert not bad, "\n".join(bad[:20])
