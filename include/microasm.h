@@ -181,6 +181,10 @@ int ma_genotype_batch(ma_ctx_t* ctx, const ma_batch_t* b, const ma_asm_out_t* as
 int ma_process_batch(ma_ctx_t* ctx, const ma_batch_t* b, const ma_gate_out_t* gate,
                      const ma_asm_out_t* asmb, const ma_var_out_t* vars, const ma_geno_out_t* geno);
 
+/* Kernel timing mode: 0 = off, 1 = reset at every API call (default), 2 = accumulate across calls
+ * until ma_timing_control is called again (used by bench.py to time kernels over the timed region). */
+int ma_timing_control(ma_ctx_t* ctx, int mode);
+
 /* Per-kernel timing of the last call, measured with HIP events on the launch stream.
  * names[i] points to a static string; returns the number of entries written (<= cap). */
 int ma_last_kernel_times(ma_ctx_t* ctx, const char** names, float* ms, int cap);

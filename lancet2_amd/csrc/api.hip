@@ -230,6 +230,14 @@ int ma_synchronize(ma_ctx_t* ctx) {
   return MA_OK;
 }
 
+int ma_timing_control(ma_ctx_t* ctx, int mode) {
+  if (!ctx) return MA_ERR_ARG;
+  ctx->timing = mode != 0;
+  ctx->accumulate = mode == 2;
+  ctx->timers_used = 0;
+  return MA_OK;
+}
+
 int ma_last_kernel_times(ma_ctx_t* ctx, const char** names, float* ms, int cap) {
   if (!ctx) return MA_ERR_ARG;
   MA_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -246,7 +254,7 @@ int ma_last_kernel_times(ma_ctx_t* ctx, const char** names, float* ms, int cap) 
 #define MA_BEGIN(ctx)                                   \
   if (!(ctx)) return MA_ERR_ARG;                        \
   MA_HIP(ctx, hipSetDevice((ctx)->device));             \
-  (ctx)->timers_used = 0;
+  if (!(ctx)->accumulate) (ctx)->timers_used = 0;
 
 #define MA_TRY(expr)          \
   do {                        \

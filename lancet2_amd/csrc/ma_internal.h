@@ -68,6 +68,7 @@ struct ma_ctx {
   std::vector<ma::KernelTimer> timers;
   size_t timers_used = 0;
   bool timing = true;
+  bool accumulate = false;
 
   void tic(const char* name);
   void toc();

@@ -27,6 +27,7 @@ def load_library(path=None):
     lib.ma_last_error.argtypes = [C.c_void_p]
     lib.ma_set_stream.argtypes = [C.c_void_p, C.c_void_p]
     lib.ma_synchronize.argtypes = [C.c_void_p]
+    lib.ma_timing_control.argtypes = [C.c_void_p, C.c_int]
     lib.ma_repeat_gate_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     lib.ma_assemble_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     lib.ma_msa_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -71,10 +72,13 @@ class Engine:
     def synchronize(self):
         self._check(self.lib.ma_synchronize(self.h), "ma_synchronize")
 
-    def kernel_times(self):
-        names = (C.c_char_p * 64)()
-        ms = (C.c_float * 64)()
-        n = self.lib.ma_last_kernel_times(self.h, names, ms, 64)
+    def timing_control(self, mode):
+        self._check(self.lib.ma_timing_control(self.h, mode), "ma_timing_control")
+
+    def kernel_times(self, cap=8192):
+        names = (C.c_char_p * cap)()
+        ms = (C.c_float * cap)()
+        n = self.lib.ma_last_kernel_times(self.h, names, ms, cap)
         return [(names[i].decode(), float(ms[i])) for i in range(max(n, 0))]
 
     # ---- host-array convenience (MA_MEM_HOST): numpy in, numpy out ----
