@@ -138,7 +138,13 @@ int launch_assemble(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& out, const
     carve_ws(probe, tmp, 1);
   }
   size_t const per_window = probe.off + 4096;
-  size_t budget = size_t(24) << 30;  // workspace budget per chunk
+  size_t budget = size_t(24) << 30;
+  {
+    size_t free_b = 0, total_b = 0;  // size the in-flight window count for the GPU's HBM (288 GB on MI355X)
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+      budget = static_cast<size_t>(static_cast<double>(free_b + ctx->ws_build.cap) * 0.35);
+    }
+  }
   if (const char* e = getenv("MA_WS_GB")) budget = static_cast<size_t>(atoi(e)) << 30;
   int chunk = static_cast<int>(std::max<size_t>(1, std::min<size_t>(n, budget / per_window)));
   MA_HIP(ctx, ctx->ws_build.reserve(per_window * static_cast<size_t>(chunk)));

@@ -4,14 +4,18 @@
 // kNW with convex gaps 0/-6/-6,-2/-26,-1: caller/msa_builder.h:72-89) and the caller::VariantSet
 // constructor (caller/variant_extractor.cpp:24-233, variant_bubble.cpp:16-116, raw_variant.cpp:44-77).
 //
-// One wavefront per window; the window's components are processed one after another.  For every
-// haplotype the sequence-to-DAG DP (five i32 matrices H,F,E,O,Q kept in HBM because SPOA's traceback
-// compares VALUES) is filled by all 64 lanes as a skewed pipeline: lane l owns a contiguous chunk of
-// columns and handles graph row (t - l) at step t, receiving the (H,E,Q) of the column to its left
-// from lane l-1 through a wave shuffle; predecessor rows are read back from HBM.  Traceback, graph
-// update (Graph::AddAlignment), the DFS topological sort and the bubble walk are short serial loops
-// driven by lane 0.  Edge weights are not tracked: the reference only reads topology, labels and
-// ranks from the POA graph (variant_extractor.cpp:47-58, :84-94, :159-181).
+// One wavefront per window; the window's components are processed one after another.
+//  * The POA graph (node chars, in/out adjacency with 16-bit ids, per-edge haplotype label masks,
+//    aligned-node rings, rank <-> node maps, DFS scratch, the alignment path) lives in LDS: the graph
+//    update (Graph::AddAlignment), SPOA's DFS topological sort and the bubble walk are pointer-chasing
+//    serial loops, so they run at LDS latency on lane 0 instead of HBM latency.
+//  * The sequence-to-DAG DP keeps SPOA's five i32 matrices (H,F,E,O,Q) in HBM because the traceback
+//    compares VALUES.  All 64 lanes fill them as a skewed pipeline: lane l owns a contiguous chunk of
+//    columns and handles DP row (t - l + 1) at step t; the (H,E,Q) of the column to its left arrive
+//    from lane l-1 by wave shuffle; the previous row stays in registers, so a row whose only
+//    predecessor is the previous rank (the common case) reads nothing from HBM.
+// Edge weights are not tracked: the reference only reads topology, labels and ranks from the POA
+// graph (variant_extractor.cpp:47-58, :84-94, :159-181).
 #include <algorithm>
 #include <cstdlib>
 #include <vector>
@@ -22,50 +26,37 @@ namespace ma {
 
 namespace {
 
-constexpr int kPIn = 8;    // in/out edges per POA node
-constexpr int kPAl = 4;    // aligned nodes per POA node
+constexpr int kPE = 4;     // in / out edges and aligned nodes kept per POA node
 constexpr i32 kNegInf = static_cast<i32>(0x80000000u) + 1024;
 constexpr i32 M_ = 0, N_ = -6, G_ = -6, E_ = -2, Q_ = -26, C_ = -1;  // msa_builder.h:72-77
+constexpr u16 kNone16 = 0xFFFFu;
 
 struct PoaWs {
-  u32 pnc;        // node capacity
-  u32 pec;        // edge capacity
-  size_t cells;   // DP cells per matrix per window
+  u32 pn;         // node capacity (LDS)
   u32 max_l;
-  u8* nchar;      // [w][pnc]
-  u8* nin;
-  u8* nout;
-  u8* nal;
-  u32* in_e;      // [w][pnc][kPIn] edge ids
-  u32* out_e;
-  u32* al;        // [w][pnc][kPAl] node ids
-  u32* e_tail;    // [w][pec]
-  u32* e_head;
-  u32* e_lab;     // label bitmask
-  u32* rank2node; // [w][pnc]
-  u32* node2rank; // [w][pnc]
-  u32* row_pred0; // [w][pnc+2] offset into preds
-  u32* preds;     // [w][pec]  predecessor ROW indices (rank + 1) in in-edge order
-  u32* tmp;       // [w][5*pnc] marks / ignored / dfs stack
-  i32* aln;       // [w][2*(pnc + max_l + 2)] alignment pairs (node id | -1, seq pos | -1)
+  size_t cells;   // DP cells per matrix per window (skewed body)
+  u32 cw_max;     // columns per lane for the longest haplotype (multiple of 4)
   i32* H;         // [w][cells]
   i32* F;
   i32* E;
   i32* O;
   i32* Q;
+  i32* C0;        // [w][5][pn + 2] column 0 of H, F, E, O, Q
 };
 
-struct PG {  // per-window graph view (lane 0 mutates it)
-  u32 nn, ne, nseq, nrank;
-  u32 pnc, pec;
-  u8 *nchar, *nin, *nout, *nal;
-  u32 *in_e, *out_e, *al, *e_tail, *e_head, *e_lab, *rank2node, *node2rank;
-  i32 seq_first[32];
+struct PG {  // LDS-resident POA graph of one window
+  u32 nn, nseq, nrank;
+  u32 pn;
+  u8 *nchar, *nin, *nout, *nal, *marks, *ignored;
+  u16 *in_tail, *out_head, *out_lab, *al, *rank2node, *node2rank;
+  u16* stack;       // DFS stack; aliased by the column-0 DP values during alignment
+  u32 stack_cap;
+  i32 seq_first[16];
   bool overflow;
 };
 
 __device__ i32 pg_add_node(PG& g, u8 ch) {
-  if (g.nn >= g.pnc) {
+  if (g.nn >= g.pn) {
     g.overflow = true;
     return 0;
   }
@@ -75,24 +66,20 @@ __device__ i32 pg_add_node(PG& g, u8 ch) {
   return static_cast<i32>(id);
 }
 __device__ void pg_add_edge(PG& g, u32 tail, u32 head) {  // spoa::Graph::AddEdge (weights dropped)
-  u32 const label = g.nseq;
-  for (int x = 0; x < g.nout[tail]; ++x) {
-    u32 const ei = g.out_e[tail * kPIn + x];
-    if (g.e_head[ei] == head) {
-      g.e_lab[ei] |= (1u << label);
+  u16 const lab = static_cast<u16>(1u << g.nseq);
+  for (int x = 0; x < g.nout[tail]; ++x)
+    if (g.out_head[tail * kPE + x] == head) {
+      g.out_lab[tail * kPE + x] |= lab;
       return;
     }
-  }
-  if (g.ne >= g.pec || g.nout[tail] >= kPIn || g.nin[head] >= kPIn) {
+  if (g.nout[tail] >= kPE || g.nin[head] >= kPE) {
     g.overflow = true;
     return;
   }
-  u32 const ei = g.ne++;
-  g.e_tail[ei] = tail;
-  g.e_head[ei] = head;
-  g.e_lab[ei] = 1u << label;
-  g.out_e[tail * kPIn + g.nout[tail]++] = ei;
-  g.in_e[head * kPIn + g.nin[head]++] = ei;
+  g.out_head[tail * kPE + g.nout[tail]] = static_cast<u16>(head);
+  g.out_lab[tail * kPE + g.nout[tail]] = lab;
+  g.nout[tail]++;
+  g.in_tail[head * kPE + g.nin[head]++] = static_cast<u16>(tail);
 }
 __device__ i32 pg_add_sequence(PG& g, const u8* seq, u32 begin, u32 end) {  // spoa::Graph::AddSequence
   if (begin == end) return -1;
@@ -107,113 +94,107 @@ __device__ i32 pg_add_sequence(PG& g, const u8* seq, u32 begin, u32 end) {  // s
   return static_cast<i32>(first);
 }
 __device__ i32 pg_successor(const PG& g, u32 node, u32 label) {  // spoa::Graph::Node::Successor
-  for (int x = 0; x < g.nout[node]; ++x) {
-    u32 const ei = g.out_e[node * kPIn + x];
-    if (g.e_lab[ei] & (1u << label)) return static_cast<i32>(g.e_head[ei]);
-  }
+  for (int x = 0; x < g.nout[node]; ++x)
+    if (g.out_lab[node * kPE + x] & (1u << label)) return static_cast<i32>(g.out_head[node * kPE + x]);
   return -1;
 }
 // spoa::Graph::TopologicalSort
-__device__ void pg_toposort(PG& g, u32* tmp) {
-  u8* marks = reinterpret_cast<u8*>(tmp);
-  u8* ignored = reinterpret_cast<u8*>(tmp + g.pnc / 4 + 1);
-  u32* stack = tmp + 2 * (g.pnc / 4 + 1);
-  u32 const stack_cap = 4 * g.pnc;
-  for (u32 i = 0; i < g.nn; ++i) marks[i] = ignored[i] = 0;
+__device__ void pg_toposort(PG& g) {
+  for (u32 i = 0; i < g.nn; ++i) g.marks[i] = g.ignored[i] = 0;
   g.nrank = 0;
+  u16* stack = g.stack;
   for (u32 s = 0; s < g.nn; ++s) {
-    if (marks[s] != 0) continue;
+    if (g.marks[s] != 0) continue;
     u32 sp = 0;
-    stack[sp++] = s;
+    stack[sp++] = static_cast<u16>(s);
     while (sp > 0) {
       u32 const cur = stack[sp - 1];
       bool valid = true;
-      if (marks[cur] != 2) {
+      if (g.marks[cur] != 2) {
         for (int x = 0; x < g.nin[cur]; ++x) {
-          u32 const t = g.e_tail[g.in_e[cur * kPIn + x]];
-          if (marks[t] != 2) {
-            if (sp < stack_cap) stack[sp++] = t; else g.overflow = true;
+          u32 const t = g.in_tail[cur * kPE + x];
+          if (g.marks[t] != 2) {
+            if (sp < g.stack_cap) stack[sp++] = static_cast<u16>(t); else g.overflow = true;
             valid = false;
           }
         }
-        if (!ignored[cur]) {
+        if (!g.ignored[cur]) {
           for (int x = 0; x < g.nal[cur]; ++x) {
-            u32 const an = g.al[cur * kPAl + x];
-            if (marks[an] != 2) {
-              if (sp < stack_cap) stack[sp++] = an; else g.overflow = true;
-              ignored[an] = 1;
+            u32 const an = g.al[cur * kPE + x];
+            if (g.marks[an] != 2) {
+              if (sp < g.stack_cap) stack[sp++] = static_cast<u16>(an); else g.overflow = true;
+              g.ignored[an] = 1;
               valid = false;
             }
           }
         }
         if (valid) {
-          marks[cur] = 2;
-          if (!ignored[cur]) {
-            g.rank2node[g.nrank++] = cur;
-            for (int x = 0; x < g.nal[cur]; ++x) g.rank2node[g.nrank++] = g.al[cur * kPAl + x];
+          g.marks[cur] = 2;
+          if (!g.ignored[cur]) {
+            g.rank2node[g.nrank++] = static_cast<u16>(cur);
+            for (int x = 0; x < g.nal[cur]; ++x) g.rank2node[g.nrank++] = g.al[cur * kPE + x];
           }
         } else {
-          marks[cur] = 1;
+          g.marks[cur] = 1;
         }
       }
       if (valid) sp--;
       if (g.overflow) return;
     }
   }
-  for (u32 r = 0; r < g.nrank; ++r) g.node2rank[g.rank2node[r]] = r;
+  for (u32 r = 0; r < g.nrank; ++r) g.node2rank[g.rank2node[r]] = static_cast<u16>(r);
 }
 
-// spoa::Graph::AddAlignment
-__device__ void pg_add_alignment(PG& g, const i32* aln, u32 naln, const u8* seq, u32 len, u32* tmp) {
+// spoa::Graph::AddAlignment; aln pairs are (node id + 1 | 0, seq pos + 1 | 0) in LDS
+__device__ void pg_add_alignment(PG& g, const u16* aln, u32 naln, const u8* seq, u32 len) {
   if (len == 0) return;
   if (naln == 0) {
     i32 const first = pg_add_sequence(g, seq, 0, len);
     g.seq_first[g.nseq++] = first;
-    if (!g.overflow) pg_toposort(g, tmp);
+    if (!g.overflow) pg_toposort(g);
     return;
   }
   i32 vfront = -1, vback = -1;
   for (u32 x = 0; x < naln; ++x)
-    if (aln[2 * x + 1] != -1) {
-      if (vfront < 0) vfront = aln[2 * x + 1];
-      vback = aln[2 * x + 1];
+    if (aln[2 * x + 1] != 0) {
+      if (vfront < 0) vfront = static_cast<i32>(aln[2 * x + 1]) - 1;
+      vback = static_cast<i32>(aln[2 * x + 1]) - 1;
     }
   i32 begin = pg_add_sequence(g, seq, 0, static_cast<u32>(vfront));
   i32 prev = begin >= 0 ? static_cast<i32>(g.nn - 1) : -1;
   i32 const last = pg_add_sequence(g, seq, static_cast<u32>(vback) + 1, len);
   for (u32 x = 0; x < naln && !g.overflow; ++x) {
-    i32 const sp = aln[2 * x + 1];
-    if (sp == -1) continue;
+    if (aln[2 * x + 1] == 0) continue;
+    u32 const sp = static_cast<u32>(aln[2 * x + 1]) - 1;
     u8 const ch = seq[sp];
     i32 curr = -1;
-    i32 const nd = aln[2 * x];
-    if (nd == -1) {
+    if (aln[2 * x] == 0) {
       curr = pg_add_node(g, ch);
     } else {
-      u32 const jt = static_cast<u32>(nd);
+      u32 const jt = static_cast<u32>(aln[2 * x]) - 1;
       if (g.nchar[jt] == ch) {
-        curr = nd;
+        curr = static_cast<i32>(jt);
       } else {
         for (int y = 0; y < g.nal[jt]; ++y)
-          if (g.nchar[g.al[jt * kPAl + y]] == ch) {
-            curr = static_cast<i32>(g.al[jt * kPAl + y]);
+          if (g.nchar[g.al[jt * kPE + y]] == ch) {
+            curr = static_cast<i32>(g.al[jt * kPE + y]);
             break;
           }
         if (curr < 0) {
           curr = pg_add_node(g, ch);
           if (g.overflow) break;
           int const na = g.nal[jt];
-          if (na + 1 > kPAl) {
+          if (na + 1 > kPE) {
             g.overflow = true;
             break;
           }
           for (int y = 0; y < na; ++y) {
-            u32 const kt = g.al[jt * kPAl + y];
-            g.al[kt * kPAl + g.nal[kt]++] = static_cast<u32>(curr);
-            g.al[static_cast<u32>(curr) * kPAl + g.nal[curr]++] = kt;
+            u32 const kt = g.al[jt * kPE + y];
+            g.al[kt * kPE + g.nal[kt]++] = static_cast<u16>(curr);
+            g.al[static_cast<u32>(curr) * kPE + g.nal[curr]++] = static_cast<u16>(kt);
           }
-          g.al[jt * kPAl + g.nal[jt]++] = static_cast<u32>(curr);
-          g.al[static_cast<u32>(curr) * kPAl + g.nal[curr]++] = jt;
+          g.al[jt * kPE + g.nal[jt]++] = static_cast<u16>(curr);
+          g.al[static_cast<u32>(curr) * kPE + g.nal[curr]++] = static_cast<u16>(jt);
         }
       }
     }
@@ -224,7 +205,7 @@ __device__ void pg_add_alignment(PG& g, const i32* aln, u32 naln, const u8* seq,
   }
   if (last >= 0 && prev >= 0) pg_add_edge(g, static_cast<u32>(prev), static_cast<u32>(last));
   g.seq_first[g.nseq++] = begin;
-  if (!g.overflow) pg_toposort(g, tmp);
+  if (!g.overflow) pg_toposort(g);
 }
 
 __device__ i32 classify_variant(const u8* r, u32 rl, const u8* a, u32 al) {  // raw_variant.cpp:44-77
@@ -257,9 +238,243 @@ __device__ int bytes_cmp(const u8* a, u32 al, const u8* b, u32 bl) {  // std::st
   return al < bl ? -1 : (al > bl ? 1 : 0);
 }
 
+
+// predecessor DP row x of DP row i (row = rank + 1), in in-edge order
+__device__ __forceinline__ u32 row_pred(const PG& g, u32 node, u32 x) {
+  return static_cast<u32>(g.node2rank[g.in_tail[node * kPE + x]]) + 1u;
+}
+
+// DP matrices are stored SKEWED so that the pipeline's stores coalesce: cell (i, j >= 1) belongs to lane
+// l = (j-1)/cw, c = (j-1)%cw and lives at (i + l) * 64*cw + l*cw + c -- at pipeline step t every lane
+// works on i + l == t + 1, so one store instruction of the wave covers 64 * 16 B of contiguous HBM.
+// Column 0 of the five matrices is kept in five small side arrays.
+struct DP {
+  i32 *H, *F, *E, *O, *Q;      // skewed bodies
+  i32 *H0, *F0, *E0, *O0, *Q0; // column 0, [V + 1]
+  u32 cw, rs;                  // columns per lane (multiple of 4), row stride = 64 * cw
+  __device__ __forceinline__ size_t off(u32 i, u32 j) const {  // j >= 1
+    u32 const l = (j - 1) / cw;
+    return static_cast<size_t>(i + l) * rs + (j - 1);
+  }
+  __device__ __forceinline__ i32 h(u32 i, u32 j) const { return j ? H[off(i, j)] : H0[i]; }
+  __device__ __forceinline__ i32 f(u32 i, u32 j) const { return j ? F[off(i, j)] : F0[i]; }
+  __device__ __forceinline__ i32 e(u32 i, u32 j) const { return j ? E[off(i, j)] : E0[i]; }
+  __device__ __forceinline__ i32 o(u32 i, u32 j) const { return j ? O[off(i, j)] : O0[i]; }
+  __device__ __forceinline__ i32 q(u32 i, u32 j) const { return j ? Q[off(i, j)] : Q0[i]; }
+};
+
+// Skewed-pipeline fill of the five DP matrices (SisdAlignmentEngine::Convex, alignment phase).
+// Fast path (L <= 64 * CWM): the row a lane finished in the previous step stays in registers.
+constexpr int CWM = 16;
+__device__ void poa_fill(const PG& g, const DP& d, u32 V, u32 L, int lane, const u8* seq, const i32* col0) {
+  u32 const cw = d.cw;
+  u32 const jb = 1 + lane * cw;
+  u32 const je = min(L + 1, jb + cw);
+  u32 const nl = (L + cw - 1) / cw;
+  u32 scp[CWM / 4];  // the lane's sequence chars, packed 4 per register
+#pragma unroll
+  for (int c4 = 0; c4 < CWM / 4; ++c4) {
+    u32 pk = 0;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) pk |= static_cast<u32>((jb + c4 * 4 + b < je) ? seq[jb + c4 * 4 + b - 1] : 0) << (8 * b);
+    scp[c4] = pk;
+  }
+  i32 pH[CWM], pF[CWM], pO[CWM];
+  i32 pHl = 0;
+#pragma unroll
+  for (int c = 0; c < CWM; ++c) pH[c] = pF[c] = pO[c] = 0;
+  i32 hl = 0, el = 0, ql = 0;
+  for (u32 t = 0; t + 1 < V + nl; ++t) {
+    i32 const hL = __shfl_up(hl, 1), eL = __shfl_up(el, 1), qL = __shfl_up(ql, 1);
+    i32 const row = static_cast<i32>(t) - lane + 1;
+    bool const work = lane < static_cast<int>(nl) && row >= 1 && row <= static_cast<i32>(V);
+    u32 node = 0, np = 0;
+    bool needs_hbm = false;
+    if (work) {
+      node = g.rank2node[row - 1];
+      np = g.nin[node];
+      if (np == 0) needs_hbm = true;
+      for (u32 x = 0; x < np; ++x) needs_hbm |= !(row_pred(g, node, x) + 1 == static_cast<u32>(row) && row >= 2);
+    }
+    // rows read back from HBM were written by other lanes of this wave >= 2 steps ago: make them visible
+    if (__any(needs_hbm)) __threadfence_block();
+    if (work) {
+      u32 const i = static_cast<u32>(row);
+      u32 const nch = g.nchar[node];
+      i32 f[CWM], o[CWM], hm[CWM];
+      for (u32 x = 0; x < (np ? np : 1u); ++x) {
+        u32 const pr = np ? row_pred(g, node, x) : 0u;
+        if (pr + 1 == i && i >= 2) {  // previous rank: still in registers
+          i32 hprev = pHl;
+#pragma unroll
+          for (int c = 0; c < CWM; ++c) {
+            i32 const mc = (nch == ((scp[c >> 2] >> (8 * (c & 3))) & 0xFFu)) ? M_ : N_;
+            i32 const fv = max(pH[c] + G_, pF[c] + E_);
+            i32 const ov = max(pH[c] + Q_, pO[c] + C_);
+            i32 const hv = hprev + mc;
+            hprev = pH[c];
+            if (x == 0) {
+              f[c] = fv;
+              o[c] = ov;
+              hm[c] = hv;
+            } else {
+              f[c] = max(f[c], fv);
+              o[c] = max(o[c], ov);
+              hm[c] = max(hm[c], hv);
+            }
+          }
+        } else {
+          size_t const pb = static_cast<size_t>(pr + lane) * d.rs + static_cast<size_t>(lane) * cw;
+          i32 hprev = lane == 0 ? d.H0[pr]
+                                : d.H[static_cast<size_t>(pr + lane - 1) * d.rs + static_cast<size_t>(lane) * cw - 1];
+#pragma unroll
+          for (int c = 0; c < CWM; ++c) {
+            bool const in = static_cast<u32>(c) < cw;
+            i32 const hc = in ? d.H[pb + c] : 0;
+            i32 const fc = in ? d.F[pb + c] : 0;
+            i32 const oc = in ? d.O[pb + c] : 0;
+            i32 const mc = (nch == ((scp[c >> 2] >> (8 * (c & 3))) & 0xFFu)) ? M_ : N_;
+            i32 const fv = max(hc + G_, fc + E_);
+            i32 const ov = max(hc + Q_, oc + C_);
+            i32 const hv = hprev + mc;
+            hprev = hc;
+            if (x == 0) {
+              f[c] = fv;
+              o[c] = ov;
+              hm[c] = hv;
+            } else {
+              f[c] = max(f[c], fv);
+              o[c] = max(o[c], ov);
+              hm[c] = max(hm[c], hv);
+            }
+          }
+        }
+      }
+      i32 hleft, eleft, qleft;
+      if (lane == 0) {  // column 0 (kept in LDS): H = max(O, F), E = Q = -inf
+        hleft = max(col0[2 * i], col0[2 * i + 1]);
+        eleft = kNegInf;
+        qleft = kNegInf;
+      } else {
+        hleft = hL;
+        eleft = eL;
+        qleft = qL;
+      }
+      pHl = hleft;
+      i32 ev[CWM], qv[CWM];
+#pragma unroll
+      for (int c = 0; c < CWM; ++c) {
+        i32 const e = max(hleft + G_, eleft + E_);
+        i32 const q = max(hleft + Q_, qleft + C_);
+        i32 const h = max(hm[c], max(max(f[c], e), max(o[c], q)));
+        ev[c] = e;
+        qv[c] = q;
+        if (jb + c < je) {  // columns past the haplotype end are never read back
+          hleft = h;
+          eleft = e;
+          qleft = q;
+        }
+        pH[c] = h;
+        pF[c] = f[c];
+        pO[c] = o[c];
+      }
+      size_t const ob = static_cast<size_t>(i + lane) * d.rs + static_cast<size_t>(lane) * cw;  // 16 B aligned
+#pragma unroll
+      for (int c4 = 0; c4 < CWM / 4; ++c4) {
+        if (static_cast<u32>(c4 * 4) < cw) {
+          *reinterpret_cast<int4*>(d.H + ob + c4 * 4) = make_int4(pH[c4 * 4], pH[c4 * 4 + 1], pH[c4 * 4 + 2], pH[c4 * 4 + 3]);
+          *reinterpret_cast<int4*>(d.F + ob + c4 * 4) = make_int4(f[c4 * 4], f[c4 * 4 + 1], f[c4 * 4 + 2], f[c4 * 4 + 3]);
+          *reinterpret_cast<int4*>(d.O + ob + c4 * 4) = make_int4(o[c4 * 4], o[c4 * 4 + 1], o[c4 * 4 + 2], o[c4 * 4 + 3]);
+          *reinterpret_cast<int4*>(d.E + ob + c4 * 4) = make_int4(ev[c4 * 4], ev[c4 * 4 + 1], ev[c4 * 4 + 2], ev[c4 * 4 + 3]);
+          *reinterpret_cast<int4*>(d.Q + ob + c4 * 4) = make_int4(qv[c4 * 4], qv[c4 * 4 + 1], qv[c4 * 4 + 2], qv[c4 * 4 + 3]);
+        }
+      }
+      hl = hleft;
+      el = eleft;
+      ql = qleft;
+    }
+  }
+  __threadfence_block();
+}
+
+// Generic path for haplotypes longer than 64 * CWM columns: same recurrences and layout, every
+// predecessor row is read back from HBM (no register-resident row).
+__device__ void poa_fill_long(const PG& g, const DP& d, u32 V, u32 L, int lane, const u8* seq, const i32* col0) {
+  u32 const cw = d.cw;
+  u32 const jb = 1 + lane * cw;
+  u32 const je = min(L + 1, jb + cw);
+  u32 const nl = (L + cw - 1) / cw;
+  i32 hl = 0, el = 0, ql = 0;
+  for (u32 t = 0; t + 1 < V + nl; ++t) {
+    i32 const hL = __shfl_up(hl, 1), eL = __shfl_up(el, 1), qL = __shfl_up(ql, 1);
+    i32 const row = static_cast<i32>(t) - lane + 1;
+    __threadfence_block();
+    if (lane < static_cast<int>(nl) && row >= 1 && row <= static_cast<i32>(V)) {
+      u32 const i = static_cast<u32>(row);
+      u32 const node = g.rank2node[i - 1];
+      u32 const np = g.nin[node];
+      u8 const nch = g.nchar[node];
+      i32 hleft, eleft, qleft;
+      if (lane == 0) {
+        hleft = max(col0[2 * i], col0[2 * i + 1]);
+        eleft = kNegInf;
+        qleft = kNegInf;
+      } else {
+        hleft = hL;
+        eleft = eL;
+        qleft = qL;
+      }
+      for (u32 j = jb; j < je; ++j) {
+        i32 const mc = (nch == seq[j - 1]) ? M_ : N_;
+        i32 f = kNegInf, o = kNegInf, hm = kNegInf;
+        for (u32 x = 0; x < (np ? np : 1u); ++x) {
+          u32 const pr = np ? row_pred(g, node, x) : 0u;
+          i32 const hpj = d.h(pr, j);
+          i32 const fv = max(hpj + G_, d.f(pr, j) + E_);
+          i32 const ov = max(hpj + Q_, d.o(pr, j) + C_);
+          i32 const hv = d.h(pr, j - 1) + mc;
+          f = x == 0 ? fv : max(f, fv);
+          o = x == 0 ? ov : max(o, ov);
+          hm = x == 0 ? hv : max(hm, hv);
+        }
+        i32 const e = max(hleft + G_, eleft + E_);
+        i32 const q = max(hleft + Q_, qleft + C_);
+        i32 const h = max(hm, max(max(f, e), max(o, q)));
+        size_t const ox = d.off(i, j);
+        d.F[ox] = f;
+        d.O[ox] = o;
+        d.E[ox] = e;
+        d.Q[ox] = q;
+        d.H[ox] = h;
+        hleft = h;
+        eleft = e;
+        qleft = q;
+      }
+      hl = hleft;
+      el = eleft;
+      ql = qleft;
+    }
+  }
+  __threadfence_block();
+}
+
+#ifdef MA_PROFILE
+__device__ unsigned long long g_prof[16];
+#define PROF_T0() unsigned long long _t0 = __builtin_amdgcn_s_memtime()
+#define PROF_ACC(slot)                                                        \
+  do {                                                                        \
+    unsigned long long _t1 = __builtin_amdgcn_s_memtime();                    \
+    if (lane == 0) atomicAdd(&g_prof[slot], _t1 - _t0);                       \
+    _t0 = _t1;                                                                \
+  } while (0)
+#else
+#define PROF_T0() do {} while (0)
+#define PROF_ACC(slot) do {} while (0)
+#endif
+
 struct Shared {
   u32 V, L, W;
-  u32 go;        // 1: run the pipelined fill for the current haplotype
+  u32 go;
   u32 abort_;
 };
 
@@ -275,6 +490,7 @@ struct MsaArgs {
 };
 
 __global__ __launch_bounds__(64) void k_msa(MsaArgs A) {
+  extern __shared__ u32 lds_raw[];
   __shared__ Shared sh;
   int const lw = blockIdx.x;
   int const w = A.win0 + lw;
@@ -289,31 +505,48 @@ __global__ __launch_bounds__(64) void k_msa(MsaArgs A) {
     if (lane == 0) A.o.win_nvars[w] = 0;
     return;
   }
-  size_t const nb = static_cast<size_t>(lw) * ws.pnc, eb = static_cast<size_t>(lw) * ws.pec;
+  // ---- carve the LDS graph ----
+  u32 const PN = ws.pn;
   PG g;
-  g.pnc = ws.pnc;
-  g.pec = ws.pec;
-  g.nchar = ws.nchar + nb;
-  g.nin = ws.nin + nb;
-  g.nout = ws.nout + nb;
-  g.nal = ws.nal + nb;
-  g.in_e = ws.in_e + nb * kPIn;
-  g.out_e = ws.out_e + nb * kPIn;
-  g.al = ws.al + nb * kPAl;
-  g.e_tail = ws.e_tail + eb;
-  g.e_head = ws.e_head + eb;
-  g.e_lab = ws.e_lab + eb;
-  g.rank2node = ws.rank2node + nb;
-  g.node2rank = ws.node2rank + nb;
-  u32* row_pred0 = ws.row_pred0 + static_cast<size_t>(lw) * (ws.pnc + 2);
-  u32* preds = ws.preds + eb;
-  u32* tmp = ws.tmp + nb * 5;
-  i32* aln = ws.aln + static_cast<size_t>(lw) * 2 * (ws.pnc + ws.max_l + 2);
-  i32* H = ws.H + static_cast<size_t>(lw) * ws.cells;
-  i32* F = ws.F + static_cast<size_t>(lw) * ws.cells;
-  i32* E = ws.E + static_cast<size_t>(lw) * ws.cells;
-  i32* O = ws.O + static_cast<size_t>(lw) * ws.cells;
-  i32* Q = ws.Q + static_cast<size_t>(lw) * ws.cells;
+  g.pn = PN;
+  {
+    u8* p8 = reinterpret_cast<u8*>(lds_raw);
+    u16* p16 = reinterpret_cast<u16*>(p8 + 6 * static_cast<size_t>(PN));
+    g.nchar = p8;
+    g.nin = p8 + PN;
+    g.nout = p8 + 2 * PN;
+    g.nal = p8 + 3 * PN;
+    g.marks = p8 + 4 * PN;
+    g.ignored = p8 + 5 * PN;
+    g.in_tail = p16;
+    g.out_head = p16 + kPE * PN;
+    g.out_lab = p16 + 2 * kPE * PN;
+    g.al = p16 + 3 * kPE * PN;
+    g.rank2node = p16 + 4 * kPE * PN;
+    g.node2rank = g.rank2node + PN;
+    g.stack = g.node2rank + PN;   // 4 * PN + 8 u16 == 2 * (PN + 1) i32 (+ slack) for the column-0 values
+    g.stack_cap = 4 * PN;
+  }
+  i32* col0 = reinterpret_cast<i32*>(g.stack);                 // [(PN + 1) * 2]: O, F of column 0
+  u16* aln = g.stack + 4 * PN + 8;                            // [(PN + max_l + 2) * 2]
+  u32 const aln_cap = PN + ws.max_l + 2;
+  DP d;
+  d.H = ws.H + static_cast<size_t>(lw) * ws.cells;
+  d.F = ws.F + static_cast<size_t>(lw) * ws.cells;
+  d.E = ws.E + static_cast<size_t>(lw) * ws.cells;
+  d.O = ws.O + static_cast<size_t>(lw) * ws.cells;
+  d.Q = ws.Q + static_cast<size_t>(lw) * ws.cells;
+  {
+    i32* c0 = ws.C0 + static_cast<size_t>(lw) * 5 * (PN + 2);
+    d.H0 = c0;
+    d.F0 = c0 + (PN + 2);
+    d.E0 = c0 + 2 * (PN + 2);
+    d.O0 = c0 + 3 * (PN + 2);
+    d.Q0 = c0 + 4 * (PN + 2);
+  }
+  d.cw = 4;
+  d.rs = 256;
+  i32* H = d.H;  // also the raw-allele scratch of the bubble walk
 
   u32 nvars = 0, pool = 0;
   bool overflow = false;
@@ -322,46 +555,39 @@ __global__ __launch_bounds__(64) void k_msa(MsaArgs A) {
     size_t const ci = static_cast<size_t>(w) * MC + c;
     u32 const hap0 = A.a.comp_hap0[ci], nh = A.a.comp_nhaps[ci];
     if (lane == 0) {
-      g.nn = g.ne = g.nseq = g.nrank = 0;
-      g.overflow = false;
+      g.nn = g.nseq = g.nrank = 0;
+      g.overflow = nh > 16;  // label masks are 16 bit
     }
     for (u32 h = 0; h < nh; ++h) {
       size_t const hi = static_cast<size_t>(w) * MH + hap0 + h;
       const u8* seq = A.a.hap_bases + hi * ML;
       u32 const L = A.a.hap_len[hi];
-      // ---- lane 0: row metadata + column 0 (SisdAlignmentEngine::Initialize, kNW convex) ----
+      PROF_T0();
+      // ---- lane 0: column 0 of the DP (SisdAlignmentEngine::Initialize, kNW convex) ----
       if (lane == 0) {
         sh.go = 0;
         sh.abort_ = g.overflow ? 1u : 0u;
         if (!g.overflow && g.nn > 0 && L > 0) {
           u32 const V = g.nrank, W = L + 1;
-          if (static_cast<size_t>(V + 1) * W > ws.cells) {
+          u32 const cwl = ((L + 63) / 64 + 3) & ~3u;
+          if (static_cast<size_t>(V + 65) * 64 * cwl > ws.cells) {
             g.overflow = true;
             sh.abort_ = 1;
           } else {
-            u32 po = 0;
-            row_pred0[0] = 0;
-            row_pred0[1] = 0;
-            for (u32 r = 0; r < V; ++r) {
-              u32 const nd = g.rank2node[r];
-              for (int x = 0; x < g.nin[nd]; ++x) preds[po++] = g.node2rank[g.e_tail[g.in_e[nd * kPIn + x]]] + 1;
-              row_pred0[r + 2] = po;
-            }
-            O[0] = 0; Q[0] = 0; F[0] = 0; E[0] = 0; H[0] = 0;
+            col0[0] = 0;
+            col0[1] = 0;
             for (u32 i = 1; i <= V; ++i) {
-              u32 const p0 = row_pred0[i], p1 = row_pred0[i + 1];
-              i32 pen_o = p0 == p1 ? Q_ - C_ : kNegInf;
-              i32 pen_f = p0 == p1 ? G_ - E_ : kNegInf;
-              for (u32 x = p0; x < p1; ++x) {
-                pen_o = max(pen_o, O[static_cast<size_t>(preds[x]) * W]);
-                pen_f = max(pen_f, F[static_cast<size_t>(preds[x]) * W]);
+              u32 const node = g.rank2node[i - 1];
+              u32 const np = g.nin[node];
+              i32 pen_o = np == 0 ? Q_ - C_ : kNegInf;
+              i32 pen_f = np == 0 ? G_ - E_ : kNegInf;
+              for (u32 x = 0; x < np; ++x) {
+                u32 const pr = row_pred(g, node, x);
+                pen_o = max(pen_o, col0[2 * pr]);
+                pen_f = max(pen_f, col0[2 * pr + 1]);
               }
-              size_t const ix = static_cast<size_t>(i) * W;
-              O[ix] = pen_o + C_;
-              Q[ix] = kNegInf;
-              F[ix] = pen_f + E_;
-              E[ix] = kNegInf;
-              H[ix] = max(O[ix], F[ix]);
+              col0[2 * i] = pen_o + C_;
+              col0[2 * i + 1] = pen_f + E_;
             }
             sh.V = V;
             sh.L = L;
@@ -372,86 +598,45 @@ __global__ __launch_bounds__(64) void k_msa(MsaArgs A) {
       }
       __syncthreads();
       if (sh.go) {
-        u32 const V = sh.V, W = sh.W;
-        // row 0
+        u32 const V = sh.V;
+        d.cw = ((L + 63) / 64 + 3) & ~3u;
+        d.rs = 64 * d.cw;
+        // column 0 and row 0 to HBM (the traceback may touch them)
+        for (u32 i = lane; i <= V; i += 64) {
+          i32 const ov = col0[2 * i], fv = col0[2 * i + 1];
+          d.O0[i] = ov;
+          d.F0[i] = fv;
+          d.Q0[i] = i == 0 ? 0 : kNegInf;
+          d.E0[i] = i == 0 ? 0 : kNegInf;
+          d.H0[i] = i == 0 ? 0 : max(ov, fv);
+        }
         for (u32 j = 1 + lane; j <= L; j += 64) {
-          O[j] = kNegInf;
-          Q[j] = Q_ + static_cast<i32>(j - 1) * C_;
-          F[j] = kNegInf;
-          E[j] = G_ + static_cast<i32>(j - 1) * E_;
-          H[j] = max(Q[j], E[j]);
+          size_t const ox = d.off(0, j);
+          i32 const qv = Q_ + static_cast<i32>(j - 1) * C_, ev = G_ + static_cast<i32>(j - 1) * E_;
+          d.O[ox] = kNegInf;
+          d.Q[ox] = qv;
+          d.F[ox] = kNegInf;
+          d.E[ox] = ev;
+          d.H[ox] = max(qv, ev);
         }
         __threadfence_block();
         __syncthreads();
-        // ---- skewed pipeline fill (SisdAlignmentEngine::Convex, alignment phase) ----
-        u32 const cw = (L + 63) / 64;                  // columns per lane
-        u32 const jb = 1 + lane * cw;                  // first column of this lane
-        u32 const je = min(L + 1, jb + cw);            // one past the last column
-        u32 const nl = (L + cw - 1) / cw;              // lanes with a non-empty chunk
-        i32 hl = 0, el = 0, ql = 0;                    // (H,E,Q) at my last column of the row just done
-        for (u32 t = 0; t < V + nl - 1 + 1; ++t) {
-          i32 const hL = __shfl_up(hl, 1), eL = __shfl_up(el, 1), qL = __shfl_up(ql, 1);
-          i32 const row = static_cast<i32>(t) - lane + 1;
-          if (lane < static_cast<int>(nl) && row >= 1 && row <= static_cast<i32>(V)) {
-            u32 const i = static_cast<u32>(row);
-            size_t const ix = static_cast<size_t>(i) * W;
-            u8 const nch = g.nchar[g.rank2node[i - 1]];
-            u32 const p0 = row_pred0[i], p1 = row_pred0[i + 1];
-            i32 hleft, eleft, qleft;
-            if (lane == 0) {
-              hleft = H[ix];
-              eleft = E[ix];
-              qleft = Q[ix];
-            } else {
-              hleft = hL;
-              eleft = eL;
-              qleft = qL;
-            }
-            for (u32 j = jb; j < je; ++j) {
-              i32 const mc = (nch == seq[j - 1]) ? M_ : N_;
-              i32 f, o, hm;
-              {
-                size_t const px = static_cast<size_t>(p0 == p1 ? 0u : preds[p0]) * W;
-                f = max(H[px + j] + G_, F[px + j] + E_);
-                o = max(H[px + j] + Q_, O[px + j] + C_);
-                hm = H[px + j - 1] + mc;
-              }
-              for (u32 x = p0 + 1; x < p1; ++x) {
-                size_t const px = static_cast<size_t>(preds[x]) * W;
-                f = max(f, max(H[px + j] + G_, F[px + j] + E_));
-                o = max(o, max(H[px + j] + Q_, O[px + j] + C_));
-                hm = max(hm, H[px + j - 1] + mc);
-              }
-              i32 const e = max(hleft + G_, eleft + E_);
-              i32 const q = max(hleft + Q_, qleft + C_);
-              i32 const h = max(hm, max(max(f, e), max(o, q)));
-              F[ix + j] = f;
-              O[ix + j] = o;
-              E[ix + j] = e;
-              Q[ix + j] = q;
-              H[ix + j] = h;
-              hleft = h;
-              eleft = e;
-              qleft = q;
-            }
-            hl = hleft;
-            el = eleft;
-            ql = qleft;
-          }
-          __threadfence_block();
-        }
+        PROF_ACC(0);
+        if (d.cw <= CWM) poa_fill(g, d, V, L, lane, seq, col0);
+        else poa_fill_long(g, d, V, L, lane, seq, col0);
         __syncthreads();
+        PROF_ACC(1);
       }
       // ---- lane 0: best end cell, traceback (SisdAlignmentEngine::Convex backtrack), graph update ----
       if (lane == 0 && !g.overflow) {
         u32 naln = 0;
         if (sh.go) {
-          u32 const V = sh.V, W = sh.W;
+          u32 const V = sh.V;
           i32 max_score = kNegInf;
           u32 max_i = 0, max_j = 0;
           for (u32 r = 0; r < V; ++r) {
             if (g.nout[g.rank2node[r]] != 0) continue;
-            i32 const hv = H[static_cast<size_t>(r + 1) * W + L];
+            i32 const hv = d.h(r + 1, L);
             if (max_score < hv) {
               max_score = hv;
               max_i = r + 1;
@@ -459,19 +644,25 @@ __global__ __launch_bounds__(64) void k_msa(MsaArgs A) {
             }
           }
           u32 i = max_i, j = max_j, prev_i = 0, prev_j = 0;
-          u32 const aln_cap = ws.pnc + ws.max_l + 2;
-          while (!(i == 0 && j == 0) && !(max_i == 0 && max_j == 0)) {
-            size_t const ix = static_cast<size_t>(i) * W;
-            i32 const Hij = H[ix + j];
+          auto push = [&](bool has_node, u32 node, bool has_pos, u32 pos) {
+            if (naln + 1 >= aln_cap) {
+              g.overflow = true;
+              return;
+            }
+            aln[2 * naln] = has_node ? static_cast<u16>(node + 1) : 0;
+            aln[2 * naln + 1] = has_pos ? static_cast<u16>(pos + 1) : 0;
+            naln++;
+          };
+          while (!(i == 0 && j == 0) && !(max_i == 0 && max_j == 0) && !g.overflow) {
+            i32 const Hij = d.h(i, j);
             bool found = false, ext_left = false, ext_up = false;
+            u32 const node = i ? g.rank2node[i - 1] : 0u;
+            u32 const np = i ? g.nin[node] : 0u;
             if (i != 0 && j != 0) {
-              u8 const nch = g.nchar[g.rank2node[i - 1]];
-              i32 const mc = (nch == seq[j - 1]) ? M_ : N_;
-              u32 const p0 = row_pred0[i], p1 = row_pred0[i + 1];
-              u32 const np = p1 - p0;
+              i32 const mc = (g.nchar[node] == seq[j - 1]) ? M_ : N_;
               for (u32 x = 0; x < (np ? np : 1u); ++x) {
-                u32 const pi = np ? preds[p0 + x] : 0u;
-                if (Hij == H[static_cast<size_t>(pi) * W + (j - 1)] + mc) {
+                u32 const pi = np ? row_pred(g, node, x) : 0u;
+                if (Hij == d.h(pi, j - 1) + mc) {
                   prev_i = pi;
                   prev_j = j - 1;
                   found = true;
@@ -480,15 +671,13 @@ __global__ __launch_bounds__(64) void k_msa(MsaArgs A) {
               }
             }
             if (!found && i != 0) {
-              u32 const p0 = row_pred0[i], p1 = row_pred0[i + 1];
-              u32 const np = p1 - p0;
               for (u32 x = 0; x < (np ? np : 1u); ++x) {
-                u32 const pi = np ? preds[p0 + x] : 0u;
-                size_t const px = static_cast<size_t>(pi) * W + j;
-                bool ok = (ext_up |= (Hij == F[px] + E_));
-                if (!ok) ok = Hij == H[px] + G_;
-                if (!ok) ok = (ext_up |= (Hij == O[px] + C_));
-                if (!ok) ok = Hij == H[px] + Q_;
+                u32 const pi = np ? row_pred(g, node, x) : 0u;
+                i32 const hpj = d.h(pi, j);
+                bool ok = (ext_up |= (Hij == d.f(pi, j) + E_));
+                if (!ok) ok = Hij == hpj + G_;
+                if (!ok) ok = (ext_up |= (Hij == d.o(pi, j) + C_));
+                if (!ok) ok = Hij == hpj + Q_;
                 if (ok) {
                   prev_i = pi;
                   prev_j = j;
@@ -498,86 +687,71 @@ __global__ __launch_bounds__(64) void k_msa(MsaArgs A) {
               }
             }
             if (!found && j != 0) {
-              bool ok = (ext_left |= (Hij == E[ix + j - 1] + E_));
-              if (!ok) ok = Hij == H[ix + j - 1] + G_;
-              if (!ok) ok = (ext_left |= (Hij == Q[ix + j - 1] + C_));
-              if (!ok) ok = Hij == H[ix + j - 1] + Q_;
+              i32 const hl1 = d.h(i, j - 1);
+              bool ok = (ext_left |= (Hij == d.e(i, j - 1) + E_));
+              if (!ok) ok = Hij == hl1 + G_;
+              if (!ok) ok = (ext_left |= (Hij == d.q(i, j - 1) + C_));
+              if (!ok) ok = Hij == hl1 + Q_;
               if (ok) {
                 prev_i = i;
                 prev_j = j - 1;
                 found = true;
               }
             }
-            if (naln + 2 >= aln_cap) {
-              g.overflow = true;
-              break;
-            }
-            aln[2 * naln] = (i == prev_i) ? -1 : static_cast<i32>(g.rank2node[i - 1]);
-            aln[2 * naln + 1] = (j == prev_j) ? -1 : static_cast<i32>(j - 1);
-            naln++;
+            push(i != prev_i, node, j != prev_j, j - 1);
             i = prev_i;
             j = prev_j;
             if (ext_left) {
-              while (true) {
-                if (naln + 2 >= aln_cap) {
-                  g.overflow = true;
-                  break;
-                }
-                aln[2 * naln] = -1;
-                aln[2 * naln + 1] = static_cast<i32>(j - 1);
-                naln++;
+              while (!g.overflow) {
+                push(false, 0, true, j - 1);
                 --j;
-                size_t const rx = static_cast<size_t>(i) * W;
-                bool const e_stop = E[rx + j] + E_ != E[rx + j + 1];
-                bool const q_stop = Q[rx + j] + C_ != Q[rx + j + 1];
+                bool const e_stop = d.e(i, j) + E_ != d.e(i, j + 1);
+                bool const q_stop = d.q(i, j) + C_ != d.q(i, j + 1);
                 if (e_stop && q_stop) break;
               }
             } else if (ext_up) {
-              while (true) {
+              while (!g.overflow) {
                 bool stop = true;
                 prev_i = 0;
-                u32 const p0 = row_pred0[i], p1 = row_pred0[i + 1];
-                size_t const cx = static_cast<size_t>(i) * W + j;
-                for (u32 x = p0; x < p1; ++x) {
-                  size_t const px = static_cast<size_t>(preds[x]) * W + j;
-                  if (F[cx] == F[px] + E_ || O[cx] == O[px] + C_) {
-                    prev_i = preds[x];
+                u32 const nd2 = g.rank2node[i - 1];
+                u32 const np2 = g.nin[nd2];
+                i32 const fc = d.f(i, j), oc = d.o(i, j);
+                for (u32 x = 0; x < np2; ++x) {
+                  u32 const pr = row_pred(g, nd2, x);
+                  if (fc == d.f(pr, j) + E_ || oc == d.o(pr, j) + C_) {
+                    prev_i = pr;
                     stop = false;
                     break;
                   }
                 }
                 if (stop) {
-                  for (u32 x = p0; x < p1; ++x) {
-                    size_t const px = static_cast<size_t>(preds[x]) * W + j;
-                    if (F[cx] == H[px] + G_ || O[cx] == H[px] + Q_) {
-                      prev_i = preds[x];
+                  for (u32 x = 0; x < np2; ++x) {
+                    u32 const pr = row_pred(g, nd2, x);
+                    i32 const hp2 = d.h(pr, j);
+                    if (fc == hp2 + G_ || oc == hp2 + Q_) {
+                      prev_i = pr;
                       break;
                     }
                   }
                 }
-                if (naln + 2 >= aln_cap) {
-                  g.overflow = true;
-                  break;
-                }
-                aln[2 * naln] = static_cast<i32>(g.rank2node[i - 1]);
-                aln[2 * naln + 1] = -1;
-                naln++;
+                push(true, nd2, false, 0);
                 i = prev_i;
                 if (stop || i == 0) break;
               }
             }
-            if (g.overflow) break;
           }
           // std::reverse(alignment)
           for (u32 x = 0; x < naln / 2; ++x) {
-            i32 const a0 = aln[2 * x], a1 = aln[2 * x + 1];
+            u16 const a0 = aln[2 * x], a1 = aln[2 * x + 1];
             aln[2 * x] = aln[2 * (naln - 1 - x)];
             aln[2 * x + 1] = aln[2 * (naln - 1 - x) + 1];
             aln[2 * (naln - 1 - x)] = a0;
             aln[2 * (naln - 1 - x) + 1] = a1;
           }
         }
-        if (!g.overflow) pg_add_alignment(g, aln, naln, seq, L, tmp);
+        PROF_ACC(2);
+        if (!g.overflow) pg_add_alignment(g, aln, naln, seq, L);
+        PROF_ACC(3);
       }
       __syncthreads();
     }
@@ -588,8 +762,8 @@ __global__ __launch_bounds__(64) void k_msa(MsaArgs A) {
         overflow = true;
       } else if (g.nseq >= 2) {
         u32 const ns = g.nseq;
-        i32 active[32];
-        u32 hap_pos[32], starts[32];
+        i32 active[16];
+        u32 hap_pos[16], starts[16];
         for (u32 s = 0; s < ns; ++s) {
           active[s] = g.seq_first[s];
           hap_pos[s] = 0;
@@ -600,7 +774,7 @@ __global__ __launch_bounds__(64) void k_msa(MsaArgs A) {
         // raw allele strings live in tmp memory: [ns][cap]
         u32 const acap = 2 * ws.max_l + 8;
         u8* raw = reinterpret_cast<u8*>(H);  // DP matrices are free now
-        u32 rawlen[32];
+        u32 rawlen[16];
         auto converged = [&]() {
           for (u32 s = 1; s < ns; ++s)
             if (active[s] != active[0]) return false;
@@ -640,8 +814,8 @@ __global__ __launch_bounds__(64) void k_msa(MsaArgs A) {
               }
           }
           // group identical non-REF alleles (CreateNormalizedBubble); alt_of[s] = group id or -1
-          i32 alt_of[32];
-          u32 grp_rep[32];
+          i32 alt_of[16];
+          u32 grp_rep[16];
           u32 ngrp = 0;
           for (u32 s = 1; s < ns; ++s) {
             alt_of[s] = -1;
@@ -659,7 +833,7 @@ __global__ __launch_bounds__(64) void k_msa(MsaArgs A) {
           if (ngrp == 0) continue;
           // NormalizeVcfParsimony (variant_bubble.cpp:89-116): trims act on views [lo, hi) of the raw strings
           u32 rlo = 0, rhi = rawlen[0];
-          u32 glo[32], ghi[32];
+          u32 glo[16], ghi[16];
           for (u32 gi = 0; gi < ngrp; ++gi) {
             glo[gi] = 0;
             ghi[gi] = rawlen[grp_rep[gi]];
@@ -685,7 +859,7 @@ __global__ __launch_bounds__(64) void k_msa(MsaArgs A) {
             start_pos += init_len - (rhi - rlo);
           }
           // AssembleMultiallelicVariant: ALTs sorted by sequence (variant_extractor.cpp:229)
-          u32 ordg[32];
+          u32 ordg[16];
           for (u32 gi = 0; gi < ngrp; ++gi) {
             u32 jx = gi;
             while (jx > 0 && bytes_cmp(raw + grp_rep[ordg[jx - 1]] * acap + glo[ordg[jx - 1]], ghi[ordg[jx - 1]] - glo[ordg[jx - 1]],
@@ -713,7 +887,7 @@ __global__ __launch_bounds__(64) void k_msa(MsaArgs A) {
             A.o.var_hap_allele[vi * MH + hx] = 0;
             A.o.var_hap_start[vi * MH + hx] = 0;
           }
-          u32 rank_of_grp[32];
+          u32 rank_of_grp[16];
           for (u32 ai = 0; ai < ngrp; ++ai) {
             u32 const gi = ordg[ai];
             rank_of_grp[gi] = ai;
@@ -747,24 +921,31 @@ __global__ __launch_bounds__(64) void k_msa(MsaArgs A) {
   }
 }
 
+#ifdef MA_PROFILE
+extern "C" void ma_debug_prof(unsigned long long* out, int reset) {
+  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prof), sizeof(unsigned long long) * 16);
+  if (reset) {
+    unsigned long long z[16] = {0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, sizeof(z));
+  }
+}
+#endif
+
 int launch_msa(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& a, const ma_var_out_t& o) {
   int const n = b.n_windows;
   if (n == 0) return MA_OK;
   ma_params_t const& P = ctx->prm;
+  if (P.max_haps > 16) {
+    ctx->err = "ma_msa_batch: max_haps > 16 not supported (16-bit haplotype label masks)";
+    return MA_ERR_PARAM;
+  }
   PoaWs ws{};
-  ws.max_l = static_cast<u32>(P.max_hap_len);
-  ws.pnc = static_cast<u32>(2 * P.max_hap_len + 512);
-  if (const char* e = getenv("MA_POA_NODE_CAP")) ws.pnc = static_cast<u32>(atoi(e));
-  ws.pec = 2 * ws.pnc;
-  // DP rows are bounded by the node capacity; columns by the longest haplotype.  To keep the footprint
-  // proportional to the data, size the matrices from the batch's longest haplotype (one tiny D2H).
+  // longest haplotype of the batch decides the DP width and the LDS graph capacity (one small D2H)
   u32 max_len = 0;
   {
-    // hap_len is [n * max_haps]; a host-side max over a device array needs a copy
     size_t const cnt = static_cast<size_t>(n) * P.max_haps;
-    std::vector<u32> hl(cnt);
+    std::vector<u32> hl(cnt), st(n), nc(n), h0(static_cast<size_t>(n) * P.max_comps), nh(static_cast<size_t>(n) * P.max_comps);
     MA_HIP(ctx, hipMemcpyAsync(hl.data(), a.hap_len, cnt * 4, hipMemcpyDeviceToHost, ctx->stream));
-    std::vector<u32> st(n), nc(n), h0(static_cast<size_t>(n) * P.max_comps), nh(static_cast<size_t>(n) * P.max_comps);
     MA_HIP(ctx, hipMemcpyAsync(st.data(), a.win_status, 4ull * n, hipMemcpyDeviceToHost, ctx->stream));
     MA_HIP(ctx, hipMemcpyAsync(nc.data(), a.win_ncomp, 4ull * n, hipMemcpyDeviceToHost, ctx->stream));
     MA_HIP(ctx, hipMemcpyAsync(h0.data(), a.comp_hap0, 4ull * n * P.max_comps, hipMemcpyDeviceToHost, ctx->stream));
@@ -780,55 +961,45 @@ int launch_msa(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& a, const ma_var
   }
   max_len = std::max<u32>(max_len, 16);
   ws.max_l = max_len;
-  u32 const rows_cap = std::min<u32>(ws.pnc, 2 * max_len + 256) + 1;
-  ws.cells = static_cast<size_t>(rows_cap) * (max_len + 1);
+  u32 pn = max_len + std::max<u32>(256, max_len / 4);
+  if (const char* e = getenv("MA_POA_NODE_CAP")) pn = static_cast<u32>(atoi(e));
+  pn = std::min<u32>((pn + 7) & ~7u, 65000);
+  // LDS: 6 B + 16 * 2 B + 2 * 2 B + 4 * 2 B per node, + alignment path
+  auto lds_bytes = [&](u32 p) { return size_t(6) * p + size_t(2) * (4 * kPE * p + 2 * p + 4 * p + 8) + size_t(4) * (p + max_len + 2) + 64; };
+  while (lds_bytes(pn) > 156 * 1024 && pn > max_len + 32) pn -= 8;
+  ws.pn = pn;
+  size_t const lds = lds_bytes(pn);
+  ws.cw_max = ((max_len + 63) / 64 + 3) & ~3u;
+  ws.cells = static_cast<size_t>(pn + 66) * 64 * ws.cw_max;
   if (ws.cells < static_cast<size_t>(P.max_haps) * (2 * max_len + 8) / 4 + 64)  // raw-allele scratch lives in H
     ws.cells = static_cast<size_t>(P.max_haps) * (2 * max_len + 8) / 4 + 64;
 
-  auto carve = [&](char* base, size_t A, PoaWs& g) -> size_t {
-    size_t off = 0;
-    auto take = [&](size_t bytes) {
-      off = (off + 255) & ~size_t(255);
-      char* p = base ? base + off : nullptr;
-      off += bytes;
-      return p;
-    };
-    size_t const NC = g.pnc, EC = g.pec;
-    g.nchar = reinterpret_cast<u8*>(take(A * NC));
-    g.nin = reinterpret_cast<u8*>(take(A * NC));
-    g.nout = reinterpret_cast<u8*>(take(A * NC));
-    g.nal = reinterpret_cast<u8*>(take(A * NC));
-    g.in_e = reinterpret_cast<u32*>(take(A * NC * kPIn * 4));
-    g.out_e = reinterpret_cast<u32*>(take(A * NC * kPIn * 4));
-    g.al = reinterpret_cast<u32*>(take(A * NC * kPAl * 4));
-    g.e_tail = reinterpret_cast<u32*>(take(A * EC * 4));
-    g.e_head = reinterpret_cast<u32*>(take(A * EC * 4));
-    g.e_lab = reinterpret_cast<u32*>(take(A * EC * 4));
-    g.rank2node = reinterpret_cast<u32*>(take(A * NC * 4));
-    g.node2rank = reinterpret_cast<u32*>(take(A * NC * 4));
-    g.row_pred0 = reinterpret_cast<u32*>(take(A * (NC + 2) * 4));
-    g.preds = reinterpret_cast<u32*>(take(A * EC * 4));
-    g.tmp = reinterpret_cast<u32*>(take(A * NC * 5 * 4));
-    g.aln = reinterpret_cast<i32*>(take(A * 2 * (NC + g.max_l + 2) * 4));
-    g.H = reinterpret_cast<i32*>(take(A * g.cells * 4));
-    g.F = reinterpret_cast<i32*>(take(A * g.cells * 4));
-    g.E = reinterpret_cast<i32*>(take(A * g.cells * 4));
-    g.O = reinterpret_cast<i32*>(take(A * g.cells * 4));
-    g.Q = reinterpret_cast<i32*>(take(A * g.cells * 4));
-    return off;
-  };
-  PoaWs probe = ws;
-  size_t const per_window = carve(nullptr, 1, probe) + 4096;
+  size_t const per_window = 5 * ws.cells * 4 + 5 * (static_cast<size_t>(pn) + 2) * 4 + 8192;
   size_t budget = size_t(24) << 30;
+  {
+    size_t free_b = 0, total_b = 0;  // size the in-flight window count for the GPU's HBM (288 GB on MI355X)
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
+      budget = static_cast<size_t>(static_cast<double>(free_b + ctx->ws_poa.cap) * 0.55);
+  }
   if (const char* e = getenv("MA_WS_GB")) budget = static_cast<size_t>(atoi(e)) << 30;
   int const chunk = static_cast<int>(std::max<size_t>(1, std::min<size_t>(n, budget / per_window)));
   MA_HIP(ctx, ctx->ws_poa.reserve(per_window * static_cast<size_t>(chunk)));
+  if (lds > 65536)
+    MA_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_msa), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    static_cast<int>(lds)));
   for (int win0 = 0; win0 < n; win0 += chunk) {
     int const nwin = std::min(chunk, n - win0);
-    carve(static_cast<char*>(ctx->ws_poa.p), static_cast<size_t>(nwin), ws);
+    char* base = static_cast<char*>(ctx->ws_poa.p);
+    size_t const msz = (static_cast<size_t>(nwin) * ws.cells * 4 + 255) & ~size_t(255);
+    ws.H = reinterpret_cast<i32*>(base);
+    ws.F = reinterpret_cast<i32*>(base + msz);
+    ws.E = reinterpret_cast<i32*>(base + 2 * msz);
+    ws.O = reinterpret_cast<i32*>(base + 3 * msz);
+    ws.Q = reinterpret_cast<i32*>(base + 4 * msz);
+    ws.C0 = reinterpret_cast<i32*>(base + 5 * msz);
     MsaArgs args{b, a, o, ws, P, win0};
     ctx->tic("k_msa");
-    hipLaunchKernelGGL(k_msa, dim3(nwin), dim3(64), 0, ctx->stream, args);
+    hipLaunchKernelGGL(k_msa, dim3(nwin), dim3(64), lds, ctx->stream, args);
     ctx->toc();
     MA_HIP(ctx, hipGetLastError());
   }
