@@ -262,6 +262,70 @@ __global__ __launch_bounds__(256) void k_vote(GArgs A, u32 hist_len) {
   if (lane == 0) A.ws.centre[lp] = best == 0 ? 0x7FFFFFFF : (bd - m);
 }
 
+// traceback shared by both alignment kernels (rules of oracle/align.cpp: diagonal, then E, then F;
+// prefer opening a gap) + BuildCigar (genotyper.cpp:45-69)
+__device__ void align_traceback(GArgs const& A, const u32* tb, int lane, i32 B, i32 c, i32 m, i32 best, i32 bi, i32 bj,
+                                i32* arec, u32* acig) {
+  int const MCG = A.prm.max_cigar;
+  u32 ops[64];   // reversed run-length ops, len << 4 | op
+  int nops = 0;
+  u32 total_ops = 0;
+  auto push = [&](u32 op) {
+    if (nops > 0 && (ops[nops - 1] & 0xFu) == op && nops <= 64) {
+      ops[nops - 1] += 16u;
+    } else {
+      total_ops++;
+      if (nops < 64) ops[nops++] = (1u << 4) | op; else nops = 65;  // overflow marker
+    }
+  };
+  i32 i = bi, j = bj;
+  int state = 0;
+  while (true) {
+    if (state == 0 && (i == 0 || j == 0)) break;
+    i32 const t = j - i - c + B;
+    u32 const wv = tb[(static_cast<size_t>(i) * A.ws.tb_words + (t >> 3)) * 64 + lane];
+    u32 const nib = (wv >> (4 * (t & 7))) & 0xFu;
+    if (state == 0) {
+      u32 const src = nib & 3u;
+      if (src == 0) {
+        push(0);
+        --i;
+        --j;
+      } else {
+        state = src == 1 ? 1 : 2;
+      }
+    } else if (state == 1) {
+      push(2);  // D
+      --j;
+      if (nib & 4u) state = 0;
+    } else {
+      push(1);  // I
+      --i;
+      if (nib & 8u) state = 0;
+    }
+  }
+  i32 const qs = i, rs = j, qe = bi, re = bj;
+  arec[0] = 1;
+  arec[1] = best;
+  arec[2] = rs;
+  arec[3] = re;
+  arec[4] = qs;
+  arec[5] = qe;
+  // BuildCigar (genotyper.cpp:45-69): S(qs) + core + S(qlen - qe); ops were collected reversed
+  u32 ncig = 0, widx = 0;
+  auto emit = [&](u32 v) {
+    if (static_cast<int>(widx) < MCG) acig[1 + widx] = v;
+    widx++;
+    ncig++;
+  };
+  if (qs > 0) emit((static_cast<u32>(qs) << 4) | 4u);
+  int const kept = nops > 64 ? 64 : nops;
+  for (int x = kept - 1; x >= 0; --x) emit(ops[x]);
+  if (qe < m) emit((static_cast<u32>(m - qe) << 4) | 4u);
+  acig[0] = (nops > 64) ? (total_ops + (qs > 0) + (qe < m)) : ncig;
+}
+
+
 // ---- banded overlap DP + traceback: one lane per pair ----
 __global__ __launch_bounds__(64) void k_align(GArgs A, u32 seg_words) {
   extern __shared__ u32 lds[];
@@ -382,63 +446,153 @@ __global__ __launch_bounds__(64) void k_align(GArgs A, u32 seg_words) {
     acig[0] = 0;
     return;
   }
-  // traceback (rules of oracle/align.cpp: diagonal, then E, then F; prefer opening a gap)
-  u32 ops[64];   // reversed run-length ops, len << 4 | op
-  int nops = 0;
-  u32 total_ops = 0;
-  auto push = [&](u32 op) {
-    if (nops > 0 && (ops[nops - 1] & 0xFu) == op && nops <= 64) {
-      ops[nops - 1] += 16u;
-    } else {
-      total_ops++;
-      if (nops < 64) ops[nops++] = (1u << 4) | op; else nops = 65;  // overflow marker
-    }
-  };
-  i32 i = bi, j = bj;
-  int state = 0;
-  while (true) {
-    if (state == 0 && (i == 0 || j == 0)) break;
-    i32 const t = j - i - c + B;
-    u32 const wv = tb[(static_cast<size_t>(i) * A.ws.tb_words + (t >> 3)) * 64 + lane];
-    u32 const nib = (wv >> (4 * (t & 7))) & 0xFu;
-    if (state == 0) {
-      u32 const src = nib & 3u;
-      if (src == 0) {
-        push(0);
-        --i;
-        --j;
-      } else {
-        state = src == 1 ? 1 : 2;
+  align_traceback(A, tb, lane, B, c, m, best, bi, bj, arec, acig);
+}
+
+// ---- register-resident variant of k_align for the default band (B = 64) ----
+// The (H,F) band row lives in 2B+2 VGPRs (packed i16x2) and the row body is fully unrolled, so the
+// inner loop is pure VALU: no LDS round trip for the DP state, ~2 waves per SIMD.  The haplotype
+// segment (4 bit/base, with wall codes 6 = "column 0", 7 = "outside the haplotype") stays in LDS and
+// is re-aligned once per row with funnel shifts.  Same cell rules, tie rules and outputs as k_align.
+constexpr i32 NEGR = -20000;
+template <int B>
+__global__ __launch_bounds__(64) void k_align_reg(GArgs A, u32 seg_words) {
+  extern __shared__ u32 lds[];
+  constexpr int WD = 2 * B + 1;
+  constexpr int NW = (WD + 7) / 8;  // traceback / segment words per row
+  int const lane = threadIdx.x;
+  u32* SEG = lds;  // [seg_words][64]
+  u64 const lp = static_cast<u64>(blockIdx.x) * 64 + lane;
+  bool const live = lp < A.npairs;
+  PairId id{0, 0, 0};
+  i32 m = 0, n = 0, c = 0;
+  const u8* rb = nullptr;
+  const u8* hb = nullptr;
+  bool active = false;
+  if (live) {
+    id = pair_decode(A, A.pair0 + lp);
+    size_t const hi = static_cast<size_t>(id.w) * A.prm.max_haps + id.slot;
+    n = static_cast<i32>(A.a.hap_len[hi]);
+    hb = A.a.hap_bases + hi * A.prm.max_hap_len;
+    u64 const ro = A.b.read_off[id.r];
+    m = static_cast<i32>(A.b.read_off[id.r + 1] - ro);
+    rb = A.b.read_bases + ro;
+    c = A.ws.centre[lp];
+    active = c != 0x7FFFFFFF && m >= SK && n >= SK && static_cast<u32>(m) + 1 <= A.ws.tb_rows;
+  }
+  i32 const mrows = active ? m : 0;
+  i32 mmax = mrows;
+  for (int off = 32; off > 0; off >>= 1) mmax = max(mmax, __shfl_xor(mmax, off));
+
+  u32 HF[WD + 1];  // packed (H lo16, F hi16) of the previous row; HF[WD] = sentinel
+  i32 const j0 = c - B;  // hap base index of segment position 0
+  if (active) {
+    i32 const seglen = m + 2 * B + 1;
+    for (i32 wd = 0; wd * 8 < seglen + 8; ++wd) {
+      u32 pk = 0;
+      for (int x = 0; x < 8; ++x) {
+        i32 const hbidx = j0 + wd * 8 + x;
+        u32 const e = hbidx == -1 ? 6u : ((hbidx < -1 || hbidx >= n) ? 7u : enc_base(hb[hbidx]));
+        pk |= e << (4 * x);
       }
-    } else if (state == 1) {
-      push(2);  // D
-      --j;
-      if (nib & 4u) state = 0;
-    } else {
-      push(1);  // I
-      --i;
-      if (nib & 8u) state = 0;
+      if (static_cast<u32>(wd) < seg_words) SEG[static_cast<size_t>(wd) * 64 + lane] = pk;
     }
   }
-  i32 const qs = i, rs = j, qe = bi, re = bj;
-  arec[0] = 1;
-  arec[1] = best;
-  arec[2] = rs;
-  arec[3] = re;
-  arec[4] = qs;
-  arec[5] = qe;
-  // BuildCigar (genotyper.cpp:45-69): S(qs) + core + S(qlen - qe); ops were collected reversed
-  u32 ncig = 0, widx = 0;
-  auto emit = [&](u32 v) {
-    if (static_cast<int>(widx) < MCG) acig[1 + widx] = v;
-    widx++;
-    ncig++;
-  };
-  if (qs > 0) emit((static_cast<u32>(qs) << 4) | 4u);
-  int const kept = nops > 64 ? 64 : nops;
-  for (int x = kept - 1; x >= 0; --x) emit(ops[x]);
-  if (qe < m) emit((static_cast<u32>(m - qe) << 4) | 4u);
-  acig[0] = (nops > 64) ? (total_ops + (qs > 0) + (qe < m)) : ncig;
+#pragma unroll
+  for (int t = 0; t <= WD; ++t) {
+    i32 const j = c - B + t;
+    i32 const h = (t < WD && j >= 0 && j <= n) ? 0 : NEGR;
+    HF[t] = (static_cast<u32>(h) & 0xFFFFu) | (static_cast<u32>(NEGR) << 16);
+  }
+  size_t const tb_base = static_cast<size_t>(blockIdx.x) * A.ws.tb_rows * A.ws.tb_words * 64;
+  u32* tb = A.ws.tb + tb_base;
+  i32 best = NEGR, bi = -1, bj = -1;
+  for (i32 i = 1; i <= mmax; ++i) {
+    if (i <= mrows) {
+      u32 const qi = enc_base(rb[i - 1]);
+      i32 const smis = qi > 3 ? -1 : -4;
+      u32 const qcmp = qi > 3 ? 15u : qi;  // never equal to a haplotype code when ambiguous
+      // segment words for rel = (i-1) .. (i-1)+WD, re-aligned so that cell t uses nibble t of sw[]
+      u32 const wbase = static_cast<u32>(i - 1) >> 3, sh = (static_cast<u32>(i - 1) & 7u) * 4u;
+      u32 sw[NW];
+      {
+        u32 prev = SEG[static_cast<size_t>(wbase) * 64 + lane];
+#pragma unroll
+        for (int k = 0; k < NW; ++k) {
+          u32 const nx = SEG[static_cast<size_t>(wbase + k + 1) * 64 + lane];
+          sw[k] = sh ? ((prev >> sh) | (nx << (32u - sh))) : prev;
+          prev = nx;
+        }
+      }
+      i32 lh = NEGR, le = NEGR, last_h = NEGR;
+      u32 word = 0;
+      u32* tbrow = tb + static_cast<size_t>(i) * A.ws.tb_words * 64 + lane;
+#pragma unroll
+      for (int t = 0; t < WD; ++t) {
+        u32 const code = (sw[t >> 3] >> (4 * (t & 7))) & 0xFu;
+        i32 const dh = static_cast<i16>(HF[t] & 0xFFFFu);
+        i32 const uh = static_cast<i16>(HF[t + 1] & 0xFFFFu), uf = static_cast<i32>(HF[t + 1]) >> 16;
+        i32 const s = code > 3 ? -1 : (code == qcmp ? 1 : smis);
+        i32 const dg = dh + s;
+        i32 const eo = lh - (GO + GE), ee = le - GE;
+        i32 const fo = uh - (GO + GE), fe = uf - GE;
+        i32 e = max(eo, ee), f = max(fo, fe);
+        i32 h = max(dg, max(e, f));
+        u32 nib = (dg >= e && dg >= f) ? 0u : (e >= f ? 1u : 2u);
+        nib |= (eo >= ee ? 4u : 0u) | (fo >= fe ? 8u : 0u);
+        bool const wall = code >= 6;
+        h = wall ? (code == 6 ? 0 : NEGR) : h;
+        e = wall ? NEGR : e;
+        f = wall ? NEGR : f;
+        HF[t] = (static_cast<u32>(h) & 0xFFFFu) | (static_cast<u32>(f) << 16);
+        lh = h;
+        le = e;
+        last_h = code == 7 ? last_h : h;
+        word |= nib << (4 * (t & 7));
+        if ((t & 7) == 7 || t == WD - 1) {
+          tbrow[static_cast<size_t>(t >> 3) * 64] = word;
+          word = 0;
+        }
+      }
+      // end cell (i, n) for i < m: the last in-haplotype cell of the row is column n iff the band reaches it
+      if (i < mrows && i + c + B >= n && i + c - B <= n) {
+        if (last_h >= best) {  // later rows win ties (larger i)
+          best = last_h;
+          bi = i;
+          bj = n;
+        }
+      }
+    }
+  }
+  // end cells (m, j): scan the final row left to right (smaller j wins ties; row m beats earlier rows on ties)
+  if (active) {
+    bool first = true;
+#pragma unroll
+    for (int t = 0; t < WD; ++t) {
+      i32 const j = mrows + c - B + t;
+      i32 const h = static_cast<i16>(HF[t] & 0xFFFFu);
+      if (j >= 0 && j <= n) {
+        if (h > best || (first && h == best)) {
+          best = h;
+          bi = mrows;
+          bj = j;
+        }
+        if (h >= best) first = false;
+      }
+    }
+  }
+  if (!live) return;
+  int const MH = A.prm.max_haps, MCG = A.prm.max_cigar;
+  size_t const rec = (static_cast<size_t>(id.r) * MH + id.slot);
+  i32* arec = A.o.aln_rec + rec * 6;
+  u32* acig = A.o.aln_cigar + rec * (1 + MCG);
+  bool const hit = active && bi >= 0 && best >= A.prm.min_aln_score;
+  if (!hit) {
+    for (int x = 0; x < 6; ++x) arec[x] = 0;
+    acig[0] = 0;
+    return;
+  }
+  align_traceback(A, tb, lane, B, c, m, best, bi, bj, arec, acig);
 }
 
 // ---- scoring epilogue ----
@@ -853,6 +1007,13 @@ int launch_genotype(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& a, const m
       ctx->tic("k_vote");
       hipLaunchKernelGGL(k_vote, dim3((A.npairs + 3) / 4), dim3(256), 4ull * hist_len * 2, ctx->stream, A, hist_len);
       ctx->toc();
+      if (P.band == 64) {
+        ctx->tic("k_align_reg");
+        hipLaunchKernelGGL(k_align_reg<64>, dim3(static_cast<u32>(ng)), dim3(64), static_cast<size_t>(seg_words + 2) * 64 * 4,
+                           ctx->stream, A, seg_words + 2);
+        ctx->toc();
+        continue;
+      }
       ctx->tic("k_align");
       if (lds_align > 65536)
         MA_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_align),
