@@ -1,0 +1,115 @@
+"""CPU tests: the oracle reproduces the committed golden vectors, the synthetic generator is
+deterministic, and the multi-GPU sharding path (gloo, world_size 2) covers every window exactly once."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from harness import OracleEngine, compare_asm, compare_geno, compare_vars
+from lancet2_amd import capi, shard, synth
+
+GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
+
+
+def load_golden(path):
+    z = np.load(path)
+    meta = z["meta"]
+    n, nr = int(meta[0]), int(meta[1])
+    params = capi.Params(*[int(x) for x in meta[2:]])
+    arrs = {k[3:]: z[k] for k in z.files if k.startswith("in_")}
+    outs = {pref: {k[len(pref) + 1:]: z[k] for k in z.files if k.startswith(pref + "_")} for pref in ("gate", "asm", "var", "geno")}
+    return params, arrs, n, nr, outs
+
+
+@pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p) for p in GOLDEN])
+def test_oracle_matches_golden(path):
+    params, arrs, n, nr, want = load_golden(path)
+    orc = OracleEngine(params)
+    g = orc.gate(arrs, n, nr)
+    assert np.array_equal(g["max_approx"], want["gate"]["max_approx"])
+    assert np.array_equal(g["max_exact"], want["gate"]["max_exact"])
+    a = orc.assemble(arrs, n, nr)
+    assert not compare_asm(params, a, want["asm"], n)
+    v = orc.msa(arrs, n, nr, a)
+    assert not compare_vars(params, v, want["var"], n)
+    q = orc.genotype(arrs, n, nr, a, v)
+    assert not compare_geno(params, q, want["geno"], n, nr, v["win_nvars"], arrs["read_win_off"])
+
+
+def test_golden_vectors_are_nontrivial():
+    assert len(GOLDEN) >= 4
+    tot_vars = 0
+    for p in GOLDEN:
+        _, _, n, nr, want = load_golden(p)
+        tot_vars += int(want["var"]["win_nvars"].sum())
+        assert (want["asm"]["win_ncomp"] > 0).any()
+    assert tot_vars >= 8
+
+
+def test_generator_is_deterministic():
+    a1, n1, r1 = synth.make_config_batch("C1", 2, first_index=77)
+    a2, n2, r2 = synth.make_config_batch("C1", 2, first_index=77)
+    assert n1 == n2 and r1 == r2 and all(np.array_equal(a1[k], a2[k]) for k in a1)
+    # collector order (core/read_collector.cpp:42-53): pass-filter first, then role, sample, qname
+    flags = a1["read_flags"][: int(a1["read_win_off"][1])]
+    passf = (flags & capi.MA_RF_PASS) > 0
+    assert not (np.diff(passf.astype(int)) > 0).any()
+
+
+def test_tile_batch_offsets():
+    arrs, n, nr = synth.make_config_batch("C1", 2, first_index=5, depths=(4, 4))
+    t, tn, tnr = synth.tile_batch(arrs, n, nr, 3)
+    assert tn == 3 * n and tnr == 3 * nr
+    assert t["ref_off"][-1] == 3 * arrs["ref_off"][-1] and t["read_off"][-1] == 3 * arrs["read_off"][-1]
+    for rep in range(3):
+        lo, hi = int(t["ref_off"][rep * n]), int(t["ref_off"][rep * n + 1])
+        assert np.array_equal(t["ref_bases"][lo:hi], arrs["ref_bases"][: int(arrs["ref_off"][1])])
+
+
+def test_shard_indices_cover_every_window_once():
+    for n, world in ((10, 1), (10, 2), (17, 4), (3, 8)):
+        seen = sorted(i for r in range(world) for i in shard.shard_indices(n, r, world))
+        assert seen == list(range(n))
+        per_rank = [[f"w{i}" for i in shard.shard_indices(n, r, world)] for r in range(world)]
+        assert shard.merge_shards(per_rank, n, world) == [f"w{i}" for i in range(n)]
+
+
+def _gloo_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    try:
+        n = 5
+        mine = shard.shard_indices(n, rank, world)
+        params = capi.default_params(min_k=25, max_k=25)
+        wins = [synth.make_window(3000 + i, W=600, depths=(12, 12)) for i in mine]
+        arrs, nw, nr = synth.pack_batch(wins)
+        asm = OracleEngine(params).assemble(arrs, nw, nr)
+        ks = [int(k) for k in asm["win_k"]]
+        t = shard.max_over_ranks(float(rank + 1), dist)  # max over ranks -> world
+        gathered = [None] * world
+        dist.all_gather_object(gathered, (mine, ks))
+        q.put((rank, t, gathered))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gloo_sharding():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 1000)
+    procs = [ctx.Process(target=_gloo_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, t, gathered in res:
+        assert t == 2.0
+        covered = sorted(i for mine, _ in gathered for i in mine)
+        assert covered == list(range(5))
+        assert all(k == 25 for _, ks in gathered for k in ks)

@@ -164,3 +164,63 @@ def test_process_batch_end_to_end():
     assert not compare_vars(params, v, wv, n)
     bad = compare_geno(params, q, wq, n, nr, wv["win_nvars"], arrs["read_win_off"])
     assert not bad, "\n".join(bad[:20])
+
+
+import glob  # noqa: E402
+import os  # noqa: E402
+
+_GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
+
+
+@pytest.mark.parametrize("path", _GOLDEN, ids=[os.path.basename(p) for p in _GOLDEN])
+def test_hip_path_matches_golden(path):
+    """The committed fixtures (inputs + expected outputs of every stage) through ma_process_batch."""
+    from lancet2_amd.engine import Engine
+    from test_golden_and_shard import load_golden
+    params, arrs, n, nr, want = load_golden(path)
+    eng = Engine(params)
+    try:
+        g, a, v, q = eng.process(arrs, n, nr, debug=True)
+    finally:
+        eng.close()
+    assert np.array_equal(g["max_approx"], want["gate"]["max_approx"])
+    assert not compare_asm(params, a, want["asm"], n)
+    assert not compare_vars(params, v, want["var"], n)
+    bad = compare_geno(params, q, want["geno"], n, nr, want["var"]["win_nvars"], arrs["read_win_off"])
+    assert not bad, "\n".join(bad[:10])
+
+
+def test_full_size_properties():
+    """BASELINE-sized batch (C2, 1024 windows): size-independent properties instead of an oracle run --
+    tiling invariance (every replica of a window yields identical results), REF haplotype == reference
+    anchor substring, read-support conservation (allele counts never exceed the reads of the sample)."""
+    from lancet2_amd.engine import Engine
+    params = capi.default_params(min_k=25, max_k=25)
+    base, n0, nr0 = synth.make_config_batch("C2", 16, first_index=4000)
+    arrs, n, nr = synth.tile_batch(base, n0, nr0, 64)
+    eng = Engine(params)
+    try:
+        g, a, v, q = eng.process(arrs, n, nr, debug=False)
+    finally:
+        eng.close()
+    MH, ML, MC, MV = params.max_haps, params.max_hap_len, params.max_comps, params.max_vars
+    S, NA = params.num_samples, params.max_alts + 1
+    for name in ("win_status", "win_k", "win_ncomp"):
+        x = a[name].reshape(64, n0)
+        assert (x == x[0]).all(), name
+    assert (v["win_nvars"].reshape(64, n0) == v["win_nvars"][:n0]).all()
+    cnt = q["allele_counts"].reshape(64, -1)
+    assert (cnt == cnt[0]).all()
+    assert (a["win_ncomp"] > 0).mean() > 0.8
+    reads_per_win = np.diff(arrs["read_win_off"].astype(np.int64))
+    for w in range(n0):
+        if a["win_ncomp"][w] == 0:
+            continue
+        ci = w * MC
+        hi = w * MH + int(a["comp_hap0"][ci])
+        L = int(a["hap_len"][hi])
+        anchor = int(a["comp_anchor"][ci])
+        ref = arrs["ref_bases"][int(arrs["ref_off"][w]): int(arrs["ref_off"][w + 1])]
+        assert np.array_equal(a["hap_bases"][hi * ML: hi * ML + L], ref[anchor: anchor + L])
+        per_var = q["allele_counts"][w * MV * S * NA * 2:(w + 1) * MV * S * NA * 2].reshape(MV, -1).sum(axis=1)
+        assert per_var.max() <= reads_per_win[w]
