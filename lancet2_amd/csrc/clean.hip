@@ -418,7 +418,7 @@ struct CleanArgs {
   ma_params_t prm;
 };
 
-__global__ __launch_bounds__(64) void k_clean(CleanArgs A) {
+__global__ __launch_bounds__(64, 8) void k_clean(CleanArgs A) {
   if (threadIdx.x != 0) return;  // canonical serial order: lane 0 drives the window
   int const a = blockIdx.x;
   GraphWs const& ws = A.ws;
