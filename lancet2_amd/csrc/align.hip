@@ -65,6 +65,8 @@ struct AlnWs {
   u32* idx_code;       // [n * MH][max_hap_len] (0xFFFFFFFF = no valid 11-mer)
   // per pair
   i32* centre;         // [pairs in chunk]
+  u32* dp_list;        // [pairs in chunk] pairs that need the DP (compacted by k_vote)
+  u32* dp_count;       // device counter
   u32* tb;             // traceback nibbles
   u32 tb_words;        // words per row
   u32 tb_rows;         // rows per pair (max read len + 1)
@@ -259,7 +261,60 @@ __global__ __launch_bounds__(256) void k_vote(GArgs A, u32 hist_len) {
       bd = od;
     }
   }
-  if (lane == 0) A.ws.centre[lp] = best == 0 ? 0x7FFFFFFF : (bd - m);
+  best = __shfl(best, 0);
+  bd = __shfl(bd, 0);
+  if (best == 0) {  // no shared 11-mer: no hit (record stays zero)
+    if (lane == 0) A.ws.centre[lp] = 0x7FFFFFFF;
+    return;
+  }
+  i32 const c = bd - m;
+  // ---- gapless certificate --------------------------------------------------------------------------
+  // If the read lies fully inside the haplotype on the voted diagonal (no overhang), has X <= 2
+  // mismatches and no ambiguous base there, and no other diagonal collected >= m - 10 - 11 X votes, then
+  // the gapless alignment is the UNIQUE optimum of the canonical banded overlap DP:
+  //   * any path with g >= 1 gaps scores <= m - 15 g - 5 X' < m - 5 X   (15 g <= 5 X <= 10 is impossible);
+  //   * a gapless path on another diagonal d' scoring >= m - 5 X has X' <= X mismatches over >= m - 5X + 5X'
+  //     bases, hence >= m - 10 - 11 X exact 11-mers, i.e. that many votes -- excluded by the vote bound.
+  // So (score, rs, re, CIGAR = mM) can be written without running the DP.  Everything else goes to k_align.
+  u32 v2 = 0;
+  for (i32 x = lane; x < nd; x += 64)
+    if (x != bd) v2 = max(v2, static_cast<u32>(hist[x]));
+  for (int off = 32; off > 0; off >>= 1) v2 = max(v2, __shfl_xor(v2, off));
+  bool const inside = c >= 0 && c + m <= n;
+  u32 mism = 0, amb = 0;
+  if (inside) {
+    const u8* hb = A.a.hap_bases + hi * A.prm.max_hap_len;
+    for (i32 i = lane; i < m; i += 64) {
+      u32 const qe = enc_base(rb[i]), te = enc_base(hb[c + i]);
+      amb |= (qe > 3 || te > 3) ? 1u : 0u;
+      mism += qe != te;
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    mism += __shfl_xor(mism, off);
+    amb |= __shfl_xor(amb, off);
+  }
+  bool const fast = inside && !amb && mism <= 2 && static_cast<i32>(v2) + 10 + 11 * static_cast<i32>(mism) < m &&
+                    m - 5 * static_cast<i32>(mism) >= A.prm.min_aln_score && m < (1 << 27);
+  if (lane == 0) {
+    if (fast) {
+      size_t const rec = static_cast<size_t>(id.r) * A.prm.max_haps + id.slot;
+      i32* arec = A.o.aln_rec + rec * 6;
+      u32* acig = A.o.aln_cigar + rec * (1 + A.prm.max_cigar);
+      arec[0] = 1;
+      arec[1] = m - 5 * static_cast<i32>(mism);
+      arec[2] = c;
+      arec[3] = c + m;
+      arec[4] = 0;
+      arec[5] = m;
+      acig[0] = 1;
+      acig[1] = static_cast<u32>(m) << 4;
+      A.ws.centre[lp] = 0x7FFFFFFE;
+    } else {
+      A.ws.centre[lp] = c;
+      A.ws.dp_list[atomicAdd(A.ws.dp_count, 1u)] = static_cast<u32>(lp);
+    }
+  }
 }
 
 // traceback shared by both alignment kernels (rules of oracle/align.cpp: diagonal, then E, then F;
@@ -333,8 +388,9 @@ __global__ __launch_bounds__(64) void k_align(GArgs A, u32 seg_words) {
   i32 const B = A.ws.band, WD = 2 * B + 1;
   u32* HF = lds;                                 // [WD + 1][64] packed (H lo16, F hi16)
   u32* SEG = lds + static_cast<size_t>(WD + 1) * 64;  // [seg_words][64] haplotype segment, 4 bit/base
-  u64 const lp = static_cast<u64>(blockIdx.x) * 64 + lane;
-  bool const live = lp < A.npairs;
+  u64 const li = static_cast<u64>(blockIdx.x) * 64 + lane;
+  bool const live = li < *A.ws.dp_count;
+  u64 const lp = live ? A.ws.dp_list[li] : 0;
   PairId id{0, 0, 0};
   i32 m = 0, n = 0, c = 0;
   const u8* rb = nullptr;
@@ -462,8 +518,9 @@ __global__ __launch_bounds__(64) void k_align_reg(GArgs A, u32 seg_words) {
   constexpr int NW = (WD + 7) / 8;  // traceback / segment words per row
   int const lane = threadIdx.x;
   u32* SEG = lds;  // [seg_words][64]
-  u64 const lp = static_cast<u64>(blockIdx.x) * 64 + lane;
-  bool const live = lp < A.npairs;
+  u64 const li = static_cast<u64>(blockIdx.x) * 64 + lane;
+  bool const live = li < *A.ws.dp_count;
+  u64 const lp = live ? A.ws.dp_list[li] : 0;
   PairId id{0, 0, 0};
   i32 m = 0, n = 0, c = 0;
   const u8* rb = nullptr;
@@ -994,19 +1051,27 @@ int launch_genotype(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& a, const m
     if (const char* e = getenv("MA_TB_GB")) budget = static_cast<size_t>(atoi(e)) << 30;
     u64 const groups_total = (total_pairs + 63) / 64;
     u64 const groups_chunk = std::max<u64>(1, std::min<u64>(groups_total, budget / tb_per_group));
-    MA_HIP(ctx, ctx->ws_misc.reserve(groups_chunk * tb_per_group + groups_chunk * 64 * 4 + 4096));
+    MA_HIP(ctx, ctx->ws_misc.reserve(groups_chunk * tb_per_group + groups_chunk * 64 * 8 + 8192));
     ws.tb = ctx->ws_misc.as<u32>();
     ws.centre = reinterpret_cast<i32*>(reinterpret_cast<char*>(ctx->ws_misc.p) + groups_chunk * tb_per_group);
+    ws.dp_list = reinterpret_cast<u32*>(ws.centre + groups_chunk * 64);
+    ws.dp_count = ws.dp_list + groups_chunk * 64 + 16;
     u32 const hist_len = ((max_read_len + static_cast<u32>(P.max_hap_len) + 2 + 1) & ~1u);
     u32 const seg_words = (max_read_len + 2 * P.band + 1 + 7) / 8 + 1;
     size_t const lds_align = (static_cast<size_t>(2 * P.band + 2) * 64 + static_cast<size_t>(seg_words) * 64) * 4;
     for (u64 g0 = 0; g0 < groups_total; g0 += groups_chunk) {
-      u64 const ng = std::min<u64>(groups_chunk, groups_total - g0);
+      u64 ng = std::min<u64>(groups_chunk, groups_total - g0);
       A.pair0 = g0 * 64;
       A.npairs = static_cast<u32>(std::min<u64>(ng * 64, total_pairs - A.pair0));
+      MA_HIP(ctx, hipMemsetAsync(ws.dp_count, 0, 4, ctx->stream));
       ctx->tic("k_vote");
       hipLaunchKernelGGL(k_vote, dim3((A.npairs + 3) / 4), dim3(256), 4ull * hist_len * 2, ctx->stream, A, hist_len);
       ctx->toc();
+      u32 ndp = 0;
+      MA_HIP(ctx, hipMemcpyAsync(&ndp, ws.dp_count, 4, hipMemcpyDeviceToHost, ctx->stream));
+      MA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      if (ndp == 0) continue;
+      ng = (ndp + 63) / 64;
       if (P.band == 64) {
         ctx->tic("k_align_reg");
         hipLaunchKernelGGL(k_align_reg<64>, dim3(static_cast<u32>(ng)), dim3(64), static_cast<size_t>(seg_words + 2) * 64 * 4,
