@@ -44,12 +44,22 @@ struct PoaWs {
   i32* C0;        // [w][5][pn + 2] column 0 of H, F, E, O, Q
 };
 
+// All graph arrays live in the kernel's dynamic LDS.  They are addressed as offsets into the
+// __shared__ array (NOT through generic pointers kept in a struct: those compile to flat_load + pointer
+// reloads from scratch instead of ds_read).
+extern __shared__ unsigned char ma_lds[];
+template <class T>
+struct LdsArr {
+  u32 off;  // byte offset into ma_lds
+  __device__ __forceinline__ T& operator[](u32 i) const { return *reinterpret_cast<T*>(&ma_lds[off + i * sizeof(T)]); }
+};
+
 struct PG {  // LDS-resident POA graph of one window
   u32 nn, nseq, nrank;
   u32 pn;
-  u8 *nchar, *nin, *nout, *nal, *marks, *ignored;
-  u16 *in_tail, *out_head, *out_lab, *al, *rank2node, *node2rank;
-  u16* stack;       // DFS stack; aliased by the column-0 DP values during alignment
+  LdsArr<u8> nchar, nin, nout, nal, marks, ignored;
+  LdsArr<u16> in_tail, out_head, out_lab, al, rank2node, node2rank;
+  LdsArr<u16> stack;  // DFS stack; aliased by the column-0 DP values during alignment
   u32 stack_cap;
   i32 seq_first[16];
   bool overflow;
@@ -102,7 +112,7 @@ __device__ i32 pg_successor(const PG& g, u32 node, u32 label) {  // spoa::Graph:
 __device__ void pg_toposort(PG& g) {
   for (u32 i = 0; i < g.nn; ++i) g.marks[i] = g.ignored[i] = 0;
   g.nrank = 0;
-  u16* stack = g.stack;
+  LdsArr<u16> const stack = g.stack;
   for (u32 s = 0; s < g.nn; ++s) {
     if (g.marks[s] != 0) continue;
     u32 sp = 0;
@@ -146,7 +156,7 @@ __device__ void pg_toposort(PG& g) {
 }
 
 // spoa::Graph::AddAlignment; aln pairs are (node id + 1 | 0, seq pos + 1 | 0) in LDS
-__device__ void pg_add_alignment(PG& g, const u16* aln, u32 naln, const u8* seq, u32 len) {
+__device__ void pg_add_alignment(PG& g, LdsArr<u16> aln, u32 naln, const u8* seq, u32 len) {
   if (len == 0) return;
   if (naln == 0) {
     i32 const first = pg_add_sequence(g, seq, 0, len);
@@ -266,7 +276,7 @@ struct DP {
 // Skewed-pipeline fill of the five DP matrices (SisdAlignmentEngine::Convex, alignment phase).
 // Fast path (L <= 64 * CWM): the row a lane finished in the previous step stays in registers.
 constexpr int CWM = 16;
-__device__ void poa_fill(const PG& g, const DP& d, u32 V, u32 L, int lane, const u8* seq, const i32* col0) {
+__device__ void poa_fill(const PG& g, const DP& d, u32 V, u32 L, int lane, const u8* seq, LdsArr<i32> col0) {
   u32 const cw = d.cw;
   u32 const jb = 1 + lane * cw;
   u32 const je = min(L + 1, jb + cw);
@@ -399,7 +409,7 @@ __device__ void poa_fill(const PG& g, const DP& d, u32 V, u32 L, int lane, const
 
 // Generic path for haplotypes longer than 64 * CWM columns: same recurrences and layout, every
 // predecessor row is read back from HBM (no register-resident row).
-__device__ void poa_fill_long(const PG& g, const DP& d, u32 V, u32 L, int lane, const u8* seq, const i32* col0) {
+__device__ void poa_fill_long(const PG& g, const DP& d, u32 V, u32 L, int lane, const u8* seq, LdsArr<i32> col0) {
   u32 const cw = d.cw;
   u32 const jb = 1 + lane * cw;
   u32 const je = min(L + 1, jb + cw);
@@ -490,7 +500,6 @@ struct MsaArgs {
 };
 
 __global__ __launch_bounds__(64) void k_msa(MsaArgs A) {
-  extern __shared__ u32 lds_raw[];
   __shared__ Shared sh;
   int const lw = blockIdx.x;
   int const w = A.win0 + lw;
@@ -510,25 +519,24 @@ __global__ __launch_bounds__(64) void k_msa(MsaArgs A) {
   PG g;
   g.pn = PN;
   {
-    u8* p8 = reinterpret_cast<u8*>(lds_raw);
-    u16* p16 = reinterpret_cast<u16*>(p8 + 6 * static_cast<size_t>(PN));
-    g.nchar = p8;
-    g.nin = p8 + PN;
-    g.nout = p8 + 2 * PN;
-    g.nal = p8 + 3 * PN;
-    g.marks = p8 + 4 * PN;
-    g.ignored = p8 + 5 * PN;
-    g.in_tail = p16;
-    g.out_head = p16 + kPE * PN;
-    g.out_lab = p16 + 2 * kPE * PN;
-    g.al = p16 + 3 * kPE * PN;
-    g.rank2node = p16 + 4 * kPE * PN;
-    g.node2rank = g.rank2node + PN;
-    g.stack = g.node2rank + PN;   // 4 * PN + 8 u16 == 2 * (PN + 1) i32 (+ slack) for the column-0 values
+    u32 const b16 = 6 * PN;  // PN is a multiple of 8
+    g.nchar.off = 0;
+    g.nin.off = PN;
+    g.nout.off = 2 * PN;
+    g.nal.off = 3 * PN;
+    g.marks.off = 4 * PN;
+    g.ignored.off = 5 * PN;
+    g.in_tail.off = b16;
+    g.out_head.off = b16 + 2 * (kPE * PN);
+    g.out_lab.off = b16 + 2 * (2 * kPE * PN);
+    g.al.off = b16 + 2 * (3 * kPE * PN);
+    g.rank2node.off = b16 + 2 * (4 * kPE * PN);
+    g.node2rank.off = g.rank2node.off + 2 * PN;
+    g.stack.off = g.node2rank.off + 2 * PN;  // 4 * PN + 8 u16 == 2 * (PN + 1) i32 (+ slack) for column 0
     g.stack_cap = 4 * PN;
   }
-  i32* col0 = reinterpret_cast<i32*>(g.stack);                 // [(PN + 1) * 2]: O, F of column 0
-  u16* aln = g.stack + 4 * PN + 8;                            // [(PN + max_l + 2) * 2]
+  LdsArr<i32> col0{g.stack.off};                       // [(PN + 1) * 2]: O, F of column 0
+  LdsArr<u16> aln{g.stack.off + 2 * (4 * PN + 8)};    // [(PN + max_l + 2) * 2]
   u32 const aln_cap = PN + ws.max_l + 2;
   DP d;
   d.H = ws.H + static_cast<size_t>(lw) * ws.cells;
