@@ -36,11 +36,11 @@ struct PoaWs {
   u32 max_l;
   size_t cells;   // DP cells per matrix per window (skewed body)
   u32 cw_max;     // columns per lane for the longest haplotype (multiple of 4)
-  i32* H;         // [w][cells]
-  i32* F;
-  i32* E;
-  i32* O;
-  i32* Q;
+  i16* H;         // [w][cells] saturated i16
+  i16* F;
+  i16* E;
+  i16* O;
+  i16* Q;
   i32* C0;        // [w][5][pn + 2] column 0 of H, F, E, O, Q
 };
 
@@ -258,24 +258,34 @@ __device__ __forceinline__ u32 row_pred(const PG& g, u32 node, u32 x) {
 // l = (j-1)/cw, c = (j-1)%cw and lives at (i + l) * 64*cw + l*cw + c -- at pipeline step t every lane
 // works on i + l == t + 1, so one store instruction of the wave covers 64 * 16 B of contiguous HBM.
 // Column 0 of the five matrices is kept in five small side arrays.
+// Bodies are stored as saturated i16: every value on or next to an optimal path is a real score
+// (>= -6 * max_hap_len - 26 > -32768), and "minus infinity" cells only ever lose max() comparisons and
+// equality tests, so clamping them to -32768 cannot change the traceback (column 0 stays i32).
 struct DP {
-  i32 *H, *F, *E, *O, *Q;      // skewed bodies
+  i16 *H, *F, *E, *O, *Q;      // skewed bodies
   i32 *H0, *F0, *E0, *O0, *Q0; // column 0, [V + 1]
   u32 cw, rs;                  // columns per lane (multiple of 4), row stride = 64 * cw
   __device__ __forceinline__ size_t off(u32 i, u32 j) const {  // j >= 1
     u32 const l = (j - 1) / cw;
     return static_cast<size_t>(i + l) * rs + (j - 1);
   }
-  __device__ __forceinline__ i32 h(u32 i, u32 j) const { return j ? H[off(i, j)] : H0[i]; }
-  __device__ __forceinline__ i32 f(u32 i, u32 j) const { return j ? F[off(i, j)] : F0[i]; }
-  __device__ __forceinline__ i32 e(u32 i, u32 j) const { return j ? E[off(i, j)] : E0[i]; }
-  __device__ __forceinline__ i32 o(u32 i, u32 j) const { return j ? O[off(i, j)] : O0[i]; }
-  __device__ __forceinline__ i32 q(u32 i, u32 j) const { return j ? Q[off(i, j)] : Q0[i]; }
+  // column 0 holds true i32 values; clamp on read so both sources compare on the same scale
+  __device__ __forceinline__ static i32 c0(i32 v) { return v < -32768 ? -32768 : v; }
+  __device__ __forceinline__ i32 h(u32 i, u32 j) const { return j ? H[off(i, j)] : c0(H0[i]); }
+  __device__ __forceinline__ i32 f(u32 i, u32 j) const { return j ? F[off(i, j)] : c0(F0[i]); }
+  __device__ __forceinline__ i32 e(u32 i, u32 j) const { return j ? E[off(i, j)] : c0(E0[i]); }
+  __device__ __forceinline__ i32 o(u32 i, u32 j) const { return j ? O[off(i, j)] : c0(O0[i]); }
+  __device__ __forceinline__ i32 q(u32 i, u32 j) const { return j ? Q[off(i, j)] : c0(Q0[i]); }
 };
 
 // Skewed-pipeline fill of the five DP matrices (SisdAlignmentEngine::Convex, alignment phase).
 // Fast path (L <= 64 * CWM): the row a lane finished in the previous step stays in registers.
 constexpr int CWM = 16;
+__device__ __forceinline__ u32 sat_pack(i32 a, i32 b) {  // two saturated i16 in one register
+  a = a < -32768 ? -32768 : a;
+  b = b < -32768 ? -32768 : b;
+  return (static_cast<u32>(a) & 0xFFFFu) | (static_cast<u32>(b) << 16);
+}
 __device__ void poa_fill(const PG& g, const DP& d, u32 V, u32 L, int lane, const u8* seq, LdsArr<i32> col0) {
   u32 const cw = d.cw;
   u32 const jb = 1 + lane * cw;
@@ -335,7 +345,7 @@ __device__ void poa_fill(const PG& g, const DP& d, u32 V, u32 L, int lane, const
           }
         } else {
           size_t const pb = static_cast<size_t>(pr + lane) * d.rs + static_cast<size_t>(lane) * cw;
-          i32 hprev = lane == 0 ? d.H0[pr]
+          i32 hprev = lane == 0 ? DP::c0(d.H0[pr])
                                 : d.H[static_cast<size_t>(pr + lane - 1) * d.rs + static_cast<size_t>(lane) * cw - 1];
 #pragma unroll
           for (int c = 0; c < CWM; ++c) {
@@ -388,15 +398,24 @@ __device__ void poa_fill(const PG& g, const DP& d, u32 V, u32 L, int lane, const
         pF[c] = f[c];
         pO[c] = o[c];
       }
-      size_t const ob = static_cast<size_t>(i + lane) * d.rs + static_cast<size_t>(lane) * cw;  // 16 B aligned
+      size_t const ob = static_cast<size_t>(i + lane) * d.rs + static_cast<size_t>(lane) * cw;  // 8-element aligned
 #pragma unroll
-      for (int c4 = 0; c4 < CWM / 4; ++c4) {
-        if (static_cast<u32>(c4 * 4) < cw) {
-          *reinterpret_cast<int4*>(d.H + ob + c4 * 4) = make_int4(pH[c4 * 4], pH[c4 * 4 + 1], pH[c4 * 4 + 2], pH[c4 * 4 + 3]);
-          *reinterpret_cast<int4*>(d.F + ob + c4 * 4) = make_int4(f[c4 * 4], f[c4 * 4 + 1], f[c4 * 4 + 2], f[c4 * 4 + 3]);
-          *reinterpret_cast<int4*>(d.O + ob + c4 * 4) = make_int4(o[c4 * 4], o[c4 * 4 + 1], o[c4 * 4 + 2], o[c4 * 4 + 3]);
-          *reinterpret_cast<int4*>(d.E + ob + c4 * 4) = make_int4(ev[c4 * 4], ev[c4 * 4 + 1], ev[c4 * 4 + 2], ev[c4 * 4 + 3]);
-          *reinterpret_cast<int4*>(d.Q + ob + c4 * 4) = make_int4(qv[c4 * 4], qv[c4 * 4 + 1], qv[c4 * 4 + 2], qv[c4 * 4 + 3]);
+      for (int c8 = 0; c8 < CWM / 8; ++c8) {
+        if (static_cast<u32>(c8 * 8) < cw) {
+          int const c = c8 * 8;
+          if (static_cast<u32>(c + 4) < cw) {
+            *reinterpret_cast<uint4*>(d.H + ob + c) = make_uint4(sat_pack(pH[c], pH[c + 1]), sat_pack(pH[c + 2], pH[c + 3]), sat_pack(pH[c + 4], pH[c + 5]), sat_pack(pH[c + 6], pH[c + 7]));
+            *reinterpret_cast<uint4*>(d.F + ob + c) = make_uint4(sat_pack(f[c], f[c + 1]), sat_pack(f[c + 2], f[c + 3]), sat_pack(f[c + 4], f[c + 5]), sat_pack(f[c + 6], f[c + 7]));
+            *reinterpret_cast<uint4*>(d.O + ob + c) = make_uint4(sat_pack(o[c], o[c + 1]), sat_pack(o[c + 2], o[c + 3]), sat_pack(o[c + 4], o[c + 5]), sat_pack(o[c + 6], o[c + 7]));
+            *reinterpret_cast<uint4*>(d.E + ob + c) = make_uint4(sat_pack(ev[c], ev[c + 1]), sat_pack(ev[c + 2], ev[c + 3]), sat_pack(ev[c + 4], ev[c + 5]), sat_pack(ev[c + 6], ev[c + 7]));
+            *reinterpret_cast<uint4*>(d.Q + ob + c) = make_uint4(sat_pack(qv[c], qv[c + 1]), sat_pack(qv[c + 2], qv[c + 3]), sat_pack(qv[c + 4], qv[c + 5]), sat_pack(qv[c + 6], qv[c + 7]));
+          } else {  // cw == c + 4: only four columns left in this lane's chunk
+            *reinterpret_cast<uint2*>(d.H + ob + c) = make_uint2(sat_pack(pH[c], pH[c + 1]), sat_pack(pH[c + 2], pH[c + 3]));
+            *reinterpret_cast<uint2*>(d.F + ob + c) = make_uint2(sat_pack(f[c], f[c + 1]), sat_pack(f[c + 2], f[c + 3]));
+            *reinterpret_cast<uint2*>(d.O + ob + c) = make_uint2(sat_pack(o[c], o[c + 1]), sat_pack(o[c + 2], o[c + 3]));
+            *reinterpret_cast<uint2*>(d.E + ob + c) = make_uint2(sat_pack(ev[c], ev[c + 1]), sat_pack(ev[c + 2], ev[c + 3]));
+            *reinterpret_cast<uint2*>(d.Q + ob + c) = make_uint2(sat_pack(qv[c], qv[c + 1]), sat_pack(qv[c + 2], qv[c + 3]));
+          }
         }
       }
       hl = hleft;
@@ -451,11 +470,11 @@ __device__ void poa_fill_long(const PG& g, const DP& d, u32 V, u32 L, int lane, 
         i32 const q = max(hleft + Q_, qleft + C_);
         i32 const h = max(hm, max(max(f, e), max(o, q)));
         size_t const ox = d.off(i, j);
-        d.F[ox] = f;
-        d.O[ox] = o;
-        d.E[ox] = e;
-        d.Q[ox] = q;
-        d.H[ox] = h;
+        d.F[ox] = static_cast<i16>(DP::c0(f));
+        d.O[ox] = static_cast<i16>(DP::c0(o));
+        d.E[ox] = static_cast<i16>(DP::c0(e));
+        d.Q[ox] = static_cast<i16>(DP::c0(q));
+        d.H[ox] = static_cast<i16>(DP::c0(h));
         hleft = h;
         eleft = e;
         qleft = q;
@@ -554,7 +573,7 @@ __global__ __launch_bounds__(64) void k_msa(MsaArgs A) {
   }
   d.cw = 4;
   d.rs = 256;
-  i32* H = d.H;  // also the raw-allele scratch of the bubble walk
+  i16* H = d.H;  // also the raw-allele scratch of the bubble walk
 
   u32 nvars = 0, pool = 0;
   bool overflow = false;
@@ -577,7 +596,7 @@ __global__ __launch_bounds__(64) void k_msa(MsaArgs A) {
         sh.abort_ = g.overflow ? 1u : 0u;
         if (!g.overflow && g.nn > 0 && L > 0) {
           u32 const V = g.nrank, W = L + 1;
-          u32 const cwl = ((L + 63) / 64 + 3) & ~3u;
+          u32 const cwl = ((L + 63) / 64 + 7) & ~7u;
           if (static_cast<size_t>(V + 65) * 64 * cwl > ws.cells) {
             g.overflow = true;
             sh.abort_ = 1;
@@ -607,7 +626,7 @@ __global__ __launch_bounds__(64) void k_msa(MsaArgs A) {
       __syncthreads();
       if (sh.go) {
         u32 const V = sh.V;
-        d.cw = ((L + 63) / 64 + 3) & ~3u;
+        d.cw = ((L + 63) / 64 + 7) & ~7u;
         d.rs = 64 * d.cw;
         // column 0 and row 0 to HBM (the traceback may touch them)
         for (u32 i = lane; i <= V; i += 64) {
@@ -621,11 +640,11 @@ __global__ __launch_bounds__(64) void k_msa(MsaArgs A) {
         for (u32 j = 1 + lane; j <= L; j += 64) {
           size_t const ox = d.off(0, j);
           i32 const qv = Q_ + static_cast<i32>(j - 1) * C_, ev = G_ + static_cast<i32>(j - 1) * E_;
-          d.O[ox] = kNegInf;
-          d.Q[ox] = qv;
-          d.F[ox] = kNegInf;
-          d.E[ox] = ev;
-          d.H[ox] = max(qv, ev);
+          d.O[ox] = -32768;
+          d.Q[ox] = static_cast<i16>(DP::c0(qv));
+          d.F[ox] = -32768;
+          d.E[ox] = static_cast<i16>(DP::c0(ev));
+          d.H[ox] = static_cast<i16>(DP::c0(max(qv, ev)));
         }
         __threadfence_block();
         __syncthreads();
@@ -977,12 +996,12 @@ int launch_msa(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& a, const ma_var
   while (lds_bytes(pn) > 156 * 1024 && pn > max_len + 32) pn -= 8;
   ws.pn = pn;
   size_t const lds = lds_bytes(pn);
-  ws.cw_max = ((max_len + 63) / 64 + 3) & ~3u;
+  ws.cw_max = ((max_len + 63) / 64 + 7) & ~7u;
   ws.cells = static_cast<size_t>(pn + 66) * 64 * ws.cw_max;
-  if (ws.cells < static_cast<size_t>(P.max_haps) * (2 * max_len + 8) / 4 + 64)  // raw-allele scratch lives in H
-    ws.cells = static_cast<size_t>(P.max_haps) * (2 * max_len + 8) / 4 + 64;
+  if (ws.cells < static_cast<size_t>(P.max_haps) * (2 * max_len + 8) / 2 + 64)  // raw-allele scratch lives in H
+    ws.cells = static_cast<size_t>(P.max_haps) * (2 * max_len + 8) / 2 + 64;
 
-  size_t const per_window = 5 * ws.cells * 4 + 5 * (static_cast<size_t>(pn) + 2) * 4 + 8192;
+  size_t const per_window = 5 * ws.cells * 2 + 5 * (static_cast<size_t>(pn) + 2) * 4 + 8192;
   size_t budget = size_t(24) << 30;
   {
     size_t free_b = 0, total_b = 0;  // size the in-flight window count for the GPU's HBM (288 GB on MI355X)
@@ -998,12 +1017,12 @@ int launch_msa(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& a, const ma_var
   for (int win0 = 0; win0 < n; win0 += chunk) {
     int const nwin = std::min(chunk, n - win0);
     char* base = static_cast<char*>(ctx->ws_poa.p);
-    size_t const msz = (static_cast<size_t>(nwin) * ws.cells * 4 + 255) & ~size_t(255);
-    ws.H = reinterpret_cast<i32*>(base);
-    ws.F = reinterpret_cast<i32*>(base + msz);
-    ws.E = reinterpret_cast<i32*>(base + 2 * msz);
-    ws.O = reinterpret_cast<i32*>(base + 3 * msz);
-    ws.Q = reinterpret_cast<i32*>(base + 4 * msz);
+    size_t const msz = (static_cast<size_t>(nwin) * ws.cells * 2 + 255) & ~size_t(255);
+    ws.H = reinterpret_cast<i16*>(base);
+    ws.F = reinterpret_cast<i16*>(base + msz);
+    ws.E = reinterpret_cast<i16*>(base + 2 * msz);
+    ws.O = reinterpret_cast<i16*>(base + 3 * msz);
+    ws.Q = reinterpret_cast<i16*>(base + 4 * msz);
     ws.C0 = reinterpret_cast<i32*>(base + 5 * msz);
     MsaArgs args{b, a, o, ws, P, win0};
     ctx->tic("k_msa");
