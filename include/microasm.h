@@ -90,7 +90,14 @@ typedef struct ma_batch {
   const uint32_t* read_qname_id;  /* host-interned QNAME, unique per distinct name within a window */
   const uint8_t* read_sample;     /* cbdg::Read::SampleIndex() */
   const uint8_t* read_flags;      /* MA_RF_* */
+  /* OPTIONAL (may be NULL) performance hint: window-relative 0-based reference offset at which base 0 of
+   * the read is expected to align (cbdg::Read::StartPos0() - window start - leading soft clip), or
+   * MA_NO_HINT.  Results never depend on it: k-mers that equal the reference k-mer at the hinted offset
+   * skip the hash table, everything else takes the general path. */
+  const int32_t* read_hint;
 } ma_batch_t;
+
+#define MA_NO_HINT INT32_MIN
 
 enum ma_read_flags {
   MA_RF_PASS = 1u << 0,  /* cbdg::Read::PassesAlnFilters(): mapq >= 20 (cbdg/read.h:35-38) */

@@ -16,6 +16,7 @@ MA_RF_PASS, MA_RF_CASE, MA_RF_REV = 1, 2, 4
 MA_W_NO_HAPLOTYPE, MA_W_HAP_OVERFLOW, MA_W_LEN_OVERFLOW = 1, 2, 4
 MA_W_BFS_LIMIT, MA_W_TABLE_OVERFLOW, MA_W_VAR_OVERFLOW = 8, 16, 32
 MA_MEM_HOST, MA_MEM_DEVICE = 0, 1
+MA_NO_HINT = -(1 << 31)
 
 
 class Params(C.Structure):
@@ -37,7 +38,8 @@ class Batch(C.Structure):
     _fields_ = [("n_windows", C.c_int32), ("n_reads", C.c_int64),
                 ("ref_bases", C.c_void_p), ("ref_off", C.c_void_p), ("read_win_off", C.c_void_p),
                 ("read_off", C.c_void_p), ("read_bases", C.c_void_p), ("read_quals", C.c_void_p),
-                ("read_qname_id", C.c_void_p), ("read_sample", C.c_void_p), ("read_flags", C.c_void_p)]
+                ("read_qname_id", C.c_void_p), ("read_sample", C.c_void_p), ("read_flags", C.c_void_p),
+                ("read_hint", C.c_void_p)]
 
 
 class GateOut(C.Structure):
@@ -64,7 +66,7 @@ class GenoOut(C.Structure):
 
 BATCH_DTYPES = dict(ref_bases=np.uint8, ref_off=np.uint32, read_win_off=np.uint32,
                     read_off=np.uint64, read_bases=np.uint8, read_quals=np.uint8,
-                    read_qname_id=np.uint32, read_sample=np.uint8, read_flags=np.uint8)
+                    read_qname_id=np.uint32, read_sample=np.uint8, read_flags=np.uint8, read_hint=np.int32)
 
 
 def asm_out_spec(p, n):

@@ -124,13 +124,15 @@ int stage_batch(ma_ctx* ctx, const ma_batch_t* b, DBatch* d) {
     d->ref_bases = b->ref_bases; d->ref_off = b->ref_off; d->read_win_off = b->read_win_off;
     d->read_off = b->read_off; d->read_bases = b->read_bases; d->read_quals = b->read_quals;
     d->read_qname_id = b->read_qname_id; d->read_sample = b->read_sample; d->read_flags = b->read_flags;
+    d->read_hint = b->read_hint;
     return MA_OK;
   }
   size_t const n = b->n_windows, nr = static_cast<size_t>(b->n_reads);
   size_t const ref_bytes = n ? b->ref_off[n] : 0;
   size_t const read_bytes = nr ? b->read_off[nr] : 0;
   struct Item { const void* src; size_t bytes; size_t pad; const void** dst; };
-  Item items[9] = {
+  d->read_hint = nullptr;
+  Item items[10] = {
       {b->ref_bases, ref_bytes, 64, reinterpret_cast<const void**>(&d->ref_bases)},
       {b->ref_off, 4 * (n + 1), 0, reinterpret_cast<const void**>(&d->ref_off)},
       {b->read_win_off, 4 * (n + 1), 0, reinterpret_cast<const void**>(&d->read_win_off)},
@@ -139,8 +141,10 @@ int stage_batch(ma_ctx* ctx, const ma_batch_t* b, DBatch* d) {
       {b->read_quals, read_bytes, 64, reinterpret_cast<const void**>(&d->read_quals)},
       {b->read_qname_id, 4 * nr, 0, reinterpret_cast<const void**>(&d->read_qname_id)},
       {b->read_sample, nr, 0, reinterpret_cast<const void**>(&d->read_sample)},
-      {b->read_flags, nr, 0, reinterpret_cast<const void**>(&d->read_flags)}};
-  for (int i = 0; i < 9; ++i) {
+      {b->read_flags, nr, 0, reinterpret_cast<const void**>(&d->read_flags)},
+      {b->read_hint, b->read_hint ? 4 * nr : 0, 0, reinterpret_cast<const void**>(&d->read_hint)}};
+  for (int i = 0; i < 10; ++i) {
+    if (i == 9 && !b->read_hint) break;
     MA_HIP(ctx, ctx->in_stage[i].reserve(items[i].bytes + items[i].pad + 16));
     if (items[i].bytes)
       MA_HIP(ctx, hipMemcpyAsync(ctx->in_stage[i].p, items[i].src, items[i].bytes, hipMemcpyHostToDevice, ctx->stream));

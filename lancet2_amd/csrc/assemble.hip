@@ -92,6 +92,7 @@ int launch_assemble(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& out, const
   ws.mc_log2 = std::max(10, ceil_log2(static_cast<u64>(max_read_inst) * 4 / 3 + 16));
   ws.inst_stride = (max_inst + 63) & ~63u;
   ws.ref_stride = (max_refk + 63) & ~63u;
+  ws.max_ref_len = max_refk + static_cast<u32>(P.min_k) + 8;  // longest reference window (+ slack)
   u32 nc = 8192;
   if (const char* e = getenv("MA_NODE_CAP")) nc = static_cast<u32>(atoi(e));
   nc = std::max<u32>(nc, 2 * max_refk + 64);
@@ -121,6 +122,7 @@ int launch_assemble(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& out, const
     g.nd_edge = c.take<u32>(A * NC * kEdgeCap);
     g.nd_ekey = c.take<u32>(A * NC * kEdgeCap);
     g.ref_node = c.take<u32>(A * g.ref_stride);
+    g.ref_slot = c.take<u32>(A * g.ref_stride);
     g.nd_comp = c.take<u32>(A * NC);
     g.nd_len = c.take<u32>(A * NC);
     g.nd_alive = c.take<u8>(A * NC);

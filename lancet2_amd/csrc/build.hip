@@ -151,78 +151,291 @@ __device__ __forceinline__ bool canon_plus(const u8* s, int k) {
   return true;
 }
 
+// ---- hinted build -------------------------------------------------------------------------------------
+// Reads arrive pre-aligned (they come from a BAM): ~85-90 % of their k-mers are byte-identical to the
+// reference k-mer at the read's aligned offset.  Such an instance IS the reference node at that position
+// (same string => same canonical k-mer), so it needs no hashing, no table probe and no HBM traffic; its
+// read support is accumulated in LDS counters per reference position.  Only k-mers that overlap a
+// mismatch / indel / clipped base (or reads without a hint) take the general hash-table path.
+// Exactness: the hint only selects the path; a wrong hint merely sends the k-mer down the general path.
+//
+// Mate-mer de-duplication (graph.h:102-117) for the fast path: reads with the same (qname, role, sample)
+// are adjacent in collector order; one thread owns such a GROUP and keeps a bitmask of the offsets of
+// the first member that were counted, so the second member's k-mer at the same reference position is
+// recognised as a duplicate.  Groups where this local reasoning could be wrong (more than two members,
+// reads longer than the mask, a general-path k-mer that turns out to be a reference node, a qname shared
+// by two samples of one role) are routed wholesale through the general mate-mer set (GEN bit).
+constexpr int kMaskWords = 10;  // fast-path bitmask covers reads with <= 320 k-mers
+
+struct BuildLds {
+  u8* ref;        // [max_ref_len + 8]
+  u32* ref_slot;  // [ref_stride]   slot | plus << 30
+  u32* cnt;       // [ref_stride * (S + 2)]
+  u32* mask;      // [kMaskWords][kBT]
+  u32* xs_key;    // [kXs]  (qname << 1 | role) + 1
+  u8* xs_sample;  // [kXs]
+};
+constexpr u32 kXs = 1024;
+
+__device__ __forceinline__ u32 lds_bytes_build(u32 max_ref_len, u32 ref_stride, int S) {
+  return ((max_ref_len + 8 + 15) & ~15u) + 4u * ref_stride + 4u * ref_stride * (S + 2) + 4u * kMaskWords * kBT + 4u * kXs +
+         kXs;
+}
+
 __global__ __launch_bounds__(kBT) void k_build_insert(DBatch b, GraphWs ws) {
+  extern __shared__ unsigned char lds_build[];
+  __shared__ u32 xs_flag;
   int const a = blockIdx.x;
   int const w = static_cast<int>(ws.active[a]);
   int const k = ws.k;
+  int const S = ws.num_samples, CW = S + 2;
   u32 const mask = (1u << ws.tc_log2) - 1;
   u64* keys = ws.tbl_key + (static_cast<size_t>(a) << ws.tc_log2);
   u32* first = ws.tbl_first + (static_cast<size_t>(a) << ws.tc_log2);
+  u32* gcnt = ws.tbl_cnt + (static_cast<size_t>(a) << ws.tc_log2) * CW;
   u32* inst_slot = ws.inst_slot + static_cast<size_t>(a) * ws.inst_stride;
+  u32* ref_slot_g = ws.ref_slot + static_cast<size_t>(a) * ws.ref_stride;
   u32 const ns = seq_count(b, w);
   u32 const base_idx = b.read_win_off[w] + w;
   const f64* phred = reinterpret_cast<const f64*>(c_phred_bits);
 
-  // (A) reference k-mers: one thread per position, direct O(k) hash (no qualities)
+  // LDS carve
+  u32 off = 0;
+  u8* l_ref = lds_build;
+  off += (ws.max_ref_len + 8 + 15) & ~15u;
+  u32* l_slot = reinterpret_cast<u32*>(lds_build + off);
+  off += 4u * ws.ref_stride;
+  u32* l_cnt = reinterpret_cast<u32*>(lds_build + off);
+  off += 4u * ws.ref_stride * CW;
+  u32* l_mask = reinterpret_cast<u32*>(lds_build + off);
+  off += 4u * kMaskWords * kBT;
+  u32* l_xkey = reinterpret_cast<u32*>(lds_build + off);
+  off += 4u * kXs;
+  u8* l_xsmp = lds_build + off;
+  off += kXs;
+  off = (off + 3) & ~3u;
+  u32* l_xgrp = reinterpret_cast<u32*>(lds_build + off);  // groups seen per (qname, role) key
+
+  SeqInfo const rsi = seq_info(b, w, 0, k);
+  i32 const ref_len = static_cast<i32>(rsi.len);
   {
-    SeqInfo const si = seq_info(b, w, 0, k);
-    const u8* s = b.ref_bases + si.off;
-    for (u32 p = threadIdx.x; p < si.nk; p += kBT) {
-      u64 hf = 0, hr = 0, pw = 1;
-      for (int i = 0; i < k; ++i) {
-        hf = hf * kHashP + s[p + i];
-        hr += pw * dev_complement(s[p + i]);
-        pw *= kHashP;
+    const u8* s = b.ref_bases + rsi.off;
+    for (u32 i = threadIdx.x; i < rsi.len && i < ws.max_ref_len + 8; i += kBT) l_ref[i] = s[i];
+    for (u32 i = threadIdx.x; i < ws.ref_stride * CW; i += kBT) l_cnt[i] = 0;
+    for (u32 i = threadIdx.x; i < kXs; i += kBT) {
+      l_xkey[i] = 0;
+      l_xgrp[i] = 0;
+    }
+    if (threadIdx.x == 0) xs_flag = 0;
+  }
+  __syncthreads();
+  bool const hints = b.read_hint != nullptr && rsi.len <= ws.max_ref_len + 8;
+
+  // (A) reference k-mers: one thread per position, direct O(k) hash (no qualities)
+  for (u32 p = threadIdx.x; p < rsi.nk; p += kBT) {
+    u64 hf = 0, hr = 0, pw = 1;
+    for (int i = 0; i < k; ++i) {
+      hf = hf * kHashP + l_ref[p + i];
+      hr += pw * dev_complement(l_ref[p + i]);
+      pw *= kHashP;
+    }
+    bool const plus = canon_plus(l_ref + p, k);
+    u64 id = dev_fmix64(plus ? hf : hr);
+    id = id ? id : 1;
+    u32 const slot = table_insert(keys, mask, id);
+    if (slot != kNoNode) atomicMin(&first[slot], p);  // seq_inst_base of the reference is 0
+    inst_slot[p] = (slot & kInstSlotMask) | (plus ? kInstPlus : 0u);
+    l_slot[p] = (slot & kInstSlotMask) | (plus ? kInstPlus : 0u);
+    ref_slot_g[p] = slot;
+  }
+  // (X) does a (qname, role) occur in two different samples?  (then the adjacent-group shortcut is not
+  //     the whole story: route every group through the general mate-mer set)
+  if (hints) {
+    for (u32 s_idx = 1 + threadIdx.x; s_idx < ns; s_idx += kBT) {
+      u32 const r = b.read_win_off[w] + s_idx - 1;
+      if (!(b.read_flags[r] & MA_RF_PASS)) continue;
+      u32 const key = ((b.read_qname_id[r] << 1) | ((b.read_flags[r] & MA_RF_CASE) ? 1u : 0u)) + 1u;
+      u8 const smp = b.read_sample[r];
+      u32 h = (key * 2654435761u) >> 22;  // kXs == 1024
+      bool done = false;
+      for (u32 probe = 0; probe < kXs && !done; ++probe) {
+        u32 cur = l_xkey[h];
+        if (cur == 0) {
+          u32 const old = atomicCAS(&l_xkey[h], 0u, key);
+          if (old == 0) {
+            l_xsmp[h] = smp;  // racy readers below re-check after the barrier-free window: see (X2)
+            cur = key;
+            done = true;
+            break;
+          }
+          cur = old;
+        }
+        if (cur == key) {
+          done = true;
+          break;
+        }
+        h = (h + 1) & (kXs - 1);
       }
-      bool const plus = canon_plus(s + p, k);
-      u64 id = dev_fmix64(plus ? hf : hr);
-      id = id ? id : 1;
-      u32 const slot = table_insert(keys, mask, id);
-      u32 const inst = p;  // seq_inst_base of the reference is 0
-      if (slot != kNoNode) atomicMin(&first[slot], inst);
-      inst_slot[inst] = (slot & kInstSlotMask) | (plus ? kInstPlus : 0u);
+      if (!done) xs_flag = 1;  // table full: be conservative
     }
   }
-  // (B) reads: one thread per read, rolling hashes + lagged f64 prefix sums
-  for (u32 s_idx = 1 + threadIdx.x; s_idx < ns; s_idx += kBT) {
-    SeqInfo const si = seq_info(b, w, s_idx, k);
-    if (si.nk == 0) continue;
-    const u8* s = b.read_bases + si.off;
-    const u8* q = b.read_quals + si.off;
-    u32 const ibase = ws.seq_inst_base[base_idx + s_idx];
-    u64 hf = 0, hr = 0, pw = 1;
-    f64 lead = 0.0, lag = 0.0;  // prefix[o+k] and prefix[o] of graph.cpp:283-285
-    for (int i = 0; i < k; ++i) {
-      hf = hf * kHashP + s[i];
-      hr += pw * dev_complement(s[i]);
-      pw *= kHashP;
-      f64 const pe = phred[q[i]];
-      lead = (i == 0) ? pe : lead + pe;
-    }
-    for (u32 o = 0; o < si.nk; ++o) {
-      bool const plus = canon_plus(s + o, k);
-      u64 id = dev_fmix64(plus ? hf : hr);
-      id = id ? id : 1;
-      u32 const slot = table_insert(keys, mask, id);
-      u32 const inst = ibase + o;
-      if (slot != kNoNode) atomicMin(&first[slot], inst);
-      // floor(prefix[o+k] - prefix[o]) == 0  <=>  difference < 1.0 (prefix is non-decreasing)
-      bool const errfree = (lead - lag) < 1.0;
-      inst_slot[inst] = (slot & kInstSlotMask) | (plus ? kInstPlus : 0u) | (errfree ? kInstErrFree : 0u);
-      if (o + 1 < si.nk) {
-        u8 const c_out = s[o], c_in = s[o + k];
-        hf = (hf - ws.pk1 * c_out) * kHashP + c_in;
-        hr = (hr - dev_complement(c_out)) * ws.pinv + ws.pk1 * dev_complement(c_in);
-        f64 const pl = phred[q[o]];
-        lag = (o == 0) ? pl : lag + pl;
-        lead = lead + phred[q[o + k]];
+  __syncthreads();
+  auto same_group = [&](u32 ra, u32 rb) {
+    return (b.read_flags[rb] & MA_RF_PASS) && b.read_qname_id[ra] == b.read_qname_id[rb] &&
+           ((b.read_flags[ra] ^ b.read_flags[rb]) & MA_RF_CASE) == 0 && b.read_sample[ra] == b.read_sample[rb];
+  };
+  if (hints) {  // (X2) second pass: every key must belong to ONE sample and to ONE run of adjacent reads
+    for (u32 s_idx = 1 + threadIdx.x; s_idx < ns; s_idx += kBT) {
+      u32 const r = b.read_win_off[w] + s_idx - 1;
+      if (!(b.read_flags[r] & MA_RF_PASS)) continue;
+      bool const leader = !(s_idx > 1 && same_group(r, r - 1));
+      u32 const key = ((b.read_qname_id[r] << 1) | ((b.read_flags[r] & MA_RF_CASE) ? 1u : 0u)) + 1u;
+      u32 h = (key * 2654435761u) >> 22;
+      for (u32 probe = 0; probe < kXs; ++probe) {
+        u32 const cur = l_xkey[h];
+        if (cur == key) {
+          if (l_xsmp[h] != b.read_sample[r]) xs_flag = 1;
+          if (leader && atomicAdd(&l_xgrp[h], 1u) != 0) xs_flag = 1;  // same name in two separate runs
+          break;
+        }
+        if (cur == 0) break;
+        h = (h + 1) & (kXs - 1);
       }
     }
+  }
+  __syncthreads();
+  bool const all_generic = !hints || xs_flag != 0;
+
+  // (B) reads: one thread per GROUP of adjacent reads with equal (qname, role, sample)
+  for (u32 s_idx = 1 + threadIdx.x; s_idx < ns; s_idx += kBT) {
+    u32 const r0 = b.read_win_off[w] + s_idx - 1;
+    if (!(b.read_flags[r0] & MA_RF_PASS)) continue;
+    if (s_idx > 1 && same_group(r0, r0 - 1)) continue;  // not the leader
+    u32 gsize = 1;
+    while (s_idx + gsize < ns && same_group(r0, r0 + gsize)) gsize++;
+    bool generic = all_generic || gsize > 2;
+    i32 hint0 = 0;
+    u32 nk0 = 0;
+    // ---- pass 1: classify every instance of the group, insert general-path k-mers ----
+    for (u32 gm = 0; gm < gsize; ++gm) {
+      u32 const sx = s_idx + gm;
+      SeqInfo const si = seq_info(b, w, sx, k);
+      if (si.nk == 0) continue;
+      const u8* s = b.read_bases + si.off;
+      const u8* q = b.read_quals + si.off;
+      u32 const ibase = ws.seq_inst_base[base_idx + sx];
+      i32 const hint = (hints && !generic) ? b.read_hint[r0 + gm] : MA_NO_HINT;
+      bool const use_hint = hint != MA_NO_HINT && hint > -100000 && hint < 100000 && si.nk <= 32u * kMaskWords;
+      if (!use_hint && hints && !generic && si.nk > 32u * kMaskWords) generic = true;
+      if (gm == 0) {
+        hint0 = hint;
+        nk0 = si.nk;
+      }
+      if (gm < 2 && !generic)
+        for (int mw = 0; mw < kMaskWords; ++mw) l_mask[mw * kBT + threadIdx.x] = gm == 0 ? 0u : l_mask[mw * kBT + threadIdx.x];
+      // rolling state
+      f64 lead = 0.0, lag = 0.0;
+      for (int i = 0; i < k; ++i) {
+        f64 const pe = phred[q[i]];
+        lead = (i == 0) ? pe : lead + pe;
+      }
+      i32 mm = 0;  // mismatches of read[o, o+k) against ref[hint+o, ...)
+      auto base_match = [&](i32 i) -> bool {
+        i32 const rp = hint + i;
+        return rp >= 0 && rp < ref_len && s[i] == l_ref[rp];
+      };
+      if (use_hint)
+        for (int i = 0; i < k; ++i) mm += base_match(i) ? 0 : 1;
+      u64 hf = 0, hr = 0;
+      i64 hash_at = -2;  // instance offset the rolling hashes currently describe
+      for (u32 o = 0; o < si.nk; ++o) {
+        bool const errfree = (lead - lag) < 1.0;
+        u32 word;
+        if (use_hint && mm == 0) {  // FAST: identical to the reference k-mer at hint + o
+          u32 const p = static_cast<u32>(hint + static_cast<i32>(o));
+          word = p | kInstFast | (errfree ? kInstErrFree : 0u);
+        } else {
+          if (hash_at == static_cast<i64>(o) - 1) {
+            u8 const c_out = s[o - 1], c_in = s[o + k - 1];
+            hf = (hf - ws.pk1 * c_out) * kHashP + c_in;
+            hr = (hr - dev_complement(c_out)) * ws.pinv + ws.pk1 * dev_complement(c_in);
+          } else {
+            hf = 0;
+            hr = 0;
+            u64 pw = 1;
+            for (int i = 0; i < k; ++i) {
+              hf = hf * kHashP + s[o + i];
+              hr += pw * dev_complement(s[o + i]);
+              pw *= kHashP;
+            }
+          }
+          hash_at = o;
+          bool const plus = canon_plus(s + o, k);
+          u64 id = dev_fmix64(plus ? hf : hr);
+          id = id ? id : 1;
+          u32 const slot = table_insert(keys, mask, id);
+          u32 old_first = 0xFFFFFFFFu;
+          if (slot != kNoNode) old_first = atomicMin(&first[slot], ibase + o);
+          word = (slot & kInstSlotMask) | (plus ? kInstPlus : 0u) | (errfree ? kInstErrFree : 0u);
+          // a general-path k-mer that IS a reference node: the local mate-mer reasoning below is incomplete
+          if (errfree && old_first < rsi.nk) generic = true;
+        }
+        inst_slot[ibase + o] = word;
+        if (o + 1 < si.nk) {
+          f64 const pl = phred[q[o]];
+          lag = (o == 0) ? pl : lag + pl;
+          lead = lead + phred[q[o + k]];
+          if (use_hint) mm += (base_match(static_cast<i32>(o)) ? 0 : -1) + (base_match(static_cast<i32>(o) + k) ? 0 : 1);
+        }
+      }
+    }
+    // ---- pass 2: read support.  FAST error-free instances are counted here (LDS); everything that must go
+    //      through the general mate-mer set gets the GEN bit and is handled by k_mm_insert / k_count ----
+    for (u32 gm = 0; gm < gsize; ++gm) {
+      u32 const sx = s_idx + gm;
+      SeqInfo const si = seq_info(b, w, sx, k);
+      if (si.nk == 0) continue;
+      u32 const ibase = ws.seq_inst_base[base_idx + sx];
+      u32 const r = r0 + gm;
+      u32 smp = b.read_sample[r];
+      if (smp >= static_cast<u32>(S)) smp = S - 1;
+      u32 const role = (b.read_flags[r] & MA_RF_CASE) ? 1u : 0u;
+      for (u32 o = 0; o < si.nk; ++o) {
+        u32 const word = inst_slot[ibase + o];
+        if (!(word & kInstErrFree)) continue;
+        if (generic || !(word & kInstFast)) {
+          inst_slot[ibase + o] = word | kInstGen;
+          continue;
+        }
+        u32 const p = word & kInstSlotMask;
+        bool dup = false;
+        if (gm == 1 && nk0 > 0) {  // did the first member count this reference position?
+          i64 const o0 = static_cast<i64>(p) - hint0;
+          if (o0 >= 0 && o0 < static_cast<i64>(nk0)) dup = (l_mask[(o0 >> 5) * kBT + threadIdx.x] >> (o0 & 31)) & 1u;
+        }
+        if (gm == 0) l_mask[(o >> 5) * kBT + threadIdx.x] |= 1u << (o & 31);
+        if (dup) continue;
+        atomicAdd(&l_cnt[p * CW + smp], 1u);
+        atomicAdd(&l_cnt[p * CW + S + role], 1u);
+      }
+    }
+  }
+  __syncthreads();
+  // (C) flush the per-position LDS counters into the table rows of the reference nodes
+  for (u32 i = threadIdx.x; i < rsi.nk * CW; i += kBT) {
+    u32 const v = l_cnt[i];
+    if (v == 0) continue;
+    u32 const p = i / CW, x = i % CW;
+    u32 const slot = l_slot[p] & kInstSlotMask;
+    atomicAdd(&gcnt[static_cast<size_t>(slot) * CW + x], v);
   }
 }
 
 __device__ __forceinline__ u64 mm_key_of(u32 slot, u32 qname, u32 role) {
   return ((static_cast<u64>(slot) << 33) | (static_cast<u64>(qname) << 1) | role) + 1ull;
+}
+__device__ __forceinline__ u32 inst_table_slot(u32 word, const u32* ref_slot_g) {
+  return (word & kInstFast) ? ref_slot_g[word & kInstSlotMask] : (word & kInstSlotMask);
 }
 
 __global__ __launch_bounds__(kBT) void k_mm_insert(DBatch b, GraphWs ws) {
@@ -232,6 +445,7 @@ __global__ __launch_bounds__(kBT) void k_mm_insert(DBatch b, GraphWs ws) {
   u64* keys = ws.mm_key + (static_cast<size_t>(a) << ws.mc_log2);
   u32* mins = ws.mm_min + (static_cast<size_t>(a) << ws.mc_log2);
   const u32* inst_slot = ws.inst_slot + static_cast<size_t>(a) * ws.inst_stride;
+  const u32* ref_slot_g = ws.ref_slot + static_cast<size_t>(a) * ws.ref_stride;
   u32 const ns = seq_count(b, w);
   u32 const base_idx = b.read_win_off[w] + w;
   for (u32 s_idx = 1 + threadIdx.x; s_idx < ns; s_idx += kBT) {
@@ -243,8 +457,8 @@ __global__ __launch_bounds__(kBT) void k_mm_insert(DBatch b, GraphWs ws) {
     u32 const ibase = ws.seq_inst_base[base_idx + s_idx];
     for (u32 o = 0; o < si.nk; ++o) {
       u32 const v = inst_slot[ibase + o];
-      if (!(v & kInstErrFree)) continue;
-      u64 const key = mm_key_of(v & kInstSlotMask, qn, role);
+      if ((v & (kInstErrFree | kInstGen)) != (kInstErrFree | kInstGen)) continue;
+      u64 const key = mm_key_of(inst_table_slot(v, ref_slot_g), qn, role);
       u32 slot = static_cast<u32>(dev_fmix64(key)) & mask;
       for (u32 probe = 0; probe <= mask; ++probe) {
         u64 cur = keys[slot];
@@ -272,6 +486,7 @@ __global__ __launch_bounds__(kBT) void k_count(DBatch b, GraphWs ws) {
   const u32* mins = ws.mm_min + (static_cast<size_t>(a) << ws.mc_log2);
   u32* cnt = ws.tbl_cnt + (static_cast<size_t>(a) << ws.tc_log2) * CW;
   const u32* inst_slot = ws.inst_slot + static_cast<size_t>(a) * ws.inst_stride;
+  const u32* ref_slot_g = ws.ref_slot + static_cast<size_t>(a) * ws.ref_stride;
   u32 const ns = seq_count(b, w);
   u32 const base_idx = b.read_win_off[w] + w;
   for (u32 s_idx = 1 + threadIdx.x; s_idx < ns; s_idx += kBT) {
@@ -285,8 +500,8 @@ __global__ __launch_bounds__(kBT) void k_count(DBatch b, GraphWs ws) {
     u32 const ibase = ws.seq_inst_base[base_idx + s_idx];
     for (u32 o = 0; o < si.nk; ++o) {
       u32 const v = inst_slot[ibase + o];
-      if (!(v & kInstErrFree)) continue;
-      u32 const nslot = v & kInstSlotMask;
+      if ((v & (kInstErrFree | kInstGen)) != (kInstErrFree | kInstGen)) continue;
+      u32 const nslot = inst_table_slot(v, ref_slot_g);
       u64 const key = mm_key_of(nslot, qn, role);
       u32 slot = static_cast<u32>(dev_fmix64(key)) & mask;
       for (u32 probe = 0; probe <= mask; ++probe) {
@@ -350,8 +565,9 @@ __global__ __launch_bounds__(kBT) void k_rank(DBatch b, GraphWs ws, u32 min_node
     SeqInfo const si = seq_info(b, w, s, ws.k);
     u32 const ibase = ws.seq_inst_base[base_idx + s];
     for (u32 o = 0; o < si.nk; ++o) {
-      u32 const slot = inst_slot[ibase + o] & kInstSlotMask;
-      mine += (first[slot] == ibase + o);
+      u32 const v = inst_slot[ibase + o];
+      if (v & kInstFast) continue;  // a hinted instance is a reference node: never a first insertion
+      mine += (first[v & kInstSlotMask] == ibase + o);
     }
   }
   u32 total;
@@ -374,6 +590,7 @@ __global__ __launch_bounds__(kBT) void k_rank(DBatch b, GraphWs ws, u32 min_node
     }
     for (u32 o = 0; o < si.nk; ++o) {
       u32 const v = inst_slot[ibase + o];
+      if (v & kInstFast) continue;
       u32 const slot = v & kInstSlotMask;
       if (first[slot] != ibase + o) continue;
       slot_node[slot] = idx;
@@ -422,6 +639,7 @@ __global__ __launch_bounds__(kBT) void k_edges(DBatch b, GraphWs ws) {
   if (ws.win_flags[w] & 4u) return;
   const u32* slot_node = ws.slot_node + (static_cast<size_t>(a) << ws.tc_log2);
   const u32* inst_slot = ws.inst_slot + static_cast<size_t>(a) * ws.inst_stride;
+  const u32* refn = ws.ref_node + static_cast<size_t>(a) * ws.ref_stride;
   size_t const nb = static_cast<size_t>(a) * ws.nc;
   u32 const ns = seq_count(b, w);
   u32 const base_idx = b.read_win_off[w] + w;
@@ -433,8 +651,9 @@ __global__ __launch_bounds__(kBT) void k_edges(DBatch b, GraphWs ws) {
     u32 const ibase = ws.seq_inst_base[base_idx + s];
     u32 const o_beg = s == 0 ? threadIdx.x : 0u, o_step = s == 0 ? kBT : 1u, o_end = si.nk - 1;
     for (u32 o = o_beg; o < o_end; o += o_step) {
-      u32 const na = slot_node[inst_slot[ibase + o] & kInstSlotMask];
-      u32 const nbn = slot_node[inst_slot[ibase + o + 1] & kInstSlotMask];
+      u32 const wa = inst_slot[ibase + o], wb = inst_slot[ibase + o + 1];
+      u32 const na = (wa & kInstFast) ? refn[wa & kInstSlotMask] : slot_node[wa & kInstSlotMask];
+      u32 const nbn = (wb & kInstFast) ? refn[wb & kInstSlotMask] : slot_node[wb & kInstSlotMask];
       if (na == kNoNode || nbn == kNoNode) continue;
       // edge kind from the STORED signs of both nodes (graph.cpp:333-336)
       u32 const sa_minus = ws.nd_sign[nb + na] ? 0u : 1u, sb_minus = ws.nd_sign[nb + nbn] ? 0u : 1u;
@@ -485,7 +704,12 @@ int run_build_pass(ma_ctx* ctx, const DBatch& b, const GraphWs& ws) {
   MA_HIP(ctx, hipMemsetAsync(ws.mm_key, 0, A * mcap * 8, ctx->stream));
   MA_HIP(ctx, hipMemsetAsync(ws.mm_min, 0xFF, A * mcap * 4, ctx->stream));
   ctx->tic("k_build_insert");
-  hipLaunchKernelGGL(k_build_insert, dim3(ws.n_active), dim3(kBT), 0, ctx->stream, b, ws);
+  size_t const lds_b = ((ws.max_ref_len + 8 + 15) & ~15u) + 4ull * ws.ref_stride + 4ull * ws.ref_stride * (ws.num_samples + 2) +
+                       4ull * kMaskWords * kBT + 4ull * kXs + kXs + 4ull * kXs + 64;
+  if (lds_b > 65536)
+    MA_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_build_insert),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_b)));
+  hipLaunchKernelGGL(k_build_insert, dim3(ws.n_active), dim3(kBT), lds_b, ctx->stream, b, ws);
   ctx->toc();
   ctx->tic("k_mm_insert");
   hipLaunchKernelGGL(k_mm_insert, dim3(ws.n_active), dim3(kBT), 0, ctx->stream, b, ws);

@@ -14,9 +14,14 @@ namespace ma {
 
 constexpr int kEdgeCap = 16;       // edges per node (reference: InlinedVector<Edge, 8>, node.h:42)
 constexpr u32 kNoNode = 0xFFFFFFFFu;
+// instance word: [31] error-free  [30] canonical == as-seen (PLUS)  [29] FAST: k-mer equals the reference
+// k-mer at the hinted offset, low bits hold that reference POSITION instead of a table slot
+// [28] GEN: read support goes through the general mate-mer set  [27:0] slot / reference position
 constexpr u32 kInstErrFree = 1u << 31;
 constexpr u32 kInstPlus = 1u << 30;
-constexpr u32 kInstSlotMask = (1u << 30) - 1;
+constexpr u32 kInstFast = 1u << 29;
+constexpr u32 kInstGen = 1u << 28;
+constexpr u32 kInstSlotMask = (1u << 28) - 1;
 constexpr int kMaxSamples = 8;
 
 struct GraphWs {
@@ -53,7 +58,9 @@ struct GraphWs {
   u32* nd_edge;           // [a][NC][kEdgeCap]  dst << 2 | kind
   u32* nd_ekey;           // [a][NC][kEdgeCap]  insertion-order key (build only)
   u32* ref_node;          // [a][max_ref_kmers] node idx of each reference k-mer (kNoNode if pruned): mRefNodeIds
+  u32* ref_slot;          // [a][max_ref_kmers] table slot of each reference k-mer
   u32 ref_stride;
+  u32 max_ref_len;
   // clean-stage scratch
   u32* nd_comp;           // [a][NC]
   u32* nd_len;            // [a][NC]

@@ -60,7 +60,7 @@ struct ma_ctx {
   hipStream_t stream = nullptr;
   std::string err;
   // staging for MA_MEM_HOST
-  ma::DevBuf in_stage[9];
+  ma::DevBuf in_stage[10];
   std::vector<ma::DevBuf> out_stage;
   // per-stage workspaces (grow-only, reused across calls)
   ma::DevBuf ws_build, ws_nodes, ws_clean, ws_poa, ws_aln, ws_misc;
@@ -104,6 +104,7 @@ struct DBatch {
   const u32* read_qname_id;
   const u8* read_sample;
   const u8* read_flags;
+  const i32* read_hint;  // may be null
 };
 
 int launch_gate(ma_ctx* ctx, const DBatch& b, u32* max_approx, u32* max_exact);

@@ -20,18 +20,37 @@ def _rand_dna(rng, n):
     return BASES[rng.integers(0, 4, size=n)]
 
 
-def _apply_variants(genome, variants):
-    """variants: list of (pos, ref_len, alt_bytes) on genome coordinates, non-overlapping."""
+def _apply_variants(genome, variants, with_map=False):
+    """variants: list of (pos, ref_len, alt_bytes) on genome coordinates, non-overlapping.
+    with_map: also return [(hap_pos, shift)] breakpoints: for hap positions >= hap_pos, ref = hap - shift."""
     out = []
     last = 0
+    hap_len = 0
+    shift = 0
+    bps = [(0, 0)]
     for pos, rlen, alt in sorted(variants, key=lambda v: v[0]):
         if pos < last:
             continue
         out.append(genome[last:pos])
+        hap_len += pos - last
         out.append(np.frombuffer(alt, dtype=np.uint8) if len(alt) else np.zeros(0, np.uint8))
+        hap_len += len(alt)
         last = pos + rlen
+        shift += len(alt) - rlen
+        bps.append((hap_len, shift))
     out.append(genome[last:])
-    return np.concatenate(out)
+    seq = np.concatenate(out)
+    return (seq, bps) if with_map else seq
+
+
+def _hap_to_ref(bps, hap_pos):
+    shift = 0
+    for hp, sh in bps:
+        if hap_pos >= hp:
+            shift = sh
+        else:
+            break
+    return hap_pos - shift
 
 
 def make_window(index, W=1001, depths=(30, 30), roles=(0, 1), snv_rate=1e-3, indel_rate=2e-4,
@@ -103,7 +122,7 @@ def make_window(index, W=1001, depths=(30, 30), roles=(0, 1), snv_rate=1e-3, ind
     def hap_seq(hbit, with_som):
         vs = [(p, r, a) for (p, r, a, m) in germ if m & (1 << hbit)]
         vs += [v for (v, h, _vaf) in with_som if h == hbit]
-        return _apply_variants(genome, vs)
+        return _apply_variants(genome, vs, with_map=True)
 
     hapN = [hap_seq(0, []), hap_seq(1, [])]
     reads = []
@@ -114,9 +133,9 @@ def make_window(index, W=1001, depths=(30, 30), roles=(0, 1), snv_rate=1e-3, ind
             hb = int(rng.integers(0, 2))
             if role == 1 and som:
                 carried = [x for x in som if x[1] == hb and rng.random() < min(1.0, 2.0 * x[2])]
-                hseq = hap_seq(hb, carried) if carried else hapN[hb]
+                hseq, bps = hap_seq(hb, carried) if carried else hapN[hb]
             else:
-                hseq = hapN[hb]
+                hseq, bps = hapN[hb]
             ins = int(max(read_len + 10, rng.normal(400, 50)))
             # fragment start so that reads tile the window incl. its edges
             fs = int(rng.integers(FLANK - ins, FLANK + W))
@@ -131,7 +150,7 @@ def make_window(index, W=1001, depths=(30, 30), roles=(0, 1), snv_rate=1e-3, ind
             for start, seq, rev in mates:
                 # keep only reads overlapping the window (approximate hap->genome coordinates)
                 if start + read_len <= FLANK or start >= FLANK + W:
-                    continue
+                    continue  # (hap coordinates are within a few bases of genome coordinates)
                 x = np.arange(read_len) / (read_len - 1.0)
                 q = 37.0 - 17.0 * x * x + rng.normal(0, 1.5, read_len)
                 q = np.clip(np.round(q), 2, 41).astype(np.uint8)
@@ -144,7 +163,8 @@ def make_window(index, W=1001, depths=(30, 30), roles=(0, 1), snv_rate=1e-3, ind
                     idx = np.nonzero(err)[0]
                     seq[idx] = BASES[(np.searchsorted(BASES, seq[idx]) + rng.integers(1, 4, len(idx))) % 4]
                 reads.append(dict(seq=seq, qual=q, qname=name, sample=s, role=role, rev=rev,
-                                  passf=not lowq, start=start - FLANK))
+                                  passf=not lowq, start=start - FLANK,
+                                  hint=_hap_to_ref(bps, start) - FLANK))  # what a BAM record's POS gives
     # collector order (read_collector.cpp:42-53)
     reads.sort(key=lambda r: (0 if r["passf"] else 1, r["role"], r["sample"], r["qname"], r["start"]))
     return dict(ref=genome[FLANK:FLANK + W].copy(), reads=reads)
@@ -172,6 +192,8 @@ def pack_batch(windows):
         read_flags=np.fromiter(((MA_RF_PASS if r["passf"] else 0) | (MA_RF_CASE if r["role"] == 1 else 0) |
                                 (MA_RF_REV if r["rev"] else 0) for w in windows for r in w["reads"]),
                                dtype=np.uint8, count=nr),
+        read_hint=np.fromiter((r.get("hint", -(1 << 31)) for w in windows for r in w["reads"]),
+                              dtype=np.int32, count=nr),
     )
     # pad byte arrays so that vector loads past the end stay inside the allocation
     for k in ("ref_bases", "read_bases", "read_quals"):
@@ -198,8 +220,9 @@ def tile_batch(arrs, n, nr, times):
     out["ref_off"] = tile_off(arrs["ref_off"], np.uint32)
     out["read_win_off"] = tile_off(arrs["read_win_off"], np.uint32)
     out["read_off"] = tile_off(arrs["read_off"], np.uint64)
-    for k in ("read_qname_id", "read_sample", "read_flags"):
-        out[k] = np.tile(arrs[k], times)
+    for k in ("read_qname_id", "read_sample", "read_flags", "read_hint"):
+        if k in arrs:
+            out[k] = np.tile(arrs[k], times)
     return out, n * times, nr * times
 
 

@@ -224,3 +224,78 @@ def test_full_size_properties():
         assert np.array_equal(a["hap_bases"][hi * ML: hi * ML + L], ref[anchor: anchor + L])
         per_var = q["allele_counts"][w * MV * S * NA * 2:(w + 1) * MV * S * NA * 2].reshape(MV, -1).sum(axis=1)
         assert per_var.max() <= reads_per_win[w]
+
+
+def test_hints_never_change_results():
+    """read_hint is a pure performance hint: absent, exact, shifted and random hints give identical
+    assembly output (and all equal the oracle, which ignores hints)."""
+    from lancet2_amd.engine import Engine
+    params = capi.default_params(min_k=25, max_k=25)
+    arrs, n, nr = synth.make_config_batch("C2", 4, first_index=900)
+    want = OracleEngine(params).assemble(arrs, n, nr)
+    rng = np.random.default_rng(5)
+    variants = {
+        "exact": arrs["read_hint"].copy(),
+        "none": None,
+        "no_hint_value": np.full(nr, capi.MA_NO_HINT, dtype=np.int32),
+        "shifted": (arrs["read_hint"] + rng.integers(-3, 4, nr)).astype(np.int32),
+        "random": rng.integers(-400, 1400, nr).astype(np.int32),
+        "huge": np.full(nr, 2_000_000_000, dtype=np.int32),
+    }
+    eng = Engine(params)
+    try:
+        for name, h in variants.items():
+            a2 = dict(arrs)
+            if h is None:
+                a2.pop("read_hint")
+            else:
+                a2["read_hint"] = h
+            got = eng.assemble(a2, n, nr)
+            bad = compare_asm(params, got, want, n)
+            assert not bad, name + ": " + "\n".join(bad[:10])
+    finally:
+        eng.close()
+
+
+def test_mate_mer_dedup_corner_cases():
+    """Overlapping mates, a read duplicated under the same qname, qnames shared across samples and a
+    qname split into two non-adjacent runs: the hinted fast path must agree with the general path."""
+    from lancet2_amd.engine import Engine
+    params = capi.default_params(min_k=25, max_k=25, num_samples=3)
+    base = synth.make_window(950, W=1001, depths=(20, 20, 20), roles=(0, 0, 1))
+    reads = base["reads"]
+    passing = [r for r in reads if r["passf"]]
+    # (1) fully overlapping mate: copy of a read with the same qname right after it
+    extra = []
+    for r in passing[:40:4]:
+        c = dict(r)
+        c["seq"] = r["seq"].copy()
+        c["qual"] = r["qual"].copy()
+        extra.append((r, c))
+    # (2) same qname in two different samples of the same role (samples 0 and 1 are both normals)
+    s0 = [r for r in passing if r["sample"] == 0][:10]
+    s1 = [r for r in passing if r["sample"] == 1][:10]
+    for x, y in zip(s0, s1):
+        y["qname"] = x["qname"]
+    out = []
+    for r in reads:
+        out.append(r)
+        for orig, c in extra:
+            if orig is r:
+                out.append(c)
+    # (3) a third copy far away from its group (non-adjacent run) -- keep collector order otherwise
+    far = dict(passing[50])
+    far["seq"] = passing[50]["seq"].copy()
+    far["qual"] = passing[50]["qual"].copy()
+    last_pass = max(i for i, r in enumerate(out) if r["passf"] and r["sample"] == passing[50]["sample"])
+    out.insert(last_pass + 1, far)
+    win = dict(ref=base["ref"], reads=out)
+    arrs, n, nr = synth.pack_batch([win, synth.make_window(951, W=1001, depths=(20, 20, 20), roles=(0, 0, 1))])
+    want = OracleEngine(params).assemble(arrs, n, nr)
+    eng = Engine(params)
+    try:
+        got = eng.assemble(arrs, n, nr)
+    finally:
+        eng.close()
+    bad = compare_asm(params, got, want, n)
+    assert not bad, "\n".join(bad[:10])
