@@ -8,7 +8,7 @@
 
 namespace ma {
 
-int run_build_pass(ma_ctx* ctx, const DBatch& b, const GraphWs& ws);
+int run_build_pass(ma_ctx* ctx, const DBatch& b, GraphWs& ws, u32* counters_dev, int tc_log2_alloc);
 int run_count_inst(ma_ctx* ctx, const DBatch& b, const GraphWs& ws, int win0, int nwin, u32* maxima_dev);
 int run_select_active(ma_ctx* ctx, const GraphWs& ws, int win0, int nwin, const u32* gate_approx, u32* win_k,
                       u32* active, u32* n_active_dev);
@@ -67,6 +67,7 @@ int launch_assemble(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& out, const
     *win_flags = c.take<u32>(n);
     *active = c.take<u32>(n);
     *counters = c.take<u32>(16);
+    ws.rd_flag = c.take<u8>(static_cast<size_t>(b.n_reads) + 16);
   };
   GraphWs ws{};
   u32 *win_flags = nullptr, *active = nullptr, *counters = nullptr;
@@ -90,6 +91,7 @@ int launch_assemble(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& out, const
 
   ws.tc_log2 = std::max(10, ceil_log2(static_cast<u64>(max_inst) * 4 / 3 + 16));
   ws.mc_log2 = std::max(10, ceil_log2(static_cast<u64>(max_read_inst) * 4 / 3 + 16));
+  int const tc_log2_alloc = ws.tc_log2;
   ws.inst_stride = (max_inst + 63) & ~63u;
   ws.ref_stride = (max_refk + 63) & ~63u;
   ws.max_ref_len = max_refk + static_cast<u32>(P.min_k) + 8;  // longest reference window (+ slack)
@@ -110,6 +112,8 @@ int launch_assemble(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& out, const
     g.slot_node = c.take<u32>(A * tcap);
     g.tbl_cnt = c.take<u32>(A * tcap * (S + 2));
     g.inst_slot = c.take<u32>(A * g.inst_stride);
+    g.slowq = c.take<u32>(A * g.inst_stride);
+    g.n_slow = c.take<u32>(A);
     g.mm_key = c.take<u64>(A * mcap);
     g.mm_min = c.take<u32>(A * mcap);
     g.n_nodes = c.take<u32>(A);
@@ -170,7 +174,8 @@ int launch_assemble(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& out, const
       if (host_cnt[1] == 0) break;  // every window of the chunk is resolved (graph.cpp:106 loop exit)
       if (ws.n_active > 0) {
         MA_TRY_RC(run_count_inst(ctx, b, ws, win0, nwin, counters));
-        MA_TRY_RC(run_build_pass(ctx, b, ws));
+        ws.tc_log2 = tc_log2_alloc;
+        MA_TRY_RC(run_build_pass(ctx, b, ws, counters + 12, tc_log2_alloc));
         MA_TRY_RC(run_clean_pass(ctx, b, ws, out));
       }
     }

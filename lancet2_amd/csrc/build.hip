@@ -182,80 +182,187 @@ __device__ __forceinline__ u32 lds_bytes_build(u32 max_ref_len, u32 ref_stride, 
          kXs;
 }
 
-__global__ __launch_bounds__(kBT) void k_build_insert(DBatch b, GraphWs ws) {
+// Shared prologue: stage the window's reference bytes in LDS.
+__device__ __forceinline__ void stage_ref(const DBatch& b, const SeqInfo& rsi, u8* l_ref, u32 cap) {
+  const u8* s = b.ref_bases + rsi.off;
+  for (u32 i = threadIdx.x; i < rsi.len && i < cap; i += kBT) l_ref[i] = s[i];
+}
+__device__ __forceinline__ bool same_group(const DBatch& b, u32 ra, u32 rb) {
+  return (b.read_flags[rb] & MA_RF_PASS) && b.read_qname_id[ra] == b.read_qname_id[rb] &&
+         ((b.read_flags[ra] ^ b.read_flags[rb]) & MA_RF_CASE) == 0 && b.read_sample[ra] == b.read_sample[rb];
+}
+
+// (1) k_classify: every read instance is classified WITHOUT touching the hash table.  All lanes run the same
+//     cheap loop (rolling reference-mismatch count + lagged f64 Phred prefix sums); instances that need the
+//     general path are appended to the window's slow queue so that k_insert can hash them with full lanes.
+__global__ __launch_bounds__(kBT) void k_classify(DBatch b, GraphWs ws, u32* max_slow) {
+  extern __shared__ unsigned char lds_build[];
+  __shared__ u32 n_slow_sh;
+  int const a = blockIdx.x;
+  int const w = static_cast<int>(ws.active[a]);
+  int const k = ws.k;
+  u32* inst_slot = ws.inst_slot + static_cast<size_t>(a) * ws.inst_stride;
+  u32* slowq = ws.slowq + static_cast<size_t>(a) * ws.inst_stride;
+  u32 const ns = seq_count(b, w);
+  u32 const base_idx = b.read_win_off[w] + w;
+  const f64* phred = reinterpret_cast<const f64*>(c_phred_bits);
+  u8* l_ref = lds_build;
+  SeqInfo const rsi = seq_info(b, w, 0, k);
+  i32 const ref_len = static_cast<i32>(rsi.len);
+  stage_ref(b, rsi, l_ref, ws.max_ref_len + 8);
+  if (threadIdx.x == 0) n_slow_sh = 0;
+  __syncthreads();
+  bool const hints = b.read_hint != nullptr && rsi.len <= ws.max_ref_len + 8;
+  for (u32 s_idx = 1 + threadIdx.x; s_idx < ns; s_idx += kBT) {
+    SeqInfo const si = seq_info(b, w, s_idx, k);
+    u32 const r = b.read_win_off[w] + s_idx - 1;
+    ws.rd_flag[r] = 0;
+    if (si.nk == 0) continue;
+    const u8* s = b.read_bases + si.off;
+    const u8* q = b.read_quals + si.off;
+    u32 const ibase = ws.seq_inst_base[base_idx + s_idx];
+    i32 const hint = hints ? b.read_hint[r] : MA_NO_HINT;
+    bool const use_hint = hint != MA_NO_HINT && hint > -100000 && hint < 100000 && si.nk <= 32u * kMaskWords;
+    f64 lead = 0.0, lag = 0.0;  // prefix[o+k] and prefix[o] of graph.cpp:283-285
+    i32 mm = 0;                 // mismatches of read[o, o+k) against ref[hint+o, ...)
+    for (int i = 0; i < k; ++i) {
+      f64 const pe = phred[q[i]];
+      lead = (i == 0) ? pe : lead + pe;
+      i32 const rp = hint + i;
+      mm += (use_hint && rp >= 0 && rp < ref_len && s[i] == l_ref[rp]) ? 0 : 1;
+    }
+    for (u32 o = 0; o < si.nk; ++o) {
+      // floor(prefix[o+k] - prefix[o]) == 0  <=>  difference < 1.0 (prefix is non-decreasing)
+      bool const errfree = (lead - lag) < 1.0;
+      u32 word;
+      if (use_hint && mm == 0) {  // FAST: byte-identical to the reference k-mer at hint + o
+        word = static_cast<u32>(hint + static_cast<i32>(o)) | kInstFast | (errfree ? kInstErrFree : 0u);
+      } else {
+        word = kInstSlotMask | (errfree ? kInstErrFree : 0u);  // slot filled in by k_insert
+        u32 const qi = atomicAdd(&n_slow_sh, 1u);
+        slowq[qi] = (s_idx << 12) | o;
+      }
+      inst_slot[ibase + o] = word;
+      if (o + 1 < si.nk) {
+        u8 const b_out = s[o], b_in = s[o + k];
+        f64 const pl = phred[q[o]];
+        lag = (o == 0) ? pl : lag + pl;
+        lead = lead + phred[q[o + k]];
+        if (use_hint) {
+          i32 const rp_out = hint + static_cast<i32>(o), rp_in = hint + static_cast<i32>(o) + k;
+          mm -= (rp_out >= 0 && rp_out < ref_len && b_out == l_ref[rp_out]) ? 0 : 1;
+          mm += (rp_in >= 0 && rp_in < ref_len && b_in == l_ref[rp_in]) ? 0 : 1;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    ws.n_slow[a] = n_slow_sh;
+    atomicMax(max_slow, n_slow_sh);
+  }
+}
+
+// (2) k_insert: reference k-mers, then the slow queue -- one k-mer per lane, hashed from scratch (O(k)), so
+//     every lane of every wave does the same work.  A general-path k-mer that IS a reference node flags its
+//     read: the group-local mate-mer reasoning of k_support would be incomplete for that group.
+__global__ __launch_bounds__(kBT) void k_insert(DBatch b, GraphWs ws) {
+  int const a = blockIdx.x;
+  int const w = static_cast<int>(ws.active[a]);
+  int const k = ws.k;
+  u32 const mask = (1u << ws.tc_log2) - 1;
+  u64* keys = ws.tbl_key + (static_cast<size_t>(a) << ws.tc_log2);
+  u32* first = ws.tbl_first + (static_cast<size_t>(a) << ws.tc_log2);
+  u32* inst_slot = ws.inst_slot + static_cast<size_t>(a) * ws.inst_stride;
+  const u32* slowq = ws.slowq + static_cast<size_t>(a) * ws.inst_stride;
+  u32* ref_slot_g = ws.ref_slot + static_cast<size_t>(a) * ws.ref_stride;
+  u32 const base_idx = b.read_win_off[w] + w;
+  SeqInfo const rsi = seq_info(b, w, 0, k);
+  auto hash_insert = [&](const u8* s, u32 inst, u32* old_first) -> u32 {
+    u64 hf = 0, hr = 0, pw = 1;
+    for (int i = 0; i < k; ++i) {
+      hf = hf * kHashP + s[i];
+      hr += pw * dev_complement(s[i]);
+      pw *= kHashP;
+    }
+    bool const plus = canon_plus(s, k);
+    u64 id = dev_fmix64(plus ? hf : hr);
+    id = id ? id : 1;
+    u32 const slot = table_insert(keys, mask, id);
+    *old_first = 0xFFFFFFFFu;
+    if (slot == kNoNode) {
+      atomicOr(&ws.win_flags[w], 4u);  // table full (cannot happen with the capacity planning)
+      return plus ? kInstPlus : 0u;
+    }
+    *old_first = atomicMin(&first[slot], inst);
+    return (slot & kInstSlotMask) | (plus ? kInstPlus : 0u);
+  };
+  // (A) reference k-mers (graph.cpp:264-267): instance index == reference position
+  {
+    const u8* s = b.ref_bases + rsi.off;
+    for (u32 p = threadIdx.x; p < rsi.nk; p += kBT) {
+      u32 of;
+      u32 const word = hash_insert(s + p, p, &of);
+      inst_slot[p] = word;
+      ref_slot_g[p] = word & kInstSlotMask;
+    }
+  }
+  __syncthreads();  // every reference node has first < n_ref_kmers from here on
+  // (B) slow queue
+  u32 const nq = ws.n_slow[a];
+  for (u32 x = threadIdx.x; x < nq; x += kBT) {
+    u32 const item = slowq[x];
+    u32 const s_idx = item >> 12, o = item & 0xFFFu;
+    SeqInfo const si = seq_info(b, w, s_idx, k);
+    u32 const inst = ws.seq_inst_base[base_idx + s_idx] + o;
+    u32 const errfree = inst_slot[inst] & kInstErrFree;
+    u32 of;
+    u32 const word = hash_insert(b.read_bases + si.off + o, inst, &of);
+    inst_slot[inst] = word | errfree;
+    if (errfree && of < rsi.nk) ws.rd_flag[b.read_win_off[w] + s_idx - 1] = 1;
+  }
+}
+
+// (3) k_support: read support of the FAST instances (node.cpp:18-24 + graph.h:102-117), one thread per group
+//     of adjacent reads with equal (qname, role, sample); per-reference-position counters live in LDS.
+__global__ __launch_bounds__(kBT) void k_support(DBatch b, GraphWs ws) {
   extern __shared__ unsigned char lds_build[];
   __shared__ u32 xs_flag;
   int const a = blockIdx.x;
   int const w = static_cast<int>(ws.active[a]);
   int const k = ws.k;
   int const S = ws.num_samples, CW = S + 2;
-  u32 const mask = (1u << ws.tc_log2) - 1;
-  u64* keys = ws.tbl_key + (static_cast<size_t>(a) << ws.tc_log2);
-  u32* first = ws.tbl_first + (static_cast<size_t>(a) << ws.tc_log2);
   u32* gcnt = ws.tbl_cnt + (static_cast<size_t>(a) << ws.tc_log2) * CW;
   u32* inst_slot = ws.inst_slot + static_cast<size_t>(a) * ws.inst_stride;
-  u32* ref_slot_g = ws.ref_slot + static_cast<size_t>(a) * ws.ref_stride;
+  const u32* ref_slot_g = ws.ref_slot + static_cast<size_t>(a) * ws.ref_stride;
   u32 const ns = seq_count(b, w);
   u32 const base_idx = b.read_win_off[w] + w;
-  const f64* phred = reinterpret_cast<const f64*>(c_phred_bits);
-
-  // LDS carve
   u32 off = 0;
-  u8* l_ref = lds_build;
-  off += (ws.max_ref_len + 8 + 15) & ~15u;
-  u32* l_slot = reinterpret_cast<u32*>(lds_build + off);
-  off += 4u * ws.ref_stride;
   u32* l_cnt = reinterpret_cast<u32*>(lds_build + off);
   off += 4u * ws.ref_stride * CW;
   u32* l_mask = reinterpret_cast<u32*>(lds_build + off);
   off += 4u * kMaskWords * kBT;
   u32* l_xkey = reinterpret_cast<u32*>(lds_build + off);
   off += 4u * kXs;
+  u32* l_xgrp = reinterpret_cast<u32*>(lds_build + off);
+  off += 4u * kXs;
   u8* l_xsmp = lds_build + off;
-  off += kXs;
-  off = (off + 3) & ~3u;
-  u32* l_xgrp = reinterpret_cast<u32*>(lds_build + off);  // groups seen per (qname, role) key
-
   SeqInfo const rsi = seq_info(b, w, 0, k);
-  i32 const ref_len = static_cast<i32>(rsi.len);
-  {
-    const u8* s = b.ref_bases + rsi.off;
-    for (u32 i = threadIdx.x; i < rsi.len && i < ws.max_ref_len + 8; i += kBT) l_ref[i] = s[i];
-    for (u32 i = threadIdx.x; i < ws.ref_stride * CW; i += kBT) l_cnt[i] = 0;
-    for (u32 i = threadIdx.x; i < kXs; i += kBT) {
-      l_xkey[i] = 0;
-      l_xgrp[i] = 0;
-    }
-    if (threadIdx.x == 0) xs_flag = 0;
+  for (u32 i = threadIdx.x; i < ws.ref_stride * CW; i += kBT) l_cnt[i] = 0;
+  for (u32 i = threadIdx.x; i < kXs; i += kBT) {
+    l_xkey[i] = 0;
+    l_xgrp[i] = 0;
   }
+  if (threadIdx.x == 0) xs_flag = 0;
   __syncthreads();
   bool const hints = b.read_hint != nullptr && rsi.len <= ws.max_ref_len + 8;
-
-  // (A) reference k-mers: one thread per position, direct O(k) hash (no qualities)
-  for (u32 p = threadIdx.x; p < rsi.nk; p += kBT) {
-    u64 hf = 0, hr = 0, pw = 1;
-    for (int i = 0; i < k; ++i) {
-      hf = hf * kHashP + l_ref[p + i];
-      hr += pw * dev_complement(l_ref[p + i]);
-      pw *= kHashP;
-    }
-    bool const plus = canon_plus(l_ref + p, k);
-    u64 id = dev_fmix64(plus ? hf : hr);
-    id = id ? id : 1;
-    u32 const slot = table_insert(keys, mask, id);
-    if (slot != kNoNode) atomicMin(&first[slot], p);  // seq_inst_base of the reference is 0
-    inst_slot[p] = (slot & kInstSlotMask) | (plus ? kInstPlus : 0u);
-    l_slot[p] = (slot & kInstSlotMask) | (plus ? kInstPlus : 0u);
-    ref_slot_g[p] = slot;
-  }
-  // (X) does a (qname, role) occur in two different samples?  (then the adjacent-group shortcut is not
-  //     the whole story: route every group through the general mate-mer set)
+  // (X) every (qname, role) key must belong to ONE sample and to ONE run of adjacent reads; otherwise the
+  //     adjacent-group shortcut is not the whole story and every group goes through the general set.
   if (hints) {
     for (u32 s_idx = 1 + threadIdx.x; s_idx < ns; s_idx += kBT) {
       u32 const r = b.read_win_off[w] + s_idx - 1;
       if (!(b.read_flags[r] & MA_RF_PASS)) continue;
       u32 const key = ((b.read_qname_id[r] << 1) | ((b.read_flags[r] & MA_RF_CASE) ? 1u : 0u)) + 1u;
-      u8 const smp = b.read_sample[r];
       u32 h = (key * 2654435761u) >> 22;  // kXs == 1024
       bool done = false;
       for (u32 probe = 0; probe < kXs && !done; ++probe) {
@@ -263,32 +370,23 @@ __global__ __launch_bounds__(kBT) void k_build_insert(DBatch b, GraphWs ws) {
         if (cur == 0) {
           u32 const old = atomicCAS(&l_xkey[h], 0u, key);
           if (old == 0) {
-            l_xsmp[h] = smp;  // racy readers below re-check after the barrier-free window: see (X2)
-            cur = key;
+            l_xsmp[h] = b.read_sample[r];
             done = true;
             break;
           }
           cur = old;
         }
-        if (cur == key) {
-          done = true;
-          break;
-        }
-        h = (h + 1) & (kXs - 1);
+        if (cur == key) done = true; else h = (h + 1) & (kXs - 1);
       }
       if (!done) xs_flag = 1;  // table full: be conservative
     }
   }
   __syncthreads();
-  auto same_group = [&](u32 ra, u32 rb) {
-    return (b.read_flags[rb] & MA_RF_PASS) && b.read_qname_id[ra] == b.read_qname_id[rb] &&
-           ((b.read_flags[ra] ^ b.read_flags[rb]) & MA_RF_CASE) == 0 && b.read_sample[ra] == b.read_sample[rb];
-  };
-  if (hints) {  // (X2) second pass: every key must belong to ONE sample and to ONE run of adjacent reads
+  if (hints) {
     for (u32 s_idx = 1 + threadIdx.x; s_idx < ns; s_idx += kBT) {
       u32 const r = b.read_win_off[w] + s_idx - 1;
       if (!(b.read_flags[r] & MA_RF_PASS)) continue;
-      bool const leader = !(s_idx > 1 && same_group(r, r - 1));
+      bool const leader = !(s_idx > 1 && same_group(b, r, r - 1));
       u32 const key = ((b.read_qname_id[r] << 1) | ((b.read_flags[r] & MA_RF_CASE) ? 1u : 0u)) + 1u;
       u32 h = (key * 2654435761u) >> 22;
       for (u32 probe = 0; probe < kXs; ++probe) {
@@ -306,91 +404,20 @@ __global__ __launch_bounds__(kBT) void k_build_insert(DBatch b, GraphWs ws) {
   __syncthreads();
   bool const all_generic = !hints || xs_flag != 0;
 
-  // (B) reads: one thread per GROUP of adjacent reads with equal (qname, role, sample)
   for (u32 s_idx = 1 + threadIdx.x; s_idx < ns; s_idx += kBT) {
     u32 const r0 = b.read_win_off[w] + s_idx - 1;
     if (!(b.read_flags[r0] & MA_RF_PASS)) continue;
-    if (s_idx > 1 && same_group(r0, r0 - 1)) continue;  // not the leader
+    if (s_idx > 1 && same_group(b, r0, r0 - 1)) continue;  // not the leader
     u32 gsize = 1;
-    while (s_idx + gsize < ns && same_group(r0, r0 + gsize)) gsize++;
+    while (s_idx + gsize < ns && same_group(b, r0, r0 + gsize)) gsize++;
     bool generic = all_generic || gsize > 2;
+    for (u32 gm = 0; gm < gsize && !generic; ++gm) {
+      SeqInfo const si = seq_info(b, w, s_idx + gm, k);
+      if (ws.rd_flag[r0 + gm] || si.nk > 32u * kMaskWords) generic = true;
+    }
     i32 hint0 = 0;
     u32 nk0 = 0;
-    // ---- pass 1: classify every instance of the group, insert general-path k-mers ----
-    for (u32 gm = 0; gm < gsize; ++gm) {
-      u32 const sx = s_idx + gm;
-      SeqInfo const si = seq_info(b, w, sx, k);
-      if (si.nk == 0) continue;
-      const u8* s = b.read_bases + si.off;
-      const u8* q = b.read_quals + si.off;
-      u32 const ibase = ws.seq_inst_base[base_idx + sx];
-      i32 const hint = (hints && !generic) ? b.read_hint[r0 + gm] : MA_NO_HINT;
-      bool const use_hint = hint != MA_NO_HINT && hint > -100000 && hint < 100000 && si.nk <= 32u * kMaskWords;
-      if (!use_hint && hints && !generic && si.nk > 32u * kMaskWords) generic = true;
-      if (gm == 0) {
-        hint0 = hint;
-        nk0 = si.nk;
-      }
-      if (gm < 2 && !generic)
-        for (int mw = 0; mw < kMaskWords; ++mw) l_mask[mw * kBT + threadIdx.x] = gm == 0 ? 0u : l_mask[mw * kBT + threadIdx.x];
-      // rolling state
-      f64 lead = 0.0, lag = 0.0;
-      for (int i = 0; i < k; ++i) {
-        f64 const pe = phred[q[i]];
-        lead = (i == 0) ? pe : lead + pe;
-      }
-      i32 mm = 0;  // mismatches of read[o, o+k) against ref[hint+o, ...)
-      auto base_match = [&](i32 i) -> bool {
-        i32 const rp = hint + i;
-        return rp >= 0 && rp < ref_len && s[i] == l_ref[rp];
-      };
-      if (use_hint)
-        for (int i = 0; i < k; ++i) mm += base_match(i) ? 0 : 1;
-      u64 hf = 0, hr = 0;
-      i64 hash_at = -2;  // instance offset the rolling hashes currently describe
-      for (u32 o = 0; o < si.nk; ++o) {
-        bool const errfree = (lead - lag) < 1.0;
-        u32 word;
-        if (use_hint && mm == 0) {  // FAST: identical to the reference k-mer at hint + o
-          u32 const p = static_cast<u32>(hint + static_cast<i32>(o));
-          word = p | kInstFast | (errfree ? kInstErrFree : 0u);
-        } else {
-          if (hash_at == static_cast<i64>(o) - 1) {
-            u8 const c_out = s[o - 1], c_in = s[o + k - 1];
-            hf = (hf - ws.pk1 * c_out) * kHashP + c_in;
-            hr = (hr - dev_complement(c_out)) * ws.pinv + ws.pk1 * dev_complement(c_in);
-          } else {
-            hf = 0;
-            hr = 0;
-            u64 pw = 1;
-            for (int i = 0; i < k; ++i) {
-              hf = hf * kHashP + s[o + i];
-              hr += pw * dev_complement(s[o + i]);
-              pw *= kHashP;
-            }
-          }
-          hash_at = o;
-          bool const plus = canon_plus(s + o, k);
-          u64 id = dev_fmix64(plus ? hf : hr);
-          id = id ? id : 1;
-          u32 const slot = table_insert(keys, mask, id);
-          u32 old_first = 0xFFFFFFFFu;
-          if (slot != kNoNode) old_first = atomicMin(&first[slot], ibase + o);
-          word = (slot & kInstSlotMask) | (plus ? kInstPlus : 0u) | (errfree ? kInstErrFree : 0u);
-          // a general-path k-mer that IS a reference node: the local mate-mer reasoning below is incomplete
-          if (errfree && old_first < rsi.nk) generic = true;
-        }
-        inst_slot[ibase + o] = word;
-        if (o + 1 < si.nk) {
-          f64 const pl = phred[q[o]];
-          lag = (o == 0) ? pl : lag + pl;
-          lead = lead + phred[q[o + k]];
-          if (use_hint) mm += (base_match(static_cast<i32>(o)) ? 0 : -1) + (base_match(static_cast<i32>(o) + k) ? 0 : 1);
-        }
-      }
-    }
-    // ---- pass 2: read support.  FAST error-free instances are counted here (LDS); everything that must go
-    //      through the general mate-mer set gets the GEN bit and is handled by k_mm_insert / k_count ----
+    for (int mw = 0; mw < kMaskWords; ++mw) l_mask[mw * kBT + threadIdx.x] = 0;
     for (u32 gm = 0; gm < gsize; ++gm) {
       u32 const sx = s_idx + gm;
       SeqInfo const si = seq_info(b, w, sx, k);
@@ -400,11 +427,15 @@ __global__ __launch_bounds__(kBT) void k_build_insert(DBatch b, GraphWs ws) {
       u32 smp = b.read_sample[r];
       if (smp >= static_cast<u32>(S)) smp = S - 1;
       u32 const role = (b.read_flags[r] & MA_RF_CASE) ? 1u : 0u;
+      if (gm == 0) {
+        hint0 = hints ? b.read_hint[r] : 0;
+        nk0 = si.nk;
+      }
       for (u32 o = 0; o < si.nk; ++o) {
         u32 const word = inst_slot[ibase + o];
         if (!(word & kInstErrFree)) continue;
         if (generic || !(word & kInstFast)) {
-          inst_slot[ibase + o] = word | kInstGen;
+          inst_slot[ibase + o] = word | kInstGen;  // exact handling by k_mm_insert / k_count
           continue;
         }
         u32 const p = word & kInstSlotMask;
@@ -421,13 +452,11 @@ __global__ __launch_bounds__(kBT) void k_build_insert(DBatch b, GraphWs ws) {
     }
   }
   __syncthreads();
-  // (C) flush the per-position LDS counters into the table rows of the reference nodes
   for (u32 i = threadIdx.x; i < rsi.nk * CW; i += kBT) {
     u32 const v = l_cnt[i];
     if (v == 0) continue;
     u32 const p = i / CW, x = i % CW;
-    u32 const slot = l_slot[p] & kInstSlotMask;
-    atomicAdd(&gcnt[static_cast<size_t>(slot) * CW + x], v);
+    atomicAdd(&gcnt[static_cast<size_t>(ref_slot_g[p]) * CW + x], v);
   }
 }
 
@@ -652,6 +681,9 @@ __global__ __launch_bounds__(kBT) void k_edges(DBatch b, GraphWs ws) {
     u32 const o_beg = s == 0 ? threadIdx.x : 0u, o_step = s == 0 ? kBT : 1u, o_end = si.nk - 1;
     for (u32 o = o_beg; o < o_end; o += o_step) {
       u32 const wa = inst_slot[ibase + o], wb = inst_slot[ibase + o + 1];
+      // both k-mers are reference nodes at consecutive positions: this (k+1)-mer is the reference's own edge,
+      // already inserted (with a smaller order key) by the reference sequence itself
+      if (s != 0 && (wa & kInstFast) && (wb & kInstFast) && (wb & kInstSlotMask) == (wa & kInstSlotMask) + 1) continue;
       u32 const na = (wa & kInstFast) ? refn[wa & kInstSlotMask] : slot_node[wa & kInstSlotMask];
       u32 const nbn = (wb & kInstFast) ? refn[wb & kInstSlotMask] : slot_node[wb & kInstSlotMask];
       if (na == kNoNode || nbn == kNoNode) continue;
@@ -694,22 +726,37 @@ __global__ __launch_bounds__(kBT) void k_edge_sort(GraphWs ws) {
 }
 
 // ---- host side: one k attempt of the build stage for the active windows ----
-int run_build_pass(ma_ctx* ctx, const DBatch& b, const GraphWs& ws) {
+int run_build_pass(ma_ctx* ctx, const DBatch& b, GraphWs& ws, u32* counters_dev, int tc_log2_alloc) {
   if (ws.n_active == 0) return MA_OK;
   size_t const A = ws.n_active;
+  int const S = ws.num_samples;
+  // (1) classify (no table traffic) -> how many k-mers need the table at most
+  MA_HIP(ctx, hipMemsetAsync(counters_dev, 0, 4, ctx->stream));
+  size_t const lds_c = ((ws.max_ref_len + 8 + 15) & ~15u) + 64;
+  ctx->tic("k_classify");
+  hipLaunchKernelGGL(k_classify, dim3(ws.n_active), dim3(kBT), lds_c, ctx->stream, b, ws, counters_dev);
+  ctx->toc();
+  u32 max_slow = 0;
+  MA_HIP(ctx, hipMemcpyAsync(&max_slow, counters_dev, 4, hipMemcpyDeviceToHost, ctx->stream));
+  MA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  int tc = 10;
+  while ((size_t(1) << tc) < (static_cast<size_t>(max_slow) + ws.ref_stride) * 4 / 3 + 16) ++tc;
+  ws.tc_log2 = tc < tc_log2_alloc ? tc : tc_log2_alloc;
   size_t const tcap = size_t(1) << ws.tc_log2, mcap = size_t(1) << ws.mc_log2;
   MA_HIP(ctx, hipMemsetAsync(ws.tbl_key, 0, A * tcap * 8, ctx->stream));
   MA_HIP(ctx, hipMemsetAsync(ws.tbl_first, 0x7F, A * tcap * 4, ctx->stream));  // 0x7F7F7F7F > any instance
-  MA_HIP(ctx, hipMemsetAsync(ws.tbl_cnt, 0, A * tcap * 4 * (ws.num_samples + 2), ctx->stream));
+  MA_HIP(ctx, hipMemsetAsync(ws.tbl_cnt, 0, A * tcap * 4 * (S + 2), ctx->stream));
   MA_HIP(ctx, hipMemsetAsync(ws.mm_key, 0, A * mcap * 8, ctx->stream));
   MA_HIP(ctx, hipMemsetAsync(ws.mm_min, 0xFF, A * mcap * 4, ctx->stream));
-  ctx->tic("k_build_insert");
-  size_t const lds_b = ((ws.max_ref_len + 8 + 15) & ~15u) + 4ull * ws.ref_stride + 4ull * ws.ref_stride * (ws.num_samples + 2) +
-                       4ull * kMaskWords * kBT + 4ull * kXs + kXs + 4ull * kXs + 64;
-  if (lds_b > 65536)
-    MA_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_build_insert),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_b)));
-  hipLaunchKernelGGL(k_build_insert, dim3(ws.n_active), dim3(kBT), lds_b, ctx->stream, b, ws);
+  ctx->tic("k_insert");
+  hipLaunchKernelGGL(k_insert, dim3(ws.n_active), dim3(kBT), 0, ctx->stream, b, ws);
+  ctx->toc();
+  size_t const lds_s = 4ull * ws.ref_stride * (S + 2) + 4ull * kMaskWords * kBT + 8ull * kXs + kXs + 64;
+  if (lds_s > 65536)
+    MA_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_support), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    static_cast<int>(lds_s)));
+  ctx->tic("k_support");
+  hipLaunchKernelGGL(k_support, dim3(ws.n_active), dim3(kBT), lds_s, ctx->stream, b, ws);
   ctx->toc();
   ctx->tic("k_mm_insert");
   hipLaunchKernelGGL(k_mm_insert, dim3(ws.n_active), dim3(kBT), 0, ctx->stream, b, ws);

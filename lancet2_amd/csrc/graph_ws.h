@@ -42,6 +42,9 @@ struct GraphWs {
   u32* tbl_first;
   u32* tbl_cnt;
   u32* inst_slot;
+  u32* slowq;             // [a][inst_stride] (seq << 12 | offset) of the instances that need the hash table
+  u32* n_slow;            // [a]
+  u8* rd_flag;            // [n_reads] general-path k-mer of this read hit a reference node
   u64* mm_key;
   u32* mm_min;
   // compact graph (per active slot, NC nodes)
