@@ -43,26 +43,13 @@ __constant__ u64 c_phred_bits_a[256] = {
 __constant__ i8 c_score_matrix[25] = {1, -4, -4, -4, 0, -4, 1, -4, -4, 0, -4, -4, 1, -4, 0,
                                       -4, -4, -4, 1, 0, 0, 0, 0, 0, 0};  // scoring_constants.h:35-41
 
-__device__ __forceinline__ u32 enc_base(u8 c) {  // scoring_constants.h:48-74
-  switch (c) {
-    case 'A': case 'a': return 0;
-    case 'C': case 'c': return 1;
-    case 'G': case 'g': return 2;
-    case 'T': case 't': return 3;
-    default: return 4;
-  }
-}
-
 struct AlnWs {
   // planning
   u32* win_slotmask;   // [n] bitmask of haplotype slots to align
   u64* pair_off;       // [n + 1]
-  u32* counters;       // [8]: 0 max read len
+  u32* counters;       // [8]: 0 max read len, 1 max reads per window, 2 entries in vote_wg
+  u32* vote_wg;        // [n * MH] compact list of (window * MH + slot) to align against
   // haplotype seed index, per (window, slot)
-  u32 idx_cap;
-  u16* idx_head;       // [n * MH][idx_cap]  (0xFFFF = empty)
-  u16* idx_next;       // [n * MH][max_hap_len]
-  u32* idx_code;       // [n * MH][max_hap_len] (0xFFFFFFFF = no valid 11-mer)
   // per pair
   i32* centre;         // [pairs in chunk]
   u32* dp_list;        // [pairs in chunk] pairs that need the DP (compacted by k_vote)
@@ -87,6 +74,7 @@ struct GArgs {
   ma_params_t prm;
   u64 pair0;     // first global pair index of this chunk
   u32 npairs;    // pairs in this chunk
+  u32 dp0;       // first dp_list entry of this DP launch
 };
 
 __global__ void k_max_reads(DBatch b, u32* out) {
@@ -112,6 +100,10 @@ __global__ void k_plan(GArgs A) {
     }
   }
   A.ws.win_slotmask[w] = mask;
+  if (mask) {  // dense work list: a (window, slot) grid would leave most workgroups (and whole XCDs) empty
+    u32 at = atomicAdd(&A.ws.counters[2], static_cast<u32>(__popc(mask)));
+    for (u32 mm = mask; mm; mm &= mm - 1) A.ws.vote_wg[at++] = static_cast<u32>(w) * P.max_haps + (__ffs(mm) - 1);
+  }
   u32 const nr = A.b.read_win_off[w + 1] - A.b.read_win_off[w];
   A.ws.pair_off[w] = static_cast<u64>(nr) * __popc(mask);  // counts; scanned below
   u32 ml = 0;
@@ -166,17 +158,49 @@ __device__ PairId pair_decode(GArgs const& A, u64 p) {
   return id;
 }
 
-// ---- haplotype 11-mer index ----
-__global__ __launch_bounds__(256) void k_hap_index(GArgs A) {
-  int const w = blockIdx.x / A.prm.max_haps, slot = blockIdx.x % A.prm.max_haps;
-  if (!(A.ws.win_slotmask[w] & (1u << slot))) return;
+#ifdef MA_PROFILE
+__device__ unsigned long long g_vprof[16];
+#define VPROF_T0() unsigned long long _t0 = __builtin_amdgcn_s_memtime()
+#define VPROF_ACC(slot)                                                       \
+  do {                                                                        \
+    unsigned long long _t1 = __builtin_amdgcn_s_memtime();                    \
+    if (lane == 0) atomicAdd(&g_vprof[slot], _t1 - _t0);                      \
+    _t0 = _t1;                                                                \
+  } while (0)
+#else
+#define VPROF_T0() do {} while (0)
+#define VPROF_ACC(slot) do {} while (0)
+#endif
+
+// ---- seed vote: one workgroup per (window, haplotype), one wave per read ----
+// The haplotype's 11-mer index (bucket heads + chains + codes) lives in LDS for the lifetime of the
+// workgroup, so the per-read work never leaves the CU: every read of the window votes against it.
+struct HapIdx {
+  const u16* head;  // [kIdxCap]      0xFFFF = empty
+  const u16* next;  // [max_hap_len]
+  const u32* code;  // [max_hap_len]  0xFFFFFFFF = no valid 11-mer
+};
+__device__ __forceinline__ void vote_pair(GArgs const& A, u64 lp, PairId id, HapIdx ix, u16* hist, int lane);
+
+__global__ __launch_bounds__(256) void k_vote(GArgs A, u32 hist_len) {
+  extern __shared__ u32 lds_vote[];
+  u32 const item = A.ws.vote_wg[blockIdx.x];
+  int const w = item / A.prm.max_haps, slot = item % A.prm.max_haps;
+  u32 const mask = A.ws.win_slotmask[w];
+  u32 const si = __popc(mask & ((1u << slot) - 1u));
+  u32 const r0 = A.b.read_win_off[w], nr = A.b.read_win_off[w + 1] - r0;
+  u64 const p0 = A.ws.pair_off[w] + static_cast<u64>(si) * nr;  // global pair index of read 0
+  if (p0 + nr <= A.pair0 || p0 >= A.pair0 + A.npairs) return;
+  u32 const ML = A.prm.max_hap_len;
+  u32* code = lds_vote;                                    // [ML]
+  u16* head = reinterpret_cast<u16*>(code + ML);           // [kIdxCap]
+  u16* next = head + kIdxCap;                              // [ML]
+  u16* hist_all = next + ((ML + 1) & ~1u);                 // [4][hist_len]
   size_t const hi = static_cast<size_t>(w) * A.prm.max_haps + slot;
   u32 const n = A.a.hap_len[hi];
-  const u8* hb = A.a.hap_bases + hi * A.prm.max_hap_len;
-  u16* head = A.ws.idx_head + hi * A.ws.idx_cap;
-  u16* next = A.ws.idx_next + hi * A.prm.max_hap_len;
-  u32* code = A.ws.idx_code + hi * A.prm.max_hap_len;
-  for (u32 x = threadIdx.x; x < A.ws.idx_cap; x += 256) head[x] = 0xFFFFu;
+  const u8* hb = A.a.hap_bases + hi * ML;
+  for (u32 x = threadIdx.x; x < kIdxCap / 2; x += 256) reinterpret_cast<u32*>(head)[x] = 0xFFFFFFFFu;
+  for (u32 x = threadIdx.x; x < 4 * hist_len / 2; x += 256) reinterpret_cast<u32*>(hist_all)[x] = 0;
   __syncthreads();
   for (u32 j = threadIdx.x; j + SK <= n; j += 256) {
     u32 cd = 0;
@@ -188,81 +212,113 @@ __global__ __launch_bounds__(256) void k_hap_index(GArgs A) {
     }
     code[j] = ok ? cd : 0xFFFFFFFFu;
     if (!ok) continue;
-    u32 const bkt = (cd * 2654435761u) >> (32 - 12);  // idx_cap == 4096
+    u32 const bkt = (cd * 2654435761u) >> (32 - 12);  // kIdxCap == 4096
     // push-front into the bucket chain (order irrelevant: votes commute).  16-bit CAS via 32-bit word.
     u32* word = reinterpret_cast<u32*>(head) + (bkt >> 1);
     u32 const shift = (bkt & 1u) * 16u;
     u32 old = *word;
     while (true) {
-      u32 const prev16 = (old >> shift) & 0xFFFFu;
-      next[j] = static_cast<u16>(prev16);
-      u32 const nw = (old & ~(0xFFFFu << shift)) | (static_cast<u32>(j) << shift);
+      next[j] = static_cast<u16>((old >> shift) & 0xFFFFu);
+      u32 const nw = (old & ~(0xFFFFu << shift)) | (j << shift);
       u32 const seen = atomicCAS(word, old, nw);
       if (seen == old) break;
       old = seen;
     }
   }
+  __syncthreads();
+  int const wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  HapIdx const ix{head, next, code};
+  u16* hist = hist_all + static_cast<size_t>(wave) * hist_len;
+  for (u32 ri = wave; ri < nr; ri += 4) {
+    u64 const p = p0 + ri;
+    if (p < A.pair0 || p >= A.pair0 + A.npairs) continue;
+    vote_pair(A, p - A.pair0, PairId{w, r0 + ri, static_cast<u32>(slot)}, ix, hist, lane);
+  }
 }
 
-// ---- seed vote: one wave per pair ----
-__global__ __launch_bounds__(256) void k_vote(GArgs A, u32 hist_len) {
-  extern __shared__ u16 lds_hist[];  // [4 waves][hist_len]
-  int const wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  u64 const lp = static_cast<u64>(blockIdx.x) * 4 + wave;
-  if (lp >= A.npairs) return;
-  PairId const id = pair_decode(A, A.pair0 + lp);
+__device__ __forceinline__ void vote_pair(GArgs const& A, u64 lp, PairId id, HapIdx ix, u16* hist, int lane) {
   size_t const hi = static_cast<size_t>(id.w) * A.prm.max_haps + id.slot;
   i32 const n = static_cast<i32>(A.a.hap_len[hi]);
   u64 const ro = A.b.read_off[id.r];
   i32 const m = static_cast<i32>(A.b.read_off[id.r + 1] - ro);
   const u8* rb = A.b.read_bases + ro;
-  u16* hist = lds_hist + static_cast<size_t>(wave) * hist_len;
   i32 const nd = m + n + 1;  // diagonals d in [-m, n] -> hist[d + m]
-  for (i32 x = lane; x < nd; x += 64) hist[x] = 0;
-  __builtin_amdgcn_wave_barrier();
-  if (m >= SK && n >= SK) {
-    const u16* head = A.ws.idx_head + hi * A.ws.idx_cap;
-    const u16* next = A.ws.idx_next + hi * A.prm.max_hap_len;
-    const u32* code = A.ws.idx_code + hi * A.prm.max_hap_len;
-    for (i32 i = lane; i + SK <= m; i += 64) {
-      u32 cd = 0;
-      bool ok = true;
-      for (int x = 0; x < SK; ++x) {
-        u32 const e = enc_base(rb[i + x]);
-        ok &= e < 4;
-        cd = (cd << 2) | (e & 3u);
-      }
-      if (!ok) continue;
-      u32 const bkt = (cd * 2654435761u) >> (32 - 12);
-      for (u32 j = head[bkt]; j != 0xFFFFu; j = next[j]) {
-        if (code[j] != cd) continue;
-        i32 const d = static_cast<i32>(j) - i + m;
-        // 16-bit LDS counter: atomic add on the containing 32-bit word
-        atomicAdd(reinterpret_cast<u32*>(hist) + (d >> 1), 1u << ((d & 1) * 16));
-      }
+  const u16* head = ix.head;
+  const u16* next = ix.next;
+  const u32* code = ix.code;
+  // this lane's read positions i = lane, lane + 64, ... and their 11-mer codes (0xFFFFFFFF: none)
+  VPROF_T0();
+  constexpr int kPos = 4;  // the first 256 read positions keep their codes in registers
+  u32 cds[kPos];
+  bool const seeded = m >= SK && n >= SK;
+  auto code_at = [&](i32 i) -> u32 {
+    if (!seeded || i + SK > m) return 0xFFFFFFFFu;
+    u32 cd = 0;
+    bool ok = true;
+    for (int x = 0; x < SK; ++x) {
+      u32 const e = enc_base(rb[i + x]);
+      ok &= e < 4;
+      cd = (cd << 2) | (e & 3u);
     }
-  }
+    return ok ? cd : 0xFFFFFFFFu;
+  };
+#pragma unroll
+  for (int t = 0; t < kPos; ++t) cds[t] = code_at(lane + 64 * t);
+  // visit every (read position, matching haplotype position) pair of this lane
+  auto walk = [&](auto&& fn) {
+#pragma unroll
+    for (int t = 0; t < kPos; ++t) {
+      u32 const cd = cds[t];
+      if (cd == 0xFFFFFFFFu) continue;
+      i32 const i = lane + 64 * t;
+      u32 const bkt = (cd * 2654435761u) >> (32 - 12);
+      for (u32 j = head[bkt]; j != 0xFFFFu; j = next[j])
+        if (code[j] == cd) fn(static_cast<i32>(j) - i + m);
+    }
+    for (i32 i = lane + 64 * kPos; seeded && i + SK <= m; i += 64) {  // long reads: re-encode
+      u32 const cd = code_at(i);
+      if (cd == 0xFFFFFFFFu) continue;
+      u32 const bkt = (cd * 2654435761u) >> (32 - 12);
+      for (u32 j = head[bkt]; j != 0xFFFFu; j = next[j])
+        if (code[j] == cd) fn(static_cast<i32>(j) - i + m);
+    }
+  };
+  VPROF_ACC(0);
+  // 16-bit LDS counters: atomic add on the containing 32-bit word
+  walk([&](i32 d) { atomicAdd(reinterpret_cast<u32*>(hist) + (d >> 1), 1u << ((d & 1) * 16)); });
   __builtin_amdgcn_wave_barrier();
-  // arg-max, ties -> smallest diagonal
+  VPROF_ACC(1);
+  // arg-max over the touched diagonals, ties -> smallest diagonal
   u32 best = 0;
   i32 bd = 0x7FFFFFFF;
-  for (i32 x = lane; x < nd; x += 64) {
-    u32 const v = hist[x];
-    if (v > best || (v == best && v > 0 && x < bd)) {
+  walk([&](i32 d) {
+    u32 const v = hist[d];
+    if (v > best || (v == best && d < bd)) {
       best = v;
-      bd = x;
+      bd = d;
     }
-  }
+  });
   for (int off = 32; off > 0; off >>= 1) {
-    u32 const ob = __shfl_down(best, off);
-    i32 const od = __shfl_down(bd, off);
+    u32 const ob = __shfl_xor(best, off);
+    i32 const od = __shfl_xor(bd, off);
     if (ob > best || (ob == best && ob > 0 && od < bd)) {
       best = ob;
       bd = od;
     }
   }
-  best = __shfl(best, 0);
-  bd = __shfl(bd, 0);
+  VPROF_ACC(2);
+  // second best (any other diagonal), then restore the all-zero histogram
+  u32 v2 = 0;
+  walk([&](i32 d) {
+    if (d != bd) v2 = max(v2, static_cast<u32>(hist[d]));
+  });
+  for (int off = 32; off > 0; off >>= 1) v2 = max(v2, __shfl_xor(v2, off));
+  __builtin_amdgcn_wave_barrier();
+  VPROF_ACC(3);
+  walk([&](i32 d) { hist[d] = 0; });
+  __builtin_amdgcn_wave_barrier();
+  VPROF_ACC(4);
+  (void)nd;
   if (best == 0) {  // no shared 11-mer: no hit (record stays zero)
     if (lane == 0) A.ws.centre[lp] = 0x7FFFFFFF;
     return;
@@ -276,10 +332,6 @@ __global__ __launch_bounds__(256) void k_vote(GArgs A, u32 hist_len) {
   //   * a gapless path on another diagonal d' scoring >= m - 5 X has X' <= X mismatches over >= m - 5X + 5X'
   //     bases, hence >= m - 10 - 11 X exact 11-mers, i.e. that many votes -- excluded by the vote bound.
   // So (score, rs, re, CIGAR = mM) can be written without running the DP.  Everything else goes to k_align.
-  u32 v2 = 0;
-  for (i32 x = lane; x < nd; x += 64)
-    if (x != bd) v2 = max(v2, static_cast<u32>(hist[x]));
-  for (int off = 32; off > 0; off >>= 1) v2 = max(v2, __shfl_xor(v2, off));
   bool const inside = c >= 0 && c + m <= n;
   u32 mism = 0, amb = 0;
   if (inside) {
@@ -294,6 +346,7 @@ __global__ __launch_bounds__(256) void k_vote(GArgs A, u32 hist_len) {
     mism += __shfl_xor(mism, off);
     amb |= __shfl_xor(amb, off);
   }
+  VPROF_ACC(5);
   bool const fast = inside && !amb && mism <= 2 && static_cast<i32>(v2) + 10 + 11 * static_cast<i32>(mism) < m &&
                     m - 5 * static_cast<i32>(mism) >= A.prm.min_aln_score && m < (1 << 27);
   if (lane == 0) {
@@ -315,7 +368,25 @@ __global__ __launch_bounds__(256) void k_vote(GArgs A, u32 hist_len) {
       A.ws.dp_list[atomicAdd(A.ws.dp_count, 1u)] = static_cast<u32>(lp);
     }
   }
+  VPROF_ACC(6);
+#ifdef MA_PROFILE
+  if (lane == 0) atomicAdd(&g_vprof[7], 1ull);
+#endif
 }
+
+#ifdef MA_PROFILE
+}  // namespace
+}  // namespace ma
+extern "C" void ma_debug_vprof(unsigned long long* out, int reset) {
+  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(ma::g_vprof), sizeof(unsigned long long) * 16);
+  if (reset) {
+    unsigned long long z[16] = {0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(ma::g_vprof), z, sizeof(z));
+  }
+}
+namespace ma {
+namespace {
+#endif
 
 // traceback shared by both alignment kernels (rules of oracle/align.cpp: diagonal, then E, then F;
 // prefer opening a gap) + BuildCigar (genotyper.cpp:45-69)
@@ -388,7 +459,7 @@ __global__ __launch_bounds__(64) void k_align(GArgs A, u32 seg_words) {
   i32 const B = A.ws.band, WD = 2 * B + 1;
   u32* HF = lds;                                 // [WD + 1][64] packed (H lo16, F hi16)
   u32* SEG = lds + static_cast<size_t>(WD + 1) * 64;  // [seg_words][64] haplotype segment, 4 bit/base
-  u64 const li = static_cast<u64>(blockIdx.x) * 64 + lane;
+  u64 const li = static_cast<u64>(A.dp0) + static_cast<u64>(blockIdx.x) * 64 + lane;
   bool const live = li < *A.ws.dp_count;
   u64 const lp = live ? A.ws.dp_list[li] : 0;
   PairId id{0, 0, 0};
@@ -518,7 +589,7 @@ __global__ __launch_bounds__(64) void k_align_reg(GArgs A, u32 seg_words) {
   constexpr int NW = (WD + 7) / 8;  // traceback / segment words per row
   int const lane = threadIdx.x;
   u32* SEG = lds;  // [seg_words][64]
-  u64 const li = static_cast<u64>(blockIdx.x) * 64 + lane;
+  u64 const li = static_cast<u64>(A.dp0) + static_cast<u64>(blockIdx.x) * 64 + lane;
   bool const live = li < *A.ws.dp_count;
   u64 const lp = live ? A.ws.dp_list[li] : 0;
   PairId id{0, 0, 0};
@@ -978,7 +1049,6 @@ int launch_genotype(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& a, const m
   A.prm = P;
   AlnWs& ws = A.ws;
   ws.band = P.band;
-  ws.idx_cap = kIdxCap;
   // evidence table: sized from the largest window (reads x a few variants each); the read count per
   // window is known from read_win_off only on the device, so a first tiny pass fetches the maxima
   ws.ev_cap = 8192;
@@ -1008,9 +1078,7 @@ int launch_genotype(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& a, const m
     ws.win_slotmask = reinterpret_cast<u32*>(take(4ull * n));
     ws.pair_off = reinterpret_cast<u64*>(take(8ull * (n + 1)));
     ws.counters = reinterpret_cast<u32*>(take(64));
-    ws.idx_head = reinterpret_cast<u16*>(take(2ull * n * MH * kIdxCap));
-    ws.idx_next = reinterpret_cast<u16*>(take(2ull * n * MH * P.max_hap_len));
-    ws.idx_code = reinterpret_cast<u32*>(take(4ull * n * MH * P.max_hap_len));
+    ws.vote_wg = reinterpret_cast<u32*>(take(4ull * n * MH));
     ws.ev_key = reinterpret_cast<u64*>(take(8ull * n * ws.ev_cap));
     ws.ev_min = reinterpret_cast<u32*>(take(4ull * n * ws.ev_cap));
     ws.asg_allele = reinterpret_cast<u8*>(take(NR * MV + 16));
@@ -1035,56 +1103,64 @@ int launch_genotype(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& a, const m
   hipLaunchKernelGGL(k_scan_pairs, dim3(1), dim3(1024), 0, ctx->stream, ws.pair_off, n);
   ctx->toc();
   u64 total_pairs = 0;
-  u32 max_read_len = 0;
+  u32 plan_counters[4] = {0, 0, 0, 0};
   MA_HIP(ctx, hipMemcpyAsync(&total_pairs, ws.pair_off + n, 8, hipMemcpyDeviceToHost, ctx->stream));
-  MA_HIP(ctx, hipMemcpyAsync(&max_read_len, ws.counters, 4, hipMemcpyDeviceToHost, ctx->stream));
+  MA_HIP(ctx, hipMemcpyAsync(plan_counters, ws.counters, 16, hipMemcpyDeviceToHost, ctx->stream));
   MA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  u32 const max_read_len = plan_counters[0], n_vote_wg = plan_counters[2];
 
   if (total_pairs > 0) {
-    ctx->tic("k_hap_index");
-    hipLaunchKernelGGL(k_hap_index, dim3(n * MH), dim3(256), 0, ctx->stream, A);
-    ctx->toc();
     ws.tb_rows = max_read_len + 1;
     ws.tb_words = static_cast<u32>((2 * P.band + 1 + 7) / 8);
     size_t const tb_per_group = static_cast<size_t>(ws.tb_rows) * ws.tb_words * 64 * 4;  // 64 pairs
-    size_t budget = size_t(8) << 30;
+    size_t free_b = 0, total_b = 0;
+    MA_HIP(ctx, hipMemGetInfo(&free_b, &total_b));
+    size_t budget = std::max<size_t>(size_t(1) << 30, (free_b + ctx->ws_misc.cap) / 4);
     if (const char* e = getenv("MA_TB_GB")) budget = static_cast<size_t>(atoi(e)) << 30;
-    u64 const groups_total = (total_pairs + 63) / 64;
-    u64 const groups_chunk = std::max<u64>(1, std::min<u64>(groups_total, budget / tb_per_group));
-    MA_HIP(ctx, ctx->ws_misc.reserve(groups_chunk * tb_per_group + groups_chunk * 64 * 8 + 8192));
+    // vote chunks: bounded only by the 8 B / pair of centre + dp_list (and 32-bit local pair ids)
+    u64 const pairs_chunk = std::min<u64>(total_pairs, std::min<u64>(u64(1) << 30, budget / 4 / 8));
+    u64 const dp_groups_max = std::max<u64>(1, (budget - pairs_chunk * 8) / tb_per_group);
+    size_t const tb_bytes = std::min<u64>(dp_groups_max, (pairs_chunk + 63) / 64) * tb_per_group;
+    MA_HIP(ctx, ctx->ws_misc.reserve(tb_bytes + (pairs_chunk + 64) * 8 + 8192));
     ws.tb = ctx->ws_misc.as<u32>();
-    ws.centre = reinterpret_cast<i32*>(reinterpret_cast<char*>(ctx->ws_misc.p) + groups_chunk * tb_per_group);
-    ws.dp_list = reinterpret_cast<u32*>(ws.centre + groups_chunk * 64);
-    ws.dp_count = ws.dp_list + groups_chunk * 64 + 16;
+    ws.centre = reinterpret_cast<i32*>(reinterpret_cast<char*>(ctx->ws_misc.p) + tb_bytes);
+    ws.dp_list = reinterpret_cast<u32*>(ws.centre + pairs_chunk + 16);
+    ws.dp_count = ws.dp_list + pairs_chunk + 16;
     u32 const hist_len = ((max_read_len + static_cast<u32>(P.max_hap_len) + 2 + 1) & ~1u);
+    size_t const lds_vote = 4ull * P.max_hap_len + 2ull * kIdxCap + 2ull * ((P.max_hap_len + 1) & ~1) + 8ull * hist_len;
+    if (lds_vote > 65536)
+      MA_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_vote), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      static_cast<int>(lds_vote)));
     u32 const seg_words = (max_read_len + 2 * P.band + 1 + 7) / 8 + 1;
     size_t const lds_align = (static_cast<size_t>(2 * P.band + 2) * 64 + static_cast<size_t>(seg_words) * 64) * 4;
-    for (u64 g0 = 0; g0 < groups_total; g0 += groups_chunk) {
-      u64 ng = std::min<u64>(groups_chunk, groups_total - g0);
-      A.pair0 = g0 * 64;
-      A.npairs = static_cast<u32>(std::min<u64>(ng * 64, total_pairs - A.pair0));
+    for (u64 p0 = 0; p0 < total_pairs; p0 += pairs_chunk) {
+      A.pair0 = p0;
+      A.npairs = static_cast<u32>(std::min<u64>(pairs_chunk, total_pairs - p0));
       MA_HIP(ctx, hipMemsetAsync(ws.dp_count, 0, 4, ctx->stream));
       ctx->tic("k_vote");
-      hipLaunchKernelGGL(k_vote, dim3((A.npairs + 3) / 4), dim3(256), 4ull * hist_len * 2, ctx->stream, A, hist_len);
+      hipLaunchKernelGGL(k_vote, dim3(n_vote_wg), dim3(256), lds_vote, ctx->stream, A, hist_len);
       ctx->toc();
       u32 ndp = 0;
       MA_HIP(ctx, hipMemcpyAsync(&ndp, ws.dp_count, 4, hipMemcpyDeviceToHost, ctx->stream));
       MA_HIP(ctx, hipStreamSynchronize(ctx->stream));
-      if (ndp == 0) continue;
-      ng = (ndp + 63) / 64;
-      if (P.band == 64) {
-        ctx->tic("k_align_reg");
-        hipLaunchKernelGGL(k_align_reg<64>, dim3(static_cast<u32>(ng)), dim3(64), static_cast<size_t>(seg_words + 2) * 64 * 4,
-                           ctx->stream, A, seg_words + 2);
+      u64 const ng_total = (static_cast<u64>(ndp) + 63) / 64;
+      for (u64 g0 = 0; g0 < ng_total; g0 += dp_groups_max) {
+        u32 const ng = static_cast<u32>(std::min<u64>(dp_groups_max, ng_total - g0));
+        A.dp0 = static_cast<u32>(g0 * 64);
+        if (P.band == 64) {
+          ctx->tic("k_align_reg");
+          hipLaunchKernelGGL(k_align_reg<64>, dim3(ng), dim3(64), static_cast<size_t>(seg_words + 2) * 64 * 4, ctx->stream, A,
+                             seg_words + 2);
+          ctx->toc();
+          continue;
+        }
+        ctx->tic("k_align");
+        if (lds_align > 65536)
+          MA_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_align),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_align)));
+        hipLaunchKernelGGL(k_align, dim3(ng), dim3(64), lds_align, ctx->stream, A, seg_words);
         ctx->toc();
-        continue;
       }
-      ctx->tic("k_align");
-      if (lds_align > 65536)
-        MA_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_align),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_align)));
-      hipLaunchKernelGGL(k_align, dim3(static_cast<u32>(ng)), dim3(64), lds_align, ctx->stream, A, seg_words);
-      ctx->toc();
     }
   }
   ctx->tic("k_assign");

@@ -80,21 +80,6 @@ struct GraphWs {
   int num_samples;
 };
 
-__device__ __forceinline__ u8 dev_complement(u8 b) {  // base/rev_comp.h:15-31
-  switch (b) {
-    case 'A': return 'T';
-    case 'a': return 't';
-    case 'T': return 'A';
-    case 't': return 'a';
-    case 'C': return 'G';
-    case 'c': return 'g';
-    case 'G': return 'C';
-    case 'g': return 'c';
-    case 'n': return 'n';
-    default: return 'N';
-  }
-}
-
 __device__ __forceinline__ u64 dev_fmix64(u64 x) {
   x ^= x >> 33;
   x *= 0xff51afd7ed558ccdULL;

@@ -113,4 +113,28 @@ int launch_msa(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& a, const ma_var
 int launch_genotype(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& a, const ma_var_out_t& v,
                     const ma_geno_out_t& o);
 
+// Branch-free on purpose: a `switch` over the base compiles to a tree of divergent branches per byte.
+//   'A' 0x41  'C' 0x43  'G' 0x47  'T' 0x54: bit 1 separates {A,T} from {C,G}; A^T = 0x15, C^G = 0x04.
+constexpr u32 kAcgtBits = (1u << ('A' - 'A')) | (1u << ('C' - 'A')) | (1u << ('G' - 'A')) | (1u << ('T' - 'A'));
+
+__device__ __forceinline__ bool dev_is_acgt_upper(u32 u) {  // u already upper-cased (c & 0xDF)
+  u32 const k = u - 'A';
+  return k < 32u && ((kAcgtBits >> (k & 31u)) & 1u);
+}
+
+__device__ __forceinline__ u8 dev_complement(u8 b) {  // base/rev_comp.h:15-31
+  u32 const c = b, u = c & 0xDFu, lower = c & 0x20u;
+  u32 const comp = (u ^ ((u & 2u) ? 0x04u : 0x15u)) | lower;
+  bool const acgt = dev_is_acgt_upper(u);  // then c is that letter, upper or lower case
+  u32 const other = (c == 'n') ? u32('n') : u32('N');
+  return static_cast<u8>(acgt ? comp : other);
+}
+
+__device__ __forceinline__ u32 enc_base(u8 b) {  // scoring_constants.h:48-74: A 0, C 1, G 2, T 3, other 4
+  u32 const c = b;
+  u32 e = (c >> 1) & 3u;  // A 0, C 1, T 2, G 3
+  e ^= e >> 1;            // A 0, C 1, G 2, T 3
+  return dev_is_acgt_upper(c & 0xDFu) ? e : 4u;
+}
+
 }  // namespace ma

@@ -124,7 +124,8 @@ from harness import compare_geno  # noqa: E402
 
 
 @pytest.mark.parametrize("cfg,nwin,kw", [("C2", 6, {}), ("C3", 3, {}), ("C4", 1, dict(depths=(60, 60))),
-                                          ("C5", 3, dict(num_samples=3))])
+                                          ("C5", 3, dict(num_samples=3)), ("C2", 3, dict(read_len=300)),
+                                          ("C2", 2, dict(read_len=101, error_scale=4.0))])
 def test_genotype_parity(cfg, nwin, kw):
     from lancet2_amd.engine import Engine
     ns = kw.pop("num_samples", 2)

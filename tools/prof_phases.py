@@ -1,0 +1,40 @@
+"""Developer tool: per-phase cycle breakdown of k_vote / k_msa from a -DMA_PROFILE build.
+
+  make -C lancet2_amd/csrc clean && make -C lancet2_amd/csrc HIPFLAGS_EXTRA=-DMA_PROFILE LIB=../libmicroasm_prof.so
+  python tools/prof_phases.py [n_windows]
+
+Not part of the product path or the tests.
+"""
+import ctypes as C
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from lancet2_amd import capi, synth  # noqa: E402
+from lancet2_amd import engine as E  # noqa: E402
+
+capi.LIB_PATH = os.path.join(capi.REPO, "lancet2_amd", "libmicroasm_prof.so")
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+arrs, nw, nr = synth.make_config_batch("C2", 64)
+arrs, nw, nr = synth.tile_batch(arrs, nw, nr, n // 64)
+eng = E.Engine(capi.default_params(min_k=25, max_k=25))
+eng.process(arrs, nw, nr)
+buf = (C.c_ulonglong * 16)()
+for sym, names in (("ma_debug_vprof", ["encode", "vote", "argmax", "second", "clear", "mismatch", "emit", "pairs"]),
+                   ("ma_debug_prof", [f"msa{i}" for i in range(8)])):
+    fn = getattr(eng.lib, sym, None)
+    if fn is None:
+        continue
+    fn(buf, 1)
+eng.timing_control(1)
+eng.process(arrs, nw, nr)
+print({k: round(v, 2) for k, v in eng.kernel_times()})
+for sym, names in (("ma_debug_vprof", ["encode", "vote", "argmax", "second", "clear", "mismatch", "emit", "pairs"]),
+                   ("ma_debug_prof", [f"msa{i}" for i in range(8)])):
+    fn = getattr(eng.lib, sym, None)
+    if fn is None:
+        continue
+    fn(buf, 0)
+    vals = list(buf)[:len(names)]
+    print(sym, {k: v for k, v in zip(names, vals)})
+eng.close()
