@@ -4,16 +4,26 @@
 // kNW with convex gaps 0/-6/-6,-2/-26,-1: caller/msa_builder.h:72-89) and the caller::VariantSet
 // constructor (caller/variant_extractor.cpp:24-233, variant_bubble.cpp:16-116, raw_variant.cpp:44-77).
 //
-// One wavefront per window; the window's components are processed one after another.
+// One workgroup of 256 threads (4 wavefronts) per window; its components are processed one after another.
 //  * The POA graph (node chars, in/out adjacency with 16-bit ids, per-edge haplotype label masks,
-//    aligned-node rings, rank <-> node maps, DFS scratch, the alignment path) lives in LDS: the graph
-//    update (Graph::AddAlignment), SPOA's DFS topological sort and the bubble walk are pointer-chasing
-//    serial loops, so they run at LDS latency on lane 0 instead of HBM latency.
-//  * The sequence-to-DAG DP keeps SPOA's five i32 matrices (H,F,E,O,Q) in HBM because the traceback
-//    compares VALUES.  All 64 lanes fill them as a skewed pipeline: lane l owns a contiguous chunk of
-//    columns and handles DP row (t - l + 1) at step t; the (H,E,Q) of the column to its left arrive
-//    from lane l-1 by wave shuffle; the previous row stays in registers, so a row whose only
-//    predecessor is the previous rank (the common case) reads nothing from HBM.
+//    aligned-node rings, rank <-> node maps) lives in LDS (~42 B per node).
+//  * Sequence-to-DAG DP (SisdAlignmentEngine::Convex): 256 lanes fill the matrix as a skewed pipeline.
+//    Lane l owns CW consecutive columns and handles DP row (t - l + 1) at step t; (H,E,Q) of the
+//    column to its left arrive by wave shuffle (LDS mailbox across the three wave boundaries); the two
+//    previous rows stay in registers.  A row is written to HBM only if a later row needs it and cannot
+//    take it from registers (a predecessor that is neither rank-1 nor rank-2: the ends of indel arcs).
+//  * SPOA's traceback compares VALUES of five i32 matrices.  Every comparison it can make at a cell
+//    only involves values the fill has in registers when it computes that cell, so the fill evaluates
+//    them on the spot and stores a 10-bit decision code per cell (2 B instead of 20 B of matrices):
+//      [1:0] move: 0 diagonal, 1 up, 2 left          [2] the move opens an extension run (ext_up/ext_left)
+//      [3]   left-extension run continues INTO this cell from its left neighbour
+//      [4]   up-extension run continues through an F/O predecessor  [5] ... stops at an H predecessor
+//      [7:6] predecessor index of the move             [9:8] predecessor index of the up-extension
+//    The traceback reads one code per step; runs of diagonal moves over rank-consecutive rows, left runs
+//    and up runs are detected 64 cells at a time with a wave ballot.
+//  * Graph::AddAlignment is lane-parallel (every path node is touched by exactly one alignment entry);
+//    SPOA's DFS topological sort stays a serial LDS loop on thread 0 (its order defines the ranks).
+//  * The bubble walk of VariantExtractor skips converged stretches 256 nodes at a time.
 // Edge weights are not tracked: the reference only reads topology, labels and ranks from the POA
 // graph (variant_extractor.cpp:47-58, :84-94, :159-181).
 #include <algorithm>
@@ -26,27 +36,30 @@ namespace ma {
 
 namespace {
 
-constexpr int kPE = 4;     // in / out edges and aligned nodes kept per POA node
+constexpr int kPE = 4;        // in / out edges and aligned nodes kept per POA node
+constexpr int kT = 256;       // threads per window
+constexpr u32 kSlowCap = 256; // rows with a cached predecessor-row list
 constexpr i32 kNegInf = static_cast<i32>(0x80000000u) + 1024;
 constexpr i32 M_ = 0, N_ = -6, G_ = -6, E_ = -2, Q_ = -26, C_ = -1;  // msa_builder.h:72-77
-constexpr u16 kNone16 = 0xFFFFu;
+
+constexpr u32 RI_FAST = 1u << 11;     // single predecessor == previous rank
+constexpr u32 RI_SLOWTAB = 1u << 12;  // predecessor rows cached in slowpred[info >> 16]
+constexpr u32 RI_STORE = 1u << 13;    // a later row reads this row back from HBM
 
 struct PoaWs {
-  u32 pn;         // node capacity (LDS)
-  u32 max_l;
-  size_t cells;   // DP cells per matrix per window (skewed body)
-  u32 cw_max;     // columns per lane for the longest haplotype (multiple of 4)
-  i16* H;         // [w][cells] saturated i16
-  i16* F;
-  i16* E;
-  i16* O;
-  i16* Q;
-  i32* C0;        // [w][5][pn + 2] column 0 of H, F, E, O, Q
+  u32 pn;            // node capacity (LDS)
+  u32 max_l;         // longest haplotype of the batch
+  u32 w_stride;      // i32 per stored row and matrix
+  u32 row_slots;     // stored rows per window
+  size_t code_cells; // u16 per window
+  size_t row_cells;  // i32 per window
+  u16* codes;
+  i32* rows;
+  i32* hlast;        // [w][pn + 8] H(i, L)
 };
 
-// All graph arrays live in the kernel's dynamic LDS.  They are addressed as offsets into the
-// __shared__ array (NOT through generic pointers kept in a struct: those compile to flat_load + pointer
-// reloads from scratch instead of ds_read).
+// All per-window state lives in the kernel's dynamic LDS and is addressed as offsets into the
+// __shared__ array (NOT through generic pointers kept in a struct: those compile to flat_load).
 extern __shared__ unsigned char ma_lds[];
 template <class T>
 struct LdsArr {
@@ -54,66 +67,155 @@ struct LdsArr {
   __device__ __forceinline__ T& operator[](u32 i) const { return *reinterpret_cast<T*>(&ma_lds[off + i * sizeof(T)]); }
 };
 
-struct PG {  // LDS-resident POA graph of one window
-  u32 nn, nseq, nrank;
-  u32 pn;
-  LdsArr<u8> nchar, nin, nout, nal, marks, ignored;
-  LdsArr<u16> in_tail, out_head, out_lab, al, rank2node, node2rank;
-  LdsArr<u16> stack;  // DFS stack; aliased by the column-0 DP values during alignment
-  u32 stack_cap;
+struct WgState {
+  u32 nn, nseq, nrank, overflow;
   i32 seq_first[16];
-  bool overflow;
+  u32 mode, V, L, cw, naln, nslow;
+  i32 best;
+  u32 best_row;
+  i32 mbox[2][4][4];
+  u32 wsum[4];
+  i32 red_v[4];
+  u32 red_r[4];
+  i32 begin, prev0, lastn;
+  u32 nv;
+  u32 x_done, x_a, x_ns;
+  u32 win_overflow;
+};
+#define ST (*reinterpret_cast<WgState*>(ma_lds))
+constexpr u32 kStBytes = (sizeof(WgState) + 15u) & ~15u;
+
+struct GL {  // LDS layout of one window's POA graph + scratch
+  u32 pn;
+  LdsArr<u8> nchar, nin, nout, nal;
+  LdsArr<u16> in_tail, out_head, out_lab, al, rank2node, node2rank, ndepth;
+  // scratch, alignment phase
+  LdsArr<u32> rowinfo;
+  LdsArr<u16> rowslot, rowdepth, slowpred, aln;
+  u32 aln_cap;
+  // scratch, graph update (aliases rowinfo .. rowdepth)
+  LdsArr<u16> cnode, cpos, ccur;
+  // scratch, topological sort (aliases everything above)
+  LdsArr<u16> stack;
+  LdsArr<u8> marks, ignored;
+  u32 stack_cap;
 };
 
-__device__ i32 pg_add_node(PG& g, u8 ch) {
-  if (g.nn >= g.pn) {
-    g.overflow = true;
+__host__ __device__ inline size_t poa_lds_bytes(u32 pn, u32 ml) {
+  size_t const graph = size_t(42) * pn;
+  size_t const s_aln = size_t(8) * (pn + 2) + 8 * kSlowCap + size_t(4) * (pn + ml + 2);
+  size_t const s_topo = size_t(10) * pn;
+  return kStBytes + graph + (s_aln > s_topo ? s_aln : s_topo) + 16;
+}
+
+__device__ __forceinline__ GL poa_carve(u32 PN, u32 ML) {
+  GL g;
+  g.pn = PN;
+  u32 o = kStBytes;
+  g.nchar.off = o;
+  g.nin.off = o + PN;
+  g.nout.off = o + 2 * PN;
+  g.nal.off = o + 3 * PN;
+  o += 4 * PN;
+  g.in_tail.off = o;
+  g.out_head.off = o + 8 * PN;
+  g.out_lab.off = o + 16 * PN;
+  g.al.off = o + 24 * PN;
+  o += 32 * PN;
+  g.rank2node.off = o;
+  g.node2rank.off = o + 2 * PN;
+  g.ndepth.off = o + 4 * PN;
+  o += 6 * PN;
+  u32 const S = o;
+  g.rowinfo.off = S;
+  g.rowslot.off = S + 4 * (PN + 2);
+  g.rowdepth.off = S + 6 * (PN + 2);
+  g.slowpred.off = S + 8 * (PN + 2);
+  g.aln.off = S + 8 * (PN + 2) + 8 * kSlowCap;
+  g.aln_cap = PN + ML + 2;
+  g.cnode.off = S;
+  g.cpos.off = S + 2 * (ML + 2);
+  g.ccur.off = S + 4 * (ML + 2);
+  g.stack.off = S;
+  g.stack_cap = 4 * PN;
+  g.marks.off = S + 8 * PN;
+  g.ignored.off = S + 9 * PN;
+  return g;
+}
+
+// Barrier that orders LDS traffic only: the pipeline's HBM stores stay in flight across steps.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// ---- serial graph primitives (thread 0): spoa::Graph ----
+__device__ i32 pg_add_node(GL const& g, u8 ch) {
+  if (ST.nn >= g.pn) {
+    ST.overflow = 1;
     return 0;
   }
-  u32 const id = g.nn++;
+  u32 const id = ST.nn++;
   g.nchar[id] = ch;
   g.nin[id] = g.nout[id] = g.nal[id] = 0;
   return static_cast<i32>(id);
 }
-__device__ void pg_add_edge(PG& g, u32 tail, u32 head) {  // spoa::Graph::AddEdge (weights dropped)
-  u16 const lab = static_cast<u16>(1u << g.nseq);
-  for (int x = 0; x < g.nout[tail]; ++x)
+// spoa::Graph::AddEdge (weights dropped).  Also used lane-parallel by the graph update: there every
+// call touches the out-list of a distinct tail and the in-list of a distinct head.
+__device__ void pg_add_edge(GL const& g, u32 tail, u32 head, u16 lab) {
+  u32 const no = g.nout[tail];
+  for (u32 x = 0; x < no; ++x)
     if (g.out_head[tail * kPE + x] == head) {
       g.out_lab[tail * kPE + x] |= lab;
       return;
     }
-  if (g.nout[tail] >= kPE || g.nin[head] >= kPE) {
-    g.overflow = true;
+  u32 const ni = g.nin[head];
+  if (no >= kPE || ni >= kPE) {
+    atomicOr(&ST.overflow, 1u);
     return;
   }
-  g.out_head[tail * kPE + g.nout[tail]] = static_cast<u16>(head);
-  g.out_lab[tail * kPE + g.nout[tail]] = lab;
-  g.nout[tail]++;
-  g.in_tail[head * kPE + g.nin[head]++] = static_cast<u16>(tail);
+  g.out_head[tail * kPE + no] = static_cast<u16>(head);
+  g.out_lab[tail * kPE + no] = lab;
+  g.nout[tail] = static_cast<u8>(no + 1);
+  g.in_tail[head * kPE + ni] = static_cast<u16>(tail);
+  g.nin[head] = static_cast<u8>(ni + 1);
 }
-__device__ i32 pg_add_sequence(PG& g, const u8* seq, u32 begin, u32 end) {  // spoa::Graph::AddSequence
-  if (begin == end) return -1;
+__device__ i32 pg_add_sequence(GL const& g, const u8* seq, u32 begin, u32 end) {  // spoa::Graph::AddSequence
+  if (begin >= end) return -1;
   i32 prev = -1;
-  u32 const first = g.nn;
+  u32 const first = ST.nn;
+  u16 const lab = static_cast<u16>(1u << ST.nseq);
   for (u32 i = begin; i < end; ++i) {
     i32 const cur = pg_add_node(g, seq[i]);
-    if (g.overflow) return -1;
-    if (prev >= 0) pg_add_edge(g, static_cast<u32>(prev), static_cast<u32>(cur));
+    if (ST.overflow) return -1;
+    if (prev >= 0) pg_add_edge(g, static_cast<u32>(prev), static_cast<u32>(cur), lab);
     prev = cur;
   }
   return static_cast<i32>(first);
 }
-__device__ i32 pg_successor(const PG& g, u32 node, u32 label) {  // spoa::Graph::Node::Successor
+__device__ i32 pg_successor(GL const& g, u32 node, u32 label) {  // spoa::Graph::Node::Successor
   for (int x = 0; x < g.nout[node]; ++x)
     if (g.out_lab[node * kPE + x] & (1u << label)) return static_cast<i32>(g.out_head[node * kPE + x]);
   return -1;
 }
-// spoa::Graph::TopologicalSort
-__device__ void pg_toposort(PG& g) {
-  for (u32 i = 0; i < g.nn; ++i) g.marks[i] = g.ignored[i] = 0;
-  g.nrank = 0;
+// spoa::Graph::TopologicalSort.  Also records every node's minimum hop distance from a root at the
+// moment it gets its rank (all in-neighbours are ranked by then): that distance is all column 0 of the
+// DP depends on (SisdAlignmentEngine::Initialize: O0 = Q + C d, F0 = G + E d).
+__device__ void pg_toposort(GL const& g) {
+  u32 const nn = ST.nn;
+  for (u32 i = 0; i < nn; ++i) g.marks[i] = g.ignored[i] = 0;
+  u32 nrank = 0;
+  bool overflow = false;
   LdsArr<u16> const stack = g.stack;
-  for (u32 s = 0; s < g.nn; ++s) {
+  auto emit = [&](u32 node) {
+    g.rank2node[nrank++] = static_cast<u16>(node);
+    u32 const ni = g.nin[node];
+    u32 d = 0;
+    if (ni) {
+      d = 0xFFFFu;
+      for (u32 x = 0; x < ni; ++x) d = min(d, static_cast<u32>(g.ndepth[g.in_tail[node * kPE + x]]));
+      d += 1;
+    }
+    g.ndepth[node] = static_cast<u16>(d);
+  };
+  for (u32 s = 0; s < nn && !overflow; ++s) {
     if (g.marks[s] != 0) continue;
     u32 sp = 0;
     stack[sp++] = static_cast<u16>(s);
@@ -124,7 +226,7 @@ __device__ void pg_toposort(PG& g) {
         for (int x = 0; x < g.nin[cur]; ++x) {
           u32 const t = g.in_tail[cur * kPE + x];
           if (g.marks[t] != 2) {
-            if (sp < g.stack_cap) stack[sp++] = static_cast<u16>(t); else g.overflow = true;
+            if (sp < g.stack_cap) stack[sp++] = static_cast<u16>(t); else overflow = true;
             valid = false;
           }
         }
@@ -132,7 +234,7 @@ __device__ void pg_toposort(PG& g) {
           for (int x = 0; x < g.nal[cur]; ++x) {
             u32 const an = g.al[cur * kPE + x];
             if (g.marks[an] != 2) {
-              if (sp < g.stack_cap) stack[sp++] = static_cast<u16>(an); else g.overflow = true;
+              if (sp < g.stack_cap) stack[sp++] = static_cast<u16>(an); else overflow = true;
               g.ignored[an] = 1;
               valid = false;
             }
@@ -141,81 +243,19 @@ __device__ void pg_toposort(PG& g) {
         if (valid) {
           g.marks[cur] = 2;
           if (!g.ignored[cur]) {
-            g.rank2node[g.nrank++] = static_cast<u16>(cur);
-            for (int x = 0; x < g.nal[cur]; ++x) g.rank2node[g.nrank++] = g.al[cur * kPE + x];
+            emit(cur);
+            for (int x = 0; x < g.nal[cur]; ++x) emit(g.al[cur * kPE + x]);
           }
         } else {
           g.marks[cur] = 1;
         }
       }
       if (valid) sp--;
-      if (g.overflow) return;
+      if (overflow) break;
     }
   }
-  for (u32 r = 0; r < g.nrank; ++r) g.node2rank[g.rank2node[r]] = static_cast<u16>(r);
-}
-
-// spoa::Graph::AddAlignment; aln pairs are (node id + 1 | 0, seq pos + 1 | 0) in LDS
-__device__ void pg_add_alignment(PG& g, LdsArr<u16> aln, u32 naln, const u8* seq, u32 len) {
-  if (len == 0) return;
-  if (naln == 0) {
-    i32 const first = pg_add_sequence(g, seq, 0, len);
-    g.seq_first[g.nseq++] = first;
-    if (!g.overflow) pg_toposort(g);
-    return;
-  }
-  i32 vfront = -1, vback = -1;
-  for (u32 x = 0; x < naln; ++x)
-    if (aln[2 * x + 1] != 0) {
-      if (vfront < 0) vfront = static_cast<i32>(aln[2 * x + 1]) - 1;
-      vback = static_cast<i32>(aln[2 * x + 1]) - 1;
-    }
-  i32 begin = pg_add_sequence(g, seq, 0, static_cast<u32>(vfront));
-  i32 prev = begin >= 0 ? static_cast<i32>(g.nn - 1) : -1;
-  i32 const last = pg_add_sequence(g, seq, static_cast<u32>(vback) + 1, len);
-  for (u32 x = 0; x < naln && !g.overflow; ++x) {
-    if (aln[2 * x + 1] == 0) continue;
-    u32 const sp = static_cast<u32>(aln[2 * x + 1]) - 1;
-    u8 const ch = seq[sp];
-    i32 curr = -1;
-    if (aln[2 * x] == 0) {
-      curr = pg_add_node(g, ch);
-    } else {
-      u32 const jt = static_cast<u32>(aln[2 * x]) - 1;
-      if (g.nchar[jt] == ch) {
-        curr = static_cast<i32>(jt);
-      } else {
-        for (int y = 0; y < g.nal[jt]; ++y)
-          if (g.nchar[g.al[jt * kPE + y]] == ch) {
-            curr = static_cast<i32>(g.al[jt * kPE + y]);
-            break;
-          }
-        if (curr < 0) {
-          curr = pg_add_node(g, ch);
-          if (g.overflow) break;
-          int const na = g.nal[jt];
-          if (na + 1 > kPE) {
-            g.overflow = true;
-            break;
-          }
-          for (int y = 0; y < na; ++y) {
-            u32 const kt = g.al[jt * kPE + y];
-            g.al[kt * kPE + g.nal[kt]++] = static_cast<u16>(curr);
-            g.al[static_cast<u32>(curr) * kPE + g.nal[curr]++] = static_cast<u16>(kt);
-          }
-          g.al[jt * kPE + g.nal[jt]++] = static_cast<u16>(curr);
-          g.al[static_cast<u32>(curr) * kPE + g.nal[curr]++] = static_cast<u16>(jt);
-        }
-      }
-    }
-    if (g.overflow) break;
-    if (begin < 0) begin = curr;
-    if (prev >= 0) pg_add_edge(g, static_cast<u32>(prev), static_cast<u32>(curr));
-    prev = curr;
-  }
-  if (last >= 0 && prev >= 0) pg_add_edge(g, static_cast<u32>(prev), static_cast<u32>(last));
-  g.seq_first[g.nseq++] = begin;
-  if (!g.overflow) pg_toposort(g);
+  ST.nrank = nrank;
+  if (overflow) ST.overflow = 1;
 }
 
 __device__ i32 classify_variant(const u8* r, u32 rl, const u8* a, u32 al) {  // raw_variant.cpp:44-77
@@ -248,244 +288,21 @@ __device__ int bytes_cmp(const u8* a, u32 al, const u8* b, u32 bl) {  // std::st
   return al < bl ? -1 : (al > bl ? 1 : 0);
 }
 
-
-// predecessor DP row x of DP row i (row = rank + 1), in in-edge order
-__device__ __forceinline__ u32 row_pred(const PG& g, u32 node, u32 x) {
+// DP row of predecessor x of DP row i (row = rank + 1), in in-edge order
+__device__ __forceinline__ u32 pred_row(GL const& g, u32 i, u32 info, u32 x) {
+  if (info & RI_FAST) return i - 1;
+  if (info & RI_SLOWTAB) return g.slowpred[(info >> 16) * kPE + x];
+  u32 const node = g.rank2node[i - 1];
   return static_cast<u32>(g.node2rank[g.in_tail[node * kPE + x]]) + 1u;
 }
 
-// DP matrices are stored SKEWED so that the pipeline's stores coalesce: cell (i, j >= 1) belongs to lane
-// l = (j-1)/cw, c = (j-1)%cw and lives at (i + l) * 64*cw + l*cw + c -- at pipeline step t every lane
-// works on i + l == t + 1, so one store instruction of the wave covers 64 * 16 B of contiguous HBM.
-// Column 0 of the five matrices is kept in five small side arrays.
-// Bodies are stored as saturated i16: every value on or next to an optimal path is a real score
-// (>= -6 * max_hap_len - 26 > -32768), and "minus infinity" cells only ever lose max() comparisons and
-// equality tests, so clamping them to -32768 cannot change the traceback (column 0 stays i32).
-struct DP {
-  i16 *H, *F, *E, *O, *Q;      // skewed bodies
-  i32 *H0, *F0, *E0, *O0, *Q0; // column 0, [V + 1]
-  u32 cw, rs;                  // columns per lane (multiple of 4), row stride = 64 * cw
-  __device__ __forceinline__ size_t off(u32 i, u32 j) const {  // j >= 1
-    u32 const l = (j - 1) / cw;
-    return static_cast<size_t>(i + l) * rs + (j - 1);
-  }
-  // column 0 holds true i32 values; clamp on read so both sources compare on the same scale
-  __device__ __forceinline__ static i32 c0(i32 v) { return v < -32768 ? -32768 : v; }
-  __device__ __forceinline__ i32 h(u32 i, u32 j) const { return j ? H[off(i, j)] : c0(H0[i]); }
-  __device__ __forceinline__ i32 f(u32 i, u32 j) const { return j ? F[off(i, j)] : c0(F0[i]); }
-  __device__ __forceinline__ i32 e(u32 i, u32 j) const { return j ? E[off(i, j)] : c0(E0[i]); }
-  __device__ __forceinline__ i32 o(u32 i, u32 j) const { return j ? O[off(i, j)] : c0(O0[i]); }
-  __device__ __forceinline__ i32 q(u32 i, u32 j) const { return j ? Q[off(i, j)] : c0(Q0[i]); }
-};
-
-// Skewed-pipeline fill of the five DP matrices (SisdAlignmentEngine::Convex, alignment phase).
-// Fast path (L <= 64 * CWM): the row a lane finished in the previous step stays in registers.
-constexpr int CWM = 16;
-__device__ __forceinline__ u32 sat_pack(i32 a, i32 b) {  // two saturated i16 in one register
-  a = a < -32768 ? -32768 : a;
-  b = b < -32768 ? -32768 : b;
-  return (static_cast<u32>(a) & 0xFFFFu) | (static_cast<u32>(b) << 16);
+// closed forms of DP row 0 and DP column 0 (SisdAlignmentEngine::Initialize, kNW convex)
+__device__ __forceinline__ i32 row0_h(u32 j) {
+  return j == 0 ? 0 : max(Q_ + static_cast<i32>(j - 1) * C_, G_ + static_cast<i32>(j - 1) * E_);
 }
-__device__ void poa_fill(const PG& g, const DP& d, u32 V, u32 L, int lane, const u8* seq, LdsArr<i32> col0) {
-  u32 const cw = d.cw;
-  u32 const jb = 1 + lane * cw;
-  u32 const je = min(L + 1, jb + cw);
-  u32 const nl = (L + cw - 1) / cw;
-  u32 scp[CWM / 4];  // the lane's sequence chars, packed 4 per register
-#pragma unroll
-  for (int c4 = 0; c4 < CWM / 4; ++c4) {
-    u32 pk = 0;
-#pragma unroll
-    for (int b = 0; b < 4; ++b) pk |= static_cast<u32>((jb + c4 * 4 + b < je) ? seq[jb + c4 * 4 + b - 1] : 0) << (8 * b);
-    scp[c4] = pk;
-  }
-  i32 pH[CWM], pF[CWM], pO[CWM];
-  i32 pHl = 0;
-#pragma unroll
-  for (int c = 0; c < CWM; ++c) pH[c] = pF[c] = pO[c] = 0;
-  i32 hl = 0, el = 0, ql = 0;
-  for (u32 t = 0; t + 1 < V + nl; ++t) {
-    i32 const hL = __shfl_up(hl, 1), eL = __shfl_up(el, 1), qL = __shfl_up(ql, 1);
-    i32 const row = static_cast<i32>(t) - lane + 1;
-    bool const work = lane < static_cast<int>(nl) && row >= 1 && row <= static_cast<i32>(V);
-    u32 node = 0, np = 0;
-    bool needs_hbm = false;
-    if (work) {
-      node = g.rank2node[row - 1];
-      np = g.nin[node];
-      if (np == 0) needs_hbm = true;
-      for (u32 x = 0; x < np; ++x) needs_hbm |= !(row_pred(g, node, x) + 1 == static_cast<u32>(row) && row >= 2);
-    }
-    // rows read back from HBM were written by other lanes of this wave >= 2 steps ago: make them visible
-    if (__any(needs_hbm)) __threadfence_block();
-    if (work) {
-      u32 const i = static_cast<u32>(row);
-      u32 const nch = g.nchar[node];
-      i32 f[CWM], o[CWM], hm[CWM];
-      for (u32 x = 0; x < (np ? np : 1u); ++x) {
-        u32 const pr = np ? row_pred(g, node, x) : 0u;
-        if (pr + 1 == i && i >= 2) {  // previous rank: still in registers
-          i32 hprev = pHl;
-#pragma unroll
-          for (int c = 0; c < CWM; ++c) {
-            i32 const mc = (nch == ((scp[c >> 2] >> (8 * (c & 3))) & 0xFFu)) ? M_ : N_;
-            i32 const fv = max(pH[c] + G_, pF[c] + E_);
-            i32 const ov = max(pH[c] + Q_, pO[c] + C_);
-            i32 const hv = hprev + mc;
-            hprev = pH[c];
-            if (x == 0) {
-              f[c] = fv;
-              o[c] = ov;
-              hm[c] = hv;
-            } else {
-              f[c] = max(f[c], fv);
-              o[c] = max(o[c], ov);
-              hm[c] = max(hm[c], hv);
-            }
-          }
-        } else {
-          size_t const pb = static_cast<size_t>(pr + lane) * d.rs + static_cast<size_t>(lane) * cw;
-          i32 hprev = lane == 0 ? DP::c0(d.H0[pr])
-                                : d.H[static_cast<size_t>(pr + lane - 1) * d.rs + static_cast<size_t>(lane) * cw - 1];
-#pragma unroll
-          for (int c = 0; c < CWM; ++c) {
-            bool const in = static_cast<u32>(c) < cw;
-            i32 const hc = in ? d.H[pb + c] : 0;
-            i32 const fc = in ? d.F[pb + c] : 0;
-            i32 const oc = in ? d.O[pb + c] : 0;
-            i32 const mc = (nch == ((scp[c >> 2] >> (8 * (c & 3))) & 0xFFu)) ? M_ : N_;
-            i32 const fv = max(hc + G_, fc + E_);
-            i32 const ov = max(hc + Q_, oc + C_);
-            i32 const hv = hprev + mc;
-            hprev = hc;
-            if (x == 0) {
-              f[c] = fv;
-              o[c] = ov;
-              hm[c] = hv;
-            } else {
-              f[c] = max(f[c], fv);
-              o[c] = max(o[c], ov);
-              hm[c] = max(hm[c], hv);
-            }
-          }
-        }
-      }
-      i32 hleft, eleft, qleft;
-      if (lane == 0) {  // column 0 (kept in LDS): H = max(O, F), E = Q = -inf
-        hleft = max(col0[2 * i], col0[2 * i + 1]);
-        eleft = kNegInf;
-        qleft = kNegInf;
-      } else {
-        hleft = hL;
-        eleft = eL;
-        qleft = qL;
-      }
-      pHl = hleft;
-      i32 ev[CWM], qv[CWM];
-#pragma unroll
-      for (int c = 0; c < CWM; ++c) {
-        i32 const e = max(hleft + G_, eleft + E_);
-        i32 const q = max(hleft + Q_, qleft + C_);
-        i32 const h = max(hm[c], max(max(f[c], e), max(o[c], q)));
-        ev[c] = e;
-        qv[c] = q;
-        if (jb + c < je) {  // columns past the haplotype end are never read back
-          hleft = h;
-          eleft = e;
-          qleft = q;
-        }
-        pH[c] = h;
-        pF[c] = f[c];
-        pO[c] = o[c];
-      }
-      size_t const ob = static_cast<size_t>(i + lane) * d.rs + static_cast<size_t>(lane) * cw;  // 8-element aligned
-#pragma unroll
-      for (int c8 = 0; c8 < CWM / 8; ++c8) {
-        if (static_cast<u32>(c8 * 8) < cw) {
-          int const c = c8 * 8;
-          if (static_cast<u32>(c + 4) < cw) {
-            *reinterpret_cast<uint4*>(d.H + ob + c) = make_uint4(sat_pack(pH[c], pH[c + 1]), sat_pack(pH[c + 2], pH[c + 3]), sat_pack(pH[c + 4], pH[c + 5]), sat_pack(pH[c + 6], pH[c + 7]));
-            *reinterpret_cast<uint4*>(d.F + ob + c) = make_uint4(sat_pack(f[c], f[c + 1]), sat_pack(f[c + 2], f[c + 3]), sat_pack(f[c + 4], f[c + 5]), sat_pack(f[c + 6], f[c + 7]));
-            *reinterpret_cast<uint4*>(d.O + ob + c) = make_uint4(sat_pack(o[c], o[c + 1]), sat_pack(o[c + 2], o[c + 3]), sat_pack(o[c + 4], o[c + 5]), sat_pack(o[c + 6], o[c + 7]));
-            *reinterpret_cast<uint4*>(d.E + ob + c) = make_uint4(sat_pack(ev[c], ev[c + 1]), sat_pack(ev[c + 2], ev[c + 3]), sat_pack(ev[c + 4], ev[c + 5]), sat_pack(ev[c + 6], ev[c + 7]));
-            *reinterpret_cast<uint4*>(d.Q + ob + c) = make_uint4(sat_pack(qv[c], qv[c + 1]), sat_pack(qv[c + 2], qv[c + 3]), sat_pack(qv[c + 4], qv[c + 5]), sat_pack(qv[c + 6], qv[c + 7]));
-          } else {  // cw == c + 4: only four columns left in this lane's chunk
-            *reinterpret_cast<uint2*>(d.H + ob + c) = make_uint2(sat_pack(pH[c], pH[c + 1]), sat_pack(pH[c + 2], pH[c + 3]));
-            *reinterpret_cast<uint2*>(d.F + ob + c) = make_uint2(sat_pack(f[c], f[c + 1]), sat_pack(f[c + 2], f[c + 3]));
-            *reinterpret_cast<uint2*>(d.O + ob + c) = make_uint2(sat_pack(o[c], o[c + 1]), sat_pack(o[c + 2], o[c + 3]));
-            *reinterpret_cast<uint2*>(d.E + ob + c) = make_uint2(sat_pack(ev[c], ev[c + 1]), sat_pack(ev[c + 2], ev[c + 3]));
-            *reinterpret_cast<uint2*>(d.Q + ob + c) = make_uint2(sat_pack(qv[c], qv[c + 1]), sat_pack(qv[c + 2], qv[c + 3]));
-          }
-        }
-      }
-      hl = hleft;
-      el = eleft;
-      ql = qleft;
-    }
-  }
-  __threadfence_block();
-}
-
-// Generic path for haplotypes longer than 64 * CWM columns: same recurrences and layout, every
-// predecessor row is read back from HBM (no register-resident row).
-__device__ void poa_fill_long(const PG& g, const DP& d, u32 V, u32 L, int lane, const u8* seq, LdsArr<i32> col0) {
-  u32 const cw = d.cw;
-  u32 const jb = 1 + lane * cw;
-  u32 const je = min(L + 1, jb + cw);
-  u32 const nl = (L + cw - 1) / cw;
-  i32 hl = 0, el = 0, ql = 0;
-  for (u32 t = 0; t + 1 < V + nl; ++t) {
-    i32 const hL = __shfl_up(hl, 1), eL = __shfl_up(el, 1), qL = __shfl_up(ql, 1);
-    i32 const row = static_cast<i32>(t) - lane + 1;
-    __threadfence_block();
-    if (lane < static_cast<int>(nl) && row >= 1 && row <= static_cast<i32>(V)) {
-      u32 const i = static_cast<u32>(row);
-      u32 const node = g.rank2node[i - 1];
-      u32 const np = g.nin[node];
-      u8 const nch = g.nchar[node];
-      i32 hleft, eleft, qleft;
-      if (lane == 0) {
-        hleft = max(col0[2 * i], col0[2 * i + 1]);
-        eleft = kNegInf;
-        qleft = kNegInf;
-      } else {
-        hleft = hL;
-        eleft = eL;
-        qleft = qL;
-      }
-      for (u32 j = jb; j < je; ++j) {
-        i32 const mc = (nch == seq[j - 1]) ? M_ : N_;
-        i32 f = kNegInf, o = kNegInf, hm = kNegInf;
-        for (u32 x = 0; x < (np ? np : 1u); ++x) {
-          u32 const pr = np ? row_pred(g, node, x) : 0u;
-          i32 const hpj = d.h(pr, j);
-          i32 const fv = max(hpj + G_, d.f(pr, j) + E_);
-          i32 const ov = max(hpj + Q_, d.o(pr, j) + C_);
-          i32 const hv = d.h(pr, j - 1) + mc;
-          f = x == 0 ? fv : max(f, fv);
-          o = x == 0 ? ov : max(o, ov);
-          hm = x == 0 ? hv : max(hm, hv);
-        }
-        i32 const e = max(hleft + G_, eleft + E_);
-        i32 const q = max(hleft + Q_, qleft + C_);
-        i32 const h = max(hm, max(max(f, e), max(o, q)));
-        size_t const ox = d.off(i, j);
-        d.F[ox] = static_cast<i16>(DP::c0(f));
-        d.O[ox] = static_cast<i16>(DP::c0(o));
-        d.E[ox] = static_cast<i16>(DP::c0(e));
-        d.Q[ox] = static_cast<i16>(DP::c0(q));
-        d.H[ox] = static_cast<i16>(DP::c0(h));
-        hleft = h;
-        eleft = e;
-        qleft = q;
-      }
-      hl = hleft;
-      el = eleft;
-      ql = qleft;
-    }
-  }
-  __threadfence_block();
-}
+__device__ __forceinline__ i32 col0_o(u32 d) { return Q_ + C_ * static_cast<i32>(d); }
+__device__ __forceinline__ i32 col0_f(u32 d) { return G_ + E_ * static_cast<i32>(d); }
+__device__ __forceinline__ i32 col0_h(u32 d) { return max(col0_o(d), col0_f(d)); }
 
 #ifdef MA_PROFILE
 __device__ unsigned long long g_prof[16];
@@ -493,7 +310,7 @@ __device__ unsigned long long g_prof[16];
 #define PROF_ACC(slot)                                                        \
   do {                                                                        \
     unsigned long long _t1 = __builtin_amdgcn_s_memtime();                    \
-    if (lane == 0) atomicAdd(&g_prof[slot], _t1 - _t0);                       \
+    if (tid == 0) atomicAdd(&g_prof[slot], _t1 - _t0);                        \
     _t0 = _t1;                                                                \
   } while (0)
 #else
@@ -501,13 +318,536 @@ __device__ unsigned long long g_prof[16];
 #define PROF_ACC(slot) do {} while (0)
 #endif
 
-struct Shared {
-  u32 V, L, W;
-  u32 go;
-  u32 abort_;
-};
+// block-wide exclusive scan of one value per thread (two barriers)
+__device__ u32 block_excl_scan(u32 v, int tid, u32& total) {
+  int const lane = tid & 63, wave = tid >> 6;
+  u32 inc = v;
+  for (int d = 1; d < 64; d <<= 1) {
+    u32 const y = __shfl_up(inc, d);
+    if (lane >= d) inc += y;
+  }
+  if (lane == 63) ST.wsum[wave] = inc;
+  __syncthreads();
+  u32 base = 0, tot = 0;
+  for (int k = 0; k < 4; ++k) {
+    u32 const s = ST.wsum[k];
+    if (k < wave) base += s;
+    tot += s;
+  }
+  __syncthreads();
+  total = tot;
+  return base + inc - v;
+}
 
-}  // namespace
+// ---- the skewed-pipeline fill: decision codes + the rows later rows must read back ----
+template <int CW>
+__device__ void poa_fill(GL const& g, PoaWs const& ws, u16* codes, i32* rows, i32* hlast, u32 V, u32 L, int tid,
+                         const u8* seq) {
+  int const lane = tid & 63, wave = tid >> 6;
+  u32 const gl = static_cast<u32>(tid);
+  u32 const jb = 1 + gl * CW;
+  u32 const je = min(L + 1, jb + CW);
+  u32 const nl = (L + CW - 1) / CW;
+  bool const lane_on = gl < nl;
+  u32 const glL = (L - 1) / CW, cL = (L - 1) % CW;
+  u32 sc[CW];
+#pragma unroll
+  for (int c = 0; c < CW; ++c) sc[c] = (lane_on && jb + c < je) ? seq[jb + c - 1] : 0u;
+  constexpr bool kPrev2 = CW <= 8;  // wide lanes keep only one previous row in registers
+  constexpr int CW2 = kPrev2 ? CW : 1;
+  i32 H1[CW], F1[CW], O1[CW], H2[CW2], F2[CW2], O2[CW2];
+#pragma unroll
+  for (int c = 0; c < CW; ++c) H1[c] = F1[c] = O1[c] = 0;
+#pragma unroll
+  for (int c = 0; c < CW2; ++c) H2[c] = F2[c] = O2[c] = 0;
+  i32 hl1 = 0, hl2 = 0, hl = 0, el = 0, ql = 0;
+  u32 pend = 0;
+  u32 const steps = V + nl - 1;
+  for (u32 t = 0; t < steps; ++t) {
+    i32 hL = __shfl_up(hl, 1), eL = __shfl_up(el, 1), qL = __shfl_up(ql, 1);
+    if (lane == 0 && wave > 0) {
+      i32 const* mb = ST.mbox[(t + 1) & 1][wave - 1];
+      hL = mb[0];
+      eL = mb[1];
+      qL = mb[2];
+    }
+    i32 const row = static_cast<i32>(t) - static_cast<i32>(gl) + 1;
+    bool const work = lane_on && row >= 1 && row <= static_cast<i32>(V);
+    bool stored = false;
+    if (work) {
+      u32 const i = static_cast<u32>(row);
+      u32 const info = g.rowinfo[i];
+      u32 const nch = info & 0xFFu, np = (info >> 8) & 7u;
+      i32 hleft, eleft, qleft;
+      if (gl == 0) {  // column 0: H = max(O, F), E = Q = -inf
+        hleft = col0_h(g.rowdepth[i]);
+        eleft = kNegInf;
+        qleft = kNegInf;
+      } else {
+        hleft = hL;
+        eleft = eL;
+        qleft = qL;
+      }
+      i32 const hl0 = hleft;
+      i32 hh[CW], ff[CW], oo[CW];
+      u32 cd[CW];
+      if (info & RI_FAST) {
+        i32 hd = hl1;
+#pragma unroll
+        for (int c = 0; c < CW; ++c) {
+          i32 const ph = H1[c], pf = F1[c], po = O1[c];
+          i32 const a1 = pf + E_, a2 = ph + G_, a3 = po + C_, a4 = ph + Q_;
+          i32 const fv = max(a1, a2), ov = max(a3, a4);
+          i32 const hm = hd + ((nch == sc[c]) ? M_ : N_);
+          hd = ph;
+          i32 const b1 = eleft + E_, b2 = hleft + G_, b3 = qleft + C_, b4 = hleft + Q_;
+          i32 const e = max(b1, b2), q = max(b3, b4);
+          i32 const u = max(fv, ov), l = max(e, q);
+          i32 const h = max(hm, max(u, l));
+          bool const D = h == hm, U = h == u;
+          bool const eu = (h == a1) || ((h != a2) && (h == a3));
+          bool const elx = (h == b1) || ((h != b2) && (h == b3));
+          bool const lc = (b1 == e) || (b3 == q);
+          bool const us = (fv == a1) || (ov == a3);
+          bool const uh = (fv == a2) || (ov == a4);
+          u32 code = D ? 0u : (U ? 1u : 2u);
+          code |= (!D && (U ? eu : elx)) ? 4u : 0u;
+          code |= lc ? 8u : 0u;
+          code |= us ? 16u : (uh ? 32u : 0u);
+          cd[c] = code;
+          hh[c] = h;
+          ff[c] = fv;
+          oo[c] = ov;
+          if (jb + c < je) {  // columns past the haplotype end are never read back
+            hleft = h;
+            eleft = e;
+            qleft = q;
+          }
+        }
+      } else {
+        // general row: any number of predecessors, each taken from the rank-1 / rank-2 registers, the
+        // closed form of row 0 (a node without in-edges hangs off the virtual start row) or the row store
+        auto fetch = [&](u32 pr, i32(&th)[CW], i32(&tf)[CW], i32(&to)[CW], i32& thd) {
+          if (pr == 0) {
+#pragma unroll
+            for (int c = 0; c < CW; ++c) {
+              th[c] = row0_h(jb + c);
+              tf[c] = kNegInf;
+              to[c] = kNegInf;
+            }
+            thd = row0_h(jb - 1);
+          } else if (pr + 1 == i) {
+#pragma unroll
+            for (int c = 0; c < CW; ++c) {
+              th[c] = H1[c];
+              tf[c] = F1[c];
+              to[c] = O1[c];
+            }
+            thd = hl1;
+          } else if (kPrev2 && pr + 2 == i) {
+#pragma unroll
+            for (int c = 0; c < CW; ++c) {
+              th[c] = H2[kPrev2 ? c : 0];
+              tf[c] = F2[kPrev2 ? c : 0];
+              to[c] = O2[kPrev2 ? c : 0];
+            }
+            thd = hl2;
+          } else {
+            u32 const slot = g.rowslot[pr];
+            const i32* rb = rows + static_cast<size_t>(slot) * 3 * ws.w_stride + static_cast<size_t>(gl) * CW;
+#pragma unroll
+            for (int c = 0; c < CW; ++c) {
+              th[c] = rb[c];
+              tf[c] = rb[ws.w_stride + c];
+              to[c] = rb[2 * static_cast<size_t>(ws.w_stride) + c];
+            }
+            thd = gl == 0 ? col0_h(g.rowdepth[pr]) : rb[-1];
+          }
+        };
+        u32 const npe = np ? np : 1u;
+        for (u32 x = 0; x < npe; ++x) {
+          u32 const pr = np ? pred_row(g, i, info, x) : 0u;
+          i32 th[CW], tf[CW], to[CW], hd;
+          fetch(pr, th, tf, to, hd);
+#pragma unroll
+          for (int c = 0; c < CW; ++c) {
+            i32 const fv = max(tf[c] + E_, th[c] + G_), ov = max(to[c] + C_, th[c] + Q_);
+            i32 const hv = hd + ((nch == sc[c]) ? M_ : N_);
+            hd = th[c];
+            if (x == 0) {
+              ff[c] = fv;
+              oo[c] = ov;
+              hh[c] = hv;  // running max of the diagonal candidates
+            } else {
+              ff[c] = max(ff[c], fv);
+              oo[c] = max(oo[c], ov);
+              hh[c] = max(hh[c], hv);
+            }
+          }
+        }
+        u32 elmask = 0, lcmask = 0;
+#pragma unroll
+        for (int c = 0; c < CW; ++c) {
+          i32 const b1 = eleft + E_, b2 = hleft + G_, b3 = qleft + C_, b4 = hleft + Q_;
+          i32 const e = max(b1, b2), q = max(b3, b4);
+          i32 const h = max(hh[c], max(max(ff[c], oo[c]), max(e, q)));
+          if ((h == b1) || ((h != b2) && (h == b3))) elmask |= 1u << c;
+          if ((b1 == e) || (b3 == q)) lcmask |= 1u << c;
+          hh[c] = h;
+          if (jb + c < je) {
+            hleft = h;
+            eleft = e;
+            qleft = q;
+          }
+        }
+        // second pass over the predecessors: which one SPOA's backtrack would pick, in its test order
+        u32 dmask = 0, umask = 0, eumask = 0, usmask = 0, uhmask = 0;
+        u32 xs[CW];  // predecessor indices: [1:0] diagonal, [3:2] up, [5:4] F/O extension, [7:6] H extension
+#pragma unroll
+        for (int c = 0; c < CW; ++c) xs[c] = 0;
+        for (u32 x = 0; x < npe; ++x) {
+          u32 const pr = np ? pred_row(g, i, info, x) : 0u;
+          i32 th[CW], tf[CW], to[CW], hd;
+          fetch(pr, th, tf, to, hd);
+#pragma unroll
+          for (int c = 0; c < CW; ++c) {
+            i32 const a1 = tf[c] + E_, a2 = th[c] + G_, a3 = to[c] + C_, a4 = th[c] + Q_;
+            i32 const hv = hd + ((nch == sc[c]) ? M_ : N_);
+            hd = th[c];
+            i32 const h = hh[c];
+            u32 const bit = 1u << c;
+            if (!(dmask & bit) && h == hv) {
+              dmask |= bit;
+              xs[c] |= x;
+            }
+            bool const t1 = h == a1, t2 = h == a2, t3 = h == a3, t4 = h == a4;
+            if (!(umask & bit) && (t1 || t2 || t3 || t4)) {
+              umask |= bit;
+              xs[c] |= x << 2;
+              if (t1 || (!t2 && t3)) eumask |= bit;
+            }
+            if (np) {  // a row without in-edges has an empty predecessor loop in the up-extension walk
+              if (!(usmask & bit) && ((ff[c] == a1) || (oo[c] == a3))) {
+                usmask |= bit;
+                xs[c] |= x << 4;
+              }
+              if (!(uhmask & bit) && ((ff[c] == a2) || (oo[c] == a4))) {
+                uhmask |= bit;
+                xs[c] |= x << 6;
+              }
+            }
+          }
+        }
+#pragma unroll
+        for (int c = 0; c < CW; ++c) {
+          u32 const bit = 1u << c;
+          bool const D = dmask & bit, U = umask & bit;
+          u32 code = D ? 0u : (U ? 1u : 2u);
+          code |= (!D && (U ? ((eumask & bit) != 0) : ((elmask & bit) != 0))) ? 4u : 0u;
+          code |= (lcmask & bit) ? 8u : 0u;
+          bool const us = usmask & bit, uh = uhmask & bit;
+          code |= us ? 16u : (uh ? 32u : 0u);
+          code |= (D ? (xs[c] & 3u) : (U ? ((xs[c] >> 2) & 3u) : 0u)) << 6;
+          code |= (us ? ((xs[c] >> 4) & 3u) : (uh ? ((xs[c] >> 6) & 3u) : 0u)) << 8;
+          cd[c] = code;
+        }
+      }
+      // the two previous rows stay in registers
+#pragma unroll
+      for (int c = 0; c < CW; ++c) {
+        if (kPrev2) {
+          H2[kPrev2 ? c : 0] = H1[c];
+          F2[kPrev2 ? c : 0] = F1[c];
+          O2[kPrev2 ? c : 0] = O1[c];
+        }
+        H1[c] = hh[c];
+        F1[c] = ff[c];
+        O1[c] = oo[c];
+      }
+      hl2 = hl1;
+      hl1 = hl0;
+      // decision codes: step-major, so one store of the wave covers 64 * CW * 2 contiguous bytes
+      u32* cp = reinterpret_cast<u32*>(codes + (static_cast<size_t>(t) * nl + gl) * CW);
+      if constexpr (CW % 8 == 0) {
+#pragma unroll
+        for (int c = 0; c < CW; c += 8)
+          *reinterpret_cast<uint4*>(cp + c / 2) = make_uint4(cd[c] | (cd[c + 1] << 16), cd[c + 2] | (cd[c + 3] << 16),
+                                                             cd[c + 4] | (cd[c + 5] << 16), cd[c + 6] | (cd[c + 7] << 16));
+      } else if constexpr (CW % 4 == 0) {
+#pragma unroll
+        for (int c = 0; c < CW; c += 4)
+          *reinterpret_cast<uint2*>(cp + c / 2) = make_uint2(cd[c] | (cd[c + 1] << 16), cd[c + 2] | (cd[c + 3] << 16));
+      } else {
+#pragma unroll
+        for (int c = 0; c < CW; c += 2) cp[c / 2] = cd[c] | (cd[c + 1] << 16);
+      }
+      if (info & RI_STORE) {
+        u32 const slot = g.rowslot[i];
+        i32* rb = rows + static_cast<size_t>(slot) * 3 * ws.w_stride + static_cast<size_t>(gl) * CW;
+#pragma unroll
+        for (int c = 0; c < CW; ++c) {
+          if (jb + c < je) {
+            rb[c] = hh[c];
+            rb[ws.w_stride + c] = ff[c];
+            rb[2 * static_cast<size_t>(ws.w_stride) + c] = oo[c];
+          }
+        }
+        stored = true;
+      }
+      if (gl == glL) {
+        i32 v = hh[0];
+#pragma unroll
+        for (int c = 1; c < CW; ++c) v = (static_cast<u32>(c) == cL) ? hh[c] : v;
+        hlast[i] = v;
+      }
+      hl = hleft;
+      el = eleft;
+      ql = qleft;
+    }
+    if (lane == 63 && wave < 3) {
+      i32* mb = ST.mbox[t & 1][wave];
+      mb[0] = hl;
+      mb[1] = el;
+      mb[2] = ql;
+    }
+    // a stored row is read back >= 3 steps after it was written; make it visible one step after the store
+    pend = (pend << 1) | (__any(stored) ? 1u : 0u);
+    if (pend & 2u) __threadfence_block();
+    lds_barrier();
+  }
+}
+
+// ---- traceback (wave 0, all lanes carry the same state): SisdAlignmentEngine::Convex backtrack ----
+struct EdgeVals {
+  i32 h, f, e, o, q;
+};
+__device__ __forceinline__ EdgeVals edge_vals(GL const& g, u32 i, u32 j) {  // cells of row 0 / column 0
+  EdgeVals v;
+  if (i == 0 && j == 0) {
+    v.h = v.f = v.e = v.o = v.q = 0;
+  } else if (i == 0) {
+    v.q = Q_ + static_cast<i32>(j - 1) * C_;
+    v.e = G_ + static_cast<i32>(j - 1) * E_;
+    v.h = max(v.q, v.e);
+    v.f = v.o = kNegInf;
+  } else {
+    u32 const d = g.rowdepth[i];
+    v.o = col0_o(d);
+    v.f = col0_f(d);
+    v.h = max(v.o, v.f);
+    v.e = v.q = kNegInf;
+  }
+  return v;
+}
+
+__device__ u32 poa_traceback(GL const& g, const u16* codes, u32 cw, u32 V, u32 L, u32 best_row, bool have_end, int lane) {
+  u32 const nl = (L + cw - 1) / cw;
+  auto code_at = [&](u32 i, u32 j) -> u32 {  // i >= 1, j >= 1
+    u32 const glj = (j - 1) / cw, c = (j - 1) - glj * cw;
+    return codes[(static_cast<size_t>(i + glj - 1) * nl + glj) * cw + c];
+  };
+  u32 naln = 0;
+  bool overflow = false;
+  auto push1 = [&](u32 node1, u32 pos1) {  // node id + 1 | 0, seq pos + 1 | 0
+    if (naln + 1 >= g.aln_cap) {
+      overflow = true;
+      return;
+    }
+    if (lane == 0) {
+      g.aln[2 * naln] = static_cast<u16>(node1);
+      g.aln[2 * naln + 1] = static_cast<u16>(pos1);
+    }
+    naln++;
+  };
+  u32 i = have_end ? best_row : 0u, j = have_end ? L : 0u;
+  u32 prev_i = 0, prev_j = 0;
+  while (!(i == 0 && j == 0) && !overflow) {
+    if (i >= 1 && j >= 1) {
+      // 64 cells down the diagonal at once: a run of diagonal moves over rank-consecutive rows
+      {
+        u32 const k = static_cast<u32>(lane);
+        bool ok = false;
+        if (i >= k + 2 && j >= k + 1) ok = ((code_at(i - k, j - k) & 3u) == 0u) && (g.rowinfo[i - k] & RI_FAST);
+        unsigned long long const m = __ballot(ok);
+        u32 const run = m == ~0ull ? 64u : static_cast<u32>(__builtin_ctzll(~m));
+        if (run > 0) {
+          if (naln + run + 1 >= g.aln_cap) {
+            overflow = true;
+            break;
+          }
+          if (k < run) {
+            g.aln[2 * (naln + k)] = static_cast<u16>(g.rank2node[i - k - 1] + 1u);
+            g.aln[2 * (naln + k) + 1] = static_cast<u16>(j - k);
+          }
+          naln += run;
+          i -= run;
+          j -= run;
+          prev_i = i;
+          prev_j = j;
+          continue;
+        }
+      }
+      u32 const cd = code_at(i, j);
+      u32 const info = g.rowinfo[i];
+      u32 const np = (info >> 8) & 7u;
+      u32 const node = g.rank2node[i - 1];
+      u32 const kind = cd & 3u;
+      bool const ext = cd & 4u;
+      u32 const x = (cd >> 6) & 3u;
+      if (kind == 0) {
+        prev_i = np ? pred_row(g, i, info, x) : 0u;
+        prev_j = j - 1;
+        push1(node + 1, j);
+        i = prev_i;
+        j = prev_j;
+      } else if (kind == 1) {
+        prev_i = np ? pred_row(g, i, info, x) : 0u;
+        prev_j = j;
+        push1(node + 1, 0);
+        i = prev_i;
+        if (ext) {  // walk up the F/O extension run in column j
+          while (!overflow && i >= 1) {
+            {
+              u32 const k = static_cast<u32>(lane);
+              bool ok = false;
+              if (i >= k + 2) ok = (code_at(i - k, j) & 16u) && (g.rowinfo[i - k] & RI_FAST);
+              unsigned long long const m = __ballot(ok);
+              u32 const run = m == ~0ull ? 64u : static_cast<u32>(__builtin_ctzll(~m));
+              if (run > 0) {
+                if (naln + run + 1 >= g.aln_cap) {
+                  overflow = true;
+                  break;
+                }
+                if (k < run) {
+                  g.aln[2 * (naln + k)] = static_cast<u16>(g.rank2node[i - k - 1] + 1u);
+                  g.aln[2 * (naln + k) + 1] = 0;
+                }
+                naln += run;
+                i -= run;
+                prev_i = i;
+                continue;  // i >= 2 - 1 >= 1 here: the last consumed row was >= 2
+              }
+            }
+            u32 const c2 = code_at(i, j);
+            u32 const info2 = g.rowinfo[i];
+            bool const us = c2 & 16u, uh = c2 & 32u;
+            u32 const pi = (us || uh) ? pred_row(g, i, info2, (c2 >> 8) & 3u) : 0u;
+            push1(g.rank2node[i - 1] + 1u, 0);
+            prev_i = pi;
+            i = pi;
+            if (!us || i == 0) break;
+          }
+        }
+      } else {
+        prev_i = i;
+        prev_j = j - 1;
+        push1(0, j);
+        j = prev_j;
+        if (ext) {  // left extension run along row i: entries (none, pos) while the E/Q chain continues
+          while (!overflow && j >= 1) {
+            u32 const k = static_cast<u32>(lane);
+            bool cont = false;
+            if (j >= k + 1) cont = code_at(i, j - k) & 8u;
+            unsigned long long const m = __ballot(cont);
+            u32 const nc = m == ~0ull ? 64u : static_cast<u32>(__builtin_ctzll(~m));
+            u32 const cnt = nc < 64u ? nc + 1u : 64u;
+            if (naln + cnt + 1 >= g.aln_cap) {
+              overflow = true;
+              break;
+            }
+            if (k < cnt) {
+              g.aln[2 * (naln + k)] = 0;
+              g.aln[2 * (naln + k) + 1] = static_cast<u16>(j - k);  // pos + 1 with pos = j - k - 1
+            }
+            naln += cnt;
+            j -= cnt;
+            if (nc < 64u) break;
+          }
+        }
+      }
+      continue;
+    }
+    // ---- row 0 / column 0: closed-form values, same tests in the same order ----
+    i32 const Hij = edge_vals(g, i, j).h;
+    bool found = false, ext_left = false, ext_up = false;
+    u32 const node = i ? g.rank2node[i - 1] : 0u;
+    u32 const info = i ? g.rowinfo[i] : 0u;
+    u32 const np = i ? ((info >> 8) & 7u) : 0u;
+    if (i != 0) {
+      for (u32 x = 0; x < (np ? np : 1u); ++x) {
+        u32 const pi = np ? pred_row(g, i, info, x) : 0u;
+        EdgeVals const pv = edge_vals(g, pi, j);
+        bool ok = (ext_up |= (Hij == pv.f + E_));
+        if (!ok) ok = Hij == pv.h + G_;
+        if (!ok) ok = (ext_up |= (Hij == pv.o + C_));
+        if (!ok) ok = Hij == pv.h + Q_;
+        if (ok) {
+          prev_i = pi;
+          prev_j = j;
+          found = true;
+          break;
+        }
+      }
+    }
+    if (!found && j != 0) {
+      EdgeVals const lv = edge_vals(g, i, j - 1);
+      bool ok = (ext_left |= (Hij == lv.e + E_));
+      if (!ok) ok = Hij == lv.h + G_;
+      if (!ok) ok = (ext_left |= (Hij == lv.q + C_));
+      if (!ok) ok = Hij == lv.h + Q_;
+      if (ok) {
+        prev_i = i;
+        prev_j = j - 1;
+        found = true;
+      }
+    }
+    push1(i != prev_i ? node + 1 : 0u, j != prev_j ? j : 0u);
+    i = prev_i;
+    j = prev_j;
+    if (ext_left) {
+      while (!overflow) {
+        push1(0, j);
+        --j;
+        bool const e_stop = edge_vals(g, i, j).e + E_ != edge_vals(g, i, j + 1).e;
+        bool const q_stop = edge_vals(g, i, j).q + C_ != edge_vals(g, i, j + 1).q;
+        if ((e_stop && q_stop) || j == 0) break;
+      }
+    } else if (ext_up) {
+      while (!overflow && i >= 1) {
+        bool stop = true;
+        prev_i = 0;
+        u32 const nd2 = g.rank2node[i - 1];
+        u32 const info2 = g.rowinfo[i];
+        u32 const np2 = (info2 >> 8) & 7u;
+        EdgeVals const cv = edge_vals(g, i, j);
+        for (u32 x = 0; x < np2; ++x) {
+          u32 const pr = pred_row(g, i, info2, x);
+          EdgeVals const pv = edge_vals(g, pr, j);
+          if (cv.f == pv.f + E_ || cv.o == pv.o + C_) {
+            prev_i = pr;
+            stop = false;
+            break;
+          }
+        }
+        if (stop) {
+          for (u32 x = 0; x < np2; ++x) {
+            u32 const pr = pred_row(g, i, info2, x);
+            i32 const hp2 = edge_vals(g, pr, j).h;
+            if (cv.f == hp2 + G_ || cv.o == hp2 + Q_) {
+              prev_i = pr;
+              break;
+            }
+          }
+        }
+        push1(nd2 + 1u, 0);
+        i = prev_i;
+        if (stop || i == 0) break;
+      }
+    }
+  }
+  if (overflow && lane == 0) ST.overflow = 1;
+  return naln;
+}
 
 struct MsaArgs {
   DBatch b;
@@ -518,11 +858,11 @@ struct MsaArgs {
   int win0;
 };
 
-__global__ __launch_bounds__(64) void k_msa(MsaArgs A) {
-  __shared__ Shared sh;
+template <int CWMAX>
+__global__ __launch_bounds__(kT, 2) void k_msa(MsaArgs A) {
+  int const tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   int const lw = blockIdx.x;
   int const w = A.win0 + lw;
-  int const lane = threadIdx.x;
   ma_params_t const& P = A.prm;
   PoaWs const& ws = A.ws;
   int const MC = P.max_comps, MH = P.max_haps, ML = P.max_hap_len, MV = P.max_vars, MA = P.max_alts,
@@ -530,286 +870,355 @@ __global__ __launch_bounds__(64) void k_msa(MsaArgs A) {
 
   u32 const ncomp = (A.a.win_status[w] & MA_W_NO_HAPLOTYPE) ? 0u : A.a.win_ncomp[w];
   if (ncomp == 0) {
-    if (lane == 0) A.o.win_nvars[w] = 0;
+    if (tid == 0) A.o.win_nvars[w] = 0;
     return;
   }
-  // ---- carve the LDS graph ----
   u32 const PN = ws.pn;
-  PG g;
-  g.pn = PN;
-  {
-    u32 const b16 = 6 * PN;  // PN is a multiple of 8
-    g.nchar.off = 0;
-    g.nin.off = PN;
-    g.nout.off = 2 * PN;
-    g.nal.off = 3 * PN;
-    g.marks.off = 4 * PN;
-    g.ignored.off = 5 * PN;
-    g.in_tail.off = b16;
-    g.out_head.off = b16 + 2 * (kPE * PN);
-    g.out_lab.off = b16 + 2 * (2 * kPE * PN);
-    g.al.off = b16 + 2 * (3 * kPE * PN);
-    g.rank2node.off = b16 + 2 * (4 * kPE * PN);
-    g.node2rank.off = g.rank2node.off + 2 * PN;
-    g.stack.off = g.node2rank.off + 2 * PN;  // 4 * PN + 8 u16 == 2 * (PN + 1) i32 (+ slack) for column 0
-    g.stack_cap = 4 * PN;
-  }
-  LdsArr<i32> col0{g.stack.off};                       // [(PN + 1) * 2]: O, F of column 0
-  LdsArr<u16> aln{g.stack.off + 2 * (4 * PN + 8)};    // [(PN + max_l + 2) * 2]
-  u32 const aln_cap = PN + ws.max_l + 2;
-  DP d;
-  d.H = ws.H + static_cast<size_t>(lw) * ws.cells;
-  d.F = ws.F + static_cast<size_t>(lw) * ws.cells;
-  d.E = ws.E + static_cast<size_t>(lw) * ws.cells;
-  d.O = ws.O + static_cast<size_t>(lw) * ws.cells;
-  d.Q = ws.Q + static_cast<size_t>(lw) * ws.cells;
-  {
-    i32* c0 = ws.C0 + static_cast<size_t>(lw) * 5 * (PN + 2);
-    d.H0 = c0;
-    d.F0 = c0 + (PN + 2);
-    d.E0 = c0 + 2 * (PN + 2);
-    d.O0 = c0 + 3 * (PN + 2);
-    d.Q0 = c0 + 4 * (PN + 2);
-  }
-  d.cw = 4;
-  d.rs = 256;
-  i16* H = d.H;  // also the raw-allele scratch of the bubble walk
+  GL const g = poa_carve(PN, ws.max_l);
+  u16* const codes = ws.codes + static_cast<size_t>(lw) * ws.code_cells;
+  i32* const rows = ws.rows + static_cast<size_t>(lw) * ws.row_cells;
+  i32* const hlast = ws.hlast + static_cast<size_t>(lw) * (PN + 8);
+  u8* const raw = reinterpret_cast<u8*>(codes);  // raw-allele scratch of the bubble walk (codes are dead by then)
 
+  // thread 0's running output state
   u32 nvars = 0, pool = 0;
   bool overflow = false;
+  if (tid == 0) ST.win_overflow = 0;
+  PROF_T0();
 
-  for (u32 c = 0; c < ncomp && !overflow; ++c) {
+  for (u32 c = 0; c < ncomp; ++c) {
+    __syncthreads();
+    if (ST.win_overflow) break;
     size_t const ci = static_cast<size_t>(w) * MC + c;
     u32 const hap0 = A.a.comp_hap0[ci], nh = A.a.comp_nhaps[ci];
-    if (lane == 0) {
-      g.nn = g.nseq = g.nrank = 0;
-      g.overflow = nh > 16;  // label masks are 16 bit
+    if (tid == 0) {
+      ST.nn = ST.nseq = ST.nrank = 0;
+      ST.overflow = nh > 16 ? 1u : 0u;  // label masks are 16 bit
     }
     for (u32 h = 0; h < nh; ++h) {
       size_t const hi = static_cast<size_t>(w) * MH + hap0 + h;
       const u8* seq = A.a.hap_bases + hi * ML;
       u32 const L = A.a.hap_len[hi];
-      PROF_T0();
-      // ---- lane 0: column 0 of the DP (SisdAlignmentEngine::Initialize, kNW convex) ----
-      if (lane == 0) {
-        sh.go = 0;
-        sh.abort_ = g.overflow ? 1u : 0u;
-        if (!g.overflow && g.nn > 0 && L > 0) {
-          u32 const V = g.nrank, W = L + 1;
-          u32 const cwl = ((L + 63) / 64 + 7) & ~7u;
-          if (static_cast<size_t>(V + 65) * 64 * cwl > ws.cells) {
-            g.overflow = true;
-            sh.abort_ = 1;
+      __syncthreads();
+      if (tid == 0) {
+        u32 mode = 0;
+        if (!ST.overflow && L > 0) {
+          if (ST.nn == 0) {
+            if (L > PN) ST.overflow = 1; else mode = 1;
           } else {
-            col0[0] = 0;
-            col0[1] = 0;
-            for (u32 i = 1; i <= V; ++i) {
-              u32 const node = g.rank2node[i - 1];
-              u32 const np = g.nin[node];
-              i32 pen_o = np == 0 ? Q_ - C_ : kNegInf;
-              i32 pen_f = np == 0 ? G_ - E_ : kNegInf;
-              for (u32 x = 0; x < np; ++x) {
-                u32 const pr = row_pred(g, node, x);
-                pen_o = max(pen_o, col0[2 * pr]);
-                pen_f = max(pen_f, col0[2 * pr + 1]);
-              }
-              col0[2 * i] = pen_o + C_;
-              col0[2 * i + 1] = pen_f + E_;
+            u32 const V = ST.nrank;
+            u32 const cw = L <= 1024 ? 4u : (L <= 1536 ? 6u : (L <= 2048 ? 8u : (L <= 3072 ? 12u : 16u)));
+            u32 const nl = (L + cw - 1) / cw;
+            if (L > 4096 || V > PN || static_cast<size_t>(V + nl) * nl * cw > ws.code_cells) {
+              ST.overflow = 1;
+            } else {
+              mode = 2;
+              ST.V = V;
+              ST.cw = cw;
             }
-            sh.V = V;
-            sh.L = L;
-            sh.W = W;
-            sh.go = 1;
           }
         }
+        ST.mode = mode;
+        ST.L = L;
+        ST.nslow = 0;
+        ST.naln = 0;
       }
       __syncthreads();
-      if (sh.go) {
-        u32 const V = sh.V;
-        d.cw = ((L + 63) / 64 + 7) & ~7u;
-        d.rs = 64 * d.cw;
-        // column 0 and row 0 to HBM (the traceback may touch them)
-        for (u32 i = lane; i <= V; i += 64) {
-          i32 const ov = col0[2 * i], fv = col0[2 * i + 1];
-          d.O0[i] = ov;
-          d.F0[i] = fv;
-          d.Q0[i] = i == 0 ? 0 : kNegInf;
-          d.E0[i] = i == 0 ? 0 : kNegInf;
-          d.H0[i] = i == 0 ? 0 : max(ov, fv);
+      u32 const mode = ST.mode;
+      if (mode == 0) continue;
+      if (mode == 1) {
+        // first sequence of the component: a linear chain whose topological order is the identity
+        u16 const lab = static_cast<u16>(1u << ST.nseq);
+        for (u32 i = tid; i < L; i += kT) {
+          g.nchar[i] = seq[i];
+          g.nin[i] = i > 0 ? 1 : 0;
+          g.nout[i] = i + 1 < L ? 1 : 0;
+          g.nal[i] = 0;
+          g.in_tail[i * kPE] = static_cast<u16>(i - 1);
+          g.out_head[i * kPE] = static_cast<u16>(i + 1);
+          g.out_lab[i * kPE] = lab;
+          g.rank2node[i] = static_cast<u16>(i);
+          g.node2rank[i] = static_cast<u16>(i);
+          g.ndepth[i] = static_cast<u16>(i);
         }
-        for (u32 j = 1 + lane; j <= L; j += 64) {
-          size_t const ox = d.off(0, j);
-          i32 const qv = Q_ + static_cast<i32>(j - 1) * C_, ev = G_ + static_cast<i32>(j - 1) * E_;
-          d.O[ox] = -32768;
-          d.Q[ox] = static_cast<i16>(DP::c0(qv));
-          d.F[ox] = -32768;
-          d.E[ox] = static_cast<i16>(DP::c0(ev));
-          d.H[ox] = static_cast<i16>(DP::c0(max(qv, ev)));
+        __syncthreads();
+        if (tid == 0) {
+          ST.seq_first[ST.nseq] = 0;
+          ST.nseq++;
+          ST.nn = L;
+          ST.nrank = L;
         }
-        __threadfence_block();
-        __syncthreads();
-        PROF_ACC(0);
-        if (d.cw <= CWM) poa_fill(g, d, V, L, lane, seq, col0);
-        else poa_fill_long(g, d, V, L, lane, seq, col0);
-        __syncthreads();
-        PROF_ACC(1);
+        PROF_ACC(6);
+        continue;
       }
-      // ---- lane 0: best end cell, traceback (SisdAlignmentEngine::Convex backtrack), graph update ----
-      if (lane == 0 && !g.overflow) {
-        u32 naln = 0;
-        if (sh.go) {
-          u32 const V = sh.V;
-          i32 max_score = kNegInf;
-          u32 max_i = 0, max_j = 0;
-          for (u32 r = 0; r < V; ++r) {
-            if (g.nout[g.rank2node[r]] != 0) continue;
-            i32 const hv = d.h(r + 1, L);
-            if (max_score < hv) {
-              max_score = hv;
-              max_i = r + 1;
-              max_j = L;
+      // ---- mode 2: align the haplotype to the graph ----
+      u32 const V = ST.V, cw = ST.cw;
+      // per-row descriptors; which rows must be kept in HBM
+      for (u32 i = tid; i <= V + 1; i += kT) g.rowslot[i] = 0;
+      __syncthreads();
+      for (u32 i = 1 + tid; i <= V; i += kT) {
+        u32 const node = g.rank2node[i - 1];
+        u32 const np = g.nin[node];
+        u32 pr[kPE];
+        for (u32 x = 0; x < kPE; ++x) pr[x] = x < np ? static_cast<u32>(g.node2rank[g.in_tail[node * kPE + x]]) + 1u : 0u;
+        u32 info = static_cast<u32>(g.nchar[node]) | (np << 8);
+        if (np == 1 && pr[0] + 1 == i) {
+          info |= RI_FAST;
+        } else if (np > 0) {
+          u32 const idx = atomicAdd(&ST.nslow, 1u);
+          if (idx < kSlowCap) {
+            for (u32 x = 0; x < np; ++x) g.slowpred[idx * kPE + x] = static_cast<u16>(pr[x]);
+            info |= RI_SLOWTAB | (idx << 16);
+          }
+        }
+        for (u32 x = 0; x < np; ++x)
+          if (pr[x] + 1 != i && !(cw <= 8 && pr[x] + 2 == i)) g.rowslot[pr[x]] = 1;
+        g.rowinfo[i] = info;
+        g.rowdepth[i] = g.ndepth[node];
+      }
+      __syncthreads();
+      {
+        u32 const per = (V + kT) / kT;  // rows 1 .. V in contiguous chunks
+        u32 const lo = min(1 + tid * per, V + 1), hi2 = min(lo + per, V + 1);
+        u32 cnt = 0;
+        for (u32 i = lo; i < hi2; ++i) cnt += g.rowslot[i];
+        u32 total = 0;
+        u32 slot = block_excl_scan(cnt, tid, total);
+        for (u32 i = lo; i < hi2; ++i) {
+          if (g.rowslot[i]) {
+            g.rowslot[i] = static_cast<u16>(slot++);
+            g.rowinfo[i] |= RI_STORE;
+          } else {
+            g.rowslot[i] = 0xFFFFu;
+          }
+        }
+        if (total > ws.row_slots && tid == 0) ST.overflow = 1;
+      }
+      __syncthreads();
+      if (ST.overflow) continue;
+      PROF_ACC(0);
+      if (cw == 4) {
+        poa_fill<4>(g, ws, codes, rows, hlast, V, L, tid, seq);
+      } else if constexpr (CWMAX > 4) {
+        if (cw == 6) {
+          poa_fill<6>(g, ws, codes, rows, hlast, V, L, tid, seq);
+        } else if (cw == 8) {
+          poa_fill<8>(g, ws, codes, rows, hlast, V, L, tid, seq);
+        } else if constexpr (CWMAX > 8) {
+          if (cw == 12) poa_fill<12>(g, ws, codes, rows, hlast, V, L, tid, seq);
+          else poa_fill<16>(g, ws, codes, rows, hlast, V, L, tid, seq);
+        }
+      }
+      __syncthreads();  // full fence: codes and hlast are read below
+      PROF_ACC(1);
+      // best end cell: first maximum, in rank order, over the nodes without out-edges
+      {
+        i32 bv = kNegInf;
+        u32 br = 0xFFFFFFFFu;
+        for (u32 r = tid; r < V; r += kT) {
+          if (g.nout[g.rank2node[r]] != 0) continue;
+          i32 const hv = hlast[r + 1];
+          if (br == 0xFFFFFFFFu || hv > bv) {
+            bv = hv;
+            br = r + 1;
+          }
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+          i32 const ov = __shfl_xor(bv, off);
+          u32 const orow = __shfl_xor(br, off);
+          if (orow != 0xFFFFFFFFu && (br == 0xFFFFFFFFu || ov > bv || (ov == bv && orow < br))) {
+            bv = ov;
+            br = orow;
+          }
+        }
+        if (lane == 0) {
+          ST.red_v[wave] = bv;
+          ST.red_r[wave] = br;
+        }
+        __syncthreads();
+        if (tid == 0) {
+          i32 fv = kNegInf;
+          u32 fr = 0xFFFFFFFFu;
+          for (int k = 0; k < 4; ++k) {
+            i32 const ov = ST.red_v[k];
+            u32 const orow = ST.red_r[k];
+            if (orow != 0xFFFFFFFFu && (fr == 0xFFFFFFFFu || ov > fv || (ov == fv && orow < fr))) {
+              fv = ov;
+              fr = orow;
             }
           }
-          u32 i = max_i, j = max_j, prev_i = 0, prev_j = 0;
-          auto push = [&](bool has_node, u32 node, bool has_pos, u32 pos) {
-            if (naln + 1 >= aln_cap) {
-              g.overflow = true;
-              return;
-            }
-            aln[2 * naln] = has_node ? static_cast<u16>(node + 1) : 0;
-            aln[2 * naln + 1] = has_pos ? static_cast<u16>(pos + 1) : 0;
-            naln++;
-          };
-          while (!(i == 0 && j == 0) && !(max_i == 0 && max_j == 0) && !g.overflow) {
-            i32 const Hij = d.h(i, j);
-            bool found = false, ext_left = false, ext_up = false;
-            u32 const node = i ? g.rank2node[i - 1] : 0u;
-            u32 const np = i ? g.nin[node] : 0u;
-            if (i != 0 && j != 0) {
-              i32 const mc = (g.nchar[node] == seq[j - 1]) ? M_ : N_;
-              for (u32 x = 0; x < (np ? np : 1u); ++x) {
-                u32 const pi = np ? row_pred(g, node, x) : 0u;
-                if (Hij == d.h(pi, j - 1) + mc) {
-                  prev_i = pi;
-                  prev_j = j - 1;
-                  found = true;
-                  break;
-                }
-              }
-            }
-            if (!found && i != 0) {
-              for (u32 x = 0; x < (np ? np : 1u); ++x) {
-                u32 const pi = np ? row_pred(g, node, x) : 0u;
-                i32 const hpj = d.h(pi, j);
-                bool ok = (ext_up |= (Hij == d.f(pi, j) + E_));
-                if (!ok) ok = Hij == hpj + G_;
-                if (!ok) ok = (ext_up |= (Hij == d.o(pi, j) + C_));
-                if (!ok) ok = Hij == hpj + Q_;
-                if (ok) {
-                  prev_i = pi;
-                  prev_j = j;
-                  found = true;
-                  break;
-                }
-              }
-            }
-            if (!found && j != 0) {
-              i32 const hl1 = d.h(i, j - 1);
-              bool ok = (ext_left |= (Hij == d.e(i, j - 1) + E_));
-              if (!ok) ok = Hij == hl1 + G_;
-              if (!ok) ok = (ext_left |= (Hij == d.q(i, j - 1) + C_));
-              if (!ok) ok = Hij == hl1 + Q_;
-              if (ok) {
-                prev_i = i;
-                prev_j = j - 1;
-                found = true;
-              }
-            }
-            push(i != prev_i, node, j != prev_j, j - 1);
-            i = prev_i;
-            j = prev_j;
-            if (ext_left) {
-              while (!g.overflow) {
-                push(false, 0, true, j - 1);
-                --j;
-                bool const e_stop = d.e(i, j) + E_ != d.e(i, j + 1);
-                bool const q_stop = d.q(i, j) + C_ != d.q(i, j + 1);
-                if (e_stop && q_stop) break;
-              }
-            } else if (ext_up) {
-              while (!g.overflow) {
-                bool stop = true;
-                prev_i = 0;
-                u32 const nd2 = g.rank2node[i - 1];
-                u32 const np2 = g.nin[nd2];
-                i32 const fc = d.f(i, j), oc = d.o(i, j);
-                for (u32 x = 0; x < np2; ++x) {
-                  u32 const pr = row_pred(g, nd2, x);
-                  if (fc == d.f(pr, j) + E_ || oc == d.o(pr, j) + C_) {
-                    prev_i = pr;
-                    stop = false;
+          ST.best = fv;
+          ST.best_row = fr;
+        }
+        __syncthreads();
+      }
+      if (wave == 0) {
+        u32 const br = ST.best_row;
+        u32 const naln = poa_traceback(g, codes, cw, V, L, br == 0xFFFFFFFFu ? 0u : br, br != 0xFFFFFFFFu, lane);
+        if (lane == 0) ST.naln = naln;
+      }
+      __syncthreads();
+      PROF_ACC(2);
+      if (ST.overflow) continue;
+      // ---- spoa::Graph::AddAlignment; the path is stored reversed in aln ----
+      u32 const naln = ST.naln;
+      if (naln == 0) {
+        if (tid == 0) {
+          i32 const first = pg_add_sequence(g, seq, 0, L);
+          ST.seq_first[ST.nseq] = first;
+          ST.nseq++;
+        }
+      } else {
+        u16 const lab = static_cast<u16>(1u << ST.nseq);
+        // entries that carry a sequence position, compacted in path order
+        u32 nv = 0;
+        {
+          u32 const per = (naln + kT - 1) / kT;
+          u32 const lo = min(static_cast<u32>(tid) * per, naln), hi2 = min(lo + per, naln);
+          u32 cnt = 0;
+          for (u32 x = lo; x < hi2; ++x) cnt += g.aln[2 * (naln - 1 - x) + 1] != 0;
+          u32 at = block_excl_scan(cnt, tid, nv);
+          for (u32 x = lo; x < hi2; ++x) {
+            u32 const p1 = g.aln[2 * (naln - 1 - x) + 1];
+            if (p1 == 0) continue;
+            g.cnode[at] = g.aln[2 * (naln - 1 - x)];
+            g.cpos[at] = static_cast<u16>(p1 - 1);
+            ++at;
+          }
+        }
+        __syncthreads();
+        if (tid == 0) {
+          if (nv == 0) {
+            ST.overflow = 1;  // cannot happen for a global alignment of a non-empty sequence
+          } else {
+            u32 const vfront = g.cpos[0], vback = g.cpos[nv - 1];
+            i32 const begin = pg_add_sequence(g, seq, 0, vfront);
+            ST.begin = begin;
+            ST.prev0 = begin >= 0 ? static_cast<i32>(ST.nn - 1) : -1;
+            ST.lastn = pg_add_sequence(g, seq, vback + 1, L);
+          }
+          ST.nv = nv;
+        }
+        __syncthreads();
+        if (!ST.overflow) {
+          u32 const pv = (nv + kT - 1) / kT;  // <= 16
+          u32 const vlo = min(static_cast<u32>(tid) * pv, nv), vhi = min(vlo + pv, nv);
+          u32 newmask = 0, grpmask = 0;
+          for (u32 v = vlo; v < vhi; ++v) {
+            u8 const ch = seq[g.cpos[v]];
+            u32 const jt1 = g.cnode[v];
+            u32 cur = 0xFFFFu;
+            if (jt1 != 0) {
+              u32 const jt = jt1 - 1;
+              if (g.nchar[jt] == ch) {
+                cur = jt;
+              } else {
+                u32 const na = g.nal[jt];
+                for (u32 y = 0; y < na; ++y) {
+                  u32 const kt = g.al[jt * kPE + y];
+                  if (g.nchar[kt] == ch) {
+                    cur = kt;
                     break;
                   }
                 }
-                if (stop) {
-                  for (u32 x = 0; x < np2; ++x) {
-                    u32 const pr = row_pred(g, nd2, x);
-                    i32 const hp2 = d.h(pr, j);
-                    if (fc == hp2 + G_ || oc == hp2 + Q_) {
-                      prev_i = pr;
-                      break;
-                    }
-                  }
+                if (cur == 0xFFFFu) grpmask |= 1u << (v - vlo);
+              }
+            }
+            if (cur == 0xFFFFu) newmask |= 1u << (v - vlo);
+            g.ccur[v] = static_cast<u16>(cur);
+          }
+          u32 total_new = 0;
+          u32 id = ST.nn + block_excl_scan(__popc(newmask), tid, total_new);
+          bool const fits = ST.nn + total_new <= PN;
+          if (fits) {
+            for (u32 v = vlo; v < vhi; ++v) {
+              if (!(newmask & (1u << (v - vlo)))) continue;
+              u32 const cur = id++;
+              g.ccur[v] = static_cast<u16>(cur);
+              g.nchar[cur] = seq[g.cpos[v]];
+              g.nin[cur] = g.nout[cur] = g.nal[cur] = 0;
+              if (grpmask & (1u << (v - vlo))) {  // join the aligned ring of node jt
+                u32 const jt = static_cast<u32>(g.cnode[v]) - 1;
+                u32 const na = g.nal[jt];
+                if (na + 1 > kPE) {
+                  atomicOr(&ST.overflow, 1u);
+                  continue;
                 }
-                push(true, nd2, false, 0);
-                i = prev_i;
-                if (stop || i == 0) break;
+                for (u32 y = 0; y < na; ++y) {
+                  u32 const kt = g.al[jt * kPE + y];
+                  u32 const nk = g.nal[kt];
+                  g.al[kt * kPE + nk] = static_cast<u16>(cur);
+                  g.nal[kt] = static_cast<u8>(nk + 1);
+                  g.al[cur * kPE + y] = static_cast<u16>(kt);
+                }
+                g.al[jt * kPE + na] = static_cast<u16>(cur);
+                g.nal[jt] = static_cast<u8>(na + 1);
+                g.al[cur * kPE + na] = static_cast<u16>(jt);
+                g.nal[cur] = static_cast<u8>(na + 1);
               }
             }
           }
-          // std::reverse(alignment)
-          for (u32 x = 0; x < naln / 2; ++x) {
-            u16 const a0 = aln[2 * x], a1 = aln[2 * x + 1];
-            aln[2 * x] = aln[2 * (naln - 1 - x)];
-            aln[2 * x + 1] = aln[2 * (naln - 1 - x) + 1];
-            aln[2 * (naln - 1 - x)] = a0;
-            aln[2 * (naln - 1 - x) + 1] = a1;
+          __syncthreads();
+          if (tid == 0) {
+            if (!fits) ST.overflow = 1; else ST.nn += total_new;
+          }
+          if (fits) {
+            for (u32 v = vlo; v < vhi; ++v) {
+              i32 const tail = v == 0 ? ST.prev0 : static_cast<i32>(g.ccur[v - 1]);
+              if (tail >= 0) pg_add_edge(g, static_cast<u32>(tail), g.ccur[v], lab);
+            }
+          }
+          __syncthreads();
+          if (tid == 0 && !ST.overflow) {
+            if (ST.lastn >= 0) pg_add_edge(g, g.ccur[nv - 1], static_cast<u32>(ST.lastn), lab);
+            ST.seq_first[ST.nseq] = ST.begin >= 0 ? ST.begin : static_cast<i32>(g.ccur[0]);
+            ST.nseq++;
           }
         }
-        PROF_ACC(2);
-        if (!g.overflow) pg_add_alignment(g, aln, naln, seq, L);
-        PROF_ACC(3);
       }
       __syncthreads();
+      PROF_ACC(3);
+      if (tid == 0 && !ST.overflow) pg_toposort(g);
+      __syncthreads();
+      if (!ST.overflow) {
+        u32 const nrank = ST.nrank;
+        for (u32 r = tid; r < nrank; r += kT) g.node2rank[g.rank2node[r]] = static_cast<u16>(r);
+      }
+      PROF_ACC(4);
     }
+    __syncthreads();
 
-    // ---- lane 0: VariantExtractor over the component's POA graph ----
-    if (lane == 0) {
-      if (g.overflow) {
-        overflow = true;
-      } else if (g.nseq >= 2) {
-        u32 const ns = g.nseq;
-        i32 active[16];
-        u32 hap_pos[16], starts[16];
-        for (u32 s = 0; s < ns; ++s) {
-          active[s] = g.seq_first[s];
-          hap_pos[s] = 0;
-        }
-        u32 ref_pos = A.a.comp_anchor[ci];  // window-relative ref_anchor_pos (variant_builder.cpp:146)
-        i32 prev_match = -1;
-        u8* pl = A.o.allele_pool + static_cast<size_t>(w) * MP;
-        // raw allele strings live in tmp memory: [ns][cap]
-        u32 const acap = 2 * ws.max_l + 8;
-        u8* raw = reinterpret_cast<u8*>(H);  // DP matrices are free now
-        u32 rawlen[16];
-        auto converged = [&]() {
-          for (u32 s = 1; s < ns; ++s)
-            if (active[s] != active[0]) return false;
-          return true;
-        };
-        while (true) {
-          if (converged()) {
-            if (active[0] < 0) break;
+    // ---- VariantExtractor over the component's POA graph: thread 0 walks, everybody helps skipping ----
+    bool const do_extract = !ST.overflow && ST.nseq >= 2;
+    if (tid == 0 && ST.overflow) overflow = true;
+    u32 const ns = ST.nseq;
+    u32 const nn = ST.nn;
+    i32 active[16];
+    u32 hap_pos[16], starts[16];
+    u32 ref_pos = 0;
+    i32 prev_match = -1;
+    bool x_init = false;
+    u32 const allmask = ns >= 32 ? 0xFFFFFFFFu : ((1u << ns) - 1u);
+    while (do_extract) {
+      if (tid == 0) {
+        if (!x_init) {
+          for (u32 s = 0; s < ns; ++s) {
+            active[s] = ST.seq_first[s];
+            hap_pos[s] = 0;
+          }
+          ref_pos = A.a.comp_anchor[ci];  // window-relative ref_anchor_pos (variant_builder.cpp:146)
+          x_init = true;
+        } else {
+          // converged at node a: the next `run` nodes a, a+1, ... are passed by every haplotype
+          u32 run = ST.wsum[0];
+          if (run == 64) {
+            run += ST.wsum[1];
+            if (run == 128) {
+              run += ST.wsum[2];
+              if (run == 192) run += ST.wsum[3];
+            }
+          }
+          if (run == 0) {  // one plain converged step
             prev_match = active[0];
             for (u32 s = 0; s < ns; ++s)
               if (active[s] >= 0) {
@@ -817,7 +1226,29 @@ __global__ __launch_bounds__(64) void k_msa(MsaArgs A) {
                 hap_pos[s]++;
               }
             ref_pos++;
-            continue;
+          } else {
+            i32 const a = active[0];
+            prev_match = a + static_cast<i32>(run) - 1;
+            for (u32 s = 0; s < ns; ++s) {
+              active[s] = a + static_cast<i32>(run);
+              hap_pos[s] += run;
+            }
+            ref_pos += run;
+          }
+        }
+        u8* pl = A.o.allele_pool + static_cast<size_t>(w) * MP;
+        u32 const acap = 2 * ws.max_l + 8;  // raw allele strings: [ns][acap]
+        u32 rawlen[16];
+        auto converged = [&]() {
+          for (u32 s = 1; s < ns; ++s)
+            if (active[s] != active[0]) return false;
+          return true;
+        };
+        bool done = false;
+        while (true) {
+          if (converged()) {
+            if (active[0] < 0) done = true;
+            break;  // hand the converged stretch to the whole workgroup
           }
           bool const has_prev = prev_match >= 0;
           u32 const aoff = has_prev ? 1u : 0u;
@@ -830,7 +1261,7 @@ __global__ __launch_bounds__(64) void k_msa(MsaArgs A) {
           while (!converged()) {
             u32 min_rank = 0xFFFFFFFFu;
             for (u32 s = 0; s < ns; ++s)
-              if (active[s] >= 0) min_rank = min(min_rank, g.node2rank[active[s]]);
+              if (active[s] >= 0) min_rank = min(min_rank, static_cast<u32>(g.node2rank[active[s]]));
             if (min_rank == 0xFFFFFFFFu) break;
             for (u32 s = 0; s < ns; ++s)
               if (active[s] >= 0 && g.node2rank[active[s]] == min_rank) {
@@ -900,6 +1331,7 @@ __global__ __launch_bounds__(64) void k_msa(MsaArgs A) {
           for (u32 gi = 0; gi < ngrp; ++gi) need += ghi[gi] - glo[gi];
           if (static_cast<int>(nvars) >= MV || static_cast<int>(ngrp) > MA || static_cast<int>(pool + need) > MP) {
             overflow = true;
+            done = true;
             break;
           }
           size_t const vi = static_cast<size_t>(w) * MV + nvars;
@@ -936,17 +1368,36 @@ __global__ __launch_bounds__(64) void k_msa(MsaArgs A) {
           A.o.var_hap_start[vi * MH + 0] = starts[0];
           nvars++;
         }
+        ST.x_done = done ? 1u : 0u;
+        ST.x_a = static_cast<u32>(active[0]);
       }
-      sh.abort_ = overflow ? 1u : 0u;
+      __syncthreads();
+      if (ST.x_done) break;
+      {
+        // thread k: do ALL haplotypes step from node a + k to node a + k + 1?
+        u32 const v = ST.x_a + static_cast<u32>(tid);
+        bool ok = false;
+        if (v + 1 < nn) {
+          u32 const no = g.nout[v];
+          for (u32 x = 0; x < no; ++x)
+            if (g.out_head[v * kPE + x] == v + 1 && (g.out_lab[v * kPE + x] & allmask) == allmask) ok = true;
+        }
+        unsigned long long const m = __ballot(ok);
+        u32 const cnt = m == ~0ull ? 64u : static_cast<u32>(__builtin_ctzll(~m));
+        if (lane == 0) ST.wsum[wave] = cnt;
+      }
+      __syncthreads();
     }
-    __syncthreads();
-    overflow = sh.abort_ != 0;
+    if (tid == 0 && overflow) ST.win_overflow = 1;
+    PROF_ACC(5);
   }
-  if (lane == 0) {
+  if (tid == 0) {
     A.o.win_nvars[w] = nvars;
     if (overflow) A.a.win_status[w] |= MA_W_VAR_OVERFLOW;
   }
 }
+
+}  // namespace
 
 #ifdef MA_PROFILE
 extern "C" void ma_debug_prof(unsigned long long* out, int reset) {
@@ -964,6 +1415,10 @@ int launch_msa(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& a, const ma_var
   ma_params_t const& P = ctx->prm;
   if (P.max_haps > 16) {
     ctx->err = "ma_msa_batch: max_haps > 16 not supported (16-bit haplotype label masks)";
+    return MA_ERR_PARAM;
+  }
+  if (P.max_hap_len > 4096) {
+    ctx->err = "ma_msa_batch: max_hap_len > 4096 not supported (256 lanes x 16 columns)";
     return MA_ERR_PARAM;
   }
   PoaWs ws{};
@@ -991,17 +1446,23 @@ int launch_msa(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& a, const ma_var
   u32 pn = max_len + std::max<u32>(256, max_len / 4);
   if (const char* e = getenv("MA_POA_NODE_CAP")) pn = static_cast<u32>(atoi(e));
   pn = std::min<u32>((pn + 7) & ~7u, 65000);
-  // LDS: 6 B + 16 * 2 B + 2 * 2 B + 4 * 2 B per node, + alignment path
-  auto lds_bytes = [&](u32 p) { return size_t(6) * p + size_t(2) * (4 * kPE * p + 2 * p + 4 * p + 8) + size_t(4) * (p + max_len + 2) + 64; };
-  while (lds_bytes(pn) > 156 * 1024 && pn > max_len + 32) pn -= 8;
+  // two workgroups per CU when the graph fits in 80 KB of LDS, one otherwise
+  while (poa_lds_bytes(pn, max_len) > 80 * 1024 && pn > max_len + 128) pn -= 8;
+  while (poa_lds_bytes(pn, max_len) > 159 * 1024 && pn > max_len + 32) pn -= 8;
+  size_t const lds = poa_lds_bytes(pn, max_len);
+  if (lds > 160 * 1024) {
+    ctx->err = "ma_msa_batch: haplotypes too long for the LDS-resident POA graph";
+    return MA_ERR_PARAM;
+  }
   ws.pn = pn;
-  size_t const lds = lds_bytes(pn);
-  ws.cw_max = ((max_len + 63) / 64 + 7) & ~7u;
-  ws.cells = static_cast<size_t>(pn + 66) * 64 * ws.cw_max;
-  if (ws.cells < static_cast<size_t>(P.max_haps) * (2 * max_len + 8) / 2 + 64)  // raw-allele scratch lives in H
-    ws.cells = static_cast<size_t>(P.max_haps) * (2 * max_len + 8) / 2 + 64;
+  ws.w_stride = (max_len + 7) & ~7u;
+  ws.row_slots = pn / 2;
+  ws.code_cells = (static_cast<size_t>(pn + 257) * (max_len + 16) + 7) & ~size_t(7);
+  if (ws.code_cells * 2 < static_cast<size_t>(P.max_haps) * (2 * max_len + 8) + 64)  // raw-allele scratch lives in the codes
+    ws.code_cells = (static_cast<size_t>(P.max_haps) * (2 * max_len + 8) / 2 + 64 + 7) & ~size_t(7);
+  ws.row_cells = static_cast<size_t>(ws.row_slots) * 3 * ws.w_stride;
 
-  size_t const per_window = 5 * ws.cells * 2 + 5 * (static_cast<size_t>(pn) + 2) * 4 + 8192;
+  size_t const per_window = ws.code_cells * 2 + ws.row_cells * 4 + (static_cast<size_t>(pn) + 8) * 4;
   size_t budget = size_t(24) << 30;
   {
     size_t free_b = 0, total_b = 0;  // size the in-flight window count for the GPU's HBM (288 GB on MI355X)
@@ -1010,23 +1471,21 @@ int launch_msa(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& a, const ma_var
   }
   if (const char* e = getenv("MA_WS_GB")) budget = static_cast<size_t>(atoi(e)) << 30;
   int const chunk = static_cast<int>(std::max<size_t>(1, std::min<size_t>(n, budget / per_window)));
-  MA_HIP(ctx, ctx->ws_poa.reserve(per_window * static_cast<size_t>(chunk)));
-  if (lds > 65536)
-    MA_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_msa), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    static_cast<int>(lds)));
+  MA_HIP(ctx, ctx->ws_poa.reserve(per_window * static_cast<size_t>(chunk) + 1024));
+  auto kern = max_len <= 1024 ? k_msa<4> : (max_len <= 2048 ? k_msa<8> : k_msa<16>);
+  MA_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  static_cast<int>(lds)));
   for (int win0 = 0; win0 < n; win0 += chunk) {
     int const nwin = std::min(chunk, n - win0);
     char* base = static_cast<char*>(ctx->ws_poa.p);
-    size_t const msz = (static_cast<size_t>(nwin) * ws.cells * 2 + 255) & ~size_t(255);
-    ws.H = reinterpret_cast<i16*>(base);
-    ws.F = reinterpret_cast<i16*>(base + msz);
-    ws.E = reinterpret_cast<i16*>(base + 2 * msz);
-    ws.O = reinterpret_cast<i16*>(base + 3 * msz);
-    ws.Q = reinterpret_cast<i16*>(base + 4 * msz);
-    ws.C0 = reinterpret_cast<i32*>(base + 5 * msz);
+    size_t const csz = (static_cast<size_t>(nwin) * ws.code_cells * 2 + 255) & ~size_t(255);
+    size_t const rsz = (static_cast<size_t>(nwin) * ws.row_cells * 4 + 255) & ~size_t(255);
+    ws.codes = reinterpret_cast<u16*>(base);
+    ws.rows = reinterpret_cast<i32*>(base + csz);
+    ws.hlast = reinterpret_cast<i32*>(base + csz + rsz);
     MsaArgs args{b, a, o, ws, P, win0};
     ctx->tic("k_msa");
-    hipLaunchKernelGGL(k_msa, dim3(nwin), dim3(64), lds, ctx->stream, args);
+    hipLaunchKernelGGL(kern, dim3(nwin), dim3(kT), lds, ctx->stream, args);
     ctx->toc();
     MA_HIP(ctx, hipGetLastError());
   }
