@@ -73,7 +73,8 @@ struct WgState {
   u32 mode, V, L, cw, naln, nslow;
   i32 best;
   u32 best_row;
-  i32 mbox[2][4][4];
+  i32 ftot[2][4][2];  // fill: per-wave totals of the two prefix maxima, double buffered by row parity
+  i32 fbnd[2][4][4];  // fill: what the next wave's first lane needs to rebuild this wave's last column
   u32 wsum[4];
   i32 red_v[4];
   u32 red_r[4];
@@ -339,17 +340,47 @@ __device__ u32 block_excl_scan(u32 v, int tid, u32& total) {
   return base + inc - v;
 }
 
-// ---- the skewed-pipeline fill: decision codes + the rows later rows must read back ----
+// ---- wave-wide prefix maximum with DPP (no LDS traffic) ----
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ i32 dpp_mov(i32 x, i32 ident) {
+  return __builtin_amdgcn_update_dpp(ident, x, CTRL, ROW_MASK, 0xF, false);
+}
+__device__ __forceinline__ i32 wave_incl_max(i32 x, i32 ident) {
+  x = max(x, dpp_mov<0x111, 0xF>(x, ident));  // row_shr:1
+  x = max(x, dpp_mov<0x112, 0xF>(x, ident));  // row_shr:2
+  x = max(x, dpp_mov<0x114, 0xF>(x, ident));  // row_shr:4
+  x = max(x, dpp_mov<0x118, 0xF>(x, ident));  // row_shr:8
+  x = max(x, dpp_mov<0x142, 0xA>(x, ident));  // row_bcast:15 -> rows 1, 3
+  x = max(x, dpp_mov<0x143, 0xC>(x, ident));  // row_bcast:31 -> rows 2, 3
+  return x;
+}
+__device__ __forceinline__ i32 wave_shr1(i32 x, i32 ident) { return dpp_mov<0x138, 0xF>(x, ident); }  // wave_shr:1
+
+// ---- the row-synchronous fill: decision codes + the rows later rows must read back ----
+// All 256 lanes work on the same DP row; lane l owns the CW columns 1 + l CW .. .  The vertical and
+// diagonal terms of a cell only need the predecessor rows (registers / row store).  The horizontal
+// gap chains are closed with two prefix maxima over the row instead of a left-to-right sweep:
+// with m_k = max(diagonal, F, O) of column k (m_0 = H of column 0) the recurrences
+//     E_j = max(H_{j-1} + g, E_{j-1} + e)      Q_j = max(H_{j-1} + q, Q_{j-1} + c)      H_j = max(m_j, E_j, Q_j)
+// unroll (all dropped terms are strictly dominated because g < e, q < c, q + 1 < 0) to
+//     Q_j = q + (j-1) c + max_{k<j}(m_k - k c)
+//     E_j = max( g + (j-1) e + max_{k<j}(m_k - k e),   Q_j-ish: q + g + (j-2) c + max_{k<j}(m_k - k c) )
+// which are the SAME integers the sweep produces, so the backtrack tests see identical values.
+// Rows have uniform shape across the workgroup, so rows with several / far predecessors cost one slower
+// step instead of stalling a skewed pipeline.
 template <int CW>
 __device__ void poa_fill(GL const& g, PoaWs const& ws, u16* codes, i32* rows, i32* hlast, u32 V, u32 L, int tid,
                          const u8* seq) {
+  static_assert(E_ == -2 && C_ == -1, "prefix-max keys are written for e = -2, c = -1");
   int const lane = tid & 63, wave = tid >> 6;
   u32 const gl = static_cast<u32>(tid);
   u32 const jb = 1 + gl * CW;
   u32 const je = min(L + 1, jb + CW);
   u32 const nl = (L + CW - 1) / CW;
+  u32 const W = nl * CW;
   bool const lane_on = gl < nl;
   u32 const glL = (L - 1) / CW, cL = (L - 1) % CW;
+  constexpr i32 NEG = -(1 << 30);
   u32 sc[CW];
 #pragma unroll
   for (int c = 0; c < CW; ++c) sc[c] = (lane_on && jb + c < je) ? seq[jb + c - 1] : 0u;
@@ -360,214 +391,275 @@ __device__ void poa_fill(GL const& g, PoaWs const& ws, u16* codes, i32* rows, i3
   for (int c = 0; c < CW; ++c) H1[c] = F1[c] = O1[c] = 0;
 #pragma unroll
   for (int c = 0; c < CW2; ++c) H2[c] = F2[c] = O2[c] = 0;
-  i32 hl1 = 0, hl2 = 0, hl = 0, el = 0, ql = 0;
-  u32 pend = 0;
-  u32 const steps = V + nl - 1;
-  for (u32 t = 0; t < steps; ++t) {
-    i32 hL = __shfl_up(hl, 1), eL = __shfl_up(el, 1), qL = __shfl_up(ql, 1);
-    if (lane == 0 && wave > 0) {
-      i32 const* mb = ST.mbox[(t + 1) & 1][wave - 1];
-      hL = mb[0];
-      eL = mb[1];
-      qL = mb[2];
+  i32 hl1 = 0, hl2 = 0;  // H(i-1, jb-1), H(i-2, jb-1)
+  bool stored_prev = false;
+  u32 info = g.rowinfo[1];
+  u32 depth = g.rowdepth[1];
+  for (u32 i = 1; i <= V; ++i) {
+    u32 const nch = info & 0xFFu, np = (info >> 8) & 7u;
+    bool const fast = info & RI_FAST, store = info & RI_STORE;
+    u32 const info_cur = info;
+    i32 const h0 = col0_h(depth);
+    if (i < V) {  // next row's descriptor: hide the LDS latency behind this row
+      info = g.rowinfo[i + 1];
+      depth = g.rowdepth[i + 1];
     }
-    i32 const row = static_cast<i32>(t) - static_cast<i32>(gl) + 1;
-    bool const work = lane_on && row >= 1 && row <= static_cast<i32>(V);
-    bool stored = false;
-    if (work) {
-      u32 const i = static_cast<u32>(row);
-      u32 const info = g.rowinfo[i];
-      u32 const nch = info & 0xFFu, np = (info >> 8) & 7u;
-      i32 hleft, eleft, qleft;
-      if (gl == 0) {  // column 0: H = max(O, F), E = Q = -inf
-        hleft = col0_h(g.rowdepth[i]);
-        eleft = kNegInf;
-        qleft = kNegInf;
+    auto fetch = [&](u32 pr, i32(&th)[CW], i32(&tf)[CW], i32(&to)[CW], i32& thd) {
+      if (pr == 0) {
+#pragma unroll
+        for (int c = 0; c < CW; ++c) {
+          th[c] = row0_h(jb + c);
+          tf[c] = kNegInf;
+          to[c] = kNegInf;
+        }
+        thd = row0_h(jb - 1);
+      } else if (pr + 1 == i) {
+#pragma unroll
+        for (int c = 0; c < CW; ++c) {
+          th[c] = H1[c];
+          tf[c] = F1[c];
+          to[c] = O1[c];
+        }
+        thd = hl1;
+      } else if (kPrev2 && pr + 2 == i) {
+#pragma unroll
+        for (int c = 0; c < CW; ++c) {
+          th[c] = H2[kPrev2 ? c : 0];
+          tf[c] = F2[kPrev2 ? c : 0];
+          to[c] = O2[kPrev2 ? c : 0];
+        }
+        thd = hl2;
       } else {
-        hleft = hL;
-        eleft = eL;
-        qleft = qL;
+        u32 const slot = g.rowslot[pr];
+        const i32* rb = rows + static_cast<size_t>(slot) * 3 * ws.w_stride + static_cast<size_t>(gl) * CW;
+#pragma unroll
+        for (int c = 0; c < CW; ++c) {
+          bool const in = lane_on && jb + c < je;
+          th[c] = in ? rb[c] : 0;
+          tf[c] = in ? rb[ws.w_stride + c] : 0;
+          to[c] = in ? rb[2 * static_cast<size_t>(ws.w_stride) + c] : 0;
+        }
+        thd = gl == 0 ? col0_h(g.rowdepth[pr]) : (lane_on ? rb[-1] : 0);
       }
-      i32 const hl0 = hleft;
-      i32 hh[CW], ff[CW], oo[CW];
-      u32 cd[CW];
-      if (info & RI_FAST) {
-        i32 hd = hl1;
-#pragma unroll
-        for (int c = 0; c < CW; ++c) {
-          i32 const ph = H1[c], pf = F1[c], po = O1[c];
-          i32 const a1 = pf + E_, a2 = ph + G_, a3 = po + C_, a4 = ph + Q_;
-          i32 const fv = max(a1, a2), ov = max(a3, a4);
-          i32 const hm = hd + ((nch == sc[c]) ? M_ : N_);
-          hd = ph;
-          i32 const b1 = eleft + E_, b2 = hleft + G_, b3 = qleft + C_, b4 = hleft + Q_;
-          i32 const e = max(b1, b2), q = max(b3, b4);
-          i32 const u = max(fv, ov), l = max(e, q);
-          i32 const h = max(hm, max(u, l));
-          bool const D = h == hm, U = h == u;
-          bool const eu = (h == a1) || ((h != a2) && (h == a3));
-          bool const elx = (h == b1) || ((h != b2) && (h == b3));
-          bool const lc = (b1 == e) || (b3 == q);
-          bool const us = (fv == a1) || (ov == a3);
-          bool const uh = (fv == a2) || (ov == a4);
-          u32 code = D ? 0u : (U ? 1u : 2u);
-          code |= (!D && (U ? eu : elx)) ? 4u : 0u;
-          code |= lc ? 8u : 0u;
-          code |= us ? 16u : (uh ? 32u : 0u);
-          cd[c] = code;
-          hh[c] = h;
-          ff[c] = fv;
-          oo[c] = ov;
-          if (jb + c < je) {  // columns past the haplotype end are never read back
-            hleft = h;
-            eleft = e;
-            qleft = q;
-          }
-        }
-      } else {
-        // general row: any number of predecessors, each taken from the rank-1 / rank-2 registers, the
-        // closed form of row 0 (a node without in-edges hangs off the virtual start row) or the row store
-        auto fetch = [&](u32 pr, i32(&th)[CW], i32(&tf)[CW], i32(&to)[CW], i32& thd) {
-          if (pr == 0) {
-#pragma unroll
-            for (int c = 0; c < CW; ++c) {
-              th[c] = row0_h(jb + c);
-              tf[c] = kNegInf;
-              to[c] = kNegInf;
-            }
-            thd = row0_h(jb - 1);
-          } else if (pr + 1 == i) {
-#pragma unroll
-            for (int c = 0; c < CW; ++c) {
-              th[c] = H1[c];
-              tf[c] = F1[c];
-              to[c] = O1[c];
-            }
-            thd = hl1;
-          } else if (kPrev2 && pr + 2 == i) {
-#pragma unroll
-            for (int c = 0; c < CW; ++c) {
-              th[c] = H2[kPrev2 ? c : 0];
-              tf[c] = F2[kPrev2 ? c : 0];
-              to[c] = O2[kPrev2 ? c : 0];
-            }
-            thd = hl2;
-          } else {
-            u32 const slot = g.rowslot[pr];
-            const i32* rb = rows + static_cast<size_t>(slot) * 3 * ws.w_stride + static_cast<size_t>(gl) * CW;
-#pragma unroll
-            for (int c = 0; c < CW; ++c) {
-              th[c] = rb[c];
-              tf[c] = rb[ws.w_stride + c];
-              to[c] = rb[2 * static_cast<size_t>(ws.w_stride) + c];
-            }
-            thd = gl == 0 ? col0_h(g.rowdepth[pr]) : rb[-1];
-          }
-        };
-        u32 const npe = np ? np : 1u;
-        for (u32 x = 0; x < npe; ++x) {
-          u32 const pr = np ? pred_row(g, i, info, x) : 0u;
-          i32 th[CW], tf[CW], to[CW], hd;
-          fetch(pr, th, tf, to, hd);
-#pragma unroll
-          for (int c = 0; c < CW; ++c) {
-            i32 const fv = max(tf[c] + E_, th[c] + G_), ov = max(to[c] + C_, th[c] + Q_);
-            i32 const hv = hd + ((nch == sc[c]) ? M_ : N_);
-            hd = th[c];
-            if (x == 0) {
-              ff[c] = fv;
-              oo[c] = ov;
-              hh[c] = hv;  // running max of the diagonal candidates
-            } else {
-              ff[c] = max(ff[c], fv);
-              oo[c] = max(oo[c], ov);
-              hh[c] = max(hh[c], hv);
-            }
-          }
-        }
-        u32 elmask = 0, lcmask = 0;
-#pragma unroll
-        for (int c = 0; c < CW; ++c) {
-          i32 const b1 = eleft + E_, b2 = hleft + G_, b3 = qleft + C_, b4 = hleft + Q_;
-          i32 const e = max(b1, b2), q = max(b3, b4);
-          i32 const h = max(hh[c], max(max(ff[c], oo[c]), max(e, q)));
-          if ((h == b1) || ((h != b2) && (h == b3))) elmask |= 1u << c;
-          if ((b1 == e) || (b3 == q)) lcmask |= 1u << c;
-          hh[c] = h;
-          if (jb + c < je) {
-            hleft = h;
-            eleft = e;
-            qleft = q;
-          }
-        }
-        // second pass over the predecessors: which one SPOA's backtrack would pick, in its test order
-        u32 dmask = 0, umask = 0, eumask = 0, usmask = 0, uhmask = 0;
-        u32 xs[CW];  // predecessor indices: [1:0] diagonal, [3:2] up, [5:4] F/O extension, [7:6] H extension
-#pragma unroll
-        for (int c = 0; c < CW; ++c) xs[c] = 0;
-        for (u32 x = 0; x < npe; ++x) {
-          u32 const pr = np ? pred_row(g, i, info, x) : 0u;
-          i32 th[CW], tf[CW], to[CW], hd;
-          fetch(pr, th, tf, to, hd);
-#pragma unroll
-          for (int c = 0; c < CW; ++c) {
-            i32 const a1 = tf[c] + E_, a2 = th[c] + G_, a3 = to[c] + C_, a4 = th[c] + Q_;
-            i32 const hv = hd + ((nch == sc[c]) ? M_ : N_);
-            hd = th[c];
-            i32 const h = hh[c];
-            u32 const bit = 1u << c;
-            if (!(dmask & bit) && h == hv) {
-              dmask |= bit;
-              xs[c] |= x;
-            }
-            bool const t1 = h == a1, t2 = h == a2, t3 = h == a3, t4 = h == a4;
-            if (!(umask & bit) && (t1 || t2 || t3 || t4)) {
-              umask |= bit;
-              xs[c] |= x << 2;
-              if (t1 || (!t2 && t3)) eumask |= bit;
-            }
-            if (np) {  // a row without in-edges has an empty predecessor loop in the up-extension walk
-              if (!(usmask & bit) && ((ff[c] == a1) || (oo[c] == a3))) {
-                usmask |= bit;
-                xs[c] |= x << 4;
-              }
-              if (!(uhmask & bit) && ((ff[c] == a2) || (oo[c] == a4))) {
-                uhmask |= bit;
-                xs[c] |= x << 6;
-              }
-            }
-          }
-        }
-#pragma unroll
-        for (int c = 0; c < CW; ++c) {
-          u32 const bit = 1u << c;
-          bool const D = dmask & bit, U = umask & bit;
-          u32 code = D ? 0u : (U ? 1u : 2u);
-          code |= (!D && (U ? ((eumask & bit) != 0) : ((elmask & bit) != 0))) ? 4u : 0u;
-          code |= (lcmask & bit) ? 8u : 0u;
-          bool const us = usmask & bit, uh = uhmask & bit;
-          code |= us ? 16u : (uh ? 32u : 0u);
-          code |= (D ? (xs[c] & 3u) : (U ? ((xs[c] >> 2) & 3u) : 0u)) << 6;
-          code |= (us ? ((xs[c] >> 4) & 3u) : (uh ? ((xs[c] >> 6) & 3u) : 0u)) << 8;
-          cd[c] = code;
-        }
-      }
-      // the two previous rows stay in registers
+    };
+    u32 const npe = np ? np : 1u;
+    // ---- vertical + diagonal part: m = max(diag, F, O) ----
+    i32 hh[CW], ff[CW], oo[CW], hmv[CW];
+    if (fast) {
+      i32 hd = hl1;
 #pragma unroll
       for (int c = 0; c < CW; ++c) {
-        if (kPrev2) {
-          H2[kPrev2 ? c : 0] = H1[c];
-          F2[kPrev2 ? c : 0] = F1[c];
-          O2[kPrev2 ? c : 0] = O1[c];
-        }
-        H1[c] = hh[c];
-        F1[c] = ff[c];
-        O1[c] = oo[c];
+        i32 const ph = H1[c];
+        ff[c] = max(F1[c] + E_, ph + G_);
+        oo[c] = max(O1[c] + C_, ph + Q_);
+        hmv[c] = hd + ((nch == sc[c]) ? M_ : N_);
+        hd = ph;
       }
-      hl2 = hl1;
-      hl1 = hl0;
-      // decision codes: step-major, so one store of the wave covers 64 * CW * 2 contiguous bytes
-      u32* cp = reinterpret_cast<u32*>(codes + (static_cast<size_t>(t) * nl + gl) * CW);
+    } else {
+      for (u32 x = 0; x < npe; ++x) {
+        u32 const pr = np ? pred_row(g, i, info_cur, x) : 0u;
+        i32 th[CW], tf[CW], to[CW], hd;
+        fetch(pr, th, tf, to, hd);
+#pragma unroll
+        for (int c = 0; c < CW; ++c) {
+          i32 const fv = max(tf[c] + E_, th[c] + G_), ov = max(to[c] + C_, th[c] + Q_);
+          i32 const hv = hd + ((nch == sc[c]) ? M_ : N_);
+          hd = th[c];
+          if (x == 0) {
+            ff[c] = fv;
+            oo[c] = ov;
+            hmv[c] = hv;
+          } else {
+            ff[c] = max(ff[c], fv);
+            oo[c] = max(oo[c], ov);
+            hmv[c] = max(hmv[c], hv);
+          }
+        }
+      }
+    }
+    // ---- prefix maxima of m_k + k and m_k + 2k over the row (column 0 enters through lane 0) ----
+    i32 run1 = gl == 0 ? h0 : NEG, run2 = run1;
+    i32 pl1 = run1, pl2 = run2;  // prefix BEFORE this lane's last column (for the next wave's first lane)
+#pragma unroll
+    for (int c = 0; c < CW; ++c) {
+      i32 const m = max(hmv[c], max(ff[c], oo[c]));
+      hh[c] = m;
+      bool const in = lane_on && jb + c < je;
+      i32 const j = static_cast<i32>(jb) + c;
+      if (c == CW - 1) {
+        pl1 = run1;
+        pl2 = run2;
+      }
+      run1 = max(run1, in ? m + j : NEG);
+      run2 = max(run2, in ? m + 2 * j : NEG);
+    }
+    i32 const inc1 = wave_incl_max(run1, NEG), inc2 = wave_incl_max(run2, NEG);
+    i32 const ex1 = wave_shr1(inc1, NEG), ex2 = wave_shr1(inc2, NEG);
+    u32 const par = i & 1u;
+    if (lane == 63) {
+      ST.ftot[par][wave][0] = inc1;
+      ST.ftot[par][wave][1] = inc2;
+      ST.fbnd[par][wave][0] = max(ex1, pl1);
+      ST.fbnd[par][wave][1] = max(ex2, pl2);
+      ST.fbnd[par][wave][2] = hh[CW - 1];
+    }
+    if (stored_prev) __threadfence_block();  // last row's store is read back two or more rows from now
+    lds_barrier();
+    i32 cb1 = NEG, cb2 = NEG, cbp1 = NEG, cbp2 = NEG;  // all earlier waves / all waves before the previous one
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      if (k < wave) {
+        cb1 = max(cb1, ST.ftot[par][k][0]);
+        cb2 = max(cb2, ST.ftot[par][k][1]);
+      }
+      if (k + 1 < wave) {
+        cbp1 = max(cbp1, ST.ftot[par][k][0]);
+        cbp2 = max(cbp2, ST.ftot[par][k][1]);
+      }
+    }
+    // ---- E, Q, H of this lane's columns ----
+    i32 ee[CW], qq[CW];
+    {
+      i32 s1 = max(cb1, ex1), s2 = max(cb2, ex2);
+      if (gl == 0) s1 = s2 = h0;
+#pragma unroll
+      for (int c = 0; c < CW; ++c) {
+        i32 const j = static_cast<i32>(jb) + c;
+        i32 const q = s1 + Q_ - (j - 1);
+        i32 const e = max(s2 + G_ - 2 * (j - 1), s1 + Q_ + G_ - (j - 2));
+        i32 const m = hh[c];
+        bool const in = lane_on && jb + c < je;
+        s1 = max(s1, in ? m + j : NEG);
+        s2 = max(s2, in ? m + 2 * j : NEG);
+        ee[c] = e;
+        qq[c] = q;
+        hh[c] = max(m, max(e, q));
+      }
+    }
+    // ---- (H, E, Q) of the column to the left of this lane ----
+    i32 hN = wave_shr1(hh[CW - 1], 0), eN = wave_shr1(ee[CW - 1], 0), qN = wave_shr1(qq[CW - 1], 0);
+    if (lane == 0) {
+      if (wave == 0) {
+        hN = h0;
+        eN = kNegInf;
+        qN = kNegInf;
+      } else {  // rebuild the previous wave's last column from what its lane 63 published
+        i32 const s1 = max(cbp1, ST.fbnd[par][wave - 1][0]), s2 = max(cbp2, ST.fbnd[par][wave - 1][1]);
+        i32 const j = static_cast<i32>(jb) - 1;
+        qN = s1 + Q_ - (j - 1);
+        eN = max(s2 + G_ - 2 * (j - 1), s1 + Q_ + G_ - (j - 2));
+        hN = max(ST.fbnd[par][wave - 1][2], max(eN, qN));
+      }
+    }
+    // ---- decision codes ----
+    u32 cd[CW];
+    if (fast) {
+      i32 hleft = hN, eleft = eN, qleft = qN;
+#pragma unroll
+      for (int c = 0; c < CW; ++c) {
+        i32 const ph = H1[c];
+        i32 const a1 = F1[c] + E_, a2 = ph + G_, a3 = O1[c] + C_, a4 = ph + Q_;
+        i32 const fv = ff[c], ov = oo[c], hm = hmv[c], h = hh[c], e = ee[c], q = qq[c];
+        i32 const b1 = eleft + E_, b2 = hleft + G_, b3 = qleft + C_;
+        bool const D = h == hm, U = h == max(fv, ov);
+        bool const eu = (h == a1) || ((h != a2) && (h == a3));
+        bool const elx = (h == b1) || ((h != b2) && (h == b3));
+        bool const lc = (b1 == e) || (b3 == q);
+        bool const us = (fv == a1) || (ov == a3);
+        bool const uh = (fv == a2) || (ov == a4);
+        u32 code = D ? 0u : (U ? 1u : 2u);
+        code |= (!D && (U ? eu : elx)) ? 4u : 0u;
+        code |= lc ? 8u : 0u;
+        code |= us ? 16u : (uh ? 32u : 0u);
+        cd[c] = code;
+        hleft = h;
+        eleft = e;
+        qleft = q;
+      }
+    } else {
+      u32 elmask = 0, lcmask = 0;
+      {
+        i32 hleft = hN, eleft = eN, qleft = qN;
+#pragma unroll
+        for (int c = 0; c < CW; ++c) {
+          i32 const h = hh[c];
+          i32 const b1 = eleft + E_, b2 = hleft + G_, b3 = qleft + C_;
+          if ((h == b1) || ((h != b2) && (h == b3))) elmask |= 1u << c;
+          if ((b1 == ee[c]) || (b3 == qq[c])) lcmask |= 1u << c;
+          hleft = h;
+          eleft = ee[c];
+          qleft = qq[c];
+        }
+      }
+      // second pass over the predecessors: which one SPOA's backtrack would pick, in its test order
+      u32 dmask = 0, umask = 0, eumask = 0, usmask = 0, uhmask = 0;
+      u32 xs[CW];  // predecessor indices: [1:0] diagonal, [3:2] up, [5:4] F/O extension, [7:6] H extension
+#pragma unroll
+      for (int c = 0; c < CW; ++c) xs[c] = 0;
+      for (u32 x = 0; x < npe; ++x) {
+        u32 const pr = np ? pred_row(g, i, info_cur, x) : 0u;
+        i32 th[CW], tf[CW], to[CW], hd;
+        fetch(pr, th, tf, to, hd);
+#pragma unroll
+        for (int c = 0; c < CW; ++c) {
+          i32 const a1 = tf[c] + E_, a2 = th[c] + G_, a3 = to[c] + C_, a4 = th[c] + Q_;
+          i32 const hv = hd + ((nch == sc[c]) ? M_ : N_);
+          hd = th[c];
+          i32 const h = hh[c];
+          u32 const bit = 1u << c;
+          if (!(dmask & bit) && h == hv) {
+            dmask |= bit;
+            xs[c] |= x;
+          }
+          bool const t1 = h == a1, t2 = h == a2, t3 = h == a3, t4 = h == a4;
+          if (!(umask & bit) && (t1 || t2 || t3 || t4)) {
+            umask |= bit;
+            xs[c] |= x << 2;
+            if (t1 || (!t2 && t3)) eumask |= bit;
+          }
+          if (np) {  // a row without in-edges has an empty predecessor loop in the up-extension walk
+            if (!(usmask & bit) && ((ff[c] == a1) || (oo[c] == a3))) {
+              usmask |= bit;
+              xs[c] |= x << 4;
+            }
+            if (!(uhmask & bit) && ((ff[c] == a2) || (oo[c] == a4))) {
+              uhmask |= bit;
+              xs[c] |= x << 6;
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < CW; ++c) {
+        u32 const bit = 1u << c;
+        bool const D = dmask & bit, U = umask & bit;
+        u32 code = D ? 0u : (U ? 1u : 2u);
+        code |= (!D && (U ? ((eumask & bit) != 0) : ((elmask & bit) != 0))) ? 4u : 0u;
+        code |= (lcmask & bit) ? 8u : 0u;
+        bool const us = usmask & bit, uh = uhmask & bit;
+        code |= us ? 16u : (uh ? 32u : 0u);
+        code |= (D ? (xs[c] & 3u) : (U ? ((xs[c] >> 2) & 3u) : 0u)) << 6;
+        code |= (us ? ((xs[c] >> 4) & 3u) : (uh ? ((xs[c] >> 6) & 3u) : 0u)) << 8;
+        cd[c] = code;
+      }
+    }
+    // the two previous rows stay in registers
+#pragma unroll
+    for (int c = 0; c < CW; ++c) {
+      if (kPrev2) {
+        H2[kPrev2 ? c : 0] = H1[c];
+        F2[kPrev2 ? c : 0] = F1[c];
+        O2[kPrev2 ? c : 0] = O1[c];
+      }
+      H1[c] = hh[c];
+      F1[c] = ff[c];
+      O1[c] = oo[c];
+    }
+    hl2 = hl1;
+    hl1 = hN;
+    if (lane_on) {
+      // decision codes, row-major: one store of the wave covers 64 * CW * 2 contiguous bytes
+      u32* cp = reinterpret_cast<u32*>(codes + static_cast<size_t>(i) * W + static_cast<size_t>(gl) * CW);
       if constexpr (CW % 8 == 0) {
 #pragma unroll
         for (int c = 0; c < CW; c += 8)
@@ -581,7 +673,7 @@ __device__ void poa_fill(GL const& g, PoaWs const& ws, u16* codes, i32* rows, i3
 #pragma unroll
         for (int c = 0; c < CW; c += 2) cp[c / 2] = cd[c] | (cd[c + 1] << 16);
       }
-      if (info & RI_STORE) {
+      if (store) {
         u32 const slot = g.rowslot[i];
         i32* rb = rows + static_cast<size_t>(slot) * 3 * ws.w_stride + static_cast<size_t>(gl) * CW;
 #pragma unroll
@@ -592,7 +684,6 @@ __device__ void poa_fill(GL const& g, PoaWs const& ws, u16* codes, i32* rows, i3
             rb[2 * static_cast<size_t>(ws.w_stride) + c] = oo[c];
           }
         }
-        stored = true;
       }
       if (gl == glL) {
         i32 v = hh[0];
@@ -600,20 +691,8 @@ __device__ void poa_fill(GL const& g, PoaWs const& ws, u16* codes, i32* rows, i3
         for (int c = 1; c < CW; ++c) v = (static_cast<u32>(c) == cL) ? hh[c] : v;
         hlast[i] = v;
       }
-      hl = hleft;
-      el = eleft;
-      ql = qleft;
     }
-    if (lane == 63 && wave < 3) {
-      i32* mb = ST.mbox[t & 1][wave];
-      mb[0] = hl;
-      mb[1] = el;
-      mb[2] = ql;
-    }
-    // a stored row is read back >= 3 steps after it was written; make it visible one step after the store
-    pend = (pend << 1) | (__any(stored) ? 1u : 0u);
-    if (pend & 2u) __threadfence_block();
-    lds_barrier();
+    stored_prev = store;
   }
 }
 
@@ -643,8 +722,7 @@ __device__ __forceinline__ EdgeVals edge_vals(GL const& g, u32 i, u32 j) {  // c
 __device__ u32 poa_traceback(GL const& g, const u16* codes, u32 cw, u32 V, u32 L, u32 best_row, bool have_end, int lane) {
   u32 const nl = (L + cw - 1) / cw;
   auto code_at = [&](u32 i, u32 j) -> u32 {  // i >= 1, j >= 1
-    u32 const glj = (j - 1) / cw, c = (j - 1) - glj * cw;
-    return codes[(static_cast<size_t>(i + glj - 1) * nl + glj) * cw + c];
+    return codes[static_cast<size_t>(i) * (nl * cw) + (j - 1)];
   };
   u32 naln = 0;
   bool overflow = false;
@@ -909,7 +987,7 @@ __global__ __launch_bounds__(kT, 2) void k_msa(MsaArgs A) {
             u32 const V = ST.nrank;
             u32 const cw = L <= 1024 ? 4u : (L <= 1536 ? 6u : (L <= 2048 ? 8u : (L <= 3072 ? 12u : 16u)));
             u32 const nl = (L + cw - 1) / cw;
-            if (L > 4096 || V > PN || static_cast<size_t>(V + nl) * nl * cw > ws.code_cells) {
+            if (L > 4096 || V > PN || static_cast<size_t>(V + 1) * nl * cw > ws.code_cells) {
               ST.overflow = 1;
             } else {
               mode = 2;
@@ -1457,7 +1535,7 @@ int launch_msa(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& a, const ma_var
   ws.pn = pn;
   ws.w_stride = (max_len + 7) & ~7u;
   ws.row_slots = pn / 2;
-  ws.code_cells = (static_cast<size_t>(pn + 257) * (max_len + 16) + 7) & ~size_t(7);
+  ws.code_cells = (static_cast<size_t>(pn + 2) * (max_len + 16) + 7) & ~size_t(7);
   if (ws.code_cells * 2 < static_cast<size_t>(P.max_haps) * (2 * max_len + 8) + 64)  // raw-allele scratch lives in the codes
     ws.code_cells = (static_cast<size_t>(P.max_haps) * (2 * max_len + 8) / 2 + 64 + 7) & ~size_t(7);
   ws.row_cells = static_cast<size_t>(ws.row_slots) * 3 * ws.w_stride;
