@@ -345,6 +345,7 @@ template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ i32 dpp_mov(i32 x, i32 ident) {
   return __builtin_amdgcn_update_dpp(ident, x, CTRL, ROW_MASK, 0xF, false);
 }
+constexpr i32 kScanIdent = static_cast<i32>(0x80000000u);  // identity of max: lets the compiler fold mov_dpp + max
 __device__ __forceinline__ i32 wave_incl_max(i32 x, i32 ident) {
   x = max(x, dpp_mov<0x111, 0xF>(x, ident));  // row_shr:1
   x = max(x, dpp_mov<0x112, 0xF>(x, ident));  // row_shr:2
@@ -380,7 +381,7 @@ __device__ void poa_fill(GL const& g, PoaWs const& ws, u16* codes, i32* rows, i3
   u32 const W = nl * CW;
   bool const lane_on = gl < nl;
   u32 const glL = (L - 1) / CW, cL = (L - 1) % CW;
-  constexpr i32 NEG = -(1 << 30);
+  constexpr i32 NEG = kScanIdent;
   u32 sc[CW];
 #pragma unroll
   for (int c = 0; c < CW; ++c) sc[c] = (lane_on && jb + c < je) ? seq[jb + c - 1] : 0u;
@@ -393,9 +394,15 @@ __device__ void poa_fill(GL const& g, PoaWs const& ws, u16* codes, i32* rows, i3
   for (int c = 0; c < CW2; ++c) H2[c] = F2[c] = O2[c] = 0;
   i32 hl1 = 0, hl2 = 0;  // H(i-1, jb-1), H(i-2, jb-1)
   bool stored_prev = false;
+#ifdef MA_PROFILE
+  unsigned long long pa = 0, pb = 0, pc = 0, pn_gen = 0;
+#endif
   u32 info = g.rowinfo[1];
   u32 depth = g.rowdepth[1];
   for (u32 i = 1; i <= V; ++i) {
+#ifdef MA_PROFILE
+    unsigned long long const q0 = __builtin_amdgcn_s_memtime();
+#endif
     u32 const nch = info & 0xFFu, np = (info >> 8) & 7u;
     bool const fast = info & RI_FAST, store = info & RI_STORE;
     u32 const info_cur = info;
@@ -484,14 +491,15 @@ __device__ void poa_fill(GL const& g, PoaWs const& ws, u16* codes, i32* rows, i3
     for (int c = 0; c < CW; ++c) {
       i32 const m = max(hmv[c], max(ff[c], oo[c]));
       hh[c] = m;
-      bool const in = lane_on && jb + c < je;
       i32 const j = static_cast<i32>(jb) + c;
       if (c == CW - 1) {
         pl1 = run1;
         pl2 = run2;
       }
-      run1 = max(run1, in ? m + j : NEG);
-      run2 = max(run2, in ? m + 2 * j : NEG);
+      // no validity mask: columns past the haplotype end lie to the right of every valid column and
+      // prefix maxima only flow rightwards
+      run1 = max(run1, m + j);
+      run2 = max(run2, m + 2 * j);
     }
     i32 const inc1 = wave_incl_max(run1, NEG), inc2 = wave_incl_max(run2, NEG);
     i32 const ex1 = wave_shr1(inc1, NEG), ex2 = wave_shr1(inc2, NEG);
@@ -504,18 +512,21 @@ __device__ void poa_fill(GL const& g, PoaWs const& ws, u16* codes, i32* rows, i3
       ST.fbnd[par][wave][2] = hh[CW - 1];
     }
     if (stored_prev) __threadfence_block();  // last row's store is read back two or more rows from now
+#ifdef MA_PROFILE
+    unsigned long long const q1 = __builtin_amdgcn_s_memtime();
+#endif
     lds_barrier();
+#ifdef MA_PROFILE
+    unsigned long long const q2 = __builtin_amdgcn_s_memtime();
+#endif
     i32 cb1 = NEG, cb2 = NEG, cbp1 = NEG, cbp2 = NEG;  // all earlier waves / all waves before the previous one
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-      if (k < wave) {
-        cb1 = max(cb1, ST.ftot[par][k][0]);
-        cb2 = max(cb2, ST.ftot[par][k][1]);
-      }
-      if (k + 1 < wave) {
-        cbp1 = max(cbp1, ST.ftot[par][k][0]);
-        cbp2 = max(cbp2, ST.ftot[par][k][1]);
-      }
+      i32 const t1 = ST.ftot[par][k][0], t2 = ST.ftot[par][k][1];
+      cb1 = max(cb1, k < wave ? t1 : NEG);
+      cb2 = max(cb2, k < wave ? t2 : NEG);
+      cbp1 = max(cbp1, k + 1 < wave ? t1 : NEG);
+      cbp2 = max(cbp2, k + 1 < wave ? t2 : NEG);
     }
     // ---- E, Q, H of this lane's columns ----
     i32 ee[CW], qq[CW];
@@ -528,9 +539,8 @@ __device__ void poa_fill(GL const& g, PoaWs const& ws, u16* codes, i32* rows, i3
         i32 const q = s1 + Q_ - (j - 1);
         i32 const e = max(s2 + G_ - 2 * (j - 1), s1 + Q_ + G_ - (j - 2));
         i32 const m = hh[c];
-        bool const in = lane_on && jb + c < je;
-        s1 = max(s1, in ? m + j : NEG);
-        s2 = max(s2, in ? m + 2 * j : NEG);
+        s1 = max(s1, m + j);
+        s2 = max(s2, m + 2 * j);
         ee[c] = e;
         qq[c] = q;
         hh[c] = max(m, max(e, q));
@@ -565,12 +575,13 @@ __device__ void poa_fill(GL const& g, PoaWs const& ws, u16* codes, i32* rows, i3
         bool const eu = (h == a1) || ((h != a2) && (h == a3));
         bool const elx = (h == b1) || ((h != b2) && (h == b3));
         bool const lc = (b1 == e) || (b3 == q);
+        // fv = max(a1, a2), ov = max(a3, a4): if neither F nor O extends (a1 < a2 and a3 < a4) then fv == a2,
+        // i.e. the H-predecessor test of the up-extension walk holds
         bool const us = (fv == a1) || (ov == a3);
-        bool const uh = (fv == a2) || (ov == a4);
         u32 code = D ? 0u : (U ? 1u : 2u);
         code |= (!D && (U ? eu : elx)) ? 4u : 0u;
         code |= lc ? 8u : 0u;
-        code |= us ? 16u : (uh ? 32u : 0u);
+        code |= us ? 16u : 32u;
         cd[c] = code;
         hleft = h;
         eleft = e;
@@ -693,7 +704,23 @@ __device__ void poa_fill(GL const& g, PoaWs const& ws, u16* codes, i32* rows, i3
       }
     }
     stored_prev = store;
+#ifdef MA_PROFILE
+    unsigned long long const q3 = __builtin_amdgcn_s_memtime();
+    pa += q1 - q0;
+    pb += q2 - q1;
+    pc += q3 - q2;
+    pn_gen += fast ? 0 : 1;
+#endif
   }
+#ifdef MA_PROFILE
+  if (tid == 0) {
+    atomicAdd(&g_prof[8], pa);
+    atomicAdd(&g_prof[9], pb);
+    atomicAdd(&g_prof[10], pc);
+    atomicAdd(&g_prof[11], pn_gen);
+    atomicAdd(&g_prof[12], static_cast<unsigned long long>(V));
+  }
+#endif
 }
 
 // ---- traceback (wave 0, all lanes carry the same state): SisdAlignmentEngine::Convex backtrack ----
