@@ -89,10 +89,10 @@ constexpr u32 kStBytes = (sizeof(WgState) + 15u) & ~15u;
 struct GL {  // LDS layout of one window's POA graph + scratch
   u32 pn;
   LdsArr<u8> nchar, nin, nout, nal;
-  LdsArr<u16> in_tail, out_head, out_lab, al, rank2node, node2rank, ndepth;
+  LdsArr<u16> in_tail, out_head, out_lab, al, rank2node, node2rank;
   // scratch, alignment phase
   LdsArr<u32> rowinfo;
-  LdsArr<u16> rowslot, rowdepth, slowpred, aln;
+  LdsArr<u16> rowslot, rowdepth, runhead, slowpred, aln;
   u32 aln_cap;
   // scratch, graph update (aliases rowinfo .. rowdepth)
   LdsArr<u16> cnode, cpos, ccur;
@@ -103,8 +103,8 @@ struct GL {  // LDS layout of one window's POA graph + scratch
 };
 
 __host__ __device__ inline size_t poa_lds_bytes(u32 pn, u32 ml) {
-  size_t const graph = size_t(42) * pn;
-  size_t const s_aln = size_t(8) * (pn + 2) + 8 * kSlowCap + size_t(4) * (pn + ml + 2);
+  size_t const graph = size_t(40) * pn;
+  size_t const s_aln = size_t(10) * (pn + 2) + 8 * kSlowCap + size_t(4) * (pn + ml + 2);
   size_t const s_topo = size_t(10) * pn;
   return kStBytes + graph + (s_aln > s_topo ? s_aln : s_topo) + 16;
 }
@@ -125,14 +125,14 @@ __device__ __forceinline__ GL poa_carve(u32 PN, u32 ML) {
   o += 32 * PN;
   g.rank2node.off = o;
   g.node2rank.off = o + 2 * PN;
-  g.ndepth.off = o + 4 * PN;
-  o += 6 * PN;
+  o += 4 * PN;
   u32 const S = o;
   g.rowinfo.off = S;
   g.rowslot.off = S + 4 * (PN + 2);
   g.rowdepth.off = S + 6 * (PN + 2);
-  g.slowpred.off = S + 8 * (PN + 2);
-  g.aln.off = S + 8 * (PN + 2) + 8 * kSlowCap;
+  g.runhead.off = S + 8 * (PN + 2);
+  g.slowpred.off = S + 10 * (PN + 2);
+  g.aln.off = S + 10 * (PN + 2) + 8 * kSlowCap;
   g.aln_cap = PN + ML + 2;
   g.cnode.off = S;
   g.cpos.off = S + 2 * (ML + 2);
@@ -196,67 +196,88 @@ __device__ i32 pg_successor(GL const& g, u32 node, u32 label) {  // spoa::Graph:
     if (g.out_lab[node * kPE + x] & (1u << label)) return static_cast<i32>(g.out_head[node * kPE + x]);
   return -1;
 }
-// spoa::Graph::TopologicalSort.  Also records every node's minimum hop distance from a root at the
-// moment it gets its rank (all in-neighbours are ranked by then): that distance is all column 0 of the
-// DP depends on (SisdAlignmentEngine::Initialize: O0 = Q + C d, F0 = G + E d).
-__device__ void pg_toposort(GL const& g) {
+// spoa::Graph::TopologicalSort, run by wave 0 (marks / ignored are zeroed by the caller).
+// SPOA visits the roots s = 0, 1, 2, ... and runs a DFS over unranked ancestors from each unmarked one, so
+// when root s is reached every node with a smaller id is already marked.  A root without aligned nodes
+// whose in-neighbours all have smaller ids is therefore ranked on the spot; runs of such roots (and of
+// already-marked ones) are handled 64 at a time with a ballot.  Every other root gets the serial DFS.
+__device__ void pg_toposort(GL const& g, int lane) {
   u32 const nn = ST.nn;
-  for (u32 i = 0; i < nn; ++i) g.marks[i] = g.ignored[i] = 0;
-  u32 nrank = 0;
-  bool overflow = false;
+  u32 nrank = 0, s = 0;
+  u32 overflow = 0;
   LdsArr<u16> const stack = g.stack;
-  auto emit = [&](u32 node) {
-    g.rank2node[nrank++] = static_cast<u16>(node);
-    u32 const ni = g.nin[node];
-    u32 d = 0;
-    if (ni) {
-      d = 0xFFFFu;
-      for (u32 x = 0; x < ni; ++x) d = min(d, static_cast<u32>(g.ndepth[g.in_tail[node * kPE + x]]));
-      d += 1;
+  while (s < nn && !overflow) {
+    u32 const v = s + static_cast<u32>(lane);
+    bool trivial = false, marked = false;
+    if (v < nn) {
+      marked = g.marks[v] != 0;
+      if (!marked && g.nal[v] == 0) {
+        u32 const ni = g.nin[v];
+        bool ok = true;
+        for (u32 x = 0; x < ni; ++x) ok = ok && g.in_tail[v * kPE + x] < v;
+        trivial = ok;
+      }
     }
-    g.ndepth[node] = static_cast<u16>(d);
-  };
-  for (u32 s = 0; s < nn && !overflow; ++s) {
-    if (g.marks[s] != 0) continue;
-    u32 sp = 0;
-    stack[sp++] = static_cast<u16>(s);
-    while (sp > 0) {
-      u32 const cur = stack[sp - 1];
-      bool valid = true;
-      if (g.marks[cur] != 2) {
-        for (int x = 0; x < g.nin[cur]; ++x) {
-          u32 const t = g.in_tail[cur * kPE + x];
-          if (g.marks[t] != 2) {
-            if (sp < g.stack_cap) stack[sp++] = static_cast<u16>(t); else overflow = true;
-            valid = false;
-          }
-        }
-        if (!g.ignored[cur]) {
-          for (int x = 0; x < g.nal[cur]; ++x) {
-            u32 const an = g.al[cur * kPE + x];
-            if (g.marks[an] != 2) {
-              if (sp < g.stack_cap) stack[sp++] = static_cast<u16>(an); else overflow = true;
-              g.ignored[an] = 1;
+    unsigned long long const pm = __ballot(v < nn && (marked || trivial));
+    u32 const run = pm == ~0ull ? 64u : static_cast<u32>(__builtin_ctzll(~pm));
+    if (run > 0) {
+      unsigned long long const keep = run == 64 ? ~0ull : ((1ull << run) - 1ull);
+      unsigned long long const tm = __ballot(trivial) & keep;
+      if (static_cast<u32>(lane) < run && trivial) {
+        u32 const r = nrank + static_cast<u32>(__popcll(tm & ((1ull << lane) - 1ull)));
+        g.rank2node[r] = static_cast<u16>(v);
+        g.marks[v] = 2;
+      }
+      nrank += static_cast<u32>(__popcll(tm));
+      s += run;
+      continue;
+    }
+    if (lane == 0) {  // root s is unmarked and not trivial
+      u32 sp = 0;
+      stack[sp++] = static_cast<u16>(s);
+      while (sp > 0) {
+        u32 const cur = stack[sp - 1];
+        bool valid = true;
+        if (g.marks[cur] != 2) {
+          for (int x = 0; x < g.nin[cur]; ++x) {
+            u32 const t = g.in_tail[cur * kPE + x];
+            if (g.marks[t] != 2) {
+              if (sp < g.stack_cap) stack[sp++] = static_cast<u16>(t); else overflow = 1;
               valid = false;
             }
           }
-        }
-        if (valid) {
-          g.marks[cur] = 2;
           if (!g.ignored[cur]) {
-            emit(cur);
-            for (int x = 0; x < g.nal[cur]; ++x) emit(g.al[cur * kPE + x]);
+            for (int x = 0; x < g.nal[cur]; ++x) {
+              u32 const an = g.al[cur * kPE + x];
+              if (g.marks[an] != 2) {
+                if (sp < g.stack_cap) stack[sp++] = static_cast<u16>(an); else overflow = 1;
+                g.ignored[an] = 1;
+                valid = false;
+              }
+            }
           }
-        } else {
-          g.marks[cur] = 1;
+          if (valid) {
+            g.marks[cur] = 2;
+            if (!g.ignored[cur]) {
+              g.rank2node[nrank++] = static_cast<u16>(cur);
+              for (int x = 0; x < g.nal[cur]; ++x) g.rank2node[nrank++] = g.al[cur * kPE + x];
+            }
+          } else {
+            g.marks[cur] = 1;
+          }
         }
+        if (valid) sp--;
+        if (overflow) break;
       }
-      if (valid) sp--;
-      if (overflow) break;
     }
+    nrank = __shfl(nrank, 0);
+    overflow = __shfl(overflow, 0);
+    s += 1;
   }
-  ST.nrank = nrank;
-  if (overflow) ST.overflow = 1;
+  if (lane == 0) {
+    ST.nrank = nrank;
+    if (overflow) ST.overflow = 1;
+  }
 }
 
 __device__ i32 classify_variant(const u8* r, u32 rl, const u8* a, u32 al) {  // raw_variant.cpp:44-77
@@ -338,6 +359,24 @@ __device__ u32 block_excl_scan(u32 v, int tid, u32& total) {
   __syncthreads();
   total = tot;
   return base + inc - v;
+}
+
+// block-wide exclusive prefix maximum of one value per thread (two barriers)
+__device__ u32 block_excl_scan_max(u32 v, int tid) {
+  int const lane = tid & 63, wave = tid >> 6;
+  u32 inc = v;
+  for (int d = 1; d < 64; d <<= 1) {
+    u32 const y = __shfl_up(inc, d);
+    if (lane >= d) inc = max(inc, y);
+  }
+  if (lane == 63) ST.wsum[wave] = inc;
+  u32 ex = __shfl_up(inc, 1);
+  if (lane == 0) ex = 0;
+  __syncthreads();
+  for (int k = 0; k < 4; ++k)
+    if (k < wave) ex = max(ex, ST.wsum[k]);
+  __syncthreads();
+  return ex;
 }
 
 // ---- wave-wide prefix maximum with DPP (no LDS traffic) ----
@@ -1044,7 +1083,6 @@ __global__ __launch_bounds__(kT, 2) void k_msa(MsaArgs A) {
           g.out_lab[i * kPE] = lab;
           g.rank2node[i] = static_cast<u16>(i);
           g.node2rank[i] = static_cast<u16>(i);
-          g.ndepth[i] = static_cast<u16>(i);
         }
         __syncthreads();
         if (tid == 0) {
@@ -1079,16 +1117,23 @@ __global__ __launch_bounds__(kT, 2) void k_msa(MsaArgs A) {
         for (u32 x = 0; x < np; ++x)
           if (pr[x] + 1 != i && !(cw <= 8 && pr[x] + 2 == i)) g.rowslot[pr[x]] = 1;
         g.rowinfo[i] = info;
-        g.rowdepth[i] = g.ndepth[node];
       }
       __syncthreads();
       {
         u32 const per = (V + kT) / kT;  // rows 1 .. V in contiguous chunks
         u32 const lo = min(1 + tid * per, V + 1), hi2 = min(lo + per, V + 1);
-        u32 cnt = 0;
-        for (u32 i = lo; i < hi2; ++i) cnt += g.rowslot[i];
-        u32 total = 0;
+        u32 cnt = 0, nslow = 0, last_slow = 0;
+        for (u32 i = lo; i < hi2; ++i) {
+          cnt += g.rowslot[i];
+          if (!(g.rowinfo[i] & RI_FAST)) {
+            nslow++;
+            last_slow = i;
+          }
+        }
+        u32 total = 0, total_slow = 0;
         u32 slot = block_excl_scan(cnt, tid, total);
+        u32 at = block_excl_scan(nslow, tid, total_slow);
+        u32 head = block_excl_scan_max(last_slow, tid);  // last row before this chunk that is not FAST
         for (u32 i = lo; i < hi2; ++i) {
           if (g.rowslot[i]) {
             g.rowslot[i] = static_cast<u16>(slot++);
@@ -1096,8 +1141,40 @@ __global__ __launch_bounds__(kT, 2) void k_msa(MsaArgs A) {
           } else {
             g.rowslot[i] = 0xFFFFu;
           }
+          if (!(g.rowinfo[i] & RI_FAST)) {
+            head = i;
+            g.aln[at++] = static_cast<u16>(i);  // the alignment path buffer is free until the traceback
+          }
+          g.runhead[i] = static_cast<u16>(head);
         }
         if (total > ws.row_slots && tid == 0) ST.overflow = 1;
+        __syncthreads();
+        // column 0 of the DP only depends on every node's minimum hop distance d from a root
+        // (SisdAlignmentEngine::Initialize: O0 = Q + C d, F0 = G + E d).  Rows that are not FAST take it
+        // from their predecessors, serially in rank order; FAST rows just count up from their run head.
+        if (tid == 0) {
+          for (u32 k = 0; k < total_slow; ++k) {
+            u32 const r = g.aln[k];
+            u32 const inf = g.rowinfo[r];
+            u32 const np = (inf >> 8) & 7u;
+            u32 d = 0;
+            if (np) {
+              d = 0xFFFFu;
+              for (u32 x = 0; x < np; ++x) {
+                u32 const p = pred_row(g, r, inf, x);
+                u32 const hp = g.runhead[p];
+                d = min(d, static_cast<u32>(g.rowdepth[hp]) + (p - hp));
+              }
+              d += 1;
+            }
+            g.rowdepth[r] = static_cast<u16>(d);
+          }
+        }
+        __syncthreads();
+        for (u32 i = lo; i < hi2; ++i) {
+          u32 const hp = g.runhead[i];
+          if (hp != i) g.rowdepth[i] = static_cast<u16>(g.rowdepth[hp] + (i - hp));
+        }
       }
       __syncthreads();
       if (ST.overflow) continue;
@@ -1283,7 +1360,12 @@ __global__ __launch_bounds__(kT, 2) void k_msa(MsaArgs A) {
       }
       __syncthreads();
       PROF_ACC(3);
-      if (tid == 0 && !ST.overflow) pg_toposort(g);
+      if (!ST.overflow) {
+        u32 const nn2 = ST.nn;
+        for (u32 i = tid; i < nn2; i += kT) g.marks[i] = g.ignored[i] = 0;
+      }
+      __syncthreads();
+      if (wave == 0 && !ST.overflow) pg_toposort(g, lane);
       __syncthreads();
       if (!ST.overflow) {
         u32 const nrank = ST.nrank;
