@@ -17,6 +17,13 @@ namespace ma {
 
 namespace {
 
+#ifdef MA_PROFILE
+__device__ unsigned long long g_cprof[16];
+__device__ unsigned long long g_cwin[4096 * 4];
+#define CCOUNT(slot) atomicAdd(&g_cprof[slot], 1ull)
+#else
+#define CCOUNT(slot) do {} while (0)
+#endif
 constexpr int kMaxWalks = 64;
 constexpr u32 kNoParent = 0xFFFFFFFFu;
 
@@ -294,8 +301,278 @@ __device__ void compress_node(Win& g, u32 nid, bool dflt, u8* absorbed) {
       emplace_edge(g, nbd, mirror_of(nid, s2n));
       erase_edge(g, nbd, mirror_of(ob, o2n));
     }
+    CCOUNT(12);
     absorbed[ob] = 1;
   }
+}
+
+// is_potential_buddy with the far neighbour reported (same tests, same order)
+__device__ bool is_potential_buddy_f2(const Win& g, u32 src, u32 conn, u32* f2node) {
+  u32 const nb = conn >> 2;
+  *f2node = kNoNode;
+  if (g.nedge[src] == 1 && g.nedge[nb] == 1) {
+    if ((g.edge[src * kEdgeCap] >> 2) == nb && (g.edge[nb * kEdgeCap] >> 2) == src) return false;
+  }
+  if (g.nedge[nb] > 2 || g.nedge[nb] == 0 || has_self_loop(g, nb)) return false;
+  u32 const expected = mirror_of(src, conn);
+  u32 const exp_src_minus = (expected >> 1) & 1u;
+  bool const dir_dflt = (exp_src_minus == 0u) == (g.sign[nb] != 0);
+  u32 f = 0;
+  int const c1 = edges_in_dir(g, nb, dir_dflt, &f);
+  if (c1 != 1 || f != expected) return false;
+  u32 f2 = 0;
+  int const c2 = edges_in_dir(g, nb, !dir_dflt, &f2);
+  if (c2 != 1 || (f2 >> 2) == src) return false;
+  *f2node = f2 >> 2;
+  return g.nedge[f2 >> 2] <= 2;
+}
+
+// CompressNode for the regular case -- a walk down a chain of degree-2 nodes -- with the absorbing
+// node and the next candidate held in registers: one batch of independent loads per merge instead of
+// ~60 dependent ones.  It only ever takes POSITIVE decisions (the exact find_compressible_edge /
+// is_potential_buddy predicates evaluated on register copies of what memory holds); as soon as a test
+// fails or anything unusual shows up (node coincidences of a cycle, duplicate edges) it writes its
+// state back and hands over to the generic compress_node, which re-evaluates from memory.
+__device__ void compress_node_fast(Win& g, u32 nid, bool dflt, u8* absorbed) {
+  // NOTE: no dynamically indexed local arrays in here -- they would live in scratch (HBM latency)
+  if (static_cast<i64>(nid) == g.source || static_cast<i64>(nid) == g.sink) return;
+  u32 xn = g.nedge[nid];
+  if (xn > 2 || xn == 0) return;
+  u32 const K1 = static_cast<u32>(g.k) - 1;
+  int const S = g.S;
+  u32 xe0, xe1;
+  {
+    uint2 const ev = *reinterpret_cast<const uint2*>(g.edge + static_cast<size_t>(nid) * kEdgeCap);
+    xe0 = ev.x;
+    xe1 = ev.y;
+  }
+  u32 const xsign = g.sign[nid];
+  u32 const exp_minus = dflt ? (xsign ? 0u : 1u) : (xsign ? 1u : 0u);
+  bool dirty = false, xloaded = false;
+  u32 xlen = 0, xlabel = 0, xhead = 0, xtail = 0;
+  u32 xcnt[kMaxSamples], xrole0 = 0, xrole1 = 0;
+#pragma unroll
+  for (int t = 0; t < kMaxSamples; ++t) xcnt[t] = 0;
+  // opposite side: buddy test cached per edge value (its inputs do not change while we walk the other way)
+  bool opp_known = false, opp_ok = false;
+  u32 opp_val = 0, opp_nb = kNoNode, opp_f2 = kNoNode;
+  auto flush = [&]() {
+    if (!dirty) return;
+    g.nedge[nid] = static_cast<u8>(xn);
+    g.edge[static_cast<size_t>(nid) * kEdgeCap] = xe0;
+    g.edge[static_cast<size_t>(nid) * kEdgeCap + 1] = xe1;
+    if (xloaded) {
+      g.len[nid] = xlen;
+      g.label[nid] = static_cast<u8>(xlabel);
+#pragma unroll
+      for (int t = 0; t < kMaxSamples; ++t)
+        if (t < S) g.cnt[nid * S + t] = xcnt[t];
+      g.role[nid * 2] = xrole0;
+      g.role[nid * 2 + 1] = xrole1;
+      g.head[nid] = xhead;
+      g.tail[nid] = xtail;
+    }
+    dirty = false;
+  };
+  // carried record of the next candidate (what memory holds for it right now)
+  bool have_b = false;
+  u32 b_id = 0, bn = 0, be0 = 0, be1 = 0, bsign = 0;
+  while (true) {
+    // ---- find_compressible_edge(nid, dflt) on the register copy ----
+    if (xn > 2 || xn == 0) break;
+    if ((xe0 >> 2) == nid || (xn == 2 && (xe1 >> 2) == nid)) break;
+    bool const d0 = ((xe0 >> 1) & 1u) == exp_minus;
+    bool const d1 = xn == 2 && ((xe1 >> 1) & 1u) == exp_minus;
+    int const cdir = (d0 ? 1 : 0) + (d1 ? 1 : 0);
+    int const copp = static_cast<int>(xn) - cdir;
+    if (cdir != 1) break;
+    u32 const cand = d0 ? xe0 : xe1;
+    u32 const opp = d0 ? xe1 : xe0;  // only meaningful when copp == 1
+    u32 const d = cand >> 2;
+    if (static_cast<i64>(d) == g.source || static_cast<i64>(d) == g.sink) break;
+    if (!have_b || b_id != d) {
+      bn = g.nedge[d];
+      uint2 const ev = *reinterpret_cast<const uint2*>(g.edge + static_cast<size_t>(d) * kEdgeCap);
+      be0 = ev.x;
+      be1 = ev.y;
+      bsign = g.sign[d];
+      b_id = d;
+      have_b = true;
+    }
+    // merge operands of b: independent of the tests below, issued with them
+    u32 const blen = g.len[d], blabel = g.label[d], bhead = g.head[d], btail = g.tail[d];
+    u32 bcnt[kMaxSamples];
+#pragma unroll
+    for (int t = 0; t < kMaxSamples; ++t) bcnt[t] = t < S ? g.cnt[d * S + t] : 0u;
+    u32 const brole0 = g.role[d * 2], brole1 = g.role[d * 2 + 1];
+    u32 const bdesc = g.sdesc[bhead == kNoNode ? d : bhead];
+    // ---- is_potential_buddy(nid, cand) ----
+    if (xn == 1 && bn == 1 && (xe0 >> 2) == d && (be0 >> 2) == nid) break;
+    if (bn > 2 || bn == 0) break;
+    if ((be0 >> 2) == d || (bn == 2 && (be1 >> 2) == d)) break;
+    u32 const expected = mirror_of(nid, cand);
+    u32 const exp_src_minus = (expected >> 1) & 1u;
+    bool const dir_dflt = (exp_src_minus == 0u) == (bsign != 0);
+    u32 const b_exp_minus = dir_dflt ? (bsign ? 0u : 1u) : (bsign ? 1u : 0u);
+    bool const m0 = ((be0 >> 1) & 1u) == b_exp_minus;
+    bool const m1 = bn == 2 && ((be1 >> 1) & 1u) == b_exp_minus;
+    int const c1 = (m0 ? 1 : 0) + (m1 ? 1 : 0);
+    int const c2 = static_cast<int>(bn) - c1;
+    if (c1 != 1 || c2 != 1) break;
+    u32 const f = m0 ? be0 : be1;
+    u32 const f2 = m0 ? be1 : be0;
+    if (f != expected) break;
+    if ((f2 >> 2) == nid) break;
+    u32 const fn = f2 >> 2;
+    u32 fnn = g.nedge[fn];
+    if (fnn > 2) break;
+    u32 fe0, fe1, fe2 = 0;
+    {
+      uint2 const ev = *reinterpret_cast<const uint2*>(g.edge + static_cast<size_t>(fn) * kEdgeCap);
+      fe0 = ev.x;
+      fe1 = ev.y;
+    }
+    u32 const fsign = g.sign[fn];
+    // ---- opposite side of nid ----
+    if (copp > 1) break;
+    if (copp == 1) {
+      if (!opp_known || opp_val != opp) {
+        flush();
+        opp_ok = is_potential_buddy_f2(g, nid, opp, &opp_f2);
+        opp_known = true;
+        opp_val = opp;
+        opp_nb = opp >> 2;
+      }
+      if (!opp_ok) break;
+      // a cycle folding back onto the opposite side: let the generic code sort it out
+      if (d == opp_nb || fn == opp_nb || d == opp_f2 || fn == opp_f2) break;
+    }
+    if (fn == d || fnn == 0) break;  // cannot happen on a consistent graph
+    // ---- Node::Merge(b, kind) + Kmer::Merge ----
+    if (!xloaded) {
+      xlen = g.len[nid];
+      xlabel = g.label[nid];
+#pragma unroll
+      for (int t = 0; t < kMaxSamples; ++t) xcnt[t] = t < S ? g.cnt[nid * S + t] : 0u;
+      xrole0 = g.role[nid * 2];
+      xrole1 = g.role[nid * 2 + 1];
+      xhead = g.head[nid];
+      xtail = g.tail[nid];
+      xloaded = true;
+    }
+    u32 const ob = d, kind = cand & 3u;
+    bool const append = kind == 0 || kind == 1;
+    bool const rc = kind == 1 || kind == 2;
+    if (bhead != kNoNode && bhead == btail) {  // single slice: everything in registers
+      u32 st = bdesc & 0xFFu, ln = (bdesc >> 8) & 0xFFu, rcb = (bdesc >> 16) & 1u;
+      if (rc) {
+        st = static_cast<u32>(g.k) - st - ln;
+        rcb ^= 1u;
+      }
+      u32 const s = bhead;
+      if (ln > K1) {
+        if (append) st += K1;
+        ln -= K1;
+        g.sdesc[s] = st | (ln << 8) | (rcb << 16);
+        if (append) {
+          g.snext[xtail] = s;
+          g.sprev[s] = xtail;
+          g.snext[s] = kNoNode;
+          xtail = s;
+        } else {
+          g.sprev[xhead] = s;
+          g.snext[s] = xhead;
+          g.sprev[s] = kNoNode;
+          xhead = s;
+        }
+      }
+    } else {
+      g.head[nid] = xhead;
+      g.tail[nid] = xtail;
+      if (rc) slices_reverse(g, ob);
+      if (append) {
+        slices_drop_front(g, ob, K1);
+        if (g.head[ob] != kNoNode) {
+          g.snext[g.tail[nid]] = g.head[ob];
+          g.sprev[g.head[ob]] = g.tail[nid];
+          g.tail[nid] = g.tail[ob];
+        }
+      } else {
+        slices_drop_back(g, ob, K1);
+        if (g.head[ob] != kNoNode) {
+          g.sprev[g.head[nid]] = g.tail[ob];
+          g.snext[g.tail[ob]] = g.head[nid];
+          g.head[nid] = g.head[ob];
+        }
+      }
+      xhead = g.head[nid];
+      xtail = g.tail[nid];
+    }
+    g.head[ob] = kNoNode;
+    g.tail[ob] = kNoNode;
+    xlen += blen - K1;
+    xlabel |= blabel;
+    {
+      u64 const this_len = xlen, other_len = blen, total_len = this_len + other_len;  // node.cpp:91
+#pragma unroll
+      for (int t = 0; t < kMaxSamples; ++t)
+        if (t < S)
+          xcnt[t] = static_cast<u32>((static_cast<u64>(xcnt[t]) * this_len + static_cast<u64>(bcnt[t]) * other_len) / total_len);
+      xrole0 = static_cast<u32>((static_cast<u64>(xrole0) * this_len + static_cast<u64>(brole0) * other_len) / total_len);
+      xrole1 = static_cast<u32>((static_cast<u64>(xrole1) * this_len + static_cast<u64>(brole1) * other_len) / total_len);
+    }
+    // ---- edges (graph.cpp:600-645) ----
+    if (xe0 == cand) xe0 = xe1;  // erase_edge(nid, cand)
+    xe1 = 0;
+    xn--;
+    u32 const src_minus = (kind >> 1) & 1u, dst_minus = kind & 1u;
+    u32 const o2n = f2;
+    u32 const o2n_src_minus = (o2n >> 1) & 1u, o2n_dst_minus = o2n & 1u;
+    u32 const ne_src_minus = (dst_minus != o2n_src_minus) ? (src_minus ^ 1u) : src_minus;
+    u32 const s2n = (fn << 2) | (ne_src_minus << 1) | o2n_dst_minus;
+    // emplace_edge(nid, s2n): xn is 0 or 1 here
+    if (!(xn == 1 && xe0 == s2n)) {
+      if (xn == 0) xe0 = s2n; else xe1 = s2n;
+      xn++;
+    }
+    {  // emplace_edge(fn, mirror(nid, s2n)); erase_edge(fn, mirror(ob, o2n))
+      u32 const add = mirror_of(nid, s2n), del = mirror_of(ob, o2n);
+      bool const present = (fnn >= 1 && fe0 == add) || (fnn >= 2 && fe1 == add);
+      if (!present) {
+        if (fnn == 0) fe0 = add; else if (fnn == 1) fe1 = add; else fe2 = add;
+        fnn++;
+      }
+      if (fnn >= 1 && fe0 == del) {
+        fe0 = fe1;
+        fe1 = fe2;
+        fe2 = 0;
+        fnn--;
+      } else if (fnn >= 2 && fe1 == del) {
+        fe1 = fe2;
+        fe2 = 0;
+        fnn--;
+      } else if (fnn >= 3 && fe2 == del) {
+        fe2 = 0;
+        fnn--;
+      }
+      g.nedge[fn] = static_cast<u8>(fnn);
+      g.edge[static_cast<size_t>(fn) * kEdgeCap] = fe0;
+      g.edge[static_cast<size_t>(fn) * kEdgeCap + 1] = fe1;
+      if (fnn > 2) g.edge[static_cast<size_t>(fn) * kEdgeCap + 2] = fe2;
+    }
+    CCOUNT(11);
+    absorbed[ob] = 2;  // absorbed by the register walk: nothing points at it any more
+    dirty = true;
+    // the far neighbour is the next candidate
+    b_id = fn;
+    bn = fnn;
+    be0 = fe0;
+    be1 = fe1;
+    bsign = fsign;
+    have_b = fnn <= 2;
+  }
+  flush();
+  compress_node(g, nid, dflt, absorbed);  // re-evaluates from memory: finishes the walk or stops it
 }
 
 // CompressGraph (graph.cpp:558-576)
@@ -304,11 +581,19 @@ __device__ void compress_graph(Win& g, u32 comp) {
   for (u32 i = 0; i < g.n; ++i) absorbed[i] = 0;
   for (u32 i = 0; i < g.n; ++i) {
     if (!g.alive[i] || g.comp[i] != comp || absorbed[i]) continue;
-    compress_node(g, i, true, absorbed);
-    compress_node(g, i, false, absorbed);
+    compress_node_fast(g, i, true, absorbed);
+    compress_node_fast(g, i, false, absorbed);
   }
-  for (u32 i = 0; i < g.n; ++i)
-    if (absorbed[i]) remove_node(g, i);
+  for (u32 i = 0; i < g.n; ++i) {
+    if (absorbed[i] == 2) {
+      // remove_node would only look for mirror edges that the walk has already erased (no edge to an
+      // absorbed node is ever created again: rewired edges point at absorbers)
+      g.alive[i] = 0;
+      g.nedge[i] = 0;
+    } else if (absorbed[i]) {
+      remove_node(g, i);
+    }
+  }
 }
 
 // RemoveTips (graph.cpp:801-840)
@@ -411,6 +696,29 @@ __device__ u32 median_sorted(const u32* v, u32 n) {  // compute_stats.h:146-159 
 
 }  // namespace
 
+#ifdef MA_PROFILE
+#define CPROF_T0() unsigned long long _t0 = __builtin_amdgcn_s_memtime()
+#define CPROF_ACC(slot)                                                       \
+  do {                                                                        \
+    unsigned long long _t1 = __builtin_amdgcn_s_memtime();                    \
+    atomicAdd(&g_cprof[slot], _t1 - _t0);                                     \
+    _t0 = _t1;                                                                \
+  } while (0)
+extern "C" void ma_debug_cwin(unsigned long long* out, int n) {
+  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_cwin), sizeof(unsigned long long) * 4 * n);
+}
+extern "C" void ma_debug_cprof(unsigned long long* out, int reset) {
+  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_cprof), sizeof(unsigned long long) * 16);
+  if (reset) {
+    unsigned long long z[16] = {0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_cprof), z, sizeof(z));
+  }
+}
+#else
+#define CPROF_T0() do {} while (0)
+#define CPROF_ACC(slot) do {} while (0)
+#endif
+
 struct CleanArgs {
   DBatch b;
   GraphWs ws;
@@ -418,7 +726,7 @@ struct CleanArgs {
   ma_params_t prm;
 };
 
-__global__ __launch_bounds__(64, 8) void k_clean(CleanArgs A) {
+__global__ __launch_bounds__(64, 4) void k_clean(CleanArgs A) {
   if (threadIdx.x != 0) return;  // canonical serial order: lane 0 drives the window
   int const a = blockIdx.x;
   GraphWs const& ws = A.ws;
@@ -464,6 +772,10 @@ __global__ __launch_bounds__(64, 8) void k_clean(CleanArgs A) {
   g.flags = 0;
   u32 const NC = ws.nc;
   u32 const K = static_cast<u32>(g.k);
+  CPROF_T0();
+#ifdef MA_PROFILE
+  unsigned long long const t_begin = __builtin_amdgcn_s_memtime();
+#endif
 
   for (u32 i = 0; i < g.n; ++i) {
     g.comp[i] = 0;
@@ -474,6 +786,7 @@ __global__ __launch_bounds__(64, 8) void k_clean(CleanArgs A) {
     g.sdesc[i] = 0u | (K << 8);
   }
 
+  CPROF_ACC(0);
   // ---- MarkConnectedComponents (graph.cpp:392-463): ids in discovery order over canonical order ----
   u32 ncomp_all = 0;
   {
@@ -496,6 +809,7 @@ __global__ __launch_bounds__(64, 8) void k_clean(CleanArgs A) {
       }
     }
   }
+  CPROF_ACC(1);
   // component sizes + anchors in one pass (FindSource / FindSink, graph.cpp:469-509): components are
   // disjoint and pruning one never touches another, so the candidates can be resolved up front.
   // Candidate = component with source != sink and ref anchor length >= min_anchor_len.
@@ -560,6 +874,7 @@ __global__ __launch_bounds__(64, 8) void k_clean(CleanArgs A) {
   u32 status = 0;
   u32 ncomp_out = 0, slot = 0;
   bool retry = false;
+  CPROF_ACC(2);
 
   for (int ci = 0; ci < ncand && !retry; ++ci) {
     u32 const comp = cand_comp[ci];
@@ -570,9 +885,13 @@ __global__ __launch_bounds__(64, 8) void k_clean(CleanArgs A) {
 
     // ---- PruneComponent (graph.cpp:515-540) ----
     compress_graph(g, comp);
+    CPROF_ACC(3);
     remove_low_cov(g, comp);
+    CPROF_ACC(4);
     compress_graph(g, comp);
+    CPROF_ACC(5);
     remove_tips(g, comp);
+    CPROF_ACC(6);
     if (g.flags & 4u) break;
 
     // ---- BuildTraversalIndex (traversal_index.cpp:34-119) ----
@@ -638,6 +957,7 @@ __global__ __launch_bounds__(64, 8) void k_clean(CleanArgs A) {
     u32 const src_state = flat_of[g.source] * 2 + (g.sign[g.source] ? 0u : 1u);
     u32 const snk_flat = flat_of[g.sink];
 
+    CPROF_ACC(7);
     // ---- HasCycle (cycle_finder.cpp:55-100) ----
     {
       for (u32 s = 0; s < 2 * V; ++s) color[s] = 0;
@@ -706,6 +1026,7 @@ __global__ __launch_bounds__(64, 8) void k_clean(CleanArgs A) {
       break;
     }
 
+    CPROF_ACC(8);
     // ---- BuildHaplotypes: MaxFlow::NextPath loop (max_flow.cpp:162-280, graph.cpp:846-891) ----
     for (u32 e = 0; e < E; ++e) traversed[e] = 0;
     uint4* arena = ws.arena + static_cast<size_t>(a) * ws.ac;
@@ -792,6 +1113,7 @@ __global__ __launch_bounds__(64, 8) void k_clean(CleanArgs A) {
       nwalks++;
       walk_pool_used += wl;
     }
+    CPROF_ACC(9);
     if (arena_over) status |= MA_W_TABLE_OVERFLOW;
     if (hit_limit) status |= MA_W_BFS_LIMIT;
     if (nwalks == 0) continue;  // graph.cpp:225
@@ -913,6 +1235,7 @@ __global__ __launch_bounds__(64, 8) void k_clean(CleanArgs A) {
       has_alt = true;
       slot++;
     }
+    CPROF_ACC(10);
     A.out.comp_anchor[cidx] = cand_soff[ci];
     A.out.comp_hap0[cidx] = hap0;
     A.out.comp_nhaps[cidx] = slot - hap0;
@@ -937,6 +1260,14 @@ __global__ __launch_bounds__(64, 8) void k_clean(CleanArgs A) {
     A.out.win_status[w] = MA_W_NO_HAPLOTYPE;
     return;
   }
+#ifdef MA_PROFILE
+  if (w < 4096) {
+    g_cwin[w * 4 + 0] = __builtin_amdgcn_s_memtime() - t_begin;
+    g_cwin[w * 4 + 1] = g.n;
+    g_cwin[w * 4 + 2] = ncomp_all;
+    g_cwin[w * 4 + 3] = static_cast<unsigned long long>(ncand);
+  }
+#endif
   u32 nalt = 0;
   for (u32 c = 0; c < ncomp_out; ++c) nalt += A.out.comp_nhaps[static_cast<size_t>(w) * MC + c] - 1;
   if (nalt == 0) status |= MA_W_NO_HAPLOTYPE;  // variant_builder.cpp:231-240
