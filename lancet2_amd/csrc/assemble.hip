@@ -2,6 +2,7 @@
 // the k-cascade loop runs on the host, each attempt launching the build passes (build.hip) and the
 // cleaning/enumeration kernel (clean.hip) for the windows that are still unresolved at that k.
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 
 #include "graph_ws.h"
@@ -144,16 +145,13 @@ int launch_assemble(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& out, const
     carve_ws(probe, tmp, 1);
   }
   size_t const per_window = probe.off + 4096;
-  size_t budget = size_t(24) << 30;
-  {
-    size_t free_b = 0, total_b = 0;  // size the in-flight window count for the GPU's HBM (288 GB on MI355X)
-    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
-      budget = static_cast<size_t>(static_cast<double>(free_b + ctx->ws_build.cap) * 0.35);
-    }
-  }
+  size_t budget = stage_budget(0.30, ctx->ws_build.cap, size_t(24) << 30);
   if (const char* e = getenv("MA_WS_GB")) budget = static_cast<size_t>(atoi(e)) << 30;
   int chunk = static_cast<int>(std::max<size_t>(1, std::min<size_t>(n, budget / per_window)));
   MA_HIP(ctx, ctx->ws_build.reserve(per_window * static_cast<size_t>(chunk)));
+  if (getenv("MA_VERBOSE"))
+    fprintf(stderr, "[microasm] assemble: %d windows, %.2f MB/window, budget %.1f GB -> chunks of %d (nc %u, tc_log2 %d)\n", n,
+            per_window / 1048576.0, budget / 1073741824.0, chunk, ws.nc, ws.tc_log2);
 
   for (int win0 = 0; win0 < n; win0 += chunk) {
     int const nwin = std::min(chunk, n - win0);

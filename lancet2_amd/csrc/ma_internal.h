@@ -113,6 +113,19 @@ int launch_msa(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& a, const ma_var
 int launch_genotype(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& a, const ma_var_out_t& v,
                     const ma_geno_out_t& o);
 
+// Workspace budget of one stage: a fixed share of the device's HBM (288 GB on MI355X), so that the
+// chunking does not depend on the order in which the stages first allocated, capped by what is free now
+// (the stage's own buffer counts as free: it is reused).
+inline size_t stage_budget(double share_of_total, size_t own_cap, size_t fallback) {
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return fallback;
+  size_t const want = static_cast<size_t>(static_cast<double>(total_b) * share_of_total);
+  size_t const avail = free_b + own_cap;
+  size_t const guard = size_t(2) << 30;
+  size_t const cap = avail > guard ? avail - guard : avail / 2;
+  return want < cap ? want : cap;
+}
+
 // Branch-free on purpose: a `switch` over the base compiles to a tree of divergent branches per byte.
 //   'A' 0x41  'C' 0x43  'G' 0x47  'T' 0x54: bit 1 separates {A,T} from {C,G}; A^T = 0x15, C^G = 0x04.
 constexpr u32 kAcgtBits = (1u << ('A' - 'A')) | (1u << ('C' - 'A')) | (1u << ('G' - 'A')) | (1u << ('T' - 'A'));

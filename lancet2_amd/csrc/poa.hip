@@ -27,6 +27,7 @@
 // Edge weights are not tracked: the reference only reads topology, labels and ranks from the POA
 // graph (variant_extractor.cpp:47-58, :84-94, :159-181).
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <vector>
 
@@ -1650,15 +1651,13 @@ int launch_msa(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& a, const ma_var
   ws.row_cells = static_cast<size_t>(ws.row_slots) * 3 * ws.w_stride;
 
   size_t const per_window = ws.code_cells * 2 + ws.row_cells * 4 + (static_cast<size_t>(pn) + 8) * 4;
-  size_t budget = size_t(24) << 30;
-  {
-    size_t free_b = 0, total_b = 0;  // size the in-flight window count for the GPU's HBM (288 GB on MI355X)
-    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
-      budget = static_cast<size_t>(static_cast<double>(free_b + ctx->ws_poa.cap) * 0.55);
-  }
+  size_t budget = stage_budget(0.30, ctx->ws_poa.cap, size_t(24) << 30);
   if (const char* e = getenv("MA_WS_GB")) budget = static_cast<size_t>(atoi(e)) << 30;
   int const chunk = static_cast<int>(std::max<size_t>(1, std::min<size_t>(n, budget / per_window)));
   MA_HIP(ctx, ctx->ws_poa.reserve(per_window * static_cast<size_t>(chunk) + 1024));
+  if (getenv("MA_VERBOSE"))
+    fprintf(stderr, "[microasm] msa: %d windows, %.2f MB/window, budget %.1f GB -> chunks of %d (pn %u, max_len %u, lds %zu)\n", n,
+            per_window / 1048576.0, budget / 1073741824.0, chunk, pn, max_len, lds);
   auto kern = max_len <= 1024 ? k_msa<4> : (max_len <= 2048 ? k_msa<8> : k_msa<16>);
   MA_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   static_cast<int>(lds)));
