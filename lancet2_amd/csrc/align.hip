@@ -366,6 +366,15 @@ __device__ __forceinline__ void vote_pair(GArgs const& A, u64 lp, PairId id, Hap
     } else {
       A.ws.centre[lp] = c;
       A.ws.dp_list[atomicAdd(A.ws.dp_count, 1u)] = static_cast<u32>(lp);
+#ifdef MA_PROFILE
+      // why did the certificate fail?  8: overhang  9: ambiguous  10: > 2 mismatches  11: vote bound  12: low score
+      int const why = !inside ? 8 : (amb ? 9 : (mism > 2 ? 10 : (static_cast<i32>(v2) + 10 + 11 * static_cast<i32>(mism) >= m ? 11 : 12)));
+      atomicAdd(&g_vprof[why], 1ull);
+      if (!inside) {
+        i32 const o = (c < 0 ? -c : 0) + (c + m > n ? c + m - n : 0);
+        atomicAdd(&g_vprof[13], static_cast<unsigned long long>(o));
+      }
+#endif
     }
   }
   VPROF_ACC(6);

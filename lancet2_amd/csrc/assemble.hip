@@ -84,11 +84,13 @@ int launch_assemble(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& out, const
   // capacity planning: instance maxima at the smallest k (the largest instance counts)
   ws.k = P.min_k;
   MA_TRY_RC(run_count_inst(ctx, b, ws, 0, n, counters));
-  u32 maxima[4] = {0, 0, 0, 0};
-  MA_HIP(ctx, hipMemcpyAsync(maxima, counters, 16, hipMemcpyDeviceToHost, ctx->stream));
+  u32 maxima[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  MA_HIP(ctx, hipMemcpyAsync(maxima, counters, 32, hipMemcpyDeviceToHost, ctx->stream));
   MA_HIP(ctx, hipStreamSynchronize(ctx->stream));
   u32 const max_inst = std::max<u32>(maxima[0], 1), max_read_inst = std::max<u32>(maxima[1], 1);
   u32 const max_refk = std::max<u32>(maxima[2], 1);
+  ws.max_reads = std::max<u32>(maxima[3], 1);
+  ws.max_read_len = std::max<u32>(maxima[4], 1);
 
   ws.tc_log2 = std::max(10, ceil_log2(static_cast<u64>(max_inst) * 4 / 3 + 16));
   ws.mc_log2 = std::max(10, ceil_log2(static_cast<u64>(max_read_inst) * 4 / 3 + 16));

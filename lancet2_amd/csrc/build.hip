@@ -75,11 +75,15 @@ __global__ __launch_bounds__(kBT) void k_count_inst(DBatch b, GraphWs ws, int wi
   if (blockIdx.x >= static_cast<u32>(nwin)) return;
   u32 const ns = seq_count(b, w);
   u32 const base_idx = b.read_win_off[w] + w;
-  u32 running = 0, read_inst = 0;
+  u32 running = 0, read_inst = 0, max_len = 0;
   for (u32 s0 = 0; s0 < ns; s0 += kBT) {
     u32 const s = s0 + threadIdx.x;
     u32 nk = 0;
-    if (s < ns) nk = seq_info(b, w, s, ws.k).nk;
+    if (s < ns) {
+      SeqInfo const si = seq_info(b, w, s, ws.k);
+      nk = si.nk;
+      if (s > 0) max_len = max(max_len, si.len);
+    }
     u32 tot;
     u32 const ex = block_excl_scan(nk, sh, &tot);
     if (s < ns) ws.seq_inst_base[base_idx + s] = running + ex;
@@ -96,7 +100,9 @@ __global__ __launch_bounds__(kBT) void k_count_inst(DBatch b, GraphWs ws, int wi
     atomicMax(&maxima[0], running);
     atomicMax(&maxima[1], read_inst);
     atomicMax(&maxima[2], refk);
+    atomicMax(&maxima[3], ns - 1);
   }
+  if (max_len) atomicMax(&maxima[4], max_len);
 }
 
 // ---- choose the windows that attempt this k (graph.cpp:106-120) ----
@@ -111,6 +117,24 @@ __global__ void k_select_active(GraphWs ws, int win0, int nwin, const u32* gate_
   if (gate_approx[w] >= static_cast<u32>(ws.k)) return;  // HasExactOrApproxRepeat -> continue
   u32 const a = atomicAdd(n_active, 1u);
   active[a] = static_cast<u32>(w);
+}
+
+// instance index -> sequence: the largest s with base[s] <= ii (sequences without k-mers share the base of
+// their successor, so the last one of an equal run is the one that owns the instance)
+constexpr u32 kSeqCap = 2048;  // sequences whose instance bases are cached in LDS
+__device__ __forceinline__ u32 seq_of(const u32* base, u32 ns, u32 ii) {
+  u32 lo = 0, hi = ns;
+  while (hi - lo > 1) {
+    u32 const mid = (lo + hi) >> 1;
+    if (base[mid] <= ii) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+// stage the window's per-sequence instance bases in LDS when they fit (callers __syncthreads afterwards)
+__device__ __forceinline__ const u32* stage_seq_bases(const u32* gbase, u32 ns, u32* l_base) {
+  if (ns > kSeqCap) return gbase;
+  for (u32 s = threadIdx.x; s < ns; s += blockDim.x) l_base[s] = gbase[s];
+  return l_base;
 }
 
 __device__ __forceinline__ u32 table_insert(u64* keys, u32 mask, u64 id) {
@@ -192,74 +216,149 @@ __device__ __forceinline__ bool same_group(const DBatch& b, u32 ra, u32 rb) {
          ((b.read_flags[ra] ^ b.read_flags[rb]) & MA_RF_CASE) == 0 && b.read_sample[ra] == b.read_sample[rb];
 }
 
-// (1) k_classify: every read instance is classified WITHOUT touching the hash table.  All lanes run the same
-//     cheap loop (rolling reference-mismatch count + lagged f64 Phred prefix sums); instances that need the
-//     general path are appended to the window's slow queue so that k_insert can hash them with full lanes.
-__global__ __launch_bounds__(kBT) void k_classify(DBatch b, GraphWs ws, u32* max_slow) {
+// (1) k_classify: every read instance is classified WITHOUT touching the hash table.  One wavefront per tile
+//     of 64 consecutive reads (one read per lane: the f64 Phred prefix sums are a serial chain per read).
+//     The tile's bases and qualities are contiguous in the batch, so they are staged in LDS with coalesced
+//     loads -- a lane walking its read byte by byte straight from HBM costs one cache-line fetch per byte
+//     once thousands of lanes do it (measured: ~180x read amplification).  Instances that need the general
+//     path are remembered in a per-lane bitmask and appended to the window's slow queue at the end with
+//     one atomic per wave, so that k_insert can hash them with full lanes.
+__global__ __launch_bounds__(64) void k_classify(DBatch b, GraphWs ws, u32* max_slow, u32 tiles_per_win, u32 tile_cap) {
   extern __shared__ unsigned char lds_build[];
-  __shared__ u32 n_slow_sh;
-  int const a = blockIdx.x;
+  int const a = blockIdx.x / tiles_per_win;
+  u32 const tile = blockIdx.x % tiles_per_win;
   int const w = static_cast<int>(ws.active[a]);
   int const k = ws.k;
+  int const lane = threadIdx.x;
+  u32 const ns = seq_count(b, w);
+  u32 const nreads = ns - 1;
+  if (tile * 64 >= nreads) return;
+  u32 const cnt = min(64u, nreads - tile * 64);
   u32* inst_slot = ws.inst_slot + static_cast<size_t>(a) * ws.inst_stride;
   u32* slowq = ws.slowq + static_cast<size_t>(a) * ws.inst_stride;
-  u32 const ns = seq_count(b, w);
   u32 const base_idx = b.read_win_off[w] + w;
-  const f64* phred = reinterpret_cast<const f64*>(c_phred_bits);
+  // LDS carve
+  u32 const ref_cap = (ws.max_ref_len + 8 + 15) & ~15u;
   u8* l_ref = lds_build;
+  f64* l_phred = reinterpret_cast<f64*>(lds_build + ref_cap);
+  u8* l_bases = lds_build + ref_cap + 2048;
+  u8* l_quals = l_bases + tile_cap;
+  u32* l_mask = reinterpret_cast<u32*>(l_quals + tile_cap);  // [kMaskWords][64]
   SeqInfo const rsi = seq_info(b, w, 0, k);
   i32 const ref_len = static_cast<i32>(rsi.len);
-  stage_ref(b, rsi, l_ref, ws.max_ref_len + 8);
-  if (threadIdx.x == 0) n_slow_sh = 0;
+  {
+    const u8* s = b.ref_bases + rsi.off;
+    for (u32 i = lane; i < rsi.len && i < ws.max_ref_len + 8; i += 64) l_ref[i] = s[i];
+  }
+  for (u32 i = lane; i < 256; i += 64) reinterpret_cast<u64*>(l_phred)[i] = c_phred_bits[i];
+  u32 const r0 = b.read_win_off[w] + tile * 64;
+  u64 const byte0 = b.read_off[r0], byte1 = b.read_off[r0 + cnt];
+  u64 const al0 = byte0 & ~static_cast<u64>(3);
+  u64 const total_end = b.read_off[b.n_reads];
+  {
+    // 4-byte aligned coalesced copy; the last word is read byte-wise if it would cross the end of the batch
+    u64 const nwords = (byte1 - al0 + 3) >> 2;
+    for (u64 x = lane; x < nwords; x += 64) {
+      u64 const at = al0 + 4 * x;
+      u32 vb, vq;
+      if (at + 4 <= total_end) {
+        vb = *reinterpret_cast<const u32*>(b.read_bases + at);
+        vq = *reinterpret_cast<const u32*>(b.read_quals + at);
+      } else {
+        vb = vq = 0;
+        for (u64 y = 0; at + y < total_end; ++y) {
+          vb |= static_cast<u32>(b.read_bases[at + y]) << (8 * y);
+          vq |= static_cast<u32>(b.read_quals[at + y]) << (8 * y);
+        }
+      }
+      if (4 * x + 4 <= tile_cap) {
+        reinterpret_cast<u32*>(l_bases)[x] = vb;
+        reinterpret_cast<u32*>(l_quals)[x] = vq;
+      }
+    }
+  }
+  for (int mw = 0; mw < kMaskWords; ++mw) l_mask[mw * 64 + lane] = 0;
   __syncthreads();
   bool const hints = b.read_hint != nullptr && rsi.len <= ws.max_ref_len + 8;
-  for (u32 s_idx = 1 + threadIdx.x; s_idx < ns; s_idx += kBT) {
+  u32 nslow = 0;
+  bool all_slow = false;
+  u32 s_idx = 0, my_nk = 0;
+  if (lane < static_cast<int>(cnt)) {
+    s_idx = 1 + tile * 64 + lane;
     SeqInfo const si = seq_info(b, w, s_idx, k);
-    u32 const r = b.read_win_off[w] + s_idx - 1;
+    u32 const r = r0 + lane;
     ws.rd_flag[r] = 0;
-    if (si.nk == 0) continue;
-    const u8* s = b.read_bases + si.off;
-    const u8* q = b.read_quals + si.off;
-    u32 const ibase = ws.seq_inst_base[base_idx + s_idx];
-    i32 const hint = hints ? b.read_hint[r] : MA_NO_HINT;
-    bool const use_hint = hint != MA_NO_HINT && hint > -100000 && hint < 100000 && si.nk <= 32u * kMaskWords;
-    f64 lead = 0.0, lag = 0.0;  // prefix[o+k] and prefix[o] of graph.cpp:283-285
-    i32 mm = 0;                 // mismatches of read[o, o+k) against ref[hint+o, ...)
-    for (int i = 0; i < k; ++i) {
-      f64 const pe = phred[q[i]];
-      lead = (i == 0) ? pe : lead + pe;
-      i32 const rp = hint + i;
-      mm += (use_hint && rp >= 0 && rp < ref_len && s[i] == l_ref[rp]) ? 0 : 1;
-    }
-    for (u32 o = 0; o < si.nk; ++o) {
-      // floor(prefix[o+k] - prefix[o]) == 0  <=>  difference < 1.0 (prefix is non-decreasing)
-      bool const errfree = (lead - lag) < 1.0;
-      u32 word;
-      if (use_hint && mm == 0) {  // FAST: byte-identical to the reference k-mer at hint + o
-        word = static_cast<u32>(hint + static_cast<i32>(o)) | kInstFast | (errfree ? kInstErrFree : 0u);
-      } else {
-        word = kInstSlotMask | (errfree ? kInstErrFree : 0u);  // slot filled in by k_insert
-        u32 const qi = atomicAdd(&n_slow_sh, 1u);
-        slowq[qi] = (s_idx << 12) | o;
+    u64 const rel = si.off - al0;
+    bool const fits = rel + si.len <= tile_cap;  // always true: tile_cap covers 64 reads of the longest length
+    if (si.nk != 0 && fits) {
+      my_nk = si.nk;
+      const u8* s = l_bases + rel;
+      const u8* q = l_quals + rel;
+      u32 const ibase = ws.seq_inst_base[base_idx + s_idx];
+      i32 const hint = hints ? b.read_hint[r] : MA_NO_HINT;
+      bool const use_hint = hint != MA_NO_HINT && hint > -100000 && hint < 100000 && si.nk <= 32u * kMaskWords;
+      all_slow = !use_hint;
+      f64 lead = 0.0, lag = 0.0;  // prefix[o+k] and prefix[o] of graph.cpp:283-285
+      i32 mm = 0;                 // mismatches of read[o, o+k) against ref[hint+o, ...)
+      for (int i = 0; i < k; ++i) {
+        f64 const pe = l_phred[q[i]];
+        lead = (i == 0) ? pe : lead + pe;
+        i32 const rp = hint + i;
+        mm += (use_hint && rp >= 0 && rp < ref_len && s[i] == l_ref[rp]) ? 0 : 1;
       }
-      inst_slot[ibase + o] = word;
-      if (o + 1 < si.nk) {
-        u8 const b_out = s[o], b_in = s[o + k];
-        f64 const pl = phred[q[o]];
-        lag = (o == 0) ? pl : lag + pl;
-        lead = lead + phred[q[o + k]];
-        if (use_hint) {
-          i32 const rp_out = hint + static_cast<i32>(o), rp_in = hint + static_cast<i32>(o) + k;
-          mm -= (rp_out >= 0 && rp_out < ref_len && b_out == l_ref[rp_out]) ? 0 : 1;
-          mm += (rp_in >= 0 && rp_in < ref_len && b_in == l_ref[rp_in]) ? 0 : 1;
+      for (u32 o = 0; o < si.nk; ++o) {
+        // floor(prefix[o+k] - prefix[o]) == 0  <=>  difference < 1.0 (prefix is non-decreasing)
+        bool const errfree = (lead - lag) < 1.0;
+        u32 word = (errfree ? kInstErrFree : 0u) | (o + 1 == si.nk ? kInstLast : 0u);
+        if (use_hint && mm == 0) {  // FAST: byte-identical to the reference k-mer at hint + o
+          word |= static_cast<u32>(hint + static_cast<i32>(o)) | kInstFast;
+        } else {
+          word |= kInstSlotMask;  // slot filled in by k_insert
+          nslow++;
+          if (use_hint) l_mask[(o >> 5) * 64 + lane] |= 1u << (o & 31);
+        }
+        inst_slot[ibase + o] = word;
+        if (o + 1 < si.nk) {
+          u8 const b_out = s[o], b_in = s[o + k];
+          f64 const pl = l_phred[q[o]];
+          lag = (o == 0) ? pl : lag + pl;
+          lead = lead + l_phred[q[o + k]];
+          if (use_hint) {
+            i32 const rp_out = hint + static_cast<i32>(o), rp_in = hint + static_cast<i32>(o) + k;
+            mm -= (rp_out >= 0 && rp_out < ref_len && b_out == l_ref[rp_out]) ? 0 : 1;
+            mm += (rp_in >= 0 && rp_in < ref_len && b_in == l_ref[rp_in]) ? 0 : 1;
+          }
         }
       }
     }
   }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    ws.n_slow[a] = n_slow_sh;
-    atomicMax(max_slow, n_slow_sh);
+  // append this tile's slow instances to the window's queue: one atomic per wave
+  u32 inc = nslow;
+  for (int d = 1; d < 64; d <<= 1) {
+    u32 const y = __shfl_up(inc, d);
+    if (lane >= d) inc += y;
+  }
+  u32 const wave_total = __shfl(inc, 63);
+  u32 qbase = 0;
+  if (lane == 0 && wave_total) {
+    qbase = atomicAdd(&ws.n_slow[a], wave_total);
+    atomicMax(max_slow, qbase + wave_total);
+  }
+  qbase = __shfl(qbase, 0);
+  u32 at = qbase + inc - nslow;
+  if (nslow) {
+    if (all_slow) {
+      for (u32 o = 0; o < my_nk; ++o) slowq[at++] = (s_idx << 12) | o;
+    } else {
+      for (int mw = 0; mw < kMaskWords; ++mw) {
+        u32 m = l_mask[mw * 64 + lane];
+        while (m) {
+          u32 const bit = __ffs(m) - 1;
+          m &= m - 1;
+          slowq[at++] = (s_idx << 12) | (mw * 32 + bit);
+        }
+      }
+    }
   }
 }
 
@@ -303,7 +402,7 @@ __global__ __launch_bounds__(kBT) void k_insert(DBatch b, GraphWs ws) {
     for (u32 p = threadIdx.x; p < rsi.nk; p += kBT) {
       u32 of;
       u32 const word = hash_insert(s + p, p, &of);
-      inst_slot[p] = word;
+      inst_slot[p] = word | (p + 1 == rsi.nk ? kInstLast : 0u);
       ref_slot_g[p] = word & kInstSlotMask;
     }
   }
@@ -315,10 +414,11 @@ __global__ __launch_bounds__(kBT) void k_insert(DBatch b, GraphWs ws) {
     u32 const s_idx = item >> 12, o = item & 0xFFFu;
     SeqInfo const si = seq_info(b, w, s_idx, k);
     u32 const inst = ws.seq_inst_base[base_idx + s_idx] + o;
-    u32 const errfree = inst_slot[inst] & kInstErrFree;
+    u32 const keep = inst_slot[inst] & (kInstErrFree | kInstLast);
+    u32 const errfree = keep & kInstErrFree;
     u32 of;
     u32 const word = hash_insert(b.read_bases + si.off + o, inst, &of);
-    inst_slot[inst] = word | errfree;
+    inst_slot[inst] = word | keep;
     if (errfree && of < rsi.nk) ws.rd_flag[b.read_win_off[w] + s_idx - 1] = 1;
   }
 }
@@ -732,9 +832,20 @@ int run_build_pass(ma_ctx* ctx, const DBatch& b, GraphWs& ws, u32* counters_dev,
   int const S = ws.num_samples;
   // (1) classify (no table traffic) -> how many k-mers need the table at most
   MA_HIP(ctx, hipMemsetAsync(counters_dev, 0, 4, ctx->stream));
-  size_t const lds_c = ((ws.max_ref_len + 8 + 15) & ~15u) + 64;
+  MA_HIP(ctx, hipMemsetAsync(ws.n_slow, 0, 4 * A, ctx->stream));
+  u32 const tiles_per_win = std::max<u32>(1, (ws.max_reads + 63) / 64);
+  u32 const tile_cap = (64 * ws.max_read_len + 8 + 15) & ~15u;
+  size_t const lds_c = ((ws.max_ref_len + 8 + 15) & ~15u) + 2048 + 2ull * tile_cap + 4ull * kMaskWords * 64 + 64;
+  if (lds_c > 160 * 1024) {
+    ctx->err = "ma_assemble_batch: reads too long for the LDS-staged classifier";
+    return MA_ERR_PARAM;
+  }
+  if (lds_c > 65536)
+    MA_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_classify), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    static_cast<int>(lds_c)));
   ctx->tic("k_classify");
-  hipLaunchKernelGGL(k_classify, dim3(ws.n_active), dim3(kBT), lds_c, ctx->stream, b, ws, counters_dev);
+  hipLaunchKernelGGL(k_classify, dim3(ws.n_active * tiles_per_win), dim3(64), lds_c, ctx->stream, b, ws, counters_dev,
+                     tiles_per_win, tile_cap);
   ctx->toc();
   u32 max_slow = 0;
   MA_HIP(ctx, hipMemcpyAsync(&max_slow, counters_dev, 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -779,7 +890,7 @@ int run_build_pass(ma_ctx* ctx, const DBatch& b, GraphWs& ws, u32* counters_dev,
 }
 
 int run_count_inst(ma_ctx* ctx, const DBatch& b, const GraphWs& ws, int win0, int nwin, u32* maxima_dev) {
-  MA_HIP(ctx, hipMemsetAsync(maxima_dev, 0, 16, ctx->stream));
+  MA_HIP(ctx, hipMemsetAsync(maxima_dev, 0, 32, ctx->stream));
   hipLaunchKernelGGL(k_count_inst, dim3(nwin), dim3(kBT), 0, ctx->stream, b, ws, win0, nwin, maxima_dev);
   MA_HIP(ctx, hipGetLastError());
   return MA_OK;

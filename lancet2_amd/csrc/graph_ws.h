@@ -16,12 +16,14 @@ constexpr int kEdgeCap = 16;       // edges per node (reference: InlinedVector<E
 constexpr u32 kNoNode = 0xFFFFFFFFu;
 // instance word: [31] error-free  [30] canonical == as-seen (PLUS)  [29] FAST: k-mer equals the reference
 // k-mer at the hinted offset, low bits hold that reference POSITION instead of a table slot
-// [28] GEN: read support goes through the general mate-mer set  [27:0] slot / reference position
+// [28] GEN: read support goes through the general mate-mer set  [27] LAST k-mer of its sequence
+// [26:0] slot / reference position
 constexpr u32 kInstErrFree = 1u << 31;
 constexpr u32 kInstPlus = 1u << 30;
 constexpr u32 kInstFast = 1u << 29;
 constexpr u32 kInstGen = 1u << 28;
-constexpr u32 kInstSlotMask = (1u << 28) - 1;
+constexpr u32 kInstLast = 1u << 27;
+constexpr u32 kInstSlotMask = (1u << 27) - 1;
 constexpr int kMaxSamples = 8;
 
 struct GraphWs {
@@ -35,6 +37,8 @@ struct GraphWs {
   u32* seq_inst_base;     // [n_reads + n_windows]: index read_win_off[w] + w is the ref of window w, reads follow
   u32* win_ninst;         // [n_windows] total instances of window w at this k
   u32* win_nread_inst;    // [n_windows] instances that come from reads
+  u32 max_reads;          // most reads of any window of the batch
+  u32 max_read_len;       // longest read of the batch
   // table
   int tc_log2, mc_log2;
   u32 inst_stride;
