@@ -567,7 +567,11 @@ __device__ __forceinline__ u32 inst_table_slot(u32 word, const u32* ref_slot_g) 
   return (word & kInstFast) ? ref_slot_g[word & kInstSlotMask] : (word & kInstSlotMask);
 }
 
+// k_mm_insert / k_count / k_rank / k_edges walk the window's instance words in FLAT order (lane i reads
+// word base + i: coalesced); the read of an instance is recovered from the per-sequence instance bases
+// only for the few instances that need it.
 __global__ __launch_bounds__(kBT) void k_mm_insert(DBatch b, GraphWs ws) {
+  __shared__ u32 l_base[kSeqCap];
   int const a = blockIdx.x;
   int const w = static_cast<int>(ws.active[a]);
   u32 const mask = (1u << ws.mc_log2) - 1;
@@ -577,36 +581,36 @@ __global__ __launch_bounds__(kBT) void k_mm_insert(DBatch b, GraphWs ws) {
   const u32* ref_slot_g = ws.ref_slot + static_cast<size_t>(a) * ws.ref_stride;
   u32 const ns = seq_count(b, w);
   u32 const base_idx = b.read_win_off[w] + w;
-  for (u32 s_idx = 1 + threadIdx.x; s_idx < ns; s_idx += kBT) {
-    SeqInfo const si = seq_info(b, w, s_idx, ws.k);
-    if (si.nk == 0) continue;
+  const u32* sbase = stage_seq_bases(ws.seq_inst_base + base_idx, ns, l_base);
+  __syncthreads();
+  u32 const ninst = ws.win_ninst[w], nref = ninst - ws.win_nread_inst[w];
+  for (u32 ii = nref + threadIdx.x; ii < ninst; ii += kBT) {
+    u32 const v = inst_slot[ii];
+    if ((v & (kInstErrFree | kInstGen)) != (kInstErrFree | kInstGen)) continue;
+    u32 const s_idx = seq_of(sbase, ns, ii);
     u32 const r = b.read_win_off[w] + s_idx - 1;
     u32 const qn = b.read_qname_id[r];
     u32 const role = (b.read_flags[r] & MA_RF_CASE) ? 1u : 0u;
-    u32 const ibase = ws.seq_inst_base[base_idx + s_idx];
-    for (u32 o = 0; o < si.nk; ++o) {
-      u32 const v = inst_slot[ibase + o];
-      if ((v & (kInstErrFree | kInstGen)) != (kInstErrFree | kInstGen)) continue;
-      u64 const key = mm_key_of(inst_table_slot(v, ref_slot_g), qn, role);
-      u32 slot = static_cast<u32>(dev_fmix64(key)) & mask;
-      for (u32 probe = 0; probe <= mask; ++probe) {
-        u64 cur = keys[slot];
-        if (cur != key && cur == 0) {
-          unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long*>(&keys[slot]), 0ull,
-                                             static_cast<unsigned long long>(key));
-          cur = (old == 0ull) ? key : old;
-        }
-        if (cur == key) {
-          atomicMin(&mins[slot], ibase + o);
-          break;
-        }
-        slot = (slot + 1) & mask;
+    u64 const key = mm_key_of(inst_table_slot(v, ref_slot_g), qn, role);
+    u32 slot = static_cast<u32>(dev_fmix64(key)) & mask;
+    for (u32 probe = 0; probe <= mask; ++probe) {
+      u64 cur = keys[slot];
+      if (cur != key && cur == 0) {
+        unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long*>(&keys[slot]), 0ull,
+                                           static_cast<unsigned long long>(key));
+        cur = (old == 0ull) ? key : old;
       }
+      if (cur == key) {
+        atomicMin(&mins[slot], ii);
+        break;
+      }
+      slot = (slot + 1) & mask;
     }
   }
 }
 
 __global__ __launch_bounds__(kBT) void k_count(DBatch b, GraphWs ws) {
+  __shared__ u32 l_base[kSeqCap];
   int const a = blockIdx.x;
   int const w = static_cast<int>(ws.active[a]);
   int const S = ws.num_samples, CW = S + 2;
@@ -618,41 +622,41 @@ __global__ __launch_bounds__(kBT) void k_count(DBatch b, GraphWs ws) {
   const u32* ref_slot_g = ws.ref_slot + static_cast<size_t>(a) * ws.ref_stride;
   u32 const ns = seq_count(b, w);
   u32 const base_idx = b.read_win_off[w] + w;
-  for (u32 s_idx = 1 + threadIdx.x; s_idx < ns; s_idx += kBT) {
-    SeqInfo const si = seq_info(b, w, s_idx, ws.k);
-    if (si.nk == 0) continue;
+  const u32* sbase = stage_seq_bases(ws.seq_inst_base + base_idx, ns, l_base);
+  __syncthreads();
+  u32 const ninst = ws.win_ninst[w], nref = ninst - ws.win_nread_inst[w];
+  for (u32 ii = nref + threadIdx.x; ii < ninst; ii += kBT) {
+    u32 const v = inst_slot[ii];
+    if ((v & (kInstErrFree | kInstGen)) != (kInstErrFree | kInstGen)) continue;
+    u32 const s_idx = seq_of(sbase, ns, ii);
     u32 const r = b.read_win_off[w] + s_idx - 1;
     u32 const qn = b.read_qname_id[r];
     u32 const role = (b.read_flags[r] & MA_RF_CASE) ? 1u : 0u;
     u32 sample = b.read_sample[r];
     if (sample >= static_cast<u32>(S)) sample = S - 1;
-    u32 const ibase = ws.seq_inst_base[base_idx + s_idx];
-    for (u32 o = 0; o < si.nk; ++o) {
-      u32 const v = inst_slot[ibase + o];
-      if ((v & (kInstErrFree | kInstGen)) != (kInstErrFree | kInstGen)) continue;
-      u32 const nslot = inst_table_slot(v, ref_slot_g);
-      u64 const key = mm_key_of(nslot, qn, role);
-      u32 slot = static_cast<u32>(dev_fmix64(key)) & mask;
-      for (u32 probe = 0; probe <= mask; ++probe) {
-        u64 const cur = keys[slot];
-        if (cur == key) break;
-        if (cur == 0) {
-          slot = kNoNode;
-          break;
-        }
-        slot = (slot + 1) & mask;
+    u32 const nslot = inst_table_slot(v, ref_slot_g);
+    u64 const key = mm_key_of(nslot, qn, role);
+    u32 slot = static_cast<u32>(dev_fmix64(key)) & mask;
+    for (u32 probe = 0; probe <= mask; ++probe) {
+      u64 const cur = keys[slot];
+      if (cur == key) break;
+      if (cur == 0) {
+        slot = kNoNode;
+        break;
       }
-      if (slot == kNoNode || mins[slot] != ibase + o) continue;  // a previous (qname, role, kmer) wins
-      atomicAdd(&cnt[static_cast<size_t>(nslot) * CW + sample], 1u);
-      atomicAdd(&cnt[static_cast<size_t>(nslot) * CW + S + role], 1u);
+      slot = (slot + 1) & mask;
     }
+    if (slot == kNoNode || mins[slot] != ii) continue;  // a previous (qname, role, kmer) wins
+    atomicAdd(&cnt[static_cast<size_t>(nslot) * CW + sample], 1u);
+    atomicAdd(&cnt[static_cast<size_t>(nslot) * CW + S + role], 1u);
   }
 }
 
 // low-coverage pruning (graph.cpp:363-390 with component 0 == everything, no anchors yet) and
 // canonical ranking of the survivors by first-insertion order.
 __global__ __launch_bounds__(kBT) void k_rank(DBatch b, GraphWs ws, u32 min_node_cov) {
-  __shared__ u32 sh[kBT];
+  __shared__ u32 sh[kBT / 64];
+  __shared__ u32 l_base[kSeqCap];
   int const a = blockIdx.x;
   int const w = static_cast<int>(ws.active[a]);
   int const S = ws.num_samples, CW = S + 2;
@@ -684,58 +688,83 @@ __global__ __launch_bounds__(kBT) void k_rank(DBatch b, GraphWs ws, u32 min_node
   }
   __syncthreads();
 
-  // 2. canonical ranking: count "first instance of a surviving node" per contiguous block of sequences
+  // 2. canonical ranking: node index = number of "first instance of a surviving node" events before it in
+  //    instance order.  Four consecutive instance words per thread and tile (one 16-byte load), block scan.
   u32 const ns = seq_count(b, w);
   u32 const base_idx = b.read_win_off[w] + w;
-  u32 const per = (ns + kBT - 1) / kBT;
-  u32 const s_beg = min(ns, threadIdx.x * per), s_end = min(ns, s_beg + per);
-  u32 mine = 0;
-  for (u32 s = s_beg; s < s_end; ++s) {
-    SeqInfo const si = seq_info(b, w, s, ws.k);
-    u32 const ibase = ws.seq_inst_base[base_idx + s];
-    for (u32 o = 0; o < si.nk; ++o) {
-      u32 const v = inst_slot[ibase + o];
-      if (v & kInstFast) continue;  // a hinted instance is a reference node: never a first insertion
-      mine += (first[v & kInstSlotMask] == ibase + o);
+  const u32* sbase = stage_seq_bases(ws.seq_inst_base + base_idx, ns, l_base);
+  __syncthreads();
+  u32 const ninst = ws.win_ninst[w];
+  u32 const read_byte0 = static_cast<u32>(0);
+  (void)read_byte0;
+  u64 const win_read_off0 = b.read_off[b.read_win_off[w]];
+  int const lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  u32 running = 0;
+  for (u32 tile0 = 0; tile0 < ninst; tile0 += 4 * kBT) {
+    u32 const ii0 = tile0 + 4 * threadIdx.x;
+    uint4 v4 = make_uint4(kInstFast, kInstFast, kInstFast, kInstFast);
+    if (ii0 < ninst) v4 = *reinterpret_cast<const uint4*>(inst_slot + ii0);  // inst_stride is a multiple of 64 words
+    u32 const vv[4] = {v4.x, v4.y, v4.z, v4.w};
+    u32 fmask = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      u32 const ii = ii0 + j, v = vv[j];
+      if (ii < ninst && !(v & kInstFast) && first[v & kInstSlotMask] == ii) fmask |= 1u << j;
+    }
+    u32 const mine = __popc(fmask);
+    u32 inc = mine;
+    for (int d = 1; d < 64; d <<= 1) {
+      u32 const y = __shfl_up(inc, d);
+      if (lane >= d) inc += y;
+    }
+    if (lane == 63) sh[wave] = inc;
+    __syncthreads();
+    u32 before = 0, tile_total = 0;
+    for (int x = 0; x < kBT / 64; ++x) {
+      u32 const t = sh[x];
+      if (x < wave) before += t;
+      tile_total += t;
+    }
+    __syncthreads();
+    u32 idx = running + before + inc - mine;
+    running += tile_total;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (!(fmask & (1u << j))) continue;
+      u32 const ii = ii0 + j, v = vv[j];
+      u32 const slot = v & kInstSlotMask;
+      if (idx < ws.nc) {
+        u32 const s = seq_of(sbase, ns, ii);
+        u32 const o = ii - sbase[s];
+        u32 label = 1;  // Label::REFERENCE
+        u32 srcbit = 0, rel_off = 0;
+        if (s > 0) {
+          u32 const r = b.read_win_off[w] + s - 1;
+          label = (b.read_flags[r] & MA_RF_CASE) ? 4u : 2u;  // Label::CASE / Label::CTRL
+          srcbit = 0x80000000u;
+          rel_off = static_cast<u32>(b.read_off[r] - win_read_off0);
+        }
+        slot_node[slot] = idx;
+        for (int i = 0; i < S; ++i) ws.nd_cnt[(nb + idx) * S + i] = cnt[static_cast<size_t>(slot) * CW + i];
+        ws.nd_role[(nb + idx) * 2 + 0] = cnt[static_cast<size_t>(slot) * CW + S];
+        ws.nd_role[(nb + idx) * 2 + 1] = cnt[static_cast<size_t>(slot) * CW + S + 1];
+        ws.nd_src[nb + idx] = srcbit | (rel_off + o);
+        ws.nd_label[nb + idx] = static_cast<u8>(label);
+        ws.nd_sign[nb + idx] = (v & kInstPlus) ? 1 : 0;
+        ws.nd_nedge[nb + idx] = 0;
+      }
+      idx++;
     }
   }
-  u32 total;
-  u32 idx = block_excl_scan(mine, sh, &total);
+  u32 const total = running;
   if (threadIdx.x == 0) ws.n_nodes[a] = total;
   if (total >= ws.nc) {  // capacity exceeded: flagged, window fails
     if (threadIdx.x == 0) atomicOr(&ws.win_flags[w], 4u);
     return;
   }
-  for (u32 s = s_beg; s < s_end; ++s) {
-    SeqInfo const si = seq_info(b, w, s, ws.k);
-    u32 const ibase = ws.seq_inst_base[base_idx + s];
-    u32 label = 1;  // Label::REFERENCE
-    u32 srcbit = 0, rel_off = 0;
-    if (s > 0) {
-      u32 const r = b.read_win_off[w] + s - 1;
-      label = (b.read_flags[r] & MA_RF_CASE) ? 4u : 2u;  // Label::CASE / Label::CTRL
-      srcbit = 0x80000000u;
-      rel_off = static_cast<u32>(si.off - b.read_off[b.read_win_off[w]]);
-    }
-    for (u32 o = 0; o < si.nk; ++o) {
-      u32 const v = inst_slot[ibase + o];
-      if (v & kInstFast) continue;
-      u32 const slot = v & kInstSlotMask;
-      if (first[slot] != ibase + o) continue;
-      slot_node[slot] = idx;
-      for (int i = 0; i < S; ++i) ws.nd_cnt[(nb + idx) * S + i] = cnt[static_cast<size_t>(slot) * CW + i];
-      ws.nd_role[(nb + idx) * 2 + 0] = cnt[static_cast<size_t>(slot) * CW + S];
-      ws.nd_role[(nb + idx) * 2 + 1] = cnt[static_cast<size_t>(slot) * CW + S + 1];
-      ws.nd_src[nb + idx] = srcbit | (rel_off + o);
-      ws.nd_label[nb + idx] = static_cast<u8>(label);
-      ws.nd_sign[nb + idx] = (v & kInstPlus) ? 1 : 0;
-      ws.nd_nedge[nb + idx] = 0;
-      for (int e = 0; e < kEdgeCap; ++e) {
-        ws.nd_edge[(nb + idx) * kEdgeCap + e] = 0xFFFFFFFFu;
-        ws.nd_ekey[(nb + idx) * kEdgeCap + e] = 0xFFFFFFFFu;
-      }
-      idx++;
-    }
+  for (u32 x = threadIdx.x; x < total * kEdgeCap; x += kBT) {
+    ws.nd_edge[nb * kEdgeCap + x] = 0xFFFFFFFFu;
+    ws.nd_ekey[nb * kEdgeCap + x] = 0xFFFFFFFFu;
   }
   __syncthreads();
   // 3. mRefNodeIds (graph.cpp:264-267): node of every reference k-mer (kNoNode when pruned)
@@ -772,29 +801,27 @@ __global__ __launch_bounds__(kBT) void k_edges(DBatch b, GraphWs ws) {
   size_t const nb = static_cast<size_t>(a) * ws.nc;
   u32 const ns = seq_count(b, w);
   u32 const base_idx = b.read_win_off[w] + w;
-  // the reference sequence is long: all threads share it (one (k+1)-mer per thread, strided); every read is
-  // walked by one thread
-  for (u32 s = 0; s < ns; s = (s == 0 ? 1 + threadIdx.x : s + kBT)) {
-    SeqInfo const si = seq_info(b, w, s, ws.k);
-    if (si.nk < 2) continue;
-    u32 const ibase = ws.seq_inst_base[base_idx + s];
-    u32 const o_beg = s == 0 ? threadIdx.x : 0u, o_step = s == 0 ? kBT : 1u, o_end = si.nk - 1;
-    for (u32 o = o_beg; o < o_end; o += o_step) {
-      u32 const wa = inst_slot[ibase + o], wb = inst_slot[ibase + o + 1];
-      // both k-mers are reference nodes at consecutive positions: this (k+1)-mer is the reference's own edge,
-      // already inserted (with a smaller order key) by the reference sequence itself
-      if (s != 0 && (wa & kInstFast) && (wb & kInstFast) && (wb & kInstSlotMask) == (wa & kInstSlotMask) + 1) continue;
-      u32 const na = (wa & kInstFast) ? refn[wa & kInstSlotMask] : slot_node[wa & kInstSlotMask];
-      u32 const nbn = (wb & kInstFast) ? refn[wb & kInstSlotMask] : slot_node[wb & kInstSlotMask];
-      if (na == kNoNode || nbn == kNoNode) continue;
-      // edge kind from the STORED signs of both nodes (graph.cpp:333-336)
-      u32 const sa_minus = ws.nd_sign[nb + na] ? 0u : 1u, sb_minus = ws.nd_sign[nb + nbn] ? 0u : 1u;
-      u32 const fwd = (sa_minus << 1) | sb_minus;                 // MakeFwdEdgeKind(sA, sB)
-      u32 const rev = ((sb_minus ^ 1u) << 1) | (sa_minus ^ 1u);   // RevEdgeKind(fwd) seen from B
-      u32 const key = 2u * (ibase + o);
-      edge_insert(ws, nb, na, (nbn << 2) | fwd, key, &ws.win_flags[w]);
-      edge_insert(ws, nb, nbn, (na << 2) | rev, key + 1u, &ws.win_flags[w]);
-    }
+  // one (k+1)-mer per lane in flat instance order: (ii, ii + 1) unless ii is the last k-mer of its sequence
+  u32 const ninst = ws.win_ninst[w], nref = ninst - ws.win_nread_inst[w];
+  (void)ns;
+  (void)base_idx;
+  for (u32 ii = threadIdx.x; ii + 1 < ninst; ii += kBT) {
+    u32 const wa = inst_slot[ii];
+    if (wa & kInstLast) continue;
+    u32 const wb = inst_slot[ii + 1];
+    // both k-mers are reference nodes at consecutive positions: this (k+1)-mer is the reference's own edge,
+    // already inserted (with a smaller order key) by the reference sequence itself
+    if (ii >= nref && (wa & kInstFast) && (wb & kInstFast) && (wb & kInstSlotMask) == (wa & kInstSlotMask) + 1) continue;
+    u32 const na = (wa & kInstFast) ? refn[wa & kInstSlotMask] : slot_node[wa & kInstSlotMask];
+    u32 const nbn = (wb & kInstFast) ? refn[wb & kInstSlotMask] : slot_node[wb & kInstSlotMask];
+    if (na == kNoNode || nbn == kNoNode) continue;
+    // edge kind from the STORED signs of both nodes (graph.cpp:333-336)
+    u32 const sa_minus = ws.nd_sign[nb + na] ? 0u : 1u, sb_minus = ws.nd_sign[nb + nbn] ? 0u : 1u;
+    u32 const fwd = (sa_minus << 1) | sb_minus;                 // MakeFwdEdgeKind(sA, sB)
+    u32 const rev = ((sb_minus ^ 1u) << 1) | (sa_minus ^ 1u);   // RevEdgeKind(fwd) seen from B
+    u32 const key = 2u * ii;
+    edge_insert(ws, nb, na, (nbn << 2) | fwd, key, &ws.win_flags[w]);
+    edge_insert(ws, nb, nbn, (na << 2) | rev, key + 1u, &ws.win_flags[w]);
   }
 }
 
