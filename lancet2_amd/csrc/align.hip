@@ -179,10 +179,25 @@ struct HapIdx {
   const u16* head;  // [kIdxCap]      0xFFFF = empty
   const u16* next;  // [max_hap_len]
   const u32* code;  // [max_hap_len]  0xFFFFFFFF = no valid 11-mer
+  const u32* hlo;   // bit planes of the haplotype's 2-bit base codes: bit j of word j >> 5
+  const u32* hhi;
+  const u32* hbad;  // base j is not A/C/G/T
+  u32* rplanes;     // this wave's read planes: [3][rwords]
+  u32 rwords;
 };
+// 11 consecutive bits of a bit plane starting at bit i (planes are padded with two zero words)
+__device__ __forceinline__ u32 plane11(const u32* pl, u32 i) {
+  u64 const two = static_cast<u64>(pl[i >> 5]) | (static_cast<u64>(pl[(i >> 5) + 1]) << 32);
+  return static_cast<u32>(two >> (i & 31u)) & 0x7FFu;
+}
+// 32 consecutive bits of a bit plane starting at bit i
+__device__ __forceinline__ u32 plane32(const u32* pl, u32 i) {
+  u64 const two = static_cast<u64>(pl[i >> 5]) | (static_cast<u64>(pl[(i >> 5) + 1]) << 32);
+  return static_cast<u32>(two >> (i & 31u));
+}
 __device__ __forceinline__ void vote_pair(GArgs const& A, u64 lp, PairId id, HapIdx ix, u16* hist, int lane);
 
-__global__ __launch_bounds__(256) void k_vote(GArgs A, u32 hist_len) {
+__global__ __launch_bounds__(256) void k_vote(GArgs A, u32 hist_len, u32 rwords) {
   extern __shared__ u32 lds_vote[];
   u32 const item = A.ws.vote_wg[blockIdx.x];
   int const w = item / A.prm.max_haps, slot = item % A.prm.max_haps;
@@ -192,24 +207,43 @@ __global__ __launch_bounds__(256) void k_vote(GArgs A, u32 hist_len) {
   u64 const p0 = A.ws.pair_off[w] + static_cast<u64>(si) * nr;  // global pair index of read 0
   if (p0 + nr <= A.pair0 || p0 >= A.pair0 + A.npairs) return;
   u32 const ML = A.prm.max_hap_len;
+  u32 const pw = (ML + 31) / 32 + 2;  // words per haplotype bit plane (two zero words of padding)
   u32* code = lds_vote;                                    // [ML]
   u16* head = reinterpret_cast<u16*>(code + ML);           // [kIdxCap]
   u16* next = head + kIdxCap;                              // [ML]
   u16* hist_all = next + ((ML + 1) & ~1u);                 // [4][hist_len]
+  u32* hlo = reinterpret_cast<u32*>(hist_all + 4 * hist_len);  // [3][pw]
+  u32* hhi = hlo + pw;
+  u32* hbad = hhi + pw;
+  u32* rplanes_all = hbad + pw;                            // [4 waves][3][rwords]
   size_t const hi = static_cast<size_t>(w) * A.prm.max_haps + slot;
   u32 const n = A.a.hap_len[hi];
   const u8* hb = A.a.hap_bases + hi * ML;
   for (u32 x = threadIdx.x; x < kIdxCap / 2; x += 256) reinterpret_cast<u32*>(head)[x] = 0xFFFFFFFFu;
   for (u32 x = threadIdx.x; x < 4 * hist_len / 2; x += 256) reinterpret_cast<u32*>(hist_all)[x] = 0;
+  // haplotype bases -> three bit planes (one coalesced byte load per base, wave ballots)
+  for (u32 j0 = 0; j0 < pw * 32; j0 += 256) {
+    u32 const j = j0 + threadIdx.x;
+    u32 const e = j < n ? enc_base(hb[j]) : 0u;
+    unsigned long long const blo = __ballot(e & 1u), bhi = __ballot(e & 2u), bbad = __ballot(e > 3u);
+    if ((threadIdx.x & 63) == 0 && (j >> 5) + 1 < pw + 1) {
+      u32 const wd = j >> 5;
+      if (wd < pw) {
+        hlo[wd] = static_cast<u32>(blo);
+        hhi[wd] = static_cast<u32>(bhi);
+        hbad[wd] = static_cast<u32>(bbad);
+      }
+      if (wd + 1 < pw) {
+        hlo[wd + 1] = static_cast<u32>(blo >> 32);
+        hhi[wd + 1] = static_cast<u32>(bhi >> 32);
+        hbad[wd + 1] = static_cast<u32>(bbad >> 32);
+      }
+    }
+  }
   __syncthreads();
   for (u32 j = threadIdx.x; j + SK <= n; j += 256) {
-    u32 cd = 0;
-    bool ok = true;
-    for (int x = 0; x < SK; ++x) {
-      u32 const e = enc_base(hb[j + x]);
-      ok &= e < 4;
-      cd = (cd << 2) | (e & 3u);
-    }
+    bool const ok = plane11(hbad, j) == 0;
+    u32 const cd = plane11(hlo, j) | (plane11(hhi, j) << 11);  // any injective code of the 11-mer will do
     code[j] = ok ? cd : 0xFFFFFFFFu;
     if (!ok) continue;
     u32 const bkt = (cd * 2654435761u) >> (32 - 12);  // kIdxCap == 4096
@@ -227,7 +261,7 @@ __global__ __launch_bounds__(256) void k_vote(GArgs A, u32 hist_len) {
   }
   __syncthreads();
   int const wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  HapIdx const ix{head, next, code};
+  HapIdx const ix{head, next, code, hlo, hhi, hbad, rplanes_all + static_cast<size_t>(wave) * 3 * rwords, rwords};
   u16* hist = hist_all + static_cast<size_t>(wave) * hist_len;
   for (u32 ri = wave; ri < nr; ri += 4) {
     u64 const p = p0 + ri;
@@ -246,21 +280,31 @@ __device__ __forceinline__ void vote_pair(GArgs const& A, u64 lp, PairId id, Hap
   const u16* head = ix.head;
   const u16* next = ix.next;
   const u32* code = ix.code;
-  // this lane's read positions i = lane, lane + 64, ... and their 11-mer codes (0xFFFFFFFF: none)
   VPROF_T0();
+  // the read as three bit planes in LDS: one coalesced byte load per base
+  u32* rlo = ix.rplanes;
+  u32* rhi = rlo + ix.rwords;
+  u32* rbad = rhi + ix.rwords;
+  for (i32 i0 = 0; i0 < static_cast<i32>(ix.rwords) * 32; i0 += 64) {
+    i32 const i = i0 + lane;
+    u32 const e = i < m ? enc_base(rb[i]) : 0u;
+    unsigned long long const blo = __ballot(e & 1u), bhi = __ballot(e & 2u), bbad = __ballot(e > 3u);
+    if (lane < 2 && static_cast<u32>(i0 >> 5) + lane < ix.rwords) {
+      u32 const wd = (i0 >> 5) + lane;
+      rlo[wd] = static_cast<u32>(blo >> (32 * lane));
+      rhi[wd] = static_cast<u32>(bhi >> (32 * lane));
+      rbad[wd] = static_cast<u32>(bbad >> (32 * lane));
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  // this lane's read positions i = lane, lane + 64, ... and their 11-mer codes (0xFFFFFFFF: none)
   constexpr int kPos = 4;  // the first 256 read positions keep their codes in registers
   u32 cds[kPos];
   bool const seeded = m >= SK && n >= SK;
   auto code_at = [&](i32 i) -> u32 {
     if (!seeded || i + SK > m) return 0xFFFFFFFFu;
-    u32 cd = 0;
-    bool ok = true;
-    for (int x = 0; x < SK; ++x) {
-      u32 const e = enc_base(rb[i + x]);
-      ok &= e < 4;
-      cd = (cd << 2) | (e & 3u);
-    }
-    return ok ? cd : 0xFFFFFFFFu;
+    if (plane11(rbad, i) != 0) return 0xFFFFFFFFu;
+    return plane11(rlo, i) | (plane11(rhi, i) << 11);
   };
 #pragma unroll
   for (int t = 0; t < kPos; ++t) cds[t] = code_at(lane + 64 * t);
@@ -335,11 +379,12 @@ __device__ __forceinline__ void vote_pair(GArgs const& A, u64 lp, PairId id, Hap
   bool const inside = c >= 0 && c + m <= n;
   u32 mism = 0, amb = 0;
   if (inside) {
-    const u8* hb = A.a.hap_bases + hi * A.prm.max_hap_len;
-    for (i32 i = lane; i < m; i += 64) {
-      u32 const qe = enc_base(rb[i]), te = enc_base(hb[c + i]);
-      amb |= (qe > 3 || te > 3) ? 1u : 0u;
-      mism += qe != te;
+    for (i32 i = 32 * lane; i < m; i += 32 * 64) {  // 32 bases per lane: XOR of the bit planes
+      u32 const valid = m - i >= 32 ? 0xFFFFFFFFu : ((1u << (m - i)) - 1u);
+      u32 const xlo = rlo[i >> 5] ^ plane32(ix.hlo, c + i), xhi = rhi[i >> 5] ^ plane32(ix.hhi, c + i);
+      u32 const bad = rbad[i >> 5] | plane32(ix.hbad, c + i);
+      mism += __popc((xlo | xhi | bad) & valid);  // an ambiguous base never equals anything
+      amb |= (bad & valid) ? 1u : 0u;
     }
   }
   for (int off = 32; off > 0; off >>= 1) {
@@ -1134,7 +1179,10 @@ int launch_genotype(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& a, const m
     ws.dp_list = reinterpret_cast<u32*>(ws.centre + pairs_chunk + 16);
     ws.dp_count = ws.dp_list + pairs_chunk + 16;
     u32 const hist_len = ((max_read_len + static_cast<u32>(P.max_hap_len) + 2 + 1) & ~1u);
-    size_t const lds_vote = 4ull * P.max_hap_len + 2ull * kIdxCap + 2ull * ((P.max_hap_len + 1) & ~1) + 8ull * hist_len;
+    u32 const pw_host = (static_cast<u32>(P.max_hap_len) + 31) / 32 + 2;
+    u32 const rwords = (max_read_len + 31) / 32 + 2;
+    size_t const lds_vote = 4ull * P.max_hap_len + 2ull * kIdxCap + 2ull * ((P.max_hap_len + 1) & ~1) + 8ull * hist_len +
+                            12ull * pw_host + 48ull * rwords + 64;
     if (lds_vote > 65536)
       MA_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_vote), hipFuncAttributeMaxDynamicSharedMemorySize,
                                       static_cast<int>(lds_vote)));
@@ -1145,7 +1193,7 @@ int launch_genotype(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& a, const m
       A.npairs = static_cast<u32>(std::min<u64>(pairs_chunk, total_pairs - p0));
       MA_HIP(ctx, hipMemsetAsync(ws.dp_count, 0, 4, ctx->stream));
       ctx->tic("k_vote");
-      hipLaunchKernelGGL(k_vote, dim3(n_vote_wg), dim3(256), lds_vote, ctx->stream, A, hist_len);
+      hipLaunchKernelGGL(k_vote, dim3(n_vote_wg), dim3(256), lds_vote, ctx->stream, A, hist_len, rwords);
       ctx->toc();
       u32 ndp = 0;
       MA_HIP(ctx, hipMemcpyAsync(&ndp, ws.dp_count, 4, hipMemcpyDeviceToHost, ctx->stream));
