@@ -164,7 +164,7 @@ __device__ unsigned long long g_vprof[16];
 #define VPROF_ACC(slot)                                                       \
   do {                                                                        \
     unsigned long long _t1 = __builtin_amdgcn_s_memtime();                    \
-    if (lane == 0) atomicAdd(&g_vprof[slot], _t1 - _t0);                      \
+    if (lane == 0) ix.prof[slot] += _t1 - _t0;                                \
     _t0 = _t1;                                                                \
   } while (0)
 #else
@@ -184,6 +184,10 @@ struct HapIdx {
   const u32* hbad;  // base j is not A/C/G/T
   u32* rplanes;     // this wave's read planes: [3][rwords]
   u32 rwords;
+  u32* dpbuf;       // this wave's pending DP pairs: [64] + count at [64]
+#ifdef MA_PROFILE
+  unsigned long long* prof;  // this wave's phase cycle counters
+#endif
 };
 // 11 consecutive bits of a bit plane starting at bit i (planes are padded with two zero words)
 __device__ __forceinline__ u32 plane11(const u32* pl, u32 i) {
@@ -195,7 +199,21 @@ __device__ __forceinline__ u32 plane32(const u32* pl, u32 i) {
   u64 const two = static_cast<u64>(pl[i >> 5]) | (static_cast<u64>(pl[(i >> 5) + 1]) << 32);
   return static_cast<u32>(two >> (i & 31u));
 }
-__device__ __forceinline__ void vote_pair(GArgs const& A, u64 lp, PairId id, HapIdx ix, u16* hist, int lane);
+// append this wave's buffered DP pairs to the global list: one atomic per 64 pairs
+__device__ __forceinline__ void vote_flush_dp(GArgs const& A, HapIdx ix, int lane) {
+  u32 const cnt = ix.dpbuf[64];
+  if (cnt == 0) return;
+  u32 base = 0;
+  if (lane == 0) base = atomicAdd(A.ws.dp_count, cnt);
+  base = __shfl(base, 0);
+  if (static_cast<u32>(lane) < cnt) A.ws.dp_list[base + lane] = ix.dpbuf[lane];
+  __builtin_amdgcn_wave_barrier();
+  if (lane == 0) ix.dpbuf[64] = 0;
+  __builtin_amdgcn_wave_barrier();
+}
+constexpr int kPre = 4;  // read bases prefetched per lane (covers reads up to 256 bases)
+__device__ __forceinline__ void vote_pair(GArgs const& A, u64 lp, PairId id, HapIdx ix, u16* hist, int lane, u64 ro, i32 m,
+                                          const u32 (&pre)[kPre]);
 
 __global__ __launch_bounds__(256) void k_vote(GArgs A, u32 hist_len, u32 rwords) {
   extern __shared__ u32 lds_vote[];
@@ -216,11 +234,16 @@ __global__ __launch_bounds__(256) void k_vote(GArgs A, u32 hist_len, u32 rwords)
   u32* hhi = hlo + pw;
   u32* hbad = hhi + pw;
   u32* rplanes_all = hbad + pw;                            // [4 waves][3][rwords]
+  u32* dpbuf_all = rplanes_all + 12 * rwords;              // [4 waves][65]
+  u32* l_roff = dpbuf_all + 4 * 65;                        // [nr + 1] read byte offsets relative to the window's first read
   size_t const hi = static_cast<size_t>(w) * A.prm.max_haps + slot;
   u32 const n = A.a.hap_len[hi];
   const u8* hb = A.a.hap_bases + hi * ML;
   for (u32 x = threadIdx.x; x < kIdxCap / 2; x += 256) reinterpret_cast<u32*>(head)[x] = 0xFFFFFFFFu;
   for (u32 x = threadIdx.x; x < 4 * hist_len / 2; x += 256) reinterpret_cast<u32*>(hist_all)[x] = 0;
+  u64 const roff0 = A.b.read_off[r0];
+  for (u32 x = threadIdx.x; x <= nr; x += 256) l_roff[x] = static_cast<u32>(A.b.read_off[r0 + x] - roff0);
+  if (threadIdx.x < 4) dpbuf_all[threadIdx.x * 65 + 64] = 0;
   // haplotype bases -> three bit planes (one coalesced byte load per base, wave ballots)
   for (u32 j0 = 0; j0 < pw * 32; j0 += 256) {
     u32 const j = j0 + threadIdx.x;
@@ -261,20 +284,54 @@ __global__ __launch_bounds__(256) void k_vote(GArgs A, u32 hist_len, u32 rwords)
   }
   __syncthreads();
   int const wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  HapIdx const ix{head, next, code, hlo, hhi, hbad, rplanes_all + static_cast<size_t>(wave) * 3 * rwords, rwords};
+#ifdef MA_PROFILE
+  __shared__ unsigned long long sh_prof[4][8];
+  if (lane < 8) sh_prof[wave][lane] = 0;
+  unsigned long long const k_t0 = __builtin_amdgcn_s_memtime();
+  HapIdx const ix{head, next, code, hlo, hhi, hbad, rplanes_all + static_cast<size_t>(wave) * 3 * rwords, rwords,
+                  dpbuf_all + wave * 65, sh_prof[wave]};
+#else
+  HapIdx const ix{head, next, code, hlo, hhi, hbad, rplanes_all + static_cast<size_t>(wave) * 3 * rwords, rwords,
+                  dpbuf_all + wave * 65};
+#endif
   u16* hist = hist_all + static_cast<size_t>(wave) * hist_len;
+  // software pipeline: the next read's bases are in flight while the current read is voted
+  auto fetch = [&](u32 ri, u32 (&pre)[kPre]) {
+    u32 const o = l_roff[ri], len = l_roff[ri + 1] - o;
+    const u8* rb = A.b.read_bases + roff0 + o;
+#pragma unroll
+    for (int x = 0; x < kPre; ++x) {
+      u32 const i = lane + 64 * x;
+      pre[x] = i < len ? rb[i] : 0u;
+    }
+  };
+  u32 cur[kPre], nxt[kPre];
+#pragma unroll
+  for (int x = 0; x < kPre; ++x) cur[x] = nxt[x] = 0;
+  if (static_cast<u32>(wave) < nr) fetch(wave, cur);
   for (u32 ri = wave; ri < nr; ri += 4) {
+    if (ri + 4 < nr) fetch(ri + 4, nxt);
     u64 const p = p0 + ri;
-    if (p < A.pair0 || p >= A.pair0 + A.npairs) continue;
-    vote_pair(A, p - A.pair0, PairId{w, r0 + ri, static_cast<u32>(slot)}, ix, hist, lane);
+    if (p >= A.pair0 && p < A.pair0 + A.npairs) {
+      u32 const o = l_roff[ri];
+      vote_pair(A, p - A.pair0, PairId{w, r0 + ri, static_cast<u32>(slot)}, ix, hist, lane, roff0 + o,
+                static_cast<i32>(l_roff[ri + 1] - o), cur);
+    }
+#pragma unroll
+    for (int x = 0; x < kPre; ++x) cur[x] = nxt[x];
   }
+  vote_flush_dp(A, ix, lane);
+#ifdef MA_PROFILE
+  __builtin_amdgcn_wave_barrier();
+  if (lane < 8) atomicAdd(&g_vprof[lane], sh_prof[wave][lane]);
+  if (lane == 0) atomicAdd(&g_vprof[14], __builtin_amdgcn_s_memtime() - k_t0);
+#endif
 }
 
-__device__ __forceinline__ void vote_pair(GArgs const& A, u64 lp, PairId id, HapIdx ix, u16* hist, int lane) {
+__device__ __forceinline__ void vote_pair(GArgs const& A, u64 lp, PairId id, HapIdx ix, u16* hist, int lane, u64 ro, i32 m,
+                                          const u32 (&pre)[kPre]) {
   size_t const hi = static_cast<size_t>(id.w) * A.prm.max_haps + id.slot;
   i32 const n = static_cast<i32>(A.a.hap_len[hi]);
-  u64 const ro = A.b.read_off[id.r];
-  i32 const m = static_cast<i32>(A.b.read_off[id.r + 1] - ro);
   const u8* rb = A.b.read_bases + ro;
   i32 const nd = m + n + 1;  // diagonals d in [-m, n] -> hist[d + m]
   const u16* head = ix.head;
@@ -287,7 +344,15 @@ __device__ __forceinline__ void vote_pair(GArgs const& A, u64 lp, PairId id, Hap
   u32* rbad = rhi + ix.rwords;
   for (i32 i0 = 0; i0 < static_cast<i32>(ix.rwords) * 32; i0 += 64) {
     i32 const i = i0 + lane;
-    u32 const e = i < m ? enc_base(rb[i]) : 0u;
+    int const t = i0 >> 6;
+    u32 byte = 0;
+    if (t < kPre) {
+#pragma unroll
+      for (int x = 0; x < kPre; ++x) byte = t == x ? pre[x] : byte;
+    } else if (i < m) {
+      byte = rb[i];
+    }
+    u32 const e = i < m ? enc_base(static_cast<u8>(byte)) : 0u;
     unsigned long long const blo = __ballot(e & 1u), bhi = __ballot(e & 2u), bbad = __ballot(e > 3u);
     if (lane < 2 && static_cast<u32>(i0 >> 5) + lane < ix.rwords) {
       u32 const wd = (i0 >> 5) + lane;
@@ -308,16 +373,22 @@ __device__ __forceinline__ void vote_pair(GArgs const& A, u64 lp, PairId id, Hap
   };
 #pragma unroll
   for (int t = 0; t < kPos; ++t) cds[t] = code_at(lane + 64 * t);
+  // first matching haplotype position of every cached read position (0xFFFF: none) and whether its chain holds
+  // further matches (repeats): the later passes over the votes then cost one LDS access per position
+  u32 mj[kPos];
+  u32 more = 0;
   // visit every (read position, matching haplotype position) pair of this lane
   auto walk = [&](auto&& fn) {
 #pragma unroll
     for (int t = 0; t < kPos; ++t) {
-      u32 const cd = cds[t];
-      if (cd == 0xFFFFFFFFu) continue;
+      if (mj[t] == 0xFFFFu) continue;
       i32 const i = lane + 64 * t;
-      u32 const bkt = (cd * 2654435761u) >> (32 - 12);
-      for (u32 j = head[bkt]; j != 0xFFFFu; j = next[j])
-        if (code[j] == cd) fn(static_cast<i32>(j) - i + m);
+      fn(static_cast<i32>(mj[t]) - i + m);
+      if (more & (1u << t)) {
+        u32 const cd = cds[t];
+        for (u32 j = next[mj[t]]; j != 0xFFFFu; j = next[j])
+          if (code[j] == cd) fn(static_cast<i32>(j) - i + m);
+      }
     }
     for (i32 i = lane + 64 * kPos; seeded && i + SK <= m; i += 64) {  // long reads: re-encode
       u32 const cd = code_at(i);
@@ -328,8 +399,49 @@ __device__ __forceinline__ void vote_pair(GArgs const& A, u64 lp, PairId id, Hap
     }
   };
   VPROF_ACC(0);
-  // 16-bit LDS counters: atomic add on the containing 32-bit word
-  walk([&](i32 d) { atomicAdd(reinterpret_cast<u32*>(hist) + (d >> 1), 1u << ((d & 1) * 16)); });
+  // 16-bit LDS counters: atomic add on the containing 32-bit word.  A read that sits on one diagonal makes
+  // all 64 lanes hit the same counter; those same-address atomics serialise, so the first match of every
+  // lane is pre-combined with a ballot and only further matches (repeats) vote one by one.
+  {
+    auto vote1 = [&](i32 d) { atomicAdd(reinterpret_cast<u32*>(hist) + (d >> 1), 1u << ((d & 1) * 16)); };
+#pragma unroll
+    for (int t = 0; t < kPos; ++t) {
+      u32 const cd = cds[t];
+      i32 const i = lane + 64 * t;
+      u32 j = 0xFFFFu;
+      if (cd != 0xFFFFFFFFu) {
+        j = head[(cd * 2654435761u) >> (32 - 12)];
+        while (j != 0xFFFFu && code[j] != cd) j = next[j];
+      }
+      mj[t] = j;
+      i32 const d = j != 0xFFFFu ? static_cast<i32>(j) - i + m : -1;
+      unsigned long long const have = __ballot(d >= 0);
+      if (have) {
+        i32 const d0 = __shfl(d, __builtin_ctzll(have));
+        unsigned long long const same = __ballot(d == d0);
+        if (same == have) {
+          if (lane == __builtin_ctzll(have)) {
+            u32 const cnt = static_cast<u32>(__popcll(have));
+            atomicAdd(reinterpret_cast<u32*>(hist) + (d0 >> 1), cnt << ((d0 & 1) * 16));
+          }
+        } else if (d >= 0) {
+          vote1(d);
+        }
+      }
+      if (j != 0xFFFFu)
+        for (j = next[j]; j != 0xFFFFu; j = next[j])
+          if (code[j] == cd) {
+            more |= 1u << t;
+            vote1(static_cast<i32>(j) - i + m);
+          }
+    }
+    for (i32 i = lane + 64 * kPos; seeded && i + SK <= m; i += 64) {  // long reads
+      u32 const cd = code_at(i);
+      if (cd == 0xFFFFFFFFu) continue;
+      for (u32 j = head[(cd * 2654435761u) >> (32 - 12)]; j != 0xFFFFu; j = next[j])
+        if (code[j] == cd) vote1(static_cast<i32>(j) - i + m);
+    }
+  }
   __builtin_amdgcn_wave_barrier();
   VPROF_ACC(1);
   // arg-max over the touched diagonals, ties -> smallest diagonal
@@ -410,21 +522,14 @@ __device__ __forceinline__ void vote_pair(GArgs const& A, u64 lp, PairId id, Hap
       A.ws.centre[lp] = 0x7FFFFFFE;
     } else {
       A.ws.centre[lp] = c;
-      A.ws.dp_list[atomicAdd(A.ws.dp_count, 1u)] = static_cast<u32>(lp);
-#ifdef MA_PROFILE
-      // why did the certificate fail?  8: overhang  9: ambiguous  10: > 2 mismatches  11: vote bound  12: low score
-      int const why = !inside ? 8 : (amb ? 9 : (mism > 2 ? 10 : (static_cast<i32>(v2) + 10 + 11 * static_cast<i32>(mism) >= m ? 11 : 12)));
-      atomicAdd(&g_vprof[why], 1ull);
-      if (!inside) {
-        i32 const o = (c < 0 ? -c : 0) + (c + m > n ? c + m - n : 0);
-        atomicAdd(&g_vprof[13], static_cast<unsigned long long>(o));
-      }
-#endif
+      ix.dpbuf[ix.dpbuf[64]++] = static_cast<u32>(lp);
     }
   }
+  __builtin_amdgcn_wave_barrier();
+  if (ix.dpbuf[64] == 64) vote_flush_dp(A, ix, lane);
   VPROF_ACC(6);
 #ifdef MA_PROFILE
-  if (lane == 0) atomicAdd(&g_vprof[7], 1ull);
+  if (lane == 0) ix.prof[7] += 1;
 #endif
 }
 
@@ -1182,7 +1287,7 @@ int launch_genotype(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& a, const m
     u32 const pw_host = (static_cast<u32>(P.max_hap_len) + 31) / 32 + 2;
     u32 const rwords = (max_read_len + 31) / 32 + 2;
     size_t const lds_vote = 4ull * P.max_hap_len + 2ull * kIdxCap + 2ull * ((P.max_hap_len + 1) & ~1) + 8ull * hist_len +
-                            12ull * pw_host + 48ull * rwords + 64;
+                            12ull * pw_host + 48ull * rwords + 4ull * 4 * 65 + 4ull * (plan_counters[1] + 2) + 64;
     if (lds_vote > 65536)
       MA_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_vote), hipFuncAttributeMaxDynamicSharedMemorySize,
                                       static_cast<int>(lds_vote)));
