@@ -5,8 +5,11 @@
 // max_flow.cpp; path.cpp).
 //
 // One wavefront per window attempt.  The algorithm is order dependent by construction (floor-averaged
-// coverage merges, edge-list order, first-found walks), so it is executed in the CANONICAL order of
-// DESIGN.md by lane 0 of the wave on the compact arrays build.hip produced; node sequences are never
+// coverage merges, edge-list order, first-found walks), so its control flow runs in the CANONICAL order of
+// DESIGN.md, executed UNIFORMLY by all 64 lanes (same addresses, same values: a wave instruction costs the
+// same with one lane or 64), and every loop over all nodes / reference k-mers / bases -- flag scans,
+// initialisation, candidate collection in index order, byte copies and compares -- is split across the
+// lanes with ballots keeping the index order.  It works on the compact arrays build.hip produced; node sequences are never
 // materialised during cleaning -- a node is a doubly linked list of SLICES of original k-mers
 // (start, len, revcomp), which reproduces Kmer::Merge's string semantics (kmer.cpp:48-109) exactly,
 // including for the reference's stored-sign edge quirk.  Haplotype bases are spelled from the batch's
@@ -141,15 +144,28 @@ __device__ void remove_node(Win& g, u32 i) {
   g.nedge[i] = 0;
 }
 
+// lanes of the wave cooperate on index ranges; stores of one lane are made visible to the others here
+__device__ __forceinline__ void wave_sync_mem() { __threadfence_block(); }
+__device__ __forceinline__ u32 lane_id() { return threadIdx.x; }
+// append the indices i (in increasing order) whose flag is set to list[]: 64 indices per ballot
+__device__ __forceinline__ void ordered_append(bool flag, u32 i, u32* list, u32& count) {
+  unsigned long long const m = __ballot(flag);
+  if (flag) list[count + __popcll(m & ((1ull << lane_id()) - 1ull))] = i;
+  count += static_cast<u32>(__popcll(m));
+}
+
 // RemoveLowCovNodes (graph.cpp:363-390)
 __device__ void remove_low_cov(Win& g, u32 comp) {
   u32* rm = g.scratch;
   u32 nrm = 0;
-  for (u32 i = 0; i < g.n; ++i) {
-    if (!g.alive[i] || g.comp[i] != comp) continue;
-    if (static_cast<i64>(i) == g.source || static_cast<i64>(i) == g.sink) continue;
-    if (nd_all_singletons(g, i) || nd_total(g, i) < g.min_node_cov) rm[nrm++] = i;
+  for (u32 base = 0; base < g.n; base += 64) {
+    u32 const i = base + lane_id();
+    bool flag = false;
+    if (i < g.n && g.alive[i] && g.comp[i] == comp && static_cast<i64>(i) != g.source && static_cast<i64>(i) != g.sink)
+      flag = nd_all_singletons(g, i) || nd_total(g, i) < g.min_node_cov;
+    ordered_append(flag, i, rm, nrm);
   }
+  wave_sync_mem();
   for (u32 x = 0; x < nrm; ++x) remove_node(g, rm[x]);
 }
 
@@ -578,22 +594,36 @@ __device__ void compress_node_fast(Win& g, u32 nid, bool dflt, u8* absorbed) {
 // CompressGraph (graph.cpp:558-576)
 __device__ void compress_graph(Win& g, u32 comp) {
   u8* absorbed = reinterpret_cast<u8*>(g.scratch + g.nc);
-  for (u32 i = 0; i < g.n; ++i) absorbed[i] = 0;
-  for (u32 i = 0; i < g.n; ++i) {
-    if (!g.alive[i] || g.comp[i] != comp || absorbed[i]) continue;
-    compress_node_fast(g, i, true, absorbed);
-    compress_node_fast(g, i, false, absorbed);
-  }
-  for (u32 i = 0; i < g.n; ++i) {
-    if (absorbed[i] == 2) {
-      // remove_node would only look for mirror edges that the walk has already erased (no edge to an
-      // absorbed node is ever created again: rewired edges point at absorbers)
-      g.alive[i] = 0;
-      g.nedge[i] = 0;
-    } else if (absorbed[i]) {
-      remove_node(g, i);
+  for (u32 i = lane_id(); i < g.n; i += 64) absorbed[i] = 0;
+  wave_sync_mem();
+  for (u32 base = 0; base < g.n; base += 64) {
+    // alive / comp do not change inside this loop; absorbed does and is re-read when a node's turn comes
+    u32 const il = base + lane_id();
+    unsigned long long todo = __ballot(il < g.n && g.alive[il] && g.comp[il] == comp && !absorbed[il]);
+    while (todo) {
+      u32 const i = base + static_cast<u32>(__builtin_ctzll(todo));
+      todo &= todo - 1;
+      if (absorbed[i]) continue;
+      compress_node_fast(g, i, true, absorbed);
+      compress_node_fast(g, i, false, absorbed);
     }
   }
+  // absorbed == 2 (register walk): remove_node would only look for mirror edges that the walk has already
+  // erased (no edge to an absorbed node is ever created again: rewired edges point at absorbers), so the
+  // node is simply switched off.  absorbed == 1 (generic path) goes through remove_node, in index order.
+  bool any_generic = false;
+  for (u32 i = lane_id(); i < g.n; i += 64) {
+    u32 const ab = absorbed[i];
+    if (ab == 2) {
+      g.alive[i] = 0;
+      g.nedge[i] = 0;
+    }
+    any_generic |= ab == 1;
+  }
+  wave_sync_mem();
+  if (__ballot(any_generic))
+    for (u32 i = 0; i < g.n; ++i)
+      if (absorbed[i] == 1) remove_node(g, i);
 }
 
 // RemoveTips (graph.cpp:801-840)
@@ -602,14 +632,19 @@ __device__ void remove_tips(Win& g, u32 comp) {
   while (current > 0) {
     u32* rm = g.scratch;
     u32 nrm = 0;
-    for (u32 i = 0; i < g.n; ++i) {
-      if (!g.alive[i]) continue;
-      bool const anchor = static_cast<i64>(i) == g.source || static_cast<i64>(i) == g.sink;
-      if (g.comp[i] != comp || anchor || g.nedge[i] > 1) continue;
-      u32 const uniq = g.len[i] - static_cast<u32>(g.k) + 1;
-      if (uniq >= static_cast<u32>(g.k)) continue;
-      rm[nrm++] = i;
+    for (u32 base = 0; base < g.n; base += 64) {
+      u32 const i = base + lane_id();
+      bool flag = false;
+      if (i < g.n && g.alive[i]) {
+        bool const anchor = static_cast<i64>(i) == g.source || static_cast<i64>(i) == g.sink;
+        if (g.comp[i] == comp && !anchor && g.nedge[i] <= 1) {
+          u32 const uniq = g.len[i] - static_cast<u32>(g.k) + 1;
+          flag = uniq < static_cast<u32>(g.k);
+        }
+      }
+      ordered_append(flag, i, rm, nrm);
     }
+    wave_sync_mem();
     if (nrm > 0) {
       for (u32 x = 0; x < nrm; ++x) remove_node(g, rm[x]);
       compress_graph(g, comp);
@@ -701,7 +736,7 @@ __device__ u32 median_sorted(const u32* v, u32 n) {  // compute_stats.h:146-159 
 #define CPROF_ACC(slot)                                                       \
   do {                                                                        \
     unsigned long long _t1 = __builtin_amdgcn_s_memtime();                    \
-    atomicAdd(&g_cprof[slot], _t1 - _t0);                                     \
+    if (threadIdx.x == 0) atomicAdd(&g_cprof[slot], _t1 - _t0);               \
     _t0 = _t1;                                                                \
   } while (0)
 extern "C" void ma_debug_cwin(unsigned long long* out, int n) {
@@ -727,8 +762,8 @@ struct CleanArgs {
 };
 
 __global__ __launch_bounds__(64, 4) void k_clean(CleanArgs A) {
-  if (threadIdx.x != 0) return;  // canonical serial order: lane 0 drives the window
   int const a = blockIdx.x;
+  u32 const lane = threadIdx.x;
   GraphWs const& ws = A.ws;
   int const w = static_cast<int>(ws.active[a]);
   ma_params_t const& P = A.prm;
@@ -738,7 +773,7 @@ __global__ __launch_bounds__(64, 4) void k_clean(CleanArgs A) {
   if (ws.win_flags[w] & 4u) {  // build-stage capacity overflow: report and stop retrying
     A.out.win_status[w] = MA_W_TABLE_OVERFLOW | MA_W_NO_HAPLOTYPE;
     A.out.win_ncomp[w] = 0;
-    atomicOr(&ws.win_flags[w], 1u);
+    if (lane == 0) atomicOr(&ws.win_flags[w], 1u);
     return;
   }
 
@@ -777,7 +812,7 @@ __global__ __launch_bounds__(64, 4) void k_clean(CleanArgs A) {
   unsigned long long const t_begin = __builtin_amdgcn_s_memtime();
 #endif
 
-  for (u32 i = 0; i < g.n; ++i) {
+  for (u32 i = lane; i < g.n; i += 64) {
     g.comp[i] = 0;
     g.len[i] = K;
     g.alive[i] = 1;
@@ -785,6 +820,7 @@ __global__ __launch_bounds__(64, 4) void k_clean(CleanArgs A) {
     g.snext[i] = g.sprev[i] = kNoNode;
     g.sdesc[i] = 0u | (K << 8);
   }
+  wave_sync_mem();
 
   CPROF_ACC(0);
   // ---- MarkConnectedComponents (graph.cpp:392-463): ids in discovery order over canonical order ----
@@ -824,20 +860,22 @@ __global__ __launch_bounds__(64, 4) void k_clean(CleanArgs A) {
     u32* first_off = g.scratch;            // [ncomp_all+1]
     u32* last_off = g.scratch + NC;        // [ncomp_all+1]
     u32* csize = g.scratch + 2 * NC;       // [ncomp_all+1]
-    for (u32 c = 0; c <= ncomp_all; ++c) {
-      first_off[c] = kNoNode;
-      last_off[c] = kNoNode;
+    for (u32 c = lane; c <= ncomp_all; c += 64) {
+      first_off[c] = kNoNode;  // minimum of the qualifying offsets
+      last_off[c] = 0;         // maximum (only read when first_off exists)
       csize[c] = 0;
     }
-    for (u32 i = 0; i < g.n; ++i) csize[g.comp[i]]++;
-    for (u32 r = 0; r < n_refk; ++r) {
+    wave_sync_mem();
+    for (u32 i = lane; i < g.n; i += 64) atomicAdd(&csize[g.comp[i]], 1u);
+    for (u32 r = lane; r < n_refk; r += 64) {
       u32 const nd = refn[r];
       if (nd == kNoNode) continue;
       if (nd_total(g, nd) < g.min_anchor_cov) continue;
       u32 const c = g.comp[nd];
-      if (first_off[c] == kNoNode) first_off[c] = r;
-      last_off[c] = r;
+      atomicMin(&first_off[c], r);
+      atomicMax(&last_off[c], r);
     }
+    wave_sync_mem();
     for (u32 c = 1; c <= ncomp_all; ++c) {
       if (first_off[c] == kNoNode) continue;
       u32 const so = first_off[c], ko = last_off[c];
@@ -907,12 +945,15 @@ __global__ __launch_bounds__(64, 4) void k_clean(CleanArgs A) {
     u8* color = reinterpret_cast<u8*>(g.scratch + 24 * NC);      // [2V]
     u32* stack = g.scratch + 25 * NC;      // DFS frames (2 u32 each) / walk pool afterwards
     u32 V = 0, E = 0;
-    for (u32 i = 0; i < g.n; ++i) {
-      flat_of[i] = kNoNode;
-      if (!g.alive[i] || g.comp[i] != comp) continue;
-      flat_of[i] = V;
-      flat_nodes[V++] = i;
+    for (u32 base = 0; base < g.n; base += 64) {
+      u32 const i = base + lane;
+      bool const in = i < g.n && g.alive[i] && g.comp[i] == comp;
+      unsigned long long const m = __ballot(in);
+      if (i < g.n) flat_of[i] = in ? V + static_cast<u32>(__popcll(m & ((1ull << lane) - 1ull))) : kNoNode;
+      if (in) flat_nodes[V + __popcll(m & ((1ull << lane) - 1ull))] = i;
+      V += static_cast<u32>(__popcll(m));
     }
+    wave_sync_mem();
     for (u32 s = 0; s < 2 * V; ++s) rcnt[s] = 0;
     for (u32 f = 0; f < V; ++f) {
       u32 const i = flat_nodes[f];
@@ -1150,7 +1191,8 @@ __global__ __launch_bounds__(64, 4) void k_clean(CleanArgs A) {
         status |= MA_W_LEN_OVERFLOW;
         len = ML;
       }
-      for (u32 x = 0; x < len; ++x) A.out.hap_bases[hi * ML + x] = ref_anchor[x];
+      for (u32 x = lane; x < len; x += 64) A.out.hap_bases[hi * ML + x] = ref_anchor[x];
+      wave_sync_mem();
       A.out.hap_len[hi] = len;
       A.out.hap_nruns[hi] = 1;
       A.out.hap_runs[(hi * MR) * 2 + 0] = wgt;
@@ -1207,9 +1249,9 @@ __global__ __launch_bounds__(64, 4) void k_clean(CleanArgs A) {
           size_t const oi2 = static_cast<size_t>(w) * MH + h;
           if (A.out.hap_len[oi2] != pos) continue;
           const u8* ob = A.out.hap_bases + oi2 * ML;
-          bool same = true;
-          for (u32 x = 0; x < pos && same; ++x) same = ob[x] == hb[x];
-          dup = same;
+          bool diff = false;
+          for (u32 x = lane; x < pos; x += 64) diff |= ob[x] != hb[x];
+          dup = __ballot(diff) == 0;
         }
       }
       if (dup) continue;
@@ -1252,7 +1294,7 @@ __global__ __launch_bounds__(64, 4) void k_clean(CleanArgs A) {
   if (g.flags & 4u) {
     A.out.win_status[w] = MA_W_TABLE_OVERFLOW | MA_W_NO_HAPLOTYPE;
     A.out.win_ncomp[w] = 0;
-    atomicOr(&ws.win_flags[w], 1u);
+    if (lane == 0) atomicOr(&ws.win_flags[w], 1u);
     return;
   }
   if (retry || ncomp_out == 0) {  // graph.cpp:230-234 / results.empty(): try the next k
@@ -1273,7 +1315,7 @@ __global__ __launch_bounds__(64, 4) void k_clean(CleanArgs A) {
   if (nalt == 0) status |= MA_W_NO_HAPLOTYPE;  // variant_builder.cpp:231-240
   A.out.win_ncomp[w] = ncomp_out;
   A.out.win_status[w] = status;
-  atomicOr(&ws.win_flags[w], 1u);
+  if (lane == 0) atomicOr(&ws.win_flags[w], 1u);
 }
 
 int run_clean_pass(ma_ctx* ctx, const DBatch& b, const GraphWs& ws, const ma_asm_out_t& out) {
