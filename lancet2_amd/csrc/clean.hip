@@ -21,8 +21,8 @@ namespace ma {
 namespace {
 
 #ifdef MA_PROFILE
-__device__ unsigned long long g_cprof[16];
-__device__ unsigned long long g_cwin[4096 * 4];
+__device__ __forceinline__ unsigned long long g_cprof[16];
+__device__ __forceinline__ unsigned long long g_cwin[4096 * 4];
 #define CCOUNT(slot) do {} while (0)
 #else
 #define CCOUNT(slot) do {} while (0)
@@ -63,12 +63,12 @@ struct Win {
 __device__ __forceinline__ u32 kind_rev(u32 kind) { return (((kind & 1u) ^ 1u) << 1) | (((kind >> 1) & 1u) ^ 1u); }
 __device__ __forceinline__ u32 mirror_of(u32 self, u32 val) { return (self << 2) | kind_rev(val & 3u); }
 
-__device__ u32 nd_total(const Win& g, u32 i) {
+__device__ __forceinline__ u32 nd_total(const Win& g, u32 i) {
   u32 t = 0;
   for (int s = 0; s < g.S; ++s) t += g.cnt[i * g.S + s];
   return t;
 }
-__device__ bool nd_all_singletons(const Win& g, u32 i) {
+__device__ __forceinline__ bool nd_all_singletons(const Win& g, u32 i) {
   bool any = false, all = true;
   for (int s = 0; s < g.S; ++s) {
     u32 const c = g.cnt[i * g.S + s];
@@ -78,7 +78,7 @@ __device__ bool nd_all_singletons(const Win& g, u32 i) {
   return any && all;
 }
 // Node::Confidence (node.cpp:59-79)
-__device__ u32 nd_confidence(const Win& g, u32 i) {
+__device__ __forceinline__ u32 nd_confidence(const Win& g, u32 i) {
   if (nd_all_singletons(g, i)) return 1;
   u32 const total = nd_total(g, i);
   if (total == 0) return 0;
@@ -90,7 +90,7 @@ __device__ u32 nd_confidence(const Win& g, u32 i) {
   return static_cast<u32>(static_cast<f64>(total) * concordance) + bonus;
 }
 
-__device__ void emplace_edge(Win& g, u32 i, u32 val) {  // node.h:59-64
+__device__ __forceinline__ void emplace_edge(Win& g, u32 i, u32 val) {  // node.h:59-64
   u32* e = g.edge + i * kEdgeCap;
   int const n = g.nedge[i];
   for (int x = 0; x < n; ++x)
@@ -102,7 +102,7 @@ __device__ void emplace_edge(Win& g, u32 i, u32 val) {  // node.h:59-64
   e[n] = val;
   g.nedge[i] = static_cast<u8>(n + 1);
 }
-__device__ void erase_edge(Win& g, u32 i, u32 val) {  // node.h:66-71
+__device__ __forceinline__ void erase_edge(Win& g, u32 i, u32 val) {  // node.h:66-71
   u32* e = g.edge + i * kEdgeCap;
   int const n = g.nedge[i];
   for (int x = 0; x < n; ++x)
@@ -112,14 +112,14 @@ __device__ void erase_edge(Win& g, u32 i, u32 val) {  // node.h:66-71
       return;
     }
 }
-__device__ bool has_self_loop(const Win& g, u32 i) {
+__device__ __forceinline__ bool has_self_loop(const Win& g, u32 i) {
   const u32* e = g.edge + i * kEdgeCap;
   for (int x = 0; x < g.nedge[i]; ++x)
     if ((e[x] >> 2) == i) return true;
   return false;
 }
 // FindEdgesInDirection (node.cpp:118-127): count + first match
-__device__ int edges_in_dir(const Win& g, u32 i, bool dflt, u32* first) {
+__device__ __forceinline__ int edges_in_dir(const Win& g, u32 i, bool dflt, u32* first) {
   u32 const exp_minus = dflt ? (g.sign[i] ? 0u : 1u) : (g.sign[i] ? 1u : 0u);
   const u32* e = g.edge + i * kEdgeCap;
   int c = 0;
@@ -132,7 +132,7 @@ __device__ int edges_in_dir(const Win& g, u32 i, bool dflt, u32* first) {
 }
 
 // Graph::RemoveNode (graph.cpp:347-361)
-__device__ void remove_node(Win& g, u32 i) {
+__device__ __forceinline__ void remove_node(Win& g, u32 i) {
   if (!g.alive[i]) return;
   const u32* e = g.edge + i * kEdgeCap;
   for (int x = 0; x < g.nedge[i]; ++x) {
@@ -155,7 +155,7 @@ __device__ __forceinline__ void ordered_append(bool flag, u32 i, u32* list, u32&
 }
 
 // RemoveLowCovNodes (graph.cpp:363-390)
-__device__ void remove_low_cov(Win& g, u32 comp) {
+__device__ __forceinline__ void remove_low_cov(Win& g, u32 comp) {
   u32* rm = g.scratch;
   u32 nrm = 0;
   for (u32 base = 0; base < g.n; base += 64) {
@@ -170,7 +170,7 @@ __device__ void remove_low_cov(Win& g, u32 comp) {
 }
 
 // ---- slice lists: a node's sequence in its stored orientation ----
-__device__ void slices_reverse(Win& g, u32 node) {  // sequence := RevComp(sequence)
+__device__ __forceinline__ void slices_reverse(Win& g, u32 node) {  // sequence := RevComp(sequence)
   u32 s = g.head[node];
   while (s != kNoNode) {
     u32 const nx = g.snext[s];
@@ -185,7 +185,7 @@ __device__ void slices_reverse(Win& g, u32 node) {  // sequence := RevComp(seque
   g.head[node] = g.tail[node];
   g.tail[node] = h;
 }
-__device__ void slices_drop_front(Win& g, u32 node, u32 nb) {
+__device__ __forceinline__ void slices_drop_front(Win& g, u32 node, u32 nb) {
   while (nb > 0) {
     u32 const s = g.head[node];
     u32 const d = g.sdesc[s];
@@ -201,7 +201,7 @@ __device__ void slices_drop_front(Win& g, u32 node, u32 nb) {
     }
   }
 }
-__device__ void slices_drop_back(Win& g, u32 node, u32 nb) {
+__device__ __forceinline__ void slices_drop_back(Win& g, u32 node, u32 nb) {
   while (nb > 0) {
     u32 const s = g.tail[node];
     u32 const d = g.sdesc[s];
@@ -219,7 +219,7 @@ __device__ void slices_drop_back(Win& g, u32 node, u32 nb) {
 }
 
 // Node::Merge (node.cpp:81-112) + Kmer::Merge / MergeCords (kmer.cpp:48-109)
-__device__ void merge_node(Win& g, u32 x, u32 b, u32 kind) {
+__device__ __forceinline__ void merge_node(Win& g, u32 x, u32 b, u32 kind) {
   u32 const K1 = static_cast<u32>(g.k) - 1;
   u32 const blen = g.len[b];
   bool const append = kind == 0 || kind == 1;  // PLUS_PLUS / PLUS_MINUS append, MINUS_* prepend
@@ -256,7 +256,7 @@ __device__ void merge_node(Win& g, u32 x, u32 b, u32 kind) {
 }
 
 // IsPotentialBuddyEdge (graph.cpp:758-799); conn = edge value stored at src
-__device__ bool is_potential_buddy(const Win& g, u32 src, u32 conn) {
+__device__ __forceinline__ bool is_potential_buddy(const Win& g, u32 src, u32 conn) {
   u32 const nb = conn >> 2;
   if (g.nedge[src] == 1 && g.nedge[nb] == 1) {
     if ((g.edge[src * kEdgeCap] >> 2) == nb && (g.edge[nb * kEdgeCap] >> 2) == src) return false;
@@ -276,7 +276,7 @@ __device__ bool is_potential_buddy(const Win& g, u32 src, u32 conn) {
 }
 
 // FindCompressibleEdge (graph.cpp:688-717)
-__device__ bool find_compressible_edge(const Win& g, u32 src, bool dflt, u32* out) {
+__device__ __forceinline__ bool find_compressible_edge(const Win& g, u32 src, bool dflt, u32* out) {
   if (g.nedge[src] > 2 || g.nedge[src] == 0 || has_self_loop(g, src)) return false;
   if (static_cast<i64>(src) == g.source || static_cast<i64>(src) == g.sink) return false;
   u32 cand = 0;
@@ -297,7 +297,7 @@ __device__ bool find_compressible_edge(const Win& g, u32 src, bool dflt, u32* ou
 }
 
 // CompressNode (graph.cpp:600-645)
-__device__ void compress_node(Win& g, u32 nid, bool dflt, u8* absorbed) {
+__device__ __forceinline__ void compress_node(Win& g, u32 nid, bool dflt, u8* absorbed) {
   u32 s2o = 0;
   while (find_compressible_edge(g, nid, dflt, &s2o)) {
     u32 const ob = s2o >> 2, kind = s2o & 3u;
@@ -323,7 +323,7 @@ __device__ void compress_node(Win& g, u32 nid, bool dflt, u8* absorbed) {
 }
 
 // is_potential_buddy with the far neighbour reported (same tests, same order)
-__device__ bool is_potential_buddy_f2(const Win& g, u32 src, u32 conn, u32* f2node) {
+__device__ __forceinline__ bool is_potential_buddy_f2(const Win& g, u32 src, u32 conn, u32* f2node) {
   u32 const nb = conn >> 2;
   *f2node = kNoNode;
   if (g.nedge[src] == 1 && g.nedge[nb] == 1) {
@@ -349,7 +349,7 @@ __device__ bool is_potential_buddy_f2(const Win& g, u32 src, u32 conn, u32* f2no
 // is_potential_buddy predicates evaluated on register copies of what memory holds); as soon as a test
 // fails or anything unusual shows up (node coincidences of a cycle, duplicate edges) it writes its
 // state back and hands over to the generic compress_node, which re-evaluates from memory.
-__device__ void compress_node_fast(Win& g, u32 nid, bool dflt, u8* absorbed) {
+__device__ __forceinline__ void compress_node_fast(Win& g, u32 nid, bool dflt, u8* absorbed) {
   // NOTE: no dynamically indexed local arrays in here -- they would live in scratch (HBM latency)
   if (static_cast<i64>(nid) == g.source || static_cast<i64>(nid) == g.sink) return;
   u32 xn = g.nedge[nid];
@@ -592,7 +592,7 @@ __device__ void compress_node_fast(Win& g, u32 nid, bool dflt, u8* absorbed) {
 }
 
 // CompressGraph (graph.cpp:558-576)
-__device__ void compress_graph(Win& g, u32 comp) {
+__device__ __forceinline__ void compress_graph(Win& g, u32 comp) {
   u8* absorbed = reinterpret_cast<u8*>(g.scratch + g.nc);
   for (u32 i = lane_id(); i < g.n; i += 64) absorbed[i] = 0;
   wave_sync_mem();
@@ -604,8 +604,8 @@ __device__ void compress_graph(Win& g, u32 comp) {
       u32 const i = base + static_cast<u32>(__builtin_ctzll(todo));
       todo &= todo - 1;
       if (absorbed[i]) continue;
-      compress_node_fast(g, i, true, absorbed);
-      compress_node_fast(g, i, false, absorbed);
+#pragma nounroll
+      for (int dir = 1; dir >= 0; --dir) compress_node_fast(g, i, dir != 0, absorbed);
     }
   }
   // absorbed == 2 (register walk): remove_node would only look for mirror edges that the walk has already
@@ -626,31 +626,24 @@ __device__ void compress_graph(Win& g, u32 comp) {
       if (absorbed[i] == 1) remove_node(g, i);
 }
 
-// RemoveTips (graph.cpp:801-840)
-__device__ void remove_tips(Win& g, u32 comp) {
-  u32 current = 1;
-  while (current > 0) {
-    u32* rm = g.scratch;
-    u32 nrm = 0;
-    for (u32 base = 0; base < g.n; base += 64) {
-      u32 const i = base + lane_id();
-      bool flag = false;
-      if (i < g.n && g.alive[i]) {
-        bool const anchor = static_cast<i64>(i) == g.source || static_cast<i64>(i) == g.sink;
-        if (g.comp[i] == comp && !anchor && g.nedge[i] <= 1) {
-          u32 const uniq = g.len[i] - static_cast<u32>(g.k) + 1;
-          flag = uniq < static_cast<u32>(g.k);
-        }
+// RemoveTips (graph.cpp:801-840): one round of tip collection, in index order; the caller removes them and
+// re-compresses until a round finds none
+__device__ __forceinline__ u32 collect_tips(Win& g, u32 comp, u32* rm) {
+  u32 nrm = 0;
+  for (u32 base = 0; base < g.n; base += 64) {
+    u32 const i = base + lane_id();
+    bool flag = false;
+    if (i < g.n && g.alive[i]) {
+      bool const anchor = static_cast<i64>(i) == g.source || static_cast<i64>(i) == g.sink;
+      if (g.comp[i] == comp && !anchor && g.nedge[i] <= 1) {
+        u32 const uniq = g.len[i] - static_cast<u32>(g.k) + 1;
+        flag = uniq < static_cast<u32>(g.k);
       }
-      ordered_append(flag, i, rm, nrm);
     }
-    wave_sync_mem();
-    if (nrm > 0) {
-      for (u32 x = 0; x < nrm; ++x) remove_node(g, rm[x]);
-      compress_graph(g, comp);
-    }
-    current = nrm;
+    ordered_append(flag, i, rm, nrm);
   }
+  wave_sync_mem();
+  return nrm;
 }
 
 // ---- sequence spelling ----
@@ -666,7 +659,7 @@ __device__ __forceinline__ u8 slice_base(const Win& g, u32 o, u32 d, u32 j) {  /
 }
 // append the oriented sequence of `node` (dflt: stored orientation, else reverse complement) minus its
 // first `skip` bases to out[*pos..], bounded by cap.  Returns false on overflow.
-__device__ bool emit_node_seq(const Win& g, u32 node, bool dflt, u32 skip, u8* out, u32* pos, u32 cap) {
+__device__ __forceinline__ bool emit_node_seq(const Win& g, u32 node, bool dflt, u32 skip, u8* out, u32* pos, u32 cap) {
   bool ok = true;
   if (dflt) {
     for (u32 s = g.head[node]; s != kNoNode; s = g.snext[s]) {
@@ -710,7 +703,7 @@ struct OnlineStats {  // base/compute_stats.h:75-125
   __device__ f64 sd() const { return sqrt(variance()); }
 };
 
-__device__ void isort_u32(u32* v, u32 n) {
+__device__ __forceinline__ void isort_u32(u32* v, u32 n) {
   for (u32 i = 1; i < n; ++i) {
     u32 const x = v[i];
     u32 j = i;
@@ -721,7 +714,7 @@ __device__ void isort_u32(u32* v, u32 n) {
     v[j] = x;
   }
 }
-__device__ u32 median_sorted(const u32* v, u32 n) {  // compute_stats.h:146-159 on sorted data
+__device__ __forceinline__ u32 median_sorted(const u32* v, u32 n) {  // compute_stats.h:146-159 on sorted data
   if (n == 0) return 0;
   if (n == 1) return v[0];
   u32 const half = v[n / 2];
@@ -922,13 +915,20 @@ __global__ __launch_bounds__(64, 4) void k_clean(CleanArgs A) {
     const u8* ref_anchor = g.refb + cand_soff[ci];
 
     // ---- PruneComponent (graph.cpp:515-540) ----
-    compress_graph(g, comp);
-    CPROF_ACC(3);
-    remove_low_cov(g, comp);
-    CPROF_ACC(4);
-    compress_graph(g, comp);
-    CPROF_ACC(5);
-    remove_tips(g, comp);
+    // compress; remove low coverage; compress; { remove tips; compress } until no tip is left -- written as
+    // one loop so that the (large, fully inlined) compression code exists once
+#pragma nounroll
+    for (int phase = 0;; ++phase) {
+      if (phase == 1) remove_low_cov(g, comp);
+      if (phase >= 2) {
+        u32* rm = g.scratch;
+        u32 const nrm = collect_tips(g, comp, rm);
+        if (nrm == 0) break;
+        for (u32 x = 0; x < nrm; ++x) remove_node(g, rm[x]);
+      }
+      compress_graph(g, comp);
+      if (phase == 0) CPROF_ACC(3);
+    }
     CPROF_ACC(6);
     if (g.flags & 4u) break;
 
