@@ -21,8 +21,8 @@ namespace ma {
 namespace {
 
 #ifdef MA_PROFILE
-__device__ __forceinline__ unsigned long long g_cprof[16];
-__device__ __forceinline__ unsigned long long g_cwin[4096 * 4];
+__device__ unsigned long long g_cprof[16];
+__device__ unsigned long long g_cwin[4096 * 4];
 #define CCOUNT(slot) do {} while (0)
 #else
 #define CCOUNT(slot) do {} while (0)
@@ -803,6 +803,7 @@ __global__ __launch_bounds__(64, 4) void k_clean(CleanArgs A) {
   CPROF_T0();
 #ifdef MA_PROFILE
   unsigned long long const t_begin = __builtin_amdgcn_s_memtime();
+  u32 dbg_rounds = 0;
 #endif
 
   for (u32 i = lane; i < g.n; i += 64) {
@@ -817,26 +818,66 @@ __global__ __launch_bounds__(64, 4) void k_clean(CleanArgs A) {
 
   CPROF_ACC(0);
   // ---- MarkConnectedComponents (graph.cpp:392-463): ids in discovery order over canonical order ----
+  // The reference labels components in BFS discovery order starting from the smallest unvisited node, i.e.
+  // component ids increase with the components' smallest node index.  Computed lane-parallel: every node
+  // carries the smallest node index it knows of in its component (min over neighbours + pointer jumping
+  // until nothing changes: O(log n) rounds on the chains of a k-mer graph), then the roots are numbered
+  // in index order.
   u32 ncomp_all = 0;
   {
-    u32* q = g.scratch;  // FIFO; every node is pushed once per incident edge at most -> bound by visited check
-    for (u32 i = 0; i < g.n; ++i) {
-      if (g.comp[i] != 0) continue;
-      ncomp_all++;
-      u32 qh = 0, qt = 0;
-      q[qt++] = i;
-      g.comp[i] = ncomp_all;
-      while (qh < qt) {
-        u32 const cur = q[qh++];
-        for (int x = 0; x < g.nedge[cur]; ++x) {
-          u32 const d = g.edge[cur * kEdgeCap + x] >> 2;
-          if (g.comp[d] == 0) {
-            g.comp[d] = ncomp_all;
-            q[qt++] = d;
-          }
+    u32* lab = g.scratch;          // [n] smallest known node index of the component
+    u32* cid = g.scratch + NC;     // [n] component id of a root
+    for (u32 i = lane; i < g.n; i += 64) lab[i] = i;
+    wave_sync_mem();
+    // FastSV-style hooking (Zhang, Azad, Hu 2020): lab[] is a forest of pointers towards smaller indices;
+    // every edge hooks the parent of one end (and the end itself) onto the grandparent of the other, then
+    // every node shortcuts to its grandparent.  At the fixed point every tree is a star rooted at the
+    // smallest index of its component.
+    u32 rounds = 0;
+    while (true) {
+      ++rounds;
+      bool changed = false;
+      for (u32 i = lane; i < g.n; i += 64) {
+        u32 const pu = lab[i];
+        u32 const gu = lab[pu];
+        u32 const ne = g.nedge[i];
+        u32 best = gu;
+        for (u32 x = 0; x < ne; ++x) {
+          u32 const v = g.edge[i * kEdgeCap + x] >> 2;
+          best = min(best, lab[lab[v]]);
+        }
+        if (best < gu) {
+          atomicMin(&lab[pu], best);
+          atomicMin(&lab[i], best);
+          changed = true;
         }
       }
+      wave_sync_mem();
+      for (u32 i = lane; i < g.n; i += 64) {
+        u32 const pu = lab[i];
+        u32 const gu = lab[pu];
+        if (gu < pu) {
+          lab[i] = gu;
+          changed = true;
+        }
+      }
+      wave_sync_mem();
+      if (!__ballot(changed)) break;
     }
+    for (u32 base = 0; base < g.n; base += 64) {
+      u32 const i = base + lane;
+      bool const root = i < g.n && lab[i] == i;
+      unsigned long long const m = __ballot(root);
+      if (root) cid[i] = ncomp_all + 1 + static_cast<u32>(__popcll(m & ((1ull << lane) - 1ull)));
+      ncomp_all += static_cast<u32>(__popcll(m));
+    }
+    wave_sync_mem();
+    for (u32 i = lane; i < g.n; i += 64) g.comp[i] = cid[lab[i]];
+    wave_sync_mem();
+#ifdef MA_PROFILE
+    dbg_rounds = rounds;
+#endif
+    (void)rounds;
   }
   CPROF_ACC(1);
   // component sizes + anchors in one pass (FindSource / FindSink, graph.cpp:469-509): components are
@@ -1306,7 +1347,7 @@ __global__ __launch_bounds__(64, 4) void k_clean(CleanArgs A) {
   if (w < 4096) {
     g_cwin[w * 4 + 0] = __builtin_amdgcn_s_memtime() - t_begin;
     g_cwin[w * 4 + 1] = g.n;
-    g_cwin[w * 4 + 2] = ncomp_all;
+    g_cwin[w * 4 + 2] = dbg_rounds;
     g_cwin[w * 4 + 3] = static_cast<unsigned long long>(ncand);
   }
 #endif
