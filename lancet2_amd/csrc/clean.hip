@@ -218,6 +218,13 @@ __device__ __forceinline__ void slices_drop_back(Win& g, u32 node, u32 nb) {
   }
 }
 
+// floor((a * la + b * lb) / (la + lb)) of node.cpp:93-104; the 64-bit division is ~10x the cost of the 32-bit one
+__device__ __forceinline__ u32 weighted_floor_avg(u32 a, u64 la, u32 b, u64 lb) {
+  u64 const num = static_cast<u64>(a) * la + static_cast<u64>(b) * lb, den = la + lb;
+  if ((num >> 32) == 0 && (den >> 32) == 0) return static_cast<u32>(num) / static_cast<u32>(den);
+  return static_cast<u32>(num / den);
+}
+
 // Node::Merge (node.cpp:81-112) + Kmer::Merge / MergeCords (kmer.cpp:48-109)
 __device__ __forceinline__ void merge_node(Win& g, u32 x, u32 b, u32 kind) {
   u32 const K1 = static_cast<u32>(g.k) - 1;
@@ -244,15 +251,11 @@ __device__ __forceinline__ void merge_node(Win& g, u32 x, u32 b, u32 kind) {
   g.len[x] += blen - K1;
   g.label[x] |= g.label[b];
   u64 const this_len = g.len[x];  // length AFTER the merge (node.cpp:91)
-  u64 const other_len = blen, total_len = this_len + other_len;
-  for (int s = 0; s < g.S; ++s) {
-    u64 const av = g.cnt[x * g.S + s], bv = g.cnt[b * g.S + s];
-    g.cnt[x * g.S + s] = static_cast<u32>((av * this_len + bv * other_len) / total_len);
-  }
-  for (int r = 0; r < 2; ++r) {
-    u64 const av = g.role[x * 2 + r], bv = g.role[b * 2 + r];
-    g.role[x * 2 + r] = static_cast<u32>((av * this_len + bv * other_len) / total_len);
-  }
+  u64 const other_len = blen;
+  for (int s = 0; s < g.S; ++s)
+    g.cnt[x * g.S + s] = weighted_floor_avg(g.cnt[x * g.S + s], this_len, g.cnt[b * g.S + s], other_len);
+  for (int r = 0; r < 2; ++r)
+    g.role[x * 2 + r] = weighted_floor_avg(g.role[x * 2 + r], this_len, g.role[b * 2 + r], other_len);
 }
 
 // IsPotentialBuddyEdge (graph.cpp:758-799); conn = edge value stored at src
@@ -421,7 +424,8 @@ __device__ __forceinline__ void compress_node_fast(Win& g, u32 nid, bool dflt, u
 #pragma unroll
     for (int t = 0; t < kMaxSamples; ++t) bcnt[t] = t < S ? g.cnt[d * S + t] : 0u;
     u32 const brole0 = g.role[d * 2], brole1 = g.role[d * 2 + 1];
-    u32 const bdesc = g.sdesc[bhead == kNoNode ? d : bhead];
+    u32 const bdesc_self = g.sdesc[d];  // issued with the batch: a never-merged node's only slice is itself
+    u32 const bdesc = (bhead == d || bhead == kNoNode) ? bdesc_self : g.sdesc[bhead];
     // ---- is_potential_buddy(nid, cand) ----
     if (xn == 1 && bn == 1 && (xe0 >> 2) == d && (be0 >> 2) == nid) break;
     if (bn > 2 || bn == 0) break;
@@ -529,13 +533,12 @@ __device__ __forceinline__ void compress_node_fast(Win& g, u32 nid, bool dflt, u
     xlen += blen - K1;
     xlabel |= blabel;
     {
-      u64 const this_len = xlen, other_len = blen, total_len = this_len + other_len;  // node.cpp:91
+      u64 const this_len = xlen, other_len = blen;  // node.cpp:91: length AFTER the merge
 #pragma unroll
       for (int t = 0; t < kMaxSamples; ++t)
-        if (t < S)
-          xcnt[t] = static_cast<u32>((static_cast<u64>(xcnt[t]) * this_len + static_cast<u64>(bcnt[t]) * other_len) / total_len);
-      xrole0 = static_cast<u32>((static_cast<u64>(xrole0) * this_len + static_cast<u64>(brole0) * other_len) / total_len);
-      xrole1 = static_cast<u32>((static_cast<u64>(xrole1) * this_len + static_cast<u64>(brole1) * other_len) / total_len);
+        if (t < S) xcnt[t] = weighted_floor_avg(xcnt[t], this_len, bcnt[t], other_len);
+      xrole0 = weighted_floor_avg(xrole0, this_len, brole0, other_len);
+      xrole1 = weighted_floor_avg(xrole1, this_len, brole1, other_len);
     }
     // ---- edges (graph.cpp:600-645) ----
     if (xe0 == cand) xe0 = xe1;  // erase_edge(nid, cand)
