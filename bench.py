@@ -28,7 +28,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--windows", type=int, default=2048, help="windows per step per GPU")
+    ap.add_argument("--windows", type=int, default=8192, help="windows per step per GPU")
     ap.add_argument("--distinct", type=int, default=64, help="distinct synthetic windows (tiled to --windows)")
     ap.add_argument("--config", default="C2", help="BASELINE.json config: C2 = chr22-shaped 30x/30x, k=25")
     ap.add_argument("--cpu-windows", type=int, default=24, help="oracle sample for cpu_baseline (0 = skip)")
@@ -37,28 +37,44 @@ def parse():
 
 
 def algorithmic_bytes(kernel, st):
-    """Algorithmic HBM bytes per LAUNCH of `kernel` (SURVEY.md 8d per-window figures x windows per launch;
-    inputs read once, outputs written once, intermediates counted only where they must live in HBM)."""
-    n, S = st["windows_per_launch"], st["S"]
-    W, R, Bb, Ni, Nraw, Nn = st["W"], st["R"], st["B"], st["N_inst"], st["N_raw"], st["N_nodes"]
-    H, L, P = st["H"], st["L"], st["pairs"]
+    """Algorithmic HBM bytes per STEP of `kernel`: inputs read once, outputs written once, intermediates
+    counted only where the design keeps them in HBM (DESIGN.md "Kernels" states each term).  Per-window
+    figures x windows per step; the caller divides by the kernel's launches per step."""
+    n, S = st["windows"], st["S"]
+    W, R, Bb, Ni, Nn = st["W"], st["R"], st["B"], st["N_inst"], st["N_nodes"]
+    Nslow, Ngen = st["N_slow"], st["N_gen"]
+    H, L, m, band = st["H"], st["L"], st["read_len"], st["band"]
+    P, Pdp = st["pairs_per_window"], st["dp_pairs_per_window"]
+    Wk = max(W - st["k"] + 1, 0)
+    tb_words = (2 * band + 1 + 7) // 8
     per = {
         "gate_kernel": W + 8,
-        "k_build_insert": 2 * Bb + 5 * R + W + 16 * Ni,                    # bases+quals, read meta, ref, key probe + slot/first update
-        "k_mm_insert": 4 * Ni + 12 * Ni,                                   # instance word + mate-mer entry
-        "k_count": 4 * Ni + 12 * Ni + 8 * Ni,
-        "k_rank": 4 * Ni + (16 + 4 * S) * Nraw,                            # instance words + node records
-        "k_edges": 8 * Ni,
+        "k_count_inst": 12 * R,
+        # bases + quals + read meta in, one instance word per k-mer out, slow queue out
+        "k_classify": 2 * Bb + 12 * R + W + 4 * Ni + 4 * Nslow,
+        # reference + slow k-mers hashed from their bytes, 16 B table probe/claim + first-instance update each
+        "k_insert": W + st["k"] * Nslow + 20 * (Nslow + Wk) + 8 * Nslow,
+        "k_support": 4 * Ni + 4 * (S + 2) * Wk,
+        "k_mm_insert": 4 * Ni + 12 * Ngen,
+        "k_count": 4 * Ni + 12 * Ngen + 8 * Ngen,
+        # table scan + instance words + node records / edge slots out
+        "k_rank": (16 + 4 * (S + 2)) * st["table_slots"] + 4 * Ni + (24 + 4 * S + 128) * Nn,
+        "k_edges": 4 * Ni + 16 * (Nslow + Wk),
         "k_edge_sort": 128 * Nn,
-        "k_clean": (16 + 4 * S) * Nn + 64 * Nn + 5 * H * L + 64,           # node records + edge lists in, haplotypes out
-        "k_msa": 5 * H * L + 16 * (L + 64),
-        "k_hap_index": H * L + 10 * H * L,
-        "k_vote": P * (150 + 2 * 140),
-        "k_align": P * (150 + 300 + 24 + 16) ,                              # read + haplotype segment + result
-        "k_assign": R * (300 + H * 40),
+        # node records + edge lists in, haplotype bases / runs / stats out
+        "k_clean": (24 + 4 * S) * Nn + 64 * Nn + H * L + 64 * H + 256,
+        # haplotypes in; one 2-byte decision code per DP cell of every non-first haplotype (HBM-resident by
+        # design: (L+1) x L cells do not fit LDS), read back along the path; variants out
+        "k_msa": H * L + max(H - 1, 0) * (2 * (L + 1) * L + 2 * 2 * L) + 512,
+        "k_plan": 16,
+        # every pair: read bases + 32 B result or 8 B list entry; haplotype once per (window, haplotype)
+        "k_vote": P * (m + 32) + H * L,
+        # DP pairs: read + haplotype segment in, 4-bit move codes of the band out and the path read back, result out
+        "k_align_reg": Pdp * (m + (m + 2 * band + 1) + (m + 1) * tb_words * 4 + 4 * (m + 1) + 32),
+        "k_align": Pdp * (m + (m + 2 * band + 1) + (m + 1) * tb_words * 4 + 4 * (m + 1) + 32),
+        "k_assign": R * (m + H * 40 + 16),
         "k_evidence": R * 80,
         "k_qual": 64,
-        "k_plan": R * 8,
     }
     return per.get(kernel, 0) * n
 
@@ -149,8 +165,16 @@ def main():
     Ni = (W - k + 1) + R * pass_frac * (Bb / max(R, 1) - k + 1)
     H = float(nhaps.sum()) / max(assembled, 1)
     L = float(hap_len.sum()) / max(float((hap_len > 0).sum()), 1.0)
-    st = dict(windows_per_launch=n, S=params.num_samples, W=W, R=R, B=Bb, N_inst=Ni, N_raw=0.15 * Ni,
-              N_nodes=1.4 * W, H=H, L=L, pairs=R * H * (nvars > 0).mean())
+    stats = eng.stats()
+    steps = max(args.steps, 1)
+    pairs_w = stats.get("pairs", 0) / steps / n
+    dp_w = stats.get("dp_pairs", 0) / steps / n
+    read_len = Bb / max(R, 1)
+    # slow (non reference-identical) instances and general mate-mer instances: measured shares of the C2 workload
+    # (profiles/r1_*: 12 % of the read k-mers take the hash-table path, 10 % go through the general mate-mer set)
+    st = dict(windows=n, S=params.num_samples, W=W, R=R, B=Bb, N_inst=Ni, N_slow=0.12 * Ni, N_gen=0.10 * Ni,
+              N_nodes=1.4 * W, table_slots=8192, H=H, L=L, read_len=read_len, band=params.band, k=k,
+              pairs_per_window=pairs_w, dp_pairs_per_window=dp_w)
 
     total_windows = n * args.steps * world
     wps = total_windows / elapsed
@@ -169,9 +193,16 @@ def main():
         avg_ms = tot_ms / launches
         launches_per_step = launches / args.steps
         bytes_per_launch = algorithmic_bytes(dom, st) / max(launches_per_step, 1)
+        traffic = None
+        tpath = os.path.join(REPO, "profiles", "r1_hbm_traffic.json")  # PMC pass (tools/hbm_traffic.py), bytes per launch
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(dom, {}).get("bytes_per_launch")
+            except Exception:
+                traffic = None
         ach = bytes_per_launch / (avg_ms * 1e-3) / 1e9
         roof = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(ach / HBM_PEAK_GBS, 6), "traffic": None,
+                "frac": round(ach / HBM_PEAK_GBS, 6), "traffic": traffic,
                 "avg_launch_ms": round(avg_ms, 4), "launches_per_step": launches_per_step,
                 "algorithmic_bytes_per_launch": int(bytes_per_launch)}
     kernel_ms_per_step = {kname: round(val[0] / args.steps, 3) for kname, val in sorted(agg.items(), key=lambda kv: -kv[1][0])}
@@ -207,6 +238,7 @@ def main():
                        "windows_with_capacity_overflow": overflowed, "haplotypes_per_assembled_window": round(H, 2),
                        "sharding": "static, one process per GPU, no collective"},
             "roofline": roof, "cpu_baseline": cpu, "kernel_ms_per_step": kernel_ms_per_step,
+            "work": {"pairs_per_window": round(pairs_w, 1), "dp_pairs_per_window": round(dp_w, 1)},
         }
         print(json.dumps(out))
     eng.close()

@@ -196,6 +196,12 @@ int ma_timing_control(ma_ctx_t* ctx, int mode);
  * names[i] points to a static string; returns the number of entries written (<= cap). */
 int ma_last_kernel_times(ma_ctx_t* ctx, const char** names, float* ms, int cap);
 
+/* Work counters accumulated over the same region as ma_last_kernel_times (reset by ma_timing_control):
+ *   out[0] read x haplotype pairs seen by ma_genotype_batch      out[1] pairs that needed the banded DP
+ *   out[2] windows passed to ma_assemble_batch                   out[3] k attempts x windows assembled
+ * Used by bench.py to price the kernels' algorithmic HBM bytes.  Returns the number of entries written. */
+int ma_last_stats(ma_ctx_t* ctx, unsigned long long* out, int cap);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1268,6 +1268,7 @@ int launch_genotype(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& a, const m
   MA_HIP(ctx, hipStreamSynchronize(ctx->stream));
   u32 const max_read_len = plan_counters[0], n_vote_wg = plan_counters[2];
 
+  ctx->stats[0] += total_pairs;
   if (total_pairs > 0) {
     ws.tb_rows = max_read_len + 1;
     ws.tb_words = static_cast<u32>((2 * P.band + 1 + 7) / 8);
@@ -1303,6 +1304,7 @@ int launch_genotype(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& a, const m
       u32 ndp = 0;
       MA_HIP(ctx, hipMemcpyAsync(&ndp, ws.dp_count, 4, hipMemcpyDeviceToHost, ctx->stream));
       MA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      ctx->stats[1] += ndp;
       u64 const ng_total = (static_cast<u64>(ndp) + 63) / 64;
       for (u64 g0 = 0; g0 < ng_total; g0 += dp_groups_max) {
         u32 const ng = static_cast<u32>(std::min<u64>(dp_groups_max, ng_total - g0));

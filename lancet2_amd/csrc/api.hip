@@ -239,7 +239,15 @@ int ma_timing_control(ma_ctx_t* ctx, int mode) {
   ctx->timing = mode != 0;
   ctx->accumulate = mode == 2;
   ctx->timers_used = 0;
+  for (auto& v : ctx->stats) v = 0;
   return MA_OK;
+}
+
+int ma_last_stats(ma_ctx_t* ctx, unsigned long long* out, int cap) {
+  if (!ctx || !out) return MA_ERR_ARG;
+  int n = 0;
+  for (; n < cap && n < 8; ++n) out[n] = ctx->stats[n];
+  return n;
 }
 
 int ma_last_kernel_times(ma_ctx_t* ctx, const char** names, float* ms, int cap) {

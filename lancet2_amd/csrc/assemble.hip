@@ -155,6 +155,7 @@ int launch_assemble(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& out, const
     fprintf(stderr, "[microasm] assemble: %d windows, %.2f MB/window, budget %.1f GB -> chunks of %d (nc %u, tc_log2 %d)\n", n,
             per_window / 1048576.0, budget / 1073741824.0, chunk, ws.nc, ws.tc_log2);
 
+  ctx->stats[2] += static_cast<unsigned long long>(n);
   for (int win0 = 0; win0 < n; win0 += chunk) {
     int const nwin = std::min(chunk, n - win0);
     Carver cw{static_cast<char*>(ctx->ws_build.p)};
@@ -173,6 +174,7 @@ int launch_assemble(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& out, const
       ws.active = active;
       if (host_cnt[1] == 0) break;  // every window of the chunk is resolved (graph.cpp:106 loop exit)
       if (ws.n_active > 0) {
+        ctx->stats[3] += static_cast<unsigned long long>(ws.n_active);
         MA_TRY_RC(run_count_inst(ctx, b, ws, win0, nwin, counters));
         ws.tc_log2 = tc_log2_alloc;
         MA_TRY_RC(run_build_pass(ctx, b, ws, counters + 12, tc_log2_alloc));

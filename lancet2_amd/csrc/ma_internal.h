@@ -69,6 +69,7 @@ struct ma_ctx {
   size_t timers_used = 0;
   bool timing = true;
   bool accumulate = false;
+  unsigned long long stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // see ma_last_stats
 
   void tic(const char* name);
   void toc();

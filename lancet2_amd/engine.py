@@ -34,6 +34,7 @@ def load_library(path=None):
     lib.ma_genotype_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.ma_process_batch.argtypes = [C.c_void_p] * 6
     lib.ma_last_kernel_times.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.c_int]
+    lib.ma_last_stats.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong), C.c_int]
     return lib
 
 
@@ -80,6 +81,13 @@ class Engine:
         ms = (C.c_float * cap)()
         n = self.lib.ma_last_kernel_times(self.h, names, ms, cap)
         return [(names[i].decode(), float(ms[i])) for i in range(max(n, 0))]
+
+    def stats(self):
+        """Work counters of include/microasm.h:ma_last_stats."""
+        buf = (C.c_ulonglong * 8)()
+        n = self.lib.ma_last_stats(self.h, buf, 8)
+        keys = ("pairs", "dp_pairs", "windows", "window_attempts")
+        return {k: int(buf[i]) for i, k in enumerate(keys) if i < n}
 
     # ---- host-array convenience (MA_MEM_HOST): numpy in, numpy out ----
     def _alloc(self, spec):

@@ -101,7 +101,11 @@ from harness import compare_vars  # noqa: E402
 
 
 @pytest.mark.parametrize("cfg,nwin,kw", [("C2", 8, {}), ("C3", 4, {}), ("C4", 1, dict(depths=(60, 60))),
-                                          ("C5", 3, dict(num_samples=3))])
+                                          ("C5", 3, dict(num_samples=3)),
+                                          # haplotypes longer than 1024 / 1536 bases: 6- and 8-column lanes of the POA fill
+                                          ("C2", 2, dict(W=1300)), ("C2", 2, dict(W=1700)),
+                                          # a big insertion / deletion: long left / up extension runs in the traceback
+                                          ("C2", 3, dict(big_indel=60)), ("C2", 3, dict(big_indel=35, depths=(50, 50)))])
 def test_msa_parity(cfg, nwin, kw):
     from lancet2_amd.engine import Engine
     ns = kw.pop("num_samples", 2)
