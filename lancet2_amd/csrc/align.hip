@@ -185,6 +185,7 @@ struct HapIdx {
   u32* rplanes;     // this wave's read planes: [3][rwords]
   u32 rwords;
   u32* dpbuf;       // this wave's pending DP pairs: [64] + count at [64]
+  u32 hap_amb;      // the haplotype holds a base that is not A/C/G/T
 #ifdef MA_PROFILE
   unsigned long long* prof;  // this wave's phase cycle counters
 #endif
@@ -288,11 +289,17 @@ __global__ __launch_bounds__(256) void k_vote(GArgs A, u32 hist_len, u32 rwords)
   __shared__ unsigned long long sh_prof[4][8];
   if (lane < 8) sh_prof[wave][lane] = 0;
   unsigned long long const k_t0 = __builtin_amdgcn_s_memtime();
+  u32 hap_amb = 0;
+  for (u32 x = lane; x < pw; x += 64) hap_amb |= hbad[x];
+  hap_amb = __ballot(hap_amb != 0) ? 1u : 0u;
   HapIdx const ix{head, next, code, hlo, hhi, hbad, rplanes_all + static_cast<size_t>(wave) * 3 * rwords, rwords,
-                  dpbuf_all + wave * 65, sh_prof[wave]};
+                  dpbuf_all + wave * 65, hap_amb, sh_prof[wave]};
 #else
+  u32 hap_amb = 0;
+  for (u32 x = lane; x < pw; x += 64) hap_amb |= hbad[x];
+  hap_amb = __ballot(hap_amb != 0) ? 1u : 0u;
   HapIdx const ix{head, next, code, hlo, hhi, hbad, rplanes_all + static_cast<size_t>(wave) * 3 * rwords, rwords,
-                  dpbuf_all + wave * 65};
+                  dpbuf_all + wave * 65, hap_amb};
 #endif
   u16* hist = hist_all + static_cast<size_t>(wave) * hist_len;
   // software pipeline: the next read's bases are in flight while the current read is voted
@@ -402,8 +409,12 @@ __device__ __forceinline__ void vote_pair(GArgs const& A, u64 lp, PairId id, Hap
   // 16-bit LDS counters: atomic add on the containing 32-bit word.  A read that sits on one diagonal makes
   // all 64 lanes hit the same counter; those same-address atomics serialise, so the first match of every
   // lane is pre-combined with a ballot and only further matches (repeats) vote one by one.
+  u32 nvotes = 0;  // this lane's votes; summed over the wave below
   {
-    auto vote1 = [&](i32 d) { atomicAdd(reinterpret_cast<u32*>(hist) + (d >> 1), 1u << ((d & 1) * 16)); };
+    auto vote1 = [&](i32 d) {
+      atomicAdd(reinterpret_cast<u32*>(hist) + (d >> 1), 1u << ((d & 1) * 16));
+      nvotes++;
+    };
 #pragma unroll
     for (int t = 0; t < kPos; ++t) {
       u32 const cd = cds[t];
@@ -423,6 +434,7 @@ __device__ __forceinline__ void vote_pair(GArgs const& A, u64 lp, PairId id, Hap
           if (lane == __builtin_ctzll(have)) {
             u32 const cnt = static_cast<u32>(__popcll(have));
             atomicAdd(reinterpret_cast<u32*>(hist) + (d0 >> 1), cnt << ((d0 & 1) * 16));
+            nvotes += cnt;
           }
         } else if (d >= 0) {
           vote1(d);
@@ -480,45 +492,83 @@ __device__ __forceinline__ void vote_pair(GArgs const& A, u64 lp, PairId id, Hap
     return;
   }
   i32 const c = bd - m;
-  // ---- gapless certificate --------------------------------------------------------------------------
-  // If the read lies fully inside the haplotype on the voted diagonal (no overhang), has X <= 2
-  // mismatches and no ambiguous base there, and no other diagonal collected >= m - 10 - 11 X votes, then
-  // the gapless alignment is the UNIQUE optimum of the canonical banded overlap DP:
-  //   * any path with g >= 1 gaps scores <= m - 15 g - 5 X' < m - 5 X   (15 g <= 5 X <= 10 is impossible);
+  // ---- gapless certificates ------------------------------------------------------------------------
+  // P0 = the gapless path on the voted diagonal c (read rows [qs, qe) against haplotype columns [rs, re)),
+  // X its mismatches, S0 = (qe - qs) - 5 X.  Scores: match +1, mismatch -4, a gap of length L costs 12 + 3 L.
+  //
+  // (I) read fully inside the haplotype (no overhang), X <= 2, no ambiguous base on P0, and no other
+  //     diagonal with >= m - 10 - 11 X votes: P0 is the UNIQUE optimum of the banded overlap DP:
+  //   * any path with g >= 1 gaps scores <= m - 15 g < m - 5 X;
   //   * a gapless path on another diagonal d' scoring >= m - 5 X has X' <= X mismatches over >= m - 5X + 5X'
   //     bases, hence >= m - 10 - 11 X exact 11-mers, i.e. that many votes -- excluded by the vote bound.
-  // So (score, rs, re, CIGAR = mM) can be written without running the DP.  Everything else goes to k_align.
-  bool const inside = c >= 0 && c + m <= n;
-  u32 mism = 0, amb = 0;
-  if (inside) {
+  //
+  // (II) the read overhangs ONE end of the haplotype by o bases (the overhang is soft clipped), X <= 2, no
+  //     ambiguous base anywhere in read or haplotype, and 11 S0 > 6 m + 50 + 5 V_off where V_off is the number
+  //     of votes that did NOT go to c.  Again P0 is the unique optimum:
+  //   * a path P != P0 that pairs some row on diagonal c: rows inside the overlap gain at most 5 each, and only
+  //     the X mismatch rows of P0 can gain at all; overhang rows can only be paired on diagonals c + d, d > 0,
+  //     there are at most d_max of them (+1 each) and coming back to c costs a gap of total length >= d_max:
+  //     score(P) - S0 <= 5 X + d_max - (12 + 3 d_max) < 0; without overhang rows P needs >= 1 gap: <= 5 X - 15 < 0.
+  //   * a path that never touches c is g + 1 gapless segments on other diagonals with L_s bases and x_s
+  //     mismatches; a segment contains >= L_s - 10 - 11 x_s exact 11-mers, each of which is a vote off c, so
+  //     sum x_s >= (L - 10 (g+1) - V_off) / 11 with L = sum L_s <= m, and
+  //     score <= L - 5 sum x_s - 15 g <= (6 m + 50 (g+1) + 5 V_off) / 11 - 15 g <= (6 m + 50 + 5 V_off) / 11 < S0.
+  //   Every prefix of a unique optimum is optimal for its end cell, so the traceback's diagonal-first rule
+  //   retraces P0 down to the start cell, and no other end cell reaches S0.
+  // Either way (score, rs, re, qs, qe, CIGAR) is written without running the DP; the rest goes to k_align.
+  i32 const o_left = c < 0 ? -c : 0, o_right = c + m > n ? c + m - n : 0;
+  bool const inside = o_left == 0 && o_right == 0;
+  i32 const qs = o_left, qe = m - o_right;  // overlap rows [qs, qe)
+  u32 mism = 0, amb = 0, ramb = 0;
+  if (qe - qs > 0 && (o_left == 0 || o_right == 0)) {
     for (i32 i = 32 * lane; i < m; i += 32 * 64) {  // 32 bases per lane: XOR of the bit planes
-      u32 const valid = m - i >= 32 ? 0xFFFFFFFFu : ((1u << (m - i)) - 1u);
-      u32 const xlo = rlo[i >> 5] ^ plane32(ix.hlo, c + i), xhi = rhi[i >> 5] ^ plane32(ix.hhi, c + i);
-      u32 const bad = rbad[i >> 5] | plane32(ix.hbad, c + i);
-      mism += __popc((xlo | xhi | bad) & valid);  // an ambiguous base never equals anything
-      amb |= (bad & valid) ? 1u : 0u;
+      i32 const lo = max(qs - i, 0), hi = min(qe - i, 32);  // overlap bits of this word: [lo, hi)
+      u32 const rb_bad = rbad[i >> 5];
+      ramb |= rb_bad;  // bits past the read's end are zero
+      if (hi > lo) {
+        u32 const valid = (hi >= 32 ? 0xFFFFFFFFu : ((1u << hi) - 1u)) & ~((1u << lo) - 1u);
+        // haplotype bits aligned to read bit 0 of this word: haplotype position c + i + b for bit b >= lo
+        i32 const hp = c + i + lo;  // >= 0
+        u32 const hl = plane32(ix.hlo, hp) << lo, hh = plane32(ix.hhi, hp) << lo, hbd = plane32(ix.hbad, hp) << lo;
+        u32 const bad = rb_bad | hbd;
+        mism += __popc(((rlo[i >> 5] ^ hl) | (rhi[i >> 5] ^ hh) | bad) & valid);  // an ambiguous base never equals anything
+        amb |= (bad & valid) ? 1u : 0u;
+      }
     }
   }
+  u32 vtot = nvotes;
   for (int off = 32; off > 0; off >>= 1) {
     mism += __shfl_xor(mism, off);
     amb |= __shfl_xor(amb, off);
+    ramb |= __shfl_xor(ramb, off);
+    vtot += __shfl_xor(vtot, off);
   }
   VPROF_ACC(5);
-  bool const fast = inside && !amb && mism <= 2 && static_cast<i32>(v2) + 10 + 11 * static_cast<i32>(mism) < m &&
-                    m - 5 * static_cast<i32>(mism) >= A.prm.min_aln_score && m < (1 << 27);
+  i32 const X = static_cast<i32>(mism);
+  i32 const S0 = (qe - qs) - 5 * X;
+  i32 const v_off = static_cast<i32>(vtot) - static_cast<i32>(best);
+  bool const ok_common = !amb && X <= 2 && S0 >= A.prm.min_aln_score && m < (1 << 27);
+  bool const fast_in = inside && ok_common && static_cast<i32>(v2) + 10 + 11 * X < m;
+  bool const fast_ov = !inside && (o_left == 0 || o_right == 0) && ok_common && !ramb && !ix.hap_amb &&
+                       11 * S0 > 6 * m + 50 + 5 * v_off && A.prm.max_cigar >= 2;
+  bool const fast = fast_in || fast_ov;
   if (lane == 0) {
     if (fast) {
       size_t const rec = static_cast<size_t>(id.r) * A.prm.max_haps + id.slot;
       i32* arec = A.o.aln_rec + rec * 6;
       u32* acig = A.o.aln_cigar + rec * (1 + A.prm.max_cigar);
       arec[0] = 1;
-      arec[1] = m - 5 * static_cast<i32>(mism);
-      arec[2] = c;
-      arec[3] = c + m;
-      arec[4] = 0;
-      arec[5] = m;
-      acig[0] = 1;
-      acig[1] = static_cast<u32>(m) << 4;
+      arec[1] = S0;
+      arec[2] = c + qs;
+      arec[3] = c + qe;
+      arec[4] = qs;
+      arec[5] = qe;
+      // BuildCigar (genotyper.cpp:45-69): S(qs) + core + S(m - qe); ops: 0 M, 4 S
+      u32 nc = 0;
+      if (qs > 0) acig[1 + nc++] = (static_cast<u32>(qs) << 4) | 4u;
+      acig[1 + nc++] = static_cast<u32>(qe - qs) << 4;
+      if (qe < m) acig[1 + nc++] = (static_cast<u32>(m - qe) << 4) | 4u;
+      acig[0] = nc;
       A.ws.centre[lp] = 0x7FFFFFFE;
     } else {
       A.ws.centre[lp] = c;
