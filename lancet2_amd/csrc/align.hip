@@ -515,7 +515,13 @@ __device__ __forceinline__ void vote_pair(GArgs const& A, u64 lp, PairId id, Hap
   //     score <= L - 5 sum x_s - 15 g <= (6 m + 50 (g+1) + 5 V_off) / 11 - 15 g <= (6 m + 50 + 5 V_off) / 11 < S0.
   //   Every prefix of a unique optimum is optimal for its end cell, so the traceback's diagonal-first rule
   //   retraces P0 down to the start cell, and no other end cell reaches S0.
-  // Either way (score, rs, re, qs, qe, CIGAR) is written without running the DP; the rest goes to k_align.
+  // (III) NO HIT: the read overhangs one end, nothing is ambiguous, and no path can reach min_aln_score:
+  //   * paths touching c score <= max(S0, L0 - 14) with L0 = qe - qs (first bullet of (II), any X);
+  //   * paths avoiding c pair at most Lmax = min(m, L0 + band) rows (the band keeps them within `band`
+  //     diagonals of c, so the rows that hang further out than that can not be paired at all), hence score
+  //     <= (6 Lmax + 50 + 5 V_off) / 11 by the second bullet of (II).
+  // In cases (I)/(II) (score, rs, re, qs, qe, CIGAR) is written without running the DP, in case (III) the
+  // record stays "no alignment"; everything else goes to k_align.
   i32 const o_left = c < 0 ? -c : 0, o_right = c + m > n ? c + m - n : 0;
   bool const inside = o_left == 0 && o_right == 0;
   i32 const qs = o_left, qe = m - o_right;  // overlap rows [qs, qe)
@@ -552,8 +558,13 @@ __device__ __forceinline__ void vote_pair(GArgs const& A, u64 lp, PairId id, Hap
   bool const fast_ov = !inside && (o_left == 0 || o_right == 0) && ok_common && !ramb && !ix.hap_amb &&
                        11 * S0 > 6 * m + 50 + 5 * v_off && A.prm.max_cigar >= 2;
   bool const fast = fast_in || fast_ov;
+  i32 const L0 = qe - qs, lmax = min(m, L0 + A.ws.band), ms = A.prm.min_aln_score;
+  bool const nohit = !inside && (o_left == 0 || o_right == 0) && !ramb && !ix.hap_amb && S0 < ms && L0 - 14 < ms &&
+                     6 * lmax + 50 + 5 * v_off < 11 * ms;
   if (lane == 0) {
-    if (fast) {
+    if (nohit) {
+      A.ws.centre[lp] = 0x7FFFFFFF;  // record stays zero: no alignment
+    } else if (fast) {
       size_t const rec = static_cast<size_t>(id.r) * A.prm.max_haps + id.slot;
       i32* arec = A.o.aln_rec + rec * 6;
       u32* acig = A.o.aln_cigar + rec * (1 + A.prm.max_cigar);
