@@ -1,6 +1,7 @@
 """Developer tool: aggregate a rocprofv3 --pmc counter_collection.csv per kernel name."""
 import csv
 import glob
+import re
 import sys
 from collections import defaultdict
 
@@ -10,7 +11,8 @@ calls = defaultdict(int)
 for path in glob.glob(root + "/**/*counter_collection.csv", recursive=True):
     with open(path) as fh:
         for row in csv.DictReader(fh):
-            name = row["Kernel_Name"].split("(")[0].split("::")[-1][:40]
+            m = re.search(r"(k_[a-z_0-9]+|gate_kernel)", row["Kernel_Name"])
+            name = m.group(1) if m else row["Kernel_Name"].split("(")[0][:40]
             agg[name][row["Counter_Name"]] += float(row["Counter_Value"])
             calls[(name, row["Dispatch_Id"])] += 0
 ndisp = defaultdict(set)
