@@ -94,7 +94,7 @@ int launch_assemble(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& out, const
 
   ws.tc_log2 = std::max(10, ceil_log2(static_cast<u64>(max_inst) * 4 / 3 + 16));
   ws.mc_log2 = std::max(10, ceil_log2(static_cast<u64>(max_read_inst) * 4 / 3 + 16));
-  int const tc_log2_alloc = ws.tc_log2;
+  int const tc_log2_alloc = ws.tc_log2, mc_log2_alloc = ws.mc_log2;
   ws.inst_stride = (max_inst + 63) & ~63u;
   ws.ref_stride = (max_refk + 63) & ~63u;
   ws.max_ref_len = max_refk + static_cast<u32>(P.min_k) + 8;  // longest reference window (+ slack)
@@ -177,6 +177,7 @@ int launch_assemble(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& out, const
         ctx->stats[3] += static_cast<unsigned long long>(ws.n_active);
         MA_TRY_RC(run_count_inst(ctx, b, ws, win0, nwin, counters));
         ws.tc_log2 = tc_log2_alloc;
+        ws.mc_log2 = mc_log2_alloc;  // run_build_pass shrinks both to what this attempt needs
         MA_TRY_RC(run_build_pass(ctx, b, ws, counters + 12, tc_log2_alloc));
         MA_TRY_RC(run_clean_pass(ctx, b, ws, out));
       }

@@ -425,9 +425,10 @@ __global__ __launch_bounds__(kBT) void k_insert(DBatch b, GraphWs ws) {
 
 // (3) k_support: read support of the FAST instances (node.cpp:18-24 + graph.h:102-117), one thread per group
 //     of adjacent reads with equal (qname, role, sample); per-reference-position counters live in LDS.
-__global__ __launch_bounds__(kBT) void k_support(DBatch b, GraphWs ws) {
+__global__ __launch_bounds__(kBT) void k_support(DBatch b, GraphWs ws, u32* max_gen) {
   extern __shared__ unsigned char lds_build[];
   __shared__ u32 xs_flag;
+  __shared__ u32 gen_count;  // instances routed through the general mate-mer set (sizes that set)
   int const a = blockIdx.x;
   int const w = static_cast<int>(ws.active[a]);
   int const k = ws.k;
@@ -453,7 +454,10 @@ __global__ __launch_bounds__(kBT) void k_support(DBatch b, GraphWs ws) {
     l_xkey[i] = 0;
     l_xgrp[i] = 0;
   }
-  if (threadIdx.x == 0) xs_flag = 0;
+  if (threadIdx.x == 0) {
+    xs_flag = 0;
+    gen_count = 0;
+  }
   __syncthreads();
   bool const hints = b.read_hint != nullptr && rsi.len <= ws.max_ref_len + 8;
   // (X) every (qname, role) key must belong to ONE sample and to ONE run of adjacent reads; otherwise the
@@ -516,7 +520,7 @@ __global__ __launch_bounds__(kBT) void k_support(DBatch b, GraphWs ws) {
       if (ws.rd_flag[r0 + gm] || si.nk > 32u * kMaskWords) generic = true;
     }
     i32 hint0 = 0;
-    u32 nk0 = 0;
+    u32 nk0 = 0, ngen = 0;
     for (int mw = 0; mw < kMaskWords; ++mw) l_mask[mw * kBT + threadIdx.x] = 0;
     for (u32 gm = 0; gm < gsize; ++gm) {
       u32 const sx = s_idx + gm;
@@ -536,6 +540,7 @@ __global__ __launch_bounds__(kBT) void k_support(DBatch b, GraphWs ws) {
         if (!(word & kInstErrFree)) continue;
         if (generic || !(word & kInstFast)) {
           inst_slot[ibase + o] = word | kInstGen;  // exact handling by k_mm_insert / k_count
+          ngen++;
           continue;
         }
         u32 const p = word & kInstSlotMask;
@@ -550,8 +555,10 @@ __global__ __launch_bounds__(kBT) void k_support(DBatch b, GraphWs ws) {
         atomicAdd(&l_cnt[p * CW + S + role], 1u);
       }
     }
+    if (ngen) atomicAdd(&gen_count, ngen);
   }
   __syncthreads();
+  if (threadIdx.x == 0) atomicMax(max_gen, gen_count);
   for (u32 i = threadIdx.x; i < rsi.nk * CW; i += kBT) {
     u32 const v = l_cnt[i];
     if (v == 0) continue;
@@ -880,12 +887,11 @@ int run_build_pass(ma_ctx* ctx, const DBatch& b, GraphWs& ws, u32* counters_dev,
   int tc = 10;
   while ((size_t(1) << tc) < (static_cast<size_t>(max_slow) + ws.ref_stride) * 4 / 3 + 16) ++tc;
   ws.tc_log2 = tc < tc_log2_alloc ? tc : tc_log2_alloc;
-  size_t const tcap = size_t(1) << ws.tc_log2, mcap = size_t(1) << ws.mc_log2;
+  int const mc_log2_alloc = ws.mc_log2;
+  size_t const tcap = size_t(1) << ws.tc_log2;
   MA_HIP(ctx, hipMemsetAsync(ws.tbl_key, 0, A * tcap * 8, ctx->stream));
   MA_HIP(ctx, hipMemsetAsync(ws.tbl_first, 0x7F, A * tcap * 4, ctx->stream));  // 0x7F7F7F7F > any instance
   MA_HIP(ctx, hipMemsetAsync(ws.tbl_cnt, 0, A * tcap * 4 * (S + 2), ctx->stream));
-  MA_HIP(ctx, hipMemsetAsync(ws.mm_key, 0, A * mcap * 8, ctx->stream));
-  MA_HIP(ctx, hipMemsetAsync(ws.mm_min, 0xFF, A * mcap * 4, ctx->stream));
   ctx->tic("k_insert");
   hipLaunchKernelGGL(k_insert, dim3(ws.n_active), dim3(kBT), 0, ctx->stream, b, ws);
   ctx->toc();
@@ -894,8 +900,21 @@ int run_build_pass(ma_ctx* ctx, const DBatch& b, GraphWs& ws, u32* counters_dev,
     MA_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_support), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     static_cast<int>(lds_s)));
   ctx->tic("k_support");
-  hipLaunchKernelGGL(k_support, dim3(ws.n_active), dim3(kBT), lds_s, ctx->stream, b, ws);
+  MA_HIP(ctx, hipMemsetAsync(counters_dev + 1, 0, 4, ctx->stream));
+  hipLaunchKernelGGL(k_support, dim3(ws.n_active), dim3(kBT), lds_s, ctx->stream, b, ws, counters_dev + 1);
   ctx->toc();
+  // the general mate-mer set only has to hold the instances k_support routed to it
+  {
+    u32 max_gen = 0;
+    MA_HIP(ctx, hipMemcpyAsync(&max_gen, counters_dev + 1, 4, hipMemcpyDeviceToHost, ctx->stream));
+    MA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    int mc = 10;
+    while ((size_t(1) << mc) < static_cast<size_t>(max_gen) * 4 / 3 + 16) ++mc;
+    ws.mc_log2 = mc < mc_log2_alloc ? mc : mc_log2_alloc;
+  }
+  size_t const mcap = size_t(1) << ws.mc_log2;
+  MA_HIP(ctx, hipMemsetAsync(ws.mm_key, 0, A * mcap * 8, ctx->stream));
+  MA_HIP(ctx, hipMemsetAsync(ws.mm_min, 0xFF, A * mcap * 4, ctx->stream));
   ctx->tic("k_mm_insert");
   hipLaunchKernelGGL(k_mm_insert, dim3(ws.n_active), dim3(kBT), 0, ctx->stream, b, ws);
   ctx->toc();
