@@ -31,7 +31,7 @@ def parse():
     ap.add_argument("--windows", type=int, default=8192, help="windows per step per GPU")
     ap.add_argument("--distinct", type=int, default=64, help="distinct synthetic windows (tiled to --windows)")
     ap.add_argument("--config", default="C2", help="BASELINE.json config: C2 = chr22-shaped 30x/30x, k=25")
-    ap.add_argument("--cpu-windows", type=int, default=24, help="oracle sample for cpu_baseline (0 = skip)")
+    ap.add_argument("--cpu-windows", type=int, default=96, help="oracle sample for cpu_baseline (0 = skip)")
     ap.add_argument("--no-cpu", action="store_true")
     return ap.parse_args()
 
@@ -79,8 +79,50 @@ def algorithmic_bytes(kernel, st):
     return per.get(kernel, 0) * n
 
 
+def _oracle_chunk(job):
+    """One worker of the CPU baseline: the whole path (oracle) over `count` windows starting at `first`."""
+    config, first, count, num_samples = job
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    from harness import OracleEngine
+    from lancet2_amd import capi, synth
+    params = capi.default_params(min_k=25, max_k=25, num_samples=num_samples)
+    sub, sn, snr = synth.make_config_batch(config, count, first_index=first)
+    orc = OracleEngine(params)
+    t0 = time.perf_counter()
+    orc.gate(sub, sn, snr)
+    oa = orc.assemble(sub, sn, snr)
+    ov = orc.msa(sub, sn, snr, oa)
+    orc.genotype(sub, sn, snr, oa, ov, debug=False)
+    return sn, time.perf_counter() - t0
+
+
+def cpu_baselines(args, num_samples):
+    """Oracle (a port of the reference path) on a bounded sample of the same workload: (i) one thread -- the
+    reported cpu_baseline -- and (ii) one worker process per host core, the reference's own threading model
+    (pipeline_executor.cpp:174-197).  Runs BEFORE the GPU is initialised (it forks)."""
+    import multiprocessing as mp
+    n1 = args.cpu_windows
+    sn, ct = _oracle_chunk((args.config, 10_000, n1, num_samples))
+    cpu = {"value": round(sn / ct, 3), "unit": "windows/s", "cores": 1, "kind": "port",
+           "sample": f"{sn} windows of the same {args.config} workload through the whole path (oracle, 1 thread, {ct:.1f} s)"}
+    cores = os.cpu_count() or 1
+    per = 12
+    jobs = [(args.config, 10_000 + 1000 * i, per, num_samples) for i in range(cores)]
+    with mp.get_context("fork").Pool(cores) as pool:
+        res = pool.map(_oracle_chunk, jobs, chunksize=1)
+    tot = sum(r[0] for r in res)
+    slowest = max(r[1] for r in res)  # workers run concurrently; input synthesis (Python) is not timed
+    cpu_mt = {"value": round(tot / slowest, 3), "unit": "windows/s", "cores": cores, "kind": "port",
+              "sample": f"{tot} windows, one oracle process per host core ({cores} x {per} windows), slowest worker {slowest:.1f} s"}
+    return cpu, cpu_mt
+
+
 def main():
     args = parse()
+    world0 = int(os.environ.get("WORLD_SIZE", "1"))
+    cpu = cpu_mt = None
+    if world0 == 1 and not args.no_cpu and args.cpu_windows > 0:
+        cpu, cpu_mt = cpu_baselines(args, 3 if args.config == "C5" else 2)
     import torch
     import torch.distributed as dist
 
@@ -207,23 +249,23 @@ def main():
                 "algorithmic_bytes_per_launch": int(bytes_per_launch)}
     kernel_ms_per_step = {kname: round(val[0] / args.steps, 3) for kname, val in sorted(agg.items(), key=lambda kv: -kv[1][0])}
 
-    # ---- CPU baseline: the oracle (a port of the reference path) on a bounded sample, rank 0, N = 1 ----
-    cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu and args.cpu_windows > 0:
-        sys.path.insert(0, os.path.join(REPO, "tests"))
-        from harness import OracleEngine
-        m = min(args.cpu_windows, n0)
-        sub, sn, snr = synth.make_config_batch(args.config, m, first_index=10_000)
-        orc = OracleEngine(params)
-        c0 = time.perf_counter()
-        og = orc.gate(sub, sn, snr)
-        oa = orc.assemble(sub, sn, snr)
-        ov = orc.msa(sub, sn, snr, oa)
-        orc.genotype(sub, sn, snr, oa, ov, debug=False)
-        ct = time.perf_counter() - c0
-        cpu = {"value": round(sn / ct, 3), "unit": "windows/s", "cores": 1, "kind": "port",
-               "sample": f"{sn} windows of the same {args.config} workload through the whole path (oracle, 1 thread, {ct:.1f} s)"}
-        del og
+    # ---- per-stage table: HIP-event time, algorithmic bytes, achieved GB/s; cell rates of the two DP kernels ----
+    stages = {}
+    for kname, (tot_ms, launches) in agg.items():
+        ab = algorithmic_bytes(kname, st)
+        ms_step = tot_ms / args.steps
+        if ab <= 0 or ms_step <= 0:
+            continue
+        gbs = ab / (ms_step * 1e-3) / 1e9
+        stages[kname] = {"ms_per_step": round(ms_step, 3), "algorithmic_MB_per_step": round(ab / 1e6, 1),
+                         "GB_per_s": round(gbs, 1), "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 5)}
+    cells = {}
+    if "k_msa" in agg:
+        c = n * max(H - 1, 0) * (L + 1) * L  # every non-first haplotype against the (L+1)-row graph
+        cells["k_msa_GCUPS"] = round(c / (agg["k_msa"][0] / args.steps * 1e-3) / 1e9, 1)
+    if "k_align_reg" in agg:
+        c = n * dp_w * read_len * (2 * params.band + 1)
+        cells["k_align_reg_GCUPS"] = round(c / (agg["k_align_reg"][0] / args.steps * 1e-3) / 1e9, 1)
 
     if rank == 0:
         out = {
@@ -237,7 +279,8 @@ def main():
                        "assembled_windows_per_s": round(asm_wps, 2), "assembled_fraction": round(assembled / n, 4),
                        "windows_with_capacity_overflow": overflowed, "haplotypes_per_assembled_window": round(H, 2),
                        "sharding": "static, one process per GPU, no collective"},
-            "roofline": roof, "cpu_baseline": cpu, "kernel_ms_per_step": kernel_ms_per_step,
+            "roofline": roof, "cpu_baseline": cpu, "cpu_baseline_all_cores": cpu_mt,
+            "kernel_ms_per_step": kernel_ms_per_step, "stages": stages, "dp_cell_rates": cells,
             "work": {"pairs_per_window": round(pairs_w, 1), "dp_pairs_per_window": round(dp_w, 1)},
         }
         print(json.dumps(out))
