@@ -196,6 +196,12 @@ int ma_timing_control(ma_ctx_t* ctx, int mode);
  * names[i] points to a static string; returns the number of entries written (<= cap). */
 int ma_last_kernel_times(ma_ctx_t* ctx, const char** names, float* ms, int cap);
 
+/* ma_process_batch runs a batch as `n` contiguous window ranges concurrently, each on its own HIP stream and
+ * workspace (the stages have complementary bottlenecks, so two ranges in flight fill each other's gaps).
+ * n = 0 (default): automatic -- 2 for batches of >= 2048 windows, else 1.  Results do not depend on n.
+ * The caller's stream (ma_set_stream) still orders the call as a whole. */
+int ma_set_streams(ma_ctx_t* ctx, int n);
+
 /* Work counters accumulated over the same region as ma_last_kernel_times (reset by ma_timing_control):
  *   out[0] read x haplotype pairs seen by ma_genotype_batch      out[1] pairs that needed the banded DP
  *   out[2] windows passed to ma_assemble_batch                   out[3] k attempts x windows assembled

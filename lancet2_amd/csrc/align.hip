@@ -1334,7 +1334,7 @@ int launch_genotype(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& a, const m
     ws.tb_rows = max_read_len + 1;
     ws.tb_words = static_cast<u32>((2 * P.band + 1 + 7) / 8);
     size_t const tb_per_group = static_cast<size_t>(ws.tb_rows) * ws.tb_words * 64 * 4;  // 64 pairs
-    size_t budget = std::max<size_t>(size_t(1) << 30, stage_budget(0.15, ctx->ws_misc.cap, size_t(8) << 30));
+    size_t budget = std::max<size_t>(size_t(1) << 30, stage_budget(0.15, ctx->ws_misc.cap, size_t(8) << 30, ctx->hbm_share));
     if (const char* e = getenv("MA_TB_GB")) budget = static_cast<size_t>(atoi(e)) << 30;
     // vote chunks: bounded only by the 8 B / pair of centre + dp_list (and 32-bit local pair ids)
     u64 const pairs_chunk = std::min<u64>(total_pairs, std::min<u64>(u64(1) << 30, budget / 4 / 8));

@@ -2,6 +2,7 @@
 // point fails with MA_ERR_NO_DEVICE when there is no HIP device.
 #include <cstring>
 #include <new>
+#include <thread>
 
 #include "ma_internal.h"
 
@@ -170,6 +171,102 @@ int check_params(const ma_params_t& p) {
 
 }  // namespace
 
+
+namespace {
+
+__global__ void k_rebase_u32(const u32* src, u32* dst, int n, u32 base) {
+  int const i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = src[i] - base;
+}
+
+// advance the non-null pointer members [first, last) of an output struct by `units` x (bytes per unit)
+template <class S>
+void advance_fields(S* s, const std::vector<OutField>& per_unit, size_t first, size_t last, size_t units) {
+  for (size_t i = first; i < last && i < per_unit.size(); ++i) {
+    void*& p = ptr_at(s, per_unit[i].offset);
+    if (p) p = static_cast<char*>(p) + per_unit[i].bytes * units;
+  }
+}
+
+// One contiguous window range [w0, w1) of the batch on a child context.  All pointers are device pointers.
+int run_lane(ma_ctx* ch, hipEvent_t start, const DBatch& full, int w0, int w1, u32 r0, u32 r1, ma_gate_out_t g,
+             ma_asm_out_t a, ma_var_out_t v, ma_geno_out_t q) {
+  MA_HIP(ch, hipSetDevice(ch->device));
+  MA_HIP(ch, hipStreamWaitEvent(ch->stream, start, 0));
+  int const n = w1 - w0;
+  DBatch d = full;
+  d.n_windows = n;
+  d.n_reads = static_cast<i64>(r1) - r0;
+  d.ref_off = full.ref_off + w0;                 // absolute offsets into ref_bases
+  MA_HIP(ch, ch->lane_rwo.reserve(4ull * (n + 1) + 64));
+  u32* rwo = ch->lane_rwo.as<u32>();
+  hipLaunchKernelGGL(k_rebase_u32, dim3((n + 1 + 255) / 256), dim3(256), 0, ch->stream, full.read_win_off + w0, rwo,
+                     n + 1, r0);
+  d.read_win_off = rwo;                          // the lane's reads are numbered from 0 ...
+  d.read_off = full.read_off + r0;               // ... their byte offsets stay absolute
+  d.read_qname_id = full.read_qname_id + r0;
+  d.read_sample = full.read_sample + r0;
+  d.read_flags = full.read_flags + r0;
+  d.read_hint = full.read_hint ? full.read_hint + r0 : nullptr;
+  ma_params_t const& p = ch->prm;
+  advance_fields(&g, gate_fields(p, 1), 0, 2, w0);
+  advance_fields(&a, asm_fields(p, 1), 0, 99, w0);
+  advance_fields(&v, var_fields(p, 1), 0, 99, w0);
+  std::vector<OutField> const gf = geno_fields(p, 1, 1);
+  advance_fields(&q, gf, 0, 2, w0);   // allele_counts, var_qual: per window
+  advance_fields(&q, gf, 2, 6, r0);   // alignment / assignment taps: per read
+  MA_TRY_RC(launch_gate(ch, d, g.max_approx, g.max_exact));
+  MA_TRY_RC(launch_assemble(ch, d, a, g.max_approx));
+  MA_TRY_RC(launch_msa(ch, d, a, v));
+  MA_TRY_RC(launch_genotype(ch, d, a, v, q));
+  MA_HIP(ch, hipEventRecord(ch->lane_done, ch->stream));
+  return MA_OK;
+}
+
+int process_in_lanes(ma_ctx* ctx, int lanes, const DBatch& d, const ma_gate_out_t& g, const ma_asm_out_t& a,
+                     const ma_var_out_t& v, const ma_geno_out_t& q) {
+  while (static_cast<int>(ctx->lanes.size()) < lanes) {
+    ma_ctx* ch = new (std::nothrow) ma_ctx();
+    if (!ch) return MA_ERR_NOMEM;
+    ch->device = ctx->device;
+    ch->memspace = MA_MEM_DEVICE;
+    MA_HIP(ctx, hipStreamCreateWithFlags(&ch->stream, hipStreamNonBlocking));
+    MA_HIP(ctx, hipEventCreateWithFlags(&ch->lane_done, hipEventDisableTiming));
+    ctx->lanes.push_back(ch);
+  }
+  if (!ctx->lane_done) MA_HIP(ctx, hipEventCreateWithFlags(&ctx->lane_done, hipEventDisableTiming));
+  // window boundaries and the read index at each of them
+  std::vector<int> wb(lanes + 1);
+  std::vector<u32> rb(lanes + 1, 0);
+  for (int k = 0; k <= lanes; ++k) wb[k] = static_cast<int>(static_cast<long long>(d.n_windows) * k / lanes);
+  for (int k = 0; k <= lanes; ++k)
+    MA_HIP(ctx, hipMemcpyAsync(&rb[k], d.read_win_off + wb[k], 4, hipMemcpyDeviceToHost, ctx->stream));
+  MA_HIP(ctx, hipEventRecord(ctx->lane_done, ctx->stream));  // inputs (and staging copies) are ready after this
+  MA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  std::vector<int> rc(lanes, MA_OK);
+  std::vector<std::thread> th;
+  for (int k = 0; k < lanes; ++k) {
+    ma_ctx* ch = ctx->lanes[k];
+    ch->prm = ctx->prm;
+    ch->timing = ctx->timing;
+    ch->accumulate = ctx->accumulate;
+    if (!ch->accumulate) ch->timers_used = 0;
+    ch->hbm_share = ctx->hbm_share / lanes;
+    th.emplace_back([&, k, ch]() { rc[k] = run_lane(ch, ctx->lane_done, d, wb[k], wb[k + 1], rb[k], rb[k + 1], g, a, v, q); });
+  }
+  for (auto& t : th) t.join();
+  for (int k = 0; k < lanes; ++k) {
+    if (rc[k] != MA_OK) {
+      ctx->err = "lane " + std::to_string(k) + ": " + ctx->lanes[k]->err;
+      return rc[k];
+    }
+    MA_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->lanes[k]->lane_done, 0));
+  }
+  return MA_OK;
+}
+
+}  // namespace
+
 extern "C" {
 
 void ma_default_params(ma_params_t* p) {
@@ -217,6 +314,13 @@ void ma_destroy(ma_ctx_t* ctx) {
     (void)hipEventDestroy(t.beg);
     (void)hipEventDestroy(t.end);
   }
+  for (ma_ctx* ch : ctx->lanes) {
+    hipStream_t const cs = ch->stream;
+    ch->lane_rwo.release();
+    ma_destroy(ch);
+    if (cs) (void)hipStreamDestroy(cs);
+  }
+  if (ctx->lane_done) (void)hipEventDestroy(ctx->lane_done);
   delete ctx;
 }
 
@@ -240,13 +344,23 @@ int ma_timing_control(ma_ctx_t* ctx, int mode) {
   ctx->accumulate = mode == 2;
   ctx->timers_used = 0;
   for (auto& v : ctx->stats) v = 0;
+  for (ma_ctx* ch : ctx->lanes) ma_timing_control(ch, mode);
+  return MA_OK;
+}
+
+int ma_set_streams(ma_ctx_t* ctx, int n) {
+  if (!ctx || n < 0 || n > 8) return MA_ERR_ARG;
+  ctx->n_lanes = n;
   return MA_OK;
 }
 
 int ma_last_stats(ma_ctx_t* ctx, unsigned long long* out, int cap) {
   if (!ctx || !out) return MA_ERR_ARG;
   int n = 0;
-  for (; n < cap && n < 8; ++n) out[n] = ctx->stats[n];
+  for (; n < cap && n < 8; ++n) {
+    out[n] = ctx->stats[n];
+    for (ma_ctx* ch : ctx->lanes) out[n] += ch->stats[n];
+  }
   return n;
 }
 
@@ -259,6 +373,14 @@ int ma_last_kernel_times(ma_ctx_t* ctx, const char** names, float* ms, int cap) 
     float t = 0.f;
     (void)hipEventElapsedTime(&t, ctx->timers[i].beg, ctx->timers[i].end);
     ms[n] = t;
+  }
+  for (ma_ctx* ch : ctx->lanes) {  // kernels launched on the child lanes of ma_process_batch
+    for (size_t i = 0; i < ch->timers_used && n < cap; ++i, ++n) {
+      names[n] = ch->timers[i].name;
+      float t = 0.f;
+      (void)hipEventElapsedTime(&t, ch->timers[i].beg, ch->timers[i].end);
+      ms[n] = t;
+    }
   }
   return n;
 }
@@ -356,10 +478,18 @@ int ma_process_batch(ma_ctx_t* ctx, const ma_batch_t* b, const ma_gate_out_t* ga
   MA_TRY(v.prepare(ctx, vars, var_fields(ctx->prm, d.n_windows), 16, false));
   OutMirror<ma_geno_out_t> q;
   MA_TRY(q.prepare(ctx, geno, geno_fields(ctx->prm, d.n_windows, d.n_reads), 32, false));
-  MA_TRY(launch_gate(ctx, d, g.dev.max_approx, g.dev.max_exact));
-  MA_TRY(launch_assemble(ctx, d, a.dev, g.dev.max_approx));
-  MA_TRY(launch_msa(ctx, d, a.dev, v.dev));
-  MA_TRY(launch_genotype(ctx, d, a.dev, v.dev, q.dev));
+  int lanes = ctx->n_lanes > 0 ? ctx->n_lanes : (d.n_windows >= 2048 ? 2 : 1);
+  if (const char* e = getenv("MA_STREAMS")) lanes = atoi(e) > 0 ? atoi(e) : lanes;
+  if (lanes > d.n_windows / 2) lanes = d.n_windows / 2 > 0 ? d.n_windows / 2 : 1;
+  if (lanes > 8) lanes = 8;
+  if (lanes <= 1) {
+    MA_TRY(launch_gate(ctx, d, g.dev.max_approx, g.dev.max_exact));
+    MA_TRY(launch_assemble(ctx, d, a.dev, g.dev.max_approx));
+    MA_TRY(launch_msa(ctx, d, a.dev, v.dev));
+    MA_TRY(launch_genotype(ctx, d, a.dev, v.dev, q.dev));
+  } else {
+    MA_TRY(process_in_lanes(ctx, lanes, d, g.dev, a.dev, v.dev, q.dev));
+  }
   MA_TRY(g.download(ctx));
   MA_TRY(a.download(ctx));
   MA_TRY(v.download(ctx));

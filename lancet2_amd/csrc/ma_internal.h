@@ -1,6 +1,7 @@
 // Internal definitions of the MI355X microassembly engine (product code; never includes oracle/).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 
 #include <cstdint>
 #include <cstdio>
@@ -70,6 +71,14 @@ struct ma_ctx {
   bool timing = true;
   bool accumulate = false;
   unsigned long long stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // see ma_last_stats
+  // ma_process_batch splits a batch into `n_lanes` contiguous window ranges that run concurrently on child
+  // contexts (own stream + workspaces): the stages have complementary bottlenecks (latency-bound graph
+  // cleaning, VALU-bound DP, HBM-bound table passes), so two batches in flight fill the gaps of one.
+  int n_lanes = 0;  // 0 = automatic (2 for batches of >= 2048 windows, else 1)
+  std::vector<ma_ctx*> lanes;
+  ma::DevBuf lane_rwo;      // rebased read_win_off of a child lane
+  hipEvent_t lane_done = nullptr;
+  double hbm_share = 1.0;   // fraction of the device this context plans its workspaces for
 
   void tic(const char* name);
   void toc();
@@ -117,10 +126,16 @@ int launch_genotype(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& a, const m
 // Workspace budget of one stage: a fixed share of the device's HBM (288 GB on MI355X), so that the
 // chunking does not depend on the order in which the stages first allocated, capped by what is free now
 // (the stage's own buffer counts as free: it is reused).
-inline size_t stage_budget(double share_of_total, size_t own_cap, size_t fallback) {
+inline size_t stage_budget(double share_of_total, size_t own_cap, size_t fallback, double ctx_share = 1.0) {
   size_t free_b = 0, total_b = 0;
   if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return fallback;
-  size_t const want = static_cast<size_t>(static_cast<double>(total_b) * share_of_total);
+  // several engines on one GPU (one per stream): MA_HBM_SHARE = the fraction of the device this one may plan for
+  double scale = ctx_share;
+  if (const char* e = getenv("MA_HBM_SHARE")) {
+    double const v = atof(e);
+    if (v > 0.0 && v <= 1.0) scale *= v;
+  }
+  size_t const want = static_cast<size_t>(static_cast<double>(total_b) * share_of_total * scale);
   size_t const avail = free_b + own_cap;
   size_t const guard = size_t(2) << 30;
   size_t const cap = avail > guard ? avail - guard : avail / 2;

@@ -1651,7 +1651,7 @@ int launch_msa(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& a, const ma_var
   ws.row_cells = static_cast<size_t>(ws.row_slots) * 3 * ws.w_stride;
 
   size_t const per_window = ws.code_cells * 2 + ws.row_cells * 4 + (static_cast<size_t>(pn) + 8) * 4;
-  size_t budget = stage_budget(0.30, ctx->ws_poa.cap, size_t(24) << 30);
+  size_t budget = stage_budget(0.30, ctx->ws_poa.cap, size_t(24) << 30, ctx->hbm_share);
   if (const char* e = getenv("MA_WS_GB")) budget = static_cast<size_t>(atoi(e)) << 30;
   int const chunk = static_cast<int>(std::max<size_t>(1, std::min<size_t>(n, budget / per_window)));
   MA_HIP(ctx, ctx->ws_poa.reserve(per_window * static_cast<size_t>(chunk) + 1024));

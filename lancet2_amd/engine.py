@@ -35,6 +35,7 @@ def load_library(path=None):
     lib.ma_process_batch.argtypes = [C.c_void_p] * 6
     lib.ma_last_kernel_times.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.c_int]
     lib.ma_last_stats.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong), C.c_int]
+    lib.ma_set_streams.argtypes = [C.c_void_p, C.c_int]
     return lib
 
 
@@ -81,6 +82,10 @@ class Engine:
         ms = (C.c_float * cap)()
         n = self.lib.ma_last_kernel_times(self.h, names, ms, cap)
         return [(names[i].decode(), float(ms[i])) for i in range(max(n, 0))]
+
+    def set_streams(self, n):
+        """Number of concurrent window ranges ma_process_batch uses (0 = automatic)."""
+        self._check(self.lib.ma_set_streams(self.h, n), "ma_set_streams")
 
     def stats(self):
         """Work counters of include/microasm.h:ma_last_stats."""

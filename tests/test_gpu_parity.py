@@ -149,6 +149,27 @@ def test_genotype_parity(cfg, nwin, kw):
     assert want["allele_counts"].sum() > 0 and (want["aln_rec"].reshape(-1, 6)[:, 0] > 0).sum() > 100
 
 
+@pytest.mark.parametrize("streams", [2, 3])
+def test_process_batch_in_concurrent_lanes(streams):
+    """ma_process_batch split into window ranges on separate streams gives the single-stream (= oracle) result."""
+    from lancet2_amd.engine import Engine
+    params = capi.default_params(min_k=25, max_k=25)
+    arrs, n, nr = synth.make_config_batch("C2", 7, first_index=900)
+    orc = OracleEngine(params)
+    want_a = orc.assemble(arrs, n, nr)
+    want_v = orc.msa(arrs, n, nr, want_a)
+    want_q = orc.genotype(arrs, n, nr, want_a, want_v)
+    eng = Engine(params)
+    try:
+        eng.set_streams(streams)
+        _, got_a, got_v, got_q = eng.process(arrs, n, nr, debug=True)
+    finally:
+        eng.close()
+    bad = compare_asm(params, got_a, want_a, n) + compare_vars(params, got_v, want_v, n)
+    bad += compare_geno(params, got_q, want_q, n, nr, want_v["win_nvars"], arrs["read_win_off"])
+    assert not bad, "\n".join(bad[:20])
+
+
 def test_process_batch_end_to_end():
     """gate -> assemble -> msa -> genotype chained on the device equals the oracle chain."""
     from lancet2_amd.engine import Engine
