@@ -198,7 +198,7 @@ int ma_last_kernel_times(ma_ctx_t* ctx, const char** names, float* ms, int cap);
 
 /* ma_process_batch runs a batch as `n` contiguous window ranges concurrently, each on its own HIP stream and
  * workspace (the stages have complementary bottlenecks, so two ranges in flight fill each other's gaps).
- * n = 0 (default): automatic -- 2 for batches of >= 2048 windows, else 1.  Results do not depend on n.
+ * n = 0 (default): automatic -- 3 for batches of >= 6144 windows, 2 for >= 2048, else 1.  Results do not depend on n.
  * The caller's stream (ma_set_stream) still orders the call as a whole. */
 int ma_set_streams(ma_ctx_t* ctx, int n);
 

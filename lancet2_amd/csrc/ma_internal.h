@@ -74,7 +74,7 @@ struct ma_ctx {
   // ma_process_batch splits a batch into `n_lanes` contiguous window ranges that run concurrently on child
   // contexts (own stream + workspaces): the stages have complementary bottlenecks (latency-bound graph
   // cleaning, VALU-bound DP, HBM-bound table passes), so two batches in flight fill the gaps of one.
-  int n_lanes = 0;  // 0 = automatic (2 for batches of >= 2048 windows, else 1)
+  int n_lanes = 0;  // 0 = automatic (3 for batches of >= 6144 windows, 2 for >= 2048, else 1)
   std::vector<ma_ctx*> lanes;
   ma::DevBuf lane_rwo;      // rebased read_win_off of a child lane
   hipEvent_t lane_done = nullptr;
