@@ -72,6 +72,8 @@ struct WgState {
   u32 nn, nseq, nrank, overflow;
   i32 seq_first[16];
   u32 mode, V, L, cw, naln, nslow;
+  u32 band, band_fail;  // this alignment tries the 256-column band first / its traceback ran off the band
+  i32 edge_max;         // maximum H over the band's exit cells
   i32 best;
   u32 best_row;
   i32 ftot[2][4][2];  // fill: per-wave totals of the two prefix maxima, double buffered by row parity
@@ -91,9 +93,10 @@ struct GL {  // LDS layout of one window's POA graph + scratch
   u32 pn;
   LdsArr<u8> nchar, nin, nout, nal;
   LdsArr<u16> in_tail, out_head, out_lab, al, rank2node, node2rank;
+  LdsArr<u16> npos;  // backbone coordinate of a node (guides the DP band): reference index, or the neighbour's + 1
   // scratch, alignment phase
   LdsArr<u32> rowinfo;
-  LdsArr<u16> rowslot, rowdepth, runhead, slowpred, aln;
+  LdsArr<u16> rowslot, rowdepth, runhead, rowj0, slowpred, aln;
   u32 aln_cap;
   // scratch, graph update (aliases rowinfo .. rowdepth)
   LdsArr<u16> cnode, cpos, ccur;
@@ -104,8 +107,8 @@ struct GL {  // LDS layout of one window's POA graph + scratch
 };
 
 __host__ __device__ inline size_t poa_lds_bytes(u32 pn, u32 ml) {
-  size_t const graph = size_t(40) * pn;
-  size_t const s_aln = size_t(10) * (pn + 2) + 8 * kSlowCap + size_t(4) * (pn + ml + 2);
+  size_t const graph = size_t(42) * pn;
+  size_t const s_aln = size_t(12) * (pn + 2) + 8 * kSlowCap + size_t(4) * (pn + ml + 2);
   size_t const s_topo = size_t(10) * pn;
   return kStBytes + graph + (s_aln > s_topo ? s_aln : s_topo) + 16;
 }
@@ -126,14 +129,16 @@ __device__ __forceinline__ GL poa_carve(u32 PN, u32 ML) {
   o += 32 * PN;
   g.rank2node.off = o;
   g.node2rank.off = o + 2 * PN;
-  o += 4 * PN;
+  g.npos.off = o + 4 * PN;
+  o += 6 * PN;
   u32 const S = o;
   g.rowinfo.off = S;
   g.rowslot.off = S + 4 * (PN + 2);
   g.rowdepth.off = S + 6 * (PN + 2);
   g.runhead.off = S + 8 * (PN + 2);
-  g.slowpred.off = S + 10 * (PN + 2);
-  g.aln.off = S + 10 * (PN + 2) + 8 * kSlowCap;
+  g.rowj0.off = S + 10 * (PN + 2);
+  g.slowpred.off = S + 12 * (PN + 2);
+  g.aln.off = S + 12 * (PN + 2) + 8 * kSlowCap;
   g.aln_cap = PN + ML + 2;
   g.cnode.off = S;
   g.cpos.off = S + 2 * (ML + 2);
@@ -149,7 +154,7 @@ __device__ __forceinline__ GL poa_carve(u32 PN, u32 ML) {
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // ---- serial graph primitives (thread 0): spoa::Graph ----
-__device__ i32 pg_add_node(GL const& g, u8 ch) {
+__device__ i32 pg_add_node(GL const& g, u8 ch, u32 pos) {
   if (ST.nn >= g.pn) {
     ST.overflow = 1;
     return 0;
@@ -157,6 +162,7 @@ __device__ i32 pg_add_node(GL const& g, u8 ch) {
   u32 const id = ST.nn++;
   g.nchar[id] = ch;
   g.nin[id] = g.nout[id] = g.nal[id] = 0;
+  g.npos[id] = static_cast<u16>(min(pos, 0xFFFFu));
   return static_cast<i32>(id);
 }
 // spoa::Graph::AddEdge (weights dropped).  Also used lane-parallel by the graph update: there every
@@ -185,7 +191,7 @@ __device__ i32 pg_add_sequence(GL const& g, const u8* seq, u32 begin, u32 end) {
   u32 const first = ST.nn;
   u16 const lab = static_cast<u16>(1u << ST.nseq);
   for (u32 i = begin; i < end; ++i) {
-    i32 const cur = pg_add_node(g, seq[i]);
+    i32 const cur = pg_add_node(g, seq[i], i);  // unaligned stretch: its own index is as good a guess as any
     if (ST.overflow) return -1;
     if (prev >= 0) pg_add_edge(g, static_cast<u32>(prev), static_cast<u32>(cur), lab);
     prev = cur;
@@ -763,6 +769,389 @@ __device__ void poa_fill(GL const& g, PoaWs const& ws, u16* codes, i32* rows, i3
 #endif
 }
 
+// ---- banded fill (wave 0 only): 256 columns around the expected diagonal, exact by certificate ----
+// Haplotypes differ from the graph's backbone by a few variants, so the optimal path stays close to the
+// diagonal "column = backbone coordinate of the row's node".  Row i gets the 256-column window
+// [j0(i), j0(i) + 255] (j0 = 1 mod 4) centred on that coordinate and ONE wavefront fills it: no barriers, no
+// LDS exchange, a quarter of the cells.
+// Everything outside the window counts as minus infinity.  Exactness is certified afterwards:
+//   every way a path can leave the band passes through an "exit" cell (a window cell whose up / diagonal /
+//   right successor lies outside the successor row's window; row 0 / column 0 cells next to uncovered
+//   ground); all transition scores are <= 0, so a path that ever left the band scores <= E = the maximum
+//   H over exit cells.  If S (the best end score found inside the band) satisfies S - 32 > E then
+//   (a) S is the true optimum, (b) every DP value the backtrack can test at a path cell is either one it
+//   compares against a value >= S (then equality forces exactness on both sides) or a gap-state value that
+//   is >= its path neighbour's H - 26 >= S - 26 > E, hence also attained inside the band: the banded
+//   decision codes along the path equal the full DP's.  Otherwise the caller repeats the row-synchronous
+//   full fill.
+// Lane l owns the four window columns j0 + 4 l .. j0 + 4 l + 3.  When the window slides (always by a multiple
+// of four columns, usually one lane every four rows) the register rows slide with it: a whole-wave DPP shift;
+// the columns that fall off the left edge are exits, the ones that enter start at minus infinity.
+__device__ __forceinline__ i32 wave_shl1(i32 x, i32 fill) { return dpp_mov<0x130, 0xF>(x, fill); }  // lane l <- lane l + 1
+
+__device__ void poa_fill_band(GL const& g, PoaWs const& ws, u16* codes, i32* rows, i32* hlast, u32 V, u32 L, int lane,
+                              const u8* seq, i32* edge_out) {
+  constexpr int CW = 4;
+  constexpr i32 NEG = kScanIdent;
+  i32 H1[CW], F1[CW], O1[CW], H2[CW], F2[CW], O2[CW];
+#pragma unroll
+  for (int c = 0; c < CW; ++c) H1[c] = F1[c] = O1[c] = H2[c] = F2[c] = O2[c] = kNegInf;
+  u32 sc[CW];
+  i32 edge = kNegInf;
+  u32 info = g.rowinfo[1];
+  u32 depth = g.rowdepth[1];
+  u32 j0n = g.rowj0[1];
+  u32 j0 = j0n;  // window the register rows are aligned to
+  auto load_sc = [&]() {
+#pragma unroll
+    for (int c = 0; c < CW; ++c) {
+      u32 const j = j0 + 4u * lane + c;
+      sc[c] = (j >= 1 && j <= L) ? seq[j - 1] : 0u;
+    }
+  };
+  load_sc();
+  // the four characters that enter at lane 63 on the next one-lane slide (uniform; fetched one slide ahead)
+  u32 sc_in[CW];
+  auto load_sc_in = [&]() {
+#pragma unroll
+    for (int c = 0; c < CW; ++c) {
+      u32 const j = j0 + 256 + c;
+      sc_in[c] = j <= L ? seq[j - 1] : 0u;
+    }
+  };
+  load_sc_in();
+  for (u32 i = 1; i <= V; ++i) {
+    u32 const nch = info & 0xFFu, np = (info >> 8) & 7u;
+    bool const fast = info & RI_FAST, store = info & RI_STORE;
+    u32 const info_cur = info;
+    i32 const h0 = col0_h(depth);
+    u32 const j0_new = j0n;
+    if (i < V) {
+      info = g.rowinfo[i + 1];
+      depth = g.rowdepth[i + 1];
+      j0n = g.rowj0[i + 1];
+    }
+    // ---- slide the register rows to this row's window ----
+    if (j0_new != j0) {
+      i32 const sh = (static_cast<i32>(j0_new) - static_cast<i32>(j0)) / 4;  // lanes; > 0: window moves right
+      // columns that fall off: they had no successor inside the band
+      {
+        bool const dropped = sh > 0 ? lane < sh : lane >= 64 + sh;
+        u32 const jbo = j0 + 4u * lane;
+        if (dropped) {
+#pragma unroll
+          for (int c = 0; c < CW; ++c)
+            if (jbo + c >= 1 && jbo + c <= L) edge = max(edge, max(H1[c], H2[c]));
+        }
+      }
+      if (sh == 1) {
+#pragma unroll
+        for (int c = 0; c < CW; ++c) {
+          H1[c] = wave_shl1(H1[c], kNegInf);
+          F1[c] = wave_shl1(F1[c], kNegInf);
+          O1[c] = wave_shl1(O1[c], kNegInf);
+          H2[c] = wave_shl1(H2[c], kNegInf);
+          F2[c] = wave_shl1(F2[c], kNegInf);
+          O2[c] = wave_shl1(O2[c], kNegInf);
+          sc[c] = static_cast<u32>(wave_shl1(static_cast<i32>(sc[c]), static_cast<i32>(sc_in[c])));
+        }
+        j0 = j0_new;
+      } else {
+        int const src = lane + sh;
+        bool const in = src >= 0 && src < 64;
+#pragma unroll
+        for (int c = 0; c < CW; ++c) {
+          i32 const h1 = __shfl(H1[c], src & 63), f1 = __shfl(F1[c], src & 63), o1 = __shfl(O1[c], src & 63);
+          i32 const h2 = __shfl(H2[c], src & 63), f2 = __shfl(F2[c], src & 63), o2 = __shfl(O2[c], src & 63);
+          H1[c] = in ? h1 : kNegInf;
+          F1[c] = in ? f1 : kNegInf;
+          O1[c] = in ? o1 : kNegInf;
+          H2[c] = in ? h2 : kNegInf;
+          F2[c] = in ? f2 : kNegInf;
+          O2[c] = in ? o2 : kNegInf;
+        }
+        j0 = j0_new;
+        load_sc();
+      }
+      load_sc_in();
+    }
+    u32 const jb = j0 + 4u * lane;
+    // ---- vertical + diagonal part ----
+    i32 hh[CW], ff[CW], oo[CW], hmv[CW];
+    // H(pr, jb - 1) from the left neighbour lane's last column, column 0 at the matrix edge, -inf at the band edge
+    auto left_of = [&](i32 last_col_value, u32 pr) -> i32 {
+      i32 const v = wave_shr1(last_col_value, kNegInf);
+      if (lane != 0) return v;
+      return jb == 1 ? (pr == 0 ? 0 : col0_h(g.rowdepth[pr])) : kNegInf;
+    };
+    // a stored row restricted to this window (its own window may sit elsewhere)
+    auto fetch_store = [&](u32 pr, i32(&th)[CW], i32(&tf)[CW], i32(&to)[CW], i32& thd) {
+      u32 const pj0 = g.rowj0[pr];
+      int const d = (static_cast<i32>(j0) - static_cast<i32>(pj0)) / 4;  // this lane reads the stored lane l + d
+      int const sl = lane + d;
+      bool const in = sl >= 0 && sl < 64;
+      u32 const slot = g.rowslot[pr];
+      const i32* base = rows + static_cast<size_t>(slot) * 3 * ws.w_stride;
+      int4 vh = make_int4(kNegInf, kNegInf, kNegInf, kNegInf), vf = vh, vo = vh;
+      if (in) {
+        vh = *reinterpret_cast<const int4*>(base + 4 * sl);
+        vf = *reinterpret_cast<const int4*>(base + ws.w_stride + 4 * sl);
+        vo = *reinterpret_cast<const int4*>(base + 2 * static_cast<size_t>(ws.w_stride) + 4 * sl);
+      }
+      th[0] = vh.x; th[1] = vh.y; th[2] = vh.z; th[3] = vh.w;
+      tf[0] = vf.x; tf[1] = vf.y; tf[2] = vf.z; tf[3] = vf.w;
+      to[0] = vo.x; to[1] = vo.y; to[2] = vo.z; to[3] = vo.w;
+      // H(pr, jb - 1): the stored column just left of this lane's first one
+      i32 hd = kNegInf;
+      if (jb == 1) {
+        hd = col0_h(g.rowdepth[pr]);
+      } else if (sl >= 1 && sl <= 64) {
+        hd = base[4 * sl - 1];
+      }
+      thd = hd;
+      // stored columns this window does not cover are exits of row pr towards this row
+      int const ml = d > 0 ? lane : (d < 0 ? lane : -1);  // stored lane inspected by this lane
+      if (d != 0 && ml >= 0) {
+        bool const dropped = d > 0 ? ml < d : ml >= 64 + d;
+        if (dropped) {
+          int4 const xh = *reinterpret_cast<const int4*>(base + 4 * ml);
+          u32 const xj = pj0 + 4u * ml;
+          if (xj <= L) edge = max(edge, xh.x);
+          if (xj + 1 <= L) edge = max(edge, xh.y);
+          if (xj + 2 <= L) edge = max(edge, xh.z);
+          if (xj + 3 <= L) edge = max(edge, xh.w);
+        }
+      }
+    };
+    auto fetch = [&](u32 pr, i32(&th)[CW], i32(&tf)[CW], i32(&to)[CW], i32& thd) {
+      if (pr == 0) {
+#pragma unroll
+        for (int c = 0; c < CW; ++c) {
+          th[c] = row0_h(jb + c);
+          tf[c] = kNegInf;
+          to[c] = kNegInf;
+        }
+        thd = row0_h(jb - 1);
+      } else if (pr + 1 == i) {
+#pragma unroll
+        for (int c = 0; c < CW; ++c) {
+          th[c] = H1[c];
+          tf[c] = F1[c];
+          to[c] = O1[c];
+        }
+        thd = left_of(H1[3], pr);
+      } else if (pr + 2 == i) {
+#pragma unroll
+        for (int c = 0; c < CW; ++c) {
+          th[c] = H2[c];
+          tf[c] = F2[c];
+          to[c] = O2[c];
+        }
+        thd = left_of(H2[3], pr);
+      } else {
+        fetch_store(pr, th, tf, to, thd);
+      }
+    };
+    u32 const npe = np ? np : 1u;
+    if (fast) {
+      i32 hd = left_of(H1[3], i - 1);
+#pragma unroll
+      for (int c = 0; c < CW; ++c) {
+        i32 const ph = H1[c];
+        ff[c] = max(F1[c] + E_, ph + G_);
+        oo[c] = max(O1[c] + C_, ph + Q_);
+        hmv[c] = hd + ((nch == sc[c]) ? M_ : N_);
+        hd = ph;
+      }
+    } else {
+      for (u32 x = 0; x < npe; ++x) {
+        u32 const pr = np ? pred_row(g, i, info_cur, x) : 0u;
+        i32 th[CW], tf[CW], to[CW], hd;
+        fetch(pr, th, tf, to, hd);
+#pragma unroll
+        for (int c = 0; c < CW; ++c) {
+          i32 const fv = max(tf[c] + E_, th[c] + G_), ov = max(to[c] + C_, th[c] + Q_);
+          i32 const hv = hd + ((nch == sc[c]) ? M_ : N_);
+          hd = th[c];
+          if (x == 0) {
+            ff[c] = fv;
+            oo[c] = ov;
+            hmv[c] = hv;
+          } else {
+            ff[c] = max(ff[c], fv);
+            oo[c] = max(oo[c], ov);
+            hmv[c] = max(hmv[c], hv);
+          }
+        }
+      }
+      // row 0 ground that this window does not cover (a node without in-edges hangs off the virtual start row)
+      if (np == 0 && j0 + 256 <= L) edge = max(edge, row0_h(j0 + 256));
+      if (np == 0 && j0 > 1) edge = max(edge, row0_h(1));
+    }
+    // the previous rows' cell whose diagonal successor would be the column right of this window
+    if (lane == 63 && jb + 3 < L) edge = max(edge, max(H1[3], H2[3]));
+    // column 0 of this row is an exit when the window does not start at column 1
+    if (j0 > 1) edge = max(edge, h0);
+    // ---- prefix maxima over the window (column 0 enters through lane 0 when the window starts at column 1) ----
+    i32 run1 = (j0 == 1 && lane == 0) ? h0 : NEG, run2 = run1;
+#pragma unroll
+    for (int c = 0; c < CW; ++c) {
+      bool const in = jb + c <= L;
+      i32 const m = max(hmv[c], max(ff[c], oo[c]));
+      hh[c] = m;
+      i32 const j = static_cast<i32>(jb) + c;
+      run1 = max(run1, in ? m + j : NEG);
+      run2 = max(run2, in ? m + 2 * j : NEG);
+    }
+    i32 const inc1 = wave_incl_max(run1, NEG), inc2 = wave_incl_max(run2, NEG);
+    i32 s1 = wave_shr1(inc1, NEG), s2 = wave_shr1(inc2, NEG);
+    if (j0 == 1 && lane == 0) s1 = s2 = h0;
+    i32 ee[CW], qq[CW];
+#pragma unroll
+    for (int c = 0; c < CW; ++c) {
+      i32 const j = static_cast<i32>(jb) + c;
+      bool const in = jb + c <= L;
+      bool const have_left = s1 > -(1 << 28);  // false only for the first window column when it is not column 1
+      i32 const q = have_left ? s1 + Q_ - (j - 1) : kNegInf;
+      i32 const e = have_left ? max(s2 + G_ - 2 * (j - 1), s1 + Q_ + G_ - (j - 2)) : kNegInf;
+      i32 const m = hh[c];
+      s1 = max(s1, in ? m + j : NEG);
+      s2 = max(s2, in ? m + 2 * j : NEG);
+      ee[c] = e;
+      qq[c] = q;
+      hh[c] = max(m, max(e, q));
+    }
+    // ---- (H, E, Q) of the column to the left of this lane's first column ----
+    i32 hN = wave_shr1(hh[3], kNegInf), eN = wave_shr1(ee[3], kNegInf), qN = wave_shr1(qq[3], kNegInf);
+    if (lane == 0) {
+      hN = jb == 1 ? h0 : kNegInf;
+      eN = kNegInf;
+      qN = kNegInf;
+    }
+    // ---- decision codes ----
+    u32 cd[CW];
+    if (fast) {
+      i32 hleft = hN, eleft = eN, qleft = qN;
+#pragma unroll
+      for (int c = 0; c < CW; ++c) {
+        i32 const ph = H1[c];
+        i32 const a1 = F1[c] + E_, a2 = ph + G_, a3 = O1[c] + C_;
+        i32 const fv = ff[c], ov = oo[c], hm = hmv[c], h = hh[c], e = ee[c], q = qq[c];
+        i32 const b1 = eleft + E_, b2 = hleft + G_, b3 = qleft + C_;
+        bool const D = h == hm, U = h == max(fv, ov);
+        bool const eu = (h == a1) || ((h != a2) && (h == a3));
+        bool const elx = (h == b1) || ((h != b2) && (h == b3));
+        bool const lc = (b1 == e) || (b3 == q);
+        bool const us = (fv == a1) || (ov == a3);
+        u32 code = D ? 0u : (U ? 1u : 2u);
+        code |= (!D && (U ? eu : elx)) ? 4u : 0u;
+        code |= lc ? 8u : 0u;
+        code |= us ? 16u : 32u;
+        cd[c] = code;
+        hleft = h;
+        eleft = e;
+        qleft = q;
+      }
+    } else {
+      u32 elmask = 0, lcmask = 0;
+      {
+        i32 hleft = hN, eleft = eN, qleft = qN;
+#pragma unroll
+        for (int c = 0; c < CW; ++c) {
+          i32 const h = hh[c];
+          i32 const b1 = eleft + E_, b2 = hleft + G_, b3 = qleft + C_;
+          if ((h == b1) || ((h != b2) && (h == b3))) elmask |= 1u << c;
+          if ((b1 == ee[c]) || (b3 == qq[c])) lcmask |= 1u << c;
+          hleft = h;
+          eleft = ee[c];
+          qleft = qq[c];
+        }
+      }
+      u32 dmask = 0, umask = 0, eumask = 0, usmask = 0, uhmask = 0;
+      u32 xs[CW] = {0, 0, 0, 0};
+      for (u32 x = 0; x < npe; ++x) {
+        u32 const pr = np ? pred_row(g, i, info_cur, x) : 0u;
+        i32 th[CW], tf[CW], to[CW], hd;
+        fetch(pr, th, tf, to, hd);
+#pragma unroll
+        for (int c = 0; c < CW; ++c) {
+          i32 const a1v = tf[c] + E_, a2v = th[c] + G_, a3v = to[c] + C_, a4v = th[c] + Q_;
+          i32 const hv = hd + ((nch == sc[c]) ? M_ : N_);
+          hd = th[c];
+          i32 const h = hh[c];
+          u32 const bit = 1u << c;
+          if (!(dmask & bit) && h == hv) {
+            dmask |= bit;
+            xs[c] |= x;
+          }
+          bool const t1v = h == a1v, t2v = h == a2v, t3v = h == a3v, t4v = h == a4v;
+          if (!(umask & bit) && (t1v || t2v || t3v || t4v)) {
+            umask |= bit;
+            xs[c] |= x << 2;
+            if (t1v || (!t2v && t3v)) eumask |= bit;
+          }
+          if (np) {
+            if (!(usmask & bit) && ((ff[c] == a1v) || (oo[c] == a3v))) {
+              usmask |= bit;
+              xs[c] |= x << 4;
+            }
+            if (!(uhmask & bit) && ((ff[c] == a2v) || (oo[c] == a4v))) {
+              uhmask |= bit;
+              xs[c] |= x << 6;
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < CW; ++c) {
+        u32 const bit = 1u << c;
+        bool const D = dmask & bit, U = umask & bit;
+        u32 code = D ? 0u : (U ? 1u : 2u);
+        code |= (!D && (U ? ((eumask & bit) != 0) : ((elmask & bit) != 0))) ? 4u : 0u;
+        code |= (lcmask & bit) ? 8u : 0u;
+        bool const us = usmask & bit, uh = uhmask & bit;
+        code |= us ? 16u : (uh ? 32u : 0u);
+        code |= (D ? (xs[c] & 3u) : (U ? ((xs[c] >> 2) & 3u) : 0u)) << 6;
+        code |= (us ? ((xs[c] >> 4) & 3u) : (uh ? ((xs[c] >> 6) & 3u) : 0u)) << 8;
+        cd[c] = code;
+      }
+    }
+    // right exit of this row: the last window column when the haplotype goes on beyond it
+    if (lane == 63 && jb + 3 < L) edge = max(edge, hh[3]);
+    // rotate the register rows
+#pragma unroll
+    for (int c = 0; c < CW; ++c) {
+      H2[c] = H1[c];
+      F2[c] = F1[c];
+      O2[c] = O1[c];
+      H1[c] = hh[c];
+      F1[c] = ff[c];
+      O1[c] = oo[c];
+    }
+    *reinterpret_cast<uint2*>(codes + static_cast<size_t>(i) * 256 + 4u * lane) =
+        make_uint2(cd[0] | (cd[1] << 16), cd[2] | (cd[3] << 16));
+    if (store) {
+      u32 const slot = g.rowslot[i];
+      i32* rb = rows + static_cast<size_t>(slot) * 3 * ws.w_stride + 4u * lane;
+      *reinterpret_cast<int4*>(rb) = make_int4(hh[0], hh[1], hh[2], hh[3]);
+      *reinterpret_cast<int4*>(rb + ws.w_stride) = make_int4(ff[0], ff[1], ff[2], ff[3]);
+      *reinterpret_cast<int4*>(rb + 2 * static_cast<size_t>(ws.w_stride)) = make_int4(oo[0], oo[1], oo[2], oo[3]);
+      __threadfence_block();  // other lanes read it back (lane offsets differ between windows)
+    }
+    if (L >= j0 && L <= j0 + 255 && static_cast<u32>(lane) == (L - j0) / 4) {
+      u32 const cL = (L - j0) & 3u;
+      i32 v = hh[0];
+#pragma unroll
+      for (int c = 1; c < CW; ++c) v = (static_cast<u32>(c) == cL) ? hh[c] : v;
+      hlast[i] = v;
+    } else if (lane == 0 && !(L >= j0 && L <= j0 + 255)) {
+      hlast[i] = kNegInf;
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) edge = max(edge, __shfl_xor(edge, off));
+  if (lane == 0) *edge_out = edge;
+}
+
 // ---- traceback (wave 0, all lanes carry the same state): SisdAlignmentEngine::Convex backtrack ----
 struct EdgeVals {
   i32 h, f, e, o, q;
@@ -786,9 +1175,19 @@ __device__ __forceinline__ EdgeVals edge_vals(GL const& g, u32 i, u32 j) {  // c
   return v;
 }
 
-__device__ u32 poa_traceback(GL const& g, const u16* codes, u32 cw, u32 V, u32 L, u32 best_row, bool have_end, int lane) {
+__device__ u32 poa_traceback(GL const& g, const u16* codes, u32 cw, u32 V, u32 L, u32 best_row, bool have_end, int lane,
+                             bool band) {
   u32 const nl = (L + cw - 1) / cw;
+  bool off_band = false;  // band mode: a cell outside its row's window was needed -> the caller falls back
   auto code_at = [&](u32 i, u32 j) -> u32 {  // i >= 1, j >= 1
+    if (band) {
+      u32 const j0 = g.rowj0[i];
+      if (j < j0 || j > j0 + 255) {
+        off_band = true;
+        return 2u;  // a plain "left" move: lets the caller's loops terminate
+      }
+      return codes[static_cast<size_t>(i) * 256 + (j - j0)];
+    }
     return codes[static_cast<size_t>(i) * (nl * cw) + (j - 1)];
   };
   u32 naln = 0;
@@ -806,7 +1205,7 @@ __device__ u32 poa_traceback(GL const& g, const u16* codes, u32 cw, u32 V, u32 L
   };
   u32 i = have_end ? best_row : 0u, j = have_end ? L : 0u;
   u32 prev_i = 0, prev_j = 0;
-  while (!(i == 0 && j == 0) && !overflow) {
+  while (!(i == 0 && j == 0) && !overflow && !__ballot(off_band)) {
     if (i >= 1 && j >= 1) {
       // 64 cells down the diagonal at once: a run of diagonal moves over rank-consecutive rows
       {
@@ -990,6 +1389,10 @@ __device__ u32 poa_traceback(GL const& g, const u16* codes, u32 cw, u32 V, u32 L
       }
     }
   }
+  if (__ballot(off_band)) {
+    if (lane == 0) ST.band_fail = 1;
+    return 0;
+  }
   if (overflow && lane == 0) ST.overflow = 1;
   return naln;
 }
@@ -1060,6 +1463,7 @@ __global__ __launch_bounds__(kT, 2) void k_msa(MsaArgs A) {
               mode = 2;
               ST.V = V;
               ST.cw = cw;
+              ST.band = (L >= 400 && static_cast<size_t>(V + 1) * 256 <= ws.code_cells) ? 1u : 0u;
             }
           }
         }
@@ -1084,6 +1488,7 @@ __global__ __launch_bounds__(kT, 2) void k_msa(MsaArgs A) {
           g.out_lab[i * kPE] = lab;
           g.rank2node[i] = static_cast<u16>(i);
           g.node2rank[i] = static_cast<u16>(i);
+          g.npos[i] = static_cast<u16>(i);
         }
         __syncthreads();
         if (tid == 0) {
@@ -1118,6 +1523,12 @@ __global__ __launch_bounds__(kT, 2) void k_msa(MsaArgs A) {
         for (u32 x = 0; x < np; ++x)
           if (pr[x] + 1 != i && !(cw <= 8 && pr[x] + 2 == i)) g.rowslot[pr[x]] = 1;
         g.rowinfo[i] = info;
+        {  // band window of this row: 256 columns centred on the node's backbone coordinate, j0 = 1 mod 4
+          i32 const want = static_cast<i32>(g.npos[node]) + 1 - 128;
+          u32 j0 = ((static_cast<u32>(max(want, 1)) - 1u) & ~3u) + 1u;
+          u32 const jmax = L > 256 ? (((L - 256) + 3u) & ~3u) + 1u : 1u;
+          g.rowj0[i] = static_cast<u16>(min(j0, jmax));
+        }
       }
       __syncthreads();
       {
@@ -1180,65 +1591,81 @@ __global__ __launch_bounds__(kT, 2) void k_msa(MsaArgs A) {
       __syncthreads();
       if (ST.overflow) continue;
       PROF_ACC(0);
-      if (cw == 4) {
-        poa_fill<4>(g, ws, codes, rows, hlast, V, L, tid, seq);
-      } else if constexpr (CWMAX > 4) {
-        if (cw == 6) {
-          poa_fill<6>(g, ws, codes, rows, hlast, V, L, tid, seq);
-        } else if (cw == 8) {
-          poa_fill<8>(g, ws, codes, rows, hlast, V, L, tid, seq);
-        } else if constexpr (CWMAX > 8) {
-          if (cw == 12) poa_fill<12>(g, ws, codes, rows, hlast, V, L, tid, seq);
-          else poa_fill<16>(g, ws, codes, rows, hlast, V, L, tid, seq);
-        }
-      }
-      __syncthreads();  // full fence: codes and hlast are read below
-      PROF_ACC(1);
-      // best end cell: first maximum, in rank order, over the nodes without out-edges
-      {
-        i32 bv = kNegInf;
-        u32 br = 0xFFFFFFFFu;
-        for (u32 r = tid; r < V; r += kT) {
-          if (g.nout[g.rank2node[r]] != 0) continue;
-          i32 const hv = hlast[r + 1];
-          if (br == 0xFFFFFFFFu || hv > bv) {
-            bv = hv;
-            br = r + 1;
-          }
-        }
-        for (int off = 32; off > 0; off >>= 1) {
-          i32 const ov = __shfl_xor(bv, off);
-          u32 const orow = __shfl_xor(br, off);
-          if (orow != 0xFFFFFFFFu && (br == 0xFFFFFFFFu || ov > bv || (ov == bv && orow < br))) {
-            bv = ov;
-            br = orow;
-          }
-        }
-        if (lane == 0) {
-          ST.red_v[wave] = bv;
-          ST.red_r[wave] = br;
-        }
-        __syncthreads();
-        if (tid == 0) {
-          i32 fv = kNegInf;
-          u32 fr = 0xFFFFFFFFu;
-          for (int k = 0; k < 4; ++k) {
-            i32 const ov = ST.red_v[k];
-            u32 const orow = ST.red_r[k];
-            if (orow != 0xFFFFFFFFu && (fr == 0xFFFFFFFFu || ov > fv || (ov == fv && orow < fr))) {
-              fv = ov;
-              fr = orow;
+      // attempt 0: the 256-column band on one wavefront (exact when its certificate holds, see poa_fill_band);
+      // attempt 1: the full row-synchronous fill
+      for (int attempt = ST.band ? 0 : 1; attempt < 2; ++attempt) {
+        if (attempt == 0) {
+          if (tid == 0) ST.band_fail = 0;
+          if (wave == 0) poa_fill_band(g, ws, codes, rows, hlast, V, L, lane, seq, &ST.edge_max);
+        } else {
+          if (cw == 4) {
+            poa_fill<4>(g, ws, codes, rows, hlast, V, L, tid, seq);
+          } else if constexpr (CWMAX > 4) {
+            if (cw == 6) {
+              poa_fill<6>(g, ws, codes, rows, hlast, V, L, tid, seq);
+            } else if (cw == 8) {
+              poa_fill<8>(g, ws, codes, rows, hlast, V, L, tid, seq);
+            } else if constexpr (CWMAX > 8) {
+              if (cw == 12) poa_fill<12>(g, ws, codes, rows, hlast, V, L, tid, seq);
+              else poa_fill<16>(g, ws, codes, rows, hlast, V, L, tid, seq);
             }
           }
-          ST.best = fv;
-          ST.best_row = fr;
+        }
+        __syncthreads();  // full fence: codes and hlast are read below
+        PROF_ACC(1);
+      // best end cell: first maximum, in rank order, over the nodes without out-edges
+        {
+          i32 bv = kNegInf;
+          u32 br = 0xFFFFFFFFu;
+          for (u32 r = tid; r < V; r += kT) {
+            if (g.nout[g.rank2node[r]] != 0) continue;
+            i32 const hv = hlast[r + 1];
+            if (br == 0xFFFFFFFFu || hv > bv) {
+              bv = hv;
+              br = r + 1;
+            }
+          }
+          for (int off = 32; off > 0; off >>= 1) {
+            i32 const ov = __shfl_xor(bv, off);
+            u32 const orow = __shfl_xor(br, off);
+            if (orow != 0xFFFFFFFFu && (br == 0xFFFFFFFFu || ov > bv || (ov == bv && orow < br))) {
+              bv = ov;
+              br = orow;
+            }
+          }
+          if (lane == 0) {
+            ST.red_v[wave] = bv;
+            ST.red_r[wave] = br;
+          }
+          __syncthreads();
+          if (tid == 0) {
+            i32 fv = kNegInf;
+            u32 fr = 0xFFFFFFFFu;
+            for (int k = 0; k < 4; ++k) {
+              i32 const ov = ST.red_v[k];
+              u32 const orow = ST.red_r[k];
+              if (orow != 0xFFFFFFFFu && (fr == 0xFFFFFFFFu || ov > fv || (ov == fv && orow < fr))) {
+                fv = ov;
+                fr = orow;
+              }
+            }
+            ST.best = fv;
+            ST.best_row = fr;
+          }
+          __syncthreads();
+        }
+        bool const band_now = attempt == 0;
+        bool const certified = !band_now || (ST.best_row != 0xFFFFFFFFu && ST.best - 32 > ST.edge_max);
+        if (wave == 0 && certified) {
+          u32 const br = ST.best_row;
+          u32 const naln = poa_traceback(g, codes, cw, V, L, br == 0xFFFFFFFFu ? 0u : br, br != 0xFFFFFFFFu, lane, band_now);
+          if (lane == 0) ST.naln = naln;
         }
         __syncthreads();
-      }
-      if (wave == 0) {
-        u32 const br = ST.best_row;
-        u32 const naln = poa_traceback(g, codes, cw, V, L, br == 0xFFFFFFFFu ? 0u : br, br != 0xFFFFFFFFu, lane);
-        if (lane == 0) ST.naln = naln;
+        if (band_now && certified && !ST.band_fail) break;  // the band was enough
+#ifdef MA_PROFILE
+        if (band_now && tid == 0) atomicAdd(&g_prof[13], 1ull);
+#endif
       }
       __syncthreads();
       PROF_ACC(2);
@@ -1320,6 +1747,21 @@ __global__ __launch_bounds__(kT, 2) void k_msa(MsaArgs A) {
               g.ccur[v] = static_cast<u16>(cur);
               g.nchar[cur] = seq[g.cpos[v]];
               g.nin[cur] = g.nout[cur] = g.nal[cur] = 0;
+              {
+                // band guide: a node aligned to graph node jt sits where jt sits; an unaligned (inserted) one
+                // takes the coordinate of the nearest aligned path entry before it (+ its distance), else v
+                u32 pos = v;
+                if (g.cnode[v] != 0) {
+                  pos = g.npos[static_cast<u32>(g.cnode[v]) - 1];
+                } else {
+                  for (u32 back = 1; back <= v && back <= 64; ++back)
+                    if (g.cnode[v - back] != 0) {
+                      pos = static_cast<u32>(g.npos[static_cast<u32>(g.cnode[v - back]) - 1]) + back;
+                      break;
+                    }
+                }
+                g.npos[cur] = static_cast<u16>(min(pos, 0xFFFFu));
+              }
               if (grpmask & (1u << (v - vlo))) {  // join the aligned ring of node jt
                 u32 const jt = static_cast<u32>(g.cnode[v]) - 1;
                 u32 const na = g.nal[jt];

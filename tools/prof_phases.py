@@ -21,7 +21,7 @@ eng = E.Engine(capi.default_params(min_k=25, max_k=25))
 eng.process(arrs, nw, nr)
 buf = (C.c_ulonglong * 16)()
 for sym, names in (("ma_debug_cprof", ["init", "components", "anchors", "compress1", "lowcov", "compress2", "tips", "trav_index", "cycle+cx", "maxflow", "emit", "merges_fast", "merges_generic"]), ("ma_debug_vprof", ["encode", "vote", "argmax", "second", "clear", "mismatch", "emit", "pairs", "x8", "x9", "x10", "x11", "x12", "x13", "wave_total"]),
-                   ("ma_debug_prof", ["prep", "fill", "end+traceback", "add_alignment", "toposort", "extract", "first_seq", "x", "fill_pre", "fill_barrier", "fill_post", "rows_generic", "rows"])):
+                   ("ma_debug_prof", ["prep", "fill", "end+traceback", "add_alignment", "toposort", "extract", "first_seq", "x", "fill_pre", "fill_barrier", "fill_post", "rows_generic", "rows", "band_fallbacks"])):
     fn = getattr(eng.lib, sym, None)
     if fn is None:
         continue
@@ -30,7 +30,7 @@ eng.timing_control(1)
 eng.process(arrs, nw, nr)
 print({k: round(v, 2) for k, v in eng.kernel_times()})
 for sym, names in (("ma_debug_cprof", ["init", "components", "anchors", "compress1", "lowcov", "compress2", "tips", "trav_index", "cycle+cx", "maxflow", "emit", "merges_fast", "merges_generic"]), ("ma_debug_vprof", ["encode", "vote", "argmax", "second", "clear", "mismatch", "emit", "pairs", "x8", "x9", "x10", "x11", "x12", "x13", "wave_total"]),
-                   ("ma_debug_prof", ["prep", "fill", "end+traceback", "add_alignment", "toposort", "extract", "first_seq", "x", "fill_pre", "fill_barrier", "fill_post", "rows_generic", "rows"])):
+                   ("ma_debug_prof", ["prep", "fill", "end+traceback", "add_alignment", "toposort", "extract", "first_seq", "x", "fill_pre", "fill_barrier", "fill_post", "rows_generic", "rows", "band_fallbacks"])):
     fn = getattr(eng.lib, sym, None)
     if fn is None:
         continue
