@@ -52,6 +52,7 @@ struct PoaWs {
   u32 max_l;         // longest haplotype of the batch
   u32 w_stride;      // i32 per stored row and matrix
   u32 row_slots;     // stored rows per window
+  u32 use_band;      // try the 256-column banded fill first (MA_POA_BAND=1; off by default: no faster end to end yet)
   size_t code_cells; // u16 per window
   size_t row_cells;  // i32 per window
   u16* codes;
@@ -1463,7 +1464,7 @@ __global__ __launch_bounds__(kT, 2) void k_msa(MsaArgs A) {
               mode = 2;
               ST.V = V;
               ST.cw = cw;
-              ST.band = (L >= 400 && static_cast<size_t>(V + 1) * 256 <= ws.code_cells) ? 1u : 0u;
+              ST.band = (ws.use_band && L >= 400 && static_cast<size_t>(V + 1) * 256 <= ws.code_cells) ? 1u : 0u;
             }
           }
         }
@@ -2087,6 +2088,7 @@ int launch_msa(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& a, const ma_var
   ws.pn = pn;
   ws.w_stride = (max_len + 7) & ~7u;
   ws.row_slots = pn / 2;
+  ws.use_band = getenv("MA_POA_BAND") && atoi(getenv("MA_POA_BAND")) != 0 ? 1u : 0u;
   ws.code_cells = (static_cast<size_t>(pn + 2) * (max_len + 16) + 7) & ~size_t(7);
   if (ws.code_cells * 2 < static_cast<size_t>(P.max_haps) * (2 * max_len + 8) + 64)  // raw-allele scratch lives in the codes
     ws.code_cells = (static_cast<size_t>(P.max_haps) * (2 * max_len + 8) / 2 + 64 + 7) & ~size_t(7);
