@@ -124,6 +124,25 @@ def test_msa_parity(cfg, nwin, kw):
     assert want["win_nvars"].sum() > 0
 
 
+@pytest.mark.parametrize("cfg,nwin,kw", [("C2", 6, {}), ("C2", 2, dict(W=1700)), ("C2", 3, dict(big_indel=60))])
+def test_msa_parity_banded_fill(cfg, nwin, kw, monkeypatch):
+    """The optional 256-column banded POA fill (MA_POA_BAND=1) is exact by certificate or falls back."""
+    from lancet2_amd.engine import Engine
+    monkeypatch.setenv("MA_POA_BAND", "1")
+    params = capi.default_params(min_k=25, max_k=25)
+    arrs, n, nr = synth.make_config_batch(cfg, nwin, first_index=300, **kw)
+    orc = OracleEngine(params)
+    asm = orc.assemble(arrs, n, nr)
+    want = orc.msa(arrs, n, nr, asm)
+    eng = Engine(params)
+    try:
+        got = eng.msa(arrs, n, nr, asm)
+    finally:
+        eng.close()
+    bad = compare_vars(params, got, want, n)
+    assert not bad, "\n".join(bad[:20])
+
+
 from harness import compare_geno  # noqa: E402
 
 
