@@ -10,6 +10,7 @@
  *   ma_msa_batch           <- caller::MsaBuilder::UpdateSpoaState + caller::VariantSet ctor
  *                             (caller/msa_builder.h:81-92, caller/variant_set.h:25)
  *   ma_genotype_batch      <- caller::Genotyper::Genotype                 (caller/genotyper.h:219)
+ *   ma_annotate_batch      <- core::VariantAnnotator::Annotate{Sequence,Graph}Complexity (core/variant_annotator.h)
  *   ma_process_batch       <- the chained body of ProcessWindow           (core/variant_builder.cpp:229-262)
  *
  * Conventions: plain pointers and sizes only; all buffers are caller owned, struct-of-arrays;
@@ -169,6 +170,17 @@ typedef struct ma_geno_out {
   double* asg_score;      /* [n_reads * max_vars] */
 } ma_geno_out_t;
 
+/* ---- variant annotation (core/variant_annotator.cpp:43-101; VCF INFO SEQ_CX / GRAPH_CX) ------ */
+typedef struct ma_cx_out {
+  /* per variant, stride max_vars.  SequenceComplexity (base/sequence_complexity.h:106-158), merged over the
+   * variant's (ALT, haplotype) sites with MergeMax exactly as AnnotateSequenceComplexity does */
+  int32_t* seq_cx_i;  /* [.. * 4] ContextHRun, DeltaHRun, TrPeriod, IsStutterIndel */
+  float* seq_cx_f;    /* [.. * 4] ContextEntropy, DeltaEntropy, TrAffinity, TrPurity */
+  double* seq_cx_d;   /* [.. * 3] ContextFlankLQ, ContextHaplotypeLQ, DeltaFlankLQ */
+  double* graph_cx;   /* [.. * 3] GraphEntanglementIndex, TipToPathCovRatio, MaxSingleDirDegree
+                       * (caller::GraphMetrics, variant_annotator.cpp:87-99) */
+} ma_cx_out_t;
+
 typedef struct ma_ctx ma_ctx_t;
 
 int ma_create(const ma_params_t* prm, int device, int memspace, ma_ctx_t** out);
@@ -183,6 +195,12 @@ int ma_assemble_batch(ma_ctx_t* ctx, const ma_batch_t* b, const ma_asm_out_t* ou
 int ma_msa_batch(ma_ctx_t* ctx, const ma_batch_t* b, const ma_asm_out_t* asmb, const ma_var_out_t* out);
 int ma_genotype_batch(ma_ctx_t* ctx, const ma_batch_t* b, const ma_asm_out_t* asmb,
                       const ma_var_out_t* vars, const ma_geno_out_t* out);
+/* VariantAnnotator::AnnotateSequenceComplexity + AnnotateGraphComplexity (core/variant_annotator.cpp:43-101,
+ * called from VariantBuilder::ExtractVariants, core/variant_builder.cpp:159-160) for every variant of the batch.
+ * gc_frac = the --genome-gc-bias background GC fraction of the LongdustQ null model (default 0.41).
+ * Integer features are exact; the f32/f64 features go through device log2f/log1p/log10. */
+int ma_annotate_batch(ma_ctx_t* ctx, const ma_batch_t* b, const ma_asm_out_t* asmb, const ma_var_out_t* vars,
+                      double gc_frac, const ma_cx_out_t* out);
 /* gate -> assemble -> msa -> genotype on one batch; any output struct may be NULL-filled only in
  * its optional members. */
 int ma_process_batch(ma_ctx_t* ctx, const ma_batch_t* b, const ma_gate_out_t* gate,

@@ -64,6 +64,10 @@ class GenoOut(C.Structure):
         "allele_counts", "var_qual", "aln_rec", "aln_cigar", "asg_allele", "asg_score")]
 
 
+class CxOut(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("seq_cx_i", "seq_cx_f", "seq_cx_d", "graph_cx")]
+
+
 BATCH_DTYPES = dict(ref_bases=np.uint8, ref_off=np.uint32, read_win_off=np.uint32,
                     read_off=np.uint64, read_bases=np.uint8, read_quals=np.uint8,
                     read_qname_id=np.uint32, read_sample=np.uint8, read_flags=np.uint8, read_hint=np.int32)
@@ -97,6 +101,12 @@ def geno_out_spec(p, n, n_reads, debug=True):
         spec.update(aln_rec=(np.int32, n_reads * MH * 6), aln_cigar=(np.uint32, n_reads * MH * (1 + MCG)),
                     asg_allele=(np.uint8, n_reads * MV), asg_score=(np.float64, n_reads * MV))
     return spec
+
+
+def cx_out_spec(p, n):
+    MV = p.max_vars
+    return dict(seq_cx_i=(np.int32, n * MV * 4), seq_cx_f=(np.float32, n * MV * 4),
+                seq_cx_d=(np.float64, n * MV * 3), graph_cx=(np.float64, n * MV * 3))
 
 
 def gate_out_spec(n):

@@ -437,4 +437,77 @@ int orc_genotype_batch(const ma_params_t* prm, const ma_batch_t* b, const ma_asm
   return 0;
 }
 
+// ---- unit taps for the known-answer tests + the batched annotator ------------------
+int orc_max_hrun(const char* s, uint64_t n) { return MaxHomopolymerRun(std::string_view(s, n)); }
+float orc_entropy(const char* s, uint64_t n) { return LocalShannonEntropy(std::string_view(s, n)); }
+// out: per repeat 5 x i32 (period, start, span, errors, exact) ; copies[] f32.  Returns the number found.
+int orc_find_repeats(const char* s, uint64_t n, int approx, int32_t* out, float* copies, int cap) {
+  auto const rs = approx ? FindApproxRepeats(std::string_view(s, n)) : FindExactRepeats(std::string_view(s, n));
+  for (usize i = 0; i < rs.size() && static_cast<int>(i) < cap; ++i) {
+    out[i * 5 + 0] = rs[i].period;
+    out[i * 5 + 1] = rs[i].start;
+    out[i * 5 + 2] = rs[i].span;
+    out[i * 5 + 3] = rs[i].errors;
+    out[i * 5 + 4] = rs[i].exact ? 1 : 0;
+    copies[i] = rs[i].copies;
+  }
+  return static_cast<int>(rs.size());
+}
+double orc_longdust(const char* s, uint64_t n, int k, int max_len, double gc, int one_strand) {
+  LongdustQ const q(k, max_len, gc);
+  return one_strand ? q.ScoreOneStrand(std::string_view(s, n)) : q.Score(std::string_view(s, n));
+}
+int orc_longdust_ftable(int k, int max_len, double gc, double* out) {
+  LongdustQ const q(k, max_len, gc);
+  for (usize i = 0; i < q.F.size(); ++i) out[i] = q.F[i];
+  return static_cast<int>(q.F.size());
+}
+// SequenceComplexityScorer::Score on one (ref, alt) pair; out_i[4], out_f[4], out_d[3] as ma_cx_out_t
+void orc_seqcx_score(const char* ref, uint64_t rn, uint64_t rpos, uint64_t rlen, const char* alt, uint64_t an,
+                     uint64_t apos, uint64_t alen, double gc, int32_t* out_i, float* out_f, double* out_d) {
+  SeqCxScorer const sc(gc);
+  SeqCx const c = sc.Score({std::string_view(ref, rn), rpos, rlen}, {std::string_view(alt, an), apos, alen});
+  out_i[0] = c.ctx_hrun; out_i[1] = c.delta_hrun; out_i[2] = c.tr_period; out_i[3] = c.stutter;
+  out_f[0] = c.ctx_entropy; out_f[1] = c.delta_entropy; out_f[2] = c.tr_affinity; out_f[3] = c.tr_purity;
+  out_d[0] = c.ctx_flank_lq; out_d[1] = c.ctx_hap_lq; out_d[2] = c.delta_flank_lq;
+}
+
+int orc_annotate_batch(const ma_params_t* prm, const ma_batch_t* b, const ma_asm_out_t* a, const ma_var_out_t* v,
+                       double gc_frac, const ma_cx_out_t* o) {
+  int const MC = prm->max_comps, MH = prm->max_haps, MV = prm->max_vars, MA = prm->max_alts;
+  SeqCxScorer const sc(gc_frac);
+  for (int w = 0; w < b->n_windows; ++w) {
+    if (v->win_nvars[w] == 0) continue;
+    auto const comps = LoadComps(prm, a, w);
+    for (u32 i = 0; i < v->win_nvars[w]; ++i) {
+      usize const vi = static_cast<usize>(w) * MV + i;
+      u32 const c = v->var_comp[vi];
+      auto const& cv = comps[c];
+      std::vector<std::string_view> haps(cv.haps.begin(), cv.haps.end());
+      std::vector<AltSites> alts(v->var_nalts[vi]);
+      for (u32 ai = 0; ai < v->var_nalts[vi]; ++ai) {
+        alts[ai].len = v->alt_len[vi * MA + ai];
+        // var_hap_* are indexed by haplotype-of-the-component (AltAllele::mLocalHapStart0Idxs)
+        for (u32 h = 1; h < haps.size(); ++h)
+          if (v->var_hap_allele[vi * MH + h] == ai + 1) alts[ai].hap_starts.emplace_back(h, v->var_hap_start[vi * MH + h]);
+      }
+      SeqCx const s = AnnotateVariant(sc, haps, v->var_ref_start[vi], v->var_ref_len[vi], alts);
+      o->seq_cx_i[vi * 4 + 0] = s.ctx_hrun; o->seq_cx_i[vi * 4 + 1] = s.delta_hrun;
+      o->seq_cx_i[vi * 4 + 2] = s.tr_period; o->seq_cx_i[vi * 4 + 3] = s.stutter;
+      o->seq_cx_f[vi * 4 + 0] = s.ctx_entropy; o->seq_cx_f[vi * 4 + 1] = s.delta_entropy;
+      o->seq_cx_f[vi * 4 + 2] = s.tr_affinity; o->seq_cx_f[vi * 4 + 3] = s.tr_purity;
+      o->seq_cx_d[vi * 3 + 0] = s.ctx_flank_lq; o->seq_cx_d[vi * 3 + 1] = s.ctx_hap_lq;
+      o->seq_cx_d[vi * 3 + 2] = s.delta_flank_lq;
+      // cbdg/graph_complexity.h:160-166 + variant_annotator.cpp:87-99
+      usize const ci = static_cast<usize>(w) * MC + c;
+      f64 const cc = static_cast<f64>(a->comp_cx[ci * 3 + 0]), bp = static_cast<f64>(a->comp_cx[ci * 3 + 1]);
+      f64 const raw = (cc * bp * a->comp_cxf[ci * 4 + 1]) / (a->comp_cxf[ci * 4 + 0] + 1e-6);
+      o->graph_cx[vi * 3 + 0] = std::log10(1.0 + raw);
+      o->graph_cx[vi * 3 + 1] = a->comp_cxf[ci * 4 + 2];
+      o->graph_cx[vi * 3 + 2] = static_cast<f64>(a->comp_cx[ci * 3 + 2]);
+    }
+  }
+  return 0;
+}
+
 }  // extern "C"

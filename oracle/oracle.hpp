@@ -156,4 +156,52 @@ u32 ComputeEditDistance(const std::vector<CigarUnit>& cigar, const std::vector<u
                         const u8* t, usize tlen);
 usize CigarRefPosToQueryPos(const std::vector<CigarUnit>& cigar, usize ref_pos);
 
+// --- sequence-complexity annotation (seqcx.cpp) -------------------------------
+struct LongdustQ {  // base/longdust_scorer.h:217-462
+  std::vector<f64> F;
+  f64 gc;
+  int k;
+  u32 mask, num_kmers;
+  explicit LongdustQ(int kmer_len = 7, int max_len = 1024, f64 gc_frac = 0.41);
+  f64 ComputeF(int ell) const;
+  f64 ScoreOneStrand(std::string_view seq) const;
+  f64 Score(std::string_view seq) const;
+};
+struct TandemRepeat {  // base/sequence_complexity.h:28-47
+  i32 period = 0;
+  f32 copies = 0.0F;
+  i32 start = 0, span = 0, errors = 0;
+  bool exact = false;
+  f32 Purity() const { return span <= 0 ? 0.0F : 1.0F - (static_cast<f32>(errors) / static_cast<f32>(span)); }
+};
+struct TrFeatures { i32 dist = -1, period = 0; f32 purity = 0.0F; i32 stutter = 0; };  // sequence_complexity.h:52-58
+struct HapRegion { std::string_view hap; usize pos = 0, len = 0; };                    // sequence_complexity.h:16-21
+struct SeqCx {  // base/sequence_complexity.h:106-158 (11 features, VCF SEQ_CX order)
+  i32 ctx_hrun = 0;
+  f32 ctx_entropy = 0.0F;
+  f64 ctx_flank_lq = 0.0, ctx_hap_lq = 0.0;
+  i32 delta_hrun = 0;
+  f32 delta_entropy = 0.0F;
+  f64 delta_flank_lq = 0.0;
+  f32 tr_affinity = 0.0F, tr_purity = 0.0F;
+  i32 tr_period = 0, stutter = 0;
+  void MergeMax(const SeqCx& o);
+};
+std::string_view ExtractFlank(std::string_view hap, usize pos, usize len, i64 flank);
+i32 MaxHomopolymerRun(std::string_view s);
+f32 LocalShannonEntropy(std::string_view s);
+std::vector<TandemRepeat> FindExactRepeats(std::string_view s, i32 max_period = 6, f32 min_copies = 2.5F);
+std::vector<TandemRepeat> FindApproxRepeats(std::string_view s, i32 max_period = 6, f32 min_copies = 3.0F,
+                                            i32 max_edits = 1);
+TrFeatures FlattenTRFeatures(const std::vector<TandemRepeat>& rs, i32 vpos, i32 vlen);
+struct SeqCxScorer {  // base/sequence_complexity.h:186-300
+  LongdustQ flank, hap;
+  explicit SeqCxScorer(f64 gc_frac = 0.41);
+  SeqCx Score(const HapRegion& ref, const HapRegion& alt) const;
+};
+struct AltSites { usize len = 0; std::vector<std::pair<u32, u32>> hap_starts; };
+// core/variant_annotator.cpp:43-85 for one variant; haps[0] is the component's REF haplotype
+SeqCx AnnotateVariant(const SeqCxScorer& sc, const std::vector<std::string_view>& haps, usize ref_pos, usize ref_len,
+                      const std::vector<AltSites>& alts);
+
 }  // namespace orc

@@ -24,6 +24,8 @@ def load_oracle():
     lib.orc_median_u32.restype = C.c_uint32
     lib.orc_edit_distance.restype = C.c_uint32
     lib.orc_refpos_to_qpos.restype = C.c_uint64
+    lib.orc_entropy.restype = C.c_float
+    lib.orc_longdust.restype = C.c_double
     return lib
 
 
@@ -72,6 +74,16 @@ class OracleEngine:
         rc = self.lib.orc_genotype_batch(C.byref(self.p), C.byref(b), C.byref(capi.fill_struct(capi.AsmOut, asm)),
                                          C.byref(capi.fill_struct(capi.VarOut, var)),
                                          C.byref(capi.fill_struct(capi.GenoOut, out)))
+        assert rc == 0
+        return out
+
+
+    def annotate(self, arrs, n, nr, asm, var, gc_frac=0.41):
+        out = capi.alloc_host(capi.cx_out_spec(self.p, n))
+        b = capi.make_batch_struct(arrs, n, nr)
+        rc = self.lib.orc_annotate_batch(C.byref(self.p), C.byref(b), C.byref(capi.fill_struct(capi.AsmOut, asm)),
+                                         C.byref(capi.fill_struct(capi.VarOut, var)), C.c_double(gc_frac),
+                                         C.byref(capi.fill_struct(capi.CxOut, out)))
         assert rc == 0
         return out
 

@@ -250,3 +250,174 @@ def test_confidence_examples():  # src/lancet/cbdg/node.cpp:53-58
     assert conf([1, 0], 2, False) == 1
     assert conf([0, 0], 2, True) == 0
     assert conf([3], 2, False) == 1        # lazily-sized counts: floor(3 * 1/2)
+
+
+# ==== SURVEY 8 f3: sequence-complexity annotation ==============================================
+def max_hrun(s):
+    return oracle().orc_max_hrun(b(s), C.c_uint64(len(s)))
+
+
+def entropy(s):
+    return float(oracle().orc_entropy(b(s), C.c_uint64(len(s))))
+
+
+def find_repeats(s, approx):
+    out = np.zeros(5 * 256, np.int32)
+    cp = np.zeros(256, np.float32)
+    n = oracle().orc_find_repeats(b(s), C.c_uint64(len(s)), int(approx), out.ctypes.data_as(C.c_void_p),
+                                  cp.ctypes.data_as(C.c_void_p), 256)
+    return [dict(period=int(out[5 * i]), start=int(out[5 * i + 1]), span=int(out[5 * i + 2]),
+                 errors=int(out[5 * i + 3]), exact=bool(out[5 * i + 4]), copies=float(cp[i])) for i in range(n)]
+
+
+def longdust(s, k=7, max_len=1024, gc=0.41, one_strand=False):
+    return float(oracle().orc_longdust(b(s), C.c_uint64(len(s)), k, max_len, C.c_double(gc), int(one_strand)))
+
+
+def seqcx(ref, rpos, rlen, alt, apos, alen, gc=0.41):
+    oi, of, od = np.zeros(4, np.int32), np.zeros(4, np.float32), np.zeros(3, np.float64)
+    oracle().orc_seqcx_score(b(ref), C.c_uint64(len(ref)), C.c_uint64(rpos), C.c_uint64(rlen), b(alt),
+                             C.c_uint64(len(alt)), C.c_uint64(apos), C.c_uint64(alen), C.c_double(gc),
+                             oi.ctypes.data_as(C.c_void_p), of.ctypes.data_as(C.c_void_p),
+                             od.ctypes.data_as(C.c_void_p))
+    return dict(ctx_hrun=int(oi[0]), delta_hrun=int(oi[1]), tr_period=int(oi[2]), stutter=int(oi[3]),
+                ctx_entropy=float(of[0]), delta_entropy=float(of[1]), tr_affinity=float(of[2]),
+                tr_purity=float(of[3]), ctx_flank_lq=float(od[0]), ctx_hap_lq=float(od[1]),
+                delta_flank_lq=float(od[2]))
+
+
+# ---- tests/base/sequence_complexity_test.cpp:16-28 ----
+def test_max_homopolymer_run():
+    assert max_hrun("") == 0
+    assert max_hrun("A") == 1
+    assert max_hrun("ACGT") == 1
+    assert max_hrun("AACCCGTTT") == 3
+    assert max_hrun("AAAAAAA") == 7
+    assert max_hrun("ATCAAAAAGTC") == 5
+    assert max_hrun("T" * 50) == 50
+
+
+# ---- tests/base/sequence_complexity_test.cpp:35-53 ----
+def test_local_shannon_entropy():
+    assert entropy("") == 0.0
+    assert entropy("AAAA") == 0.0
+    assert entropy("TTTTTTTT") == 0.0
+    assert entropy("ACGT") == pytest.approx(2.0, abs=1e-3)
+    assert entropy("AACCGGTT") == pytest.approx(2.0, abs=1e-3)
+    assert entropy("ACACAC") == pytest.approx(1.0, abs=1e-3)
+    assert entropy("AACCGG") == pytest.approx(np.log2(3.0), abs=1e-2)
+
+
+# ---- tests/base/sequence_complexity_test.cpp:60-117 ----
+def test_find_exact_repeats():
+    rs = find_repeats("ATATATATAT", approx=False)
+    assert rs
+    best = rs[0]
+    for r in rs:
+        if r["copies"] > best["copies"] or (r["copies"] == best["copies"] and r["period"] < best["period"]):
+            best = r
+    assert best["period"] == 2 and best["copies"] == pytest.approx(5.0, abs=0.01)
+    assert best["span"] == 10 and best["exact"] and best["errors"] == 0
+    rs = find_repeats("AAAAAA", approx=False)
+    hit = [r for r in rs if r["period"] == 1 and r["copies"] >= 6.0]
+    assert hit and all(r["span"] == 6 and r["exact"] for r in hit)
+    assert all(r["period"] > 0 for r in find_repeats("ACGTACGA", approx=False))
+    # primitive-motif enforcement: ATAT must never be reported with period 4
+    assert all(r["period"] != 4 for r in find_repeats("ATATATAT", approx=False))
+
+
+# ---- tests/base/sequence_complexity_test.cpp:120-145 ----
+def test_find_approx_repeats():
+    rs = find_repeats("CAGCAACAGCAG", approx=True)
+    found = False
+    for r in rs:
+        assert r["period"] >= 1 and r["copies"] >= 1.0 and r["span"] >= r["period"] and r["errors"] >= 0
+        purity = 1.0 - r["errors"] / r["span"]
+        assert 0.0 <= purity <= 1.0
+        if r["period"] == 3 and r["copies"] >= 3.0:
+            found = True
+            assert r["errors"] >= 1 and purity >= 0.75
+    assert found
+
+
+# ---- tests/base/sequence_complexity_test.cpp:152-222 ----
+def test_seqcx_score_cases():
+    ref = "C" * 90 + "A" * 20 + "G" * 90
+    alt = "C" * 90 + "A" * 25 + "G" * 85
+    c = seqcx(ref, 90, 20, alt, 90, 25)
+    assert c["ctx_hrun"] >= 20 and c["ctx_entropy"] >= 0.0 and c["delta_hrun"] >= 0
+    assert c["ctx_flank_lq"] >= 0.0 and c["ctx_hap_lq"] >= 0.0
+    hap = "ACGT" * 50
+    c = seqcx(hap, 100, 1, hap, 100, 1)
+    assert c["ctx_hrun"] == 1 and c["ctx_entropy"] == pytest.approx(2.0, abs=0.1)
+    assert c["delta_hrun"] == 0 and c["delta_entropy"] == pytest.approx(0.0, abs=0.01)
+    hap = "ACGTACGTACGTACGTACGTACGTACGTACGT" + "TGCATGCATGCATGCATGCATGCATGCATGCA"
+    c = seqcx(hap, 16, 1, hap, 16, 1)
+    assert 0.0 <= c["tr_affinity"] <= 1.0 and c["tr_purity"] >= 0.0 and c["tr_period"] >= 0 and c["stutter"] >= 0
+    hap = "A" * 200
+    c = seqcx(hap, 100, 1, hap, 100, 1, gc=0.5)
+    assert c["ctx_hap_lq"] == pytest.approx(np.log1p(longdust(hap, 7, 4096, 0.5)), abs=1e-4)
+
+
+# ---- tests/base/sequence_complexity_test.cpp:229-271 (GC bias) ----
+def test_longdust_gc_bias():
+    rnd = "GCTAAGGTCCTTGAACGGATTCATAGCCTGAGATTTCAAC" "TGCAAGGTCCTCATGAACTTTAGCCCAAGATTCTGAACGT"
+    assert longdust(rnd, gc=0.5) < 0.5 and longdust(rnd, gc=0.41) < 0.5
+    at_rich = "ATATATGTAACTTAATGTATTATATTGATGAATTTAATGG" "ATTAAGTCATATTAATGATTAATATGATATAAGAAATAGG"
+    assert longdust(at_rich, gc=0.41) <= longdust(at_rich, gc=0.5)
+    assert longdust("A" * 50) > 0.5 and longdust("CA" * 25) > 0.5
+    assert longdust("A" * 100, gc=0.5) > 0.0
+
+
+# ---- tests/base/longdust_scorer_test.cpp:296-351 ----
+def test_longdust_properties():
+    for s in ("", "ATCG", "ATCGAT", "N" * 19):
+        assert longdust(s) == 0.0
+    assert longdust("A" * 10) > 0.0 and longdust("A" * 20) > 0.6 and longdust("A" * 50) > 1.0
+    assert longdust("A" * 20) < longdust("A" * 50) < longdust("A" * 100)
+    s5, s10, s20 = (longdust("TTAGGG" * c) for c in (5, 10, 20))
+    assert s5 < s10 <= s20
+    assert longdust("T" * 30) > 0.6 and longdust("T" * 30) >= longdust("T" * 30, one_strand=True)
+    assert longdust("TTAGGG" * 20) == pytest.approx(longdust("ttaggg" * 20))
+    assert longdust("AAAAAAANAAAAAAA") < longdust("A" * 15)
+    rng = np.random.default_rng(42)
+    for n in (100, 200, 500):
+        assert longdust("".join("ACGT"[i] for i in rng.integers(0, 4, n))) < 0.1
+
+
+# ---- tests/base/longdust_scorer_test.cpp:385-430, 582-610 ----
+def test_longdust_ftable_shape_and_monotone_homopolymers():
+    for k, ml, gc in ((7, 1024, 0.41), (7, 256, 0.5), (7, 64, 0.5), (7, 512, 0.5)):
+        out = np.zeros(ml + 1, np.float64)
+        n = oracle().orc_longdust_ftable(k, ml, C.c_double(gc), out.ctypes.data_as(C.c_void_p))
+        assert n == ml + 1 and out[0] == 0.0
+        assert np.all(out >= 0.0) and np.all(np.diff(out) >= 0.0)
+    for base in "ACGT":
+        prev = 0.0
+        for copies in range(7, 51):
+            sc = longdust(base * copies)
+            assert sc >= prev - 1e-9
+            prev = sc
+
+
+def test_longdust_closed_form_for_homopolymers():
+    """Independent restatement (python, math.lgamma): poly-A of n bases at k=7, uniform GC has one 7-mer with
+    count c = n - 6, so Q = (lgamma(c + 1) - 4^7 f1(c / 4^7)) / c with f1 the Poisson series of
+    longdust_scorer.h:350-389."""
+    import math
+
+    def f1(lam):
+        acc, sum_n, scaled = 0.0, 0.0, lam
+        for cnt in range(2, 10001):
+            sum_n += math.log(cnt)
+            scaled *= lam / cnt
+            z = scaled * sum_n
+            if z < acc * 1e-9:
+                break
+            acc += z
+        return acc * math.exp(-lam)
+
+    for n in (10, 20, 50, 100, 300):
+        c = n - 6
+        want = max(0.0, (math.lgamma(c + 1) - 16384 * f1(c / 16384)) / c)
+        assert longdust("A" * n, 7, 1024, 0.5) == pytest.approx(want, rel=1e-12)
