@@ -75,6 +75,10 @@ def algorithmic_bytes(kernel, st):
         "k_assign": R * (m + H * 40 + 16),
         "k_evidence": R * 80,
         "k_qual": 64,
+        # annotation: REF haplotype of each component in, one f64 out; +-50 windows of the REF and of
+        # every ALT site in, 11 features + 3 graph metrics (88 B) out per variant
+        "k_hap_lq": L + 8,
+        "k_seqcx": st.get("V", 0) * (3 * 110 + 88),
     }
     return per.get(kernel, 0) * n
 
@@ -93,6 +97,7 @@ def _oracle_chunk(job):
     oa = orc.assemble(sub, sn, snr)
     ov = orc.msa(sub, sn, snr, oa)
     orc.genotype(sub, sn, snr, oa, ov, debug=False)
+    orc.annotate(sub, sn, snr, oa, ov)
     return sn, time.perf_counter() - t0
 
 
@@ -159,13 +164,15 @@ def main():
     a = dev_alloc(capi.asm_out_spec(params, n))
     v = dev_alloc(capi.var_out_spec(params, n))
     q = dev_alloc(capi.geno_out_spec(params, n, nr, debug=False))
+    cx = dev_alloc(capi.cx_out_spec(params, n))
     gs, as_, vs, qs = (capi.fill_struct(capi.GateOut, g), capi.fill_struct(capi.AsmOut, a),
                        capi.fill_struct(capi.VarOut, v), capi.fill_struct(capi.GenoOut, q))
+    cxs = capi.fill_struct(capi.CxOut, cx)
     eng = Engine(params, device=local_rank, memspace=capi.MA_MEM_DEVICE)
     stream = torch.cuda.current_stream(dev)
     eng.set_stream(stream.cuda_stream)
 
-    def step():
+    def step():  # the metric's path: gate -> assembly -> POA/variants -> genotyping
         eng.process_device(b, gs, as_, vs, qs)
 
     def barrier():
@@ -185,6 +192,20 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     ktimes = eng.kernel_times()
+    # SEQ_CX / GRAPH_CX annotation of the batch's variants (a "next" row: not part of the metric's
+    # path) -- timed on its own, after the timed region, and reported beside it
+    eng.timing_control(0)
+    eng.annotate_device(b, as_, vs, cxs, 0.41)
+    barrier()
+    eng.timing_control(2)
+    ta = time.perf_counter()
+    for _ in range(args.steps):
+        eng.annotate_device(b, as_, vs, cxs, 0.41)
+    barrier()
+    annot_ms = (time.perf_counter() - ta) * 1e3 / max(args.steps, 1)
+    annot_k = {}
+    for name, ms in eng.kernel_times():
+        annot_k[name] = annot_k.get(name, 0.0) + ms / max(args.steps, 1)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -216,7 +237,7 @@ def main():
     # (profiles/r1_*: 12 % of the read k-mers take the hash-table path, 10 % go through the general mate-mer set)
     st = dict(windows=n, S=params.num_samples, W=W, R=R, B=Bb, N_inst=Ni, N_slow=0.12 * Ni, N_gen=0.10 * Ni,
               N_nodes=1.4 * W, table_slots=8192, H=H, L=L, read_len=read_len, band=params.band, k=k,
-              pairs_per_window=pairs_w, dp_pairs_per_window=dp_w)
+              pairs_per_window=pairs_w, dp_pairs_per_window=dp_w, V=float(nvars.sum()) / n)
 
     total_windows = n * args.steps * world
     wps = total_windows / elapsed
@@ -282,6 +303,9 @@ def main():
             "roofline": roof, "cpu_baseline": cpu, "cpu_baseline_all_cores": cpu_mt,
             "kernel_ms_per_step": kernel_ms_per_step, "stages": stages, "dp_cell_rates": cells,
             "work": {"pairs_per_window": round(pairs_w, 1), "dp_pairs_per_window": round(dp_w, 1)},
+            # SURVEY 8 f3 (next row), outside the metric's timed region: ma_annotate_batch over the same batch
+            "annotation": {"ms_per_step": round(annot_ms, 3), "variants_per_window": round(float(nvars.sum()) / n, 2),
+                           "kernel_ms_per_step": {k_: round(v_, 3) for k_, v_ in annot_k.items()}},
         }
         print(json.dumps(out))
     eng.close()

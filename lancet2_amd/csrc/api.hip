@@ -72,6 +72,12 @@ std::vector<OutField> geno_fields(const ma_params_t& p, int n, i64 nr) {
           {off_of(&ma_geno_out_t::asg_score), 8 * R * MV}};
 }
 
+std::vector<OutField> cx_fields(const ma_params_t& p, int n) {
+  size_t const N = n, MV = p.max_vars;
+  return {{off_of(&ma_cx_out_t::seq_cx_i), 4 * N * MV * 4}, {off_of(&ma_cx_out_t::seq_cx_f), 4 * N * MV * 4},
+          {off_of(&ma_cx_out_t::seq_cx_d), 8 * N * MV * 3}, {off_of(&ma_cx_out_t::graph_cx), 8 * N * MV * 3}};
+}
+
 void*& ptr_at(void* strct, size_t off) { return *reinterpret_cast<void**>(static_cast<char*>(strct) + off); }
 void* ptr_at(const void* strct, size_t off) {
   return *reinterpret_cast<void* const*>(static_cast<const char*>(strct) + off);
@@ -309,7 +315,7 @@ void ma_destroy(ma_ctx_t* ctx) {
   for (auto& b : ctx->in_stage) b.release();
   for (auto& b : ctx->out_stage) b.release();
   ctx->ws_build.release(); ctx->ws_nodes.release(); ctx->ws_clean.release();
-  ctx->ws_poa.release(); ctx->ws_aln.release(); ctx->ws_misc.release();
+  ctx->ws_poa.release(); ctx->ws_aln.release(); ctx->ws_misc.release(); ctx->ws_cx.release();
   for (auto& t : ctx->timers) {
     (void)hipEventDestroy(t.beg);
     (void)hipEventDestroy(t.end);
@@ -460,6 +466,26 @@ int ma_genotype_batch(ma_ctx_t* ctx, const ma_batch_t* b, const ma_asm_out_t* as
   MA_TRY(g.prepare(ctx, out, geno_fields(ctx->prm, d.n_windows, d.n_reads), 32, false));
   MA_TRY(launch_genotype(ctx, d, a.dev, v.dev, g.dev));
   MA_TRY(g.download(ctx));
+  if (ctx->memspace == MA_MEM_HOST) MA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return MA_OK;
+}
+
+int ma_annotate_batch(ma_ctx_t* ctx, const ma_batch_t* b, const ma_asm_out_t* asmb, const ma_var_out_t* vars,
+                      double gc_frac, const ma_cx_out_t* out) {
+  MA_BEGIN(ctx);
+  if (!out || !asmb || !vars || !b || b->n_windows < 0) return MA_ERR_ARG;
+  if (!out->seq_cx_i || !out->seq_cx_f || !out->seq_cx_d || !out->graph_cx) return MA_ERR_ARG;
+  if (!(gc_frac == gc_frac)) return MA_ERR_ARG;  // NaN
+  DBatch d{};
+  d.n_windows = b->n_windows;  // only the window count is read: the inputs are the assembly + variant outputs
+  OutMirror<ma_asm_out_t> a;
+  MA_TRY(a.prepare(ctx, asmb, asm_fields(ctx->prm, d.n_windows), 2, true));
+  OutMirror<ma_var_out_t> v;
+  MA_TRY(v.prepare(ctx, vars, var_fields(ctx->prm, d.n_windows), 16, true));
+  OutMirror<ma_cx_out_t> c;
+  MA_TRY(c.prepare(ctx, out, cx_fields(ctx->prm, d.n_windows), 40, false));
+  MA_TRY(launch_annotate(ctx, d, a.dev, v.dev, gc_frac, c.dev));
+  MA_TRY(c.download(ctx));
   if (ctx->memspace == MA_MEM_HOST) MA_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return MA_OK;
 }

@@ -21,6 +21,7 @@ using i16 = int16_t;
 using i32 = int32_t;
 using i64 = int64_t;
 using f64 = double;
+using f32 = float;
 
 // node-identity hash shared with the oracle (oracle/common.hpp: HashStr64)
 constexpr u64 kHashP = 0x9E3779B97F4A7C15ULL;
@@ -65,6 +66,11 @@ struct ma_ctx {
   std::vector<ma::DevBuf> out_stage;
   // per-stage workspaces (grow-only, reused across calls)
   ma::DevBuf ws_build, ws_nodes, ws_clean, ws_poa, ws_aln, ws_misc;
+  // annotation tables (annotate.hip): rebuilt when the GC fraction or max_hap_len changes
+  ma::DevBuf ws_cx;
+  double cx_gc = -1.0;
+  int cx_ml = 0;
+  std::vector<double> cx_host;
   // kernel timing
   std::vector<ma::KernelTimer> timers;
   size_t timers_used = 0;
@@ -122,6 +128,8 @@ int launch_assemble(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& o, const u
 int launch_msa(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& a, const ma_var_out_t& o);
 int launch_genotype(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& a, const ma_var_out_t& v,
                     const ma_geno_out_t& o);
+int launch_annotate(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& a, const ma_var_out_t& v, double gc_frac,
+                    const ma_cx_out_t& o);
 
 // Workspace budget of one stage: a fixed share of the device's HBM (288 GB on MI355X), so that the
 // chunking does not depend on the order in which the stages first allocated, capped by what is free now

@@ -33,6 +33,7 @@ def load_library(path=None):
     lib.ma_msa_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.ma_genotype_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.ma_process_batch.argtypes = [C.c_void_p] * 6
+    lib.ma_annotate_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p]
     lib.ma_last_kernel_times.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.c_int]
     lib.ma_last_stats.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong), C.c_int]
     lib.ma_set_streams.argtypes = [C.c_void_p, C.c_int]
@@ -132,6 +133,17 @@ class Engine:
                     "ma_genotype_batch")
         return out
 
+    def annotate(self, arrs, n, nr, asm, var, gc_frac=0.41):
+        """VariantAnnotator (core/variant_annotator.cpp:43-101): SEQ_CX + GRAPH_CX of every variant."""
+        out = self._alloc(capi.cx_out_spec(self.p, n))
+        b = capi.make_batch_struct(arrs, n, nr)
+        a = capi.fill_struct(capi.AsmOut, asm)
+        v = capi.fill_struct(capi.VarOut, var)
+        o = capi.fill_struct(capi.CxOut, out)
+        self._check(self.lib.ma_annotate_batch(self.h, C.byref(b), C.byref(a), C.byref(v), C.c_double(gc_frac),
+                                               C.byref(o)), "ma_annotate_batch")
+        return out
+
     def process(self, arrs, n, nr, debug=False):
         g = self._alloc(capi.gate_out_spec(n))
         a = self._alloc(capi.asm_out_spec(self.p, n))
@@ -148,3 +160,7 @@ class Engine:
     def process_device(self, batch_struct, gate, asm, var, geno):
         self._check(self.lib.ma_process_batch(self.h, C.byref(batch_struct), C.byref(gate), C.byref(asm),
                                               C.byref(var), C.byref(geno)), "ma_process_batch")
+
+    def annotate_device(self, batch_struct, asm, var, cx, gc_frac=0.41):
+        self._check(self.lib.ma_annotate_batch(self.h, C.byref(batch_struct), C.byref(asm), C.byref(var),
+                                               C.c_double(gc_frac), C.byref(cx)), "ma_annotate_batch")

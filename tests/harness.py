@@ -204,3 +204,59 @@ def compare_geno(p, got, want, n, nr, win_nvars, read_win_off):
     if dq > 1e-9:
         bad.append(f"var_qual max abs diff {dq}")
     return bad
+
+
+SEQCX_FLOAT_TOL = 1e-5  # north_star's floating-point tolerance; the integer features must be equal
+
+
+def compare_cx(p, got, want, win_nvars):
+    """Integer features bit-exact, float features within SEQCX_FLOAT_TOL, only over the variants that exist."""
+    MV = p.max_vars
+    n = len(win_nvars)
+    mask = (np.arange(MV)[None, :] < np.asarray(win_nvars)[:, None]).reshape(-1)
+    for key, width in (("seq_cx_i", 4), ("seq_cx_f", 4), ("seq_cx_d", 3), ("graph_cx", 3)):
+        g = got[key].reshape(n * MV, width)[mask]
+        w = want[key].reshape(n * MV, width)[mask]
+        if key == "seq_cx_i":
+            bad = np.argwhere(g != w)
+            assert bad.size == 0, f"{key}: first mismatch at {bad[0]}: got {g[tuple(bad[0])]} want {w[tuple(bad[0])]}"
+        else:
+            assert np.all(np.isfinite(g)), key
+            err = np.abs(g.astype(np.float64) - w.astype(np.float64))
+            assert err.size == 0 or err.max() <= SEQCX_FLOAT_TOL, f"{key}: max abs error {err.max()}"
+    return int(mask.sum())
+
+
+def handmade_annotation_case(p, cases):
+    """Builds assembly + variant output buffers by hand: one window per case, one component.
+    case = dict(haps=[ref, alt1, ...], ref_pos, ref_len, alts=[(alt_len, {hap_idx: start})...], cx=(cc, bp, deg),
+                cxf=(unitig_ratio, cov_cv, tip_ratio))"""
+    n = len(cases)
+    asm = capi.alloc_host(capi.asm_out_spec(p, n))
+    var = capi.alloc_host(capi.var_out_spec(p, n))
+    MC, MH, ML, MV, MA = p.max_comps, p.max_haps, p.max_hap_len, p.max_vars, p.max_alts
+    for w, cs in enumerate(cases):
+        asm["win_ncomp"][w] = 1
+        asm["win_k"][w] = 25
+        ci = w * MC
+        asm["comp_hap0"][ci] = 0
+        asm["comp_nhaps"][ci] = len(cs["haps"])
+        asm["comp_cx"][ci * 3:ci * 3 + 3] = cs.get("cx", (3, 2, 2))
+        asm["comp_cxf"][ci * 4:ci * 4 + 4] = tuple(cs.get("cxf", (0.5, 0.25, 0.125))) + (0.0,)
+        for h, seq in enumerate(cs["haps"]):
+            hi = w * MH + h
+            asm["hap_len"][hi] = len(seq)
+            asm["hap_bases"][hi * ML:hi * ML + len(seq)] = np.frombuffer(seq.encode(), np.uint8)
+        var["win_nvars"][w] = 1
+        vi = w * MV
+        var["var_comp"][vi] = 0
+        var["var_ref_start"][vi] = cs["ref_pos"]
+        var["var_ref_len"][vi] = cs["ref_len"]
+        var["var_nalts"][vi] = len(cs["alts"])
+        var["var_hap_start"][vi * MH] = cs["ref_pos"]
+        for ai, (alen, sites) in enumerate(cs["alts"]):
+            var["alt_len"][vi * MA + ai] = alen
+            for h, st in sites.items():
+                var["var_hap_allele"][vi * MH + h] = ai + 1
+                var["var_hap_start"][vi * MH + h] = st
+    return asm, var

@@ -344,3 +344,95 @@ def test_mate_mer_dedup_corner_cases():
         eng.close()
     bad = compare_asm(params, got, want, n)
     assert not bad, "\n".join(bad[:10])
+
+
+# ---- SEQ_CX / GRAPH_CX annotation (core/variant_annotator.cpp:43-101) -----------------------------
+from harness import compare_cx, handmade_annotation_case  # noqa: E402
+
+
+@pytest.mark.parametrize("cfg,nwin,kw,gc", [("C2", 8, {}, 0.41), ("C2", 6, dict(str_unit=b"CA"), 0.41),
+                                             ("C2", 6, dict(str_unit=b"A"), 0.5), ("C2", 4, dict(str_unit=b"CAG"), 0.41),
+                                             ("C2", 3, dict(big_indel=60), 0.41), ("C5", 3, dict(num_samples=3), 0.3)])
+def test_annotate_parity(cfg, nwin, kw, gc):
+    from lancet2_amd.engine import Engine
+    kw = dict(kw)
+    ns = kw.pop("num_samples", 2)
+    params = capi.default_params(min_k=25, max_k=37, num_samples=ns)
+    arrs, n, nr = synth.make_config_batch(cfg, nwin, first_index=700, **kw)
+    orc = OracleEngine(params)
+    asm = orc.assemble(arrs, n, nr)
+    var = orc.msa(arrs, n, nr, asm)
+    want = orc.annotate(arrs, n, nr, asm, var, gc)
+    eng = Engine(params)
+    try:
+        got = eng.annotate(arrs, n, nr, asm, var, gc)
+    finally:
+        eng.close()
+    assert compare_cx(params, got, want, var["win_nvars"]) > 0
+
+
+def _handmade_cases():
+    rng = np.random.default_rng(77)
+
+    def rnd(n):
+        return "".join("ACGT"[i] for i in rng.integers(0, 4, n))
+
+    cases = []
+    # the reference's own Score() fixtures (tests/base/sequence_complexity_test.cpp:152-222, :294-322)
+    ref = "C" * 90 + "A" * 20 + "G" * 90
+    cases.append(dict(haps=[ref, "C" * 90 + "A" * 25 + "G" * 85, "C" * 90 + "A" * 30 + "G" * 80], ref_pos=90, ref_len=20,
+                      alts=[(25, {1: 90}), (30, {2: 90})]))
+    acgt = "ACGT" * 50
+    cases.append(dict(haps=[acgt, acgt], ref_pos=100, ref_len=1, alts=[(1, {1: 100})]))
+    two = "ACGTACGTACGTACGTACGTACGTACGTACGT" + "TGCATGCATGCATGCATGCATGCATGCATGCA"
+    cases.append(dict(haps=[two, two], ref_pos=16, ref_len=1, alts=[(1, {1: 16})]))
+    cases.append(dict(haps=["A" * 200, "A" * 201], ref_pos=100, ref_len=1, alts=[(2, {1: 100})]))
+    # no ALT site at all: Score(ref, ref) (variant_annotator.cpp:76-82)
+    cases.append(dict(haps=[rnd(300), rnd(300)], ref_pos=150, ref_len=3, alts=[(1, {})]))
+    # variant at the very start / end of short haplotypes, haplotype shorter than k = 7
+    cases.append(dict(haps=["ACGTA", "ACTA"], ref_pos=0, ref_len=2, alts=[(1, {1: 0})]))
+    r = rnd(120)
+    cases.append(dict(haps=[r, r[:-1] + "A"], ref_pos=119, ref_len=1, alts=[(1, {1: 119})]))
+    # N and lower-case bases (k-mer runs reset, entropy ignores them, repeats compare bytes)
+    r = rnd(400)
+    rn = r[:180] + "NNnn" + r[184:200] + "acacacacacacacac" + r[216:]
+    cases.append(dict(haps=[rn, rn[:205] + rn[207:]], ref_pos=204, ref_len=3, alts=[(1, {1: 204})]))
+    # stutter: 1-unit contraction of a dinucleotide repeat; imperfect trinucleotide repeat next to the site
+    base = rnd(150)
+    strr = base + "CA" * 14 + rnd(150)
+    cases.append(dict(haps=[strr, base + "CA" * 13 + strr[178:]], ref_pos=149, ref_len=3, alts=[(1, {1: 149})]))
+    tri = rnd(100) + "CAGCAACAGCAGCAGCTGCAG" + rnd(100)
+    cases.append(dict(haps=[tri, tri[:98] + "T" + tri[99:]], ref_pos=98, ref_len=1, alts=[(1, {1: 98})]))
+    # a 400-base deletion (window = 100 + 400 bases) and a 300-base insertion, several haplotypes per allele
+    big = rnd(1500)
+    dele = big[:500] + big[900:]
+    ins = big[:700] + rnd(300) + big[700:]
+    cases.append(dict(haps=[big, dele, dele, ins], ref_pos=499, ref_len=401, alts=[(1, {1: 499, 2: 499})]))
+    cases.append(dict(haps=[big, dele, dele, ins], ref_pos=699, ref_len=1, alts=[(301, {3: 699})]))
+    # multi-allelic with hexamer and homopolymer contexts
+    hexa = rnd(200) + "TTAGGG" * 9 + rnd(200)
+    cases.append(dict(haps=[hexa, hexa[:254] + hexa[260:], hexa[:230] + "G" + hexa[231:], hexa[:254] + "TTAGGG" + hexa[254:]],
+                      ref_pos=229, ref_len=31, alts=[(25, {1: 229}), (31, {2: 229}), (37, {3: 229})],
+                      cx=(60, 55, 4), cxf=(0.01, 1.75, 0.5)))
+    return cases
+
+
+@pytest.mark.parametrize("gc", [0.41, 0.5])
+def test_annotate_handmade_cases(gc):
+    """Edge cases the synthetic windows never produce, driven straight through ma_annotate_batch."""
+    from lancet2_amd.engine import Engine
+    params = capi.default_params(min_k=25, max_k=25)
+    cases = _handmade_cases()
+    asm, var = handmade_annotation_case(params, cases)
+    n = len(cases)
+    arrs = dict(ref_off=np.zeros(n + 1, np.uint32), read_win_off=np.zeros(n + 1, np.uint32))
+    orc = OracleEngine(params)
+    want = orc.annotate(arrs, n, 0, asm, var, gc)
+    eng = Engine(params)
+    try:
+        got = eng.annotate(arrs, n, 0, asm, var, gc)
+    finally:
+        eng.close()
+    assert compare_cx(params, got, want, var["win_nvars"]) == n
+    # sanity against the reference's expectations for its own fixtures
+    assert want["seq_cx_i"][0] >= 20 and want["seq_cx_i"].reshape(n, -1, 4)[1, 0, 0] == 1
