@@ -38,7 +38,8 @@ def main():
         a = orc.assemble(arrs, nw, nr)
         v = orc.msa(arrs, nw, nr, a)
         q = orc.genotype(arrs, nw, nr, a, v, debug=True)
-        for pref, d in (("gate_", g), ("asm_", a), ("var_", v), ("geno_", q)):
+        cx = orc.annotate(arrs, nw, nr, a, v)  # SEQ_CX / GRAPH_CX at the default GC fraction 0.41
+        for pref, d in (("gate_", g), ("asm_", a), ("var_", v), ("geno_", q), ("cx_", cx)):
             out.update({pref + k: val for k, val in d.items()})
         out["meta"] = np.array([nw, nr] + [getattr(params, f) for f, _ in capi.Params._fields_], dtype=np.int64)
         path = os.path.join(HERE, name + ".npz")

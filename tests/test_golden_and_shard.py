@@ -6,7 +6,7 @@ import os
 import numpy as np
 import pytest
 
-from harness import OracleEngine, compare_asm, compare_geno, compare_vars
+from harness import OracleEngine, compare_asm, compare_cx, compare_geno, compare_vars
 from lancet2_amd import capi, shard, synth
 
 GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
@@ -18,7 +18,7 @@ def load_golden(path):
     n, nr = int(meta[0]), int(meta[1])
     params = capi.Params(*[int(x) for x in meta[2:]])
     arrs = {k[3:]: z[k] for k in z.files if k.startswith("in_")}
-    outs = {pref: {k[len(pref) + 1:]: z[k] for k in z.files if k.startswith(pref + "_")} for pref in ("gate", "asm", "var", "geno")}
+    outs = {pref: {k[len(pref) + 1:]: z[k] for k in z.files if k.startswith(pref + "_")} for pref in ("gate", "asm", "var", "geno", "cx")}
     return params, arrs, n, nr, outs
 
 
@@ -35,6 +35,7 @@ def test_oracle_matches_golden(path):
     assert not compare_vars(params, v, want["var"], n)
     q = orc.genotype(arrs, n, nr, a, v)
     assert not compare_geno(params, q, want["geno"], n, nr, v["win_nvars"], arrs["read_win_off"])
+    compare_cx(params, orc.annotate(arrs, n, nr, a, v), want["cx"], v["win_nvars"])
 
 
 def test_golden_vectors_are_nontrivial():

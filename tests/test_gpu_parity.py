@@ -226,6 +226,7 @@ def test_hip_path_matches_golden(path):
     eng = Engine(params)
     try:
         g, a, v, q = eng.process(arrs, n, nr, debug=True)
+        cx = eng.annotate(arrs, n, nr, a, v)
     finally:
         eng.close()
     assert np.array_equal(g["max_approx"], want["gate"]["max_approx"])
@@ -233,6 +234,8 @@ def test_hip_path_matches_golden(path):
     assert not compare_vars(params, v, want["var"], n)
     bad = compare_geno(params, q, want["geno"], n, nr, want["var"]["win_nvars"], arrs["read_win_off"])
     assert not bad, "\n".join(bad[:10])
+    from harness import compare_cx
+    compare_cx(params, cx, want["cx"], want["var"]["win_nvars"])
 
 
 def test_full_size_properties():
