@@ -190,6 +190,8 @@ __device__ __forceinline__ bool canon_plus(const u8* s, int k) {
 // reads longer than the mask, a general-path k-mer that turns out to be a reference node, a qname shared
 // by two samples of one role) are routed wholesale through the general mate-mer set (GEN bit).
 constexpr int kMaskWords = 10;  // fast-path bitmask covers reads with <= 320 k-mers
+constexpr u32 kMmLdsCap = 32768;              // entries of the LDS mate-mer set of k_mm_lds
+constexpr u32 kMmLdsMax = kMmLdsCap * 7 / 8;  // general instances per window it accepts (distinct keys are fewer)
 
 struct BuildLds {
   u8* ref;        // [max_ref_len + 8]
@@ -558,7 +560,14 @@ __global__ __launch_bounds__(kBT) void k_support(DBatch b, GraphWs ws, u32* max_
     if (ngen) atomicAdd(&gen_count, ngen);
   }
   __syncthreads();
-  if (threadIdx.x == 0) atomicMax(max_gen, gen_count);
+  if (threadIdx.x == 0) {
+    // Windows whose (qname, role) keys each map to ONE run of adjacent reads (xs_flag == 0) and whose general
+    // instances fit the LDS set are finished by k_mm_lds; the others need the HBM-resident set (max_gen[1]).
+    bool const lds_ok = !all_generic && ns <= kSeqCap && gen_count <= kMmLdsMax && ws.tc_log2 <= 20;
+    ws.mm_mode[a] = gen_count | (lds_ok ? 0u : 0x80000000u);
+    atomicMax(max_gen, gen_count);
+    if (!lds_ok) atomicMax(max_gen + 1, gen_count);
+  }
   for (u32 i = threadIdx.x; i < rsi.nk * CW; i += kBT) {
     u32 const v = l_cnt[i];
     if (v == 0) continue;
@@ -580,6 +589,7 @@ __device__ __forceinline__ u32 inst_table_slot(u32 word, const u32* ref_slot_g) 
 __global__ __launch_bounds__(kBT) void k_mm_insert(DBatch b, GraphWs ws) {
   __shared__ u32 l_base[kSeqCap];
   int const a = blockIdx.x;
+  if (!(ws.mm_mode[a] & 0x80000000u)) return;  // done by k_mm_lds
   int const w = static_cast<int>(ws.active[a]);
   u32 const mask = (1u << ws.mc_log2) - 1;
   u64* keys = ws.mm_key + (static_cast<size_t>(a) << ws.mc_log2);
@@ -619,6 +629,7 @@ __global__ __launch_bounds__(kBT) void k_mm_insert(DBatch b, GraphWs ws) {
 __global__ __launch_bounds__(kBT) void k_count(DBatch b, GraphWs ws) {
   __shared__ u32 l_base[kSeqCap];
   int const a = blockIdx.x;
+  if (!(ws.mm_mode[a] & 0x80000000u)) return;  // done by k_mm_lds
   int const w = static_cast<int>(ws.active[a]);
   int const S = ws.num_samples, CW = S + 2;
   u32 const mask = (1u << ws.mc_log2) - 1;
@@ -656,6 +667,132 @@ __global__ __launch_bounds__(kBT) void k_count(DBatch b, GraphWs ws) {
     if (slot == kNoNode || mins[slot] != ii) continue;  // a previous (qname, role, kmer) wins
     atomicAdd(&cnt[static_cast<size_t>(nslot) * CW + sample], 1u);
     atomicAdd(&cnt[static_cast<size_t>(nslot) * CW + S + role], 1u);
+  }
+}
+
+// k_mm_lds: the general mate-mer set (graph.h:102-117) and its read support (node.cpp:18-24) for one window, entirely
+// in LDS.  k_mm_insert / k_count keep a (slot, qname, role) set per window in HBM: ~12 k random 128-byte-line
+// accesses per window and pass (profiles/: 8-10 GB of traffic per launch for ~0.6 GB of useful bytes).  When every
+// (qname, role) key of the window is one run of adjacent reads (k_support checked that: xs_flag == 0), the run's
+// leader index is a dense 11-bit name, so key = slot << 11 | leader fits 32 bits and a 32 k-entry set fits in LDS.
+// The key also determines what is counted -- sample and role are those of the leader -- so "the first instance of
+// a key counts" needs no minimum: one coalesced walk builds the set, the support is then read off the set.
+constexpr int kMmT = 1024;
+constexpr u32 kMmQueue = 4096;
+constexpr u32 kMmAux = kSeqCap + kSeqCap / 2 + kMmQueue;  // 28 KB
+__global__ __launch_bounds__(kMmT) void k_mm_lds(DBatch b, GraphWs ws) {
+  __shared__ u32 l_set[kMmLdsCap];
+  __shared__ u32 l_aux[kMmAux];  // walk: instance bases | run leaders | queue; afterwards: packed u16 support counters
+  __shared__ u32 l_qn;
+  u32* const l_base = l_aux;
+  u16* const l_lead = reinterpret_cast<u16*>(l_aux + kSeqCap);
+  u32* const l_queue = l_aux + kSeqCap + kSeqCap / 2;
+  int const a = blockIdx.x;
+  u32 const mode = ws.mm_mode[a];
+  if ((mode & 0x80000000u) || mode == 0) return;
+  int const w = static_cast<int>(ws.active[a]);
+  int const S = ws.num_samples, CW = S + 2;
+  u32* cnt = ws.tbl_cnt + (static_cast<size_t>(a) << ws.tc_log2) * CW;
+  const u32* inst_slot = ws.inst_slot + static_cast<size_t>(a) * ws.inst_stride;
+  const u32* ref_slot_g = ws.ref_slot + static_cast<size_t>(a) * ws.ref_stride;
+  u32 const ns = seq_count(b, w);
+  u32 const base_idx = b.read_win_off[w] + w;
+  u32 const r_base = b.read_win_off[w];
+  for (u32 i = threadIdx.x; i < kMmLdsCap; i += kMmT) l_set[i] = 0;
+  for (u32 s = threadIdx.x; s < ns; s += kMmT) {
+    l_base[s] = ws.seq_inst_base[base_idx + s];
+    u32 lead = s;  // sequence s >= 1 is read r_base + s - 1; its run's leader
+    while (lead > 1 && same_group(b, r_base + lead - 1, r_base + lead - 2)) --lead;
+    l_lead[s] = static_cast<u16>(lead);
+  }
+  __syncthreads();
+  u32 const ninst = ws.win_ninst[w], nref = ninst - ws.win_nread_inst[w];
+  // (qname, role, node) of one general instance -> set
+  auto const visit = [&](u32 ii, u32 word) {
+    u32 const lead = l_lead[seq_of(l_base, ns, ii)];
+    u32 const nslot = inst_table_slot(word, ref_slot_g);
+    u32 const key = ((nslot << 11) | (lead - 1)) + 1u;
+    u32 h = (key * 2654435761u) >> 17;  // kMmLdsCap == 1 << 15
+    for (u32 probe = 0; probe < kMmLdsCap; ++probe) {
+      u32 cur = l_set[h];
+      if (cur == 0) {
+        u32 const old = atomicCAS(&l_set[h], 0u, key);
+        cur = old == 0 ? key : old;
+      }
+      if (cur == key) break;
+      h = (h + 1) & (kMmLdsCap - 1);
+    }
+  };
+  // Only ~20 % of the instances are general ones: visiting them where they are found keeps 4 of 5 lanes idle
+  // through a chain of dependent LDS / L2 accesses.  Each chunk of 16 k words is therefore scanned with
+  // coalesced loads first, the general instances are queued (one LDS atomic per wavefront), and the queue is
+  // then visited with full wavefronts.
+  constexpr int kU = 4;           // independent loads in flight per thread
+  constexpr u32 kChunk = kMmT * 16;
+  u32 const lane = threadIdx.x & 63u;
+  for (u32 c0 = nref; c0 < ninst; c0 += kChunk) {
+    if (threadIdx.x == 0) l_qn = 0;
+    __syncthreads();
+    u32 const c1 = min(c0 + kChunk, ninst);
+    for (u32 i0 = c0 + threadIdx.x; i0 < c1 + kMmT * kU; i0 += kMmT * kU) {  // whole wavefronts reach the ballots
+      u32 v[kU];
+#pragma unroll
+      for (int u = 0; u < kU; ++u) {
+        u32 const ii = i0 + u * kMmT;
+        v[u] = ii < c1 ? inst_slot[ii] : 0u;
+      }
+#pragma unroll
+      for (int u = 0; u < kU; ++u) {
+        bool const gen = (v[u] & (kInstErrFree | kInstGen)) == (kInstErrFree | kInstGen);
+        u64 const m = __ballot(gen);
+        if (m == 0) continue;
+        u32 qb = 0;
+        if (lane == 0) qb = atomicAdd(&l_qn, static_cast<u32>(__popcll(m)));
+        qb = __shfl(qb, 0, 64);
+        if (gen) {
+          u32 const at = qb + static_cast<u32>(__popcll(m & ((1ull << lane) - 1ull)));
+          if (at < kMmQueue) l_queue[at] = i0 + u * kMmT;
+          else visit(i0 + u * kMmT, v[u]);  // queue full (more than a quarter of the chunk): visit in place
+        }
+      }
+    }
+    __syncthreads();
+    u32 const qn = min(l_qn, kMmQueue);
+    for (u32 q = threadIdx.x; q < qn; q += kMmT) {
+      u32 const ii = l_queue[q];
+      visit(ii, inst_slot[ii]);
+    }
+    __syncthreads();
+  }
+  // Read support: one count per key, for the leader's sample and role.  Random global atomics would cost a
+  // 128-byte HBM line each (measured: 6 of this kernel's 8 ms), so the counts are accumulated in LDS as packed
+  // u16 (a slot has at most 2047 names) for a range of slots at a time and added to the window's table in index
+  // order: a wavefront's 64 counters share two lines.
+  u32 const slots_per_pass = (2u * kMmAux) / static_cast<u32>(CW);
+  u32 const tcap = 1u << ws.tc_log2;
+  for (u32 s0 = 0; s0 < tcap; s0 += slots_per_pass) {
+    for (u32 i = threadIdx.x; i < kMmAux; i += kMmT) l_aux[i] = 0;
+    __syncthreads();
+    for (u32 i = threadIdx.x; i < kMmLdsCap; i += kMmT) {
+      u32 const key = l_set[i];
+      if (key == 0) continue;
+      u32 const nslot = (key - 1u) >> 11;
+      if (nslot < s0 || nslot - s0 >= slots_per_pass) continue;
+      u32 const r = r_base + ((key - 1u) & 2047u);
+      u32 sample = b.read_sample[r];
+      if (sample >= static_cast<u32>(S)) sample = S - 1;
+      u32 const role = (b.read_flags[r] & MA_RF_CASE) ? 1u : 0u;
+      u32 const i1 = (nslot - s0) * CW + sample, i2 = (nslot - s0) * CW + S + role;
+      atomicAdd(&l_aux[i1 >> 1], 1u << ((i1 & 1u) * 16u));
+      atomicAdd(&l_aux[i2 >> 1], 1u << ((i2 & 1u) * 16u));
+    }
+    __syncthreads();
+    u32 const nc = min(slots_per_pass, tcap - s0) * CW;
+    for (u32 j = threadIdx.x; j < nc; j += kMmT) {
+      u32 const c = (l_aux[j >> 1] >> ((j & 1u) * 16u)) & 0xFFFFu;
+      if (c) atomicAdd(&cnt[static_cast<size_t>(s0) * CW + j], c);  // no return value: the wave does not wait for it
+    }
+    __syncthreads();
   }
 }
 
@@ -900,27 +1037,44 @@ int run_build_pass(ma_ctx* ctx, const DBatch& b, GraphWs& ws, u32* counters_dev,
     MA_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_support), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     static_cast<int>(lds_s)));
   ctx->tic("k_support");
-  MA_HIP(ctx, hipMemsetAsync(counters_dev + 1, 0, 4, ctx->stream));
+  MA_HIP(ctx, hipMemsetAsync(counters_dev + 1, 0, 8, ctx->stream));
   hipLaunchKernelGGL(k_support, dim3(ws.n_active), dim3(kBT), lds_s, ctx->stream, b, ws, counters_dev + 1);
   ctx->toc();
-  // the general mate-mer set only has to hold the instances k_support routed to it
-  {
-    u32 max_gen = 0;
-    MA_HIP(ctx, hipMemcpyAsync(&max_gen, counters_dev + 1, 4, hipMemcpyDeviceToHost, ctx->stream));
-    MA_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    int mc = 10;
-    while ((size_t(1) << mc) < static_cast<size_t>(max_gen) * 4 / 3 + 16) ++mc;
-    ws.mc_log2 = mc < mc_log2_alloc ? mc : mc_log2_alloc;
+  // windows whose general instances fit an LDS set are finished by k_mm_lds; the HBM-resident set only has to
+  // hold what the remaining windows routed to it (usually nothing)
+  ctx->tic("k_mm_lds");
+  hipLaunchKernelGGL(k_mm_lds, dim3(ws.n_active), dim3(kMmT), 0, ctx->stream, b, ws);
+  ctx->toc();
+  u32 max_gen[2] = {0, 0};
+  MA_HIP(ctx, hipMemcpyAsync(max_gen, counters_dev + 1, 8, hipMemcpyDeviceToHost, ctx->stream));
+  MA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (getenv("MA_VERBOSE")) {
+    std::vector<u32> mm(A);
+    MA_HIP(ctx, hipMemcpy(mm.data(), ws.mm_mode, 4 * A, hipMemcpyDeviceToHost));
+    size_t nfb = 0, big = 0;
+    u64 tot = 0;
+    for (u32 v : mm) {
+      nfb += v >> 31;
+      big += (v & 0x7FFFFFFFu) > kMmLdsMax;
+      tot += v & 0x7FFFFFFFu;
+    }
+    fprintf(stderr, "[ma] mate-mer sets: %zu windows, %zu need the HBM set (%zu by size), mean general instances %.0f, max %u / %u\n",
+            A, nfb, big, static_cast<double>(tot) / static_cast<double>(A), max_gen[0], max_gen[1]);
   }
-  size_t const mcap = size_t(1) << ws.mc_log2;
-  MA_HIP(ctx, hipMemsetAsync(ws.mm_key, 0, A * mcap * 8, ctx->stream));
-  MA_HIP(ctx, hipMemsetAsync(ws.mm_min, 0xFF, A * mcap * 4, ctx->stream));
-  ctx->tic("k_mm_insert");
-  hipLaunchKernelGGL(k_mm_insert, dim3(ws.n_active), dim3(kBT), 0, ctx->stream, b, ws);
-  ctx->toc();
-  ctx->tic("k_count");
-  hipLaunchKernelGGL(k_count, dim3(ws.n_active), dim3(kBT), 0, ctx->stream, b, ws);
-  ctx->toc();
+  if (max_gen[1] > 0) {
+    int mc = 10;
+    while ((size_t(1) << mc) < static_cast<size_t>(max_gen[1]) * 4 / 3 + 16) ++mc;
+    ws.mc_log2 = mc < mc_log2_alloc ? mc : mc_log2_alloc;
+    size_t const mcap = size_t(1) << ws.mc_log2;
+    MA_HIP(ctx, hipMemsetAsync(ws.mm_key, 0, A * mcap * 8, ctx->stream));
+    MA_HIP(ctx, hipMemsetAsync(ws.mm_min, 0xFF, A * mcap * 4, ctx->stream));
+    ctx->tic("k_mm_insert");
+    hipLaunchKernelGGL(k_mm_insert, dim3(ws.n_active), dim3(kBT), 0, ctx->stream, b, ws);
+    ctx->toc();
+    ctx->tic("k_count");
+    hipLaunchKernelGGL(k_count, dim3(ws.n_active), dim3(kBT), 0, ctx->stream, b, ws);
+    ctx->toc();
+  }
   ctx->tic("k_rank");
   hipLaunchKernelGGL(k_rank, dim3(ws.n_active), dim3(kBT), 0, ctx->stream, b, ws,
                      static_cast<u32>(ctx->prm.min_node_cov));
