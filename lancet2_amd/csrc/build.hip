@@ -935,7 +935,21 @@ __device__ __forceinline__ void edge_insert(GraphWs const& ws, size_t nb, u32 no
   atomicOr(flags, 4u);  // more than kEdgeCap distinct edges at one node
 }
 
-__global__ __launch_bounds__(kBT) void k_edges(DBatch b, GraphWs ws) {
+// k_edges: an edge and its mirror per (k+1)-mer (graph.cpp:333-337).  ~7 of 8 read (k+1)-mers are the reference's
+// own edges and are skipped; the rest repeat a few thousand distinct edges many times.  Inserting every occurrence
+// into the per-node 16-slot lists in HBM cost a chain of dependent random line accesses each (measured: 8 ms,
+// ~60 GB of traffic per launch).  The window's distinct directed edges are therefore collected in an LDS set
+// first -- key = src << 17 | dst << 2 | kind, value = smallest order key (first occurrence) -- and each of them
+// is then stored once, its slot taken from a per-node LDS counter.  k_edge_sort orders the slots by order key.
+constexpr int kEdT = 1024;
+constexpr u32 kEdgeSet = 16384;
+constexpr u32 kEdgeNodes = 16384;
+constexpr u32 kEdgeEmpty = 0xFFFFFFFFu;
+__global__ __launch_bounds__(kEdT) void k_edges(DBatch b, GraphWs ws) {
+  __shared__ u32 l_key[kEdgeSet];
+  __shared__ u32 l_min[kEdgeSet];
+  __shared__ u8 l_deg[kEdgeNodes];
+  __shared__ u32 l_fail;
   int const a = blockIdx.x;
   int const w = static_cast<int>(ws.active[a]);
   if (ws.win_flags[w] & 4u) return;
@@ -943,29 +957,98 @@ __global__ __launch_bounds__(kBT) void k_edges(DBatch b, GraphWs ws) {
   const u32* inst_slot = ws.inst_slot + static_cast<size_t>(a) * ws.inst_stride;
   const u32* refn = ws.ref_node + static_cast<size_t>(a) * ws.ref_stride;
   size_t const nb = static_cast<size_t>(a) * ws.nc;
-  u32 const ns = seq_count(b, w);
-  u32 const base_idx = b.read_win_off[w] + w;
+  u32 const n_nodes = min(ws.n_nodes[a], ws.nc);
+  bool const use_set = ws.nc <= kEdgeNodes;  // per-node slot counters in LDS; 15-bit node indices in the packed key
+  for (u32 i = threadIdx.x; i < kEdgeSet; i += kEdT) {
+    l_key[i] = kEdgeEmpty;
+    l_min[i] = 0xFFFFFFFFu;
+  }
+  for (u32 i = threadIdx.x; i < kEdgeNodes / 4u; i += kEdT) reinterpret_cast<u32*>(l_deg)[i] = 0;
+  if (threadIdx.x == 0) l_fail = use_set ? 0u : 1u;
+  __syncthreads();
   // one (k+1)-mer per lane in flat instance order: (ii, ii + 1) unless ii is the last k-mer of its sequence
   u32 const ninst = ws.win_ninst[w], nref = ninst - ws.win_nread_inst[w];
-  (void)ns;
-  (void)base_idx;
-  for (u32 ii = threadIdx.x; ii + 1 < ninst; ii += kBT) {
-    u32 const wa = inst_slot[ii];
-    if (wa & kInstLast) continue;
-    u32 const wb = inst_slot[ii + 1];
+  u32 const last = ninst > 0 ? ninst - 1 : 0;
+  auto const set_insert = [&](u32 src, u32 val, u32 okey) {
+    u32 const key = (src << 17) | val;
+    if (key == kEdgeEmpty) {
+      l_fail = 1;
+      return;
+    }
+    u32 h = (key * 2654435761u) >> 18;  // kEdgeSet == 1 << 14
+    for (u32 probe = 0; probe < 256u; ++probe) {
+      u32 cur = l_key[h];
+      if (cur == kEdgeEmpty) {
+        u32 const old = atomicCAS(&l_key[h], kEdgeEmpty, key);
+        cur = old == kEdgeEmpty ? key : old;
+      }
+      if (cur == key) {
+        atomicMin(&l_min[h], okey);
+        return;
+      }
+      h = (h + 1) & (kEdgeSet - 1);
+    }
+    l_fail = 1;  // set (nearly) full: the window is redone with direct insertion below
+  };
+  // returns false for (k+1)-mers that add nothing
+  auto const edge_of = [&](u32 ii, u32 wa, u32 wb, u32* na, u32* nbn, u32* fwd, u32* rev) -> bool {
+    if (wa & kInstLast) return false;
     // both k-mers are reference nodes at consecutive positions: this (k+1)-mer is the reference's own edge,
     // already inserted (with a smaller order key) by the reference sequence itself
-    if (ii >= nref && (wa & kInstFast) && (wb & kInstFast) && (wb & kInstSlotMask) == (wa & kInstSlotMask) + 1) continue;
-    u32 const na = (wa & kInstFast) ? refn[wa & kInstSlotMask] : slot_node[wa & kInstSlotMask];
-    u32 const nbn = (wb & kInstFast) ? refn[wb & kInstSlotMask] : slot_node[wb & kInstSlotMask];
-    if (na == kNoNode || nbn == kNoNode) continue;
+    if (ii >= nref && (wa & kInstFast) && (wb & kInstFast) && (wb & kInstSlotMask) == (wa & kInstSlotMask) + 1) return false;
+    *na = (wa & kInstFast) ? refn[wa & kInstSlotMask] : slot_node[wa & kInstSlotMask];
+    *nbn = (wb & kInstFast) ? refn[wb & kInstSlotMask] : slot_node[wb & kInstSlotMask];
+    if (*na == kNoNode || *nbn == kNoNode) return false;
     // edge kind from the STORED signs of both nodes (graph.cpp:333-336)
-    u32 const sa_minus = ws.nd_sign[nb + na] ? 0u : 1u, sb_minus = ws.nd_sign[nb + nbn] ? 0u : 1u;
-    u32 const fwd = (sa_minus << 1) | sb_minus;                 // MakeFwdEdgeKind(sA, sB)
-    u32 const rev = ((sb_minus ^ 1u) << 1) | (sa_minus ^ 1u);   // RevEdgeKind(fwd) seen from B
-    u32 const key = 2u * ii;
-    edge_insert(ws, nb, na, (nbn << 2) | fwd, key, &ws.win_flags[w]);
-    edge_insert(ws, nb, nbn, (na << 2) | rev, key + 1u, &ws.win_flags[w]);
+    u32 const sa_minus = ws.nd_sign[nb + *na] ? 0u : 1u, sb_minus = ws.nd_sign[nb + *nbn] ? 0u : 1u;
+    *fwd = (sa_minus << 1) | sb_minus;                 // MakeFwdEdgeKind(sA, sB)
+    *rev = ((sb_minus ^ 1u) << 1) | (sa_minus ^ 1u);   // RevEdgeKind(fwd) seen from B
+    return true;
+  };
+  constexpr int kU = 4;
+  if (use_set) {
+    for (u32 i0 = threadIdx.x; i0 < last; i0 += kEdT * kU) {
+      u32 wa[kU], wb[kU];
+#pragma unroll
+      for (int u = 0; u < kU; ++u) {
+        u32 const ii = i0 + u * kEdT;
+        wa[u] = ii < last ? inst_slot[ii] : kInstLast;
+        wb[u] = ii < last ? inst_slot[ii + 1] : 0u;
+      }
+#pragma unroll
+      for (int u = 0; u < kU; ++u) {
+        u32 const ii = i0 + u * kEdT;
+        u32 na, nbn, fwd, rev;
+        if (!edge_of(ii, wa[u], wb[u], &na, &nbn, &fwd, &rev)) continue;
+        set_insert(na, (nbn << 2) | fwd, 2u * ii);
+        set_insert(nbn, (na << 2) | rev, 2u * ii + 1u);
+      }
+    }
+  }
+  __syncthreads();
+  if (l_fail == 0) {
+    for (u32 i = threadIdx.x; i < kEdgeSet; i += kEdT) {
+      u32 const key = l_key[i];
+      if (key == kEdgeEmpty) continue;
+      u32 const src = key >> 17, val = key & 0x1FFFFu;
+      // one u8 counter per node, four to a word
+      u32 const old = atomicAdd(reinterpret_cast<u32*>(l_deg) + (src >> 2), 1u << ((src & 3u) * 8u));
+      u32 const slot = (old >> ((src & 3u) * 8u)) & 0xFFu;
+      if (slot >= static_cast<u32>(kEdgeCap) || src >= n_nodes) {
+        atomicOr(&ws.win_flags[w], 4u);  // more than kEdgeCap distinct edges at one node
+        continue;
+      }
+      ws.nd_edge[(nb + src) * kEdgeCap + slot] = val;
+      ws.nd_ekey[(nb + src) * kEdgeCap + slot] = l_min[i];
+    }
+    return;
+  }
+  // direct insertion (set unusable for this window)
+  for (u32 ii = threadIdx.x; ii < last; ii += kEdT) {
+    u32 na, nbn, fwd, rev;
+    if (!edge_of(ii, inst_slot[ii], inst_slot[ii + 1], &na, &nbn, &fwd, &rev)) continue;
+    edge_insert(ws, nb, na, (nbn << 2) | fwd, 2u * ii, &ws.win_flags[w]);
+    edge_insert(ws, nb, nbn, (na << 2) | rev, 2u * ii + 1u, &ws.win_flags[w]);
   }
 }
 
@@ -1080,7 +1163,7 @@ int run_build_pass(ma_ctx* ctx, const DBatch& b, GraphWs& ws, u32* counters_dev,
                      static_cast<u32>(ctx->prm.min_node_cov));
   ctx->toc();
   ctx->tic("k_edges");
-  hipLaunchKernelGGL(k_edges, dim3(ws.n_active), dim3(kBT), 0, ctx->stream, b, ws);
+  hipLaunchKernelGGL(k_edges, dim3(ws.n_active), dim3(kEdT), 0, ctx->stream, b, ws);
   ctx->toc();
   ctx->tic("k_edge_sort");
   hipLaunchKernelGGL(k_edge_sort, dim3(ws.n_active), dim3(kBT), 0, ctx->stream, ws);
