@@ -367,6 +367,21 @@ __global__ __launch_bounds__(64) void k_classify(DBatch b, GraphWs ws, u32* max_
 // (2) k_insert: reference k-mers, then the slow queue -- one k-mer per lane, hashed from scratch (O(k)), so
 //     every lane of every wave does the same work.  A general-path k-mer that IS a reference node flags its
 //     read: the group-local mate-mer reasoning of k_support would be incomplete for that group.
+// node identity of the k-mer s[0, k): canonical decision + fmix64 of the polynomial hash of the canonical string.
+// The reverse-complement strand is hashed as the forward hash of the reversed complemented string (one multiply
+// per base instead of a running power).
+__device__ __forceinline__ u64 kmer_id(const u8* s, int k, bool* plus_out) {
+  u64 hf = 0, hr = 0;
+  for (int i = 0; i < k; ++i) {
+    hf = hf * kHashP + s[i];
+    hr = hr * kHashP + dev_complement(s[k - 1 - i]);
+  }
+  bool const plus = canon_plus(s, k);
+  u64 const id = dev_fmix64(plus ? hf : hr);
+  *plus_out = plus;
+  return id ? id : 1;
+}
+
 __global__ __launch_bounds__(kBT) void k_insert(DBatch b, GraphWs ws) {
   int const a = blockIdx.x;
   int const w = static_cast<int>(ws.active[a]);
@@ -380,15 +395,8 @@ __global__ __launch_bounds__(kBT) void k_insert(DBatch b, GraphWs ws) {
   u32 const base_idx = b.read_win_off[w] + w;
   SeqInfo const rsi = seq_info(b, w, 0, k);
   auto hash_insert = [&](const u8* s, u32 inst, u32* old_first) -> u32 {
-    u64 hf = 0, hr = 0, pw = 1;
-    for (int i = 0; i < k; ++i) {
-      hf = hf * kHashP + s[i];
-      hr += pw * dev_complement(s[i]);
-      pw *= kHashP;
-    }
-    bool const plus = canon_plus(s, k);
-    u64 id = dev_fmix64(plus ? hf : hr);
-    id = id ? id : 1;
+    bool plus;
+    u64 const id = kmer_id(s, k, &plus);
     u32 const slot = table_insert(keys, mask, id);
     *old_first = 0xFFFFFFFFu;
     if (slot == kNoNode) {
