@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LIB_PATH = os.path.join(REPO, "lancet2_amd", "libmicroasm.so")
+LIB_PATH = os.environ.get("MA_LIB") or os.path.join(REPO, "lancet2_amd", "libmicroasm.so")  # MA_LIB: developer A/B builds
 
 MA_RF_PASS, MA_RF_CASE, MA_RF_REV = 1, 2, 4
 MA_W_NO_HAPLOTYPE, MA_W_HAP_OVERFLOW, MA_W_LEN_OVERFLOW = 1, 2, 4
