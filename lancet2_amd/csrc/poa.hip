@@ -616,15 +616,19 @@ __device__ void poa_fill(GL const& g, PoaWs const& ws, u16* codes, i32* rows, i3
       for (int c = 0; c < CW; ++c) {
         i32 const ph = H1[c];
         i32 const a1 = F1[c] + E_, a2 = ph + G_, a3 = O1[c] + C_, a4 = ph + Q_;
-        i32 const fv = ff[c], ov = oo[c], hm = hmv[c], h = hh[c], e = ee[c], q = qq[c];
+        i32 const fv = ff[c], ov = oo[c], hm = hmv[c], h = hh[c], e = ee[c];
         i32 const b1 = eleft + E_, b2 = hleft + G_, b3 = qleft + C_;
+        // fv = max(a1, a2), ov = max(a3, a4), e = max(b1, b2), q = max(b3, b4) (the prefix-max values ARE these
+        // maxima), so SPOA's ordered equality tests collapse to: which argument of the winning max is it?
+        //   up:   h == a1 || (h != a2 && h == a3)   ==   (h == fv) ? a1 >= a2 : a3 >= a4      (given h == max(fv, ov))
+        //   left: h == b1 || (h != b2 && h == b3)   ==   (h == e)  ? b1 >= b2 : b3 >= b4      (given h == max(e, q))
+        i32 const b4 = hleft + Q_;
+        bool const A1 = a1 >= a2, A3 = a3 >= a4, B1 = b1 >= b2, B3 = b3 >= b4;
         bool const D = h == hm, U = h == max(fv, ov);
-        bool const eu = (h == a1) || ((h != a2) && (h == a3));
-        bool const elx = (h == b1) || ((h != b2) && (h == b3));
-        bool const lc = (b1 == e) || (b3 == q);
-        // fv = max(a1, a2), ov = max(a3, a4): if neither F nor O extends (a1 < a2 and a3 < a4) then fv == a2,
-        // i.e. the H-predecessor test of the up-extension walk holds
-        bool const us = (fv == a1) || (ov == a3);
+        bool const eu = (h == fv) ? A1 : A3;
+        bool const elx = (h == e) ? B1 : B3;
+        bool const lc = B1 || B3;
+        bool const us = A1 || A3;
         u32 code = D ? 0u : (U ? 1u : 2u);
         code |= (!D && (U ? eu : elx)) ? 4u : 0u;
         code |= lc ? 8u : 0u;
@@ -632,7 +636,7 @@ __device__ void poa_fill(GL const& g, PoaWs const& ws, u16* codes, i32* rows, i3
         cd[c] = code;
         hleft = h;
         eleft = e;
-        qleft = q;
+        qleft = qq[c];
       }
     } else {
       u32 elmask = 0, lcmask = 0;
