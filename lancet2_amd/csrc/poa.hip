@@ -52,12 +52,16 @@ struct PoaWs {
   u32 max_l;         // longest haplotype of the batch
   u32 w_stride;      // i32 per stored row and matrix
   u32 row_slots;     // stored rows per window
-  u32 use_band;      // try the 256-column banded fill first (MA_POA_BAND=1; off by default: no faster end to end yet)
+  u32 use_band;      // try the 256-column banded fill first (see launch_msa: MA_POA_BAND)
   size_t code_cells; // u16 per window
   size_t row_cells;  // i32 per window
   u16* codes;
   i32* rows;
   i32* hlast;        // [w][pn + 8] H(i, L)
+  // split mode (banded fill in its own kernel, k_msa_band): image of a window's LDS between kernel rounds
+  u32 split;
+  u32 img_words;     // u32 per image (the whole dynamic LDS block of k_msa)
+  u8* img;           // [w][img_words * 4]
 };
 
 // All per-window state lives in the kernel's dynamic LDS and is addressed as offsets into the
@@ -86,6 +90,9 @@ struct WgState {
   u32 nv;
   u32 x_done, x_a, x_ns;
   u32 win_overflow;
+  // split mode: where k_msa resumes after k_msa_band has filled the pending alignment, and thread 0's output cursor
+  u32 c_cur, h_cur, pending, done;
+  u32 nvars, pool, var_overflow;
 };
 #define ST (*reinterpret_cast<WgState*>(ma_lds))
 constexpr u32 kStBytes = (sizeof(WgState) + 15u) & ~15u;
@@ -1409,6 +1416,7 @@ struct MsaArgs {
   PoaWs ws;
   ma_params_t prm;
   int win0;
+  u32 round;  // split mode: 0 = start, > 0 = resume from the LDS image
 };
 
 template <int CWMAX>
@@ -1433,27 +1441,57 @@ __global__ __launch_bounds__(kT, 2) void k_msa(MsaArgs A) {
   i32* const hlast = ws.hlast + static_cast<size_t>(lw) * (PN + 8);
   u8* const raw = reinterpret_cast<u8*>(codes);  // raw-allele scratch of the bubble walk (codes are dead by then)
 
+  // Split mode: the banded fill of an alignment runs in k_msa_band (one wavefront per window, a dozen windows per
+  // CU instead of two) between two launches of this kernel.  This kernel then works like a coroutine: when an
+  // alignment is ready for the band it saves its whole LDS block (graph + state) to HBM and returns; the next
+  // launch restores the block and carries on right after the fill.
+  u32* const img = ws.split ? reinterpret_cast<u32*>(ws.img) + static_cast<size_t>(lw) * ws.img_words : nullptr;
+  bool resume = false;
+  if (A.round > 0) {
+    if (reinterpret_cast<const WgState*>(img)->done) return;
+    for (u32 i = tid; i < ws.img_words; i += kT) reinterpret_cast<u32*>(ma_lds)[i] = img[i];
+    __syncthreads();
+    resume = true;
+  }
   // thread 0's running output state
   u32 nvars = 0, pool = 0;
   bool overflow = false;
-  if (tid == 0) ST.win_overflow = 0;
+  if (resume) {
+    if (tid == 0) {
+      nvars = ST.nvars;
+      pool = ST.pool;
+      overflow = ST.var_overflow != 0;
+    }
+  } else if (tid == 0) {
+    ST.win_overflow = 0;
+    ST.done = 0;
+    ST.pending = 0;
+    ST.c_cur = ST.h_cur = 0;
+  }
+  __syncthreads();
   PROF_T0();
+  bool yielded = false;
+  u32 const c_start = resume ? ST.c_cur : 0u;
 
-  for (u32 c = 0; c < ncomp; ++c) {
+  for (u32 c = c_start; c < ncomp; ++c) {
+    bool const rc = resume && c == c_start;  // re-entering the component the pending alignment belongs to
     __syncthreads();
     if (ST.win_overflow) break;
     size_t const ci = static_cast<size_t>(w) * MC + c;
     u32 const hap0 = A.a.comp_hap0[ci], nh = A.a.comp_nhaps[ci];
-    if (tid == 0) {
+    if (tid == 0 && !rc) {
       ST.nn = ST.nseq = ST.nrank = 0;
       ST.overflow = nh > 16 ? 1u : 0u;  // label masks are 16 bit
     }
-    for (u32 h = 0; h < nh; ++h) {
+    u32 const h_start = rc ? ST.h_cur : 0u;
+    for (u32 h = h_start; h < nh; ++h) {
+      bool const rh = rc && h == h_start;  // the alignment k_msa_band has just filled
       size_t const hi = static_cast<size_t>(w) * MH + hap0 + h;
       const u8* seq = A.a.hap_bases + hi * ML;
       u32 const L = A.a.hap_len[hi];
       __syncthreads();
-      if (tid == 0) {
+      if (tid == 0 && rh) ST.pending = 0;
+      if (tid == 0 && !rh) {
         u32 mode = 0;
         if (!ST.overflow && L > 0) {
           if (ST.nn == 0) {
@@ -1507,6 +1545,7 @@ __global__ __launch_bounds__(kT, 2) void k_msa(MsaArgs A) {
       }
       // ---- mode 2: align the haplotype to the graph ----
       u32 const V = ST.V, cw = ST.cw;
+      if (!rh) {
       // per-row descriptors; which rows must be kept in HBM
       for (u32 i = tid; i <= V + 1; i += kT) g.rowslot[i] = 0;
       __syncthreads();
@@ -1596,12 +1635,28 @@ __global__ __launch_bounds__(kT, 2) void k_msa(MsaArgs A) {
       __syncthreads();
       if (ST.overflow) continue;
       PROF_ACC(0);
+      if (ws.split && ST.band && ST.nslow <= kSlowCap) {  // hand the fill to k_msa_band and come back afterwards
+        if (tid == 0) {
+          ST.c_cur = c;
+          ST.h_cur = h;
+          ST.pending = 1;
+          ST.band_fail = 0;
+          ST.nvars = nvars;
+          ST.pool = pool;
+          ST.var_overflow = overflow ? 1u : 0u;
+        }
+        yielded = true;
+        break;
+      }
+      }  // !rh
       // attempt 0: the 256-column band on one wavefront (exact when its certificate holds, see poa_fill_band);
       // attempt 1: the full row-synchronous fill
       for (int attempt = ST.band ? 0 : 1; attempt < 2; ++attempt) {
         if (attempt == 0) {
-          if (tid == 0) ST.band_fail = 0;
-          if (wave == 0) poa_fill_band(g, ws, codes, rows, hlast, V, L, lane, seq, &ST.edge_max);
+          if (!rh) {  // (split mode: k_msa_band has done this between the two launches)
+            if (tid == 0) ST.band_fail = 0;
+            if (wave == 0) poa_fill_band(g, ws, codes, rows, hlast, V, L, lane, seq, &ST.edge_max);
+          }
         } else {
           if (cw == 4) {
             poa_fill<4>(g, ws, codes, rows, hlast, V, L, tid, seq);
@@ -1821,6 +1876,7 @@ __global__ __launch_bounds__(kT, 2) void k_msa(MsaArgs A) {
       }
       PROF_ACC(4);
     }
+    if (yielded) break;
     __syncthreads();
 
     // ---- VariantExtractor over the component's POA graph: thread 0 walks, everybody helps skipping ----
@@ -2026,10 +2082,66 @@ __global__ __launch_bounds__(kT, 2) void k_msa(MsaArgs A) {
     if (tid == 0 && overflow) ST.win_overflow = 1;
     PROF_ACC(5);
   }
+  if (yielded) {  // save the LDS block; the next launch of this kernel resumes from it
+    __syncthreads();
+    for (u32 i = tid; i < ws.img_words; i += kT) img[i] = reinterpret_cast<const u32*>(ma_lds)[i];
+    return;
+  }
   if (tid == 0) {
     A.o.win_nvars[w] = nvars;
     if (overflow) A.a.win_status[w] |= MA_W_VAR_OVERFLOW;
+    if (ws.split) {
+      ST.done = 1;
+      ST.pending = 0;
+    }
   }
+  if (ws.split) {
+    __syncthreads();
+    for (u32 i = tid; i < kStBytes / 4; i += kT) img[i] = reinterpret_cast<const u32*>(ma_lds)[i];
+  }
+}
+
+// Split mode: the banded fill of every window's pending alignment, one wavefront per window.  Only the state block
+// and the row descriptors are staged (20 KB of LDS instead of the graph's 77 KB), so a CU holds many windows and the
+// dependent instruction chains of the row recurrence overlap across them.
+__global__ __launch_bounds__(64) void k_msa_band(MsaArgs A) {
+  int const lane = threadIdx.x;
+  int const lw = blockIdx.x;
+  int const w = A.win0 + lw;
+  ma_params_t const& P = A.prm;
+  PoaWs const& ws = A.ws;
+  if ((A.a.win_status[w] & MA_W_NO_HAPLOTYPE) || A.a.win_ncomp[w] == 0) return;
+  u32* const img = reinterpret_cast<u32*>(ws.img) + static_cast<size_t>(lw) * ws.img_words;
+  {
+    const WgState* pst = reinterpret_cast<const WgState*>(img);
+    if (pst->done || !pst->pending) return;
+  }
+  u32 const PN = ws.pn;
+  GL const full = poa_carve(PN, ws.max_l);
+  u32 const desc_bytes = 12u * (PN + 2u) + 8u * kSlowCap;  // rowinfo | rowslot | rowdepth | runhead | rowj0 | slowpred
+  for (u32 i = lane; i < kStBytes / 4; i += 64) reinterpret_cast<u32*>(ma_lds)[i] = img[i];
+  for (u32 i = lane; i < desc_bytes / 4; i += 64)
+    reinterpret_cast<u32*>(ma_lds + kStBytes)[i] = img[full.rowinfo.off / 4 + i];
+  GL g{};
+  g.pn = PN;
+  g.rowinfo.off = kStBytes;
+  g.rowslot.off = kStBytes + 4 * (PN + 2);
+  g.rowdepth.off = kStBytes + 6 * (PN + 2);
+  g.runhead.off = kStBytes + 8 * (PN + 2);
+  g.rowj0.off = kStBytes + 10 * (PN + 2);
+  g.slowpred.off = kStBytes + 12 * (PN + 2);
+  __builtin_amdgcn_s_waitcnt(0);
+  __builtin_amdgcn_wave_barrier();
+  __syncthreads();
+  size_t const ci = static_cast<size_t>(w) * P.max_comps + ST.c_cur;
+  size_t const hi = static_cast<size_t>(w) * P.max_haps + A.a.comp_hap0[ci] + ST.h_cur;
+  const u8* seq = A.a.hap_bases + hi * P.max_hap_len;
+  u16* const codes = ws.codes + static_cast<size_t>(lw) * ws.code_cells;
+  i32* const rows = ws.rows + static_cast<size_t>(lw) * ws.row_cells;
+  i32* const hlast = ws.hlast + static_cast<size_t>(lw) * (PN + 8);
+  poa_fill_band(g, ws, codes, rows, hlast, ST.V, ST.L, lane, seq, &ST.edge_max);
+  __syncthreads();
+  if (lane == 0) reinterpret_cast<WgState*>(img)->edge_max = ST.edge_max;
 }
 
 }  // namespace
@@ -2058,7 +2170,7 @@ int launch_msa(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& a, const ma_var
   }
   PoaWs ws{};
   // longest haplotype of the batch decides the DP width and the LDS graph capacity (one small D2H)
-  u32 max_len = 0;
+  u32 max_len = 0, rounds = 1;  // rounds: split mode, 1 + the most alignments of any window
   {
     size_t const cnt = static_cast<size_t>(n) * P.max_haps;
     std::vector<u32> hl(cnt), st(n), nc(n), h0(static_cast<size_t>(n) * P.max_comps), nh(static_cast<size_t>(n) * P.max_comps);
@@ -2070,10 +2182,13 @@ int launch_msa(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& a, const ma_var
     MA_HIP(ctx, hipStreamSynchronize(ctx->stream));
     for (int w = 0; w < n; ++w) {
       if (st[w] & MA_W_NO_HAPLOTYPE) continue;
+      u32 alignments = 0;
       for (u32 c = 0; c < nc[w]; ++c) {
         size_t const ci = static_cast<size_t>(w) * P.max_comps + c;
         for (u32 h = 0; h < nh[ci]; ++h) max_len = std::max(max_len, hl[static_cast<size_t>(w) * P.max_haps + h0[ci] + h]);
+        alignments += nh[ci] > 1 ? nh[ci] - 1 : 0;
       }
+      rounds = std::max(rounds, alignments + 1);
     }
   }
   max_len = std::max<u32>(max_len, 16);
@@ -2092,17 +2207,24 @@ int launch_msa(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& a, const ma_var
   ws.pn = pn;
   ws.w_stride = (max_len + 7) & ~7u;
   ws.row_slots = pn / 2;
-  ws.use_band = getenv("MA_POA_BAND") && atoi(getenv("MA_POA_BAND")) != 0 ? 1u : 0u;
+  // MA_POA_BAND: 2 (default) = 256-column banded fill in its own kernel (k_msa_band), 1 = banded fill inside k_msa,
+  // 0 = full row-synchronous fill only.  Results are identical (the band is certified or redone in full).
+  int const band_mode = getenv("MA_POA_BAND") ? atoi(getenv("MA_POA_BAND")) : 2;
+  ws.use_band = band_mode != 0 ? 1u : 0u;
+  ws.split = band_mode == 2 ? 1u : 0u;
+  ws.img_words = static_cast<u32>((lds + 3) / 4);
   ws.code_cells = (static_cast<size_t>(pn + 2) * (max_len + 16) + 7) & ~size_t(7);
   if (ws.code_cells * 2 < static_cast<size_t>(P.max_haps) * (2 * max_len + 8) + 64)  // raw-allele scratch lives in the codes
     ws.code_cells = (static_cast<size_t>(P.max_haps) * (2 * max_len + 8) / 2 + 64 + 7) & ~size_t(7);
   ws.row_cells = static_cast<size_t>(ws.row_slots) * 3 * ws.w_stride;
 
-  size_t const per_window = ws.code_cells * 2 + ws.row_cells * 4 + (static_cast<size_t>(pn) + 8) * 4;
+  size_t const img_bytes = ws.split ? ((static_cast<size_t>(ws.img_words) * 4 + 255) & ~size_t(255)) : 0;
+  ws.img_words = static_cast<u32>(ws.split ? img_bytes / 4 : ws.img_words);
+  size_t const per_window = ws.code_cells * 2 + ws.row_cells * 4 + (static_cast<size_t>(pn) + 8) * 4 + img_bytes;
   size_t budget = stage_budget(0.30, ctx->ws_poa.cap, size_t(24) << 30, ctx->hbm_share);
   if (const char* e = getenv("MA_WS_GB")) budget = static_cast<size_t>(atoi(e)) << 30;
   int const chunk = static_cast<int>(std::max<size_t>(1, std::min<size_t>(n, budget / per_window)));
-  MA_HIP(ctx, ctx->ws_poa.reserve(per_window * static_cast<size_t>(chunk) + 1024));
+  MA_HIP(ctx, ctx->ws_poa.reserve(per_window * static_cast<size_t>(chunk) + 4096));
   if (getenv("MA_VERBOSE"))
     fprintf(stderr, "[microasm] msa: %d windows, %.2f MB/window, budget %.1f GB -> chunks of %d (pn %u, max_len %u, lds %zu)\n", n,
             per_window / 1048576.0, budget / 1073741824.0, chunk, pn, max_len, lds);
@@ -2117,10 +2239,28 @@ int launch_msa(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& a, const ma_var
     ws.codes = reinterpret_cast<u16*>(base);
     ws.rows = reinterpret_cast<i32*>(base + csz);
     ws.hlast = reinterpret_cast<i32*>(base + csz + rsz);
-    MsaArgs args{b, a, o, ws, P, win0};
-    ctx->tic("k_msa");
-    hipLaunchKernelGGL(kern, dim3(nwin), dim3(kT), lds, ctx->stream, args);
-    ctx->toc();
+    size_t const hsz = (static_cast<size_t>(nwin) * (pn + 8) * 4 + 255) & ~size_t(255);
+    ws.img = reinterpret_cast<u8*>(base + csz + rsz + hsz);
+    MsaArgs args{b, a, o, ws, P, win0, 0u};
+    if (!ws.split) {
+      ctx->tic("k_msa");
+      hipLaunchKernelGGL(kern, dim3(nwin), dim3(kT), lds, ctx->stream, args);
+      ctx->toc();
+    } else {
+      // one round per pending alignment: k_msa runs up to the next banded fill, k_msa_band fills, k_msa resumes
+      size_t const band_lds = kStBytes + 12ull * (pn + 2) + 8ull * kSlowCap + 16;
+      for (u32 r = 0; r < rounds; ++r) {
+        args.round = r;
+        ctx->tic("k_msa");
+        hipLaunchKernelGGL(kern, dim3(nwin), dim3(kT), lds, ctx->stream, args);
+        ctx->toc();
+        if (r + 1 < rounds) {
+          ctx->tic("k_msa_band");
+          hipLaunchKernelGGL(k_msa_band, dim3(nwin), dim3(64), band_lds, ctx->stream, args);
+          ctx->toc();
+        }
+      }
+    }
     MA_HIP(ctx, hipGetLastError());
   }
   return MA_OK;

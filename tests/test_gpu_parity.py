@@ -124,11 +124,13 @@ def test_msa_parity(cfg, nwin, kw):
     assert want["win_nvars"].sum() > 0
 
 
+@pytest.mark.parametrize("band_mode", ["0", "1"])
 @pytest.mark.parametrize("cfg,nwin,kw", [("C2", 6, {}), ("C2", 2, dict(W=1700)), ("C2", 3, dict(big_indel=60))])
-def test_msa_parity_banded_fill(cfg, nwin, kw, monkeypatch):
-    """The optional 256-column banded POA fill (MA_POA_BAND=1) is exact by certificate or falls back."""
+def test_msa_parity_fill_modes(cfg, nwin, kw, band_mode, monkeypatch):
+    """The default is the banded POA fill in its own kernel (MA_POA_BAND=2, exercised by every other test); the
+    full row-synchronous fill (0) and the banded fill inside k_msa (1) must give the same bits."""
     from lancet2_amd.engine import Engine
-    monkeypatch.setenv("MA_POA_BAND", "1")
+    monkeypatch.setenv("MA_POA_BAND", band_mode)
     params = capi.default_params(min_k=25, max_k=25)
     arrs, n, nr = synth.make_config_batch(cfg, nwin, first_index=300, **kw)
     orc = OracleEngine(params)
