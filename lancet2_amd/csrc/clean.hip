@@ -367,11 +367,18 @@ __device__ __forceinline__ void compress_node_fast(Win& g, u32 nid, bool dflt, u
   }
   u32 const xsign = g.sign[nid];
   u32 const exp_minus = dflt ? (xsign ? 0u : 1u) : (xsign ? 1u : 0u);
-  bool dirty = false, xloaded = false;
-  u32 xlen = 0, xlabel = 0, xhead = 0, xtail = 0;
-  u32 xcnt[kMaxSamples], xrole0 = 0, xrole1 = 0;
+  bool dirty = false;
+  // The whole record of nid is fetched here, with its edges, and every load of one walk step is issued in two
+  // unconditional straight-line batches (the record of the neighbour b; then the far neighbour + b's slice): a
+  // load behind a branch cannot be hoisted, and the compiler then waits for memory at every use.
+  bool const xloaded = true;
+  u32 xlen = g.len[nid], xlabel = g.label[nid], xhead = g.head[nid], xtail = g.tail[nid];
+  u32 xcnt[kMaxSamples], xrole0 = g.role[nid * 2], xrole1 = g.role[nid * 2 + 1];
 #pragma unroll
-  for (int t = 0; t < kMaxSamples; ++t) xcnt[t] = 0;
+  for (int t = 0; t < kMaxSamples; ++t) {
+    u32 const v = g.cnt[nid * S + (t < S ? t : 0)];
+    xcnt[t] = t < S ? v : 0u;
+  }
   // opposite side: buddy test cached per edge value (its inputs do not change while we walk the other way)
   bool opp_known = false, opp_ok = false;
   u32 opp_val = 0, opp_nb = kNoNode, opp_f2 = kNoNode;
@@ -393,9 +400,6 @@ __device__ __forceinline__ void compress_node_fast(Win& g, u32 nid, bool dflt, u
     }
     dirty = false;
   };
-  // carried record of the next candidate (what memory holds for it right now)
-  bool have_b = false;
-  u32 b_id = 0, bn = 0, be0 = 0, be1 = 0, bsign = 0;
   while (true) {
     // ---- find_compressible_edge(nid, dflt) on the register copy ----
     if (xn > 2 || xn == 0) break;
@@ -409,23 +413,20 @@ __device__ __forceinline__ void compress_node_fast(Win& g, u32 nid, bool dflt, u
     u32 const opp = d0 ? xe1 : xe0;  // only meaningful when copp == 1
     u32 const d = cand >> 2;
     if (static_cast<i64>(d) == g.source || static_cast<i64>(d) == g.sink) break;
-    if (!have_b || b_id != d) {
-      bn = g.nedge[d];
-      uint2 const ev = *reinterpret_cast<const uint2*>(g.edge + static_cast<size_t>(d) * kEdgeCap);
-      be0 = ev.x;
-      be1 = ev.y;
-      bsign = g.sign[d];
-      b_id = d;
-      have_b = true;
-    }
-    // merge operands of b: independent of the tests below, issued with them
+    // ---- batch 1: the record of b, straight from memory (the previous step's stores to it are ordered before) ----
+    u32 const bn = g.nedge[d];
+    uint2 const bev = *reinterpret_cast<const uint2*>(g.edge + static_cast<size_t>(d) * kEdgeCap);
+    u32 const be0 = bev.x, be1 = bev.y;
+    u32 const bsign = g.sign[d];
     u32 const blen = g.len[d], blabel = g.label[d], bhead = g.head[d], btail = g.tail[d];
     u32 bcnt[kMaxSamples];
 #pragma unroll
-    for (int t = 0; t < kMaxSamples; ++t) bcnt[t] = t < S ? g.cnt[d * S + t] : 0u;
+    for (int t = 0; t < kMaxSamples; ++t) {
+      u32 const v = g.cnt[d * S + (t < S ? t : 0)];
+      bcnt[t] = t < S ? v : 0u;
+    }
     u32 const brole0 = g.role[d * 2], brole1 = g.role[d * 2 + 1];
-    u32 const bdesc_self = g.sdesc[d];  // issued with the batch: a never-merged node's only slice is itself
-    u32 const bdesc = (bhead == d || bhead == kNoNode) ? bdesc_self : g.sdesc[bhead];
+    u32 const bdesc_self = g.sdesc[d];  // a never-merged node's only slice is itself
     // ---- is_potential_buddy(nid, cand) ----
     if (xn == 1 && bn == 1 && (xe0 >> 2) == d && (be0 >> 2) == nid) break;
     if (bn > 2 || bn == 0) break;
@@ -444,15 +445,15 @@ __device__ __forceinline__ void compress_node_fast(Win& g, u32 nid, bool dflt, u
     if (f != expected) break;
     if ((f2 >> 2) == nid) break;
     u32 const fn = f2 >> 2;
+    // ---- batch 2: the far neighbour and b's first slice ----
     u32 fnn = g.nedge[fn];
+    uint2 const fev = *reinterpret_cast<const uint2*>(g.edge + static_cast<size_t>(fn) * kEdgeCap);
+    u32 const bdesc_head = g.sdesc[bhead != kNoNode ? bhead : d];
+    // one wait for the whole batch: without this the loads that are only used after the next test are sunk behind it
+    asm volatile("" ::"v"(fnn), "v"(fev.x), "v"(fev.y), "v"(bdesc_head));
+    u32 const bdesc = (bhead == d || bhead == kNoNode) ? bdesc_self : bdesc_head;
     if (fnn > 2) break;
-    u32 fe0, fe1, fe2 = 0;
-    {
-      uint2 const ev = *reinterpret_cast<const uint2*>(g.edge + static_cast<size_t>(fn) * kEdgeCap);
-      fe0 = ev.x;
-      fe1 = ev.y;
-    }
-    u32 const fsign = g.sign[fn];
+    u32 fe0 = fev.x, fe1 = fev.y, fe2 = 0;
     // ---- opposite side of nid ----
     if (copp > 1) break;
     if (copp == 1) {
@@ -469,17 +470,6 @@ __device__ __forceinline__ void compress_node_fast(Win& g, u32 nid, bool dflt, u
     }
     if (fn == d || fnn == 0) break;  // cannot happen on a consistent graph
     // ---- Node::Merge(b, kind) + Kmer::Merge ----
-    if (!xloaded) {
-      xlen = g.len[nid];
-      xlabel = g.label[nid];
-#pragma unroll
-      for (int t = 0; t < kMaxSamples; ++t) xcnt[t] = t < S ? g.cnt[nid * S + t] : 0u;
-      xrole0 = g.role[nid * 2];
-      xrole1 = g.role[nid * 2 + 1];
-      xhead = g.head[nid];
-      xtail = g.tail[nid];
-      xloaded = true;
-    }
     u32 const ob = d, kind = cand & 3u;
     bool const append = kind == 0 || kind == 1;
     bool const rc = kind == 1 || kind == 2;
@@ -527,6 +517,9 @@ __device__ __forceinline__ void compress_node_fast(Win& g, u32 nid, bool dflt, u
       }
       xhead = g.head[nid];
       xtail = g.tail[nid];
+      // settle these loads inside the rare branch: pending at the join they would make the common path wait for
+      // all its outstanding memory operations on every merge
+      asm volatile("" ::"v"(xhead), "v"(xtail));
     }
     g.head[ob] = kNoNode;
     g.tail[ob] = kNoNode;
@@ -582,13 +575,6 @@ __device__ __forceinline__ void compress_node_fast(Win& g, u32 nid, bool dflt, u
     CCOUNT(11);
     absorbed[ob] = 2;  // absorbed by the register walk: nothing points at it any more
     dirty = true;
-    // the far neighbour is the next candidate
-    b_id = fn;
-    bn = fnn;
-    be0 = fe0;
-    be1 = fe1;
-    bsign = fsign;
-    have_b = fnn <= 2;
   }
   flush();
   compress_node(g, nid, dflt, absorbed);  // re-evaluates from memory: finishes the walk or stops it
