@@ -2118,18 +2118,26 @@ __global__ __launch_bounds__(64) void k_msa_band(MsaArgs A) {
   }
   u32 const PN = ws.pn;
   GL const full = poa_carve(PN, ws.max_l);
-  u32 const desc_bytes = 12u * (PN + 2u) + 8u * kSlowCap;  // rowinfo | rowslot | rowdepth | runhead | rowj0 | slowpred
+  // staged: rowinfo | rowslot | rowdepth | rowj0 | slowpred (runhead is not needed by the fill)
   for (u32 i = lane; i < kStBytes / 4; i += 64) reinterpret_cast<u32*>(ma_lds)[i] = img[i];
-  for (u32 i = lane; i < desc_bytes / 4; i += 64)
-    reinterpret_cast<u32*>(ma_lds + kStBytes)[i] = img[full.rowinfo.off / 4 + i];
   GL g{};
   g.pn = PN;
   g.rowinfo.off = kStBytes;
   g.rowslot.off = kStBytes + 4 * (PN + 2);
   g.rowdepth.off = kStBytes + 6 * (PN + 2);
-  g.runhead.off = kStBytes + 8 * (PN + 2);
-  g.rowj0.off = kStBytes + 10 * (PN + 2);
-  g.slowpred.off = kStBytes + 12 * (PN + 2);
+  g.rowj0.off = kStBytes + 8 * (PN + 2);
+  g.slowpred.off = kStBytes + 10 * (PN + 2);
+  g.runhead.off = g.rowj0.off;  // unused
+  {
+    auto const copy = [&](u32 dst_off, u32 src_off, u32 bytes) {
+      for (u32 i = lane; i < bytes / 4; i += 64) reinterpret_cast<u32*>(ma_lds + dst_off)[i] = img[src_off / 4 + i];
+    };
+    copy(g.rowinfo.off, full.rowinfo.off, 4 * (PN + 2));
+    copy(g.rowslot.off, full.rowslot.off, 2 * (PN + 2));
+    copy(g.rowdepth.off, full.rowdepth.off, 2 * (PN + 2));
+    copy(g.rowj0.off, full.rowj0.off, 2 * (PN + 2));
+    copy(g.slowpred.off, full.slowpred.off, 8 * kSlowCap);
+  }
   __builtin_amdgcn_s_waitcnt(0);
   __builtin_amdgcn_wave_barrier();
   __syncthreads();
@@ -2248,7 +2256,7 @@ int launch_msa(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& a, const ma_var
       ctx->toc();
     } else {
       // one round per pending alignment: k_msa runs up to the next banded fill, k_msa_band fills, k_msa resumes
-      size_t const band_lds = kStBytes + 12ull * (pn + 2) + 8ull * kSlowCap + 16;
+      size_t const band_lds = kStBytes + 10ull * (pn + 2) + 8ull * kSlowCap + 16;
       for (u32 r = 0; r < rounds; ++r) {
         args.round = r;
         ctx->tic("k_msa");
