@@ -326,7 +326,8 @@ __device__ int bytes_cmp(const u8* a, u32 al, const u8* b, u32 bl) {  // std::st
 }
 
 // DP row of predecessor x of DP row i (row = rank + 1), in in-edge order
-__device__ __forceinline__ u32 pred_row(GL const& g, u32 i, u32 info, u32 x) {
+template <class G>
+__device__ __forceinline__ u32 pred_row(G const& g, u32 i, u32 info, u32 x) {
   if (info & RI_FAST) return i - 1;
   if (info & RI_SLOWTAB) return g.slowpred[(info >> 16) * kPE + x];
   u32 const node = g.rank2node[i - 1];
@@ -801,7 +802,8 @@ __device__ void poa_fill(GL const& g, PoaWs const& ws, u16* codes, i32* rows, i3
 // the columns that fall off the left edge are exits, the ones that enter start at minus infinity.
 __device__ __forceinline__ i32 wave_shl1(i32 x, i32 fill) { return dpp_mov<0x130, 0xF>(x, fill); }  // lane l <- lane l + 1
 
-__device__ void poa_fill_band(GL const& g, PoaWs const& ws, u16* codes, i32* rows, i32* hlast, u32 V, u32 L, int lane,
+template <class G>
+__device__ void poa_fill_band(G const& g, PoaWs const& ws, u16* codes, i32* rows, i32* hlast, u32 V, u32 L, int lane,
                               const u8* seq, i32* edge_out) {
   constexpr int CW = 4;
   constexpr i32 NEG = kScanIdent;
@@ -2101,9 +2103,24 @@ __global__ __launch_bounds__(kT, 2) void k_msa(MsaArgs A) {
   }
 }
 
+// The row descriptors of a pending alignment, read straight from the window's LDS image in HBM: every access is
+// wave-uniform and the fill asks for row i + 1 while it works on row i, so no LDS staging is needed and the
+// occupancy of k_msa_band is bounded by its registers alone.
+struct DescView {
+  const u32* __restrict__ rowinfo;
+  const u16* __restrict__ rowslot;
+  const u16* __restrict__ rowdepth;
+  const u16* __restrict__ rowj0;
+  const u16* __restrict__ slowpred;
+  // only reached for rows without a cached predecessor list, which k_msa never hands over (nslow <= kSlowCap)
+  const u16* __restrict__ rank2node;
+  const u16* __restrict__ node2rank;
+  const u16* __restrict__ in_tail;
+};
+
 // Split mode: the banded fill of every window's pending alignment, one wavefront per window.  Only the state block
-// and the row descriptors are staged (20 KB of LDS instead of the graph's 77 KB), so a CU holds many windows and the
-// dependent instruction chains of the row recurrence overlap across them.
+// is staged in LDS (instead of the graph's 77 KB), so a CU holds sixteen windows and the dependent instruction
+// chains of the row recurrence overlap across them.
 __global__ __launch_bounds__(64) void k_msa_band(MsaArgs A) {
   int const lane = threadIdx.x;
   int const lw = blockIdx.x;
@@ -2118,26 +2135,17 @@ __global__ __launch_bounds__(64) void k_msa_band(MsaArgs A) {
   }
   u32 const PN = ws.pn;
   GL const full = poa_carve(PN, ws.max_l);
-  // staged: rowinfo | rowslot | rowdepth | rowj0 | slowpred (runhead is not needed by the fill)
   for (u32 i = lane; i < kStBytes / 4; i += 64) reinterpret_cast<u32*>(ma_lds)[i] = img[i];
-  GL g{};
-  g.pn = PN;
-  g.rowinfo.off = kStBytes;
-  g.rowslot.off = kStBytes + 4 * (PN + 2);
-  g.rowdepth.off = kStBytes + 6 * (PN + 2);
-  g.rowj0.off = kStBytes + 8 * (PN + 2);
-  g.slowpred.off = kStBytes + 10 * (PN + 2);
-  g.runhead.off = g.rowj0.off;  // unused
-  {
-    auto const copy = [&](u32 dst_off, u32 src_off, u32 bytes) {
-      for (u32 i = lane; i < bytes / 4; i += 64) reinterpret_cast<u32*>(ma_lds + dst_off)[i] = img[src_off / 4 + i];
-    };
-    copy(g.rowinfo.off, full.rowinfo.off, 4 * (PN + 2));
-    copy(g.rowslot.off, full.rowslot.off, 2 * (PN + 2));
-    copy(g.rowdepth.off, full.rowdepth.off, 2 * (PN + 2));
-    copy(g.rowj0.off, full.rowj0.off, 2 * (PN + 2));
-    copy(g.slowpred.off, full.slowpred.off, 8 * kSlowCap);
-  }
+  const u8* const ib = reinterpret_cast<const u8*>(img);
+  DescView g;
+  g.rowinfo = reinterpret_cast<const u32*>(ib + full.rowinfo.off);
+  g.rowslot = reinterpret_cast<const u16*>(ib + full.rowslot.off);
+  g.rowdepth = reinterpret_cast<const u16*>(ib + full.rowdepth.off);
+  g.rowj0 = reinterpret_cast<const u16*>(ib + full.rowj0.off);
+  g.slowpred = reinterpret_cast<const u16*>(ib + full.slowpred.off);
+  g.rank2node = reinterpret_cast<const u16*>(ib + full.rank2node.off);
+  g.node2rank = reinterpret_cast<const u16*>(ib + full.node2rank.off);
+  g.in_tail = reinterpret_cast<const u16*>(ib + full.in_tail.off);
   __builtin_amdgcn_s_waitcnt(0);
   __builtin_amdgcn_wave_barrier();
   __syncthreads();
@@ -2256,7 +2264,7 @@ int launch_msa(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& a, const ma_var
       ctx->toc();
     } else {
       // one round per pending alignment: k_msa runs up to the next banded fill, k_msa_band fills, k_msa resumes
-      size_t const band_lds = kStBytes + 10ull * (pn + 2) + 8ull * kSlowCap + 16;
+      size_t const band_lds = kStBytes + 16;
       for (u32 r = 0; r < rounds; ++r) {
         args.round = r;
         ctx->tic("k_msa");
