@@ -441,3 +441,31 @@ def test_annotate_handmade_cases(gc):
     assert compare_cx(params, got, want, var["win_nvars"]) == n
     # sanity against the reference's expectations for its own fixtures
     assert want["seq_cx_i"][0] >= 20 and want["seq_cx_i"].reshape(n, -1, 4)[1, 0, 0] == 1
+
+
+@pytest.mark.parametrize("cfg,nwin,first,kw", [("C2", 40, 20_000, {}), ("C3", 10, 30_000, {}),
+                                                ("C2", 12, 40_000, dict(error_scale=3.0, indel_rate=1e-3)),
+                                                ("C2", 8, 50_000, dict(str_unit=b"CAG", n_somatic=3))])
+def test_process_batch_seed_sweep(cfg, nwin, first, kw):
+    """Many more seeds than the targeted cases above: the whole chain (+ annotation) against the oracle, with the
+    default settings (read hints, banded POA kernel, automatic lanes)."""
+    from lancet2_amd.engine import Engine
+    params = capi.default_params(min_k=25, max_k=37)
+    arrs, n, nr = synth.make_config_batch(cfg, nwin, first_index=first, **kw)
+    orc = OracleEngine(params)
+    wg = orc.gate(arrs, n, nr)
+    wa = orc.assemble(arrs, n, nr)
+    wv = orc.msa(arrs, n, nr, wa)
+    wq = orc.genotype(arrs, n, nr, wa, wv)
+    wc = orc.annotate(arrs, n, nr, wa, wv)
+    eng = Engine(params)
+    try:
+        g, a, v, q = eng.process(arrs, n, nr, debug=True)
+        cx = eng.annotate(arrs, n, nr, a, v)
+    finally:
+        eng.close()
+    assert np.array_equal(g["max_approx"], wg["max_approx"]) and np.array_equal(g["max_exact"], wg["max_exact"])
+    bad = compare_asm(params, a, wa, n) + compare_vars(params, v, wv, n)
+    bad += compare_geno(params, q, wq, n, nr, wv["win_nvars"], arrs["read_win_off"])
+    assert not bad, "\n".join(bad[:20])
+    compare_cx(params, cx, wc, wv["win_nvars"])
