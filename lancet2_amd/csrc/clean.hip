@@ -352,6 +352,7 @@ __device__ __forceinline__ bool is_potential_buddy_f2(const Win& g, u32 src, u32
 // is_potential_buddy predicates evaluated on register copies of what memory holds); as soon as a test
 // fails or anything unusual shows up (node coincidences of a cycle, duplicate edges) it writes its
 // state back and hands over to the generic compress_node, which re-evaluates from memory.
+template <int SMAX>  // per-sample registers of the walk: 2 covers tumour/normal, kMaxSamples everything else
 __device__ __forceinline__ void compress_node_fast(Win& g, u32 nid, bool dflt, u8* absorbed) {
   // NOTE: no dynamically indexed local arrays in here -- they would live in scratch (HBM latency)
   if (static_cast<i64>(nid) == g.source || static_cast<i64>(nid) == g.sink) return;
@@ -373,9 +374,9 @@ __device__ __forceinline__ void compress_node_fast(Win& g, u32 nid, bool dflt, u
   // load behind a branch cannot be hoisted, and the compiler then waits for memory at every use.
   bool const xloaded = true;
   u32 xlen = g.len[nid], xlabel = g.label[nid], xhead = g.head[nid], xtail = g.tail[nid];
-  u32 xcnt[kMaxSamples], xrole0 = g.role[nid * 2], xrole1 = g.role[nid * 2 + 1];
+  u32 xcnt[SMAX], xrole0 = g.role[nid * 2], xrole1 = g.role[nid * 2 + 1];
 #pragma unroll
-  for (int t = 0; t < kMaxSamples; ++t) {
+  for (int t = 0; t < SMAX; ++t) {
     u32 const v = g.cnt[nid * S + (t < S ? t : 0)];
     xcnt[t] = t < S ? v : 0u;
   }
@@ -391,7 +392,7 @@ __device__ __forceinline__ void compress_node_fast(Win& g, u32 nid, bool dflt, u
       g.len[nid] = xlen;
       g.label[nid] = static_cast<u8>(xlabel);
 #pragma unroll
-      for (int t = 0; t < kMaxSamples; ++t)
+      for (int t = 0; t < SMAX; ++t)
         if (t < S) g.cnt[nid * S + t] = xcnt[t];
       g.role[nid * 2] = xrole0;
       g.role[nid * 2 + 1] = xrole1;
@@ -419,9 +420,9 @@ __device__ __forceinline__ void compress_node_fast(Win& g, u32 nid, bool dflt, u
     u32 const be0 = bev.x, be1 = bev.y;
     u32 const bsign = g.sign[d];
     u32 const blen = g.len[d], blabel = g.label[d], bhead = g.head[d], btail = g.tail[d];
-    u32 bcnt[kMaxSamples];
+    u32 bcnt[SMAX];
 #pragma unroll
-    for (int t = 0; t < kMaxSamples; ++t) {
+    for (int t = 0; t < SMAX; ++t) {
       u32 const v = g.cnt[d * S + (t < S ? t : 0)];
       bcnt[t] = t < S ? v : 0u;
     }
@@ -528,7 +529,7 @@ __device__ __forceinline__ void compress_node_fast(Win& g, u32 nid, bool dflt, u
     {
       u64 const this_len = xlen, other_len = blen;  // node.cpp:91: length AFTER the merge
 #pragma unroll
-      for (int t = 0; t < kMaxSamples; ++t)
+      for (int t = 0; t < SMAX; ++t)
         if (t < S) xcnt[t] = weighted_floor_avg(xcnt[t], this_len, bcnt[t], other_len);
       xrole0 = weighted_floor_avg(xrole0, this_len, brole0, other_len);
       xrole1 = weighted_floor_avg(xrole1, this_len, brole1, other_len);
@@ -594,7 +595,10 @@ __device__ __forceinline__ void compress_graph(Win& g, u32 comp) {
       todo &= todo - 1;
       if (absorbed[i]) continue;
 #pragma nounroll
-      for (int dir = 1; dir >= 0; --dir) compress_node_fast(g, i, dir != 0, absorbed);
+      for (int dir = 1; dir >= 0; --dir) {
+        if (g.S <= 2) compress_node_fast<2>(g, i, dir != 0, absorbed);
+        else compress_node_fast<kMaxSamples>(g, i, dir != 0, absorbed);
+      }
     }
   }
   // absorbed == 2 (register walk): remove_node would only look for mirror edges that the walk has already
