@@ -469,3 +469,25 @@ def test_process_batch_seed_sweep(cfg, nwin, first, kw):
     bad += compare_geno(params, q, wq, n, nr, wv["win_nvars"], arrs["read_win_off"])
     assert not bad, "\n".join(bad[:20])
     compare_cx(params, cx, wc, wv["win_nvars"])
+
+
+def test_process_batch_deep_window():
+    """A 300x/300x panel-style window (4288 reads, 50 bp indels): more sequences than the LDS-resident shortcuts
+    of the build stage accept (k_mm_lds falls back to the HBM mate-mer set), four haplotypes, 13 variants."""
+    from lancet2_amd.engine import Engine
+    params = capi.default_params(min_k=25, max_k=25)
+    arrs, n, nr = synth.make_config_batch("C4", 1, first_index=60000, depths=(300, 300))
+    assert nr > 2048
+    orc = OracleEngine(params)
+    wa = orc.assemble(arrs, n, nr)
+    wv = orc.msa(arrs, n, nr, wa)
+    wq = orc.genotype(arrs, n, nr, wa, wv)
+    eng = Engine(params)
+    try:
+        _, a, v, q = eng.process(arrs, n, nr, debug=True)
+    finally:
+        eng.close()
+    bad = compare_asm(params, a, wa, n) + compare_vars(params, v, wv, n)
+    bad += compare_geno(params, q, wq, n, nr, wv["win_nvars"], arrs["read_win_off"])
+    assert not bad, "\n".join(bad[:20])
+    assert int(wv["win_nvars"][0]) >= 8
