@@ -652,34 +652,49 @@ __device__ __forceinline__ u8 slice_base(const Win& g, u32 o, u32 d, u32 j) {  /
 }
 // append the oriented sequence of `node` (dflt: stored orientation, else reverse complement) minus its
 // first `skip` bases to out[*pos..], bounded by cap.  Returns false on overflow.
+// A unitig is a linked list of slices, mostly one base each (every merged k-mer adds its non-overlapping base), so
+// spelling it base by base is one chain of dependent loads per base.  Instead the list is walked once for the slice
+// ids (one dependent load per slice), and the slices are then spelled 64 at a time: descriptor, source and base
+// loads of 64 slices are in flight together and a prefix sum of the slice lengths gives every base its position.
 __device__ __forceinline__ bool emit_node_seq(const Win& g, u32 node, bool dflt, u32 skip, u8* out, u32* pos, u32 cap) {
-  bool ok = true;
+  u32* ids = g.scratch + 7u * g.nc;  // adjacency scratch of the traversal index: dead once the walks are enumerated
+  u32 ns = 0;
   if (dflt) {
-    for (u32 s = g.head[node]; s != kNoNode; s = g.snext[s]) {
-      u32 const d = g.sdesc[s], ln = (d >> 8) & 0xFFu;
-      for (u32 j = 0; j < ln; ++j) {
-        if (skip > 0) {
-          skip--;
-          continue;
-        }
-        if (*pos < cap) out[*pos] = slice_base(g, s, d, j); else ok = false;
-        (*pos)++;
-      }
-    }
+    for (u32 s = g.head[node]; s != kNoNode; s = g.snext[s]) ids[ns++] = s;
   } else {
-    for (u32 s = g.tail[node]; s != kNoNode; s = g.sprev[s]) {
-      u32 const d = g.sdesc[s], ln = (d >> 8) & 0xFFu;
-      for (u32 j = ln; j-- > 0;) {
-        if (skip > 0) {
-          skip--;
-          continue;
-        }
-        if (*pos < cap) out[*pos] = dev_complement(slice_base(g, s, d, j)); else ok = false;
-        (*pos)++;
-      }
-    }
+    for (u32 s = g.tail[node]; s != kNoNode; s = g.sprev[s]) ids[ns++] = s;
   }
-  return ok;
+  wave_sync_mem();
+  u32 const lane = lane_id();
+  bool over = false;
+  u32 emitted = 0;  // bases of the node spelled by the blocks before this one
+  for (u32 b0 = 0; b0 < ns; b0 += 64) {
+    u32 const idx = b0 + lane;
+    u32 s = 0, d = 0, ln = 0;
+    if (idx < ns) {
+      s = ids[idx];
+      d = g.sdesc[s];
+      ln = (d >> 8) & 0xFFu;
+    }
+    u32 inc = ln;
+#pragma unroll
+    for (u32 o = 1; o < 64; o <<= 1) {
+      u32 const y = __shfl_up(inc, o, 64);
+      if (lane >= o) inc += y;
+    }
+    u32 const off = emitted + inc - ln;
+    for (u32 j = 0; j < ln; ++j) {
+      u32 const e = off + j;  // index of this base within the node's oriented sequence
+      if (e < skip) continue;
+      u32 const at = *pos + (e - skip);
+      u8 const base = dflt ? slice_base(g, s, d, j) : dev_complement(slice_base(g, s, d, ln - 1 - j));
+      if (at < cap) out[at] = base; else over = true;
+    }
+    emitted += __shfl(inc, 63, 64);
+  }
+  *pos += emitted > skip ? emitted - skip : 0u;
+  wave_sync_mem();
+  return __ballot(over) == 0;
 }
 
 struct OnlineStats {  // base/compute_stats.h:75-125
