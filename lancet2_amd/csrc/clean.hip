@@ -658,14 +658,25 @@ __device__ __forceinline__ u8 slice_base(const Win& g, u32 o, u32 d, u32 j) {  /
 // loads of 64 slices are in flight together and a prefix sum of the slice lengths gives every base its position.
 __device__ __forceinline__ bool emit_node_seq(const Win& g, u32 node, bool dflt, u32 skip, u8* out, u32* pos, u32 cap) {
   u32* ids = g.scratch + 7u * g.nc;  // adjacency scratch of the traversal index: dead once the walks are enumerated
+  u32 const lane = lane_id();
+  // The list is followed 64 candidates at a time: slices of neighbouring k-mers have neighbouring indices, so lane l
+  // looks at slice s + l (s - l when walking backwards); as long as each one links to the next index the whole run
+  // belongs to the list -- by induction from s -- and costs one round trip instead of one per slice.
   u32 ns = 0;
-  if (dflt) {
-    for (u32 s = g.head[node]; s != kNoNode; s = g.snext[s]) ids[ns++] = s;
-  } else {
-    for (u32 s = g.tail[node]; s != kNoNode; s = g.sprev[s]) ids[ns++] = s;
+  {
+    u32 s = dflt ? g.head[node] : g.tail[node];
+    while (s != kNoNode) {
+      u32 const mine = dflt ? s + lane : s - lane;  // wraps past 0 when walking backwards: rejected by the bound
+      u32 const nx = mine < g.nc ? (dflt ? g.snext[mine] : g.sprev[mine]) : kNoNode;
+      bool const linked = nx == (dflt ? mine + 1u : mine - 1u) && (dflt || mine != 0u);
+      unsigned long long const m = __ballot(linked);
+      u32 const run = m == ~0ull ? 63u : static_cast<u32>(__builtin_ctzll(~m));  // lanes 0 .. run are on the list
+      if (lane <= run) ids[ns + lane] = mine;
+      ns += run + 1u;
+      s = static_cast<u32>(__builtin_amdgcn_readlane(static_cast<int>(nx), static_cast<int>(run)));
+    }
   }
   wave_sync_mem();
-  u32 const lane = lane_id();
   bool over = false;
   u32 emitted = 0;  // bases of the node spelled by the blocks before this one
   for (u32 b0 = 0; b0 < ns; b0 += 64) {
