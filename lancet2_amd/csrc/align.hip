@@ -26,6 +26,8 @@
 #include <cstdlib>
 #include <vector>
 
+#include <type_traits>
+
 #include "ma_internal.h"
 
 namespace ma {
@@ -875,33 +877,45 @@ __global__ __launch_bounds__(64) void k_align_reg(GArgs A, u32 seg_words) {
       i32 lh = NEGR, le = NEGR, last_h = NEGR;
       u32 word = 0;
       u32* tbrow = tb + static_cast<size_t>(i) * A.ws.tb_words * 64 + lane;
+      // Rows whose band window lies inside the haplotype for every pair of the wavefront (almost all of them: reads
+      // hanging over a haplotype end are settled by the certificates) skip the wall handling: ~7 of ~50 operations
+      // per cell.
+      bool const my_walls = (c - B + i <= 0) || (c + B + i - 1 >= n);
+      auto const row = [&](auto walls_tag) {
+        constexpr bool WALLS = decltype(walls_tag)::value;
 #pragma unroll
-      for (int t = 0; t < WD; ++t) {
-        u32 const code = (sw[t >> 3] >> (4 * (t & 7))) & 0xFu;
-        i32 const dh = static_cast<i16>(HF[t] & 0xFFFFu);
-        i32 const uh = static_cast<i16>(HF[t + 1] & 0xFFFFu), uf = static_cast<i32>(HF[t + 1]) >> 16;
-        i32 const s = code > 3 ? -1 : (code == qcmp ? 1 : smis);
-        i32 const dg = dh + s;
-        i32 const eo = lh - (GO + GE), ee = le - GE;
-        i32 const fo = uh - (GO + GE), fe = uf - GE;
-        i32 e = max(eo, ee), f = max(fo, fe);
-        i32 h = max(dg, max(e, f));
-        u32 nib = (dg >= e && dg >= f) ? 0u : (e >= f ? 1u : 2u);
-        nib |= (eo >= ee ? 4u : 0u) | (fo >= fe ? 8u : 0u);
-        bool const wall = code >= 6;
-        h = wall ? (code == 6 ? 0 : NEGR) : h;
-        e = wall ? NEGR : e;
-        f = wall ? NEGR : f;
-        HF[t] = (static_cast<u32>(h) & 0xFFFFu) | (static_cast<u32>(f) << 16);
-        lh = h;
-        le = e;
-        last_h = code == 7 ? last_h : h;
-        word |= nib << (4 * (t & 7));
-        if ((t & 7) == 7 || t == WD - 1) {
-          tbrow[static_cast<size_t>(t >> 3) * 64] = word;
-          word = 0;
+        for (int t = 0; t < WD; ++t) {
+          u32 const code = (sw[t >> 3] >> (4 * (t & 7))) & 0xFu;
+          i32 const dh = static_cast<i16>(HF[t] & 0xFFFFu);
+          i32 const uh = static_cast<i16>(HF[t + 1] & 0xFFFFu), uf = static_cast<i32>(HF[t + 1]) >> 16;
+          i32 const s = code > 3 ? -1 : (code == qcmp ? 1 : smis);
+          i32 const dg = dh + s;
+          i32 const eo = lh - (GO + GE), ee = le - GE;
+          i32 const fo = uh - (GO + GE), fe = uf - GE;
+          i32 e = max(eo, ee), f = max(fo, fe);
+          i32 h = max(dg, max(e, f));
+          u32 nib = (dg >= e && dg >= f) ? 0u : (e >= f ? 1u : 2u);
+          nib |= (eo >= ee ? 4u : 0u) | (fo >= fe ? 8u : 0u);
+          if constexpr (WALLS) {
+            bool const wall = code >= 6;
+            h = wall ? (code == 6 ? 0 : NEGR) : h;
+            e = wall ? NEGR : e;
+            f = wall ? NEGR : f;
+            last_h = code == 7 ? last_h : h;
+          } else {
+            last_h = h;
+          }
+          HF[t] = (static_cast<u32>(h) & 0xFFFFu) | (static_cast<u32>(f) << 16);
+          lh = h;
+          le = e;
+          word |= nib << (4 * (t & 7));
+          if ((t & 7) == 7 || t == WD - 1) {
+            tbrow[static_cast<size_t>(t >> 3) * 64] = word;
+            word = 0;
+          }
         }
-      }
+      };
+      if (__ballot(my_walls) != 0) row(std::true_type{}); else row(std::false_type{});
       // end cell (i, n) for i < m: the last in-haplotype cell of the row is column n iff the band reaches it
       if (i < mrows && i + c + B >= n && i + c - B <= n) {
         if (last_h >= best) {  // later rows win ties (larger i)
