@@ -118,6 +118,7 @@ int launch_assemble(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& out, const
     g.slowq = c.take<u32>(A * g.inst_stride);
     g.n_slow = c.take<u32>(A);
     g.mm_mode = c.take<u32>(A);
+    g.win_tc = c.take<u32>(A);
     g.mm_key = c.take<u64>(A * mcap);
     g.mm_min = c.take<u32>(A * mcap);
     g.n_nodes = c.take<u32>(A);

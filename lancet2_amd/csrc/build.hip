@@ -386,7 +386,6 @@ __global__ __launch_bounds__(kBT) void k_insert(DBatch b, GraphWs ws) {
   int const a = blockIdx.x;
   int const w = static_cast<int>(ws.active[a]);
   int const k = ws.k;
-  u32 const mask = (1u << ws.tc_log2) - 1;
   u64* keys = ws.tbl_key + (static_cast<size_t>(a) << ws.tc_log2);
   u32* first = ws.tbl_first + (static_cast<size_t>(a) << ws.tc_log2);
   u32* inst_slot = ws.inst_slot + static_cast<size_t>(a) * ws.inst_stride;
@@ -394,6 +393,22 @@ __global__ __launch_bounds__(kBT) void k_insert(DBatch b, GraphWs ws) {
   u32* ref_slot_g = ws.ref_slot + static_cast<size_t>(a) * ws.ref_stride;
   u32 const base_idx = b.read_win_off[w] + w;
   SeqInfo const rsi = seq_info(b, w, 0, k);
+  // The table stride (tc_log2) is sized for the window with the most k-mers; this window uses -- and initialises --
+  // only as many slots as it needs.  Nothing re-hashes later: every stage goes through the slot in the instance word.
+  u32 tcw = 10;
+  while (tcw < static_cast<u32>(ws.tc_log2) && (1u << tcw) < (ws.n_slow[a] + rsi.nk) * 4u / 3u + 16u) ++tcw;
+  u32 const mask = (1u << tcw) - 1;
+  {
+    int const CW = ws.num_samples + 2;
+    u32* cnt = ws.tbl_cnt + (static_cast<size_t>(a) << ws.tc_log2) * CW;
+    for (u32 i = threadIdx.x; i <= mask; i += kBT) {
+      keys[i] = 0;
+      first[i] = 0x7F7F7F7Fu;  // > any instance
+    }
+    for (u32 i = threadIdx.x; i < (mask + 1u) * CW; i += kBT) cnt[i] = 0;
+    if (threadIdx.x == 0) ws.win_tc[a] = tcw;
+    __syncthreads();
+  }
   auto hash_insert = [&](const u8* s, u32 inst, u32* old_first) -> u32 {
     bool plus;
     u64 const id = kmer_id(s, k, &plus);
@@ -777,7 +792,7 @@ __global__ __launch_bounds__(kMmT) void k_mm_lds(DBatch b, GraphWs ws) {
   // u16 (a slot has at most 2047 names) for a range of slots at a time and added to the window's table in index
   // order: a wavefront's 64 counters share two lines.
   u32 const slots_per_pass = (2u * kMmAux) / static_cast<u32>(CW);
-  u32 const tcap = 1u << ws.tc_log2;
+  u32 const tcap = 1u << ws.win_tc[a];
   for (u32 s0 = 0; s0 < tcap; s0 += slots_per_pass) {
     for (u32 i = threadIdx.x; i < kMmAux; i += kMmT) l_aux[i] = 0;
     __syncthreads();
@@ -812,7 +827,7 @@ __global__ __launch_bounds__(kBT) void k_rank(DBatch b, GraphWs ws, u32 min_node
   int const a = blockIdx.x;
   int const w = static_cast<int>(ws.active[a]);
   int const S = ws.num_samples, CW = S + 2;
-  u32 const tcap = 1u << ws.tc_log2;
+  u32 const tcap = 1u << ws.win_tc[a];  // slots this window uses (k_insert)
   const u64* keys = ws.tbl_key + (static_cast<size_t>(a) << ws.tc_log2);
   u32* first = ws.tbl_first + (static_cast<size_t>(a) << ws.tc_log2);
   u32* slot_node = ws.slot_node + (static_cast<size_t>(a) << ws.tc_log2);
@@ -1116,10 +1131,7 @@ int run_build_pass(ma_ctx* ctx, const DBatch& b, GraphWs& ws, u32* counters_dev,
   while ((size_t(1) << tc) < (static_cast<size_t>(max_slow) + ws.ref_stride) * 4 / 3 + 16) ++tc;
   ws.tc_log2 = tc < tc_log2_alloc ? tc : tc_log2_alloc;
   int const mc_log2_alloc = ws.mc_log2;
-  size_t const tcap = size_t(1) << ws.tc_log2;
-  MA_HIP(ctx, hipMemsetAsync(ws.tbl_key, 0, A * tcap * 8, ctx->stream));
-  MA_HIP(ctx, hipMemsetAsync(ws.tbl_first, 0x7F, A * tcap * 4, ctx->stream));  // 0x7F7F7F7F > any instance
-  MA_HIP(ctx, hipMemsetAsync(ws.tbl_cnt, 0, A * tcap * 4 * (S + 2), ctx->stream));
+  // (k_insert initialises the slots each window uses: no table-wide memsets)
   ctx->tic("k_insert");
   hipLaunchKernelGGL(k_insert, dim3(ws.n_active), dim3(kBT), 0, ctx->stream, b, ws);
   ctx->toc();

@@ -49,6 +49,7 @@ struct GraphWs {
   u32* slowq;             // [a][inst_stride] (seq << 12 | offset) of the instances that need the hash table
   u32* n_slow;            // [a]
   u32* mm_mode;           // [a] general mate-mer instances of the window; bit31: needs the HBM-resident set
+  u32* win_tc;            // [a] log2 of the table slots this window uses (<= tc_log2, the stride)
   u8* rd_flag;            // [n_reads] general-path k-mer of this read hit a reference node
   u64* mm_key;
   u32* mm_min;
