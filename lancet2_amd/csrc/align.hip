@@ -804,6 +804,39 @@ __global__ __launch_bounds__(64) void k_align(GArgs A, u32 seg_words) {
 // segment (4 bit/base, with wall codes 6 = "column 0", 7 = "outside the haplotype") stays in LDS and
 // is re-aligned once per row with funnel shifts.  Same cell rules, tie rules and outputs as k_align.
 constexpr i32 NEGR = -20000;
+// Interior pairs first, pairs whose band can reach a haplotype end last: k_align_reg picks its row body per
+// WAVEFRONT (the lean one needs every pair of the wavefront to stay clear of the haplotype ends), so the two kinds
+// must not be interleaved.  Order inside the list never affects a result (every pair is independent).
+__global__ __launch_bounds__(256) void k_dp_partition(GArgs A, u32 ndp, u32* out, u32* cnt2) {
+  u32 const li = blockIdx.x * 256u + threadIdx.x, lane = threadIdx.x & 63u;
+  bool const live = li < ndp;
+  u32 lp = 0;
+  bool interior = false;
+  if (live) {
+    lp = A.ws.dp_list[li];
+    PairId const id = pair_decode(A, A.pair0 + lp);
+    size_t const hi = static_cast<size_t>(id.w) * A.prm.max_haps + id.slot;
+    i32 const n = static_cast<i32>(A.a.hap_len[hi]);
+    i32 const m = static_cast<i32>(A.b.read_off[id.r + 1] - A.b.read_off[id.r]);
+    i32 const c = A.ws.centre[lp], band = A.ws.band;
+    // no band row reaches column -1 or n (+ the 7 columns the last segment word carries beyond the band)
+    interior = c >= band && c + m + band + 8 <= n;
+  }
+  unsigned long long const mi = __ballot(live && interior), me = __ballot(live && !interior);
+  u32 bi = 0, be = 0;
+  if (lane == 0) {
+    if (mi) bi = atomicAdd(&cnt2[0], static_cast<u32>(__popcll(mi)));
+    if (me) be = atomicAdd(&cnt2[1], static_cast<u32>(__popcll(me)));
+  }
+  bi = __shfl(bi, 0, 64);
+  be = __shfl(be, 0, 64);
+  unsigned long long const below = (1ull << lane) - 1ull;
+  if (live) {
+    if (interior) out[bi + static_cast<u32>(__popcll(mi & below))] = lp;
+    else out[ndp - 1u - (be + static_cast<u32>(__popcll(me & below)))] = lp;
+  }
+}
+
 template <int B>
 __global__ __launch_bounds__(64) void k_align_reg(GArgs A, u32 seg_words) {
   extern __shared__ u32 lds[];
@@ -834,7 +867,9 @@ __global__ __launch_bounds__(64) void k_align_reg(GArgs A, u32 seg_words) {
   i32 mmax = mrows;
   for (int off = 32; off > 0; off >>= 1) mmax = max(mmax, __shfl_xor(mmax, off));
 
-  u32 HF[WD + 1];  // packed (H lo16, F hi16) of the previous row; HF[WD] = sentinel
+  // packed previous row, BIASED by what the next row subtracts anyway: lo16 = H - (GO + GE), hi16 = F - GE; HF[WD] = sentinel
+  u32 HF[WD + 1];
+  constexpr i32 GOE = GO + GE;
   i32 const j0 = c - B;  // hap base index of segment position 0
   if (active) {
     i32 const seglen = m + 2 * B + 1;
@@ -852,7 +887,7 @@ __global__ __launch_bounds__(64) void k_align_reg(GArgs A, u32 seg_words) {
   for (int t = 0; t <= WD; ++t) {
     i32 const j = c - B + t;
     i32 const h = (t < WD && j >= 0 && j <= n) ? 0 : NEGR;
-    HF[t] = (static_cast<u32>(h) & 0xFFFFu) | (static_cast<u32>(NEGR) << 16);
+    HF[t] = (static_cast<u32>(h - GOE) & 0xFFFFu) | (static_cast<u32>(NEGR - GE) << 16);
   }
   size_t const tb_base = static_cast<size_t>(blockIdx.x) * A.ws.tb_rows * A.ws.tb_words * 64;
   u32* tb = A.ws.tb + tb_base;
@@ -874,29 +909,45 @@ __global__ __launch_bounds__(64) void k_align_reg(GArgs A, u32 seg_words) {
           prev = nx;
         }
       }
-      i32 lh = NEGR, le = NEGR, last_h = NEGR;
+      i32 le = NEGR, last_h = NEGR;
       u32 word = 0;
       u32* tbrow = tb + static_cast<size_t>(i) * A.ws.tb_words * 64 + lane;
-      // Rows whose band window lies inside the haplotype for every pair of the wavefront (almost all of them: reads
-      // hanging over a haplotype end are settled by the certificates) skip the wall handling: ~7 of ~50 operations
-      // per cell.
-      bool const my_walls = (c - B + i <= 0) || (c + B + i - 1 >= n);
-      auto const row = [&](auto walls_tag) {
-        constexpr bool WALLS = decltype(walls_tag)::value;
+      // Rows whose band window holds nothing but A/C/G/T for every pair of the wavefront -- no haplotype end (walls),
+      // no N; almost all rows: reads hanging over a haplotype end are settled by the certificates -- take the lean
+      // body: the substitution score comes from one XOR per word (nibble == 0 <=> match) and there is no wall logic.
+      // Codes 4 (N), 6 and 7 (walls) all have bit 2 set, A/C/G/T do not.
+      u32 any_special = 0;
+#pragma unroll
+      for (int k = 0; k < NW; ++k) any_special |= sw[k];
+      // (the last word also carries a few columns beyond the band: including them only makes the test conservative)
+      any_special &= 0x44444444u;
+      i32 const smis_b = smis + GOE;  // substitution scores biased by GO + GE (see HF)
+      auto const row = [&](auto special_tag) {
+        constexpr bool SPECIAL = decltype(special_tag)::value;
+        u32 const qrep = qcmp * 0x11111111u;
+        i32 dhm = static_cast<i16>(HF[0] & 0xFFFFu);  // H(i-1, diag) - GOE; afterwards carried over from the cell before
+        i32 lhm = NEGR - GOE;                          // H(i, t-1) - GOE
 #pragma unroll
         for (int t = 0; t < WD; ++t) {
-          u32 const code = (sw[t >> 3] >> (4 * (t & 7))) & 0xFu;
-          i32 const dh = static_cast<i16>(HF[t] & 0xFFFFu);
-          i32 const uh = static_cast<i16>(HF[t + 1] & 0xFFFFu), uf = static_cast<i32>(HF[t + 1]) >> 16;
-          i32 const s = code > 3 ? -1 : (code == qcmp ? 1 : smis);
-          i32 const dg = dh + s;
-          i32 const eo = lh - (GO + GE), ee = le - GE;
-          i32 const fo = uh - (GO + GE), fe = uf - GE;
+          u32 const up = HF[t + 1];
+          i32 const uhm = static_cast<i16>(up & 0xFFFFu), ufm = static_cast<i32>(up) >> 16;
+          i32 sb;
+          u32 code = 0;
+          if constexpr (SPECIAL) {
+            code = (sw[t >> 3] >> (4 * (t & 7))) & 0xFu;
+            sb = code > 3 ? (GOE - 1) : (code == qcmp ? (GOE + 1) : smis_b);
+          } else {
+            u32 const x = ((sw[t >> 3] ^ qrep) >> (4 * (t & 7))) & 0xFu;
+            sb = x == 0 ? (GOE + 1) : smis_b;
+          }
+          i32 const dg = dhm + sb;
+          i32 const eo = lhm, ee = le - GE;
+          i32 const fo = uhm, fe = ufm;
           i32 e = max(eo, ee), f = max(fo, fe);
           i32 h = max(dg, max(e, f));
-          u32 nib = (dg >= e && dg >= f) ? 0u : (e >= f ? 1u : 2u);
+          u32 nib = (h == dg) ? 0u : (e >= f ? 1u : 2u);  // dg >= e && dg >= f  <=>  dg is the maximum
           nib |= (eo >= ee ? 4u : 0u) | (fo >= fe ? 8u : 0u);
-          if constexpr (WALLS) {
+          if constexpr (SPECIAL) {
             bool const wall = code >= 6;
             h = wall ? (code == 6 ? 0 : NEGR) : h;
             e = wall ? NEGR : e;
@@ -905,9 +956,11 @@ __global__ __launch_bounds__(64) void k_align_reg(GArgs A, u32 seg_words) {
           } else {
             last_h = h;
           }
-          HF[t] = (static_cast<u32>(h) & 0xFFFFu) | (static_cast<u32>(f) << 16);
-          lh = h;
+          i32 const hm = h - GOE, fm = f - GE;
+          HF[t] = __builtin_amdgcn_perm(static_cast<u32>(fm), static_cast<u32>(hm), 0x05040100u);  // lo16(hm) | lo16(fm) << 16
+          lhm = hm;
           le = e;
+          dhm = uhm;
           word |= nib << (4 * (t & 7));
           if ((t & 7) == 7 || t == WD - 1) {
             tbrow[static_cast<size_t>(t >> 3) * 64] = word;
@@ -915,7 +968,7 @@ __global__ __launch_bounds__(64) void k_align_reg(GArgs A, u32 seg_words) {
           }
         }
       };
-      if (__ballot(my_walls) != 0) row(std::true_type{}); else row(std::false_type{});
+      if (__ballot(any_special != 0) != 0) row(std::true_type{}); else row(std::false_type{});
       // end cell (i, n) for i < m: the last in-haplotype cell of the row is column n iff the band reaches it
       if (i < mrows && i + c + B >= n && i + c - B <= n) {
         if (last_h >= best) {  // later rows win ties (larger i)
@@ -932,7 +985,7 @@ __global__ __launch_bounds__(64) void k_align_reg(GArgs A, u32 seg_words) {
 #pragma unroll
     for (int t = 0; t < WD; ++t) {
       i32 const j = mrows + c - B + t;
-      i32 const h = static_cast<i16>(HF[t] & 0xFFFFu);
+      i32 const h = static_cast<i16>(HF[t] & 0xFFFFu) + GOE;
       if (j >= 0 && j <= n) {
         if (h > best || (first && h == best)) {
           best = h;
@@ -1354,11 +1407,12 @@ int launch_genotype(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& a, const m
     u64 const pairs_chunk = std::min<u64>(total_pairs, std::min<u64>(u64(1) << 30, budget / 4 / 8));
     u64 const dp_groups_max = std::max<u64>(1, (budget - pairs_chunk * 8) / tb_per_group);
     size_t const tb_bytes = std::min<u64>(dp_groups_max, (pairs_chunk + 63) / 64) * tb_per_group;
-    MA_HIP(ctx, ctx->ws_misc.reserve(tb_bytes + (pairs_chunk + 64) * 8 + 8192));
+    MA_HIP(ctx, ctx->ws_misc.reserve(tb_bytes + (pairs_chunk + 64) * 12 + 8192));
     ws.tb = ctx->ws_misc.as<u32>();
     ws.centre = reinterpret_cast<i32*>(reinterpret_cast<char*>(ctx->ws_misc.p) + tb_bytes);
     ws.dp_list = reinterpret_cast<u32*>(ws.centre + pairs_chunk + 16);
     ws.dp_count = ws.dp_list + pairs_chunk + 16;
+    u32* const dp_sorted = ws.dp_count + 16;  // [pairs_chunk] the DP list, interior pairs first (k_dp_partition)
     u32 const hist_len = ((max_read_len + static_cast<u32>(P.max_hap_len) + 2 + 1) & ~1u);
     u32 const pw_host = (static_cast<u32>(P.max_hap_len) + 31) / 32 + 2;
     u32 const rwords = (max_read_len + 31) / 32 + 2;
@@ -1380,6 +1434,15 @@ int launch_genotype(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& a, const m
       MA_HIP(ctx, hipMemcpyAsync(&ndp, ws.dp_count, 4, hipMemcpyDeviceToHost, ctx->stream));
       MA_HIP(ctx, hipStreamSynchronize(ctx->stream));
       ctx->stats[1] += ndp;
+      GArgs const Avote = A;
+      if (ndp > 0 && P.band == 64) {
+        MA_HIP(ctx, hipMemsetAsync(ws.dp_count + 4, 0, 8, ctx->stream));
+        ctx->tic("k_dp_partition");
+        hipLaunchKernelGGL(k_dp_partition, dim3((ndp + 255) / 256), dim3(256), 0, ctx->stream, A, ndp, dp_sorted,
+                           ws.dp_count + 4);
+        ctx->toc();
+        A.ws.dp_list = dp_sorted;
+      }
       u64 const ng_total = (static_cast<u64>(ndp) + 63) / 64;
       for (u64 g0 = 0; g0 < ng_total; g0 += dp_groups_max) {
         u32 const ng = static_cast<u32>(std::min<u64>(dp_groups_max, ng_total - g0));
@@ -1398,6 +1461,7 @@ int launch_genotype(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& a, const m
         hipLaunchKernelGGL(k_align, dim3(ng), dim3(64), lds_align, ctx->stream, A, seg_words);
         ctx->toc();
       }
+      A = Avote;
     }
   }
   ctx->tic("k_assign");
