@@ -371,13 +371,15 @@ __global__ __launch_bounds__(64) void k_classify(DBatch b, GraphWs ws, u32* max_
 // The reverse-complement strand is hashed as the forward hash of the reversed complemented string (one multiply
 // per base instead of a running power).
 __device__ __forceinline__ u64 kmer_id(const u8* s, int k, bool* plus_out) {
-  u64 hf = 0, hr = 0;
-  for (int i = 0; i < k; ++i) {
-    hf = hf * kHashP + s[i];
-    hr = hr * kHashP + dev_complement(s[k - 1 - i]);
-  }
+  // the canonical decision usually falls within the first base or two, so only the canonical strand is hashed
   bool const plus = canon_plus(s, k);
-  u64 const id = dev_fmix64(plus ? hf : hr);
+  u64 h = 0;
+#pragma unroll 8  // eight independent byte loads in flight instead of one round trip per base
+  for (int i = 0; i < k; ++i) {  // one loop for both strands: lanes of a wavefront disagree about the strand
+    u8 const b = s[plus ? i : k - 1 - i];
+    h = h * kHashP + (plus ? b : dev_complement(b));
+  }
+  u64 const id = dev_fmix64(h);
   *plus_out = plus;
   return id ? id : 1;
 }
