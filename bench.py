@@ -86,6 +86,9 @@ def algorithmic_bytes(kernel, st):
     return per.get(kernel, 0) * n
 
 
+_START = None  # multi-worker baseline: every worker finishes synthesising its windows before any of them is timed
+
+
 def _oracle_chunk(job):
     """One worker of the CPU baseline: the whole path (oracle) over `count` windows starting at `first`."""
     config, first, count, num_samples = job
@@ -95,6 +98,11 @@ def _oracle_chunk(job):
     params = capi.default_params(min_k=25, max_k=25, num_samples=num_samples)
     sub, sn, snr = synth.make_config_batch(config, count, first_index=first)
     orc = OracleEngine(params)
+    if _START is not None:
+        try:
+            _START.wait(timeout=120)
+        except Exception:
+            pass
     t0 = time.perf_counter()
     orc.gate(sub, sn, snr)
     oa = orc.assemble(sub, sn, snr)
@@ -116,8 +124,21 @@ def cpu_baselines(args, num_samples):
     cores = os.cpu_count() or 1
     per = 12
     jobs = [(args.config, 10_000 + 1000 * i, per, num_samples) for i in range(cores)]
-    with mp.get_context("fork").Pool(cores) as pool:
-        res = pool.map(_oracle_chunk, jobs, chunksize=1)
+    global _START
+    ctx = mp.get_context("fork")
+    _START = ctx.Barrier(cores)  # inherited by the forked workers
+    out_q = ctx.Queue()
+
+    def _worker(job):
+        out_q.put(_oracle_chunk(job))
+
+    procs = [ctx.Process(target=_worker, args=(j,)) for j in jobs]  # exactly one process per job (the barrier counts them)
+    for pr in procs:
+        pr.start()
+    res = [out_q.get(timeout=900) for _ in procs]
+    for pr in procs:
+        pr.join()
+    _START = None
     tot = sum(r[0] for r in res)
     slowest = max(r[1] for r in res)  # workers run concurrently; input synthesis (Python) is not timed
     cpu_mt = {"value": round(tot / slowest, 3), "unit": "windows/s", "cores": cores, "kind": "port",
