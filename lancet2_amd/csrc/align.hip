@@ -408,11 +408,54 @@ __device__ __forceinline__ void vote_pair(GArgs const& A, u64 lp, PairId id, Hap
     }
   };
   VPROF_ACC(0);
-  // 16-bit LDS counters: atomic add on the containing 32-bit word.  A read that sits on one diagonal makes
-  // all 64 lanes hit the same counter; those same-address atomics serialise, so the first match of every
-  // lane is pre-combined with a ballot and only further matches (repeats) vote one by one.
-  u32 nvotes = 0;  // this lane's votes; summed over the wave below
-  {
+  // ---- pass A: first match of every cached read position, and is the vote unanimous? ----
+  // Nine pairs in ten put every vote on ONE diagonal (error-free or nearly error-free reads, no repeat): the histogram
+  // then has a single non-zero counter, so the winner is that diagonal with all the votes and the runner-up has none
+  // -- no histogram update, no arg-max, no clearing.  Everything else takes the histogram path below.
+  u32 nvotes = 0;  // this lane's votes; summed over the wave further down
+  u32 best = 0, v2 = 0;
+  i32 bd = 0x7FFFFFFF;
+  bool unan = !(seeded && m - SK + 1 > 64 * kPos);  // long reads vote outside the cached positions
+  u32 ucnt = 0;
+  i32 u_d = -1;
+#pragma unroll
+  for (int t = 0; t < kPos; ++t) {
+    u32 const cd = cds[t];
+    i32 const i = lane + 64 * t;
+    u32 j = 0xFFFFu;
+    if (cd != 0xFFFFFFFFu) {
+      j = head[(cd * 2654435761u) >> (32 - 12)];
+      while (j != 0xFFFFu && code[j] != cd) j = next[j];
+    }
+    mj[t] = j;
+    if (j != 0xFFFFu)
+      for (u32 j2 = next[j]; j2 != 0xFFFFu; j2 = next[j2])
+        if (code[j2] == cd) {
+          more |= 1u << t;
+          break;
+        }
+    i32 const d = j != 0xFFFFu ? static_cast<i32>(j) - i + m : -1;
+    unsigned long long const have = __ballot(d >= 0);
+    if (have) {
+      i32 const d0 = __shfl(d, __builtin_ctzll(have));
+      if (__ballot(d == d0) != have || (u_d >= 0 && d0 != u_d)) unan = false;
+      u_d = d0;
+      ucnt += static_cast<u32>(__popcll(have));
+    }
+  }
+  if (__ballot(more != 0) != 0) unan = false;
+  if (unan) {
+    best = ucnt;
+    bd = ucnt ? u_d : 0x7FFFFFFF;
+    if (lane == 0) nvotes = ucnt;
+    VPROF_ACC(1);
+    VPROF_ACC(2);
+    VPROF_ACC(3);
+    VPROF_ACC(4);
+  } else {
+    // 16-bit LDS counters: atomic add on the containing 32-bit word.  A read that sits on one diagonal makes
+    // all 64 lanes hit the same counter; those same-address atomics serialise, so the first match of every
+    // lane is pre-combined with a ballot and only further matches (repeats) vote one by one.
     auto vote1 = [&](i32 d) {
       atomicAdd(reinterpret_cast<u32*>(hist) + (d >> 1), 1u << ((d & 1) * 16));
       nvotes++;
@@ -421,12 +464,7 @@ __device__ __forceinline__ void vote_pair(GArgs const& A, u64 lp, PairId id, Hap
     for (int t = 0; t < kPos; ++t) {
       u32 const cd = cds[t];
       i32 const i = lane + 64 * t;
-      u32 j = 0xFFFFu;
-      if (cd != 0xFFFFFFFFu) {
-        j = head[(cd * 2654435761u) >> (32 - 12)];
-        while (j != 0xFFFFu && code[j] != cd) j = next[j];
-      }
-      mj[t] = j;
+      u32 j = mj[t];
       i32 const d = j != 0xFFFFu ? static_cast<i32>(j) - i + m : -1;
       unsigned long long const have = __ballot(d >= 0);
       if (have) {
@@ -442,12 +480,9 @@ __device__ __forceinline__ void vote_pair(GArgs const& A, u64 lp, PairId id, Hap
           vote1(d);
         }
       }
-      if (j != 0xFFFFu)
+      if (more & (1u << t))
         for (j = next[j]; j != 0xFFFFu; j = next[j])
-          if (code[j] == cd) {
-            more |= 1u << t;
-            vote1(static_cast<i32>(j) - i + m);
-          }
+          if (code[j] == cd) vote1(static_cast<i32>(j) - i + m);
     }
     for (i32 i = lane + 64 * kPos; seeded && i + SK <= m; i += 64) {  // long reads
       u32 const cd = code_at(i);
@@ -455,39 +490,36 @@ __device__ __forceinline__ void vote_pair(GArgs const& A, u64 lp, PairId id, Hap
       for (u32 j = head[(cd * 2654435761u) >> (32 - 12)]; j != 0xFFFFu; j = next[j])
         if (code[j] == cd) vote1(static_cast<i32>(j) - i + m);
     }
-  }
-  __builtin_amdgcn_wave_barrier();
-  VPROF_ACC(1);
-  // arg-max over the touched diagonals, ties -> smallest diagonal
-  u32 best = 0;
-  i32 bd = 0x7FFFFFFF;
-  walk([&](i32 d) {
-    u32 const v = hist[d];
-    if (v > best || (v == best && d < bd)) {
-      best = v;
-      bd = d;
+    __builtin_amdgcn_wave_barrier();
+    VPROF_ACC(1);
+    // arg-max over the touched diagonals, ties -> smallest diagonal
+    walk([&](i32 d) {
+      u32 const v = hist[d];
+      if (v > best || (v == best && d < bd)) {
+        best = v;
+        bd = d;
+      }
+    });
+    for (int off = 32; off > 0; off >>= 1) {
+      u32 const ob = __shfl_xor(best, off);
+      i32 const od = __shfl_xor(bd, off);
+      if (ob > best || (ob == best && ob > 0 && od < bd)) {
+        best = ob;
+        bd = od;
+      }
     }
-  });
-  for (int off = 32; off > 0; off >>= 1) {
-    u32 const ob = __shfl_xor(best, off);
-    i32 const od = __shfl_xor(bd, off);
-    if (ob > best || (ob == best && ob > 0 && od < bd)) {
-      best = ob;
-      bd = od;
-    }
+    VPROF_ACC(2);
+    // second best (any other diagonal), then restore the all-zero histogram
+    walk([&](i32 d) {
+      if (d != bd) v2 = max(v2, static_cast<u32>(hist[d]));
+    });
+    for (int off = 32; off > 0; off >>= 1) v2 = max(v2, __shfl_xor(v2, off));
+    __builtin_amdgcn_wave_barrier();
+    VPROF_ACC(3);
+    walk([&](i32 d) { hist[d] = 0; });
+    __builtin_amdgcn_wave_barrier();
+    VPROF_ACC(4);
   }
-  VPROF_ACC(2);
-  // second best (any other diagonal), then restore the all-zero histogram
-  u32 v2 = 0;
-  walk([&](i32 d) {
-    if (d != bd) v2 = max(v2, static_cast<u32>(hist[d]));
-  });
-  for (int off = 32; off > 0; off >>= 1) v2 = max(v2, __shfl_xor(v2, off));
-  __builtin_amdgcn_wave_barrier();
-  VPROF_ACC(3);
-  walk([&](i32 d) { hist[d] = 0; });
-  __builtin_amdgcn_wave_barrier();
-  VPROF_ACC(4);
   (void)nd;
   if (best == 0) {  // no shared 11-mer: no hit (record stays zero)
     if (lane == 0) A.ws.centre[lp] = 0x7FFFFFFF;
