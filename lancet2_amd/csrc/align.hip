@@ -202,6 +202,9 @@ __device__ __forceinline__ u32 plane32(const u32* pl, u32 i) {
   u64 const two = static_cast<u64>(pl[i >> 5]) | (static_cast<u64>(pl[(i >> 5) + 1]) << 32);
   return static_cast<u32>(two >> (i & 31u));
 }
+// index entry == read code?  Bit 31 of an entry flags "this 11-mer occurs more than once in the haplotype".
+constexpr u32 kCodeDup = 0x80000000u;
+__device__ __forceinline__ bool same_code(u32 entry, u32 cd) { return ((entry ^ cd) & ~kCodeDup) == 0; }
 // append this wave's buffered DP pairs to the global list: one atomic per 64 pairs
 __device__ __forceinline__ void vote_flush_dp(GArgs const& A, HapIdx ix, int lane) {
   u32 const cnt = ix.dpbuf[64];
@@ -284,6 +287,15 @@ __global__ __launch_bounds__(256) void k_vote(GArgs A, u32 hist_len, u32 rwords)
       if (seen == old) break;
       old = seen;
     }
+  }
+  __syncthreads();
+  // flag the 11-mers that occur more than once in the haplotype (a vote on them is never unanimous)
+  for (u32 j = threadIdx.x; j + SK <= n; j += 256) {
+    u32 const cd = code[j];
+    if (cd == 0xFFFFFFFFu) continue;
+    u32 cnt = 0;
+    for (u32 x = head[(cd * 2654435761u) >> (32 - 12)]; x != 0xFFFFu && cnt < 2; x = next[x]) cnt += same_code(code[x], cd);
+    if (cnt >= 2) code[j] = cd | kCodeDup;  // (other threads compare through same_code: the flag never disturbs them)
   }
   __syncthreads();
   int const wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -396,7 +408,7 @@ __device__ __forceinline__ void vote_pair(GArgs const& A, u64 lp, PairId id, Hap
       if (more & (1u << t)) {
         u32 const cd = cds[t];
         for (u32 j = next[mj[t]]; j != 0xFFFFu; j = next[j])
-          if (code[j] == cd) fn(static_cast<i32>(j) - i + m);
+          if (same_code(code[j], cd)) fn(static_cast<i32>(j) - i + m);
       }
     }
     for (i32 i = lane + 64 * kPos; seeded && i + SK <= m; i += 64) {  // long reads: re-encode
@@ -404,7 +416,7 @@ __device__ __forceinline__ void vote_pair(GArgs const& A, u64 lp, PairId id, Hap
       if (cd == 0xFFFFFFFFu) continue;
       u32 const bkt = (cd * 2654435761u) >> (32 - 12);
       for (u32 j = head[bkt]; j != 0xFFFFu; j = next[j])
-        if (code[j] == cd) fn(static_cast<i32>(j) - i + m);
+        if (same_code(code[j], cd)) fn(static_cast<i32>(j) - i + m);
     }
   };
   VPROF_ACC(0);
@@ -425,15 +437,11 @@ __device__ __forceinline__ void vote_pair(GArgs const& A, u64 lp, PairId id, Hap
     u32 j = 0xFFFFu;
     if (cd != 0xFFFFFFFFu) {
       j = head[(cd * 2654435761u) >> (32 - 12)];
-      while (j != 0xFFFFu && code[j] != cd) j = next[j];
+      u32 entry = 0;
+      while (j != 0xFFFFu && !same_code(entry = code[j], cd)) j = next[j];
+      if (j != 0xFFFFu && (entry & kCodeDup)) more |= 1u << t;  // repeats: the chain holds further matches
     }
     mj[t] = j;
-    if (j != 0xFFFFu)
-      for (u32 j2 = next[j]; j2 != 0xFFFFu; j2 = next[j2])
-        if (code[j2] == cd) {
-          more |= 1u << t;
-          break;
-        }
     i32 const d = j != 0xFFFFu ? static_cast<i32>(j) - i + m : -1;
     unsigned long long const have = __ballot(d >= 0);
     if (have) {
@@ -482,13 +490,13 @@ __device__ __forceinline__ void vote_pair(GArgs const& A, u64 lp, PairId id, Hap
       }
       if (more & (1u << t))
         for (j = next[j]; j != 0xFFFFu; j = next[j])
-          if (code[j] == cd) vote1(static_cast<i32>(j) - i + m);
+          if (same_code(code[j], cd)) vote1(static_cast<i32>(j) - i + m);
     }
     for (i32 i = lane + 64 * kPos; seeded && i + SK <= m; i += 64) {  // long reads
       u32 const cd = code_at(i);
       if (cd == 0xFFFFFFFFu) continue;
       for (u32 j = head[(cd * 2654435761u) >> (32 - 12)]; j != 0xFFFFu; j = next[j])
-        if (code[j] == cd) vote1(static_cast<i32>(j) - i + m);
+        if (same_code(code[j], cd)) vote1(static_cast<i32>(j) - i + m);
     }
     __builtin_amdgcn_wave_barrier();
     VPROF_ACC(1);
