@@ -64,6 +64,23 @@ class GenoOut(C.Structure):
         "allele_counts", "var_qual", "aln_rec", "aln_cigar", "asg_allele", "asg_score")]
 
 
+def load_cdll(path=None):
+    """dlopen the product library.  PyTorch's ROCm wheels bundle their own HIP runtime (torch/lib/libamdhip64.so, no
+    SONAME), libmicroasm.so is linked against the system one: whichever of the two initialises second in a process
+    finds no device.  Preloading torch's runtime globally (when torch is installed; torch itself is NOT imported) makes
+    both resolve to the same runtime whatever the import order."""
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is not None and spec.submodule_search_locations:
+            hip = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+            if os.path.exists(hip):
+                C.CDLL(hip, mode=C.RTLD_GLOBAL)
+    except Exception:  # no torch, or its runtime cannot be loaded here (CPU-only container): use the system runtime
+        pass
+    return C.CDLL(path or LIB_PATH)
+
+
 class CxOut(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("seq_cx_i", "seq_cx_f", "seq_cx_d", "graph_cx")]
 

@@ -20,7 +20,7 @@ def load_library(path=None):
     if not os.path.exists(path):
         raise EngineError(f"{path} not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
                           "(the engine has no CPU fallback)")
-    lib = C.CDLL(path)
+    lib = capi.load_cdll(path)
     lib.ma_last_error.restype = C.c_char_p
     lib.ma_create.argtypes = [C.POINTER(capi.Params), C.c_int, C.c_int, C.POINTER(C.c_void_p)]
     lib.ma_destroy.argtypes = [C.c_void_p]

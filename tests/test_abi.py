@@ -19,7 +19,7 @@ def declared_symbols():
 
 def test_library_exports_every_declared_symbol():
     assert os.path.exists(capi.LIB_PATH), "build first: python -c 'import __graft_entry__ as g; g.build()'"
-    lib = C.CDLL(capi.LIB_PATH)
+    lib = capi.load_cdll()
     syms = declared_symbols()
     assert len(syms) >= 12
     for s in syms:
@@ -33,7 +33,7 @@ def test_struct_layout_matches_header():
     assert C.sizeof(capi.VarOut) == 14 * C.sizeof(C.c_void_p)
     assert C.sizeof(capi.GenoOut) == 6 * C.sizeof(C.c_void_p)
     assert C.sizeof(capi.CxOut) == 4 * C.sizeof(C.c_void_p)
-    lib = C.CDLL(capi.LIB_PATH)
+    lib = capi.load_cdll()
     p = capi.Params()
     lib.ma_default_params(C.byref(p))
     d = capi.default_params()
@@ -44,7 +44,7 @@ def test_struct_layout_matches_header():
 def test_no_cpu_fallback_without_device():
     if os.path.exists("/dev/kfd"):  # (not torch.cuda.is_available(): no second HIP runtime in the test process)
         pytest.skip("GPU present")
-    lib = C.CDLL(capi.LIB_PATH)
+    lib = capi.load_cdll()
     h = C.c_void_p()
     p = capi.default_params()
     rc = lib.ma_create(C.byref(p), 0, 0, C.byref(h))
