@@ -1386,7 +1386,7 @@ int launch_genotype(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& a, const m
     hipLaunchKernelGGL(k_max_reads, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, b, cnt);
     u32 mr = 0;
     MA_HIP(ctx, hipMemcpyAsync(&mr, cnt, 4, hipMemcpyDeviceToHost, ctx->stream));
-    MA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    MA_HIP(ctx, ma_stream_sync(ctx));
     u64 want = static_cast<u64>(mr) * 8 + 1024;
     u32 cap = 8192;
     while (cap < want && cap < (1u << 24)) cap <<= 1;
@@ -1433,7 +1433,7 @@ int launch_genotype(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& a, const m
   u32 plan_counters[4] = {0, 0, 0, 0};
   MA_HIP(ctx, hipMemcpyAsync(&total_pairs, ws.pair_off + n, 8, hipMemcpyDeviceToHost, ctx->stream));
   MA_HIP(ctx, hipMemcpyAsync(plan_counters, ws.counters, 16, hipMemcpyDeviceToHost, ctx->stream));
-  MA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  MA_HIP(ctx, ma_stream_sync(ctx));
   u32 const max_read_len = plan_counters[0], n_vote_wg = plan_counters[2];
 
   ctx->stats[0] += total_pairs;
@@ -1472,7 +1472,7 @@ int launch_genotype(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& a, const m
       ctx->toc();
       u32 ndp = 0;
       MA_HIP(ctx, hipMemcpyAsync(&ndp, ws.dp_count, 4, hipMemcpyDeviceToHost, ctx->stream));
-      MA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      MA_HIP(ctx, ma_stream_sync(ctx));
       ctx->stats[1] += ndp;
       GArgs const Avote = A;
       if (ndp > 0 && P.band == 64) {

@@ -534,7 +534,7 @@ int launch_annotate(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& a, const m
   f64* base = ctx->ws_cx.as<f64>();
   if (rebuild) {
     std::vector<f64>& h = ctx->cx_host;  // must outlive the async copy
-    MA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    MA_HIP(ctx, ma_stream_sync(ctx));
     h.assign(tab_f64, 0.0);
     for (size_t l = 1; l <= ML; ++l) {
       h[l] = null_model_f(4, gc_frac, static_cast<int>(l));

@@ -248,7 +248,7 @@ int process_in_lanes(ma_ctx* ctx, int lanes, const DBatch& d, const ma_gate_out_
   for (int k = 0; k <= lanes; ++k)
     MA_HIP(ctx, hipMemcpyAsync(&rb[k], d.read_win_off + wb[k], 4, hipMemcpyDeviceToHost, ctx->stream));
   MA_HIP(ctx, hipEventRecord(ctx->lane_done, ctx->stream));  // inputs (and staging copies) are ready after this
-  MA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  MA_HIP(ctx, ma_stream_sync(ctx));
   std::vector<int> rc(lanes, MA_OK);
   std::vector<std::thread> th;
   for (int k = 0; k < lanes; ++k) {
@@ -327,6 +327,7 @@ void ma_destroy(ma_ctx_t* ctx) {
     if (cs) (void)hipStreamDestroy(cs);
   }
   if (ctx->lane_done) (void)hipEventDestroy(ctx->lane_done);
+  if (ctx->sync_ev) (void)hipEventDestroy(ctx->sync_ev);
   delete ctx;
 }
 
@@ -340,7 +341,7 @@ int ma_set_stream(ma_ctx_t* ctx, void* s) {
 
 int ma_synchronize(ma_ctx_t* ctx) {
   if (!ctx) return MA_ERR_ARG;
-  MA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  MA_HIP(ctx, ma_stream_sync(ctx));
   return MA_OK;
 }
 
@@ -372,7 +373,7 @@ int ma_last_stats(ma_ctx_t* ctx, unsigned long long* out, int cap) {
 
 int ma_last_kernel_times(ma_ctx_t* ctx, const char** names, float* ms, int cap) {
   if (!ctx) return MA_ERR_ARG;
-  MA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  MA_HIP(ctx, ma_stream_sync(ctx));
   int n = 0;
   for (size_t i = 0; i < ctx->timers_used && n < cap; ++i, ++n) {
     names[n] = ctx->timers[i].name;
@@ -411,7 +412,7 @@ int ma_repeat_gate_batch(ma_ctx_t* ctx, const ma_batch_t* b, const ma_gate_out_t
   MA_TRY(g.prepare(ctx, out, gate_fields(ctx->prm, d.n_windows), 0, false));
   MA_TRY(launch_gate(ctx, d, g.dev.max_approx, g.dev.max_exact));
   MA_TRY(g.download(ctx));
-  if (ctx->memspace == MA_MEM_HOST) MA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (ctx->memspace == MA_MEM_HOST) MA_HIP(ctx, ma_stream_sync(ctx));
   return MA_OK;
 }
 
@@ -429,7 +430,7 @@ int ma_assemble_batch(ma_ctx_t* ctx, const ma_batch_t* b, const ma_asm_out_t* ou
   MA_TRY(launch_gate(ctx, d, approx, exact));
   MA_TRY(launch_assemble(ctx, d, a.dev, approx));
   MA_TRY(a.download(ctx));
-  if (ctx->memspace == MA_MEM_HOST) MA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (ctx->memspace == MA_MEM_HOST) MA_HIP(ctx, ma_stream_sync(ctx));
   return MA_OK;
 }
 
@@ -447,7 +448,7 @@ int ma_msa_batch(ma_ctx_t* ctx, const ma_batch_t* b, const ma_asm_out_t* asmb, c
   // win_status may gain MA_W_VAR_OVERFLOW
   if (ctx->memspace == MA_MEM_HOST) {
     MA_HIP(ctx, hipMemcpyAsync(asmb->win_status, a.dev.win_status, 4ull * d.n_windows, hipMemcpyDeviceToHost, ctx->stream));
-    MA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    MA_HIP(ctx, ma_stream_sync(ctx));
   }
   return MA_OK;
 }
@@ -466,7 +467,7 @@ int ma_genotype_batch(ma_ctx_t* ctx, const ma_batch_t* b, const ma_asm_out_t* as
   MA_TRY(g.prepare(ctx, out, geno_fields(ctx->prm, d.n_windows, d.n_reads), 32, false));
   MA_TRY(launch_genotype(ctx, d, a.dev, v.dev, g.dev));
   MA_TRY(g.download(ctx));
-  if (ctx->memspace == MA_MEM_HOST) MA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (ctx->memspace == MA_MEM_HOST) MA_HIP(ctx, ma_stream_sync(ctx));
   return MA_OK;
 }
 
@@ -486,7 +487,7 @@ int ma_annotate_batch(ma_ctx_t* ctx, const ma_batch_t* b, const ma_asm_out_t* as
   MA_TRY(c.prepare(ctx, out, cx_fields(ctx->prm, d.n_windows), 40, false));
   MA_TRY(launch_annotate(ctx, d, a.dev, v.dev, gc_frac, c.dev));
   MA_TRY(c.download(ctx));
-  if (ctx->memspace == MA_MEM_HOST) MA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (ctx->memspace == MA_MEM_HOST) MA_HIP(ctx, ma_stream_sync(ctx));
   return MA_OK;
 }
 
@@ -520,7 +521,7 @@ int ma_process_batch(ma_ctx_t* ctx, const ma_batch_t* b, const ma_gate_out_t* ga
   MA_TRY(a.download(ctx));
   MA_TRY(v.download(ctx));
   MA_TRY(q.download(ctx));
-  if (ctx->memspace == MA_MEM_HOST) MA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (ctx->memspace == MA_MEM_HOST) MA_HIP(ctx, ma_stream_sync(ctx));
   return MA_OK;
 }
 

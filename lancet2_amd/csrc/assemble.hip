@@ -86,7 +86,7 @@ int launch_assemble(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& out, const
   MA_TRY_RC(run_count_inst(ctx, b, ws, 0, n, counters));
   u32 maxima[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   MA_HIP(ctx, hipMemcpyAsync(maxima, counters, 32, hipMemcpyDeviceToHost, ctx->stream));
-  MA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  MA_HIP(ctx, ma_stream_sync(ctx));
   u32 const max_inst = std::max<u32>(maxima[0], 1), max_read_inst = std::max<u32>(maxima[1], 1);
   u32 const max_refk = std::max<u32>(maxima[2], 1);
   ws.max_reads = std::max<u32>(maxima[3], 1);
@@ -171,7 +171,7 @@ int launch_assemble(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& out, const
       MA_TRY_RC(run_select_active(ctx, ws, win0, nwin, gate_approx, out.win_k, active, counters + 8));
       u32 host_cnt[2] = {0, 0};
       MA_HIP(ctx, hipMemcpyAsync(host_cnt, counters + 8, 8, hipMemcpyDeviceToHost, ctx->stream));
-      MA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      MA_HIP(ctx, ma_stream_sync(ctx));
       ws.n_active = static_cast<int>(host_cnt[0]);
       ws.active = active;
       if (host_cnt[1] == 0) break;  // every window of the chunk is resolved (graph.cpp:106 loop exit)

@@ -1128,7 +1128,7 @@ int run_build_pass(ma_ctx* ctx, const DBatch& b, GraphWs& ws, u32* counters_dev,
   ctx->toc();
   u32 max_slow = 0;
   MA_HIP(ctx, hipMemcpyAsync(&max_slow, counters_dev, 4, hipMemcpyDeviceToHost, ctx->stream));
-  MA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  MA_HIP(ctx, ma_stream_sync(ctx));
   int tc = 10;
   while ((size_t(1) << tc) < (static_cast<size_t>(max_slow) + ws.ref_stride) * 4 / 3 + 16) ++tc;
   ws.tc_log2 = tc < tc_log2_alloc ? tc : tc_log2_alloc;
@@ -1152,7 +1152,7 @@ int run_build_pass(ma_ctx* ctx, const DBatch& b, GraphWs& ws, u32* counters_dev,
   ctx->toc();
   u32 max_gen[2] = {0, 0};
   MA_HIP(ctx, hipMemcpyAsync(max_gen, counters_dev + 1, 8, hipMemcpyDeviceToHost, ctx->stream));
-  MA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  MA_HIP(ctx, ma_stream_sync(ctx));
   if (getenv("MA_VERBOSE")) {
     std::vector<u32> mm(A);
     MA_HIP(ctx, hipMemcpy(mm.data(), ws.mm_mode, 4 * A, hipMemcpyDeviceToHost));

@@ -85,6 +85,7 @@ struct ma_ctx {
   ma::DevBuf lane_rwo;      // rebased read_win_off of a child lane
   hipEvent_t lane_done = nullptr;
   double hbm_share = 1.0;   // fraction of the device this context plans its workspaces for
+  hipEvent_t sync_ev = nullptr;  // blocking-sync event: host threads sleep instead of spinning while the stream drains
 
   void tic(const char* name);
   void toc();
@@ -98,6 +99,19 @@ struct ma_ctx {
       return MA_ERR_HIP;                                                               \
     }                                                                                  \
   } while (0)
+
+// Wait for the context's stream without burning a host core: one process per GPU and up to three lane threads per
+// process would otherwise spin on hipStreamSynchronize (8 GPUs: 24 busy cores for nothing).
+inline hipError_t ma_stream_sync(ma_ctx* ctx) {
+  if (getenv("MA_SPIN_SYNC")) return hipStreamSynchronize(ctx->stream);
+  if (!ctx->sync_ev) {
+    hipError_t const e = hipEventCreateWithFlags(&ctx->sync_ev, hipEventBlockingSync | hipEventDisableTiming);
+    if (e != hipSuccess) return e;
+  }
+  hipError_t const e = hipEventRecord(ctx->sync_ev, ctx->stream);
+  if (e != hipSuccess) return e;
+  return hipEventSynchronize(ctx->sync_ev);
+}
 
 #define MA_TRY_RC(expr)            \
   do {                             \

@@ -2195,7 +2195,7 @@ int launch_msa(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& a, const ma_var
     MA_HIP(ctx, hipMemcpyAsync(nc.data(), a.win_ncomp, 4ull * n, hipMemcpyDeviceToHost, ctx->stream));
     MA_HIP(ctx, hipMemcpyAsync(h0.data(), a.comp_hap0, 4ull * n * P.max_comps, hipMemcpyDeviceToHost, ctx->stream));
     MA_HIP(ctx, hipMemcpyAsync(nh.data(), a.comp_nhaps, 4ull * n * P.max_comps, hipMemcpyDeviceToHost, ctx->stream));
-    MA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    MA_HIP(ctx, ma_stream_sync(ctx));
     for (int w = 0; w < n; ++w) {
       if (st[w] & MA_W_NO_HAPLOTYPE) continue;
       u32 alignments = 0;
