@@ -588,7 +588,7 @@ __global__ __launch_bounds__(kBT) void k_support(DBatch b, GraphWs ws, u32* max_
   if (threadIdx.x == 0) {
     // Windows whose (qname, role) keys each map to ONE run of adjacent reads (xs_flag == 0) and whose general
     // instances fit the LDS set are finished by k_mm_lds; the others need the HBM-resident set (max_gen[1]).
-    bool const lds_ok = !all_generic && ns <= kSeqCap && gen_count <= kMmLdsMax && ws.tc_log2 <= 20;
+    bool const lds_ok = !all_generic && ns <= kSeqCap && gen_count <= 4u * kMmLdsMax && ws.tc_log2 <= 20;  // <= 4 passes
     ws.mm_mode[a] = gen_count | (lds_ok ? 0u : 0x80000000u);
     atomicMax(max_gen, gen_count);
     if (!lds_ok) atomicMax(max_gen + 1, gen_count);
@@ -723,6 +723,11 @@ __global__ __launch_bounds__(kMmT) void k_mm_lds(DBatch b, GraphWs ws) {
   u32 const ns = seq_count(b, w);
   u32 const base_idx = b.read_win_off[w] + w;
   u32 const r_base = b.read_win_off[w];
+  // Windows with more general instances than one set holds (deep samples) take several passes, pass p handling the
+  // table slots with slot % npass == p: every key lives in exactly one pass, so each pass is complete in itself.
+  u32 const npass = (mode + kMmLdsMax - 1u) / kMmLdsMax;
+  for (u32 pass = 0; pass < npass; ++pass) {
+  __syncthreads();
   for (u32 i = threadIdx.x; i < kMmLdsCap; i += kMmT) l_set[i] = 0;
   for (u32 s = threadIdx.x; s < ns; s += kMmT) {
     l_base[s] = ws.seq_inst_base[base_idx + s];
@@ -736,6 +741,7 @@ __global__ __launch_bounds__(kMmT) void k_mm_lds(DBatch b, GraphWs ws) {
   auto const visit = [&](u32 ii, u32 word) {
     u32 const lead = l_lead[seq_of(l_base, ns, ii)];
     u32 const nslot = inst_table_slot(word, ref_slot_g);
+    if (npass > 1 && nslot % npass != pass) return;
     u32 const key = ((nslot << 11) | (lead - 1)) + 1u;
     u32 h = (key * 2654435761u) >> 17;  // kMmLdsCap == 1 << 15
     for (u32 probe = 0; probe < kMmLdsCap; ++probe) {
@@ -819,6 +825,7 @@ __global__ __launch_bounds__(kMmT) void k_mm_lds(DBatch b, GraphWs ws) {
     }
     __syncthreads();
   }
+  }  // pass
 }
 
 // low-coverage pruning (graph.cpp:363-390 with component 0 == everything, no anchors yet) and
