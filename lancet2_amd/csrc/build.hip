@@ -799,14 +799,54 @@ __global__ __launch_bounds__(kMmT) void k_mm_lds(DBatch b, GraphWs ws) {
   // 128-byte HBM line each (measured: 6 of this kernel's 8 ms), so the counts are accumulated in LDS as packed
   // u16 (a slot has at most 2047 names) for a range of slots at a time and added to the window's table in index
   // order: a wavefront's 64 counters share two lines.
-  u32 const slots_per_pass = (2u * kMmAux) / static_cast<u32>(CW);
+  // The set is not probed any more: its keys are compacted to the front (every thread reads its 32 entries into
+  // registers first, so compacting in place is safe) and the rest of the set joins l_aux as counter space -- three
+  // or four slot ranges instead of ten, each scanning only the keys.
+  u32 nkeys = 0;
+  {
+    constexpr u32 kPer = kMmLdsCap / kMmT;  // 32 consecutive entries per thread
+    u32 mine[kPer];
+    u32 cntk = 0;
+#pragma unroll
+    for (u32 x = 0; x < kPer; ++x) {
+      mine[x] = l_set[threadIdx.x * kPer + x];
+      cntk += mine[x] != 0;
+    }
+    __syncthreads();
+    // exclusive scan of cntk over the 1024 threads: wave scan + wave totals in l_aux
+    u32 inc = cntk;
+#pragma unroll
+    for (u32 o = 1; o < 64; o <<= 1) {
+      u32 const y = __shfl_up(inc, o, 64);
+      if (lane >= o) inc += y;
+    }
+    if (lane == 63) l_aux[threadIdx.x >> 6] = inc;
+    __syncthreads();
+    u32 woff = 0, total = 0;
+    for (u32 k = 0; k < kMmT / 64; ++k) {
+      u32 const t = l_aux[k];
+      if (k < (threadIdx.x >> 6)) woff += t;
+      total += t;
+    }
+    __syncthreads();
+    u32 at = woff + inc - cntk;
+#pragma unroll
+    for (u32 x = 0; x < kPer; ++x)
+      if (mine[x] != 0) l_set[at++] = mine[x];
+    nkeys = total;
+    __syncthreads();
+  }
+  // counter space: l_aux, then the free tail of l_set (u32 words, two u16 counters each)
+  u32 const tail_words = kMmLdsCap - nkeys;
+  u32 const ctr_words = kMmAux + tail_words;
+  auto const ctr = [&](u32 wd) -> u32& { return wd < kMmAux ? l_aux[wd] : l_set[nkeys + (wd - kMmAux)]; };
+  u32 const slots_per_pass = (2u * ctr_words) / static_cast<u32>(CW);
   u32 const tcap = 1u << ws.win_tc[a];
   for (u32 s0 = 0; s0 < tcap; s0 += slots_per_pass) {
-    for (u32 i = threadIdx.x; i < kMmAux; i += kMmT) l_aux[i] = 0;
+    for (u32 i = threadIdx.x; i < ctr_words; i += kMmT) ctr(i) = 0;
     __syncthreads();
-    for (u32 i = threadIdx.x; i < kMmLdsCap; i += kMmT) {
+    for (u32 i = threadIdx.x; i < nkeys; i += kMmT) {
       u32 const key = l_set[i];
-      if (key == 0) continue;
       u32 const nslot = (key - 1u) >> 11;
       if (nslot < s0 || nslot - s0 >= slots_per_pass) continue;
       u32 const r = r_base + ((key - 1u) & 2047u);
@@ -814,13 +854,13 @@ __global__ __launch_bounds__(kMmT) void k_mm_lds(DBatch b, GraphWs ws) {
       if (sample >= static_cast<u32>(S)) sample = S - 1;
       u32 const role = (b.read_flags[r] & MA_RF_CASE) ? 1u : 0u;
       u32 const i1 = (nslot - s0) * CW + sample, i2 = (nslot - s0) * CW + S + role;
-      atomicAdd(&l_aux[i1 >> 1], 1u << ((i1 & 1u) * 16u));
-      atomicAdd(&l_aux[i2 >> 1], 1u << ((i2 & 1u) * 16u));
+      atomicAdd(&ctr(i1 >> 1), 1u << ((i1 & 1u) * 16u));
+      atomicAdd(&ctr(i2 >> 1), 1u << ((i2 & 1u) * 16u));
     }
     __syncthreads();
     u32 const nc = min(slots_per_pass, tcap - s0) * CW;
     for (u32 j = threadIdx.x; j < nc; j += kMmT) {
-      u32 const c = (l_aux[j >> 1] >> ((j & 1u) * 16u)) & 0xFFFFu;
+      u32 const c = (ctr(j >> 1) >> ((j & 1u) * 16u)) & 0xFFFFu;
       if (c) atomicAdd(&cnt[static_cast<size_t>(s0) * CW + j], c);  // no return value: the wave does not wait for it
     }
     __syncthreads();
