@@ -384,7 +384,21 @@ __device__ __forceinline__ u64 kmer_id(const u8* s, int k, bool* plus_out) {
   return id ? id : 1;
 }
 
-__global__ __launch_bounds__(kBT) void k_insert(DBatch b, GraphWs ws) {
+// 85 % of the slow k-mers of a window are repeats (a variant's k-mers come back in every read that carries it), and
+// the table insert is bound by L2 atomic throughput (two returning atomics per instance).  So the window's distinct
+// k-mers are collected in an LDS map first (id -> smallest instance); the HBM table is then sized for the DISTINCT
+// k-mers (a quarter of the slots the instance count would ask for: less to initialise here, less to scan in k_rank and
+// k_mm_lds), each distinct k-mer goes into it once, and a last pass hands every instance its table slot.  k-mers that
+// do not fit the map (deep samples) are deferred and take the direct path with its atomics.
+constexpr int kInsT = 1024;
+constexpr u32 kInsMap = 8192;         // LDS map entries
+constexpr u32 kInstTemp = 1u << 26;   // instance word holds a map entry, not yet a table slot (slots are < 2^21)
+constexpr u32 kInstDefer = 1u << 25;  // instance waits for the direct path
+__global__ __launch_bounds__(kInsT) void k_insert(DBatch b, GraphWs ws) {
+  __shared__ u64 l_key[kInsMap];
+  __shared__ u32 l_min[kInsMap];
+  __shared__ u32 l_slot[kInsMap];
+  __shared__ u32 l_nmap, l_ndef;
   int const a = blockIdx.x;
   int const w = static_cast<int>(ws.active[a]);
   int const k = ws.k;
@@ -395,58 +409,150 @@ __global__ __launch_bounds__(kBT) void k_insert(DBatch b, GraphWs ws) {
   u32* ref_slot_g = ws.ref_slot + static_cast<size_t>(a) * ws.ref_stride;
   u32 const base_idx = b.read_win_off[w] + w;
   SeqInfo const rsi = seq_info(b, w, 0, k);
-  // The table stride (tc_log2) is sized for the window with the most k-mers; this window uses -- and initialises --
-  // only as many slots as it needs.  Nothing re-hashes later: every stage goes through the slot in the instance word.
-  u32 tcw = 10;
-  while (tcw < static_cast<u32>(ws.tc_log2) && (1u << tcw) < (ws.n_slow[a] + rsi.nk) * 4u / 3u + 16u) ++tcw;
-  u32 const mask = (1u << tcw) - 1;
-  {
-    int const CW = ws.num_samples + 2;
-    u32* cnt = ws.tbl_cnt + (static_cast<size_t>(a) << ws.tc_log2) * CW;
-    for (u32 i = threadIdx.x; i <= mask; i += kBT) {
-      keys[i] = 0;
-      first[i] = 0x7F7F7F7Fu;  // > any instance
-    }
-    for (u32 i = threadIdx.x; i < (mask + 1u) * CW; i += kBT) cnt[i] = 0;
-    if (threadIdx.x == 0) ws.win_tc[a] = tcw;
-    __syncthreads();
-  }
-  auto hash_insert = [&](const u8* s, u32 inst, u32* old_first) -> u32 {
-    bool plus;
-    u64 const id = kmer_id(s, k, &plus);
-    u32 const slot = table_insert(keys, mask, id);
-    *old_first = 0xFFFFFFFFu;
-    if (slot == kNoNode) {
-      atomicOr(&ws.win_flags[w], 4u);  // table full (cannot happen with the capacity planning)
-      return plus ? kInstPlus : 0u;
-    }
-    *old_first = atomicMin(&first[slot], inst);
-    return (slot & kInstSlotMask) | (plus ? kInstPlus : 0u);
-  };
-  // (A) reference k-mers (graph.cpp:264-267): instance index == reference position
-  {
-    const u8* s = b.ref_bases + rsi.off;
-    for (u32 p = threadIdx.x; p < rsi.nk; p += kBT) {
-      u32 of;
-      u32 const word = hash_insert(s + p, p, &of);
-      inst_slot[p] = word | (p + 1 == rsi.nk ? kInstLast : 0u);
-      ref_slot_g[p] = word & kInstSlotMask;
-    }
-  }
-  __syncthreads();  // every reference node has first < n_ref_kmers from here on
-  // (B) slow queue
   u32 const nq = ws.n_slow[a];
-  for (u32 x = threadIdx.x; x < nq; x += kBT) {
+  for (u32 i = threadIdx.x; i < kInsMap; i += kInsT) {
+    l_key[i] = 0;
+    l_min[i] = 0xFFFFFFFFu;
+  }
+  if (threadIdx.x == 0) l_nmap = l_ndef = 0;
+  __syncthreads();
+  // map entry of an id (kNoNode: no room along this probe sequence -- then there never will be for this id)
+  auto map_entry = [&](u64 id) -> u32 {
+    u32 e = static_cast<u32>(id >> 32) & (kInsMap - 1);
+    for (u32 probe = 0; probe < 64; ++probe) {
+      u64 cur = l_key[e];
+      if (cur == 0) {
+        unsigned long long const old = atomicCAS(reinterpret_cast<unsigned long long*>(&l_key[e]), 0ull,
+                                                 static_cast<unsigned long long>(id));
+        if (old == 0ull) atomicAdd(&l_nmap, 1u);
+        cur = old == 0ull ? id : old;
+      }
+      if (cur == id) return e;
+      e = (e + 1) & (kInsMap - 1);
+    }
+    return kNoNode;
+  };
+  // ---- pass 1: every k-mer into the map; its instance word temporarily names the map entry ----
+  {  // (A) reference k-mers (graph.cpp:264-267): instance index == reference position
+    const u8* s = b.ref_bases + rsi.off;
+    for (u32 p = threadIdx.x; p < rsi.nk; p += kInsT) {
+      bool plus;
+      u64 const id = kmer_id(s + p, k, &plus);
+      u32 const e = map_entry(id);
+      u32 const flags = (plus ? kInstPlus : 0u) | (p + 1 == rsi.nk ? kInstLast : 0u);
+      if (e != kNoNode) {
+        atomicMin(&l_min[e], p);
+        inst_slot[p] = e | kInstTemp | flags;
+      } else {
+        atomicAdd(&l_ndef, 1u);
+        inst_slot[p] = kInstDefer | flags;
+      }
+    }
+  }
+  for (u32 x = threadIdx.x; x < nq; x += kInsT) {  // (B) slow queue
     u32 const item = slowq[x];
     u32 const s_idx = item >> 12, o = item & 0xFFFu;
     SeqInfo const si = seq_info(b, w, s_idx, k);
     u32 const inst = ws.seq_inst_base[base_idx + s_idx] + o;
     u32 const keep = inst_slot[inst] & (kInstErrFree | kInstLast);
-    u32 const errfree = keep & kInstErrFree;
-    u32 of;
-    u32 const word = hash_insert(b.read_bases + si.off + o, inst, &of);
-    inst_slot[inst] = word | keep;
-    if (errfree && of < rsi.nk) ws.rd_flag[b.read_win_off[w] + s_idx - 1] = 1;
+    bool plus;
+    u64 const id = kmer_id(b.read_bases + si.off + o, k, &plus);
+    u32 const e = map_entry(id);
+    if (e != kNoNode) {
+      atomicMin(&l_min[e], inst);
+      inst_slot[inst] = e | kInstTemp | (plus ? kInstPlus : 0u) | keep;
+    } else {
+      atomicAdd(&l_ndef, 1u);
+      inst_slot[inst] = kInstDefer | (plus ? kInstPlus : 0u) | keep;
+    }
+  }
+  __syncthreads();
+  // ---- the table: as many slots as the distinct k-mers need (the stride tc_log2 is sized for the busiest window;
+  //      nothing re-hashes later: every stage goes through the slot in the instance word) ----
+  u32 tcw = 10;
+  while (tcw < static_cast<u32>(ws.tc_log2) && (1u << tcw) < (l_nmap + l_ndef) * 4u / 3u + 16u) ++tcw;
+  u32 const mask = (1u << tcw) - 1;
+  {
+    int const CW = ws.num_samples + 2;
+    u32* cnt = ws.tbl_cnt + (static_cast<size_t>(a) << ws.tc_log2) * CW;
+    for (u32 i = threadIdx.x; i <= mask; i += kInsT) {
+      keys[i] = 0;
+      first[i] = 0x7F7F7F7Fu;  // > any instance
+    }
+    for (u32 i = threadIdx.x; i < (mask + 1u) * CW; i += kInsT) cnt[i] = 0;
+    if (threadIdx.x == 0) ws.win_tc[a] = tcw;
+    __syncthreads();
+  }
+  // ---- pass 2: every distinct k-mer of the map into the HBM table, once ----
+  for (u32 e = threadIdx.x; e < kInsMap; e += kInsT) {
+    u64 const id = l_key[e];
+    if (id == 0) continue;
+    u32 const slot = table_insert(keys, mask, id);
+    l_slot[e] = slot;
+    if (slot == kNoNode) atomicOr(&ws.win_flags[w], 4u);  // table full (cannot happen with the capacity planning)
+    else first[slot] = l_min[e];  // plain store: ids of the map never take the direct path
+  }
+  // deferred instances (ids without room in the map): the direct path, reference k-mers first
+  bool const any_def = l_ndef != 0;
+  auto direct_insert = [&](u64 id, u32 inst, u32* old_first) -> u32 {
+    u32 const slot = table_insert(keys, mask, id);
+    *old_first = 0xFFFFFFFFu;
+    if (slot == kNoNode) {
+      atomicOr(&ws.win_flags[w], 4u);
+      return 0u;
+    }
+    *old_first = atomicMin(&first[slot], inst);
+    return slot & kInstSlotMask;
+  };
+  if (any_def) {
+    __syncthreads();
+    const u8* s = b.ref_bases + rsi.off;
+    for (u32 p = threadIdx.x; p < rsi.nk; p += kInsT) {
+      u32 const word = inst_slot[p];
+      if (!(word & kInstDefer)) continue;
+      bool plus;
+      u64 const id = kmer_id(s + p, k, &plus);
+      u32 of;
+      u32 const fin = direct_insert(id, p, &of) | (word & (kInstPlus | kInstLast));
+      inst_slot[p] = fin;
+      ref_slot_g[p] = fin & kInstSlotMask;
+    }
+    __syncthreads();  // a later instance of a reference k-mer sees a reference position as the minimum
+    for (u32 x = threadIdx.x; x < nq; x += kInsT) {
+      u32 const item = slowq[x];
+      u32 const s_idx = item >> 12, o = item & 0xFFFu;
+      u32 const inst = ws.seq_inst_base[base_idx + s_idx] + o;
+      u32 const word = inst_slot[inst];
+      if (!(word & kInstDefer)) continue;
+      SeqInfo const si = seq_info(b, w, s_idx, k);
+      bool plus;
+      u64 const id = kmer_id(b.read_bases + si.off + o, k, &plus);
+      u32 of;
+      inst_slot[inst] = direct_insert(id, inst, &of) | (word & (kInstPlus | kInstLast | kInstErrFree));
+      if ((word & kInstErrFree) && of < rsi.nk) ws.rd_flag[b.read_win_off[w] + s_idx - 1] = 1;
+    }
+  }
+  __syncthreads();
+  // ---- pass 3: instance words get their table slot; reads with a general-path k-mer that is a reference node ----
+  for (u32 p = threadIdx.x; p < rsi.nk; p += kInsT) {
+    u32 const word = inst_slot[p];
+    if (!(word & kInstTemp)) continue;
+    u32 const slot = l_slot[word & (kInsMap - 1)];
+    u32 const fin = (slot == kNoNode ? 0u : (slot & kInstSlotMask)) | (word & (kInstPlus | kInstLast));
+    inst_slot[p] = fin;
+    ref_slot_g[p] = fin & kInstSlotMask;
+  }
+  for (u32 x = threadIdx.x; x < nq; x += kInsT) {
+    u32 const item = slowq[x];
+    u32 const s_idx = item >> 12, o = item & 0xFFFu;
+    u32 const inst = ws.seq_inst_base[base_idx + s_idx] + o;
+    u32 const word = inst_slot[inst];
+    if (!(word & kInstTemp)) continue;  // direct path: finished above
+    u32 const e = word & (kInsMap - 1);
+    u32 const slot = l_slot[e];
+    inst_slot[inst] = (slot == kNoNode ? 0u : (slot & kInstSlotMask)) | (word & (kInstPlus | kInstLast | kInstErrFree));
+    // the k-mer is also a reference k-mer <=> the smallest instance of its id is a reference position
+    if ((word & kInstErrFree) && l_min[e] < rsi.nk) ws.rd_flag[b.read_win_off[w] + s_idx - 1] = 1;
   }
 }
 
@@ -1182,7 +1288,7 @@ int run_build_pass(ma_ctx* ctx, const DBatch& b, GraphWs& ws, u32* counters_dev,
   int const mc_log2_alloc = ws.mc_log2;
   // (k_insert initialises the slots each window uses: no table-wide memsets)
   ctx->tic("k_insert");
-  hipLaunchKernelGGL(k_insert, dim3(ws.n_active), dim3(kBT), 0, ctx->stream, b, ws);
+  hipLaunchKernelGGL(k_insert, dim3(ws.n_active), dim3(kInsT), 0, ctx->stream, b, ws);
   ctx->toc();
   size_t const lds_s = 4ull * ws.ref_stride * (S + 2) + 4ull * kMaskWords * kBT + 8ull * kXs + kXs + 64;
   if (lds_s > 65536)
