@@ -562,6 +562,7 @@ __global__ __launch_bounds__(kBT) void k_support(DBatch b, GraphWs ws, u32* max_
   extern __shared__ unsigned char lds_build[];
   __shared__ u32 xs_flag;
   __shared__ u32 gen_count;  // instances routed through the general mate-mer set (sizes that set)
+  __shared__ u32 n_leaders;
   int const a = blockIdx.x;
   int const w = static_cast<int>(ws.active[a]);
   int const k = ws.k;
@@ -575,7 +576,7 @@ __global__ __launch_bounds__(kBT) void k_support(DBatch b, GraphWs ws, u32* max_
   u32* l_cnt = reinterpret_cast<u32*>(lds_build + off);
   off += 4u * ws.ref_stride * CW;
   u32* l_mask = reinterpret_cast<u32*>(lds_build + off);
-  off += 4u * kMaskWords * kBT;
+  off += 4u * max(static_cast<u32>(kMaskWords * kBT), ws.max_reads + 2u);
   u32* l_xkey = reinterpret_cast<u32*>(lds_build + off);
   off += 4u * kXs;
   u32* l_xgrp = reinterpret_cast<u32*>(lds_build + off);
@@ -641,10 +642,26 @@ __global__ __launch_bounds__(kBT) void k_support(DBatch b, GraphWs ws, u32* max_
   __syncthreads();
   bool const all_generic = !hints || xs_flag != 0;
 
+  // One WAVEFRONT per group of mates, a lane per k-mer: the instance words of a read are read coalesced, the offsets
+  // of the first mate that were counted are one ballot per 64 k-mers (kept in scalar registers), and the second mate
+  // looks its reference position up in them.  (A thread per group walked its reads' words one by one: serial,
+  // uncoalesced, 250 dependent loads per thread.)
+  // leaders of the groups, in any order (counting commutes)
+  u32* const l_leaders = l_mask;  // [max_reads + 2] (the per-thread masks of the old mapping lived here)
+  if (threadIdx.x == 0) n_leaders = 0;
+  __syncthreads();
   for (u32 s_idx = 1 + threadIdx.x; s_idx < ns; s_idx += kBT) {
     u32 const r0 = b.read_win_off[w] + s_idx - 1;
     if (!(b.read_flags[r0] & MA_RF_PASS)) continue;
     if (s_idx > 1 && same_group(b, r0, r0 - 1)) continue;  // not the leader
+    l_leaders[atomicAdd(&n_leaders, 1u)] = s_idx;
+  }
+  __syncthreads();
+  u32 const wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+  u32 wave_gen = 0;
+  for (u32 gi = wave; gi < n_leaders; gi += kBT / 64) {
+    u32 const s_idx = l_leaders[gi];
+    u32 const r0 = b.read_win_off[w] + s_idx - 1;
     u32 gsize = 1;
     while (s_idx + gsize < ns && same_group(b, r0, r0 + gsize)) gsize++;
     bool generic = all_generic || gsize > 2;
@@ -653,8 +670,10 @@ __global__ __launch_bounds__(kBT) void k_support(DBatch b, GraphWs ws, u32* max_
       if (ws.rd_flag[r0 + gm] || si.nk > 32u * kMaskWords) generic = true;
     }
     i32 hint0 = 0;
-    u32 nk0 = 0, ngen = 0;
-    for (int mw = 0; mw < kMaskWords; ++mw) l_mask[mw * kBT + threadIdx.x] = 0;
+    u32 nk0 = 0;
+    unsigned long long m0[kMaskWords / 2];  // offsets of the first mate that were counted
+#pragma unroll
+    for (int x = 0; x < kMaskWords / 2; ++x) m0[x] = 0;
     for (u32 gm = 0; gm < gsize; ++gm) {
       u32 const sx = s_idx + gm;
       SeqInfo const si = seq_info(b, w, sx, k);
@@ -668,28 +687,39 @@ __global__ __launch_bounds__(kBT) void k_support(DBatch b, GraphWs ws, u32* max_
         hint0 = hints ? b.read_hint[r] : 0;
         nk0 = si.nk;
       }
-      for (u32 o = 0; o < si.nk; ++o) {
-        u32 const word = inst_slot[ibase + o];
-        if (!(word & kInstErrFree)) continue;
-        if (generic || !(word & kInstFast)) {
-          inst_slot[ibase + o] = word | kInstGen;  // exact handling by k_mm_insert / k_count
-          ngen++;
-          continue;
-        }
+      for (u32 ob = 0; ob < si.nk; ob += 64) {
+        u32 const o = ob + lane;
+        u32 const word = o < si.nk ? inst_slot[ibase + o] : 0u;
+        bool const ef = (word & kInstErrFree) != 0;
+        bool const to_gen = ef && (generic || !(word & kInstFast));
+        if (to_gen) inst_slot[ibase + o] = word | kInstGen;  // exact handling by the mate-mer set kernels
+        wave_gen += static_cast<u32>(__popcll(__ballot(to_gen)));
+        bool const fast = ef && !to_gen;
         u32 const p = word & kInstSlotMask;
         bool dup = false;
-        if (gm == 1 && nk0 > 0) {  // did the first member count this reference position?
+        if (gm == 1 && nk0 > 0 && fast) {  // did the first member count this reference position?
           i64 const o0 = static_cast<i64>(p) - hint0;
-          if (o0 >= 0 && o0 < static_cast<i64>(nk0)) dup = (l_mask[(o0 >> 5) * kBT + threadIdx.x] >> (o0 & 31)) & 1u;
+          if (o0 >= 0 && o0 < static_cast<i64>(nk0)) {
+            unsigned long long wd = 0;
+#pragma unroll
+            for (int x = 0; x < kMaskWords / 2; ++x) wd = (o0 >> 6) == x ? m0[x] : wd;
+            dup = (wd >> (o0 & 63)) & 1ull;
+          }
         }
-        if (gm == 0) l_mask[(o >> 5) * kBT + threadIdx.x] |= 1u << (o & 31);
-        if (dup) continue;
-        atomicAdd(&l_cnt[p * CW + smp], 1u);
-        atomicAdd(&l_cnt[p * CW + S + role], 1u);
+        if (gm == 0 && !generic) {
+          unsigned long long const cm = __ballot(fast);
+#pragma unroll
+          for (int x = 0; x < kMaskWords / 2; ++x)
+            if (static_cast<int>(ob >> 6) == x) m0[x] = cm;
+        }
+        if (fast && !dup) {
+          atomicAdd(&l_cnt[p * CW + smp], 1u);
+          atomicAdd(&l_cnt[p * CW + S + role], 1u);
+        }
       }
     }
-    if (ngen) atomicAdd(&gen_count, ngen);
   }
+  if (lane == 0 && wave_gen) atomicAdd(&gen_count, wave_gen);
   __syncthreads();
   if (threadIdx.x == 0) {
     // Windows whose (qname, role) keys each map to ONE run of adjacent reads (xs_flag == 0) and whose general
@@ -1290,7 +1320,7 @@ int run_build_pass(ma_ctx* ctx, const DBatch& b, GraphWs& ws, u32* counters_dev,
   ctx->tic("k_insert");
   hipLaunchKernelGGL(k_insert, dim3(ws.n_active), dim3(kInsT), 0, ctx->stream, b, ws);
   ctx->toc();
-  size_t const lds_s = 4ull * ws.ref_stride * (S + 2) + 4ull * kMaskWords * kBT + 8ull * kXs + kXs + 64;
+  size_t const lds_s = 4ull * ws.ref_stride * (S + 2) + 4ull * std::max<size_t>(kMaskWords * kBT, ws.max_reads + 2) + 8ull * kXs + kXs + 64;
   if (lds_s > 65536)
     MA_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_support), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     static_cast<int>(lds_s)));
