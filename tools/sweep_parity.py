@@ -1,0 +1,37 @@
+"""Developer tool: one-off bit-exact parity sweep of the whole chain over many more seeds than the test-suite uses."""
+import os
+import sys
+
+import numpy as np
+
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, R)
+sys.path.insert(0, os.path.join(R, "tests"))
+from harness import OracleEngine, compare_asm, compare_cx, compare_geno, compare_vars  # noqa: E402
+from lancet2_amd import capi, synth  # noqa: E402
+from lancet2_amd.engine import Engine  # noqa: E402
+
+CASES = [("C2", 96, 70_000, {}, dict(min_k=25, max_k=25)), ("C3", 32, 71_000, {}, dict(min_k=25, max_k=25)),
+         ("C2", 24, 72_000, dict(str_unit=b"AT", n_somatic=2), {}), ("C5", 8, 73_000, {}, dict(min_k=25, max_k=25, num_samples=3)),
+         ("C2", 16, 74_000, dict(W=1500, indel_rate=1e-3), dict(min_k=25, max_k=25)),
+         ("C2", 12, 75_000, dict(big_indel=40), dict(min_k=25, max_k=25))]
+tot = 0
+for cfg, nwin, first, kw, pk in CASES:
+    params = capi.default_params(**pk)
+    arrs, n, nr = synth.make_config_batch(cfg, nwin, first_index=first, **kw)
+    orc = OracleEngine(params)
+    wg, wa = orc.gate(arrs, n, nr), orc.assemble(arrs, n, nr)
+    wv = orc.msa(arrs, n, nr, wa)
+    wq = orc.genotype(arrs, n, nr, wa, wv)
+    wc = orc.annotate(arrs, n, nr, wa, wv)
+    eng = Engine(params)
+    g, a, v, q = eng.process(arrs, n, nr, debug=True)
+    cx = eng.annotate(arrs, n, nr, a, v)
+    eng.close()
+    bad = [] if np.array_equal(g["max_approx"], wg["max_approx"]) else ["gate"]
+    bad += compare_asm(params, a, wa, n) + compare_vars(params, v, wv, n)
+    bad += compare_geno(params, q, wq, n, nr, wv["win_nvars"], arrs["read_win_off"])
+    compare_cx(params, cx, wc, wv["win_nvars"])
+    print(cfg, nwin, kw, "variants", int(wv["win_nvars"].sum()), "OK" if not bad else bad[:5], flush=True)
+    tot += len(bad)
+sys.exit(1 if tot else 0)
