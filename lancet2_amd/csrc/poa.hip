@@ -4,14 +4,21 @@
 // kNW with convex gaps 0/-6/-6,-2/-26,-1: caller/msa_builder.h:72-89) and the caller::VariantSet
 // constructor (caller/variant_extractor.cpp:24-233, variant_bubble.cpp:16-116, raw_variant.cpp:44-77).
 //
-// One workgroup of 256 threads (4 wavefronts) per window; its components are processed one after another.
-//  * The POA graph (node chars, in/out adjacency with 16-bit ids, per-edge haplotype label masks,
-//    aligned-node rings, rank <-> node maps) lives in LDS (~42 B per node).
-//  * Sequence-to-DAG DP (SisdAlignmentEngine::Convex): 256 lanes fill the matrix as a skewed pipeline.
-//    Lane l owns CW consecutive columns and handles DP row (t - l + 1) at step t; (H,E,Q) of the
-//    column to its left arrive by wave shuffle (LDS mailbox across the three wave boundaries); the two
-//    previous rows stay in registers.  A row is written to HBM only if a later row needs it and cannot
-//    take it from registers (a predecessor that is neither rank-1 nor rank-2: the ends of indel arcs).
+// Two kernels per alignment round (launch_msa):
+//  * k_msa -- one workgroup of 256 threads (4 wavefronts) per window; its components and haplotypes are processed one
+//    after another.  The POA graph (node chars, in/out adjacency with 16-bit ids, per-edge haplotype label masks,
+//    aligned-node rings, rank <-> node maps) lives in LDS (~42 B per node).  The kernel is a coroutine: when the next
+//    haplotype <-> graph alignment is ready for the DP it writes the row descriptors, saves its whole LDS block to HBM
+//    and returns; the next launch restores the block and continues after the fill (best end cell, certificate,
+//    traceback, graph update, toposort, variants).
+//  * k_msa_band -- ONE wavefront per window fills a 256-column band around every row's backbone coordinate
+//    (poa_fill_band), reading the descriptors straight from the saved block: sixteen windows per CU instead of two.
+//    The band is exact by certificate (see poa_fill_band) or the alignment is redone with the full fill.
+//  * Full fill (poa_fill<CW>, fallback and MA_POA_BAND=0): row-synchronous, all 256 lanes work on ONE DP row, lane l
+//    owns CW consecutive columns; the horizontal gap chains (E, Q) are closed with two prefix maxima over the row
+//    (DPP scans + one LDS exchange across the wave boundaries); the previous two rows stay in registers.  A row is
+//    written to HBM only if a later row needs it and cannot take it from registers (a predecessor that is neither
+//    rank-1 nor rank-2: the ends of indel arcs).
 //  * SPOA's traceback compares VALUES of five i32 matrices.  Every comparison it can make at a cell
 //    only involves values the fill has in registers when it computes that cell, so the fill evaluates
 //    them on the spot and stores a 10-bit decision code per cell (2 B instead of 20 B of matrices):
@@ -22,7 +29,8 @@
 //    The traceback reads one code per step; runs of diagonal moves over rank-consecutive rows, left runs
 //    and up runs are detected 64 cells at a time with a wave ballot.
 //  * Graph::AddAlignment is lane-parallel (every path node is touched by exactly one alignment entry);
-//    SPOA's DFS topological sort stays a serial LDS loop on thread 0 (its order defines the ranks).
+//    SPOA's DFS topological sort ranks the trivial roots 64 at a time and runs the DFS only for the rest
+//    (its order defines the ranks).
 //  * The bubble walk of VariantExtractor skips converged stretches 256 nodes at a time.
 // Edge weights are not tracked: the reference only reads topology, labels and ranks from the POA
 // graph (variant_extractor.cpp:47-58, :84-94, :159-181).
