@@ -9,16 +9,16 @@
 // (genotyper.cpp:423-456, caller/variant_support.cpp:24-30) and SomaticLogOddsRatio
 // (caller/variant_call.cpp:316-345).
 //
-// Kernels (HBM traffic per read x haplotype pair: 2 reads of ~150 B + one haplotype segment in, a
-// 4-bit/cell traceback tile out and partially back in, 24 + 4*n_cigar bytes of result):
-//   k_plan       per window: which haplotype slots get aligned, pair counts
-//   k_hap_index  per haplotype slot: 11-mer chained hash index (head/next) in HBM
-//   k_vote       one wave per pair: every shared 11-mer votes for its diagonal in an LDS histogram;
-//                wave arg-max = band centre
-//   k_align      one LANE per pair (inter-task SIMD: all lanes run the same row/band loop, no
-//                cross-lane traffic); (H,F) band rows packed i16x2 in LDS laid out [band][lane]
-//                (conflict-free), haplotype segment packed 4 bit/base in LDS, traceback nibbles
-//                written to HBM coalesced as [row][word][lane]; per-lane traceback -> CIGAR
+// Kernels:
+//   k_plan          per window: which haplotype slots get aligned, pair counts, the (window, haplotype) work list
+//   k_vote          workgroup per (window, haplotype): 11-mer chained index + haplotype bit planes in LDS; wave per
+//                   read: shared 11-mers vote for their diagonal (unanimous votes skip the histogram); arg-max =
+//                   band centre; the three gapless certificates settle 92 % of the pairs right here
+//   k_dp_partition  DP list reordered: pairs whose band can reach a haplotype end last
+//   k_align_reg     one LANE per pair (inter-task SIMD, no cross-lane traffic); the (H,F) band row packed i16x2 in
+//                   registers, row body fully unrolled (lean / general variant per wavefront and row), haplotype
+//                   segment 4 bit/base in LDS, traceback nibbles written to HBM coalesced as [row][word][lane];
+//                   per-lane traceback -> CIGAR.  k_align: the same with the band row in LDS, for band != 64
 //   k_assign     one lane per read: best allele per variant over the haplotypes of each component
 //   k_evidence   first read per (variant, sample, allele, qname) counts, by strand
 //   k_qual       SOLOR site quality

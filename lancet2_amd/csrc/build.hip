@@ -3,19 +3,21 @@
 // RemoveLowCovNodes(0) pass (graph.cpp:135, :363-390) and produces the compact, canonically ordered
 // node/edge arrays the cleaning kernel (clean.hip) walks.
 //
-// One 256-thread workgroup per window attempt.  Five data-parallel passes over the k-mer INSTANCES of
-// the window (reference k-mers first, then each filter-passing read in collector order -- that
-// sequence-major order is the canonical first-insertion order of DESIGN.md):
-//   k_build_insert  rolling canonical hash (fwd + rev-comp polynomial, fmix64), inward canonical
-//                   compare (kmer.cpp:17-28), open-addressing insert with atomicCAS, atomicMin of the
-//                   first-instance index (= try_emplace keeps the first inserter, graph.cpp:325-326);
-//                   sequential f64 Phred prefix sums per read (graph.cpp:280-304) via two lagged
-//                   accumulators -> error-free bit.
-//   k_mm_insert     (qname, role, node) set with atomicMin of the first error-free instance
-//   k_count         the winning instance increments per-sample / per-role support (node.cpp:18-24)
-//   k_rank          low-coverage pruning + canonical ranking of survivors, node records
-//   k_edges         forward + mirror edge of every (k+1)-mer whose two nodes survive, de-duplicated
-//                   per node with the order key of the first occurrence; k_edge_sort orders them.
+// One workgroup per window attempt and kernel.  Data-parallel passes over the k-mer INSTANCES of the window
+// (reference k-mers first, then each filter-passing read in collector order -- that sequence-major order is
+// the canonical first-insertion order of DESIGN.md); every instance owns one 32-bit instance word (graph_ws.h):
+//   k_classify   wave per tile of 64 reads staged in LDS: error-free bit from sequential f64 Phred prefix sums
+//                (graph.cpp:280-304, two lagged accumulators); k-mers equal to the reference k-mer at the read's
+//                hinted offset become FAST instances (no hashing), the others go to the window's slow queue
+//   k_insert     distinct slow + reference k-mers in an LDS map (canonical decision kmer.cpp:17-28, polynomial +
+//                fmix64 id), then one open-addressing insert per distinct k-mer; first instance = try_emplace
+//                (graph.cpp:325-326)
+//   k_support    read support of FAST instances with the mate-mer rule (graph.h:102-117), wave per group of mates
+//   k_mm_lds     (qname, role, node) set of the remaining instances in LDS + their support (node.cpp:18-24);
+//                k_mm_insert / k_count: the HBM-resident fallback of that set
+//   k_rank       low-coverage pruning + canonical ranking of survivors, node records
+//   k_edges      forward + mirror edge of every (k+1)-mer whose two nodes survive, distinct edges collected in an
+//                LDS set with the order key of the first occurrence; k_edge_sort orders them.
 #include "graph_ws.h"
 
 namespace ma {
