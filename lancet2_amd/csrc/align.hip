@@ -90,7 +90,7 @@ __global__ void k_plan(GArgs A) {
   int const w = blockIdx.x * blockDim.x + threadIdx.x;
   if (w >= A.b.n_windows) return;
   ma_params_t const& P = A.prm;
-  u32 mask = 0;
+  u32 mask = 0, hl = 0;
   u32 const nv = A.v.win_nvars[w];
   if (nv > 0 && !(A.a.win_status[w] & MA_W_NO_HAPLOTYPE)) {
     for (u32 c = 0; c < A.a.win_ncomp[w]; ++c) {
@@ -98,9 +98,13 @@ __global__ void k_plan(GArgs A) {
       for (u32 x = 0; x < nv && !has; ++x) has = A.v.var_comp[static_cast<size_t>(w) * P.max_vars + x] == c;
       if (!has) continue;  // variant_builder.cpp:248: components without variants are not genotyped
       size_t const ci = static_cast<size_t>(w) * P.max_comps + c;
-      for (u32 h = 0; h < A.a.comp_nhaps[ci]; ++h) mask |= 1u << (A.a.comp_hap0[ci] + h);
+      for (u32 h = 0; h < A.a.comp_nhaps[ci]; ++h) {
+        mask |= 1u << (A.a.comp_hap0[ci] + h);
+        hl = max(hl, A.a.hap_len[static_cast<size_t>(w) * P.max_haps + A.a.comp_hap0[ci] + h]);
+      }
     }
   }
+  if (hl) atomicMax(&A.ws.counters[3], hl);  // longest haplotype that is aligned: sizes k_vote's LDS
   A.ws.win_slotmask[w] = mask;
   if (mask) {  // dense work list: a (window, slot) grid would leave most workgroups (and whole XCDs) empty
     u32 at = atomicAdd(&A.ws.counters[2], static_cast<u32>(__popc(mask)));
@@ -221,7 +225,7 @@ constexpr int kPre = 4;  // read bases prefetched per lane (covers reads up to 2
 __device__ __forceinline__ void vote_pair(GArgs const& A, u64 lp, PairId id, HapIdx ix, u16* hist, int lane, u64 ro, i32 m,
                                           const u32 (&pre)[kPre]);
 
-__global__ __launch_bounds__(256) void k_vote(GArgs A, u32 hist_len, u32 rwords) {
+__global__ __launch_bounds__(256) void k_vote(GArgs A, u32 hist_len, u32 rwords, u32 ml_eff) {
   extern __shared__ u32 lds_vote[];
   u32 const item = A.ws.vote_wg[blockIdx.x];
   int const w = item / A.prm.max_haps, slot = item % A.prm.max_haps;
@@ -230,7 +234,9 @@ __global__ __launch_bounds__(256) void k_vote(GArgs A, u32 hist_len, u32 rwords)
   u32 const r0 = A.b.read_win_off[w], nr = A.b.read_win_off[w + 1] - r0;
   u64 const p0 = A.ws.pair_off[w] + static_cast<u64>(si) * nr;  // global pair index of read 0
   if (p0 + nr <= A.pair0 || p0 >= A.pair0 + A.npairs) return;
-  u32 const ML = A.prm.max_hap_len;
+  // LDS is carved for the longest haplotype that is actually aligned in this batch (ml_eff), not for the capacity
+  // max_hap_len: half the footprint on 1 kb windows, five workgroups per CU instead of three
+  u32 const ML = ml_eff;
   u32 const pw = (ML + 31) / 32 + 2;  // words per haplotype bit plane (two zero words of padding)
   u32* code = lds_vote;                                    // [ML]
   u16* head = reinterpret_cast<u16*>(code + ML);           // [kIdxCap]
@@ -244,7 +250,7 @@ __global__ __launch_bounds__(256) void k_vote(GArgs A, u32 hist_len, u32 rwords)
   u32* l_roff = dpbuf_all + 4 * 65;                        // [nr + 1] read byte offsets relative to the window's first read
   size_t const hi = static_cast<size_t>(w) * A.prm.max_haps + slot;
   u32 const n = A.a.hap_len[hi];
-  const u8* hb = A.a.hap_bases + hi * ML;
+  const u8* hb = A.a.hap_bases + hi * A.prm.max_hap_len;
   for (u32 x = threadIdx.x; x < kIdxCap / 2; x += 256) reinterpret_cast<u32*>(head)[x] = 0xFFFFFFFFu;
   for (u32 x = threadIdx.x; x < 4 * hist_len / 2; x += 256) reinterpret_cast<u32*>(hist_all)[x] = 0;
   u64 const roff0 = A.b.read_off[r0];
@@ -1453,10 +1459,11 @@ int launch_genotype(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& a, const m
     ws.dp_list = reinterpret_cast<u32*>(ws.centre + pairs_chunk + 16);
     ws.dp_count = ws.dp_list + pairs_chunk + 16;
     u32* const dp_sorted = ws.dp_count + 16;  // [pairs_chunk] the DP list, interior pairs first (k_dp_partition)
-    u32 const hist_len = ((max_read_len + static_cast<u32>(P.max_hap_len) + 2 + 1) & ~1u);
-    u32 const pw_host = (static_cast<u32>(P.max_hap_len) + 31) / 32 + 2;
+    u32 const ml_eff = std::min<u32>(static_cast<u32>(P.max_hap_len), (std::max<u32>(plan_counters[3], 64u) + 31u) & ~31u);
+    u32 const hist_len = ((max_read_len + ml_eff + 2 + 1) & ~1u);
+    u32 const pw_host = (ml_eff + 31) / 32 + 2;
     u32 const rwords = (max_read_len + 31) / 32 + 2;
-    size_t const lds_vote = 4ull * P.max_hap_len + 2ull * kIdxCap + 2ull * ((P.max_hap_len + 1) & ~1) + 8ull * hist_len +
+    size_t const lds_vote = 4ull * ml_eff + 2ull * kIdxCap + 2ull * ((ml_eff + 1) & ~1) + 8ull * hist_len +
                             12ull * pw_host + 48ull * rwords + 4ull * 4 * 65 + 4ull * (plan_counters[1] + 2) + 64;
     if (lds_vote > 65536)
       MA_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_vote), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1468,7 +1475,7 @@ int launch_genotype(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& a, const m
       A.npairs = static_cast<u32>(std::min<u64>(pairs_chunk, total_pairs - p0));
       MA_HIP(ctx, hipMemsetAsync(ws.dp_count, 0, 4, ctx->stream));
       ctx->tic("k_vote");
-      hipLaunchKernelGGL(k_vote, dim3(n_vote_wg), dim3(256), lds_vote, ctx->stream, A, hist_len, rwords);
+      hipLaunchKernelGGL(k_vote, dim3(n_vote_wg), dim3(256), lds_vote, ctx->stream, A, hist_len, rwords, ml_eff);
       ctx->toc();
       u32 ndp = 0;
       MA_HIP(ctx, hipMemcpyAsync(&ndp, ws.dp_count, 4, hipMemcpyDeviceToHost, ctx->stream));
