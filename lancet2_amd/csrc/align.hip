@@ -355,6 +355,12 @@ __global__ __launch_bounds__(256) void k_vote(GArgs A, u32 hist_len, u32 rwords,
 #endif
 }
 
+// "no alignment": the hit flag of the pair's record is cleared explicitly (every reader tests it before anything else),
+// so the multi-GB internal record arrays need no memset per batch.
+__device__ __forceinline__ void write_no_hit(GArgs const& A, PairId id) {
+  A.o.aln_rec[(static_cast<size_t>(id.r) * A.prm.max_haps + id.slot) * 6] = 0;
+}
+
 __device__ __forceinline__ void vote_pair(GArgs const& A, u64 lp, PairId id, HapIdx ix, u16* hist, int lane, u64 ro, i32 m,
                                           const u32 (&pre)[kPre]) {
   size_t const hi = static_cast<size_t>(id.w) * A.prm.max_haps + id.slot;
@@ -535,8 +541,11 @@ __device__ __forceinline__ void vote_pair(GArgs const& A, u64 lp, PairId id, Hap
     VPROF_ACC(4);
   }
   (void)nd;
-  if (best == 0) {  // no shared 11-mer: no hit (record stays zero)
-    if (lane == 0) A.ws.centre[lp] = 0x7FFFFFFF;
+  if (best == 0) {  // no shared 11-mer: no hit
+    if (lane == 0) {
+      A.ws.centre[lp] = 0x7FFFFFFF;
+      write_no_hit(A, id);
+    }
     return;
   }
   i32 const c = bd - m;
@@ -611,7 +620,8 @@ __device__ __forceinline__ void vote_pair(GArgs const& A, u64 lp, PairId id, Hap
                      6 * lmax + 50 + 5 * v_off < 11 * ms;
   if (lane == 0) {
     if (nohit) {
-      A.ws.centre[lp] = 0x7FFFFFFF;  // record stays zero: no alignment
+      A.ws.centre[lp] = 0x7FFFFFFF;  // no alignment
+      write_no_hit(A, id);
     } else if (fast) {
       size_t const rec = static_cast<size_t>(id.r) * A.prm.max_haps + id.slot;
       i32* arec = A.o.aln_rec + rec * 6;
@@ -1428,8 +1438,10 @@ int launch_genotype(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& a, const m
   MA_HIP(ctx, hipMemsetAsync(ws.ev_min, 0xFF, 4ull * n * ws.ev_cap, ctx->stream));
   MA_HIP(ctx, hipMemsetAsync(A.o.allele_counts, 0,
                              4ull * n * MV * P.num_samples * (P.max_alts + 1) * 2, ctx->stream));
-  MA_HIP(ctx, hipMemsetAsync(A.o.aln_rec, 0, 4ull * NR * MH * 6, ctx->stream));
-  MA_HIP(ctx, hipMemsetAsync(A.o.aln_cigar, 0, 4ull * NR * MH * (1 + MCG), ctx->stream));
+  // every planned pair gets its hit flag written (a record, or an explicit "no alignment"): only the caller's debug
+  // taps are cleared, so that everything that is not an alignment reads as zero there
+  if (o_in.aln_rec) MA_HIP(ctx, hipMemsetAsync(A.o.aln_rec, 0, 4ull * NR * MH * 6, ctx->stream));
+  if (o_in.aln_cigar) MA_HIP(ctx, hipMemsetAsync(A.o.aln_cigar, 0, 4ull * NR * MH * (1 + MCG), ctx->stream));
 
   ctx->tic("k_plan");
   hipLaunchKernelGGL(k_plan, dim3((n + 127) / 128), dim3(128), 0, ctx->stream, A);
