@@ -491,3 +491,24 @@ def test_process_batch_deep_window():
     bad += compare_geno(params, q, wq, n, nr, wv["win_nvars"], arrs["read_win_off"])
     assert not bad, "\n".join(bad[:20])
     assert int(wv["win_nvars"][0]) >= 8
+
+
+@pytest.mark.parametrize("band,kw", [(32, {}), (96, dict(big_indel=50)), (128, dict(big_indel=80, depths=(40, 40)))])
+def test_genotype_parity_other_band_widths(band, kw):
+    """Band half-widths other than the default 64 take the generic alignment kernel (band row in LDS): narrow band
+    and the wide bands a deep panel with long indels asks for (BASELINE configs[3])."""
+    from lancet2_amd.engine import Engine
+    params = capi.default_params(min_k=25, max_k=25, band=band)
+    arrs, n, nr = synth.make_config_batch("C2", 3, first_index=91_000, **kw)
+    orc = OracleEngine(params)
+    asm = orc.assemble(arrs, n, nr)
+    var = orc.msa(arrs, n, nr, asm)
+    want = orc.genotype(arrs, n, nr, asm, var)
+    eng = Engine(params)
+    try:
+        got = eng.genotype(arrs, n, nr, asm, var)
+    finally:
+        eng.close()
+    bad = compare_geno(params, got, want, n, nr, var["win_nvars"], arrs["read_win_off"])
+    assert not bad, "\n".join(bad[:20])
+    assert (want["aln_rec"].reshape(-1, 6)[:, 0] > 0).sum() > 100
