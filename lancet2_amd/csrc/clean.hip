@@ -23,6 +23,7 @@ namespace {
 #ifdef MA_PROFILE
 __device__ unsigned long long g_cprof[16];
 __device__ unsigned long long g_cwin[4096 * 4];
+__device__ unsigned g_cmerge[4096 * 8];
 #define CCOUNT(slot) do {} while (0)
 #else
 #define CCOUNT(slot) do {} while (0)
@@ -56,8 +57,12 @@ struct Win {
   u32* sprev;
   u32* sdesc;
   u32* scratch;
+  u32* link;  // LDS: packed two-neighbour records of the chain nodes (compress_walk_par)
   i64 source, sink;
   u32 flags;  // bit2: capacity overflow
+#ifdef MA_PROFILE
+  u32 dbg_phase, dbg_merges[2], dbg_maxwalk[2], dbg_walks[2];
+#endif
 };
 
 __device__ __forceinline__ u32 kind_rev(u32 kind) { return (((kind & 1u) ^ 1u) << 1) | (((kind >> 1) & 1u) ^ 1u); }
@@ -368,6 +373,9 @@ __device__ __forceinline__ void compress_node_fast(Win& g, u32 nid, bool dflt, u
   }
   u32 const xsign = g.sign[nid];
   u32 const exp_minus = dflt ? (xsign ? 0u : 1u) : (xsign ? 1u : 0u);
+#ifdef MA_PROFILE
+  u32 dbg_nm = 0;
+#endif
   bool dirty = false;
   // The whole record of nid is fetched here, with its edges, and every load of one walk step is issued in two
   // unconditional straight-line batches (the record of the neighbour b; then the far neighbour + b's slice): a
@@ -574,11 +582,302 @@ __device__ __forceinline__ void compress_node_fast(Win& g, u32 nid, bool dflt, u
       if (fnn > 2) g.edge[static_cast<size_t>(fn) * kEdgeCap + 2] = fe2;
     }
     CCOUNT(11);
+#ifdef MA_PROFILE
+    ++dbg_nm;
+#endif
     absorbed[ob] = 2;  // absorbed by the register walk: nothing points at it any more
     dirty = true;
   }
+#ifdef MA_PROFILE
+  { int const ph = g.dbg_phase ? 1 : 0; g.dbg_merges[ph] += dbg_nm; g.dbg_maxwalk[ph] = max(g.dbg_maxwalk[ph], dbg_nm); g.dbg_walks[ph] += dbg_nm ? 1 : 0; }
+#endif
   flush();
   compress_node(g, nid, dflt, absorbed);  // re-evaluates from memory: finishes the walk or stops it
+}
+
+// Two-neighbour record of a node in one word, for following chains without touching HBM: bit 31 = the node has
+// exactly two edges (and both fit), bit 30 = sign, bits 15-29 / 0-14 = the two edges (dst << 2 | kind, dst < 8192).
+// The table is a HINT: every merge decision is re-derived from the records in memory, so a stale word only ends a
+// lane-parallel run early.
+constexpr u32 kLinkCap = 2048;
+__device__ __forceinline__ u32 pack_link(const Win& g, u32 i) {
+  if (g.nedge[i] != 2) return 0u;
+  uint2 const ev = *reinterpret_cast<const uint2*>(g.edge + static_cast<size_t>(i) * kEdgeCap);
+  if ((ev.x | ev.y) >> 15) return 0u;
+  return 0x80000000u | (static_cast<u32>(g.sign[i] != 0) << 30) | (ev.y << 15) | ev.x;
+}
+__device__ __forceinline__ u32 link_of(const Win& g, u32 i) { return i < kLinkCap ? g.link[i] : pack_link(g, i); }
+__device__ __forceinline__ void build_links(Win& g) {
+  u32 const top = g.n < kLinkCap ? g.n : kLinkCap;
+  for (u32 i = lane_id(); i < top; i += 64) g.link[i] = g.alive[i] ? pack_link(g, i) : 0u;
+  wave_sync_mem();
+}
+
+// floor(num / den) for num < 2^32 with m = floor(2^32 / den): the estimate mulhi(num, m) is q - 1 or q
+__device__ __forceinline__ u32 magic_floor_div(u32 num, u32 den, u32 m) {
+  u32 q = __umulhi(num, m);
+  u32 const r = num - q * den;
+  return q + (r >= den ? 1u : 0u);
+}
+
+// The same walk with the 64 lanes put to work.  A chain walk is a strictly sequential recurrence (every merge
+// re-links the absorber to the node after the absorbed one), but only two things in it are truly serial: following
+// the chain (one 16-byte record per hop) and the floor-rounded running averages of Node::Merge (node.cpp:93-104).
+// Everything else -- the buddy predicates, the slice trimming and linking, the bookkeeping of the absorbed node --
+// is independent per chain position once the position's incoming edge is known.  So: follow up to 64 hops reading
+// records only, hand position t to lane t, evaluate on ORIGINAL records exactly the predicates the sequential walk
+// would evaluate on its rewritten ones (the rewrite replaces the back edge mirror(b[t-1], ..) of b[t] by
+// mirror(nid, cand[t]): same direction bit, so the tests translate one to one), cut the run at the first position
+// with any failing or unusual test, and apply the surviving prefix: slices and flags lane-parallel, the averages as a
+// scalar recurrence with a per-position reciprocal prepared in parallel.  Takes only merges the sequential walk
+// takes, in the same order; whatever it leaves is re-evaluated from memory by compress_node_fast / compress_node.
+__device__ __forceinline__ void compress_walk_par(Win& g, u32 nid, bool dflt, u8* absorbed) {
+  if (static_cast<i64>(nid) == g.source || static_cast<i64>(nid) == g.sink) return;
+  u32 const xn = g.nedge[nid];
+  if (xn > 2 || xn == 0) return;
+  u32 const lane = lane_id();
+  u32 const K = static_cast<u32>(g.k), K1 = K - 1;
+  int const S = g.S;
+  u32 xe0, xe1;
+  {
+    uint2 const ev = *reinterpret_cast<const uint2*>(g.edge + static_cast<size_t>(nid) * kEdgeCap);
+    xe0 = ev.x;
+    xe1 = xn == 2 ? ev.y : 0u;
+  }
+  u32 const xsign = g.sign[nid];
+  u32 const exp_minus = dflt ? (xsign ? 0u : 1u) : (xsign ? 1u : 0u);
+  if ((xe0 >> 2) == nid || (xn == 2 && (xe1 >> 2) == nid)) return;
+  bool const d0 = ((xe0 >> 1) & 1u) == exp_minus;
+  bool const d1 = xn == 2 && ((xe1 >> 1) & 1u) == exp_minus;
+  if ((d0 ? 1 : 0) + (d1 ? 1 : 0) != 1) return;
+  u32 cand = d0 ? xe0 : xe1;
+  u32 const opp = d0 ? xe1 : xe0;  // the edge on the other side (xn == 2 only): untouched by this walk
+  u32 opp_nb = kNoNode, opp_f2 = kNoNode;
+  if (xn == 2) {
+    if (!is_potential_buddy_f2(g, nid, opp, &opp_f2)) return;
+    opp_nb = opp >> 2;
+  }
+  bool const append = ((cand >> 1) & 1u) == 0u;  // PLUS_* appends, MINUS_* prepends: constant along the walk
+  bool loaded = false;
+  u32 xlen = 0, xlabel = 0, xhead = 0, xtail = 0, X0 = 0, X1 = 0, X2 = 0, X3 = 0;
+  u32 exp_c = mirror_of(nid, cand);  // the back edge of the first chain node as memory holds it
+  while (true) {
+    // ---- follow the chain through the link table: position t -> lane t ----
+    u32 my_cand = 0, nst = 0;
+    {
+      u32 c = cand;
+#pragma nounroll
+      for (u32 t = 0; t < 64; ++t) {
+        my_cand = lane == t ? c : my_cand;
+        nst = t + 1;
+        u32 const rec = __builtin_amdgcn_readfirstlane(link_of(g, c >> 2));
+        if (!(rec >> 31)) break;
+        u32 const be0 = rec & 0x7FFFu, be1 = (rec >> 15) & 0x7FFFu, bsign = (rec >> 30) & 1u;
+        u32 const exp_src_minus = ((c & 1u) ^ 1u);  // src bit of mirror(., c)
+        bool const dir_dflt = (exp_src_minus == 0u) == (bsign != 0);
+        u32 const b_exp_minus = dir_dflt ? (bsign ? 0u : 1u) : (bsign ? 1u : 0u);
+        bool const m0 = ((be0 >> 1) & 1u) == b_exp_minus;
+        u32 const f2 = m0 ? be1 : be0;
+        c = (f2 & ~3u) | (c & 2u) | (f2 & 1u);
+      }
+    }
+    // ---- every position's tests, on its own lane ----
+    bool const act = lane < nst;
+    u32 const d = act ? (my_cand >> 2) : nid;
+    u32 const bn = g.nedge[d];
+    uint2 const bev = *reinterpret_cast<const uint2*>(g.edge + static_cast<size_t>(d) * kEdgeCap);
+    u32 const bsign = g.sign[d];
+    u32 const blen = g.len[d], blabel = g.label[d], bhead = g.head[d], btail = g.tail[d];
+    u32 const a0 = g.cnt[d * S], a1 = S > 1 ? g.cnt[d * S + 1] : 0u;
+    u32 const a2 = g.role[d * 2], a3 = g.role[d * 2 + 1];
+    bool ok = act && static_cast<i64>(d) != g.source && static_cast<i64>(d) != g.sink;
+    ok = ok && bn == 2 && (bev.x >> 2) != d && (bev.y >> 2) != d;
+    u32 const kind = my_cand & 3u;
+    u32 f2;
+    {
+      u32 const exp_src_minus = (kind & 1u) ^ 1u;
+      bool const dir_dflt = (exp_src_minus == 0u) == (bsign != 0);
+      u32 const b_exp_minus = dir_dflt ? (bsign ? 0u : 1u) : (bsign ? 1u : 0u);
+      bool const m0 = ((bev.x >> 1) & 1u) == b_exp_minus, m1 = ((bev.y >> 1) & 1u) == b_exp_minus;
+      ok = ok && (m0 != m1);
+      u32 const f = m0 ? bev.x : bev.y;
+      f2 = m0 ? bev.y : bev.x;
+      // the back edge as memory holds it: the mirror of the previous position's onward edge (of nid's for t = 0)
+      u32 const back = __shfl_up(mirror_of(d, f2), 1);
+      ok = ok && f == (lane == 0 ? exp_c : back) && (f2 >> 2) != nid;
+    }
+    u32 const fn = ok ? (f2 >> 2) : nid;
+    u32 const fnn = g.nedge[fn];
+    u32 const sl = (ok && bhead != kNoNode) ? bhead : d;
+    u32 const bdesc = g.sdesc[sl];
+    ok = ok && fnn <= 2 && fnn != 0 && fn != d;
+    ok = ok && !(xn == 2 && (d == opp_nb || fn == opp_nb || d == opp_f2 || fn == opp_f2));
+    ok = ok && bhead != kNoNode && bhead == btail;
+    u32 const src_minus = (kind >> 1) & 1u, dst_minus = kind & 1u;
+    ok = ok && dst_minus == ((f2 >> 1) & 1u);  // the rewired edge leaves nid on the same side
+    u32 const s2n = (f2 & ~3u) | (src_minus << 1) | (f2 & 1u);
+    ok = ok && !(xn == 2 && s2n == opp);
+    ok = ok && blen >= K1;
+    {  // the table's idea of this position's incoming edge must be what the previous position really leads to
+      u32 const prev_s2n = __shfl_up(s2n, 1);
+      ok = ok && (lane == 0 || my_cand == prev_s2n);
+    }
+    u32 r;
+    {
+      unsigned long long const bad = __ballot(!ok);
+      r = bad ? static_cast<u32>(__builtin_ctzll(bad)) : 64u;
+    }
+    if (r == 0) break;
+    if (!loaded) {
+      // uniform values, told so: the running averages below then run on the scalar unit
+      xlen = __builtin_amdgcn_readfirstlane(g.len[nid]);
+      xlabel = g.label[nid];
+      xhead = g.head[nid];
+      xtail = g.tail[nid];
+      X0 = __builtin_amdgcn_readfirstlane(g.cnt[nid * S]);
+      X1 = S > 1 ? __builtin_amdgcn_readfirstlane(g.cnt[nid * S + 1]) : 0u;
+      X2 = __builtin_amdgcn_readfirstlane(g.role[nid * 2]);
+      X3 = __builtin_amdgcn_readfirstlane(g.role[nid * 2 + 1]);
+    }
+    bool in = lane < r;
+    // lengths after each merge (inclusive prefix sum), reciprocals, overflow bound of the 32-bit averages
+    u32 this_len = in ? blen - K1 : 0u;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      u32 const up = __shfl_up(this_len, o);
+      if (lane >= static_cast<u32>(o)) this_len += up;
+    }
+    this_len += xlen;
+    u32 const den = this_len + blen;
+    {
+      u32 mx = in ? max(max(a0, a1), max(a2, a3)) : 0u, md = in ? den : 0u;
+      u32 lb = in ? blabel : 0u;
+      bool const wide = in && (this_len < xlen || den < this_len);
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        mx = max(mx, static_cast<u32>(__shfl_xor(mx, o)));
+        md = max(md, static_cast<u32>(__shfl_xor(md, o)));
+        lb |= static_cast<u32>(__shfl_xor(lb, o));
+      }
+      mx = max(max(mx, max(X0, X1)), max(X2, X3));
+      if (__ballot(wide) || ((static_cast<u64>(mx) * md) >> 32) != 0) break;  // 64-bit averages: sequential code
+      xlabel |= lb;
+    }
+    if (!loaded) loaded = true;
+    u32 const magic = static_cast<u32>((1ull << 32) / (den < 2 ? 2u : den));
+    // ---- the serial part: four floor-rounded running averages ----
+#pragma nounroll
+    for (u32 t = 0; t < r; ++t) {
+      u32 const tl = __builtin_amdgcn_readlane(this_len, t), ol = __builtin_amdgcn_readlane(blen, t);
+      u32 const mg = __builtin_amdgcn_readlane(magic, t), dn = tl + ol;
+      X0 = magic_floor_div(X0 * tl + __builtin_amdgcn_readlane(a0, t) * ol, dn, mg);
+      X1 = magic_floor_div(X1 * tl + __builtin_amdgcn_readlane(a1, t) * ol, dn, mg);
+      X2 = magic_floor_div(X2 * tl + __builtin_amdgcn_readlane(a2, t) * ol, dn, mg);
+      X3 = magic_floor_div(X3 * tl + __builtin_amdgcn_readlane(a3, t) * ol, dn, mg);
+    }
+    xlen = __builtin_amdgcn_readlane(this_len, r - 1);
+    // ---- slices: trim k-1 bases off the joining end, then link the survivors in walk order ----
+    {
+      u32 st = bdesc & 0xFFu, ln = (bdesc >> 8) & 0xFFu, rcb = (bdesc >> 16) & 1u;
+      if (kind == 1 || kind == 2) {
+        st = K - st - ln;
+        rcb ^= 1u;
+      }
+      bool const keep = in && ln > K1;
+      if (keep) {
+        if (append) st += K1;
+        ln -= K1;
+        g.sdesc[bhead] = st | (ln << 8) | (rcb << 16);
+      }
+      unsigned long long const kept = __ballot(keep);
+      unsigned long long const below = kept & ((1ull << lane) - 1ull), above = kept & ~((2ull << lane) - 1ull);
+      u32 const pl = below ? 63u - static_cast<u32>(__builtin_clzll(below)) : 0u;
+      u32 const nl = above ? static_cast<u32>(__builtin_ctzll(above)) : 0u;
+      u32 const ps = __shfl(bhead, static_cast<int>(pl)), ns = __shfl(bhead, static_cast<int>(nl));
+      if (keep) {
+        if (append) {
+          u32 const before = below ? ps : xtail;
+          g.snext[before] = bhead;
+          g.sprev[bhead] = before;
+          g.snext[bhead] = above ? ns : kNoNode;
+        } else {
+          u32 const after = below ? ps : xhead;
+          g.sprev[after] = bhead;
+          g.snext[bhead] = after;
+          g.sprev[bhead] = above ? ns : kNoNode;
+        }
+      }
+      if (kept) {
+        u32 const last = __builtin_amdgcn_readlane(bhead, 63u - static_cast<u32>(__builtin_clzll(kept)));
+        if (append) xtail = last; else xhead = last;
+      }
+      if (in) {
+        g.head[d] = kNoNode;
+        g.tail[d] = kNoNode;
+        absorbed[d] = 2;
+      }
+    }
+    // ---- edges: nid now points at the node after the last absorbed one (graph.cpp:600-645) ----
+    u32 const s2n_last = __builtin_amdgcn_readlane(s2n, r - 1);
+    u32 const f2_last = __builtin_amdgcn_readlane(f2, r - 1);
+    u32 const ob_last = __builtin_amdgcn_readlane(d, r - 1);
+    if (xn == 2) {
+      xe0 = opp;
+      xe1 = s2n_last;
+    } else {
+      xe0 = s2n_last;
+      xe1 = 0;
+    }
+    wave_sync_mem();
+    {
+      u32 const fl = f2_last >> 2;
+      u32 fnl = g.nedge[fl];
+      uint2 const fev = *reinterpret_cast<const uint2*>(g.edge + static_cast<size_t>(fl) * kEdgeCap);
+      u32 fe0 = fev.x, fe1 = fev.y, fe2 = 0;
+      u32 const add = mirror_of(nid, s2n_last), del = mirror_of(ob_last, f2_last);
+      bool const present = (fnl >= 1 && fe0 == add) || (fnl >= 2 && fe1 == add);
+      if (!present) {
+        if (fnl == 0) fe0 = add; else if (fnl == 1) fe1 = add; else fe2 = add;
+        fnl++;
+      }
+      if (fnl >= 1 && fe0 == del) {
+        fe0 = fe1;
+        fe1 = fe2;
+        fe2 = 0;
+        fnl--;
+      } else if (fnl >= 2 && fe1 == del) {
+        fe1 = fe2;
+        fe2 = 0;
+        fnl--;
+      } else if (fnl >= 3 && fe2 == del) {
+        fe2 = 0;
+        fnl--;
+      }
+      g.nedge[fl] = static_cast<u8>(fnl);
+      g.edge[static_cast<size_t>(fl) * kEdgeCap] = fe0;
+      g.edge[static_cast<size_t>(fl) * kEdgeCap + 1] = fe1;
+      if (fnl > 2) g.edge[static_cast<size_t>(fl) * kEdgeCap + 2] = fe2;
+      if (fl < kLinkCap)
+        g.link[fl] = (fnl == 2 && !((fe0 | fe1) >> 15)) ? (0x80000000u | (static_cast<u32>(g.sign[fl] != 0) << 30) | (fe1 << 15) | fe0) : 0u;
+    }
+    cand = s2n_last;
+    exp_c = mirror_of(nid, cand);
+    if (r < 64) break;
+  }
+  if (loaded) {
+    g.edge[static_cast<size_t>(nid) * kEdgeCap] = xe0;
+    g.edge[static_cast<size_t>(nid) * kEdgeCap + 1] = xe1;
+    g.len[nid] = xlen;
+    g.label[nid] = static_cast<u8>(xlabel);
+    g.cnt[nid * S] = X0;
+    if (S > 1) g.cnt[nid * S + 1] = X1;
+    g.role[nid * 2] = X2;
+    g.role[nid * 2 + 1] = X3;
+    g.head[nid] = xhead;
+    g.tail[nid] = xtail;
+    if (nid < kLinkCap) g.link[nid] = 0u;  // several slices now: no walk passes through it
+    wave_sync_mem();
+  }
 }
 
 // CompressGraph (graph.cpp:558-576)
@@ -586,6 +885,7 @@ __device__ __forceinline__ void compress_graph(Win& g, u32 comp) {
   u8* absorbed = reinterpret_cast<u8*>(g.scratch + g.nc);
   for (u32 i = lane_id(); i < g.n; i += 64) absorbed[i] = 0;
   wave_sync_mem();
+  if (g.S <= 2) build_links(g);
   for (u32 base = 0; base < g.n; base += 64) {
     // alive / comp do not change inside this loop; absorbed does and is re-read when a node's turn comes
     u32 const il = base + lane_id();
@@ -596,7 +896,10 @@ __device__ __forceinline__ void compress_graph(Win& g, u32 comp) {
       if (absorbed[i]) continue;
 #pragma nounroll
       for (int dir = 1; dir >= 0; --dir) {
-        if (g.S <= 2) compress_node_fast<2>(g, i, dir != 0, absorbed);
+        if (g.S <= 2) {
+          compress_walk_par(g, i, dir != 0, absorbed);
+          compress_node_fast<2>(g, i, dir != 0, absorbed);
+        }
         else compress_node_fast<kMaxSamples>(g, i, dir != 0, absorbed);
       }
     }
@@ -754,6 +1057,9 @@ __device__ __forceinline__ u32 median_sorted(const u32* v, u32 n) {  // compute_
 extern "C" void ma_debug_cwin(unsigned long long* out, int n) {
   (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_cwin), sizeof(unsigned long long) * 4 * n);
 }
+extern "C" void ma_debug_cmerge(unsigned* out, int n) {
+  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_cmerge), sizeof(unsigned) * 8 * n);
+}
 extern "C" void ma_debug_cprof(unsigned long long* out, int reset) {
   (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_cprof), sizeof(unsigned long long) * 16);
   if (reset) {
@@ -789,7 +1095,9 @@ __global__ __launch_bounds__(64, 4) void k_clean(CleanArgs A) {
     return;
   }
 
+  __shared__ u32 l_link[kLinkCap];
   Win g;
+  g.link = l_link;
   g.refb = A.b.ref_bases + A.b.ref_off[w];
   g.readb = A.b.read_bases + A.b.read_off[A.b.read_win_off[w]];
   g.ref_len = A.b.ref_off[w + 1] - A.b.ref_off[w];
@@ -817,6 +1125,9 @@ __global__ __launch_bounds__(64, 4) void k_clean(CleanArgs A) {
   g.scratch = ws.scratch + nb * 32;
   g.source = g.sink = -1;
   g.flags = 0;
+#ifdef MA_PROFILE
+  g.dbg_phase = 0; g.dbg_merges[0] = g.dbg_merges[1] = g.dbg_maxwalk[0] = g.dbg_maxwalk[1] = g.dbg_walks[0] = g.dbg_walks[1] = 0;
+#endif
   u32 const NC = ws.nc;
   u32 const K = static_cast<u32>(g.k);
   CPROF_T0();
@@ -986,6 +1297,9 @@ __global__ __launch_bounds__(64, 4) void k_clean(CleanArgs A) {
         if (nrm == 0) break;
         for (u32 x = 0; x < nrm; ++x) remove_node(g, rm[x]);
       }
+#ifdef MA_PROFILE
+      g.dbg_phase = phase;
+#endif
       compress_graph(g, comp);
       if (phase == 0) CPROF_ACC(3);
     }
@@ -1366,6 +1680,7 @@ __global__ __launch_bounds__(64, 4) void k_clean(CleanArgs A) {
   if (w < 4096) {
     g_cwin[w * 4 + 0] = __builtin_amdgcn_s_memtime() - t_begin;
     g_cwin[w * 4 + 1] = g.n;
+    if (w < 4096) { g_cmerge[w*8+0]=g.dbg_merges[0]; g_cmerge[w*8+1]=g.dbg_merges[1]; g_cmerge[w*8+2]=g.dbg_maxwalk[0]; g_cmerge[w*8+3]=g.dbg_maxwalk[1]; g_cmerge[w*8+4]=g.dbg_walks[0]; g_cmerge[w*8+5]=g.dbg_walks[1]; g_cmerge[w*8+6]=g.n; }
     g_cwin[w * 4 + 2] = dbg_rounds;
     g_cwin[w * 4 + 3] = static_cast<unsigned long long>(ncand);
   }

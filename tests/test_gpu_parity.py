@@ -514,8 +514,8 @@ def test_genotype_parity_other_band_widths(band, kw):
     assert (want["aln_rec"].reshape(-1, 6)[:, 0] > 0).sum() > 100
 
 
-@pytest.mark.parametrize("streams", [1, 2])
-def test_device_memspace_matches_host_memspace(streams):
+@pytest.mark.parametrize("streams,taps", [(1, False), (1, True), (2, True)])
+def test_device_memspace_matches_host_memspace(streams, taps):
     """MA_MEM_DEVICE (caller-owned device buffers, what bench.py times) gives the bytes of MA_MEM_HOST."""
     torch = pytest.importorskip("torch")
     from lancet2_amd.engine import Engine
@@ -523,7 +523,7 @@ def test_device_memspace_matches_host_memspace(streams):
     arrs, n, nr = synth.make_config_batch("C2", 6, first_index=95_000)
     eng = Engine(params)
     try:
-        hg, ha, hv, hq = eng.process(arrs, n, nr, debug=False)
+        hg, ha, hv, hq = eng.process(arrs, n, nr, debug=taps)
     finally:
         eng.close()
     dev = torch.device("cuda", 0)
@@ -534,7 +534,7 @@ def test_device_memspace_matches_host_memspace(streams):
         return {k: torch.zeros(int(sz) * np.dtype(dt).itemsize, dtype=torch.uint8, device=dev) for k, (dt, sz) in spec.items()}
 
     g, a, v = dev_alloc(capi.gate_out_spec(n)), dev_alloc(capi.asm_out_spec(params, n)), dev_alloc(capi.var_out_spec(params, n))
-    q = dev_alloc(capi.geno_out_spec(params, n, nr, debug=False))
+    q = dev_alloc(capi.geno_out_spec(params, n, nr, debug=taps))
     deng = Engine(params, memspace=capi.MA_MEM_DEVICE)
     try:
         deng.set_streams(streams)
@@ -544,9 +544,50 @@ def test_device_memspace_matches_host_memspace(streams):
         torch.cuda.synchronize(dev)
     finally:
         deng.close()
-    for name, host, devd in (("gate", hg, g), ("asm", ha, a), ("var", hv, v), ("geno", hq, q)):
-        for k, hv_ in host.items():
-            got = devd[k].cpu().numpy().view(hv_.dtype)
-            if name == "asm" and k in ("hap_bases", "hap_runs", "hap_stats"):
-                continue  # only the used prefix of every slot is defined; compared through the derived outputs
-            assert np.array_equal(got, hv_), f"{name}.{k}"
+    def back(spec, devd):
+        return {k: devd[k].cpu().numpy().view(np.dtype(dt)) for k, (dt, _) in spec.items()}
+
+    dg, da, dv = back(capi.gate_out_spec(n), g), back(capi.asm_out_spec(params, n), a), back(capi.var_out_spec(params, n), v)
+    dq = back(capi.geno_out_spec(params, n, nr, debug=taps), q)
+    assert np.array_equal(dg["max_approx"], hg["max_approx"])
+    # the helpers compare the defined part of every buffer (unused slots of a capacity-sized array are not written)
+    bad = compare_asm(params, da, ha, n) + compare_vars(params, dv, hv, n)
+    if taps:
+        bad += compare_geno(params, dq, hq, n, nr, hv["win_nvars"], arrs["read_win_off"])
+    assert not bad, "\n".join(bad[:10])
+    per = params.num_samples * (params.max_alts + 1) * 2
+    diff = np.nonzero(dq["allele_counts"] != hq["allele_counts"])[0]
+    assert diff.size == 0, "allele_counts differ at (window, variant, slot) " + str(
+        [(int(x) // (per * params.max_vars), int(x) // per % params.max_vars, int(x) % per, int(dq["allele_counts"][x]),
+          int(hq["allele_counts"][x])) for x in diff[:12]]) + " win_nvars " + str(hv["win_nvars"].tolist())
+    assert np.array_equal(dq["var_qual"].view(np.uint64), hq["var_qual"].view(np.uint64))
+
+
+def test_outputs_do_not_depend_on_previous_batches_or_debug_taps():
+    """One engine, batches of different shapes back to back: workspaces are reused (never cleared wholesale), so
+    anything a kernel forgets to write would surface as the previous batch's bytes.  The run without the debug taps
+    (internal alignment records, the path bench.py times) must give the counts of the run with them."""
+    from lancet2_amd.engine import Engine
+    params = capi.default_params(min_k=25, max_k=25)
+    big, nb, nrb = synth.make_config_batch("C3", 12, first_index=97_000)
+    arrs, n, nr = synth.make_config_batch("C2", 6, first_index=95_000)
+    eng = Engine(params)
+    try:
+        eng.process(big, nb, nrb, debug=False)
+        g0, a0, v0, q0 = eng.process(arrs, n, nr, debug=False)
+        eng.process(big, nb, nrb, debug=True)
+        g1, a1, v1, q1 = eng.process(arrs, n, nr, debug=True)
+    finally:
+        eng.close()
+    fresh = Engine(params)
+    try:
+        g2, a2, v2, q2 = fresh.process(arrs, n, nr, debug=True)
+    finally:
+        fresh.close()
+    for tag, a, v, q in (("no taps", a0, v0, q0), ("taps", a1, v1, q1)):
+        bad = compare_asm(params, a, a2, n) + compare_vars(params, v, v2, n)
+        assert not bad, tag + "\n" + "\n".join(bad[:10])
+        assert np.array_equal(q["allele_counts"], q2["allele_counts"]), tag
+        assert np.array_equal(q["var_qual"].view(np.uint64), q2["var_qual"].view(np.uint64)), tag
+    bad = compare_geno(params, q1, q2, n, nr, v2["win_nvars"], arrs["read_win_off"])
+    assert not bad, "\n".join(bad[:10])
