@@ -631,10 +631,10 @@ __device__ __forceinline__ u32 magic_floor_div(u32 num, u32 den, u32 m) {
 // with any failing or unusual test, and apply the surviving prefix: slices and flags lane-parallel, the averages as a
 // scalar recurrence with a per-position reciprocal prepared in parallel.  Takes only merges the sequential walk
 // takes, in the same order; whatever it leaves is re-evaluated from memory by compress_node_fast / compress_node.
-__device__ __forceinline__ void compress_walk_par(Win& g, u32 nid, bool dflt, u8* absorbed) {
-  if (static_cast<i64>(nid) == g.source || static_cast<i64>(nid) == g.sink) return;
+__device__ __forceinline__ bool compress_walk_par(Win& g, u32 nid, bool dflt, u8* absorbed) {
+  if (static_cast<i64>(nid) == g.source || static_cast<i64>(nid) == g.sink) return true;
   u32 const xn = g.nedge[nid];
-  if (xn > 2 || xn == 0) return;
+  if (xn > 2 || xn == 0) return true;
   u32 const lane = lane_id();
   u32 const K = static_cast<u32>(g.k), K1 = K - 1;
   int const S = g.S;
@@ -646,19 +646,21 @@ __device__ __forceinline__ void compress_walk_par(Win& g, u32 nid, bool dflt, u8
   }
   u32 const xsign = g.sign[nid];
   u32 const exp_minus = dflt ? (xsign ? 0u : 1u) : (xsign ? 1u : 0u);
-  if ((xe0 >> 2) == nid || (xn == 2 && (xe1 >> 2) == nid)) return;
+  if ((xe0 >> 2) == nid || (xn == 2 && (xe1 >> 2) == nid)) return true;
   bool const d0 = ((xe0 >> 1) & 1u) == exp_minus;
   bool const d1 = xn == 2 && ((xe1 >> 1) & 1u) == exp_minus;
-  if ((d0 ? 1 : 0) + (d1 ? 1 : 0) != 1) return;
+  if ((d0 ? 1 : 0) + (d1 ? 1 : 0) != 1) return true;
   u32 cand = d0 ? xe0 : xe1;
   u32 const opp = d0 ? xe1 : xe0;  // the edge on the other side (xn == 2 only): untouched by this walk
   u32 opp_nb = kNoNode, opp_f2 = kNoNode;
   if (xn == 2) {
-    if (!is_potential_buddy_f2(g, nid, opp, &opp_f2)) return;
+    if (!is_potential_buddy_f2(g, nid, opp, &opp_f2)) return true;
     opp_nb = opp >> 2;
   }
   bool const append = ((cand >> 1) & 1u) == 0u;  // PLUS_* appends, MINUS_* prepends: constant along the walk
   bool loaded = false;
+  bool settled = false;  // the walk ended on a test the generic code fails too: nothing left for it to re-evaluate
+  bool clean = true;     // this chunk's rewiring replaced exactly one edge of the node after the run
   u32 xlen = 0, xlabel = 0, xhead = 0, xtail = 0, X0 = 0, X1 = 0, X2 = 0, X3 = 0;
   u32 exp_c = mirror_of(nid, cand);  // the back edge of the first chain node as memory holds it
   while (true) {
@@ -710,6 +712,7 @@ __device__ __forceinline__ void compress_walk_par(Win& g, u32 nid, bool dflt, u8
     u32 const fnn = g.nedge[fn];
     u32 const sl = (ok && bhead != kNoNode) ? bhead : d;
     u32 const bdesc = g.sdesc[sl];
+    bool const neg = act && (!ok || fnn > 2);  // so far only tests of the generic predicates themselves
     ok = ok && fnn <= 2 && fnn != 0 && fn != d;
     ok = ok && !(xn == 2 && (d == opp_nb || fn == opp_nb || d == opp_f2 || fn == opp_f2));
     ok = ok && bhead != kNoNode && bhead == btail;
@@ -718,16 +721,26 @@ __device__ __forceinline__ void compress_walk_par(Win& g, u32 nid, bool dflt, u8
     u32 const s2n = (f2 & ~3u) | (src_minus << 1) | (f2 & 1u);
     ok = ok && !(xn == 2 && s2n == opp);
     ok = ok && blen >= K1;
+    bool negv;
     {  // the table's idea of this position's incoming edge must be what the previous position really leads to
       u32 const prev_s2n = __shfl_up(s2n, 1);
-      ok = ok && (lane == 0 || my_cand == prev_s2n);
+      bool const chained = lane == 0 || my_cand == prev_s2n;
+      ok = ok && chained;
+      negv = neg && chained;
     }
     u32 r;
     {
       unsigned long long const bad = __ballot(!ok);
       r = bad ? static_cast<u32>(__builtin_ctzll(bad)) : 64u;
     }
-    if (r == 0) break;
+    // Position r failed.  If it failed a generic predicate, evaluated on what memory holds for it now (position 0:
+    // as read; later positions: as read, when the rewiring below swapped exactly one edge, which the back-edge
+    // translation already accounts for), the generic code would stop here as well.
+    bool const neg_r = r < 64 && __builtin_amdgcn_readlane(static_cast<u32>(negv), r & 63u) != 0;
+    if (r == 0) {
+      settled = neg_r;
+      break;
+    }
     if (!loaded) {
       // uniform values, told so: the running averages below then run on the scalar unit
       xlen = __builtin_amdgcn_readfirstlane(g.len[nid]);
@@ -836,6 +849,7 @@ __device__ __forceinline__ void compress_walk_par(Win& g, u32 nid, bool dflt, u8
       u32 fe0 = fev.x, fe1 = fev.y, fe2 = 0;
       u32 const add = mirror_of(nid, s2n_last), del = mirror_of(ob_last, f2_last);
       bool const present = (fnl >= 1 && fe0 == add) || (fnl >= 2 && fe1 == add);
+      u32 const fnl_before = fnl;
       if (!present) {
         if (fnl == 0) fe0 = add; else if (fnl == 1) fe1 = add; else fe2 = add;
         fnl++;
@@ -853,6 +867,7 @@ __device__ __forceinline__ void compress_walk_par(Win& g, u32 nid, bool dflt, u8
         fe2 = 0;
         fnl--;
       }
+      clean = !present && fnl == fnl_before;
       g.nedge[fl] = static_cast<u8>(fnl);
       g.edge[static_cast<size_t>(fl) * kEdgeCap] = fe0;
       g.edge[static_cast<size_t>(fl) * kEdgeCap + 1] = fe1;
@@ -862,7 +877,10 @@ __device__ __forceinline__ void compress_walk_par(Win& g, u32 nid, bool dflt, u8
     }
     cand = s2n_last;
     exp_c = mirror_of(nid, cand);
-    if (r < 64) break;
+    if (r < 64) {
+      settled = neg_r && clean;
+      break;
+    }
   }
   if (loaded) {
     g.edge[static_cast<size_t>(nid) * kEdgeCap] = xe0;
@@ -878,6 +896,7 @@ __device__ __forceinline__ void compress_walk_par(Win& g, u32 nid, bool dflt, u8
     if (nid < kLinkCap) g.link[nid] = 0u;  // several slices now: no walk passes through it
     wave_sync_mem();
   }
+  return settled;
 }
 
 // CompressGraph (graph.cpp:558-576)
@@ -897,8 +916,7 @@ __device__ __forceinline__ void compress_graph(Win& g, u32 comp) {
 #pragma nounroll
       for (int dir = 1; dir >= 0; --dir) {
         if (g.S <= 2) {
-          compress_walk_par(g, i, dir != 0, absorbed);
-          compress_node_fast<2>(g, i, dir != 0, absorbed);
+          if (!compress_walk_par(g, i, dir != 0, absorbed)) compress_node_fast<2>(g, i, dir != 0, absorbed);
         }
         else compress_node_fast<kMaxSamples>(g, i, dir != 0, absorbed);
       }
