@@ -899,6 +899,26 @@ __device__ __forceinline__ bool compress_walk_par(Win& g, u32 nid, bool dflt, u8
   return settled;
 }
 
+// Exact negative filter for CompressNode, cheap enough to run on 64 nodes at once: find_compressible_edge(i, .) can
+// only succeed if every neighbour of i passes is_potential_buddy, and that needs the neighbour to have exactly two
+// edges, one of them back to i, the other to a node with at most two edges.  False means "no direction of i is
+// compressible on what memory holds now"; true means "ask the real predicates".
+__device__ __forceinline__ bool may_compress(const Win& g, u32 i) {
+  if (static_cast<i64>(i) == g.source || static_cast<i64>(i) == g.sink) return false;
+  u32 const xn = g.nedge[i];
+  if (xn == 0 || xn > 2) return false;
+  uint2 const ev = *reinterpret_cast<const uint2*>(g.edge + static_cast<size_t>(i) * kEdgeCap);
+  for (u32 x = 0; x < xn; ++x) {
+    u32 const nb = (x == 0 ? ev.x : ev.y) >> 2;
+    if (g.nedge[nb] != 2) return false;
+    uint2 const ne = *reinterpret_cast<const uint2*>(g.edge + static_cast<size_t>(nb) * kEdgeCap);
+    bool const via0 = (ne.x >> 2) == i && g.nedge[ne.y >> 2] <= 2;
+    bool const via1 = (ne.y >> 2) == i && g.nedge[ne.x >> 2] <= 2;
+    if (!via0 && !via1) return false;
+  }
+  return true;
+}
+
 // CompressGraph (graph.cpp:558-576)
 __device__ __forceinline__ void compress_graph(Win& g, u32 comp) {
   u8* absorbed = reinterpret_cast<u8*>(g.scratch + g.nc);
@@ -910,9 +930,14 @@ __device__ __forceinline__ void compress_graph(Win& g, u32 comp) {
     u32 const il = base + lane_id();
     unsigned long long todo = __ballot(il < g.n && g.alive[il] && g.comp[il] == comp && !absorbed[il]);
     while (todo) {
-      u32 const i = base + static_cast<u32>(__builtin_ctzll(todo));
-      todo &= todo - 1;
-      if (absorbed[i]) continue;
+      // Nodes that cannot compress leave the graph as it is, so one lane-parallel look at the rest of the block
+      // stays valid up to the first node that may; after that node has had its turn the rest is looked at again.
+      bool const pre = ((todo >> lane_id()) & 1ull) && !absorbed[il] && may_compress(g, il);
+      unsigned long long const can = __ballot(pre) & todo;
+      if (!can) break;
+      u32 const first = static_cast<u32>(__builtin_ctzll(can));
+      u32 const i = base + first;
+      todo &= ~((2ull << first) - 1ull);
 #pragma nounroll
       for (int dir = 1; dir >= 0; --dir) {
         if (g.S <= 2) {
