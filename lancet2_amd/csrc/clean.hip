@@ -24,9 +24,14 @@ namespace {
 __device__ unsigned long long g_cprof[16];
 __device__ unsigned long long g_cwin[4096 * 4];
 __device__ unsigned g_cmerge[4096 * 8];
+__device__ unsigned long long g_ctime[4096 * 6];
+#define TSTAMP(v) unsigned long long v = __builtin_amdgcn_s_memtime()
+#define TACC(slot, a, b) g.dbg_t[slot] += (b) - (a)
 #define CCOUNT(slot) do {} while (0)
 #else
 #define CCOUNT(slot) do {} while (0)
+#define TSTAMP(v) do {} while (0)
+#define TACC(slot, a, b) do {} while (0)
 #endif
 constexpr int kMaxWalks = 64;
 constexpr u32 kNoParent = 0xFFFFFFFFu;
@@ -62,6 +67,7 @@ struct Win {
   u32 flags;  // bit2: capacity overflow
 #ifdef MA_PROFILE
   u32 dbg_phase, dbg_merges[2], dbg_maxwalk[2], dbg_walks[2];
+  unsigned long long dbg_t[6];
 #endif
 };
 
@@ -595,21 +601,28 @@ __device__ __forceinline__ void compress_node_fast(Win& g, u32 nid, bool dflt, u
   compress_node(g, nid, dflt, absorbed);  // re-evaluates from memory: finishes the walk or stops it
 }
 
-// Two-neighbour record of a node in one word, for following chains without touching HBM: bit 31 = the node has
-// exactly two edges (and both fit), bit 30 = sign, bits 15-29 / 0-14 = the two edges (dst << 2 | kind, dst < 8192).
-// The table is a HINT: every merge decision is re-derived from the records in memory, so a stale word only ends a
-// lane-parallel run early.
-constexpr u32 kLinkCap = 2048;
-__device__ __forceinline__ u32 pack_link(const Win& g, u32 i) {
-  if (g.nedge[i] != 2) return 0u;
-  uint2 const ev = *reinterpret_cast<const uint2*>(g.edge + static_cast<size_t>(i) * kEdgeCap);
-  if ((ev.x | ev.y) >> 15) return 0u;
-  return 0x80000000u | (static_cast<u32>(g.sign[i] != 0) << 30) | (ev.y << 15) | ev.x;
+// Chain-following table in LDS, so that a walk does not touch HBM to find its way.  A walk arrives at node b by an
+// edge whose dst-side strand bit is j and leaves by the edge of b whose src-side bit is j (the back edge has !j:
+// Kmer sign cancels out of FindEdgesInDirection here).  State = b << 1 | j; next[state] = state after one hop, or
+// kNoLink when b does not have exactly two edges.  The table is a HINT: every merge decision is re-derived from the
+// records in memory, so a stale entry only ends a lane-parallel run early.
+constexpr u32 kLinkCap = 2048;  // nodes covered (2 x u16 each = the kernel's 8 KB of LDS)
+constexpr u32 kNoLink = 0xFFFFu;
+__device__ __forceinline__ void set_links(Win& g, u32 i, u32 n_edges, u32 e0, u32 e1) {
+  if (i >= kLinkCap) return;
+  u16* next = reinterpret_cast<u16*>(g.link);
+#pragma unroll
+  for (u32 j = 0; j < 2; ++j) {
+    u32 const on = (((e0 >> 1) & 1u) != j) ? e1 : e0;
+    next[i * 2 + j] = static_cast<u16>((n_edges == 2 && (on >> 2) < 0x7FFFu) ? (((on >> 2) << 1) | (on & 1u)) : kNoLink);
+  }
 }
-__device__ __forceinline__ u32 link_of(const Win& g, u32 i) { return i < kLinkCap ? g.link[i] : pack_link(g, i); }
 __device__ __forceinline__ void build_links(Win& g) {
   u32 const top = g.n < kLinkCap ? g.n : kLinkCap;
-  for (u32 i = lane_id(); i < top; i += 64) g.link[i] = g.alive[i] ? pack_link(g, i) : 0u;
+  for (u32 i = lane_id(); i < top; i += 64) {
+    uint2 const ev = *reinterpret_cast<const uint2*>(g.edge + static_cast<size_t>(i) * kEdgeCap);
+    set_links(g, i, g.alive[i] ? g.nedge[i] : 0u, ev.x, ev.y);
+  }
   wave_sync_mem();
 }
 
@@ -664,25 +677,26 @@ __device__ __forceinline__ bool compress_walk_par(Win& g, u32 nid, bool dflt, u8
   u32 xlen = 0, xlabel = 0, xhead = 0, xtail = 0, X0 = 0, X1 = 0, X2 = 0, X3 = 0;
   u32 exp_c = mirror_of(nid, cand);  // the back edge of the first chain node as memory holds it
   while (true) {
+    TSTAMP(ts0);
     // ---- follow the chain through the link table: position t -> lane t ----
-    u32 my_cand = 0, nst = 0;
+    u32 my_cand;
+    u32 nst = 0;
     {
-      u32 c = cand;
+      const u16* next = reinterpret_cast<const u16*>(g.link);
+      u32 st = ((cand >> 2) << 1) | (cand & 1u), my_st = 0;
 #pragma nounroll
       for (u32 t = 0; t < 64; ++t) {
-        my_cand = lane == t ? c : my_cand;
+        my_st = lane == t ? st : my_st;
         nst = t + 1;
-        u32 const rec = __builtin_amdgcn_readfirstlane(link_of(g, c >> 2));
-        if (!(rec >> 31)) break;
-        u32 const be0 = rec & 0x7FFFu, be1 = (rec >> 15) & 0x7FFFu, bsign = (rec >> 30) & 1u;
-        u32 const exp_src_minus = ((c & 1u) ^ 1u);  // src bit of mirror(., c)
-        bool const dir_dflt = (exp_src_minus == 0u) == (bsign != 0);
-        u32 const b_exp_minus = dir_dflt ? (bsign ? 0u : 1u) : (bsign ? 1u : 0u);
-        bool const m0 = ((be0 >> 1) & 1u) == b_exp_minus;
-        u32 const f2 = m0 ? be1 : be0;
-        c = (f2 & ~3u) | (c & 2u) | (f2 & 1u);
+        if ((st >> 1) >= kLinkCap) break;
+        u32 const nx = __builtin_amdgcn_readfirstlane(static_cast<u32>(next[st]));
+        if (nx == kNoLink) break;
+        st = nx;
       }
+      my_cand = ((my_st >> 1) << 2) | (cand & 2u) | (my_st & 1u);
     }
+    TSTAMP(ts1);
+    TACC(1, ts0, ts1);
     // ---- every position's tests, on its own lane ----
     bool const act = lane < nst;
     u32 const d = act ? (my_cand >> 2) : nid;
@@ -736,6 +750,8 @@ __device__ __forceinline__ bool compress_walk_par(Win& g, u32 nid, bool dflt, u8
     // Position r failed.  If it failed a generic predicate, evaluated on what memory holds for it now (position 0:
     // as read; later positions: as read, when the rewiring below swapped exactly one edge, which the back-edge
     // translation already accounts for), the generic code would stop here as well.
+    TSTAMP(ts2);
+    TACC(2, ts1, ts2);
     bool const neg_r = r < 64 && __builtin_amdgcn_readlane(static_cast<u32>(negv), r & 63u) != 0;
     if (r == 0) {
       settled = neg_r;
@@ -872,11 +888,12 @@ __device__ __forceinline__ bool compress_walk_par(Win& g, u32 nid, bool dflt, u8
       g.edge[static_cast<size_t>(fl) * kEdgeCap] = fe0;
       g.edge[static_cast<size_t>(fl) * kEdgeCap + 1] = fe1;
       if (fnl > 2) g.edge[static_cast<size_t>(fl) * kEdgeCap + 2] = fe2;
-      if (fl < kLinkCap)
-        g.link[fl] = (fnl == 2 && !((fe0 | fe1) >> 15)) ? (0x80000000u | (static_cast<u32>(g.sign[fl] != 0) << 30) | (fe1 << 15) | fe0) : 0u;
+      set_links(g, fl, fnl, fe0, fe1);
     }
     cand = s2n_last;
     exp_c = mirror_of(nid, cand);
+    TSTAMP(ts3);
+    TACC(3, ts2, ts3);
     if (r < 64) {
       settled = neg_r && clean;
       break;
@@ -893,7 +910,7 @@ __device__ __forceinline__ bool compress_walk_par(Win& g, u32 nid, bool dflt, u8
     g.role[nid * 2 + 1] = X3;
     g.head[nid] = xhead;
     g.tail[nid] = xtail;
-    if (nid < kLinkCap) g.link[nid] = 0u;  // several slices now: no walk passes through it
+    set_links(g, nid, 0u, 0u, 0u);  // several slices now: no lane-parallel walk passes through it
     wave_sync_mem();
   }
   return settled;
@@ -921,10 +938,13 @@ __device__ __forceinline__ bool may_compress(const Win& g, u32 i) {
 
 // CompressGraph (graph.cpp:558-576)
 __device__ __forceinline__ void compress_graph(Win& g, u32 comp) {
+  TSTAMP(tg0);
   u8* absorbed = reinterpret_cast<u8*>(g.scratch + g.nc);
   for (u32 i = lane_id(); i < g.n; i += 64) absorbed[i] = 0;
   wave_sync_mem();
   if (g.S <= 2) build_links(g);
+  TSTAMP(tg2);
+  TACC(5, tg0, tg2);
   for (u32 base = 0; base < g.n; base += 64) {
     // alive / comp do not change inside this loop; absorbed does and is re-read when a node's turn comes
     u32 const il = base + lane_id();
@@ -932,8 +952,11 @@ __device__ __forceinline__ void compress_graph(Win& g, u32 comp) {
     while (todo) {
       // Nodes that cannot compress leave the graph as it is, so one lane-parallel look at the rest of the block
       // stays valid up to the first node that may; after that node has had its turn the rest is looked at again.
+      TSTAMP(tf0);
       bool const pre = ((todo >> lane_id()) & 1ull) && !absorbed[il] && may_compress(g, il);
       unsigned long long const can = __ballot(pre) & todo;
+      TSTAMP(tf1);
+      TACC(0, tf0, tf1);
       if (!can) break;
       u32 const first = static_cast<u32>(__builtin_ctzll(can));
       u32 const i = base + first;
@@ -963,6 +986,8 @@ __device__ __forceinline__ void compress_graph(Win& g, u32 comp) {
   if (__ballot(any_generic))
     for (u32 i = 0; i < g.n; ++i)
       if (absorbed[i] == 1) remove_node(g, i);
+  TSTAMP(tg1);
+  TACC(4, tg0, tg1);
 }
 
 // RemoveTips (graph.cpp:801-840): one round of tip collection, in index order; the caller removes them and
@@ -1100,6 +1125,9 @@ __device__ __forceinline__ u32 median_sorted(const u32* v, u32 n) {  // compute_
 extern "C" void ma_debug_cwin(unsigned long long* out, int n) {
   (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_cwin), sizeof(unsigned long long) * 4 * n);
 }
+extern "C" void ma_debug_ctime(unsigned long long* out, int n) {
+  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ctime), sizeof(unsigned long long) * 6 * n);
+}
 extern "C" void ma_debug_cmerge(unsigned* out, int n) {
   (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_cmerge), sizeof(unsigned) * 8 * n);
 }
@@ -1114,6 +1142,59 @@ extern "C" void ma_debug_cprof(unsigned long long* out, int reset) {
 #define CPROF_T0() do {} while (0)
 #define CPROF_ACC(slot) do {} while (0)
 #endif
+
+// MarkConnectedComponents (graph.cpp:392-463), lane-parallel; returns the number of components.  `lab` is working
+// storage for n words: the caller passes LDS when the graph fits (the pointer-jumping loads are dependent gathers),
+// the window's scratch otherwise.
+__device__ __forceinline__ u32 label_components(Win& g, u32* lab, u32* cid, u32 lane) {
+  u32 ncomp_all = 0;
+  for (u32 i = lane; i < g.n; i += 64) lab[i] = i;
+  wave_sync_mem();
+  // FastSV-style hooking (Zhang, Azad, Hu 2020): lab[] is a forest of pointers towards smaller indices;
+  // every edge hooks the parent of one end (and the end itself) onto the grandparent of the other, then
+  // every node shortcuts to its grandparent.  At the fixed point every tree is a star rooted at the
+  // smallest index of its component.
+  while (true) {
+    bool changed = false;
+    for (u32 i = lane; i < g.n; i += 64) {
+      u32 const pu = lab[i];
+      u32 const gu = lab[pu];
+      u32 const ne = g.nedge[i];
+      u32 best = gu;
+      for (u32 x = 0; x < ne; ++x) {
+        u32 const v = g.edge[i * kEdgeCap + x] >> 2;
+        best = min(best, lab[lab[v]]);
+      }
+      if (best < gu) {
+        atomicMin(&lab[pu], best);
+        atomicMin(&lab[i], best);
+        changed = true;
+      }
+    }
+    wave_sync_mem();
+    for (u32 i = lane; i < g.n; i += 64) {
+      u32 const pu = lab[i];
+      u32 const gu = lab[pu];
+      if (gu < pu) {
+        lab[i] = gu;
+        changed = true;
+      }
+    }
+    wave_sync_mem();
+    if (!__ballot(changed)) break;
+  }
+  for (u32 base = 0; base < g.n; base += 64) {
+    u32 const i = base + lane;
+    bool const root = i < g.n && lab[i] == i;
+    unsigned long long const m = __ballot(root);
+    if (root) cid[i] = ncomp_all + 1 + static_cast<u32>(__popcll(m & ((1ull << lane) - 1ull)));
+    ncomp_all += static_cast<u32>(__popcll(m));
+  }
+  wave_sync_mem();
+  for (u32 i = lane; i < g.n; i += 64) g.comp[i] = cid[lab[i]];
+  wave_sync_mem();
+  return ncomp_all;
+}
 
 struct CleanArgs {
   DBatch b;
@@ -1169,6 +1250,7 @@ __global__ __launch_bounds__(64, 4) void k_clean(CleanArgs A) {
   g.source = g.sink = -1;
   g.flags = 0;
 #ifdef MA_PROFILE
+  for (int q = 0; q < 6; ++q) g.dbg_t[q] = 0;
   g.dbg_phase = 0; g.dbg_merges[0] = g.dbg_merges[1] = g.dbg_maxwalk[0] = g.dbg_maxwalk[1] = g.dbg_walks[0] = g.dbg_walks[1] = 0;
 #endif
   u32 const NC = ws.nc;
@@ -1196,62 +1278,8 @@ __global__ __launch_bounds__(64, 4) void k_clean(CleanArgs A) {
   // carries the smallest node index it knows of in its component (min over neighbours + pointer jumping
   // until nothing changes: O(log n) rounds on the chains of a k-mer graph), then the roots are numbered
   // in index order.
-  u32 ncomp_all = 0;
-  {
-    u32* lab = g.scratch;          // [n] smallest known node index of the component
-    u32* cid = g.scratch + NC;     // [n] component id of a root
-    for (u32 i = lane; i < g.n; i += 64) lab[i] = i;
-    wave_sync_mem();
-    // FastSV-style hooking (Zhang, Azad, Hu 2020): lab[] is a forest of pointers towards smaller indices;
-    // every edge hooks the parent of one end (and the end itself) onto the grandparent of the other, then
-    // every node shortcuts to its grandparent.  At the fixed point every tree is a star rooted at the
-    // smallest index of its component.
-    u32 rounds = 0;
-    while (true) {
-      ++rounds;
-      bool changed = false;
-      for (u32 i = lane; i < g.n; i += 64) {
-        u32 const pu = lab[i];
-        u32 const gu = lab[pu];
-        u32 const ne = g.nedge[i];
-        u32 best = gu;
-        for (u32 x = 0; x < ne; ++x) {
-          u32 const v = g.edge[i * kEdgeCap + x] >> 2;
-          best = min(best, lab[lab[v]]);
-        }
-        if (best < gu) {
-          atomicMin(&lab[pu], best);
-          atomicMin(&lab[i], best);
-          changed = true;
-        }
-      }
-      wave_sync_mem();
-      for (u32 i = lane; i < g.n; i += 64) {
-        u32 const pu = lab[i];
-        u32 const gu = lab[pu];
-        if (gu < pu) {
-          lab[i] = gu;
-          changed = true;
-        }
-      }
-      wave_sync_mem();
-      if (!__ballot(changed)) break;
-    }
-    for (u32 base = 0; base < g.n; base += 64) {
-      u32 const i = base + lane;
-      bool const root = i < g.n && lab[i] == i;
-      unsigned long long const m = __ballot(root);
-      if (root) cid[i] = ncomp_all + 1 + static_cast<u32>(__popcll(m & ((1ull << lane) - 1ull)));
-      ncomp_all += static_cast<u32>(__popcll(m));
-    }
-    wave_sync_mem();
-    for (u32 i = lane; i < g.n; i += 64) g.comp[i] = cid[lab[i]];
-    wave_sync_mem();
-#ifdef MA_PROFILE
-    dbg_rounds = rounds;
-#endif
-    (void)rounds;
-  }
+  u32 const ncomp_all = g.n <= kLinkCap ? label_components(g, l_link, g.scratch + NC, lane)
+                                        : label_components(g, g.scratch, g.scratch + NC, lane);
   CPROF_ACC(1);
   // component sizes + anchors in one pass (FindSource / FindSink, graph.cpp:469-509): components are
   // disjoint and pruning one never touches another, so the candidates can be resolved up front.
@@ -1723,6 +1751,7 @@ __global__ __launch_bounds__(64, 4) void k_clean(CleanArgs A) {
   if (w < 4096) {
     g_cwin[w * 4 + 0] = __builtin_amdgcn_s_memtime() - t_begin;
     g_cwin[w * 4 + 1] = g.n;
+    if (w < 4096) for (int q = 0; q < 6; ++q) g_ctime[w * 6 + q] = g.dbg_t[q];
     if (w < 4096) { g_cmerge[w*8+0]=g.dbg_merges[0]; g_cmerge[w*8+1]=g.dbg_merges[1]; g_cmerge[w*8+2]=g.dbg_maxwalk[0]; g_cmerge[w*8+3]=g.dbg_maxwalk[1]; g_cmerge[w*8+4]=g.dbg_walks[0]; g_cmerge[w*8+5]=g.dbg_walks[1]; g_cmerge[w*8+6]=g.n; }
     g_cwin[w * 4 + 2] = dbg_rounds;
     g_cwin[w * 4 + 3] = static_cast<unsigned long long>(ncand);

@@ -21,4 +21,9 @@ names = ["merges_ph0", "merges_later", "maxwalk_ph0", "maxwalk_later", "walks_ph
 for j, nm in enumerate(names):
     print("%-14s mean %8.1f  median %6d  max %6d" % (nm, m[:, j].mean(), np.median(m[:, j]), m[:, j].max()))
 print(m[:8, :7])
+tb = (C.c_ulonglong * (6 * 64))()
+eng.lib.ma_debug_ctime(tb, 64)
+t = np.array(list(tb), dtype=np.int64).reshape(64, 6)
+for j, nm in enumerate(['filter', 'hop', 'validate', 'apply', 'compress_graph_total', 'init+links']):
+    print('%-22s mean ticks %10.0f' % (nm, t[:, j].mean()))
 eng.close()
