@@ -683,12 +683,13 @@ __device__ __forceinline__ bool compress_walk_par(Win& g, u32 nid, bool dflt, u8
     u32 nst = 0;
     {
       const u16* next = reinterpret_cast<const u16*>(g.link);
-      u32 st = ((cand >> 2) << 1) | (cand & 1u), my_st = 0;
+      // everything but the capture runs on the scalar unit: one LDS read per hop
+      u32 st = __builtin_amdgcn_readfirstlane(((cand >> 2) << 1) | (cand & 1u)), my_st = 0;
 #pragma nounroll
-      for (u32 t = 0; t < 64; ++t) {
-        my_st = lane == t ? st : my_st;
-        nst = t + 1;
-        if ((st >> 1) >= kLinkCap) break;
+      while (true) {
+        my_st = lane == nst ? st : my_st;
+        ++nst;
+        if (nst == 64 || (st >> 1) >= kLinkCap) break;
         u32 const nx = __builtin_amdgcn_readfirstlane(static_cast<u32>(next[st]));
         if (nx == kNoLink) break;
         st = nx;
@@ -795,14 +796,25 @@ __device__ __forceinline__ bool compress_walk_par(Win& g, u32 nid, bool dflt, u8
     if (!loaded) loaded = true;
     u32 const magic = static_cast<u32>((1ull << 32) / (den < 2 ? 2u : den));
     // ---- the serial part: four floor-rounded running averages ----
+    {
+      // wave-uniform by construction; said explicitly so that the loop is selected onto the scalar unit (the vector
+      // 32-bit multiplies run at quarter rate and this loop is the serial part of the walk)
+      u32 s0 = __builtin_amdgcn_readfirstlane(X0), s1 = __builtin_amdgcn_readfirstlane(X1);
+      u32 s2 = __builtin_amdgcn_readfirstlane(X2), s3 = __builtin_amdgcn_readfirstlane(X3);
+      u32 const rr = __builtin_amdgcn_readfirstlane(r);
 #pragma nounroll
-    for (u32 t = 0; t < r; ++t) {
-      u32 const tl = __builtin_amdgcn_readlane(this_len, t), ol = __builtin_amdgcn_readlane(blen, t);
-      u32 const mg = __builtin_amdgcn_readlane(magic, t), dn = tl + ol;
-      X0 = magic_floor_div(X0 * tl + __builtin_amdgcn_readlane(a0, t) * ol, dn, mg);
-      X1 = magic_floor_div(X1 * tl + __builtin_amdgcn_readlane(a1, t) * ol, dn, mg);
-      X2 = magic_floor_div(X2 * tl + __builtin_amdgcn_readlane(a2, t) * ol, dn, mg);
-      X3 = magic_floor_div(X3 * tl + __builtin_amdgcn_readlane(a3, t) * ol, dn, mg);
+      for (u32 t = 0; t < rr; ++t) {
+        u32 const tl = __builtin_amdgcn_readlane(this_len, t), ol = __builtin_amdgcn_readlane(blen, t);
+        u32 const mg = __builtin_amdgcn_readlane(magic, t), dn = tl + ol;
+        s0 = magic_floor_div(s0 * tl + __builtin_amdgcn_readlane(a0, t) * ol, dn, mg);
+        s1 = magic_floor_div(s1 * tl + __builtin_amdgcn_readlane(a1, t) * ol, dn, mg);
+        s2 = magic_floor_div(s2 * tl + __builtin_amdgcn_readlane(a2, t) * ol, dn, mg);
+        s3 = magic_floor_div(s3 * tl + __builtin_amdgcn_readlane(a3, t) * ol, dn, mg);
+      }
+      X0 = s0;
+      X1 = s1;
+      X2 = s2;
+      X3 = s3;
     }
     xlen = __builtin_amdgcn_readlane(this_len, r - 1);
     // ---- slices: trim k-1 bases off the joining end, then link the survivors in walk order ----
@@ -857,7 +869,6 @@ __device__ __forceinline__ bool compress_walk_par(Win& g, u32 nid, bool dflt, u8
       xe0 = s2n_last;
       xe1 = 0;
     }
-    wave_sync_mem();
     {
       u32 const fl = f2_last >> 2;
       u32 fnl = g.nedge[fl];
@@ -896,8 +907,9 @@ __device__ __forceinline__ bool compress_walk_par(Win& g, u32 nid, bool dflt, u8
     TACC(3, ts2, ts3);
     if (r < 64) {
       settled = neg_r && clean;
-      break;
+      break;  // the exit below fences
     }
+    wave_sync_mem();  // the next chunk links its first surviving slice behind this chunk's last one
   }
   if (loaded) {
     g.edge[static_cast<size_t>(nid) * kEdgeCap] = xe0;
@@ -1301,14 +1313,36 @@ __global__ __launch_bounds__(64, 4) void k_clean(CleanArgs A) {
       csize[c] = 0;
     }
     wave_sync_mem();
-    for (u32 i = lane; i < g.n; i += 64) atomicAdd(&csize[g.comp[i]], 1u);
-    for (u32 r = lane; r < n_refk; r += 64) {
-      u32 const nd = refn[r];
-      if (nd == kNoNode) continue;
-      if (nd_total(g, nd) < g.min_anchor_cov) continue;
-      u32 const c = g.comp[nd];
-      atomicMin(&first_off[c], r);
-      atomicMax(&last_off[c], r);
+    // neighbouring indices mostly share a component: one atomic per distinct component of the 64, issued by the
+    // group's first lane, instead of 64 atomics queueing on one address
+    for (u32 base = 0; base < g.n; base += 64) {
+      u32 const i = base + lane;
+      u32 const c = i < g.n ? g.comp[i] : 0u;
+      unsigned long long rem = __ballot(i < g.n);
+      while (rem) {
+        u32 const l0 = static_cast<u32>(__builtin_ctzll(rem));
+        u32 const c0 = __builtin_amdgcn_readlane(c, l0);
+        unsigned long long const m = __ballot(i < g.n && c == c0) & rem;
+        if (lane == l0) atomicAdd(&csize[c0], static_cast<u32>(__popcll(m)));
+        rem &= ~m;
+      }
+    }
+    for (u32 base = 0; base < n_refk; base += 64) {
+      u32 const r = base + lane;
+      u32 const nd = r < n_refk ? refn[r] : kNoNode;
+      bool const valid = nd != kNoNode && nd_total(g, nd) >= g.min_anchor_cov;
+      u32 const c = valid ? g.comp[nd] : 0u;
+      unsigned long long rem = __ballot(valid);
+      while (rem) {
+        u32 const l0 = static_cast<u32>(__builtin_ctzll(rem));
+        u32 const c0 = __builtin_amdgcn_readlane(c, l0);
+        unsigned long long const m = __ballot(valid && c == c0) & rem;
+        if (lane == l0) {  // offsets grow with the lane: the group's extremes are its first and last lane
+          atomicMin(&first_off[c0], base + l0);
+          atomicMax(&last_off[c0], base + 63u - static_cast<u32>(__builtin_clzll(m)));
+        }
+        rem &= ~m;
+      }
     }
     wave_sync_mem();
     for (u32 c = 1; c <= ncomp_all; ++c) {
