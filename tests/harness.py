@@ -260,3 +260,56 @@ def handmade_annotation_case(p, cases):
                 var["var_hap_allele"][vi * MH + h] = ai + 1
                 var["var_hap_start"][vi * MH + h] = st
     return asm, var
+
+
+
+class DeviceArena:
+    """hipMalloc / hipMemcpy through ctypes on the HIP runtime the product library is using (no torch import: the
+    first import of torch on a cold box takes minutes).  Test infrastructure for the MA_MEM_DEVICE entry points."""
+
+    def __init__(self):
+        import ctypes as C
+        import importlib.util
+        import os
+        path = "libamdhip64.so"
+        spec = importlib.util.find_spec("torch")
+        if spec is not None and spec.submodule_search_locations:
+            cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+            if os.path.exists(cand):
+                path = cand  # the runtime capi.load_cdll() made global
+        self.C = C
+        self.hip = C.CDLL(path, mode=C.RTLD_GLOBAL)
+        self.hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+        self.hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        self.hip.hipMemset.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
+        self.hip.hipFree.argtypes = [C.c_void_p]
+        self.ptrs = []
+
+    def _check(self, rc, what):
+        assert rc == 0, f"{what} failed with hipError {rc}"
+
+    def alloc(self, nbytes):
+        p = self.C.c_void_p()
+        self._check(self.hip.hipMalloc(self.C.byref(p), max(int(nbytes), 16)), "hipMalloc")
+        self._check(self.hip.hipMemset(p, 0, max(int(nbytes), 16)), "hipMemset")
+        self.ptrs.append(p)
+        return int(p.value)
+
+    def upload(self, arr):
+        arr = np.ascontiguousarray(arr)
+        p = self.alloc(arr.nbytes)
+        if arr.nbytes:
+            self._check(self.hip.hipMemcpy(p, arr.ctypes.data, arr.nbytes, 1), "hipMemcpy H2D")
+        return p
+
+    def download(self, ptr, dtype, count):
+        out = np.zeros(int(count), dtype=dtype)
+        self._check(self.hip.hipDeviceSynchronize(), "hipDeviceSynchronize")
+        if out.nbytes:
+            self._check(self.hip.hipMemcpy(out.ctypes.data, ptr, out.nbytes, 2), "hipMemcpy D2H")
+        return out
+
+    def close(self):
+        for p in self.ptrs:
+            self.hip.hipFree(p)
+        self.ptrs = []

@@ -517,7 +517,7 @@ def test_genotype_parity_other_band_widths(band, kw):
 @pytest.mark.parametrize("streams,taps", [(1, False), (1, True), (2, True)])
 def test_device_memspace_matches_host_memspace(streams, taps):
     """MA_MEM_DEVICE (caller-owned device buffers, what bench.py times) gives the bytes of MA_MEM_HOST."""
-    torch = pytest.importorskip("torch")
+    from harness import DeviceArena
     from lancet2_amd.engine import Engine
     params = capi.default_params(min_k=25, max_k=25)
     arrs, n, nr = synth.make_config_batch("C2", 6, first_index=95_000)
@@ -526,29 +526,22 @@ def test_device_memspace_matches_host_memspace(streams, taps):
         hg, ha, hv, hq = eng.process(arrs, n, nr, debug=taps)
     finally:
         eng.close()
-    dev = torch.device("cuda", 0)
-    dbatch = {k: torch.from_numpy(v.view(np.uint8) if v.dtype != np.uint8 else v).to(dev) for k, v in arrs.items()}
-    b = capi.make_batch_struct(dbatch, n, nr)
-
-    def dev_alloc(spec):
-        return {k: torch.zeros(int(sz) * np.dtype(dt).itemsize, dtype=torch.uint8, device=dev) for k, (dt, sz) in spec.items()}
-
-    g, a, v = dev_alloc(capi.gate_out_spec(n)), dev_alloc(capi.asm_out_spec(params, n)), dev_alloc(capi.var_out_spec(params, n))
-    q = dev_alloc(capi.geno_out_spec(params, n, nr, debug=taps))
+    specs = [capi.gate_out_spec(n), capi.asm_out_spec(params, n), capi.var_out_spec(params, n),
+             capi.geno_out_spec(params, n, nr, debug=taps)]
     deng = Engine(params, memspace=capi.MA_MEM_DEVICE)
+    arena = DeviceArena()
     try:
+        b = capi.make_batch_struct({k: arena.upload(v) for k, v in arrs.items()}, n, nr)
+        ptrs = [{k: arena.alloc(int(sz) * np.dtype(dt).itemsize) for k, (dt, sz) in spec.items()} for spec in specs]
         deng.set_streams(streams)
-        deng.process_device(b, capi.fill_struct(capi.GateOut, g), capi.fill_struct(capi.AsmOut, a),
-                            capi.fill_struct(capi.VarOut, v), capi.fill_struct(capi.GenoOut, q))
+        deng.process_device(b, capi.fill_struct(capi.GateOut, ptrs[0]), capi.fill_struct(capi.AsmOut, ptrs[1]),
+                            capi.fill_struct(capi.VarOut, ptrs[2]), capi.fill_struct(capi.GenoOut, ptrs[3]))
         deng.synchronize()
-        torch.cuda.synchronize(dev)
+        dg, da, dv, dq = [{k: arena.download(pt[k], dt, sz) for k, (dt, sz) in spec.items()}
+                          for spec, pt in zip(specs, ptrs)]
     finally:
         deng.close()
-    def back(spec, devd):
-        return {k: devd[k].cpu().numpy().view(np.dtype(dt)) for k, (dt, _) in spec.items()}
-
-    dg, da, dv = back(capi.gate_out_spec(n), g), back(capi.asm_out_spec(params, n), a), back(capi.var_out_spec(params, n), v)
-    dq = back(capi.geno_out_spec(params, n, nr, debug=taps), q)
+        arena.close()
     assert np.array_equal(dg["max_approx"], hg["max_approx"])
     # the helpers compare the defined part of every buffer (unused slots of a capacity-sized array are not written)
     bad = compare_asm(params, da, ha, n) + compare_vars(params, dv, hv, n)

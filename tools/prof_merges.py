@@ -12,6 +12,8 @@ from lancet2_amd import engine as E  # noqa: E402
 capi.LIB_PATH = os.path.join(capi.REPO, "lancet2_amd", "libmicroasm_prof.so")
 cfg = sys.argv[1] if len(sys.argv) > 1 else "C3"
 arrs, nw, nr = synth.make_config_batch(cfg, 64)
+if len(sys.argv) > 2:
+    arrs, nw, nr = synth.tile_batch(arrs, nw, nr, int(sys.argv[2]) // 64)
 eng = E.Engine(capi.default_params(min_k=25, max_k=25))
 eng.process(arrs, nw, nr)
 buf = (C.c_uint * (8 * 64))()
@@ -24,6 +26,6 @@ print(m[:8, :7])
 tb = (C.c_ulonglong * (6 * 64))()
 eng.lib.ma_debug_ctime(tb, 64)
 t = np.array(list(tb), dtype=np.int64).reshape(64, 6)
-for j, nm in enumerate(['filter', 'hop', 'validate', 'apply', 'compress_graph_total', 'init+links']):
+for j, nm in enumerate(['emit:list walk', 'emit:spell', 'ref hap', 'dedup', 'finalize stats', 'emit total']):
     print('%-22s mean ticks %10.0f' % (nm, t[:, j].mean()))
 eng.close()
