@@ -26,6 +26,6 @@ print(m[:8, :7])
 tb = (C.c_ulonglong * (6 * 64))()
 eng.lib.ma_debug_ctime(tb, 64)
 t = np.array(list(tb), dtype=np.int64).reshape(64, 6)
-for j, nm in enumerate(['emit:list walk', 'emit:spell', 'ref hap', 'dedup', 'finalize stats', 'emit total']):
+for j, nm in enumerate(['filter', 'hop', 'validate', 'apply', 'compress_graph_total', 'init+links']):
     print('%-22s mean ticks %10.0f' % (nm, t[:, j].mean()))
 eng.close()
