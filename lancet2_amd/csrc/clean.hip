@@ -62,7 +62,8 @@ struct Win {
   u32* sprev;
   u32* sdesc;
   u32* scratch;
-  u32* link;  // LDS: packed two-neighbour records of the chain nodes (compress_walk_par)
+  u32* link;  // LDS, 8 KB: component labels, then the chain-following table, then the slice ranks
+  bool ranked;  // link holds rank_slices() of the current graph
   i64 source, sink;
   u32 flags;  // bit2: capacity overflow
 #ifdef MA_PROFILE
@@ -1039,6 +1040,35 @@ __device__ __forceinline__ u8 slice_base(const Win& g, u32 o, u32 d, u32 j) {  /
 // spelling it base by base is one chain of dependent loads per base.  Instead the list is walked once for the slice
 // ids (one dependent load per slice), and the slices are then spelled 64 at a time: descriptor, source and base
 // loads of 64 slices are in flight together and a prefix sum of the slice lengths gives every base its position.
+// Slice lists are linked lists through HBM, and a merged chain of k-mers is a list of single-base slices in k-mer
+// index order, i.e. scattered: following one costs a memory round trip per base.  Instead every slice learns its
+// list's last slice and its distance from it by pointer jumping (Wyllie), all lists of the window at once, in LDS:
+// rank[s] = dist << 16 | last.  A slice that was trimmed away (slices_drop_front) still points INTO a live list;
+// such a stale link is recognised by the missing back pointer and starts a list of its own.
+__device__ __forceinline__ void rank_slices(Win& g) {
+  u32 const lane = lane_id();
+  u32* rank = g.link;
+  for (u32 i = lane; i < g.n; i += 64) {
+    u32 const nx = g.snext[i];
+    bool const fwd = nx != kNoNode && nx < g.n && g.sprev[nx] == i;
+    rank[i] = fwd ? ((1u << 16) | nx) : i;
+  }
+  wave_sync_mem();
+  while (true) {
+    bool changed = false;
+    for (u32 i = lane; i < g.n; i += 64) {
+      u32 const mine = rank[i];
+      u32 const to = rank[mine & 0xFFFFu];
+      if ((to & 0xFFFFu) != (mine & 0xFFFFu)) {  // my target is not a last slice yet: jump over it
+        rank[i] = ((mine & 0xFFFF0000u) + (to & 0xFFFF0000u)) | (to & 0xFFFFu);
+        changed = true;
+      }
+    }
+    wave_sync_mem();
+    if (!__ballot(changed)) break;
+  }
+}
+
 __device__ __forceinline__ bool emit_node_seq(const Win& g, u32 node, bool dflt, u32 skip, u8* out, u32* pos, u32 cap) {
   u32* ids = g.scratch + 7u * g.nc;  // adjacency scratch of the traversal index: dead once the walks are enumerated
   u32 const lane = lane_id();
@@ -1046,7 +1076,18 @@ __device__ __forceinline__ bool emit_node_seq(const Win& g, u32 node, bool dflt,
   // looks at slice s + l (s - l when walking backwards); as long as each one links to the next index the whole run
   // belongs to the list -- by induction from s -- and costs one round trip instead of one per slice.
   u32 ns = 0;
-  {
+  if (g.ranked) {
+    // every slice of the window looks itself up: on this node's list (same last slice, not beyond its head)?
+    u32 const h = g.head[node], t = g.tail[node];
+    if (h != kNoNode) {
+      u32 const hd = g.link[h] >> 16;
+      for (u32 i = lane; i < g.n; i += 64) {
+        u32 const rk = g.link[i];
+        if ((rk & 0xFFFFu) == t && (rk >> 16) <= hd) ids[dflt ? hd - (rk >> 16) : (rk >> 16)] = i;
+      }
+      ns = hd + 1u;
+    }
+  } else {
     u32 s = dflt ? g.head[node] : g.tail[node];
     while (s != kNoNode) {
       u32 const mine = dflt ? s + lane : s - lane;  // wraps past 0 when walking backwards: rejected by the bound
@@ -1234,6 +1275,7 @@ __global__ __launch_bounds__(64, 4) void k_clean(CleanArgs A) {
   __shared__ u32 l_link[kLinkCap];
   Win g;
   g.link = l_link;
+  g.ranked = false;
   g.refb = A.b.ref_bases + A.b.ref_off[w];
   g.readb = A.b.read_bases + A.b.read_off[A.b.read_win_off[w]];
   g.ref_len = A.b.ref_off[w + 1] - A.b.ref_off[w];
@@ -1385,6 +1427,7 @@ __global__ __launch_bounds__(64, 4) void k_clean(CleanArgs A) {
 
   for (int ci = 0; ci < ncand && !retry; ++ci) {
     u32 const comp = cand_comp[ci];
+    g.ranked = false;  // the table is the chain-following table again
     g.source = cand_src[ci];
     g.sink = cand_snk[ci];
     u32 const anchor_len = cand_koff[ci] - cand_soff[ci] + K;
@@ -1638,6 +1681,8 @@ __global__ __launch_bounds__(64, 4) void k_clean(CleanArgs A) {
     if (hit_limit) status |= MA_W_BFS_LIMIT;
     if (nwalks == 0) continue;  // graph.cpp:225
 
+    g.ranked = g.n <= kLinkCap;  // 2048 slices x (distance, last slice) = the 8 KB of LDS
+    if (g.ranked) rank_slices(g);
     // stable sort by MinWeight desc (graph.cpp:876-879)
     int order[kMaxWalks];
     for (int i = 0; i < nwalks; ++i) {
