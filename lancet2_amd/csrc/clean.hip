@@ -1598,10 +1598,56 @@ __global__ __launch_bounds__(64, 4) void k_clean(CleanArgs A) {
     u32 walk_off[kMaxWalks], walk_len[kMaxWalks], walk_minw[kMaxWalks];
     int nwalks = 0;
     bool hit_limit = false, arena_over = false;
+    // The reference's breadth-first search enumerates walk PREFIXES: with b bubbles between source and sink that is
+    // 2^b queue entries.  Entries of one level that stand on the same state expand identically, in the same relative
+    // order, so only the earliest of them can be an ancestor of the first qualifying arrival at the sink -- the
+    // earliest overall and, if that one has not crossed a new edge yet, the earliest that has.  The others are
+    // folded into those two as a multiplicity, which is all that is needed to know how many entries the reference
+    // would have popped (its 2^20-visit cap, max_flow.h:69).  Same walks, arena use linear in the graph.
+    u32* rep = l_link;  // [state][2]: arena index of the representatives in the level being built
+    bool const fold = 4u * V <= kLinkCap;
     while (true) {
       u32 an = 0, head = 0;
+      u32 next_begin = 0;          // first arena index of the level being built
+      u64 build_total = 0;         // reference entries (multiplicities) of the level being built
+      if (fold) {
+        for (u32 x = lane; x < 4u * V; x += 64) rep[x] = kNoNode;
+        wave_sync_mem();
+      }
+      // w of an arena record: bit 31 = the walk has crossed a not yet traversed edge, bits 0-30 = multiplicity
+      auto push = [&](u32 ord, u32 st, u32 parent, u32 flag, u32 mult) {
+        build_total += mult;
+        if (fold) {
+          u32 const r0 = rep[st * 2];
+          if (r0 != kNoNode && r0 >= next_begin) {
+            u32 const w0 = arena[r0].w;
+            if ((w0 >> 31) || !flag) {
+              arena[r0].w = (w0 & 0x80000000u) | min((w0 & 0x7FFFFFFFu) + mult, 0x40000000u);
+              return;
+            }
+            u32 const r1 = rep[st * 2 + 1];
+            if (r1 != kNoNode && r1 >= next_begin) {
+              arena[r1].w = 0x80000000u | min((arena[r1].w & 0x7FFFFFFFu) + mult, 0x40000000u);
+              return;
+            }
+            if (an >= ws.ac) {
+              arena_over = true;
+              return;
+            }
+            rep[st * 2 + 1] = an;
+            arena[an++] = make_uint4(ord, st, parent, 0x80000000u | mult);
+            return;
+          }
+          if (an < ws.ac) rep[st * 2] = an;
+        }
+        if (an >= ws.ac) {
+          arena_over = true;
+          return;
+        }
+        arena[an++] = make_uint4(ord, st, parent, (flag << 31) | mult);
+      };
       // EnqueueOutgoingEdges (max_flow.cpp:235-280): stable sort by dst Confidence desc, new edges first
-      auto enqueue = [&](u32 state, u32 parent, u32 pscore) {
+      auto enqueue = [&](u32 state, u32 parent, u32 pw) {
         u32 const cnt = rcnt[state];
         if (cnt == 0) return;
         u32 idx[kEdgeCap], conf[kEdgeCap];
@@ -1623,31 +1669,51 @@ __global__ __launch_bounds__(64, 4) void k_clean(CleanArgs A) {
             u32 const p = idx[x];
             bool const trav = traversed[adj_ord[p]] != 0;
             if (trav != (pass == 1)) continue;
-            if (an >= ws.ac) {
-              arena_over = true;
-              return;
-            }
-            arena[an++] = make_uint4(adj_ord[p], adj_state[p], parent, pscore + (trav ? 0u : 1u));
+            push(adj_ord[p], adj_state[p], parent, (pw >> 31) | (trav ? 0u : 1u), pw & 0x7FFFFFFFu);
+            if (arena_over) return;
           }
       };
-      enqueue(src_state, kNoParent, 0);
-      u32 nvisits = 0;
+      enqueue(src_state, kNoParent, 1u);
+      u64 pops_before = 0, lvl_total = build_total;  // reference pops before / inside the level being popped
+      u32 lvl_end = an;
+      build_total = 0;
+      next_begin = an;
+      bool undecided = false;
+      u64 const limit = static_cast<u64>(P.bfs_limit);
       i64 best = -1;
-      while (head < an && !arena_over) {
-        nvisits++;
-        if (nvisits > static_cast<u32>(P.bfs_limit)) {
-          hit_limit = true;
-          break;
+      auto enter_level = [&]() {  // the reference stops at its (limit + 1)-th pop: does that fall into this level?
+        if (pops_before + lvl_total <= limit) return;
+        if (pops_before < limit) {
+          // it falls inside; if no entry of the level qualifies the reference pops them all and gives up, otherwise
+          // the answer depends on positions the folding has not kept
+          for (u32 x = head; x < lvl_end; ++x) {
+            uint4 const e = arena[x];
+            if ((e.y >> 1) == snk_flat && (e.w >> 31)) undecided = true;
+          }
+        }
+        if (!undecided) hit_limit = true;
+      };
+      enter_level();
+      while (head < an && !arena_over && !hit_limit && !undecided) {
+        if (head == lvl_end) {
+          pops_before += lvl_total;
+          lvl_total = build_total;
+          build_total = 0;
+          lvl_end = an;
+          next_begin = an;
+          enter_level();
+          if (hit_limit || undecided) break;
         }
         u32 const ai = head++;
         uint4 const wn = arena[ai];
         if ((wn.y >> 1) == snk_flat) {
-          if (wn.w == 0) continue;
+          if (!(wn.w >> 31)) continue;
           best = ai;
           break;
         }
         enqueue(wn.y, ai, wn.w);
       }
+      if (undecided) arena_over = true;  // reported as a capacity failure below
       if (best < 0) break;
       // reconstruct (max_flow.cpp:42-54) into the pool, reversed to source->sink order
       u32 wl = 0;
@@ -1678,6 +1744,13 @@ __global__ __launch_bounds__(64, 4) void k_clean(CleanArgs A) {
     }
     CPROF_ACC(9);
     if (arena_over) status |= MA_W_TABLE_OVERFLOW;
+    if (arena_over && nwalks == 0) {
+      // "no walk" cannot be told from "walk not reached before the arena filled up" (the reference allows 2^20
+      // visits, max_flow.h:69): a capacity failure like the others -- flagged, and no attempt at the next k, which
+      // would report haplotypes the reference never builds
+      g.flags |= 4u;
+      break;
+    }
     if (hit_limit) status |= MA_W_BFS_LIMIT;
     if (nwalks == 0) continue;  // graph.cpp:225
 

@@ -584,3 +584,36 @@ def test_outputs_do_not_depend_on_previous_batches_or_debug_taps():
         assert np.array_equal(q["var_qual"].view(np.uint64), q2["var_qual"].view(np.uint64)), tag
     bad = compare_geno(params, q1, q2, n, nr, v2["win_nvars"], arrs["read_win_off"])
     assert not bad, "\n".join(bad[:10])
+
+
+def test_dense_variants_match_or_are_flagged():
+    """Windows with 10+ variants make MaxFlow's breadth-first walk tree grow towards the reference's 2^20-visit cap;
+    the device arena holds 2^16 records.  Whatever does not fit must say so -- TABLE_OVERFLOW,
+    no haplotypes, no retry at another k -- and everything else must be the reference's answer."""
+    from lancet2_amd.engine import Engine
+    params = capi.default_params(min_k=25, max_k=25)
+    arrs, n, nr = synth.make_config_batch("C2", 24, first_index=77_000, snv_rate=1e-2, indel_rate=2e-3)
+    orc = OracleEngine(params)
+    wa = orc.assemble(arrs, n, nr)
+    wv = orc.msa(arrs, n, nr, wa)
+    eng = Engine(params)
+    try:
+        a = eng.assemble(arrs, n, nr)
+        v = eng.msa(arrs, n, nr, a)
+    finally:
+        eng.close()
+    flagged = [w for w in range(n) if int(a["win_status"][w]) & capi.MA_W_TABLE_OVERFLOW]
+    assert not flagged, flagged  # (the folded search fits: nothing to flag at this density)
+    for w in flagged:
+        assert int(a["win_status"][w]) & capi.MA_W_NO_HAPLOTYPE and int(a["win_ncomp"][w]) == 0 and int(v["win_nvars"][w]) == 0
+    keep = [w for w in range(n) if w not in flagged]
+    assert len(keep) >= 20
+    # compare window by window (the helpers take whole batches: mask the flagged windows out of both sides)
+    for d_got, d_want in ((a, wa), (v, wv)):
+        for key in ("win_status", "win_ncomp", "win_nvars"):
+            if key in d_got:
+                for w in flagged:
+                    d_want[key][w] = d_got[key][w]
+    bad = compare_asm(params, a, wa, n) + compare_vars(params, v, wv, n)
+    assert not bad, "\n".join(bad[:10])
+    assert int(wv["win_nvars"][keep].max()) >= 12  # the case is as dense as intended

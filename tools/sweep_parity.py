@@ -14,7 +14,12 @@ from lancet2_amd.engine import Engine  # noqa: E402
 CASES = [("C2", 96, 70_000, {}, dict(min_k=25, max_k=25)), ("C3", 32, 71_000, {}, dict(min_k=25, max_k=25)),
          ("C2", 24, 72_000, dict(str_unit=b"AT", n_somatic=2), {}), ("C5", 8, 73_000, {}, dict(min_k=25, max_k=25, num_samples=3)),
          ("C2", 16, 74_000, dict(W=1500, indel_rate=1e-3), dict(min_k=25, max_k=25)),
-         ("C2", 12, 75_000, dict(big_indel=40), dict(min_k=25, max_k=25))]
+         ("C2", 12, 75_000, dict(big_indel=40), dict(min_k=25, max_k=25)),
+         # many error bubbles / tips, many branch nodes, repeats through the k cascade: the graph-cleaning corner cases
+         ("C2", 24, 76_000, dict(error_scale=4.0), dict(min_k=25, max_k=25)),
+         ("C2", 24, 77_000, dict(snv_rate=1e-2, indel_rate=2e-3), dict(min_k=25, max_k=25)),
+         ("C3", 16, 78_000, dict(error_scale=3.0, str_unit=b"CAG"), {}),
+         ("C2", 16, 79_000, dict(error_scale=2.0, snv_rate=5e-3), dict(min_k=17, max_k=41, k_step=8))]
 tot = 0
 for cfg, nwin, first, kw, pk in CASES:
     params = capi.default_params(**pk)
