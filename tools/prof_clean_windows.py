@@ -8,7 +8,7 @@ from lancet2_amd import capi, synth  # noqa: E402
 from lancet2_amd import engine as E  # noqa: E402
 
 capi.LIB_PATH = os.path.join(capi.REPO, "lancet2_amd", "libmicroasm_prof.so")
-arrs, nw, nr = synth.make_config_batch("C2", 64, first_index=int(sys.argv[1]) if len(sys.argv) > 1 else 0)
+arrs, nw, nr = synth.make_config_batch(sys.argv[2] if len(sys.argv) > 2 else "C2", 64, first_index=int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 eng = E.Engine(capi.default_params(min_k=25, max_k=25))
 eng.process(arrs, nw, nr)
 eng.process(arrs, nw, nr)
