@@ -1605,7 +1605,13 @@ __global__ __launch_bounds__(64, 4) void k_clean(CleanArgs A) {
     // folded into those two as a multiplicity, which is all that is needed to know how many entries the reference
     // would have popped (its 2^20-visit cap, max_flow.h:69).  Same walks, arena use linear in the graph.
     u32* rep = l_link;  // [state][2]: arena index of the representatives in the level being built
-    bool const fold = 4u * V <= kLinkCap;
+    bool const fold = 5u * V <= kLinkCap;
+    // Node::Confidence (f64 arithmetic) of every node of the component, once: the search asks for it per outgoing
+    // edge of every popped entry
+    if (fold) {
+      for (u32 f = lane; f < V; f += 64) l_link[4u * V + f] = nd_confidence(g, flat_nodes[f]);
+      wave_sync_mem();
+    }
     while (true) {
       u32 an = 0, head = 0;
       u32 next_begin = 0;          // first arena index of the level being built
@@ -1654,7 +1660,7 @@ __global__ __launch_bounds__(64, 4) void k_clean(CleanArgs A) {
         u32 const m = cnt < static_cast<u32>(kEdgeCap) ? cnt : static_cast<u32>(kEdgeCap);
         for (u32 x = 0; x < m; ++x) {
           u32 const p = rstart[state] + x;
-          u32 const cf = nd_confidence(g, flat_nodes[adj_state[p] >> 1]);
+          u32 const cf = fold ? l_link[4u * V + (adj_state[p] >> 1)] : nd_confidence(g, flat_nodes[adj_state[p] >> 1]);
           u32 j = x;
           while (j > 0 && conf[j - 1] < cf) {
             conf[j] = conf[j - 1];
@@ -1731,9 +1737,10 @@ __global__ __launch_bounds__(64, 4) void k_clean(CleanArgs A) {
         }
       }
       // MinWeight over the walk's nodes (path.cpp:34-37)
-      u32 mw = nd_confidence(g, ord_src[walk_pool[off]]);
+      auto conf_of = [&](u32 node) { return fold ? l_link[4u * V + flat_of[node]] : nd_confidence(g, node); };
+      u32 mw = conf_of(ord_src[walk_pool[off]]);
       for (u32 x = 0; x < wl; ++x) {
-        u32 const cf = nd_confidence(g, ord_val[walk_pool[off + x]] >> 2);
+        u32 const cf = conf_of(ord_val[walk_pool[off + x]] >> 2);
         mw = mw < cf ? mw : cf;
       }
       walk_off[nwalks] = off;

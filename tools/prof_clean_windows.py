@@ -20,6 +20,11 @@ tot = sum(r[0] for r in rows)
 print("mean ticks", tot // 64, "max", rows[0][0])
 for r in rows[:12]:
     print("win %2d ticks %10d nodes %5d comps %4d cands %2d" % (r[4], r[0], r[1], r[2], r[3]))
+tb = (C.c_ulonglong * (6 * 64))()
+eng.lib.ma_debug_ctime(tb, 64)
+for r in rows[:4] + rows[30:33] + rows[-2:]:
+    i = r[4]
+    print("win %2d total %8d  comps+anchors %8d  compress+tips %8d  index+cycle+cx %8d  maxflow %8d  emit %8d" % ((i, r[0]) + tuple(tb[6 * i + q] for q in range(5))))
 print("...")
 for r in rows[-4:]:
     print("win %2d ticks %10d nodes %5d comps %4d cands %2d" % (r[4], r[0], r[1], r[2], r[3]))
