@@ -617,3 +617,29 @@ def test_dense_variants_match_or_are_flagged():
     bad = compare_asm(params, a, wa, n) + compare_vars(params, v, wv, n)
     assert not bad, "\n".join(bad[:10])
     assert int(wv["win_nvars"][keep].max()) >= 12  # the case is as dense as intended
+
+
+@pytest.mark.parametrize("bfs_limit", [6, 40, 300, 3000])
+def test_traversal_limit_is_the_references(bfs_limit):
+    """MaxFlow::HitTraversalLimit (max_flow.h:69) with the cap pulled down into reach: the folded search has to
+    know how many entries the reference's queue would have popped.  A window is either the reference's answer,
+    BFS_LIMIT flag included, or flagged TABLE_OVERFLOW (the cap fell inside a level that holds a qualifying arrival)."""
+    from lancet2_amd.engine import Engine
+    params = capi.default_params(min_k=25, max_k=25, bfs_limit=bfs_limit)
+    arrs, n, nr = synth.make_config_batch("C2", 12, first_index=77_000, snv_rate=1e-2, indel_rate=2e-3)
+    wa = OracleEngine(params).assemble(arrs, n, nr)
+    eng = Engine(params)
+    try:
+        a = eng.assemble(arrs, n, nr)
+    finally:
+        eng.close()
+    flagged = [w for w in range(n) if int(a["win_status"][w]) & capi.MA_W_TABLE_OVERFLOW]
+    assert len(flagged) <= n // 2, flagged
+    for key in ("win_status", "win_ncomp"):
+        for w in flagged:
+            wa[key][w] = a[key][w]
+    bad = compare_asm(params, a, wa, n)
+    assert not bad, "\n".join(bad[:10])
+    if bfs_limit <= 40:  # the cap was meant to bite: the reference's answer is not the uncapped one
+        full = OracleEngine(capi.default_params(min_k=25, max_k=25)).assemble(arrs, n, nr)
+        assert not (np.array_equal(full["win_status"], wa["win_status"]) and np.array_equal(full["comp_nhaps"], wa["comp_nhaps"]))
