@@ -4,7 +4,7 @@
 The reference itself cannot be built or imported here, so these vectors pin the ORACLE
 (which is in turn pinned to the reference's known-answer tests by tests/test_oracle_kat.py); they guard
 both the oracle against regressions (CPU test) and the HIP path against the oracle (GPU test).
-Run from the repo root:  python tests/golden/make_golden.py
+Run from the repo root:  python tests/golden/make_golden.py [case ...]
 """
 import os
 import sys
@@ -24,11 +24,16 @@ CASES = {
     "c2_cascade": ("C2", 2, 1100, {}, {}),
     "c5_three_samples": ("C5", 1, 1200, dict(min_k=25, max_k=25, num_samples=3), {}),
     "c4_indel50": ("C4", 1, 1300, dict(min_k=25, max_k=25), dict(depths=(40, 40))),
+    # 18 variants / 5 haplotypes in one window: MaxFlow's walk tree is 2^18 prefixes wide in the reference's search
+    "c2_dense_variants": ("C2", 1, 77_009, dict(min_k=25, max_k=25), dict(snv_rate=1e-2, indel_rate=2e-3)),
 }
 
 
 def main():
+    only = set(sys.argv[1:])  # optional: regenerate just the named cases
     for name, (cfg, n, first, pk, gk) in CASES.items():
+        if only and name not in only:
+            continue
         params = capi.default_params(**pk)
         arrs, nw, nr = synth.make_config_batch(cfg, n, first_index=first, **gk)
         orc = OracleEngine(params)
