@@ -1476,47 +1476,62 @@ __global__ __launch_bounds__(64, 4) void k_clean(CleanArgs A) {
       V += static_cast<u32>(__popcll(m));
     }
     wave_sync_mem();
-    for (u32 s = 0; s < 2 * V; ++s) rcnt[s] = 0;
-    for (u32 f = 0; f < V; ++f) {
-      u32 const i = flat_nodes[f];
-      for (int x = 0; x < g.nedge[i]; ++x) {
-        u32 const e = g.edge[i * kEdgeCap + x];
-        if (flat_of[e >> 2] == kNoNode) continue;
-        rcnt[f * 2 + ((e >> 1) & 1u)]++;
-        E++;
+    // one lane per node: edge counts per strand side, then the two prefix sums of the reference's loops in one --
+    // a state's block starts where the edges of the nodes before it end, and so do the node's edge ordinals
+    {
+      u32 carry = 0;
+      for (u32 f0 = 0; f0 < V; f0 += 64) {
+        u32 const f = f0 + lane;
+        u32 c0 = 0, c1 = 0;
+        if (f < V) {
+          u32 const i = flat_nodes[f];
+          u32 const ne = g.nedge[i];
+          for (u32 x = 0; x < ne; ++x) {
+            u32 const e = g.edge[i * kEdgeCap + x];
+            if (flat_of[e >> 2] == kNoNode) continue;
+            if ((e >> 1) & 1u) c1++; else c0++;
+          }
+        }
+        u32 incl = c0 + c1;
+#pragma unroll
+        for (u32 o = 1; o < 64; o <<= 1) {
+          u32 const y = __shfl_up(incl, o, 64);
+          if (lane >= o) incl += y;
+        }
+        if (f < V) {
+          u32 const base = carry + incl - (c0 + c1);
+          rstart[f * 2] = base;
+          rstart[f * 2 + 1] = base + c0;
+          rcnt[f * 2] = c0;
+          rcnt[f * 2 + 1] = c1;
+        }
+        carry += __shfl(incl, 63, 64);
       }
+      E = carry;
+      wave_sync_mem();
     }
     if (E > 4 * NC || 2 * V > 2 * NC) {
       g.flags |= 4u;
       break;
     }
-    {
-      u32 off = 0;
-      for (u32 s = 0; s < 2 * V; ++s) {
-        rstart[s] = off;
-        off += rcnt[s];
-        rcnt[s] = 0;
+    for (u32 f = lane; f < V; f += 64) {
+      u32 const i = flat_nodes[f];
+      u32 const ne = g.nedge[i];
+      u32 const b0 = rstart[f * 2], b1 = rstart[f * 2 + 1];
+      u32 k0 = 0, k1 = 0;
+      for (u32 x = 0; x < ne; ++x) {
+        u32 const e = g.edge[i * kEdgeCap + x];
+        u32 const df = flat_of[e >> 2];
+        if (df == kNoNode) continue;
+        u32 const ord = b0 + k0 + k1;  // ordinals count the node's edges in list order, whatever their side
+        u32 const slot = ((e >> 1) & 1u) ? b1 + k1++ : b0 + k0++;
+        ord_src[ord] = i;
+        ord_val[ord] = e;
+        adj_state[slot] = df * 2 + (e & 1u);
+        adj_ord[slot] = ord;
       }
     }
-    {
-      u32 ord = 0;
-      for (u32 f = 0; f < V; ++f) {
-        u32 const i = flat_nodes[f];
-        for (int x = 0; x < g.nedge[i]; ++x) {
-          u32 const e = g.edge[i * kEdgeCap + x];
-          u32 const df = flat_of[e >> 2];
-          if (df == kNoNode) continue;
-          u32 const ss = f * 2 + ((e >> 1) & 1u);
-          u32 const ds = df * 2 + (e & 1u);
-          ord_src[ord] = i;
-          ord_val[ord] = e;
-          adj_state[rstart[ss] + rcnt[ss]] = ds;
-          adj_ord[rstart[ss] + rcnt[ss]] = ord;
-          rcnt[ss]++;
-          ord++;
-        }
-      }
-    }
+    wave_sync_mem();
     u32 const src_state = flat_of[g.source] * 2 + (g.sign[g.source] ? 0u : 1u);
     u32 const snk_flat = flat_of[g.sink];
 
