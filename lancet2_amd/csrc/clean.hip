@@ -1574,25 +1574,48 @@ __global__ __launch_bounds__(64, 4) void k_clean(CleanArgs A) {
     u32 cx_cc = 0, cx_bp = 0, cx_maxdeg = 0;
     f64 cx_unitig = 0.0, cx_cv = 0.0, cx_tip = 0.0;
     {
-      u32 nn = 0, ne = 0, unitigs = 0;
+      u32 nn = V, ne = 0, unitigs = 0;
       OnlineStats cov, tip, uni;
-      for (u32 f = 0; f < V; ++f) {
-        u32 const i = flat_nodes[f];
-        nn++;
-        u32 d = 0, o = 0;
-        u32 const self_minus = g.sign[i] ? 0u : 1u;
-        for (int x = 0; x < g.nedge[i]; ++x) {
-          if (((g.edge[i * kEdgeCap + x] >> 1) & 1u) == self_minus) d++; else o++;
+      // degrees and coverages one lane per node; the f64 running statistics then take the nodes in index order
+      // from registers (Welford's update is order-sensitive in its last bits)
+      u32 ne_l = 0, mx_l = 0, bp_l = 0, un_l = 0;
+      for (u32 f0 = 0; f0 < V; f0 += 64) {
+        u32 const f = f0 + lane;
+        u32 tot = 0, cls = 0;  // cls: 1 = tip, 2 = unitig, 0 = neither
+        if (f < V) {
+          u32 const i = flat_nodes[f];
+          u32 d = 0, o = 0;
+          u32 const self_minus = g.sign[i] ? 0u : 1u;
+          u32 const nei = g.nedge[i];
+          for (u32 x = 0; x < nei; ++x) {
+            if (((g.edge[i * kEdgeCap + x] >> 1) & 1u) == self_minus) d++; else o++;
+          }
+          ne_l += d + o;
+          mx_l = max(mx_l, max(d, o));
+          if (d >= 2 || o >= 2) bp_l++;
+          if (d == 1 && o == 1) un_l++;
+          tot = nd_total(g, i);
+          cls = (d == 0 || o == 0) ? 1u : ((d == 1 && o == 1) ? 2u : 0u);
         }
-        ne += d + o;
-        u32 const mx = d > o ? d : o;
-        cx_maxdeg = cx_maxdeg > mx ? cx_maxdeg : mx;
-        if (d >= 2 || o >= 2) cx_bp++;
-        if (d == 1 && o == 1) unitigs++;
-        f64 const cv = static_cast<f64>(nd_total(g, i));
-        cov.add(cv);
-        if (d == 0 || o == 0) tip.add(cv); else if (d == 1 && o == 1) uni.add(cv);
+        u32 const cntb = V - f0 < 64u ? V - f0 : 64u;
+        for (u32 l = 0; l < cntb; ++l) {
+          f64 const cv = static_cast<f64>(__builtin_amdgcn_readlane(tot, l));
+          u32 const c = __builtin_amdgcn_readlane(cls, l);
+          cov.add(cv);
+          if (c == 1u) tip.add(cv); else if (c == 2u) uni.add(cv);
+        }
       }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        ne_l += static_cast<u32>(__shfl_xor(ne_l, o));
+        bp_l += static_cast<u32>(__shfl_xor(bp_l, o));
+        un_l += static_cast<u32>(__shfl_xor(un_l, o));
+        mx_l = max(mx_l, static_cast<u32>(__shfl_xor(mx_l, o)));
+      }
+      ne = ne_l;
+      cx_bp = bp_l;
+      unitigs = un_l;
+      cx_maxdeg = mx_l;
       ne /= 2;
       cx_cc = ne >= nn ? ne - nn + 1 : 0;
       cx_unitig = nn > 0 ? static_cast<f64>(unitigs) / static_cast<f64>(nn) : 0.0;
@@ -1798,10 +1821,15 @@ __global__ __launch_bounds__(64, 4) void k_clean(CleanArgs A) {
     {
       u32* confs = g.scratch;  // reuse
       u32 ncf = 0;
-      for (u32 f = 0; f < V; ++f) {
-        u32 const i = flat_nodes[f];
-        if (g.label[i] & 1u) confs[ncf++] = nd_confidence(g, i);
+      for (u32 f0 = 0; f0 < V; f0 += 64) {  // one lane per node, appended in node order
+        u32 const f = f0 + lane;
+        u32 const i = f < V ? flat_nodes[f] : 0u;
+        bool const is_ref = f < V && (g.label[i] & 1u);
+        unsigned long long const m = __ballot(is_ref);
+        if (is_ref) confs[ncf + __popcll(m & ((1ull << lane) - 1ull))] = nd_confidence(g, i);
+        ncf += static_cast<u32>(__popcll(m));
       }
+      wave_sync_mem();
       isort_u32(confs, ncf);
       u32 const wgt = ncf == 0 ? 1u : median_sorted(confs, ncf);
       size_t const hi = static_cast<size_t>(w) * MH + slot;
