@@ -1146,6 +1146,25 @@ struct OnlineStats {  // base/compute_stats.h:75-125
   __device__ f64 sd() const { return sqrt(variance()); }
 };
 
+// ascending sort of a short list kept in the window's scratch: up to 64 values are ranked in registers (lane l counts
+// the values that sort before its own; equal values keep their order) instead of shuffling them through memory
+__device__ __forceinline__ void isort_u32(u32* v, u32 n);
+__device__ __forceinline__ void sort_small_u32(u32* v, u32 n) {
+  if (n > 64) {
+    isort_u32(v, n);
+    return;
+  }
+  u32 const lane = lane_id();
+  u32 const x = lane < n ? v[lane] : 0xFFFFFFFFu;
+  u32 rank = 0;
+  for (u32 j = 0; j < n; ++j) {
+    u32 const y = __builtin_amdgcn_readlane(x, j);
+    rank += (y < x || (y == x && j < lane)) ? 1u : 0u;
+  }
+  wave_sync_mem();  // every lane has read before any lane writes
+  if (lane < n) v[rank] = x;
+  wave_sync_mem();
+}
 __device__ __forceinline__ void isort_u32(u32* v, u32 n) {
   for (u32 i = 1; i < n; ++i) {
     u32 const x = v[i];
@@ -1830,7 +1849,7 @@ __global__ __launch_bounds__(64, 4) void k_clean(CleanArgs A) {
         ncf += static_cast<u32>(__popcll(m));
       }
       wave_sync_mem();
-      isort_u32(confs, ncf);
+      sort_small_u32(confs, ncf);
       u32 const wgt = ncf == 0 ? 1u : median_sorted(confs, ncf);
       size_t const hi = static_cast<size_t>(w) * MH + slot;
       u32 len = anchor_len;
@@ -1912,7 +1931,7 @@ __global__ __launch_bounds__(64, 4) void k_clean(CleanArgs A) {
       f64 const total = mean * static_cast<f64>(st.n);
       f64 cv = 0.0, qcv = 0.0;
       if (mean > 0.0) cv = sdv / mean;
-      isort_u32(covs, ncov);
+      sort_small_u32(covs, ncov);
       f64 const med = static_cast<f64>(median_sorted(covs, ncov));
       if (ncov >= 4) {
         f64 const q1 = static_cast<f64>(covs[ncov / 4]), q3 = static_cast<f64>(covs[(ncov * 3) / 4]);
