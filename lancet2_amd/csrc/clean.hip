@@ -1820,6 +1820,18 @@ __global__ __launch_bounds__(64, 4) void k_clean(CleanArgs A) {
 
     g.ranked = g.n <= kLinkCap;  // 2048 slices x (distance, last slice) = the 8 KB of LDS
     if (g.ranked) rank_slices(g);
+    // Node::Confidence and the total coverage of the component's nodes, behind the slice ranks: every walk asks for
+    // both at every node it passes
+    bool const have_tab = g.ranked && g.n + 2u * V <= kLinkCap;
+    if (have_tab) {
+      for (u32 f = lane; f < V; f += 64) {
+        l_link[g.n + f] = nd_confidence(g, flat_nodes[f]);
+        l_link[g.n + V + f] = nd_total(g, flat_nodes[f]);
+      }
+      wave_sync_mem();
+    }
+    auto conf_at = [&](u32 node) { return have_tab ? l_link[g.n + flat_of[node]] : nd_confidence(g, node); };
+    auto total_at = [&](u32 node) { return have_tab ? l_link[g.n + V + flat_of[node]] : nd_total(g, node); };
     // stable sort by MinWeight desc (graph.cpp:876-879)
     int order[kMaxWalks];
     for (int i = 0; i < nwalks; ++i) {
@@ -1888,9 +1900,9 @@ __global__ __launch_bounds__(64, 4) void k_clean(CleanArgs A) {
         bool const dflt = ((e0 >> 1) & 1u) == 0u;  // walk[0].SrcSign() == PLUS
         u32 const before = pos;
         ok &= emit_node_seq(g, sn, dflt, 0, hb, &pos, ML);
-        covs[ncov++] = nd_total(g, sn);
+        covs[ncov++] = total_at(sn);
         if (static_cast<int>(nruns) < MR) {
-          A.out.hap_runs[(hi * MR + nruns) * 2 + 0] = nd_confidence(g, sn);
+          A.out.hap_runs[(hi * MR + nruns) * 2 + 0] = conf_at(sn);
           A.out.hap_runs[(hi * MR + nruns) * 2 + 1] = pos - before;
         } else runs_ok = false;
         nruns++;
@@ -1901,9 +1913,9 @@ __global__ __launch_bounds__(64, 4) void k_clean(CleanArgs A) {
         bool const dflt = (e & 1u) == 0u;  // conn.DstSign() == PLUS
         u32 const before = pos;
         ok &= emit_node_seq(g, dn, dflt, K - 1, hb, &pos, ML);
-        covs[ncov++] = nd_total(g, dn);
+        covs[ncov++] = total_at(dn);
         if (static_cast<int>(nruns) < MR) {
-          A.out.hap_runs[(hi * MR + nruns) * 2 + 0] = nd_confidence(g, dn);
+          A.out.hap_runs[(hi * MR + nruns) * 2 + 0] = conf_at(dn);
           A.out.hap_runs[(hi * MR + nruns) * 2 + 1] = pos - before;
         } else runs_ok = false;
         nruns++;
