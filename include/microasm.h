@@ -48,7 +48,8 @@ enum ma_wstatus {
   MA_W_HAP_OVERFLOW = 1u << 1,   /* more haplotypes / components than max_haps / max_comps */
   MA_W_LEN_OVERFLOW = 1u << 2,   /* haplotype longer than max_hap_len or more runs than max_runs */
   MA_W_BFS_LIMIT = 1u << 3,      /* MaxFlow::HitTraversalLimit (max_flow.h:69) in some component */
-  MA_W_TABLE_OVERFLOW = 1u << 4, /* k-mer table / edge list / arena capacity exceeded */
+  MA_W_TABLE_OVERFLOW = 1u << 4, /* k-mer table / edge list / search arena capacity exceeded, or the traversal cap fell where
+                                    the folded walk search cannot place it: the window's result is not the reference's */
   MA_W_VAR_OVERFLOW = 1u << 5    /* more variants / alleles / allele bytes than the caps */
 };
 
