@@ -14,6 +14,18 @@
 // (start, len, revcomp), which reproduces Kmer::Merge's string semantics (kmer.cpp:48-109) exactly,
 // including for the reference's stored-sign edge quirk.  Haplotype bases are spelled from the batch's
 // ref/read bytes only when a walk is emitted.
+//
+// Three places where the serial order is kept but the work is not serial (each is re-derived from memory or proven
+// in place, so a stale hint or an unusual graph only costs speed):
+//   * CompressNode: chains are followed through a next-state table in LDS, 64 positions at a time, every lane
+//     validates its position's merge against the records in HBM, and only the floor-rounded running averages run as
+//     a (scalar) recurrence (compress_walk_par); a lane-parallel exact negative filter skips nodes that cannot merge;
+//   * MaxFlow::NextPath: queue entries of one level that stand on the same state are folded into the earliest one (two,
+//     if the earliest has not crossed a new edge yet), with multiplicities standing in for the reference's visit count;
+//   * slice lists are ranked by pointer jumping in LDS before haplotypes are spelled.
+// Loops over the nodes of a component (traversal index, complexity metrics, confidence tables) run one lane per node;
+// a loop that walks global memory serially costs a memory round trip per iteration and a kernel of one wavefront per
+// window lasts as long as its slowest window.
 #include "graph_ws.h"
 
 namespace ma {
