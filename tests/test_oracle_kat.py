@@ -421,3 +421,24 @@ def test_longdust_closed_form_for_homopolymers():
         c = n - 6
         want = max(0.0, (math.lgamma(c + 1) - 16384 * f1(c / 16384)) / c)
         assert longdust("A" * n, 7, 1024, 0.5) == pytest.approx(want, rel=1e-12)
+
+
+def test_graph_complexity_chain_and_single_bubble():
+    """tests/cbdg/graph_test.cpp:96-205: a linear chain has cyclomatic complexity E - V + 1 = 0, no branch point and
+    at most one edge per direction; a single bubble has M = 1, a maximum single-direction degree of 2 and at least
+    one branch point.  Here through the whole cleaning path: a window without a variant prunes down to a chain
+    (source, middle, sink), a window with one somatic SNV to exactly one bubble."""
+    from harness import OracleEngine
+    from lancet2_amd import capi, synth
+    p = capi.default_params(min_k=25, max_k=25)
+    clean = dict(snv_rate=1e-9, indel_rate=0.0, error_scale=0.0)
+    for n_somatic, want_m, want_deg in ((0, 0, 1), (1, 1, 2)):
+        arrs, n, nr = synth.make_config_batch("C2", 3, first_index=5000, n_somatic=n_somatic, **clean)
+        a = OracleEngine(p).assemble(arrs, n, nr)
+        cx = a["comp_cx"].reshape(n, p.max_comps, 3)[:, 0]
+        assert a["win_ncomp"].tolist() == [1, 1, 1]
+        for cyclomatic, branch_points, max_dir in cx.tolist():
+            assert cyclomatic == want_m
+            assert max_dir <= want_deg if n_somatic == 0 else max_dir == want_deg
+            assert (branch_points == 0) if n_somatic == 0 else (branch_points >= 1)
+        assert a["comp_nhaps"].reshape(n, p.max_comps)[:, 0].tolist() == [1 + n_somatic] * 3
