@@ -102,3 +102,25 @@ def test_error_codes_on_bad_arguments():
         assert lib.ma_repeat_gate_batch(h, C.byref(b0), C.byref(capi.fill_struct(capi.GateOut, g))) == 0
     finally:
         lib.ma_destroy(h)
+
+
+def test_python_constants_mirror_the_header():
+    """The status bits and read flags of lancet2_amd/capi.py are the enum values of include/microasm.h."""
+    import re
+    from lancet2_amd import capi
+    text = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "microasm.h")).read()
+    found = {}
+    for name, expr in re.findall(r"\b(MA_[A-Z_0-9]+)\s*=\s*([^,/\n}]+)", text):
+        expr = expr.strip()
+        m = re.fullmatch(r"(\d+)u?\s*<<\s*(\d+)", expr)
+        if m:
+            found[name] = int(m.group(1)) << int(m.group(2))
+        elif re.fullmatch(r"-?\d+u?", expr):
+            found[name] = int(expr.rstrip("u"))
+    assert {"MA_W_NO_HAPLOTYPE", "MA_W_TABLE_OVERFLOW", "MA_MEM_DEVICE"} <= set(found)
+    checked = 0
+    for name, value in found.items():
+        if hasattr(capi, name):
+            assert getattr(capi, name) == value, name
+            checked += 1
+    assert checked >= 8
