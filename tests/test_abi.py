@@ -124,3 +124,30 @@ def test_python_constants_mirror_the_header():
             assert getattr(capi, name) == value, name
             checked += 1
     assert checked >= 8
+
+
+def test_ctypes_offsets_match_the_compiled_header(tmp_path):
+    """Every field of every boundary struct sits where a C compiler puts it: a probe built with gcc from
+    include/microasm.h prints sizeof / offsetof, the ctypes mirror must agree field by field."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    structs = {"ma_params_t": capi.Params, "ma_batch_t": capi.Batch, "ma_gate_out_t": capi.GateOut,
+               "ma_asm_out_t": capi.AsmOut, "ma_var_out_t": capi.VarOut, "ma_geno_out_t": capi.GenoOut,
+               "ma_cx_out_t": capi.CxOut}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "microasm.h"', 'int main(void) {']
+    for cname, cls in structs.items():
+        lines.append(f'  printf("{cname} %zu\\n", sizeof({cname}));')
+        for fname, _ in cls._fields_:
+            lines.append(f'  printf("{cname}.{fname} %zu\\n", offsetof({cname}, {fname}));')
+    lines += ['  return 0;', '}']
+    src = tmp_path / "probe.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "probe"
+    subprocess.check_call(["gcc", "-std=c11", "-I", os.path.dirname(HEADER), str(src), "-o", str(exe)])
+    got = dict(line.split() for line in subprocess.check_output([str(exe)], text=True).splitlines())
+    for cname, cls in structs.items():
+        assert int(got[cname]) == C.sizeof(cls), cname
+        for fname, _ in cls._fields_:
+            assert int(got[f"{cname}.{fname}"]) == getattr(cls, fname).offset, f"{cname}.{fname}"
