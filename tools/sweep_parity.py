@@ -20,8 +20,10 @@ CASES = [("C2", 96, 70_000, {}, dict(min_k=25, max_k=25)), ("C3", 32, 71_000, {}
          ("C2", 24, 77_000, dict(snv_rate=1e-2, indel_rate=2e-3), dict(min_k=25, max_k=25)),
          ("C3", 16, 78_000, dict(error_scale=3.0, str_unit=b"CAG"), {}),
          ("C2", 16, 79_000, dict(error_scale=2.0, snv_rate=5e-3), dict(min_k=17, max_k=41, k_step=8))]
+shift = int(sys.argv[1]) if len(sys.argv) > 1 else 0  # other windows of the same shapes
 tot = 0
 for cfg, nwin, first, kw, pk in CASES:
+    first += shift
     params = capi.default_params(**pk)
     arrs, n, nr = synth.make_config_batch(cfg, nwin, first_index=first, **kw)
     orc = OracleEngine(params)
