@@ -5,13 +5,17 @@ A step = one pass of the whole hot path (repeat gate -> cbdg assembly -> POA/var
 genotyping: ma_process_batch) over one batch of synthetic tumour/normal windows that is already resident
 in HBM.  N > 1: one process per GPU (torch.distributed / RCCL only for the barrier + max-over-ranks),
 windows statically sharded, NO data-path collective (windows never communicate) -> weak scaling.
+`python bench.py --gpus N` without a launcher starts the N ranks itself (torch.distributed.run as a child
+process, before this process has touched a GPU); under an external torchrun it is one of the ranks.
 
-Prints ONE JSON line on rank 0 (see README/DESIGN.md for the fields).
+Prints ONE JSON line on rank 0.  Roofline bytes are SURVEY.md 8(d)'s algorithmic bytes and nothing else: every
+stage reads its inputs once and writes its outputs once; traceback tiles, decision codes, LDS images and table
+re-scans are intermediates and are NOT counted (DESIGN.md section 5 restates the terms).
 """
 import argparse
-import ctypes as C
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -20,7 +24,9 @@ import numpy as np
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+# 256 CUs x 4 SIMDs x 32 lanes/cycle x 2.4 GHz (same guide: a wave64 VALU instruction issues over 2 cycles)
+VALU_PEAK_LANE_OPS = 256 * 4 * 32 * 2.4e9  # = 78.6e12 lane-operations/s
 WORKLOADS = {
     "C3": "C3: whole-genome-shaped tumour/normal 60x/30x, 1001 bp windows, 150 bp paired reads, k=25 (the workload "
           "BASELINE.json's metric is quoted on = configs[2]; every GPU runs its own shard of windows)",
@@ -28,6 +34,17 @@ WORKLOADS = {
     "C4": "C4: deep panel 500x/500x with 50 bp indels (BASELINE.json configs[3])",
     "C5": "C5: 1 tumour + 2 normals, 30x each (BASELINE.json configs[4])",
 }
+STR_UNITS = (b"A", b"CA", b"CAG", b"GATA", b"TTTCC", b"AGGGTT")
+# which kernels make up which SURVEY 8(a) stage
+STAGE_OF = {"gate_kernel": "gate",
+            "k_count_inst": "build", "k_classify": "build", "k_insert": "build", "k_support": "build",
+            "k_mm_lds": "build", "k_mm_insert": "build", "k_count": "build", "k_rank": "build", "k_edges": "build",
+            "k_edge_sort": "build",
+            "k_clean": "clean",
+            "k_msa": "poa", "k_msa_band": "poa",
+            "k_plan": "genotype", "k_vote": "genotype", "k_dp_scatter": "genotype", "k_align_reg": "genotype",
+            "k_align_wave": "genotype", "k_align_gen": "genotype", "k_assign": "genotype", "k_evidence": "genotype",
+            "k_qual": "genotype"}
 
 
 def parse():
@@ -36,64 +53,101 @@ def parse():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--windows", type=int, default=8192, help="windows per step per GPU")
-    ap.add_argument("--distinct", type=int, default=64, help="distinct synthetic windows (tiled to --windows)")
+    ap.add_argument("--distinct", type=int, default=2048, help="distinct synthetic windows (tiled to --windows)")
+    ap.add_argument("--str-every", type=int, default=8, help="every n-th window carries a short tandem repeat (0 = none)")
     ap.add_argument("--config", default="C3",
                     help="C3 = WGS-shaped tumour/normal 60x/30x (the workload BASELINE.json's metric is quoted on); "
                          "C2 = chr22-shaped 30x/30x (configs[1]); C4, C5")
-    ap.add_argument("--no-also", action="store_true", help="skip the short secondary measurement of the other WGS config")
+    ap.add_argument("--no-also", action="store_true", help="skip the secondary measurements (k cascade, other config, host path)")
     ap.add_argument("--cpu-windows", type=int, default=64, help="oracle sample for cpu_baseline (0 = skip)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--gen-workers", type=int, default=0, help="processes that synthesise windows (0 = min(16, cores))")
     return ap.parse_args()
 
 
-def algorithmic_bytes(kernel, st):
-    """Algorithmic HBM bytes per STEP of `kernel`: inputs read once, outputs written once, intermediates
-    counted only where the design keeps them in HBM (DESIGN.md "Kernels" states each term).  Per-window
-    figures x windows per step; the caller divides by the kernel's launches per step."""
-    n, S = st["windows"], st["S"]
-    W, R, Bb, Ni, Nn = st["W"], st["R"], st["B"], st["N_inst"], st["N_nodes"]
-    Nslow, Ngen = st["N_slow"], st["N_gen"]
-    H, L, m, band = st["H"], st["L"], st["read_len"], st["band"]
-    P, Pdp = st["pairs_per_window"], st["dp_pairs_per_window"]
-    Wk = max(W - st["k"] + 1, 0)
-    tb_words = (2 * band + 1 + 7) // 8
-    per = {
-        "gate_kernel": W + 8,
-        "k_count_inst": 12 * R,
-        # bases + quals + read meta in, one instance word per k-mer out, slow queue out
-        "k_classify": 2 * Bb + 12 * R + W + 4 * Ni + 4 * Nslow,
-        # reference + slow k-mers hashed from their bytes, 16 B table probe/claim + first-instance update each
-        "k_insert": W + st["k"] * Nslow + 20 * (Nslow + Wk) + 8 * Nslow,
-        "k_support": 4 * Ni + 4 * (S + 2) * Wk,
-        "k_mm_insert": 4 * Ni + 12 * Ngen,
-        "k_count": 4 * Ni + 12 * Ngen + 8 * Ngen,
-        # table scan + instance words + node records / edge slots out
-        "k_rank": (16 + 4 * (S + 2)) * st["table_slots"] + 4 * Ni + (24 + 4 * S + 128) * Nn,
-        "k_edges": 4 * Ni + 16 * (Nslow + Wk),
-        "k_edge_sort": 128 * Nn,
-        # node records + edge lists in, haplotype bases / runs / stats out
-        "k_clean": (24 + 4 * S) * Nn + 64 * Nn + H * L + 64 * H + 256,
-        # k_msa (graph update, traceback, variants): haplotypes in; per alignment the window's LDS image (graph +
-        # state, st["poa_img"] bytes) saved and restored once and the decision codes read back along the path
-        "k_msa": H * L + max(H - 1, 0) * (2 * st.get("poa_img", 78000) + 2 * 2 * L) + 512,
-        # k_msa_band (the DP fill): row descriptors (10 B/row) + haplotype in; one 2-byte decision code per cell of
-        # the 256-column band and H(i, L) per row out (HBM-resident by design: the codes do not fit LDS)
-        "k_msa_band": max(H - 1, 0) * (10 * (L + 1) + L + 2 * 256 * (L + 1) + 4 * (L + 1)),
-        "k_plan": 16,
-        # every pair: read bases + 32 B result or 8 B list entry; haplotype once per (window, haplotype)
-        "k_vote": P * (m + 32) + H * L,
-        # DP pairs: read + haplotype segment in, 4-bit move codes of the band out and the path read back, result out
-        "k_align_reg": Pdp * (m + (m + 2 * band + 1) + (m + 1) * tb_words * 4 + 4 * (m + 1) + 32),
-        "k_align": Pdp * (m + (m + 2 * band + 1) + (m + 1) * tb_words * 4 + 4 * (m + 1) + 32),
-        "k_assign": R * (m + H * 40 + 16),
-        "k_evidence": R * 80,
-        "k_qual": 64,
-        # annotation (SURVEY 8 f3): REF haplotype of each component in, one f64 out; +-50 windows of the REF and of
-        # every ALT site in, 11 features + 3 graph metrics (88 B) out per variant
-        "k_hap_lq": L + 8,
-        "k_seqcx": st.get("V", 0) * (3 * 110 + 88),
-    }
-    return per.get(kernel, 0) * n
+# ---- algorithmic bytes per window-attempt, by stage ------------------------------------------------
+def survey_bytes(stage, st):
+    """Per WINDOW (per k attempt for build/clean) -- the caller multiplies by windows / attempts per step.
+    W window bases, R reads, B read bases, S samples, N_inst k-mer instances, N_raw distinct k-mers, H haplotypes,
+    L mean haplotype length, var_bases allele bases written by the POA stage, n_cigar = record stride (max_cigar)."""
+    W, R, B, S = st["W"], st["R"], st["B"], st["S"]
+    Ni, Nraw, H, L = st["N_inst"], st["N_raw"], st["H"], st["L"]
+    if stage == "gate":
+        return W + 4
+    if stage == "build":
+        return 2 * B + 5 * R + W + 16 * Ni + (16 + 4 * S) * Nraw
+    if stage == "clean":
+        return (16 + 4 * S) * Nraw + 5 * H * L + 64
+    if stage == "poa":
+        return 5 * H * L + 16 * (st["L_ref"] + st["var_bases"])
+    if stage == "genotype":
+        return 2 * B + H * L + (24 + 4 * st["n_cigar"]) * R * H
+    return 0
+
+
+def units_per_step(stage, st):
+    """how many times a stage's per-window figure is paid per step: k attempts for build/clean, assembled windows
+    for the stages behind the assembler"""
+    if stage == "gate":
+        return st["windows"]
+    if stage in ("build", "clean"):
+        return st["attempts_per_step"]
+    return st["assembled"]
+
+
+# ---- synthetic windows ---------------------------------------------------------------------------------------------
+def _gen_chunk(job):
+    config, first, count, str_every = job
+    from lancet2_amd import synth
+    kw = dict(synth.CONFIGS[config])
+    wins = []
+    for i in range(count):
+        idx = first + i
+        k2 = dict(kw)
+        if str_every and idx % str_every == str_every - 1:
+            k2["str_unit"] = STR_UNITS[(idx // str_every) % len(STR_UNITS)]
+        wins.append(synth.make_window(idx, **k2))
+    return synth.pack_batch(wins)
+
+
+def concat_batches(parts):
+    """[(arrs, n, nr)] -> one packed batch"""
+    out = {}
+    n = sum(p[1] for p in parts)
+    nr = sum(p[2] for p in parts)
+    for k in ("ref_bases", "read_bases", "read_quals"):
+        out[k] = np.concatenate([p[0][k][:-64] for p in parts] + [np.zeros(64, np.uint8)])
+
+    def cat_off(key, dtype):
+        chunks, base = [], np.uint64(0)
+        for p in parts:
+            off = p[0][key].astype(np.uint64)
+            chunks.append(off[:-1] + base)
+            base = base + off[-1]
+        chunks.append(np.array([base], np.uint64))
+        return np.concatenate(chunks).astype(dtype)
+
+    out["ref_off"] = cat_off("ref_off", np.uint32)
+    out["read_win_off"] = cat_off("read_win_off", np.uint32)
+    out["read_off"] = cat_off("read_off", np.uint64)
+    for k in ("read_qname_id", "read_sample", "read_flags", "read_hint"):
+        out[k] = np.concatenate([p[0][k] for p in parts])
+    return out, n, nr
+
+
+def make_windows(config, count, first, str_every, workers):
+    """seeded windows [first, first + count) of `config`, synthesised by a pool of processes (forked BEFORE the GPU is
+    initialised); the result does not depend on the number of workers"""
+    import multiprocessing as mp
+    per = 32
+    jobs = [(config, first + o, min(per, count - o), str_every) for o in range(0, count, per)]
+    workers = max(1, min(workers, len(jobs)))
+    if workers == 1:
+        parts = [_gen_chunk(j) for j in jobs]
+    else:
+        with mp.get_context("fork").Pool(workers) as pool:
+            parts = pool.map(_gen_chunk, jobs, chunksize=1)
+    return concat_batches(parts)
 
 
 _START = None  # multi-worker baseline: every worker finishes synthesising its windows before any of them is timed
@@ -101,12 +155,12 @@ _START = None  # multi-worker baseline: every worker finishes synthesising its w
 
 def _oracle_chunk(job):
     """One worker of the CPU baseline: the whole path (oracle) over `count` windows starting at `first`."""
-    config, first, count, num_samples = job
+    config, first, count, num_samples, str_every = job
     sys.path.insert(0, os.path.join(REPO, "tests"))
     from harness import OracleEngine
-    from lancet2_amd import capi, synth
+    from lancet2_amd import capi
     params = capi.default_params(min_k=25, max_k=25, num_samples=num_samples)
-    sub, sn, snr = synth.make_config_batch(config, count, first_index=first)
+    sub, sn, snr = _gen_chunk((config, first, count, str_every))
     orc = OracleEngine(params)
     if _START is not None:
         try:
@@ -118,7 +172,6 @@ def _oracle_chunk(job):
     oa = orc.assemble(sub, sn, snr)
     ov = orc.msa(sub, sn, snr, oa)
     orc.genotype(sub, sn, snr, oa, ov, debug=False)
-    orc.annotate(sub, sn, snr, oa, ov)
     return sn, time.perf_counter() - t0
 
 
@@ -128,12 +181,13 @@ def cpu_baselines(args, num_samples):
     (pipeline_executor.cpp:174-197).  Runs BEFORE the GPU is initialised (it forks)."""
     import multiprocessing as mp
     n1 = args.cpu_windows
-    sn, ct = _oracle_chunk((args.config, 10_000, n1, num_samples))
+    sn, ct = _oracle_chunk((args.config, 10_000, n1, num_samples, args.str_every))
     cpu = {"value": round(sn / ct, 3), "unit": "windows/s", "cores": 1, "kind": "port",
-           "sample": f"{sn} windows of the same {args.config} workload through the whole path (oracle, 1 thread, {ct:.1f} s)"}
+           "sample": f"the first {sn} windows of the same {args.config} workload through the metric's path (gate, assembly, "
+                     f"POA/variants, genotyping; oracle, 1 thread, {ct:.1f} s)"}
     cores = os.cpu_count() or 1
     per = 4  # windows per worker: the leg stays around half a minute even when the box schedules far fewer cores than it reports
-    jobs = [(args.config, 10_000 + 1000 * i, per, num_samples) for i in range(cores)]
+    jobs = [(args.config, 10_000 + 1000 * i, per, num_samples, args.str_every) for i in range(cores)]
     global _START
     ctx = mp.get_context("fork")
     _START = ctx.Barrier(cores)  # inherited by the forked workers
@@ -156,18 +210,53 @@ def cpu_baselines(args, num_samples):
     return cpu, cpu_mt
 
 
+def spawn_ranks(args):
+    """--gpus N without a launcher: start the N ranks as children (one process per GPU) and relay rank 0's line.
+    Nothing in THIS process has touched a GPU (torch.cuda.device_count() does not initialise it on this image)."""
+    import socket
+    import torch
+    have = torch.cuda.device_count()
+    if have < args.gpus:
+        print(json.dumps({"error": f"--gpus {args.gpus} but this node exposes {have} GPU(s)"}))
+        return 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse()
-    world0 = int(os.environ.get("WORLD_SIZE", "1"))
-    cpu = cpu_mt = None
-    if world0 == 1 and not args.no_cpu and args.cpu_windows > 0:
-        cpu, cpu_mt = cpu_baselines(args, 3 if args.config == "C5" else 2)
-    import torch
-    import torch.distributed as dist
-
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    num_samples = 3 if args.config == "C5" else 2
+    workers = args.gen_workers or max(1, min(16, (os.cpu_count() or 1) // max(1, world)))
+
+    # ---- everything that forks happens before the GPU is initialised ----
+    distinct = min(args.distinct, args.windows)
+    first = 10_000 + rank * 1_000_000
+    t_gen = time.perf_counter()
+    arrs0, n0, nr0 = make_windows(args.config, distinct, first, args.str_every, workers)
+    also_arrs = None
+    other = {"C3": "C2", "C2": "C3"}.get(args.config)
+    if other and world == 1 and not args.no_also:
+        also_arrs = make_windows(other, min(distinct, 512), first, args.str_every, workers)
+    t_gen = time.perf_counter() - t_gen
+    cpu = cpu_mt = None
+    if world == 1 and not args.no_cpu and args.cpu_windows > 0:
+        cpu, cpu_mt = cpu_baselines(args, num_samples)
+
+    import torch
+    import torch.distributed as dist
+
     if not torch.cuda.is_available():
         print(json.dumps({"error": "no GPU: the engine has no CPU fallback"}))
         sys.exit(2)
@@ -181,14 +270,14 @@ def main():
     from lancet2_amd.engine import Engine
 
     params = capi.default_params(min_k=25, max_k=25)  # BASELINE config: k = 25 (single attempt)
-    if args.config == "C5":
-        params.num_samples = 3
-    # ---- synthetic batch (distinct seeds per rank), tiled up to --windows ----
-    distinct = min(args.distinct, args.windows)
-    arrs, n0, nr0 = synth.make_config_batch(args.config, distinct, first_index=10_000 + rank * 100_000)
+    params.num_samples = num_samples
     times = max(1, args.windows // n0)
-    arrs, n, nr = synth.tile_batch(arrs, n0, nr0, times)
-    dbatch = {k: torch.from_numpy(v.view(np.uint8) if v.dtype != np.uint8 else v).to(dev) for k, v in arrs.items()}
+    arrs, n, nr = synth.tile_batch(arrs0, n0, nr0, times)
+
+    def to_dev(a_):
+        return {k: torch.from_numpy(v_.view(np.uint8) if v_.dtype != np.uint8 else v_).to(dev) for k, v_ in a_.items()}
+
+    dbatch = to_dev(arrs)
     b = capi.make_batch_struct(dbatch, n, nr)
 
     def dev_alloc(spec):
@@ -215,6 +304,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    # one untimed step in statistics mode: workload counters for the algorithmic-byte model
+    eng.timing_control(3)
+    step()
+    torch.cuda.synchronize(dev)
+    wstats = eng.stats()
     eng.timing_control(0)
     for _ in range(args.warmup):
         step()
@@ -246,101 +340,192 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # ---- workload statistics from the results (for the algorithmic-bytes model) ----
+    # ---- workload statistics from the inputs, the results and the engine's counters ----
     status = a["win_status"].view(torch.int32).cpu().numpy().view(np.uint32)
-    ncomp = a["win_ncomp"].view(torch.int32).cpu().numpy()
     nvars = v["win_nvars"].view(torch.int32).cpu().numpy()
     hap_len = a["hap_len"].view(torch.int32).cpu().numpy().reshape(n, params.max_haps)
     nhaps = a["comp_nhaps"].view(torch.int32).cpu().numpy().reshape(n, params.max_comps)
-    assembled = int(((status & capi.MA_W_NO_HAPLOTYPE) == 0).sum())
+    ncomp = a["win_ncomp"].view(torch.int32).cpu().numpy()
+    gate_approx = g["max_approx"].view(torch.int32).cpu().numpy()
+    alt_len = v["alt_len"].view(torch.int32).cpu().numpy().reshape(n, params.max_vars, params.max_alts)
+    nalts = v["var_nalts"].view(torch.int32).cpu().numpy().reshape(n, params.max_vars)
+    ref_len_v = v["var_ref_len"].view(torch.int32).cpu().numpy().reshape(n, params.max_vars)
+    ok = (status & capi.MA_W_NO_HAPLOTYPE) == 0
+    assembled = int(ok.sum())
+    gated = int((gate_approx >= 25).sum())
     overflowed = int((status & (capi.MA_W_HAP_OVERFLOW | capi.MA_W_LEN_OVERFLOW | capi.MA_W_TABLE_OVERFLOW |
                                 capi.MA_W_VAR_OVERFLOW)).astype(bool).sum())
+    steps = max(args.steps, 1)
+    attempts = max(wstats.get("window_attempts", 0), 1)   # of the one statistics step
     R = nr / n
     Bb = float(arrs["read_off"][-1]) / n
     W = float(arrs["ref_off"][-1]) / n
-    k = 25
-    pass_frac = float((arrs["read_flags"] & capi.MA_RF_PASS).astype(bool).mean())
-    Ni = (W - k + 1) + R * pass_frac * (Bb / max(R, 1) - k + 1)
-    H = float(nhaps.sum()) / max(assembled, 1)
-    L = float(hap_len.sum()) / max(float((hap_len > 0).sum()), 1.0)
-    steps = max(args.steps, 1)
+    cmask = np.arange(params.max_comps)[None, :] < ncomp[:, None]
+    H = float(nhaps[cmask & ok[:, None]].sum()) / max(assembled, 1)
+    hmask = np.arange(params.max_haps)[None, :] < np.where(cmask, nhaps, 0).sum(axis=1)[:, None]
+    L = float(hap_len[hmask & ok[:, None]].sum()) / max(float((hmask & ok[:, None]).sum()), 1.0)
+    vmask = (np.arange(params.max_vars)[None, :] < nvars[:, None]) & ok[:, None]
+    amask = vmask[:, :, None] & (np.arange(params.max_alts)[None, None, :] < nalts[:, :, None])
+    var_bases = float(ref_len_v[vmask].sum() + alt_len[amask].sum()) / max(assembled, 1)
     pairs_w = stats.get("pairs", 0) / steps / n
     dp_w = stats.get("dp_pairs", 0) / steps / n
     read_len = Bb / max(R, 1)
-    # slow (non reference-identical) instances and general mate-mer instances: measured shares of the C2 workload
-    # (profiles/r1_*: 12 % of the read k-mers take the hash-table path, 10 % go through the general mate-mer set)
-    st = dict(windows=n, S=params.num_samples, W=W, R=R, B=Bb, N_inst=Ni, N_slow=0.12 * Ni, N_gen=0.10 * Ni,
-              N_nodes=1.4 * W, table_slots=8192, H=H, L=L, read_len=read_len, band=params.band, k=k,
-              pairs_per_window=pairs_w, dp_pairs_per_window=dp_w, V=float(nvars.sum()) / n)
-
-    # ---- short secondary measurement of the other WGS-shaped config (reported beside the metric, never as `value`) ----
-    also = None
-    other = {"C3": "C2", "C2": "C3"}.get(args.config)
-    if other and world == 1 and not args.no_also:
-        o_arrs, o_n0, o_nr0 = synth.make_config_batch(other, distinct, first_index=10_000)
-        o_arrs, o_n, o_nr = synth.tile_batch(o_arrs, o_n0, o_nr0, max(1, args.windows // o_n0))
-        o_dbatch = {k: torch.from_numpy(v_.view(np.uint8) if v_.dtype != np.uint8 else v_).to(dev) for k, v_ in o_arrs.items()}
-        o_b = capi.make_batch_struct(o_dbatch, o_n, o_nr)
-        o_q = dev_alloc(capi.geno_out_spec(params, o_n, o_nr, debug=False))
-        o_qs = capi.fill_struct(capi.GenoOut, o_q)
-        eng.timing_control(0)
-        eng.process_device(o_b, gs, as_, vs, o_qs)
-        barrier()
-        t_o = time.perf_counter()
-        for _ in range(2):
-            eng.process_device(o_b, gs, as_, vs, o_qs)
-        barrier()
-        also = {"workload": WORKLOADS[other], "value": round(2 * o_n / (time.perf_counter() - t_o), 2), "unit": "windows/s",
-                "steps": 2, "windows_per_step": o_n}
+    st = dict(windows=n, S=params.num_samples, W=W, R=R, B=Bb,
+              N_inst=wstats.get("kmer_instances", 0) / attempts, N_raw=wstats.get("distinct_kmers", 0) / attempts,
+              H=H, L=L, L_ref=L, var_bases=var_bases, n_cigar=params.max_cigar,
+              attempts_per_step=stats.get("window_attempts", 0) / steps, assembled=assembled)
+    stage_bytes_step = {s: survey_bytes(s, st) * units_per_step(s, st) for s in ("gate", "build", "clean", "poa", "genotype")}
 
     total_windows = n * args.steps * world
     wps = total_windows / elapsed
     asm_wps = assembled * args.steps * world / elapsed
 
-    # ---- dominant kernel + roofline ----
+    # ---- per-kernel / per-stage times ----
     agg = {}
     for name, ms in ktimes:
         s = agg.setdefault(name, [0.0, 0])
         s[0] += ms
         s[1] += 1
+    kernel_ms_per_step = {kname: round(val[0] / args.steps, 3) for kname, val in sorted(agg.items(), key=lambda kv: -kv[1][0])}
+    stage_ms = {}
+    for kname, (tot_ms, _) in agg.items():
+        sname = STAGE_OF.get(kname, "other")
+        stage_ms[sname] = stage_ms.get(sname, 0.0) + tot_ms / args.steps
+    stages = {}
+    for s, ms in sorted(stage_ms.items(), key=lambda kv: -kv[1]):
+        ab = stage_bytes_step.get(s, 0)
+        gbs = ab / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        stages[s] = {"kernel_ms_per_step": round(ms, 3), "algorithmic_MB_per_step": round(ab / 1e6, 1),
+                     "MB_per_window": round(survey_bytes(s, st) / 1e6, 4), "GB_per_s": round(gbs, 1),
+                     "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 5)}
+    step_bytes = sum(stage_bytes_step.values())
+
+    # ---- dominant kernel: HBM roofline by its stage's SURVEY 8(d) bytes, and a VALU roofline from the PMC pass ----
     dom = max(agg.items(), key=lambda kv: kv[1][0])[0] if agg else None
-    roof = None
+    roof = roof_valu = None
+    prof = {}
+    for cand in ("r2_pmc_per_kernel.json", "r1_hbm_traffic.json"):
+        tpath = os.path.join(REPO, "profiles", cand)
+        if os.path.exists(tpath):
+            try:
+                prof = json.load(open(tpath))
+                prof["_file"] = "profiles/" + cand
+                break
+            except Exception:
+                prof = {}
     if dom:
         tot_ms, launches = agg[dom]
         avg_ms = tot_ms / launches
         launches_per_step = launches / args.steps
-        bytes_per_launch = algorithmic_bytes(dom, st) / max(launches_per_step, 1)
-        traffic = None
-        tpath = os.path.join(REPO, "profiles", "r1_hbm_traffic.json")  # PMC pass (tools/hbm_traffic.py), bytes per launch
-        if os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath)).get(dom, {}).get("bytes_per_launch")
-            except Exception:
-                traffic = None
+        sname = STAGE_OF.get(dom, "other")
+        bytes_per_launch = stage_bytes_step.get(sname, 0) / max(launches_per_step, 1)
         ach = bytes_per_launch / (avg_ms * 1e-3) / 1e9
-        roof = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(ach / HBM_PEAK_GBS, 6), "traffic": traffic,
+        pk = prof.get(dom, {})
+        roof = {"bound": "hbm", "kernel": dom, "stage": sname, "achieved": round(ach, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(ach / HBM_PEAK_GBS, 6), "traffic": pk.get("bytes_per_launch"),
+                "traffic_source": prof.get("_file") if pk else None,
                 "avg_launch_ms": round(avg_ms, 4), "launches_per_step": launches_per_step,
-                "algorithmic_bytes_per_launch": int(bytes_per_launch)}
-    kernel_ms_per_step = {kname: round(val[0] / args.steps, 3) for kname, val in sorted(agg.items(), key=lambda kv: -kv[1][0])}
+                "algorithmic_bytes_per_launch": int(bytes_per_launch),
+                "note": "achieved = the WHOLE stage's SURVEY 8(d) bytes per launch / this kernel's mean launch time "
+                        "(HIP events on the launch stream); intermediates (traceback tiles etc.) are not counted"}
+        if pk.get("valu_insts_per_launch"):
+            lane_ops = pk["valu_insts_per_launch"] * 64.0
+            av = lane_ops / (avg_ms * 1e-3)
+            roof_valu = {"bound": "valu", "kernel": dom, "achieved": round(av / 1e12, 3), "peak": round(VALU_PEAK_LANE_OPS / 1e12, 1),
+                         "unit": "T lane-ops/s", "frac": round(av / VALU_PEAK_LANE_OPS, 4),
+                         "valu_insts_per_launch": pk["valu_insts_per_launch"], "source": prof.get("_file"),
+                         "note": "SQ_INSTS_VALU (wave instructions, committed PMC pass of this command) x 64 lanes / this run's "
+                                 "mean launch time; peak = 256 CU x 4 SIMD x 32 lanes x 2.4 GHz"}
 
-    # ---- per-stage table: HIP-event time, algorithmic bytes, achieved GB/s; cell rates of the two DP kernels ----
-    stages = {}
-    for kname, (tot_ms, launches) in agg.items():
-        ab = algorithmic_bytes(kname, st)
-        ms_step = tot_ms / args.steps
-        if ab <= 0 or ms_step <= 0:
-            continue
-        gbs = ab / (ms_step * 1e-3) / 1e9
-        stages[kname] = {"ms_per_step": round(ms_step, 3), "algorithmic_MB_per_step": round(ab / 1e6, 1),
-                         "GB_per_s": round(gbs, 1), "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 5)}
-    cells = {}
-    if "k_msa_band" in agg:
-        c = n * max(H - 1, 0) * (L + 1) * 256  # every non-first haplotype: 256-column band over the (L+1)-row graph
-        cells["k_msa_band_GCUPS"] = round(c / (agg["k_msa_band"][0] / args.steps * 1e-3) / 1e9, 1)
-    if "k_align_reg" in agg:
-        c = n * dp_w * read_len * (2 * params.band + 1)
-        cells["k_align_reg_GCUPS"] = round(c / (agg["k_align_reg"][0] / args.steps * 1e-3) / 1e9, 1)
+    # ---- secondary measurements (never `value`) ----
+    also = {}
+    eng.close()  # its workspaces are grow-only shares of the whole HBM: one engine at a time
+    if world == 1 and not args.no_also:
+        # (1) the default k cascade (min_k 13 .. max_k 127, graph_params.h:11-26) on the same windows
+        cparams = capi.default_params()
+        cparams.num_samples = num_samples
+        ceng = Engine(cparams, device=local_rank, memspace=capi.MA_MEM_DEVICE)
+        ceng.set_stream(stream.cuda_stream)
+        ceng.timing_control(0)
+        ceng.process_device(b, gs, as_, vs, qs)
+        barrier()
+        ceng.timing_control(2)
+        t_c = time.perf_counter()
+        for _ in range(2):
+            ceng.process_device(b, gs, as_, vs, qs)
+        barrier()
+        dt = time.perf_counter() - t_c
+        cst = ceng.stats()
+        cstatus = a["win_status"].view(torch.int32).cpu().numpy().view(np.uint32)
+        also["k_cascade"] = {"workload": "the same windows with the reference's default cascade k = 13, 19, ... 127",
+                             "value": round(2 * n / dt, 2), "unit": "windows/s", "steps": 2,
+                             "k_attempts_per_window": round(cst.get("window_attempts", 0) / 2 / n, 2),
+                             "assembled_fraction": round(float(((cstatus & capi.MA_W_NO_HAPLOTYPE) == 0).mean()), 4)}
+        ceng.close()
+        # (2) the other WGS-shaped config
+        if also_arrs is not None:
+            o_arrs, o_n0, o_nr0 = also_arrs
+            o_arrs, o_n, o_nr = synth.tile_batch(o_arrs, o_n0, o_nr0, max(1, args.windows // o_n0))
+            o_dbatch = to_dev(o_arrs)
+            o_b = capi.make_batch_struct(o_dbatch, o_n, o_nr)
+            o_q = dev_alloc(capi.geno_out_spec(params, o_n, o_nr, debug=False))
+            o_qs = capi.fill_struct(capi.GenoOut, o_q)
+            oeng = Engine(params, device=local_rank, memspace=capi.MA_MEM_DEVICE)
+            oeng.set_stream(stream.cuda_stream)
+            oeng.timing_control(0)
+            oeng.process_device(o_b, gs, as_, vs, o_qs)
+            barrier()
+            t_o = time.perf_counter()
+            for _ in range(2):
+                oeng.process_device(o_b, gs, as_, vs, o_qs)
+            barrier()
+            also["other_config"] = {"workload": WORKLOADS[other], "value": round(2 * o_n / (time.perf_counter() - t_o), 2),
+                                    "unit": "windows/s", "steps": 2, "windows_per_step": o_n, "distinct_windows": o_n0}
+            oeng.close()
+            del o_dbatch, o_q
+        # (3) host path: caller-owned PINNED host buffers through MA_MEM_HOST -- the library stages inputs through HBM and
+        #     copies every fixed-stride output array back (PCIe both ways inside the timed region)
+        try:
+            rep = max(1, min(n, 2048) // n0)
+            h_arrs, hn, h_nr = synth.tile_batch(arrs0, n0, nr0, rep)
+            keep = []
+
+            def pinned(nbytes):
+                t_ = torch.empty(max(int(nbytes), 16), dtype=torch.uint8, pin_memory=True)
+                keep.append(t_)
+                return t_.numpy()
+
+            h_in = {}
+            for k_, v_ in h_arrs.items():
+                v_ = np.ascontiguousarray(v_)
+                buf = pinned(v_.nbytes)[: v_.nbytes].view(v_.dtype)
+                buf[...] = v_
+                h_in[k_] = buf
+
+            def pinned_out(spec):
+                return {k_: pinned(int(sz) * np.dtype(dt_).itemsize)[: int(sz) * np.dtype(dt_).itemsize].view(dt_)
+                        for k_, (dt_, sz) in spec.items()}
+
+            hg, ha = pinned_out(capi.gate_out_spec(hn)), pinned_out(capi.asm_out_spec(params, hn))
+            hv, hq = pinned_out(capi.var_out_spec(params, hn)), pinned_out(capi.geno_out_spec(params, hn, h_nr, debug=False))
+            heng = Engine(params, device=local_rank, memspace=capi.MA_MEM_HOST)
+            hb = capi.make_batch_struct(h_in, hn, h_nr)
+            hs = (capi.fill_struct(capi.GateOut, hg), capi.fill_struct(capi.AsmOut, ha), capi.fill_struct(capi.VarOut, hv),
+                  capi.fill_struct(capi.GenoOut, hq))
+            heng.process_device(hb, *hs)
+            t_h = time.perf_counter()
+            for _ in range(2):
+                heng.process_device(hb, *hs)
+            dt = time.perf_counter() - t_h
+            in_mb = sum(x.nbytes for x in h_in.values()) / 1e6
+            out_mb = sum(x.nbytes for d_ in (hg, ha, hv, hq) for x in d_.values()) / 1e6
+            also["host_path"] = {"value": round(2 * hn / dt, 2), "unit": "windows/s", "windows_per_step": hn,
+                                 "input_MB_per_step": round(in_mb, 1), "output_MB_per_step": round(out_mb, 1),
+                                 "note": "MA_MEM_HOST with pinned caller buffers: H2D staging + compute + D2H of every "
+                                         "fixed-stride output array, one stream, no overlap between batches"}
+            heng.close()
+        except Exception as exc:  # the host leg must never cost the headline
+            also["host_path"] = {"error": str(exc)[:200]}
 
     if rank == 0:
         out = {
@@ -349,20 +534,33 @@ def main():
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8/i32 (f64 statistics)", "data": "synthetic",
             "config": {"workload": WORKLOADS.get(args.config, args.config),
-                       "windows_per_step_per_gpu": n, "distinct_windows": n0, "reads_per_window": round(R, 1),
+                       "windows_per_step_per_gpu": n, "distinct_windows": n0,
+                       "str_windows": f"every {args.str_every}th window carries a 12-copy tandem repeat" if args.str_every else "none",
+                       "reads_per_window": round(R, 1),
                        "assembled_windows_per_s": round(asm_wps, 2), "assembled_fraction": round(assembled / n, 4),
+                       "repeat_gated_fraction": round(gated / n, 4),
                        "windows_with_capacity_overflow": overflowed, "haplotypes_per_assembled_window": round(H, 2),
-                       "sharding": "static, one process per GPU, no collective"},
-            "roofline": roof, "cpu_baseline": cpu, "cpu_baseline_all_cores": cpu_mt,
-            "kernel_ms_per_step": kernel_ms_per_step, "stages": stages, "dp_cell_rates": cells,
-            "work": {"pairs_per_window": round(pairs_w, 1), "dp_pairs_per_window": round(dp_w, 1)},
+                       "sharding": "static, one process per GPU, no collective",
+                       "input_synthesis_s": round(t_gen, 1)},
+            "roofline": roof, "roofline_valu": roof_valu, "cpu_baseline": cpu, "cpu_baseline_all_cores": cpu_mt,
+            "step_algorithmic": {"MB_per_step": round(step_bytes / 1e6, 1),
+                                 "GB_per_s": round(step_bytes / (elapsed / args.steps) / 1e9, 1),
+                                 "frac_of_hbm_peak": round(step_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 5)},
+            "kernel_ms_per_step": kernel_ms_per_step, "stages": stages,
+            "work": {"pairs_per_window": round(pairs_w, 1), "dp_pairs_per_window": round(dp_w, 1),
+                     "dp_pairs_by_region_width": {k_: round(stats.get(k_, 0) / steps / n, 2)
+                                                  for k_ in ("dp_w41", "dp_w65", "dp_w129", "dp_wide")},
+                     "kmer_instances_per_attempt": round(st["N_inst"], 1), "distinct_kmers_per_attempt": round(st["N_raw"], 1),
+                     "nodes_after_lowcov_per_attempt": round(wstats.get("nodes_after_lowcov", 0) / attempts, 1),
+                     "slow_instances_per_attempt": round(wstats.get("slow_instances", 0) / attempts, 1),
+                     "mean_haplotype_len": round(L, 1), "variant_bases_per_assembled_window": round(var_bases, 1),
+                     "mean_read_len": round(read_len, 1)},
             # SURVEY 8 f3 (next row), outside the metric's timed region: ma_annotate_batch over the same batch
-            "also": also,
+            "also": also or None,
             "annotation": {"ms_per_step": round(annot_ms, 3), "variants_per_window": round(float(nvars.sum()) / n, 2),
                            "kernel_ms_per_step": {k_: round(v_, 3) for k_, v_ in annot_k.items()}},
         }
         print(json.dumps(out))
-    eng.close()
     if world > 1:
         dist.destroy_process_group()
 

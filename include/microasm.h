@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MA_VERSION 1
+#define MA_VERSION 2
 
 enum ma_error {
   MA_OK = 0,
@@ -61,8 +61,12 @@ typedef struct ma_params {
   int32_t min_anchor_len;                /* 150  (graph.cpp:88) */
   int32_t max_mismatch;                  /* 2    (graph.h:129) */
   int32_t bfs_limit;                     /* 1<<20 (max_flow.h:69) */
-  /* read<->haplotype aligner (genotyper.cpp:89-191 as restated in DESIGN.md) */
-  int32_t band;                          /* half band width, default 64 */
+  /* read<->haplotype aligner (genotyper.cpp:89-191 as restated in DESIGN.md).  There is no band parameter: like the
+   * reference (bw = 10000, genotyper.cpp:140) the search region never excludes an alignment its seeds support; it is
+   * derived per pair from the seed diagonals, the read length and min_aln_score. */
+  int32_t aln_tier;                      /* testing knob, results NEVER depend on it.  0 (default): every pair takes the
+                                            cheapest exact route.  bit 0: all DP pairs through the generic any-width kernel;
+                                            bit 1: the gapless certificates are off (every seeded pair runs the DP) */
   int32_t min_aln_score;                 /* 80 (minimap2 min_dp_max default) */
   /* engine caps (outputs are fixed-stride; overflow sets a status bit) */
   int32_t max_comps;                     /* components kept per window (default 4) */
@@ -208,7 +212,9 @@ int ma_process_batch(ma_ctx_t* ctx, const ma_batch_t* b, const ma_gate_out_t* ga
                      const ma_asm_out_t* asmb, const ma_var_out_t* vars, const ma_geno_out_t* geno);
 
 /* Kernel timing mode: 0 = off, 1 = reset at every API call (default), 2 = accumulate across calls
- * until ma_timing_control is called again (used by bench.py to time kernels over the timed region). */
+ * until ma_timing_control is called again (used by bench.py to time kernels over the timed region), 3 = as 2 and
+ * one extra small kernel per k attempt gathers the workload statistics ma_last_stats reports in out[8..11]
+ * (bench.py runs one untimed step in this mode). */
 int ma_timing_control(ma_ctx_t* ctx, int mode);
 
 /* Per-kernel timing of the last call, measured with HIP events on the launch stream.
@@ -222,8 +228,11 @@ int ma_last_kernel_times(ma_ctx_t* ctx, const char** names, float* ms, int cap);
 int ma_set_streams(ma_ctx_t* ctx, int n);
 
 /* Work counters accumulated over the same region as ma_last_kernel_times (reset by ma_timing_control):
- *   out[0] read x haplotype pairs seen by ma_genotype_batch      out[1] pairs that needed the banded DP
+ *   out[0] read x haplotype pairs seen by ma_genotype_batch      out[1] pairs that needed the DP
  *   out[2] windows passed to ma_assemble_batch                   out[3] k attempts x windows assembled
+ *   out[4..7] DP pairs by region width: <= 41, <= 65, <= 129 diagonals, wider (any-width kernel)
+ *   out[8..11] (timing mode 3 only) distinct k-mers, nodes after the first low-coverage pass, k-mer instances on the
+ *              hash-table path, k-mer instances -- each summed over the window attempts
  * Used by bench.py to price the kernels' algorithmic HBM bytes.  Returns the number of entries written. */
 int ma_last_stats(ma_ctx_t* ctx, unsigned long long* out, int cap);
 

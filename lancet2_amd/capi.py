@@ -22,13 +22,13 @@ MA_NO_HINT = -(1 << 31)
 class Params(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "min_k", "max_k", "k_step", "min_node_cov", "min_anchor_cov", "num_samples",
-        "min_anchor_len", "max_mismatch", "bfs_limit", "band", "min_aln_score",
+        "min_anchor_len", "max_mismatch", "bfs_limit", "aln_tier", "min_aln_score",
         "max_comps", "max_haps", "max_hap_len", "max_runs", "max_vars", "max_alts",
         "max_allele_bytes", "max_cigar", "case_ctrl_mode")]
 
 
 def default_params(**kw):
-    p = Params(13, 127, 6, 2, 5, 2, 150, 2, 1 << 20, 64, 80, 4, 16, 2048, 256, 64, 4, 4096, 16, 1)
+    p = Params(13, 127, 6, 2, 5, 2, 150, 2, 1 << 20, 0, 80, 4, 16, 2048, 256, 64, 4, 4096, 16, 1)
     for k, v in kw.items():
         setattr(p, k, v)
     return p

@@ -2,8 +2,9 @@
 // traceback, the CIGAR-walk allele-scoring epilogue, evidence de-duplication and site QUAL.
 //
 // Replaces caller::Genotyper::Genotype (caller/genotyper.cpp:224-235): AlignToAllHaplotypes
-// (:376-411, minimap2 2.30 in the reference -- restated as the canonical seed-vote + banded overlap
-// DP of DESIGN.md, parity unpinned), AssignReadToAlleles (:269-362), ScoreReadAtVariant /
+// (:376-411, minimap2 2.30 in the reference -- restated as the canonical seed-anchored overlap DP of
+// the search region R = [vmin - K, vmax + K] is DERIVED from the seed diagonals, the
+// read length and min_aln_score, there is no band parameter), AssignReadToAlleles (:269-362), ScoreReadAtVariant /
 // ComputeLocalScore / ComputeSoftClipPenalty / ComputeEditDistance (caller/combined_scorer.cpp:24-108,
 // caller/local_scorer.cpp:166-305, hts/cigar_utils.h:48-139), AddToTable + VariantSupport::AddEvidence
 // (genotyper.cpp:423-456, caller/variant_support.cpp:24-30) and SomaticLogOddsRatio
@@ -12,13 +13,18 @@
 // Kernels:
 //   k_plan          per window: which haplotype slots get aligned, pair counts, the (window, haplotype) work list
 //   k_vote          workgroup per (window, haplotype): 11-mer chained index + haplotype bit planes in LDS; wave per
-//                   read: shared 11-mers vote for their diagonal (unanimous votes skip the histogram); arg-max =
-//                   band centre; the three gapless certificates settle 92 % of the pairs right here
-//   k_dp_partition  DP list reordered: pairs whose band can reach a haplotype end last
-//   k_align_reg     one LANE per pair (inter-task SIMD, no cross-lane traffic); the (H,F) band row packed i16x2 in
-//                   registers, row body fully unrolled (lean / general variant per wavefront and row), haplotype
-//                   segment 4 bit/base in LDS, traceback nibbles written to HBM coalesced as [row][word][lane];
-//                   per-lane traceback -> CIGAR.  k_align: the same with the band row in LDS, for band != 64
+//                   read: shared 11-mers vote for their diagonal (unanimous votes skip the histogram); the extreme
+//                   seed diagonals give the search region; the three gapless certificates settle most pairs right
+//                   here; the others are classified by the width of their region
+//   k_dp_scatter    DP list sorted by (width class, can the region reach a haplotype end)
+//   k_align_reg<W>  one LANE per pair (inter-task SIMD, no cross-lane traffic); the (H,F) row of the region packed
+//                   i16x2 in W+1 registers, row body fully unrolled (lean / general variant per wavefront and row),
+//                   haplotype segment 4 bit/base in LDS, traceback nibbles written to HBM coalesced as
+//                   [row][word][lane]; per-lane traceback -> CIGAR.  W = 33 .. 129 cells: a 150-base read needs 39 +
+//                   the spread of its seed diagonals.
+//   k_align_wave    one WAVEFRONT per pair for wider regions (seeds spread by tandem repeats / duplications): 64 cells
+//                   of a row at a time, the horizontal gap chain closed with a wave prefix maximum, rows in LDS
+//   k_align_gen     last resort for regions no LDS row holds: lane per pair, row in HBM
 //   k_assign     one lane per read: best allele per variant over the haplotypes of each component
 //   k_evidence   first read per (variant, sample, allele, qname) counts, by strand
 //   k_qual       SOLOR site quality
@@ -38,6 +44,7 @@ constexpr int SK = 11;                 // seed length (minimap2 -k 11 in the ref
 constexpr int kIdxCap = 4096;          // hash buckets per haplotype index (>= 2 * max_hap_len rounded)
 constexpr i32 GO = 12, GE = 3;         // scoring_constants.h:17-20
 constexpr i32 NEGS = -16000;           // "minus infinity" that survives i16 packing
+constexpr u32 kMinChainVotes = 4;      // exact 11-mers a chain of minimap2's min_chain_score 40 needs at least (oracle/align.cpp rule 2)
 __constant__ u64 c_phred_bits_a[256] = {
 #include "../../include/ma_phred_lut.inc"
 };
@@ -45,7 +52,19 @@ __constant__ u64 c_phred_bits_a[256] = {
 __constant__ i8 c_score_matrix[25] = {1, -4, -4, -4, 0, -4, 1, -4, -4, 0, -4, -4, 1, -4, 0,
                                       -4, -4, -4, 1, 0, 0, 0, 0, 0, 0};  // scoring_constants.h:35-41
 
+// Width classes of the DP kernels.  A pair whose region is wr diagonals wide runs in the first class that holds it.
+constexpr int kNumReg = 6;
+__host__ __device__ constexpr int reg_width(int c) {  // cells per row of k_align_reg's instantiations
+  return c == 0 ? 33 : c == 1 ? 41 : c == 2 ? 49 : c == 3 ? 65 : c == 4 ? 97 : 129;
+}
+// wider regions: one WAVEFRONT per pair (k_align_wave), two LDS footprints; the lane-per-pair kernel with its row in HBM
+// (k_align_gen) only for regions no LDS row holds
+constexpr int kClsWaveS = kNumReg, kClsWaveB = kNumReg + 1, kClsGlobal = kNumReg + 2, kNumCls = kNumReg + 3;
+constexpr int kNumKeys = 2 * kNumCls;  // key = class * 2 + (region can reach a haplotype end)
+constexpr u32 kWaveSmallW = 512;       // widest region of the small wavefront class
+
 struct AlnWs {
+  u32 wave_big_w;      // widest region the big wavefront class holds for this batch's longest read (host computed)
   // planning
   u32* win_slotmask;   // [n] bitmask of haplotype slots to align
   u64* pair_off;       // [n + 1]
@@ -53,18 +72,21 @@ struct AlnWs {
   u32* vote_wg;        // [n * MH] compact list of (window * MH + slot) to align against
   // haplotype seed index, per (window, slot)
   // per pair
-  i32* centre;         // [pairs in chunk]
+  i32* centre;         // [pairs in chunk] first diagonal of the pair's region (vmin - K), or a sentinel
+  u32* band_w;         // [pairs in chunk] width of the region in diagonals | key << 16
   u32* dp_list;        // [pairs in chunk] pairs that need the DP (compacted by k_vote)
-  u32* dp_count;       // device counter
+  u32* dp_count;       // device counters: [0] DP pairs, [4 ..] pairs per key, [40] widest region of the HBM class
   u32* tb;             // traceback nibbles
-  u32 tb_words;        // words per row
+  u32 tb_words;        // words per row (of the launch)
   u32 tb_rows;         // rows per pair (max read len + 1)
+  u32* gen_row;        // k_align_gen's (H,F) rows (HBM)
+  u32 gen_w;           // widest region of this k_align_gen / k_align_wave launch
+  unsigned long long* tbw;  // k_align_wave's traceback bit planes
   // evidence table per window
   u32 ev_cap;
   u64* ev_key;         // [n][ev_cap]
   u32* ev_min;         // [n][ev_cap]
   u8* asg_allele;      // [n_reads * MV] (internal copy when the caller passes NULL)
-  i32 band;
 };
 
 struct GArgs {
@@ -77,6 +99,7 @@ struct GArgs {
   u64 pair0;     // first global pair index of this chunk
   u32 npairs;    // pairs in this chunk
   u32 dp0;       // first dp_list entry of this DP launch
+  u32 dp_n;      // entries of this DP launch
 };
 
 __global__ void k_max_reads(DBatch b, u32* out) {
@@ -190,7 +213,7 @@ struct HapIdx {
   const u32* hbad;  // base j is not A/C/G/T
   u32* rplanes;     // this wave's read planes: [3][rwords]
   u32 rwords;
-  u32* dpbuf;       // this wave's pending DP pairs: [64] + count at [64]
+  u32* dpbuf;       // this wave's pending DP pairs: [64] + count at [64] + their keys at [65 .. 129)
   u32 hap_amb;      // the haplotype holds a base that is not A/C/G/T
 #ifdef MA_PROFILE
   unsigned long long* prof;  // this wave's phase cycle counters
@@ -217,6 +240,13 @@ __device__ __forceinline__ void vote_flush_dp(GArgs const& A, HapIdx ix, int lan
   if (lane == 0) base = atomicAdd(A.ws.dp_count, cnt);
   base = __shfl(base, 0);
   if (static_cast<u32>(lane) < cnt) A.ws.dp_list[base + lane] = ix.dpbuf[lane];
+  u32 const key = static_cast<u32>(lane) < cnt ? ix.dpbuf[65 + lane] : 0xFFFFFFFFu;
+  for (unsigned long long todo = __ballot(static_cast<u32>(lane) < cnt); todo;) {  // pairs per key: one atomic per key present
+    u32 const k0 = __shfl(key, __builtin_ctzll(todo));
+    unsigned long long const same = __ballot(key == k0);
+    if (lane == 0) atomicAdd(&A.ws.dp_count[4 + k0], static_cast<u32>(__popcll(same)));
+    todo &= ~same;
+  }
   __builtin_amdgcn_wave_barrier();
   if (lane == 0) ix.dpbuf[64] = 0;
   __builtin_amdgcn_wave_barrier();
@@ -246,8 +276,8 @@ __global__ __launch_bounds__(256) void k_vote(GArgs A, u32 hist_len, u32 rwords,
   u32* hhi = hlo + pw;
   u32* hbad = hhi + pw;
   u32* rplanes_all = hbad + pw;                            // [4 waves][3][rwords]
-  u32* dpbuf_all = rplanes_all + 12 * rwords;              // [4 waves][65]
-  u32* l_roff = dpbuf_all + 4 * 65;                        // [nr + 1] read byte offsets relative to the window's first read
+  u32* dpbuf_all = rplanes_all + 12 * rwords;              // [4 waves][129]
+  u32* l_roff = dpbuf_all + 4 * 129;                        // [nr + 1] read byte offsets relative to the window's first read
   size_t const hi = static_cast<size_t>(w) * A.prm.max_haps + slot;
   u32 const n = A.a.hap_len[hi];
   const u8* hb = A.a.hap_bases + hi * A.prm.max_hap_len;
@@ -255,7 +285,7 @@ __global__ __launch_bounds__(256) void k_vote(GArgs A, u32 hist_len, u32 rwords,
   for (u32 x = threadIdx.x; x < 4 * hist_len / 2; x += 256) reinterpret_cast<u32*>(hist_all)[x] = 0;
   u64 const roff0 = A.b.read_off[r0];
   for (u32 x = threadIdx.x; x <= nr; x += 256) l_roff[x] = static_cast<u32>(A.b.read_off[r0 + x] - roff0);
-  if (threadIdx.x < 4) dpbuf_all[threadIdx.x * 65 + 64] = 0;
+  if (threadIdx.x < 4) dpbuf_all[threadIdx.x * 129 + 64] = 0;
   // haplotype bases -> three bit planes (one coalesced byte load per base, wave ballots)
   for (u32 j0 = 0; j0 < pw * 32; j0 += 256) {
     u32 const j = j0 + threadIdx.x;
@@ -313,13 +343,13 @@ __global__ __launch_bounds__(256) void k_vote(GArgs A, u32 hist_len, u32 rwords,
   for (u32 x = lane; x < pw; x += 64) hap_amb |= hbad[x];
   hap_amb = __ballot(hap_amb != 0) ? 1u : 0u;
   HapIdx const ix{head, next, code, hlo, hhi, hbad, rplanes_all + static_cast<size_t>(wave) * 3 * rwords, rwords,
-                  dpbuf_all + wave * 65, hap_amb, sh_prof[wave]};
+                  dpbuf_all + wave * 129, hap_amb, sh_prof[wave]};
 #else
   u32 hap_amb = 0;
   for (u32 x = lane; x < pw; x += 64) hap_amb |= hbad[x];
   hap_amb = __ballot(hap_amb != 0) ? 1u : 0u;
   HapIdx const ix{head, next, code, hlo, hhi, hbad, rplanes_all + static_cast<size_t>(wave) * 3 * rwords, rwords,
-                  dpbuf_all + wave * 65, hap_amb};
+                  dpbuf_all + wave * 129, hap_amb};
 #endif
   u16* hist = hist_all + static_cast<size_t>(wave) * hist_len;
   // software pipeline: the next read's bases are in flight while the current read is voted
@@ -367,6 +397,7 @@ __device__ __forceinline__ void vote_pair(GArgs const& A, u64 lp, PairId id, Hap
   i32 const n = static_cast<i32>(A.a.hap_len[hi]);
   const u8* rb = A.b.read_bases + ro;
   i32 const nd = m + n + 1;  // diagonals d in [-m, n] -> hist[d + m]
+  i32 const Kr = m - A.prm.min_aln_score - GO > 0 ? (m - A.prm.min_aln_score - GO) / GE : 0;  // reach K of the search region
   const u16* head = ix.head;
   const u16* next = ix.next;
   const u32* code = ix.code;
@@ -439,6 +470,7 @@ __device__ __forceinline__ void vote_pair(GArgs const& A, u64 lp, PairId id, Hap
   u32 nvotes = 0;  // this lane's votes; summed over the wave further down
   u32 best = 0, v2 = 0;
   i32 bd = 0x7FFFFFFF;
+  i32 dlo = 0x7FFFFFFF, dhi = -1;  // extreme diagonals that received a vote (histogram index: diagonal + m)
   bool unan = !(seeded && m - SK + 1 > 64 * kPos);  // long reads vote outside the cached positions
   u32 ucnt = 0;
   i32 u_d = -1;
@@ -467,6 +499,7 @@ __device__ __forceinline__ void vote_pair(GArgs const& A, u64 lp, PairId id, Hap
   if (unan) {
     best = ucnt;
     bd = ucnt ? u_d : 0x7FFFFFFF;
+    if (ucnt >= kMinChainVotes) dlo = dhi = u_d;  // one seeded diagonal: an anchor iff it holds the whole chain minimum
     if (lane == 0) nvotes = ucnt;
     VPROF_ACC(1);
     VPROF_ACC(2);
@@ -519,6 +552,14 @@ __device__ __forceinline__ void vote_pair(GArgs const& A, u64 lp, PairId id, Hap
         best = v;
         bd = d;
       }
+      // anchor diagonal (oracle/align.cpp rule 2): >= kMinChainVotes votes within reach K of it
+      u32 sum = v;
+      if (sum < kMinChainVotes)
+        for (i32 y = max(d - Kr, 0); y <= min(d + Kr, nd - 1) && sum < kMinChainVotes; ++y) sum += y != d ? hist[y] : 0u;
+      if (sum >= kMinChainVotes) {
+        dlo = min(dlo, d);
+        dhi = max(dhi, d);
+      }
     });
     for (int off = 32; off > 0; off >>= 1) {
       u32 const ob = __shfl_xor(best, off);
@@ -527,6 +568,8 @@ __device__ __forceinline__ void vote_pair(GArgs const& A, u64 lp, PairId id, Hap
         best = ob;
         bd = od;
       }
+      dlo = min(dlo, __shfl_xor(dlo, off));
+      dhi = max(dhi, __shfl_xor(dhi, off));
     }
     VPROF_ACC(2);
     // second best (any other diagonal), then restore the all-zero histogram
@@ -540,8 +583,7 @@ __device__ __forceinline__ void vote_pair(GArgs const& A, u64 lp, PairId id, Hap
     __builtin_amdgcn_wave_barrier();
     VPROF_ACC(4);
   }
-  (void)nd;
-  if (best == 0) {  // no shared 11-mer: no hit
+  if (best == 0 || dhi < 0) {  // no shared 11-mer, or only stray ones that anchor no chain: no hit
     if (lane == 0) {
       A.ws.centre[lp] = 0x7FFFFFFF;
       write_no_hit(A, id);
@@ -549,12 +591,22 @@ __device__ __forceinline__ void vote_pair(GArgs const& A, u64 lp, PairId id, Hap
     return;
   }
   i32 const c = bd - m;
+  // ---- search region (oracle/align.cpp rule 3) ---------------------------------
+  // cost(P) = m - score(P): every read row costs >= 0 and a gap shifting the diagonal by s costs >= 12 + 3 s, so a hit
+  // (score >= min_aln_score) through a seed on diagonal d stays within [d - K, d + K]: R = [vmin - K, vmax + K].
+  i32 const ms = A.prm.min_aln_score;
+  i32 const K = Kr;
+  i32 const vmin = dlo - m, vmax = dhi - m;
+  i32 const r_lo = vmin - K;
+  u32 const r_w = static_cast<u32>(vmax - vmin + 2 * K + 1);
   // ---- gapless certificates ------------------------------------------------------------------------
-  // P0 = the gapless path on the voted diagonal c (read rows [qs, qe) against haplotype columns [rs, re)),
+  // P0 = the gapless path on the most-voted diagonal c (read rows [qs, qe) against haplotype columns [rs, re)),
   // X its mismatches, S0 = (qe - qs) - 5 X.  Scores: match +1, mismatch -4, a gap of length L costs 12 + 3 L.
+  // (I) and (II) show that P0 beats EVERY other overlap alignment of the two sequences, inside R or not; c is a seed
+  // diagonal, so P0 lies in R and is the canonical answer.
   //
   // (I) read fully inside the haplotype (no overhang), X <= 2, no ambiguous base on P0, and no other
-  //     diagonal with >= m - 10 - 11 X votes: P0 is the UNIQUE optimum of the banded overlap DP:
+  //     diagonal with >= m - 10 - 11 X votes: P0 is the UNIQUE optimum:
   //   * any path with g >= 1 gaps scores <= m - 15 g < m - 5 X;
   //   * a gapless path on another diagonal d' scoring >= m - 5 X has X' <= X mismatches over >= m - 5X + 5X'
   //     bases, hence >= m - 10 - 11 X exact 11-mers, i.e. that many votes -- excluded by the vote bound.
@@ -572,13 +624,13 @@ __device__ __forceinline__ void vote_pair(GArgs const& A, u64 lp, PairId id, Hap
   //     score <= L - 5 sum x_s - 15 g <= (6 m + 50 (g+1) + 5 V_off) / 11 - 15 g <= (6 m + 50 + 5 V_off) / 11 < S0.
   //   Every prefix of a unique optimum is optimal for its end cell, so the traceback's diagonal-first rule
   //   retraces P0 down to the start cell, and no other end cell reaches S0.
-  // (III) NO HIT: the read overhangs one end, nothing is ambiguous, and no path can reach min_aln_score:
+  // (III) NO HIT: the read overhangs one end, nothing is ambiguous, and no path INSIDE R can reach min_aln_score:
   //   * paths touching c score <= max(S0, L0 - 14) with L0 = qe - qs (first bullet of (II), any X);
-  //   * paths avoiding c pair at most Lmax = min(m, L0 + band) rows (the band keeps them within `band`
-  //     diagonals of c, so the rows that hang further out than that can not be paired at all), hence score
-  //     <= (6 Lmax + 50 + 5 V_off) / 11 by the second bullet of (II).
+  //   * paths avoiding c stay on diagonals of R; with a left overhang diagonal d pairs rows [max(0, -d), m), so all of
+  //     them together pair at most Lmax = min(m, L0 + (vmax + K - c)) rows (right overhang: L0 + (c - vmin + K)),
+  //     hence score <= (6 Lmax + 50 + 5 V_off) / 11 by the second bullet of (II).
   // In cases (I)/(II) (score, rs, re, qs, qe, CIGAR) is written without running the DP, in case (III) the
-  // record stays "no alignment"; everything else goes to k_align.
+  // record stays "no alignment"; everything else goes to the DP kernels.
   i32 const o_left = c < 0 ? -c : 0, o_right = c + m > n ? c + m - n : 0;
   bool const inside = o_left == 0 && o_right == 0;
   i32 const qs = o_left, qe = m - o_right;  // overlap rows [qs, qe)
@@ -610,13 +662,14 @@ __device__ __forceinline__ void vote_pair(GArgs const& A, u64 lp, PairId id, Hap
   i32 const X = static_cast<i32>(mism);
   i32 const S0 = (qe - qs) - 5 * X;
   i32 const v_off = static_cast<i32>(vtot) - static_cast<i32>(best);
-  bool const ok_common = !amb && X <= 2 && S0 >= A.prm.min_aln_score && m < (1 << 27);
+  bool const certs = !(A.prm.aln_tier & 2);
+  bool const ok_common = certs && !amb && X <= 2 && S0 >= ms && m < (1 << 27);
   bool const fast_in = inside && ok_common && static_cast<i32>(v2) + 10 + 11 * X < m;
   bool const fast_ov = !inside && (o_left == 0 || o_right == 0) && ok_common && !ramb && !ix.hap_amb &&
                        11 * S0 > 6 * m + 50 + 5 * v_off && A.prm.max_cigar >= 2;
   bool const fast = fast_in || fast_ov;
-  i32 const L0 = qe - qs, lmax = min(m, L0 + A.ws.band), ms = A.prm.min_aln_score;
-  bool const nohit = !inside && (o_left == 0 || o_right == 0) && !ramb && !ix.hap_amb && S0 < ms && L0 - 14 < ms &&
+  i32 const L0 = qe - qs, lmax = min(m, L0 + K + (o_left ? vmax - c : c - vmin));
+  bool const nohit = certs && !inside && (o_left == 0 || o_right == 0) && !ramb && !ix.hap_amb && S0 < ms && L0 - 14 < ms &&
                      6 * lmax + 50 + 5 * v_off < 11 * ms;
   if (lane == 0) {
     if (nohit) {
@@ -640,8 +693,21 @@ __device__ __forceinline__ void vote_pair(GArgs const& A, u64 lp, PairId id, Hap
       acig[0] = nc;
       A.ws.centre[lp] = 0x7FFFFFFE;
     } else {
-      A.ws.centre[lp] = c;
-      ix.dpbuf[ix.dpbuf[64]++] = static_cast<u32>(lp);
+      // width class of the region; can a row of the kernel's window reach column 0 or n (+ the 7 columns the last
+      // segment word carries beyond it)?  k_align_reg picks its row body per wavefront, so the two kinds are kept apart
+      int cls = kNumReg;
+      if (!(A.prm.aln_tier & 1))
+        for (cls = 0; cls < kNumReg && r_w > static_cast<u32>(reg_width(cls)); ++cls) {}
+      if (cls == kNumReg) cls = r_w <= kWaveSmallW ? kClsWaveS : (r_w <= A.ws.wave_big_w ? kClsWaveB : kClsGlobal);
+      i32 const kw = cls < kNumReg ? reg_width(cls) : static_cast<i32>(r_w);
+      u32 const wall = (r_lo >= 0 && r_lo + kw + m + 8 <= n) ? 0u : 1u;
+      u32 const key = static_cast<u32>(cls) * 2u + wall;
+      if (cls == kClsGlobal) atomicMax(&A.ws.dp_count[40], r_w);
+      A.ws.centre[lp] = r_lo;
+      A.ws.band_w[lp] = r_w | (key << 16);
+      u32 const at = ix.dpbuf[64]++;
+      ix.dpbuf[at] = static_cast<u32>(lp);
+      ix.dpbuf[65 + at] = key;
     }
   }
   __builtin_amdgcn_wave_barrier();
@@ -666,10 +732,12 @@ namespace ma {
 namespace {
 #endif
 
-// traceback shared by both alignment kernels (rules of oracle/align.cpp: diagonal, then E, then F;
-// prefer opening a gap) + BuildCigar (genotyper.cpp:45-69)
-__device__ void align_traceback(GArgs const& A, const u32* tb, int lane, i32 B, i32 c, i32 m, i32 best, i32 bi, i32 bj,
-                                i32* arec, u32* acig) {
+// traceback shared by the alignment kernels (rules of oracle/align.cpp: diagonal, then E, then F;
+// prefer opening a gap) + BuildCigar (genotyper.cpp:45-69).  fetch(i, t) returns the move nibble of cell (i, j),
+// t = j - i - lo: bits 0-1 source of H (0 diagonal, 1 E, 2 F), bit 2 E opened here, bit 3 F opened here.
+template <class Fetch>
+__device__ void align_traceback(GArgs const& A, Fetch fetch, i32 lo, i32 m, i32 best, i32 bi, i32 bj, i32* arec, u32* acig,
+                                bool write) {
   int const MCG = A.prm.max_cigar;
   u32 ops[64];   // reversed run-length ops, len << 4 | op
   int nops = 0;
@@ -684,11 +752,11 @@ __device__ void align_traceback(GArgs const& A, const u32* tb, int lane, i32 B, 
   };
   i32 i = bi, j = bj;
   int state = 0;
-  while (true) {
+  // every step consumes a row or a column or leaves a gap state; the bound only matters if a tile were ever corrupt
+  for (i32 guard = 2 * (bi + bj) + 8; guard > 0; --guard) {
     if (state == 0 && (i == 0 || j == 0)) break;
-    i32 const t = j - i - c + B;
-    u32 const wv = tb[(static_cast<size_t>(i) * A.ws.tb_words + (t >> 3)) * 64 + lane];
-    u32 const nib = (wv >> (4 * (t & 7))) & 0xFu;
+    if (i < 0 || j < 0) break;
+    u32 const nib = fetch(i, j - i - lo);
     if (state == 0) {
       u32 const src = nib & 3u;
       if (src == 0) {
@@ -708,6 +776,7 @@ __device__ void align_traceback(GArgs const& A, const u32* tb, int lane, i32 B, 
       if (nib & 8u) state = 0;
     }
   }
+  if (!write) return;
   i32 const qs = i, rs = j, qe = bi, re = bj;
   arec[0] = 1;
   arec[1] = best;
@@ -729,80 +798,226 @@ __device__ void align_traceback(GArgs const& A, const u32* tb, int lane, i32 B, 
   acig[0] = (nops > 64) ? (total_ops + (qs > 0) + (qe < m)) : ncig;
 }
 
+// one DP pair of a launch: its sequences and its search region
+struct DpPair {
+  PairId id;
+  i32 m, n, lo, wr;
+  const u8* rb;
+  const u8* hb;
+  bool live, active;
+};
+__device__ __forceinline__ DpPair dp_pair_load(GArgs const& A, u32 li) {
+  DpPair p{};
+  p.live = li < A.dp_n;
+  if (!p.live) return p;
+  u64 const lp = A.ws.dp_list[A.dp0 + li];
+  p.id = pair_decode(A, A.pair0 + lp);
+  size_t const hi = static_cast<size_t>(p.id.w) * A.prm.max_haps + p.id.slot;
+  p.n = static_cast<i32>(A.a.hap_len[hi]);
+  p.hb = A.a.hap_bases + hi * A.prm.max_hap_len;
+  u64 const ro = A.b.read_off[p.id.r];
+  p.m = static_cast<i32>(A.b.read_off[p.id.r + 1] - ro);
+  p.rb = A.b.read_bases + ro;
+  p.lo = A.ws.centre[lp];
+  p.wr = static_cast<i32>(A.ws.band_w[lp] & 0xFFFFu);
+  p.active = p.m >= SK && p.n >= SK && static_cast<u32>(p.m) + 1 <= A.ws.tb_rows;
+  return p;
+}
+__device__ __forceinline__ void dp_pair_store(GArgs const& A, DpPair const& p, const u32* tb, int lane, i32 best, i32 bi,
+                                              i32 bj) {
+  if (!p.live) return;
+  size_t const rec = static_cast<size_t>(p.id.r) * A.prm.max_haps + p.id.slot;
+  i32* arec = A.o.aln_rec + rec * 6;
+  u32* acig = A.o.aln_cigar + rec * (1 + A.prm.max_cigar);
+  bool const hit = p.active && bi >= 0 && best >= A.prm.min_aln_score;
+  if (!hit) {
+    for (int x = 0; x < 6; ++x) arec[x] = 0;
+    acig[0] = 0;
+    return;
+  }
+  u32 const tbw = A.ws.tb_words;
+  align_traceback(
+      A,
+      [&](i32 i, i32 t) {
+        u32 const wv = tb[(static_cast<size_t>(i) * tbw + (t >> 3)) * 64 + lane];
+        return (wv >> (4 * (t & 7))) & 0xFu;
+      },
+      p.lo, p.m, best, bi, bj, arec, acig, true);
+}
 
-// ---- banded overlap DP + traceback: one lane per pair ----
-__global__ __launch_bounds__(64) void k_align(GArgs A, u32 seg_words) {
+// ---- overlap DP over a WIDE region: one wavefront per pair ----
+// Seeds spread over hundreds of diagonals (tandem repeats, segmental duplications) make regions far wider than a
+// register row.  Here the 64 lanes walk a row 64 cells at a time: everything but the horizontal gap chain is
+// independent per cell, and the chain E(t) = max_{t' < t} (B(t') + 3 t') - 12 - 3 t over the best non-horizontal
+// entries B is one wave-wide prefix maximum plus a carry between the 64-cell chunks (the recurrence
+// E(t) = max(H(t-1) - 15, E(t-1) - 3) unrolled: opening from a cell whose H is its own E never beats extending it).
+// The previous row (H, F per cell) and the encoded sequences live in LDS; the move bits go to HBM as four 64-bit
+// ballots per chunk.  Same cell rules, tie rules and outputs as the lane-per-pair kernels.
+constexpr i32 NEGW = -(1 << 28);
+__device__ __forceinline__ i32 wave_excl_prefix_max(i32 v, int lane) {  // max over the lanes below this one (NEGW for lane 0)
+  i32 x = __shfl_up(v, 1, 64);
+  x = lane >= 1 ? x : NEGW;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    i32 const y = __shfl_up(x, o, 64);
+    x = lane >= o ? max(x, y) : x;
+  }
+  return x;
+}
+__global__ __launch_bounds__(64) void k_align_wave(GArgs A, u32 nchunk_alloc) {
   extern __shared__ u32 lds[];
   int const lane = threadIdx.x;
-  i32 const B = A.ws.band, WD = 2 * B + 1;
-  u32* HF = lds;                                 // [WD + 1][64] packed (H lo16, F hi16)
-  u32* SEG = lds + static_cast<size_t>(WD + 1) * 64;  // [seg_words][64] haplotype segment, 4 bit/base
-  u64 const li = static_cast<u64>(A.dp0) + static_cast<u64>(blockIdx.x) * 64 + lane;
-  bool const live = li < *A.ws.dp_count;
-  u64 const lp = live ? A.ws.dp_list[li] : 0;
-  PairId id{0, 0, 0};
-  i32 m = 0, n = 0, c = 0;
-  const u8* rb = nullptr;
-  const u8* hb = nullptr;
-  bool active = false;
-  if (live) {
-    id = pair_decode(A, A.pair0 + lp);
-    size_t const hi = static_cast<size_t>(id.w) * A.prm.max_haps + id.slot;
-    n = static_cast<i32>(A.a.hap_len[hi]);
-    hb = A.a.hap_bases + hi * A.prm.max_hap_len;
-    u64 const ro = A.b.read_off[id.r];
-    m = static_cast<i32>(A.b.read_off[id.r + 1] - ro);
-    rb = A.b.read_bases + ro;
-    c = A.ws.centre[lp];
-    active = c != 0x7FFFFFFF && m >= SK && n >= SK && static_cast<u32>(m) + 1 <= A.ws.tb_rows;
+  u32 const pi = blockIdx.x;
+  if (pi >= A.dp_n) return;
+  u64 const lp = A.ws.dp_list[A.dp0 + pi];
+  PairId const id = pair_decode(A, A.pair0 + lp);
+  size_t const hidx = static_cast<size_t>(id.w) * A.prm.max_haps + id.slot;
+  i32 const n = static_cast<i32>(A.a.hap_len[hidx]);
+  const u8* hb = A.a.hap_bases + hidx * A.prm.max_hap_len;
+  u64 const ro = A.b.read_off[id.r];
+  i32 const m = static_cast<i32>(A.b.read_off[id.r + 1] - ro);
+  const u8* rb = A.b.read_bases + ro;
+  i32 const lo = A.ws.centre[lp];
+  i32 const wr = static_cast<i32>(A.ws.band_w[lp] & 0xFFFFu);
+  size_t const rec = static_cast<size_t>(id.r) * A.prm.max_haps + id.slot;
+  i32* arec = A.o.aln_rec + rec * 6;
+  u32* acig = A.o.aln_cigar + rec * (1 + A.prm.max_cigar);
+  bool const active = m >= SK && n >= SK && static_cast<u32>(m) + 1 <= A.ws.tb_rows;
+  if (!active) {
+    if (lane < 6) arec[lane] = 0;
+    if (lane == 0) acig[0] = 0;
+    return;
   }
-  i32 const mrows = active ? m : 0;
-  // wave-uniform row count
-  i32 mmax = mrows;
-  for (int off = 32; off > 0; off >>= 1) mmax = max(mmax, __shfl_xor(mmax, off));
-
-  // haplotype segment: bases hap[j0 .. j0 + seglen) with j0 = c - B (0-based base index j-1 for cell j)
-  // cell (i, t) uses hap base index (j - 1) = i + c - B + t - 1  ->  rel = (i - 1) + t  in [0, m + 2B)
-  i32 const j0 = c - B;  // hap base index of rel 0
-  if (active) {
-    i32 const seglen = m + 2 * B + 1;
-    for (i32 wd = 0; wd * 8 < seglen; ++wd) {
-      u32 pk = 0;
-      for (int x = 0; x < 8; ++x) {
-        i32 const hbidx = j0 + wd * 8 + x;
-        u32 const e = (hbidx >= 0 && hbidx < n) ? enc_base(hb[hbidx]) : 4u;
-        pk |= e << (4 * x);
+  u32 const GW = A.ws.gen_w;
+  i32* Hrow = reinterpret_cast<i32*>(lds);          // [GW + 2] previous row, updated in place
+  i32* Frow = Hrow + GW + 2;                         // [GW + 2]
+  u8* hcode = reinterpret_cast<u8*>(Frow + GW + 2);  // [m + wr + 1] haplotype codes of base indices lo - 1 ... (5: outside)
+  u8* qcode = hcode + ((m + wr + 4) & ~3);           // [m]
+  for (i32 x = lane; x < m + wr + 1; x += 64) {
+    i32 const hbidx = lo - 1 + x;
+    hcode[x] = static_cast<u8>((hbidx >= 0 && hbidx < n) ? enc_base(hb[hbidx]) : 5u);
+  }
+  for (i32 x = lane; x < m; x += 64) qcode[x] = static_cast<u8>(enc_base(rb[x]));
+  // row 0: H = 0 for 0 <= j <= n inside the region; F = minus infinity
+  for (i32 t = lane; t <= wr; t += 64) {
+    i32 const j = lo + t;
+    Hrow[t] = (t < wr && j >= 0 && j <= n) ? 0 : NEGW;
+    Frow[t] = NEGW;
+  }
+  __builtin_amdgcn_wave_barrier();
+  i32 const nchunk = (wr + 63) >> 6;
+  unsigned long long* tile = A.ws.tbw + static_cast<size_t>(pi) * A.ws.tb_rows * nchunk_alloc * 4;
+  i32 best = NEGW, bi = -1, bj = -1;  // per lane; reduced at the end
+  for (i32 i = 1; i <= m; ++i) {
+    u32 const qi = qcode[i - 1];
+    i32 carry = NEGW;                  // max of B(t') + 3 t' over the cells of the chunks before this one
+    i32 left_h = NEGW, left_e = NEGW;  // H, E of the last cell of the chunk before this one
+    for (i32 c = 0; c < nchunk; ++c) {
+      i32 const t = (c << 6) + lane, j = i + lo + t;
+      bool const inreg = t < wr;
+      i32 const tt = inreg ? t : wr;  // clamp: cell wr is the minus-infinity sentinel
+      i32 const oh = Hrow[tt], uh = Hrow[tt + (inreg ? 1 : 0)], uf = Frow[tt + (inreg ? 1 : 0)];
+      u32 const hc = inreg ? hcode[i + t] : 5u;  // base index (j - 1) = lo - 1 + (i + t)
+      i32 const s = (qi > 3 || hc > 3) ? -1 : (qi == hc ? 1 : -4);
+      bool const cell = inreg && j >= 1 && j <= n;  // an ordinary cell; (i, 0) is a free start, the rest does not exist
+      i32 const dg = oh + s;
+      i32 const fo = uh - (GO + GE), fe = uf - GE;
+      i32 const f = cell ? max(fo, fe) : NEGW;
+      i32 const bnh = cell ? max(dg, f) : ((inreg && j == 0) ? 0 : NEGW);  // best non-horizontal entry
+      i32 const g = bnh + GE * t;
+      i32 const pm = max(carry, wave_excl_prefix_max(g, lane));
+      i32 const e = cell ? pm - GO - GE * t : NEGW;
+      i32 const h = max(bnh, e);
+      // H, E of the left neighbour for the "gap opened here" bit
+      i32 hl = __shfl_up(h, 1, 64), el = __shfl_up(e, 1, 64);
+      hl = lane ? hl : left_h;
+      el = lane ? el : left_e;
+      i32 const eo = hl - (GO + GE), ee = el - GE;
+      u32 nib = (dg >= e && dg >= f) ? 0u : (e >= f ? 1u : 2u);
+      nib |= (eo >= ee ? 4u : 0u) | (fo >= fe ? 8u : 0u);
+      __builtin_amdgcn_wave_barrier();  // every lane has read the old row before anyone overwrites it
+      if (inreg) {
+        Hrow[t] = h;
+        Frow[t] = f;
       }
-      SEG[static_cast<size_t>(wd) * 64 + lane] = pk;
+      unsigned long long const b0 = __ballot(nib & 1u), b1 = __ballot(nib & 2u), b2 = __ballot(nib & 4u), b3 = __ballot(nib & 8u);
+      if (lane < 4) tile[(static_cast<size_t>(i) * nchunk_alloc + c) * 4 + lane] = lane == 0 ? b0 : (lane == 1 ? b1 : (lane == 2 ? b2 : b3));
+      carry = max(carry, __shfl(max(pm, g), 63, 64));
+      left_h = __shfl(h, 63, 64);
+      left_e = __shfl(e, 63, 64);
+      // end cells: (m, j) for any j, (i, n) for i < m
+      if (inreg && j >= 0 && j <= n && (i == m || j == n)) {
+        if (h > best || (h == best && (i > bi || (i == bi && j < bj)))) {
+          best = h;
+          bi = i;
+          bj = j;
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
     }
-    // row 0: H = 0 for 0 <= j <= n, else NEG; F = NEG
-    for (i32 t = 0; t <= WD; ++t) {
-      i32 const j = c - B + t;
-      i32 const h = (t < WD && j >= 0 && j <= n) ? 0 : NEGS;
-      HF[static_cast<size_t>(t) * 64 + lane] = (static_cast<u32>(h) & 0xFFFFu) | (static_cast<u32>(NEGS) << 16);
+  }
+  for (int off = 32; off > 0; off >>= 1) {  // best end cell of the wave: max score, ties -> larger i, then smaller j
+    i32 const ob = __shfl_xor(best, off), oi = __shfl_xor(bi, off), oj = __shfl_xor(bj, off);
+    if (ob > best || (ob == best && (oi > bi || (oi == bi && oj < bj)))) {
+      best = ob;
+      bi = oi;
+      bj = oj;
     }
+  }
+  bool const hit = bi >= 0 && best >= A.prm.min_aln_score;
+  if (!hit) {
+    if (lane < 6) arec[lane] = 0;
+    if (lane == 0) acig[0] = 0;
+    return;
+  }
+  // the traceback is a serial walk; every lane follows it (uniform loads), lane 0 writes the record
+  align_traceback(
+      A,
+      [&](i32 ri, i32 t) {
+        const unsigned long long* q = tile + (static_cast<size_t>(ri) * nchunk_alloc + (t >> 6)) * 4;
+        u32 const sh = static_cast<u32>(t) & 63u;
+        return static_cast<u32>(((q[0] >> sh) & 1ull) | (((q[1] >> sh) & 1ull) << 1) | (((q[2] >> sh) & 1ull) << 2) |
+                                (((q[3] >> sh) & 1ull) << 3));
+      },
+      lo, m, best, bi, bj, arec, acig, lane == 0);
+}
+
+// ---- last resort: a region no LDS row holds (more than ~7000 diagonals); one lane per pair, the (H,F) row in HBM ----
+__global__ __launch_bounds__(64) void k_align_gen(GArgs A) {
+  int const lane = threadIdx.x;
+  u32 const GW = A.ws.gen_w;  // widest region of the launch: row stride
+  u32* HF = A.ws.gen_row + static_cast<size_t>(blockIdx.x) * (GW + 1) * 64;  // [GW + 1][64] packed (H lo16, F hi16)
+  DpPair const P = dp_pair_load(A, blockIdx.x * 64u + lane);
+  i32 const m = P.m, n = P.n, lo = P.lo;
+  i32 const mrows = P.active ? m : 0, wr = P.active ? P.wr : 0;
+  i32 mmax = mrows, wmax = wr;  // wave-uniform loop bounds
+  for (int off = 32; off > 0; off >>= 1) {
+    mmax = max(mmax, __shfl_xor(mmax, off));
+    wmax = max(wmax, __shfl_xor(wmax, off));
+  }
+  // row 0: H = 0 for 0 <= j <= n inside the region, else NEG; F = NEG.  Cells t >= wr (other lanes' wider regions, and
+  // the sentinel t = wmax) stay NEG for good: nothing ever flows out of them.
+  for (i32 t = 0; t <= wmax; ++t) {
+    i32 const j = lo + t;
+    i32 const h = (t < wr && j >= 0 && j <= n) ? 0 : NEGS;
+    HF[static_cast<size_t>(t) * 64 + lane] = (static_cast<u32>(h) & 0xFFFFu) | (static_cast<u32>(NEGS) << 16);
   }
   size_t const tb_base = static_cast<size_t>(blockIdx.x) * A.ws.tb_rows * A.ws.tb_words * 64;
   u32* tb = A.ws.tb + tb_base;
   i32 best = NEGS, bi = -1, bj = -1;
-  if (active) {  // end cells on row 0: (0, n) -- only if m == 0 (never); nothing to do
-  }
   for (i32 i = 1; i <= mmax; ++i) {
     if (i <= mrows) {
-      u32 const qi = enc_base(rb[i - 1]);
-      i32 lh = NEGS, le = NEGS;  // H, E of the cell to the left (out of band at t == 0)
+      u32 const qi = enc_base(P.rb[i - 1]);
+      i32 lh = NEGS, le = NEGS;  // H, E of the cell to the left (outside the region at t == 0)
       u32 word = 0;
-      i32 rel = i - 1;
-      u32 segw = SEG[static_cast<size_t>(rel >> 3) * 64 + lane];
       u32 nxt = HF[lane];  // HF[t] of the previous row, pre-loaded
-      for (i32 t = 0; t < WD; ++t, ++rel) {
-        if ((rel & 7) == 0 && t > 0) segw = SEG[static_cast<size_t>(rel >> 3) * 64 + lane];
+      for (i32 t = 0; t < wr; ++t) {
         u32 const cur = nxt;
         nxt = HF[static_cast<size_t>(t + 1) * 64 + lane];
         i32 const dh = static_cast<i16>(cur & 0xFFFFu);
         i32 const uh = static_cast<i16>(nxt & 0xFFFFu), uf = static_cast<i16>(nxt >> 16);
-        i32 const j = i + c - B + t;
-        u32 const tbse = (segw >> (4 * (rel & 7))) & 0xFu;
+        i32 const j = i + lo + t;
+        u32 const tbse = (j >= 1 && j <= n) ? enc_base(P.hb[j - 1]) : 4u;
         i32 const s = (qi > 3 || tbse > 3) ? -1 : (qi == tbse ? 1 : -4);
         i32 const eo = lh - (GO + GE), ee = le - GE;
         i32 const fo = uh - (GO + GE), fe = uf - GE;
@@ -824,7 +1039,7 @@ __global__ __launch_bounds__(64) void k_align(GArgs A, u32 seg_words) {
         lh = h;
         le = e;
         word |= nib << (4 * (t & 7));
-        if ((t & 7) == 7 || t == WD - 1) {
+        if ((t & 7) == 7 || t == wr - 1) {
           tb[(static_cast<size_t>(i) * A.ws.tb_words + (t >> 3)) * 64 + lane] = word;
           word = 0;
         }
@@ -839,101 +1054,67 @@ __global__ __launch_bounds__(64) void k_align(GArgs A, u32 seg_words) {
       }
     }
   }
-  if (!live) return;
-  // ---- result record ----
-  int const MH = A.prm.max_haps, MCG = A.prm.max_cigar;
-  size_t const rec = (static_cast<size_t>(id.r) * MH + id.slot);
-  i32* arec = A.o.aln_rec + rec * 6;
-  u32* acig = A.o.aln_cigar + rec * (1 + MCG);
-  bool const hit = active && bi >= 0 && best >= A.prm.min_aln_score;
-  if (!hit) {
-    for (int x = 0; x < 6; ++x) arec[x] = 0;
-    acig[0] = 0;
-    return;
-  }
-  align_traceback(A, tb, lane, B, c, m, best, bi, bj, arec, acig);
+  dp_pair_store(A, P, tb, lane, best, bi, bj);
 }
 
-// ---- register-resident variant of k_align for the default band (B = 64) ----
-// The (H,F) band row lives in 2B+2 VGPRs (packed i16x2) and the row body is fully unrolled, so the
-// inner loop is pure VALU: no LDS round trip for the DP state, ~2 waves per SIMD.  The haplotype
-// segment (4 bit/base, with wall codes 6 = "column 0", 7 = "outside the haplotype") stays in LDS and
-// is re-aligned once per row with funnel shifts.  Same cell rules, tie rules and outputs as k_align.
+// ---- register-resident kernel for regions of up to W diagonals ----
+// The (H,F) row lives in W+1 VGPRs (packed i16x2) and the row body is fully unrolled, so the inner loop is pure VALU: no
+// LDS round trip for the DP state.  The haplotype segment (4 bit/base, with wall codes 6 = "column 0", 7 = "outside the
+// haplotype") stays in LDS and is re-aligned once per row with funnel shifts.  Same cell rules, tie rules and outputs as
+// k_align_gen.  A pair's region may be narrower than the W cells of its class (wr in (WLO, W]): the first cell outside
+// it, t = wr, is reset to "minus infinity" after every row -- a cell t only ever reads cells t and t + 1 of the row above
+// and its left neighbour, so whatever the cells t > wr compute never reaches a cell of the region, and only the
+// positions t in (WLO, W) carry the test.
 constexpr i32 NEGR = -20000;
-// Interior pairs first, pairs whose band can reach a haplotype end last: k_align_reg picks its row body per
-// WAVEFRONT (the lean one needs every pair of the wavefront to stay clear of the haplotype ends), so the two kinds
-// must not be interleaved.  Order inside the list never affects a result (every pair is independent).
-__global__ __launch_bounds__(256) void k_dp_partition(GArgs A, u32 ndp, u32* out, u32* cnt2) {
+// DP list sorted by key = class * 2 + wall (order inside a key never affects a result: every pair is independent)
+struct KeyBase { u32 b[kNumKeys]; };
+__global__ __launch_bounds__(256) void k_dp_scatter(GArgs A, u32 ndp, u32* out, u32* fill, KeyBase kb) {
   u32 const li = blockIdx.x * 256u + threadIdx.x, lane = threadIdx.x & 63u;
   bool const live = li < ndp;
-  u32 lp = 0;
-  bool interior = false;
+  u32 lp = 0, key = 0xFFFFFFFFu;
   if (live) {
     lp = A.ws.dp_list[li];
-    PairId const id = pair_decode(A, A.pair0 + lp);
-    size_t const hi = static_cast<size_t>(id.w) * A.prm.max_haps + id.slot;
-    i32 const n = static_cast<i32>(A.a.hap_len[hi]);
-    i32 const m = static_cast<i32>(A.b.read_off[id.r + 1] - A.b.read_off[id.r]);
-    i32 const c = A.ws.centre[lp], band = A.ws.band;
-    // no band row reaches column -1 or n (+ the 7 columns the last segment word carries beyond the band)
-    interior = c >= band && c + m + band + 8 <= n;
+    key = A.ws.band_w[lp] >> 16;
   }
-  unsigned long long const mi = __ballot(live && interior), me = __ballot(live && !interior);
-  u32 bi = 0, be = 0;
-  if (lane == 0) {
-    if (mi) bi = atomicAdd(&cnt2[0], static_cast<u32>(__popcll(mi)));
-    if (me) be = atomicAdd(&cnt2[1], static_cast<u32>(__popcll(me)));
-  }
-  bi = __shfl(bi, 0, 64);
-  be = __shfl(be, 0, 64);
   unsigned long long const below = (1ull << lane) - 1ull;
-  if (live) {
-    if (interior) out[bi + static_cast<u32>(__popcll(mi & below))] = lp;
-    else out[ndp - 1u - (be + static_cast<u32>(__popcll(me & below)))] = lp;
+  for (unsigned long long todo = __ballot(live); todo;) {
+    u32 const k0 = __shfl(key, __builtin_ctzll(todo));
+    unsigned long long const same = __ballot(key == k0);
+    u32 at = 0;
+    if (lane == static_cast<u32>(__builtin_ctzll(same))) at = atomicAdd(&fill[k0], static_cast<u32>(__popcll(same)));
+    at = __shfl(at, __builtin_ctzll(same));
+    if (key == k0) out[kb.b[k0] + at + static_cast<u32>(__popcll(same & below))] = lp;
+    todo &= ~same;
   }
 }
 
-template <int B>
-__global__ __launch_bounds__(64) void k_align_reg(GArgs A, u32 seg_words) {
+// waves per SIMD the register allocator is asked to keep (it otherwise spends registers on scheduling freedom)
+__host__ __device__ constexpr int reg_waves(int w) { return w <= 49 ? 4 : (w <= 65 ? 3 : (w <= 97 ? 2 : 1)); }
+template <int W, int WLO>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(reg_waves(W), 8))) void k_align_reg(GArgs A, u32 seg_words) {
   extern __shared__ u32 lds[];
-  constexpr int WD = 2 * B + 1;
+  constexpr int WD = W;
   constexpr int NW = (WD + 7) / 8;  // traceback / segment words per row
   int const lane = threadIdx.x;
   u32* SEG = lds;  // [seg_words][64]
-  u64 const li = static_cast<u64>(A.dp0) + static_cast<u64>(blockIdx.x) * 64 + lane;
-  bool const live = li < *A.ws.dp_count;
-  u64 const lp = live ? A.ws.dp_list[li] : 0;
-  PairId id{0, 0, 0};
-  i32 m = 0, n = 0, c = 0;
-  const u8* rb = nullptr;
-  const u8* hb = nullptr;
-  bool active = false;
-  if (live) {
-    id = pair_decode(A, A.pair0 + lp);
-    size_t const hi = static_cast<size_t>(id.w) * A.prm.max_haps + id.slot;
-    n = static_cast<i32>(A.a.hap_len[hi]);
-    hb = A.a.hap_bases + hi * A.prm.max_hap_len;
-    u64 const ro = A.b.read_off[id.r];
-    m = static_cast<i32>(A.b.read_off[id.r + 1] - ro);
-    rb = A.b.read_bases + ro;
-    c = A.ws.centre[lp];
-    active = c != 0x7FFFFFFF && m >= SK && n >= SK && static_cast<u32>(m) + 1 <= A.ws.tb_rows;
-  }
-  i32 const mrows = active ? m : 0;
+  DpPair const P = dp_pair_load(A, blockIdx.x * 64u + lane);
+  i32 const m = P.m, n = P.n, lo = P.lo;
+  i32 const wr = P.active ? P.wr : 0;
+  i32 const mrows = P.active ? m : 0;
   i32 mmax = mrows;
   for (int off = 32; off > 0; off >>= 1) mmax = max(mmax, __shfl_xor(mmax, off));
 
   // packed previous row, BIASED by what the next row subtracts anyway: lo16 = H - (GO + GE), hi16 = F - GE; HF[WD] = sentinel
   u32 HF[WD + 1];
   constexpr i32 GOE = GO + GE;
-  i32 const j0 = c - B;  // hap base index of segment position 0
-  if (active) {
-    i32 const seglen = m + 2 * B + 1;
+  constexpr u32 kNegPack = (static_cast<u32>(NEGR - GOE) & 0xFFFFu) | (static_cast<u32>(NEGR - GE) << 16);
+  if (P.active) {
+    i32 const seglen = m + WD;
     for (i32 wd = 0; wd * 8 < seglen + 8; ++wd) {
       u32 pk = 0;
       for (int x = 0; x < 8; ++x) {
-        i32 const hbidx = j0 + wd * 8 + x;
-        u32 const e = hbidx == -1 ? 6u : ((hbidx < -1 || hbidx >= n) ? 7u : enc_base(hb[hbidx]));
+        i32 const hbidx = lo + wd * 8 + x;
+        u32 const e = hbidx == -1 ? 6u : ((hbidx < -1 || hbidx >= n) ? 7u : enc_base(P.hb[hbidx]));
         pk |= e << (4 * x);
       }
       if (static_cast<u32>(wd) < seg_words) SEG[static_cast<size_t>(wd) * 64 + lane] = pk;
@@ -941,8 +1122,8 @@ __global__ __launch_bounds__(64) void k_align_reg(GArgs A, u32 seg_words) {
   }
 #pragma unroll
   for (int t = 0; t <= WD; ++t) {
-    i32 const j = c - B + t;
-    i32 const h = (t < WD && j >= 0 && j <= n) ? 0 : NEGR;
+    i32 const j = lo + t;
+    i32 const h = (t < wr && j >= 0 && j <= n) ? 0 : NEGR;
     HF[t] = (static_cast<u32>(h - GOE) & 0xFFFFu) | (static_cast<u32>(NEGR - GE) << 16);
   }
   size_t const tb_base = static_cast<size_t>(blockIdx.x) * A.ws.tb_rows * A.ws.tb_words * 64;
@@ -950,7 +1131,7 @@ __global__ __launch_bounds__(64) void k_align_reg(GArgs A, u32 seg_words) {
   i32 best = NEGR, bi = -1, bj = -1;
   for (i32 i = 1; i <= mmax; ++i) {
     if (i <= mrows) {
-      u32 const qi = enc_base(rb[i - 1]);
+      u32 const qi = enc_base(P.rb[i - 1]);
       i32 const smis = qi > 3 ? -1 : -4;
       u32 const qcmp = qi > 3 ? 15u : qi;  // never equal to a haplotype code when ambiguous
       // segment words for rel = (i-1) .. (i-1)+WD, re-aligned so that cell t uses nibble t of sw[]
@@ -968,14 +1149,14 @@ __global__ __launch_bounds__(64) void k_align_reg(GArgs A, u32 seg_words) {
       i32 le = NEGR, last_h = NEGR;
       u32 word = 0;
       u32* tbrow = tb + static_cast<size_t>(i) * A.ws.tb_words * 64 + lane;
-      // Rows whose band window holds nothing but A/C/G/T for every pair of the wavefront -- no haplotype end (walls),
+      // Rows whose window holds nothing but A/C/G/T for every pair of the wavefront -- no haplotype end (walls),
       // no N; almost all rows: reads hanging over a haplotype end are settled by the certificates -- take the lean
       // body: the substitution score comes from one XOR per word (nibble == 0 <=> match) and there is no wall logic.
       // Codes 4 (N), 6 and 7 (walls) all have bit 2 set, A/C/G/T do not.
       u32 any_special = 0;
 #pragma unroll
       for (int k = 0; k < NW; ++k) any_special |= sw[k];
-      // (the last word also carries a few columns beyond the band: including them only makes the test conservative)
+      // (the last word also carries a few columns beyond the window: including them only makes the test conservative)
       any_special &= 0x44444444u;
       i32 const smis_b = smis + GOE;  // substitution scores biased by GO + GE (see HF)
       auto const row = [&](auto special_tag) {
@@ -1014,19 +1195,24 @@ __global__ __launch_bounds__(64) void k_align_reg(GArgs A, u32 seg_words) {
           }
           i32 const hm = h - GOE, fm = f - GE;
           HF[t] = __builtin_amdgcn_perm(static_cast<u32>(fm), static_cast<u32>(hm), 0x05040100u);  // lo16(hm) | lo16(fm) << 16
+          if (t > WLO) HF[t] = wr == t ? kNegPack : HF[t];  // first cell outside a narrower region
           lhm = hm;
           le = e;
           dhm = uhm;
-          word |= nib << (4 * (t & 7));
-          if ((t & 7) == 7 || t == WD - 1) {
+          // nibble t & 7 of the row's word t >> 3: shifted in from the top (one v_alignbit; or-ing `nib << const` makes
+          // the compiler keep 32 pre-shifted flag constants in VGPRs)
+          word = __builtin_amdgcn_alignbit(nib, word, 4);
+          if ((t & 7) == 7) {
             tbrow[static_cast<size_t>(t >> 3) * 64] = word;
             word = 0;
+          } else if (t == WD - 1) {
+            tbrow[static_cast<size_t>(t >> 3) * 64] = word >> (4 * (7 - (t & 7)));
           }
         }
       };
       if (__ballot(any_special != 0) != 0) row(std::true_type{}); else row(std::false_type{});
-      // end cell (i, n) for i < m: the last in-haplotype cell of the row is column n iff the band reaches it
-      if (i < mrows && i + c + B >= n && i + c - B <= n) {
+      // end cell (i, n) for i < m: the last in-haplotype cell of the row is column n iff the region reaches it
+      if (i < mrows && i + lo + wr - 1 >= n && i + lo <= n) {
         if (last_h >= best) {  // later rows win ties (larger i)
           best = last_h;
           bi = i;
@@ -1036,13 +1222,13 @@ __global__ __launch_bounds__(64) void k_align_reg(GArgs A, u32 seg_words) {
     }
   }
   // end cells (m, j): scan the final row left to right (smaller j wins ties; row m beats earlier rows on ties)
-  if (active) {
+  if (P.active) {
     bool first = true;
 #pragma unroll
     for (int t = 0; t < WD; ++t) {
-      i32 const j = mrows + c - B + t;
+      i32 const j = mrows + lo + t;
       i32 const h = static_cast<i16>(HF[t] & 0xFFFFu) + GOE;
-      if (j >= 0 && j <= n) {
+      if (t < wr && j >= 0 && j <= n) {
         if (h > best || (first && h == best)) {
           best = h;
           bi = mrows;
@@ -1052,18 +1238,7 @@ __global__ __launch_bounds__(64) void k_align_reg(GArgs A, u32 seg_words) {
       }
     }
   }
-  if (!live) return;
-  int const MH = A.prm.max_haps, MCG = A.prm.max_cigar;
-  size_t const rec = (static_cast<size_t>(id.r) * MH + id.slot);
-  i32* arec = A.o.aln_rec + rec * 6;
-  u32* acig = A.o.aln_cigar + rec * (1 + MCG);
-  bool const hit = active && bi >= 0 && best >= A.prm.min_aln_score;
-  if (!hit) {
-    for (int x = 0; x < 6; ++x) arec[x] = 0;
-    acig[0] = 0;
-    return;
-  }
-  align_traceback(A, tb, lane, B, c, m, best, bi, bj, arec, acig);
+  dp_pair_store(A, P, tb, lane, best, bi, bj);
 }
 
 // ---- scoring epilogue ----
@@ -1391,7 +1566,6 @@ int launch_genotype(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& a, const m
   A.o = o_in;
   A.prm = P;
   AlnWs& ws = A.ws;
-  ws.band = P.band;
   // evidence table: sized from the largest window (reads x a few variants each); the read count per
   // window is known from read_win_off only on the device, so a first tiny pass fetches the maxima
   ws.ev_cap = 8192;
@@ -1457,68 +1631,128 @@ int launch_genotype(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& a, const m
   ctx->stats[0] += total_pairs;
   if (total_pairs > 0) {
     ws.tb_rows = max_read_len + 1;
-    ws.tb_words = static_cast<u32>((2 * P.band + 1 + 7) / 8);
-    size_t const tb_per_group = static_cast<size_t>(ws.tb_rows) * ws.tb_words * 64 * 4;  // 64 pairs
+    // LDS of k_align_wave: two i32 rows of w + 2 cells, the haplotype codes of the region and the read's codes
+    auto wave_lds_bytes = [&](u32 w) { return static_cast<size_t>(w + 2) * 8 + (max_read_len + w + 8) + max_read_len + 64; };
+    u32 big_w = 7168;
+    while (big_w > kWaveSmallW && wave_lds_bytes(big_w) > 64 * 1024) big_w -= 64;
+    if (const char* e = getenv("MA_WAVE_MAX_W")) big_w = std::max<u32>(kWaveSmallW, std::min<u32>(big_w, static_cast<u32>(atoi(e))));  // tests: reach k_align_gen
+    ws.wave_big_w = big_w;
     size_t budget = std::max<size_t>(size_t(1) << 30, stage_budget(0.15, ctx->ws_misc.cap, size_t(8) << 30, ctx->hbm_share));
     if (const char* e = getenv("MA_TB_GB")) budget = static_cast<size_t>(atoi(e)) << 30;
-    // vote chunks: bounded only by the 8 B / pair of centre + dp_list (and 32-bit local pair ids)
-    u64 const pairs_chunk = std::min<u64>(total_pairs, std::min<u64>(u64(1) << 30, budget / 4 / 8));
-    u64 const dp_groups_max = std::max<u64>(1, (budget - pairs_chunk * 8) / tb_per_group);
-    size_t const tb_bytes = std::min<u64>(dp_groups_max, (pairs_chunk + 63) / 64) * tb_per_group;
-    MA_HIP(ctx, ctx->ws_misc.reserve(tb_bytes + (pairs_chunk + 64) * 12 + 8192));
+    // vote chunks: bounded only by the 16 B / pair of region + DP lists (and 32-bit local pair ids)
+    u64 const pairs_chunk = std::min<u64>(total_pairs, std::min<u64>(u64(1) << 30, budget / 4 / 16));
+    size_t const tb_bytes = budget - pairs_chunk * 16;
+    MA_HIP(ctx, ctx->ws_misc.reserve(std::min<size_t>(tb_bytes, std::max<size_t>(size_t(256) << 20, static_cast<size_t>((pairs_chunk + 63) / 64) *
+                                                                                                    ws.tb_rows * 17 * 256)) +
+                                     (pairs_chunk + 64) * 16 + 8192));
+    // bytes available for traceback tiles; the per-pair arrays (and their atomics) start 256-byte aligned behind them
+    size_t const tb_cap = (ctx->ws_misc.cap - ((pairs_chunk + 64) * 16 + 8192)) & ~size_t(255);
     ws.tb = ctx->ws_misc.as<u32>();
-    ws.centre = reinterpret_cast<i32*>(reinterpret_cast<char*>(ctx->ws_misc.p) + tb_bytes);
-    ws.dp_list = reinterpret_cast<u32*>(ws.centre + pairs_chunk + 16);
+    ws.centre = reinterpret_cast<i32*>(reinterpret_cast<char*>(ctx->ws_misc.p) + tb_cap);
+    ws.band_w = reinterpret_cast<u32*>(ws.centre + pairs_chunk + 16);
+    ws.dp_list = ws.band_w + pairs_chunk + 16;
     ws.dp_count = ws.dp_list + pairs_chunk + 16;
-    u32* const dp_sorted = ws.dp_count + 16;  // [pairs_chunk] the DP list, interior pairs first (k_dp_partition)
+    u32* const dp_sorted = ws.dp_count + 128;  // [pairs_chunk] the DP list sorted by key (k_dp_scatter)
     u32 const ml_eff = std::min<u32>(static_cast<u32>(P.max_hap_len), (std::max<u32>(plan_counters[3], 64u) + 31u) & ~31u);
     u32 const hist_len = ((max_read_len + ml_eff + 2 + 1) & ~1u);
     u32 const pw_host = (ml_eff + 31) / 32 + 2;
     u32 const rwords = (max_read_len + 31) / 32 + 2;
     size_t const lds_vote = 4ull * ml_eff + 2ull * kIdxCap + 2ull * ((ml_eff + 1) & ~1) + 8ull * hist_len +
-                            12ull * pw_host + 48ull * rwords + 4ull * 4 * 65 + 4ull * (plan_counters[1] + 2) + 64;
+                            12ull * pw_host + 48ull * rwords + 4ull * 4 * 129 + 4ull * (plan_counters[1] + 2) + 64;
     if (lds_vote > 65536)
       MA_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_vote), hipFuncAttributeMaxDynamicSharedMemorySize,
                                       static_cast<int>(lds_vote)));
-    u32 const seg_words = (max_read_len + 2 * P.band + 1 + 7) / 8 + 1;
-    size_t const lds_align = (static_cast<size_t>(2 * P.band + 2) * 64 + static_cast<size_t>(seg_words) * 64) * 4;
     for (u64 p0 = 0; p0 < total_pairs; p0 += pairs_chunk) {
       A.pair0 = p0;
       A.npairs = static_cast<u32>(std::min<u64>(pairs_chunk, total_pairs - p0));
-      MA_HIP(ctx, hipMemsetAsync(ws.dp_count, 0, 4, ctx->stream));
+      MA_HIP(ctx, hipMemsetAsync(ws.dp_count, 0, 4 * 128, ctx->stream));
       ctx->tic("k_vote");
       hipLaunchKernelGGL(k_vote, dim3(n_vote_wg), dim3(256), lds_vote, ctx->stream, A, hist_len, rwords, ml_eff);
       ctx->toc();
-      u32 ndp = 0;
-      MA_HIP(ctx, hipMemcpyAsync(&ndp, ws.dp_count, 4, hipMemcpyDeviceToHost, ctx->stream));
+      u32 cnt[48];
+      MA_HIP(ctx, hipMemcpyAsync(cnt, ws.dp_count, sizeof(cnt), hipMemcpyDeviceToHost, ctx->stream));
       MA_HIP(ctx, ma_stream_sync(ctx));
+      u32 const ndp = cnt[0];
       ctx->stats[1] += ndp;
+      if (ndp == 0) continue;
       GArgs const Avote = A;
-      if (ndp > 0 && P.band == 64) {
-        MA_HIP(ctx, hipMemsetAsync(ws.dp_count + 4, 0, 8, ctx->stream));
-        ctx->tic("k_dp_partition");
-        hipLaunchKernelGGL(k_dp_partition, dim3((ndp + 255) / 256), dim3(256), 0, ctx->stream, A, ndp, dp_sorted,
-                           ws.dp_count + 4);
-        ctx->toc();
-        A.ws.dp_list = dp_sorted;
+      KeyBase kb{};
+      u32 acc = 0;
+      for (int k = 0; k < kNumKeys; ++k) {
+        kb.b[k] = acc;
+        acc += cnt[4 + k];
       }
-      u64 const ng_total = (static_cast<u64>(ndp) + 63) / 64;
-      for (u64 g0 = 0; g0 < ng_total; g0 += dp_groups_max) {
-        u32 const ng = static_cast<u32>(std::min<u64>(dp_groups_max, ng_total - g0));
-        A.dp0 = static_cast<u32>(g0 * 64);
-        if (P.band == 64) {
-          ctx->tic("k_align_reg");
-          hipLaunchKernelGGL(k_align_reg<64>, dim3(ng), dim3(64), static_cast<size_t>(seg_words + 2) * 64 * 4, ctx->stream, A,
-                             seg_words + 2);
-          ctx->toc();
-          continue;
+      if (acc != ndp) {
+        ctx->err = "read aligner: DP pairs per width class do not add up";
+        return MA_ERR_HIP;
+      }
+      ctx->tic("k_dp_scatter");
+      hipLaunchKernelGGL(k_dp_scatter, dim3((ndp + 255) / 256), dim3(256), 0, ctx->stream, A, ndp, dp_sorted,
+                         ws.dp_count + 64, kb);
+      ctx->toc();
+      A.ws.dp_list = dp_sorted;
+      for (int cls = 0; cls < kNumCls; ++cls) {
+        u32 const cls_n = cnt[4 + 2 * cls] + cnt[4 + 2 * cls + 1];
+        if (cls_n == 0) continue;
+        ctx->stats[4 + (cls < kNumReg ? (cls < 2 ? 0 : (cls < 4 ? 1 : 2)) : 3)] += cls_n;
+        u32 const gw = cls < kNumReg ? static_cast<u32>(reg_width(cls))
+                                     : (cls == kClsWaveS ? kWaveSmallW : (cls == kClsWaveB ? big_w : std::max<u32>(cnt[40], 1u)));
+        A.ws.tb_words = (gw + 7) / 8;
+        A.ws.gen_w = gw;
+        bool const wave = cls == kClsWaveS || cls == kClsWaveB;
+        u32 const nchunk = (gw + 63) / 64;
+        // bytes of traceback per launch group: 64 pairs of a lane-per-pair kernel, ONE pair of the wavefront kernel
+        size_t const tb_per_group = wave ? static_cast<size_t>(ws.tb_rows) * nchunk * 32
+                                         : static_cast<size_t>(ws.tb_rows) * A.ws.tb_words * 64 * 4;
+        u64 groups_max = std::max<u64>(1, tb_cap / tb_per_group);
+        A.ws.tbw = reinterpret_cast<unsigned long long*>(ws.tb);
+        if (cls == kClsGlobal) {  // (H,F) rows in HBM: one row of gw + 1 words per lane
+          size_t const row_bytes = (static_cast<size_t>(gw) + 1) * 256;
+          groups_max = std::min<u64>(groups_max, std::max<u64>(1, (size_t(2) << 30) / row_bytes));
+          MA_HIP(ctx, ctx->ws_gen.reserve(std::min<u64>(groups_max, (cls_n + 63) / 64) * row_bytes));
+          A.ws.gen_row = ctx->ws_gen.as<u32>();
         }
-        ctx->tic("k_align");
-        if (lds_align > 65536)
-          MA_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_align),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_align)));
-        hipLaunchKernelGGL(k_align, dim3(ng), dim3(64), lds_align, ctx->stream, A, seg_words);
-        ctx->toc();
+        if (tb_per_group > tb_cap) {
+          ctx->err = "read aligner: traceback tile of one pair group exceeds the workspace";
+          return MA_ERR_NOMEM;
+        }
+        u32 const per_group = wave ? 1u : 64u;  // pairs per workgroup
+        u64 const ng_total = (static_cast<u64>(cls_n) + per_group - 1) / per_group;
+        for (u64 g0 = 0; g0 < ng_total; g0 += groups_max) {
+          u32 const ng = static_cast<u32>(std::min<u64>(groups_max, ng_total - g0));
+          A.dp0 = kb.b[2 * cls] + static_cast<u32>(g0 * per_group);
+          A.dp_n = static_cast<u32>(std::min<u64>(static_cast<u64>(ng) * per_group, cls_n - g0 * per_group));
+          u32 const segw = (max_read_len + gw + 7) / 8 + 3;
+          size_t const lds_reg = static_cast<size_t>(segw) * 256;
+#define MA_LAUNCH_REG(C, WLO)                                                                                          \
+  case C:                                                                                                              \
+    ctx->tic("k_align_reg");                                                                                           \
+    hipLaunchKernelGGL((k_align_reg<reg_width(C), WLO>), dim3(ng), dim3(64), lds_reg, ctx->stream, A, segw);          \
+    ctx->toc();                                                                                                        \
+    break;
+          switch (cls) {
+            MA_LAUNCH_REG(0, 0)
+            MA_LAUNCH_REG(1, reg_width(0))
+            MA_LAUNCH_REG(2, reg_width(1))
+            MA_LAUNCH_REG(3, reg_width(2))
+            MA_LAUNCH_REG(4, reg_width(3))
+            MA_LAUNCH_REG(5, reg_width(4))
+            case kClsWaveS:
+            case kClsWaveB: {
+              size_t const lds_w = wave_lds_bytes(gw);
+              ctx->tic("k_align_wave");
+              hipLaunchKernelGGL(k_align_wave, dim3(ng), dim3(64), lds_w, ctx->stream, A, nchunk);
+              ctx->toc();
+              break;
+            }
+            default:
+              ctx->tic("k_align_gen");
+              hipLaunchKernelGGL(k_align_gen, dim3(ng), dim3(64), 0, ctx->stream, A);
+              ctx->toc();
+              break;
+          }
+#undef MA_LAUNCH_REG
+        }
       }
       A = Avote;
     }

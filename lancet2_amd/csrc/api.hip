@@ -170,7 +170,8 @@ int check_params(const ma_params_t& p) {
   if (p.max_comps < 1 || p.max_comps > 16 || p.max_haps < 2 || p.max_haps > 32) return MA_ERR_PARAM;
   if (p.max_hap_len < 256 || p.max_hap_len > 8192 || p.max_runs < 8) return MA_ERR_PARAM;
   if (p.max_vars < 1 || p.max_alts < 1 || p.max_alts > 15 || p.max_allele_bytes < 64) return MA_ERR_PARAM;
-  if (p.band < 4 || p.band > 128 || p.max_cigar < 4 || p.max_cigar > 64) return MA_ERR_PARAM;
+  if (p.aln_tier < 0 || p.aln_tier > 3 || p.max_cigar < 4 || p.max_cigar > 64) return MA_ERR_PARAM;
+  if (p.min_aln_score < 1) return MA_ERR_PARAM;  // row-0 end cells are never hits (align.hip)
   if (p.bfs_limit < 1) return MA_ERR_PARAM;
   return MA_OK;
 }
@@ -256,6 +257,7 @@ int process_in_lanes(ma_ctx* ctx, int lanes, const DBatch& d, const ma_gate_out_
     ch->prm = ctx->prm;
     ch->timing = ctx->timing;
     ch->accumulate = ctx->accumulate;
+    ch->collect = ctx->collect;
     if (!ch->accumulate) ch->timers_used = 0;
     ch->hbm_share = ctx->hbm_share / lanes;
     th.emplace_back([&, k, ch]() { rc[k] = run_lane(ch, ctx->lane_done, d, wb[k], wb[k + 1], rb[k], rb[k + 1], g, a, v, q); });
@@ -283,7 +285,7 @@ void ma_default_params(ma_params_t* p) {
   p->min_anchor_len = 150;                              // graph.cpp:88
   p->max_mismatch = 2;                                  // graph.h:129
   p->bfs_limit = 1 << 20;                               // max_flow.h:69
-  p->band = 64; p->min_aln_score = 80;
+  p->aln_tier = 0; p->min_aln_score = 80;
   p->max_comps = 4; p->max_haps = 16; p->max_hap_len = 2048; p->max_runs = 256;
   p->max_vars = 64; p->max_alts = 4; p->max_allele_bytes = 4096; p->max_cigar = 16;
   p->case_ctrl_mode = 1;
@@ -315,7 +317,7 @@ void ma_destroy(ma_ctx_t* ctx) {
   for (auto& b : ctx->in_stage) b.release();
   for (auto& b : ctx->out_stage) b.release();
   ctx->ws_build.release(); ctx->ws_nodes.release(); ctx->ws_clean.release();
-  ctx->ws_poa.release(); ctx->ws_aln.release(); ctx->ws_misc.release(); ctx->ws_cx.release();
+  ctx->ws_poa.release(); ctx->ws_aln.release(); ctx->ws_misc.release(); ctx->ws_cx.release(); ctx->ws_gen.release(); ctx->dev_stats.release();
   for (auto& t : ctx->timers) {
     (void)hipEventDestroy(t.beg);
     (void)hipEventDestroy(t.end);
@@ -348,7 +350,9 @@ int ma_synchronize(ma_ctx_t* ctx) {
 int ma_timing_control(ma_ctx_t* ctx, int mode) {
   if (!ctx) return MA_ERR_ARG;
   ctx->timing = mode != 0;
-  ctx->accumulate = mode == 2;
+  ctx->accumulate = mode >= 2;
+  ctx->collect = mode == 3;
+  ctx->dev_stats_clean = false;
   ctx->timers_used = 0;
   for (auto& v : ctx->stats) v = 0;
   for (ma_ctx* ch : ctx->lanes) ma_timing_control(ch, mode);
@@ -367,6 +371,23 @@ int ma_last_stats(ma_ctx_t* ctx, unsigned long long* out, int cap) {
   for (; n < cap && n < 8; ++n) {
     out[n] = ctx->stats[n];
     for (ma_ctx* ch : ctx->lanes) out[n] += ch->stats[n];
+  }
+  // entries 8..11: device-side workload statistics (mode 3 only; zero otherwise)
+  auto add_dev = [&](ma_ctx* c) -> int {
+    if (!c->dev_stats.p || !c->dev_stats_clean) return MA_OK;
+    unsigned long long h[4] = {0, 0, 0, 0};
+    MA_HIP(c, hipSetDevice(c->device));
+    MA_HIP(c, ma_stream_sync(c));
+    MA_HIP(c, hipMemcpy(h, c->dev_stats.p, sizeof(h), hipMemcpyDeviceToHost));
+    for (int x = 0; x < 4 && 8 + x < cap; ++x) out[8 + x] += h[x];
+    return MA_OK;
+  };
+  if (cap > 8) {
+    for (int x = 8; x < cap && x < 12; ++x) out[x] = 0;
+    if (add_dev(ctx) != MA_OK) return MA_ERR_HIP;
+    for (ma_ctx* ch : ctx->lanes)
+      if (add_dev(ch) != MA_OK) return MA_ERR_HIP;
+    n = cap < 12 ? cap : 12;
   }
   return n;
 }
@@ -395,7 +416,10 @@ int ma_last_kernel_times(ma_ctx_t* ctx, const char** names, float* ms, int cap) 
 #define MA_BEGIN(ctx)                                   \
   if (!(ctx)) return MA_ERR_ARG;                        \
   MA_HIP(ctx, hipSetDevice((ctx)->device));             \
-  if (!(ctx)->accumulate) (ctx)->timers_used = 0;
+  if (!(ctx)->accumulate) {                             \
+    (ctx)->timers_used = 0;                             \
+    for (ma_ctx* _ch : (ctx)->lanes) _ch->timers_used = 0; \
+  }
 
 #define MA_TRY(expr)          \
   do {                        \
@@ -495,6 +519,7 @@ int ma_process_batch(ma_ctx_t* ctx, const ma_batch_t* b, const ma_gate_out_t* ga
                      const ma_var_out_t* vars, const ma_geno_out_t* geno) {
   MA_BEGIN(ctx);
   if (!gate || !asmb || !vars || !geno) return MA_ERR_ARG;
+  if (!gate->max_approx || !gate->max_exact || !geno->allele_counts || !geno->var_qual) return MA_ERR_ARG;
   DBatch d;
   MA_TRY(stage_batch(ctx, b, &d));
   OutMirror<ma_gate_out_t> g;

@@ -26,6 +26,28 @@ __global__ void k_init_out(ma_asm_out_t o, u32* win_flags, int n) {
   win_flags[i] = 0;
 }
 
+// Workload statistics for bench.py's algorithmic-byte model; launched only in ma_timing_control mode 3.
+__global__ __launch_bounds__(256) void k_workload_stats(GraphWs ws, unsigned long long* acc) {
+  int const a = blockIdx.x;
+  const u64* keys = ws.tbl_key + (static_cast<size_t>(a) << ws.tc_log2);
+  u32 const slots = 1u << ws.win_tc[a];
+  u32 cnt = 0;
+  for (u32 i = threadIdx.x; i < slots; i += 256) cnt += keys[i] != 0;
+  __shared__ u32 sh[256];
+  sh[threadIdx.x] = cnt;
+  __syncthreads();
+  for (int d = 128; d > 0; d >>= 1) {
+    if (threadIdx.x < static_cast<u32>(d)) sh[threadIdx.x] += sh[threadIdx.x + d];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    atomicAdd(&acc[0], static_cast<unsigned long long>(sh[0]));              // distinct k-mers (N_raw)
+    atomicAdd(&acc[1], static_cast<unsigned long long>(ws.n_nodes[a]));      // nodes that survive the first low-coverage pass
+    atomicAdd(&acc[2], static_cast<unsigned long long>(ws.n_slow[a]));       // k-mer instances that took the hash-table path
+    atomicAdd(&acc[3], static_cast<unsigned long long>(ws.win_ninst[ws.active[a]]));  // k-mer instances (N_inst)
+  }
+}
+
 int ceil_log2(u64 v) {
   int l = 0;
   while ((u64(1) << l) < v) ++l;
@@ -181,6 +203,15 @@ int launch_assemble(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& out, const
         ws.tc_log2 = tc_log2_alloc;
         ws.mc_log2 = mc_log2_alloc;  // run_build_pass shrinks both to what this attempt needs
         MA_TRY_RC(run_build_pass(ctx, b, ws, counters + 12, tc_log2_alloc));
+        if (ctx->collect) {
+          MA_HIP(ctx, ctx->dev_stats.reserve(64));
+          if (!ctx->dev_stats_clean) {
+            MA_HIP(ctx, hipMemsetAsync(ctx->dev_stats.p, 0, 64, ctx->stream));
+            ctx->dev_stats_clean = true;
+          }
+          hipLaunchKernelGGL(k_workload_stats, dim3(ws.n_active), dim3(256), 0, ctx->stream, ws,
+                             ctx->dev_stats.as<unsigned long long>());
+        }
         MA_TRY_RC(run_clean_pass(ctx, b, ws, out));
       }
     }

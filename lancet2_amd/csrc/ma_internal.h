@@ -65,7 +65,7 @@ struct ma_ctx {
   ma::DevBuf in_stage[10];
   std::vector<ma::DevBuf> out_stage;
   // per-stage workspaces (grow-only, reused across calls)
-  ma::DevBuf ws_build, ws_nodes, ws_clean, ws_poa, ws_aln, ws_misc;
+  ma::DevBuf ws_build, ws_nodes, ws_clean, ws_poa, ws_aln, ws_misc, ws_gen;
   // annotation tables (annotate.hip): rebuilt when the GC fraction or max_hap_len changes
   ma::DevBuf ws_cx;
   double cx_gc = -1.0;
@@ -77,6 +77,9 @@ struct ma_ctx {
   bool timing = true;
   bool accumulate = false;
   unsigned long long stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // see ma_last_stats
+  bool collect = false;          // ma_timing_control mode 3: also gather the workload statistics (device side)
+  ma::DevBuf dev_stats;          // [8] u64 accumulated by k_workload_stats
+  bool dev_stats_clean = false;
   // ma_process_batch splits a batch into `n_lanes` contiguous window ranges that run concurrently on child
   // contexts (own stream + workspaces): the stages have complementary bottlenecks (latency-bound graph
   // cleaning, VALU-bound DP, HBM-bound table passes), so two batches in flight fill the gaps of one.

@@ -1,41 +1,52 @@
 // ORACLE -- TEST INFRASTRUCTURE ONLY (see common.hpp header).
 // Read <-> haplotype aligner and the CIGAR-based allele-scoring epilogue.
 //
-// PARITY UNPINNED for the aligner: the reference calls minimap2 2.30 (mm_map with
+// PARITY UNPINNED against minimap2 itself: the reference calls minimap2 2.30 (mm_map with
 // k=11,w=5 seeds, a=1 b=4 q=12 e=3 single-affine, bw=10000, zdrop off, end_bonus=10000,
-// best_n=1: caller/genotyper.cpp:89-191, :376-411); its source is not under
-// /root/reference and no reference test pins its output.  What follows is the engine's
-// CANONICAL restatement of that contract (DESIGN.md "read<->haplotype aligner"):
+// best_n=1: caller/genotyper.cpp:89-191, :376-411); its source is not under /root/reference and
+// no reference test pins its output.  What follows is the engine's CANONICAL restatement of that
+// contract (DESIGN.md "read<->haplotype aligner"); its optimal SCORES are pinned to an
+// independent brute force (tests/brute_force.py, tests/test_aligner_pins.py):
 //   1. nt4 encoding; substitution +1 / -4, any ambiguous base -1 (minimap2 sc_ambi);
 //      a gap of length L costs 12 + 3L.
-//   2. Seed vote: every exact 11-mer shared by read and haplotype votes for its diagonal
-//      d = hap_pos - read_pos; the band centre is the most-voted diagonal (ties: smallest d);
-//      no shared 11-mer => no hit.
-//   3. Banded (|j - i - centre| <= band) overlap alignment: the read is aligned end to end
-//      unless it overhangs a haplotype end, in which case the overhang is soft-clipped
-//      (start cells (0,j) and (i,0); end cells (m,j) and (i,n)).
-//   4. Best end cell: max score, ties -> larger i, then smaller j.  Traceback: diagonal
-//      first, then deletion (E), then insertion (F); inside a gap prefer opening over
-//      extending (left-aligned gaps, ksw2's default).
-//   5. A hit is reported iff score >= 80 (minimap2's default min_dp_max, which the reference
+//   2. Seeds: every exact 11-mer shared by read and haplotype lies on a diagonal d = hap_pos - read_pos and counts as
+//      one vote for it.  minimap2 drops chains scoring < 40 (min_chain_score, not overridden by the reference), and
+//      40 chained bases need at least 4 exact 11-mers: a seeded diagonal d is an ANCHOR iff the diagonals within reach
+//      of it, [d - K, d + K] (K below), hold >= 4 votes together.  Stray single matches (a random 11-mer recurs in
+//      3 % of the read x haplotype pairs of a 1 kb window) anchor nothing.  No anchor => no hit.
+//   3. Search region.  The reference sets bw = 10000 and disables z-drop, i.e. the band never
+//      limits an alignment that its seeds support.  With cost(P) = m - score(P) every row of the
+//      read costs >= 0 (match 0, mismatch 5, ambiguous 2, clipped overhang row 1, inserted row 4)
+//      and a gap that shifts the diagonal by s costs >= 12 + 3s.  A reported hit has
+//      score >= min_score, i.e. cost <= m - min_score, so an alignment through a seed on diagonal d
+//      never leaves [d - K, d + K] with K = max(0, floor((m - min_score - 12) / 3)).  The canonical
+//      search region is therefore R = [vmin - K, vmax + K] over the extreme ANCHOR diagonals: no
+//      free "band" parameter, nothing a seed-anchored hit could reach is excluded.
+//   4. Overlap alignment inside R: the read is aligned end to end unless it overhangs a haplotype
+//      end, in which case the overhang is soft-clipped (start cells (0,j) and (i,0); end cells
+//      (m,j) and (i,n)).
+//   5. Best end cell: max score, ties -> larger i, then smaller j.  Traceback: diagonal first, then
+//      deletion (E), then insertion (F); inside a gap prefer opening over extending (left-aligned
+//      gaps, ksw2's default).
+//   6. A hit is reported iff score >= 80 (minimap2's default min_dp_max, which the reference
 //      does not override).
 // The scoring epilogue below IS first-party reference code and is restated literally.
 #include "oracle.hpp"
 
 namespace orc {
 
-AlnResult AlignReadToHap(std::string_view read, std::string_view hap, const AlignParams& ap) {
-  AlnResult res;
-  i32 const m = static_cast<i32>(read.size()), n = static_cast<i32>(hap.size());
-  i32 const SK = ap.seed_k;
-  if (m < SK || n < SK) return res;
-  std::vector<u8> q(m), t(n);
-  for (i32 i = 0; i < m; ++i) q[i] = EncodeBase(read[i]);
-  for (i32 j = 0; j < n; ++j) t[j] = EncodeBase(hap[j]);
+// K of rule 3
+i32 AlignReach(i32 m, i32 min_score) {
+  i32 const c = m - min_score - 12;
+  return c > 0 ? c / 3 : 0;
+}
 
-  // --- seed vote ---
-  auto code_at = [&](const std::vector<u8>& s, i32 p, u32* code) {
-    u32 c = 0;
+// rule 2: extreme ANCHOR diagonals; false when there is none
+bool SeedDiagonals(const std::vector<u8>& q, const std::vector<u8>& t, i32 SK, i32 K, i32* vmin, i32* vmax) {
+  i32 const m = static_cast<i32>(q.size()), n = static_cast<i32>(t.size());
+  if (m < SK || n < SK) return false;
+  auto code_at = [&](const std::vector<u8>& s, i32 p, u64* code) {
+    u64 c = 0;
     for (i32 x = 0; x < SK; ++x) {
       if (s[p + x] > 3) return false;
       c = (c << 2) | s[p + x];
@@ -43,40 +54,60 @@ AlnResult AlignReadToHap(std::string_view read, std::string_view hap, const Alig
     *code = c;
     return true;
   };
-  std::unordered_map<u32, std::vector<i32>> index;
+  std::unordered_map<u64, std::vector<i32>> index;
   for (i32 j = 0; j + SK <= n; ++j) {
-    u32 c;
+    u64 c;
     if (code_at(t, j, &c)) index[c].push_back(j);
   }
-  std::vector<i32> votes(static_cast<usize>(m + n + 1), 0);  // diag d -> votes[d + m]
+  std::vector<i32> votes(static_cast<usize>(m + n + 1), 0);  // diagonal d -> votes[d + m]
   for (i32 i = 0; i + SK <= m; ++i) {
-    u32 c;
+    u64 c;
     if (!code_at(q, i, &c)) continue;
     auto it = index.find(c);
     if (it == index.end()) continue;
     for (i32 j : it->second) votes[static_cast<usize>(j - i + m)]++;
   }
-  i32 best_votes = 0, centre = 0;
-  for (i32 d = -m; d <= n; ++d)
-    if (votes[static_cast<usize>(d + m)] > best_votes) {
-      best_votes = votes[static_cast<usize>(d + m)];
-      centre = d;
-    }
-  if (best_votes == 0) return res;
+  constexpr i32 kMinChainVotes = 4;
+  bool any = false;
+  i32 const nd = m + n + 1;
+  for (i32 x = 0; x < nd; ++x) {
+    if (votes[static_cast<usize>(x)] == 0) continue;
+    i32 sum = 0;
+    for (i32 y = std::max(0, x - K); y <= std::min(nd - 1, x + K); ++y) sum += votes[static_cast<usize>(y)];
+    if (sum < kMinChainVotes) continue;
+    i32 const d = x - m;
+    if (!any) *vmin = d;
+    *vmax = d;
+    any = true;
+  }
+  return any;
+}
 
-  // --- banded overlap DP ---
-  i32 const B = ap.band, GO = 12, GE = 3;
+AlnResult AlignReadToHap(std::string_view read, std::string_view hap, const AlignParams& ap) {
+  AlnResult res;
+  i32 const m = static_cast<i32>(read.size()), n = static_cast<i32>(hap.size());
+  std::vector<u8> q(m), t(n);
+  for (i32 i = 0; i < m; ++i) q[i] = EncodeBase(read[i]);
+  for (i32 j = 0; j < n; ++j) t[j] = EncodeBase(hap[j]);
+  i32 vmin = 0, vmax = 0;
+  i32 const K = AlignReach(m, ap.min_score);
+  if (!SeedDiagonals(q, t, ap.seed_k, K, &vmin, &vmax)) return res;
+  // region R: diagonals lo .. hi; cells outside the matrix are skipped anyway, so clamp to it
+  i32 const lo = std::max(vmin - K, -m), hi = std::min(vmax + K, n);
+
+  // --- overlap DP inside R ---
+  i32 const GO = 12, GE = 3;
   i32 const NEG = -(1 << 28);
-  i32 const Wd = 2 * B + 1;  // band positions t = j - i - centre + B
+  i32 const Wd = hi - lo + 1;  // positions tt = j - i - lo
   auto IDX = [&](i32 i, i32 tt) { return static_cast<usize>(i) * Wd + tt; };
   std::vector<i32> H(static_cast<usize>(m + 1) * Wd, NEG), E(H.size(), NEG), F(H.size(), NEG);
   auto in_band = [&](i32 i, i32 j) {
-    i32 const tt = j - i - centre + B;
+    i32 const tt = j - i - lo;
     return tt >= 0 && tt < Wd && j >= 0 && j <= n;
   };
-  auto getH = [&](i32 i, i32 j) { return in_band(i, j) ? H[IDX(i, j - i - centre + B)] : NEG; };
-  auto getE = [&](i32 i, i32 j) { return in_band(i, j) ? E[IDX(i, j - i - centre + B)] : NEG; };
-  auto getF = [&](i32 i, i32 j) { return in_band(i, j) ? F[IDX(i, j - i - centre + B)] : NEG; };
+  auto getH = [&](i32 i, i32 j) { return in_band(i, j) ? H[IDX(i, j - i - lo)] : NEG; };
+  auto getE = [&](i32 i, i32 j) { return in_band(i, j) ? E[IDX(i, j - i - lo)] : NEG; };
+  auto getF = [&](i32 i, i32 j) { return in_band(i, j) ? F[IDX(i, j - i - lo)] : NEG; };
   auto sub = [&](i32 i, i32 j) -> i32 {  // 1-based cell (i,j) pairs q[i-1], t[j-1]
     u8 const a = q[i - 1], b = t[j - 1];
     if (a > 3 || b > 3) return -1;
@@ -84,7 +115,7 @@ AlnResult AlignReadToHap(std::string_view read, std::string_view hap, const Alig
   };
   for (i32 i = 0; i <= m; ++i) {
     for (i32 tt = 0; tt < Wd; ++tt) {
-      i32 const j = i + centre - B + tt;
+      i32 const j = i + lo + tt;
       if (j < 0 || j > n) continue;
       i32 h, e = NEG, f = NEG;
       if (i == 0 || j == 0) {

@@ -68,7 +68,7 @@ void orc_default_params(ma_params_t* p) {
   p->min_k = 13; p->max_k = 127; p->k_step = 6;
   p->min_node_cov = 2; p->min_anchor_cov = 5; p->num_samples = 2;
   p->min_anchor_len = 150; p->max_mismatch = 2; p->bfs_limit = 1 << 20;
-  p->band = 64; p->min_aln_score = 80;
+  p->aln_tier = 0; p->min_aln_score = 80;
   p->max_comps = 4; p->max_haps = 16; p->max_hap_len = 2048; p->max_runs = 256;
   p->max_vars = 64; p->max_alts = 4; p->max_allele_bytes = 4096; p->max_cigar = 16;
   p->case_ctrl_mode = 1;
@@ -142,11 +142,49 @@ int orc_poa_variants(const char* seqs_nul, int nseq, int m, int n, int g, int e,
   return static_cast<int>(vars.size());
 }
 
+// Pin hook for the restated SPOA engine (tests/test_aligner_pins.py): build the POA graph from the first nseq-1
+// NUL-separated sequences (unit weights), align the LAST one against it and dump, as int32 words into `out`:
+//   V, then per node v (by id): letter, n_preds, preds...;  then V ids in topological (rank) order;
+//   then A = number of alignment pairs, then A x (node id | -1, seq pos | -1); last word: the DP's optimal score.
+// Returns the number of words written, or -1 when `cap` is too small.
+int orc_poa_align_dump(const char* seqs_nul, int nseq, int m, int n, int g, int e, int q, int c, int32_t* out, int cap) {
+  std::vector<std::string> seqs;
+  const char* p = seqs_nul;
+  for (int i = 0; i < nseq; ++i) {
+    seqs.emplace_back(p);
+    p += seqs.back().size() + 1;
+  }
+  PoaScoring sc{m, n, g, e, q, c};
+  PoaGraph gr;
+  std::vector<std::string_view> views(seqs.begin(), seqs.end() - 1);
+  std::vector<std::vector<u32>> ws;
+  for (usize i = 0; i + 1 < seqs.size(); ++i) ws.emplace_back(seqs[i].size(), 1u);
+  UpdateSpoaState(gr, sc, views, ws);
+  i32 dp_score = 0;
+  PoaAlignment const aln = PoaAlign(sc, seqs.back(), gr, &dp_score);
+  std::vector<int32_t> w;
+  w.push_back(static_cast<int32_t>(gr.nodes.size()));
+  for (auto const& nd : gr.nodes) {
+    w.push_back(static_cast<int32_t>(gr.decoder[nd.code]));
+    w.push_back(static_cast<int32_t>(nd.in_edges.size()));
+    for (u32 ei : nd.in_edges) w.push_back(static_cast<int32_t>(gr.edges[ei].tail));
+  }
+  for (u32 id : gr.rank_to_node) w.push_back(static_cast<int32_t>(id));
+  w.push_back(static_cast<int32_t>(aln.size()));
+  for (auto const& pr : aln) {
+    w.push_back(pr.first);
+    w.push_back(pr.second);
+  }
+  w.push_back(dp_score);
+  if (static_cast<int>(w.size()) > cap) return -1;
+  std::memcpy(out, w.data(), w.size() * sizeof(int32_t));
+  return static_cast<int>(w.size());
+}
+
 // single read<->haplotype alignment: rec[6] = hit, score, rs, re, qs, qe; cigar as text
-int orc_align_pair(const char* read, int m, const char* hap, int n, int band, int min_score,
+int orc_align_pair(const char* read, int m, const char* hap, int n, int min_score,
                    int32_t* rec, char* cigar_txt, int cap) {
   AlignParams ap;
-  ap.band = band;
   ap.min_score = min_score;
   AlnResult a = AlignReadToHap(std::string_view(read, m), std::string_view(hap, n), ap);
   rec[0] = a.hit; rec[1] = a.score; rec[2] = a.rs; rec[3] = a.re; rec[4] = a.qs; rec[5] = a.qe;
@@ -318,7 +356,6 @@ int orc_genotype_batch(const ma_params_t* prm, const ma_batch_t* b, const ma_asm
   int const MH = prm->max_haps, MV = prm->max_vars, MA = prm->max_alts, MP = prm->max_allele_bytes;
   int const S = prm->num_samples, NA = MA + 1, MCG = prm->max_cigar;
   AlignParams ap;
-  ap.band = prm->band;
   ap.min_score = prm->min_aln_score;
   for (int w = 0; w < b->n_windows; ++w) {
     u32 const nv = vo->win_nvars[w];

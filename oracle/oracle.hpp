@@ -100,7 +100,8 @@ struct PoaScoring {  // spoa::AlignmentEngine::Create(kNW, m, n, g, e, q, c)
   i32 m = 0, n = -6, g = -6, e = -2, q = -26, c = -1;  // caller/msa_builder.h:72-77
 };
 using PoaAlignment = std::vector<std::pair<i32, i32>>;  // (node id | -1, seq pos | -1)
-PoaAlignment PoaAlign(const PoaScoring& sc, std::string_view seq, const PoaGraph& g);
+// score_out (optional): the DP's optimum H(sink, L) the backtrack starts from
+PoaAlignment PoaAlign(const PoaScoring& sc, std::string_view seq, const PoaGraph& g, i32* score_out = nullptr);
 void PoaAddAlignment(PoaGraph& g, const PoaAlignment& aln, std::string_view seq,
                      const std::vector<u32>& weights);
 // caller/msa_builder.cpp:29-42
@@ -124,7 +125,8 @@ struct RawVariant {
 std::vector<RawVariant> ExtractVariants(const PoaGraph& g, u64 ref_anchor_pos1);
 
 // --- read <-> haplotype aligner (caller/genotyper.cpp:376-411; minimap2 2.30 replaced by the
-//     canonical seed-vote + banded overlap DP documented in DESIGN.md -- parity UNPINNED) ---
+//     canonical seed-anchored overlap DP documented in DESIGN.md -- scores pinned to a brute force,
+//     parity against minimap2 itself UNPINNED) ---
 struct CigarUnit { char op; u32 len; };
 struct AlnResult {
   bool hit = false;
@@ -132,7 +134,9 @@ struct AlnResult {
   u32 hap = 0;
   std::vector<CigarUnit> cigar;  // incl. leading/trailing S (genotyper.cpp:45-69)
 };
-struct AlignParams { i32 band = 64; i32 seed_k = 11; i32 min_score = 80; };
+struct AlignParams { i32 seed_k = 11; i32 min_score = 80; };
+i32 AlignReach(i32 m, i32 min_score);  // K of the search region R = [vmin - K, vmax + K]
+bool SeedDiagonals(const std::vector<u8>& q, const std::vector<u8>& t, i32 seed_k, i32 K, i32* vmin, i32* vmax);
 AlnResult AlignReadToHap(std::string_view read, std::string_view hap, const AlignParams& ap);
 
 // --- scoring epilogue + evidence (local_scorer.cpp, combined_scorer.cpp, genotyper.cpp:269-456)

@@ -192,7 +192,7 @@ void PoaAddAlignment(PoaGraph& g, const PoaAlignment& aln, std::string_view seq,
 
 // spoa::SisdAlignmentEngine::Align, AlignmentType::kNW.  Subtype selection follows
 // AlignmentEngine::Create: g >= e -> linear; g <= q || e >= c -> affine; else convex.
-PoaAlignment PoaAlign(const PoaScoring& sc, std::string_view seq, const PoaGraph& g) {
+PoaAlignment PoaAlign(const PoaScoring& sc, std::string_view seq, const PoaGraph& g, i32* score_out) {
   u32 const L = static_cast<u32>(seq.size());
   if (g.nodes.empty() || L == 0) return {};
   enum { LINEAR, AFFINE, CONVEX } sub = sc.g >= sc.e ? LINEAR : ((sc.g <= sc.q || sc.e >= sc.c) ? AFFINE : CONVEX);
@@ -335,6 +335,7 @@ PoaAlignment PoaAlign(const PoaScoring& sc, std::string_view seq, const PoaGraph
       }
     }
   }
+  if (score_out) *score_out = max_score;
   if (max_i == 0 && max_j == 0) return {};
 
   // --- backtrack ---

@@ -1,0 +1,215 @@
+"""Pins for the two restated third-party aligners ("parity unpinned" for SPOA's convex model and for
+minimap2).  The oracle's optimal SCORES are compared with tests/brute_force.py -- numpy, different formulation,
+no shared code -- on seeded random cases and on committed golden vectors (tests/golden/pins_aligner.npz, made by
+tests/golden/make_aligner_pins.py from the brute force alone).  Tie rules (which of several co-optimal alignments
+is reported) stay documented conventions; what is pinned here is optimality and internal consistency."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import brute_force as bf
+from harness import oracle
+from pin_cases import CASES, make_haplotypes, make_pair, rand_dna
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "pins_aligner.npz")
+
+
+def oracle_align(read, hap, min_score=80):
+    lib = oracle()
+    rec = (C.c_int32 * 6)()
+    txt = C.create_string_buffer(8192)
+    rc = lib.orc_align_pair(read, len(read), hap, len(hap), min_score, rec, txt, 8192)
+    assert rc == 0
+    cig, num = [], ""
+    for ch in txt.value.decode():
+        if ch.isdigit():
+            num += ch
+        else:
+            cig.append((ch, int(num)))
+            num = ""
+    return list(rec), cig
+
+
+def check_pair(read, hap, want_hit=None, want_score=None):
+    rec, cig = oracle_align(read, hap)
+    hit, score = bf.canonical_pair(read, hap) if want_hit is None else (want_hit, want_score)
+    assert bool(rec[0]) == bool(hit), (rec, hit, score)
+    if not hit:
+        return rec, cig
+    assert rec[1] == score, f"oracle score {rec[1]} != brute-force optimum {score}"
+    # the reported alignment is worth what it claims and spans what it claims
+    s, qp, tp = bf.cigar_score(read, hap, rec[2], cig)
+    assert s == rec[1] and qp == len(read) and tp == rec[3], (s, qp, tp, rec, cig)
+    lead = cig[0][1] if cig[0][0] == "S" else 0
+    trail = cig[-1][1] if len(cig) > 1 and cig[-1][0] == "S" else 0
+    assert lead == rec[4] and len(read) - trail == rec[5]
+    # soft clips only where the read hangs over a haplotype end (overlap alignment, end bonus in the reference)
+    assert lead == 0 or rec[2] == 0
+    assert trail == 0 or rec[3] == len(hap)
+    return rec, cig
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_read_aligner_scores_are_optimal(case):
+    rng = np.random.default_rng(1234 + CASES.index(case))
+    for _ in range(60):
+        read, hap = make_pair(rng, case)
+        check_pair(read, hap)
+
+
+def test_read_aligner_golden_pins():
+    g = np.load(GOLD)
+    reads, haps = g["reads"], g["haps"]
+    ro, ho = g["read_off"], g["hap_off"]
+    for x in range(len(g["hit"])):
+        read, hap = bytes(reads[ro[x]:ro[x + 1]]), bytes(haps[ho[x]:ho[x + 1]])
+        check_pair(read, hap, bool(g["hit"][x]), int(g["score"][x]))
+
+
+def test_search_region_never_cuts_a_supported_hit():
+    """when the optimum inside R is a hit whose cost leaves more exact 11-mers on the path than
+    there are seeds outside the region's core, the UNRESTRICTED optimum is the same alignment score -- the region is
+    an optimisation of the search, like the reference's bw = 10000, not a semantic limit."""
+    rng = np.random.default_rng(99)
+    checked = 0
+    for _ in range(120):
+        read, hap = make_pair(rng, str(rng.choice(["clean", "noisy", "indel"])))
+        hit, score = bf.canonical_pair(read, hap)
+        if not hit:
+            continue
+        m = len(read)
+        cost = m - score
+        if m - 10 - 11 * (cost // 5) - cost % 5 <= 0:
+            continue  # too noisy for the seed argument: no claim
+        free, _, _ = bf.overlap_best(read, hap)
+        sd = bf.seed_diagonals(read, hap, bf.reach(m))
+        if sd[1] - sd[0] > 64:
+            continue  # spurious far seeds: the argument needs the vote counts, not exercised here
+        assert free == score, (free, score)
+        checked += 1
+    assert checked > 40
+
+
+def test_long_indels_follow_the_cost_bound():
+    """A 150-base read across a 100-300 bp deletion cannot score 80 end to end (cost 12 + 3 L); one that ends inside
+    the flank aligns to the side it mostly lies on; a 250-base read across a 40 bp indel still aligns through it."""
+    rng = np.random.default_rng(7)
+    for L in (100, 200, 300):
+        hap = rand_dna(rng, 1200)
+        alt = hap[:500] + hap[500 + L:]
+        read = alt[425:575]  # 75 bases either side of the deletion
+        rec, _ = check_pair(read, hap)
+        assert rec[0] == 0
+        rec, cig = check_pair(read, alt)
+        assert rec[0] == 1 and rec[1] == 150 and cig == [("M", 150)]
+    hap = rand_dna(rng, 1000)
+    alt = hap[:400] + hap[440:]
+    read = alt[275:525]
+    rec, cig = check_pair(read, hap)
+    assert rec[0] == 1 and rec[1] == 250 - (12 + 3 * 40) and ("D", 40) in cig
+
+
+# ---- SPOA convex model ------------------------------------------------------------------------------------------
+
+def poa_dump(seqs, sc=(0, -6, -6, -2, -26, -1)):
+    lib = oracle()
+    blob = b"".join(s + b"\0" for s in seqs)
+    cap = 64 * sum(len(s) for s in seqs) + 1024
+    out = (C.c_int32 * cap)()
+    n = lib.orc_poa_align_dump(blob, len(seqs), *sc, out, cap)
+    assert n > 0
+    w = list(out[:n])
+    V = w[0]
+    pos = 1
+    base, preds = [], []
+    for _ in range(V):
+        base.append(w[pos])
+        k = w[pos + 1]
+        preds.append(w[pos + 2: pos + 2 + k])
+        pos += 2 + k
+    order = w[pos:pos + V]
+    pos += V
+    A = w[pos]
+    pairs = [(w[pos + 1 + 2 * x], w[pos + 2 + 2 * x]) for x in range(A)]
+    return base, preds, order, pairs, w[pos + 1 + 2 * A]
+
+
+def poa_alignment_score(seq, base, preds, pairs, gaps):
+    """score of an alignment [(node | -1, seq pos | -1)]: the path must walk graph edges from a source to a sink and
+    consume the sequence in order; a run of one gap kind costs the best affine model for its length"""
+    def gap(L):
+        return max(g + (L - 1) * e for g, e in gaps)
+    succ_of = {v: set() for v in range(len(base))}
+    for v, ps in enumerate(preds):
+        for p in ps:
+            succ_of[p].add(v)
+    score, last_node, next_pos = 0, None, 0
+    run_kind, run_len = None, 0
+
+    def close():
+        nonlocal score, run_kind, run_len
+        if run_kind is not None:
+            score += gap(run_len)
+        run_kind, run_len = None, 0
+
+    for node, pos in pairs:
+        if node >= 0:
+            if last_node is None:
+                assert not preds[node], "alignment must start at a source node"
+            else:
+                assert node in succ_of[last_node], "alignment path leaves the graph"
+            last_node = node
+        if pos >= 0:
+            assert pos == next_pos
+            next_pos += 1
+        if node >= 0 and pos >= 0:
+            close()
+            score += 0 if base[node] == seq[pos] else -6
+        else:
+            kind = "ins" if node < 0 else "del"
+            if run_kind != kind:
+                close()
+                run_kind = kind
+            run_len += 1
+    close()
+    assert next_pos == len(seq)
+    assert last_node is not None and not succ_of[last_node], "alignment must end at a sink node"
+    return score
+
+
+@pytest.mark.parametrize("nh", [2, 3, 4, 5])
+def test_poa_convex_alignment_is_optimal(nh):
+    """production parameters (msa_builder.h:72-77): the optimum the restated SPOA engine computes for the last
+    haplotype equals the optimum of an independent sequence-to-DAG DP with gap(L) =
+    max(-6 - 2 (L-1), -26 - (L-1)) -- including 20/21/22-base gaps, where the two affine models cross."""
+    rng = np.random.default_rng(500 + nh)
+    gaps = ((-6, -2), (-26, -1))
+    exact = 0
+    for _ in range(12):
+        haps = make_haplotypes(rng, nh, int(rng.integers(150, 400)))
+        base, preds, order, pairs, dp_score = poa_dump(haps)
+        sinks = [v for v in range(len(base)) if not any(v in p for p in preds)]
+        want = bf.dag_global_score(haps[-1], np.array(base), preds, order, sinks)
+        assert dp_score == want, (dp_score, want)
+        # SPOA's backtrack follows "E or Q extends" jointly (restated literally in oracle/poa.cpp), so the path it
+        # returns is a valid source-to-sink alignment but may be worth less than the optimum it started from
+        got = poa_alignment_score(haps[-1], base, preds, pairs, gaps)
+        assert got <= want
+        exact += got == want
+    assert exact >= 8
+
+
+def test_poa_gap_crossover_is_at_21():
+    """msa_builder.h:64 says the models cross "at exactly 20 bp" (6 + 2L = 26 + L); in SPOA's g + (L-1) e form
+    (msa_builder.h:70) both cost 44 at L = 20 + ... : -6 - 2 (L-1) = -26 - (L-1) <=> L = 21.  Pinned: a lone 21-base
+    deletion costs 46 under either model, 20 bases cost 44 (first model), 22 bases cost 47 (second model)."""
+    assert bf.convex_gap(20) == -44 and bf.convex_gap(21) == -46 and bf.convex_gap(22) == -47
+    rng = np.random.default_rng(3)
+    for L, cost in ((20, -44), (21, -46), (22, -47), (40, -65)):
+        ref = rand_dna(rng, 300)
+        alt = ref[:150] + ref[150 + L:]
+        base, preds, order, pairs, dp_score = poa_dump([ref, alt])
+        got = poa_alignment_score(alt, base, preds, pairs, ((-6, -2), (-26, -1)))
+        assert got == cost and dp_score == cost, (L, got, dp_score)

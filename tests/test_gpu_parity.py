@@ -216,7 +216,8 @@ def test_process_batch_end_to_end():
 import glob  # noqa: E402
 import os  # noqa: E402
 
-_GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
+_GOLDEN = sorted(p for p in glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz"))
+                if not os.path.basename(p).startswith("pins_"))  # pins_*: brute-force score pins (test_aligner_pins.py)
 
 
 @pytest.mark.parametrize("path", _GOLDEN, ids=[os.path.basename(p) for p in _GOLDEN])
@@ -493,12 +494,14 @@ def test_process_batch_deep_window():
     assert int(wv["win_nvars"][0]) >= 8
 
 
-@pytest.mark.parametrize("band,kw", [(32, {}), (96, dict(big_indel=50)), (128, dict(big_indel=80, depths=(40, 40)))])
-def test_genotype_parity_other_band_widths(band, kw):
-    """Band half-widths other than the default 64 take the generic alignment kernel (band row in LDS): narrow band
-    and the wide bands a deep panel with long indels asks for (BASELINE configs[3])."""
+@pytest.mark.parametrize("tier,kw", [(1, {}), (2, dict(big_indel=50)), (3, dict(big_indel=80, depths=(40, 40))),
+                                     (0, dict(big_indel=80, depths=(40, 40), read_len=250))])
+def test_genotype_parity_alignment_tiers(tier, kw):
+    """aln_tier is a testing knob that results must not depend on: bit 0 sends every DP pair through the any-width
+    kernel (row in LDS), bit 1 switches the gapless certificates off so that every seeded pair runs the DP.  Long
+    indels (BASELINE configs[3]) and 250-base reads widen the search regions into the upper width classes."""
     from lancet2_amd.engine import Engine
-    params = capi.default_params(min_k=25, max_k=25, band=band)
+    params = capi.default_params(min_k=25, max_k=25, aln_tier=tier)
     arrs, n, nr = synth.make_config_batch("C2", 3, first_index=91_000, **kw)
     orc = OracleEngine(params)
     asm = orc.assemble(arrs, n, nr)
