@@ -48,6 +48,19 @@ __global__ __launch_bounds__(256) void k_workload_stats(GraphWs ws, unsigned lon
   }
 }
 
+// Capacity retry: windows whose graph did not fit the node array / search arena are put back to "pending" so that the
+// next pass, with larger capacities, assembles them from scratch; counts them.
+__global__ void k_reset_overflowed(ma_asm_out_t o, u32* win_flags, int n, u32* count) {
+  int const i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (!(o.win_status[i] & MA_W_TABLE_OVERFLOW)) return;
+  o.win_status[i] = MA_W_NO_HAPLOTYPE;
+  o.win_k[i] = 0;
+  o.win_ncomp[i] = 0;
+  win_flags[i] = 0;
+  atomicAdd(count, 1u);
+}
+
 int ceil_log2(u64 v) {
   int l = 0;
   while ((u64(1) << l) < v) ++l;
@@ -120,14 +133,11 @@ int launch_assemble(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& out, const
   ws.inst_stride = (max_inst + 63) & ~63u;
   ws.ref_stride = (max_refk + 63) & ~63u;
   ws.max_ref_len = max_refk + static_cast<u32>(P.min_k) + 8;  // longest reference window (+ slack)
-  u32 nc = 8192;
-  if (const char* e = getenv("MA_NODE_CAP")) nc = static_cast<u32>(atoi(e));
-  nc = std::max<u32>(nc, 2 * max_refk + 64);
-  if (max_inst > 400000) nc = std::max<u32>(nc, 32768);  // deep panels keep more recurrent-error k-mers
-  ws.nc = nc;
-  u32 ac = 1u << 16;
-  if (const char* e = getenv("MA_ARENA_CAP")) ac = static_cast<u32>(atoi(e));
-  ws.ac = ac;
+  u32 nc0 = std::max<u32>(8192, 2 * max_refk + 64);
+  if (max_inst > 400000) nc0 = std::max<u32>(nc0, 32768);  // deep panels keep more recurrent-error k-mers
+  if (const char* e = getenv("MA_NODE_CAP")) nc0 = std::max<u32>(256, static_cast<u32>(atoi(e)));  // tests: force the retry passes
+  u32 ac0 = 1u << 16;
+  if (const char* e = getenv("MA_ARENA_CAP")) ac0 = static_cast<u32>(atoi(e));
 
   // per-window workspace footprint -> chunk size
   auto carve_ws = [&](Carver& c, GraphWs& g, size_t A) {
@@ -165,54 +175,81 @@ int launch_assemble(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& out, const
     g.scratch = c.take<u32>(A * NC * 32);
     g.arena = c.take<uint4>(A * g.ac);
   };
-  Carver probe{nullptr};
-  {
-    GraphWs tmp = ws;
-    carve_ws(probe, tmp, 1);
-  }
-  size_t const per_window = probe.off + 4096;
-  size_t budget = stage_budget(0.30, ctx->ws_build.cap, size_t(24) << 30, ctx->hbm_share);
-  if (const char* e = getenv("MA_WS_GB")) budget = static_cast<size_t>(atoi(e)) << 30;
-  int chunk = static_cast<int>(std::max<size_t>(1, std::min<size_t>(n, budget / per_window)));
-  MA_HIP(ctx, ctx->ws_build.reserve(per_window * static_cast<size_t>(chunk)));
-  if (getenv("MA_VERBOSE"))
-    fprintf(stderr, "[microasm] assemble: %d windows, %.2f MB/window, budget %.1f GB -> chunks of %d (nc %u, tc_log2 %d)\n", n,
-            per_window / 1048576.0, budget / 1073741824.0, chunk, ws.nc, ws.tc_log2);
 
   ctx->stats[2] += static_cast<unsigned long long>(n);
-  for (int win0 = 0; win0 < n; win0 += chunk) {
-    int const nwin = std::min(chunk, n - win0);
-    Carver cw{static_cast<char*>(ctx->ws_build.p)};
-    carve_ws(cw, ws, static_cast<size_t>(nwin));
-    for (int k = P.min_k; k <= P.max_k; k += P.k_step) {
-      ws.k = k;
-      u64 pk1 = 1;
-      for (int i = 0; i < k - 1; ++i) pk1 *= kHashP;
-      ws.pk1 = pk1;
-      ws.pinv = mod_inverse_pow2(kHashP);
-      MA_TRY_RC(run_select_active(ctx, ws, win0, nwin, gate_approx, out.win_k, active, counters + 8));
-      u32 host_cnt[2] = {0, 0};
-      MA_HIP(ctx, hipMemcpyAsync(host_cnt, counters + 8, 8, hipMemcpyDeviceToHost, ctx->stream));
+  // Pass 0 runs every window with the planned capacities.  Windows that come back flagged TABLE_OVERFLOW (graph larger
+  // than the node array, walk search larger than the arena: the reference has no such limits) are re-assembled from
+  // scratch by up to two more passes with 4x / 16x the node capacity and 8x / 64x the search arena -- only they are active, the workspace
+  // is re-carved for fewer windows in flight.  What is still flagged afterwards is a limit growing cannot lift (more
+  // than 16 edges on a node, a traversal cap the folded search cannot place: DESIGN.md section 7).
+  for (int pass = 0; pass < 3; ++pass) {
+    u32 const grow = pass == 0 ? 1u : (pass == 1 ? 4u : 16u);
+    ws.nc = nc0 * grow;
+    // the arena of the last pass holds what the reference's own cap allows: 2^20 pops (max_flow.h:69), a few pushes each
+    // (components of more than ~400 nodes search unfolded, clean.hip)
+    ws.ac = pass == 2 ? std::max<u32>(ac0 * 16u, 1u << 22) : ac0 * (pass == 1 ? 8u : 1u);
+    ws.tc_log2 = tc_log2_alloc;
+    ws.mc_log2 = mc_log2_alloc;
+    if (pass > 0) {
+      if (getenv("MA_NO_CAP_RETRY")) break;  // tests: show what a pass leaves flagged
+      MA_HIP(ctx, hipMemsetAsync(counters + 10, 0, 4, ctx->stream));
+      hipLaunchKernelGGL(k_reset_overflowed, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, out, win_flags, n, counters + 10);
+      u32 n_over = 0;
+      MA_HIP(ctx, hipMemcpyAsync(&n_over, counters + 10, 4, hipMemcpyDeviceToHost, ctx->stream));
       MA_HIP(ctx, ma_stream_sync(ctx));
-      ws.n_active = static_cast<int>(host_cnt[0]);
-      ws.active = active;
-      if (host_cnt[1] == 0) break;  // every window of the chunk is resolved (graph.cpp:106 loop exit)
-      if (ws.n_active > 0) {
-        ctx->stats[3] += static_cast<unsigned long long>(ws.n_active);
-        MA_TRY_RC(run_count_inst(ctx, b, ws, win0, nwin, counters));
-        ws.tc_log2 = tc_log2_alloc;
-        ws.mc_log2 = mc_log2_alloc;  // run_build_pass shrinks both to what this attempt needs
-        MA_TRY_RC(run_build_pass(ctx, b, ws, counters + 12, tc_log2_alloc));
-        if (ctx->collect) {
-          MA_HIP(ctx, ctx->dev_stats.reserve(64));
-          if (!ctx->dev_stats_clean) {
-            MA_HIP(ctx, hipMemsetAsync(ctx->dev_stats.p, 0, 64, ctx->stream));
-            ctx->dev_stats_clean = true;
+      if (n_over == 0) break;
+      if (getenv("MA_VERBOSE")) fprintf(stderr, "[microasm] assemble: capacity retry %d for %u windows (nc %u, ac %u)\n", pass, n_over, ws.nc, ws.ac);
+    }
+    Carver probe{nullptr};
+    {
+      GraphWs tmp = ws;
+      carve_ws(probe, tmp, 1);
+    }
+    size_t const per_window = probe.off + 4096;
+    size_t budget = stage_budget(0.30, ctx->ws_build.cap, size_t(24) << 30, ctx->hbm_share);
+    if (const char* e = getenv("MA_WS_GB")) budget = static_cast<size_t>(atoi(e)) << 30;
+    int chunk = static_cast<int>(std::max<size_t>(1, std::min<size_t>(n, budget / per_window)));
+    MA_HIP(ctx, ctx->ws_build.reserve(per_window * static_cast<size_t>(chunk)));
+    if (getenv("MA_VERBOSE"))
+      fprintf(stderr, "[microasm] assemble: %d windows, %.2f MB/window, budget %.1f GB -> chunks of %d (nc %u, tc_log2 %d)\n", n,
+              per_window / 1048576.0, budget / 1073741824.0, chunk, ws.nc, ws.tc_log2);
+
+    for (int win0 = 0; win0 < n; win0 += chunk) {
+      int const nwin = std::min(chunk, n - win0);
+      ws.tc_log2 = tc_log2_alloc;
+      ws.mc_log2 = mc_log2_alloc;
+      Carver cw{static_cast<char*>(ctx->ws_build.p)};
+      carve_ws(cw, ws, static_cast<size_t>(nwin));
+      for (int k = P.min_k; k <= P.max_k; k += P.k_step) {
+        ws.k = k;
+        u64 pk1 = 1;
+        for (int i = 0; i < k - 1; ++i) pk1 *= kHashP;
+        ws.pk1 = pk1;
+        ws.pinv = mod_inverse_pow2(kHashP);
+        MA_TRY_RC(run_select_active(ctx, ws, win0, nwin, gate_approx, out.win_k, active, counters + 8));
+        u32 host_cnt[2] = {0, 0};
+        MA_HIP(ctx, hipMemcpyAsync(host_cnt, counters + 8, 8, hipMemcpyDeviceToHost, ctx->stream));
+        MA_HIP(ctx, ma_stream_sync(ctx));
+        ws.n_active = static_cast<int>(host_cnt[0]);
+        ws.active = active;
+        if (host_cnt[1] == 0) break;  // every window of the chunk is resolved (graph.cpp:106 loop exit)
+        if (ws.n_active > 0) {
+          ctx->stats[3] += static_cast<unsigned long long>(ws.n_active);
+          MA_TRY_RC(run_count_inst(ctx, b, ws, win0, nwin, counters));
+          ws.tc_log2 = tc_log2_alloc;
+          ws.mc_log2 = mc_log2_alloc;  // run_build_pass shrinks both to what this attempt needs
+          MA_TRY_RC(run_build_pass(ctx, b, ws, counters + 12, tc_log2_alloc));
+          if (ctx->collect) {
+            MA_HIP(ctx, ctx->dev_stats.reserve(64));
+            if (!ctx->dev_stats_clean) {
+              MA_HIP(ctx, hipMemsetAsync(ctx->dev_stats.p, 0, 64, ctx->stream));
+              ctx->dev_stats_clean = true;
+            }
+            hipLaunchKernelGGL(k_workload_stats, dim3(ws.n_active), dim3(256), 0, ctx->stream, ws,
+                               ctx->dev_stats.as<unsigned long long>());
           }
-          hipLaunchKernelGGL(k_workload_stats, dim3(ws.n_active), dim3(256), 0, ctx->stream, ws,
-                             ctx->dev_stats.as<unsigned long long>());
+          MA_TRY_RC(run_clean_pass(ctx, b, ws, out));
         }
-        MA_TRY_RC(run_clean_pass(ctx, b, ws, out));
       }
     }
   }

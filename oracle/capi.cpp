@@ -74,6 +74,14 @@ void orc_default_params(ma_params_t* p) {
   p->case_ctrl_mode = 1;
 }
 
+// control-flow event counters of the assembler since the last call (see graph.cpp); reset on read
+void orc_debug_counters(unsigned long long* out) {
+  for (int i = 0; i < 4; ++i) {
+    out[i] = g_debug_counters[i];
+    g_debug_counters[i] = 0;
+  }
+}
+
 // ---- small known-answer hooks (tests/test_oracle_kat.py) ----
 uint64_t orc_hamming(const char* a, const char* b, uint64_t n) {
   return HammingDist(std::string_view(a, n), std::string_view(b, n));
@@ -216,6 +224,7 @@ int orc_assemble_batch(const ma_params_t* prm, const ma_batch_t* b, const ma_asm
     u32 nalt = 0;
     for (auto const& c : res.comps) nalt += static_cast<u32>(c.haps.size()) - 1;
     if (nalt == 0) status |= MA_W_NO_HAPLOTYPE;
+    if (res.hit_bfs_limit) status |= MA_W_BFS_LIMIT;
     u32 ncomp = 0, slot = 0;
     for (auto const& c : res.comps) {
       if (c.hit_bfs_limit) status |= MA_W_BFS_LIMIT;

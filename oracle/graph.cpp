@@ -15,6 +15,11 @@
 
 namespace orc {
 
+// test instrumentation (tests/: which control-flow branches a crafted window reached): [0] cycle found, [1] complexity
+// gate fired, [2] traversal limit hit -- counted over every k attempt since the last reset
+unsigned long long g_debug_counters[4] = {0, 0, 0, 0};
+
+
 namespace {
 
 enum EdgeKind : u8 { PP = 0, PM = 1, MP = 2, MM = 3 };  // cbdg/kmer.h:12
@@ -601,6 +606,7 @@ std::vector<Haplotype> Graph::BuildHaplotypes(u32 comp, const TraversalIndex& id
       nvisits++;
       if (nvisits > mPrm.bfs_limit) {
         *hit_limit = true;
+        g_debug_counters[2]++;
         break;
       }
       u32 const ai = static_cast<u32>(head++);
@@ -680,7 +686,7 @@ AssemblyResult Graph::Run() {
       for (auto const& nd : mNodes) alive += nd.alive;
       fprintf(stderr, "[orc] after lowcov1 alive=%zu comps=%zu (largest %u)\n", alive, comps.size(), comps.empty() ? 0 : comps[0].n);
     }
-    bool retry = false;
+    bool retry = false, attempt_limit = false;
     for (auto const& ci : comps) {
       auto const src = FindSource(ci.id), snk = FindSink(ci.id);
       if (dbg) fprintf(stderr, "[orc] comp %u n=%u src=%d@%zu snk=%d@%zu\n", ci.id, ci.n, src.found, src.off, snk.found, snk.off);
@@ -694,17 +700,20 @@ AssemblyResult Graph::Run() {
       auto const tidx = BuildTraversalIndex(ci.id);
       if (dbg) fprintf(stderr, "[orc] pruned: nodes=%zu edges=%zu\n", tidx.nodes.size(), tidx.orig_edges.size());
       if (HasCycle(tidx)) {
+        g_debug_counters[0]++;
         if (dbg) fprintf(stderr, "[orc] cycle\n");
         retry = true;
         break;
       }
       auto const cx = ComputeComplexity(ci.id);
       if (cx.IsComplex()) {
+        g_debug_counters[1]++;
         retry = true;
         break;
       }
       bool hit = false;
       auto haps = BuildHaplotypes(ci.id, tidx, ref_anchor, &hit);
+      attempt_limit = attempt_limit || hit;
       if (dbg) fprintf(stderr, "[orc] haps=%zu cc=%llu bp=%llu\n", haps.size(), (unsigned long long)cx.cyclomatic, (unsigned long long)cx.branch_points);
       if (haps.empty()) continue;
       ComponentResult cr;
@@ -715,6 +724,9 @@ AssemblyResult Graph::Run() {
       out.comps.push_back(std::move(cr));
     }
     if (retry) out.comps.clear();
+    // MA_W_BFS_LIMIT: some component of the k attempt that produced the window's result stopped at the traversal cap --
+    // whether or not that component itself still yielded walks (it is skipped when it did not, graph.cpp:225-226)
+    out.hit_bfs_limit = !out.comps.empty() && attempt_limit;
   }
   return out;
 }

@@ -62,7 +62,10 @@ struct ComponentResult {
 struct AssemblyResult {
   std::vector<ComponentResult> comps;
   u32 used_k = 0;  // Graph::CurrentK() after the call
+  bool hit_bfs_limit = false;  // MaxFlow::HitTraversalLimit in some component of the reported attempt
 };
+
+extern unsigned long long g_debug_counters[4];  // graph.cpp: cycle / complexity gate / traversal limit events
 
 // repeat.cpp
 usize HammingDist(std::string_view a, std::string_view b);

@@ -76,3 +76,43 @@ def make_haplotypes(rng, nh, L):
         haps.append(mutate(rng, ref, sub=float(rng.choice([0.0, 0.005, 0.02])),
                            indels=[(str(rng.choice(["I", "D"])), s) for s in sizes]))
     return haps
+
+
+# ---- crafted windows (error-free reads drawn from explicit haplotypes) ---------------------------------------------
+
+def window_from_haps(rng, ref, samples, depth=30, read_len=150, qname0=0):
+    """samples: [(list of haplotype byte strings, role)]; paired error-free reads tiling every haplotype at
+    depth / len(haplotypes); returns a synth.pack_batch window dict (collector order)"""
+    reads, qn = [], qname0
+    for s, (hset, role) in enumerate(samples):
+        for h in hset:
+            n_frag = int(depth / len(hset) * len(h) / (2 * read_len))
+            for _ in range(n_frag):
+                ins = int(max(read_len + 10, rng.normal(400, 50)))
+                fs = int(rng.integers(0, max(1, len(h) - ins)))
+                frag = h[fs:fs + ins]
+                for start, seq, rev in ((fs, frag[:read_len], False), (fs + ins - read_len, frag[-read_len:], True)):
+                    reads.append(dict(seq=np.frombuffer(seq, np.uint8).copy(), qual=np.full(len(seq), 35, np.uint8),
+                                      qname=qn, sample=s, role=role, rev=rev, passf=True, start=start, hint=-(1 << 31)))
+                qn += 1
+    reads.sort(key=lambda r: (0 if r["passf"] else 1, r["role"], r["sample"], r["qname"], r["start"]))
+    return dict(ref=np.frombuffer(ref, np.uint8).copy(), reads=reads)
+
+
+def many_bubble_window(seed, nsites, spacing=38):
+    """a window of 520 + nsites * spacing + 160 bases in two stretches of read coverage: [0, 400) with one heterozygous
+    SNV, and [520, end) with `nsites` heterozygous SNVs `spacing` bases apart (every one a bubble at k < spacing).
+    ~30-45 bubbles exhaust MaxFlow's 2^20-visit cap (max_flow.h:69); >= 50 trip the complexity gate
+    (graph_complexity.h:112-121: cyclomatic complexity >= 50 and branch points >= 50)."""
+    rng = np.random.default_rng(seed)
+    W = 520 + nsites * spacing + 160
+    ref = rand_dna(rng, W)
+    alt = bytearray(ref)
+    for p in [200] + [600 + x * spacing for x in range(nsites)]:
+        alt[p] = BASES[(BASES.index(bytes([alt[p]])) + 1) % 4]
+    alt = bytes(alt)
+    reads = []
+    for part, (r_, a_) in enumerate(((ref[:400], alt[:400]), (ref[520:], alt[520:]))):
+        reads += window_from_haps(rng, r_, [([r_, a_], 0), ([r_, a_], 1)], qname0=100000 * part)["reads"]
+    reads.sort(key=lambda r: (0 if r["passf"] else 1, r["role"], r["sample"], r["qname"], r["start"]))
+    return dict(ref=np.frombuffer(ref, np.uint8).copy(), reads=reads)
