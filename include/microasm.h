@@ -166,13 +166,20 @@ typedef struct ma_var_out {
 typedef struct ma_geno_out {
   /* [n * max_vars * num_samples * (max_alts+1) * 2]: fwd, rev read counts per allele (AD = fwd+rev) */
   uint32_t* allele_counts;
-  double* var_qual;       /* [n * max_vars] site QUAL (SOLOR in case/ctrl mode, else 0) */
+  double* var_qual;       /* [n * max_vars] site QUAL: SOLOR in case/ctrl mode (variant_call.cpp:316-345), else the largest
+                           * PL[0/0] over the samples with evidence (variant_call.cpp:289-303) */
   /* optional debug taps (may be NULL): per read x haplotype slot of the read's window */
   int32_t* aln_rec;       /* [n_reads * max_haps * 6] hit, score, rs, re, qs, qe */
   uint32_t* aln_cigar;    /* [n_reads * max_haps * (1 + max_cigar)] n_ops, then len<<4|op (op: 0 M 1 I 2 D 4 S) */
   /* optional: per read x variant: allele (255 = none) and CombinedScore */
   uint8_t* asg_allele;    /* [n_reads * max_vars] */
   double* asg_score;      /* [n_reads * max_vars] */
+  /* optional (may be NULL): FORMAT PL and GQ of every sample with evidence -- Dirichlet-multinomial genotype
+   * likelihoods over the sample's allele depths (caller/genotype_likelihood.cpp:93-272), VCF genotype order
+   * (0/0, 0/1, 1/1, 0/2, ...), G = (max_alts + 1)(max_alts + 2) / 2 slots of which the first K(K+1)/2 are used for a
+   * variant with K alleles; zero for samples without evidence */
+  uint32_t* var_pl;       /* [n * max_vars * num_samples * G] */
+  uint32_t* var_gq;       /* [n * max_vars * num_samples] */
 } ma_geno_out_t;
 
 /* ---- variant annotation (core/variant_annotator.cpp:43-101; VCF INFO SEQ_CX / GRAPH_CX) ------ */

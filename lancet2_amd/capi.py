@@ -61,7 +61,7 @@ class VarOut(C.Structure):
 
 class GenoOut(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in (
-        "allele_counts", "var_qual", "aln_rec", "aln_cigar", "asg_allele", "asg_score")]
+        "allele_counts", "var_qual", "aln_rec", "aln_cigar", "asg_allele", "asg_score", "var_pl", "var_gq")]
 
 
 def load_cdll(path=None):
@@ -113,7 +113,8 @@ def var_out_spec(p, n):
 
 def geno_out_spec(p, n, n_reads, debug=True):
     MH, MV, MA, S, MCG = p.max_haps, p.max_vars, p.max_alts, p.num_samples, p.max_cigar
-    spec = dict(allele_counts=(np.uint32, n * MV * S * (MA + 1) * 2), var_qual=(np.float64, n * MV))
+    spec = dict(allele_counts=(np.uint32, n * MV * S * (MA + 1) * 2), var_qual=(np.float64, n * MV),
+                var_pl=(np.uint32, n * MV * S * ((MA + 1) * (MA + 2) // 2)), var_gq=(np.uint32, n * MV * S))
     if debug:
         spec.update(aln_rec=(np.int32, n_reads * MH * 6), aln_cigar=(np.uint32, n_reads * MH * (1 + MCG)),
                     asg_allele=(np.uint8, n_reads * MV), asg_score=(np.float64, n_reads * MV))

@@ -1506,25 +1506,98 @@ __global__ __launch_bounds__(64) void k_evidence(GArgs A) {
   }
 }
 
-// site quality (variant_call.cpp:289-345): max over case samples with evidence of SOLOR
+// Dirichlet-multinomial genotype likelihoods of one sample (caller/genotype_likelihood.cpp:93-128, :205-248): K alleles,
+// K (K + 1) / 2 genotypes in VCF order; the same sequential f64 operations as the reference, lgamma from the device
+// math library (the PLs are integers: a last-ulp difference in lgamma moves one only when it sits within ~1e-12 of a
+// rounding boundary).  Writes the PLs (optional) and returns PL[0/0]; *gq = second-smallest PL, capped at 99.
+__device__ u32 genotype_pls(const u32* cnt2, int K, u32* pl_out, u32* gq) {
+  constexpr f64 kBackgroundError = 0.005, kOverdispersion = 0.01, kAlphaFloor = 1e-6;
+  constexpr int kMaxK = 16;
+  f64 const precision = (1.0 - kOverdispersion) / kOverdispersion;
+  f64 const main_mass = 1.0 - kBackgroundError;
+  f64 const cap = 4294967295.0 / 2.0, ln_ten = 2.302585092994045684017991454684364208;
+  f64 c[kMaxK];
+  for (int k = 0; k < K; ++k) c[k] = static_cast<f64>(cnt2[2 * k] + cnt2[2 * k + 1]);
+  auto loglk = [&](int a, int b) {
+    f64 log_prob = 0.0, alpha_sum = 0.0, count_alpha_sum = 0.0;
+    for (int k = 0; k < K; ++k) {
+      f64 mu = kBackgroundError / K;
+      if (a == b) {
+        if (k == a) mu += main_mass;
+      } else {
+        if (k == a) mu += main_mass / 2.0;
+        if (k == b) mu += main_mass / 2.0;
+      }
+      f64 const alpha = fmax(kAlphaFloor, mu * precision);
+      log_prob += lgamma(c[k] + alpha) - lgamma(alpha);
+      alpha_sum += alpha;
+      count_alpha_sum += c[k] + alpha;
+    }
+    return log_prob + (lgamma(alpha_sum) - lgamma(count_alpha_sum));
+  };
+  f64 best = -1.0e300;
+  for (int b = 0; b < K; ++b)
+    for (int a = 0; a <= b; ++a) best = fmax(best, loglk(a, b));
+  u32 min1 = 0xFFFFFFFFu, min2 = 0xFFFFFFFFu, pl0 = 0;
+  int g = 0;
+  for (int b = 0; b < K; ++b)
+    for (int a = 0; a <= b; ++a, ++g) {
+      f64 const raw = -10.0 * (loglk(a, b) - best) / ln_ten;
+      u32 const pl = static_cast<u32>(round(fmin(raw, cap)));
+      if (pl_out) pl_out[g] = pl;
+      if (g == 0) pl0 = pl;
+      if (pl < min1) {
+        min2 = min1;
+        min1 = pl;
+      } else if (pl < min2) {
+        min2 = pl;
+      }
+    }
+  *gq = g < 2 ? 0u : min(min2 - min1, 99u);
+  return pl0;
+}
+
+// site quality + FORMAT PL / GQ (variant_call.cpp:141-163, :289-345): SOLOR over the case samples with evidence in
+// case/control mode, otherwise the largest PL[0/0] over the samples with evidence
 __global__ void k_qual(GArgs A) {
   i64 const idx = static_cast<i64>(blockIdx.x) * blockDim.x + threadIdx.x;
   ma_params_t const& P = A.prm;
-  int const MV = P.max_vars, NA = P.max_alts + 1, S = P.num_samples;
+  int const MV = P.max_vars, NA = P.max_alts + 1, S = P.num_samples, G = NA * (NA + 1) / 2;
   if (idx >= static_cast<i64>(A.b.n_windows) * MV) return;
   int const w = static_cast<int>(idx / MV), v = static_cast<int>(idx % MV);
   A.o.var_qual[idx] = 0.0;
-  if (static_cast<u32>(v) >= A.v.win_nvars[w] || !P.case_ctrl_mode) return;
-  // sample roles from the window's reads
-  u32 case_mask = 0;
-  for (u32 r = A.b.read_win_off[w]; r < A.b.read_win_off[w + 1]; ++r)
-    if ((A.b.read_flags[r] & MA_RF_CASE) && A.b.read_sample[r] < static_cast<u32>(S)) case_mask |= 1u << A.b.read_sample[r];
+  if (A.o.var_pl)
+    for (int x = 0; x < S * G; ++x) A.o.var_pl[static_cast<size_t>(idx) * S * G + x] = 0;
+  if (A.o.var_gq)
+    for (int x = 0; x < S; ++x) A.o.var_gq[static_cast<size_t>(idx) * S + x] = 0;
+  if (static_cast<u32>(v) >= A.v.win_nvars[w]) return;
   const u32* cnt = A.o.allele_counts + static_cast<size_t>(idx) * S * NA * 2;
   auto cov = [&](int s, bool alt) {
     u64 t = 0;
     for (int al = alt ? 1 : 0; al < (alt ? NA : 1); ++al) t += cnt[(s * NA + al) * 2] + cnt[(s * NA + al) * 2 + 1];
     return t;
   };
+  if (!P.case_ctrl_mode || A.o.var_pl || A.o.var_gq) {
+    int const K = static_cast<int>(A.v.var_nalts[idx]) + 1;
+    f64 qual = 0.0;
+    for (int s = 0; s < S; ++s) {
+      if (cov(s, false) + cov(s, true) == 0) continue;  // evidence.Find(sample) == nullptr: missing support
+      u32 gq = 0;
+      u32 const pl0 = genotype_pls(cnt + static_cast<size_t>(s) * NA * 2, K,
+                                   A.o.var_pl ? A.o.var_pl + (static_cast<size_t>(idx) * S + s) * G : nullptr, &gq);
+      if (A.o.var_gq) A.o.var_gq[static_cast<size_t>(idx) * S + s] = gq;
+      qual = fmax(qual, static_cast<f64>(pl0));
+    }
+    if (!P.case_ctrl_mode) {
+      A.o.var_qual[idx] = qual;
+      return;
+    }
+  }
+  if (!P.case_ctrl_mode) return;
+  // sample roles from the window's reads
+  u32 case_mask = 0;
+  for (u32 r = A.b.read_win_off[w]; r < A.b.read_win_off[w + 1]; ++r)
+    if ((A.b.read_flags[r] & MA_RF_CASE) && A.b.read_sample[r] < static_cast<u32>(S)) case_mask |= 1u << A.b.read_sample[r];
   f64 sum_alt = 0.0, sum_ref = 0.0, n_ctrl = 0.0;
   for (int s = 0; s < S; ++s) {
     if ((case_mask >> s) & 1u) continue;

@@ -69,7 +69,9 @@ std::vector<OutField> geno_fields(const ma_params_t& p, int n, i64 nr) {
           {off_of(&ma_geno_out_t::aln_rec), 4 * R * MH * 6},
           {off_of(&ma_geno_out_t::aln_cigar), 4 * R * MH * (1 + MCG)},
           {off_of(&ma_geno_out_t::asg_allele), R * MV},
-          {off_of(&ma_geno_out_t::asg_score), 8 * R * MV}};
+          {off_of(&ma_geno_out_t::asg_score), 8 * R * MV},
+          {off_of(&ma_geno_out_t::var_pl), 4 * N * MV * S * ((MA + 1) * (MA + 2) / 2)},
+          {off_of(&ma_geno_out_t::var_gq), 4 * N * MV * S}};
 }
 
 std::vector<OutField> cx_fields(const ma_params_t& p, int n) {
@@ -222,6 +224,7 @@ int run_lane(ma_ctx* ch, hipEvent_t start, const DBatch& full, int w0, int w1, u
   std::vector<OutField> const gf = geno_fields(p, 1, 1);
   advance_fields(&q, gf, 0, 2, w0);   // allele_counts, var_qual: per window
   advance_fields(&q, gf, 2, 6, r0);   // alignment / assignment taps: per read
+  advance_fields(&q, gf, 6, 8, w0);   // PL, GQ: per window
   MA_TRY_RC(launch_gate(ch, d, g.max_approx, g.max_exact));
   MA_TRY_RC(launch_assemble(ch, d, a, g.max_approx));
   MA_TRY_RC(launch_msa(ch, d, a, v));

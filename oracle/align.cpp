@@ -33,6 +33,8 @@
 // The scoring epilogue below IS first-party reference code and is restated literally.
 #include "oracle.hpp"
 
+#include <limits>
+
 namespace orc {
 
 // K of rule 3
@@ -190,6 +192,62 @@ AlnResult AlignReadToHap(std::string_view read, std::string_view hap, const Alig
   }
   if (res.qe < m) res.cigar.push_back({'S', static_cast<u32>(m - res.qe)});
   return res;
+}
+
+// caller/genotype_likelihood.cpp:20-79 (constants), :93-111 (LogDirichletMultinomial), :113-128 (NormalizeToPLs),
+// :205-248 (ComputeGenotypePLs).  FORMAT PL; the germline site QUAL is PL[0/0] (variant_call.cpp:289-303).
+std::vector<u32> ComputeGenotypePLs(const std::vector<int>& allele_counts) {
+  constexpr f64 kBackgroundError = 0.005, kOverdispersion = 0.01, kAlphaFloor = 1e-6;
+  int const K = static_cast<int>(allele_counts.size());
+  if (K == 0) return {};
+  f64 const precision = (1.0 - kOverdispersion) / kOverdispersion;
+  std::vector<f64> lls;
+  for (int b = 0; b < K; ++b) {
+    for (int a = 0; a <= b; ++a) {
+      std::vector<f64> mu(static_cast<usize>(K), kBackgroundError / K);
+      f64 const main_mass = 1.0 - kBackgroundError;
+      if (a == b) {
+        mu[static_cast<usize>(a)] += main_mass;
+      } else {
+        mu[static_cast<usize>(a)] += main_mass / 2.0;
+        mu[static_cast<usize>(b)] += main_mass / 2.0;
+      }
+      f64 log_prob = 0.0, alpha_sum = 0.0, count_alpha_sum = 0.0;
+      for (int k = 0; k < K; ++k) {
+        f64 const alpha = std::max(kAlphaFloor, mu[static_cast<usize>(k)] * precision);
+        f64 const cnt = static_cast<f64>(allele_counts[static_cast<usize>(k)]);
+        log_prob += std::lgamma(cnt + alpha) - std::lgamma(alpha);
+        alpha_sum += alpha;
+        count_alpha_sum += cnt + alpha;
+      }
+      log_prob += std::lgamma(alpha_sum) - std::lgamma(count_alpha_sum);
+      lls.push_back(log_prob);
+    }
+  }
+  f64 const best = *std::max_element(lls.begin(), lls.end());
+  f64 const cap = static_cast<f64>(std::numeric_limits<u32>::max()) / 2.0;
+  f64 const ln_ten = 2.302585092994045684017991454684364208;  // std::numbers::ln10
+  std::vector<u32> pls(lls.size());
+  for (usize i = 0; i < lls.size(); ++i) {
+    f64 const raw = -10.0 * (lls[i] - best) / ln_ten;
+    pls[i] = static_cast<u32>(std::round(std::min(raw, cap)));
+  }
+  return pls;
+}
+
+// caller/genotype_likelihood.cpp:250-272: second-smallest PL, capped at 99
+u32 ComputeGenotypeQuality(const std::vector<u32>& pls) {
+  if (pls.size() < 2) return 0;
+  u32 min1 = std::numeric_limits<u32>::max(), min2 = min1;
+  for (u32 v : pls) {
+    if (v < min1) {
+      min2 = min1;
+      min1 = v;
+    } else if (v < min2) {
+      min2 = v;
+    }
+  }
+  return std::min<u32>(min2 - min1, 99u);
 }
 
 // hts/cigar_utils.h:48-111

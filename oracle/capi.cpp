@@ -74,6 +74,15 @@ void orc_default_params(ma_params_t* p) {
   p->case_ctrl_mode = 1;
 }
 
+// FORMAT PL / GQ of one sample from its allele depths (caller/genotype_likelihood.cpp:205-272); returns the PL count
+int orc_genotype_pls(const int32_t* counts, int k, uint32_t* pls, uint32_t* gq) {
+  std::vector<int> c(counts, counts + k);
+  auto const out = ComputeGenotypePLs(c);
+  for (usize i = 0; i < out.size(); ++i) pls[i] = out[i];
+  *gq = ComputeGenotypeQuality(out);
+  return static_cast<int>(out.size());
+}
+
 // control-flow event counters of the assembler since the last call (see graph.cpp); reset on read
 void orc_debug_counters(unsigned long long* out) {
   for (int i = 0; i < 4; ++i) {
@@ -372,6 +381,10 @@ int orc_genotype_batch(const ma_params_t* prm, const ma_batch_t* b, const ma_asm
       usize const vi = static_cast<usize>(w) * MV + v;
       o->var_qual[vi] = 0.0;
       for (int x = 0; x < S * NA * 2; ++x) o->allele_counts[vi * S * NA * 2 + x] = 0;
+      if (o->var_pl)
+        for (int x = 0; x < S * (NA * (NA + 1) / 2); ++x) o->var_pl[vi * S * (NA * (NA + 1) / 2) + x] = 0;
+      if (o->var_gq)
+        for (int x = 0; x < S; ++x) o->var_gq[vi * S + x] = 0;
     }
     auto const reads = WindowReads(b, w);
     u32 const r0 = b->read_win_off[w];
@@ -449,6 +462,33 @@ int orc_genotype_batch(const ma_params_t* prm, const ma_batch_t* b, const ma_asm
           if (!ss.insert(rd.qname_id).second) continue;
           o->allele_counts[((vi * S + rd.sample) * NA + asg[x].allele) * 2 + (rd.rev ? 1 : 0)] += 1;
         }
+      }
+      // FORMAT PL / GQ of every sample with evidence (variant_call.cpp:141-163, variant_support.cpp:408-426) and, outside
+      // case/control mode, QUAL = max over those samples of PL[0/0] (variant_call.cpp:289-303)
+      int const G = NA * (NA + 1) / 2;
+      for (u32 v : vslot) {
+        usize const vi = static_cast<usize>(w) * MV + v;
+        int const K = static_cast<int>(vo->var_nalts[vi]) + 1;
+        f64 qual = 0.0;
+        for (int s = 0; s < S; ++s) {
+          std::vector<int> counts(static_cast<usize>(K), 0);
+          u64 tot = 0;
+          for (int al = 0; al < NA; ++al) {
+            u32 const c2 = o->allele_counts[((vi * S + s) * NA + al) * 2] + o->allele_counts[((vi * S + s) * NA + al) * 2 + 1];
+            if (al < K) counts[static_cast<usize>(al)] = static_cast<int>(c2);
+            tot += c2;
+          }
+          if (o->var_pl)
+            for (int x = 0; x < G; ++x) o->var_pl[(vi * S + s) * G + x] = 0;
+          if (o->var_gq) o->var_gq[vi * S + s] = 0;
+          if (tot == 0) continue;  // evidence.Find(sample) == nullptr: missing support
+          auto const pls = ComputeGenotypePLs(counts);
+          if (o->var_pl)
+            for (usize x = 0; x < pls.size(); ++x) o->var_pl[(vi * S + s) * G + x] = pls[x];
+          if (o->var_gq) o->var_gq[vi * S + s] = ComputeGenotypeQuality(pls);
+          qual = std::max(qual, static_cast<f64>(pls.empty() ? 0u : pls[0]));
+        }
+        if (!prm->case_ctrl_mode) o->var_qual[vi] = qual;
       }
       // QUAL = max over samples with evidence of SOLOR (variant_call.cpp:289-345)
       if (prm->case_ctrl_mode)

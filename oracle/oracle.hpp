@@ -158,6 +158,10 @@ std::vector<Assignment> AssignReadToAlleles(const Read& rd, const std::vector<st
                                             const AlignParams& ap,
                                             std::vector<AlnResult>* alns_out = nullptr);
 
+// caller/genotype_likelihood.cpp:93-307: Dirichlet-multinomial genotype PLs (VCF genotype order) and GQ
+std::vector<u32> ComputeGenotypePLs(const std::vector<int>& allele_counts);
+u32 ComputeGenotypeQuality(const std::vector<u32>& pls);
+
 // hts/cigar_utils.h:48-139
 u32 ComputeEditDistance(const std::vector<CigarUnit>& cigar, const std::vector<u8>& q,
                         const u8* t, usize tlen);

@@ -200,6 +200,10 @@ def compare_geno(p, got, want, n, nr, win_nvars, read_win_off):
     if not np.array_equal(got["allele_counts"], want["allele_counts"]):
         i = np.nonzero(got["allele_counts"] != want["allele_counts"])[0][:8]
         bad.append(f"allele_counts differ at {i.tolist()}: got {got['allele_counts'][i].tolist()} want {want['allele_counts'][i].tolist()}")
+    for key in ("var_pl", "var_gq"):
+        if key in want and key in got and not np.array_equal(got[key], want[key]):
+            i = np.nonzero(got[key] != want[key])[0][:8]
+            bad.append(f"{key} differs at {i.tolist()}: got {got[key][i].tolist()} want {want[key][i].tolist()}")
     dq = np.abs(got["var_qual"] - want["var_qual"]).max() if len(want["var_qual"]) else 0.0
     if dq > 1e-9:
         bad.append(f"var_qual max abs diff {dq}")

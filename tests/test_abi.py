@@ -31,7 +31,7 @@ def test_struct_layout_matches_header():
     assert C.sizeof(capi.Params) == 20 * 4
     assert C.sizeof(capi.AsmOut) == 13 * C.sizeof(C.c_void_p)
     assert C.sizeof(capi.VarOut) == 14 * C.sizeof(C.c_void_p)
-    assert C.sizeof(capi.GenoOut) == 6 * C.sizeof(C.c_void_p)
+    assert C.sizeof(capi.GenoOut) == 8 * C.sizeof(C.c_void_p)
     assert C.sizeof(capi.CxOut) == 4 * C.sizeof(C.c_void_p)
     lib = capi.load_cdll()
     p = capi.Params()

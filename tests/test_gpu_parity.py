@@ -170,6 +170,30 @@ def test_genotype_parity(cfg, nwin, kw):
     assert want["allele_counts"].sum() > 0 and (want["aln_rec"].reshape(-1, 6)[:, 0] > 0).sum() > 100
 
 
+@pytest.mark.parametrize("cfg,nwin,kw", [("C2", 4, {}), ("C5", 2, dict(num_samples=3)), ("C2", 2, dict(snv_rate=1e-2, indel_rate=2e-3))])
+def test_germline_quality_and_genotype_likelihoods(cfg, nwin, kw):
+    """Outside case/control mode QUAL is the largest PL[0/0] of the samples with evidence (variant_call.cpp:289-303);
+    PL / GQ are the Dirichlet-multinomial likelihoods over the allele depths (genotype_likelihood.cpp:93-272).
+    Integers on both sides: compared exactly (north_star tolerance for QUAL: 1e-5)."""
+    from lancet2_amd.engine import Engine
+    ns = kw.pop("num_samples", 2)
+    params = capi.default_params(min_k=25, max_k=25, num_samples=ns, case_ctrl_mode=0)
+    arrs, n, nr = synth.make_config_batch(cfg, nwin, first_index=7300, **kw)
+    orc = OracleEngine(params)
+    asm = orc.assemble(arrs, n, nr)
+    var = orc.msa(arrs, n, nr, asm)
+    want = orc.genotype(arrs, n, nr, asm, var)
+    eng = Engine(params)
+    try:
+        got = eng.genotype(arrs, n, nr, asm, var)
+    finally:
+        eng.close()
+    bad = compare_geno(params, got, want, n, nr, var["win_nvars"], arrs["read_win_off"])
+    assert not bad, "\n".join(bad[:20])
+    assert np.abs(got["var_qual"] - want["var_qual"]).max() <= 1e-5
+    assert want["var_qual"].max() > 20 and want["var_pl"].max() > 20 and want["var_gq"].max() > 0
+
+
 @pytest.mark.parametrize("streams", [2, 3])
 def test_process_batch_in_concurrent_lanes(streams):
     """ma_process_batch split into window ranges on separate streams gives the single-stream (= oracle) result."""

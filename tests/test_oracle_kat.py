@@ -442,3 +442,56 @@ def test_graph_complexity_chain_and_single_bubble():
             assert max_dir <= want_deg if n_somatic == 0 else max_dir == want_deg
             assert (branch_points == 0) if n_somatic == 0 else (branch_points >= 1)
         assert a["comp_nhaps"].reshape(n, p.max_comps)[:, 0].tolist() == [1 + n_somatic] * 3
+
+
+def test_genotype_pls_against_scipy():
+    """caller/genotype_likelihood.cpp:93-272 -- the oracle's Dirichlet-multinomial PLs equal an independent scipy
+    evaluation of ln P(c | alpha) = lnG(sum a) - lnG(N + sum a) + sum [lnG(c_i + a_i) - lnG(a_i)] with
+    alpha = M mu, M = (1 - 0.01) / 0.01, mu = eps / K background + (1 - eps) on the genotype's alleles, eps = 0.005;
+    plus the properties the VCF relies on (best genotype has PL 0, GQ = second-smallest PL capped at 99)."""
+    import ctypes as C
+    from scipy.special import gammaln
+    lib = oracle()
+    rng = np.random.default_rng(5)
+
+    def ref_pls(counts):
+        K = len(counts)
+        M, eps = (1.0 - 0.01) / 0.01, 0.005
+        lls = []
+        for b in range(K):
+            for a in range(b + 1):
+                mu = np.full(K, eps / K)
+                if a == b:
+                    mu[a] += 1.0 - eps
+                else:
+                    mu[a] += (1.0 - eps) / 2.0
+                    mu[b] += (1.0 - eps) / 2.0
+                al = np.maximum(1e-6, mu * M)
+                c = np.asarray(counts, dtype=np.float64)
+                lls.append(float(gammaln(al.sum()) - gammaln(c.sum() + al.sum()) + (gammaln(c + al) - gammaln(al)).sum()))
+        lls = np.array(lls)
+        return np.round(np.minimum(-10.0 * (lls - lls.max()) / np.log(10.0), 2 ** 31)).astype(np.int64), lls
+
+    cases = [[30, 0], [0, 30], [15, 15], [28, 2], [0, 0], [500, 480], [2000, 3], [10, 10, 10], [40, 0, 7, 1], [3, 0, 0, 0, 9]]
+    cases += [list(rng.integers(0, int(rng.choice([5, 40, 400])), int(rng.integers(2, 6)))) for _ in range(200)]
+    for counts in cases:
+        K = len(counts)
+        pls = (C.c_uint32 * 32)()
+        gq = C.c_uint32()
+        n = lib.orc_genotype_pls((C.c_int32 * K)(*[int(x) for x in counts]), K, pls, C.byref(gq))
+        assert n == K * (K + 1) // 2
+        got = np.array(pls[:n], dtype=np.int64)
+        want, lls = ref_pls(counts)
+        # integers: equal unless a likelihood sits on a rounding boundary to within the two libms' difference
+        raw = -10.0 * (lls - lls.max()) / np.log(10.0)
+        near = np.abs(raw - np.floor(raw) - 0.5) < 1e-6
+        assert np.array_equal(got[~near], want[~near]), (counts, got, want)
+        assert got.min() == 0
+        srt = np.sort(got)
+        assert gq.value == min(int(srt[1] - srt[0]), 99)
+    # hom-ref evidence calls 0/0, balanced evidence calls 0/1, hom-alt evidence calls 1/1
+    for counts, best in (([30, 0], 0), ([15, 15], 1), ([0, 30], 2)):
+        pls = (C.c_uint32 * 8)()
+        gq = C.c_uint32()
+        lib.orc_genotype_pls((C.c_int32 * 2)(*counts), 2, pls, C.byref(gq))
+        assert int(np.argmin(pls[:3])) == best
