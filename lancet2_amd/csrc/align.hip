@@ -61,7 +61,8 @@ __host__ __device__ constexpr int reg_width(int c) {  // cells per row of k_alig
 // (k_align_gen) only for regions no LDS row holds
 constexpr int kClsWaveS = kNumReg, kClsWaveB = kNumReg + 1, kClsGlobal = kNumReg + 2, kNumCls = kNumReg + 3;
 constexpr int kNumKeys = 2 * kNumCls;  // key = class * 2 + (region can reach a haplotype end)
-constexpr u32 kWaveSmallW = 512;       // widest region of the small wavefront class
+constexpr u32 kWaveSmallW = 0;         // (one wavefront class: a launch costs a fixed ~0.2 ms of latency, its LDS is sized for the
+                                       //  widest region that actually occurs)
 
 struct AlnWs {
   u32 wave_big_w;      // widest region the big wavefront class holds for this batch's longest read (host computed)
@@ -74,8 +75,10 @@ struct AlnWs {
   // per pair
   i32* centre;         // [pairs in chunk] first diagonal of the pair's region (vmin - K), or a sentinel
   u32* band_w;         // [pairs in chunk] width of the region in diagonals | key << 16
+  u64* vote_aux;       // [pairs in chunk] wide pairs only: most-voted diagonal - region start | votes further than 8 / 16 / 24
+                       //                  diagonals from it (saturating u16 each): k_align_wave's narrow first pass
   u32* dp_list;        // [pairs in chunk] pairs that need the DP (compacted by k_vote)
-  u32* dp_count;       // device counters: [0] DP pairs, [4 ..] pairs per key, [40] widest region of the HBM class
+  u32* dp_count;       // device counters: [0] DP pairs, [4 ..] pairs per key, [40] / [41] widest region of the HBM / wavefront class
   u32* tb;             // traceback nibbles
   u32 tb_words;        // words per row (of the launch)
   u32 tb_rows;         // rows per pair (max read len + 1)
@@ -215,6 +218,8 @@ struct HapIdx {
   u32 rwords;
   u32* dpbuf;       // this wave's pending DP pairs: [64] + count at [64] + their keys at [65 .. 129)
   u32 hap_amb;      // the haplotype holds a base that is not A/C/G/T
+  const u16* dup_pre;  // [n + 1] number of repeated (kCodeDup) 11-mers starting before position j
+  const i32* cand;     // hint shortcut: [0] number of candidate shifts (0: off), [1] anchor, [2 ..] shifts
 #ifdef MA_PROFILE
   unsigned long long* prof;  // this wave's phase cycle counters
 #endif
@@ -277,7 +282,8 @@ __global__ __launch_bounds__(256) void k_vote(GArgs A, u32 hist_len, u32 rwords,
   u32* hbad = hhi + pw;
   u32* rplanes_all = hbad + pw;                            // [4 waves][3][rwords]
   u32* dpbuf_all = rplanes_all + 12 * rwords;              // [4 waves][129]
-  u32* l_roff = dpbuf_all + 4 * 129;                        // [nr + 1] read byte offsets relative to the window's first read
+  u16* dup_pre = reinterpret_cast<u16*>(dpbuf_all + 4 * 129);  // [ML + 2]
+  u32* l_roff = reinterpret_cast<u32*>(dup_pre + ((ML + 4) & ~1u));  // [nr + 1] read byte offsets relative to the window's first read
   size_t const hi = static_cast<size_t>(w) * A.prm.max_haps + slot;
   u32 const n = A.a.hap_len[hi];
   const u8* hb = A.a.hap_bases + hi * A.prm.max_hap_len;
@@ -335,6 +341,60 @@ __global__ __launch_bounds__(256) void k_vote(GArgs A, u32 hist_len, u32 rwords,
   }
   __syncthreads();
   int const wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  // dup_pre[j] = repeated 11-mers starting before j (for the hint shortcut's vote bound)
+  __shared__ u32 sh_dup[4];
+  __shared__ i32 sh_cand[12];
+  {
+    u32 running = 0;
+    for (u32 j0 = 0; j0 <= n; j0 += 256) {
+      u32 const j = j0 + threadIdx.x;
+      bool const f = j + SK <= n && code[j] != 0xFFFFFFFFu && (code[j] & kCodeDup);
+      unsigned long long const bal = __ballot(f);
+      if (lane == 0) sh_dup[wave] = static_cast<u32>(__popcll(bal));
+      __syncthreads();
+      u32 before = running;
+      for (int x = 0; x < wave; ++x) before += sh_dup[x];
+      if (j <= n) dup_pre[j] = static_cast<u16>(min(before + static_cast<u32>(__popcll(bal & ((1ull << lane) - 1ull))), 65535u));
+      running += sh_dup[0] + sh_dup[1] + sh_dup[2] + sh_dup[3];
+      __syncthreads();
+    }
+  }
+  // Hint shortcut candidates: a read mapped at window offset `hint` lies on diagonal hint - anchor of the REF haplotype
+  // and, on an ALT haplotype, on that diagonal shifted by the net length change of the variants before it.
+  if (threadIdx.x == 0) {
+    int nc = 0;
+    sh_cand[0] = 0;
+    if (A.b.read_hint && !(A.prm.aln_tier & 2)) {
+      ma_params_t const& P = A.prm;
+      for (u32 c = 0; c < A.a.win_ncomp[w]; ++c) {
+        size_t const ci = static_cast<size_t>(w) * P.max_comps + c;
+        u32 const h0 = A.a.comp_hap0[ci], nh = A.a.comp_nhaps[ci];
+        if (static_cast<u32>(slot) < h0 || static_cast<u32>(slot) >= h0 + nh) continue;
+        u32 const h = static_cast<u32>(slot) - h0;
+        sh_cand[1] = static_cast<i32>(A.a.comp_anchor[ci]);
+        sh_cand[2 + nc++] = 0;
+        for (u32 v = 0; v < A.v.win_nvars[w] && h > 0; ++v) {
+          size_t const vi = static_cast<size_t>(w) * P.max_vars + v;
+          if (A.v.var_comp[vi] != c) continue;
+          u32 const al = A.v.var_hap_allele[vi * P.max_haps + h];
+          if (al == 0) continue;
+          i32 const sh = static_cast<i32>(A.v.var_hap_start[vi * P.max_haps + h] + A.v.alt_len[vi * P.max_alts + (al - 1)]) -
+                         static_cast<i32>(A.v.var_ref_start[vi] + A.v.var_ref_len[vi]);
+          bool seen = false;
+          for (int x = 0; x < nc; ++x) seen = seen || sh_cand[2 + x] == sh;
+          if (seen) continue;
+          if (nc >= 8) {  // too many distinct shifts: not worth trying
+            nc = 0;
+            break;
+          }
+          sh_cand[2 + nc++] = sh;
+        }
+        break;
+      }
+    }
+    sh_cand[0] = nc;
+  }
+  __syncthreads();
 #ifdef MA_PROFILE
   __shared__ unsigned long long sh_prof[4][8];
   if (lane < 8) sh_prof[wave][lane] = 0;
@@ -343,13 +403,13 @@ __global__ __launch_bounds__(256) void k_vote(GArgs A, u32 hist_len, u32 rwords,
   for (u32 x = lane; x < pw; x += 64) hap_amb |= hbad[x];
   hap_amb = __ballot(hap_amb != 0) ? 1u : 0u;
   HapIdx const ix{head, next, code, hlo, hhi, hbad, rplanes_all + static_cast<size_t>(wave) * 3 * rwords, rwords,
-                  dpbuf_all + wave * 129, hap_amb, sh_prof[wave]};
+                  dpbuf_all + wave * 129, hap_amb, dup_pre, sh_cand, sh_prof[wave]};
 #else
   u32 hap_amb = 0;
   for (u32 x = lane; x < pw; x += 64) hap_amb |= hbad[x];
   hap_amb = __ballot(hap_amb != 0) ? 1u : 0u;
   HapIdx const ix{head, next, code, hlo, hhi, hbad, rplanes_all + static_cast<size_t>(wave) * 3 * rwords, rwords,
-                  dpbuf_all + wave * 129, hap_amb};
+                  dpbuf_all + wave * 129, hap_amb, dup_pre, sh_cand};
 #endif
   u16* hist = hist_all + static_cast<size_t>(wave) * hist_len;
   // software pipeline: the next read's bases are in flight while the current read is voted
@@ -426,6 +486,57 @@ __device__ __forceinline__ void vote_pair(GArgs const& A, u64 lp, PairId id, Hap
     }
   }
   __builtin_amdgcn_wave_barrier();
+  // ---- hint shortcut: certificate (I) without the seed index --------------------------------------------------------
+  // Try the diagonals the read's mapped position suggests.  On such a diagonal c (read inside the haplotype, X <= 2
+  // mismatches, nothing ambiguous) every vote for ANOTHER diagonal comes from a read position whose 11-mer either
+  // overlaps a mismatch (<= 11 X positions) or equals a haplotype 11-mer that occurs more than once (D of the m - 10
+  // 11-mers under the read, from the prefix counts of the repeat flags): no diagonal but c holds more than D + 11 X
+  // votes, which is all certificate (I) asks of the vote histogram -- D + 11 X + 10 + 11 X < m makes P0 the unique
+  // optimum.  c itself holds >= m - 10 - 11 X >= 4 votes, so it is an anchor and P0 lies in the search region.  A wrong
+  // or missing hint only means that no candidate passes and the pair takes the general route: results never depend on it.
+  if (ix.cand[0] > 0 && !ix.hap_amb && m >= SK && m <= 2048) {
+    i32 const hint = A.b.read_hint[id.r];
+    if (hint != MA_NO_HINT) {
+      for (int x = 0; x < ix.cand[0]; ++x) {
+        i32 const c = hint - ix.cand[1] + ix.cand[2 + x];
+        if (c < 0 || c + m > n) continue;
+        u32 mism = 0, bad = 0;
+        {
+          i32 const i = 32 * lane;
+          if (i < m) {
+            i32 const hi = min(m - i, 32);
+            u32 const valid = hi >= 32 ? 0xFFFFFFFFu : ((1u << hi) - 1u);
+            u32 const hl = plane32(ix.hlo, c + i), hh = plane32(ix.hhi, c + i);
+            bad = rbad[i >> 5];
+            mism = __popc(((rlo[i >> 5] ^ hl) | (rhi[i >> 5] ^ hh)) & valid);
+          }
+        }
+        if (__ballot(bad != 0)) break;  // an N in the read: general route
+        for (int off = 32; off > 0; off >>= 1) mism += __shfl_xor(mism, off);
+        i32 const X = static_cast<i32>(mism);
+        if (X > 2) continue;
+        i32 const D = static_cast<i32>(ix.dup_pre[c + m - SK + 1]) - static_cast<i32>(ix.dup_pre[c]);
+        i32 const S0 = m - 5 * X;
+        if (D + 22 * X + 10 < m && S0 >= A.prm.min_aln_score && D < 60000) {
+          if (lane == 0) {
+            size_t const rec = static_cast<size_t>(id.r) * A.prm.max_haps + id.slot;
+            i32* arec = A.o.aln_rec + rec * 6;
+            u32* acig = A.o.aln_cigar + rec * (1 + A.prm.max_cigar);
+            arec[0] = 1;
+            arec[1] = S0;
+            arec[2] = c;
+            arec[3] = c + m;
+            arec[4] = 0;
+            arec[5] = m;
+            acig[0] = 1;
+            acig[1] = static_cast<u32>(m) << 4;
+            A.ws.centre[lp] = 0x7FFFFFFE;
+          }
+          return;
+        }
+      }
+    }
+  }
   // this lane's read positions i = lane, lane + 64, ... and their 11-mer codes (0xFFFFFFFF: none)
   constexpr int kPos = 4;  // the first 256 read positions keep their codes in registers
   u32 cds[kPos];
@@ -471,6 +582,7 @@ __device__ __forceinline__ void vote_pair(GArgs const& A, u64 lp, PairId id, Hap
   u32 best = 0, v2 = 0;
   i32 bd = 0x7FFFFFFF;
   i32 dlo = 0x7FFFFFFF, dhi = -1;  // extreme diagonals that received a vote (histogram index: diagonal + m)
+  u32 vfar8 = 0, vfar16 = 0, vfar24 = 0;  // votes further than 8 / 16 / 24 diagonals from the most-voted one
   bool unan = !(seeded && m - SK + 1 > 64 * kPos);  // long reads vote outside the cached positions
   u32 ucnt = 0;
   i32 u_d = -1;
@@ -575,8 +687,17 @@ __device__ __forceinline__ void vote_pair(GArgs const& A, u64 lp, PairId id, Hap
     // second best (any other diagonal), then restore the all-zero histogram
     walk([&](i32 d) {
       if (d != bd) v2 = max(v2, static_cast<u32>(hist[d]));
+      u32 const far = static_cast<u32>(d > bd ? d - bd : bd - d);  // every visit is one vote
+      vfar8 += far > 8u;
+      vfar16 += far > 16u;
+      vfar24 += far > 24u;
     });
-    for (int off = 32; off > 0; off >>= 1) v2 = max(v2, __shfl_xor(v2, off));
+    for (int off = 32; off > 0; off >>= 1) {
+      v2 = max(v2, __shfl_xor(v2, off));
+      vfar8 += __shfl_xor(vfar8, off);
+      vfar16 += __shfl_xor(vfar16, off);
+      vfar24 += __shfl_xor(vfar24, off);
+    }
     __builtin_amdgcn_wave_barrier();
     VPROF_ACC(3);
     walk([&](i32 d) { hist[d] = 0; });
@@ -703,6 +824,10 @@ __device__ __forceinline__ void vote_pair(GArgs const& A, u64 lp, PairId id, Hap
       u32 const wall = (r_lo >= 0 && r_lo + kw + m + 8 <= n) ? 0u : 1u;
       u32 const key = static_cast<u32>(cls) * 2u + wall;
       if (cls == kClsGlobal) atomicMax(&A.ws.dp_count[40], r_w);
+      if (cls == kClsWaveB) atomicMax(&A.ws.dp_count[41], r_w);
+      if (cls >= kNumReg)
+        A.ws.vote_aux[lp] = static_cast<u64>(static_cast<u32>(c - r_lo) & 0xFFFFu) | (static_cast<u64>(min(vfar8, 65535u)) << 16) |
+                            (static_cast<u64>(min(vfar16, 65535u)) << 32) | (static_cast<u64>(min(vfar24, 65535u)) << 48);
       A.ws.centre[lp] = r_lo;
       A.ws.band_w[lp] = r_w | (key << 16);
       u32 const at = ix.dpbuf[64]++;
@@ -854,15 +979,21 @@ __device__ __forceinline__ void dp_pair_store(GArgs const& A, DpPair const& p, c
 // The previous row (H, F per cell) and the encoded sequences live in LDS; the move bits go to HBM as four 64-bit
 // ballots per chunk.  Same cell rules, tie rules and outputs as the lane-per-pair kernels.
 constexpr i32 NEGW = -(1 << 28);
-__device__ __forceinline__ i32 wave_excl_prefix_max(i32 v, int lane) {  // max over the lanes below this one (NEGW for lane 0)
-  i32 x = __shfl_up(v, 1, 64);
-  x = lane >= 1 ? x : NEGW;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    i32 const y = __shfl_up(x, o, 64);
-    x = lane >= o ? max(x, y) : x;
-  }
-  return x;
+// wave-wide scans with DPP (no LDS crossbar traffic: the chunk loop is one dependent chain, latency is what it costs)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ i32 dpp_mov(i32 x, i32 fill) {
+  return __builtin_amdgcn_update_dpp(fill, x, CTRL, ROW_MASK, 0xF, false);
+}
+constexpr i32 kScanIdent = static_cast<i32>(0x80000000u);  // identity of max
+__device__ __forceinline__ i32 wave_shr1(i32 x, i32 fill) { return dpp_mov<0x138, 0xF>(x, fill); }  // lane l <- lane l - 1
+__device__ __forceinline__ i32 wave_excl_prefix_max(i32 x) {  // max over the lanes below this one (kScanIdent for lane 0)
+  x = max(x, dpp_mov<0x111, 0xF>(x, kScanIdent));  // row_shr:1
+  x = max(x, dpp_mov<0x112, 0xF>(x, kScanIdent));  // row_shr:2
+  x = max(x, dpp_mov<0x114, 0xF>(x, kScanIdent));  // row_shr:4
+  x = max(x, dpp_mov<0x118, 0xF>(x, kScanIdent));  // row_shr:8
+  x = max(x, dpp_mov<0x142, 0xA>(x, kScanIdent));  // row_bcast:15 -> rows 1, 3
+  x = max(x, dpp_mov<0x143, 0xC>(x, kScanIdent));  // row_bcast:31 -> rows 2, 3
+  return wave_shr1(x, kScanIdent);
 }
 __global__ __launch_bounds__(64) void k_align_wave(GArgs A, u32 nchunk_alloc) {
   extern __shared__ u32 lds[];
@@ -898,72 +1029,113 @@ __global__ __launch_bounds__(64) void k_align_wave(GArgs A, u32 nchunk_alloc) {
     hcode[x] = static_cast<u8>((hbidx >= 0 && hbidx < n) ? enc_base(hb[hbidx]) : 5u);
   }
   for (i32 x = lane; x < m; x += 64) qcode[x] = static_cast<u8>(enc_base(rb[x]));
-  // row 0: H = 0 for 0 <= j <= n inside the region; F = minus infinity
-  for (i32 t = lane; t <= wr; t += 64) {
-    i32 const j = lo + t;
-    Hrow[t] = (t < wr && j >= 0 && j <= n) ? 0 : NEGW;
-    Frow[t] = NEGW;
-  }
   __builtin_amdgcn_wave_barrier();
-  i32 const nchunk = (wr + 63) >> 6;
   unsigned long long* tile = A.ws.tbw + static_cast<size_t>(pi) * A.ws.tb_rows * nchunk_alloc * 4;
-  i32 best = NEGW, bi = -1, bj = -1;  // per lane; reduced at the end
-  for (i32 i = 1; i <= m; ++i) {
-    u32 const qi = qcode[i - 1];
-    i32 carry = NEGW;                  // max of B(t') + 3 t' over the cells of the chunks before this one
-    i32 left_h = NEGW, left_e = NEGW;  // H, E of the last cell of the chunk before this one
-    for (i32 c = 0; c < nchunk; ++c) {
-      i32 const t = (c << 6) + lane, j = i + lo + t;
-      bool const inreg = t < wr;
-      i32 const tt = inreg ? t : wr;  // clamp: cell wr is the minus-infinity sentinel
-      i32 const oh = Hrow[tt], uh = Hrow[tt + (inreg ? 1 : 0)], uf = Frow[tt + (inreg ? 1 : 0)];
-      u32 const hc = inreg ? hcode[i + t] : 5u;  // base index (j - 1) = lo - 1 + (i + t)
-      i32 const s = (qi > 3 || hc > 3) ? -1 : (qi == hc ? 1 : -4);
-      bool const cell = inreg && j >= 1 && j <= n;  // an ordinary cell; (i, 0) is a free start, the rest does not exist
-      i32 const dg = oh + s;
-      i32 const fo = uh - (GO + GE), fe = uf - GE;
-      i32 const f = cell ? max(fo, fe) : NEGW;
-      i32 const bnh = cell ? max(dg, f) : ((inreg && j == 0) ? 0 : NEGW);  // best non-horizontal entry
-      i32 const g = bnh + GE * t;
-      i32 const pm = max(carry, wave_excl_prefix_max(g, lane));
-      i32 const e = cell ? pm - GO - GE * t : NEGW;
-      i32 const h = max(bnh, e);
-      // H, E of the left neighbour for the "gap opened here" bit
-      i32 hl = __shfl_up(h, 1, 64), el = __shfl_up(e, 1, 64);
-      hl = lane ? hl : left_h;
-      el = lane ? el : left_e;
-      i32 const eo = hl - (GO + GE), ee = el - GE;
-      u32 nib = (dg >= e && dg >= f) ? 0u : (e >= f ? 1u : 2u);
-      nib |= (eo >= ee ? 4u : 0u) | (fo >= fe ? 8u : 0u);
-      __builtin_amdgcn_wave_barrier();  // every lane has read the old row before anyone overwrites it
-      if (inreg) {
-        Hrow[t] = h;
-        Frow[t] = f;
+  i32 best = NEGW, bi = -1, bj = -1;
+  // overlap DP over the diagonals [blo, blo + bw): fills the tile, leaves the best end cell in (best, bi, bj)
+  auto run = [&](i32 blo, i32 bw) {
+    // row 0: H = 0 for 0 <= j <= n inside the band; F = minus infinity
+    for (i32 t = lane; t <= bw; t += 64) {
+      i32 const j = blo + t;
+      Hrow[t] = (t < bw && j >= 0 && j <= n) ? 0 : NEGW;
+      Frow[t] = NEGW;
+    }
+    __builtin_amdgcn_wave_barrier();
+    i32 const nchunk = (bw + 63) >> 6;
+    i32 const hshift = blo - lo;  // hcode is laid out for the full region: base index (j - 1) = lo - 1 + (i + t + hshift)
+    best = NEGW;
+    bi = -1;
+    bj = -1;
+    for (i32 i = 1; i <= m; ++i) {
+      u32 const qi = qcode[i - 1];
+      i32 carry = NEGW;                  // max of B(t') + 3 t' over the cells of the chunks before this one
+      i32 left_h = NEGW, left_e = NEGW;  // H, E of the last cell of the chunk before this one
+      for (i32 c = 0; c < nchunk; ++c) {
+        i32 const t = (c << 6) + lane, j = i + blo + t;
+        bool const inreg = t < bw;
+        i32 const tt = inreg ? t : bw;  // clamp: cell bw is the minus-infinity sentinel
+        i32 const oh = Hrow[tt], uh = Hrow[tt + (inreg ? 1 : 0)], uf = Frow[tt + (inreg ? 1 : 0)];
+        u32 const hc = inreg ? hcode[i + t + hshift] : 5u;
+        i32 const s = (qi > 3 || hc > 3) ? -1 : (qi == hc ? 1 : -4);
+        bool const cell = inreg && j >= 1 && j <= n;  // an ordinary cell; (i, 0) is a free start, the rest does not exist
+        i32 const dg = oh + s;
+        i32 const fo = uh - (GO + GE), fe = uf - GE;
+        i32 const f = cell ? max(fo, fe) : NEGW;
+        i32 const bnh = cell ? max(dg, f) : ((inreg && j == 0) ? 0 : NEGW);  // best non-horizontal entry
+        i32 const g = bnh + GE * t;
+        i32 const pm = max(carry, wave_excl_prefix_max(g));
+        i32 const e = cell ? pm - GO - GE * t : NEGW;
+        i32 const h = max(bnh, e);
+        // H, E of the left neighbour for the "gap opened here" bit
+        i32 const hl = wave_shr1(h, left_h), el = wave_shr1(e, left_e);
+        i32 const eo = hl - (GO + GE), ee = el - GE;
+        u32 nib = (dg >= e && dg >= f) ? 0u : (e >= f ? 1u : 2u);
+        nib |= (eo >= ee ? 4u : 0u) | (fo >= fe ? 8u : 0u);
+        __builtin_amdgcn_wave_barrier();  // every lane has read the old row before anyone overwrites it
+        if (inreg) {
+          Hrow[t] = h;
+          Frow[t] = f;
+        }
+        unsigned long long const b0 = __ballot(nib & 1u), b1 = __ballot(nib & 2u), b2 = __ballot(nib & 4u), b3 = __ballot(nib & 8u);
+        if (lane < 4) tile[(static_cast<size_t>(i) * nchunk_alloc + c) * 4 + lane] = lane == 0 ? b0 : (lane == 1 ? b1 : (lane == 2 ? b2 : b3));
+        carry = max(carry, __builtin_amdgcn_readlane(max(pm, g), 63));
+        left_h = __builtin_amdgcn_readlane(h, 63);
+        left_e = __builtin_amdgcn_readlane(e, 63);
+        // end cells: (m, j) for any j, (i, n) for i < m
+        if (inreg && j >= 0 && j <= n && (i == m || j == n)) {
+          if (h > best || (h == best && (i > bi || (i == bi && j < bj)))) {
+            best = h;
+            bi = i;
+            bj = j;
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
       }
-      unsigned long long const b0 = __ballot(nib & 1u), b1 = __ballot(nib & 2u), b2 = __ballot(nib & 4u), b3 = __ballot(nib & 8u);
-      if (lane < 4) tile[(static_cast<size_t>(i) * nchunk_alloc + c) * 4 + lane] = lane == 0 ? b0 : (lane == 1 ? b1 : (lane == 2 ? b2 : b3));
-      carry = max(carry, __shfl(max(pm, g), 63, 64));
-      left_h = __shfl(h, 63, 64);
-      left_e = __shfl(e, 63, 64);
-      // end cells: (m, j) for any j, (i, n) for i < m
-      if (inreg && j >= 0 && j <= n && (i == m || j == n)) {
-        if (h > best || (h == best && (i > bi || (i == bi && j < bj)))) {
-          best = h;
-          bi = i;
-          bj = j;
+    }
+    for (int off = 32; off > 0; off >>= 1) {  // best end cell of the wave: max score, ties -> larger i, then smaller j
+      i32 const ob = __shfl_xor(best, off), oi = __shfl_xor(bi, off), oj = __shfl_xor(bj, off);
+      if (ob > best || (ob == best && (oi > bi || (oi == bi && oj < bj)))) {
+        best = ob;
+        bi = oi;
+        bj = oj;
+      }
+    }
+  };
+  // ---- narrow first pass -------------------------------------------------------------------------------------------
+  // A wide region usually owes its width to a few stray anchors far from where the read really lies.  First the 64
+  // diagonals [c - 32, c + 32) around the most-voted diagonal c are searched (one chunk per row).  Let C = m - score be
+  // the cost of what that finds, Kc = floor((C - 12) / 3) (0 below 15) and V_far the votes further than r from c, for an
+  // r <= 31 - Kc.  With nothing ambiguous in read or haplotype, ANY overlap alignment of cost <= C keeps at least
+  // N = m - 10 - 11 floor(C / 5) - C mod 5 exact 11-mers (a mismatch costs 5 and breaks 11, a clipped or inserted row
+  // costs >= 1 and breaks 1, a gap costs >= 15 and breaks 10), each of them a vote on the diagonal it lies on.  If
+  // N > V_far one of them lies within r of c, and a path of cost <= C strays at most Kc diagonals from any diagonal it
+  // touches: it stays inside [c - 31, c + 31].  So every alignment of the full region that is as good as the narrow
+  // result -- the optimum and all its ties -- lies inside the narrow band, where the two searches see the same cells: same
+  // end cell, same traceback.  A narrow result below min_aln_score proves nothing; the full region is searched then.
+  i32 nlo = lo;
+  bool settled = false;
+  if (wr > 96 && !(A.prm.aln_tier & 2)) {
+    u64 const aux = A.ws.vote_aux[lp];
+    i32 const c = lo + static_cast<i32>(aux & 0xFFFFu);
+    u32 amb = 0;
+    for (i32 x = lane; x < m + wr + 1; x += 64) amb |= hcode[x] == 4u;
+    for (i32 x = lane; x < m; x += 64) amb |= qcode[x] > 3u;
+    if (!__ballot(amb != 0) && c - 32 >= lo && c + 32 <= lo + wr) {
+      run(c - 32, 64);
+      if (bi >= 0 && best >= A.prm.min_aln_score) {
+        i32 const C = m - best, Kc = C >= 15 ? (C - 12) / 3 : 0;
+        i32 const rc = 31 - Kc;
+        i32 const vfar = rc >= 24 ? static_cast<i32>((aux >> 48) & 0xFFFFu)
+                                  : (rc >= 16 ? static_cast<i32>((aux >> 32) & 0xFFFFu) : (rc >= 8 ? static_cast<i32>((aux >> 16) & 0xFFFFu) : 0x7FFFFFFF));
+        i32 const nmin = m - 10 - 11 * (C / 5) - C % 5;
+        if (nmin > vfar && vfar < 65535) {
+          settled = true;
+          nlo = c - 32;
         }
       }
-      __builtin_amdgcn_wave_barrier();
     }
   }
-  for (int off = 32; off > 0; off >>= 1) {  // best end cell of the wave: max score, ties -> larger i, then smaller j
-    i32 const ob = __shfl_xor(best, off), oi = __shfl_xor(bi, off), oj = __shfl_xor(bj, off);
-    if (ob > best || (ob == best && (oi > bi || (oi == bi && oj < bj)))) {
-      best = ob;
-      bi = oi;
-      bj = oj;
-    }
-  }
+  if (!settled) run(lo, wr);
   bool const hit = bi >= 0 && best >= A.prm.min_aln_score;
   if (!hit) {
     if (lane < 6) arec[lane] = 0;
@@ -979,7 +1151,7 @@ __global__ __launch_bounds__(64) void k_align_wave(GArgs A, u32 nchunk_alloc) {
         return static_cast<u32>(((q[0] >> sh) & 1ull) | (((q[1] >> sh) & 1ull) << 1) | (((q[2] >> sh) & 1ull) << 2) |
                                 (((q[3] >> sh) & 1ull) << 3));
       },
-      lo, m, best, bi, bj, arec, acig, lane == 0);
+      nlo, m, best, bi, bj, arec, acig, lane == 0);
 }
 
 // ---- last resort: a region no LDS row holds (more than ~7000 diagonals); one lane per pair, the (H,F) row in HBM ----
@@ -1712,16 +1884,17 @@ int launch_genotype(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& a, const m
     ws.wave_big_w = big_w;
     size_t budget = std::max<size_t>(size_t(1) << 30, stage_budget(0.15, ctx->ws_misc.cap, size_t(8) << 30, ctx->hbm_share));
     if (const char* e = getenv("MA_TB_GB")) budget = static_cast<size_t>(atoi(e)) << 30;
-    // vote chunks: bounded only by the 16 B / pair of region + DP lists (and 32-bit local pair ids)
-    u64 const pairs_chunk = std::min<u64>(total_pairs, std::min<u64>(u64(1) << 30, budget / 4 / 16));
-    size_t const tb_bytes = budget - pairs_chunk * 16;
+    // vote chunks: bounded only by the 24 B / pair of region + DP lists (and 32-bit local pair ids)
+    u64 const pairs_chunk = std::min<u64>(total_pairs, std::min<u64>(u64(1) << 30, budget / 4 / 24));
+    size_t const tb_bytes = budget - pairs_chunk * 24;
     MA_HIP(ctx, ctx->ws_misc.reserve(std::min<size_t>(tb_bytes, std::max<size_t>(size_t(256) << 20, static_cast<size_t>((pairs_chunk + 63) / 64) *
                                                                                                     ws.tb_rows * 17 * 256)) +
-                                     (pairs_chunk + 64) * 16 + 8192));
+                                     (pairs_chunk + 64) * 24 + 8192));
     // bytes available for traceback tiles; the per-pair arrays (and their atomics) start 256-byte aligned behind them
-    size_t const tb_cap = (ctx->ws_misc.cap - ((pairs_chunk + 64) * 16 + 8192)) & ~size_t(255);
+    size_t const tb_cap = (ctx->ws_misc.cap - ((pairs_chunk + 64) * 24 + 8192)) & ~size_t(255);
     ws.tb = ctx->ws_misc.as<u32>();
-    ws.centre = reinterpret_cast<i32*>(reinterpret_cast<char*>(ctx->ws_misc.p) + tb_cap);
+    ws.vote_aux = reinterpret_cast<u64*>(reinterpret_cast<char*>(ctx->ws_misc.p) + tb_cap);
+    ws.centre = reinterpret_cast<i32*>(ws.vote_aux + pairs_chunk + 16);
     ws.band_w = reinterpret_cast<u32*>(ws.centre + pairs_chunk + 16);
     ws.dp_list = ws.band_w + pairs_chunk + 16;
     ws.dp_count = ws.dp_list + pairs_chunk + 16;
@@ -1731,7 +1904,7 @@ int launch_genotype(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& a, const m
     u32 const pw_host = (ml_eff + 31) / 32 + 2;
     u32 const rwords = (max_read_len + 31) / 32 + 2;
     size_t const lds_vote = 4ull * ml_eff + 2ull * kIdxCap + 2ull * ((ml_eff + 1) & ~1) + 8ull * hist_len +
-                            12ull * pw_host + 48ull * rwords + 4ull * 4 * 129 + 4ull * (plan_counters[1] + 2) + 64;
+                            12ull * pw_host + 48ull * rwords + 4ull * 4 * 129 + 2ull * (ml_eff + 6) + 4ull * (plan_counters[1] + 2) + 64;
     if (lds_vote > 65536)
       MA_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_vote), hipFuncAttributeMaxDynamicSharedMemorySize,
                                       static_cast<int>(lds_vote)));
@@ -1769,7 +1942,7 @@ int launch_genotype(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& a, const m
         if (cls_n == 0) continue;
         ctx->stats[4 + (cls < kNumReg ? (cls < 2 ? 0 : (cls < 4 ? 1 : 2)) : 3)] += cls_n;
         u32 const gw = cls < kNumReg ? static_cast<u32>(reg_width(cls))
-                                     : (cls == kClsWaveS ? kWaveSmallW : (cls == kClsWaveB ? big_w : std::max<u32>(cnt[40], 1u)));
+                                     : (cls == kClsWaveS ? kWaveSmallW : (cls == kClsWaveB ? std::min<u32>(big_w, std::max<u32>(cnt[41], 64u)) : std::max<u32>(cnt[40], 1u)));
         A.ws.tb_words = (gw + 7) / 8;
         A.ws.gen_w = gw;
         bool const wave = cls == kClsWaveS || cls == kClsWaveB;
