@@ -239,6 +239,9 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     num_samples = 3 if args.config == "C5" else 2
     workers = args.gen_workers or max(1, min(16, (os.cpu_count() or 1) // max(1, world)))
+    # under rocprofv3 (--pmc initialises the GPU before main()) a forked pool never returns: synthesise in-process
+    if any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        workers = 1
 
     # ---- everything that forks happens before the GPU is initialised ----
     distinct = min(args.distinct, args.windows)
