@@ -42,7 +42,7 @@ STAGE_OF = {"gate_kernel": "gate",
             "k_edge_sort": "build",
             "k_clean": "clean",
             "k_msa": "poa", "k_msa_band": "poa",
-            "k_plan": "genotype", "k_vote": "genotype", "k_dp_scatter": "genotype", "k_align_reg": "genotype",
+            "k_read_planes": "genotype", "k_plan": "genotype", "k_vote": "genotype", "k_dp_scatter": "genotype", "k_align_reg": "genotype",
             "k_align_wave": "genotype", "k_align_gen": "genotype", "k_assign": "genotype", "k_evidence": "genotype",
             "k_qual": "genotype"}
 

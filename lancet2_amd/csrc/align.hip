@@ -71,6 +71,7 @@ struct AlnWs {
   u64* pair_off;       // [n + 1]
   u32* counters;       // [8]: 0 max read len, 1 max reads per window, 2 entries in vote_wg
   u32* vote_wg;        // [n * MH] compact list of (window * MH + slot) to align against
+  u32* read_planes;    // [n_reads][3][rwords] every read as three bit planes (k_read_planes), read by each haplotype's k_vote
   // haplotype seed index, per (window, slot)
   // per pair
   i32* centre;         // [pairs in chunk] first diagonal of the pair's region (vmin - K), or a sentinel
@@ -105,10 +106,13 @@ struct GArgs {
   u32 dp_n;      // entries of this DP launch
 };
 
-__global__ void k_max_reads(DBatch b, u32* out) {
+__global__ void k_max_reads(DBatch b, u32* out) {  // out[0] most reads of a window, out[1] longest read
   int const w = blockIdx.x * blockDim.x + threadIdx.x;
   if (w >= b.n_windows) return;
   atomicMax(out, b.read_win_off[w + 1] - b.read_win_off[w]);
+  u32 ml = 0;
+  for (u32 r = b.read_win_off[w]; r < b.read_win_off[w + 1]; ++r) ml = max(ml, static_cast<u32>(b.read_off[r + 1] - b.read_off[r]));
+  atomicMax(out + 1, ml);
 }
 
 // ---- planning ----
@@ -204,6 +208,65 @@ __device__ unsigned long long g_vprof[16];
 #define VPROF_ACC(slot) do {} while (0)
 #endif
 
+// ---- every read as three bit planes, once (each of the window's haplotypes votes against the same planes) ----
+// plane 0 / 1: low / high bit of the 2-bit base code, plane 2: base is not A/C/G/T; bit b of word b >> 5; zero padded
+// words per read record: three planes of rwords words, padded to whole 128-byte lines (full-line stores, one or two
+// aligned lines per fetch)
+__host__ __device__ constexpr u32 plane_stride(u32 rwords) { return (3u * rwords + 31u) & ~31u; }
+constexpr int kPlaneReadsPerWave = 16;  // (one read per wavefront would make the workgroup launch rate the bottleneck)
+__global__ __launch_bounds__(256) void k_read_planes(GArgs A, u32 rwords) {
+  extern __shared__ u32 lds_pl[];  // [4 waves][3 rwords]: the words are collected here and leave as ONE coalesced store per read
+  int const lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  u32* mine = lds_pl + wave * 3u * rwords;
+  i64 const r_begin = (static_cast<i64>(blockIdx.x) * 4 + wave) * kPlaneReadsPerWave;
+  i64 const r_end = min(r_begin + kPlaneReadsPerWave, A.b.n_reads);
+  // the loop is a chain of HBM round trips: the first 256 bases of the NEXT read are in flight while this one is packed
+  constexpr int kPre = 4;
+  u32 cur[kPre], nxt[kPre];
+  i32 m_cur = 0, m_nxt = 0;
+  auto fetch = [&](i64 r, u32 (&pre)[kPre], i32* mm) {
+    u64 const ro = A.b.read_off[r];
+    *mm = static_cast<i32>(A.b.read_off[r + 1] - ro);
+    const u8* rb = A.b.read_bases + ro;
+#pragma unroll
+    for (int x = 0; x < kPre; ++x) pre[x] = lane + 64 * x < *mm ? rb[lane + 64 * x] : 0u;
+  };
+#pragma unroll
+  for (int x = 0; x < kPre; ++x) cur[x] = nxt[x] = 0;
+  if (r_begin < r_end) fetch(r_begin, cur, &m_cur);
+  for (i64 r = r_begin; r < r_end; ++r) {
+    if (r + 1 < r_end) fetch(r + 1, nxt, &m_nxt);
+    i32 const m = m_cur;
+    const u8* rb = A.b.read_bases + A.b.read_off[r];
+    for (i32 i0 = 0; i0 < static_cast<i32>(rwords) * 32; i0 += 64) {
+      i32 const i = i0 + lane;
+      int const t = i0 >> 6;
+      u32 byte = 0;
+      if (t < kPre) {
+#pragma unroll
+        for (int x = 0; x < kPre; ++x) byte = t == x ? cur[x] : byte;
+      } else if (i < m) {
+        byte = rb[i];
+      }
+      u32 const e = i < m ? enc_base(static_cast<u8>(byte)) : 0u;
+      unsigned long long const blo = __ballot(e & 1u), bhi = __ballot(e & 2u), bbad = __ballot(e > 3u);
+      if (lane < 2 && static_cast<u32>(i0 >> 5) + lane < rwords) {
+        u32 const wd = (i0 >> 5) + lane;
+        mine[wd] = static_cast<u32>(blo >> (32 * lane));
+        mine[rwords + wd] = static_cast<u32>(bhi >> (32 * lane));
+        mine[2 * rwords + wd] = static_cast<u32>(bbad >> (32 * lane));
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    u32* out = A.ws.read_planes + static_cast<size_t>(r) * plane_stride(rwords);
+    for (u32 x = lane; x < plane_stride(rwords); x += 64) out[x] = x < 3u * rwords ? mine[x] : 0u;
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int x = 0; x < kPre; ++x) cur[x] = nxt[x];
+    m_cur = m_nxt;
+  }
+}
+
 // ---- seed vote: one workgroup per (window, haplotype), one wave per read ----
 // The haplotype's 11-mer index (bucket heads + chains + codes) lives in LDS for the lifetime of the
 // workgroup, so the per-read work never leaves the CU: every read of the window votes against it.
@@ -256,9 +319,7 @@ __device__ __forceinline__ void vote_flush_dp(GArgs const& A, HapIdx ix, int lan
   if (lane == 0) ix.dpbuf[64] = 0;
   __builtin_amdgcn_wave_barrier();
 }
-constexpr int kPre = 4;  // read bases prefetched per lane (covers reads up to 256 bases)
-__device__ __forceinline__ void vote_pair(GArgs const& A, u64 lp, PairId id, HapIdx ix, u16* hist, int lane, u64 ro, i32 m,
-                                          const u32 (&pre)[kPre]);
+__device__ __forceinline__ void vote_pair(GArgs const& A, u64 lp, PairId id, HapIdx ix, u16* hist, int lane, i32 m, u32 pre);
 
 __global__ __launch_bounds__(256) void k_vote(GArgs A, u32 hist_len, u32 rwords, u32 ml_eff) {
   extern __shared__ u32 lds_vote[];
@@ -412,30 +473,21 @@ __global__ __launch_bounds__(256) void k_vote(GArgs A, u32 hist_len, u32 rwords,
                   dpbuf_all + wave * 129, hap_amb, dup_pre, sh_cand};
 #endif
   u16* hist = hist_all + static_cast<size_t>(wave) * hist_len;
-  // software pipeline: the next read's bases are in flight while the current read is voted
-  auto fetch = [&](u32 ri, u32 (&pre)[kPre]) {
-    u32 const o = l_roff[ri], len = l_roff[ri + 1] - o;
-    const u8* rb = A.b.read_bases + roff0 + o;
-#pragma unroll
-    for (int x = 0; x < kPre; ++x) {
-      u32 const i = lane + 64 * x;
-      pre[x] = i < len ? rb[i] : 0u;
-    }
+  // software pipeline: the next read's plane words (lane l < 3 rwords holds word l) are in flight while the current
+  // read is voted
+  u32 const npw = 3u * rwords;
+  auto fetch = [&](u32 ri) -> u32 {
+    return static_cast<u32>(lane) < npw ? A.ws.read_planes[static_cast<size_t>(r0 + ri) * plane_stride(rwords) + lane] : 0u;
   };
-  u32 cur[kPre], nxt[kPre];
-#pragma unroll
-  for (int x = 0; x < kPre; ++x) cur[x] = nxt[x] = 0;
-  if (static_cast<u32>(wave) < nr) fetch(wave, cur);
+  u32 cur = 0, nxt = 0;
+  if (static_cast<u32>(wave) < nr) cur = fetch(wave);
   for (u32 ri = wave; ri < nr; ri += 4) {
-    if (ri + 4 < nr) fetch(ri + 4, nxt);
+    if (ri + 4 < nr) nxt = fetch(ri + 4);
     u64 const p = p0 + ri;
-    if (p >= A.pair0 && p < A.pair0 + A.npairs) {
-      u32 const o = l_roff[ri];
-      vote_pair(A, p - A.pair0, PairId{w, r0 + ri, static_cast<u32>(slot)}, ix, hist, lane, roff0 + o,
-                static_cast<i32>(l_roff[ri + 1] - o), cur);
-    }
-#pragma unroll
-    for (int x = 0; x < kPre; ++x) cur[x] = nxt[x];
+    if (p >= A.pair0 && p < A.pair0 + A.npairs)
+      vote_pair(A, p - A.pair0, PairId{w, r0 + ri, static_cast<u32>(slot)}, ix, hist, lane,
+                static_cast<i32>(l_roff[ri + 1] - l_roff[ri]), cur);
+    cur = nxt;
   }
   vote_flush_dp(A, ix, lane);
 #ifdef MA_PROFILE
@@ -451,40 +503,20 @@ __device__ __forceinline__ void write_no_hit(GArgs const& A, PairId id) {
   A.o.aln_rec[(static_cast<size_t>(id.r) * A.prm.max_haps + id.slot) * 6] = 0;
 }
 
-__device__ __forceinline__ void vote_pair(GArgs const& A, u64 lp, PairId id, HapIdx ix, u16* hist, int lane, u64 ro, i32 m,
-                                          const u32 (&pre)[kPre]) {
+__device__ __forceinline__ void vote_pair(GArgs const& A, u64 lp, PairId id, HapIdx ix, u16* hist, int lane, i32 m, u32 pre) {
   size_t const hi = static_cast<size_t>(id.w) * A.prm.max_haps + id.slot;
   i32 const n = static_cast<i32>(A.a.hap_len[hi]);
-  const u8* rb = A.b.read_bases + ro;
   i32 const nd = m + n + 1;  // diagonals d in [-m, n] -> hist[d + m]
   i32 const Kr = m - A.prm.min_aln_score - GO > 0 ? (m - A.prm.min_aln_score - GO) / GE : 0;  // reach K of the search region
   const u16* head = ix.head;
   const u16* next = ix.next;
   const u32* code = ix.code;
   VPROF_T0();
-  // the read as three bit planes in LDS: one coalesced byte load per base
+  // the read's three bit planes (k_read_planes) into this wave's LDS slot: [3][rwords], one word per lane
   u32* rlo = ix.rplanes;
   u32* rhi = rlo + ix.rwords;
   u32* rbad = rhi + ix.rwords;
-  for (i32 i0 = 0; i0 < static_cast<i32>(ix.rwords) * 32; i0 += 64) {
-    i32 const i = i0 + lane;
-    int const t = i0 >> 6;
-    u32 byte = 0;
-    if (t < kPre) {
-#pragma unroll
-      for (int x = 0; x < kPre; ++x) byte = t == x ? pre[x] : byte;
-    } else if (i < m) {
-      byte = rb[i];
-    }
-    u32 const e = i < m ? enc_base(static_cast<u8>(byte)) : 0u;
-    unsigned long long const blo = __ballot(e & 1u), bhi = __ballot(e & 2u), bbad = __ballot(e > 3u);
-    if (lane < 2 && static_cast<u32>(i0 >> 5) + lane < ix.rwords) {
-      u32 const wd = (i0 >> 5) + lane;
-      rlo[wd] = static_cast<u32>(blo >> (32 * lane));
-      rhi[wd] = static_cast<u32>(bhi >> (32 * lane));
-      rbad[wd] = static_cast<u32>(bbad >> (32 * lane));
-    }
-  }
+  if (static_cast<u32>(lane) < 3u * ix.rwords) rlo[lane] = pre;
   __builtin_amdgcn_wave_barrier();
   // ---- hint shortcut: certificate (I) without the seed index --------------------------------------------------------
   // Try the diagonals the read's mapped position suggests.  On such a diagonal c (read inside the haplotype, X <= 2
@@ -512,8 +544,8 @@ __device__ __forceinline__ void vote_pair(GArgs const& A, u64 lp, PairId id, Hap
           }
         }
         if (__ballot(bad != 0)) break;  // an N in the read: general route
-        for (int off = 32; off > 0; off >>= 1) mism += __shfl_xor(mism, off);
-        i32 const X = static_cast<i32>(mism);
+        for (int off = m <= 256 ? 4 : 32; off > 0; off >>= 1) mism += __shfl_xor(mism, off);  // words live in lanes < m / 32
+        i32 const X = static_cast<i32>(__builtin_amdgcn_readfirstlane(mism));
         if (X > 2) continue;
         i32 const D = static_cast<i32>(ix.dup_pre[c + m - SK + 1]) - static_cast<i32>(ix.dup_pre[c]);
         i32 const S0 = m - 5 * X;
@@ -1814,14 +1846,17 @@ int launch_genotype(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& a, const m
   // evidence table: sized from the largest window (reads x a few variants each); the read count per
   // window is known from read_win_off only on the device, so a first tiny pass fetches the maxima
   ws.ev_cap = 8192;
+  u32 rwords_all = 8;  // words per read bit plane (longest read of the batch + two zero words)
   {
     MA_HIP(ctx, ctx->ws_misc.reserve(4096));
     u32* cnt = ctx->ws_misc.as<u32>();
     MA_HIP(ctx, hipMemsetAsync(cnt, 0, 16, ctx->stream));
     hipLaunchKernelGGL(k_max_reads, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, b, cnt);
-    u32 mr = 0;
-    MA_HIP(ctx, hipMemcpyAsync(&mr, cnt, 4, hipMemcpyDeviceToHost, ctx->stream));
+    u32 mr2[2] = {0, 0};
+    MA_HIP(ctx, hipMemcpyAsync(mr2, cnt, 8, hipMemcpyDeviceToHost, ctx->stream));
     MA_HIP(ctx, ma_stream_sync(ctx));
+    u32 const mr = mr2[0];
+    rwords_all = (mr2[1] + 31) / 32 + 2;
     u64 want = static_cast<u64>(mr) * 8 + 1024;
     u32 cap = 8192;
     while (cap < want && cap < (1u << 24)) cap <<= 1;
@@ -1841,6 +1876,7 @@ int launch_genotype(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& a, const m
     ws.pair_off = reinterpret_cast<u64*>(take(8ull * (n + 1)));
     ws.counters = reinterpret_cast<u32*>(take(64));
     ws.vote_wg = reinterpret_cast<u32*>(take(4ull * n * MH));
+    ws.read_planes = reinterpret_cast<u32*>(take(4ull * NR * plane_stride(rwords_all) + 256));
     ws.ev_key = reinterpret_cast<u64*>(take(8ull * n * ws.ev_cap));
     ws.ev_min = reinterpret_cast<u32*>(take(4ull * n * ws.ev_cap));
     ws.asg_allele = reinterpret_cast<u8*>(take(NR * MV + 16));
@@ -1862,6 +1898,10 @@ int launch_genotype(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& a, const m
   if (o_in.aln_rec) MA_HIP(ctx, hipMemsetAsync(A.o.aln_rec, 0, 4ull * NR * MH * 6, ctx->stream));
   if (o_in.aln_cigar) MA_HIP(ctx, hipMemsetAsync(A.o.aln_cigar, 0, 4ull * NR * MH * (1 + MCG), ctx->stream));
 
+  ctx->tic("k_read_planes");
+  hipLaunchKernelGGL(k_read_planes, dim3(static_cast<u32>((NR + 4 * kPlaneReadsPerWave - 1) / (4 * kPlaneReadsPerWave))), dim3(256),
+                     4 * 3 * rwords_all * 4, ctx->stream, A, rwords_all);
+  ctx->toc();
   ctx->tic("k_plan");
   hipLaunchKernelGGL(k_plan, dim3((n + 127) / 128), dim3(128), 0, ctx->stream, A);
   hipLaunchKernelGGL(k_scan_pairs, dim3(1), dim3(1024), 0, ctx->stream, ws.pair_off, n);
@@ -1902,7 +1942,7 @@ int launch_genotype(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& a, const m
     u32 const ml_eff = std::min<u32>(static_cast<u32>(P.max_hap_len), (std::max<u32>(plan_counters[3], 64u) + 31u) & ~31u);
     u32 const hist_len = ((max_read_len + ml_eff + 2 + 1) & ~1u);
     u32 const pw_host = (ml_eff + 31) / 32 + 2;
-    u32 const rwords = (max_read_len + 31) / 32 + 2;
+    u32 const rwords = rwords_all;  // == (max_read_len + 31) / 32 + 2
     size_t const lds_vote = 4ull * ml_eff + 2ull * kIdxCap + 2ull * ((ml_eff + 1) & ~1) + 8ull * hist_len +
                             12ull * pw_host + 48ull * rwords + 4ull * 4 * 129 + 2ull * (ml_eff + 6) + 4ull * (plan_counters[1] + 2) + 64;
     if (lds_vote > 65536)

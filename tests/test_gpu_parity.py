@@ -532,12 +532,14 @@ def test_process_batch_seed_sweep(cfg, nwin, first, kw):
     compare_cx(params, cx, wc, wv["win_nvars"])
 
 
-def test_process_batch_deep_window():
-    """A 300x/300x panel-style window (4288 reads, 50 bp indels): more sequences than the LDS-resident shortcuts
-    of the build stage accept (k_mm_lds falls back to the HBM mate-mer set), four haplotypes, 13 variants."""
+@pytest.mark.parametrize("depth", [300, 500])
+def test_process_batch_deep_window(depth):
+    """A 300x/300x and a 500x/500x (BASELINE configs[3]) panel-style window with 50 bp indels (4288 / 7100 reads): more
+    sequences than the LDS-resident shortcuts of the build stage accept (k_mm_lds falls back to the HBM mate-mer set),
+    four haplotypes, 13 variants, read<->haplotype regions widened by the 50-base indels."""
     from lancet2_amd.engine import Engine
     params = capi.default_params(min_k=25, max_k=25)
-    arrs, n, nr = synth.make_config_batch("C4", 1, first_index=60000, depths=(300, 300))
+    arrs, n, nr = synth.make_config_batch("C4", 1, first_index=60000, depths=(depth, depth))
     assert nr > 2048
     orc = OracleEngine(params)
     wa = orc.assemble(arrs, n, nr)

@@ -15,12 +15,12 @@ from lancet2_amd import engine as E  # noqa: E402
 
 capi.LIB_PATH = os.path.join(capi.REPO, "lancet2_amd", "libmicroasm_prof.so")
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 512
-arrs, nw, nr = synth.make_config_batch("C2", 64)
+arrs, nw, nr = synth.make_config_batch("C3", 64)
 arrs, nw, nr = synth.tile_batch(arrs, nw, nr, n // 64)
 eng = E.Engine(capi.default_params(min_k=25, max_k=25))
 eng.process(arrs, nw, nr)
 buf = (C.c_ulonglong * 16)()
-for sym, names in (("ma_debug_cprof", ["init", "components", "anchors", "compress1", "lowcov", "compress2", "tips", "trav_index", "cycle+cx", "maxflow", "emit", "merges_fast", "merges_generic"]), ("ma_debug_vprof", ["encode", "vote", "argmax", "second", "clear", "mismatch", "emit", "pairs", "x8", "x9", "x10", "x11", "x12", "x13", "wave_total"]),
+for sym, names in (("ma_debug_cprof", ["init", "components", "anchors", "compress1", "lowcov", "compress2", "tips", "trav_index", "cycle+cx", "maxflow", "emit", "merges_fast", "merges_generic"]), ("ma_debug_vprof", ["encode", "vote", "argmax", "second", "clear", "mismatch", "emit", "pairs", "shortcut", "shortcut_hits", "shortcut_miss", "x11", "x12", "x13", "wave_total"]),
                    ("ma_debug_prof", ["prep", "fill", "end+traceback", "add_alignment", "toposort", "extract", "first_seq", "x", "fill_pre", "fill_barrier", "fill_post", "rows_generic", "rows", "band_fallbacks"])):
     fn = getattr(eng.lib, sym, None)
     if fn is None:
@@ -29,7 +29,7 @@ for sym, names in (("ma_debug_cprof", ["init", "components", "anchors", "compres
 eng.timing_control(1)
 eng.process(arrs, nw, nr)
 print({k: round(v, 2) for k, v in eng.kernel_times()})
-for sym, names in (("ma_debug_cprof", ["init", "components", "anchors", "compress1", "lowcov", "compress2", "tips", "trav_index", "cycle+cx", "maxflow", "emit", "merges_fast", "merges_generic"]), ("ma_debug_vprof", ["encode", "vote", "argmax", "second", "clear", "mismatch", "emit", "pairs", "x8", "x9", "x10", "x11", "x12", "x13", "wave_total"]),
+for sym, names in (("ma_debug_cprof", ["init", "components", "anchors", "compress1", "lowcov", "compress2", "tips", "trav_index", "cycle+cx", "maxflow", "emit", "merges_fast", "merges_generic"]), ("ma_debug_vprof", ["encode", "vote", "argmax", "second", "clear", "mismatch", "emit", "pairs", "shortcut", "shortcut_hits", "shortcut_miss", "x11", "x12", "x13", "wave_total"]),
                    ("ma_debug_prof", ["prep", "fill", "end+traceback", "add_alignment", "toposort", "extract", "first_seq", "x", "fill_pre", "fill_barrier", "fill_post", "rows_generic", "rows", "band_fallbacks"])):
     fn = getattr(eng.lib, sym, None)
     if fn is None:
