@@ -12,7 +12,7 @@ def mutate(rng, s, sub=0.0, indels=()):
     """substitutions at rate `sub`, then the given [(kind, length)] indels at random interior positions"""
     b = bytearray(s)
     for i in range(len(b)):
-        if rng.random() < sub:
+        if rng.random() < sub and bytes([b[i]]) in (b"A", b"C", b"G", b"T"):
             b[i] = BASES[(BASES.index(bytes([b[i]])) + int(rng.integers(1, 4))) % 4]
     for kind, ln in indels:
         if len(b) < 2 * ln + 40:

@@ -10,6 +10,7 @@ from lancet2_amd import capi, synth
 from pin_cases import BASES, CASES, make_pair, mutate, rand_dna
 
 pytestmark = pytest.mark.gpu
+SWEEP = int(__import__("os").environ.get("MA_SWEEP_SEED", "0"))  # tools: other seeded cases of the same shapes
 
 
 def _read(seq, qname, rev=False, sample=0, role=0):
@@ -54,7 +55,7 @@ def test_every_pin_case_flavour():
     """the flavours of tests/pin_cases.py (clean, noisy, indels up to 40, STR, overhangs, N, unrelated), 40 reads per
     haplotype pair"""
     params = capi.default_params(min_k=25, max_k=25, max_hap_len=2048)
-    rng = np.random.default_rng(4242)
+    rng = np.random.default_rng(4242 + SWEEP)
     cases, wins = [], []
     for case in CASES:
         for _ in range(3):
@@ -68,7 +69,7 @@ def test_every_pin_case_flavour():
                 if case == "unrelated":
                     reads.append(r)
                     continue
-                st = int(rng.integers(-40, len(hap) - m + 40))
+                st = int(rng.integers(-40, max(len(hap) - m + 40, -39)))
                 src = rand_dna(rng, 60) + hap + rand_dna(rng, 60)
                 sub = src[60 + st: 60 + st + m + 30]
                 k = int(rng.integers(0, 3))
@@ -96,7 +97,7 @@ def test_wide_regions_tandem_repeats_and_duplications(wave_max, monkeypatch):
     if wave_max:
         monkeypatch.setenv("MA_WAVE_MAX_W", wave_max)
     params = capi.default_params(min_k=25, max_k=25, max_hap_len=2048)
-    rng = np.random.default_rng(77)
+    rng = np.random.default_rng(77 + SWEEP)
     cases, wins = [], []
     for unit_len, rep_len in ((1, 40), (2, 60), (3, 90), (5, 150), (6, 240)):
         hap = rand_dna(rng, 1200)
@@ -132,7 +133,7 @@ def test_long_reads_and_long_indels():
     100-300 base deletions: no hit end to end against the haplotype without the deletion (cost 12 + 3 L), a clean
     hit against the one that carries it"""
     params = capi.default_params(min_k=25, max_k=25, max_hap_len=2048)
-    rng = np.random.default_rng(31)
+    rng = np.random.default_rng(31 + SWEEP)
     cases, wins = [], []
     for m in (250, 300, 400):
         hap = rand_dna(rng, 1400)

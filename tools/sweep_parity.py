@@ -19,7 +19,11 @@ CASES = [("C2", 96, 70_000, {}, dict(min_k=25, max_k=25)), ("C3", 32, 71_000, {}
          ("C2", 24, 76_000, dict(error_scale=4.0), dict(min_k=25, max_k=25)),
          ("C2", 24, 77_000, dict(snv_rate=1e-2, indel_rate=2e-3), dict(min_k=25, max_k=25)),
          ("C3", 16, 78_000, dict(error_scale=3.0, str_unit=b"CAG"), {}),
-         ("C2", 16, 79_000, dict(error_scale=2.0, snv_rate=5e-3), dict(min_k=17, max_k=41, k_step=8))]
+         ("C2", 16, 79_000, dict(error_scale=2.0, snv_rate=5e-3), dict(min_k=17, max_k=41, k_step=8)),
+         # round 2: germline mode (PL / GQ / QUAL), long reads (wide search regions), long indels
+         ("C2", 24, 80_000, {}, dict(min_k=25, max_k=25, case_ctrl_mode=0)),
+         ("C2", 12, 81_000, dict(read_len=250, big_indel=60), dict(min_k=25, max_k=25)),
+         ("C3", 16, 82_000, dict(str_unit=b"AGGGTT", error_scale=2.0), dict(min_k=25, max_k=25))]
 shift = int(sys.argv[1]) if len(sys.argv) > 1 else 0  # other windows of the same shapes
 tot = 0
 for cfg, nwin, first, kw, pk in CASES:
