@@ -198,7 +198,8 @@ typedef struct ma_ctx ma_ctx_t;
 int ma_create(const ma_params_t* prm, int device, int memspace, ma_ctx_t** out);
 void ma_destroy(ma_ctx_t* ctx);
 const char* ma_last_error(const ma_ctx_t* ctx);
-/* HIP stream all launches go to (void* == hipStream_t); NULL = the null stream. */
+/* HIP stream all launches and copies go to (void* == hipStream_t).  A context starts on a non-blocking stream of its
+ * own, so that several contexts on one device overlap; NULL selects the legacy null stream. */
 int ma_set_stream(ma_ctx_t* ctx, void* hip_stream);
 int ma_synchronize(ma_ctx_t* ctx);
 

@@ -309,6 +309,9 @@ int ma_create(const ma_params_t* prm, int device, int memspace, ma_ctx_t** out) 
   c->prm = *prm;
   c->device = device;
   c->memspace = memspace;
+  // own non-blocking stream: the legacy null stream would serialise this context against every other context and
+  // copy of the process (two feeders on one device would never overlap); ma_set_stream replaces it
+  if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) == hipSuccess) c->stream = c->own_stream;
   *out = c;
   return MA_OK;
 }
@@ -333,6 +336,7 @@ void ma_destroy(ma_ctx_t* ctx) {
   }
   if (ctx->lane_done) (void)hipEventDestroy(ctx->lane_done);
   if (ctx->sync_ev) (void)hipEventDestroy(ctx->sync_ev);
+  if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
   delete ctx;
 }
 
@@ -341,6 +345,13 @@ const char* ma_last_error(const ma_ctx_t* ctx) { return ctx ? ctx->err.c_str() :
 int ma_set_stream(ma_ctx_t* ctx, void* s) {
   if (!ctx) return MA_ERR_ARG;
   ctx->stream = static_cast<hipStream_t>(s);
+  // the context's own stream is not needed any more; an idle stream still takes one of the process's few hardware queues
+  // (4 by default) away from the lanes
+  if (ctx->own_stream && ctx->stream != ctx->own_stream) {
+    (void)hipStreamSynchronize(ctx->own_stream);
+    (void)hipStreamDestroy(ctx->own_stream);
+    ctx->own_stream = nullptr;
+  }
   return MA_OK;
 }
 

@@ -60,6 +60,7 @@ struct ma_ctx {
   int device = 0;
   int memspace = MA_MEM_HOST;
   hipStream_t stream = nullptr;
+  hipStream_t own_stream = nullptr;  // created by ma_create (non-blocking); `stream` points here until ma_set_stream
   std::string err;
   // staging for MA_MEM_HOST
   ma::DevBuf in_stage[10];

@@ -115,3 +115,20 @@ def test_two_rank_gloo_sharding():
         covered = sorted(i for mine, _ in gathered for i in mine)
         assert covered == list(range(5))
         assert all(k == 25 for _, ks in gathered for k in ks)
+
+
+def test_bench_gpus_flag_starts_ranks_or_says_why_not():
+    """`python bench.py --gpus N` without a launcher must start N ranks itself (the flag was parsed and never
+    used).  On a box with fewer GPUs it must say so instead of silently running one rank and printing n_gpus = 1."""
+    import json
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("a multi-GPU box runs the real thing")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(capi.REPO, "bench.py"), "--gpus", "2", "--steps", "1"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 2
+    msg = json.loads(r.stdout.strip().splitlines()[-1])
+    assert "error" in msg and "--gpus 2" in msg["error"]
