@@ -30,7 +30,7 @@ inline EdgeKind MakeFwdEdgeKind(u8 s, u8 d) {  // kmer.h:66-75
 }
 inline u8 SrcSignOf(u8 kind) { return (kind == PP || kind == PM) ? PLUS : MINUS; }  // kmer.h:77-92
 inline u8 DstSignOf(u8 kind) { return (kind == PP || kind == MP) ? PLUS : MINUS; }
-inline u8 RevEdgeKind(u8 kind) { return kind == PP ? MM : (kind == MM ? PP : kind); }  // kmer.h:94-105
+inline u8 RevEdgeKind(u8 kind) { return kind == PP ? static_cast<u8>(MM) : (kind == MM ? static_cast<u8>(PP) : kind); }  // kmer.h:94-105
 inline u8 RevSign(u8 s) { return s == PLUS ? MINUS : PLUS; }
 
 struct Edge {  // cbdg/edge.h:12-58 (node ids replaced by first-insertion indices)

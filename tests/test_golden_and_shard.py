@@ -132,3 +132,15 @@ def test_bench_gpus_flag_starts_ranks_or_says_why_not():
     assert r.returncode == 2
     msg = json.loads(r.stdout.strip().splitlines()[-1])
     assert "error" in msg and "--gpus 2" in msg["error"]
+
+
+def test_bench_algorithmic_bytes_are_the_surveys():
+    """bench.py prices its roofline with SURVEY.md 8(d)'s algorithmic bytes and nothing else: at the survey's own worked
+    C3 example (R = 690, B = 103.5 k, S = 2, N_inst = 87.9 k, N_raw = 15 k, H = 3, L = 1 k, n_cigar = 16) the per-stage
+    figures are the survey's 1.98 / 0.36 / 0.03 / 0.39 MB and the total its ~2.8 MB per window-attempt."""
+    import bench
+    st = dict(W=1001, R=690, B=103_500, S=2, N_inst=87_900, N_raw=15_000, H=3, L=1000, L_ref=1000, var_bases=20, n_cigar=16)
+    mb = {s: bench.survey_bytes(s, st) / 1e6 for s in ("gate", "build", "clean", "poa", "genotype")}
+    assert abs(mb["build"] - 1.98) < 0.02 and abs(mb["clean"] - 0.36) < 0.03
+    assert abs(mb["poa"] - 0.03) < 0.005 and abs(mb["genotype"] - 0.39) < 0.01
+    assert abs(sum(mb.values()) - 2.8) < 0.1
