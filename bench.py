@@ -55,6 +55,8 @@ def parse():
     ap.add_argument("--windows", type=int, default=8192, help="windows per step per GPU")
     ap.add_argument("--distinct", type=int, default=2048, help="distinct synthetic windows (tiled to --windows)")
     ap.add_argument("--str-every", type=int, default=8, help="every n-th window carries a short tandem repeat (0 = none)")
+    ap.add_argument("--nohint-every", type=int, default=50,
+                    help="every n-th read pair arrives without a mapping hint (unmapped / rescued mates); 0 = every read hinted")
     ap.add_argument("--config", default="C3",
                     help="C3 = WGS-shaped tumour/normal 60x/30x (the workload BASELINE.json's metric is quoted on); "
                          "C2 = chr22-shaped 30x/30x (configs[1]); C4, C5")
@@ -96,9 +98,12 @@ def units_per_step(stage, st):
 
 
 # ---- synthetic windows ---------------------------------------------------------------------------------------------
+NOHINT_EVERY = 50  # set from --nohint-every before any window is made (module global: the pool workers are forked)
+
+
 def _gen_chunk(job):
     config, first, count, str_every = job
-    from lancet2_amd import synth
+    from lancet2_amd import capi, synth
     kw = dict(synth.CONFIGS[config])
     wins = []
     for i in range(count):
@@ -106,7 +111,12 @@ def _gen_chunk(job):
         k2 = dict(kw)
         if str_every and idx % str_every == str_every - 1:
             k2["str_unit"] = STR_UNITS[(idx // str_every) % len(STR_UNITS)]
-        wins.append(synth.make_window(idx, **k2))
+        w = synth.make_window(idx, **k2)
+        if NOHINT_EVERY:
+            for r in w["reads"]:
+                if r["qname"] % NOHINT_EVERY == NOHINT_EVERY - 1:
+                    r["hint"] = capi.MA_NO_HINT
+        wins.append(w)
     return synth.pack_batch(wins)
 
 
@@ -232,6 +242,8 @@ def spawn_ranks(args):
 
 def main():
     args = parse()
+    global NOHINT_EVERY
+    NOHINT_EVERY = args.nohint_every
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -566,6 +578,7 @@ def main():
             "config": {"workload": WORKLOADS.get(args.config, args.config),
                        "windows_per_step_per_gpu": n, "distinct_windows": n0,
                        "str_windows": f"every {args.str_every}th window carries a 12-copy tandem repeat" if args.str_every else "none",
+                       "reads_without_hint": f"every {args.nohint_every}th read pair" if args.nohint_every else "none",
                        "reads_per_window": round(R, 1),
                        "assembled_windows_per_s": round(asm_wps, 2), "assembled_fraction": round(assembled / n, 4),
                        "repeat_gated_fraction": round(gated / n, 4),
