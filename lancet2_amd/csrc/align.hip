@@ -1146,7 +1146,7 @@ __global__ __launch_bounds__(64) void k_align_wave(GArgs A, u32 nchunk_alloc) {
   // end cell, same traceback.  A narrow result below min_aln_score proves nothing; the full region is searched then.
   i32 nlo = lo;
   bool settled = false;
-  if (wr > 96 && !(A.prm.aln_tier & 2)) {
+  if (wr > 96 && (A.ws.band_w[lp] >> 17) >= static_cast<u32>(kNumReg) && !(A.prm.aln_tier & 2)) {  // (vote_aux exists for wide classes only)
     u64 const aux = A.ws.vote_aux[lp];
     i32 const c = lo + static_cast<i32>(aux & 0xFFFFu);
     u32 amb = 0;
@@ -1985,7 +1985,10 @@ int launch_genotype(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& a, const m
                                      : (cls == kClsWaveS ? kWaveSmallW : (cls == kClsWaveB ? std::min<u32>(big_w, std::max<u32>(cnt[41], 64u)) : std::max<u32>(cnt[40], 1u)));
         A.ws.tb_words = (gw + 7) / 8;
         A.ws.gen_w = gw;
-        bool const wave = cls == kClsWaveS || cls == kClsWaveB;
+        // A register-class launch lasts at least 150 dependent rows of W cells (0.15 - 0.6 ms for W = 33 ... 129) however few
+        // pairs it holds; the wavefront kernel runs one pair per wave in ~50 us: sparse wide classes go there
+        bool const reroute = cls < kNumReg && reg_width(cls) >= 49 && cls_n <= 4096u && !getenv("MA_NO_REROUTE");
+        bool const wave = cls == kClsWaveS || cls == kClsWaveB || reroute;
         u32 const nchunk = (gw + 63) / 64;
         // bytes of traceback per launch group: 64 pairs of a lane-per-pair kernel, ONE pair of the wavefront kernel
         size_t const tb_per_group = wave ? static_cast<size_t>(ws.tb_rows) * nchunk * 32
@@ -2016,7 +2019,7 @@ int launch_genotype(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& a, const m
     hipLaunchKernelGGL((k_align_reg<reg_width(C), WLO>), dim3(ng), dim3(64), lds_reg, ctx->stream, A, segw);          \
     ctx->toc();                                                                                                        \
     break;
-          switch (cls) {
+          switch (reroute ? kClsWaveB : cls) {
             MA_LAUNCH_REG(0, 0)
             MA_LAUNCH_REG(1, reg_width(0))
             MA_LAUNCH_REG(2, reg_width(1))
