@@ -386,6 +386,34 @@ __device__ __forceinline__ u64 kmer_id(const u8* s, int k, bool* plus_out) {
   return id ? id : 1;
 }
 
+// The same id from the window's read bases staged in LDS as 4-bit codes (A 0, C 1, G 2, T 3, N 4; k_insert stages only
+// windows whose reads hold nothing else, so code -> byte is exact).  p = position of the k-mer's first base in the staged
+// stream.  Same comparisons and the same polynomial over the same bytes as kmer_id: the same id.
+__device__ __forceinline__ u32 seq_code(const u32* l_seq, u32 p) { return (l_seq[p >> 3] >> (4u * (p & 7u))) & 0xFu; }
+__device__ __forceinline__ u32 code_byte(u32 code) { return static_cast<u32>(0x0000004E54474341ULL >> (8u * code)) & 0xFFu; }  // "ACGTN"
+__device__ __forceinline__ u32 code_comp(u32 code) { return code < 4u ? 3u - code : 4u; }
+__device__ __forceinline__ u64 kmer_id_lds(const u32* l_seq, u32 p, int k, bool* plus_out) {
+  bool plus = true;
+  int const half = (k + 1) / 2;
+  for (int i = 0; i < half; ++i) {  // canonical decision (kmer.cpp:17-28): inward compare of the bytes
+    u32 const f = code_byte(seq_code(l_seq, p + i));
+    u32 const r = code_byte(code_comp(seq_code(l_seq, p + k - 1 - i)));
+    if (f != r) {
+      plus = f < r;
+      break;
+    }
+  }
+  u64 h = 0;
+#pragma unroll 8
+  for (int i = 0; i < k; ++i) {
+    u32 const cd = seq_code(l_seq, plus ? p + i : p + k - 1 - i);
+    h = h * kHashP + code_byte(plus ? cd : code_comp(cd));
+  }
+  u64 const id = dev_fmix64(h);
+  *plus_out = plus;
+  return id ? id : 1;
+}
+
 // 85 % of the slow k-mers of a window are repeats (a variant's k-mers come back in every read that carries it), and
 // the table insert is bound by L2 atomic throughput (two returning atomics per instance).  So the window's distinct
 // k-mers are collected in an LDS map first (id -> smallest instance); the HBM table is then sized for the DISTINCT
@@ -393,14 +421,17 @@ __device__ __forceinline__ u64 kmer_id(const u8* s, int k, bool* plus_out) {
 // k_mm_lds), each distinct k-mer goes into it once, and a last pass hands every instance its table slot.  k-mers that
 // do not fit the map (deep samples) are deferred and take the direct path with its atomics.
 constexpr int kInsT = 1024;
-constexpr u32 kInsMap = 8192;         // LDS map entries
+constexpr u32 kInsMap = 6144;         // LDS map entries (48 KB of ids + 24 KB of first instances: two workgroups per CU)
+constexpr u32 kInsEntryMask = 8191;   // an instance word carries its map entry in 13 bits
+constexpr u32 kSeqWords = 12288;      // the window's read bases as 4-bit codes in LDS: 48 KB = 98 304 bases
 constexpr u32 kInstTemp = 1u << 26;   // instance word holds a map entry, not yet a table slot (slots are < 2^21)
 constexpr u32 kInstDefer = 1u << 25;  // instance waits for the direct path
 __global__ __launch_bounds__(kInsT) void k_insert(DBatch b, GraphWs ws) {
   __shared__ u64 l_key[kInsMap];
-  __shared__ u32 l_min[kInsMap];
-  __shared__ u32 l_slot[kInsMap];
-  __shared__ u32 l_nmap, l_ndef;
+  __shared__ u32 l_min[kInsMap];  // smallest instance of the id; after pass 2: its table slot | bit 31 "also a reference k-mer"
+  __shared__ u32 l_seq[kSeqWords];
+  __shared__ u32 l_rpos[kSeqCap], l_ibase[kSeqCap];  // staged windows: per sequence, first base in l_seq and first instance
+  __shared__ u32 l_nmap, l_ndef, l_seq_ok;
   int const a = blockIdx.x;
   int const w = static_cast<int>(ws.active[a]);
   int const k = ws.k;
@@ -416,11 +447,48 @@ __global__ __launch_bounds__(kInsT) void k_insert(DBatch b, GraphWs ws) {
     l_key[i] = 0;
     l_min[i] = 0xFFFFFFFFu;
   }
-  if (threadIdx.x == 0) l_nmap = l_ndef = 0;
+  // The slow pass hashes ~16 k k-mers per window straight from the read bytes: chains of dependent HBM round trips per
+  // instance were 73 % of this kernel.  The window's read bases are therefore staged in LDS first (4 bit per base, aligned
+  // 8-byte loads) whenever they fit and hold nothing but A/C/G/T/N; deeper or odd windows hash from HBM as before.
+  const u8* const seq_base = [&]() {
+    const u8* const first_byte = b.read_bases + b.read_off[b.read_win_off[w]];
+    return first_byte - (reinterpret_cast<uintptr_t>(first_byte) & 7u);
+  }();
+  u64 const seq_bytes = static_cast<u64>((b.read_bases + b.read_off[b.read_win_off[w + 1]]) - seq_base);
+  u32 const ns_all = seq_count(b, w);
+  bool const stage = nq > 0 && seq_bytes <= static_cast<u64>(kSeqWords) * 8u && ns_all <= kSeqCap;
+  if (threadIdx.x == 0) {
+    l_nmap = l_ndef = 0;
+    l_seq_ok = stage ? 1u : 0u;
+  }
   __syncthreads();
+  if (stage) {
+    u32 const nwords = static_cast<u32>((seq_bytes + 7u) / 8u);
+    bool odd = false;
+    for (u32 wd = threadIdx.x; wd < nwords; wd += kInsT) {
+      uint2 const v = *reinterpret_cast<const uint2*>(seq_base + static_cast<size_t>(wd) * 8u);  // (buffers are padded by 64 bytes)
+      u32 pk = 0;
+#pragma unroll
+      for (int x = 0; x < 8; ++x) {
+        u32 const byte = ((x < 4 ? v.x : v.y) >> (8 * (x & 3))) & 0xFFu;
+        u32 const e = enc_base(static_cast<u8>(byte));
+        odd = odd || (e == 4u && byte != 'N' && static_cast<u64>(wd) * 8u + x < seq_bytes &&
+                      seq_base + static_cast<size_t>(wd) * 8u + x >= b.read_bases + b.read_off[b.read_win_off[w]]);
+        pk |= e << (4 * x);
+      }
+      l_seq[wd] = pk;
+    }
+    if (odd) l_seq_ok = 0;  // a base that is not A/C/G/T/N: the codes would not give its byte back
+    for (u32 sq = 1 + threadIdx.x; sq < ns_all; sq += kInsT) {  // sequence sq >= 1 is read read_win_off[w] + sq - 1
+      l_rpos[sq] = static_cast<u32>((b.read_bases + b.read_off[b.read_win_off[w] + sq - 1]) - seq_base);
+      l_ibase[sq] = ws.seq_inst_base[base_idx + sq];
+    }
+    __syncthreads();
+  }
+  bool const staged = l_seq_ok != 0;
   // map entry of an id (kNoNode: no room along this probe sequence -- then there never will be for this id)
   auto map_entry = [&](u64 id) -> u32 {
-    u32 e = static_cast<u32>(id >> 32) & (kInsMap - 1);
+    u32 e = static_cast<u32>(id >> 32) % kInsMap;
     for (u32 probe = 0; probe < 64; ++probe) {
       u64 cur = l_key[e];
       if (cur == 0) {
@@ -430,7 +498,7 @@ __global__ __launch_bounds__(kInsT) void k_insert(DBatch b, GraphWs ws) {
         cur = old == 0ull ? id : old;
       }
       if (cur == id) return e;
-      e = (e + 1) & (kInsMap - 1);
+      e = e + 1 == kInsMap ? 0u : e + 1;
     }
     return kNoNode;
   };
@@ -451,21 +519,51 @@ __global__ __launch_bounds__(kInsT) void k_insert(DBatch b, GraphWs ws) {
       }
     }
   }
-  for (u32 x = threadIdx.x; x < nq; x += kInsT) {  // (B) slow queue
-    u32 const item = slowq[x];
-    u32 const s_idx = item >> 12, o = item & 0xFFFu;
-    SeqInfo const si = seq_info(b, w, s_idx, k);
-    u32 const inst = ws.seq_inst_base[base_idx + s_idx] + o;
-    u32 const keep = inst_slot[inst] & (kInstErrFree | kInstLast);
-    bool plus;
-    u64 const id = kmer_id(b.read_bases + si.off + o, k, &plus);
-    u32 const e = map_entry(id);
-    if (e != kNoNode) {
-      atomicMin(&l_min[e], inst);
-      inst_slot[inst] = e | kInstTemp | (plus ? kInstPlus : 0u) | keep;
-    } else {
-      atomicAdd(&l_ndef, 1u);
-      inst_slot[inst] = kInstDefer | (plus ? kInstPlus : 0u) | keep;
+  // (B) slow queue.  Every instance is a chain of dependent HBM round trips (queue entry -> sequence record -> instance
+  // word -> k-mer bytes) and this pass was 73 % of the kernel with one instance in flight per thread: four independent
+  // chains per thread now, the LDS map only touched once all four ids are known.
+  constexpr int kIU = 4;
+  for (u32 x0 = threadIdx.x; x0 < nq; x0 += kInsT * kIU) {
+    u32 item[kIU], inst[kIU], keep[kIU];
+    u64 off[kIU], id[kIU];
+    bool live[kIU], plus[kIU];
+#pragma unroll
+    for (int u = 0; u < kIU; ++u) {
+      u32 const x = x0 + u * kInsT;
+      live[u] = x < nq;
+      item[u] = live[u] ? slowq[x] : 0u;
+    }
+#pragma unroll
+    for (int u = 0; u < kIU; ++u) {
+      u32 const s_idx = item[u] >> 12, o = item[u] & 0xFFFu;
+      if (staged) {  // (slow instances come from reads: s_idx >= 1)
+        inst[u] = live[u] ? l_ibase[s_idx] + o : 0u;
+        off[u] = live[u] ? l_rpos[s_idx] + o : 0u;  // position in l_seq
+      } else {
+        SeqInfo const si = seq_info(b, w, live[u] ? s_idx : 0u, k);
+        inst[u] = live[u] ? ws.seq_inst_base[base_idx + s_idx] + o : 0u;
+        off[u] = si.off + o;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < kIU; ++u) {
+      keep[u] = live[u] ? inst_slot[inst[u]] & (kInstErrFree | kInstLast) : 0u;
+      id[u] = 1;
+      plus[u] = true;
+      if (live[u])
+        id[u] = staged ? kmer_id_lds(l_seq, static_cast<u32>(off[u]), k, &plus[u]) : kmer_id(b.read_bases + off[u], k, &plus[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < kIU; ++u) {
+      if (!live[u]) continue;
+      u32 const e = map_entry(id[u]);
+      if (e != kNoNode) {
+        atomicMin(&l_min[e], inst[u]);
+        inst_slot[inst[u]] = e | kInstTemp | (plus[u] ? kInstPlus : 0u) | keep[u];
+      } else {
+        atomicAdd(&l_ndef, 1u);
+        inst_slot[inst[u]] = kInstDefer | (plus[u] ? kInstPlus : 0u) | keep[u];
+      }
     }
   }
   __syncthreads();
@@ -490,9 +588,10 @@ __global__ __launch_bounds__(kInsT) void k_insert(DBatch b, GraphWs ws) {
     u64 const id = l_key[e];
     if (id == 0) continue;
     u32 const slot = table_insert(keys, mask, id);
-    l_slot[e] = slot;
+    u32 const fi = l_min[e];
     if (slot == kNoNode) atomicOr(&ws.win_flags[w], 4u);  // table full (cannot happen with the capacity planning)
-    else first[slot] = l_min[e];  // plain store: ids of the map never take the direct path
+    else first[slot] = fi;  // plain store: ids of the map never take the direct path
+    l_min[e] = (slot == kNoNode ? 0x7FFFFFFFu : (slot & kInstSlotMask)) | (fi < rsi.nk ? 0x80000000u : 0u);
   }
   // deferred instances (ids without room in the map): the direct path, reference k-mers first
   bool const any_def = l_ndef != 0;
@@ -539,8 +638,8 @@ __global__ __launch_bounds__(kInsT) void k_insert(DBatch b, GraphWs ws) {
   for (u32 p = threadIdx.x; p < rsi.nk; p += kInsT) {
     u32 const word = inst_slot[p];
     if (!(word & kInstTemp)) continue;
-    u32 const slot = l_slot[word & (kInsMap - 1)];
-    u32 const fin = (slot == kNoNode ? 0u : (slot & kInstSlotMask)) | (word & (kInstPlus | kInstLast));
+    u32 const slot = l_min[word & kInsEntryMask] & 0x7FFFFFFFu;
+    u32 const fin = (slot == 0x7FFFFFFFu ? 0u : slot) | (word & (kInstPlus | kInstLast));
     inst_slot[p] = fin;
     ref_slot_g[p] = fin & kInstSlotMask;
   }
@@ -550,11 +649,10 @@ __global__ __launch_bounds__(kInsT) void k_insert(DBatch b, GraphWs ws) {
     u32 const inst = ws.seq_inst_base[base_idx + s_idx] + o;
     u32 const word = inst_slot[inst];
     if (!(word & kInstTemp)) continue;  // direct path: finished above
-    u32 const e = word & (kInsMap - 1);
-    u32 const slot = l_slot[e];
-    inst_slot[inst] = (slot == kNoNode ? 0u : (slot & kInstSlotMask)) | (word & (kInstPlus | kInstLast | kInstErrFree));
+    u32 const sv = l_min[word & kInsEntryMask], slot = sv & 0x7FFFFFFFu;
+    inst_slot[inst] = (slot == 0x7FFFFFFFu ? 0u : slot) | (word & (kInstPlus | kInstLast | kInstErrFree));
     // the k-mer is also a reference k-mer <=> the smallest instance of its id is a reference position
-    if ((word & kInstErrFree) && l_min[e] < rsi.nk) ws.rd_flag[b.read_win_off[w] + s_idx - 1] = 1;
+    if ((word & kInstErrFree) && (sv >> 31)) ws.rd_flag[b.read_win_off[w] + s_idx - 1] = 1;
   }
 }
 
@@ -1152,8 +1250,8 @@ __device__ __forceinline__ void edge_insert(GraphWs const& ws, size_t nb, u32 no
 // first -- key = src << 17 | dst << 2 | kind, value = smallest order key (first occurrence) -- and each of them
 // is then stored once, its slot taken from a per-node LDS counter.  k_edge_sort orders the slots by order key.
 constexpr int kEdT = 1024;
-constexpr u32 kEdgeSet = 16384;
-constexpr u32 kEdgeNodes = 16384;
+constexpr u32 kEdgeSet = 8192;    // 64 KB of keys + order keys and 8 KB of counters: TWO workgroups per CU (16 k entries made it
+constexpr u32 kEdgeNodes = 8192;  // one, and the lanes' copies of this kernel queued behind each other); fuller windows insert directly
 constexpr u32 kEdgeEmpty = 0xFFFFFFFFu;
 __global__ __launch_bounds__(kEdT) void k_edges(DBatch b, GraphWs ws) {
   __shared__ u32 l_key[kEdgeSet];
@@ -1185,7 +1283,7 @@ __global__ __launch_bounds__(kEdT) void k_edges(DBatch b, GraphWs ws) {
       l_fail = 1;
       return;
     }
-    u32 h = (key * 2654435761u) >> 18;  // kEdgeSet == 1 << 14
+    u32 h = (key * 2654435761u) >> 19;  // kEdgeSet == 1 << 13
     for (u32 probe = 0; probe < 256u; ++probe) {
       u32 cur = l_key[h];
       if (cur == kEdgeEmpty) {
