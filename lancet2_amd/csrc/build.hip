@@ -658,7 +658,8 @@ __global__ __launch_bounds__(kInsT) void k_insert(DBatch b, GraphWs ws) {
 
 // (3) k_support: read support of the FAST instances (node.cpp:18-24 + graph.h:102-117), one thread per group
 //     of adjacent reads with equal (qname, role, sample); per-reference-position counters live in LDS.
-__global__ __launch_bounds__(kBT) void k_support(DBatch b, GraphWs ws, u32* max_gen) {
+constexpr u32 kSupCache = 2048;  // reads per window whose records k_support keeps in LDS
+__global__ __launch_bounds__(kBT) void k_support(DBatch b, GraphWs ws, u32* max_gen, u32 cache_cap) {
   extern __shared__ unsigned char lds_build[];
   __shared__ u32 xs_flag;
   __shared__ u32 gen_count;  // instances routed through the general mate-mer set (sizes that set)
@@ -682,6 +683,15 @@ __global__ __launch_bounds__(kBT) void k_support(DBatch b, GraphWs ws, u32* max_
   u32* l_xgrp = reinterpret_cast<u32*>(lds_build + off);
   off += 4u * kXs;
   u8* l_xsmp = lds_build + off;
+  off = (off + kXs + 15u) & ~15u;
+  // Per-sequence records for the group loop below (it was 95 % of this kernel: every group re-read flags, names, samples,
+  // offsets, hints and instance bases of its reads from HBM, ten dependent round trips per group).
+  //   c_meta: flags (bits 0-2) | general-path-hit flag of k_insert (bit 3) | sample << 8 | k-mer count << 16
+  u32* c_meta = reinterpret_cast<u32*>(lds_build + off);
+  u32* c_qn = c_meta + cache_cap;
+  u32* c_ib = c_qn + cache_cap;
+  i32* c_hint = reinterpret_cast<i32*>(c_ib + cache_cap);
+  bool const cached = cache_cap != 0 && ns <= cache_cap;
   SeqInfo const rsi = seq_info(b, w, 0, k);
   for (u32 i = threadIdx.x; i < ws.ref_stride * CW; i += kBT) l_cnt[i] = 0;
   for (u32 i = threadIdx.x; i < kXs; i += kBT) {
@@ -691,6 +701,16 @@ __global__ __launch_bounds__(kBT) void k_support(DBatch b, GraphWs ws, u32* max_
   if (threadIdx.x == 0) {
     xs_flag = 0;
     gen_count = 0;
+  }
+  if (cached) {
+    for (u32 sx = 1 + threadIdx.x; sx < ns; sx += kBT) {
+      u32 const r = b.read_win_off[w] + sx - 1;
+      SeqInfo const si = seq_info(b, w, sx, k);
+      c_meta[sx] = (b.read_flags[r] & 7u) | (ws.rd_flag[r] ? 8u : 0u) | (static_cast<u32>(b.read_sample[r]) << 8) | (min(si.nk, 0xFFFFu) << 16);
+      c_qn[sx] = b.read_qname_id[r];
+      c_ib[sx] = ws.seq_inst_base[base_idx + sx];
+      c_hint[sx] = b.read_hint ? b.read_hint[r] : 0;
+    }
   }
   __syncthreads();
   bool const hints = b.read_hint != nullptr && rsi.len <= ws.max_ref_len + 8;
@@ -759,15 +779,29 @@ __global__ __launch_bounds__(kBT) void k_support(DBatch b, GraphWs ws, u32* max_
   __syncthreads();
   u32 const wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
   u32 wave_gen = 0;
+  // (sequence sa, sb of this window in one group: same_group() on the cached records)
+  auto same_group_c = [&](u32 sa, u32 sb) {
+    u32 const ma_ = c_meta[sa], mb = c_meta[sb];
+    return (mb & MA_RF_PASS) && c_qn[sa] == c_qn[sb] && ((ma_ ^ mb) & MA_RF_CASE) == 0 && ((ma_ ^ mb) & 0xFF00u) == 0;
+  };
   for (u32 gi = wave; gi < n_leaders; gi += kBT / 64) {
     u32 const s_idx = l_leaders[gi];
     u32 const r0 = b.read_win_off[w] + s_idx - 1;
     u32 gsize = 1;
-    while (s_idx + gsize < ns && same_group(b, r0, r0 + gsize)) gsize++;
+    if (cached) {
+      while (s_idx + gsize < ns && same_group_c(s_idx, s_idx + gsize)) gsize++;
+    } else {
+      while (s_idx + gsize < ns && same_group(b, r0, r0 + gsize)) gsize++;
+    }
     bool generic = all_generic || gsize > 2;
     for (u32 gm = 0; gm < gsize && !generic; ++gm) {
-      SeqInfo const si = seq_info(b, w, s_idx + gm, k);
-      if (ws.rd_flag[r0 + gm] || si.nk > 32u * kMaskWords) generic = true;
+      if (cached) {
+        u32 const mt = c_meta[s_idx + gm];
+        if ((mt & 8u) || (mt >> 16) > 32u * kMaskWords) generic = true;
+      } else {
+        SeqInfo const si = seq_info(b, w, s_idx + gm, k);
+        if (ws.rd_flag[r0 + gm] || si.nk > 32u * kMaskWords) generic = true;
+      }
     }
     i32 hint0 = 0;
     u32 nk0 = 0;
@@ -776,15 +810,28 @@ __global__ __launch_bounds__(kBT) void k_support(DBatch b, GraphWs ws, u32* max_
     for (int x = 0; x < kMaskWords / 2; ++x) m0[x] = 0;
     for (u32 gm = 0; gm < gsize; ++gm) {
       u32 const sx = s_idx + gm;
-      SeqInfo const si = seq_info(b, w, sx, k);
-      if (si.nk == 0) continue;
-      u32 const ibase = ws.seq_inst_base[base_idx + sx];
       u32 const r = r0 + gm;
-      u32 smp = b.read_sample[r];
+      SeqInfo si;
+      u32 ibase, smp, role;
+      i32 hint_r;
+      if (cached && (c_meta[sx] >> 16) != 0xFFFFu) {
+        u32 const mt = c_meta[sx];
+        si.nk = mt >> 16;
+        ibase = c_ib[sx];
+        smp = (mt >> 8) & 0xFFu;
+        role = (mt & MA_RF_CASE) ? 1u : 0u;
+        hint_r = c_hint[sx];
+      } else {
+        si = seq_info(b, w, sx, k);
+        ibase = ws.seq_inst_base[base_idx + sx];
+        smp = b.read_sample[r];
+        role = (b.read_flags[r] & MA_RF_CASE) ? 1u : 0u;
+        hint_r = hints ? b.read_hint[r] : 0;
+      }
+      if (si.nk == 0) continue;
       if (smp >= static_cast<u32>(S)) smp = S - 1;
-      u32 const role = (b.read_flags[r] & MA_RF_CASE) ? 1u : 0u;
       if (gm == 0) {
-        hint0 = hints ? b.read_hint[r] : 0;
+        hint0 = hints ? hint_r : 0;
         nk0 = si.nk;
       }
       for (u32 ob = 0; ob < si.nk; ob += 64) {
@@ -1420,13 +1467,16 @@ int run_build_pass(ma_ctx* ctx, const DBatch& b, GraphWs& ws, u32* counters_dev,
   ctx->tic("k_insert");
   hipLaunchKernelGGL(k_insert, dim3(ws.n_active), dim3(kInsT), 0, ctx->stream, b, ws);
   ctx->toc();
-  size_t const lds_s = 4ull * ws.ref_stride * (S + 2) + 4ull * std::max<size_t>(kMaskWords * kBT, ws.max_reads + 2) + 8ull * kXs + kXs + 64;
+  // + per-sequence cache (16 B per read of the busiest window, when that is at most kSupCache reads)
+  u32 const sup_cache = ws.max_reads + 2 <= kSupCache ? ws.max_reads + 2 : 0u;
+  size_t const lds_s = 4ull * ws.ref_stride * (S + 2) + 4ull * std::max<size_t>(kMaskWords * kBT, ws.max_reads + 2) + 8ull * kXs + kXs + 64 +
+                       16ull * sup_cache + 16;
   if (lds_s > 65536)
     MA_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_support), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     static_cast<int>(lds_s)));
   ctx->tic("k_support");
   MA_HIP(ctx, hipMemsetAsync(counters_dev + 1, 0, 8, ctx->stream));
-  hipLaunchKernelGGL(k_support, dim3(ws.n_active), dim3(kBT), lds_s, ctx->stream, b, ws, counters_dev + 1);
+  hipLaunchKernelGGL(k_support, dim3(ws.n_active), dim3(kBT), lds_s, ctx->stream, b, ws, counters_dev + 1, sup_cache);
   ctx->toc();
   // windows whose general instances fit an LDS set are finished by k_mm_lds; the HBM-resident set only has to
   // hold what the remaining windows routed to it (usually nothing)

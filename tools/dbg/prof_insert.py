@@ -15,8 +15,8 @@ eng.timing_control(1)
 eng.process(arrs, nw, nr)
 eng.lib.ma_debug_iprof(buf)
 d = [b - a for a, b in zip(base, list(buf))]
-names = ["init_map", "ref_kmers", "slow_queue", "table_init", "pass2_insert", "deferred", "pass3"]
-tot = sum(d[:7])
-print({k: round(v, 2) for k, v in eng.kernel_times() if k == "k_insert"})
+names = ["xs_checks", "leaders", "group_loop", "flush"]
+tot = sum(d[:4])
+print({k: round(v, 2) for k, v in eng.kernel_times() if k in ("k_insert", "k_support")})
 print({n: f"{100.0 * v / tot:.1f}%" for n, v in zip(names, d)})
 eng.close()
