@@ -15,8 +15,8 @@ eng.timing_control(1)
 eng.process(arrs, nw, nr)
 eng.lib.ma_debug_iprof(buf)
 d = [b - a for a, b in zip(base, list(buf))]
-names = ["xs_checks", "leaders", "group_loop", "flush"]
+names = ["stage", "unused", "setup+walk", "queue"]
 tot = sum(d[:4])
-print({k: round(v, 2) for k, v in eng.kernel_times() if k in ("k_insert", "k_support")})
+print({k: round(v, 2) for k, v in eng.kernel_times() if k in ("k_classify",)})
 print({n: f"{100.0 * v / tot:.1f}%" for n, v in zip(names, d)})
 eng.close()
