@@ -71,11 +71,13 @@ struct AlnWs {
   u64* pair_off;       // [n + 1]
   u32* counters;       // [8]: 0 max read len, 1 max reads per window, 2 entries in vote_wg
   u32* vote_wg;        // [n * MH] compact list of (window * MH + slot) to align against
+  u32* read_win;       // [n_reads] window of every read (k_read_planes writes it: no binary search per lane later)
   u32* read_planes;    // [n_reads][3][rwords] every read as three bit planes (k_read_planes), read by each haplotype's k_vote
   // haplotype seed index, per (window, slot)
   // per pair
   i32* centre;         // [pairs in chunk] first diagonal of the pair's region (vmin - K), or a sentinel
   u32* band_w;         // [pairs in chunk] width of the region in diagonals | key << 16
+  u32* pair_read;      // [pairs in chunk] DP pairs only: read index | haplotype slot << 27 (no binary search over pair_off later)
   u64* vote_aux;       // [pairs in chunk] wide pairs only: most-voted diagonal - region start | votes further than 8 / 16 / 24
                        //                  diagonals from it (saturating u16 each): k_align_wave's narrow first pass
   u32* dp_list;        // [pairs in chunk] pairs that need the DP (compacted by k_vote)
@@ -143,8 +145,10 @@ __global__ void k_plan(GArgs A) {
   u32 const nr = A.b.read_win_off[w + 1] - A.b.read_win_off[w];
   A.ws.pair_off[w] = static_cast<u64>(nr) * __popc(mask);  // counts; scanned below
   u32 ml = 0;
-  for (u32 r = A.b.read_win_off[w]; r < A.b.read_win_off[w + 1]; ++r)
+  for (u32 r = A.b.read_win_off[w]; r < A.b.read_win_off[w + 1]; ++r) {
     ml = max(ml, static_cast<u32>(A.b.read_off[r + 1] - A.b.read_off[r]));
+    A.ws.read_win[r] = static_cast<u32>(w);
+  }
   atomicMax(&A.ws.counters[0], ml);
   atomicMax(&A.ws.counters[1], nr);
 }
@@ -862,6 +866,7 @@ __device__ __forceinline__ void vote_pair(GArgs const& A, u64 lp, PairId id, Hap
                             (static_cast<u64>(min(vfar16, 65535u)) << 32) | (static_cast<u64>(min(vfar24, 65535u)) << 48);
       A.ws.centre[lp] = r_lo;
       A.ws.band_w[lp] = r_w | (key << 16);
+      A.ws.pair_read[lp] = id.r | (id.slot << 27);
       u32 const at = ix.dpbuf[64]++;
       ix.dpbuf[at] = static_cast<u32>(lp);
       ix.dpbuf[65 + at] = key;
@@ -968,7 +973,12 @@ __device__ __forceinline__ DpPair dp_pair_load(GArgs const& A, u32 li) {
   p.live = li < A.dp_n;
   if (!p.live) return p;
   u64 const lp = A.ws.dp_list[A.dp0 + li];
-  p.id = pair_decode(A, A.pair0 + lp);
+  {
+    u32 const pr = A.ws.pair_read[lp];
+    p.id.r = pr & 0x7FFFFFFu;
+    p.id.slot = pr >> 27;
+    p.id.w = static_cast<int>(A.ws.read_win[p.id.r]);
+  }
   size_t const hi = static_cast<size_t>(p.id.w) * A.prm.max_haps + p.id.slot;
   p.n = static_cast<i32>(A.a.hap_len[hi]);
   p.hb = A.a.hap_bases + hi * A.prm.max_hap_len;
@@ -1033,7 +1043,8 @@ __global__ __launch_bounds__(64) void k_align_wave(GArgs A, u32 nchunk_alloc) {
   u32 const pi = blockIdx.x;
   if (pi >= A.dp_n) return;
   u64 const lp = A.ws.dp_list[A.dp0 + pi];
-  PairId const id = pair_decode(A, A.pair0 + lp);
+  u32 const pr_ = A.ws.pair_read[lp];
+  PairId const id{static_cast<int>(A.ws.read_win[pr_ & 0x7FFFFFFu]), pr_ & 0x7FFFFFFu, pr_ >> 27};
   size_t const hidx = static_cast<size_t>(id.w) * A.prm.max_haps + id.slot;
   i32 const n = static_cast<i32>(A.a.hap_len[hidx]);
   const u8* hb = A.a.hap_bases + hidx * A.prm.max_hap_len;
@@ -1578,13 +1589,7 @@ __global__ __launch_bounds__(64) void k_assign(GArgs A) {
   if (r >= A.b.n_reads) return;
   ma_params_t const& P = A.prm;
   int const MH = P.max_haps, MV = P.max_vars, MA = P.max_alts, MCG = P.max_cigar, S = P.num_samples;
-  // window of this read
-  int lo = 0, hi = A.b.n_windows;
-  while (hi - lo > 1) {
-    int const mid = (lo + hi) / 2;
-    if (A.b.read_win_off[mid] <= r) lo = mid; else hi = mid;
-  }
-  int const w = lo;
+  int const w = static_cast<int>(A.ws.read_win[r]);  // (k_plan)
   u8* asg = A.ws.asg_allele + static_cast<size_t>(r) * MV;
   for (int v = 0; v < MV; ++v) asg[v] = 255;
   if (A.o.asg_allele)
@@ -1672,12 +1677,7 @@ __global__ __launch_bounds__(64) void k_evidence(GArgs A) {
   if (r >= A.b.n_reads) return;
   ma_params_t const& P = A.prm;
   int const MV = P.max_vars, NA = P.max_alts + 1, S = P.num_samples;
-  int lo = 0, hi = A.b.n_windows;
-  while (hi - lo > 1) {
-    int const mid = (lo + hi) / 2;
-    if (A.b.read_win_off[mid] <= r) lo = mid; else hi = mid;
-  }
-  int const w = lo;
+  int const w = static_cast<int>(A.ws.read_win[r]);
   u32 const nv = A.v.win_nvars[w];
   if (nv == 0) return;
   const u8* asg = A.ws.asg_allele + static_cast<size_t>(r) * MV;
@@ -1877,6 +1877,7 @@ int launch_genotype(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& a, const m
     ws.counters = reinterpret_cast<u32*>(take(64));
     ws.vote_wg = reinterpret_cast<u32*>(take(4ull * n * MH));
     ws.read_planes = reinterpret_cast<u32*>(take(4ull * NR * plane_stride(rwords_all) + 256));
+    ws.read_win = reinterpret_cast<u32*>(take(4ull * NR + 64));
     ws.ev_key = reinterpret_cast<u64*>(take(8ull * n * ws.ev_cap));
     ws.ev_min = reinterpret_cast<u32*>(take(4ull * n * ws.ev_cap));
     ws.asg_allele = reinterpret_cast<u8*>(take(NR * MV + 16));
@@ -1925,16 +1926,17 @@ int launch_genotype(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& a, const m
     size_t budget = std::max<size_t>(size_t(1) << 30, stage_budget(0.15, ctx->ws_misc.cap, size_t(8) << 30, ctx->hbm_share));
     if (const char* e = getenv("MA_TB_GB")) budget = static_cast<size_t>(atoi(e)) << 30;
     // vote chunks: bounded only by the 24 B / pair of region + DP lists (and 32-bit local pair ids)
-    u64 const pairs_chunk = std::min<u64>(total_pairs, std::min<u64>(u64(1) << 30, budget / 4 / 24));
-    size_t const tb_bytes = budget - pairs_chunk * 24;
+    u64 const pairs_chunk = std::min<u64>(total_pairs, std::min<u64>(u64(1) << 30, budget / 4 / 28));
+    size_t const tb_bytes = budget - pairs_chunk * 28;
     MA_HIP(ctx, ctx->ws_misc.reserve(std::min<size_t>(tb_bytes, std::max<size_t>(size_t(256) << 20, static_cast<size_t>((pairs_chunk + 63) / 64) *
                                                                                                     ws.tb_rows * 17 * 256)) +
-                                     (pairs_chunk + 64) * 24 + 8192));
+                                     (pairs_chunk + 64) * 28 + 8192));
     // bytes available for traceback tiles; the per-pair arrays (and their atomics) start 256-byte aligned behind them
-    size_t const tb_cap = (ctx->ws_misc.cap - ((pairs_chunk + 64) * 24 + 8192)) & ~size_t(255);
+    size_t const tb_cap = (ctx->ws_misc.cap - ((pairs_chunk + 64) * 28 + 8192)) & ~size_t(255);
     ws.tb = ctx->ws_misc.as<u32>();
     ws.vote_aux = reinterpret_cast<u64*>(reinterpret_cast<char*>(ctx->ws_misc.p) + tb_cap);
     ws.centre = reinterpret_cast<i32*>(ws.vote_aux + pairs_chunk + 16);
+    ws.pair_read = reinterpret_cast<u32*>(ws.centre) + 4 * (pairs_chunk + 16) + 256;  // behind centre / band_w / dp_list / dp_count+sorted
     ws.band_w = reinterpret_cast<u32*>(ws.centre + pairs_chunk + 16);
     ws.dp_list = ws.band_w + pairs_chunk + 16;
     ws.dp_count = ws.dp_list + pairs_chunk + 16;
