@@ -33,7 +33,7 @@ def make_pair(rng, case):
     if case == "str":  # tandem repeat inside the haplotype: seeds on many diagonals
         unit = rand_dna(rng, int(rng.integers(1, 7)))
         rep = (unit * 80)[: int(rng.integers(30, 90))]
-        p = int(rng.integers(100, n - 200))
+        p = int(rng.integers(100, max(n - 200, 101)))
         hap = hap[:p] + rep + hap[p + len(rep):]
     start = int(rng.integers(0, n - m))
     if case == "left":
