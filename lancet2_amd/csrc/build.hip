@@ -435,7 +435,8 @@ constexpr int kInsT = 1024;
 constexpr u32 kInsMap = 6144;         // LDS map entries (48 KB of ids + 24 KB of first instances: two workgroups per CU)
 constexpr u32 kInsEntryMask = 8191;   // an instance word carries its map entry in 13 bits
 constexpr u32 kSeqWords = 12288;      // the window's read bases as 4-bit codes in LDS: 48 KB = 98 304 bases
-constexpr u32 kInstTemp = 1u << 26;   // instance word holds a map entry, not yet a table slot (slots are < 2^21)
+constexpr u32 kInstTemp = 1u << 26;   // instance word holds a map entry, not yet a table slot (slots are < 2^21);
+                                      // gone from the final words, k_rank reuses the bit as kInstFirst
 constexpr u32 kInstDefer = 1u << 25;  // instance waits for the direct path
 __global__ __launch_bounds__(kInsT) void k_insert(DBatch b, GraphWs ws) {
   __shared__ u64 l_key[kInsMap];
@@ -1175,10 +1176,11 @@ __global__ __launch_bounds__(kBT) void k_rank(DBatch b, GraphWs ws, u32 min_node
   u32* first = ws.tbl_first + (static_cast<size_t>(a) << ws.tc_log2);
   u32* slot_node = ws.slot_node + (static_cast<size_t>(a) << ws.tc_log2);
   const u32* cnt = ws.tbl_cnt + (static_cast<size_t>(a) << ws.tc_log2) * CW;
-  const u32* inst_slot = ws.inst_slot + static_cast<size_t>(a) * ws.inst_stride;
+  u32* inst_slot = ws.inst_slot + static_cast<size_t>(a) * ws.inst_stride;
   size_t const nb = static_cast<size_t>(a) * ws.nc;
 
-  // 1. survivor flag into bit 31 of tbl_first (set = pruned / empty)
+  // 1. survivor flag into bit 31 of tbl_first (set = pruned / empty); a survivor marks its first instance word, so
+  //    that step 2 streams the instance words instead of gathering tbl_first once per instance
   for (u32 s = threadIdx.x; s < tcap; s += kBT) {
     slot_node[s] = kNoNode;
     if (keys[s] == 0) {
@@ -1194,7 +1196,10 @@ __global__ __launch_bounds__(kBT) void k_rank(DBatch b, GraphWs ws, u32 min_node
       all &= c <= 1;
     }
     bool const remove = (any && all) || total < min_node_cov;  // node.cpp:38-42, graph.cpp:374-378
-    if (remove) first[s] |= 0x80000000u;
+    if (remove)
+      first[s] |= 0x80000000u;
+    else
+      inst_slot[first[s]] |= kInstFirst;  // (one slot per instance: no other thread touches this word)
   }
   __syncthreads();
 
@@ -1219,7 +1224,7 @@ __global__ __launch_bounds__(kBT) void k_rank(DBatch b, GraphWs ws, u32 min_node
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       u32 const ii = ii0 + j, v = vv[j];
-      if (ii < ninst && !(v & kInstFast) && first[v & kInstSlotMask] == ii) fmask |= 1u << j;
+      if (ii < ninst && !(v & kInstFast) && (v & kInstFirst)) fmask |= 1u << j;
     }
     u32 const mine = __popc(fmask);
     u32 inc = mine;

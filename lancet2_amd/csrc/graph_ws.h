@@ -23,7 +23,8 @@ constexpr u32 kInstPlus = 1u << 30;
 constexpr u32 kInstFast = 1u << 29;
 constexpr u32 kInstGen = 1u << 28;
 constexpr u32 kInstLast = 1u << 27;
-constexpr u32 kInstSlotMask = (1u << 27) - 1;
+constexpr u32 kInstFirst = 1u << 26;  // set by k_rank: first instance of a node that survives low-coverage pruning
+constexpr u32 kInstSlotMask = (1u << 26) - 1;
 constexpr int kMaxSamples = 8;
 
 struct GraphWs {
@@ -55,7 +56,7 @@ struct GraphWs {
   u32* mm_min;
   // compact graph (per active slot, NC nodes)
   u32 nc;                 // node capacity per window
-  u32* slot_node;         // [a][TC] slot -> node idx (kNoNode if pruned)   (aliases tbl_first after ranking)
+  u32* slot_node;         // [a][TC] slot -> node idx (kNoNode if pruned) 
   u32* n_nodes;           // [a]
   u32* nd_cnt;            // [a][NC][S]
   u32* nd_role;           // [a][NC][2]

@@ -1,7 +1,7 @@
 """Developer tool: per-phase cycle breakdown of k_vote / k_msa from a -DMA_PROFILE build.
 
   make -C lancet2_amd/csrc clean && make -C lancet2_amd/csrc HIPFLAGS_EXTRA=-DMA_PROFILE LIB=../libmicroasm_prof.so
-  python tools/prof_phases.py [n_windows]
+  python tools/prof_phases.py [n_windows [bench]]
 
 Not part of the product path or the tests.
 """
@@ -15,9 +15,14 @@ from lancet2_amd import engine as E  # noqa: E402
 
 capi.LIB_PATH = os.path.join(capi.REPO, "lancet2_amd", "libmicroasm_prof.so")
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 512
-arrs, nw, nr = synth.make_config_batch("C3", 64)
-arrs, nw, nr = synth.tile_batch(arrs, nw, nr, n // 64)
+if len(sys.argv) > 2 and sys.argv[2] == "bench":  # the bench workload: n distinct windows, every 8th with a tandem repeat
+    import bench
+    arrs, nw, nr = bench.make_windows("C3", n, 10_000, 8, 8)
+else:
+    arrs, nw, nr = synth.make_config_batch("C3", 64)
+    arrs, nw, nr = synth.tile_batch(arrs, nw, nr, n // 64)
 eng = E.Engine(capi.default_params(min_k=25, max_k=25))
+eng.set_streams(1)
 eng.process(arrs, nw, nr)
 buf = (C.c_ulonglong * 16)()
 for sym, names in (("ma_debug_cprof", ["init", "components", "anchors", "compress1", "lowcov", "compress2", "tips", "trav_index", "cycle+cx", "maxflow", "emit", "merges_fast", "merges_generic"]), ("ma_debug_vprof", ["encode", "vote", "argmax", "second", "clear", "mismatch", "emit", "pairs", "shortcut", "shortcut_hits", "shortcut_miss", "x11", "x12", "x13", "wave_total"]),
