@@ -8,49 +8,68 @@
 // where L_d(m) is the longest run on diagonal d with <= m mismatches.  One pass over the W^2/2
 // byte pairs therefore answers the gate for every k of the cascade at once.
 //
-// Mapping: one 256-thread workgroup per window; the window (<= 8 KB) is staged in LDS; lane t walks
-// diagonals t+1, t+257, ...  (a wave's 64 lanes walk 64 adjacent diagonals, so the LDS reads are a
-// broadcast of s[p] plus 64 consecutive bytes).  State per lane: the positions of the last 4
-// mismatches.  HBM traffic: W bytes in, 8 bytes out per window.
+// Mapping: one 256-thread workgroup per window; the window (<= 8 KB) is staged in LDS FOUR times, copy c shifted by
+// c bytes, so that the four bytes s[p + d .. p + d + 3] of any diagonal d are ONE aligned word of copy (d & 3); lane t
+// walks diagonals t+1, t+257, ... four positions per iteration (one broadcast word of s[p ..], one word of the
+// shifted copy, xor, four byte tests).  State per lane: the positions of the last MM + 1 mismatches.  HBM traffic:
+// W bytes in, 8 bytes out per window.
 #include "ma_internal.h"
 
 namespace ma {
 
 constexpr int kGateThreads = 256;
 constexpr int kGateMaxW = 8192;
+constexpr int kGateCopy = kGateMaxW + 64;  // bytes per shifted copy (a multiple of 4)
 
+template <int MM>
 __global__ __launch_bounds__(kGateThreads) void gate_kernel(const u8* __restrict__ ref,
                                                             const u32* __restrict__ ref_off, int n_windows,
-                                                            int mm, u32* __restrict__ out_approx,
+                                                            u32* __restrict__ out_approx,
                                                             u32* __restrict__ out_exact) {
-  __shared__ u8 s[kGateMaxW + 64];
+  __shared__ u32 s4[4 * kGateCopy / 4];
   __shared__ u32 red[2];
+  u8* const s = reinterpret_cast<u8*>(s4);
   int const w = blockIdx.x;
   if (w >= n_windows) return;
   u32 const beg = ref_off[w];
   int const W = min(static_cast<int>(ref_off[w + 1] - beg), kGateMaxW);
-  for (int i = threadIdx.x; i < W; i += kGateThreads) s[i] = ref[beg + i];
+  // copy c, byte q = base q + c (the last len % 4 positions of a diagonal are walked byte by byte: no padding is read)
+  for (int i = threadIdx.x; i < W; i += kGateThreads) {
+    u8 const v = ref[beg + i];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+      if (i >= c) s[c * kGateCopy + i - c] = v;
+  }
   if (threadIdx.x < 2) red[threadIdx.x] = 0;
   __syncthreads();
 
   int best_m = 0, best_0 = 0;
   for (int d = 1 + static_cast<int>(threadIdx.x); d < W; d += kGateThreads) {
     int const len = W - d;
-    // positions of the most recent mismatches on this diagonal: m0 newest ... m3 oldest
-    int m0 = -1, m1 = -1, m2 = -1, m3 = -1;
-    for (int p = 0; p < len; ++p) {
-      bool const x = s[p] != s[p + d];
+    // positions of the most recent mismatches on this diagonal: m[0] newest ... m[MM] oldest kept
+    int m[MM + 1];
+#pragma unroll
+    for (int x = 0; x <= MM; ++x) m[x] = -1;
+    auto step = [&](int p, bool x) {
       if (x) {
-        m3 = m2;
-        m2 = m1;
-        m1 = m0;
-        m0 = p;
+#pragma unroll
+        for (int y = MM; y > 0; --y) m[y] = m[y - 1];
+        m[0] = p;
       }
-      // longest window ending at p with <= mm mismatches starts after the (mm+1)-th newest one
-      int const lim = mm == 0 ? m0 : (mm == 1 ? m1 : (mm == 2 ? m2 : m3));
-      best_m = max(best_m, p - lim);
-      best_0 = max(best_0, p - m0);
+      // longest window ending at p with <= MM mismatches starts after the (MM+1)-th newest one
+      best_m = max(best_m, p - m[MM]);
+      best_0 = max(best_0, p - m[0]);
+    };
+    const u32* const shifted = s4 + (d & 3) * (kGateCopy / 4) + (d >> 2);  // word q of it = s[4 q + d ..]
+    int p = 0;
+    for (; p + 4 <= len; p += 4) {
+      u32 const x = s4[p >> 2] ^ shifted[p >> 2];
+      step(p, (x & 0xFFu) != 0);
+      step(p + 1, (x & 0xFF00u) != 0);
+      step(p + 2, (x & 0xFF0000u) != 0);
+      step(p + 3, (x & 0xFF000000u) != 0);
     }
+    for (; p < len; ++p) step(p, s[p] != s[p + d]);
   }
   atomicMax(&red[0], static_cast<u32>(best_m));
   atomicMax(&red[1], static_cast<u32>(best_0));
@@ -64,8 +83,10 @@ __global__ __launch_bounds__(kGateThreads) void gate_kernel(const u8* __restrict
 int launch_gate(ma_ctx* ctx, const DBatch& b, u32* max_approx, u32* max_exact) {
   if (b.n_windows == 0) return MA_OK;
   ctx->tic("gate_kernel");
-  hipLaunchKernelGGL(gate_kernel, dim3(b.n_windows), dim3(kGateThreads), 0, ctx->stream, b.ref_bases,
-                     b.ref_off, b.n_windows, ctx->prm.max_mismatch, max_approx, max_exact);
+  int const mm = ctx->prm.max_mismatch;  // (0..3: checked by ma_create)
+  auto kern = mm == 0 ? gate_kernel<0> : (mm == 1 ? gate_kernel<1> : (mm == 2 ? gate_kernel<2> : gate_kernel<3>));
+  hipLaunchKernelGGL(kern, dim3(b.n_windows), dim3(kGateThreads), 0, ctx->stream, b.ref_bases, b.ref_off, b.n_windows,
+                     max_approx, max_exact);
   ctx->toc();
   MA_HIP(ctx, hipGetLastError());
   return MA_OK;

@@ -809,15 +809,28 @@ __device__ void poa_fill(GL const& g, PoaWs const& ws, u16* codes, i32* rows, i3
 // of four columns, usually one lane every four rows) the register rows slide with it: a whole-wave DPP shift;
 // the columns that fall off the left edge are exits, the ones that enter start at minus infinity.
 __device__ __forceinline__ i32 wave_shl1(i32 x, i32 fill) { return dpp_mov<0x130, 0xF>(x, fill); }  // lane l <- lane l + 1
+// the same, IN PLACE (the result is tied to x's own register, lane 63 is patched afterwards): written the other way the
+// compiler gives the shifted rows new registers and pays 28 copies on every row that does NOT slide
+__device__ __forceinline__ void wave_shl1_inplace(i32& x, i32 fill, bool last_lane) {
+  x = __builtin_amdgcn_update_dpp(x, x, 0x130, 0xF, 0xF, false);
+  x = last_lane ? fill : x;
+}
+__device__ __forceinline__ void wave_shr1_inplace(i32& x, i32 fill, bool first_lane) {  // lane l <- lane l - 1
+  x = __builtin_amdgcn_update_dpp(x, x, 0x138, 0xF, 0xF, false);
+  x = first_lane ? fill : x;
+}
 
 template <class G>
 __device__ void poa_fill_band(G const& g, PoaWs const& ws, u16* codes, i32* rows, i32* hlast, u32 V, u32 L, int lane,
                               const u8* seq, i32* edge_out) {
   constexpr int CW = 4;
   constexpr i32 NEG = kScanIdent;
-  i32 H1[CW], F1[CW], O1[CW], H2[CW], F2[CW], O2[CW];
+  i32 jr[CW];  // this lane's columns relative to the window
 #pragma unroll
-  for (int c = 0; c < CW; ++c) H1[c] = F1[c] = O1[c] = H2[c] = F2[c] = O2[c] = kNegInf;
+  for (int c = 0; c < CW; ++c) jr[c] = 4 * lane + c;
+  i32 HA[CW], FA[CW], OA[CW], HB[CW], FB[CW], OB[CW];  // the two previous rows, roles alternating (see `row`)
+#pragma unroll
+  for (int c = 0; c < CW; ++c) HA[c] = FA[c] = OA[c] = HB[c] = FB[c] = OB[c] = kNegInf;
   u32 sc[CW];
   i32 edge = kNegInf;
   u32 info = g.rowinfo[1];
@@ -842,7 +855,11 @@ __device__ void poa_fill_band(G const& g, PoaWs const& ws, u16* codes, i32* rows
     }
   };
   load_sc_in();
-  for (u32 i = 1; i <= V; ++i) {
+  // one row: (H1, F1, O1) is row i - 1, (H2, F2, O2) row i - 2 -- which row i then OVERWRITES: the caller swaps the two
+  // register sets from row to row instead of rotating them (24 copies a row, and as many again where the compiler
+  // split the rotation across the loop edge)
+  auto row = [&](u32 const i, i32(&H1)[CW], i32(&F1)[CW], i32(&O1)[CW], i32(&H2)[CW], i32(&F2)[CW], i32(&O2)[CW])
+                 __attribute__((always_inline)) {
     u32 const nch = info & 0xFFu, np = (info >> 8) & 7u;
     bool const fast = info & RI_FAST, store = info & RI_STORE;
     u32 const info_cur = info;
@@ -854,7 +871,7 @@ __device__ void poa_fill_band(G const& g, PoaWs const& ws, u16* codes, i32* rows
       j0n = g.rowj0[i + 1];
     }
     // ---- slide the register rows to this row's window ----
-    if (j0_new != j0) {
+    if (__builtin_expect(j0_new != j0, 0)) {  // (one row in four: the register copies belong on this side)
       i32 const sh = (static_cast<i32>(j0_new) - static_cast<i32>(j0)) / 4;  // lanes; > 0: window moves right
       // columns that fall off: they had no successor inside the band
       {
@@ -866,36 +883,43 @@ __device__ void poa_fill_band(G const& g, PoaWs const& ws, u16* codes, i32* rows
             if (jbo + c >= 1 && jbo + c <= L) edge = max(edge, max(H1[c], H2[c]));
         }
       }
-      if (sh == 1) {
+      // one lane at a time, every register IN PLACE (almost always a single step to the right); a second code path
+      // that builds the shifted rows in new registers costs two dozen copies on every row that does not slide
+      while (j0 < j0_new) {
 #pragma unroll
         for (int c = 0; c < CW; ++c) {
-          H1[c] = wave_shl1(H1[c], kNegInf);
-          F1[c] = wave_shl1(F1[c], kNegInf);
-          O1[c] = wave_shl1(O1[c], kNegInf);
-          H2[c] = wave_shl1(H2[c], kNegInf);
-          F2[c] = wave_shl1(F2[c], kNegInf);
-          O2[c] = wave_shl1(O2[c], kNegInf);
-          sc[c] = static_cast<u32>(wave_shl1(static_cast<i32>(sc[c]), static_cast<i32>(sc_in[c])));
+          wave_shl1_inplace(H1[c], kNegInf, lane == 63);
+          wave_shl1_inplace(F1[c], kNegInf, lane == 63);
+          wave_shl1_inplace(O1[c], kNegInf, lane == 63);
+          wave_shl1_inplace(H2[c], kNegInf, lane == 63);
+          wave_shl1_inplace(F2[c], kNegInf, lane == 63);
+          wave_shl1_inplace(O2[c], kNegInf, lane == 63);
+          i32 t = static_cast<i32>(sc[c]);
+          wave_shl1_inplace(t, static_cast<i32>(sc_in[c]), lane == 63);
+          sc[c] = static_cast<u32>(t);
         }
-        j0 = j0_new;
-      } else {
-        int const src = lane + sh;
-        bool const in = src >= 0 && src < 64;
-#pragma unroll
-        for (int c = 0; c < CW; ++c) {
-          i32 const h1 = __shfl(H1[c], src & 63), f1 = __shfl(F1[c], src & 63), o1 = __shfl(O1[c], src & 63);
-          i32 const h2 = __shfl(H2[c], src & 63), f2 = __shfl(F2[c], src & 63), o2 = __shfl(O2[c], src & 63);
-          H1[c] = in ? h1 : kNegInf;
-          F1[c] = in ? f1 : kNegInf;
-          O1[c] = in ? o1 : kNegInf;
-          H2[c] = in ? h2 : kNegInf;
-          F2[c] = in ? f2 : kNegInf;
-          O2[c] = in ? o2 : kNegInf;
-        }
-        j0 = j0_new;
-        load_sc();
+        j0 += 4;
+        load_sc_in();
       }
-      load_sc_in();
+      if (j0 > j0_new) {  // rare: the backbone coordinate steps back
+        do {
+          j0 -= 4;
+#pragma unroll
+          for (int c = 0; c < CW; ++c) {
+            wave_shr1_inplace(H1[c], kNegInf, lane == 0);
+            wave_shr1_inplace(F1[c], kNegInf, lane == 0);
+            wave_shr1_inplace(O1[c], kNegInf, lane == 0);
+            wave_shr1_inplace(H2[c], kNegInf, lane == 0);
+            wave_shr1_inplace(F2[c], kNegInf, lane == 0);
+            wave_shr1_inplace(O2[c], kNegInf, lane == 0);
+            u32 const j = j0 + c;
+            i32 t = static_cast<i32>(sc[c]);
+            wave_shr1_inplace(t, (j >= 1 && j <= L) ? static_cast<i32>(seq[j - 1]) : 0, lane == 0);
+            sc[c] = static_cast<u32>(t);
+          }
+        } while (j0 > j0_new);
+        load_sc_in();
+      }
     }
     u32 const jb = j0 + 4u * lane;
     // ---- vertical + diagonal part ----
@@ -1015,30 +1039,43 @@ __device__ void poa_fill_band(G const& g, PoaWs const& ws, u16* codes, i32* rows
     // column 0 of this row is an exit when the window does not start at column 1
     if (j0 > 1) edge = max(edge, h0);
     // ---- prefix maxima over the window (column 0 enters through lane 0 when the window starts at column 1) ----
-    i32 run1 = (j0 == 1 && lane == 0) ? h0 : NEG, run2 = run1;
+    // (columns beyond L are filled like any other: a cell only feeds cells to its right and below, so what they hold
+    //  never reaches a column <= L; nothing reads them.  Column indices are taken RELATIVE to the window, jr = j - j0:
+    //  the same maxima up to a per-row constant that cancels below, and jr is a loop invariant of the lane)
+    bool const col0 = j0 == 1 && lane == 0;  // column 0 (jr = -1) enters through lane 0
+    i32 run1 = col0 ? h0 - 1 : NEG, run2 = col0 ? h0 - 2 : NEG;
+    i32 a1r[CW], a2r[CW];
 #pragma unroll
     for (int c = 0; c < CW; ++c) {
-      bool const in = jb + c <= L;
       i32 const m = max(hmv[c], max(ff[c], oo[c]));
       hh[c] = m;
-      i32 const j = static_cast<i32>(jb) + c;
-      run1 = max(run1, in ? m + j : NEG);
-      run2 = max(run2, in ? m + 2 * j : NEG);
+      a1r[c] = m + jr[c];
+      a2r[c] = a1r[c] + jr[c];
+      run1 = max(run1, a1r[c]);
+      run2 = max(run2, a2r[c]);
     }
     i32 const inc1 = wave_incl_max(run1, NEG), inc2 = wave_incl_max(run2, NEG);
     i32 s1 = wave_shr1(inc1, NEG), s2 = wave_shr1(inc2, NEG);
-    if (j0 == 1 && lane == 0) s1 = s2 = h0;
+    if (col0) {
+      s1 = h0 - 1;
+      s2 = h0 - 2;
+    }
     i32 ee[CW], qq[CW];
+    // nothing to the left of the first window column when it is not column 1 (lane 0, c == 0 only: from the second
+    // column on the running maxima hold the lane's own cells)
+    bool const have_left = s1 > -(1 << 28);
 #pragma unroll
     for (int c = 0; c < CW; ++c) {
-      i32 const j = static_cast<i32>(jb) + c;
-      bool const in = jb + c <= L;
-      bool const have_left = s1 > -(1 << 28);  // false only for the first window column when it is not column 1
-      i32 const q = have_left ? s1 + Q_ - (j - 1) : kNegInf;
-      i32 const e = have_left ? max(s2 + G_ - 2 * (j - 1), s1 + Q_ + G_ - (j - 2)) : kNegInf;
+      // (s1 + Q - (j - 1) and max(s2 + G - 2 (j - 1), s1 + Q + G - (j - 2)) of the absolute form)
+      i32 q = s1 + (Q_ + 1 - jr[c]);
+      i32 e = max(s2 + (G_ + 2 - 2 * jr[c]), q + (G_ + 1));
+      if (c == 0) {
+        q = have_left ? q : kNegInf;
+        e = have_left ? e : kNegInf;
+      }
       i32 const m = hh[c];
-      s1 = max(s1, in ? m + j : NEG);
-      s2 = max(s2, in ? m + 2 * j : NEG);
+      s1 = max(s1, a1r[c]);
+      s2 = max(s2, a2r[c]);
       ee[c] = e;
       qq[c] = q;
       hh[c] = max(m, max(e, q));
@@ -1140,16 +1177,6 @@ __device__ void poa_fill_band(G const& g, PoaWs const& ws, u16* codes, i32* rows
     }
     // right exit of this row: the last window column when the haplotype goes on beyond it
     if (lane == 63 && jb + 3 < L) edge = max(edge, hh[3]);
-    // rotate the register rows
-#pragma unroll
-    for (int c = 0; c < CW; ++c) {
-      H2[c] = H1[c];
-      F2[c] = F1[c];
-      O2[c] = O1[c];
-      H1[c] = hh[c];
-      F1[c] = ff[c];
-      O1[c] = oo[c];
-    }
     *reinterpret_cast<uint2*>(codes + static_cast<size_t>(i) * 256 + 4u * lane) =
         make_uint2(cd[0] | (cd[1] << 16), cd[2] | (cd[3] << 16));
     if (store) {
@@ -1169,6 +1196,17 @@ __device__ void poa_fill_band(G const& g, PoaWs const& ws, u16* codes, i32* rows
     } else if (lane == 0 && !(L >= j0 && L <= j0 + 255)) {
       hlast[i] = kNegInf;
     }
+    // row i takes the place of row i - 2
+#pragma unroll
+    for (int c = 0; c < CW; ++c) {
+      H2[c] = hh[c];
+      F2[c] = ff[c];
+      O2[c] = oo[c];
+    }
+  };
+  for (u32 i = 1; i <= V; i += 2) {
+    row(i, HA, FA, OA, HB, FB, OB);
+    if (i + 1 <= V) row(i + 1, HB, FB, OB, HA, FA, OA);
   }
   for (int off = 32; off > 0; off >>= 1) edge = max(edge, __shfl_xor(edge, off));
   if (lane == 0) *edge_out = edge;
