@@ -13,7 +13,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from lancet2_amd import capi, synth  # noqa: E402
 from lancet2_amd import engine as E  # noqa: E402
 
-capi.LIB_PATH = os.path.join(capi.REPO, "lancet2_amd", "libmicroasm_prof.so")
+capi.LIB_PATH = os.path.join(capi.REPO, "lancet2_amd", os.environ.get("MA_PROF_LIB", "libmicroasm_prof.so"))
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 if len(sys.argv) > 2 and sys.argv[2] == "bench":  # the bench workload: n distinct windows, every 8th with a tandem repeat
     import bench
