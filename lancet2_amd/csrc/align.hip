@@ -323,7 +323,7 @@ __device__ __forceinline__ void vote_flush_dp(GArgs const& A, HapIdx ix, int lan
   if (lane == 0) ix.dpbuf[64] = 0;
   __builtin_amdgcn_wave_barrier();
 }
-__device__ __forceinline__ void vote_pair(GArgs const& A, u64 lp, PairId id, HapIdx ix, u16* hist, int lane, i32 m, u32 pre);
+__device__ __forceinline__ void vote_pair(GArgs const& A, u64 lp, PairId id, HapIdx ix, u16* hist, int lane, i32 m, u32 pre, i32 hint, i32 n);
 
 __global__ __launch_bounds__(256) void k_vote(GArgs A, u32 hist_len, u32 rwords, u32 ml_eff) {
   extern __shared__ u32 lds_vote[];
@@ -483,15 +483,25 @@ __global__ __launch_bounds__(256) void k_vote(GArgs A, u32 hist_len, u32 rwords,
   auto fetch = [&](u32 ri) -> u32 {
     return static_cast<u32>(lane) < npw ? A.ws.read_planes[static_cast<size_t>(r0 + ri) * plane_stride(rwords) + lane] : 0u;
   };
+  // (and its mapping hint: a load per pair that the shortcut would otherwise wait for first thing)
+  bool const hinted = A.b.read_hint != nullptr;
   u32 cur = 0, nxt = 0;
-  if (static_cast<u32>(wave) < nr) cur = fetch(wave);
+  i32 hcur = MA_NO_HINT, hnxt = MA_NO_HINT;
+  if (static_cast<u32>(wave) < nr) {
+    cur = fetch(wave);
+    if (hinted) hcur = A.b.read_hint[r0 + wave];
+  }
   for (u32 ri = wave; ri < nr; ri += 4) {
-    if (ri + 4 < nr) nxt = fetch(ri + 4);
+    if (ri + 4 < nr) {
+      nxt = fetch(ri + 4);
+      if (hinted) hnxt = A.b.read_hint[r0 + ri + 4];
+    }
     u64 const p = p0 + ri;
     if (p >= A.pair0 && p < A.pair0 + A.npairs)
       vote_pair(A, p - A.pair0, PairId{w, r0 + ri, static_cast<u32>(slot)}, ix, hist, lane,
-                static_cast<i32>(l_roff[ri + 1] - l_roff[ri]), cur);
+                static_cast<i32>(l_roff[ri + 1] - l_roff[ri]), cur, hcur, static_cast<i32>(n));
     cur = nxt;
+    hcur = hnxt;
   }
   vote_flush_dp(A, ix, lane);
 #ifdef MA_PROFILE
@@ -507,10 +517,8 @@ __device__ __forceinline__ void write_no_hit(GArgs const& A, PairId id) {
   A.o.aln_rec[(static_cast<size_t>(id.r) * A.prm.max_haps + id.slot) * 6] = 0;
 }
 
-__device__ __forceinline__ void vote_pair(GArgs const& A, u64 lp, PairId id, HapIdx ix, u16* hist, int lane, i32 m, u32 pre) {
-  size_t const hi = static_cast<size_t>(id.w) * A.prm.max_haps + id.slot;
-  i32 const n = static_cast<i32>(A.a.hap_len[hi]);
-  i32 const nd = m + n + 1;  // diagonals d in [-m, n] -> hist[d + m]
+__device__ __forceinline__ void vote_pair(GArgs const& A, u64 lp, PairId id, HapIdx ix, u16* hist, int lane, i32 m, u32 pre, i32 hint, i32 n) {
+  i32 const nd = m + n + 1;  // (n = the haplotype's length, held by the caller)  // diagonals d in [-m, n] -> hist[d + m]
   i32 const Kr = m - A.prm.min_aln_score - GO > 0 ? (m - A.prm.min_aln_score - GO) / GE : 0;  // reach K of the search region
   const u16* head = ix.head;
   const u16* next = ix.next;
@@ -531,8 +539,7 @@ __device__ __forceinline__ void vote_pair(GArgs const& A, u64 lp, PairId id, Hap
   // optimum.  c itself holds >= m - 10 - 11 X >= 4 votes, so it is an anchor and P0 lies in the search region.  A wrong
   // or missing hint only means that no candidate passes and the pair takes the general route: results never depend on it.
   if (ix.cand[0] > 0 && !ix.hap_amb && m >= SK && m <= 2048) {
-    i32 const hint = A.b.read_hint[id.r];
-    if (hint != MA_NO_HINT) {
+    if (hint != MA_NO_HINT) {  // (A.b.read_hint[id.r], fetched by the caller a read ahead)
       for (int x = 0; x < ix.cand[0]; ++x) {
         i32 const c = hint - ix.cand[1] + ix.cand[2 + x];
         if (c < 0 || c + m > n) continue;
@@ -1284,23 +1291,24 @@ constexpr i32 NEGR = -20000;
 // DP list sorted by key = class * 2 + wall (order inside a key never affects a result: every pair is independent)
 struct KeyBase { u32 b[kNumKeys]; };
 __global__ __launch_bounds__(256) void k_dp_scatter(GArgs A, u32 ndp, u32* out, u32* fill, KeyBase kb) {
-  u32 const li = blockIdx.x * 256u + threadIdx.x, lane = threadIdx.x & 63u;
+  // one global atomic per key and WORKGROUP, all keys at once: the pairs take their places inside the workgroup's
+  // share through LDS counters (a returning global atomic per key and wavefront, one key after the other, kept this
+  // kernel waiting on a handful of contended addresses for its whole life)
+  __shared__ u32 l_cnt[kNumKeys], l_base[kNumKeys];
+  u32 const li = blockIdx.x * 256u + threadIdx.x;
   bool const live = li < ndp;
-  u32 lp = 0, key = 0xFFFFFFFFu;
+  if (threadIdx.x < kNumKeys) l_cnt[threadIdx.x] = 0;
+  __syncthreads();
+  u32 lp = 0, key = 0, pos = 0;
   if (live) {
     lp = A.ws.dp_list[li];
     key = A.ws.band_w[lp] >> 16;
+    pos = atomicAdd(&l_cnt[key], 1u);
   }
-  unsigned long long const below = (1ull << lane) - 1ull;
-  for (unsigned long long todo = __ballot(live); todo;) {
-    u32 const k0 = __shfl(key, __builtin_ctzll(todo));
-    unsigned long long const same = __ballot(key == k0);
-    u32 at = 0;
-    if (lane == static_cast<u32>(__builtin_ctzll(same))) at = atomicAdd(&fill[k0], static_cast<u32>(__popcll(same)));
-    at = __shfl(at, __builtin_ctzll(same));
-    if (key == k0) out[kb.b[k0] + at + static_cast<u32>(__popcll(same & below))] = lp;
-    todo &= ~same;
-  }
+  __syncthreads();
+  if (threadIdx.x < kNumKeys && l_cnt[threadIdx.x]) l_base[threadIdx.x] = atomicAdd(&fill[threadIdx.x], l_cnt[threadIdx.x]);
+  __syncthreads();
+  if (live) out[kb.b[key] + l_base[key] + pos] = lp;
 }
 
 // waves per SIMD the register allocator is asked to keep (it otherwise spends registers on scheduling freedom)

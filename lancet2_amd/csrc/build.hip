@@ -53,21 +53,28 @@ __device__ __forceinline__ SeqInfo seq_info(const DBatch& b, int w, u32 s, int k
   return si;
 }
 
-// block-wide exclusive scan helper over a small per-thread value
+// block-wide exclusive scan helper over a small per-thread value: wave scans by shuffles, wave totals through LDS
+// (two barriers; sh holds at least kBT / 64 words)
 __device__ __forceinline__ u32 block_excl_scan(u32 v, u32* sh, u32* total) {
-  int const t = threadIdx.x;
-  sh[t] = v;
-  __syncthreads();
-  for (int d = 1; d < kBT; d <<= 1) {
-    u32 x = t >= d ? sh[t - d] : 0;
-    __syncthreads();
-    sh[t] += x;
-    __syncthreads();
+  int const t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  u32 inc = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    u32 const y = __shfl_up(inc, d);
+    if (lane >= d) inc += y;
   }
-  u32 const incl = sh[t];
-  *total = sh[kBT - 1];
+  if (lane == 63) sh[wave] = inc;
   __syncthreads();
-  return incl - v;
+  u32 before = 0, tot = 0;
+#pragma unroll
+  for (int x = 0; x < kBT / 64; ++x) {
+    u32 const c = sh[x];
+    before += x < wave ? c : 0u;
+    tot += c;
+  }
+  *total = tot;
+  __syncthreads();
+  return before + inc - v;
 }
 
 // ---- per-k instance bookkeeping: seq_inst_base + totals, over ALL windows of the chunk ----
@@ -1215,10 +1222,13 @@ __global__ __launch_bounds__(kBT) void k_rank(DBatch b, GraphWs ws, u32 min_node
   u64 const win_read_off0 = b.read_off[b.read_win_off[w]];
   int const lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   u32 running = 0;
+  uint4 const none4 = make_uint4(kInstFast, kInstFast, kInstFast, kInstFast);
+  // (the next tile's words are in flight while this tile is scanned: the pass is a chain of load -> block scan otherwise)
+  uint4 nxt4 = 4 * threadIdx.x < ninst ? *reinterpret_cast<const uint4*>(inst_slot + 4 * threadIdx.x) : none4;
   for (u32 tile0 = 0; tile0 < ninst; tile0 += 4 * kBT) {
     u32 const ii0 = tile0 + 4 * threadIdx.x;
-    uint4 v4 = make_uint4(kInstFast, kInstFast, kInstFast, kInstFast);
-    if (ii0 < ninst) v4 = *reinterpret_cast<const uint4*>(inst_slot + ii0);  // inst_stride is a multiple of 64 words
+    uint4 const v4 = nxt4;  // inst_stride is a multiple of 64 words
+    if (ii0 + 4 * kBT < ninst) nxt4 = *reinterpret_cast<const uint4*>(inst_slot + ii0 + 4 * kBT); else nxt4 = none4;
     u32 const vv[4] = {v4.x, v4.y, v4.z, v4.w};
     u32 fmask = 0;
 #pragma unroll
