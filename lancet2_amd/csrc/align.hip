@@ -325,6 +325,9 @@ __device__ __forceinline__ void vote_flush_dp(GArgs const& A, HapIdx ix, int lan
 }
 __device__ __forceinline__ void vote_pair(GArgs const& A, u64 lp, PairId id, HapIdx ix, u16* hist, int lane, i32 m, u32 pre, i32 hint, i32 n);
 
+#ifndef MA_VOTE_PF
+#define MA_VOTE_PF 2
+#endif
 __global__ __launch_bounds__(256) void k_vote(GArgs A, u32 hist_len, u32 rwords, u32 ml_eff) {
   extern __shared__ u32 lds_vote[];
   u32 const item = A.ws.vote_wg[blockIdx.x];
@@ -485,23 +488,31 @@ __global__ __launch_bounds__(256) void k_vote(GArgs A, u32 hist_len, u32 rwords,
   };
   // (and its mapping hint: a load per pair that the shortcut would otherwise wait for first thing)
   bool const hinted = A.b.read_hint != nullptr;
-  u32 cur = 0, nxt = 0;
-  i32 hcur = MA_NO_HINT, hnxt = MA_NO_HINT;
-  if (static_cast<u32>(wave) < nr) {
-    cur = fetch(wave);
-    if (hinted) hcur = A.b.read_hint[r0 + wave];
+  // kPF reads ahead: a pair that takes the shortcut is done in well under one memory latency
+  constexpr u32 kPF = MA_VOTE_PF;
+  u32 pf[kPF];
+  i32 hf[kPF];
+#pragma unroll
+  for (u32 x = 0; x < kPF; ++x) {
+    u32 const ri = wave + 4u * x;
+    pf[x] = ri < nr ? fetch(ri) : 0u;
+    hf[x] = (hinted && ri < nr) ? A.b.read_hint[r0 + ri] : MA_NO_HINT;
   }
   for (u32 ri = wave; ri < nr; ri += 4) {
-    if (ri + 4 < nr) {
-      nxt = fetch(ri + 4);
-      if (hinted) hnxt = A.b.read_hint[r0 + ri + 4];
-    }
+    u32 const ra = ri + 4u * kPF;
+    u32 const pn = ra < nr ? fetch(ra) : 0u;
+    i32 const hn = (hinted && ra < nr) ? A.b.read_hint[r0 + ra] : MA_NO_HINT;
     u64 const p = p0 + ri;
     if (p >= A.pair0 && p < A.pair0 + A.npairs)
       vote_pair(A, p - A.pair0, PairId{w, r0 + ri, static_cast<u32>(slot)}, ix, hist, lane,
-                static_cast<i32>(l_roff[ri + 1] - l_roff[ri]), cur, hcur, static_cast<i32>(n));
-    cur = nxt;
-    hcur = hnxt;
+                static_cast<i32>(l_roff[ri + 1] - l_roff[ri]), pf[0], hf[0], static_cast<i32>(n));
+#pragma unroll
+    for (u32 x = 0; x + 1 < kPF; ++x) {
+      pf[x] = pf[x + 1];
+      hf[x] = hf[x + 1];
+    }
+    pf[kPF - 1] = pn;
+    hf[kPF - 1] = hn;
   }
   vote_flush_dp(A, ix, lane);
 #ifdef MA_PROFILE
