@@ -83,7 +83,9 @@ typedef struct ma_params {
 void ma_default_params(ma_params_t* p);
 
 /* One batch of windows.  Window w owns reference bytes [ref_off[w], ref_off[w+1]) and reads
- * [read_win_off[w], read_win_off[w+1]); read r owns bases/quals [read_off[r], read_off[r+1]). */
+ * [read_win_off[w], read_win_off[w+1]); read r owns bases/quals [read_off[r], read_off[r+1]).
+ * Limits: windows up to 8192 bases (repeat gate), reads up to 608 bases (ma_genotype_batch answers MA_ERR_PARAM
+ * beyond: short-read data only, like the reference's 150 bp workloads). */
 typedef struct ma_batch {
   int32_t n_windows;
   int64_t n_reads;

@@ -328,7 +328,10 @@ __device__ __forceinline__ void vote_pair(GArgs const& A, u64 lp, PairId id, Hap
 #ifndef MA_VOTE_PF
 #define MA_VOTE_PF 2
 #endif
-__global__ __launch_bounds__(256) void k_vote(GArgs A, u32 hist_len, u32 rwords, u32 ml_eff) {
+// waves per SIMD the registers are held to (96 VGPRs): five workgroups per CU, as many as their LDS allows -- the
+// kernel spends most of its life waiting for LDS and memory, one more resident workgroup in four is worth 13 % (a sixth,
+// bought with a half-size seed index, costs more in longer bucket chains than it hides)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_vote(GArgs A, u32 hist_len, u32 rwords, u32 ml_eff) {
   extern __shared__ u32 lds_vote[];
   u32 const item = A.ws.vote_wg[blockIdx.x];
   int const w = item / A.prm.max_haps, slot = item % A.prm.max_haps;
@@ -1876,6 +1879,11 @@ int launch_genotype(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& a, const m
     MA_HIP(ctx, ma_stream_sync(ctx));
     u32 const mr = mr2[0];
     rwords_all = (mr2[1] + 31) / 32 + 2;
+    if (3u * rwords_all > 64u) {  // k_vote / k_align_*: one wavefront lane per word of a read's three bit planes
+      ctx->err = "ma_genotype_batch: reads longer than 608 bases are not supported (longest read of the batch: " +
+                 std::to_string(mr2[1]) + ")";
+      return MA_ERR_PARAM;
+    }
     u64 want = static_cast<u64>(mr) * 8 + 1024;
     u32 cap = 8192;
     while (cap < want && cap < (1u << 24)) cap <<= 1;

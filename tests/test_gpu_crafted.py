@@ -104,3 +104,16 @@ def test_capacity_overflow_is_retried_inside_the_library(env, cfg, kw, monkeypat
     assert not (a["win_status"] & capi.MA_W_TABLE_OVERFLOW).any()
     bad = compare_asm(params, a, wa, n) + compare_vars(params, v, wv, n)
     assert not bad, "\n".join(bad[:10])
+
+
+def test_reads_beyond_the_aligner_limit_are_refused():
+    """reads longer than 608 bases: an error code with a message, never a silently truncated alignment"""
+    from lancet2_amd.engine import Engine, EngineError
+    params = capi.default_params(min_k=25, max_k=25)
+    arrs, n, nr = synth.make_config_batch("C2", 1, first_index=424_300, read_len=700, depths=(12, 12))
+    eng = Engine(params)
+    try:
+        with pytest.raises(EngineError, match="608"):
+            eng.process(arrs, n, nr)
+    finally:
+        eng.close()
