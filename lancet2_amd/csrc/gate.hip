@@ -8,7 +8,7 @@
 // where L_d(m) is the longest run on diagonal d with <= m mismatches.  One pass over the W^2/2
 // byte pairs therefore answers the gate for every k of the cascade at once.
 //
-// Mapping: one 256-thread workgroup per window; the window (<= 8 KB) is staged in LDS FOUR times, copy c shifted by
+// Mapping: one 256-thread workgroup per window; the window is staged in LDS FOUR times, copy c shifted by
 // c bytes, so that the four bytes s[p + d .. p + d + 3] of any diagonal d are ONE aligned word of copy (d & 3); lane t
 // walks diagonals t+1, t+257, ... four positions per iteration (one broadcast word of s[p ..], one word of the
 // shifted copy, xor, four byte tests).  State per lane: the positions of the last MM + 1 mismatches.  HBM traffic:
@@ -19,26 +19,35 @@ namespace ma {
 
 constexpr int kGateThreads = 256;
 constexpr int kGateMaxW = 8192;
-constexpr int kGateCopy = kGateMaxW + 64;  // bytes per shifted copy (a multiple of 4)
+constexpr int kGateFastW = 2560;                 // windows up to here (the reference CLI's -w tops out at 2500) get the copies
+constexpr int kGateCopy = kGateFastW + 64;       // bytes per shifted copy (a multiple of 4)
+constexpr int kGateLds = 4 * kGateCopy;          // >= kGateMaxW + 64: a longer window fits once, unshifted
 
 template <int MM>
 __global__ __launch_bounds__(kGateThreads) void gate_kernel(const u8* __restrict__ ref,
                                                             const u32* __restrict__ ref_off, int n_windows,
                                                             u32* __restrict__ out_approx,
                                                             u32* __restrict__ out_exact) {
-  __shared__ u32 s4[4 * kGateCopy / 4];
+  // 10 KB instead of four copies of the longest window the kernel accepts (33 KB): eight workgroups per CU, not four
+  static_assert(kGateLds >= kGateMaxW + 64, "the unshifted window must fit");
+  __shared__ u32 s4[kGateLds / 4];
   __shared__ u32 red[2];
   u8* const s = reinterpret_cast<u8*>(s4);
   int const w = blockIdx.x;
   if (w >= n_windows) return;
   u32 const beg = ref_off[w];
   int const W = min(static_cast<int>(ref_off[w + 1] - beg), kGateMaxW);
+  bool const fast = W <= kGateFastW;
   // copy c, byte q = base q + c (the last len % 4 positions of a diagonal are walked byte by byte: no padding is read)
   for (int i = threadIdx.x; i < W; i += kGateThreads) {
     u8 const v = ref[beg + i];
+    if (fast) {
 #pragma unroll
-    for (int c = 0; c < 4; ++c)
-      if (i >= c) s[c * kGateCopy + i - c] = v;
+      for (int c = 0; c < 4; ++c)
+        if (i >= c) s[c * kGateCopy + i - c] = v;
+    } else {
+      s[i] = v;
+    }
   }
   if (threadIdx.x < 2) red[threadIdx.x] = 0;
   __syncthreads();
@@ -60,14 +69,16 @@ __global__ __launch_bounds__(kGateThreads) void gate_kernel(const u8* __restrict
       best_m = max(best_m, p - m[MM]);
       best_0 = max(best_0, p - m[0]);
     };
-    const u32* const shifted = s4 + (d & 3) * (kGateCopy / 4) + (d >> 2);  // word q of it = s[4 q + d ..]
     int p = 0;
-    for (; p + 4 <= len; p += 4) {
-      u32 const x = s4[p >> 2] ^ shifted[p >> 2];
-      step(p, (x & 0xFFu) != 0);
-      step(p + 1, (x & 0xFF00u) != 0);
-      step(p + 2, (x & 0xFF0000u) != 0);
-      step(p + 3, (x & 0xFF000000u) != 0);
+    if (fast) {
+      const u32* const shifted = s4 + (d & 3) * (kGateCopy / 4) + (d >> 2);  // word q of it = s[4 q + d ..]
+      for (; p + 4 <= len; p += 4) {
+        u32 const x = s4[p >> 2] ^ shifted[p >> 2];
+        step(p, (x & 0xFFu) != 0);
+        step(p + 1, (x & 0xFF00u) != 0);
+        step(p + 2, (x & 0xFF0000u) != 0);
+        step(p + 3, (x & 0xFF000000u) != 0);
+      }
     }
     for (; p < len; ++p) step(p, s[p] != s[p + d]);
   }

@@ -54,6 +54,34 @@ def test_repeat_gate_parity_random(engine):
     assert np.array_equal(got["max_exact"], want["max_exact"])
 
 
+@pytest.mark.parametrize("mm", [0, 1, 2, 3])
+def test_repeat_gate_parity_window_lengths(mm):
+    """window lengths around the kernel's word loop (len % 4), its shifted-copy limit (2560) and its maximum (8192),
+    with planted approximate repeats, for every mismatch budget"""
+    from lancet2_amd.engine import Engine
+    rng = np.random.default_rng(77 + mm)
+    wins = []
+    for W in (5, 6, 7, 8, 97, 1001, 2499, 2560, 2561, 3001, 8192):
+        ref = synth.BASES[rng.integers(0, 4, W)].copy()
+        if W > 200:  # an approximate repeat of 60 bases with `mm` substitutions, far apart
+            src, dst = 10, W - 80
+            ref[dst:dst + 60] = ref[src:src + 60]
+            for x in rng.choice(60, size=mm, replace=False):
+                ref[dst + x] = ord("A") if ref[dst + x] != ord("A") else ord("C")
+        wins.append(dict(ref=ref, reads=[]))
+    arrs, n, nr = synth.pack_batch(wins)
+    params = capi.default_params(max_mismatch=mm)
+    want = OracleEngine(params).gate(arrs, n, nr)
+    eng = Engine(params)
+    try:
+        got = eng.gate(arrs, n, nr)
+    finally:
+        eng.close()
+    assert np.array_equal(got["max_approx"], want["max_approx"]), (got["max_approx"], want["max_approx"])
+    assert np.array_equal(got["max_exact"], want["max_exact"])
+    assert int(want["max_approx"][-1]) >= 60
+
+
 from harness import compare_asm  # noqa: E402
 
 
