@@ -74,7 +74,7 @@ struct PoaWs {
 
 // All per-window state lives in the kernel's dynamic LDS and is addressed as offsets into the
 // __shared__ array (NOT through generic pointers kept in a struct: those compile to flat_load).
-extern __shared__ unsigned char ma_lds[];
+extern __shared__ __attribute__((aligned(16))) unsigned char ma_lds[];
 template <class T>
 struct LdsArr {
   u32 off;  // byte offset into ma_lds
@@ -1497,7 +1497,19 @@ __global__ __launch_bounds__(kT, 2) void k_msa(MsaArgs A) {
   bool resume = false;
   if (A.round > 0) {
     if (reinterpret_cast<const WgState*>(img)->done) return;
-    for (u32 i = tid; i < ws.img_words; i += kT) reinterpret_cast<u32*>(ma_lds)[i] = img[i];
+    {  // 16 bytes per thread and load, four loads in flight (img_words is a multiple of 64, the image 256-byte aligned)
+      const uint4* src = reinterpret_cast<const uint4*>(img);
+      uint4* dst = reinterpret_cast<uint4*>(ma_lds);
+      u32 const nq = ws.img_words / 4u;
+      for (u32 i0 = tid; i0 < nq; i0 += 4u * kT) {
+        uint4 v[4];
+#pragma unroll
+        for (u32 u = 0; u < 4; ++u) v[u] = i0 + u * kT < nq ? src[i0 + u * kT] : make_uint4(0, 0, 0, 0);
+#pragma unroll
+        for (u32 u = 0; u < 4; ++u)
+          if (i0 + u * kT < nq) dst[i0 + u * kT] = v[u];
+      }
+    }
     __syncthreads();
     resume = true;
   }
@@ -2132,7 +2144,12 @@ __global__ __launch_bounds__(kT, 2) void k_msa(MsaArgs A) {
   }
   if (yielded) {  // save the LDS block; the next launch of this kernel resumes from it
     __syncthreads();
-    for (u32 i = tid; i < ws.img_words; i += kT) img[i] = reinterpret_cast<const u32*>(ma_lds)[i];
+    {
+      uint4* dst = reinterpret_cast<uint4*>(img);
+      const uint4* src = reinterpret_cast<const uint4*>(ma_lds);
+      u32 const nq = ws.img_words / 4u;
+      for (u32 i = tid; i < nq; i += kT) dst[i] = src[i];
+    }
     return;
   }
   if (tid == 0) {
