@@ -61,6 +61,7 @@ struct PoaWs {
   u32 w_stride;      // i32 per stored row and matrix
   u32 row_slots;     // stored rows per window
   u32 use_band;      // try the 256-column banded fill first (see launch_msa: MA_POA_BAND)
+  u32 no_direct;     // MA_POA_NO_DIRECT: every alignment goes through a fill (tests: the shortcut changes nothing)
   size_t code_cells; // u16 per window
   size_t row_cells;  // i32 per window
   u16* codes;
@@ -1605,6 +1606,29 @@ __global__ __launch_bounds__(kT, 2) void k_msa(MsaArgs A) {
       }
       // ---- mode 2: align the haplotype to the graph ----
       u32 const V = ST.V, cw = ST.cw;
+      // The graph is still the component's first sequence (a linear chain in rank order) and the haplotype is that
+      // sequence with at most TWO substitutions.  For every prefix pair (i, i) the diagonal scores -6 per substitution,
+      // >= -12, and any other path to (i, i) has a vertical and a horizontal gap, <= -12: H(i, i) is the diagonal's score,
+      // so every diagonal cell passes the backtrack's FIRST test (H == H(diagonal predecessor) + score) and SPOA retraces
+      // exactly the diagonal from the only end cell, ties or not.  The alignment is written down without a fill (three
+      // substitutions could lose to a mismatch-free path with two unit gaps: those take the DP).  About 30 % of all
+      // alignments on the bench workload.
+      bool direct = false;
+      if (!rh && ST.nseq == 1 && L == V && !ws.no_direct) {
+        u32 mism = 0;
+        for (u32 i = tid; i < L; i += kT) mism += g.nchar[g.rank2node[i]] != seq[i];
+        u32 total = 0;
+        (void)block_excl_scan(mism, tid, total);
+        direct = total <= 2;
+        if (direct) {
+          for (u32 k = tid; k < L; k += kT) {  // the path as the traceback stores it: end first, (node + 1, column)
+            g.aln[2 * k] = static_cast<u16>(g.rank2node[V - 1 - k] + 1u);
+            g.aln[2 * k + 1] = static_cast<u16>(L - k);
+          }
+          if (tid == 0) ST.naln = L;
+        }
+      }
+      if (!direct) {
       if (!rh) {
       // per-row descriptors; which rows must be kept in HBM
       for (u32 i = tid; i <= V + 1; i += kT) g.rowslot[i] = 0;
@@ -1787,6 +1811,7 @@ __global__ __launch_bounds__(kT, 2) void k_msa(MsaArgs A) {
         if (band_now && tid == 0) atomicAdd(&g_prof[13], 1ull);
 #endif
       }
+      }  // !direct
       __syncthreads();
       PROF_ACC(2);
       if (ST.overflow) continue;
@@ -2291,6 +2316,7 @@ int launch_msa(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& a, const ma_var
   int const band_mode = getenv("MA_POA_BAND") ? atoi(getenv("MA_POA_BAND")) : 2;
   ws.use_band = band_mode != 0 ? 1u : 0u;
   ws.split = band_mode == 2 ? 1u : 0u;
+  ws.no_direct = getenv("MA_POA_NO_DIRECT") ? 1u : 0u;
   ws.img_words = static_cast<u32>((lds + 3) / 4);
   ws.code_cells = (static_cast<size_t>(pn + 2) * (max_len + 16) + 7) & ~size_t(7);
   if (ws.code_cells * 2 < static_cast<size_t>(P.max_haps) * (2 * max_len + 8) + 64)  // raw-allele scratch lives in the codes
