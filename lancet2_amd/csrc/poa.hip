@@ -404,6 +404,17 @@ __device__ u32 block_excl_scan_max(u32 v, int tid) {
   return ex;
 }
 
+// block-wide minimum of one value per thread (two barriers)
+__device__ u32 block_min(u32 v, int tid) {
+  int const lane = tid & 63, wave = tid >> 6;
+  for (int off = 32; off > 0; off >>= 1) v = min(v, static_cast<u32>(__shfl_xor(v, off)));
+  if (lane == 0) ST.wsum[wave] = v;
+  __syncthreads();
+  u32 const r = min(min(ST.wsum[0], ST.wsum[1]), min(ST.wsum[2], ST.wsum[3]));
+  __syncthreads();
+  return r;
+}
+
 // ---- wave-wide prefix maximum with DPP (no LDS traffic) ----
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ i32 dpp_mov(i32 x, i32 ident) {
@@ -1606,26 +1617,72 @@ __global__ __launch_bounds__(kT, 2) void k_msa(MsaArgs A) {
       }
       // ---- mode 2: align the haplotype to the graph ----
       u32 const V = ST.V, cw = ST.cw;
-      // The graph is still the component's first sequence (a linear chain in rank order) and the haplotype is that
-      // sequence with at most TWO substitutions.  For every prefix pair (i, i) the diagonal scores -6 per substitution,
-      // >= -12, and any other path to (i, i) has a vertical and a horizontal gap, <= -12: H(i, i) is the diagonal's score,
-      // so every diagonal cell passes the backtrack's FIRST test (H == H(diagonal predecessor) + score) and SPOA retraces
-      // exactly the diagonal from the only end cell, ties or not.  The alignment is written down without a fill (three
-      // substitutions could lose to a mismatch-free path with two unit gaps: those take the DP).  About 30 % of all
-      // alignments on the bench workload.
+      // ---- alignments that need no fill: the graph is still the component's first sequence R (a linear chain in rank
+      //      order, V nodes), the haplotype Q (L bases) is R with at most two substitutions, or with ONE indel and nothing else.
+      // (a) L == V, <= 2 substitutions.  For every prefix pair (i, i) the diagonal scores -6 per substitution, >= -12, and
+      //     any other path to (i, i) has a vertical and a horizontal gap, <= -12: H(i, i) is the diagonal's score, so every
+      //     diagonal cell passes the backtrack's FIRST test (H == H(diagonal predecessor) + score) and SPOA retraces exactly
+      //     the diagonal from the only end cell, ties or not.  (Three substitutions could lose to a mismatch-free path with
+      //     two unit gaps: those take the DP.)
+      // (b) |V - L| = l > 0 and common prefix + common suffix >= min(V, L): Q is R with one insertion / deletion of l bases
+      //     at any place a in [min - lcs, lcp].  g(l) = max(G + (l-1) E, Q + (l-1) C) is the best score of ANY cell pair
+      //     whose lengths differ by l (gap costs are superadditive, substitutions cost), and it is reached by every prefix
+      //     pair on the shifted diagonal that has a valid place a' <= its length: from the end cell the first test passes
+      //     (match, H equal) down to the LEFTMOST place a_min = max(0, min - lcs); there it fails (a base mismatch, by
+      //     minimality, and no neighbour scores above g(l)), the cell's only optimal entry is the gap (a path entering it
+      //     the other way needs l + 1 and 1 gap bases), the gap run's extension flags hold for exactly its l cells (opening
+      //     anywhere but after the exact prefix, H = 0, costs a second gap), and the exact prefix is retraced diagonally.
+      //     So SPOA's backtrack yields: shifted diagonal, the l gap cells at a_min, main diagonal -- written down here.
+      // About half of all alignments on the bench workload.  MA_POA_NO_DIRECT sends them through the fill (tests).
       bool direct = false;
-      if (!rh && ST.nseq == 1 && L == V && !ws.no_direct) {
-        u32 mism = 0;
-        for (u32 i = tid; i < L; i += kT) mism += g.nchar[g.rank2node[i]] != seq[i];
-        u32 total = 0;
-        (void)block_excl_scan(mism, tid, total);
-        direct = total <= 2;
-        if (direct) {
-          for (u32 k = tid; k < L; k += kT) {  // the path as the traceback stores it: end first, (node + 1, column)
-            g.aln[2 * k] = static_cast<u16>(g.rank2node[V - 1 - k] + 1u);
-            g.aln[2 * k + 1] = static_cast<u16>(L - k);
+      if (!rh && ST.nseq == 1 && !ws.no_direct && L > 0 && V > 0) {
+        u32 const m = min(L, V);
+        if (L == V) {
+          u32 mism = 0;
+          for (u32 i = tid; i < L; i += kT) mism += g.nchar[g.rank2node[i]] != seq[i];
+          u32 total = 0;
+          (void)block_excl_scan(mism, tid, total);
+          direct = total <= 2;
+          if (direct) {
+            for (u32 k = tid; k < L; k += kT) {  // the path as the traceback stores it: end first, (node + 1, column)
+              g.aln[2 * k] = static_cast<u16>(g.rank2node[V - 1 - k] + 1u);
+              g.aln[2 * k + 1] = static_cast<u16>(L - k);
+            }
+            if (tid == 0) ST.naln = L;
           }
-          if (tid == 0) ST.naln = L;
+        } else {
+          u32 p1 = m, s1 = m;  // first mismatch from the front / from the back
+          for (u32 i = tid; i < m; i += kT) {
+            if (g.nchar[g.rank2node[i]] != seq[i]) p1 = min(p1, i);
+            if (g.nchar[g.rank2node[V - 1 - i]] != seq[L - 1 - i]) s1 = min(s1, i);
+          }
+          u32 const lcp = block_min(p1, tid), lcs = block_min(s1, tid);
+          direct = lcp + lcs >= m;
+          if (direct) {
+            u32 const gl = L > V ? L - V : V - L;
+            u32 const a0 = m > lcs ? m - lcs : 0u;  // leftmost place of the indel
+            u32 const nd = m - a0;                    // cells on the shifted diagonal
+            bool const del = V > L;                   // graph nodes without a base: vertical gap
+            u32 const total = nd + gl + a0;
+            for (u32 k = tid; k < total; k += kT) {
+              u32 node1, col;
+              if (k < nd) {
+                node1 = g.rank2node[V - 1 - k] + 1u;
+                col = L - k;
+              } else if (k < nd + gl) {
+                u32 const t = k - nd;  // t-th gap cell from the end
+                node1 = del ? g.rank2node[a0 + gl - 1 - t] + 1u : 0u;
+                col = del ? 0u : a0 + gl - t;
+              } else {
+                u32 const t = k - nd - gl;
+                node1 = g.rank2node[a0 - 1 - t] + 1u;
+                col = a0 - t;
+              }
+              g.aln[2 * k] = static_cast<u16>(node1);
+              g.aln[2 * k + 1] = static_cast<u16>(col);
+            }
+            if (tid == 0) ST.naln = total;
+          }
         }
       }
       if (!direct) {

@@ -174,31 +174,42 @@ def test_msa_parity_fill_modes(cfg, nwin, kw, band_mode, monkeypatch):
 
 
 @pytest.mark.parametrize("no_direct", [False, True])
-def test_msa_parity_single_substitution_haplotypes(no_direct, monkeypatch):
-    """A first haplotype that is the reference haplotype with one or two substitutions is aligned without a DP fill
-    (SPOA's backtrack retraces the diagonal, poa.hip); with MA_POA_NO_DIRECT it takes the fill like any other: same
-    bits, and the batch really holds such haplotypes (and others)."""
+@pytest.mark.parametrize("kw,need", [(dict(indel_rate=6e-4), (2, 2, 2)),
+                                     (dict(str_unit=b"A", indel_rate=4e-4), (2, 4, 2))])  # homopolymers: the indel slides
+def test_msa_parity_haplotypes_aligned_without_a_fill(kw, need, no_direct, monkeypatch):
+    """A first haplotype that is the reference haplotype with one or two substitutions, or with one indel and nothing
+    else, is aligned without a DP fill (SPOA's backtrack is known in closed form, poa.hip); with MA_POA_NO_DIRECT it takes
+    the fill like any other: same bits, and the batch really holds such haplotypes of each kind (and others)."""
     from lancet2_amd.engine import Engine
     if no_direct:
         monkeypatch.setenv("MA_POA_NO_DIRECT", "1")
     params = capi.default_params(min_k=25, max_k=25)
-    arrs, n, nr = synth.make_config_batch("C2", 16, first_index=4100)
+    arrs, n, nr = synth.make_config_batch("C2", 24, first_index=4100, **kw)
     orc = OracleEngine(params)
     asm = orc.assemble(arrs, n, nr)
     want = orc.msa(arrs, n, nr, asm)
     MH, ML, MC = params.max_haps, params.max_hap_len, params.max_comps
     hl, hb = asm["hap_len"].reshape(n, MH), asm["hap_bases"].reshape(n, MH, ML)
-    single = other = 0
+    single = indel = other = 0
     for w in range(n):
         for c in range(int(asm["win_ncomp"][w])):
             b, k = int(asm["comp_hap0"].reshape(n, MC)[w, c]), int(asm["comp_nhaps"].reshape(n, MC)[w, c])
             if k < 2:
                 continue
-            same_len = hl[w, b] == hl[w, b + 1]
-            d = int((hb[w, b, :hl[w, b]] != hb[w, b + 1, :hl[w, b]]).sum()) if same_len else -1
-            single += d in (1, 2)
-            other += d not in (1, 2)
-    assert single >= 2 and other >= 2, (single, other)
+            R, Q = hb[w, b, :hl[w, b]], hb[w, b + 1, :hl[w, b + 1]]
+            m = min(len(R), len(Q))
+            if len(R) == len(Q):
+                d = int((R != Q).sum())
+                single += d <= 2
+                other += d > 2
+            else:
+                neq = np.nonzero(R[:m] != Q[:m])[0]
+                lcp = int(neq[0]) if len(neq) else m
+                neq = np.nonzero(R[::-1][:m] != Q[::-1][:m])[0]
+                lcs = int(neq[0]) if len(neq) else m
+                indel += lcp + lcs >= m
+                other += lcp + lcs < m
+    assert single >= need[0] and indel >= need[1] and other >= need[2], (single, indel, other)
     eng = Engine(params)
     try:
         got = eng.msa(arrs, n, nr, asm)
