@@ -118,6 +118,7 @@ int launch_assemble(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& out, const
 
   // capacity planning: instance maxima at the smallest k (the largest instance counts)
   ws.k = P.min_k;
+  ws.win_k = out.win_k;  // (all zero here: every window is counted at the first rung)
   MA_TRY_RC(run_count_inst(ctx, b, ws, 0, n, counters));
   u32 maxima[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   MA_HIP(ctx, hipMemcpyAsync(maxima, counters, 32, hipMemcpyDeviceToHost, ctx->stream));
@@ -220,12 +221,10 @@ int launch_assemble(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& out, const
       ws.mc_log2 = mc_log2_alloc;
       Carver cw{static_cast<char*>(ctx->ws_build.p)};
       carve_ws(cw, ws, static_cast<size_t>(nwin));
-      for (int k = P.min_k; k <= P.max_k; k += P.k_step) {
-        ws.k = k;
-        u64 pk1 = 1;
-        for (int i = 0; i < k - 1; ++i) pk1 *= kHashP;
-        ws.pk1 = pk1;
-        ws.pinv = mod_inverse_pow2(kHashP);
+      // one pass per rung a window still has to climb, not per rung of the ladder: every pending window attempts its own
+      // next k (k_select_active); a second pass only sees the windows whose graph at that k had a cycle / was too complex
+      int const rungs = (P.max_k - P.min_k) / P.k_step + 1;
+      for (int kpass = 0; kpass <= rungs; ++kpass) {
         MA_TRY_RC(run_select_active(ctx, ws, win0, nwin, gate_approx, out.win_k, active, counters + 8));
         u32 host_cnt[2] = {0, 0};
         MA_HIP(ctx, hipMemcpyAsync(host_cnt, counters + 8, 8, hipMemcpyDeviceToHost, ctx->stream));

@@ -82,6 +82,8 @@ __global__ __launch_bounds__(kBT) void k_count_inst(DBatch b, GraphWs ws, int wi
   __shared__ u32 sh[kBT];
   int const w = win0 + blockIdx.x;
   if (blockIdx.x >= static_cast<u32>(nwin)) return;
+  if (ws.win_flags[w] & 1u) return;  // resolved in an earlier pass: no instances to plan for
+  int const kw = win_kmer(ws, w);
   u32 const ns = seq_count(b, w);
   u32 const base_idx = b.read_win_off[w] + w;
   u32 running = 0, read_inst = 0, max_len = 0;
@@ -89,7 +91,7 @@ __global__ __launch_bounds__(kBT) void k_count_inst(DBatch b, GraphWs ws, int wi
     u32 const s = s0 + threadIdx.x;
     u32 nk = 0;
     if (s < ns) {
-      SeqInfo const si = seq_info(b, w, s, ws.k);
+      SeqInfo const si = seq_info(b, w, s, kw);
       nk = si.nk;
       if (s > 0) max_len = max(max_len, si.len);
     }
@@ -102,7 +104,7 @@ __global__ __launch_bounds__(kBT) void k_count_inst(DBatch b, GraphWs ws, int wi
     running += tot;
   }
   if (threadIdx.x == 0) {
-    u32 const refk = seq_info(b, w, 0, ws.k).nk;
+    u32 const refk = seq_info(b, w, 0, kw).nk;
     read_inst = running - refk;
     ws.win_ninst[w] = running;
     ws.win_nread_inst[w] = read_inst;
@@ -114,16 +116,29 @@ __global__ __launch_bounds__(kBT) void k_count_inst(DBatch b, GraphWs ws, int wi
   if (max_len) atomicMax(&maxima[4], max_len);
 }
 
-// ---- choose the windows that attempt this k (graph.cpp:106-120) ----
+// ---- choose the windows of this pass and the k each of them attempts (graph.cpp:106-120) ----
+// The reference climbs the ladder min_k, min_k + step, ... per window: a k whose repeat gate fires is skipped, a k whose
+// graph has a cycle / is too complex sends the window to the next one.  Windows are independent, so every pending window
+// takes ITS next k here and one pass of the build / clean kernels serves all of them, each at its own k (a pass per k
+// of the ladder cost twenty passes of mostly idle kernels).  win_k[w] = Graph::CurrentK(): the k attempted last; a window
+// that runs out of ladder ends on its last rung, unresolved, as the reference's loop does.
 __global__ void k_select_active(GraphWs ws, int win0, int nwin, const u32* gate_approx, u32* win_k, u32* active,
-                                u32* n_active) {
+                                u32* n_active, int min_k, int max_k, int k_step) {
   int const i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= nwin) return;
   int const w = win0 + i;
-  if (ws.win_flags[w] & 1u) return;           // done at an earlier k
-  atomicAdd(n_active + 1, 1u);                  // still pending
-  win_k[w] = static_cast<u32>(ws.k);            // Graph::CurrentK()
-  if (gate_approx[w] >= static_cast<u32>(ws.k)) return;  // HasExactOrApproxRepeat -> continue
+  if (ws.win_flags[w] & 1u) return;           // done in an earlier pass
+  u32 const last = win_k[w];
+  u32 k = last ? last + static_cast<u32>(k_step) : static_cast<u32>(min_k);
+  u32 const ga = gate_approx[w];
+  if (k <= ga) k += ((ga - k) / static_cast<u32>(k_step) + 1u) * static_cast<u32>(k_step);  // HasExactOrApproxRepeat -> continue
+  if (k > static_cast<u32>(max_k)) {          // ladder exhausted
+    win_k[w] = static_cast<u32>(min_k + (max_k - min_k) / k_step * k_step);
+    atomicOr(&ws.win_flags[w], 1u);
+    return;
+  }
+  atomicAdd(n_active + 1, 1u);                // still pending
+  win_k[w] = k;                                // Graph::CurrentK()
   u32 const a = atomicAdd(n_active, 1u);
   active[a] = static_cast<u32>(w);
 }
@@ -239,7 +254,7 @@ __global__ __launch_bounds__(64) void k_classify(DBatch b, GraphWs ws, u32* max_
   int const a = blockIdx.x / tiles_per_win;
   u32 const tile = blockIdx.x % tiles_per_win;
   int const w = static_cast<int>(ws.active[a]);
-  int const k = ws.k;
+  int const k = win_kmer(ws, w);
   int const lane = threadIdx.x;
   u32 const ns = seq_count(b, w);
   u32 const nreads = ns - 1;
@@ -453,7 +468,7 @@ __global__ __launch_bounds__(kInsT) void k_insert(DBatch b, GraphWs ws) {
   __shared__ u32 l_nmap, l_ndef, l_seq_ok;
   int const a = blockIdx.x;
   int const w = static_cast<int>(ws.active[a]);
-  int const k = ws.k;
+  int const k = win_kmer(ws, w);
   u64* keys = ws.tbl_key + (static_cast<size_t>(a) << ws.tc_log2);
   u32* first = ws.tbl_first + (static_cast<size_t>(a) << ws.tc_log2);
   u32* inst_slot = ws.inst_slot + static_cast<size_t>(a) * ws.inst_stride;
@@ -685,7 +700,7 @@ __global__ __launch_bounds__(kBT) void k_support(DBatch b, GraphWs ws, u32* max_
   __shared__ u32 n_leaders;
   int const a = blockIdx.x;
   int const w = static_cast<int>(ws.active[a]);
-  int const k = ws.k;
+  int const k = win_kmer(ws, w);
   int const S = ws.num_samples, CW = S + 2;
   u32* gcnt = ws.tbl_cnt + (static_cast<size_t>(a) << ws.tc_log2) * CW;
   u32* inst_slot = ws.inst_slot + static_cast<size_t>(a) * ws.inst_stride;
@@ -1293,7 +1308,7 @@ __global__ __launch_bounds__(kBT) void k_rank(DBatch b, GraphWs ws, u32 min_node
   }
   __syncthreads();
   // 3. mRefNodeIds (graph.cpp:264-267): node of every reference k-mer (kNoNode when pruned)
-  SeqInfo const rsi = seq_info(b, w, 0, ws.k);
+  SeqInfo const rsi = seq_info(b, w, 0, win_kmer(ws, w));
   u32* refn = ws.ref_node + static_cast<size_t>(a) * ws.ref_stride;
   for (u32 p = threadIdx.x; p < ws.ref_stride; p += kBT)
     refn[p] = p < rsi.nk ? slot_node[inst_slot[p] & kInstSlotMask] : kNoNode;
@@ -1564,7 +1579,7 @@ int run_select_active(ma_ctx* ctx, const GraphWs& ws, int win0, int nwin, const 
                       u32* active, u32* n_active_dev) {
   MA_HIP(ctx, hipMemsetAsync(n_active_dev, 0, 8, ctx->stream));
   hipLaunchKernelGGL(k_select_active, dim3((nwin + 255) / 256), dim3(256), 0, ctx->stream, ws, win0, nwin,
-                     gate_approx, win_k, active, n_active_dev);
+                     gate_approx, win_k, active, n_active_dev, ctx->prm.min_k, ctx->prm.max_k, ctx->prm.k_step);
   MA_HIP(ctx, hipGetLastError());
   return MA_OK;
 }

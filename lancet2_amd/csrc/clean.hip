@@ -1310,7 +1310,7 @@ __global__ __launch_bounds__(64, 4) void k_clean(CleanArgs A) {
   g.refb = A.b.ref_bases + A.b.ref_off[w];
   g.readb = A.b.read_bases + A.b.read_off[A.b.read_win_off[w]];
   g.ref_len = A.b.ref_off[w + 1] - A.b.ref_off[w];
-  g.k = ws.k;
+  g.k = win_kmer(ws, w);
   g.S = ws.num_samples;
   g.n = ws.n_nodes[a];
   g.nc = ws.nc;

@@ -29,7 +29,9 @@ constexpr int kMaxSamples = 8;
 
 struct GraphWs {
   // ---- per k attempt ----
-  int k;
+  int k;                  // the ladder's first k: what a window without a k of its own yet is counted with (capacity planning)
+  const u32* win_k;       // [n_windows] the k window w attempts in this pass (0: none yet) -- every window climbs its OWN
+                          // ladder, so one pass serves windows at different k (k_select_active)
   u64 pk1;   // P^(k-1) mod 2^64
   u64 pinv;  // P^-1   mod 2^64
   int n_active;
@@ -86,6 +88,13 @@ struct GraphWs {
   u32* win_flags;         // [n_windows] bit0 done, bit1 retry-at-next-k requested
   int num_samples;
 };
+
+// the k window w is built / cleaned with in the current pass
+__device__ __forceinline__ int win_kmer(GraphWs const& ws, int w) {
+  u32 const k = ws.win_k[w];
+  return k ? static_cast<int>(k) : ws.k;
+}
+
 
 __device__ __forceinline__ u64 dev_fmix64(u64 x) {
   x ^= x >> 33;
