@@ -117,3 +117,30 @@ def test_reads_beyond_the_aligner_limit_are_refused():
             eng.process(arrs, n, nr)
     finally:
         eng.close()
+
+
+def test_windows_that_run_out_of_ladder_and_windows_at_different_rungs_share_a_pass():
+    """Every window climbs its own k ladder inside one pass: a window whose repeat outlasts the ladder (gated at every rung)
+    ends unresolved on the last rung like the reference's loop, next to windows that assemble at 13, 19, ... and to
+    tandem-repeat windows that need a larger k."""
+    from lancet2_amd.engine import Engine
+    params = capi.default_params()  # the reference's ladder 13, 19, ... 127
+    wins = [synth.make_window(424_400 + i, **dict(synth.CONFIGS["C2"])) for i in range(3)]
+    wins += [synth.make_window(424_410 + i, **dict(synth.CONFIGS["C2"], str_unit=u)) for i, u in enumerate((b"CA", b"GATA", b"AGGGTT"))]
+    rep = synth.make_window(424_420, **dict(synth.CONFIGS["C2"]))
+    rep["ref"][700:860] = rep["ref"][100:260]  # a 160-base exact repeat: HasExactOrApproxRepeat at every k <= 127
+    wins.append(rep)
+    arrs, n, nr = synth.pack_batch(wins)
+    orc = OracleEngine(params)
+    wg, wa = orc.gate(arrs, n, nr), orc.assemble(arrs, n, nr)
+    eng = Engine(params)
+    try:
+        g = eng.gate(arrs, n, nr)
+        a = eng.assemble(arrs, n, nr)
+    finally:
+        eng.close()
+    assert np.array_equal(g["max_approx"], wg["max_approx"])
+    bad = compare_asm(params, a, wa, n)
+    assert not bad, "\n".join(bad[:20])
+    assert int(wg["max_approx"][-1]) >= 160 and int(wa["win_k"][-1]) == 127 and (wa["win_status"][-1] & capi.MA_W_NO_HAPLOTYPE)
+    assert len(set(int(k) for k in wa["win_k"])) >= 3, wa["win_k"]
