@@ -68,6 +68,7 @@ struct AlnWs {
   u32 wave_big_w;      // widest region the big wavefront class holds for this batch's longest read (host computed)
   // planning
   u32* win_slotmask;   // [n] bitmask of haplotype slots to align
+  u32* win_case;       // [n] bitmask of the samples that have a CASE read in the window (k_plan_reads)
   u64* pair_off;       // [n + 1]
   u32* counters;       // [8]: 0 max read len, 1 max reads per window, 2 entries in vote_wg
   u32* vote_wg;        // [n * MH] compact list of (window * MH + slot) to align against
@@ -144,13 +145,32 @@ __global__ void k_plan(GArgs A) {
   }
   u32 const nr = A.b.read_win_off[w + 1] - A.b.read_win_off[w];
   A.ws.pair_off[w] = static_cast<u64>(nr) * __popc(mask);  // counts; scanned below
-  u32 ml = 0;
-  for (u32 r = A.b.read_win_off[w]; r < A.b.read_win_off[w + 1]; ++r) {
+  atomicMax(&A.ws.counters[1], nr);
+}
+
+// The per-read part of the plan, one wavefront per window (a thread per window walking its 600 reads was 600 dependent
+// iterations): read -> window map, longest read, and which samples are CASE samples (k_qual asked every variant's thread
+// to find that out from the window's reads again).
+__global__ __launch_bounds__(256) void k_plan_reads(GArgs A) {
+  int const w = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (w >= A.b.n_windows) return;
+  u32 const r0 = A.b.read_win_off[w], r1 = A.b.read_win_off[w + 1];
+  u32 const S = static_cast<u32>(A.prm.num_samples);
+  u32 ml = 0, cm = 0;
+  for (u32 r = r0 + lane; r < r1; r += 64) {
     ml = max(ml, static_cast<u32>(A.b.read_off[r + 1] - A.b.read_off[r]));
     A.ws.read_win[r] = static_cast<u32>(w);
+    u32 const smp = A.b.read_sample[r];
+    if ((A.b.read_flags[r] & MA_RF_CASE) && smp < S) cm |= 1u << smp;
   }
-  atomicMax(&A.ws.counters[0], ml);
-  atomicMax(&A.ws.counters[1], nr);
+  for (int off = 32; off > 0; off >>= 1) {
+    ml = max(ml, static_cast<u32>(__shfl_xor(ml, off)));
+    cm |= static_cast<u32>(__shfl_xor(cm, off));
+  }
+  if (lane == 0) {
+    A.ws.win_case[w] = cm;
+    if (ml) atomicMax(&A.ws.counters[0], ml);
+  }
 }
 
 __global__ void k_scan_pairs(u64* pair_off, int n) {  // single block exclusive scan (n <= few 100k)
@@ -224,24 +244,34 @@ __global__ __launch_bounds__(256) void k_read_planes(GArgs A, u32 rwords) {
   u32* mine = lds_pl + wave * 3u * rwords;
   i64 const r_begin = (static_cast<i64>(blockIdx.x) * 4 + wave) * kPlaneReadsPerWave;
   i64 const r_end = min(r_begin + kPlaneReadsPerWave, A.b.n_reads);
-  // the loop is a chain of HBM round trips: the first 256 bases of the NEXT read are in flight while this one is packed
+  // the loop would be a chain of HBM round trips (offset -> bases -> store): the wave's 17 read offsets are fetched at once,
+  // one per lane, and the first 256 bases of the next TWO reads are in flight while this one is packed
   constexpr int kPre = 4;
-  u32 cur[kPre], nxt[kPre];
-  i32 m_cur = 0, m_nxt = 0;
+  u64 my_off = 0;
+  if (lane <= kPlaneReadsPerWave && r_begin + lane <= A.b.n_reads) my_off = A.b.read_off[r_begin + lane];
+  auto off_of = [&](int x) -> u64 {  // x uniform: read r_begin + x
+    u32 const lo = static_cast<u32>(__builtin_amdgcn_readlane(static_cast<int>(static_cast<u32>(my_off)), x));
+    u32 const hi = static_cast<u32>(__builtin_amdgcn_readlane(static_cast<int>(static_cast<u32>(my_off >> 32)), x));
+    return (static_cast<u64>(hi) << 32) | lo;
+  };
+  u32 cur[kPre], nxt[kPre], nxt2[kPre];
+  i32 m_cur = 0, m_nxt = 0, m_nxt2 = 0;
   auto fetch = [&](i64 r, u32 (&pre)[kPre], i32* mm) {
-    u64 const ro = A.b.read_off[r];
-    *mm = static_cast<i32>(A.b.read_off[r + 1] - ro);
+    int const x = static_cast<int>(r - r_begin);
+    u64 const ro = off_of(x);
+    *mm = static_cast<i32>(off_of(x + 1) - ro);
     const u8* rb = A.b.read_bases + ro;
 #pragma unroll
-    for (int x = 0; x < kPre; ++x) pre[x] = lane + 64 * x < *mm ? rb[lane + 64 * x] : 0u;
+    for (int q = 0; q < kPre; ++q) pre[q] = lane + 64 * q < *mm ? rb[lane + 64 * q] : 0u;
   };
 #pragma unroll
-  for (int x = 0; x < kPre; ++x) cur[x] = nxt[x] = 0;
+  for (int x = 0; x < kPre; ++x) cur[x] = nxt[x] = nxt2[x] = 0;
   if (r_begin < r_end) fetch(r_begin, cur, &m_cur);
+  if (r_begin + 1 < r_end) fetch(r_begin + 1, nxt, &m_nxt);
   for (i64 r = r_begin; r < r_end; ++r) {
-    if (r + 1 < r_end) fetch(r + 1, nxt, &m_nxt);
+    if (r + 2 < r_end) fetch(r + 2, nxt2, &m_nxt2);
     i32 const m = m_cur;
-    const u8* rb = A.b.read_bases + A.b.read_off[r];
+    const u8* rb = A.b.read_bases + off_of(static_cast<int>(r - r_begin));
     for (i32 i0 = 0; i0 < static_cast<i32>(rwords) * 32; i0 += 64) {
       i32 const i = i0 + lane;
       int const t = i0 >> 6;
@@ -266,8 +296,12 @@ __global__ __launch_bounds__(256) void k_read_planes(GArgs A, u32 rwords) {
     for (u32 x = lane; x < plane_stride(rwords); x += 64) out[x] = x < 3u * rwords ? mine[x] : 0u;
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int x = 0; x < kPre; ++x) cur[x] = nxt[x];
+    for (int x = 0; x < kPre; ++x) {
+      cur[x] = nxt[x];
+      nxt[x] = nxt2[x];
+    }
     m_cur = m_nxt;
+    m_nxt = m_nxt2;
   }
 }
 
@@ -1820,10 +1854,7 @@ __global__ void k_qual(GArgs A) {
     }
   }
   if (!P.case_ctrl_mode) return;
-  // sample roles from the window's reads
-  u32 case_mask = 0;
-  for (u32 r = A.b.read_win_off[w]; r < A.b.read_win_off[w + 1]; ++r)
-    if ((A.b.read_flags[r] & MA_RF_CASE) && A.b.read_sample[r] < static_cast<u32>(S)) case_mask |= 1u << A.b.read_sample[r];
+  u32 const case_mask = A.ws.win_case[w];  // sample roles from the window's reads (k_plan_reads)
   f64 sum_alt = 0.0, sum_ref = 0.0, n_ctrl = 0.0;
   for (int s = 0; s < S; ++s) {
     if ((case_mask >> s) & 1u) continue;
@@ -1900,6 +1931,7 @@ int launch_genotype(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& a, const m
       return p;
     };
     ws.win_slotmask = reinterpret_cast<u32*>(take(4ull * n));
+    ws.win_case = reinterpret_cast<u32*>(take(4ull * n));
     ws.pair_off = reinterpret_cast<u64*>(take(8ull * (n + 1)));
     ws.counters = reinterpret_cast<u32*>(take(64));
     ws.vote_wg = reinterpret_cast<u32*>(take(4ull * n * MH));
@@ -1932,6 +1964,7 @@ int launch_genotype(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& a, const m
   ctx->toc();
   ctx->tic("k_plan");
   hipLaunchKernelGGL(k_plan, dim3((n + 127) / 128), dim3(128), 0, ctx->stream, A);
+  hipLaunchKernelGGL(k_plan_reads, dim3((n + 3) / 4), dim3(256), 0, ctx->stream, A);
   hipLaunchKernelGGL(k_scan_pairs, dim3(1), dim3(1024), 0, ctx->stream, ws.pair_off, n);
   ctx->toc();
   u64 total_pairs = 0;
