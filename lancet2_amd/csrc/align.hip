@@ -1819,17 +1819,19 @@ __device__ u32 genotype_pls(const u32* cnt2, int K, u32* pl_out, u32* gq) {
 
 // site quality + FORMAT PL / GQ (variant_call.cpp:141-163, :289-345): SOLOR over the case samples with evidence in
 // case/control mode, otherwise the largest PL[0/0] over the samples with evidence
+// kWithPl = false: case / control mode without the PL / GQ outputs -- the genotype likelihoods (f64 lgamma, 128 VGPRs and
+// a scratch frame) are compiled out of the kernel the somatic path launches
+template <bool kWithPl>
 __global__ void k_qual(GArgs A) {
-  i64 const idx = static_cast<i64>(blockIdx.x) * blockDim.x + threadIdx.x;
+  i64 const tix = static_cast<i64>(blockIdx.x) * blockDim.x + threadIdx.x;
   ma_params_t const& P = A.prm;
   int const MV = P.max_vars, NA = P.max_alts + 1, S = P.num_samples, G = NA * (NA + 1) / 2;
-  if (idx >= static_cast<i64>(A.b.n_windows) * MV) return;
-  int const w = static_cast<int>(idx / MV), v = static_cast<int>(idx % MV);
-  A.o.var_qual[idx] = 0.0;
-  if (A.o.var_pl)
-    for (int x = 0; x < S * G; ++x) A.o.var_pl[static_cast<size_t>(idx) * S * G + x] = 0;
-  if (A.o.var_gq)
-    for (int x = 0; x < S; ++x) A.o.var_gq[static_cast<size_t>(idx) * S + x] = 0;
+  if (tix >= static_cast<i64>(A.b.n_windows) * MV) return;
+  // variant-major: a wavefront is variant slot v of 64 consecutive windows -- nearly full for the first slots, gone at once
+  // for the slots no window uses (window-major put a window's two or three variants alone on a wavefront of 64 slots)
+  int const w = static_cast<int>(tix % A.b.n_windows), v = static_cast<int>(tix / A.b.n_windows);
+  i64 const idx = static_cast<i64>(w) * MV + v;
+  // (var_qual, var_pl, var_gq are zeroed by the launcher: a thread clearing its own 30 PLs writes 120-byte strides)
   if (static_cast<u32>(v) >= A.v.win_nvars[w]) return;
   const u32* cnt = A.o.allele_counts + static_cast<size_t>(idx) * S * NA * 2;
   auto cov = [&](int s, bool alt) {
@@ -1837,7 +1839,7 @@ __global__ void k_qual(GArgs A) {
     for (int al = alt ? 1 : 0; al < (alt ? NA : 1); ++al) t += cnt[(s * NA + al) * 2] + cnt[(s * NA + al) * 2 + 1];
     return t;
   };
-  if (!P.case_ctrl_mode || A.o.var_pl || A.o.var_gq) {
+  if constexpr (kWithPl) {
     int const K = static_cast<int>(A.v.var_nalts[idx]) + 1;
     f64 qual = 0.0;
     for (int s = 0; s < S; ++s) {
@@ -2115,8 +2117,15 @@ int launch_genotype(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& a, const m
   hipLaunchKernelGGL(k_evidence, dim3(static_cast<u32>((NR + 63) / 64)), dim3(64), 0, ctx->stream, A);
   ctx->toc();
   ctx->tic("k_qual");
-  hipLaunchKernelGGL(k_qual, dim3(static_cast<u32>((static_cast<size_t>(n) * MV + 255) / 256)), dim3(256), 0,
-                     ctx->stream, A);
+  {
+    int const NAq = P.max_alts + 1, Gq = NAq * (NAq + 1) / 2;
+    MA_HIP(ctx, hipMemsetAsync(A.o.var_qual, 0, 8ull * n * MV, ctx->stream));
+    if (A.o.var_pl) MA_HIP(ctx, hipMemsetAsync(A.o.var_pl, 0, 4ull * n * MV * P.num_samples * Gq, ctx->stream));
+    if (A.o.var_gq) MA_HIP(ctx, hipMemsetAsync(A.o.var_gq, 0, 4ull * n * MV * P.num_samples, ctx->stream));
+    bool const with_pl = !P.case_ctrl_mode || A.o.var_pl || A.o.var_gq;
+    auto kq = with_pl ? k_qual<true> : k_qual<false>;
+    hipLaunchKernelGGL(kq, dim3(static_cast<u32>((static_cast<size_t>(n) * MV + 255) / 256)), dim3(256), 0, ctx->stream, A);
+  }
   ctx->toc();
   MA_HIP(ctx, hipGetLastError());
   return MA_OK;
