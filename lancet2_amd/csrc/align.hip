@@ -1582,36 +1582,41 @@ __device__ Scored score_at_variant(Cig cg, i32 score, i32 rs, i32 re, const u8* 
       u32 const op = cop(cg.c[x]), len = clen(cg.c[x]);
       bool const cons_ref = op == 0 || op == 2;
       if (rs + tpos >= vend && cons_ref) break;
+      // (only the op's positions inside [vstart, vend) do anything: they are visited directly, in the same order -- a
+      //  150-base match op walked base by base for the two or three bases under a variant kept 7 of 64 lanes busy)
+      i32 const y_lo = max(0, vstart - (rs + tpos));
+      i32 const y_hi = min(static_cast<i32>(len), vend - (rs + tpos));
       if (op == 0) {
-        for (u32 y = 0; y < len; ++y, ++tpos, ++qpos) {
-          i32 const ap = rs + tpos;
-          if (!(ap >= vstart && ap < vend)) continue;
+        for (i32 y = y_lo; y < y_hi; ++y) {
+          u32 const qp = qpos + static_cast<u32>(y);
+          u32 const tp = static_cast<u32>(tpos + y);
           ++aligned;
-          if (!(qpos >= rlen || static_cast<u32>(tpos) >= tlen)) {
-            u32 const qe = enc_base(rb[qpos]), te = enc_base(target[tpos]);
+          if (!(qp >= rlen || tp >= tlen)) {
+            u32 const qe = enc_base(rb[qp]), te = enc_base(target[tp]);
             i8 const r = kMatrix[te * 5 + qe];
             raw += static_cast<f64>(r);
-            f64 const wgt = qpos < rlen ? 1.0 - phred[rq[qpos]] : 1.0;
+            f64 const wgt = qp < rlen ? 1.0 - phred[rq[qp]] : 1.0;
             pbq += static_cast<f64>(r) * wgt;
             matches += (qe == te);
           }
         }
+        tpos += static_cast<i32>(len);
+        qpos += len;
       } else if (op == 1) {
         i32 const ap = rs + tpos;
         bool const inr = ap >= vstart && ap < vend;
-        for (u32 y = 0; y < len; ++y, ++qpos) {
-          if (!inr) continue;
-          ++aligned;
-          pbq += 3.0;
-        }
-      } else if (op == 2) {
-        for (u32 y = 0; y < len; ++y, ++tpos) {
-          i32 const ap = rs + tpos;
-          if (ap >= vstart && ap < vend) {
+        if (inr)
+          for (u32 y = 0; y < len; ++y) {
             ++aligned;
             pbq += 3.0;
           }
+        qpos += len;
+      } else if (op == 2) {
+        for (i32 y = y_lo; y < y_hi; ++y) {
+          ++aligned;
+          pbq += 3.0;
         }
+        tpos += static_cast<i32>(len);
       } else if (op == 4) {
         qpos += len;
       }
