@@ -2046,18 +2046,39 @@ int launch_genotype(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& a, const m
                          ws.dp_count + 64, kb);
       ctx->toc();
       A.ws.dp_list = dp_sorted;
+      auto class_n = [&](int c) { return cnt[4 + 2 * c] + cnt[4 + 2 * c + 1]; };
+      auto class_w = [&](int c) -> u32 {
+        return c < kNumReg ? static_cast<u32>(reg_width(c))
+                           : (c == kClsWaveS ? kWaveSmallW : (c == kClsWaveB ? std::min<u32>(big_w, std::max<u32>(cnt[41], 64u)) : std::max<u32>(cnt[40], 1u)));
+      };
+      // A register-class launch lasts at least 150 dependent rows of W cells (0.15 - 0.6 ms for W = 33 ... 129) however few
+      // pairs it holds; the wavefront kernel runs one pair per wave in ~50 us: sparse wide classes go there
+      auto class_reroute = [&](int c) { return c < kNumReg && reg_width(c) >= 49 && class_n(c) <= 4096u && !getenv("MA_NO_REROUTE"); };
+      auto class_wave = [&](int c) { return c == kClsWaveS || c == kClsWaveB || class_reroute(c); };
       for (int cls = 0; cls < kNumCls; ++cls) {
-        u32 const cls_n = cnt[4 + 2 * cls] + cnt[4 + 2 * cls + 1];
+        u32 cls_n = class_n(cls);
         if (cls_n == 0) continue;
         ctx->stats[4 + (cls < kNumReg ? (cls < 2 ? 0 : (cls < 4 ? 1 : 2)) : 3)] += cls_n;
-        u32 const gw = cls < kNumReg ? static_cast<u32>(reg_width(cls))
-                                     : (cls == kClsWaveS ? kWaveSmallW : (cls == kClsWaveB ? std::min<u32>(big_w, std::max<u32>(cnt[41], 64u)) : std::max<u32>(cnt[40], 1u)));
+        u32 gw = class_w(cls);
+        bool const reroute = class_reroute(cls);
+        bool const wave = class_wave(cls);
+        int last = cls;
+        if (wave) {
+          // the wavefront kernel takes every pair's own width from its record: the classes it serves that follow each other
+          // in the sorted list (nothing of a register class in between) share ONE launch, sized for the widest of them --
+          // each launch lasts a pair's 150+ dependent rows however few pairs it holds
+          for (int c2 = cls + 1; c2 < kNumCls; ++c2) {
+            u32 const n2 = class_n(c2);
+            if (n2 == 0) continue;
+            if (!class_wave(c2)) break;
+            ctx->stats[4 + (c2 < kNumReg ? (c2 < 2 ? 0 : (c2 < 4 ? 1 : 2)) : 3)] += n2;
+            cls_n += n2;
+            gw = std::max(gw, class_w(c2));
+            last = c2;
+          }
+        }
         A.ws.tb_words = (gw + 7) / 8;
         A.ws.gen_w = gw;
-        // A register-class launch lasts at least 150 dependent rows of W cells (0.15 - 0.6 ms for W = 33 ... 129) however few
-        // pairs it holds; the wavefront kernel runs one pair per wave in ~50 us: sparse wide classes go there
-        bool const reroute = cls < kNumReg && reg_width(cls) >= 49 && cls_n <= 4096u && !getenv("MA_NO_REROUTE");
-        bool const wave = cls == kClsWaveS || cls == kClsWaveB || reroute;
         u32 const nchunk = (gw + 63) / 64;
         // bytes of traceback per launch group: 64 pairs of a lane-per-pair kernel, ONE pair of the wavefront kernel
         size_t const tb_per_group = wave ? static_cast<size_t>(ws.tb_rows) * nchunk * 32
@@ -2088,7 +2109,7 @@ int launch_genotype(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& a, const m
     hipLaunchKernelGGL((k_align_reg<reg_width(C), WLO>), dim3(ng), dim3(64), lds_reg, ctx->stream, A, segw);          \
     ctx->toc();                                                                                                        \
     break;
-          switch (reroute ? kClsWaveB : cls) {
+          switch ((reroute || wave) ? kClsWaveB : cls) {
             MA_LAUNCH_REG(0, 0)
             MA_LAUNCH_REG(1, reg_width(0))
             MA_LAUNCH_REG(2, reg_width(1))
@@ -2111,6 +2132,7 @@ int launch_genotype(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& a, const m
           }
 #undef MA_LAUNCH_REG
         }
+        cls = last;  // (the classes the launch swallowed)
       }
       A = Avote;
     }

@@ -1457,10 +1457,17 @@ __global__ __launch_bounds__(kBT) void k_edge_sort(GraphWs ws) {
     u32* ek = ws.nd_ekey + (nb + i) * kEdgeCap;
     u32 v[kEdgeCap], kk[kEdgeCap];
     int m = 0;
+    // (four slots of both arrays per load: a node has two edges as a rule -- one round trip instead of three)
+    uint4 e4 = *reinterpret_cast<const uint4*>(ed), k4 = *reinterpret_cast<const uint4*>(ek);
     for (int e = 0; e < kEdgeCap; ++e) {
-      if (ed[e] == 0xFFFFFFFFu) break;
+      if ((e & 3) == 0 && e > 0) {
+        e4 = *reinterpret_cast<const uint4*>(ed + e);
+        k4 = *reinterpret_cast<const uint4*>(ek + e);
+      }
+      u32 const cv = (e & 3) == 0 ? e4.x : ((e & 3) == 1 ? e4.y : ((e & 3) == 2 ? e4.z : e4.w));
+      u32 const ck = (e & 3) == 0 ? k4.x : ((e & 3) == 1 ? k4.y : ((e & 3) == 2 ? k4.z : k4.w));
+      if (cv == 0xFFFFFFFFu) break;
       // insertion sort by first-occurrence key (EmplaceEdge order, node.h:59-64)
-      u32 const cv = ed[e], ck = ek[e];
       int j = m++;
       while (j > 0 && kk[j - 1] > ck) {
         kk[j] = kk[j - 1];
