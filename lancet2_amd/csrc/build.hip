@@ -677,16 +677,33 @@ __global__ __launch_bounds__(kInsT) void k_insert(DBatch b, GraphWs ws) {
     inst_slot[p] = fin;
     ref_slot_g[p] = fin & kInstSlotMask;
   }
-  for (u32 x = threadIdx.x; x < nq; x += kInsT) {
-    u32 const item = slowq[x];
-    u32 const s_idx = item >> 12, o = item & 0xFFFu;
-    u32 const inst = ws.seq_inst_base[base_idx + s_idx] + o;
-    u32 const word = inst_slot[inst];
-    if (!(word & kInstTemp)) continue;  // direct path: finished above
-    u32 const sv = l_min[word & kInsEntryMask], slot = sv & 0x7FFFFFFFu;
-    inst_slot[inst] = (slot == 0x7FFFFFFFu ? 0u : slot) | (word & (kInstPlus | kInstLast | kInstErrFree));
-    // the k-mer is also a reference k-mer <=> the smallest instance of its id is a reference position
-    if ((word & kInstErrFree) && (sv >> 31)) ws.rd_flag[b.read_win_off[w] + s_idx - 1] = 1;
+  // (four instances in flight per thread, like pass 1: queue entry -> [sequence record ->] instance word was three
+  //  dependent round trips per instance, seventeen instances per thread)
+  u32 const r_first = b.read_win_off[w];
+  for (u32 x0 = threadIdx.x; x0 < nq; x0 += kInsT * kIU) {
+    u32 item[kIU], inst[kIU], word[kIU];
+    bool live[kIU];
+#pragma unroll
+    for (int u = 0; u < kIU; ++u) {
+      u32 const x = x0 + u * kInsT;
+      live[u] = x < nq;
+      item[u] = live[u] ? slowq[x] : 0u;
+    }
+#pragma unroll
+    for (int u = 0; u < kIU; ++u) {
+      u32 const s_idx = item[u] >> 12, o = item[u] & 0xFFFu;
+      inst[u] = !live[u] ? 0u : (staged ? l_ibase[s_idx] : ws.seq_inst_base[base_idx + s_idx]) + o;
+    }
+#pragma unroll
+    for (int u = 0; u < kIU; ++u) word[u] = live[u] ? inst_slot[inst[u]] : 0u;
+#pragma unroll
+    for (int u = 0; u < kIU; ++u) {
+      if (!live[u] || !(word[u] & kInstTemp)) continue;  // direct path: finished above
+      u32 const sv = l_min[word[u] & kInsEntryMask], slot = sv & 0x7FFFFFFFu;
+      inst_slot[inst[u]] = (slot == 0x7FFFFFFFu ? 0u : slot) | (word[u] & (kInstPlus | kInstLast | kInstErrFree));
+      // the k-mer is also a reference k-mer <=> the smallest instance of its id is a reference position
+      if ((word[u] & kInstErrFree) && (sv >> 31)) ws.rd_flag[r_first + (item[u] >> 12) - 1] = 1;
+    }
   }
 }
 
