@@ -1072,9 +1072,8 @@ __global__ __launch_bounds__(kMmT) void k_mm_lds(DBatch b, GraphWs ws) {
   __syncthreads();
   u32 const ninst = ws.win_ninst[w], nref = ninst - ws.win_nread_inst[w];
   // (qname, role, node) of one general instance -> set
-  auto const visit = [&](u32 ii, u32 word) {
+  auto const visit_slot = [&](u32 ii, u32 nslot) {
     u32 const lead = l_lead[seq_of(l_base, ns, ii)];
-    u32 const nslot = inst_table_slot(word, ref_slot_g);
     if (npass > 1 && nslot % npass != pass) return;
     u32 const key = ((nslot << 11) | (lead - 1)) + 1u;
     u32 h = (key * 2654435761u) >> 17;  // kMmLdsCap == 1 << 15
@@ -1088,6 +1087,7 @@ __global__ __launch_bounds__(kMmT) void k_mm_lds(DBatch b, GraphWs ws) {
       h = (h + 1) & (kMmLdsCap - 1);
     }
   };
+  auto const visit = [&](u32 ii, u32 word) { visit_slot(ii, inst_table_slot(word, ref_slot_g)); };
   // Only ~20 % of the instances are general ones: visiting them where they are found keeps 4 of 5 lanes idle
   // through a chain of dependent LDS / L2 accesses.  Each chunk of 16 k words is therefore scanned with
   // coalesced loads first, the general instances are queued (one LDS atomic per wavefront), and the queue is
@@ -1123,9 +1123,21 @@ __global__ __launch_bounds__(kMmT) void k_mm_lds(DBatch b, GraphWs ws) {
     }
     __syncthreads();
     u32 const qn = min(l_qn, kMmQueue);
-    for (u32 q = threadIdx.x; q < qn; q += kMmT) {
-      u32 const ii = l_queue[q];
-      visit(ii, inst_slot[ii]);
+    // (four queue entries per thread in flight: instance word, then -- for an instance on a reference k-mer -- its table
+    //  slot, were two dependent round trips per entry)
+    for (u32 q0 = threadIdx.x; q0 < qn; q0 += kMmT * kU) {
+      u32 qi[kU], qw[kU], qs[kU];
+#pragma unroll
+      for (int u = 0; u < kU; ++u) {
+        u32 const q = q0 + u * kMmT;
+        qi[u] = q < qn ? l_queue[q] : 0xFFFFFFFFu;
+        qw[u] = qi[u] != 0xFFFFFFFFu ? inst_slot[qi[u]] : 0u;
+      }
+#pragma unroll
+      for (int u = 0; u < kU; ++u) qs[u] = qi[u] != 0xFFFFFFFFu ? inst_table_slot(qw[u], ref_slot_g) : 0u;
+#pragma unroll
+      for (int u = 0; u < kU; ++u)
+        if (qi[u] != 0xFFFFFFFFu) visit_slot(qi[u], qs[u]);
     }
     __syncthreads();
   }
