@@ -1361,14 +1361,14 @@ __global__ __launch_bounds__(256) void k_dp_scatter(GArgs A, u32 ndp, u32* out, 
 
 // waves per SIMD the register allocator is asked to keep (it otherwise spends registers on scheduling freedom)
 __host__ __device__ constexpr int reg_waves(int w) { return w <= 49 ? 4 : (w <= 65 ? 3 : (w <= 97 ? 2 : 1)); }
+// the body of one width class: `group` = the class's 64-pair group this wavefront owns
 template <int W, int WLO>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(reg_waves(W), 8))) void k_align_reg(GArgs A, u32 seg_words) {
-  extern __shared__ u32 lds[];
+__device__ __forceinline__ void align_reg_body(GArgs const& A, u32 seg_words, u32 const group, u32* lds) {
   constexpr int WD = W;
   constexpr int NW = (WD + 7) / 8;  // traceback / segment words per row
   int const lane = threadIdx.x;
   u32* SEG = lds;  // [seg_words][64]
-  DpPair const P = dp_pair_load(A, blockIdx.x * 64u + lane);
+  DpPair const P = dp_pair_load(A, group * 64u + lane);
   i32 const m = P.m, n = P.n, lo = P.lo;
   i32 const wr = P.active ? P.wr : 0;
   i32 const mrows = P.active ? m : 0;
@@ -1397,7 +1397,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(reg_waves(W)
     i32 const h = (t < wr && j >= 0 && j <= n) ? 0 : NEGR;
     HF[t] = (static_cast<u32>(h - GOE) & 0xFFFFu) | (static_cast<u32>(NEGR - GE) << 16);
   }
-  size_t const tb_base = static_cast<size_t>(blockIdx.x) * A.ws.tb_rows * A.ws.tb_words * 64;
+  size_t const tb_base = static_cast<size_t>(group) * A.ws.tb_rows * A.ws.tb_words * 64;
   u32* tb = A.ws.tb + tb_base;
   i32 best = NEGR, bi = -1, bj = -1;
   for (i32 i = 1; i <= mmax; ++i) {
@@ -1510,6 +1510,38 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(reg_waves(W)
     }
   }
   dp_pair_store(A, P, tb, lane, best, bi, bj);
+}
+
+template <int W, int WLO>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(reg_waves(W), 8))) void k_align_reg(GArgs A, u32 seg_words) {
+  extern __shared__ u32 lds[];
+  align_reg_body<W, WLO>(A, seg_words, blockIdx.x, lds);
+}
+
+// Two width classes in one launch (the first n1 workgroups are class 1's groups): a launch lasts its 150 dependent rows
+// however few pairs it holds, and the classes of one batch are independent -- side by side they cost the longer of the
+// two instead of their sum.  Only classes with the same register budget are paired.  A2 differs from A in the class's
+// slice of the DP list, its traceback words per row and its tile base.
+struct RegClass2 {
+  u32 dp0, dp_n, tb_words, gen_w;
+  u32* tb;
+};
+template <int W1, int WLO1, int W2, int WLO2>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(reg_waves(W2), 8))) void k_align_reg2(GArgs A, RegClass2 c2, u32 seg_words,
+                                                                                                              u32 n1) {
+  extern __shared__ u32 lds[];
+  static_assert(reg_waves(W1) == reg_waves(W2), "same register budget");
+  if (blockIdx.x < n1) {
+    align_reg_body<W1, WLO1>(A, seg_words, blockIdx.x, lds);
+  } else {
+    GArgs B = A;
+    B.dp0 = c2.dp0;
+    B.dp_n = c2.dp_n;
+    B.ws.tb_words = c2.tb_words;
+    B.ws.gen_w = c2.gen_w;
+    B.ws.tb = c2.tb;
+    align_reg_body<W2, WLO2>(B, seg_words, blockIdx.x - n1, lds);
+  }
 }
 
 // ---- scoring epilogue ----
@@ -2075,6 +2107,46 @@ int launch_genotype(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& a, const m
             cls_n += n2;
             gw = std::max(gw, class_w(c2));
             last = c2;
+          }
+        }
+        // two register classes of the same register budget, side by side in one launch (k_align_reg2) when both fit the
+        // traceback workspace whole
+        if (!wave && cls < kNumReg && reg_waves(reg_width(cls)) == 4 && !getenv("MA_NO_PAIR")) {
+          int c2 = -1;
+          for (int c = cls + 1; c < kNumReg; ++c) {
+            if (class_n(c) == 0) continue;
+            if (!class_wave(c) && reg_waves(reg_width(c)) == 4) c2 = c;
+            break;
+          }
+          if (c2 >= 0) {
+            u32 const n1 = cls_n, n2 = class_n(c2);
+            u32 const gw2 = class_w(c2);
+            u32 const tw1 = (gw + 7) / 8, tw2 = (gw2 + 7) / 8;
+            size_t const tpg1 = static_cast<size_t>(ws.tb_rows) * tw1 * 64 * 4, tpg2 = static_cast<size_t>(ws.tb_rows) * tw2 * 64 * 4;
+            u32 const ng1 = (n1 + 63) / 64, ng2 = (n2 + 63) / 64;
+            if (static_cast<size_t>(ng1) * tpg1 + static_cast<size_t>(ng2) * tpg2 <= tb_cap) {
+              ctx->stats[4 + (c2 < 2 ? 0 : (c2 < 4 ? 1 : 2))] += n2;
+              A.ws.tb_words = tw1;
+              A.ws.gen_w = gw;
+              A.dp0 = kb.b[2 * cls];
+              A.dp_n = n1;
+              RegClass2 const second{kb.b[2 * c2], n2, tw2, gw2, A.ws.tb + static_cast<size_t>(ng1) * tpg1 / 4};
+              u32 const segw = (max_read_len + gw2 + 7) / 8 + 3;
+              size_t const lds_reg = static_cast<size_t>(segw) * 256;
+              ctx->tic("k_align_reg");
+              if (cls == 0 && c2 == 1)
+                hipLaunchKernelGGL((k_align_reg2<reg_width(0), 0, reg_width(1), reg_width(0)>), dim3(ng1 + ng2), dim3(64), lds_reg,
+                                   ctx->stream, A, second, segw, ng1);
+              else if (cls == 0 && c2 == 2)
+                hipLaunchKernelGGL((k_align_reg2<reg_width(0), 0, reg_width(2), reg_width(1)>), dim3(ng1 + ng2), dim3(64), lds_reg,
+                                   ctx->stream, A, second, segw, ng1);
+              else
+                hipLaunchKernelGGL((k_align_reg2<reg_width(1), reg_width(0), reg_width(2), reg_width(1)>), dim3(ng1 + ng2), dim3(64),
+                                   lds_reg, ctx->stream, A, second, segw, ng1);
+              ctx->toc();
+              cls = c2;
+              continue;
+            }
           }
         }
         A.ws.tb_words = (gw + 7) / 8;
