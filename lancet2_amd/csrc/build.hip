@@ -1232,25 +1232,47 @@ __global__ __launch_bounds__(kBT) void k_rank(DBatch b, GraphWs ws, u32 min_node
 
   // 1. survivor flag into bit 31 of tbl_first (set = pruned / empty); a survivor marks its first instance word, so
   //    that step 2 streams the instance words instead of gathering tbl_first once per instance
-  for (u32 s = threadIdx.x; s < tcap; s += kBT) {
-    slot_node[s] = kNoNode;
-    if (keys[s] == 0) {
-      first[s] = 0xFFFFFFFFu;
-      continue;
+  // (four slots per thread in flight: key -> counts -> first instance -> its word is a chain of four round trips)
+  constexpr int kRU = 4;
+  for (u32 s0 = threadIdx.x; s0 < tcap; s0 += kBT * kRU) {
+    u64 ky[kRU];
+    u32 fi[kRU];
+    bool live[kRU], remove[kRU];
+#pragma unroll
+    for (int u = 0; u < kRU; ++u) {
+      u32 const s = s0 + u * kBT;
+      live[u] = s < tcap;
+      ky[u] = live[u] ? keys[s] : 0ull;
+      fi[u] = live[u] ? first[s] : 0u;
     }
-    u32 total = 0;
-    bool any = false, all = true;
-    for (int i = 0; i < S; ++i) {
-      u32 const c = cnt[static_cast<size_t>(s) * CW + i];
-      total += c;
-      any |= c > 0;
-      all &= c <= 1;
+#pragma unroll
+    for (int u = 0; u < kRU; ++u) {
+      u32 const s = s0 + u * kBT;
+      remove[u] = false;
+      if (!live[u]) continue;
+      slot_node[s] = kNoNode;
+      if (ky[u] == 0) continue;
+      u32 total = 0;
+      bool any = false, all = true;
+      for (int i = 0; i < S; ++i) {
+        u32 const c = cnt[static_cast<size_t>(s) * CW + i];
+        total += c;
+        any |= c > 0;
+        all &= c <= 1;
+      }
+      remove[u] = (any && all) || total < min_node_cov;  // node.cpp:38-42, graph.cpp:374-378
     }
-    bool const remove = (any && all) || total < min_node_cov;  // node.cpp:38-42, graph.cpp:374-378
-    if (remove)
-      first[s] |= 0x80000000u;
-    else
-      inst_slot[first[s]] |= kInstFirst;  // (one slot per instance: no other thread touches this word)
+#pragma unroll
+    for (int u = 0; u < kRU; ++u) {
+      u32 const s = s0 + u * kBT;
+      if (!live[u]) continue;
+      if (ky[u] == 0)
+        first[s] = 0xFFFFFFFFu;
+      else if (remove[u])
+        first[s] = fi[u] | 0x80000000u;
+      else
+        inst_slot[fi[u]] |= kInstFirst;  // (one slot per instance: no other thread touches this word)
+    }
   }
   __syncthreads();
 
