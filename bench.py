@@ -19,6 +19,10 @@ import subprocess
 import sys
 import time
 
+# ROCm gives a process four hardware queues unless told otherwise; the engine's concurrent lanes + the caller's stream want
+# five (set before anything initialises HIP; a value already in the environment wins)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 import numpy as np
 
 REPO = os.path.dirname(os.path.abspath(__file__))

@@ -544,7 +544,12 @@ int ma_process_batch(ma_ctx_t* ctx, const ma_batch_t* b, const ma_gate_out_t* ga
   MA_TRY(v.prepare(ctx, vars, var_fields(ctx->prm, d.n_windows), 16, false));
   OutMirror<ma_geno_out_t> q;
   MA_TRY(q.prepare(ctx, geno, geno_fields(ctx->prm, d.n_windows, d.n_reads), 32, false));
-  int lanes = ctx->n_lanes > 0 ? ctx->n_lanes : (d.n_windows >= 6144 ? 3 : (d.n_windows >= 2048 ? 2 : 1));
+  // Automatic: three lanes for big batches -- the process has four hardware queues by default (ROCm's GPU_MAX_HW_QUEUES) and a
+  // fourth lane would share one with the caller's stream (measured: -18 %); a host that raises GPU_MAX_HW_QUEUES to >= 6
+  // before HIP starts gets four (+2 %).
+  int const hwq = getenv("GPU_MAX_HW_QUEUES") ? atoi(getenv("GPU_MAX_HW_QUEUES")) : 4;
+  int lanes = ctx->n_lanes > 0 ? ctx->n_lanes
+                               : (d.n_windows >= 8192 && hwq >= 6 ? 4 : (d.n_windows >= 6144 ? 3 : (d.n_windows >= 2048 ? 2 : 1)));
   if (const char* e = getenv("MA_STREAMS")) lanes = atoi(e) > 0 ? atoi(e) : lanes;
   if (lanes > d.n_windows / 2) lanes = d.n_windows / 2 > 0 ? d.n_windows / 2 : 1;
   if (lanes > 8) lanes = 8;
