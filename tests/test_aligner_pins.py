@@ -213,3 +213,80 @@ def test_poa_gap_crossover_is_at_21():
         base, preds, order, pairs, dp_score = poa_dump([ref, alt])
         got = poa_alignment_score(alt, base, preds, pairs, ((-6, -2), (-26, -1)))
         assert got == cost and dp_score == cost, (L, got, dp_score)
+
+
+# ---- the closed forms poa.hip uses instead of a DP fill (k_msa: "alignments that need no fill") ----------------------
+
+def _closed_form_pairs(ref, alt):
+    """what poa.hip writes down for a first haplotype `alt` against the linear graph of `ref`, or None when it would
+    run the DP: (a) equal length, <= 2 substitutions: the diagonal; (b) one indel and nothing else: shifted diagonal,
+    the gap at its LEFTMOST place, main diagonal.  Pairs in path order, (node | -1, position | -1)."""
+    V, L = len(ref), len(alt)
+    if V == L:
+        if sum(a != b for a, b in zip(ref, alt)) > 2:
+            return None
+        return [(i, i) for i in range(L)]
+    m = min(V, L)
+    lcp = next((i for i in range(m) if ref[i] != alt[i]), m)
+    lcs = next((i for i in range(m) if ref[V - 1 - i] != alt[L - 1 - i]), m)
+    if lcp + lcs < m:
+        return None
+    gl, a0 = abs(V - L), max(0, m - lcs)
+    pairs = [(i, i) for i in range(a0)]
+    if V > L:
+        pairs += [(a0 + t, -1) for t in range(gl)] + [(a0 + gl + t, a0 + t) for t in range(L - a0)]
+    else:
+        pairs += [(-1, a0 + t) for t in range(gl)] + [(a0 + t, a0 + gl + t) for t in range(V - a0)]
+    return pairs
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_poa_closed_forms_equal_the_restated_spoa_backtrack(seed):
+    """The GPU path aligns a component's first haplotype without a fill when it is the backbone with <= 2 substitutions
+    or with one indel and nothing else (proof in poa.hip).  Here the SAME closed form, restated in Python, is compared with
+    the alignment the oracle's SPOA restatement returns -- substitutions anywhere (ends included), indels of 1 ... 40
+    bases (across the 21-base crossover of the two gap models) in random sequence, in homopolymers and in tandem
+    repeats, where the gap can slide and must land leftmost."""
+    rng = np.random.default_rng(9100 + seed)
+    checked = dict(sub=0, indel=0, slid=0)
+    for trial in range(60):
+        n = int(rng.integers(120, 320))
+        ref = bytearray(rand_dna(rng, n))
+        kind = trial % 4
+        if kind == 1:  # a homopolymer run
+            p = int(rng.integers(10, n - 60))
+            ref[p:p + 25] = bytes([ref[p]]) * 25
+        elif kind == 2:  # a tandem repeat of a 2-6 base unit
+            u = rand_dna(rng, int(rng.integers(2, 7)))
+            p = int(rng.integers(10, n - 80))
+            ref[p:p + 48] = (u * 48)[:48]
+        ref = bytes(ref)
+        if kind == 3 or rng.random() < 0.25:  # substitutions
+            alt = bytearray(ref)
+            for q in rng.choice(n, size=int(rng.integers(1, 3)), replace=False):
+                alt[q] = ord("A") if alt[q] != ord("A") else ord("C")
+            if rng.random() < 0.3:
+                alt[0 if rng.random() < 0.5 else n - 1] = ord("G") if ref[0] != ord("G") else ord("T")
+            alt = bytes(alt)
+            if sum(a != b for a, b in zip(ref, alt)) > 2:
+                continue
+            checked["sub"] += 1
+        else:  # one indel, placed inside the repeat when there is one
+            gl = int(rng.choice([1, 1, 2, 3, 5, 7, 12, 20, 21, 22, 30, 40]))
+            at = int(rng.integers(0, n - gl - 1)) if kind == 0 else int(rng.integers(p, p + 20))
+            if rng.random() < 0.5:
+                alt = ref[:at] + ref[at + gl:]
+            else:
+                ins = ref[at:at + gl] if kind else rand_dna(rng, gl)  # a copy of the repeat slides, random bases do not
+                alt = ref[:at] + ins + ref[at:]
+            checked["indel"] += 1
+        want = _closed_form_pairs(ref, alt)
+        if want is None:
+            continue  # (an inserted random base that happens to extend a run can make it two events: the DP's business)
+        base, preds, order, pairs, dp_score = poa_dump([ref, alt])
+        assert pairs == want, (trial, kind, len(ref), len(alt), pairs[:8], want[:8])
+        if len(ref) != len(alt):
+            m = min(len(ref), len(alt))
+            lcp = next((i for i in range(m) if ref[i] != alt[i]), m)
+            checked["slid"] += lcp > max(0, m - next((i for i in range(m) if ref[-1 - i] != alt[-1 - i]), m))
+    assert checked["sub"] >= 10 and checked["indel"] >= 20 and checked["slid"] >= 5, checked
