@@ -290,3 +290,82 @@ def test_poa_closed_forms_equal_the_restated_spoa_backtrack(seed):
             lcp = next((i for i in range(m) if ref[i] != alt[i]), m)
             checked["slid"] += lcp > max(0, m - next((i for i in range(m) if ref[-1 - i] != alt[-1 - i]), m))
     assert checked["sub"] >= 10 and checked["indel"] >= 20 and checked["slid"] >= 5, checked
+
+
+def _closed_form_later(base, preds, order, Q):
+    """The closed form DESIGN.md section 9 works out for LATER haplotypes (measured on the GPU and not kept: the rounds of
+    the POA stage are bound by a fill's latency, not by how many fills they hold): Q on a position-structured graph, best
+    gapless path with <= 1 mismatch; None otherwise.  Explicit gapless scores Hd and the backtrack's rule (first predecessor
+    in in-edge order with Hd(pred) + score == Hd(node); end node = first maximum among the sinks in rank order)."""
+    V, n = len(base), len(Q)
+    succ = [[] for _ in range(V)]
+    for v, ps in enumerate(preds):
+        for p in ps:
+            succ[p].append(v)
+    depth, Hd = [-1] * V, [0] * V
+    for v in order:
+        ds = {depth[p] for p in preds[v]}
+        if len(ds) > 1:
+            return None  # not position-structured
+        d = ds.pop() + 1 if ds else 0
+        if d >= n:
+            return None
+        depth[v] = d
+        Hd[v] = (0 if base[v] == Q[d] else -6) + (max(Hd[p] for p in preds[v]) if preds[v] else 0)
+    sinks = [v for v in order if not succ[v]]
+    if any(depth[v] != n - 1 for v in sinks):
+        return None
+    best = sinks[0]
+    for v in sinks:
+        if Hd[v] > Hd[best]:
+            best = v
+    if Hd[best] < -6:
+        return None
+    path, cur = [], best
+    while True:
+        path.append((cur, depth[cur]))
+        if not preds[cur]:
+            break
+        s = 0 if base[cur] == Q[depth[cur]] else -6
+        cur = next(p for p in preds[cur] if Hd[p] + s == Hd[cur])
+    return path[::-1]
+
+
+@pytest.mark.parametrize("seed", [0, 1])
+def test_poa_closed_form_for_later_haplotypes_equals_the_restated_spoa_backtrack(seed):
+    """graphs of 2-5 same-length haplotypes that differ by substitutions at shared, tri-allelic and adjacent sites; the
+    last haplotype's alignment by the gapless closed form (<= 1 mismatch against its best path) equals the oracle's"""
+    rng = np.random.default_rng(9300 + seed)
+    applied = with_mismatch = 0
+    for trial in range(150):
+        n = int(rng.integers(60, 160))
+        ref = bytearray(rand_dna(rng, n))
+        sites = sorted(rng.choice(n, size=int(rng.integers(1, 6)), replace=False).tolist())
+        if rng.random() < 0.4 and len(sites) >= 2 and sites[0] + 1 < n:
+            sites[1] = sites[0] + 1
+        if rng.random() < 0.3:
+            sites[0] = 0 if rng.random() < 0.5 else n - 1
+        alt1 = {q: (ord("A") if ref[q] != ord("A") else ord("C")) for q in sites}
+        alt2 = {q: next(c for c in b"GTCA" if c != ref[q] and c != alt1[q]) for q in sites}
+        haps = [bytes(ref)]
+        for _ in range(int(rng.integers(2, 5))):
+            a = bytearray(ref)
+            for q in sites:
+                r = rng.random()
+                if r < 0.35:
+                    a[q] = alt1[q]
+                elif r < 0.5:
+                    a[q] = alt2[q]
+            if bytes(a) not in haps:
+                haps.append(bytes(a))
+        if len(haps) < 3:
+            continue
+        base, preds, order, pairs, dp_score = poa_dump(haps)
+        want = _closed_form_later(base, preds, order, haps[-1])
+        if want is None:
+            continue
+        applied += 1
+        with_mismatch += dp_score == -6
+        assert pairs == want, (trial, pairs[:6], want[:6])
+        assert dp_score in (0, -6)
+    assert applied >= 60 and with_mismatch >= 15, (applied, with_mismatch)
