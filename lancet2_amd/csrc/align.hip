@@ -11,7 +11,9 @@
 // (caller/variant_call.cpp:316-345).
 //
 // Kernels:
+//   k_read_planes   every read as three bit planes, once per batch
 //   k_plan          per window: which haplotype slots get aligned, pair counts, the (window, haplotype) work list
+//   k_plan_reads    wavefront per window: read -> window map, longest read, which samples are CASE samples
 //   k_vote          workgroup per (window, haplotype): 11-mer chained index + haplotype bit planes in LDS; wave per
 //                   read: shared 11-mers vote for their diagonal (unanimous votes skip the histogram); the extreme
 //                   seed diagonals give the search region; the three gapless certificates settle most pairs right
@@ -21,13 +23,14 @@
 //                   i16x2 in W+1 registers, row body fully unrolled (lean / general variant per wavefront and row),
 //                   haplotype segment 4 bit/base in LDS, traceback nibbles written to HBM coalesced as
 //                   [row][word][lane]; per-lane traceback -> CIGAR.  W = 33 .. 129 cells: a 150-base read needs 39 +
-//                   the spread of its seed diagonals.
+//                   the spread of its seed diagonals.  k_align_reg2: two classes of the same register budget side by side
+//                   in one launch (a launch lasts its 150 dependent rows however few pairs it holds).
 //   k_align_wave    one WAVEFRONT per pair for wider regions (seeds spread by tandem repeats / duplications): 64 cells
 //                   of a row at a time, the horizontal gap chain closed with a wave prefix maximum, rows in LDS
 //   k_align_gen     last resort for regions no LDS row holds: lane per pair, row in HBM
 //   k_assign     one lane per read: best allele per variant over the haplotypes of each component
 //   k_evidence   first read per (variant, sample, allele, qname) counts, by strand
-//   k_qual       SOLOR site quality
+//   k_qual       SOLOR site quality; germline PL / GQ / QUAL (variant-major: slot v of 64 consecutive windows per wavefront)
 #include <algorithm>
 #include <cstdlib>
 #include <vector>
