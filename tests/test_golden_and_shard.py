@@ -144,3 +144,13 @@ def test_bench_algorithmic_bytes_are_the_surveys():
     assert abs(mb["build"] - 1.98) < 0.02 and abs(mb["clean"] - 0.36) < 0.03
     assert abs(mb["poa"] - 0.03) < 0.005 and abs(mb["genotype"] - 0.39) < 0.01
     assert abs(sum(mb.values()) - 2.8) < 0.1
+
+
+def test_concordance_tool_self_test():
+    """tools/concordance.py (engine records vs a Lancet2 VCF, for when a built reference is at hand) compares call sets and
+    QUALs the way it says"""
+    import subprocess
+    import sys as _sys
+    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "concordance.py")
+    out = subprocess.check_output([_sys.executable, tool, "--self-test"], text=True)
+    assert "self-test ok" in out
