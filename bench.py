@@ -106,12 +106,11 @@ NOHINT_EVERY = 50  # set from --nohint-every before any window is made (module g
 
 
 def _gen_chunk(job):
-    config, first, count, str_every = job
+    config, first, count, str_every = job  # `first` may also be the list of the chunk's window indices (count ignored)
     from lancet2_amd import capi, synth
     kw = dict(synth.CONFIGS[config])
     wins = []
-    for i in range(count):
-        idx = first + i
+    for idx in (first if isinstance(first, (list, tuple)) else range(first, first + count)):
         k2 = dict(kw)
         if str_every and idx % str_every == str_every - 1:
             k2["str_unit"] = STR_UNITS[(idx // str_every) % len(STR_UNITS)]
@@ -149,12 +148,15 @@ def concat_batches(parts):
     return out, n, nr
 
 
-def make_windows(config, count, first, str_every, workers):
-    """seeded windows [first, first + count) of `config`, synthesised by a pool of processes (forked BEFORE the GPU is
-    initialised); the result does not depend on the number of workers"""
+def make_windows(config, count, first, str_every, workers, indices=None):
+    """seeded windows [first, first + count) of `config` -- or the windows `indices` names, in that order -- synthesised by
+    a pool of processes (forked BEFORE the GPU is initialised); the result does not depend on the number of workers"""
     import multiprocessing as mp
     per = 32
-    jobs = [(config, first + o, min(per, count - o), str_every) for o in range(0, count, per)]
+    if indices is None:
+        jobs = [(config, first + o, min(per, count - o), str_every) for o in range(0, count, per)]
+    else:
+        jobs = [(config, list(indices[o:o + per]), 0, str_every) for o in range(0, len(indices), per)]
     workers = max(1, min(workers, len(jobs)))
     if workers == 1:
         parts = [_gen_chunk(j) for j in jobs]
@@ -261,9 +263,13 @@ def main():
 
     # ---- everything that forks happens before the GPU is initialised ----
     distinct = min(args.distinct, args.windows)
-    first = 10_000 + rank * 1_000_000
+    # static sharding of ONE seeded window list over the ranks: window i -> rank i mod G (lancet2_amd/shard.py);
+    # with one rank these are the windows 10 000 ... 10 000 + distinct - 1
+    from lancet2_amd.shard import shard_indices
+    first = 10_000
+    mine = [first + i for i in shard_indices(distinct * world, rank, world)]
     t_gen = time.perf_counter()
-    arrs0, n0, nr0 = make_windows(args.config, distinct, first, args.str_every, workers)
+    arrs0, n0, nr0 = make_windows(args.config, distinct, first, args.str_every, workers, indices=mine)
     also_arrs = None
     other = {"C3": "C2", "C2": "C3"}.get(args.config)
     if other and world == 1 and not args.no_also:
