@@ -854,6 +854,24 @@ __global__ __launch_bounds__(kBT) void k_support(DBatch b, GraphWs ws, u32* max_
         if (ws.rd_flag[r0 + gm] || si.nk > 32u * kMaskWords) generic = true;
       }
     }
+    // the instance words of both mates in flight at once (reads of up to 128 k-mers with cached records): one round trip
+    // per group instead of one per 64 k-mers of each mate
+    u32 pre00 = 0, pre01 = 0, pre10 = 0, pre11 = 0;
+    bool have_pre = cached && gsize <= 2;
+    for (u32 gm = 0; gm < gsize && have_pre; ++gm) {
+      u32 const nkc = c_meta[s_idx + gm] >> 16;
+      if (nkc == 0xFFFFu || nkc > 128u) have_pre = false;
+    }
+    if (have_pre) {
+      u32 const nka = c_meta[s_idx] >> 16, iba = c_ib[s_idx];
+      pre00 = lane < nka ? inst_slot[iba + lane] : 0u;
+      pre01 = 64u + lane < nka ? inst_slot[iba + 64u + lane] : 0u;
+      if (gsize == 2) {
+        u32 const nkb = c_meta[s_idx + 1] >> 16, ibb = c_ib[s_idx + 1];
+        pre10 = lane < nkb ? inst_slot[ibb + lane] : 0u;
+        pre11 = 64u + lane < nkb ? inst_slot[ibb + 64u + lane] : 0u;
+      }
+    }
     i32 hint0 = 0;
     u32 nk0 = 0;
     unsigned long long m0[kMaskWords / 2];  // offsets of the first mate that were counted
@@ -887,7 +905,8 @@ __global__ __launch_bounds__(kBT) void k_support(DBatch b, GraphWs ws, u32* max_
       }
       for (u32 ob = 0; ob < si.nk; ob += 64) {
         u32 const o = ob + lane;
-        u32 const word = o < si.nk ? inst_slot[ibase + o] : 0u;
+        u32 const word = have_pre ? (gm == 0 ? (ob == 0 ? pre00 : pre01) : (ob == 0 ? pre10 : pre11))
+                                  : (o < si.nk ? inst_slot[ibase + o] : 0u);
         bool const ef = (word & kInstErrFree) != 0;
         bool const to_gen = ef && (generic || !(word & kInstFast));
         if (to_gen) inst_slot[ibase + o] = word | kInstGen;  // exact handling by the mate-mer set kernels
