@@ -51,6 +51,12 @@ constexpr u32 kSlowCap = 256; // rows with a cached predecessor-row list
 constexpr i32 kNegInf = static_cast<i32>(0x80000000u) + 1024;
 constexpr i32 M_ = 0, N_ = -6, G_ = -6, E_ = -2, Q_ = -26, C_ = -1;  // msa_builder.h:72-77
 
+// The band tier k_msa can fill on its own wave 0 (tail of a batch, MA_POA_BAND=1); every tier has its k_msa_band.
+#ifndef MA_POA_TIER0
+#define MA_POA_TIER0 1
+#endif
+constexpr u32 kTierIn = MA_POA_TIER0;
+
 constexpr u32 RI_FAST = 1u << 11;     // single predecessor == previous rank
 constexpr u32 RI_SLOWTAB = 1u << 12;  // predecessor rows cached in slowpred[info >> 16]
 constexpr u32 RI_STORE = 1u << 13;    // a later row reads this row back from HBM
@@ -60,7 +66,10 @@ struct PoaWs {
   u32 max_l;         // longest haplotype of the batch
   u32 w_stride;      // i32 per stored row and matrix
   u32 row_slots;     // stored rows per window
-  u32 use_band;      // try the 256-column banded fill first (see launch_msa: MA_POA_BAND)
+  u32 use_band;      // try the banded fills first (see launch_msa: MA_POA_BAND)
+  u32 tier0;         // columns per lane of the first band tier: 1 / 2 / 4 = 64 / 128 / 256 columns (MA_POA_TIER0)
+  u32* tier_stats;   // [8] fills per tier 64/128/256 + (at 4) failed certificates per tier; null unless MA_VERBOSE
+  u32* pending_ctr;  // split mode: windows that yielded in the current k_msa launch
   u32 no_direct;     // MA_POA_NO_DIRECT: every alignment goes through a fill (tests: the shortcut changes nothing)
   size_t code_cells; // u16 per window
   size_t row_cells;  // i32 per window
@@ -86,7 +95,8 @@ struct WgState {
   u32 nn, nseq, nrank, overflow;
   i32 seq_first[16];
   u32 mode, V, L, cw, naln, nslow;
-  u32 band, band_fail;  // this alignment tries the 256-column band first / its traceback ran off the band
+  u32 band, band_fail;  // band tier of this alignment's current attempt (columns per lane, 0 = full fill) / its traceback ran off the band
+  u32 filled;           // split mode: k_msa_band has filled the pending alignment at tier `band`
   i32 edge_max;         // maximum H over the band's exit cells
   i32 best;
   u32 best_row;
@@ -121,6 +131,7 @@ struct GL {  // LDS layout of one window's POA graph + scratch
   LdsArr<u16> stack;
   LdsArr<u8> marks, ignored;
   u32 stack_cap;
+  __device__ __forceinline__ u32 ubyte(const u8* p) const { return *p; }
 };
 
 __host__ __device__ inline size_t poa_lds_bytes(u32 pn, u32 ml) {
@@ -431,6 +442,27 @@ __device__ __forceinline__ i32 wave_incl_max(i32 x, i32 ident) {
   return x;
 }
 __device__ __forceinline__ i32 wave_shr1(i32 x, i32 ident) { return dpp_mov<0x138, 0xF>(x, ident); }  // wave_shr:1
+
+// Decision codes live in two byte planes of one window's code area: plane A (bits 0-5 of the code: move, extension
+// flags) is written for every row, plane B (bits 6-9: the predecessor indices) only for rows that are not FAST -- a FAST
+// row has a single predecessor, index 0.  Half the bytes of one u16 per cell, and the traceback reads plane B only when
+// it stands on such a row.
+template <int CW>
+__device__ __forceinline__ void store_code_bytes(u8* dst, const u32 (&cd)[CW], u32 shift) {
+  if constexpr (CW % 4 == 0) {
+#pragma unroll
+    for (int c = 0; c < CW; c += 4)
+      *reinterpret_cast<u32*>(dst + c) = ((cd[c] >> shift) & 0x3Fu) | (((cd[c + 1] >> shift) & 0x3Fu) << 8) |
+                                         (((cd[c + 2] >> shift) & 0x3Fu) << 16) | (((cd[c + 3] >> shift) & 0x3Fu) << 24);
+  } else if constexpr (CW % 2 == 0) {
+#pragma unroll
+    for (int c = 0; c < CW; c += 2)
+      *reinterpret_cast<u16*>(dst + c) = static_cast<u16>(((cd[c] >> shift) & 0x3Fu) | (((cd[c + 1] >> shift) & 0x3Fu) << 8));
+  } else {
+#pragma unroll
+    for (int c = 0; c < CW; ++c) dst[c] = static_cast<u8>((cd[c] >> shift) & 0x3Fu);
+  }
+}
 
 // ---- the row-synchronous fill: decision codes + the rows later rows must read back ----
 // All 256 lanes work on the same DP row; lane l owns the CW columns 1 + l CW .. .  The vertical and
@@ -748,21 +780,10 @@ __device__ void poa_fill(GL const& g, PoaWs const& ws, u16* codes, i32* rows, i3
     hl2 = hl1;
     hl1 = hN;
     if (lane_on) {
-      // decision codes, row-major: one store of the wave covers 64 * CW * 2 contiguous bytes
-      u32* cp = reinterpret_cast<u32*>(codes + static_cast<size_t>(i) * W + static_cast<size_t>(gl) * CW);
-      if constexpr (CW % 8 == 0) {
-#pragma unroll
-        for (int c = 0; c < CW; c += 8)
-          *reinterpret_cast<uint4*>(cp + c / 2) = make_uint4(cd[c] | (cd[c + 1] << 16), cd[c + 2] | (cd[c + 3] << 16),
-                                                             cd[c + 4] | (cd[c + 5] << 16), cd[c + 6] | (cd[c + 7] << 16));
-      } else if constexpr (CW % 4 == 0) {
-#pragma unroll
-        for (int c = 0; c < CW; c += 4)
-          *reinterpret_cast<uint2*>(cp + c / 2) = make_uint2(cd[c] | (cd[c + 1] << 16), cd[c + 2] | (cd[c + 3] << 16));
-      } else {
-#pragma unroll
-        for (int c = 0; c < CW; c += 2) cp[c / 2] = cd[c] | (cd[c + 1] << 16);
-      }
+      // decision codes, row-major byte planes: one store of the wave covers 64 * CW contiguous bytes
+      u8* const cp = reinterpret_cast<u8*>(codes) + static_cast<size_t>(i) * W + static_cast<size_t>(gl) * CW;
+      store_code_bytes<CW>(cp, cd, 0);
+      if (!fast) store_code_bytes<CW>(cp + ws.code_cells, cd, 6);
       if (store) {
         u32 const slot = g.rowslot[i];
         i32* rb = rows + static_cast<size_t>(slot) * 3 * ws.w_stride + static_cast<size_t>(gl) * CW;
@@ -832,14 +853,15 @@ __device__ __forceinline__ void wave_shr1_inplace(i32& x, i32 fill, bool first_l
   x = first_lane ? fill : x;
 }
 
-template <class G>
-__device__ void poa_fill_band(G const& g, PoaWs const& ws, u16* codes, i32* rows, i32* hlast, u32 V, u32 L, int lane,
-                              const u8* seq, i32* edge_out) {
-  constexpr int CW = 4;
+template <int CW, class G>
+__device__ void poa_fill_band(G const& g, u32 const w_stride, size_t const plane, u16* codes, i32* rows, i32* hlast, u32 V,
+                              u32 L, int lane, const u8* seq, i32* edge_out) {
+  static_assert(CW == 1 || CW == 2 || CW == 4, "band tiers: 64, 128 or 256 columns");
+  constexpr u32 BW = 64u * CW;  // columns of the band
   constexpr i32 NEG = kScanIdent;
   i32 jr[CW];  // this lane's columns relative to the window
 #pragma unroll
-  for (int c = 0; c < CW; ++c) jr[c] = 4 * lane + c;
+  for (int c = 0; c < CW; ++c) jr[c] = CW * lane + c;
   i32 HA[CW], FA[CW], OA[CW], HB[CW], FB[CW], OB[CW];  // the two previous rows, roles alternating (see `row`)
 #pragma unroll
   for (int c = 0; c < CW; ++c) HA[c] = FA[c] = OA[c] = HB[c] = FB[c] = OB[c] = kNegInf;
@@ -852,7 +874,7 @@ __device__ void poa_fill_band(G const& g, PoaWs const& ws, u16* codes, i32* rows
   auto load_sc = [&]() {
 #pragma unroll
     for (int c = 0; c < CW; ++c) {
-      u32 const j = j0 + 4u * lane + c;
+      u32 const j = j0 + static_cast<u32>(CW) * lane + c;
       sc[c] = (j >= 1 && j <= L) ? seq[j - 1] : 0u;
     }
   };
@@ -862,8 +884,8 @@ __device__ void poa_fill_band(G const& g, PoaWs const& ws, u16* codes, i32* rows
   auto load_sc_in = [&]() {
 #pragma unroll
     for (int c = 0; c < CW; ++c) {
-      u32 const j = j0 + 256 + c;
-      sc_in[c] = j <= L ? seq[j - 1] : 0u;
+      u32 const j = j0 + BW + c;
+      sc_in[c] = j <= L ? g.ubyte(seq + (j - 1)) : 0u;
     }
   };
   load_sc_in();
@@ -884,11 +906,11 @@ __device__ void poa_fill_band(G const& g, PoaWs const& ws, u16* codes, i32* rows
     }
     // ---- slide the register rows to this row's window ----
     if (__builtin_expect(j0_new != j0, 0)) {  // (one row in four: the register copies belong on this side)
-      i32 const sh = (static_cast<i32>(j0_new) - static_cast<i32>(j0)) / 4;  // lanes; > 0: window moves right
+      i32 const sh = (static_cast<i32>(j0_new) - static_cast<i32>(j0)) / CW;  // lanes; > 0: window moves right
       // columns that fall off: they had no successor inside the band
       {
         bool const dropped = sh > 0 ? lane < sh : lane >= 64 + sh;
-        u32 const jbo = j0 + 4u * lane;
+        u32 const jbo = j0 + static_cast<u32>(CW) * lane;
         if (dropped) {
 #pragma unroll
           for (int c = 0; c < CW; ++c)
@@ -910,12 +932,12 @@ __device__ void poa_fill_band(G const& g, PoaWs const& ws, u16* codes, i32* rows
           wave_shl1_inplace(t, static_cast<i32>(sc_in[c]), lane == 63);
           sc[c] = static_cast<u32>(t);
         }
-        j0 += 4;
+        j0 += CW;
         load_sc_in();
       }
       if (j0 > j0_new) {  // rare: the backbone coordinate steps back
         do {
-          j0 -= 4;
+          j0 -= CW;
 #pragma unroll
           for (int c = 0; c < CW; ++c) {
             wave_shr1_inplace(H1[c], kNegInf, lane == 0);
@@ -933,7 +955,7 @@ __device__ void poa_fill_band(G const& g, PoaWs const& ws, u16* codes, i32* rows
         load_sc_in();
       }
     }
-    u32 const jb = j0 + 4u * lane;
+    u32 const jb = j0 + static_cast<u32>(CW) * lane;
     // ---- vertical + diagonal part ----
     i32 hh[CW], ff[CW], oo[CW], hmv[CW];
     // H(pr, jb - 1) from the left neighbour lane's last column, column 0 at the matrix edge, -inf at the band edge
@@ -945,39 +967,51 @@ __device__ void poa_fill_band(G const& g, PoaWs const& ws, u16* codes, i32* rows
     // a stored row restricted to this window (its own window may sit elsewhere)
     auto fetch_store = [&](u32 pr, i32(&th)[CW], i32(&tf)[CW], i32(&to)[CW], i32& thd) {
       u32 const pj0 = g.rowj0[pr];
-      int const d = (static_cast<i32>(j0) - static_cast<i32>(pj0)) / 4;  // this lane reads the stored lane l + d
+      int const d = (static_cast<i32>(j0) - static_cast<i32>(pj0)) / CW;  // this lane reads the stored lane l + d
       int const sl = lane + d;
       bool const in = sl >= 0 && sl < 64;
       u32 const slot = g.rowslot[pr];
-      const i32* base = rows + static_cast<size_t>(slot) * 3 * ws.w_stride;
-      int4 vh = make_int4(kNegInf, kNegInf, kNegInf, kNegInf), vf = vh, vo = vh;
+      const i32* base = rows + static_cast<size_t>(slot) * 3 * w_stride;
+#pragma unroll
+      for (int c = 0; c < CW; ++c) th[c] = tf[c] = to[c] = kNegInf;
       if (in) {
-        vh = *reinterpret_cast<const int4*>(base + 4 * sl);
-        vf = *reinterpret_cast<const int4*>(base + ws.w_stride + 4 * sl);
-        vo = *reinterpret_cast<const int4*>(base + 2 * static_cast<size_t>(ws.w_stride) + 4 * sl);
+        if constexpr (CW == 4) {
+          int4 const vh = *reinterpret_cast<const int4*>(base + 4 * sl);
+          int4 const vf = *reinterpret_cast<const int4*>(base + w_stride + 4 * sl);
+          int4 const vo = *reinterpret_cast<const int4*>(base + 2 * static_cast<size_t>(w_stride) + 4 * sl);
+          th[0] = vh.x; th[1] = vh.y; th[2] = vh.z; th[3] = vh.w;
+          tf[0] = vf.x; tf[1] = vf.y; tf[2] = vf.z; tf[3] = vf.w;
+          to[0] = vo.x; to[1] = vo.y; to[2] = vo.z; to[3] = vo.w;
+        } else if constexpr (CW == 2) {
+          int2 const vh = *reinterpret_cast<const int2*>(base + 2 * sl);
+          int2 const vf = *reinterpret_cast<const int2*>(base + w_stride + 2 * sl);
+          int2 const vo = *reinterpret_cast<const int2*>(base + 2 * static_cast<size_t>(w_stride) + 2 * sl);
+          th[0] = vh.x; th[1] = vh.y;
+          tf[0] = vf.x; tf[1] = vf.y;
+          to[0] = vo.x; to[1] = vo.y;
+        } else {
+          th[0] = base[sl];
+          tf[0] = base[w_stride + sl];
+          to[0] = base[2 * static_cast<size_t>(w_stride) + sl];
+        }
       }
-      th[0] = vh.x; th[1] = vh.y; th[2] = vh.z; th[3] = vh.w;
-      tf[0] = vf.x; tf[1] = vf.y; tf[2] = vf.z; tf[3] = vf.w;
-      to[0] = vo.x; to[1] = vo.y; to[2] = vo.z; to[3] = vo.w;
       // H(pr, jb - 1): the stored column just left of this lane's first one
       i32 hd = kNegInf;
       if (jb == 1) {
         hd = col0_h(g.rowdepth[pr]);
       } else if (sl >= 1 && sl <= 64) {
-        hd = base[4 * sl - 1];
+        hd = base[CW * sl - 1];
       }
       thd = hd;
       // stored columns this window does not cover are exits of row pr towards this row
-      int const ml = d > 0 ? lane : (d < 0 ? lane : -1);  // stored lane inspected by this lane
-      if (d != 0 && ml >= 0) {
+      if (d != 0) {
+        int const ml = lane;  // stored lane inspected by this lane
         bool const dropped = d > 0 ? ml < d : ml >= 64 + d;
         if (dropped) {
-          int4 const xh = *reinterpret_cast<const int4*>(base + 4 * ml);
-          u32 const xj = pj0 + 4u * ml;
-          if (xj <= L) edge = max(edge, xh.x);
-          if (xj + 1 <= L) edge = max(edge, xh.y);
-          if (xj + 2 <= L) edge = max(edge, xh.z);
-          if (xj + 3 <= L) edge = max(edge, xh.w);
+          u32 const xj = pj0 + static_cast<u32>(CW) * ml;
+#pragma unroll
+          for (int c = 0; c < CW; ++c)
+            if (xj + c <= L) edge = max(edge, base[CW * ml + c]);
         }
       }
     };
@@ -997,7 +1031,7 @@ __device__ void poa_fill_band(G const& g, PoaWs const& ws, u16* codes, i32* rows
           tf[c] = F1[c];
           to[c] = O1[c];
         }
-        thd = left_of(H1[3], pr);
+        thd = left_of(H1[CW - 1], pr);
       } else if (pr + 2 == i) {
 #pragma unroll
         for (int c = 0; c < CW; ++c) {
@@ -1005,14 +1039,14 @@ __device__ void poa_fill_band(G const& g, PoaWs const& ws, u16* codes, i32* rows
           tf[c] = F2[c];
           to[c] = O2[c];
         }
-        thd = left_of(H2[3], pr);
+        thd = left_of(H2[CW - 1], pr);
       } else {
         fetch_store(pr, th, tf, to, thd);
       }
     };
     u32 const npe = np ? np : 1u;
     if (fast) {
-      i32 hd = left_of(H1[3], i - 1);
+      i32 hd = left_of(H1[CW - 1], i - 1);
 #pragma unroll
       for (int c = 0; c < CW; ++c) {
         i32 const ph = H1[c];
@@ -1043,11 +1077,11 @@ __device__ void poa_fill_band(G const& g, PoaWs const& ws, u16* codes, i32* rows
         }
       }
       // row 0 ground that this window does not cover (a node without in-edges hangs off the virtual start row)
-      if (np == 0 && j0 + 256 <= L) edge = max(edge, row0_h(j0 + 256));
+      if (np == 0 && j0 + BW <= L) edge = max(edge, row0_h(j0 + BW));
       if (np == 0 && j0 > 1) edge = max(edge, row0_h(1));
     }
     // the previous rows' cell whose diagonal successor would be the column right of this window
-    if (lane == 63 && jb + 3 < L) edge = max(edge, max(H1[3], H2[3]));
+    if (lane == 63 && jb + CW - 1 < L) edge = max(edge, max(H1[CW - 1], H2[CW - 1]));
     // column 0 of this row is an exit when the window does not start at column 1
     if (j0 > 1) edge = max(edge, h0);
     // ---- prefix maxima over the window (column 0 enters through lane 0 when the window starts at column 1) ----
@@ -1093,7 +1127,7 @@ __device__ void poa_fill_band(G const& g, PoaWs const& ws, u16* codes, i32* rows
       hh[c] = max(m, max(e, q));
     }
     // ---- (H, E, Q) of the column to the left of this lane's first column ----
-    i32 hN = wave_shr1(hh[3], kNegInf), eN = wave_shr1(ee[3], kNegInf), qN = wave_shr1(qq[3], kNegInf);
+    i32 hN = wave_shr1(hh[CW - 1], kNegInf), eN = wave_shr1(ee[CW - 1], kNegInf), qN = wave_shr1(qq[CW - 1], kNegInf);
     if (lane == 0) {
       hN = jb == 1 ? h0 : kNegInf;
       eN = kNegInf;
@@ -1139,7 +1173,9 @@ __device__ void poa_fill_band(G const& g, PoaWs const& ws, u16* codes, i32* rows
         }
       }
       u32 dmask = 0, umask = 0, eumask = 0, usmask = 0, uhmask = 0;
-      u32 xs[CW] = {0, 0, 0, 0};
+      u32 xs[CW];
+#pragma unroll
+      for (int c = 0; c < CW; ++c) xs[c] = 0;
       for (u32 x = 0; x < npe; ++x) {
         u32 const pr = np ? pred_row(g, i, info_cur, x) : 0u;
         i32 th[CW], tf[CW], to[CW], hd;
@@ -1188,24 +1224,37 @@ __device__ void poa_fill_band(G const& g, PoaWs const& ws, u16* codes, i32* rows
       }
     }
     // right exit of this row: the last window column when the haplotype goes on beyond it
-    if (lane == 63 && jb + 3 < L) edge = max(edge, hh[3]);
-    *reinterpret_cast<uint2*>(codes + static_cast<size_t>(i) * 256 + 4u * lane) =
-        make_uint2(cd[0] | (cd[1] << 16), cd[2] | (cd[3] << 16));
+    if (lane == 63 && jb + CW - 1 < L) edge = max(edge, hh[CW - 1]);
+    {
+      u8* const cp = reinterpret_cast<u8*>(codes) + static_cast<size_t>(i) * BW + static_cast<u32>(CW) * lane;
+      store_code_bytes<CW>(cp, cd, 0);
+      if (!fast) store_code_bytes<CW>(cp + plane, cd, 6);
+    }
     if (store) {
       u32 const slot = g.rowslot[i];
-      i32* rb = rows + static_cast<size_t>(slot) * 3 * ws.w_stride + 4u * lane;
-      *reinterpret_cast<int4*>(rb) = make_int4(hh[0], hh[1], hh[2], hh[3]);
-      *reinterpret_cast<int4*>(rb + ws.w_stride) = make_int4(ff[0], ff[1], ff[2], ff[3]);
-      *reinterpret_cast<int4*>(rb + 2 * static_cast<size_t>(ws.w_stride)) = make_int4(oo[0], oo[1], oo[2], oo[3]);
+      i32* rb = rows + static_cast<size_t>(slot) * 3 * w_stride + static_cast<u32>(CW) * lane;
+      if constexpr (CW == 4) {
+        *reinterpret_cast<int4*>(rb) = make_int4(hh[0], hh[1], hh[2], hh[3]);
+        *reinterpret_cast<int4*>(rb + w_stride) = make_int4(ff[0], ff[1], ff[2], ff[3]);
+        *reinterpret_cast<int4*>(rb + 2 * static_cast<size_t>(w_stride)) = make_int4(oo[0], oo[1], oo[2], oo[3]);
+      } else if constexpr (CW == 2) {
+        *reinterpret_cast<int2*>(rb) = make_int2(hh[0], hh[1]);
+        *reinterpret_cast<int2*>(rb + w_stride) = make_int2(ff[0], ff[1]);
+        *reinterpret_cast<int2*>(rb + 2 * static_cast<size_t>(w_stride)) = make_int2(oo[0], oo[1]);
+      } else {
+        rb[0] = hh[0];
+        rb[w_stride] = ff[0];
+        rb[2 * static_cast<size_t>(w_stride)] = oo[0];
+      }
       __threadfence_block();  // other lanes read it back (lane offsets differ between windows)
     }
-    if (L >= j0 && L <= j0 + 255 && static_cast<u32>(lane) == (L - j0) / 4) {
-      u32 const cL = (L - j0) & 3u;
+    if (L >= j0 && L < j0 + BW && static_cast<u32>(lane) == (L - j0) / CW) {
+      u32 const cL = (L - j0) % CW;
       i32 v = hh[0];
 #pragma unroll
       for (int c = 1; c < CW; ++c) v = (static_cast<u32>(c) == cL) ? hh[c] : v;
       hlast[i] = v;
-    } else if (lane == 0 && !(L >= j0 && L <= j0 + 255)) {
+    } else if (lane == 0 && !(L >= j0 && L < j0 + BW)) {
       hlast[i] = kNegInf;
     }
     // row i takes the place of row i - 2
@@ -1247,20 +1296,27 @@ __device__ __forceinline__ EdgeVals edge_vals(GL const& g, u32 i, u32 j) {  // c
   return v;
 }
 
-__device__ u32 poa_traceback(GL const& g, const u16* codes, u32 cw, u32 V, u32 L, u32 best_row, bool have_end, int lane,
-                             bool band) {
+// bw: columns of the band the codes were written for (64, 128 or 256); 0 = the full row-synchronous fill
+__device__ u32 poa_traceback(GL const& g, const u16* codes16, size_t const plane, u32 cw, u32 V, u32 L, u32 best_row,
+                             bool have_end, int lane, u32 bw) {
+  const u8* const codes = reinterpret_cast<const u8*>(codes16);
+  bool const band = bw != 0;
   u32 const nl = (L + cw - 1) / cw;
   bool off_band = false;  // band mode: a cell outside its row's window was needed -> the caller falls back
   auto code_at = [&](u32 i, u32 j) -> u32 {  // i >= 1, j >= 1
     if (band) {
       u32 const j0 = g.rowj0[i];
-      if (j < j0 || j > j0 + 255) {
+      if (j < j0 || j >= j0 + bw) {
         off_band = true;
         return 2u;  // a plain "left" move: lets the caller's loops terminate
       }
-      return codes[static_cast<size_t>(i) * 256 + (j - j0)];
+      size_t const at = static_cast<size_t>(i) * bw + (j - j0);
+      u32 const a = codes[at];
+      return (g.rowinfo[i] & RI_FAST) ? a : (a | (static_cast<u32>(codes[plane + at]) << 6));
     }
-    return codes[static_cast<size_t>(i) * (nl * cw) + (j - 1)];
+    size_t const at = static_cast<size_t>(i) * (nl * cw) + (j - 1);
+    u32 const a = codes[at];
+    return (g.rowinfo[i] & RI_FAST) ? a : (a | (static_cast<u32>(codes[plane + at]) << 6));
   };
   u32 naln = 0;
   bool overflow = false;
@@ -1469,6 +1525,15 @@ __device__ u32 poa_traceback(GL const& g, const u16* codes, u32 cw, u32 V, u32 L
   return naln;
 }
 
+// band window of a row: 64 cwb columns centred on the node's backbone coordinate, j0 = 1 mod cwb
+__device__ __forceinline__ u16 band_j0(u32 npos, u32 L, u32 cwb) {
+  u32 const bw = 64u * cwb;
+  i32 const want = static_cast<i32>(npos) + 1 - static_cast<i32>(bw / 2);
+  u32 const j0 = ((static_cast<u32>(max(want, 1)) - 1u) & ~(cwb - 1u)) + 1u;
+  u32 const jmax = L > bw ? (((L - bw) + cwb - 1u) & ~(cwb - 1u)) + 1u : 1u;
+  return static_cast<u16>(min(j0, jmax));
+}
+
 struct MsaArgs {
   DBatch b;
   ma_asm_out_t a;
@@ -1476,7 +1541,8 @@ struct MsaArgs {
   PoaWs ws;
   ma_params_t prm;
   int win0;
-  u32 round;  // split mode: 0 = start, > 0 = resume from the LDS image
+  u32 round;   // split mode: 0 = start, > 0 = resume from the LDS image
+  u32 finish;  // split mode: last launch -- every fill still to do runs inside k_msa (no more yields)
 };
 
 template <int CWMAX>
@@ -1537,6 +1603,7 @@ __global__ __launch_bounds__(kT, 2) void k_msa(MsaArgs A) {
   } else if (tid == 0) {
     ST.win_overflow = 0;
     ST.done = 0;
+    ST.filled = 0;
     ST.pending = 0;
     ST.c_cur = ST.h_cur = 0;
   }
@@ -1578,7 +1645,9 @@ __global__ __launch_bounds__(kT, 2) void k_msa(MsaArgs A) {
               mode = 2;
               ST.V = V;
               ST.cw = cw;
-              ST.band = (ws.use_band && L >= 400 && static_cast<size_t>(V + 1) * 256 <= ws.code_cells) ? 1u : 0u;
+              // first band tier (columns per lane: 64 / 128 / 256 columns), 0 = full fill only
+              u32 const t0 = ws.tier0;
+              ST.band = (ws.use_band && L >= 400 && static_cast<size_t>(V + 1) * 256 <= ws.code_cells) ? t0 : 0u;
             }
           }
         }
@@ -1708,12 +1777,7 @@ __global__ __launch_bounds__(kT, 2) void k_msa(MsaArgs A) {
         for (u32 x = 0; x < np; ++x)
           if (pr[x] + 1 != i && !(cw <= 8 && pr[x] + 2 == i)) g.rowslot[pr[x]] = 1;
         g.rowinfo[i] = info;
-        {  // band window of this row: 256 columns centred on the node's backbone coordinate, j0 = 1 mod 4
-          i32 const want = static_cast<i32>(g.npos[node]) + 1 - 128;
-          u32 j0 = ((static_cast<u32>(max(want, 1)) - 1u) & ~3u) + 1u;
-          u32 const jmax = L > 256 ? (((L - 256) + 3u) & ~3u) + 1u : 1u;
-          g.rowj0[i] = static_cast<u16>(min(j0, jmax));
-        }
+        g.rowj0[i] = band_j0(g.npos[node], L, ST.band ? ST.band : 4u);
       }
       __syncthreads();
       {
@@ -1776,12 +1840,14 @@ __global__ __launch_bounds__(kT, 2) void k_msa(MsaArgs A) {
       __syncthreads();
       if (ST.overflow) continue;
       PROF_ACC(0);
-      if (ws.split && ST.band && ST.nslow <= kSlowCap) {  // hand the fill to k_msa_band and come back afterwards
+      if (ws.split && !A.finish && ST.band && ST.nslow <= kSlowCap) {  // hand the fill to k_msa_band<tier> and come back afterwards
         if (tid == 0) {
           ST.c_cur = c;
           ST.h_cur = h;
           ST.pending = 1;
+          ST.filled = 0;
           ST.band_fail = 0;
+          atomicAdd(ws.pending_ctr, 1u);
           ST.nvars = nvars;
           ST.pool = pool;
           ST.var_overflow = overflow ? 1u : 0u;
@@ -1790,28 +1856,35 @@ __global__ __launch_bounds__(kT, 2) void k_msa(MsaArgs A) {
         break;
       }
       }  // !rh
-      // attempt 0: the 256-column band on one wavefront (exact when its certificate holds, see poa_fill_band);
-      // attempt 1: the full row-synchronous fill
-      for (int attempt = ST.band ? 0 : 1; attempt < 2; ++attempt) {
-        if (attempt == 0) {
-          if (!rh) {  // (split mode: k_msa_band has done this between the two launches)
+      // Tiers: the narrow band first (ws.tier0: 64 or 128 columns), then 256 columns, then the full row-synchronous
+      // fill.  A band is exact when its certificate holds (see poa_fill_band) and the traceback stays inside it; a
+      // tier that fails hands the alignment to the next one -- through k_msa_band again while the batch is in split
+      // rounds, inside this kernel (wave 0) in the last launch.
+      bool filled = rh && ST.filled;  // k_msa_band has filled tier ST.band between the two launches
+      bool const can_yield = ws.split && !A.finish && ST.nslow <= kSlowCap;
+      while (true) {
+        u32 tier = ST.band;
+        if (!filled && tier != kTierIn) tier = 0;  // inside this kernel: the narrow tier or the full fill
+        if (!filled) {
+          if (tier) {
             if (tid == 0) ST.band_fail = 0;
-            if (wave == 0) poa_fill_band(g, ws, codes, rows, hlast, V, L, lane, seq, &ST.edge_max);
-          }
-        } else {
-          if (cw == 4) {
-            poa_fill<4>(g, ws, codes, rows, hlast, V, L, tid, seq);
-          } else if constexpr (CWMAX > 4) {
-            if (cw == 6) {
-              poa_fill<6>(g, ws, codes, rows, hlast, V, L, tid, seq);
-            } else if (cw == 8) {
-              poa_fill<8>(g, ws, codes, rows, hlast, V, L, tid, seq);
-            } else if constexpr (CWMAX > 8) {
-              if (cw == 12) poa_fill<12>(g, ws, codes, rows, hlast, V, L, tid, seq);
-              else poa_fill<16>(g, ws, codes, rows, hlast, V, L, tid, seq);
+            if (wave == 0) poa_fill_band<static_cast<int>(kTierIn)>(g, ws.w_stride, ws.code_cells, codes, rows, hlast, V, L, lane, seq, &ST.edge_max);
+          } else {
+            if (cw == 4) {
+              poa_fill<4>(g, ws, codes, rows, hlast, V, L, tid, seq);
+            } else if constexpr (CWMAX > 4) {
+              if (cw == 6) {
+                poa_fill<6>(g, ws, codes, rows, hlast, V, L, tid, seq);
+              } else if (cw == 8) {
+                poa_fill<8>(g, ws, codes, rows, hlast, V, L, tid, seq);
+              } else if constexpr (CWMAX > 8) {
+                if (cw == 12) poa_fill<12>(g, ws, codes, rows, hlast, V, L, tid, seq);
+                else poa_fill<16>(g, ws, codes, rows, hlast, V, L, tid, seq);
+              }
             }
           }
         }
+        filled = false;
         __syncthreads();  // full fence: codes and hlast are read below
         PROF_ACC(1);
       // best end cell: first maximum, in rank order, over the nodes without out-edges
@@ -1855,19 +1928,42 @@ __global__ __launch_bounds__(kT, 2) void k_msa(MsaArgs A) {
           }
           __syncthreads();
         }
-        bool const band_now = attempt == 0;
-        bool const certified = !band_now || (ST.best_row != 0xFFFFFFFFu && ST.best - 32 > ST.edge_max);
+        bool const certified = !tier || (ST.best_row != 0xFFFFFFFFu && ST.best - 32 > ST.edge_max);
         if (wave == 0 && certified) {
           u32 const br = ST.best_row;
-          u32 const naln = poa_traceback(g, codes, cw, V, L, br == 0xFFFFFFFFu ? 0u : br, br != 0xFFFFFFFFu, lane, band_now);
+          u32 const naln = poa_traceback(g, codes, ws.code_cells, cw, V, L, br == 0xFFFFFFFFu ? 0u : br, br != 0xFFFFFFFFu, lane, 64u * tier);
           if (lane == 0) ST.naln = naln;
         }
         __syncthreads();
-        if (band_now && certified && !ST.band_fail) break;  // the band was enough
-#ifdef MA_PROFILE
-        if (band_now && tid == 0) atomicAdd(&g_prof[13], 1ull);
-#endif
+        if (!tier || (certified && !ST.band_fail)) break;  // the band was enough / the full fill is always exact
+        // ---- next tier ----
+        u32 const next = (tier < 4u && can_yield) ? 4u : 0u;
+        if (ws.tier_stats && tid == 0) atomicAdd(&ws.tier_stats[4 + (tier == 4u ? 2 : (tier == 2u ? 1 : 0))], 1u);
+        __syncthreads();
+        if (tid == 0) {
+          ST.band = next;
+          ST.band_fail = 0;
+        }
+        if (next) {
+          for (u32 i = 1 + tid; i <= V; i += kT) g.rowj0[i] = band_j0(g.npos[g.rank2node[i - 1]], L, next);
+        }
+        __syncthreads();
+        if (next) {
+          if (tid == 0) {
+            ST.c_cur = c;
+            ST.h_cur = h;
+            ST.pending = 1;
+            ST.filled = 0;
+            atomicAdd(ws.pending_ctr, 1u);
+            ST.nvars = nvars;
+            ST.pool = pool;
+            ST.var_overflow = overflow ? 1u : 0u;
+          }
+          yielded = true;
+          break;
+        }
       }
+      if (yielded) break;
       }  // !direct
       __syncthreads();
       PROF_ACC(2);
@@ -2251,22 +2347,38 @@ __global__ __launch_bounds__(kT, 2) void k_msa(MsaArgs A) {
 // The row descriptors of a pending alignment, read straight from the window's LDS image in HBM: every access is
 // wave-uniform and the fill asks for row i + 1 while it works on row i, so no LDS staging is needed and the
 // occupancy of k_msa_band is bounded by its registers alone.
+// Every read is a SCALAR load (constant address space -> s_load_dword, counted by lgkmcnt): a vector load would share
+// the in-order vmcnt counter with the row's code store, and waiting for a descriptor would mean waiting for the store
+// issued just before it -- a store round trip (~1 us under load) on the critical path of EVERY row.
+#define MA_AS4 __attribute__((address_space(4)))
+__device__ __forceinline__ u32 sload_u32(const void* p) {  // p uniform, 4-byte aligned
+  return *reinterpret_cast<const MA_AS4 u32*>(reinterpret_cast<uintptr_t>(p));
+}
+template <class T>
+struct ScalarArr {
+  const T* base;
+  __device__ __forceinline__ u32 operator[](u32 i) const {
+    uintptr_t const a = reinterpret_cast<uintptr_t>(base + i);
+    u32 const w = sload_u32(reinterpret_cast<const void*>(a & ~uintptr_t(3)));
+    if constexpr (sizeof(T) == 4) return w;
+    else if constexpr (sizeof(T) == 2) return (w >> ((a & 2u) * 8u)) & 0xFFFFu;
+    else return (w >> ((a & 3u) * 8u)) & 0xFFu;
+  }
+};
 struct DescView {
-  const u32* __restrict__ rowinfo;
-  const u16* __restrict__ rowslot;
-  const u16* __restrict__ rowdepth;
-  const u16* __restrict__ rowj0;
-  const u16* __restrict__ slowpred;
+  ScalarArr<u32> rowinfo;
+  ScalarArr<u16> rowslot, rowdepth, rowj0, slowpred;
   // only reached for rows without a cached predecessor list, which k_msa never hands over (nslow <= kSlowCap)
-  const u16* __restrict__ rank2node;
-  const u16* __restrict__ node2rank;
-  const u16* __restrict__ in_tail;
+  ScalarArr<u16> rank2node, node2rank, in_tail;
+  // one byte at a wave-uniform address
+  __device__ __forceinline__ u32 ubyte(const u8* p) const { return ScalarArr<u8>{p}[0]; }
 };
 
-// Split mode: the banded fill of every window's pending alignment, one wavefront per window.  Only the state block
-// is staged in LDS (instead of the graph's 77 KB), so a CU holds sixteen windows and the dependent instruction
-// chains of the row recurrence overlap across them.
-__global__ __launch_bounds__(64) void k_msa_band(MsaArgs A) {
+// Split mode: the banded fill (tier CW: 64 CW columns) of every window whose pending alignment is at that tier, one
+// wavefront per window.  Only the state block is staged in LDS (instead of the graph's 77 KB), so a CU holds 16-32
+// windows and the dependent instruction chains of the row recurrence overlap across them.
+template <int CW>
+__global__ __launch_bounds__(64, CW == 1 ? 8 : (CW == 2 ? 6 : 4)) void k_msa_band(MsaArgs A) {
   int const lane = threadIdx.x;
   int const lw = blockIdx.x;
   int const w = A.win0 + lw;
@@ -2276,21 +2388,21 @@ __global__ __launch_bounds__(64) void k_msa_band(MsaArgs A) {
   u32* const img = reinterpret_cast<u32*>(ws.img) + static_cast<size_t>(lw) * ws.img_words;
   {
     const WgState* pst = reinterpret_cast<const WgState*>(img);
-    if (pst->done || !pst->pending) return;
+    if (pst->done || !pst->pending || pst->filled || pst->band != static_cast<u32>(CW)) return;
   }
   u32 const PN = ws.pn;
   GL const full = poa_carve(PN, ws.max_l);
   for (u32 i = lane; i < kStBytes / 4; i += 64) reinterpret_cast<u32*>(ma_lds)[i] = img[i];
   const u8* const ib = reinterpret_cast<const u8*>(img);
   DescView g;
-  g.rowinfo = reinterpret_cast<const u32*>(ib + full.rowinfo.off);
-  g.rowslot = reinterpret_cast<const u16*>(ib + full.rowslot.off);
-  g.rowdepth = reinterpret_cast<const u16*>(ib + full.rowdepth.off);
-  g.rowj0 = reinterpret_cast<const u16*>(ib + full.rowj0.off);
-  g.slowpred = reinterpret_cast<const u16*>(ib + full.slowpred.off);
-  g.rank2node = reinterpret_cast<const u16*>(ib + full.rank2node.off);
-  g.node2rank = reinterpret_cast<const u16*>(ib + full.node2rank.off);
-  g.in_tail = reinterpret_cast<const u16*>(ib + full.in_tail.off);
+  g.rowinfo.base = reinterpret_cast<const u32*>(ib + full.rowinfo.off);
+  g.rowslot.base = reinterpret_cast<const u16*>(ib + full.rowslot.off);
+  g.rowdepth.base = reinterpret_cast<const u16*>(ib + full.rowdepth.off);
+  g.rowj0.base = reinterpret_cast<const u16*>(ib + full.rowj0.off);
+  g.slowpred.base = reinterpret_cast<const u16*>(ib + full.slowpred.off);
+  g.rank2node.base = reinterpret_cast<const u16*>(ib + full.rank2node.off);
+  g.node2rank.base = reinterpret_cast<const u16*>(ib + full.node2rank.off);
+  g.in_tail.base = reinterpret_cast<const u16*>(ib + full.in_tail.off);
   __builtin_amdgcn_s_waitcnt(0);
   __builtin_amdgcn_wave_barrier();
   __syncthreads();
@@ -2300,9 +2412,13 @@ __global__ __launch_bounds__(64) void k_msa_band(MsaArgs A) {
   u16* const codes = ws.codes + static_cast<size_t>(lw) * ws.code_cells;
   i32* const rows = ws.rows + static_cast<size_t>(lw) * ws.row_cells;
   i32* const hlast = ws.hlast + static_cast<size_t>(lw) * (PN + 8);
-  poa_fill_band(g, ws, codes, rows, hlast, ST.V, ST.L, lane, seq, &ST.edge_max);
+  poa_fill_band<CW>(g, ws.w_stride, ws.code_cells, codes, rows, hlast, ST.V, ST.L, lane, seq, &ST.edge_max);
   __syncthreads();
-  if (lane == 0) reinterpret_cast<WgState*>(img)->edge_max = ST.edge_max;
+  if (lane == 0) {
+    reinterpret_cast<WgState*>(img)->edge_max = ST.edge_max;
+    reinterpret_cast<WgState*>(img)->filled = 1;
+    if (ws.tier_stats) atomicAdd(&ws.tier_stats[CW == 1 ? 0 : (CW == 2 ? 1 : 2)], 1u);
+  }
 }
 
 }  // namespace
@@ -2374,6 +2490,15 @@ int launch_msa(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& a, const ma_var
   ws.use_band = band_mode != 0 ? 1u : 0u;
   ws.split = band_mode == 2 ? 1u : 0u;
   ws.no_direct = getenv("MA_POA_NO_DIRECT") ? 1u : 0u;
+  // first band tier: 64 (1), 128 (2) or 256 (4) columns; a tier whose certificate fails hands over to 256 columns, then
+  // to the full fill.  Results do not depend on it (tested).
+  {
+    int const t0 = getenv("MA_POA_TIER0") ? atoi(getenv("MA_POA_TIER0")) : 1;
+    ws.tier0 = (t0 == 1 || t0 == 2) ? static_cast<u32>(t0) : 4u;
+  }
+  // split mode: a band round is launched while at least this many windows wait for a fill; fewer finish inside k_msa
+  u32 const min_pending = getenv("MA_POA_MIN_PENDING") ? static_cast<u32>(atoi(getenv("MA_POA_MIN_PENDING"))) : 256u;
+  bool const verbose = getenv("MA_VERBOSE") != nullptr;
   ws.img_words = static_cast<u32>((lds + 3) / 4);
   ws.code_cells = (static_cast<size_t>(pn + 2) * (max_len + 16) + 7) & ~size_t(7);
   if (ws.code_cells * 2 < static_cast<size_t>(P.max_haps) * (2 * max_len + 8) + 64)  // raw-allele scratch lives in the codes
@@ -2383,10 +2508,11 @@ int launch_msa(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& a, const ma_var
   size_t const img_bytes = ws.split ? ((static_cast<size_t>(ws.img_words) * 4 + 255) & ~size_t(255)) : 0;
   ws.img_words = static_cast<u32>(ws.split ? img_bytes / 4 : ws.img_words);
   size_t const per_window = ws.code_cells * 2 + ws.row_cells * 4 + (static_cast<size_t>(pn) + 8) * 4 + img_bytes;
+  (void)rounds;
   size_t budget = stage_budget(0.30, ctx->ws_poa.cap, size_t(24) << 30, ctx->hbm_share);
   if (const char* e = getenv("MA_WS_GB")) budget = static_cast<size_t>(atoi(e)) << 30;
   int const chunk = static_cast<int>(std::max<size_t>(1, std::min<size_t>(n, budget / per_window)));
-  MA_HIP(ctx, ctx->ws_poa.reserve(per_window * static_cast<size_t>(chunk) + 4096));
+  MA_HIP(ctx, ctx->ws_poa.reserve(per_window * static_cast<size_t>(chunk) + 8192));
   if (getenv("MA_VERBOSE"))
     fprintf(stderr, "[microasm] msa: %d windows, %.2f MB/window, budget %.1f GB -> chunks of %d (pn %u, max_len %u, lds %zu)\n", n,
             per_window / 1048576.0, budget / 1073741824.0, chunk, pn, max_len, lds);
@@ -2403,25 +2529,58 @@ int launch_msa(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& a, const ma_var
     ws.hlast = reinterpret_cast<i32*>(base + csz + rsz);
     size_t const hsz = (static_cast<size_t>(nwin) * (pn + 8) * 4 + 255) & ~size_t(255);
     ws.img = reinterpret_cast<u8*>(base + csz + rsz + hsz);
-    MsaArgs args{b, a, o, ws, P, win0, 0u};
+    {  // counters behind the image area: [0] pending windows of the current launch, [8..15] tier statistics
+      u32* ctr = reinterpret_cast<u32*>(base + csz + rsz + hsz + static_cast<size_t>(nwin) * img_bytes);
+      ctr = reinterpret_cast<u32*>((reinterpret_cast<uintptr_t>(ctr) + 255) & ~uintptr_t(255));
+      ws.pending_ctr = ctr;
+      ws.tier_stats = verbose ? ctr + 8 : nullptr;
+      MA_HIP(ctx, hipMemsetAsync(ctr, 0, 64, ctx->stream));
+    }
+    MsaArgs args{b, a, o, ws, P, win0, 0u, 0u};
     if (!ws.split) {
+      args.finish = 1;
       ctx->tic("k_msa");
       hipLaunchKernelGGL(kern, dim3(nwin), dim3(kT), lds, ctx->stream, args);
       ctx->toc();
     } else {
-      // one round per pending alignment: k_msa runs up to the next banded fill, k_msa_band fills, k_msa resumes
+      // Per-window progress: k_msa runs every window up to its next banded fill (or to its end); while many windows wait
+      // for a fill, k_msa_band fills them (one launch per tier that can hold work) and k_msa resumes them; once few are
+      // left, a last k_msa launch finishes them in-kernel (their remaining fills on its wave 0) -- the tail of a batch
+      // (third / fourth alignments, retried tiers) no longer costs two launches and a fill's latency per round.
       size_t const band_lds = kStBytes + 16;
-      for (u32 r = 0; r < rounds; ++r) {
+      u32 const max_rounds = 2u * rounds + 2u;  // every alignment may need two band tiers
+      for (u32 r = 0;; ++r) {
         args.round = r;
+        args.finish = 0;
         ctx->tic("k_msa");
         hipLaunchKernelGGL(kern, dim3(nwin), dim3(kT), lds, ctx->stream, args);
         ctx->toc();
-        if (r + 1 < rounds) {
-          ctx->tic("k_msa_band");
-          hipLaunchKernelGGL(k_msa_band, dim3(nwin), dim3(64), band_lds, ctx->stream, args);
+        u32 pending = 0;
+        MA_HIP(ctx, hipMemcpyAsync(&pending, ws.pending_ctr, 4, hipMemcpyDeviceToHost, ctx->stream));
+        MA_HIP(ctx, hipMemsetAsync(ws.pending_ctr, 0, 4, ctx->stream));
+        MA_HIP(ctx, ma_stream_sync(ctx));
+        if (pending == 0) break;
+        if (pending < min_pending || r + 1 >= max_rounds) {
+          args.round = r + 1;
+          args.finish = 1;
+          ctx->tic("k_msa");
+          hipLaunchKernelGGL(kern, dim3(nwin), dim3(kT), lds, ctx->stream, args);
           ctx->toc();
+          break;
         }
+        ctx->tic("k_msa_band");
+        if (ws.tier0 == 1) hipLaunchKernelGGL(k_msa_band<1>, dim3(nwin), dim3(64), band_lds, ctx->stream, args);
+        else if (ws.tier0 == 2) hipLaunchKernelGGL(k_msa_band<2>, dim3(nwin), dim3(64), band_lds, ctx->stream, args);
+        if (ws.tier0 == 4 || r > 0) hipLaunchKernelGGL(k_msa_band<4>, dim3(nwin), dim3(64), band_lds, ctx->stream, args);
+        ctx->toc();
       }
+    }
+    if (verbose) {
+      u32 tsx[8];
+      MA_HIP(ctx, hipMemcpyAsync(tsx, ws.tier_stats, 32, hipMemcpyDeviceToHost, ctx->stream));
+      MA_HIP(ctx, ma_stream_sync(ctx));
+      fprintf(stderr, "[microasm] msa tiers: fills 64/128/256 = %u/%u/%u, failed certificates = %u/%u/%u\n", tsx[0], tsx[1],
+              tsx[2], tsx[4], tsx[5], tsx[6]);
     }
     MA_HIP(ctx, hipGetLastError());
   }

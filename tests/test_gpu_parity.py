@@ -173,6 +173,34 @@ def test_msa_parity_fill_modes(cfg, nwin, kw, band_mode, monkeypatch):
     assert not bad, "\n".join(bad[:20])
 
 
+@pytest.mark.parametrize("min_pending", ["0", "1000000", None])
+@pytest.mark.parametrize("tier0", ["1", "2", "4"])
+def test_msa_parity_band_tiers(tier0, min_pending, monkeypatch):
+    """The banded fill starts with a narrow tier (64 or 128 columns per row, MA_POA_TIER0) and hands an alignment whose
+    certificate fails to the 256-column tier, then to the full fill; while many windows wait, the fills run in k_msa_band
+    rounds, the tail of a batch inside k_msa (MA_POA_MIN_PENDING = 0: always rounds, huge: never).  Same bits every way,
+    on plain windows, variant-dense windows (several alignments per window) and 60-base indels (the narrow tiers fail)."""
+    from lancet2_amd.engine import Engine
+    monkeypatch.setenv("MA_POA_TIER0", tier0)
+    monkeypatch.setenv("MA_POA_NO_DIRECT", "1")  # every alignment takes a fill
+    if min_pending is not None:
+        monkeypatch.setenv("MA_POA_MIN_PENDING", min_pending)
+    params = capi.default_params(min_k=25, max_k=25)
+    for cfg, nwin, kw in (("C2", 5, {}), ("C2", 3, dict(big_indel=60)), ("C2", 3, dict(snv_rate=8e-3, indel_rate=2e-3)),
+                          ("C2", 2, dict(W=1700))):
+        arrs, n, nr = synth.make_config_batch(cfg, nwin, first_index=5200, **kw)
+        orc = OracleEngine(params)
+        asm = orc.assemble(arrs, n, nr)
+        want = orc.msa(arrs, n, nr, asm)
+        eng = Engine(params)
+        try:
+            got = eng.msa(arrs, n, nr, asm)
+        finally:
+            eng.close()
+        bad = compare_vars(params, got, want, n)
+        assert not bad, (cfg, kw, "\n".join(bad[:20]))
+
+
 @pytest.mark.parametrize("no_direct", [False, True])
 @pytest.mark.parametrize("kw,need", [(dict(indel_rate=6e-4), (2, 2, 2)),
                                      (dict(str_unit=b"A", indel_rate=4e-4), (2, 4, 2))])  # homopolymers: the indel slides
