@@ -53,13 +53,15 @@ constexpr i32 M_ = 0, N_ = -6, G_ = -6, E_ = -2, Q_ = -26, C_ = -1;  // msa_buil
 
 // The band tier k_msa can fill on its own wave 0 (tail of a batch, MA_POA_BAND=1); every tier has its k_msa_band.
 #ifndef MA_POA_TIER0
-#define MA_POA_TIER0 1
+#define MA_POA_TIER0 2
 #endif
 constexpr u32 kTierIn = MA_POA_TIER0;
 
 constexpr u32 RI_FAST = 1u << 11;     // single predecessor == previous rank
 constexpr u32 RI_SLOWTAB = 1u << 12;  // predecessor rows cached in slowpred[info >> 16]
 constexpr u32 RI_STORE = 1u << 13;    // a later row reads this row back from HBM
+constexpr u32 RI_LEAN = 1u << 14;     // band tiers: the row takes the straight-line path of poa_fill_lean (see band_flags)
+constexpr u32 RI_SLIDE = 1u << 15;    // ... and its window sits one lane to the right of the previous row's
 
 struct PoaWs {
   u32 pn;            // node capacity (LDS)
@@ -71,6 +73,7 @@ struct PoaWs {
   u32* tier_stats;   // [8] fills per tier 64/128/256 + (at 4) failed certificates per tier; null unless MA_VERBOSE
   u32* pending_ctr;  // split mode: windows that yielded in the current k_msa launch
   u32 no_direct;     // MA_POA_NO_DIRECT: every alignment goes through a fill (tests: the shortcut changes nothing)
+  u32 lean;          // band tiers run poa_fill_lean (default) / poa_fill_band (MA_POA_LEAN=0; same codes, tested)
   size_t code_cells; // u16 per window
   size_t row_cells;  // i32 per window
   u16* codes;
@@ -98,6 +101,7 @@ struct WgState {
   u32 band, band_fail;  // band tier of this alignment's current attempt (columns per lane, 0 = full fill) / its traceback ran off the band
   u32 filled;           // split mode: k_msa_band has filled the pending alignment at tier `band`
   i32 edge_max;         // maximum H over the band's exit cells
+  i32 edge0;            // ... the part known before the fill: column 0 of the rows whose window does not start at column 1
   i32 best;
   u32 best_row;
   i32 ftot[2][4][2];  // fill: per-wave totals of the two prefix maxima, double buffered by row parity
@@ -132,6 +136,7 @@ struct GL {  // LDS layout of one window's POA graph + scratch
   LdsArr<u8> marks, ignored;
   u32 stack_cap;
   __device__ __forceinline__ u32 ubyte(const u8* p) const { return *p; }
+  __device__ __forceinline__ u32 uword(const void* p) const { return *static_cast<const u32*>(p); }
 };
 
 __host__ __device__ inline size_t poa_lds_bytes(u32 pn, u32 ml) {
@@ -1273,6 +1278,467 @@ __device__ void poa_fill_band(G const& g, u32 const w_stride, size_t const plane
   if (lane == 0) *edge_out = edge;
 }
 
+// ---- the lean banded fill: same cells, same codes as poa_fill_band, a quarter of the instructions ----
+// The row loop of poa_fill_band costs ~500 instructions a row whatever its width: half of them scalar -- execution-mask
+// bookkeeping for per-lane conditions, uniform branches for rows that might store / slide / hold column 0 / have several
+// predecessors -- and a lone wavefront issues one instruction every 4-5 cycles, so the instruction COUNT is the fill's
+// latency.  Here every row that is ordinary takes a straight-line path (RI_LEAN, decided once per alignment by
+// band_flags in k_msa): a single predecessor = the previous rank (FAST), not read back later (no RI_STORE), not a sink
+// (no hlast), a window that does not touch column 0 and sits where the previous row's sits or one lane to its right.
+// 97 % of the rows of a haplotype graph.  The other rows take row_gen: poa_fill_band's row without the second
+// register row (a predecessor that is not the previous rank comes from the row store: k_msa marks every such row).
+//  * no per-lane branches: lane conditions are constant masks (v_cndmask), entering lanes are written with v_writelane;
+//  * one scalar load per row (the descriptor of the next row) instead of three;
+//  * decision codes from SIGN BITS: a FAST row's code only depends on which argument wins each maximum
+//        fA = a1 >= a2, oA = a3 >= a4, FO = fv >= ov, eB = b1 >= b2, qB = b3 >= b4, EQ = e >= q, D = h == hm, U = h == hV
+//    (poa_fill's fast path shows that SPOA's ordered equality tests collapse to these; every test is the sign of a
+//    difference, h - hm and h - hV being >= 0), so eight differences are shifted into one register with v_alignbit and
+//    the 6-bit code is read from a 256-byte table in LDS (one bank per dword: conflict-free): ~19 instead of ~35
+//    instructions per cell.  The one cell without a left neighbour (lane 0, first column) gets neighbour values that
+//    make eB = qB = false, which is what the equality tests give there (lc = 0); nothing else reads them.
+__device__ __forceinline__ u32 lean_code_of(u32 idx) {  // idx bits, 1 = "strictly less": [7] FO [6] fA [5] oA [4] D [3] U [2] EQ [1] eB [0] qB
+  bool const FO = !(idx & 128u), fA = !(idx & 64u), oA = !(idx & 32u), D = !(idx & 16u), U = !(idx & 8u), EQ = !(idx & 4u),
+             eB = !(idx & 2u), qB = !(idx & 1u);
+  u32 code = D ? 0u : (U ? 1u : 2u);
+  code |= (!D && (U ? (FO ? fA : oA) : (EQ ? eB : qB))) ? 4u : 0u;
+  code |= (eB || qB) ? 8u : 0u;
+  code |= (fA || oA) ? 16u : 32u;
+  return code;
+}
+__device__ __forceinline__ u32 sign_into(u32 acc, i32 diff) {  // (acc << 1) | (diff < 0)
+  return __builtin_amdgcn_alignbit(acc, static_cast<u32>(diff), 31);
+}
+
+template <int CW, class G>
+__device__ void poa_fill_lean(G const& g, u32 const w_stride, size_t const plane, u16* codes16, i32* rows, i32* hlast, u32 V,
+                              u32 L, int lane, const u8* seq, i32 const edge0, u32 const lut_off, i32* edge_out) {
+  static_assert(CW == 1 || CW == 2 || CW == 4, "band tiers: 64, 128 or 256 columns");
+  constexpr u32 BW = 64u * CW;
+  constexpr i32 NEG = kScanIdent;
+  u8* const codes = reinterpret_cast<u8*>(codes16);
+  LdsArr<u8> const lut{lut_off};
+#pragma unroll
+  for (u32 k = 0; k < 4; ++k) lut[4u * lane + k] = static_cast<u8>(lean_code_of(4u * lane + k));
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  i32 jr[CW], cq[CW], ce[CW];  // window-relative columns and the per-column constants of Q and E
+#pragma unroll
+  for (int c = 0; c < CW; ++c) {
+    jr[c] = CW * lane + c;
+    cq[c] = Q_ + 1 - jr[c];
+    ce[c] = G_ + 2 - 2 * jr[c];
+  }
+  i32 H1[CW], F1[CW], O1[CW];  // the previous row, aligned to the window j0
+#pragma unroll
+  for (int c = 0; c < CW; ++c) H1[c] = F1[c] = O1[c] = kNegInf;
+  u32 sc[CW];
+  i32 edge = edge0;
+  bool const lane0 = lane == 0, lane63 = lane == 63;
+  u32 j0 = g.rowj0[1];
+  auto load_sc = [&]() {
+#pragma unroll
+    for (int c = 0; c < CW; ++c) {
+      u32 const j = j0 + static_cast<u32>(CW) * lane + c;
+      sc[c] = (j >= 1 && j <= L) ? seq[j - 1] : 0u;
+    }
+  };
+  load_sc();
+  // the characters that enter at lane 63 on the next one-lane slide: the words that hold them are fetched one slide ahead
+  // (scalar loads, always from inside the haplotype) and taken apart only when they are needed -- extracting them on the
+  // spot would put the load's latency on every slide
+  u32 scw[CW], scs[CW];
+  auto load_sc_in = [&]() {
+#pragma unroll
+    for (int c = 0; c < CW; ++c) {
+      u32 const j = min(j0 + BW + c, L);  // L >= 1
+      uintptr_t const a = reinterpret_cast<uintptr_t>(seq + (j - 1));
+      // (readfirstlane: folds away on a scalar load and pins the loop-carried word to a scalar register)
+      scw[c] = __builtin_amdgcn_readfirstlane(g.uword(reinterpret_cast<const void*>(a & ~uintptr_t(3))));
+      scs[c] = __builtin_amdgcn_readfirstlane(static_cast<u32>(a & 3u) * 8u);
+    }
+  };
+  auto sc_in = [&](int c) -> u32 {  // character of column j0 + BW + c (j0: the window BEFORE the slide), 0 beyond the end
+    return (j0 + BW + c <= L) ? ((scw[c] >> scs[c]) & 0xFFu) : 0u;
+  };
+  load_sc_in();
+  u8* cp = codes + static_cast<size_t>(BW) + static_cast<u32>(CW) * lane;  // this lane's code bytes of row 1
+
+  // ---- the straight-line row ----
+  auto row_lean = [&](u32 const info) __attribute__((always_inline)) {
+    u32 const nch = info & 0xFFu;
+    if (info & RI_SLIDE) {
+      // lane 0's columns leave the window: exits
+      i32 dm = H1[0];
+#pragma unroll
+      for (int c = 1; c < CW; ++c) dm = max(dm, H1[c]);
+      edge = max(edge, lane0 ? dm : kNegInf);
+#pragma unroll
+      for (int c = 0; c < CW; ++c) {  // lane 63 keeps the fill value: its source lane does not exist
+        H1[c] = wave_shl1(H1[c], kNegInf);
+        F1[c] = wave_shl1(F1[c], kNegInf);
+        O1[c] = wave_shl1(O1[c], kNegInf);
+        sc[c] = static_cast<u32>(wave_shl1(static_cast<i32>(sc[c]), static_cast<i32>(sc_in(c))));
+      }
+      j0 += CW;
+      load_sc_in();
+    }
+    // vertical + diagonal part (lane 0 has nothing to its left: the fill value)
+    i32 hd = wave_shr1(H1[CW - 1], kNegInf);
+    i32 ff[CW], oo[CW], hmv[CW], hh[CW], hv[CW], a1r[CW], a2r[CW];
+    u32 acc[CW];  // the sign bits of each column, most significant first
+    i32 run1 = NEG, run2 = NEG;
+#pragma unroll
+    for (int c = 0; c < CW; ++c) {
+      i32 const ph = H1[c];
+      i32 const a1 = F1[c] + E_, a2 = ph + G_, a3 = O1[c] + C_, a4 = ph + Q_;
+      i32 const fv = max(a1, a2), ov = max(a3, a4);
+      i32 const hm = hd + ((nch == sc[c]) ? M_ : N_);
+      hd = ph;
+      ff[c] = fv;
+      oo[c] = ov;
+      hmv[c] = hm;
+      hv[c] = max(fv, ov);
+      acc[c] = sign_into(sign_into(static_cast<u32>(fv - ov) >> 31, a1 - a2), a3 - a4);
+      i32 const m = max(hm, hv[c]);
+      hh[c] = m;
+      a1r[c] = m + jr[c];
+      a2r[c] = a1r[c] + jr[c];
+      run1 = max(run1, a1r[c]);
+      run2 = max(run2, a2r[c]);
+    }
+    // prefix maxima over the window
+    i32 const inc1 = wave_incl_max(run1, NEG), inc2 = wave_incl_max(run2, NEG);
+    i32 s1 = wave_shr1(inc1, NEG), s2 = wave_shr1(inc2, NEG);
+    i32 ee[CW], qq[CW];
+#pragma unroll
+    for (int c = 0; c < CW; ++c) {
+      i32 q = s1 + cq[c];
+      i32 e = max(s2 + ce[c], q + (G_ + 1));
+      if (c == 0) {  // nothing to the left of the window's first column
+        q = lane0 ? kNegInf : q;
+        e = lane0 ? kNegInf : e;
+      }
+      s1 = max(s1, a1r[c]);
+      s2 = max(s2, a2r[c]);
+      ee[c] = e;
+      qq[c] = q;
+      hh[c] = max(hh[c], max(e, q));
+    }
+    // the column to the left of this lane's first one (lane 0: values that make eB = qB = false, see above)
+    i32 hl = wave_shr1(hh[CW - 1], kNegInf), el = wave_shr1(ee[CW - 1], kNegInf - 64), ql = wave_shr1(qq[CW - 1], kNegInf - 64);
+    // decision codes: five more sign bits per column, then the table
+    u32 code = 0;
+#pragma unroll
+    for (int c = 0; c < CW; ++c) {
+      u32 a = acc[c];  // FO fA oA
+      i32 const h = hh[c];
+      a = sign_into(a, hmv[c] - h);
+      a = sign_into(a, hv[c] - h);
+      a = sign_into(a, ee[c] - qq[c]);
+      a = sign_into(a, (el - hl) + (E_ - G_));
+      a = sign_into(a, (ql - hl) + (C_ - Q_));
+      code |= static_cast<u32>(lut[a]) << (8 * c);
+      hl = h;
+      el = ee[c];
+      ql = qq[c];
+    }
+    // right exit of this row: the last window column when the haplotype goes on beyond it
+    if (j0 + BW - 1 < L) edge = max(edge, lane63 ? hh[CW - 1] : kNegInf);
+    if constexpr (CW == 4) *reinterpret_cast<u32*>(cp) = code;
+    else if constexpr (CW == 2) *reinterpret_cast<u16*>(cp) = static_cast<u16>(code);
+    else *cp = static_cast<u8>(code);
+#pragma unroll
+    for (int c = 0; c < CW; ++c) {
+      H1[c] = hh[c];
+      F1[c] = ff[c];
+      O1[c] = oo[c];
+    }
+  };
+
+  // ---- every other row: poa_fill_band's row with one register row ----
+  auto row_gen = [&](u32 const i, u32 const info) __attribute__((always_inline)) {
+    u32 const nch = info & 0xFFu, np = (info >> 8) & 7u;
+    bool const fast = info & RI_FAST, store = info & RI_STORE;
+    i32 const h0 = col0_h(g.rowdepth[i]);
+    u32 const j0_new = g.rowj0[i];
+    if (j0_new != j0) {
+      i32 const sh = (static_cast<i32>(j0_new) - static_cast<i32>(j0)) / CW;  // lanes; > 0: window moves right
+      {
+        bool const dropped = sh > 0 ? lane < sh : lane >= 64 + sh;
+        u32 const jbo = j0 + static_cast<u32>(CW) * lane;
+        if (dropped) {
+#pragma unroll
+          for (int c = 0; c < CW; ++c)
+            if (jbo + c >= 1 && jbo + c <= L) edge = max(edge, H1[c]);
+        }
+      }
+      while (j0 < j0_new) {
+#pragma unroll
+        for (int c = 0; c < CW; ++c) {
+          H1[c] = wave_shl1(H1[c], kNegInf);
+          F1[c] = wave_shl1(F1[c], kNegInf);
+          O1[c] = wave_shl1(O1[c], kNegInf);
+          sc[c] = static_cast<u32>(wave_shl1(static_cast<i32>(sc[c]), static_cast<i32>(sc_in(c))));
+        }
+        j0 += CW;
+        load_sc_in();
+      }
+      if (j0 > j0_new) {  // rare: the backbone coordinate steps back
+        do {
+          j0 -= CW;
+#pragma unroll
+          for (int c = 0; c < CW; ++c) {
+            H1[c] = wave_shr1(H1[c], kNegInf);
+            F1[c] = wave_shr1(F1[c], kNegInf);
+            O1[c] = wave_shr1(O1[c], kNegInf);
+            u32 const j = j0 + c;
+            sc[c] = static_cast<u32>(wave_shr1(static_cast<i32>(sc[c]), (j >= 1 && j <= L) ? static_cast<i32>(g.ubyte(seq + (j - 1))) : 0));
+          }
+        } while (j0 > j0_new);
+        load_sc_in();
+      }
+    }
+    u32 const jb = j0 + static_cast<u32>(CW) * lane;
+    i32 hh[CW], ff[CW], oo[CW], hmv[CW];
+    auto left_of = [&](i32 last_col_value, u32 pr) -> i32 {
+      i32 const v = wave_shr1(last_col_value, kNegInf);
+      if (lane != 0) return v;
+      return jb == 1 ? (pr == 0 ? 0 : col0_h(g.rowdepth[pr])) : kNegInf;
+    };
+    auto fetch_store = [&](u32 pr, i32(&th)[CW], i32(&tf)[CW], i32(&to)[CW], i32& thd) {
+      u32 const pj0 = g.rowj0[pr];
+      int const d = (static_cast<i32>(j0) - static_cast<i32>(pj0)) / CW;  // this lane reads the stored lane l + d
+      int const sl = lane + d;
+      bool const in = sl >= 0 && sl < 64;
+      u32 const slot = g.rowslot[pr];
+      const i32* base = rows + static_cast<size_t>(slot) * 3 * w_stride;
+#pragma unroll
+      for (int c = 0; c < CW; ++c) th[c] = tf[c] = to[c] = kNegInf;
+      if (in) {
+#pragma unroll
+        for (int c = 0; c < CW; ++c) {
+          th[c] = base[CW * sl + c];
+          tf[c] = base[w_stride + CW * sl + c];
+          to[c] = base[2 * static_cast<size_t>(w_stride) + CW * sl + c];
+        }
+      }
+      i32 hd = kNegInf;
+      if (jb == 1) {
+        hd = col0_h(g.rowdepth[pr]);
+      } else if (sl >= 1 && sl <= 64) {
+        hd = base[CW * sl - 1];
+      }
+      thd = hd;
+      if (d != 0) {  // stored columns this window does not cover are exits of row pr towards this row
+        bool const dropped = d > 0 ? lane < d : lane >= 64 + d;
+        if (dropped) {
+          u32 const xj = pj0 + static_cast<u32>(CW) * lane;
+#pragma unroll
+          for (int c = 0; c < CW; ++c)
+            if (xj + c <= L) edge = max(edge, base[CW * lane + c]);
+        }
+      }
+    };
+    auto fetch = [&](u32 pr, i32(&th)[CW], i32(&tf)[CW], i32(&to)[CW], i32& thd) {
+      if (pr == 0) {
+#pragma unroll
+        for (int c = 0; c < CW; ++c) {
+          th[c] = row0_h(jb + c);
+          tf[c] = kNegInf;
+          to[c] = kNegInf;
+        }
+        thd = row0_h(jb - 1);
+      } else if (pr + 1 == i) {
+#pragma unroll
+        for (int c = 0; c < CW; ++c) {
+          th[c] = H1[c];
+          tf[c] = F1[c];
+          to[c] = O1[c];
+        }
+        thd = left_of(H1[CW - 1], pr);
+      } else {
+        fetch_store(pr, th, tf, to, thd);
+      }
+    };
+    u32 const npe = np ? np : 1u;
+    for (u32 x = 0; x < npe; ++x) {
+      u32 const pr = np ? pred_row(g, i, info, x) : 0u;
+      i32 th[CW], tf[CW], to[CW], hd;
+      fetch(pr, th, tf, to, hd);
+#pragma unroll
+      for (int c = 0; c < CW; ++c) {
+        i32 const fv = max(tf[c] + E_, th[c] + G_), ov = max(to[c] + C_, th[c] + Q_);
+        i32 const hv = hd + ((nch == sc[c]) ? M_ : N_);
+        hd = th[c];
+        if (x == 0) {
+          ff[c] = fv;
+          oo[c] = ov;
+          hmv[c] = hv;
+        } else {
+          ff[c] = max(ff[c], fv);
+          oo[c] = max(oo[c], ov);
+          hmv[c] = max(hmv[c], hv);
+        }
+      }
+    }
+    // row 0 ground that this window does not cover (a node without in-edges hangs off the virtual start row)
+    if (np == 0 && j0 + BW <= L) edge = max(edge, row0_h(j0 + BW));
+    if (np == 0 && j0 > 1) edge = max(edge, row0_h(1));
+    // (column 0 of a row whose window does not start at column 1 is an exit: in edge0, see band_flags)
+    bool const col0 = j0 == 1 && lane == 0;  // column 0 (jr = -1) enters through lane 0
+    i32 run1 = col0 ? h0 - 1 : NEG, run2 = col0 ? h0 - 2 : NEG;
+    i32 a1r[CW], a2r[CW];
+#pragma unroll
+    for (int c = 0; c < CW; ++c) {
+      i32 const m = max(hmv[c], max(ff[c], oo[c]));
+      hh[c] = m;
+      a1r[c] = m + jr[c];
+      a2r[c] = a1r[c] + jr[c];
+      run1 = max(run1, a1r[c]);
+      run2 = max(run2, a2r[c]);
+    }
+    i32 const inc1 = wave_incl_max(run1, NEG), inc2 = wave_incl_max(run2, NEG);
+    i32 s1 = wave_shr1(inc1, NEG), s2 = wave_shr1(inc2, NEG);
+    if (col0) {
+      s1 = h0 - 1;
+      s2 = h0 - 2;
+    }
+    i32 ee[CW], qq[CW];
+    bool const have_left = s1 > -(1 << 28);
+#pragma unroll
+    for (int c = 0; c < CW; ++c) {
+      i32 q = s1 + cq[c];
+      i32 e = max(s2 + ce[c], q + (G_ + 1));
+      if (c == 0) {
+        q = have_left ? q : kNegInf;
+        e = have_left ? e : kNegInf;
+      }
+      i32 const m = hh[c];
+      s1 = max(s1, a1r[c]);
+      s2 = max(s2, a2r[c]);
+      ee[c] = e;
+      qq[c] = q;
+      hh[c] = max(m, max(e, q));
+    }
+    i32 hN = wave_shr1(hh[CW - 1], kNegInf), eN = wave_shr1(ee[CW - 1], kNegInf), qN = wave_shr1(qq[CW - 1], kNegInf);
+    if (lane == 0) {
+      hN = jb == 1 ? h0 : kNegInf;
+      eN = kNegInf;
+      qN = kNegInf;
+    }
+    // decision codes: SPOA's tests in SPOA's order (any number of predecessors)
+    u32 cd[CW];
+    u32 elmask = 0, lcmask = 0;
+    {
+      i32 hleft = hN, eleft = eN, qleft = qN;
+#pragma unroll
+      for (int c = 0; c < CW; ++c) {
+        i32 const h = hh[c];
+        i32 const b1 = eleft + E_, b2 = hleft + G_, b3 = qleft + C_;
+        if ((h == b1) || ((h != b2) && (h == b3))) elmask |= 1u << c;
+        if ((b1 == ee[c]) || (b3 == qq[c])) lcmask |= 1u << c;
+        hleft = h;
+        eleft = ee[c];
+        qleft = qq[c];
+      }
+    }
+    u32 dmask = 0, umask = 0, eumask = 0, usmask = 0, uhmask = 0;
+    u32 xs[CW];
+#pragma unroll
+    for (int c = 0; c < CW; ++c) xs[c] = 0;
+    for (u32 x = 0; x < npe; ++x) {
+      u32 const pr = np ? pred_row(g, i, info, x) : 0u;
+      i32 th[CW], tf[CW], to[CW], hd;
+      fetch(pr, th, tf, to, hd);
+#pragma unroll
+      for (int c = 0; c < CW; ++c) {
+        i32 const a1v = tf[c] + E_, a2v = th[c] + G_, a3v = to[c] + C_, a4v = th[c] + Q_;
+        i32 const hv = hd + ((nch == sc[c]) ? M_ : N_);
+        hd = th[c];
+        i32 const h = hh[c];
+        u32 const bit = 1u << c;
+        if (!(dmask & bit) && h == hv) {
+          dmask |= bit;
+          xs[c] |= x;
+        }
+        bool const t1v = h == a1v, t2v = h == a2v, t3v = h == a3v, t4v = h == a4v;
+        if (!(umask & bit) && (t1v || t2v || t3v || t4v)) {
+          umask |= bit;
+          xs[c] |= x << 2;
+          if (t1v || (!t2v && t3v)) eumask |= bit;
+        }
+        if (np) {
+          if (!(usmask & bit) && ((ff[c] == a1v) || (oo[c] == a3v))) {
+            usmask |= bit;
+            xs[c] |= x << 4;
+          }
+          if (!(uhmask & bit) && ((ff[c] == a2v) || (oo[c] == a4v))) {
+            uhmask |= bit;
+            xs[c] |= x << 6;
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < CW; ++c) {
+      u32 const bit = 1u << c;
+      bool const D = dmask & bit, U = umask & bit;
+      u32 code = D ? 0u : (U ? 1u : 2u);
+      code |= (!D && (U ? ((eumask & bit) != 0) : ((elmask & bit) != 0))) ? 4u : 0u;
+      code |= (lcmask & bit) ? 8u : 0u;
+      bool const us = usmask & bit, uh = uhmask & bit;
+      code |= us ? 16u : (uh ? 32u : 0u);
+      code |= (D ? (xs[c] & 3u) : (U ? ((xs[c] >> 2) & 3u) : 0u)) << 6;
+      code |= (us ? ((xs[c] >> 4) & 3u) : (uh ? ((xs[c] >> 6) & 3u) : 0u)) << 8;
+      cd[c] = code;
+    }
+    if (lane == 63 && jb + CW - 1 < L) edge = max(edge, hh[CW - 1]);
+    store_code_bytes<CW>(cp, cd, 0);
+    if (!fast) store_code_bytes<CW>(cp + plane, cd, 6);
+    if (store) {
+      u32 const slot = g.rowslot[i];
+      i32* rb = rows + static_cast<size_t>(slot) * 3 * w_stride + static_cast<u32>(CW) * lane;
+#pragma unroll
+      for (int c = 0; c < CW; ++c) {
+        rb[c] = hh[c];
+        rb[w_stride + c] = ff[c];
+        rb[2 * static_cast<size_t>(w_stride) + c] = oo[c];
+      }
+      __threadfence_block();  // other lanes read it back (lane offsets differ between windows)
+    }
+    if (L >= j0 && L < j0 + BW && static_cast<u32>(lane) == (L - j0) / CW) {
+      u32 const cL = (L - j0) % CW;
+      i32 v = hh[0];
+#pragma unroll
+      for (int c = 1; c < CW; ++c) v = (static_cast<u32>(c) == cL) ? hh[c] : v;
+      hlast[i] = v;
+    } else if (lane == 0 && !(L >= j0 && L < j0 + BW)) {
+      hlast[i] = kNegInf;
+    }
+#pragma unroll
+    for (int c = 0; c < CW; ++c) {
+      H1[c] = hh[c];
+      F1[c] = ff[c];
+      O1[c] = oo[c];
+    }
+    // Leave no vector load of this path in flight: where the two paths meet the compiler cannot tell which registers a load
+    // may still be writing and would wait for vmcnt(0) at the head of EVERY row -- that is, for the previous row's code
+    // store, a store round trip per row.
+    __builtin_amdgcn_s_waitcnt(0);
+  };
+
+  u32 info = g.rowinfo[1];
+  __builtin_amdgcn_s_waitcnt(0);  // (the same for the loads above: nothing in flight when the loop is entered)
+  for (u32 i = 1; i <= V; ++i) {
+    u32 const cur = info;
+    if (i < V) info = g.rowinfo[i + 1];  // the next row's descriptor: a scalar load, a row ahead
+    if (__builtin_expect((cur & RI_LEAN) != 0, 1)) row_lean(cur);
+    else row_gen(i, cur);
+    cp += BW;
+  }
+  for (int off = 32; off > 0; off >>= 1) edge = max(edge, __shfl_xor(edge, off));
+  if (lane == 0) *edge_out = edge;
+}
+
 // ---- traceback (wave 0, all lanes carry the same state): SisdAlignmentEngine::Convex backtrack ----
 struct EdgeVals {
   i32 h, f, e, o, q;
@@ -1534,6 +2000,33 @@ __device__ __forceinline__ u16 band_j0(u32 npos, u32 L, u32 cwb) {
   return static_cast<u16>(min(j0, jmax));
 }
 
+// Per-row flags of a band tier (after rowj0, RI_STORE and rowdepth are final): which rows take poa_fill_lean's
+// straight-line path, and the exits that are known before the fill (column 0 of a row is an exit when the row's window
+// does not start at column 1; its value is closed-form).
+__device__ void band_flags(GL const& g, u32 V, u32 cwb, int tid) {
+  int const lane = tid & 63, wave = tid >> 6;
+  i32 e0 = kNegInf;
+  for (u32 i = 1 + tid; i <= V; i += kT) {
+    u32 info = g.rowinfo[i] & ~(RI_LEAN | RI_SLIDE);
+    u32 const j0 = g.rowj0[i];
+    if (j0 > 1) e0 = max(e0, col0_h(g.rowdepth[i]));
+    if (i >= 2 && cwb) {
+      u32 const jp = g.rowj0[i - 1];
+      if ((info & RI_FAST) && !(info & RI_STORE) && j0 > 1 && (j0 == jp || j0 == jp + cwb) &&
+          g.nout[g.rank2node[i - 1]] != 0) {
+        info |= RI_LEAN;
+        if (j0 != jp) info |= RI_SLIDE;
+      }
+    }
+    g.rowinfo[i] = info;
+  }
+  for (int off = 32; off > 0; off >>= 1) e0 = max(e0, __shfl_xor(e0, off));
+  if (lane == 0) ST.red_v[wave] = e0;
+  __syncthreads();
+  if (tid == 0) ST.edge0 = max(max(ST.red_v[0], ST.red_v[1]), max(ST.red_v[2], ST.red_v[3]));
+  __syncthreads();
+}
+
 struct MsaArgs {
   DBatch b;
   ma_asm_out_t a;
@@ -1775,7 +2268,7 @@ __global__ __launch_bounds__(kT, 2) void k_msa(MsaArgs A) {
           }
         }
         for (u32 x = 0; x < np; ++x)
-          if (pr[x] + 1 != i && !(cw <= 8 && pr[x] + 2 == i)) g.rowslot[pr[x]] = 1;
+          if (pr[x] + 1 != i) g.rowslot[pr[x]] = 1;  // (poa_fill / poa_fill_band still take rank - 2 from registers)
         g.rowinfo[i] = info;
         g.rowj0[i] = band_j0(g.npos[node], L, ST.band ? ST.band : 4u);
       }
@@ -1838,6 +2331,7 @@ __global__ __launch_bounds__(kT, 2) void k_msa(MsaArgs A) {
         }
       }
       __syncthreads();
+      if (ST.band) band_flags(g, V, ST.band, tid);
       if (ST.overflow) continue;
       PROF_ACC(0);
       if (ws.split && !A.finish && ST.band && ST.nslow <= kSlowCap) {  // hand the fill to k_msa_band<tier> and come back afterwards
@@ -1868,7 +2362,14 @@ __global__ __launch_bounds__(kT, 2) void k_msa(MsaArgs A) {
         if (!filled) {
           if (tier) {
             if (tid == 0) ST.band_fail = 0;
-            if (wave == 0) poa_fill_band<static_cast<int>(kTierIn)>(g, ws.w_stride, ws.code_cells, codes, rows, hlast, V, L, lane, seq, &ST.edge_max);
+            if (wave == 0) {
+              if (ws.lean)
+                poa_fill_lean<static_cast<int>(kTierIn)>(g, ws.w_stride, ws.code_cells, codes, rows, hlast, V, L, lane, seq,
+                                                         ST.edge0, g.aln.off, &ST.edge_max);
+              else
+                poa_fill_band<static_cast<int>(kTierIn)>(g, ws.w_stride, ws.code_cells, codes, rows, hlast, V, L, lane, seq,
+                                                         &ST.edge_max);
+            }
           } else {
             if (cw == 4) {
               poa_fill<4>(g, ws, codes, rows, hlast, V, L, tid, seq);
@@ -1946,6 +2447,8 @@ __global__ __launch_bounds__(kT, 2) void k_msa(MsaArgs A) {
         }
         if (next) {
           for (u32 i = 1 + tid; i <= V; i += kT) g.rowj0[i] = band_j0(g.npos[g.rank2node[i - 1]], L, next);
+          __syncthreads();
+          band_flags(g, V, next, tid);
         }
         __syncthreads();
         if (next) {
@@ -2372,12 +2875,13 @@ struct DescView {
   ScalarArr<u16> rank2node, node2rank, in_tail;
   // one byte at a wave-uniform address
   __device__ __forceinline__ u32 ubyte(const u8* p) const { return ScalarArr<u8>{p}[0]; }
+  __device__ __forceinline__ u32 uword(const void* p) const { return sload_u32(p); }
 };
 
 // Split mode: the banded fill (tier CW: 64 CW columns) of every window whose pending alignment is at that tier, one
 // wavefront per window.  Only the state block is staged in LDS (instead of the graph's 77 KB), so a CU holds 16-32
 // windows and the dependent instruction chains of the row recurrence overlap across them.
-template <int CW>
+template <int CW, bool LEAN>
 __global__ __launch_bounds__(64, CW == 1 ? 8 : (CW == 2 ? 6 : 4)) void k_msa_band(MsaArgs A) {
   int const lane = threadIdx.x;
   int const lw = blockIdx.x;
@@ -2406,13 +2910,22 @@ __global__ __launch_bounds__(64, CW == 1 ? 8 : (CW == 2 ? 6 : 4)) void k_msa_ban
   __builtin_amdgcn_s_waitcnt(0);
   __builtin_amdgcn_wave_barrier();
   __syncthreads();
-  size_t const ci = static_cast<size_t>(w) * P.max_comps + ST.c_cur;
-  size_t const hi = static_cast<size_t>(w) * P.max_haps + A.a.comp_hap0[ci] + ST.h_cur;
+  // (what comes out of LDS counts as divergent: without the readfirstlanes the haplotype's address sits in vector
+  //  registers and every "scalar" load of the fill turns into a vector load)
+  u32 const c_cur = __builtin_amdgcn_readfirstlane(ST.c_cur), h_cur = __builtin_amdgcn_readfirstlane(ST.h_cur);
+  u32 const V = __builtin_amdgcn_readfirstlane(ST.V), L = __builtin_amdgcn_readfirstlane(ST.L);
+  i32 const edge0 = __builtin_amdgcn_readfirstlane(ST.edge0);
+  size_t const ci = static_cast<size_t>(w) * P.max_comps + c_cur;
+  u32 const hap0 = __builtin_amdgcn_readfirstlane(A.a.comp_hap0[ci]);
+  size_t const hi = static_cast<size_t>(w) * P.max_haps + hap0 + h_cur;
   const u8* seq = A.a.hap_bases + hi * P.max_hap_len;
   u16* const codes = ws.codes + static_cast<size_t>(lw) * ws.code_cells;
   i32* const rows = ws.rows + static_cast<size_t>(lw) * ws.row_cells;
   i32* const hlast = ws.hlast + static_cast<size_t>(lw) * (PN + 8);
-  poa_fill_band<CW>(g, ws.w_stride, ws.code_cells, codes, rows, hlast, ST.V, ST.L, lane, seq, &ST.edge_max);
+  if constexpr (LEAN)
+    poa_fill_lean<CW>(g, ws.w_stride, ws.code_cells, codes, rows, hlast, V, L, lane, seq, edge0, kStBytes + 16, &ST.edge_max);
+  else
+    poa_fill_band<CW>(g, ws.w_stride, ws.code_cells, codes, rows, hlast, V, L, lane, seq, &ST.edge_max);
   __syncthreads();
   if (lane == 0) {
     reinterpret_cast<WgState*>(img)->edge_max = ST.edge_max;
@@ -2490,10 +3003,11 @@ int launch_msa(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& a, const ma_var
   ws.use_band = band_mode != 0 ? 1u : 0u;
   ws.split = band_mode == 2 ? 1u : 0u;
   ws.no_direct = getenv("MA_POA_NO_DIRECT") ? 1u : 0u;
+  ws.lean = (getenv("MA_POA_LEAN") && atoi(getenv("MA_POA_LEAN")) == 0) ? 0u : 1u;
   // first band tier: 64 (1), 128 (2) or 256 (4) columns; a tier whose certificate fails hands over to 256 columns, then
   // to the full fill.  Results do not depend on it (tested).
   {
-    int const t0 = getenv("MA_POA_TIER0") ? atoi(getenv("MA_POA_TIER0")) : 1;
+    int const t0 = getenv("MA_POA_TIER0") ? atoi(getenv("MA_POA_TIER0")) : MA_POA_TIER0;
     ws.tier0 = (t0 == 1 || t0 == 2) ? static_cast<u32>(t0) : 4u;
   }
   // split mode: a band round is launched while at least this many windows wait for a fill; fewer finish inside k_msa
@@ -2547,7 +3061,7 @@ int launch_msa(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& a, const ma_var
       // for a fill, k_msa_band fills them (one launch per tier that can hold work) and k_msa resumes them; once few are
       // left, a last k_msa launch finishes them in-kernel (their remaining fills on its wave 0) -- the tail of a batch
       // (third / fourth alignments, retried tiers) no longer costs two launches and a fill's latency per round.
-      size_t const band_lds = kStBytes + 16;
+      size_t const band_lds = kStBytes + 16 + 256;  // state block + poa_fill_lean's code table
       u32 const max_rounds = 2u * rounds + 2u;  // every alignment may need two band tiers
       for (u32 r = 0;; ++r) {
         args.round = r;
@@ -2569,9 +3083,16 @@ int launch_msa(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& a, const ma_var
           break;
         }
         ctx->tic("k_msa_band");
-        if (ws.tier0 == 1) hipLaunchKernelGGL(k_msa_band<1>, dim3(nwin), dim3(64), band_lds, ctx->stream, args);
-        else if (ws.tier0 == 2) hipLaunchKernelGGL(k_msa_band<2>, dim3(nwin), dim3(64), band_lds, ctx->stream, args);
-        if (ws.tier0 == 4 || r > 0) hipLaunchKernelGGL(k_msa_band<4>, dim3(nwin), dim3(64), band_lds, ctx->stream, args);
+        auto band = [&](auto kfn) { hipLaunchKernelGGL(kfn, dim3(nwin), dim3(64), band_lds, ctx->stream, args); };
+        if (ws.lean) {
+          if (ws.tier0 == 1) band(k_msa_band<1, true>);
+          else if (ws.tier0 == 2) band(k_msa_band<2, true>);
+          if (ws.tier0 == 4 || r > 0) band(k_msa_band<4, true>);
+        } else {
+          if (ws.tier0 == 1) band(k_msa_band<1, false>);
+          else if (ws.tier0 == 2) band(k_msa_band<2, false>);
+          if (ws.tier0 == 4 || r > 0) band(k_msa_band<4, false>);
+        }
         ctx->toc();
       }
     }

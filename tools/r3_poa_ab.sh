@@ -6,9 +6,9 @@ for t in 1 2 4; do
   echo "== tier0=$t"
   MA_POA_TIER0=$t MA_VERBOSE=1 timeout 300 python3 tools/poa_bench.py 8192 256 2>&1 | grep -v "^\[microasm\] msa:" | tail -3
 done
-echo "== tier0=4 2048 windows"
-MA_POA_TIER0=4 timeout 300 python3 tools/poa_bench.py 2048 256 2>&1 | tail -2
-echo "== tier0=2 2048 windows"
-MA_POA_TIER0=2 timeout 300 python3 tools/poa_bench.py 2048 256 2>&1 | tail -2
-echo "== tier0=1 2048 windows"
-MA_POA_TIER0=1 timeout 300 python3 tools/poa_bench.py 2048 256 2>&1 | tail -2
+for t in 1 2 4; do
+echo "== tier0=$t 2048 windows"
+MA_POA_TIER0=$t timeout 300 python3 tools/poa_bench.py 2048 256 2>&1 | tail -2
+done
+echo "== not lean, tier0=4 8192"
+MA_POA_LEAN=0 MA_POA_TIER0=4 timeout 300 python3 tools/poa_bench.py 8192 256 2>&1 | tail -2
