@@ -73,6 +73,7 @@ struct PoaWs {
   u32* tier_stats;   // [8] fills per tier 64/128/256 + (at 4) failed certificates per tier; null unless MA_VERBOSE
   u32* pending_ctr;  // split mode: windows that yielded in the current k_msa launch
   u32 no_direct;     // MA_POA_NO_DIRECT: every alignment goes through a fill (tests: the shortcut changes nothing)
+  u32 raw_cap;       // MA_POA_RAW_CAP: bytes per haplotype of the bubble walk's LDS scratch (tests: forces the HBM route)
   u32 lean;          // band tiers run poa_fill_lean (default) / poa_fill_band (MA_POA_LEAN=0; same codes, tested)
   size_t code_cells; // u16 per window
   size_t row_cells;  // i32 per window
@@ -116,6 +117,10 @@ struct WgState {
   // split mode: where k_msa resumes after k_msa_band has filled the pending alignment, and thread 0's output cursor
   u32 c_cur, h_cur, pending, done;
   u32 nvars, pool, var_overflow;
+  // thread 0's per-haplotype state of the bubble walk: dynamically indexed arrays, which as locals live in scratch memory
+  // (an HBM round trip per access of a serial walk)
+  i32 xa_active[16], xa_alt_of[16];
+  u32 xa_hap_pos[16], xa_starts[16], xa_rawlen[16], xa_grp_rep[16], xa_glo[16], xa_ghi[16], xa_ordg[16], xa_rank_of_grp[16];
 };
 #define ST (*reinterpret_cast<WgState*>(ma_lds))
 constexpr u32 kStBytes = (sizeof(WgState) + 15u) & ~15u;
@@ -2058,7 +2063,12 @@ __global__ __launch_bounds__(kT, 2) void k_msa(MsaArgs A) {
   u16* const codes = ws.codes + static_cast<size_t>(lw) * ws.code_cells;
   i32* const rows = ws.rows + static_cast<size_t>(lw) * ws.row_cells;
   i32* const hlast = ws.hlast + static_cast<size_t>(lw) * (PN + 8);
-  u8* const raw = reinterpret_cast<u8*>(codes);  // raw-allele scratch of the bubble walk (codes are dead by then)
+  // raw-allele scratch of the bubble walk: the alignment scratch in LDS (free by then) while a bubble's alleles fit,
+  // the code area in HBM beyond that (every byte thread 0 reads back from HBM is a round trip of its serial walk)
+  u8* const raw_hbm = reinterpret_cast<u8*>(codes);
+  u8* const raw_lds = &ma_lds[g.rowinfo.off];
+  u32 const raw_lds_room = (static_cast<u32>(poa_lds_bytes(PN, ws.max_l)) - 16u - g.rowinfo.off) / 16u;  // bytes per haplotype
+  u32 const raw_lds_cap = ws.raw_cap ? min(ws.raw_cap, raw_lds_room) : raw_lds_room;
 
   // Split mode: the banded fill of an alignment runs in k_msa_band (one wavefront per window, a dozen windows per
   // CU instead of two) between two launches of this kernel.  This kernel then works like a coroutine: when an
@@ -2066,6 +2076,9 @@ __global__ __launch_bounds__(kT, 2) void k_msa(MsaArgs A) {
   // launch restores the block and carries on right after the fill.
   u32* const img = ws.split ? reinterpret_cast<u32*>(ws.img) + static_cast<size_t>(lw) * ws.img_words : nullptr;
   bool resume = false;
+#ifdef MA_PROFILE
+  unsigned long long const t_in = __builtin_amdgcn_s_memtime();
+#endif
   if (A.round > 0) {
     if (reinterpret_cast<const WgState*>(img)->done) return;
     {  // 16 bytes per thread and load, four loads in flight (img_words is a multiple of 64, the image 256-byte aligned)
@@ -2102,6 +2115,9 @@ __global__ __launch_bounds__(kT, 2) void k_msa(MsaArgs A) {
   }
   __syncthreads();
   PROF_T0();
+#ifdef MA_PROFILE
+  if (tid == 0) atomicAdd(&g_prof[7], _t0 - t_in);  // image restore
+#endif
   bool yielded = false;
   u32 const c_start = resume ? ST.c_cur : 0u;
 
@@ -2625,8 +2641,9 @@ __global__ __launch_bounds__(kT, 2) void k_msa(MsaArgs A) {
     if (tid == 0 && ST.overflow) overflow = true;
     u32 const ns = ST.nseq;
     u32 const nn = ST.nn;
-    i32 active[16];
-    u32 hap_pos[16], starts[16];
+    i32(&active)[16] = ST.xa_active;
+    u32(&hap_pos)[16] = ST.xa_hap_pos;
+    u32(&starts)[16] = ST.xa_starts;
     u32 ref_pos = 0;
     i32 prev_match = -1;
     bool x_init = false;
@@ -2669,8 +2686,8 @@ __global__ __launch_bounds__(kT, 2) void k_msa(MsaArgs A) {
           }
         }
         u8* pl = A.o.allele_pool + static_cast<size_t>(w) * MP;
-        u32 const acap = 2 * ws.max_l + 8;  // raw allele strings: [ns][acap]
-        u32 rawlen[16];
+        u32 const acap_hbm = 2 * ws.max_l + 8;  // raw allele strings: [ns][acap]
+        u32(&rawlen)[16] = ST.xa_rawlen;
         auto converged = [&]() {
           for (u32 s = 1; s < ns; ++s)
             if (active[s] != active[0]) return false;
@@ -2685,6 +2702,8 @@ __global__ __launch_bounds__(kT, 2) void k_msa(MsaArgs A) {
           bool const has_prev = prev_match >= 0;
           u32 const aoff = has_prev ? 1u : 0u;
           u32 start_pos = ref_pos - aoff;
+          u8* raw = raw_lds;  // this bubble's strings: in LDS until one outgrows its share
+          u32 acap = raw_lds_cap;
           for (u32 s = 0; s < ns; ++s) {
             rawlen[s] = 0;
             if (has_prev) raw[s * acap + rawlen[s]++] = g.nchar[prev_match];
@@ -2697,6 +2716,12 @@ __global__ __launch_bounds__(kT, 2) void k_msa(MsaArgs A) {
             if (min_rank == 0xFFFFFFFFu) break;
             for (u32 s = 0; s < ns; ++s)
               if (active[s] >= 0 && g.node2rank[active[s]] == min_rank) {
+                if (rawlen[s] >= acap && raw == raw_lds) {  // move the bubble to HBM
+                  for (u32 t = 0; t < ns; ++t)
+                    for (u32 x = 0; x < rawlen[t]; ++x) raw_hbm[t * acap_hbm + x] = raw_lds[t * raw_lds_cap + x];
+                  raw = raw_hbm;
+                  acap = acap_hbm;
+                }
                 if (rawlen[s] < acap) raw[s * acap + rawlen[s]++] = g.nchar[active[s]]; else overflow = true;
                 active[s] = pg_successor(g, static_cast<u32>(active[s]), s);
                 hap_pos[s]++;
@@ -2704,8 +2729,8 @@ __global__ __launch_bounds__(kT, 2) void k_msa(MsaArgs A) {
               }
           }
           // group identical non-REF alleles (CreateNormalizedBubble); alt_of[s] = group id or -1
-          i32 alt_of[16];
-          u32 grp_rep[16];
+          i32(&alt_of)[16] = ST.xa_alt_of;
+          u32(&grp_rep)[16] = ST.xa_grp_rep;
           u32 ngrp = 0;
           for (u32 s = 1; s < ns; ++s) {
             alt_of[s] = -1;
@@ -2723,7 +2748,8 @@ __global__ __launch_bounds__(kT, 2) void k_msa(MsaArgs A) {
           if (ngrp == 0) continue;
           // NormalizeVcfParsimony (variant_bubble.cpp:89-116): trims act on views [lo, hi) of the raw strings
           u32 rlo = 0, rhi = rawlen[0];
-          u32 glo[16], ghi[16];
+          u32(&glo)[16] = ST.xa_glo;
+          u32(&ghi)[16] = ST.xa_ghi;
           for (u32 gi = 0; gi < ngrp; ++gi) {
             glo[gi] = 0;
             ghi[gi] = rawlen[grp_rep[gi]];
@@ -2749,7 +2775,7 @@ __global__ __launch_bounds__(kT, 2) void k_msa(MsaArgs A) {
             start_pos += init_len - (rhi - rlo);
           }
           // AssembleMultiallelicVariant: ALTs sorted by sequence (variant_extractor.cpp:229)
-          u32 ordg[16];
+          u32(&ordg)[16] = ST.xa_ordg;
           for (u32 gi = 0; gi < ngrp; ++gi) {
             u32 jx = gi;
             while (jx > 0 && bytes_cmp(raw + grp_rep[ordg[jx - 1]] * acap + glo[ordg[jx - 1]], ghi[ordg[jx - 1]] - glo[ordg[jx - 1]],
@@ -2778,7 +2804,7 @@ __global__ __launch_bounds__(kT, 2) void k_msa(MsaArgs A) {
             A.o.var_hap_allele[vi * MH + hx] = 0;
             A.o.var_hap_start[vi * MH + hx] = 0;
           }
-          u32 rank_of_grp[16];
+          u32(&rank_of_grp)[16] = ST.xa_rank_of_grp;
           for (u32 ai = 0; ai < ngrp; ++ai) {
             u32 const gi = ordg[ai];
             rank_of_grp[gi] = ai;
@@ -2787,7 +2813,7 @@ __global__ __launch_bounds__(kT, 2) void k_msa(MsaArgs A) {
             A.o.alt_off[vi * MA + ai] = pool;
             A.o.alt_len[vi * MA + ai] = alen;
             for (u32 x = 0; x < alen; ++x) pl[pool++] = as[x];
-            const u8* rs = pl + A.o.var_ref_off[vi];
+            const u8* rs = raw + rlo;  // (the REF allele as it stands in the scratch: the pool copy is in HBM)
             i32 const ty = classify_variant(rs, rhi - rlo, as, alen);
             A.o.alt_type[vi * MA + ai] = ty;
             A.o.alt_length[vi * MA + ai] = variant_length(rs, rhi - rlo, as, alen, ty);
@@ -2831,6 +2857,7 @@ __global__ __launch_bounds__(kT, 2) void k_msa(MsaArgs A) {
       u32 const nq = ws.img_words / 4u;
       for (u32 i = tid; i < nq; i += kT) dst[i] = src[i];
     }
+    PROF_ACC(14);  // image save
     return;
   }
   if (tid == 0) {
@@ -3003,6 +3030,7 @@ int launch_msa(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& a, const ma_var
   ws.use_band = band_mode != 0 ? 1u : 0u;
   ws.split = band_mode == 2 ? 1u : 0u;
   ws.no_direct = getenv("MA_POA_NO_DIRECT") ? 1u : 0u;
+  ws.raw_cap = getenv("MA_POA_RAW_CAP") ? static_cast<u32>(atoi(getenv("MA_POA_RAW_CAP"))) : 0u;
   ws.lean = (getenv("MA_POA_LEAN") && atoi(getenv("MA_POA_LEAN")) == 0) ? 0u : 1u;
   // first band tier: 64 (1), 128 (2) or 256 (4) columns; a tier whose certificate fails hands over to 256 columns, then
   // to the full fill.  Results do not depend on it (tested).

@@ -201,6 +201,31 @@ def test_msa_parity_band_tiers(tier0, min_pending, monkeypatch):
         assert not bad, (cfg, kw, "\n".join(bad[:20]))
 
 
+@pytest.mark.parametrize("lean,raw_cap", [("0", None), ("1", "4"), ("1", "40")])
+def test_msa_parity_lean_fill_and_bubble_scratch(lean, raw_cap, monkeypatch):
+    """poa_fill_lean (default) against poa_fill_band (MA_POA_LEAN=0): same decision codes, so the same variants; and the
+    bubble walk's raw alleles in LDS (default) against the HBM route a bubble takes when an allele outgrows its LDS share
+    (MA_POA_RAW_CAP = 4 / 40 bytes: every bubble / the 60-base ones move)."""
+    from lancet2_amd.engine import Engine
+    monkeypatch.setenv("MA_POA_LEAN", lean)
+    if raw_cap:
+        monkeypatch.setenv("MA_POA_RAW_CAP", raw_cap)
+    params = capi.default_params(min_k=25, max_k=25)
+    for cfg, nwin, kw in (("C2", 6, {}), ("C2", 3, dict(big_indel=60)), ("C3", 3, dict(snv_rate=8e-3, indel_rate=2e-3))):
+        arrs, n, nr = synth.make_config_batch(cfg, nwin, first_index=6400, **kw)
+        orc = OracleEngine(params)
+        asm = orc.assemble(arrs, n, nr)
+        want = orc.msa(arrs, n, nr, asm)
+        eng = Engine(params)
+        try:
+            got = eng.msa(arrs, n, nr, asm)
+        finally:
+            eng.close()
+        bad = compare_vars(params, got, want, n)
+        assert not bad, (cfg, kw, "\n".join(bad[:20]))
+        assert want["win_nvars"].sum() > 0
+
+
 @pytest.mark.parametrize("no_direct", [False, True])
 @pytest.mark.parametrize("kw,need", [(dict(indel_rate=6e-4), (2, 2, 2)),
                                      (dict(str_unit=b"A", indel_rate=4e-4), (2, 4, 2))])  # homopolymers: the indel slides
