@@ -50,7 +50,13 @@ enum ma_wstatus {
   MA_W_BFS_LIMIT = 1u << 3,      /* MaxFlow::HitTraversalLimit (max_flow.h:69) in some component */
   MA_W_TABLE_OVERFLOW = 1u << 4, /* k-mer table / edge list / search arena capacity exceeded, or the traversal cap fell where
                                     the folded walk search cannot place it: the window's result is not the reference's */
-  MA_W_VAR_OVERFLOW = 1u << 5    /* more variants / alleles / allele bytes than the caps */
+  MA_W_VAR_OVERFLOW = 1u << 5,   /* more variants / alleles / allele bytes than the caps */
+  MA_W_CIGAR_OVERFLOW = 1u << 6, /* a read<->haplotype CIGAR had more than max_cigar operations and was cut before the scoring
+                                    epilogue (local_scorer.cpp:166-279 scores the whole CIGAR): re-submit the window with a
+                                    larger max_cigar -- 2 * ((read length - 80) / 15) + 3 operations always suffice */
+  MA_W_READ_OVERFLOW = 1u << 7   /* the window holds a read longer than the stage supports (assembly: 1024 bases, genotyping:
+                                    608): the stage skips the window (no haplotypes / no allele counts) instead of failing
+                                    the batch */
 };
 
 /* GraphParams (cbdg/graph_params.h:29-53) + the constants the reference hard-codes + engine caps. */

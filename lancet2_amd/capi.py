@@ -15,6 +15,7 @@ LIB_PATH = os.environ.get("MA_LIB") or os.path.join(REPO, "lancet2_amd", "libmic
 MA_RF_PASS, MA_RF_CASE, MA_RF_REV = 1, 2, 4
 MA_W_NO_HAPLOTYPE, MA_W_HAP_OVERFLOW, MA_W_LEN_OVERFLOW = 1, 2, 4
 MA_W_BFS_LIMIT, MA_W_TABLE_OVERFLOW, MA_W_VAR_OVERFLOW = 8, 16, 32
+MA_W_CIGAR_OVERFLOW, MA_W_READ_OVERFLOW = 64, 128
 MA_MEM_HOST, MA_MEM_DEVICE = 0, 1
 MA_NO_HINT = -(1 << 31)
 

@@ -112,13 +112,23 @@ struct GArgs {
   u32 dp_n;      // entries of this DP launch
 };
 
-__global__ void k_max_reads(DBatch b, u32* out) {  // out[0] most reads of a window, out[1] longest read
+// A read's three bit planes live in one wavefront (k_vote / k_align_*: a lane per word): 608 bases at most.  A window
+// that holds a longer read is not genotyped and says so (MA_W_READ_OVERFLOW) -- the batch goes on without it.
+constexpr u32 kMaxGenoRead = 608;
+__global__ void k_max_reads(DBatch b, u32* win_status, u32* out) {  // out[0] most reads of a window, out[1] longest read
   int const w = blockIdx.x * blockDim.x + threadIdx.x;
   if (w >= b.n_windows) return;
   atomicMax(out, b.read_win_off[w + 1] - b.read_win_off[w]);
   u32 ml = 0;
   for (u32 r = b.read_win_off[w]; r < b.read_win_off[w + 1]; ++r) ml = max(ml, static_cast<u32>(b.read_off[r + 1] - b.read_off[r]));
-  atomicMax(out + 1, ml);
+  // (a window the assembler skipped for its reads keeps that flag: it has no haplotypes to genotype)
+  u32 const st = win_status[w] & ~static_cast<u32>(MA_W_CIGAR_OVERFLOW);
+  if (ml > kMaxGenoRead) {
+    win_status[w] = st | static_cast<u32>(MA_W_READ_OVERFLOW);
+  } else {
+    win_status[w] = (st & MA_W_NO_HAPLOTYPE) ? st : (st & ~static_cast<u32>(MA_W_READ_OVERFLOW));
+    atomicMax(out + 1, ml);
+  }
 }
 
 // ---- planning ----
@@ -128,7 +138,7 @@ __global__ void k_plan(GArgs A) {
   ma_params_t const& P = A.prm;
   u32 mask = 0, hl = 0;
   u32 const nv = A.v.win_nvars[w];
-  if (nv > 0 && !(A.a.win_status[w] & MA_W_NO_HAPLOTYPE)) {
+  if (nv > 0 && !(A.a.win_status[w] & (MA_W_NO_HAPLOTYPE | MA_W_READ_OVERFLOW))) {
     for (u32 c = 0; c < A.a.win_ncomp[w]; ++c) {
       bool has = false;
       for (u32 x = 0; x < nv && !has; ++x) has = A.v.var_comp[static_cast<size_t>(w) * P.max_vars + x] == c;
@@ -172,7 +182,7 @@ __global__ __launch_bounds__(256) void k_plan_reads(GArgs A) {
   }
   if (lane == 0) {
     A.ws.win_case[w] = cm;
-    if (ml) atomicMax(&A.ws.counters[0], ml);
+    if (ml && !(A.a.win_status[w] & MA_W_READ_OVERFLOW)) atomicMax(&A.ws.counters[0], ml);
   }
 }
 
@@ -263,6 +273,7 @@ __global__ __launch_bounds__(256) void k_read_planes(GArgs A, u32 rwords) {
     int const x = static_cast<int>(r - r_begin);
     u64 const ro = off_of(x);
     *mm = static_cast<i32>(off_of(x + 1) - ro);
+    if (*mm > static_cast<i32>(rwords - 2) * 32) *mm = 0;  // a read of a window that is not genotyped (MA_W_READ_OVERFLOW)
     const u8* rb = A.b.read_bases + ro;
 #pragma unroll
     for (int q = 0; q < kPre; ++q) pre[q] = lane + 64 * q < *mm ? rb[lane + 64 * q] : 0u;
@@ -1720,6 +1731,8 @@ __global__ __launch_bounds__(64) void k_assign(GArgs A) {
         if (!ar[0]) continue;
         const u32* cgp = A.o.aln_cigar + rec * (1 + MCG);
         Cig cg{cgp + 1, min(cgp[0], static_cast<u32>(MCG))};
+        // the record holds max_cigar operations; the reference scores the whole CIGAR: never silently
+        if (cgp[0] > static_cast<u32>(MCG)) atomicOr(&A.a.win_status[w], static_cast<u32>(MA_W_CIGAR_OVERFLOW));
         // ExtractHapBounds (genotyper.cpp:329-352)
         i32 vstart, vlen;
         u32 allele;
@@ -1946,15 +1959,14 @@ int launch_genotype(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& a, const m
     MA_HIP(ctx, ctx->ws_misc.reserve(4096));
     u32* cnt = ctx->ws_misc.as<u32>();
     MA_HIP(ctx, hipMemsetAsync(cnt, 0, 16, ctx->stream));
-    hipLaunchKernelGGL(k_max_reads, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, b, cnt);
+    hipLaunchKernelGGL(k_max_reads, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, b, a.win_status, cnt);
     u32 mr2[2] = {0, 0};
     MA_HIP(ctx, hipMemcpyAsync(mr2, cnt, 8, hipMemcpyDeviceToHost, ctx->stream));
     MA_HIP(ctx, ma_stream_sync(ctx));
     u32 const mr = mr2[0];
     rwords_all = (mr2[1] + 31) / 32 + 2;
-    if (3u * rwords_all > 64u) {  // k_vote / k_align_*: one wavefront lane per word of a read's three bit planes
-      ctx->err = "ma_genotype_batch: reads longer than 608 bases are not supported (longest read of the batch: " +
-                 std::to_string(mr2[1]) + ")";
+    if (3u * rwords_all > 64u) {  // (cannot happen: k_max_reads leaves the windows with longer reads out)
+      ctx->err = "ma_genotype_batch: read planes do not fit a wavefront";
       return MA_ERR_PARAM;
     }
     u64 want = static_cast<u64>(mr) * 8 + 1024;

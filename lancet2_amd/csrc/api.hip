@@ -505,7 +505,11 @@ int ma_genotype_batch(ma_ctx_t* ctx, const ma_batch_t* b, const ma_asm_out_t* as
   MA_TRY(g.prepare(ctx, out, geno_fields(ctx->prm, d.n_windows, d.n_reads), 32, false));
   MA_TRY(launch_genotype(ctx, d, a.dev, v.dev, g.dev));
   MA_TRY(g.download(ctx));
-  if (ctx->memspace == MA_MEM_HOST) MA_HIP(ctx, ma_stream_sync(ctx));
+  // win_status may gain MA_W_CIGAR_OVERFLOW / MA_W_READ_OVERFLOW
+  if (ctx->memspace == MA_MEM_HOST) {
+    MA_HIP(ctx, hipMemcpyAsync(asmb->win_status, a.dev.win_status, 4ull * d.n_windows, hipMemcpyDeviceToHost, ctx->stream));
+    MA_HIP(ctx, ma_stream_sync(ctx));
+  }
   return MA_OK;
 }
 

@@ -497,10 +497,25 @@ __global__ __launch_bounds__(kInsT) void k_insert(DBatch b, GraphWs ws) {
   }
   __syncthreads();
   if (stage) {
+    const u8* const batch_lo = b.read_bases;
+    const u8* const batch_hi = b.read_bases + b.read_off[b.n_reads];
     u32 const nwords = static_cast<u32>((seq_bytes + 7u) / 8u);
     bool odd = false;
     for (u32 wd = threadIdx.x; wd < nwords; wd += kInsT) {
-      uint2 const v = *reinterpret_cast<const uint2*>(seq_base + static_cast<size_t>(wd) * 8u);  // (buffers are padded by 64 bytes)
+      // aligned 8-byte words; the first / last word of the BATCH may reach outside the caller's buffer (MA_MEM_DEVICE
+      // passes the caller's pointer through: no alignment or padding is promised) and is read byte by byte
+      const u8* const wp = seq_base + static_cast<size_t>(wd) * 8u;
+      uint2 v;
+      if (wp >= batch_lo && wp + 8 <= batch_hi) {
+        v = *reinterpret_cast<const uint2*>(wp);
+      } else {
+        u32 lo4 = 0, hi4 = 0;
+        for (int x = 0; x < 8; ++x) {
+          u32 const byte = (wp + x >= batch_lo && wp + x < batch_hi) ? wp[x] : 0u;
+          if (x < 4) lo4 |= byte << (8 * x); else hi4 |= byte << (8 * (x - 4));
+        }
+        v = make_uint2(lo4, hi4);
+      }
       u32 pk = 0;
 #pragma unroll
       for (int x = 0; x < 8; ++x) {

@@ -306,6 +306,20 @@ class DeviceArena:
             self._check(self.hip.hipMemcpy(p, arr.ctypes.data, arr.nbytes, 1), "hipMemcpy H2D")
         return p
 
+    def upload_unaligned(self, arr, shift=3, guard=256, junk=0x5A):
+        """arr at an odd offset inside a junk-filled allocation, nothing but junk before and behind it: what a caller's
+        exactly sized sub-allocation looks like to a kernel that reads aligned words around its input"""
+        arr = np.ascontiguousarray(arr)
+        total = arr.nbytes + 2 * guard + shift
+        p = self.C.c_void_p()
+        self._check(self.hip.hipMalloc(self.C.byref(p), total), "hipMalloc")
+        self._check(self.hip.hipMemset(p, junk, total), "hipMemset")
+        self.ptrs.append(p)
+        at = int(p.value) + guard + shift
+        if arr.nbytes:
+            self._check(self.hip.hipMemcpy(at, arr.ctypes.data, arr.nbytes, 1), "hipMemcpy H2D")
+        return at
+
     def download(self, ptr, dtype, count):
         out = np.zeros(int(count), dtype=dtype)
         self._check(self.hip.hipDeviceSynchronize(), "hipDeviceSynchronize")

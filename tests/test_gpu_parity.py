@@ -748,6 +748,120 @@ def test_device_memspace_matches_host_memspace(streams, taps):
     assert np.array_equal(dq["var_qual"].view(np.uint64), hq["var_qual"].view(np.uint64))
 
 
+def test_truncated_cigars_are_flagged_not_silent():
+    """The alignment records hold max_cigar operations and the scoring epilogue (local_scorer.cpp:166-279) walks the whole
+    CIGAR: with a cap that some read's CIGAR exceeds (max_cigar = 4 on indel-dense windows) every window that holds such
+    a read says so (MA_W_CIGAR_OVERFLOW) and every other window equals the oracle; with a cap that suffices (64) no window
+    is flagged and all of them equal the oracle."""
+    from lancet2_amd.engine import Engine
+    arrs, n, nr = synth.make_config_batch("C2", 4, first_index=8800, indel_rate=1.5e-2, snv_rate=2e-3)
+    rwo = arrs["read_win_off"]
+    for mcg in (4, 64):
+        params = capi.default_params(min_k=25, max_k=25, max_cigar=mcg)
+        orc = OracleEngine(params)
+        asm = orc.assemble(arrs, n, nr)
+        var = orc.msa(arrs, n, nr, asm)
+        want = orc.genotype(arrs, n, nr, asm, var)
+        status0 = asm["win_status"].copy()
+        eng = Engine(params)
+        try:
+            got = eng.genotype(arrs, n, nr, asm, var)
+        finally:
+            eng.close()
+        ncig = want["aln_cigar"].reshape(nr, params.max_haps, 1 + mcg)[:, :, 0]
+        long_win = np.array([bool((ncig[rwo[w]:rwo[w + 1]] > mcg).any()) for w in range(n)])
+        flagged = (asm["win_status"] & capi.MA_W_CIGAR_OVERFLOW) != 0
+        assert np.array_equal(asm["win_status"] & ~np.uint32(capi.MA_W_CIGAR_OVERFLOW), status0)
+        # a flag needs a long CIGAR of a read that overlaps a variant; no long CIGAR, no flag
+        assert not (flagged & ~long_win).any()
+        if mcg == 4:
+            assert flagged.any(), "the batch was meant to hold CIGARs of more than four operations"
+        else:
+            assert not flagged.any()
+        per = params.max_vars * params.num_samples * (params.max_alts + 1) * 2
+        gc, wc = got["allele_counts"].reshape(n, per), want["allele_counts"].reshape(n, per)
+        for w in range(n):
+            if not flagged[w]:
+                assert np.array_equal(gc[w], wc[w]), f"window {w} (max_cigar {mcg})"
+        assert want["allele_counts"].sum() > 0
+
+
+def test_over_long_reads_flag_their_window_not_the_batch():
+    """A read beyond what a stage supports (genotyping: 608 bases, assembly: 1024) used to fail the whole batch with
+    MA_ERR_PARAM; now its window is skipped by that stage and says so (MA_W_READ_OVERFLOW), the other windows equal the
+    oracle."""
+    from lancet2_amd.engine import Engine
+    params = capi.default_params(min_k=25, max_k=25)
+    kw = dict(synth.CONFIGS["C2"])
+    wins = [synth.make_window(9100 + i, **kw) for i in range(4)]
+    wins[1] = synth.make_window(9101, **dict(kw, read_len=700, depths=(12, 12)))
+    wins[3] = synth.make_window(9103, **dict(kw, read_len=1100, depths=(8, 8)))
+    arrs, n, nr = synth.pack_batch(wins)
+    eng = Engine(params)
+    try:
+        g, a, v, q = eng.process(arrs, n, nr, debug=False)
+    finally:
+        eng.close()
+    orc = OracleEngine(params)
+    wa = orc.assemble(arrs, n, nr)
+    wv = orc.msa(arrs, n, nr, wa)
+    wq = orc.genotype(arrs, n, nr, wa, wv, debug=False)
+    st = a["win_status"]
+    assert st[3] & capi.MA_W_READ_OVERFLOW and st[3] & capi.MA_W_NO_HAPLOTYPE      # not assembled
+    assert st[1] & capi.MA_W_READ_OVERFLOW and not (st[1] & capi.MA_W_NO_HAPLOTYPE)  # assembled, not genotyped
+    assert not (st[0] & capi.MA_W_READ_OVERFLOW) and not (st[2] & capi.MA_W_READ_OVERFLOW)
+    per = params.max_vars * params.num_samples * (params.max_alts + 1) * 2
+    gc, wc = q["allele_counts"].reshape(n, per), wq["allele_counts"].reshape(n, per)
+    for w in (0, 2):
+        assert np.array_equal(gc[w], wc[w]) and wc[w].sum() > 0
+    assert gc[1].sum() == 0 and gc[3].sum() == 0
+    # window 1's haplotypes and variants are the oracle's
+    from harness import compare_vars as cv
+    sel = np.array([0, 1, 2])
+    assert int(v["win_nvars"][1]) == int(wv["win_nvars"][1]) and int(a["win_ncomp"][1]) == int(wa["win_ncomp"][1])
+
+
+def test_device_buffers_need_no_padding_or_alignment():
+    """MA_MEM_DEVICE passes the caller's pointers through: the byte arrays (reference, read bases, qualities) sized
+    exactly -- without the 64 bytes of padding the host route adds --, at odd addresses, with junk on both sides, give the
+    same bytes (k_insert stages the window's reads with aligned 8-byte words and must not let what lies outside in)."""
+    from harness import DeviceArena
+    from lancet2_amd.engine import Engine
+    params = capi.default_params(min_k=25, max_k=25)
+    arrs, n, nr = synth.make_config_batch("C2", 5, first_index=95_500)
+    eng = Engine(params)
+    try:
+        hg, ha, hv, hq = eng.process(arrs, n, nr, debug=False)
+    finally:
+        eng.close()
+    specs = [capi.gate_out_spec(n), capi.asm_out_spec(params, n), capi.var_out_spec(params, n),
+             capi.geno_out_spec(params, n, nr, debug=False)]
+    deng = Engine(params, memspace=capi.MA_MEM_DEVICE)
+    arena = DeviceArena()
+    try:
+        dptr = {}
+        for k, v in arrs.items():
+            if k in ("ref_bases", "read_bases", "read_quals"):
+                dptr[k] = arena.upload_unaligned(v[:-64], shift={"ref_bases": 1, "read_bases": 3, "read_quals": 5}[k])
+            else:
+                dptr[k] = arena.upload(v)
+        b = capi.make_batch_struct(dptr, n, nr)
+        ptrs = [{k: arena.alloc(int(sz) * np.dtype(dt).itemsize) for k, (dt, sz) in spec.items()} for spec in specs]
+        deng.process_device(b, capi.fill_struct(capi.GateOut, ptrs[0]), capi.fill_struct(capi.AsmOut, ptrs[1]),
+                            capi.fill_struct(capi.VarOut, ptrs[2]), capi.fill_struct(capi.GenoOut, ptrs[3]))
+        deng.synchronize()
+        dg, da, dv, dq = [{k: arena.download(pt[k], dt, sz) for k, (dt, sz) in spec.items()}
+                          for spec, pt in zip(specs, ptrs)]
+    finally:
+        deng.close()
+        arena.close()
+    assert np.array_equal(dg["max_approx"], hg["max_approx"])
+    bad = compare_asm(params, da, ha, n) + compare_vars(params, dv, hv, n)
+    assert not bad, "\n".join(bad[:10])
+    assert np.array_equal(dq["allele_counts"], hq["allele_counts"])
+    assert np.array_equal(dq["var_qual"].view(np.uint64), hq["var_qual"].view(np.uint64))
+
+
 def test_outputs_do_not_depend_on_previous_batches_or_debug_taps():
     """One engine, batches of different shapes back to back: workspaces are reused (never cleared wholesale), so
     anything a kernel forgets to write would surface as the previous batch's bytes.  The run without the debug taps
