@@ -55,12 +55,22 @@ def _hap_to_ref(bps, hap_pos):
 
 def make_window(index, W=1001, depths=(30, 30), roles=(0, 1), snv_rate=1e-3, indel_rate=2e-4,
                 n_somatic=1, big_indel=0, str_unit=None, read_len=READ_LEN, error_scale=1.0,
-                low_mapq_frac=0.05, seed0=SEED0):
+                low_mapq_frac=0.05, seed0=SEED0, dup_len=0, low_complexity=0, softclip_frac=0.0, n_frac=0.0, tandem_dup=0):
     """Returns dict(ref=uint8[W], reads=list of dict) for one window.
 
     depths/roles: per-sample depth and role (0 = normal/CTRL, 1 = tumour/CASE).
     big_indel: if > 0, plant one somatic insertion and one germline deletion of that length (C4).
     str_unit: optional bytes; a short tandem repeat (12 copies) is spliced into the window.
+    dup_len: if > 0, a dispersed duplication: that many bases of the window's first third are copied into its last third
+        (a repeat of the REFERENCE longer than k: the repeat gate skips every k up to its length).
+    tandem_dup: if > 0, a germline tandem duplication of that many bases in one or both sample haplotypes (the reference
+        window has no repeat, so the gate lets k = 25 through; the graph of the reads has a cycle until k outgrows the
+        duplication -- what sends WGS windows up the k ladder).
+    low_complexity: if > 0, a stretch of that many bases drawn from a skewed two-letter alphabet.
+    softclip_frac: fraction of reads whose head or tail (8-40 bases) is replaced by unrelated low-quality bases
+        (adapter read-through / chimeric ends: what an aligner soft-clips).
+    n_frac: fraction of reads with one to three N bases (quality 2).
+    The four options draw from a random stream of their own: a window without them is unchanged.
     """
     rng = np.random.default_rng((seed0 + index) & ((1 << 63) - 1))
     G = W + 2 * FLANK
@@ -70,6 +80,15 @@ def make_window(index, W=1001, depths=(30, 30), roles=(0, 1), snv_rate=1e-3, ind
         rep = np.tile(unit, 12)
         s = FLANK + W // 2
         genome[s:s + len(rep)] = rep[: max(0, min(len(rep), G - s))]
+    rng2 = np.random.default_rng(((seed0 ^ 0x0DD5EED5) + 7919 * index) & ((1 << 63) - 1))  # the harder shapes' own stream
+    if dup_len > 0 and W >= 3 * dup_len:
+        s1 = FLANK + int(rng2.integers(40, W // 3 - dup_len // 2))
+        s2 = FLANK + int(rng2.integers(2 * W // 3 - dup_len // 2, W - dup_len - 40))
+        genome[s2:s2 + dup_len] = genome[s1:s1 + dup_len]
+    if low_complexity > 0:
+        a, b2 = BASES[rng2.permutation(4)[:2]]
+        s = FLANK + int(rng2.integers(60, max(61, W - low_complexity - 60)))
+        genome[s:s + low_complexity] = np.where(rng2.random(low_complexity) < 0.8, a, b2)
     # ---- variants (genome coordinates) ----
     germ = []  # (pos, ref_len, alt, hapmask) hapmask bit0 = A, bit1 = B
     lo, hi = FLANK + 60, FLANK + W - 60
@@ -88,6 +107,12 @@ def make_window(index, W=1001, depths=(30, 30), roles=(0, 1), snv_rate=1e-3, ind
                 germ.append((pos, ln, b"", int(rng.integers(1, 4))))
             else:
                 germ.append((pos, 0, _rand_dna(rng, ln).tobytes(), int(rng.integers(1, 4))))
+    if tandem_dup > 0:
+        for _try in range(30):
+            p = int(rng2.integers(lo + tandem_dup + 10, hi - 10))
+            if all(abs(p - g[0]) > tandem_dup + 40 for g in germ):
+                germ.append((p, 0, genome[p - tandem_dup:p].tobytes(), int(rng2.integers(1, 4))))
+                break
     som = []
     used = [g[0] for g in germ]
     for _ in range(n_somatic):
@@ -162,6 +187,17 @@ def make_window(index, W=1001, depths=(30, 30), roles=(0, 1), snv_rate=1e-3, ind
                 if err.any():
                     idx = np.nonzero(err)[0]
                     seq[idx] = BASES[(np.searchsorted(BASES, seq[idx]) + rng.integers(1, 4, len(idx))) % 4]
+                if softclip_frac > 0.0 and rng2.random() < softclip_frac:
+                    cl = int(rng2.integers(8, 41))
+                    sl = slice(0, cl) if rng2.random() < 0.5 else slice(read_len - cl, read_len)
+                    seq[sl] = _rand_dna(rng2, cl)
+                    q = q.copy()
+                    q[sl] = rng2.integers(2, 13, cl).astype(np.uint8)
+                if n_frac > 0.0 and rng2.random() < n_frac:
+                    at = rng2.integers(0, read_len, int(rng2.integers(1, 4)))
+                    seq[at] = ord("N")
+                    q = q.copy()
+                    q[at] = 2
                 reads.append(dict(seq=seq, qual=q, qname=name, sample=s, role=role, rev=rev,
                                   passf=not lowq, start=start - FLANK,
                                   hint=_hap_to_ref(bps, start) - FLANK))  # what a BAM record's POS gives
@@ -224,6 +260,25 @@ def tile_batch(arrs, n, nr, times):
         if k in arrs:
             out[k] = np.tile(arrs[k], times)
     return out, n * times, nr * times
+
+
+def slice_batch(arrs, n, w0, w1):
+    """windows [w0, w1) of a packed batch as a packed batch of their own"""
+    w1 = min(w1, n)
+    r0, r1 = int(arrs["read_win_off"][w0]), int(arrs["read_win_off"][w1])
+    b0, b1 = int(arrs["read_off"][r0]), int(arrs["read_off"][r1])
+    f0, f1 = int(arrs["ref_off"][w0]), int(arrs["ref_off"][w1])
+    pad = np.zeros(64, np.uint8)
+    out = dict(ref_bases=np.concatenate([arrs["ref_bases"][f0:f1], pad]),
+               read_bases=np.concatenate([arrs["read_bases"][b0:b1], pad]),
+               read_quals=np.concatenate([arrs["read_quals"][b0:b1], pad]),
+               ref_off=(arrs["ref_off"][w0:w1 + 1] - arrs["ref_off"][w0]).astype(np.uint32),
+               read_win_off=(arrs["read_win_off"][w0:w1 + 1] - arrs["read_win_off"][w0]).astype(np.uint32),
+               read_off=(arrs["read_off"][r0:r1 + 1] - arrs["read_off"][r0]).astype(np.uint64))
+    for k in ("read_qname_id", "read_sample", "read_flags", "read_hint"):
+        if k in arrs:
+            out[k] = arrs[k][r0:r1].copy()
+    return out, w1 - w0, r1 - r0
 
 
 CONFIGS = {

@@ -14,10 +14,16 @@ ORACLE_LIB = os.path.join(ORACLE_DIR, "liboracle.so")
 
 
 def load_oracle():
+    alt = os.environ.get("MA_ORACLE_LIB")  # bench.py's cpu_baseline leg: the -O3 -march=native build of the same sources
+    if alt and os.path.exists(alt):
+        return _declare(C.CDLL(alt))
     srcs = [os.path.join(ORACLE_DIR, f) for f in os.listdir(ORACLE_DIR) if f.endswith((".cpp", ".hpp"))]
     if (not os.path.exists(ORACLE_LIB)) or any(os.path.getmtime(s) > os.path.getmtime(ORACLE_LIB) for s in srcs):
         subprocess.check_call(["make", "-C", ORACLE_DIR, "-s"])
-    lib = C.CDLL(ORACLE_LIB)
+    return _declare(C.CDLL(ORACLE_LIB))
+
+
+def _declare(lib):
     lib.orc_hamming.restype = C.c_uint64
     lib.orc_hash64.restype = C.c_uint64
     lib.orc_phred.restype = C.c_double

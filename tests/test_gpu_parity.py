@@ -748,6 +748,33 @@ def test_device_memspace_matches_host_memspace(streams, taps):
     assert np.array_equal(dq["var_qual"].view(np.uint64), hq["var_qual"].view(np.uint64))
 
 
+@pytest.mark.parametrize("kw,pk", [(dict(tandem_dup=40), {}), (dict(tandem_dup=60), dict(min_k=25, max_k=25)),
+                                   (dict(dup_len=260), dict(min_k=25, max_k=25)),
+                                   (dict(low_complexity=100, softclip_frac=0.08, n_frac=0.04), {})])
+def test_whole_chain_parity_on_the_harder_bench_shapes(kw, pk):
+    """Tandem duplications in the sample (a repeat longer than k: cycles until the k ladder outgrows it), dispersed
+    duplications of the reference (the gate skips every k), low-complexity stretches,
+    soft-clipped and N-containing reads -- the shapes bench.py mixes into its WGS windows since round 3: every stage
+    bit-identical to the oracle, with the reference's k cascade and at the bench's single k = 25."""
+    from lancet2_amd.engine import Engine
+    params = capi.default_params(**pk)
+    arrs, n, nr = synth.make_config_batch("C3", 4, first_index=83_000, **kw)
+    orc = OracleEngine(params)
+    wa = orc.assemble(arrs, n, nr)
+    wv = orc.msa(arrs, n, nr, wa)
+    wq = orc.genotype(arrs, n, nr, wa, wv)
+    eng = Engine(params)
+    try:
+        g, a, v, q = eng.process(arrs, n, nr, debug=True)
+    finally:
+        eng.close()
+    bad = compare_asm(params, a, wa, n) + compare_vars(params, v, wv, n)
+    bad += compare_geno(params, q, wq, n, nr, wv["win_nvars"], arrs["read_win_off"])
+    assert not bad, "\n".join(bad[:12])
+    if "tandem_dup" in kw and not pk:  # the duplication sent at least one window up the ladder
+        assert (wa["win_k"] > 40).any(), wa["win_k"].tolist()
+
+
 def test_truncated_cigars_are_flagged_not_silent():
     """The alignment records hold max_cigar operations and the scoring epilogue (local_scorer.cpp:166-279) walks the whole
     CIGAR: with a cap that some read's CIGAR exceeds (max_cigar = 4 on indel-dense windows) every window that holds such

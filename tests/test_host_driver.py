@@ -42,7 +42,9 @@ def test_host_driver_records_match_the_oracle(tmp_path, mode):
     dump.mkdir()
     out = tmp_path / "records.tsv"
     n = 24
-    cmd = [exe, "--windows", str(n), "--batch", "5", "--feeders", "3", "--dump", str(dump), "--out", str(out)]
+    # (somatic: four feeder threads = four contexts on device 0, the multi-context path of an 8-GPU host in miniature)
+    cmd = [exe, "--windows", str(n), "--batch", "5", "--devices", "1", "--feeders", "4" if mode == "somatic" else "3",
+           "--dump", str(dump), "--out", str(out)]
     if mode == "germline":
         cmd.append("--germline")
     r = subprocess.run(cmd, capture_output=True, text=True)

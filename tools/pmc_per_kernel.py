@@ -15,9 +15,13 @@ and all launches of the run, statistics and warm-up steps included) -- the way b
 import csv
 import glob
 import json
+import os
 import re
 import sys
 from collections import defaultdict
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from lancet2_amd.stamp import csrc_sha16  # noqa: E402
 
 
 def collect(root, counter):
@@ -49,9 +53,11 @@ def main():
                   "bytes_per_launch": int(rd + wr), "valu_insts_per_launch": int(vi / max(nv, 1))}
     out["_note"] = ("FETCH_SIZE x 1024 x 2 (gfx950 read correction) + WRITE_SIZE x 1024; SQ_INSTS_VALU wave instructions; "
                     "averaged per launch; three separate --pmc passes of `python3 bench.py --steps 2 --no-cpu --no-also`")
+    # provenance: bench.py marks these figures stale when the kernel sources it runs are not the ones profiled here
+    out["_stamp"] = {"csrc_sha16": csrc_sha16(), "command": "python3 bench.py --steps 2 --no-cpu --no-also --gen-workers 1"}
     json.dump(out, open(sys.argv[4], "w"), indent=1, sort_keys=True)
     for k, v in out.items():
-        if k != "_note":
+        if not k.startswith("_"):
             print(f"{k:24s} launches {v['launches']:3d}  read {v['read_bytes_per_launch'] / 1e9:9.3f} GB  "
                   f"write {v['write_bytes_per_launch'] / 1e9:9.3f} GB  valu {v['valu_insts_per_launch'] / 1e6:10.2f} M")
 

@@ -23,7 +23,15 @@ CASES = [("C2", 96, 70_000, {}, dict(min_k=25, max_k=25)), ("C3", 32, 71_000, {}
          # round 2: germline mode (PL / GQ / QUAL), long reads (wide search regions), long indels
          ("C2", 24, 80_000, {}, dict(min_k=25, max_k=25, case_ctrl_mode=0)),
          ("C2", 12, 81_000, dict(read_len=250, big_indel=60), dict(min_k=25, max_k=25)),
-         ("C3", 16, 82_000, dict(str_unit=b"AGGGTT", error_scale=2.0), dict(min_k=25, max_k=25))]
+         ("C3", 16, 82_000, dict(str_unit=b"AGGGTT", error_scale=2.0), dict(min_k=25, max_k=25)),
+         # round 3: the bench's harder shapes -- dispersed duplications (cycles at k = 25: the k ladder), low-complexity
+         # stretches, soft-clipped and N-containing reads, 2 x 250 reads
+         ("C3", 16, 83_000, dict(dup_len=200), {}), ("C3", 16, 84_000, dict(dup_len=260), dict(min_k=25, max_k=25)),
+         ("C3", 16, 85_000, dict(low_complexity=100), {}),
+         ("C3", 16, 86_000, dict(softclip_frac=0.1, n_frac=0.05), dict(min_k=25, max_k=25)),
+         ("C2", 12, 87_000, dict(read_len=250, dup_len=180, softclip_frac=0.05, n_frac=0.02), {}),
+         ("C3", 16, 89_000, dict(tandem_dup=40), {}), ("C3", 16, 90_000, dict(tandem_dup=70, softclip_frac=0.03), {}),
+         ("C3", 12, 88_000, dict(dup_len=150, low_complexity=60, softclip_frac=0.03, n_frac=0.01, str_unit=b"CA"), {})]
 shift = int(sys.argv[1]) if len(sys.argv) > 1 else 0  # other windows of the same shapes
 tot = 0
 for cfg, nwin, first, kw, pk in CASES:
