@@ -625,10 +625,7 @@ def main():
         #     examples/host_driver.cpp --feeders 2 does): one batch's copies run under the other batch's kernels.
         try:
             import threading
-            if n0 > 4096:
-                h_arrs, hn, h_nr = synth.slice_batch(arrs0, n0, 0, 4096)
-            else:
-                h_arrs, hn, h_nr = synth.tile_batch(arrs0, n0, nr0, max(1, min(n, 4096) // n0))
+            h_arrs, hn, h_nr = arrs, n, nr  # the headline's own batch, from the caller's (pinned) host memory
             keep = []
 
             def pinned(nbytes):
@@ -654,17 +651,25 @@ def main():
                            capi.fill_struct(capi.VarOut, outs[2]), capi.fill_struct(capi.GenoOut, outs[3]))
                 return h_in, outs, structs, capi.make_batch_struct(h_in, hn, h_nr)
 
-            def host_leg(n_feeders, steps_each=2):
+            def host_leg(n_feeders, steps_each=3, prefetch=True):
                 os.environ["MA_HBM_SHARE"] = str(round(0.9 / n_feeders, 3))
                 feeders = [make_feeder() for _ in range(n_feeders)]
                 engs = [Engine(params, device=local_rank, memspace=capi.MA_MEM_HOST) for _ in range(n_feeders)]
                 for e_, f_ in zip(engs, feeders):
-                    e_.process_device(f_[3], *f_[2])  # warm-up (allocations)
+                    e_.timing_control(int(os.environ.get("MA_BENCH_HOST_TIMING", "2")))  # HIP events around every kernel, as in the timed region above
+                    for _ in range(2 if prefetch else 1):  # warm-up: allocations, both input sets of the prefetching route
+                        if prefetch:
+                            e_.prefetch(f_[3])
+                        e_.process_device(f_[3], *f_[2])
                 start = threading.Barrier(n_feeders + 1)
 
                 def work(e_, f_):
                     start.wait()
-                    for _ in range(steps_each):
+                    if prefetch:
+                        e_.prefetch(f_[3])
+                    for it in range(steps_each):
+                        if prefetch and it + 1 < steps_each:
+                            e_.prefetch(f_[3])  # the next batch uploads under this one's kernels (ma_prefetch_batch)
                         e_.process_device(f_[3], *f_[2])
 
                 ths = [threading.Thread(target=work, args=(e_, f_)) for e_, f_ in zip(engs, feeders)]
@@ -684,11 +689,15 @@ def main():
                         "windows_per_batch": hn, "input_MB_per_batch": round(in_mb, 1), "output_MB_per_batch": round(out_mb, 1)}
 
             also["host_path"] = host_leg(1)
-            also["host_path"]["note"] = ("MA_MEM_HOST with pinned caller buffers: H2D staging + compute + D2H of every "
-                                         "fixed-stride output array, one context, no overlap between batches")
+            also["host_path"]["note"] = ("MA_MEM_HOST with pinned caller buffers, ONE feeder thread and context: every lane uploads "
+                                         "its slice and brings back packed records of what it wrote; the next batch is uploaded "
+                                         "under this batch's kernels (ma_prefetch_batch); submitted windows/s, PCIe both ways "
+                                         "inside the timed region")
+            also["host_path_no_prefetch"] = host_leg(1, prefetch=False)
+            also["host_path_no_prefetch"]["note"] = "the same without ma_prefetch_batch: upload, kernels and download of a batch in turn"
             also["host_path_2_feeders"] = host_leg(2)
             also["host_path_2_feeders"]["note"] = ("two contexts on one device, one host thread each "
-                                                   "(examples/host_driver.cpp --feeders 2): copies of one batch under the kernels of the other")
+                                                   "(examples/host_driver.cpp --feeders 2), each prefetching its next batch")
         except Exception as exc:  # the host leg must never cost the headline
             also["host_path"] = {"error": str(exc)[:200]}
 

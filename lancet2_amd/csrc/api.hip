@@ -1,10 +1,14 @@
 // C-ABI entry points of libmicroasm.so (see include/microasm.h).  No CPU fallback: every entry
 // point fails with MA_ERR_NO_DEVICE when there is no HIP device.
+#include <chrono>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <thread>
+#include <unordered_map>
 
 #include "ma_internal.h"
+#include "pack.h"
 
 using namespace ma;
 
@@ -276,6 +280,314 @@ int process_in_lanes(ma_ctx* ctx, int lanes, const DBatch& d, const ma_gate_out_
   return MA_OK;
 }
 
+// ---- the host route (MA_MEM_HOST) of ma_process_batch -------------------------------------------------------------------
+// Every lane stages ITS slice of the caller's input arrays on its own stream, runs the four stages, packs the used part
+// of its results (pack.hip), copies the records to a pinned landing area and scatters them into the caller's arrays on its
+// own host thread.  Uploads, kernels and downloads of different lanes overlap (copy engines beside compute), and what
+// crosses PCIe on the way back is what the engine wrote: ~5 KB instead of 95 KB per window.
+struct LaneOut {
+  ma_gate_out_t g{};
+  ma_asm_out_t a{};
+  ma_var_out_t v{};
+  ma_geno_out_t q{};
+};
+
+int ensure_pinned(ma_ctx* ch, size_t bytes) {
+  if (bytes <= ch->pin_cap) return MA_OK;
+  if (ch->pin) (void)hipHostFree(ch->pin);
+  ch->pin = nullptr;
+  ch->pin_cap = 0;
+  size_t const want = bytes + bytes / 4 + 4096;
+  MA_HIP(ch, hipHostMalloc(&ch->pin, want, hipHostMallocDefault));
+  ch->pin_cap = want;
+  return MA_OK;
+}
+
+template <class S>
+int alloc_fields(ma_ctx* ch, S* dev, const S* user, const std::vector<OutField>& f, size_t stage_base,
+                 const std::vector<bool>& always) {
+  std::memset(dev, 0, sizeof(*dev));
+  if (ch->out_stage.size() < stage_base + f.size()) ch->out_stage.resize(stage_base + f.size());
+  for (size_t i = 0; i < f.size(); ++i) {
+    if (!always[i] && !ptr_at(user, f[i].offset)) continue;  // an optional member the caller left out
+    DevBuf& b = ch->out_stage[stage_base + i];
+    MA_HIP(ch, b.reserve(f[i].bytes + 16));
+    ptr_at(dev, f[i].offset) = b.p;
+  }
+  return MA_OK;
+}
+
+// Upload the slice [w0, w1) of a host batch into input set `set` of lane `ch` on `stream`; offsets stay absolute, the base
+// pointers are moved back instead.  *d is filled with the device view (valid once the copies have run).
+int stage_lane_inputs(ma_ctx* ch, int set, const ma_batch_t* b, int w0, int w1, hipStream_t stream, DBatch* d) {
+  int const n = w1 - w0;
+  u32 const r0 = b->read_win_off[w0], r1 = b->read_win_off[w1];
+  size_t const nr = static_cast<size_t>(r1) - r0;
+  size_t const f0 = b->ref_off[w0], f1 = b->ref_off[w1];
+  u64 const b0 = b->read_off[r0], b1 = b->read_off[r1];
+  constexpr size_t kPad = 64;
+  struct Item { const void* src; size_t bytes; bool padded; };
+  InputSet& in = ch->in_sets[set];
+  in.h_rwo.resize(static_cast<size_t>(n) + 1);
+  for (int i = 0; i <= n; ++i) in.h_rwo[i] = b->read_win_off[w0 + i] - r0;
+  Item const items[10] = {{b->ref_bases + f0, f1 - f0, true},
+                          {b->ref_off + w0, 4ull * (n + 1), false},
+                          {in.h_rwo.data(), 4ull * (n + 1), false},
+                          {b->read_off + r0, 8ull * (nr + 1), false},
+                          {b->read_bases + b0, static_cast<size_t>(b1 - b0), true},
+                          {b->read_quals + b0, static_cast<size_t>(b1 - b0), true},
+                          {b->read_qname_id + r0, 4 * nr, false},
+                          {b->read_sample + r0, nr, false},
+                          {b->read_flags + r0, nr, false},
+                          {b->read_hint ? b->read_hint + r0 : nullptr, b->read_hint ? 4 * nr : 0, false}};
+  char* dp[10] = {nullptr};
+  for (int i = 0; i < 10; ++i) {
+    if (i == 9 && !b->read_hint) break;
+    size_t const front = items[i].padded ? kPad : 0;
+    MA_HIP(ch, in.bufs[i].reserve(front + items[i].bytes + kPad + 16));
+    char* base = static_cast<char*>(in.bufs[i].p);
+    if (front) MA_HIP(ch, hipMemsetAsync(base, 0, front, stream));
+    if (items[i].bytes) MA_HIP(ch, hipMemcpyAsync(base + front, items[i].src, items[i].bytes, hipMemcpyHostToDevice, stream));
+    if (items[i].padded) MA_HIP(ch, hipMemsetAsync(base + front + items[i].bytes, 0, kPad, stream));
+    dp[i] = base + front;
+  }
+  *d = DBatch{};
+  d->n_windows = n;
+  d->n_reads = static_cast<i64>(nr);
+  d->ref_bases = reinterpret_cast<const u8*>(dp[0]) - f0;
+  d->ref_off = reinterpret_cast<const u32*>(dp[1]);
+  d->read_win_off = reinterpret_cast<const u32*>(dp[2]);
+  d->read_off = reinterpret_cast<const u64*>(dp[3]);
+  d->read_bases = reinterpret_cast<const u8*>(dp[4]) - b0;
+  d->read_quals = reinterpret_cast<const u8*>(dp[5]) - b0;
+  d->read_qname_id = reinterpret_cast<const u32*>(dp[6]);
+  d->read_sample = reinterpret_cast<const u8*>(dp[7]);
+  d->read_flags = reinterpret_cast<const u8*>(dp[8]);
+  d->read_hint = b->read_hint ? reinterpret_cast<const i32*>(dp[9]) : nullptr;
+  return MA_OK;
+}
+
+// set: the input set to use; ready: the event behind its uploads when ma_prefetch_batch filled it (then `staged` holds the
+// device view), null when the lane uploads its slice itself
+int run_lane_host(ma_ctx* ch, const ma_batch_t* b, int w0, int w1, const ma_gate_out_t* ug, const ma_asm_out_t* ua,
+                  const ma_var_out_t* uv, const ma_geno_out_t* uq, int set, hipEvent_t ready, const DBatch* staged) {
+  MA_HIP(ch, hipSetDevice(ch->device));
+  ma_params_t const& p = ch->prm;
+  int const n = w1 - w0;
+  bool const verbose = getenv("MA_VERBOSE") != nullptr;
+  auto const t_begin = std::chrono::steady_clock::now();
+  auto since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(); };
+  double t_up = 0, t_gate = 0, t_asm = 0, t_msa = 0, t_geno = 0, t_pack = 0, t_down = 0;
+  u32 const r0 = b->read_win_off[w0], r1 = b->read_win_off[w1];
+  size_t const nr = static_cast<size_t>(r1) - r0;
+  size_t const f0 = b->ref_off[w0], f1 = b->ref_off[w1];
+  u64 const b0 = b->read_off[r0], b1 = b->read_off[r1];
+  DBatch d{};
+  if (ready) {
+    MA_HIP(ch, hipStreamWaitEvent(ch->stream, ready, 0));
+    d = *staged;
+  } else {
+    MA_TRY_RC(stage_lane_inputs(ch, set, b, w0, w1, ch->stream, &d));
+  }
+  // ---- device-side outputs of the lane (fixed strides, as the kernels write them) ----
+  LaneOut o;
+  std::vector<OutField> const gf = gate_fields(p, n), af = asm_fields(p, n), vf = var_fields(p, n),
+                              qf = geno_fields(p, n, static_cast<i64>(nr));
+  MA_TRY_RC(alloc_fields(ch, &o.g, ug, gf, 0, std::vector<bool>(gf.size(), true)));
+  MA_TRY_RC(alloc_fields(ch, &o.a, ua, af, 2, std::vector<bool>(af.size(), true)));
+  MA_TRY_RC(alloc_fields(ch, &o.v, uv, vf, 16, std::vector<bool>(vf.size(), true)));
+  {
+    std::vector<bool> need(qf.size(), false);
+    need[0] = need[1] = true;  // allele_counts, var_qual; the taps and PL / GQ only if the caller asked for them
+    MA_TRY_RC(alloc_fields(ch, &o.q, uq, qf, 32, need));
+  }
+  t_up = since();
+  MA_TRY_RC(launch_gate(ch, d, o.g.max_approx, o.g.max_exact));
+  t_gate = since();
+  MA_TRY_RC(launch_assemble(ch, d, o.a, o.g.max_approx));
+  t_asm = since();
+  MA_TRY_RC(launch_msa(ch, d, o.a, o.v));
+  t_msa = since();
+  MA_TRY_RC(launch_genotype(ch, d, o.a, o.v, o.q));
+  t_geno = since();
+  // ---- results: small dense arrays straight into the caller's arrays, the rest as packed records ----
+  auto d2h = [&](void* host, const void* dev, size_t bytes) -> int {
+    if (host && dev && bytes) MA_HIP(ch, hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, ch->stream));
+    return MA_OK;
+  };
+  size_t const N = n, W0 = w0, MC = p.max_comps, MH = p.max_haps, MV = p.max_vars, MA_ = p.max_alts, S = p.num_samples,
+               ML = p.max_hap_len, MR = p.max_runs, MP = p.max_allele_bytes, MCG = p.max_cigar;
+  size_t const G = (MA_ + 1) * (MA_ + 2) / 2;
+  MA_TRY_RC(d2h(ug->max_approx + W0, o.g.max_approx, 4 * N));
+  MA_TRY_RC(d2h(ug->max_exact + W0, o.g.max_exact, 4 * N));
+  MA_TRY_RC(d2h(ua->win_status + W0, o.a.win_status, 4 * N));
+  MA_TRY_RC(d2h(ua->win_k + W0, o.a.win_k, 4 * N));
+  MA_TRY_RC(d2h(ua->win_ncomp + W0, o.a.win_ncomp, 4 * N));
+  MA_TRY_RC(d2h(ua->comp_anchor + W0 * MC, o.a.comp_anchor, 4 * N * MC));
+  MA_TRY_RC(d2h(ua->comp_hap0 + W0 * MC, o.a.comp_hap0, 4 * N * MC));
+  MA_TRY_RC(d2h(ua->comp_nhaps + W0 * MC, o.a.comp_nhaps, 4 * N * MC));
+  MA_TRY_RC(d2h(ua->comp_cx + W0 * MC * 3, o.a.comp_cx, 4 * N * MC * 3));
+  MA_TRY_RC(d2h(ua->comp_cxf + W0 * MC * 4, o.a.comp_cxf, 8 * N * MC * 4));
+  MA_TRY_RC(d2h(ua->hap_len + W0 * MH, o.a.hap_len, 4 * N * MH));
+  MA_TRY_RC(d2h(ua->hap_nruns + W0 * MH, o.a.hap_nruns, 4 * N * MH));
+  MA_TRY_RC(d2h(ua->hap_stats + W0 * MH * 6, o.a.hap_stats, 8 * N * MH * 6));
+  MA_TRY_RC(d2h(uv->win_nvars + W0, o.v.win_nvars, 4 * N));
+  if (uq->aln_rec) MA_TRY_RC(d2h(uq->aln_rec + static_cast<size_t>(r0) * MH * 6, o.q.aln_rec, 4 * nr * MH * 6));
+  if (uq->aln_cigar)
+    MA_TRY_RC(d2h(uq->aln_cigar + static_cast<size_t>(r0) * MH * (1 + MCG), o.q.aln_cigar, 4 * nr * MH * (1 + MCG)));
+  if (uq->asg_allele) MA_TRY_RC(d2h(uq->asg_allele + static_cast<size_t>(r0) * MV, o.q.asg_allele, nr * MV));
+  if (uq->asg_score) MA_TRY_RC(d2h(uq->asg_score + static_cast<size_t>(r0) * MV, o.q.asg_score, 8 * nr * MV));
+  // packed records: the same segment list on the device (sources = the lane's arrays) and on the host (= the caller's)
+  PackArgs D{}, H{};
+  auto seg = [&](const void* dev, void* host, size_t win_stride, size_t unit, u32 kind) {
+    if (!dev || !host) return;
+    D.seg[D.nseg++] = PackSeg{static_cast<const u8*>(dev), static_cast<u32>(win_stride), static_cast<u32>(unit), kind};
+    H.seg[H.nseg++] = PackSeg{static_cast<const u8*>(host), static_cast<u32>(win_stride), static_cast<u32>(unit), kind};
+  };
+  seg(o.a.hap_bases, ua->hap_bases ? ua->hap_bases + W0 * MH * ML : nullptr, MH * ML, ML, PK_HAP_BASES);
+  seg(o.a.hap_runs, ua->hap_runs ? ua->hap_runs + W0 * MH * MR * 2 : nullptr, MH * MR * 8, MR * 8, PK_HAP_RUNS);
+  auto vseg = [&](const void* dev, void* host_base, size_t elem_bytes, size_t per_var) {
+    seg(dev, host_base ? static_cast<u8*>(host_base) + W0 * MV * per_var * elem_bytes : nullptr, MV * per_var * elem_bytes,
+        per_var * elem_bytes, PK_VAR);
+  };
+  vseg(o.v.var_comp, uv->var_comp, 4, 1);
+  vseg(o.v.var_pos, uv->var_pos, 4, 1);
+  vseg(o.v.var_ref_start, uv->var_ref_start, 4, 1);
+  vseg(o.v.var_ref_off, uv->var_ref_off, 4, 1);
+  vseg(o.v.var_ref_len, uv->var_ref_len, 4, 1);
+  vseg(o.v.var_nalts, uv->var_nalts, 4, 1);
+  vseg(o.v.alt_off, uv->alt_off, 4, MA_);
+  vseg(o.v.alt_len, uv->alt_len, 4, MA_);
+  vseg(o.v.alt_type, uv->alt_type, 4, MA_);
+  vseg(o.v.alt_length, uv->alt_length, 4, MA_);
+  vseg(o.v.var_hap_allele, uv->var_hap_allele, 1, MH);
+  vseg(o.v.var_hap_start, uv->var_hap_start, 4, MH);
+  seg(o.v.allele_pool, uv->allele_pool ? uv->allele_pool + W0 * MP : nullptr, MP, 0, PK_POOL);
+  vseg(o.q.allele_counts, uq->allele_counts, 4, S * (MA_ + 1) * 2);
+  vseg(o.q.var_qual, uq->var_qual, 8, 1);
+  vseg(o.q.var_pl, uq->var_pl, 4, S * G);
+  vseg(o.q.var_gq, uq->var_gq, 4, S);
+  D.win_status = o.a.win_status; D.win_ncomp = o.a.win_ncomp; D.comp_hap0 = o.a.comp_hap0; D.comp_nhaps = o.a.comp_nhaps;
+  D.hap_len = o.a.hap_len; D.hap_nruns = o.a.hap_nruns; D.win_nvars = o.v.win_nvars; D.var_ref_off = o.v.var_ref_off;
+  D.var_ref_len = o.v.var_ref_len; D.var_nalts = o.v.var_nalts; D.alt_off = o.v.alt_off; D.alt_len = o.v.alt_len;
+  D.MC = H.MC = p.max_comps; D.MH = H.MH = p.max_haps; D.MV = H.MV = p.max_vars; D.MA = H.MA = p.max_alts;
+  D.MP = H.MP = p.max_allele_bytes;
+  H.win_status = ua->win_status + W0; H.win_ncomp = ua->win_ncomp + W0; H.comp_hap0 = ua->comp_hap0 + W0 * MC;
+  H.comp_nhaps = ua->comp_nhaps + W0 * MC; H.hap_len = ua->hap_len + W0 * MH; H.hap_nruns = ua->hap_nruns + W0 * MH;
+  H.win_nvars = uv->win_nvars + W0;
+  MA_HIP(ch, ch->pack_aux.reserve(4 * (2 * N + 1) + 64));
+  u8* packed = nullptr;
+  size_t packed_bytes = 0;
+  MA_TRY_RC(launch_pack(ch, D, n, ch->pack_aux.as<u32>(), &packed, &packed_bytes));
+  size_t const aux_bytes = 4 * (2 * N + 1);
+  MA_TRY_RC(ensure_pinned(ch, aux_bytes + packed_bytes + 64));
+  u32* h_aux = static_cast<u32*>(ch->pin);
+  u8* h_packed = static_cast<u8*>(ch->pin) + ((aux_bytes + 15) & ~size_t(15));
+  t_pack = since();
+  MA_TRY_RC(d2h(h_aux, ch->pack_aux.p, aux_bytes));
+  MA_TRY_RC(d2h(h_packed, packed, packed_bytes));
+  MA_HIP(ch, ma_stream_sync(ch));
+  t_down = since();
+  unpack_records(H, h_aux, h_packed, n);
+  if (verbose)
+    fprintf(stderr, "[microasm] host lane [%d, %d): enqueue-upload %.2f gate %.2f assemble %.2f msa %.2f genotype %.2f pack %.2f "
+            "download %.2f unpack %.2f ms; %.1f MB in, %.2f MB packed out\n", w0, w1, t_up, t_gate - t_up, t_asm - t_gate,
+            t_msa - t_asm, t_geno - t_msa, t_pack - t_geno, t_down - t_pack, since() - t_down,
+            (static_cast<double>(f1 - f0) + 2.0 * static_cast<double>(b1 - b0) + 21.0 * nr) / 1e6, packed_bytes / 1e6);
+  return MA_OK;
+}
+
+int ensure_lanes(ma_ctx* ctx, int lanes) {
+  while (static_cast<int>(ctx->lanes.size()) < lanes) {
+    ma_ctx* ch = new (std::nothrow) ma_ctx();
+    if (!ch) return MA_ERR_NOMEM;
+    ch->device = ctx->device;
+    ch->memspace = MA_MEM_DEVICE;
+    MA_HIP(ctx, hipStreamCreateWithFlags(&ch->stream, hipStreamNonBlocking));
+    MA_HIP(ctx, hipEventCreateWithFlags(&ch->lane_done, hipEventDisableTiming));
+    ctx->lanes.push_back(ch);
+  }
+  return MA_OK;
+}
+
+int host_lanes(const ma_ctx* ctx, int n_windows) {
+  // the caller's stream carries nothing on this route: the lanes (and the prefetch stream) have the hardware queues to
+  // themselves -- four by default (GPU_MAX_HW_QUEUES), so three lanes + the copy stream unless the host raised it
+  static int const hwq = getenv("GPU_MAX_HW_QUEUES") ? atoi(getenv("GPU_MAX_HW_QUEUES")) : 4;
+  int lanes = ctx->n_lanes > 0 ? ctx->n_lanes : (n_windows >= 2048 ? (hwq >= 6 ? 4 : 3) : (n_windows >= 512 ? 2 : 1));
+  if (const char* e = getenv("MA_STREAMS")) lanes = atoi(e) > 0 ? atoi(e) : lanes;
+  if (lanes > n_windows / 2) lanes = n_windows / 2 > 0 ? n_windows / 2 : 1;
+  return lanes > 8 ? 8 : lanes;
+}
+
+std::vector<int> lane_bounds(int n_windows, int lanes) {
+  std::vector<int> wb(lanes + 1);
+  for (int k = 0; k <= lanes; ++k) wb[k] = static_cast<int>(static_cast<long long>(n_windows) * k / lanes);
+  return wb;
+}
+
+// staged device views of a prefetched batch, per set and lane (parent context; kept beside pf_batch)
+struct PrefetchViews {
+  std::vector<DBatch> d[2];
+};
+std::mutex g_views_mu;
+std::unordered_map<ma_ctx*, PrefetchViews> g_views;
+PrefetchViews& views_of(ma_ctx* ctx) {
+  std::lock_guard<std::mutex> lk(g_views_mu);
+  return g_views[ctx];
+}
+void forget_views(ma_ctx* ctx) {
+  std::lock_guard<std::mutex> lk(g_views_mu);
+  g_views.erase(ctx);
+}
+
+int process_host(ma_ctx* ctx, int lanes, const ma_batch_t* b, const ma_gate_out_t* g, const ma_asm_out_t* a,
+                 const ma_var_out_t* v, const ma_geno_out_t* q) {
+  MA_TRY_RC(ensure_lanes(ctx, lanes));
+  std::vector<int> const wb = lane_bounds(b->n_windows, lanes);
+  // did ma_prefetch_batch upload this batch?  (the oldest set that holds it); otherwise any set that holds nothing
+  int set = -1;
+  bool prefetched = false;
+  for (int s = 0; s < 2; ++s)
+    if (ctx->pf_batch[s] == b && ctx->pf_sig[s][0] == b->n_windows && ctx->pf_sig[s][1] == b->n_reads && ctx->pf_sig[s][2] == lanes &&
+        (set < 0 || ctx->pf_seq[s] < ctx->pf_seq[set])) {
+      set = s;
+      prefetched = true;
+    }
+  if (set < 0) {
+    set = !ctx->pf_batch[0] ? 0 : (!ctx->pf_batch[1] ? 1 : (ctx->pf_seq[0] < ctx->pf_seq[1] ? 0 : 1));
+    if (ctx->pf_batch[set]) {  // both sets hold batches that were never processed: give the older one up
+      MA_HIP(ctx, hipStreamSynchronize(ctx->copy_stream));
+      ctx->pf_batch[set] = nullptr;
+    }
+  }
+  PrefetchViews& pv = views_of(ctx);
+  std::vector<int> rc(lanes, MA_OK);
+  std::vector<std::thread> th;
+  for (int k = 0; k < lanes; ++k) {
+    ma_ctx* ch = ctx->lanes[k];
+    ch->prm = ctx->prm;
+    ch->timing = ctx->timing;
+    ch->accumulate = ctx->accumulate;
+    ch->collect = ctx->collect;
+    if (!ch->accumulate) ch->timers_used = 0;
+    ch->hbm_share = ctx->hbm_share / lanes;
+    hipEvent_t const ready = prefetched ? ctx->pf_ev[set] : nullptr;
+    const DBatch* staged = prefetched ? &pv.d[set][k] : nullptr;
+    th.emplace_back([&, k, ch, ready, staged]() {
+      rc[k] = wb[k + 1] > wb[k] ? run_lane_host(ch, b, wb[k], wb[k + 1], g, a, v, q, set, ready, staged) : MA_OK;
+    });
+  }
+  for (auto& t : th) t.join();
+  ctx->pf_batch[set] = nullptr;  // consumed (or used as plain staging): free for the next prefetch
+  for (int k = 0; k < lanes; ++k)
+    if (rc[k] != MA_OK) {
+      ctx->err = "lane " + std::to_string(k) + ": " + ctx->lanes[k]->err;
+      return rc[k];
+    }
+  return MA_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -318,12 +630,24 @@ int ma_create(const ma_params_t* prm, int device, int memspace, ma_ctx_t** out) 
 
 void ma_destroy(ma_ctx_t* ctx) {
   if (!ctx) return;
+  forget_views(ctx);
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   for (auto& b : ctx->in_stage) b.release();
   for (auto& b : ctx->out_stage) b.release();
   ctx->ws_build.release(); ctx->ws_nodes.release(); ctx->ws_clean.release();
   ctx->ws_poa.release(); ctx->ws_aln.release(); ctx->ws_misc.release(); ctx->ws_cx.release(); ctx->ws_gen.release(); ctx->dev_stats.release();
+  ctx->pack_aux.release(); ctx->pack_buf.release();
+  if (ctx->pin) (void)hipHostFree(ctx->pin);
+  ctx->pin = nullptr;
+  if (ctx->copy_stream) {
+    (void)hipStreamSynchronize(ctx->copy_stream);
+    (void)hipStreamDestroy(ctx->copy_stream);
+  }
+  for (auto& e : ctx->pf_ev)
+    if (e) (void)hipEventDestroy(e);
+  for (auto& st : ctx->in_sets)
+    for (auto& bf : st.bufs) bf.release();
   for (auto& t : ctx->timers) {
     (void)hipEventDestroy(t.beg);
     (void)hipEventDestroy(t.end);
@@ -533,11 +857,51 @@ int ma_annotate_batch(ma_ctx_t* ctx, const ma_batch_t* b, const ma_asm_out_t* as
   return MA_OK;
 }
 
+int ma_prefetch_batch(ma_ctx_t* ctx, const ma_batch_t* next) {
+  if (!ctx || !next) return MA_ERR_ARG;
+  if (ctx->memspace != MA_MEM_HOST || next->n_windows <= 0 || getenv("MA_HOST_LEGACY")) return MA_OK;  // nothing to stage
+  MA_HIP(ctx, hipSetDevice(ctx->device));
+  int const set = !ctx->pf_batch[0] ? 0 : (!ctx->pf_batch[1] ? 1 : -1);
+  if (set < 0) return MA_OK;  // two batches are waiting already
+  if (!ctx->copy_stream) MA_HIP(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+  if (!ctx->pf_ev[set]) MA_HIP(ctx, hipEventCreateWithFlags(&ctx->pf_ev[set], hipEventDisableTiming));
+  int const lanes = host_lanes(ctx, next->n_windows);
+  MA_TRY_RC(ensure_lanes(ctx, lanes));
+  std::vector<int> const wb = lane_bounds(next->n_windows, lanes);
+  PrefetchViews& pv = views_of(ctx);
+  pv.d[set].assign(lanes, DBatch{});
+  for (int k = 0; k < lanes; ++k) {
+    if (wb[k + 1] <= wb[k]) continue;
+    int const rc = stage_lane_inputs(ctx->lanes[k], set, next, wb[k], wb[k + 1], ctx->copy_stream, &pv.d[set][k]);
+    if (rc != MA_OK) {
+      ctx->err = "prefetch, lane " + std::to_string(k) + ": " + ctx->lanes[k]->err;
+      return rc;
+    }
+  }
+  MA_HIP(ctx, hipEventRecord(ctx->pf_ev[set], ctx->copy_stream));
+  ctx->pf_batch[set] = next;
+  ctx->pf_sig[set][0] = next->n_windows;
+  ctx->pf_sig[set][1] = next->n_reads;
+  ctx->pf_sig[set][2] = lanes;
+  ctx->pf_seq[set] = ++ctx->pf_counter;
+  return MA_OK;
+}
+
 int ma_process_batch(ma_ctx_t* ctx, const ma_batch_t* b, const ma_gate_out_t* gate, const ma_asm_out_t* asmb,
                      const ma_var_out_t* vars, const ma_geno_out_t* geno) {
   MA_BEGIN(ctx);
   if (!gate || !asmb || !vars || !geno) return MA_ERR_ARG;
   if (!gate->max_approx || !gate->max_exact || !geno->allele_counts || !geno->var_qual) return MA_ERR_ARG;
+  if (ctx->memspace == MA_MEM_HOST && !getenv("MA_HOST_LEGACY")) {
+    // the host route: every lane uploads its own slice, computes, and brings back packed records (see process_host).
+    // The caller's stream carries nothing here, so all four default hardware queues are the lanes'.
+    if (!b || b->n_windows < 0) return MA_ERR_ARG;
+    if (b->n_windows == 0) return MA_OK;
+    if (!asmb->win_status || !asmb->win_ncomp || !asmb->comp_hap0 || !asmb->comp_nhaps || !asmb->hap_len ||
+        !asmb->hap_nruns || !vars->win_nvars)
+      return MA_ERR_ARG;
+    return process_host(ctx, host_lanes(ctx, b->n_windows), b, gate, asmb, vars, geno);
+  }
   DBatch d;
   MA_TRY(stage_batch(ctx, b, &d));
   OutMirror<ma_gate_out_t> g;

@@ -48,6 +48,13 @@ struct DevBuf {
   T* as() const { return reinterpret_cast<T*>(p); }
 };
 
+// One staged copy of a lane's slice of a host batch (MA_MEM_HOST route of ma_process_batch): two per lane, so that
+// ma_prefetch_batch can upload the next batch while this one computes.
+struct InputSet {
+  DevBuf bufs[10];
+  std::vector<uint32_t> h_rwo;  // the lane's rebased read_win_off while its upload is in flight
+};
+
 struct KernelTimer {
   const char* name;
   hipEvent_t beg, end;
@@ -90,6 +97,18 @@ struct ma_ctx {
   hipEvent_t lane_done = nullptr;
   double hbm_share = 1.0;   // fraction of the device this context plans its workspaces for
   hipEvent_t sync_ev = nullptr;  // blocking-sync event: host threads sleep instead of spinning while the stream drains
+  // host route (MA_MEM_HOST) of ma_process_batch, per lane: packed result records (pack.hip) and their pinned landing area
+  ma::DevBuf pack_aux, pack_buf;
+  void* pin = nullptr;
+  size_t pin_cap = 0;
+  ma::InputSet in_sets[2];       // (lane) input staging, double buffered
+  // (parent) ma_prefetch_batch: which batch each set of the lanes holds (null: free), in which order they were filled,
+  // the event behind the set's uploads, and the stream the uploads of a prefetch run on
+  const ma_batch_t* pf_batch[2] = {nullptr, nullptr};
+  int64_t pf_sig[2][3] = {{0, 0, 0}, {0, 0, 0}};  // n_windows, n_reads, lanes of the prefetched batch
+  unsigned long long pf_seq[2] = {0, 0}, pf_counter = 0;
+  hipEvent_t pf_ev[2] = {nullptr, nullptr};
+  hipStream_t copy_stream = nullptr;
 
   void tic(const char* name);
   void toc();

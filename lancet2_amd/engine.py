@@ -33,6 +33,7 @@ def load_library(path=None):
     lib.ma_msa_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.ma_genotype_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.ma_process_batch.argtypes = [C.c_void_p] * 6
+    lib.ma_prefetch_batch.argtypes = [C.c_void_p, C.c_void_p]
     lib.ma_annotate_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p]
     lib.ma_last_kernel_times.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.c_int]
     lib.ma_last_stats.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong), C.c_int]
@@ -161,6 +162,10 @@ class Engine:
     def process_device(self, batch_struct, gate, asm, var, geno):
         self._check(self.lib.ma_process_batch(self.h, C.byref(batch_struct), C.byref(gate), C.byref(asm),
                                               C.byref(var), C.byref(geno)), "ma_process_batch")
+
+    def prefetch(self, batch_struct):
+        """MA_MEM_HOST: start uploading the batch that the next process_device() call will be given (ma_prefetch_batch)."""
+        self._check(self.lib.ma_prefetch_batch(self.h, C.byref(batch_struct)), "ma_prefetch_batch")
 
     def annotate_device(self, batch_struct, asm, var, cx, gc_frac=0.41):
         self._check(self.lib.ma_annotate_batch(self.h, C.byref(batch_struct), C.byref(asm), C.byref(var),

@@ -106,17 +106,20 @@ def test_capacity_overflow_is_retried_inside_the_library(env, cfg, kw, monkeypat
     assert not bad, "\n".join(bad[:10])
 
 
-def test_reads_beyond_the_aligner_limit_are_refused():
-    """reads longer than 608 bases: an error code with a message, never a silently truncated alignment"""
-    from lancet2_amd.engine import Engine, EngineError
+def test_reads_beyond_the_aligner_limit_flag_their_window():
+    """reads longer than 608 bases: never a silently truncated alignment, and (since round 3) not a failed batch either --
+    the window is assembled, not genotyped, and says so (MA_W_READ_OVERFLOW; the whole story in
+    test_over_long_reads_flag_their_window_not_the_batch)"""
+    from lancet2_amd.engine import Engine
     params = capi.default_params(min_k=25, max_k=25)
     arrs, n, nr = synth.make_config_batch("C2", 1, first_index=424_300, read_len=700, depths=(12, 12))
     eng = Engine(params)
     try:
-        with pytest.raises(EngineError, match="608"):
-            eng.process(arrs, n, nr)
+        _, a, v, q = eng.process(arrs, n, nr)
     finally:
         eng.close()
+    assert a["win_status"][0] & capi.MA_W_READ_OVERFLOW
+    assert q["allele_counts"].sum() == 0
 
 
 def test_windows_that_run_out_of_ladder_and_windows_at_different_rungs_share_a_pass():

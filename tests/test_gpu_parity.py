@@ -452,7 +452,7 @@ def test_full_size_properties_c3_8192():
     assert (sums.reshape(32, n0) == sums[:n0]).all()
     gated = g["max_approx"][:n0] >= 25
     assert gated.sum() >= 16 and (a["win_ncomp"][:n0][gated] == 0).all()
-    assert ((a["win_status"][:n0] == 0).mean()) > 0.8
+    assert ((a["win_status"][:n0] == 0).mean()) > 0.7  # (gated STR / duplication windows, tandem duplications at k = 25)
     for w in range(n0):
         if a["win_ncomp"][w] == 0:
             continue
@@ -846,6 +846,92 @@ def test_over_long_reads_flag_their_window_not_the_batch():
     from harness import compare_vars as cv
     sel = np.array([0, 1, 2])
     assert int(v["win_nvars"][1]) == int(wv["win_nvars"][1]) and int(a["win_ncomp"][1]) == int(wa["win_ncomp"][1])
+
+
+@pytest.mark.parametrize("streams", [1, 3])
+def test_host_route_packed_results_equal_the_whole_array_route(streams, monkeypatch):
+    """MA_MEM_HOST: every lane uploads its own slice and brings back packed records of what it wrote (pack.hip), scattered
+    into the caller's fixed-stride arrays on the host -- against the old route that copied every array whole
+    (MA_HOST_LEGACY): the same bytes in every array, including the taps, on a batch whose windows differ in everything
+    (no reads, sub-anchor coverage, several components, 60-base indels)."""
+    from lancet2_amd.engine import Engine
+    params = capi.default_params(min_k=25, max_k=25)
+    kw = dict(synth.CONFIGS["C2"])
+    wins = [synth.make_window(9300 + i, **kw) for i in range(9)]
+    wins[2] = synth.make_window(9302, **dict(kw, depths=(2, 2)))          # below the anchor coverage
+    wins[4] = synth.make_window(9304, **dict(kw, big_indel=60))
+    wins[5] = dict(ref=wins[5]["ref"], reads=[])                            # no reads at all
+    wins[7] = synth.make_window(9307, **dict(kw, snv_rate=8e-3, indel_rate=2e-3))
+    arrs, n, nr = synth.pack_batch(wins)
+    monkeypatch.setenv("MA_HOST_LEGACY", "1")
+    eng = Engine(params)
+    try:
+        want = eng.process(arrs, n, nr, debug=True)
+    finally:
+        eng.close()
+    monkeypatch.delenv("MA_HOST_LEGACY")
+    eng = Engine(params)
+    try:
+        eng.set_streams(streams)
+        got = eng.process(arrs, n, nr, debug=True)
+    finally:
+        eng.close()
+    g, a, v, q = got
+    wg, wa, wv, wq = want
+    assert np.array_equal(g["max_approx"], wg["max_approx"]) and np.array_equal(g["max_exact"], wg["max_exact"])
+    bad = compare_asm(params, a, wa, n) + compare_vars(params, v, wv, n)
+    bad += compare_geno(params, q, wq, n, nr, wv["win_nvars"], arrs["read_win_off"])
+    assert not bad, "\n".join(bad[:12])
+    assert wv["win_nvars"].sum() > 5 and (wa["win_ncomp"] == 0).any()
+
+
+def test_prefetched_batches_give_the_same_results():
+    """ma_prefetch_batch uploads the next batch while this one computes (double-buffered input sets, one copy stream per
+    context).  Results must not depend on it: three different batches processed in turn, each prefetched before the
+    previous one is processed; a batch processed without having been prefetched in between; a third prefetch while two
+    are waiting (ignored); the same batch prefetched and processed twice."""
+    from lancet2_amd.engine import Engine
+    params = capi.default_params(min_k=25, max_k=25)
+    batches = [synth.make_config_batch("C2", 5, first_index=9400), synth.make_config_batch("C3", 3, first_index=9500),
+               synth.make_config_batch("C2", 7, first_index=9600, indel_rate=1e-3)]
+    eng = Engine(params)
+    try:
+        want = [eng.process(a_, n_, nr_, debug=False) for a_, n_, nr_ in batches]
+    finally:
+        eng.close()
+
+    def run(eng, i):
+        arrs, n, nr = batches[i]
+        outs = (capi.alloc_host(capi.gate_out_spec(n)), capi.alloc_host(capi.asm_out_spec(params, n)),
+                capi.alloc_host(capi.var_out_spec(params, n)), capi.alloc_host(capi.geno_out_spec(params, n, nr, False)))
+        eng.process_device(structs[i], capi.fill_struct(capi.GateOut, outs[0]), capi.fill_struct(capi.AsmOut, outs[1]),
+                           capi.fill_struct(capi.VarOut, outs[2]), capi.fill_struct(capi.GenoOut, outs[3]))
+        g, a, v, q = outs
+        wg, wa, wv, wq = want[i]
+        assert np.array_equal(g["max_approx"], wg["max_approx"])
+        bad = compare_asm(params, a, wa, n) + compare_vars(params, v, wv, n)
+        assert not bad, (i, bad[:6])
+        assert np.array_equal(q["allele_counts"], wq["allele_counts"]) and np.array_equal(
+            q["var_qual"].view(np.uint64), wq["var_qual"].view(np.uint64))
+
+    structs = [capi.make_batch_struct(a_, n_, nr_) for a_, n_, nr_ in batches]
+    eng = Engine(params)
+    try:
+        eng.prefetch(structs[0])
+        eng.prefetch(structs[1])
+        eng.prefetch(structs[2])      # two are waiting: ignored
+        run(eng, 0)
+        eng.prefetch(structs[2])
+        run(eng, 1)
+        run(eng, 2)
+        run(eng, 1)                   # never prefetched this time
+        eng.prefetch(structs[0])
+        eng.prefetch(structs[0])
+        run(eng, 0)
+        run(eng, 0)
+        eng.prefetch(structs[2])      # prefetched, never processed: the engine must close cleanly
+    finally:
+        eng.close()
 
 
 def test_device_buffers_need_no_padding_or_alignment():
