@@ -1,0 +1,317 @@
+// pipeline_driver.cpp -- the `pipeline` host around the engine: reference + alignment files in,
+// coordinate-sorted de-duplicated variant records out.  Three stages run side by side, as the reference's AsyncWorker /
+// PipelineExecutor do at window granularity (core/async_worker.cpp:47-110, core/pipeline_executor.cpp:174-252):
+//   extract   WindowBuilder tiles the regions; per window the skip gates (N-only, max-k repeat, inactive region), the read
+//             collector (filters, coverage-capped paired downsampling, comparator) and the coverage gate; the windows that
+//             are left are flattened into batches
+//   engine    ma_prefetch_batch(next) + ma_process_batch(this): the next batch uploads under this batch's kernels
+//   flush     results -> records -> VariantStore (same CHROM+POS+REF from overlapping windows: the better covered call wins)
+//             -> everything before the next batch's first window is written, in coordinate order
+// Build (no HIP headers needed; zlib only for BAM input):
+//   g++ -std=c++17 -O2 examples/pipeline_driver.cpp -Iinclude -Llancet2_amd -lmicroasm -Wl,-rpath,$PWD/lancet2_amd
+//       -Wl,--allow-shlib-undefined -DLANCET2_AMD_WITH_ZLIB -lz -lpthread -o pipeline_driver
+//   ./pipeline_driver --reference ref.fa --normal n.sam --tumor t.sam --region chr1:1-20000 --out calls.tsv
+// Flags follow the reference CLI (cli/cli_interface.cpp:203-303) where the engine has the knob.
+#include <condition_variable>
+#include <deque>
+#include <mutex>
+#include <thread>
+
+#include "../lancet2_amd/host/pipeline_host.hpp"
+
+using namespace lancet2_amd::host;
+
+namespace {
+
+struct Outputs {  // caller-owned fixed-stride result buffers of one batch
+  std::vector<uint32_t> u32;
+  std::vector<double> f64;
+  std::vector<uint8_t> u8;
+  std::vector<int32_t> i32;
+  ma_gate_out_t gate{};
+  ma_asm_out_t asmb{};
+  ma_var_out_t vars{};
+  ma_geno_out_t geno{};
+  void Allocate(const ma_params_t& p, int n) {
+    size_t const N = n, MC = p.max_comps, MH = p.max_haps, ML = p.max_hap_len, MR = p.max_runs, MV = p.max_vars, MA = p.max_alts,
+                 MP = p.max_allele_bytes, S = p.num_samples;
+    u32.assign(2 * N + 3 * N + 6 * N * MC + 2 * N * MH + 2 * N * MH * MR + N + 6 * N * MV + 2 * N * MV * MA + N * MV * MH +
+                   N * MV * S * (MA + 1) * 2 + 64, 0);
+    f64.assign(4 * N * MC + 6 * N * MH + N * MV, 0.0);
+    u8.assign(N * MH * ML + N * MV * MH + N * MP, 0);
+    i32.assign(2 * N * MV * MA, 0);
+    uint32_t* u = u32.data();
+    double* d = f64.data();
+    uint8_t* b = u8.data();
+    int32_t* s = i32.data();
+    auto tu = [&](size_t c) { uint32_t* r = u; u += c; return r; };
+    auto td = [&](size_t c) { double* r = d; d += c; return r; };
+    auto tb = [&](size_t c) { uint8_t* r = b; b += c; return r; };
+    auto ti = [&](size_t c) { int32_t* r = s; s += c; return r; };
+    gate.max_approx = tu(N); gate.max_exact = tu(N);
+    asmb.win_status = tu(N); asmb.win_k = tu(N); asmb.win_ncomp = tu(N);
+    asmb.comp_anchor = tu(N * MC); asmb.comp_hap0 = tu(N * MC); asmb.comp_nhaps = tu(N * MC);
+    asmb.comp_cx = tu(3 * N * MC); asmb.comp_cxf = td(4 * N * MC);
+    asmb.hap_len = tu(N * MH); asmb.hap_nruns = tu(N * MH); asmb.hap_stats = td(6 * N * MH);
+    asmb.hap_bases = tb(N * MH * ML); asmb.hap_runs = tu(2 * N * MH * MR);
+    vars.win_nvars = tu(N); vars.var_comp = tu(N * MV); vars.var_pos = tu(N * MV); vars.var_ref_start = tu(N * MV);
+    vars.var_ref_off = tu(N * MV); vars.var_ref_len = tu(N * MV); vars.var_nalts = tu(N * MV);
+    vars.alt_off = tu(N * MV * MA); vars.alt_len = tu(N * MV * MA); vars.alt_type = ti(N * MV * MA);
+    vars.alt_length = ti(N * MV * MA); vars.var_hap_allele = tb(N * MV * MH); vars.var_hap_start = tu(N * MV * MH);
+    vars.allele_pool = tb(N * MP);
+    geno.allele_counts = tu(N * MV * S * (MA + 1) * 2); geno.var_qual = td(N * MV);
+  }
+};
+
+template <class T>
+class Channel {  // bounded hand-over between two stages
+ public:
+  explicit Channel(size_t cap) : cap_(cap) {}
+  void Push(T v) {
+    std::unique_lock<std::mutex> lk(mu_);
+    cv_.wait(lk, [&] { return q_.size() < cap_; });
+    q_.push_back(std::move(v));
+    cv_.notify_all();
+  }
+  void Close() {
+    std::lock_guard<std::mutex> lk(mu_);
+    closed_ = true;
+    cv_.notify_all();
+  }
+  bool Pop(T* out) {
+    std::unique_lock<std::mutex> lk(mu_);
+    cv_.wait(lk, [&] { return !q_.empty() || closed_; });
+    if (q_.empty()) return false;
+    *out = std::move(q_.front());
+    q_.pop_front();
+    cv_.notify_all();
+    return true;
+  }
+  bool Peek(T** out) {  // the element a later Pop will return, once there is one (or the channel is closed and empty)
+    std::unique_lock<std::mutex> lk(mu_);
+    cv_.wait(lk, [&] { return !q_.empty() || closed_; });
+    if (q_.empty()) return false;
+    *out = &q_.front();
+    return true;
+  }
+
+ private:
+  std::mutex mu_;
+  std::condition_variable cv_;
+  std::deque<T> q_;
+  size_t cap_;
+  bool closed_ = false;
+};
+
+struct Job {
+  std::unique_ptr<FlatBatch> batch;
+  std::unique_ptr<Outputs> out;
+  int rc = MA_OK;
+  std::string err;
+};
+
+void DumpBatch(const std::string& dir, FlatBatch const& fb) {
+  auto put = [&](const char* name, const void* p, size_t bytes) {
+    FILE* f = std::fopen((dir + "/" + name).c_str(), "wb");
+    if (!f) { std::perror(name); std::exit(4); }
+    std::fwrite(p, 1, bytes, f);
+    std::fclose(f);
+  };
+  put("ref_bases.u8", fb.ref_bases.data(), fb.ref_bases.size());
+  put("ref_off.u32", fb.ref_off.data(), 4 * fb.ref_off.size());
+  put("read_win_off.u32", fb.read_win_off.data(), 4 * fb.read_win_off.size());
+  put("read_off.u64", fb.read_off.data(), 8 * fb.read_off.size());
+  put("read_bases.u8", fb.read_bases.data(), fb.read_bases.size());
+  put("read_quals.u8", fb.read_quals.data(), fb.read_quals.size());
+  put("read_qname_id.u32", fb.read_qname_id.data(), 4 * fb.read_qname_id.size());
+  put("read_sample.u8", fb.read_sample.data(), fb.read_sample.size());
+  put("read_flags.u8", fb.read_flags.data(), fb.read_flags.size());
+  put("read_hint.i32", fb.read_hint.data(), 4 * fb.read_hint.size());
+  std::vector<uint64_t> wins;
+  for (auto const& w : fb.windows) {
+    wins.push_back(static_cast<uint64_t>(w.chrom));
+    wins.push_back(w.start1);
+    wins.push_back(w.end1);
+    wins.push_back(w.genome_index);
+  }
+  put("windows.u64", wins.data(), 8 * wins.size());
+}
+
+AlignmentSource LoadAlignments(const std::string& path, Reference const& ref) {
+  bool const bam = path.size() > 4 && path.substr(path.size() - 4) == ".bam";
+#ifdef LANCET2_AMD_WITH_ZLIB
+  if (bam) return AlignmentSource::LoadBam(path, ref);
+#else
+  if (bam) throw std::runtime_error("built without zlib (-DLANCET2_AMD_WITH_ZLIB -lz): BAM input is not available");
+#endif
+  return AlignmentSource::LoadSam(path, ref);
+}
+
+}  // namespace
+
+int main(int argc, char** argv) {
+  std::string ref_path, out_path, dump_dir;
+  std::vector<std::string> normals, tumors, regions;
+  WindowBuilder::Params wp;
+  ReadCollector::Params rp;
+  ma_params_t prm;
+  ma_default_params(&prm);
+  bool no_active_region = false, extract_only = false;
+  int batch_windows = 512;
+  for (int i = 1; i < argc; ++i) {
+    std::string const a = argv[i];
+    auto next = [&]() -> const char* { return i + 1 < argc ? argv[++i] : ""; };
+    if (a == "--reference" || a == "-r") ref_path = next();
+    else if (a == "--normal" || a == "-n") normals.emplace_back(next());
+    else if (a == "--tumor" || a == "-t") tumors.emplace_back(next());
+    else if (a == "--region" || a == "-R") regions.emplace_back(next());
+    else if (a == "--out" || a == "-o") out_path = next();
+    else if (a == "--window-size" || a == "-w") wp.window_length = static_cast<uint32_t>(std::atoi(next()));
+    else if (a == "--pct-overlap" || a == "-p") wp.percent_overlap = static_cast<uint32_t>(std::atoi(next()));
+    else if (a == "--padding" || a == "-P") wp.region_padding = static_cast<uint32_t>(std::atoi(next()));
+    else if (a == "--min-kmer" || a == "-k") prm.min_k = std::atoi(next());
+    else if (a == "--max-kmer" || a == "-K") prm.max_k = std::atoi(next());
+    else if (a == "--kmer-step") prm.k_step = std::atoi(next());
+    else if (a == "--min-anchor-cov") prm.min_anchor_cov = std::atoi(next());
+    else if (a == "--min-node-cov") prm.min_node_cov = std::atoi(next());
+    else if (a == "--max-sample-cov") rp.max_sample_cov = std::atof(next());
+    else if (a == "--extract-pairs") rp.extract_pairs = true;
+    else if (a == "--no-active-region") no_active_region = true;
+    else if (a == "--batch-windows") batch_windows = std::max(1, std::atoi(next()));
+    else if (a == "--dump") dump_dir = next();
+    else if (a == "--extract-only") extract_only = true;  // stage 1 alone (with --dump): no device needed
+    else { std::fprintf(stderr, "pipeline_driver: unknown option %s\n", a.c_str()); return 2; }
+  }
+  if (ref_path.empty() || (normals.empty() && tumors.empty())) {
+    std::fprintf(stderr, "usage: pipeline_driver --reference ref.fa [--normal n.sam|bam]... [--tumor t.sam|bam]... [--region chr:a-b]... [--out calls.tsv]\n");
+    return 2;
+  }
+  Reference const ref = Reference::LoadFasta(ref_path);
+  std::vector<AlignmentSource> sources;
+  sources.reserve(normals.size() + tumors.size());
+  std::vector<SampleInfo> samples;
+  auto add_sample = [&](const std::string& path, Tag tag) {
+    sources.push_back(LoadAlignments(path, ref));
+    std::string name = path.substr(path.find_last_of('/') == std::string::npos ? 0 : path.find_last_of('/') + 1);
+    name = name.substr(0, name.find_last_of('.'));
+    samples.push_back({name, tag, nullptr, 0, 0, 0});
+  };
+  for (auto const& p : normals) add_sample(p, Tag::CTRL);
+  for (auto const& p : tumors) add_sample(p, Tag::CASE);
+  for (size_t i = 0; i < samples.size(); ++i) samples[i].source = &sources[i];
+  prm.num_samples = static_cast<int32_t>(samples.size());
+  prm.case_ctrl_mode = (!normals.empty() && !tumors.empty()) ? 1 : 0;  // read_collector.cpp:88-94
+  if (wp.window_length + 1 > static_cast<uint32_t>(prm.max_hap_len) - 16) prm.max_hap_len = 3072;  // -w 2500 (cli maximum)
+
+  WindowBuilder wb(&ref, wp);
+  if (regions.empty()) wb.AddAllReferenceRegions();
+  for (auto const& r : regions) wb.AddRegion(r);
+  std::vector<Window> const windows = wb.BuildWindows();
+
+  ma_ctx_t* ctx = nullptr;
+  int const crc = extract_only ? MA_OK : ma_create(&prm, 0, MA_MEM_HOST, &ctx);
+  if (crc != MA_OK) {
+    std::fprintf(stderr, "pipeline_driver: ma_create failed with %d%s\n", crc,
+                 crc == MA_ERR_NO_DEVICE ? " (no HIP device: the engine has no CPU fallback)" : "");
+    return 3;
+  }
+
+  Channel<Job> to_engine(3), to_flush(3);
+  size_t n_skipped[5] = {0, 0, 0, 0, 0};
+  // ---- stage 1: extract ----
+  std::thread extract([&] {
+    ReadCollector collector(rp, samples);
+    auto fresh = [] { Job j; j.batch = std::make_unique<FlatBatch>(); return j; };
+    Job cur = fresh();
+    size_t n_dumped = 0;
+    auto ship = [&] {
+      if (cur.batch->windows.empty()) return;
+      cur.batch->Seal();
+      if (!dump_dir.empty()) {
+        char sub[64];
+        std::snprintf(sub, sizeof sub, "/batch_%04zu", n_dumped++);
+        std::string const d = dump_dir + sub;
+        std::string const cmd = "mkdir -p '" + d + "'";
+        if (std::system(cmd.c_str()) != 0) std::exit(4);
+        DumpBatch(d, *cur.batch);
+      }
+      to_engine.Push(std::move(cur));
+      cur = fresh();
+    };
+    for (Window const& w : windows) {
+      std::string_view const seq(ref.chroms[static_cast<size_t>(w.chrom)].seq.data() + (w.start1 - 1), w.Length());
+      WindowStatus st = PreReadGate(seq, prm.max_k, no_active_region, collector.Samples(), w);
+      ReadCollector::Result rc;
+      if (st == WindowStatus::RUN) {
+        rc = collector.CollectRegion(w);
+        if (CrossSampleMeanCoverage(rc.samples, w.Length()) < static_cast<double>(prm.min_anchor_cov)) st = WindowStatus::SKIPPED_ANCHOR_COVERAGE;
+      }
+      n_skipped[static_cast<int>(st)]++;
+      if (st != WindowStatus::RUN) continue;
+      cur.batch->Add(w, seq, rc.reads);
+      if (static_cast<int>(cur.batch->windows.size()) >= batch_windows) ship();
+    }
+    ship();
+    to_engine.Close();
+  });
+  // ---- stage 2: engine ----
+  std::thread engine([&] {
+    Job j;
+    while (to_engine.Pop(&j)) {
+      if (extract_only) continue;
+      Job* nxt = nullptr;
+      if (to_engine.Peek(&nxt)) ma_prefetch_batch(ctx, &nxt->batch->view);  // uploads under this batch's kernels
+      j.out = std::make_unique<Outputs>();
+      j.out->Allocate(prm, j.batch->view.n_windows);
+      j.rc = ma_process_batch(ctx, &j.batch->view, &j.out->gate, &j.out->asmb, &j.out->vars, &j.out->geno);
+      if (j.rc != MA_OK) j.err = ma_last_error(ctx);
+      to_flush.Push(std::move(j));
+    }
+    to_flush.Close();
+  });
+  // ---- stage 3: store + ordered flush ----
+  FILE* out = out_path.empty() ? stdout : std::fopen(out_path.c_str(), "w");
+  if (!out) { std::perror("--out"); return 4; }
+  VariantStore store;
+  size_t n_records = 0, n_assembled = 0, n_flagged = 0, idx_to_flush = 0;
+  int rc_all = 0;
+  auto write = [&](std::vector<VariantRecord> recs) {
+    for (auto const& r : recs) std::fprintf(out, "%s\n", r.AsLine(ref).c_str());
+    n_records += recs.size();
+  };
+  {
+    Job j;
+    while (to_flush.Pop(&j)) {
+      if (j.rc != MA_OK) {
+        std::fprintf(stderr, "pipeline_driver: batch failed (%d): %s\n", j.rc, j.err.c_str());
+        rc_all = 5;
+        continue;
+      }
+      // pipeline_executor.cpp:215-252: the flush lags the last window done by NUM_BUFFER_WINDOWS = 100 windows, so that a
+      // call can still be replaced by a better covered duplicate from a window that overlaps its own (batches finish in
+      // window order here; windows the gates skipped count as done)
+      store.AddVariants(RecordsOfBatch(prm, *j.batch, j.out->vars, j.out->geno));
+      size_t const done_upto = j.batch->windows.back().genome_index + 1;
+      constexpr size_t kBufferWindows = 100;
+      if (done_upto > kBufferWindows && done_upto - kBufferWindows > idx_to_flush) {
+        idx_to_flush = done_upto - kBufferWindows;
+        write(store.ExtractBeforeWindow(windows[idx_to_flush]));
+      }
+      for (int w = 0; w < j.batch->view.n_windows; ++w) {
+        uint32_t const st = j.out->asmb.win_status[w];
+        n_assembled += (st & MA_W_NO_HAPLOTYPE) ? 0 : 1;
+        n_flagged += (st & ~static_cast<uint32_t>(MA_W_NO_HAPLOTYPE | MA_W_BFS_LIMIT)) ? 1 : 0;
+      }
+    }
+    write(store.ExtractAll());
+  }
+  extract.join();
+  engine.join();
+  if (ctx) ma_destroy(ctx);
+  if (out != stdout) std::fclose(out);
+  std::fprintf(stderr,
+               "pipeline_driver: %zu windows (%zu N-only, %zu max-k repeat, %zu inactive, %zu below anchor coverage), %zu assembled, "
+               "%zu with a capacity flag, %zu records\n",
+               windows.size(), n_skipped[1], n_skipped[2], n_skipped[3], n_skipped[4], n_assembled, n_flagged, n_records);
+  return rc_all;
+}

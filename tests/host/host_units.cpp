@@ -1,0 +1,174 @@
+// Unit checks of the host shell (lancet2_amd/host/pipeline_host.hpp) against facts the reference states about itself.
+// Test infrastructure: built and run by tests/test_pipeline_host.py with plain g++ (no GPU, no engine call).
+#include <cassert>
+#include <cstdio>
+
+#include "../../lancet2_amd/host/pipeline_host.hpp"
+
+using namespace lancet2_amd::host;
+
+#define CHECK(cond)                                                                  \
+  do {                                                                               \
+    if (!(cond)) {                                                                   \
+      std::fprintf(stderr, "FAILED %s:%d: %s\n", __FILE__, __LINE__, #cond);         \
+      return 1;                                                                      \
+    }                                                                                \
+  } while (0)
+
+static SamRecord Rec(const char* q, int chrom, int64_t pos0, const char* cigar, uint8_t mapq = 60, uint16_t flag = 0x3,
+                     const char* md = nullptr, size_t len = 0) {
+  SamRecord r;
+  r.qname = q;
+  r.chrom = chrom;
+  r.pos0 = pos0;
+  r.cigar = ParseCigar(cigar);
+  r.mapq = mapq;
+  r.flag = flag;
+  size_t n = len;
+  if (!n)
+    for (auto const& c : r.cigar)
+      if (c.op == 'M' || c.op == 'I' || c.op == 'S' || c.op == '=' || c.op == 'X') n += c.len;
+  r.seq.assign(n, 'A');
+  r.qual.assign(n, 30);
+  if (md) {
+    r.md = md;
+    r.has_md = true;
+  }
+  return r;
+}
+
+int main() {
+  // docs/guides/architecture.md:155-158: 1000-base windows at 20 % overlap step by 800; steps are multiples of 100
+  CHECK(WindowBuilder::StepSize({1000, 500, 20}) == 800);
+  CHECK(WindowBuilder::StepSize({1000, 500, 50}) == 500);
+  CHECK(WindowBuilder::StepSize({2500, 500, 90}) == 300);  // ceil(250 / 100) * 100
+  Reference ref;
+  ref.chroms.push_back({"chr1", std::string(10000, 'A')});
+  ref.chroms.push_back({"chrUn_x", std::string(500, 'C')});
+  ref.chroms.push_back({"chr2", std::string(3000, 'G')});
+  {  // window_builder.cpp:287-323
+    WindowBuilder wb(&ref, {1000, 500, 20});
+    RegionSpec r = RegionSpec::Parse("chr1:3000-5000");
+    wb.PadInputRegion(r);
+    CHECK(*r.start == 2500 && *r.end == 5500);
+    RegionSpec lo = RegionSpec::Parse("chr1:100-9800");
+    wb.PadInputRegion(lo);
+    CHECK(*lo.start == 1 && *lo.end == 10000);  // start underflows, end within the padding of the contig end
+    RegionSpec tiny = RegionSpec::Parse("chr1:5000-5010");  // shorter than a window even when padded: grown around itself
+    WindowBuilder wb0(&ref, {1000, 0, 20});
+    wb0.PadInputRegion(tiny);
+    CHECK(tiny.Length() >= 1000 && *tiny.start < 5000 && *tiny.end > 5010);
+  }
+  {  // tiling (window_builder.cpp:140-205): closed 1001-base windows every 800 bases while start + 1000 <= region end
+    WindowBuilder wb(&ref, {1000, 500, 20});
+    wb.AddRegion("chr1:1-6000");
+    wb.AddRegion("chr1:1-6000");  // duplicate regions yield duplicate windows: removed
+    auto const w = wb.BuildWindows();
+    CHECK(w.size() == 7);
+    for (size_t i = 0; i < w.size(); ++i) {
+      CHECK(w[i].start1 == 1 + 800 * i && w[i].end1 == w[i].start1 + 1000 && w[i].Length() == 1001);
+      CHECK(w[i].genome_index == i);
+    }
+    WindowBuilder all(&ref, {1000, 500, 20});
+    all.AddAllReferenceRegions();  // chrUn_* is excluded (window_builder.cpp:41-53)
+    auto const wa = all.BuildWindows();
+    for (auto const& x : wa) CHECK(x.chrom != 1);
+    CHECK(wa.front().chrom == 0 && wa.back().chrom == 2);
+    CHECK(WindowBuilder::ShouldExcludeChrom("chrM") && WindowBuilder::ShouldExcludeChrom("chr1_KI270706v1_random") &&
+          !WindowBuilder::ShouldExcludeChrom("chr10"));
+  }
+  {  // comparator (read_collector.cpp:42-53)
+    Read a, b;
+    a.passes = false; b.passes = true;
+    CHECK(CompareReadsByPriority(b, a) && !CompareReadsByPriority(a, b));  // pass first
+    a.passes = true; a.tag = Tag::CASE; b.tag = Tag::CTRL;
+    CHECK(CompareReadsByPriority(b, a));                                   // CTRL (2) before CASE (4)
+    a.tag = Tag::CTRL; a.sample_name = "n2"; b.sample_name = "n1";
+    CHECK(CompareReadsByPriority(b, a));
+    a.sample_name = "n1"; a.qname = "q2"; b.qname = "q10";
+    CHECK(CompareReadsByPriority(b, a));                                   // "q10" < "q2" as strings
+    a.qname = "q10"; a.start0 = 5; b.start0 = 4;
+    CHECK(CompareReadsByPriority(b, a));
+  }
+  {  // active region: two reads with a quality >= 20 mismatch at one genome position (active_region_detector.cpp:85-126)
+    CountMap m;
+    std::vector<uint8_t> q(20, 30);
+    CHECK(!ParseMd("10A9", q, 100, &m));
+    CHECK(ParseMd("10C9", q, 100, &m));   // second hit at genome position 110
+    CountMap m2;
+    std::vector<uint8_t> lowq(20, 10);
+    CHECK(!ParseMd("10A9", lowq, 100, &m2) && !ParseMd("10A9", lowq, 100, &m2));  // low base quality: not counted
+    CountMap m3;
+    CHECK(!ParseMd("5^A15", q, 100, &m3) && m3.size() == 1);  // deletion bases are letters too: the reference counts them,
+    CountMap m4;                                               // without advancing -- so one read with a two-base deletion
+    CHECK(ParseMd("5^AC15", q, 100, &m4));                     // reaches the threshold by itself (restated as is)
+    AlignmentSource src;
+    src.recs.push_back(Rec("a", 0, 1000, "50M2I48M"));
+    src.recs.push_back(Rec("b", 0, 1010, "40M2I58M"));  // both insertions sit at genome position 1050
+    src.recs.push_back(Rec("c", 0, 3000, "100M", 0));   // mapq 0: ignored
+    src.Finish(ref.chroms.size());
+    std::vector<SampleInfo> ss{{"s", Tag::CTRL, &src, 0, 0, 0}};
+    CHECK(IsActiveRegion(ss, Window{0, 801, 1801, 0}));
+    CHECK(!IsActiveRegion(ss, Window{0, 2401, 3401, 0}));
+    AlignmentSource clip;
+    clip.recs.push_back(Rec("a", 0, 500, "20S80M"));
+    clip.recs.push_back(Rec("b", 0, 500, "10S90M"));  // both clips at genome position 500
+    clip.Finish(ref.chroms.size());
+    std::vector<SampleInfo> cs{{"s", Tag::CTRL, &clip, 0, 0, 0}};
+    CHECK(IsActiveRegion(cs, Window{0, 1, 1001, 0}));
+  }
+  {  // collector: filters, both mates of a pair kept or dropped together, coverage cap, deterministic
+    AlignmentSource src;
+    for (int i = 0; i < 400; ++i) {
+      std::string const q = "p" + std::to_string(i);
+      src.recs.push_back(Rec(q.c_str(), 0, 1000 + i, "100M", 60, 0x63));
+      src.recs.push_back(Rec(q.c_str(), 0, 1300 + i, "100M", 60, 0x93));
+    }
+    src.recs.push_back(Rec("dup", 0, 1200, "100M", 60, 0x400 | 0x3));
+    src.recs.push_back(Rec("lowq", 0, 1200, "100M", 5));
+    src.recs.push_back(Rec("qcfail", 0, 1200, "100M", 60, 0x200 | 0x3));
+    src.Finish(ref.chroms.size());
+    ReadCollector::Params p;
+    p.max_sample_cov = 20.0;  // 20x over 1001 bases = 20 020 bases = 201 reads of 100
+    ReadCollector rc(p, {{"s", Tag::CASE, &src, 0, 0, 0}});
+    Window const w{0, 801, 1801, 0};
+    auto const r1 = rc.CollectRegion(w);
+    auto const r2 = rc.CollectRegion(w);
+    CHECK(r1.reads.size() == r2.reads.size() && !r1.reads.empty());
+    std::unordered_map<std::string, int> per;
+    for (size_t i = 0; i < r1.reads.size(); ++i) {
+      CHECK(r1.reads[i].qname == r2.reads[i].qname && r1.reads[i].start0 == r2.reads[i].start0);
+      CHECK(r1.reads[i].qname[0] == 'p');  // duplicate / low mapq / QC-fail records never get in
+      per[r1.reads[i].qname]++;
+      if (i) CHECK(!CompareReadsByPriority(r1.reads[i], r1.reads[i - 1]));
+    }
+    for (auto const& kv : per) CHECK(kv.second == 2);  // pairs travel together
+    CHECK(r1.samples[0].sampled_reads == 201);          // ceil(20 020 / 100) of the 800 passing reads
+    CHECK(r1.reads.size() >= 201 && r1.reads.size() <= 402);
+    CHECK(CrossSampleMeanCoverage(r1.samples, w.Length()) > 19.0);
+  }
+  {  // gates (variant_builder.cpp:107-132)
+    std::vector<SampleInfo> none;
+    CHECK(PreReadGate(std::string(1001, 'N'), 127, true, none, Window{0, 1, 1001, 0}) == WindowStatus::SKIPPED_NONLY_REF_BASES);
+    std::string rep(1001, 'A');
+    CHECK(PreReadGate(rep, 127, true, none, Window{0, 1, 1001, 0}) == WindowStatus::SKIPPED_REF_REPEAT_SEEN);
+    CHECK(!HasExactRepeat("ACGTACGA", 5) && HasExactRepeat("ACGTAACGTA", 5));
+  }
+  {  // store (variant_store.cpp:20-79): same CHROM + POS + REF keeps the better covered call; ordered extraction
+    VariantStore st;
+    VariantRecord a{0, 1500, "A", {"T"}, 10.0, {{10, 0}, {8, 5}}, 1};
+    VariantRecord b{0, 1500, "A", {"T", "G"}, 12.0, {{12, 0, 0}, {9, 6, 1}}, 2};  // the overlapping window saw more
+    VariantRecord c{0, 900, "AC", {"A"}, 5.0, {{5, 0}, {5, 0}}, 0};               // no ALT support: never written
+    VariantRecord d{2, 10, "G", {"C"}, 7.0, {{3, 0}, {2, 2}}, 9};
+    VariantRecord e{0, 1500, "A", {"T"}, 9.0, {{1, 0}, {1, 1}}, 3};               // worse covered duplicate: ignored
+    st.AddVariants({a, c, d});
+    st.AddVariants({b, e});
+    CHECK(st.Size() == 3);
+    auto const first = st.ExtractBeforeWindow(Window{0, 1601, 2601, 2});  // POS < the window's END
+    CHECK(first.size() == 1 && first[0].alts.size() == 2 && first[0].window_index == 2);
+    auto const rest = st.ExtractAll();
+    CHECK(rest.size() == 1 && rest[0].chrom == 2 && st.Size() == 0);
+  }
+  std::printf("host units ok\n");
+  return 0;
+}
