@@ -192,7 +192,7 @@ __device__ __forceinline__ GL poa_carve(u32 PN, u32 ML) {
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // ---- serial graph primitives (thread 0): spoa::Graph ----
-__device__ i32 pg_add_node(GL const& g, u8 ch, u32 pos) {
+__device__ __forceinline__ i32 pg_add_node(GL const& g, u8 ch, u32 pos) {
   if (ST.nn >= g.pn) {
     ST.overflow = 1;
     return 0;
@@ -205,7 +205,7 @@ __device__ i32 pg_add_node(GL const& g, u8 ch, u32 pos) {
 }
 // spoa::Graph::AddEdge (weights dropped).  Also used lane-parallel by the graph update: there every
 // call touches the out-list of a distinct tail and the in-list of a distinct head.
-__device__ void pg_add_edge(GL const& g, u32 tail, u32 head, u16 lab) {
+__device__ __forceinline__ void pg_add_edge(GL const& g, u32 tail, u32 head, u16 lab) {
   u32 const no = g.nout[tail];
   for (u32 x = 0; x < no; ++x)
     if (g.out_head[tail * kPE + x] == head) {
@@ -223,7 +223,7 @@ __device__ void pg_add_edge(GL const& g, u32 tail, u32 head, u16 lab) {
   g.in_tail[head * kPE + ni] = static_cast<u16>(tail);
   g.nin[head] = static_cast<u8>(ni + 1);
 }
-__device__ i32 pg_add_sequence(GL const& g, const u8* seq, u32 begin, u32 end) {  // spoa::Graph::AddSequence
+__device__ __forceinline__ i32 pg_add_sequence(GL const& g, const u8* seq, u32 begin, u32 end) {  // spoa::Graph::AddSequence
   if (begin >= end) return -1;
   i32 prev = -1;
   u32 const first = ST.nn;
@@ -236,7 +236,7 @@ __device__ i32 pg_add_sequence(GL const& g, const u8* seq, u32 begin, u32 end) {
   }
   return static_cast<i32>(first);
 }
-__device__ i32 pg_successor(GL const& g, u32 node, u32 label) {  // spoa::Graph::Node::Successor
+__device__ __forceinline__ i32 pg_successor(GL const& g, u32 node, u32 label) {  // spoa::Graph::Node::Successor
   for (int x = 0; x < g.nout[node]; ++x)
     if (g.out_lab[node * kPE + x] & (1u << label)) return static_cast<i32>(g.out_head[node * kPE + x]);
   return -1;
@@ -246,7 +246,7 @@ __device__ i32 pg_successor(GL const& g, u32 node, u32 label) {  // spoa::Graph:
 // when root s is reached every node with a smaller id is already marked.  A root without aligned nodes
 // whose in-neighbours all have smaller ids is therefore ranked on the spot; runs of such roots (and of
 // already-marked ones) are handled 64 at a time with a ballot.  Every other root gets the serial DFS.
-__device__ void pg_toposort(GL const& g, int lane) {
+__device__ __forceinline__ void pg_toposort(GL const& g, int lane) {
   u32 const nn = ST.nn;
   u32 nrank = 0, s = 0;
   u32 overflow = 0;
@@ -325,7 +325,7 @@ __device__ void pg_toposort(GL const& g, int lane) {
   }
 }
 
-__device__ i32 classify_variant(const u8* r, u32 rl, const u8* a, u32 al) {  // raw_variant.cpp:44-77
+__device__ __forceinline__ i32 classify_variant(const u8* r, u32 rl, const u8* a, u32 al) {  // raw_variant.cpp:44-77
   u32 s = 0;
   while (s < rl && s < al && r[s] == a[s]) s++;
   if (s == rl && s == al) return -1;
@@ -338,7 +338,7 @@ __device__ i32 classify_variant(const u8* r, u32 rl, const u8* a, u32 al) {  // 
   if (rc != ac) return 4;
   return rc == 1 ? 0 : 3;
 }
-__device__ i32 variant_length(const u8* r, u32 rl, const u8* a, u32 al, i32 t) {  // variant_bubble.cpp:16-47
+__device__ __forceinline__ i32 variant_length(const u8* r, u32 rl, const u8* a, u32 al, i32 t) {  // variant_bubble.cpp:16-47
   if (t == 0) return 1;
   i32 const R = static_cast<i32>(rl), A = static_cast<i32>(al);
   if (t == 1 || t == 2 || t == 4) return A - R;
@@ -348,7 +348,7 @@ __device__ i32 variant_length(const u8* r, u32 rl, const u8* a, u32 al, i32 t) {
   while (e < (R - s) && e < (A - s) && r[R - 1 - e] == a[A - 1 - e]) e++;
   return A - s - e;
 }
-__device__ int bytes_cmp(const u8* a, u32 al, const u8* b, u32 bl) {  // std::string operator<=>
+__device__ __forceinline__ int bytes_cmp(const u8* a, u32 al, const u8* b, u32 bl) {  // std::string operator<=>
   u32 const m = al < bl ? al : bl;
   for (u32 i = 0; i < m; ++i)
     if (a[i] != b[i]) return a[i] < b[i] ? -1 : 1;
@@ -387,7 +387,7 @@ __device__ unsigned long long g_prof[16];
 #endif
 
 // block-wide exclusive scan of one value per thread (two barriers)
-__device__ u32 block_excl_scan(u32 v, int tid, u32& total) {
+__device__ __forceinline__ u32 block_excl_scan(u32 v, int tid, u32& total) {
   int const lane = tid & 63, wave = tid >> 6;
   u32 inc = v;
   for (int d = 1; d < 64; d <<= 1) {
@@ -408,7 +408,7 @@ __device__ u32 block_excl_scan(u32 v, int tid, u32& total) {
 }
 
 // block-wide exclusive prefix maximum of one value per thread (two barriers)
-__device__ u32 block_excl_scan_max(u32 v, int tid) {
+__device__ __forceinline__ u32 block_excl_scan_max(u32 v, int tid) {
   int const lane = tid & 63, wave = tid >> 6;
   u32 inc = v;
   for (int d = 1; d < 64; d <<= 1) {
@@ -426,7 +426,7 @@ __device__ u32 block_excl_scan_max(u32 v, int tid) {
 }
 
 // block-wide minimum of one value per thread (two barriers)
-__device__ u32 block_min(u32 v, int tid) {
+__device__ __forceinline__ u32 block_min(u32 v, int tid) {
   int const lane = tid & 63, wave = tid >> 6;
   for (int off = 32; off > 0; off >>= 1) v = min(v, static_cast<u32>(__shfl_xor(v, off)));
   if (lane == 0) ST.wsum[wave] = v;
@@ -486,8 +486,11 @@ __device__ __forceinline__ void store_code_bytes(u8* dst, const u32 (&cd)[CW], u
 // which are the SAME integers the sweep produces, so the backtrack tests see identical values.
 // Rows have uniform shape across the workgroup, so rows with several / far predecessors cost one slower
 // step instead of stalling a skewed pipeline.
+// (always inlined, like everything that takes the graph view or the workspace by reference: an out-of-line callee needs
+//  them in memory, and "memory" for a kernel argument is a private copy per thread -- half a KB of scratch stores by every
+//  thread of every workgroup at kernel entry, 1 GB per launch, and a scratch load behind every LDS offset in the callee)
 template <int CW>
-__device__ void poa_fill(GL const& g, PoaWs const& ws, u16* codes, i32* rows, i32* hlast, u32 V, u32 L, int tid,
+__device__ __forceinline__ void poa_fill(GL const& g, PoaWs const& ws, u16* codes, i32* rows, i32* hlast, u32 V, u32 L, int tid,
                          const u8* seq) {
   static_assert(E_ == -2 && C_ == -1, "prefix-max keys are written for e = -2, c = -1");
   int const lane = tid & 63, wave = tid >> 6;
@@ -1768,7 +1771,7 @@ __device__ __forceinline__ EdgeVals edge_vals(GL const& g, u32 i, u32 j) {  // c
 }
 
 // bw: columns of the band the codes were written for (64, 128 or 256); 0 = the full row-synchronous fill
-__device__ u32 poa_traceback(GL const& g, const u16* codes16, size_t const plane, u32 cw, u32 V, u32 L, u32 best_row,
+__device__ __forceinline__ u32 poa_traceback(GL const& g, const u16* codes16, size_t const plane, u32 cw, u32 V, u32 L, u32 best_row,
                              bool have_end, int lane, u32 bw) {
   const u8* const codes = reinterpret_cast<const u8*>(codes16);
   bool const band = bw != 0;
@@ -2008,7 +2011,7 @@ __device__ __forceinline__ u16 band_j0(u32 npos, u32 L, u32 cwb) {
 // Per-row flags of a band tier (after rowj0, RI_STORE and rowdepth are final): which rows take poa_fill_lean's
 // straight-line path, and the exits that are known before the fill (column 0 of a row is an exit when the row's window
 // does not start at column 1; its value is closed-form).
-__device__ void band_flags(GL const& g, u32 V, u32 cwb, int tid) {
+__device__ __forceinline__ void band_flags(GL const& g, u32 V, u32 cwb, int tid) {
   int const lane = tid & 63, wave = tid >> 6;
   i32 e0 = kNegInf;
   for (u32 i = 1 + tid; i <= V; i += kT) {
