@@ -27,6 +27,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <mutex>
 #include <random>
 #include <string>
@@ -326,6 +327,7 @@ int main(int argc, char** argv) {
   int rc_all = 0;
   size_t n_records = 0;
   std::vector<int> flagged;
+  std::vector<std::string> pending_lines;  // records held back behind a flagged window (each starts with its window index)
   for (int j = 0; j < n_batches; ++j) {
     std::unique_lock<std::mutex> lk(mu);
     cv.wait(lk, [&]() { return results[static_cast<size_t>(j)].done; });
@@ -336,9 +338,16 @@ int main(int argc, char** argv) {
       rc_all = 5;
       continue;
     }
-    for (auto const& l : r.lines) std::fprintf(out, "%s\n", l.c_str());
-    n_records += r.lines.size();
+    // a window whose fixed-stride outputs overflowed is re-submitted below with larger buffers: its truncated first-pass
+    // records are held back, and everything from the first such window on waits, so that the output stays in window order
+    // (a real host would re-submit at once on a spare context; this example does it after the batches)
+    for (auto& l : r.lines) pending_lines.push_back(std::move(l));
     flagged.insert(flagged.end(), r.flagged.begin(), r.flagged.end());
+    if (flagged.empty()) {
+      for (auto const& l : pending_lines) std::fprintf(out, "%s\n", l.c_str());
+      n_records += pending_lines.size();
+      pending_lines.clear();
+    }
   }
   for (auto& t : threads) t.join();
   // output-format capacity flags: the caller owns the fixed-stride buffers, so the caller re-submits with larger ones
@@ -347,6 +356,7 @@ int main(int argc, char** argv) {
     big.max_haps = 32; big.max_hap_len = 4096; big.max_vars = 256; big.max_allele_bytes = 16384; big.max_runs = 512;
     ma_ctx_t* c2 = nullptr;
     for (auto& c : ctx) { ma_destroy(c); c = nullptr; }
+    std::map<int, std::vector<std::string>> redo;  // window -> its records from the larger buffers
     if (ma_create(&big, 0, MA_MEM_HOST, &c2) == MA_OK) {
       for (int w : flagged) {
         FlatBatch fb;
@@ -354,14 +364,34 @@ int main(int argc, char** argv) {
         Flatten(&windows[static_cast<size_t>(w)], 1, &fb);
         o2.Allocate(big, 1);
         if (ma_process_batch(c2, &fb.view, &o2.gate, &o2.asmb, &o2.vars, &o2.geno) == MA_OK) {
-          std::vector<std::string> lines;
           std::vector<int> still;
-          EmitRecords(big, o2, w, 1, &lines, &still);
-          for (auto const& l : lines) std::fprintf(out, "#resubmitted\t%s\n", l.c_str());
+          EmitRecords(big, o2, w, 1, &redo[w], &still);
         }
       }
       ma_destroy(c2);
     }
+    // splice: the held-back records in window order, a re-submitted window's records in place of its first-pass ones
+    int last_w = -1;
+    auto flush_redo_upto = [&](int w_excl) {
+      for (auto it = redo.begin(); it != redo.end() && it->first < w_excl;) {
+        for (auto const& l : it->second) std::fprintf(out, "%s\n", l.c_str());
+        n_records += it->second.size();
+        it = redo.erase(it);
+      }
+    };
+    for (auto const& l : pending_lines) {
+      int const w = std::atoi(l.c_str());
+      if (w != last_w) flush_redo_upto(w);
+      last_w = w;
+      if (std::find(flagged.begin(), flagged.end(), w) != flagged.end()) continue;  // replaced
+      std::fprintf(out, "%s\n", l.c_str());
+      n_records++;
+    }
+    flush_redo_upto(INT32_MAX);
+  }
+  else if (!pending_lines.empty()) {  // a failed batch: what was held back goes out as it is
+    for (auto const& l : pending_lines) std::fprintf(out, "%s\n", l.c_str());
+    n_records += pending_lines.size();
   }
   for (auto& c : ctx)
     if (c) ma_destroy(c);

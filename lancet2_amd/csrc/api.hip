@@ -623,7 +623,11 @@ int ma_create(const ma_params_t* prm, int device, int memspace, ma_ctx_t** out) 
   c->memspace = memspace;
   // own non-blocking stream: the legacy null stream would serialise this context against every other context and
   // copy of the process (two feeders on one device would never overlap); ma_set_stream replaces it
-  if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) == hipSuccess) c->stream = c->own_stream;
+  if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) {
+    delete c;  // (falling back to the null stream silently would change how the context orders against the caller's work)
+    return MA_ERR_HIP;
+  }
+  c->stream = c->own_stream;
   *out = c;
   return MA_OK;
 }
@@ -915,7 +919,8 @@ int ma_process_batch(ma_ctx_t* ctx, const ma_batch_t* b, const ma_gate_out_t* ga
   // Automatic: three lanes for big batches -- the process has four hardware queues by default (ROCm's GPU_MAX_HW_QUEUES) and a
   // fourth lane would share one with the caller's stream (measured: -18 %); a host that raises GPU_MAX_HW_QUEUES to >= 6
   // before HIP starts gets four (+2 %).
-  int const hwq = getenv("GPU_MAX_HW_QUEUES") ? atoi(getenv("GPU_MAX_HW_QUEUES")) : 4;
+  // (read once: the variable only means something if it was set before HIP started)
+  static int const hwq = getenv("GPU_MAX_HW_QUEUES") ? atoi(getenv("GPU_MAX_HW_QUEUES")) : 4;
   int lanes = ctx->n_lanes > 0 ? ctx->n_lanes
                                : (d.n_windows >= 8192 && hwq >= 6 ? 4 : (d.n_windows >= 6144 ? 3 : (d.n_windows >= 2048 ? 2 : 1)));
   if (const char* e = getenv("MA_STREAMS")) lanes = atoi(e) > 0 ? atoi(e) : lanes;
