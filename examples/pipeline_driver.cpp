@@ -32,11 +32,20 @@ struct Outputs {  // caller-owned fixed-stride result buffers of one batch
   ma_asm_out_t asmb{};
   ma_var_out_t vars{};
   ma_geno_out_t geno{};
+  ma_cx_out_t cx{};
+  std::vector<int32_t> cx_i;
+  std::vector<float> cx_f;
+  std::vector<double> cx_d;
   void Allocate(const ma_params_t& p, int n) {
     size_t const N = n, MC = p.max_comps, MH = p.max_haps, ML = p.max_hap_len, MR = p.max_runs, MV = p.max_vars, MA = p.max_alts,
                  MP = p.max_allele_bytes, S = p.num_samples;
+    size_t const G = (MA + 1) * (MA + 2) / 2;
     u32.assign(2 * N + 3 * N + 6 * N * MC + 2 * N * MH + 2 * N * MH * MR + N + 6 * N * MV + 2 * N * MV * MA + N * MV * MH +
-                   N * MV * S * (MA + 1) * 2 + 64, 0);
+                   N * MV * S * (MA + 1) * 2 + N * MV * S * G + N * MV * S + 64, 0);
+    cx_i.assign(4 * N * MV, 0);
+    cx_f.assign(4 * N * MV, 0.f);
+    cx_d.assign(6 * N * MV, 0.0);
+    cx.seq_cx_i = cx_i.data(); cx.seq_cx_f = cx_f.data(); cx.seq_cx_d = cx_d.data(); cx.graph_cx = cx_d.data() + 3 * N * MV;
     f64.assign(4 * N * MC + 6 * N * MH + N * MV, 0.0);
     u8.assign(N * MH * ML + N * MV * MH + N * MP, 0);
     i32.assign(2 * N * MV * MA, 0);
@@ -60,6 +69,7 @@ struct Outputs {  // caller-owned fixed-stride result buffers of one batch
     vars.alt_length = ti(N * MV * MA); vars.var_hap_allele = tb(N * MV * MH); vars.var_hap_start = tu(N * MV * MH);
     vars.allele_pool = tb(N * MP);
     geno.allele_counts = tu(N * MV * S * (MA + 1) * 2); geno.var_qual = td(N * MV);
+    geno.var_pl = tu(N * MV * S * G); geno.var_gq = tu(N * MV * S);  // FORMAT PL / GQ (and GT = the smallest PL)
   }
 };
 
@@ -150,7 +160,9 @@ AlignmentSource LoadAlignments(const std::string& path, Reference const& ref) {
 }  // namespace
 
 int main(int argc, char** argv) {
-  std::string ref_path, out_path, dump_dir;
+  std::string ref_path, out_path, dump_dir, vcf_path, command_line;
+  for (int i = 0; i < argc; ++i) command_line += std::string(i ? " " : "") + argv[i];
+  double gc_frac = 0.41;  // --genome-gc-bias of the reference CLI: background GC of the LongdustQ null model
   std::vector<std::string> normals, tumors, regions;
   WindowBuilder::Params wp;
   ReadCollector::Params rp;
@@ -166,6 +178,8 @@ int main(int argc, char** argv) {
     else if (a == "--tumor" || a == "-t") tumors.emplace_back(next());
     else if (a == "--region" || a == "-R") regions.emplace_back(next());
     else if (a == "--out" || a == "-o") out_path = next();
+    else if (a == "--out-vcf") vcf_path = next();  // VCF text instead of the TSV lines (adds the SEQ_CX / GRAPH_CX annotation)
+    else if (a == "--genome-gc-bias") gc_frac = std::atof(next());
     else if (a == "--window-size" || a == "-w") wp.window_length = static_cast<uint32_t>(std::atoi(next()));
     else if (a == "--pct-overlap" || a == "-p") wp.percent_overlap = static_cast<uint32_t>(std::atoi(next()));
     else if (a == "--padding" || a == "-P") wp.region_padding = static_cast<uint32_t>(std::atoi(next()));
@@ -248,7 +262,7 @@ int main(int argc, char** argv) {
       }
       n_skipped[static_cast<int>(st)]++;
       if (st != WindowStatus::RUN) continue;
-      cur.batch->Add(w, seq, rc.reads);
+      cur.batch->Add(w, seq, rc.reads, &rc.samples);
       if (static_cast<int>(cur.batch->windows.size()) >= batch_windows) ship();
     }
     ship();
@@ -264,19 +278,28 @@ int main(int argc, char** argv) {
       j.out = std::make_unique<Outputs>();
       j.out->Allocate(prm, j.batch->view.n_windows);
       j.rc = ma_process_batch(ctx, &j.batch->view, &j.out->gate, &j.out->asmb, &j.out->vars, &j.out->geno);
+      if (j.rc == MA_OK && !vcf_path.empty())  // INFO SEQ_CX / GRAPH_CX (core/variant_builder.cpp:159-160)
+        j.rc = ma_annotate_batch(ctx, &j.batch->view, &j.out->asmb, &j.out->vars, gc_frac, &j.out->cx);
       if (j.rc != MA_OK) j.err = ma_last_error(ctx);
       to_flush.Push(std::move(j));
     }
     to_flush.Close();
   });
   // ---- stage 3: store + ordered flush ----
-  FILE* out = out_path.empty() ? stdout : std::fopen(out_path.c_str(), "w");
+  bool const as_vcf = !vcf_path.empty();
+  FILE* out = as_vcf ? std::fopen(vcf_path.c_str(), "w") : (out_path.empty() ? stdout : std::fopen(out_path.c_str(), "w"));
   if (!out) { std::perror("--out"); return 4; }
+  std::vector<SampleInfo> sorted_samples = samples;
+  SortSamples(sorted_samples);
+  std::vector<Tag> tags;
+  for (auto const& s_ : sorted_samples) tags.push_back(s_.tag);
+  if (as_vcf) std::fputs(VcfHeader(ref, sorted_samples, prm.case_ctrl_mode != 0, true, command_line, ref_path).c_str(), out);
   VariantStore store;
   size_t n_records = 0, n_assembled = 0, n_flagged = 0, idx_to_flush = 0;
   int rc_all = 0;
   auto write = [&](std::vector<VariantRecord> recs) {
-    for (auto const& r : recs) std::fprintf(out, "%s\n", r.AsLine(ref).c_str());
+    for (auto const& r : recs)
+      std::fprintf(out, "%s\n", as_vcf ? AsVcfRecord(r, ref, tags, prm.case_ctrl_mode != 0).c_str() : r.AsLine(ref).c_str());
     n_records += recs.size();
   };
   {
@@ -290,7 +313,7 @@ int main(int argc, char** argv) {
       // pipeline_executor.cpp:215-252: the flush lags the last window done by NUM_BUFFER_WINDOWS = 100 windows, so that a
       // call can still be replaced by a better covered duplicate from a window that overlaps its own (batches finish in
       // window order here; windows the gates skipped count as done)
-      store.AddVariants(RecordsOfBatch(prm, *j.batch, j.out->vars, j.out->geno));
+      store.AddVariants(RecordsOfBatch(prm, *j.batch, j.out->vars, j.out->geno, as_vcf ? &j.out->cx : nullptr));
       size_t const done_upto = j.batch->windows.back().genome_index + 1;
       constexpr size_t kBufferWindows = 100;
       if (done_upto > kBufferWindows && done_upto - kBufferWindows > idx_to_flush) {

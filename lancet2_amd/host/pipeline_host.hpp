@@ -634,9 +634,13 @@ struct FlatBatch {
   std::vector<uint64_t> read_off{0};
   std::vector<int32_t> read_hint;
   std::vector<Window> windows;
+  std::vector<std::vector<double>> sample_cov;  // [window][sample] sampled bases / window length
   ma_batch_t view{};
-  void Add(Window const& w, std::string_view ref_seq, std::vector<Read> const& reads) {
+  void Add(Window const& w, std::string_view ref_seq, std::vector<Read> const& reads, std::vector<SampleInfo> const* samples = nullptr) {
     windows.push_back(w);
+    sample_cov.emplace_back();
+    if (samples)
+      for (auto const& s : *samples) sample_cov.back().push_back(static_cast<double>(s.sampled_bases) / static_cast<double>(w.Length()));
     ref_bases.insert(ref_bases.end(), ref_seq.begin(), ref_seq.end());
     ref_off.push_back(static_cast<uint32_t>(ref_bases.size()));
     std::unordered_map<std::string_view, uint32_t> names;  // (qname, role) de-duplication needs names only within a window
@@ -683,6 +687,12 @@ struct VariantRecord {
   double qual = 0.0;
   std::vector<std::vector<uint32_t>> ad;  // [sample][allele]
   size_t window_index = 0;
+  // what the VCF record needs beyond the TSV line (filled by RecordsOfBatch; empty vectors = not available)
+  std::vector<int32_t> alt_type, alt_length;        // AlleleType 0 SNV 1 INS 2 DEL 3 MNP 4 CPX; AltAllele::mLength
+  std::vector<std::vector<uint32_t>> adf, adr, pl;  // [sample][allele] forward / reverse depths; [sample][genotype] PL
+  std::vector<uint32_t> gq;                         // [sample]
+  std::vector<double> sample_window_cov;            // [sample] sampled bases / window length (SDFC's denominator)
+  std::string seq_cx, graph_cx;                     // INFO values as the reference formats them (empty: not annotated)
   uint64_t TotalCoverage() const {
     uint64_t t = 0;
     for (auto const& s : ad)
@@ -750,8 +760,144 @@ class VariantStore {
   std::map<Key, VariantRecord> data_;
 };
 
+// ---- VCF text (caller/variant_call.cpp:100-520, caller/sample_format_data.cpp:32-98, cli/vcf_header_builder.cpp:28-63) -------
+// The record layout, INFO field and the FORMAT key are the reference's.  Of the 24 FORMAT values the engine's outputs give
+// GT, AD, ADF, ADR, DP, SDFC, PRAD, PANG, PL and GQ; the read-level statistics (RMQ, NPBQ, SB, SCA, FLD, RPCD, BQCD, MQCD, ASMD,
+// CMLOD, FSSE, AHDD, HSE, PDCV) need per-read data the reference keeps in VariantSupport and are written as missing (".").
+inline constexpr const char* kVcfFormatKey =
+    "GT:AD:ADF:ADR:DP:RMQ:NPBQ:SB:SCA:FLD:RPCD:BQCD:MQCD:ASMD:SDFC:PRAD:PANG:CMLOD:FSSE:AHDD:HSE:PDCV:PL:GQ";
+inline double PolarRadius(double ref_depth, double alt_depth) {  // base/polar_coords.h:149-151
+  return std::log10(1.0 + std::sqrt((ref_depth * ref_depth) + (alt_depth * alt_depth)));
+}
+inline double PolarAngle(double alt_depth, double ref_depth) {  // base/polar_coords.h:189-262 (minimax atan2, as the reference)
+  constexpr double A = 0.1963, B = -0.9817, kHalfPi = 1.57079632679489661923, kQuarterPi = 0.78539816339744830962, kEps = 1e-10;
+  double const abs_y = std::abs(alt_depth) + kEps, abs_x = std::abs(ref_depth);
+  double const ratio = (ref_depth - std::copysign(abs_y, ref_depth)) / (abs_y + abs_x);
+  double const base = kHalfPi - std::copysign(kQuarterPi, ref_depth);
+  return std::copysign(base + (((A * ratio * ratio) + B) * ratio), alt_depth);
+}
+inline std::pair<int, int> GenotypeOfPlIndex(size_t best) {  // variant_call.cpp:262-290 (htslib's bcf_gt2alleles walk)
+  size_t klen = 0, dk = 1;
+  while (klen < best) {
+    dk++;
+    klen += dk;
+  }
+  size_t const j = dk - 1;
+  return {static_cast<int>(best - klen + j), static_cast<int>(j)};
+}
+inline std::string FormatComplexityScore(double v) {  // base/longdust_scorer.h:340-350
+  char buf[64];
+  std::snprintf(buf, sizeof buf, "%.3f", v);
+  std::string t = buf;
+  if (t.find('.') != std::string::npos) {
+    t.erase(t.find_last_not_of('0') + 1);
+    if (t.back() == '.') t.pop_back();
+  }
+  return t;
+}
+inline std::string VcfHeader(Reference const& ref, std::vector<SampleInfo> const& samples, bool case_ctrl, bool annotated,
+                             std::string const& command_line, std::string const& ref_path) {
+  std::string h = "##fileformat=VCFv4.5\n##source=lancet2_amd_pipeline_driver\n##commandLine=\"" + command_line + "\"\n##reference=\"" + ref_path + "\"\n";
+  for (auto const& c : ref.chroms) h += "##contig=<ID=" + c.name + ",length=" + std::to_string(c.seq.size()) + ">\n";
+  if (case_ctrl)
+    h += "##INFO=<ID=SHARED,Number=0,Type=Flag,Description=\"Variant ALT seen in both case & control sample(s)\">\n"
+         "##INFO=<ID=CTRL,Number=0,Type=Flag,Description=\"Variant ALT seen only in control sample(s)\">\n"
+         "##INFO=<ID=CASE,Number=0,Type=Flag,Description=\"Variant ALT seen only in case sample(s)\">\n";
+  h += "##INFO=<ID=TYPE,Number=A,Type=String,Description=\"Variant type (SNV, INS, DEL, MNP)\">\n"
+       "##INFO=<ID=LENGTH,Number=A,Type=Integer,Description=\"Variant length in base pairs\">\n"
+       "##INFO=<ID=MULTIALLELIC,Number=0,Type=Flag,Description=\"Indicates if the site has multiple ALT alleles\">\n";
+  if (annotated)
+    h += "##INFO=<ID=GRAPH_CX,Number=3,Type=String,Description=\"Graph complexity metrics: GEI,TipToPathCovRatio,MaxSingleDirDegree\">\n"
+         "##INFO=<ID=SEQ_CX,Number=11,Type=String,Description=\"Sequence complexity features: ContextHRun,ContextEntropy,ContextFlankLQ,"
+         "ContextHaplotypeLQ,DeltaHRun,DeltaEntropy,DeltaFlankLQ,TrAffinity,TrPurity,TrPeriod,IsStutterIndel\">\n";
+  static const char* kFmt[][4] = {{"GT", "1", "String", "Genotype"}, {"AD", "R", "Integer", "Allele depth"},
+      {"ADF", "R", "Integer", "Forward strand allele depth"}, {"ADR", "R", "Integer", "Reverse strand allele depth"},
+      {"DP", "1", "Integer", "Total read depth"}, {"RMQ", "R", "Float", "RMS mapping quality per allele"},
+      {"NPBQ", "R", "Float", "Normalized posterior base quality per allele (raw PBQ / allele depth)"},
+      {"SB", "1", "Float", "Strand bias log odds ratio (Haldane-corrected, coverage-invariant)"},
+      {"SCA", "1", "Float", "Soft clip asymmetry (ALT minus REF)"},
+      {"FLD", "1", "Float", "Fragment length delta (signed mean ALT isize minus mean REF isize)"},
+      {"RPCD", "1", "Float", "Read position Cohen's D effect size (. if untestable)"},
+      {"BQCD", "1", "Float", "Base quality Cohen's D effect size (. if untestable)"},
+      {"MQCD", "1", "Float", "Mapping quality Cohen's D effect size (. if untestable)"},
+      {"ASMD", "1", "Float", "Allele-specific mismatch delta (mean ALT NM minus mean REF NM minus variant length)"},
+      {"SDFC", "1", "Float", "Site depth fold change (sample DP / per-sample window mean coverage)"},
+      {"PRAD", "1", "Float", "Polar radius: log10(1 + sqrt(AD_Ref^2 + AD_Alt^2))"},
+      {"PANG", "1", "Float", "Polar angle: allele identity ratio atan2(AD_Alt, AD_Ref) in radians"},
+      {"CMLOD", "A", "Float", "Continuous mixture log-odds score per ALT allele (base-quality-weighted LOD vs null)"},
+      {"FSSE", "1", "Float", "Fragment start Shannon entropy [0,1]"}, {"AHDD", "1", "Float", "ALT-haplotype discordance delta"},
+      {"HSE", "1", "Float", "Haplotype segregation entropy [0,1]"}, {"PDCV", "1", "Float", "Path depth coefficient of variation"},
+      {"PL", "G", "Integer", "Phred-scaled genotype likelihoods (Dirichlet-Multinomial model)"},
+      {"GQ", "1", "Integer", "Genotype quality (second-lowest PL from the Dirichlet-Multinomial model, capped at 99)"}};
+  for (auto const& f : kFmt)
+    h += std::string("##FORMAT=<ID=") + f[0] + ",Number=" + f[1] + ",Type=" + f[2] + ",Description=\"" + f[3] + "\">\n";
+  h += "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT";
+  for (auto const& s : samples) h += "\t" + s.name;
+  return h + "\n";
+}
+// one VCF data line (variant_call.cpp:503-518); tags: the samples' roles, for the SHARED / CTRL / CASE state (:392-423)
+inline std::string AsVcfRecord(VariantRecord const& r, Reference const& ref, std::vector<Tag> const& tags, bool case_ctrl) {
+  static const char* kType[] = {"SNV", "INS", "DEL", "MNP", "CPX"};
+  auto join = [](auto const& v) {
+    std::string s;
+    for (size_t i = 0; i < v.size(); ++i) s += (i ? "," : "") + std::to_string(v[i]);
+    return s;
+  };
+  std::string info;
+  if (case_ctrl) {
+    bool in_ctrl = false, in_case = false;
+    for (size_t s = 0; s < r.ad.size() && s < tags.size(); ++s) {
+      uint32_t alt = 0;
+      for (size_t a = 1; a < r.ad[s].size(); ++a) alt += r.ad[s][a];
+      if (alt > 0) (tags[s] == Tag::CASE ? in_case : in_ctrl) = true;
+    }
+    info += in_case && in_ctrl ? "SHARED;" : (in_case ? "CASE;" : (in_ctrl ? "CTRL;" : "NONE;"));
+  }
+  if (r.alts.size() > 1) info += "MULTIALLELIC;";
+  info += "TYPE=";
+  for (size_t a = 0; a < r.alt_type.size(); ++a) info += std::string(a ? "," : "") + (r.alt_type[a] >= 0 && r.alt_type[a] < 5 ? kType[r.alt_type[a]] : "REF");
+  info += ";LENGTH=" + join(r.alt_length);
+  if (!r.graph_cx.empty()) info += ";GRAPH_CX=" + r.graph_cx;
+  if (!r.seq_cx.empty()) info += ";SEQ_CX=" + r.seq_cx;
+  char buf[96];
+  std::snprintf(buf, sizeof buf, "%.2f", r.qual);
+  std::string line = ref.chroms[static_cast<size_t>(r.chrom)].name + "\t" + std::to_string(r.pos1) + "\t.\t" + r.ref + "\t";
+  for (size_t a = 0; a < r.alts.size(); ++a) line += (a ? "," : "") + r.alts[a];
+  line += std::string("\t") + buf + "\t.\t" + info + "\t" + kVcfFormatKey;
+  for (size_t s = 0; s < r.ad.size(); ++s) {
+    uint64_t dp = 0;
+    for (uint32_t c : r.ad[s]) dp += c;
+    if (dp == 0) {  // no read of this sample was assigned here: SampleFormatData::SetMissingSupport
+      line += "\t./.:.:.:.:.:.:.:.:.:.:.:.:.:.:.:.:.:.:.:.:.:.:.:.";
+      continue;
+    }
+    std::string gt = "./.", pl = ".";
+    if (s < r.pl.size() && !r.pl[s].empty()) {
+      size_t const best = static_cast<size_t>(std::min_element(r.pl[s].begin(), r.pl[s].end()) - r.pl[s].begin());
+      auto const g = GenotypeOfPlIndex(best);
+      gt = std::to_string(g.first) + "/" + std::to_string(g.second);
+      pl = join(r.pl[s]);
+    }
+    double alt = 0.0;
+    for (size_t a = 1; a < r.ad[s].size(); ++a) alt += r.ad[s][a];
+    std::string sdfc = ".";
+    if (s < r.sample_window_cov.size() && r.sample_window_cov[s] > 0.0) {
+      std::snprintf(buf, sizeof buf, "%.2f", static_cast<double>(dp) / r.sample_window_cov[s]);
+      sdfc = buf;
+    }
+    char polar[64];
+    std::snprintf(polar, sizeof polar, "%.4f:%.4f", static_cast<double>(static_cast<float>(PolarRadius(r.ad[s][0], alt))),
+                  static_cast<double>(static_cast<float>(PolarAngle(alt, r.ad[s][0]))));
+    line += "\t" + gt + ":" + join(r.ad[s]) + ":" + (s < r.adf.size() ? join(r.adf[s]) : ".") + ":" +
+            (s < r.adr.size() ? join(r.adr[s]) : ".") + ":" + std::to_string(dp) + ":.:.:.:.:.:.:.:.:.:" + sdfc + ":" + polar +
+            ":.:.:.:.:.:" + pl + ":" + (s < r.gq.size() ? std::to_string(r.gq[s]) : ".");
+  }
+  return line;
+}
+
 // the engine's per-window outputs of one batch -> records (what VariantCall / CollectSupportedCalls hand to the store)
-inline std::vector<VariantRecord> RecordsOfBatch(const ma_params_t& p, FlatBatch const& fb, const ma_var_out_t& v, const ma_geno_out_t& q) {
+inline std::vector<VariantRecord> RecordsOfBatch(const ma_params_t& p, FlatBatch const& fb, const ma_var_out_t& v, const ma_geno_out_t& q,
+                                                 const ma_cx_out_t* cx = nullptr) {
   std::vector<VariantRecord> out;
   int const MV = p.max_vars, MA = p.max_alts, S = p.num_samples, NA = MA + 1;
   for (size_t w = 0; w < fb.windows.size(); ++w) {
@@ -767,11 +913,38 @@ inline std::vector<VariantRecord> RecordsOfBatch(const ma_params_t& p, FlatBatch
         r.alts.emplace_back(reinterpret_cast<const char*>(pool) + v.alt_off[vi * MA + a], v.alt_len[vi * MA + a]);
       r.qual = q.var_qual[vi];
       r.ad.assign(static_cast<size_t>(S), {});
-      for (int s = 0; s < S; ++s)
-        for (uint32_t al = 0; al <= v.var_nalts[vi]; ++al) {
+      r.adf.assign(static_cast<size_t>(S), {});
+      r.adr.assign(static_cast<size_t>(S), {});
+      uint32_t const K = v.var_nalts[vi] + 1, G = static_cast<uint32_t>(NA * (NA + 1) / 2);
+      for (int s = 0; s < S; ++s) {
+        for (uint32_t al = 0; al < K; ++al) {
           const uint32_t* c = q.allele_counts + ((vi * S + s) * NA + al) * 2;
           r.ad[static_cast<size_t>(s)].push_back(c[0] + c[1]);
+          r.adf[static_cast<size_t>(s)].push_back(c[0]);
+          r.adr[static_cast<size_t>(s)].push_back(c[1]);
         }
+        if (q.var_pl) {
+          const uint32_t* pl = q.var_pl + (vi * S + s) * G;
+          r.pl.emplace_back(pl, pl + K * (K + 1) / 2);
+        }
+        if (q.var_gq) r.gq.push_back(q.var_gq[vi * S + s]);
+      }
+      for (uint32_t a = 0; a < v.var_nalts[vi]; ++a) {
+        r.alt_type.push_back(v.alt_type[vi * MA + a]);
+        r.alt_length.push_back(v.alt_length[vi * MA + a]);
+      }
+      if (w < fb.sample_cov.size()) r.sample_window_cov = fb.sample_cov[w];
+      if (cx) {  // caller/raw_variant.h:43-46, base/sequence_complexity.cpp:462-469
+        const int32_t* ci = cx->seq_cx_i + vi * 4;
+        const float* cf = cx->seq_cx_f + vi * 4;
+        const double* cd = cx->seq_cx_d + vi * 3;
+        const double* gx = cx->graph_cx + vi * 3;
+        r.seq_cx = std::to_string(ci[0]) + "," + FormatComplexityScore(cf[0]) + "," + FormatComplexityScore(cd[0]) + "," +
+                   FormatComplexityScore(cd[1]) + "," + std::to_string(ci[1]) + "," + FormatComplexityScore(cf[1]) + "," +
+                   FormatComplexityScore(cd[2]) + "," + FormatComplexityScore(cf[2]) + "," + FormatComplexityScore(cf[3]) + "," +
+                   std::to_string(ci[2]) + "," + std::to_string(ci[3]);
+        r.graph_cx = FormatComplexityScore(gx[0]) + "," + FormatComplexityScore(gx[1]) + "," + std::to_string(static_cast<long long>(gx[2]));
+      }
       out.push_back(std::move(r));
     }
   }

@@ -169,6 +169,44 @@ int main() {
     auto const rest = st.ExtractAll();
     CHECK(rest.size() == 1 && rest[0].chrom == 2 && st.Size() == 0);
   }
+  {  // VCF text (caller/variant_call.cpp, caller/sample_format_data.cpp:32-98)
+    // GL index -> genotype: 0/0 0/1 1/1 0/2 1/2 2/2 0/3 ... (variant_call.cpp:262-290)
+    const int want[10][2] = {{0, 0}, {0, 1}, {1, 1}, {0, 2}, {1, 2}, {2, 2}, {0, 3}, {1, 3}, {2, 3}, {3, 3}};
+    for (size_t g = 0; g < 10; ++g) {
+      auto const gt = GenotypeOfPlIndex(g);
+      CHECK(gt.first == want[g][0] && gt.second == want[g][1]);
+    }
+    // tests/caller/variant_call_test.cpp: AD 30,20 renders PRAD 5.51 / PANG 0.588 with set values; the functions themselves:
+    CHECK(std::abs(PolarRadius(30, 20) - std::log10(1.0 + std::sqrt(1300.0))) < 1e-12);
+    CHECK(std::abs(PolarAngle(20, 30) - std::atan2(20.0, 30.0)) < 0.005);  // the reference's minimax atan2, restated as is
+    CHECK(std::abs(PolarAngle(20, 30) - 0.5906285633997478) < 1e-12);       // (its own arithmetic, evaluated independently)
+    CHECK(std::abs(PolarAngle(0, 30)) < 0.005 && std::abs(PolarAngle(30, 0) - 1.5707963) < 0.005);
+    CHECK(FormatComplexityScore(0.5) == "0.5" && FormatComplexityScore(2.0) == "2" && FormatComplexityScore(1.23456) == "1.235");
+    VariantRecord r{0, 1500, "A", {"T", "G"}, 12.3456, {{12, 0, 0}, {9, 6, 1}}, 2};
+    r.alt_type = {0, 0};
+    r.alt_length = {1, 1};
+    r.adf = {{6, 0, 0}, {5, 3, 1}};
+    r.adr = {{6, 0, 0}, {4, 3, 0}};
+    r.pl = {{0, 30, 300, 30, 300, 300}, {120, 0, 200, 90, 210, 400}};
+    r.gq = {30, 90};
+    r.sample_window_cov = {30.0, 32.0};
+    std::string const line = AsVcfRecord(r, ref, {Tag::CTRL, Tag::CASE}, true);
+    CHECK(line.rfind("chr1\t1500\t.\tA\tT,G\t12.35\t.\tCASE;MULTIALLELIC;TYPE=SNV,SNV;LENGTH=1,1\t", 0) == 0);
+    CHECK(line.find(std::string("\t") + kVcfFormatKey + "\t0/0:12,0,0:6,0,0:6,0,0:12:") != std::string::npos);
+    CHECK(line.find("\t0/1:9,6,1:5,3,1:4,3,0:16:.:.:.:.:.:.:.:.:.:0.50:") != std::string::npos);
+    CHECK(line.find(":120,0,200,90,210,400:90") != std::string::npos);
+    size_t colons = 0;  // 24 FORMAT values per sample
+    for (char c : line.substr(line.rfind('\t'))) colons += c == ':';
+    CHECK(colons == 23);
+    VariantRecord none = r;
+    none.ad = {{0, 0, 0}, {9, 6, 1}};
+    CHECK(AsVcfRecord(none, ref, {Tag::CTRL, Tag::CASE}, true).find("\t./.:.:.:") != std::string::npos);
+    std::vector<SampleInfo> ss{{"normal", Tag::CTRL, nullptr, 0, 0, 0}, {"tumor", Tag::CASE, nullptr, 1, 0, 0}};
+    std::string const hdr = VcfHeader(ref, ss, true, true, "cmd", "ref.fa");
+    CHECK(hdr.rfind("##fileformat=VCFv4.5\n", 0) == 0 && hdr.find("##contig=<ID=chr1,length=10000>") != std::string::npos);
+    CHECK(hdr.find("##FORMAT=<ID=PL,Number=G,Type=Integer") != std::string::npos && hdr.find("##INFO=<ID=SEQ_CX,Number=11") != std::string::npos);
+    CHECK(hdr.find("#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tnormal\ttumor\n") != std::string::npos);
+  }
   std::printf("host units ok\n");
   return 0;
 }

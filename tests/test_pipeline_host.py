@@ -202,6 +202,42 @@ def test_pipeline_driver_reproduces_the_oracle_with_overlap_duplicates_merged(tm
     assert [g_[1] for g_ in got] == sorted(g_[1] for g_ in got)  # coordinate order
     planted = {900, 1001, 3101, 3300, 4701}  # the SNVs of the fixture (1-based)
     assert planted <= {g_[1] for g_ in got}, sorted(g_[1] for g_ in got)
+    # the same run as VCF text: the reference's record layout, INFO and FORMAT key; AD / DP / GT / PL consistent with the TSV
+    vcf = tmp_path / "calls.vcf"
+    r = subprocess.run([exe, "--reference", str(tmp_path / "ref.fa"), "--normal", str(tmp_path / "normal.sam"),
+                        "--tumor", str(tmp_path / "tumor.sam"), "--region", "chr1:1-6000", "--min-kmer", "25", "--max-kmer", "25",
+                        "--batch-windows", "3", "--out-vcf", str(vcf)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    lines = open(vcf).read().splitlines()
+    assert lines[0] == "##fileformat=VCFv4.5" and any(x.startswith("##contig=<ID=chr1,length=6000>") for x in lines)
+    body = [x.split("\t") for x in lines if not x.startswith("#")]
+    assert [x for x in lines if x.startswith("#CHROM")][0].split("\t")[9:] == ["normal", "tumor"]
+    assert len(body) == len(got)
+    key = "GT:AD:ADF:ADR:DP:RMQ:NPBQ:SB:SCA:FLD:RPCD:BQCD:MQCD:ASMD:SDFC:PRAD:PANG:CMLOD:FSSE:AHDD:HSE:PDCV:PL:GQ".split(":")
+    somatic = 0
+    for f, g_ in zip(body, got):
+        assert f[0] == "chr1" and int(f[1]) == g_[1] and f[3] == g_[2] and f[4] == g_[3] and f[8] == ":".join(key)
+        assert abs(float(f[5]) - g_[4]) <= 0.005 + 1e-9  # QUAL with two decimals
+        info = f[7].split(";")
+        assert info[0] in ("SHARED", "CTRL", "CASE", "NONE") and any(x.startswith("TYPE=") for x in info)
+        assert any(x.startswith("SEQ_CX=") and x.count(",") == 10 for x in info)
+        assert any(x.startswith("GRAPH_CX=") and x.count(",") == 2 for x in info)
+        somatic += info[0] == "CASE"
+        for s_idx, col in enumerate(f[9:]):
+            vals = dict(zip(key, col.split(":")))
+            if vals["GT"] == "./.":
+                assert sum(g_[5][s_idx]) == 0
+                continue
+            ad = [int(x) for x in vals["AD"].split(",")]
+            assert ad == g_[5][s_idx] and int(vals["DP"]) == sum(ad)
+            adf, adr = [int(x) for x in vals["ADF"].split(",")], [int(x) for x in vals["ADR"].split(",")]
+            assert [a + b for a, b in zip(adf, adr)] == ad
+            pl = [int(x) for x in vals["PL"].split(",")]
+            k = len(ad)
+            assert len(pl) == k * (k + 1) // 2 and min(pl) == 0
+            a1, a2 = (int(x) for x in vals["GT"].split("/"))
+            assert pl[a2 * (a2 + 1) // 2 + a1] == 0 and 0 <= int(vals["GQ"]) <= 99
+    assert somatic >= 2  # the tumour-only SNVs at 1001 and 3101
 
 
 def sam_to_bam(sam_path, bam_path):
