@@ -203,9 +203,10 @@ void advance_fields(S* s, const std::vector<OutField>& per_unit, size_t first, s
 
 // One contiguous window range [w0, w1) of the batch on a child context.  All pointers are device pointers.
 int run_lane(ma_ctx* ch, hipEvent_t start, const DBatch& full, int w0, int w1, u32 r0, u32 r1, ma_gate_out_t g,
-             ma_asm_out_t a, ma_var_out_t v, ma_geno_out_t q) {
+             ma_asm_out_t a, ma_var_out_t v, ma_geno_out_t q, int lane_index) {
   MA_HIP(ch, hipSetDevice(ch->device));
   MA_HIP(ch, hipStreamWaitEvent(ch->stream, start, 0));
+  (void)lane_index;  // (starting the lanes a few ms apart was measured: every ms of stagger is lost, the lanes do overlap)
   int const n = w1 - w0;
   DBatch d = full;
   d.n_windows = n;
@@ -267,7 +268,7 @@ int process_in_lanes(ma_ctx* ctx, int lanes, const DBatch& d, const ma_gate_out_
     ch->collect = ctx->collect;
     if (!ch->accumulate) ch->timers_used = 0;
     ch->hbm_share = ctx->hbm_share / lanes;
-    th.emplace_back([&, k, ch]() { rc[k] = run_lane(ch, ctx->lane_done, d, wb[k], wb[k + 1], rb[k], rb[k + 1], g, a, v, q); });
+    th.emplace_back([&, k, ch]() { rc[k] = run_lane(ch, ctx->lane_done, d, wb[k], wb[k + 1], rb[k], rb[k + 1], g, a, v, q, k); });
   }
   for (auto& t : th) t.join();
   for (int k = 0; k < lanes; ++k) {
