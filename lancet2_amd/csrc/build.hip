@@ -460,6 +460,20 @@ constexpr u32 kSeqWords = 12288;      // the window's read bases as 4-bit codes 
 constexpr u32 kInstTemp = 1u << 26;   // instance word holds a map entry, not yet a table slot (slots are < 2^21);
                                       // gone from the final words, k_rank reuses the bit as kInstFirst
 constexpr u32 kInstDefer = 1u << 25;  // instance waits for the direct path
+#ifdef MA_PROFILE
+__device__ unsigned long long g_iprof[16];
+#define IPROF_T0() unsigned long long _t0 = __builtin_amdgcn_s_memtime()
+#define IPROF(slot)                                                            \
+  do {                                                                         \
+    __syncthreads();                                                           \
+    unsigned long long _t1 = __builtin_amdgcn_s_memtime();                     \
+    if (threadIdx.x == 0) atomicAdd(&g_iprof[slot], _t1 - _t0);                \
+    _t0 = _t1;                                                                 \
+  } while (0)
+#else
+#define IPROF_T0() do {} while (0)
+#define IPROF(slot) do {} while (0)
+#endif
 __global__ __launch_bounds__(kInsT) void k_insert(DBatch b, GraphWs ws) {
   __shared__ u64 l_key[kInsMap];
   __shared__ u32 l_min[kInsMap];  // smallest instance of the id; after pass 2: its table slot | bit 31 "also a reference k-mer"
@@ -477,6 +491,7 @@ __global__ __launch_bounds__(kInsT) void k_insert(DBatch b, GraphWs ws) {
   u32 const base_idx = b.read_win_off[w] + w;
   SeqInfo const rsi = seq_info(b, w, 0, k);
   u32 const nq = ws.n_slow[a];
+  IPROF_T0();
   for (u32 i = threadIdx.x; i < kInsMap; i += kInsT) {
     l_key[i] = 0;
     l_min[i] = 0xFFFFFFFFu;
@@ -535,6 +550,7 @@ __global__ __launch_bounds__(kInsT) void k_insert(DBatch b, GraphWs ws) {
     __syncthreads();
   }
   bool const staged = l_seq_ok != 0;
+  IPROF(0);  // init + staging
   // map entry of an id (kNoNode: no room along this probe sequence -- then there never will be for this id)
   auto map_entry = [&](u64 id) -> u32 {
     u32 e = static_cast<u32>(id >> 32) % kInsMap;
@@ -568,6 +584,7 @@ __global__ __launch_bounds__(kInsT) void k_insert(DBatch b, GraphWs ws) {
       }
     }
   }
+  IPROF(1);  // reference k-mers
   // (B) slow queue.  Every instance is a chain of dependent HBM round trips (queue entry -> sequence record -> instance
   // word -> k-mer bytes) and this pass was 73 % of the kernel with one instance in flight per thread: four independent
   // chains per thread now, the LDS map only touched once all four ids are known.
@@ -616,32 +633,41 @@ __global__ __launch_bounds__(kInsT) void k_insert(DBatch b, GraphWs ws) {
     }
   }
   __syncthreads();
+  IPROF(2);  // slow queue, pass 1
   // ---- the table: as many slots as the distinct k-mers need (the stride tc_log2 is sized for the busiest window;
   //      nothing re-hashes later: every stage goes through the slot in the instance word) ----
+  // When every id found room in the LDS map (always, except in deep samples) the map IS the table: slot = map entry, keys
+  // and first instances copied out with coalesced stores -- re-hashing the ids into an HBM table with one atomicCAS each
+  // (scattered, one round trip per probe) was a quarter of this kernel.  Nothing downstream probes by key: every stage goes
+  // through the slot in the instance word.
+  bool const direct_map = l_ndef == 0 && (1u << ws.tc_log2) >= kInsMap;
   u32 tcw = 10;
-  while (tcw < static_cast<u32>(ws.tc_log2) && (1u << tcw) < (l_nmap + l_ndef) * 4u / 3u + 16u) ++tcw;
+  while (tcw < static_cast<u32>(ws.tc_log2) && (1u << tcw) < (direct_map ? kInsMap : (l_nmap + l_ndef) * 4u / 3u + 16u)) ++tcw;
   u32 const mask = (1u << tcw) - 1;
   {
     int const CW = ws.num_samples + 2;
     u32* cnt = ws.tbl_cnt + (static_cast<size_t>(a) << ws.tc_log2) * CW;
     for (u32 i = threadIdx.x; i <= mask; i += kInsT) {
-      keys[i] = 0;
-      first[i] = 0x7F7F7F7Fu;  // > any instance
+      u64 const id = (direct_map && i < kInsMap) ? l_key[i] : 0ull;
+      keys[i] = id;
+      first[i] = id ? l_min[i] : 0x7F7F7F7Fu;  // (0x7F7F7F7F > any instance)
     }
     for (u32 i = threadIdx.x; i < (mask + 1u) * CW; i += kInsT) cnt[i] = 0;
     if (threadIdx.x == 0) ws.win_tc[a] = tcw;
     __syncthreads();
   }
+  IPROF(3);  // table initialisation
   // ---- pass 2: every distinct k-mer of the map into the HBM table, once ----
   for (u32 e = threadIdx.x; e < kInsMap; e += kInsT) {
     u64 const id = l_key[e];
     if (id == 0) continue;
-    u32 const slot = table_insert(keys, mask, id);
+    u32 const slot = direct_map ? e : table_insert(keys, mask, id);
     u32 const fi = l_min[e];
     if (slot == kNoNode) atomicOr(&ws.win_flags[w], 4u);  // table full (cannot happen with the capacity planning)
-    else first[slot] = fi;  // plain store: ids of the map never take the direct path
+    else if (!direct_map) first[slot] = fi;  // plain store: ids of the map never take the direct path
     l_min[e] = (slot == kNoNode ? 0x7FFFFFFFu : (slot & kInstSlotMask)) | (fi < rsi.nk ? 0x80000000u : 0u);
   }
+  IPROF(4);  // pass 2: table inserts
   // deferred instances (ids without room in the map): the direct path, reference k-mers first
   bool const any_def = l_ndef != 0;
   auto direct_insert = [&](u64 id, u32 inst, u32* old_first) -> u32 {
@@ -683,6 +709,7 @@ __global__ __launch_bounds__(kInsT) void k_insert(DBatch b, GraphWs ws) {
     }
   }
   __syncthreads();
+  IPROF(5);  // deferred ids
   // ---- pass 3: instance words get their table slot; reads with a general-path k-mer that is a reference node ----
   for (u32 p = threadIdx.x; p < rsi.nk; p += kInsT) {
     u32 const word = inst_slot[p];
@@ -720,7 +747,11 @@ __global__ __launch_bounds__(kInsT) void k_insert(DBatch b, GraphWs ws) {
       if ((word[u] & kInstErrFree) && (sv >> 31)) ws.rd_flag[r_first + (item[u] >> 12) - 1] = 1;
     }
   }
+  IPROF(6);  // pass 3
 }
+#ifdef MA_PROFILE
+extern "C" void ma_debug_iprof(unsigned long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_iprof), sizeof(unsigned long long) * 16); }
+#endif
 
 // (3) k_support: read support of the FAST instances (node.cpp:18-24 + graph.h:102-117), one thread per group
 //     of adjacent reads with equal (qname, role, sample); per-reference-position counters live in LDS.
