@@ -405,7 +405,41 @@ __global__ __launch_bounds__(64) void k_classify(DBatch b, GraphWs ws, u32* max_
 // node identity of the k-mer s[0, k): canonical decision + fmix64 of the polynomial hash of the canonical string.
 // The reverse-complement strand is hashed as the forward hash of the reversed complemented string (one multiply
 // per base instead of a running power).
+// k <= 32 and nothing but upper-case A/C/G/T (every k-mer of a WGS window at the usual k): the k-mer fits a 64-bit word at
+// two bits per base, and both the canonical decision (kmer.cpp:17-28) and the identity come from that word.  With base i at
+// bits 2i+1:2i ("little-endian" packing F) the reverse complement read as a big-endian number is simply ~F: complementing
+// a base is 3 - code, and reversing the string is what turns the little-endian packing into the big-endian reading; the
+// forward strand's big-endian value is F with its 2-bit groups reversed.  Big-endian numeric order of the codes A 0 < C 1 <
+// G 2 < T 3 is the lexicographic order of the strings, equal means palindrome means PLUS.  id = fmix64 of the canonical
+// value: node ids are internal (they never reach an output and nothing orders by them), so this need not be the oracle's
+// polynomial -- it only has to be the SAME function for every k-mer of a window, which k and the alphabet decide.  A
+// 25-mer costs ~90 instructions this way instead of ~400 (25 LDS reads, 25 64-bit multiply-adds, 13 byte compares).
+__device__ __forceinline__ u64 packed_kmer_id(u64 f_le, int k, bool* plus_out) {
+  u64 const mask = k >= 32 ? ~0ull : ((1ull << (2 * k)) - 1ull);
+  u64 const br = ~f_le & mask;
+  u32 const lo = static_cast<u32>(f_le), hi = static_cast<u32>(f_le >> 32);
+  u64 r = (static_cast<u64>(__brev(lo)) << 32) | __brev(hi);  // bit i -> bit 63 - i
+  r = ((r >> 1) & 0x5555555555555555ull) | ((r & 0x5555555555555555ull) << 1);  // ... and the two bits of a base back in order
+  u64 const bf = r >> (64 - 2 * k);
+  bool const plus = bf <= br;
+  u64 const id = dev_fmix64((plus ? bf : br) + static_cast<u64>(k) * kHashP);
+  *plus_out = plus;
+  return id ? id : 1;
+}
 __device__ __forceinline__ u64 kmer_id(const u8* s, int k, bool* plus_out) {
+  if (k <= 32) {
+    u64 f = 0;
+    bool acgt = true;
+#pragma unroll 8
+    for (int i = 0; i < k; ++i) {
+      u32 const c = s[i];
+      acgt = acgt && dev_is_acgt_upper(c);
+      u32 e = (c >> 1) & 3u;  // A 0, C 1, T 2, G 3
+      e ^= e >> 1;            // A 0, C 1, G 2, T 3
+      f |= static_cast<u64>(e) << (2 * i);
+    }
+    if (acgt) return packed_kmer_id(f, k, plus_out);
+  }
   // the canonical decision usually falls within the first base or two, so only the canonical strand is hashed
   bool const plus = canon_plus(s, k);
   u64 h = 0;
@@ -425,7 +459,35 @@ __device__ __forceinline__ u64 kmer_id(const u8* s, int k, bool* plus_out) {
 __device__ __forceinline__ u32 seq_code(const u32* l_seq, u32 p) { return (l_seq[p >> 3] >> (4u * (p & 7u))) & 0xFu; }
 __device__ __forceinline__ u32 code_byte(u32 code) { return static_cast<u32>(0x0000004E54474341ULL >> (8u * code)) & 0xFFu; }  // "ACGTN"
 __device__ __forceinline__ u32 code_comp(u32 code) { return code < 4u ? 3u - code : 4u; }
+__device__ __forceinline__ u32 squeeze_nibbles(u32 x) {  // eight 4-bit codes < 4 -> sixteen bits, base j at bits 2j+1:2j
+  x = (x | (x >> 2)) & 0x0F0F0F0Fu;
+  x = (x | (x >> 4)) & 0x00FF00FFu;
+  x = (x | (x >> 8)) & 0x0000FFFFu;
+  return x;
+}
 __device__ __forceinline__ u64 kmer_id_lds(const u32* l_seq, u32 p, int k, bool* plus_out) {
+  if (k <= 32) {  // the same packed identity as kmer_id, from five words of the staged stream
+    u32 const w0 = p >> 3, sh = 4u * (p & 7u);
+    u32 const v0 = l_seq[w0], v1 = l_seq[w0 + 1], v2 = l_seq[w0 + 2], v3 = l_seq[w0 + 3], v4 = l_seq[w0 + 4];  // (l_seq has slack)
+    u32 a0 = __builtin_amdgcn_alignbit(v1, v0, sh), a1 = __builtin_amdgcn_alignbit(v2, v1, sh),
+        a2 = __builtin_amdgcn_alignbit(v3, v2, sh), a3 = __builtin_amdgcn_alignbit(v4, v3, sh);
+    // keep the first k nibbles
+    u32 const k0 = static_cast<u32>(k);
+    auto keep = [&](u32 x, u32 first) -> u32 {
+      if (k0 <= first) return 0u;
+      u32 const n = k0 - first;
+      return n >= 8u ? x : (x & ((1u << (4u * n)) - 1u));
+    };
+    a0 = keep(a0, 0);
+    a1 = keep(a1, 8);
+    a2 = keep(a2, 16);
+    a3 = keep(a3, 24);
+    if (((a0 | a1 | a2 | a3) & 0x44444444u) == 0u) {  // no N (code 4) among them
+      u64 const f = static_cast<u64>(squeeze_nibbles(a0)) | (static_cast<u64>(squeeze_nibbles(a1)) << 16) |
+                    (static_cast<u64>(squeeze_nibbles(a2)) << 32) | (static_cast<u64>(squeeze_nibbles(a3)) << 48);
+      return packed_kmer_id(f, k, plus_out);
+    }
+  }
   bool plus = true;
   int const half = (k + 1) / 2;
   for (int i = 0; i < half; ++i) {  // canonical decision (kmer.cpp:17-28): inward compare of the bytes
@@ -477,7 +539,7 @@ __device__ unsigned long long g_iprof[16];
 __global__ __launch_bounds__(kInsT) void k_insert(DBatch b, GraphWs ws) {
   __shared__ u64 l_key[kInsMap];
   __shared__ u32 l_min[kInsMap];  // smallest instance of the id; after pass 2: its table slot | bit 31 "also a reference k-mer"
-  __shared__ u32 l_seq[kSeqWords];
+  __shared__ u32 l_seq[kSeqWords + 8];  // (+ slack: the packed identity reads five words from a k-mer's first)
   __shared__ u32 l_rpos[kSeqCap], l_ibase[kSeqCap];  // staged windows: per sequence, first base in l_seq and first instance
   __shared__ u32 l_nmap, l_ndef, l_seq_ok;
   int const a = blockIdx.x;
@@ -536,7 +598,8 @@ __global__ __launch_bounds__(kInsT) void k_insert(DBatch b, GraphWs ws) {
       for (int x = 0; x < 8; ++x) {
         u32 const byte = ((x < 4 ? v.x : v.y) >> (8 * (x & 3))) & 0xFFu;
         u32 const e = enc_base(static_cast<u8>(byte));
-        odd = odd || (e == 4u && byte != 'N' && static_cast<u64>(wd) * 8u + x < seq_bytes &&
+        // (anything but upper-case A/C/G/T/N: a lower-case base would come back from its code in upper case)
+        odd = odd || (!(e < 4u ? dev_is_acgt_upper(byte) : byte == 'N') && static_cast<u64>(wd) * 8u + x < seq_bytes &&
                       seq_base + static_cast<size_t>(wd) * 8u + x >= b.read_bases + b.read_off[b.read_win_off[w]]);
         pk |= e << (4 * x);
       }
