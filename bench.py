@@ -651,7 +651,7 @@ def main():
                            capi.fill_struct(capi.VarOut, outs[2]), capi.fill_struct(capi.GenoOut, outs[3]))
                 return h_in, outs, structs, capi.make_batch_struct(h_in, hn, h_nr)
 
-            def host_leg(n_feeders, steps_each=3, prefetch=True):
+            def host_leg(n_feeders, steps_each=5, prefetch=True):
                 os.environ["MA_HBM_SHARE"] = str(round(0.9 / n_feeders, 3))
                 feeders = [make_feeder() for _ in range(n_feeders)]
                 engs = [Engine(params, device=local_rank, memspace=capi.MA_MEM_HOST) for _ in range(n_feeders)]
@@ -664,11 +664,16 @@ def main():
                 start = threading.Barrier(n_feeders + 1)
 
                 def work(e_, f_):
-                    start.wait()
+                    # steady state of a stream of batches: the pipeline is primed before the clock starts (as the warm-up
+                    # steps of the headline are) and EVERY timed step uploads one batch and processes one -- the last
+                    # step's upload is of a batch nobody processes, so that uploads and steps stay one to one
                     if prefetch:
                         e_.prefetch(f_[3])
+                        e_.prefetch(f_[3])
+                        e_.process_device(f_[3], *f_[2])  # (one pipelined step before the clock starts)
+                    start.wait()
                     for it in range(steps_each):
-                        if prefetch and it + 1 < steps_each:
+                        if prefetch:
                             e_.prefetch(f_[3])  # the next batch uploads under this one's kernels (ma_prefetch_batch)
                         e_.process_device(f_[3], *f_[2])
 

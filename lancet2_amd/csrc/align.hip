@@ -115,12 +115,17 @@ struct GArgs {
 // A read's three bit planes live in one wavefront (k_vote / k_align_*: a lane per word): 608 bases at most.  A window
 // that holds a longer read is not genotyped and says so (MA_W_READ_OVERFLOW) -- the batch goes on without it.
 constexpr u32 kMaxGenoRead = 608;
-__global__ void k_max_reads(DBatch b, u32* win_status, u32* out) {  // out[0] most reads of a window, out[1] longest read
-  int const w = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void k_max_reads(DBatch b, u32* win_status, u32* out) {  // out[0] most reads of a window, out[1] longest read
+  // one wavefront per window, a lane per read
+  int const w = blockIdx.x * 4 + static_cast<int>(threadIdx.x >> 6);
   if (w >= b.n_windows) return;
-  atomicMax(out, b.read_win_off[w + 1] - b.read_win_off[w]);
+  u32 const lane = threadIdx.x & 63u;
   u32 ml = 0;
-  for (u32 r = b.read_win_off[w]; r < b.read_win_off[w + 1]; ++r) ml = max(ml, static_cast<u32>(b.read_off[r + 1] - b.read_off[r]));
+  for (u32 r = b.read_win_off[w] + lane; r < b.read_win_off[w + 1]; r += 64) ml = max(ml, static_cast<u32>(b.read_off[r + 1] - b.read_off[r]));
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) ml = max(ml, static_cast<u32>(__shfl_xor(ml, d, 64)));
+  if (lane != 0) return;
+  atomicMax(out, b.read_win_off[w + 1] - b.read_win_off[w]);
   // (a window the assembler skipped for its reads keeps that flag: it has no haplotypes to genotype)
   u32 const st = win_status[w] & ~static_cast<u32>(MA_W_CIGAR_OVERFLOW);
   if (ml > kMaxGenoRead) {
@@ -1959,7 +1964,7 @@ int launch_genotype(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& a, const m
     MA_HIP(ctx, ctx->ws_misc.reserve(4096));
     u32* cnt = ctx->ws_misc.as<u32>();
     MA_HIP(ctx, hipMemsetAsync(cnt, 0, 16, ctx->stream));
-    hipLaunchKernelGGL(k_max_reads, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, b, a.win_status, cnt);
+    hipLaunchKernelGGL(k_max_reads, dim3((n + 3) / 4), dim3(256), 0, ctx->stream, b, a.win_status, cnt);
     u32 mr2[2] = {0, 0};
     MA_HIP(ctx, hipMemcpyAsync(mr2, cnt, 8, hipMemcpyDeviceToHost, ctx->stream));
     MA_HIP(ctx, ma_stream_sync(ctx));

@@ -1,7 +1,11 @@
 // C-ABI entry points of libmicroasm.so (see include/microasm.h).  No CPU fallback: every entry
 // point fails with MA_ERR_NO_DEVICE when there is no HIP device.
+#include <algorithm>
 #include <chrono>
+#include <condition_variable>
 #include <cstring>
+#include <deque>
+#include <memory>
 #include <mutex>
 #include <new>
 #include <thread>
@@ -282,10 +286,18 @@ int process_in_lanes(ma_ctx* ctx, int lanes, const DBatch& d, const ma_gate_out_
 }
 
 // ---- the host route (MA_MEM_HOST) of ma_process_batch -------------------------------------------------------------------
-// Every lane stages ITS slice of the caller's input arrays on its own stream, runs the four stages, packs the used part
-// of its results (pack.hip), copies the records to a pinned landing area and scatters them into the caller's arrays on its
-// own host thread.  Uploads, kernels and downloads of different lanes overlap (copy engines beside compute), and what
-// crosses PCIe on the way back is what the engine wrote: ~5 KB instead of 95 KB per window.
+// Every lane stages ITS slice of the caller's input arrays (or finds it staged by ma_prefetch_batch), runs the four stages,
+// packs the used part of its results (pack.hip) and copies the records to a pinned landing area; the caller's thread scatters
+// them into the caller's arrays.  What crosses PCIe on the way back is what the engine wrote: ~5 KB instead of 95 KB per
+// window.
+//
+// The lanes are PERSISTENT worker threads with a job queue each.  ma_prefetch_batch does not only upload the next batch: it
+// also queues the batch's compute jobs, so a lane goes from its last kernel of batch j straight to the first kernel of batch
+// j + 1 -- the lanes drift apart instead of starting and ending every batch in lockstep, and the end-of-batch work of one
+// (pack, download, the caller's scatter, the call returning and the next one coming in) runs under the kernels of the
+// others.  ma_process_batch(j + 1) then only waits for the records and scatters them.  A job that was queued ahead assumes
+// that the call will ask for the same optional outputs as the last one did and run under the same parameters; if it does
+// not, the job's results are dropped and the batch is computed again, in the call.
 struct LaneOut {
   ma_gate_out_t g{};
   ma_asm_out_t a{};
@@ -293,24 +305,23 @@ struct LaneOut {
   ma_geno_out_t q{};
 };
 
-int ensure_pinned(ma_ctx* ch, size_t bytes) {
-  if (bytes <= ch->pin_cap) return MA_OK;
-  if (ch->pin) (void)hipHostFree(ch->pin);
-  ch->pin = nullptr;
-  ch->pin_cap = 0;
+int ensure_pinned(ma_ctx* ch, int set, size_t bytes) {
+  if (bytes <= ch->pin_cap[set]) return MA_OK;
+  if (ch->pin[set]) (void)hipHostFree(ch->pin[set]);
+  ch->pin[set] = nullptr;
+  ch->pin_cap[set] = 0;
   size_t const want = bytes + bytes / 4 + 4096;
-  MA_HIP(ch, hipHostMalloc(&ch->pin, want, hipHostMallocDefault));
-  ch->pin_cap = want;
+  MA_HIP(ch, hipHostMalloc(&ch->pin[set], want, hipHostMallocDefault));
+  ch->pin_cap[set] = want;
   return MA_OK;
 }
 
 template <class S>
-int alloc_fields(ma_ctx* ch, S* dev, const S* user, const std::vector<OutField>& f, size_t stage_base,
-                 const std::vector<bool>& always) {
+int alloc_fields(ma_ctx* ch, S* dev, const std::vector<OutField>& f, size_t stage_base, const std::vector<bool>& want) {
   std::memset(dev, 0, sizeof(*dev));
   if (ch->out_stage.size() < stage_base + f.size()) ch->out_stage.resize(stage_base + f.size());
   for (size_t i = 0; i < f.size(); ++i) {
-    if (!always[i] && !ptr_at(user, f[i].offset)) continue;  // an optional member the caller left out
+    if (!want[i]) continue;  // an optional member the caller left out
     DevBuf& b = ch->out_stage[stage_base + i];
     MA_HIP(ch, b.reserve(f[i].bytes + 16));
     ptr_at(dev, f[i].offset) = b.p;
@@ -318,9 +329,122 @@ int alloc_fields(ma_ctx* ch, S* dev, const S* user, const std::vector<OutField>&
   return MA_OK;
 }
 
-// Upload the slice [w0, w1) of a host batch into input set `set` of lane `ch` on `stream`; offsets stay absolute, the base
-// pointers are moved back instead.  *d is filled with the device view (valid once the copies have run).
-int stage_lane_inputs(ma_ctx* ch, int set, const ma_batch_t* b, int w0, int w1, hipStream_t stream, DBatch* d) {
+// The output arrays of the route, as tables: which struct (0 gate, 1 asm, 2 var, 3 geno) and member, bytes per window.
+struct DenseDesc { int strct; size_t off; size_t win_bytes; };  // small per-window arrays: copied whole
+struct SegDesc { int strct; size_t off; size_t win_stride, unit; u32 kind; };  // packed: only what a window uses
+std::vector<DenseDesc> dense_table(const ma_params_t& p) {
+  size_t const MC = p.max_comps, MH = p.max_haps;
+  return {{0, off_of(&ma_gate_out_t::max_approx), 4}, {0, off_of(&ma_gate_out_t::max_exact), 4},
+          {1, off_of(&ma_asm_out_t::win_status), 4}, {1, off_of(&ma_asm_out_t::win_k), 4},
+          {1, off_of(&ma_asm_out_t::win_ncomp), 4}, {1, off_of(&ma_asm_out_t::comp_anchor), 4 * MC},
+          {1, off_of(&ma_asm_out_t::comp_hap0), 4 * MC}, {1, off_of(&ma_asm_out_t::comp_nhaps), 4 * MC},
+          {1, off_of(&ma_asm_out_t::comp_cx), 12 * MC}, {1, off_of(&ma_asm_out_t::comp_cxf), 32 * MC},
+          {1, off_of(&ma_asm_out_t::hap_len), 4 * MH}, {1, off_of(&ma_asm_out_t::hap_nruns), 4 * MH},
+          {1, off_of(&ma_asm_out_t::hap_stats), 48 * MH}, {2, off_of(&ma_var_out_t::win_nvars), 4}};
+}
+std::vector<SegDesc> seg_table(const ma_params_t& p) {
+  size_t const MH = p.max_haps, MV = p.max_vars, MA_ = p.max_alts, S = p.num_samples, ML = p.max_hap_len, MR = p.max_runs,
+               MP = p.max_allele_bytes;
+  size_t const G = (MA_ + 1) * (MA_ + 2) / 2;
+  auto var = [&](int strct, size_t off, size_t elem, size_t per_var) {
+    return SegDesc{strct, off, MV * per_var * elem, per_var * elem, PK_VAR};
+  };
+  return {{1, off_of(&ma_asm_out_t::hap_bases), MH * ML, ML, PK_HAP_BASES},
+          {1, off_of(&ma_asm_out_t::hap_runs), MH * MR * 8, MR * 8, PK_HAP_RUNS},
+          var(2, off_of(&ma_var_out_t::var_comp), 4, 1), var(2, off_of(&ma_var_out_t::var_pos), 4, 1),
+          var(2, off_of(&ma_var_out_t::var_ref_start), 4, 1), var(2, off_of(&ma_var_out_t::var_ref_off), 4, 1),
+          var(2, off_of(&ma_var_out_t::var_ref_len), 4, 1), var(2, off_of(&ma_var_out_t::var_nalts), 4, 1),
+          var(2, off_of(&ma_var_out_t::alt_off), 4, MA_), var(2, off_of(&ma_var_out_t::alt_len), 4, MA_),
+          var(2, off_of(&ma_var_out_t::alt_type), 4, MA_), var(2, off_of(&ma_var_out_t::alt_length), 4, MA_),
+          var(2, off_of(&ma_var_out_t::var_hap_allele), 1, MH), var(2, off_of(&ma_var_out_t::var_hap_start), 4, MH),
+          {2, off_of(&ma_var_out_t::allele_pool), MP, 0, PK_POOL},
+          var(3, off_of(&ma_geno_out_t::allele_counts), 4, S * (MA_ + 1) * 2), var(3, off_of(&ma_geno_out_t::var_qual), 8, 1),
+          var(3, off_of(&ma_geno_out_t::var_pl), 4, S * G), var(3, off_of(&ma_geno_out_t::var_gq), 4, S)};
+}
+struct OutPtrs {  // the four output structs of a call, by table index
+  const void* s[4];
+  void* at(int strct, size_t off) const { return s[strct] ? ptr_at(s[strct], off) : nullptr; }
+};
+// which packed arrays the caller asked for (bit i = entry i of seg_table)
+u32 seg_mask_of(const ma_params_t& p, OutPtrs const& u) {
+  std::vector<SegDesc> const t = seg_table(p);
+  u32 m = 0;
+  for (size_t i = 0; i < t.size(); ++i)
+    if (u.at(t[i].strct, t[i].off)) m |= 1u << i;
+  return m;
+}
+bool wants_taps(const ma_geno_out_t* q) { return q->aln_rec || q->aln_cigar || q->asg_allele || q->asg_score; }
+
+// Uploads run in PIECES with at most two of them queued: the copy engine serves its ring in order, and the lanes that
+// are computing meanwhile keep sending it small transfers of their own (chunk plans, work lists: dozens per batch) that wait
+// behind everything queued before them.  Measured with a background copy beside the device-resident route: 1.6 GB queued
+// as one burst (in whatever piece size) costs the kernels' side +20 %, single 256 MB transfers 15x, 16 MB pieces each waited
+// for before the next is queued +2 % at 93 % of the link's rate.
+double wall_ms() {  // (MA_VERBOSE timelines)
+  static auto const t0 = std::chrono::steady_clock::now();
+  return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+}
+struct CopyOp {
+  void* dst;
+  const void* src;  // null: zero `bytes` bytes at dst
+  size_t bytes;
+};
+template <class F>
+int run_copy_ops(ma_ctx* owner, hipStream_t stream, hipStream_t stream2, std::vector<CopyOp> const& ops,
+                 std::vector<size_t> const& group_end, F&& group_done) {
+  // one piece at a time, waited for with a plain stream synchronise (an event or marker behind a DMA copy is a packet on a
+  // compute queue and waits for that queue's turn: 28-33 GB/s instead of 55); MA_UPLOAD_TWO_STREAMS alternates the pieces
+  // between two streams, two in flight (measured: 46.0 instead of 43.2 ms per batch of 8192 windows)
+  static size_t const piece = (getenv("MA_UPLOAD_CHUNK_MB") ? static_cast<size_t>(atoi(getenv("MA_UPLOAD_CHUNK_MB"))) : 16u) << 20;
+  auto const t_begin = std::chrono::steady_clock::now();
+  hipStream_t const st[2] = {stream, stream2 ? stream2 : stream};
+  size_t queued = 0;
+  static int const dbg_skip = getenv("MA_DEBUG_SKIP_UPLOAD") ? atoi(getenv("MA_DEBUG_SKIP_UPLOAD")) : 0;  // developer experiment:
+  static int dbg_calls = 0;                                                                                // the buffers keep what
+  if (dbg_skip > 0 && ++dbg_calls > dbg_skip) {
+    for (size_t g = 0; g < group_end.size(); ++g) group_done(g);
+    return MA_OK;
+  }                                                // the first uploads put there
+  for (CopyOp const& op : ops)  // the pads first: a handful of tiny fills
+    if (op.bytes && !op.src) MA_HIP(owner, hipMemsetAsync(op.dst, 0, op.bytes, stream));
+  size_t grp = 0;
+  for (size_t oi = 0; oi < ops.size(); ++oi) {
+    CopyOp const& op = ops[oi];
+    while (grp < group_end.size() && oi == group_end[grp]) {  // a lane's slice is complete: its lane may start
+      MA_HIP(owner, hipStreamSynchronize(stream));
+      if (stream2) MA_HIP(owner, hipStreamSynchronize(stream2));
+      group_done(grp++);
+    }
+    if (!op.bytes || !op.src) continue;
+    for (size_t o = 0; o < op.bytes; o += piece, ++queued) {
+      hipStream_t const s_ = st[queued & 1];
+      if (queued >= (stream2 ? 2u : 1u)) MA_HIP(owner, hipStreamSynchronize(s_));
+      static int const gap_us = getenv("MA_UPLOAD_GAP_US") ? atoi(getenv("MA_UPLOAD_GAP_US")) : 0;
+      if (gap_us > 0 && queued > 0) {  // (experiment: leave the link idle for a moment between pieces)
+        auto const until = std::chrono::steady_clock::now() + std::chrono::microseconds(gap_us);
+        while (std::chrono::steady_clock::now() < until) {}
+      }
+      MA_HIP(owner, hipMemcpyAsync(static_cast<char*>(op.dst) + o, static_cast<const char*>(op.src) + o, std::min(piece, op.bytes - o),
+                                   hipMemcpyHostToDevice, s_));
+    }
+  }
+  MA_HIP(owner, hipStreamSynchronize(stream));
+  if (stream2) MA_HIP(owner, hipStreamSynchronize(stream2));
+  while (grp < group_end.size()) group_done(grp++);
+  if (getenv("MA_VERBOSE")) {
+    size_t total = 0;
+    for (CopyOp const& op : ops) total += op.src ? op.bytes : 0;
+    double const ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+    fprintf(stderr, "[microasm] t=%.1f upload done: %.1f MB in %zu pieces, %.2f ms (%.1f GB/s)\n", wall_ms(), total / 1e6, queued, ms,
+            total / ms / 1e6);
+  }
+  return MA_OK;
+}
+
+// Plan the upload of the slice [w0, w1) of a host batch into input set `set` of lane `ch`: buffers reserved, the copies
+// appended to `ops`; offsets stay absolute, the base pointers are moved back instead.  *d is the device view (valid once
+// the copies have run).
+int stage_lane_inputs(ma_ctx* ch, int set, const ma_batch_t* b, int w0, int w1, std::vector<CopyOp>* ops, DBatch* d) {
   int const n = w1 - w0;
   u32 const r0 = b->read_win_off[w0], r1 = b->read_win_off[w1];
   size_t const nr = static_cast<size_t>(r1) - r0;
@@ -347,9 +471,9 @@ int stage_lane_inputs(ma_ctx* ch, int set, const ma_batch_t* b, int w0, int w1, 
     size_t const front = items[i].padded ? kPad : 0;
     MA_HIP(ch, in.bufs[i].reserve(front + items[i].bytes + kPad + 16));
     char* base = static_cast<char*>(in.bufs[i].p);
-    if (front) MA_HIP(ch, hipMemsetAsync(base, 0, front, stream));
-    if (items[i].bytes) MA_HIP(ch, hipMemcpyAsync(base + front, items[i].src, items[i].bytes, hipMemcpyHostToDevice, stream));
-    if (items[i].padded) MA_HIP(ch, hipMemsetAsync(base + front + items[i].bytes, 0, kPad, stream));
+    if (front) ops->push_back(CopyOp{base, nullptr, front});
+    ops->push_back(CopyOp{base + front, items[i].src, items[i].bytes});
+    if (items[i].padded) ops->push_back(CopyOp{base + front + items[i].bytes, nullptr, kPad});
     dp[i] = base + front;
   }
   *d = DBatch{};
@@ -368,39 +492,138 @@ int stage_lane_inputs(ma_ctx* ch, int set, const ma_batch_t* b, int w0, int w1, 
   return MA_OK;
 }
 
-// set: the input set to use; ready: the event behind its uploads when ma_prefetch_batch filled it (then `staged` holds the
-// device view), null when the lane uploads its slice itself
-int run_lane_host(ma_ctx* ch, const ma_batch_t* b, int w0, int w1, const ma_gate_out_t* ug, const ma_asm_out_t* ua,
-                  const ma_var_out_t* uv, const ma_geno_out_t* uq, int set, hipEvent_t ready, const DBatch* staged) {
+// One batch on the host route: what every lane needs to compute its slice, and what it leaves for the delivery.
+struct LaneResult {
+  int rc = MA_OK;
+  std::string err;
+  int w0 = 0, w1 = 0;
+  u32 r0 = 0;
+  size_t nr = 0;
+  u8* land = nullptr;                 // the lane's landing area of the job's set
+  std::vector<size_t> dense_off;      // dense_table entry -> offset in land
+  size_t aux_off = 0, packed_off = 0, packed_bytes = 0;
+  std::vector<std::pair<const char*, float>> times;  // the lane's kernel timers of this job, resolved
+  unsigned long long stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+};
+struct UploadTask {  // the inputs of one prefetched batch, all lanes: carried out by the context's uploader thread
+  std::vector<CopyOp> ops;           // lane after lane
+  std::vector<size_t> lane_end;      // ops[.. lane_end[k]) are the slices of lanes 0 .. k
+  std::mutex mu;
+  std::condition_variable cv;
+  size_t lanes_done = 0;             // the slices of lanes [0, lanes_done) are on the device
+  bool done = false;
+  int rc = MA_OK;
+  std::string err;
+  void wait() {
+    std::unique_lock<std::mutex> lk(mu);
+    cv.wait(lk, [&] { return done; });
+  }
+  void wait_lane(size_t k) {  // a lane starts as soon as ITS slice is there: the lanes of a batch start one after the other
+    std::unique_lock<std::mutex> lk(mu);
+    cv.wait(lk, [&] { return done || lanes_done > k; });
+  }
+};
+struct HostJob {
+  ma_batch_t batch{};                 // a copy of the caller's struct (its ARRAYS stay the caller's, valid until the call returns)
+  const ma_batch_t* b = nullptr;
+  int set = 0, lanes = 0;
+  std::vector<int> wb;
+  ma_params_t prm{};
+  bool timing = false, accumulate = false, collect = false;
+  double hbm_share = 1.0;
+  u32 mask = 0;                       // seg_table entries to compute and pack
+  std::shared_ptr<UploadTask> upload; // the upload ma_prefetch_batch started (null: every lane uploads its slice)
+  std::vector<DBatch> staged;         // the lanes' device views of that upload
+  const ma_geno_out_t* taps = nullptr;  // the caller's struct when it asked for the per-read taps (never on a job queued ahead)
+  std::vector<LaneResult> res;
+  std::mutex mu;
+  std::condition_variable cv;
+  int done = 0;
+  void wait_all() {
+    std::unique_lock<std::mutex> lk(mu);
+    cv.wait(lk, [&] { return done == lanes; });
+  }
+};
+struct LaneQueue {
+  std::mutex mu;
+  std::condition_variable cv;
+  std::deque<std::shared_ptr<HostJob>> q;
+  bool stop = false;
+  std::thread th;
+};
+struct HostAsync {
+  std::vector<std::unique_ptr<LaneQueue>> lanes;
+  std::shared_ptr<HostJob> jobs[2];   // by input set: queued (or computed) and not delivered yet
+  std::shared_ptr<UploadTask> uploads[2];  // by input set: the upload of the batch the set holds
+  std::mutex up_mu;
+  std::condition_variable up_cv;
+  std::deque<std::shared_ptr<UploadTask>> up_q;
+  bool up_stop = false;
+  std::thread uploader;
+  u32 last_mask = 0;                  // what the last call asked for: a job queued ahead computes the same
+  bool have_mask = false;
+  std::vector<std::pair<const char*, float>> times;  // kernel timers of the delivered jobs (ma_last_kernel_times)
+};
+HostAsync* async_of(ma_ctx* ctx) {
+  if (!ctx->host_async) ctx->host_async = new HostAsync();
+  return static_cast<HostAsync*>(ctx->host_async);
+}
+
+// The lane's part of a job, on the lane's worker thread: inputs, the four stages, packed records into the landing area.
+int lane_compute(ma_ctx* ch, HostJob& job, int k) {
+  LaneResult& R = job.res[k];
+  int const w0 = job.wb[k], w1 = job.wb[k + 1], set = job.set;
+  const ma_batch_t* b = job.b;
   MA_HIP(ch, hipSetDevice(ch->device));
+  ch->prm = job.prm;
+  ch->timing = job.timing;
+  ch->accumulate = job.accumulate;
+  ch->collect = job.collect;
+  ch->hbm_share = job.hbm_share;
+  ch->timers_used = 0;
+  for (auto& s : ch->stats) s = 0;
   ma_params_t const& p = ch->prm;
   int const n = w1 - w0;
   bool const verbose = getenv("MA_VERBOSE") != nullptr;
   auto const t_begin = std::chrono::steady_clock::now();
   auto since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(); };
-  double t_up = 0, t_gate = 0, t_asm = 0, t_msa = 0, t_geno = 0, t_pack = 0, t_down = 0;
+  double t_up = 0, t_gate = 0, t_asm = 0, t_msa = 0, t_geno = 0, t_pack = 0;
   u32 const r0 = b->read_win_off[w0], r1 = b->read_win_off[w1];
   size_t const nr = static_cast<size_t>(r1) - r0;
   size_t const f0 = b->ref_off[w0], f1 = b->ref_off[w1];
   u64 const b0 = b->read_off[r0], b1 = b->read_off[r1];
+  R.w0 = w0; R.w1 = w1; R.r0 = r0; R.nr = nr;
   DBatch d{};
-  if (ready) {
-    MA_HIP(ch, hipStreamWaitEvent(ch->stream, ready, 0));
-    d = *staged;
+  if (job.upload) {
+    job.upload->wait_lane(static_cast<size_t>(k));
+    if (job.upload->rc != MA_OK) {
+      ch->err = "upload: " + job.upload->err;
+      return job.upload->rc;
+    }
+    d = job.staged[k];
   } else {
-    MA_TRY_RC(stage_lane_inputs(ch, set, b, w0, w1, ch->stream, &d));
+    std::vector<CopyOp> ops;
+    MA_TRY_RC(stage_lane_inputs(ch, set, b, w0, w1, &ops, &d));
+    MA_TRY_RC(run_copy_ops(ch, ch->stream, nullptr, ops, std::vector<size_t>(), [](size_t) {}));
   }
   // ---- device-side outputs of the lane (fixed strides, as the kernels write them) ----
   LaneOut o;
   std::vector<OutField> const gf = gate_fields(p, n), af = asm_fields(p, n), vf = var_fields(p, n),
                               qf = geno_fields(p, n, static_cast<i64>(nr));
-  MA_TRY_RC(alloc_fields(ch, &o.g, ug, gf, 0, std::vector<bool>(gf.size(), true)));
-  MA_TRY_RC(alloc_fields(ch, &o.a, ua, af, 2, std::vector<bool>(af.size(), true)));
-  MA_TRY_RC(alloc_fields(ch, &o.v, uv, vf, 16, std::vector<bool>(vf.size(), true)));
+  std::vector<SegDesc> const segs = seg_table(p);
+  MA_TRY_RC(alloc_fields(ch, &o.g, gf, 0, std::vector<bool>(gf.size(), true)));
+  MA_TRY_RC(alloc_fields(ch, &o.a, af, 2, std::vector<bool>(af.size(), true)));
+  MA_TRY_RC(alloc_fields(ch, &o.v, vf, 16, std::vector<bool>(vf.size(), true)));
   {
     std::vector<bool> need(qf.size(), false);
     need[0] = need[1] = true;  // allele_counts, var_qual; the taps and PL / GQ only if the caller asked for them
-    MA_TRY_RC(alloc_fields(ch, &o.q, uq, qf, 32, need));
+    if (job.taps) {
+      need[2] = job.taps->aln_rec != nullptr; need[3] = job.taps->aln_cigar != nullptr;
+      need[4] = job.taps->asg_allele != nullptr; need[5] = job.taps->asg_score != nullptr;
+    }
+    need[6] = (job.mask >> 17) & 1u;  // seg_table: var_pl, var_gq
+    need[7] = (job.mask >> 18) & 1u;
+    MA_TRY_RC(alloc_fields(ch, &o.q, qf, 32, need));
   }
   t_up = since();
   MA_TRY_RC(launch_gate(ch, d, o.g.max_approx, o.g.max_exact));
@@ -411,91 +634,122 @@ int run_lane_host(ma_ctx* ch, const ma_batch_t* b, int w0, int w1, const ma_gate
   t_msa = since();
   MA_TRY_RC(launch_genotype(ch, d, o.a, o.v, o.q));
   t_geno = since();
-  // ---- results: small dense arrays straight into the caller's arrays, the rest as packed records ----
-  auto d2h = [&](void* host, const void* dev, size_t bytes) -> int {
-    if (host && dev && bytes) MA_HIP(ch, hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, ch->stream));
-    return MA_OK;
-  };
-  size_t const N = n, W0 = w0, MC = p.max_comps, MH = p.max_haps, MV = p.max_vars, MA_ = p.max_alts, S = p.num_samples,
-               ML = p.max_hap_len, MR = p.max_runs, MP = p.max_allele_bytes, MCG = p.max_cigar;
-  size_t const G = (MA_ + 1) * (MA_ + 2) / 2;
-  MA_TRY_RC(d2h(ug->max_approx + W0, o.g.max_approx, 4 * N));
-  MA_TRY_RC(d2h(ug->max_exact + W0, o.g.max_exact, 4 * N));
-  MA_TRY_RC(d2h(ua->win_status + W0, o.a.win_status, 4 * N));
-  MA_TRY_RC(d2h(ua->win_k + W0, o.a.win_k, 4 * N));
-  MA_TRY_RC(d2h(ua->win_ncomp + W0, o.a.win_ncomp, 4 * N));
-  MA_TRY_RC(d2h(ua->comp_anchor + W0 * MC, o.a.comp_anchor, 4 * N * MC));
-  MA_TRY_RC(d2h(ua->comp_hap0 + W0 * MC, o.a.comp_hap0, 4 * N * MC));
-  MA_TRY_RC(d2h(ua->comp_nhaps + W0 * MC, o.a.comp_nhaps, 4 * N * MC));
-  MA_TRY_RC(d2h(ua->comp_cx + W0 * MC * 3, o.a.comp_cx, 4 * N * MC * 3));
-  MA_TRY_RC(d2h(ua->comp_cxf + W0 * MC * 4, o.a.comp_cxf, 8 * N * MC * 4));
-  MA_TRY_RC(d2h(ua->hap_len + W0 * MH, o.a.hap_len, 4 * N * MH));
-  MA_TRY_RC(d2h(ua->hap_nruns + W0 * MH, o.a.hap_nruns, 4 * N * MH));
-  MA_TRY_RC(d2h(ua->hap_stats + W0 * MH * 6, o.a.hap_stats, 8 * N * MH * 6));
-  MA_TRY_RC(d2h(uv->win_nvars + W0, o.v.win_nvars, 4 * N));
-  if (uq->aln_rec) MA_TRY_RC(d2h(uq->aln_rec + static_cast<size_t>(r0) * MH * 6, o.q.aln_rec, 4 * nr * MH * 6));
-  if (uq->aln_cigar)
-    MA_TRY_RC(d2h(uq->aln_cigar + static_cast<size_t>(r0) * MH * (1 + MCG), o.q.aln_cigar, 4 * nr * MH * (1 + MCG)));
-  if (uq->asg_allele) MA_TRY_RC(d2h(uq->asg_allele + static_cast<size_t>(r0) * MV, o.q.asg_allele, nr * MV));
-  if (uq->asg_score) MA_TRY_RC(d2h(uq->asg_score + static_cast<size_t>(r0) * MV, o.q.asg_score, 8 * nr * MV));
-  // packed records: the same segment list on the device (sources = the lane's arrays) and on the host (= the caller's)
-  PackArgs D{}, H{};
-  auto seg = [&](const void* dev, void* host, size_t win_stride, size_t unit, u32 kind) {
-    if (!dev || !host) return;
-    D.seg[D.nseg++] = PackSeg{static_cast<const u8*>(dev), static_cast<u32>(win_stride), static_cast<u32>(unit), kind};
-    H.seg[H.nseg++] = PackSeg{static_cast<const u8*>(host), static_cast<u32>(win_stride), static_cast<u32>(unit), kind};
-  };
-  seg(o.a.hap_bases, ua->hap_bases ? ua->hap_bases + W0 * MH * ML : nullptr, MH * ML, ML, PK_HAP_BASES);
-  seg(o.a.hap_runs, ua->hap_runs ? ua->hap_runs + W0 * MH * MR * 2 : nullptr, MH * MR * 8, MR * 8, PK_HAP_RUNS);
-  auto vseg = [&](const void* dev, void* host_base, size_t elem_bytes, size_t per_var) {
-    seg(dev, host_base ? static_cast<u8*>(host_base) + W0 * MV * per_var * elem_bytes : nullptr, MV * per_var * elem_bytes,
-        per_var * elem_bytes, PK_VAR);
-  };
-  vseg(o.v.var_comp, uv->var_comp, 4, 1);
-  vseg(o.v.var_pos, uv->var_pos, 4, 1);
-  vseg(o.v.var_ref_start, uv->var_ref_start, 4, 1);
-  vseg(o.v.var_ref_off, uv->var_ref_off, 4, 1);
-  vseg(o.v.var_ref_len, uv->var_ref_len, 4, 1);
-  vseg(o.v.var_nalts, uv->var_nalts, 4, 1);
-  vseg(o.v.alt_off, uv->alt_off, 4, MA_);
-  vseg(o.v.alt_len, uv->alt_len, 4, MA_);
-  vseg(o.v.alt_type, uv->alt_type, 4, MA_);
-  vseg(o.v.alt_length, uv->alt_length, 4, MA_);
-  vseg(o.v.var_hap_allele, uv->var_hap_allele, 1, MH);
-  vseg(o.v.var_hap_start, uv->var_hap_start, 4, MH);
-  seg(o.v.allele_pool, uv->allele_pool ? uv->allele_pool + W0 * MP : nullptr, MP, 0, PK_POOL);
-  vseg(o.q.allele_counts, uq->allele_counts, 4, S * (MA_ + 1) * 2);
-  vseg(o.q.var_qual, uq->var_qual, 8, 1);
-  vseg(o.q.var_pl, uq->var_pl, 4, S * G);
-  vseg(o.q.var_gq, uq->var_gq, 4, S);
+  // ---- results: the small dense arrays whole, the rest as packed records, all into the landing area ----
+  OutPtrs const dev{{&o.g, &o.a, &o.v, &o.q}};
+  size_t const N = n, MH = p.max_haps, MV = p.max_vars, MCG = p.max_cigar;
+  std::vector<DenseDesc> const dense = dense_table(p);
+  PackArgs D{};
+  for (size_t i = 0; i < segs.size(); ++i) {
+    void* dp = dev.at(segs[i].strct, segs[i].off);
+    if (!((job.mask >> i) & 1u) || !dp) continue;
+    D.seg[D.nseg++] = PackSeg{static_cast<const u8*>(dp), static_cast<u32>(segs[i].win_stride), static_cast<u32>(segs[i].unit),
+                              segs[i].kind};
+  }
   D.win_status = o.a.win_status; D.win_ncomp = o.a.win_ncomp; D.comp_hap0 = o.a.comp_hap0; D.comp_nhaps = o.a.comp_nhaps;
   D.hap_len = o.a.hap_len; D.hap_nruns = o.a.hap_nruns; D.win_nvars = o.v.win_nvars; D.var_ref_off = o.v.var_ref_off;
   D.var_ref_len = o.v.var_ref_len; D.var_nalts = o.v.var_nalts; D.alt_off = o.v.alt_off; D.alt_len = o.v.alt_len;
-  D.MC = H.MC = p.max_comps; D.MH = H.MH = p.max_haps; D.MV = H.MV = p.max_vars; D.MA = H.MA = p.max_alts;
-  D.MP = H.MP = p.max_allele_bytes;
-  H.win_status = ua->win_status + W0; H.win_ncomp = ua->win_ncomp + W0; H.comp_hap0 = ua->comp_hap0 + W0 * MC;
-  H.comp_nhaps = ua->comp_nhaps + W0 * MC; H.hap_len = ua->hap_len + W0 * MH; H.hap_nruns = ua->hap_nruns + W0 * MH;
-  H.win_nvars = uv->win_nvars + W0;
+  D.MC = p.max_comps; D.MH = p.max_haps; D.MV = p.max_vars; D.MA = p.max_alts; D.MP = p.max_allele_bytes;
   MA_HIP(ch, ch->pack_aux.reserve(4 * (2 * N + 1) + 64));
-  u8* packed = nullptr;
-  size_t packed_bytes = 0;
-  MA_TRY_RC(launch_pack(ch, D, n, ch->pack_aux.as<u32>(), &packed, &packed_bytes));
+  MA_TRY_RC(launch_pack_sizes(ch, D, n, ch->pack_aux.as<u32>()));
+  // the landing area: [dense arrays][aux][records]; the records' size is only known on the device -- room for what the
+  // last batch needed and half as much again (8 KB per window the first time), checked after the fact
   size_t const aux_bytes = 4 * (2 * N + 1);
-  MA_TRY_RC(ensure_pinned(ch, aux_bytes + packed_bytes + 64));
-  u32* h_aux = static_cast<u32*>(ch->pin);
-  u8* h_packed = static_cast<u8*>(ch->pin) + ((aux_bytes + 15) & ~size_t(15));
+  size_t land_bytes = 0;
+  R.dense_off.assign(dense.size(), 0);
+  for (size_t i = 0; i < dense.size(); ++i) {
+    R.dense_off[i] = land_bytes;
+    land_bytes += (dense[i].win_bytes * N + 15) & ~size_t(15);
+  }
+  R.aux_off = land_bytes;
+  land_bytes += (aux_bytes + 15) & ~size_t(15);
+  R.packed_off = land_bytes;
+  size_t const guess = ch->last_packed ? ch->last_packed + ch->last_packed / 2 + 65536 : N * 8192 + 65536;
+  MA_TRY_RC(ensure_pinned(ch, set, land_bytes + guess));
+  R.land = static_cast<u8*>(ch->pin[set]);
+  DenseCopies C{};
+  for (size_t i = 0; i < dense.size(); ++i)
+    C.c[C.n++] = DenseCopy{dev.at(dense[i].strct, dense[i].off), R.land + R.dense_off[i], static_cast<u32>(dense[i].win_bytes * N)};
+  C.c[C.n++] = DenseCopy{ch->pack_aux.p, R.land + R.aux_off, static_cast<u32>(aux_bytes)};
+  MA_TRY_RC(launch_pack_dense(ch, C));
+  MA_TRY_RC(launch_pack_records(ch, D, n, ch->pack_aux.as<u32>(), R.land + R.packed_off, ch->pin_cap[set] - R.packed_off));
   t_pack = since();
-  MA_TRY_RC(d2h(h_aux, ch->pack_aux.p, aux_bytes));
-  MA_TRY_RC(d2h(h_packed, packed, packed_bytes));
+  if (const ma_geno_out_t* uq = job.taps) {  // debug taps, straight into the caller's arrays (the call is waiting for them)
+    auto d2h = [&](void* host, const void* devp, size_t bytes) -> int {
+      if (host && devp && bytes) MA_HIP(ch, hipMemcpyAsync(host, devp, bytes, hipMemcpyDeviceToHost, ch->stream));
+      return MA_OK;
+    };
+    MA_TRY_RC(d2h(uq->aln_rec ? uq->aln_rec + static_cast<size_t>(r0) * MH * 6 : nullptr, o.q.aln_rec, 4 * nr * MH * 6));
+    MA_TRY_RC(d2h(uq->aln_cigar ? uq->aln_cigar + static_cast<size_t>(r0) * MH * (1 + MCG) : nullptr, o.q.aln_cigar,
+                  4 * nr * MH * (1 + MCG)));
+    MA_TRY_RC(d2h(uq->asg_allele ? uq->asg_allele + static_cast<size_t>(r0) * MV : nullptr, o.q.asg_allele, nr * MV));
+    MA_TRY_RC(d2h(uq->asg_score ? uq->asg_score + static_cast<size_t>(r0) * MV : nullptr, o.q.asg_score, 8 * nr * MV));
+  }
   MA_HIP(ch, ma_stream_sync(ch));
-  t_down = since();
-  unpack_records(H, h_aux, h_packed, n);
+  size_t packed_bytes = static_cast<size_t>(reinterpret_cast<const u32*>(R.land + R.aux_off)[2 * N]) * 4u;
+  if (packed_bytes > ch->pin_cap[set] - R.packed_off) {  // did not fit: a bigger landing area (its front part again), the records again
+    MA_TRY_RC(ensure_pinned(ch, set, land_bytes + packed_bytes + 65536));
+    R.land = static_cast<u8*>(ch->pin[set]);
+    for (u32 i = 0; i < C.n; ++i) C.c[i].dst = R.land + (i < dense.size() ? R.dense_off[i] : R.aux_off);
+    MA_TRY_RC(launch_pack_dense(ch, C));
+    MA_TRY_RC(launch_pack_records(ch, D, n, ch->pack_aux.as<u32>(), R.land + R.packed_off, ch->pin_cap[set] - R.packed_off));
+    MA_HIP(ch, ma_stream_sync(ch));
+  }
+  ch->last_packed = packed_bytes;
+  R.packed_bytes = packed_bytes;
+  // the lane's timers and counters belong to this job: the next job starts from zero while the caller reads these
+  if (ch->timing) {
+    R.times.reserve(ch->timers_used);
+    for (size_t i = 0; i < ch->timers_used; ++i) {
+      float t = 0.f;
+      (void)hipEventElapsedTime(&t, ch->timers[i].beg, ch->timers[i].end);
+      R.times.emplace_back(ch->timers[i].name, t);
+    }
+  }
+  ch->timers_used = 0;
+  for (int x = 0; x < 8; ++x) {
+    R.stats[x] = ch->stats[x];
+    ch->stats[x] = 0;
+  }
   if (verbose)
-    fprintf(stderr, "[microasm] host lane [%d, %d): enqueue-upload %.2f gate %.2f assemble %.2f msa %.2f genotype %.2f pack %.2f "
-            "download %.2f unpack %.2f ms; %.1f MB in, %.2f MB packed out\n", w0, w1, t_up, t_gate - t_up, t_asm - t_gate,
-            t_msa - t_asm, t_geno - t_msa, t_pack - t_geno, t_down - t_pack, since() - t_down,
+    fprintf(stderr, "[microasm] t=%.1f host lane [%d, %d): enqueue-upload %.2f gate %.2f assemble %.2f msa %.2f genotype %.2f pack %.2f "
+            "download %.2f ms; %.1f MB in, %.2f MB packed out\n", wall_ms(), w0, w1, t_up, t_gate - t_up, t_asm - t_gate,
+            t_msa - t_asm, t_geno - t_msa, t_pack - t_geno, since() - t_pack,
             (static_cast<double>(f1 - f0) + 2.0 * static_cast<double>(b1 - b0) + 21.0 * nr) / 1e6, packed_bytes / 1e6);
   return MA_OK;
+}
+
+// The caller's part: the lane's landing area into the caller's arrays.
+void lane_deliver(const ma_params_t& p, HostJob const& job, int k, OutPtrs const& user) {
+  LaneResult const& R = job.res[k];
+  size_t const N = static_cast<size_t>(R.w1 - R.w0), W0 = R.w0;
+  if (N == 0) return;
+  std::vector<DenseDesc> const dense = dense_table(p);
+  for (size_t i = 0; i < dense.size(); ++i)
+    if (void* hp = user.at(dense[i].strct, dense[i].off))
+      std::memcpy(static_cast<u8*>(hp) + W0 * dense[i].win_bytes, R.land + R.dense_off[i], N * dense[i].win_bytes);
+  std::vector<SegDesc> const segs = seg_table(p);
+  PackArgs H{};
+  for (size_t i = 0; i < segs.size(); ++i) {
+    if (!((job.mask >> i) & 1u)) continue;
+    u8* hp = static_cast<u8*>(user.at(segs[i].strct, segs[i].off));  // (non-null: the mask is the caller's)
+    H.seg[H.nseg++] = PackSeg{hp + W0 * segs[i].win_stride, static_cast<u32>(segs[i].win_stride), static_cast<u32>(segs[i].unit),
+                              segs[i].kind};
+  }
+  // what says how much of a window is in use: the dense arrays, from the landing area (the caller may have left some out)
+  auto land_u32 = [&](int strct, size_t off) -> const u32* {
+    for (size_t i = 0; i < dense.size(); ++i)
+      if (dense[i].strct == strct && dense[i].off == off) return reinterpret_cast<const u32*>(R.land + R.dense_off[i]);
+    return nullptr;
+  };
+  H.win_status = land_u32(1, off_of(&ma_asm_out_t::win_status));
+  H.win_ncomp = land_u32(1, off_of(&ma_asm_out_t::win_ncomp));
+  H.comp_hap0 = land_u32(1, off_of(&ma_asm_out_t::comp_hap0));
+  H.comp_nhaps = land_u32(1, off_of(&ma_asm_out_t::comp_nhaps));
+  H.hap_len = land_u32(1, off_of(&ma_asm_out_t::hap_len));
+  H.hap_nruns = land_u32(1, off_of(&ma_asm_out_t::hap_nruns));
+  H.win_nvars = land_u32(2, off_of(&ma_var_out_t::win_nvars));
+  H.MC = p.max_comps; H.MH = p.max_haps; H.MV = p.max_vars; H.MA = p.max_alts; H.MP = p.max_allele_bytes;
+  unpack_records(H, reinterpret_cast<const u32*>(R.land + R.aux_off), R.land + R.packed_off, static_cast<int>(N));
 }
 
 int ensure_lanes(ma_ctx* ctx, int lanes) {
@@ -509,6 +763,109 @@ int ensure_lanes(ma_ctx* ctx, int lanes) {
     ctx->lanes.push_back(ch);
   }
   return MA_OK;
+}
+
+void lane_worker(ma_ctx* ch, LaneQueue* lq, int k) {
+  while (true) {
+    std::shared_ptr<HostJob> job;
+    {
+      std::unique_lock<std::mutex> lk(lq->mu);
+      lq->cv.wait(lk, [&] { return lq->stop || !lq->q.empty(); });
+      if (lq->q.empty()) return;  // stop, nothing left
+      job = lq->q.front();
+      lq->q.pop_front();
+    }
+    LaneResult& R = job->res[k];
+    R.rc = job->wb[k + 1] > job->wb[k] ? lane_compute(ch, *job, k) : MA_OK;
+    if (R.rc != MA_OK) {
+      R.err = ch->err;
+      (void)hipStreamSynchronize(ch->stream);  // whatever was queued before the error is done before the buffers are reused
+    }
+    {
+      std::lock_guard<std::mutex> lk(job->mu);
+      job->done++;
+    }
+    job->cv.notify_all();
+  }
+}
+
+int ensure_workers(ma_ctx* ctx, int lanes) {
+  MA_TRY_RC(ensure_lanes(ctx, lanes));
+  HostAsync* ha = async_of(ctx);
+  while (static_cast<int>(ha->lanes.size()) < lanes) {
+    int const k = static_cast<int>(ha->lanes.size());
+    ha->lanes.emplace_back(new LaneQueue());
+    LaneQueue* lq = ha->lanes.back().get();
+    lq->th = std::thread(lane_worker, ctx->lanes[k], lq, k);
+  }
+  return MA_OK;
+}
+
+void uploader_loop(ma_ctx* ctx, HostAsync* ha) {
+  (void)hipSetDevice(ctx->device);
+  while (true) {
+    std::shared_ptr<UploadTask> t;
+    {
+      std::unique_lock<std::mutex> lk(ha->up_mu);
+      ha->up_cv.wait(lk, [&] { return ha->up_stop || !ha->up_q.empty(); });
+      if (ha->up_q.empty()) return;
+      t = ha->up_q.front();
+      ha->up_q.pop_front();
+    }
+    int rc = MA_OK;
+    {
+      auto run = [&]() -> int {
+        MA_HIP(ctx, hipSetDevice(ctx->device));
+        return run_copy_ops(ctx, ctx->copy_stream, getenv("MA_UPLOAD_TWO_STREAMS") ? ctx->copy_stream2 : nullptr, t->ops, t->lane_end,
+                            [&](size_t g) {
+                              {
+                                std::lock_guard<std::mutex> lk(t->mu);
+                                t->lanes_done = g + 1;
+                              }
+                              t->cv.notify_all();
+                            });
+      };
+      rc = run();
+    }
+    {
+      std::lock_guard<std::mutex> lk(t->mu);
+      t->rc = rc;
+      if (rc != MA_OK) t->err = ctx->err;
+      t->done = true;
+    }
+    t->cv.notify_all();
+  }
+}
+
+// wait for every job that is queued or running (their results stay with the job until a call asks for them or drops them)
+void drain_host(ma_ctx* ctx) {
+  if (!ctx->host_async) return;
+  HostAsync* ha = static_cast<HostAsync*>(ctx->host_async);
+  for (auto& j : ha->jobs)
+    if (j) j->wait_all();
+  for (auto& u : ha->uploads)
+    if (u) u->wait();
+}
+
+void stop_workers(ma_ctx* ctx) {
+  if (!ctx->host_async) return;
+  HostAsync* ha = static_cast<HostAsync*>(ctx->host_async);
+  for (auto& lq : ha->lanes) {
+    {
+      std::lock_guard<std::mutex> lk(lq->mu);
+      lq->stop = true;
+    }
+    lq->cv.notify_all();
+    if (lq->th.joinable()) lq->th.join();
+  }
+  {
+    std::lock_guard<std::mutex> lk(ha->up_mu);
+    ha->up_stop = true;
+  }
+  ha->up_cv.notify_all();
+  if (ha->uploader.joinable()) ha->uploader.join();
+  delete ha;
+  ctx->host_async = nullptr;
 }
 
 int host_lanes(const ma_ctx* ctx, int n_windows) {
@@ -542,10 +899,44 @@ void forget_views(ma_ctx* ctx) {
   g_views.erase(ctx);
 }
 
+// queue the lanes' jobs of batch `b`, whose inputs are (being) staged in `set` when `ready`
+std::shared_ptr<HostJob> submit_host(ma_ctx* ctx, int lanes, const ma_batch_t* b, int set, std::shared_ptr<UploadTask> upload,
+                                     u32 mask, const ma_geno_out_t* taps) {
+  HostAsync* ha = async_of(ctx);
+  auto job = std::make_shared<HostJob>();
+  job->batch = *b;
+  job->b = &job->batch;
+  job->set = set;
+  job->lanes = lanes;
+  job->wb = lane_bounds(b->n_windows, lanes);
+  job->prm = ctx->prm;
+  job->timing = ctx->timing;
+  job->accumulate = ctx->accumulate;
+  job->collect = ctx->collect;
+  job->hbm_share = ctx->hbm_share / lanes;
+  job->mask = mask;
+  job->upload = upload;
+  if (upload) job->staged = views_of(ctx).d[set];
+  job->taps = taps;
+  job->res.resize(lanes);
+  for (int k = 0; k < lanes; ++k) {
+    LaneQueue* lq = ha->lanes[k].get();
+    {
+      std::lock_guard<std::mutex> lk(lq->mu);
+      lq->q.push_back(job);
+    }
+    lq->cv.notify_one();
+  }
+  return job;
+}
+
 int process_host(ma_ctx* ctx, int lanes, const ma_batch_t* b, const ma_gate_out_t* g, const ma_asm_out_t* a,
                  const ma_var_out_t* v, const ma_geno_out_t* q) {
-  MA_TRY_RC(ensure_lanes(ctx, lanes));
-  std::vector<int> const wb = lane_bounds(b->n_windows, lanes);
+  MA_TRY_RC(ensure_workers(ctx, lanes));
+  HostAsync* ha = async_of(ctx);
+  OutPtrs const user{{g, a, v, q}};
+  u32 const mask = seg_mask_of(ctx->prm, user);
+  bool const taps = wants_taps(q);
   // did ma_prefetch_batch upload this batch?  (the oldest set that holds it); otherwise any set that holds nothing
   int set = -1;
   bool prefetched = false;
@@ -558,35 +949,54 @@ int process_host(ma_ctx* ctx, int lanes, const ma_batch_t* b, const ma_gate_out_
   if (set < 0) {
     set = !ctx->pf_batch[0] ? 0 : (!ctx->pf_batch[1] ? 1 : (ctx->pf_seq[0] < ctx->pf_seq[1] ? 0 : 1));
     if (ctx->pf_batch[set]) {  // both sets hold batches that were never processed: give the older one up
-      MA_HIP(ctx, hipStreamSynchronize(ctx->copy_stream));
+      if (ha->jobs[set]) ha->jobs[set]->wait_all();
+      ha->jobs[set].reset();
+      if (ha->uploads[set]) ha->uploads[set]->wait();
+      ha->uploads[set].reset();
       ctx->pf_batch[set] = nullptr;
     }
   }
-  PrefetchViews& pv = views_of(ctx);
-  std::vector<int> rc(lanes, MA_OK);
-  std::vector<std::thread> th;
-  for (int k = 0; k < lanes; ++k) {
-    ma_ctx* ch = ctx->lanes[k];
-    ch->prm = ctx->prm;
-    ch->timing = ctx->timing;
-    ch->accumulate = ctx->accumulate;
-    ch->collect = ctx->collect;
-    if (!ch->accumulate) ch->timers_used = 0;
-    ch->hbm_share = ctx->hbm_share / lanes;
-    hipEvent_t const ready = prefetched ? ctx->pf_ev[set] : nullptr;
-    const DBatch* staged = prefetched ? &pv.d[set][k] : nullptr;
-    th.emplace_back([&, k, ch, ready, staged]() {
-      rc[k] = wb[k + 1] > wb[k] ? run_lane_host(ch, b, wb[k], wb[k + 1], g, a, v, q, set, ready, staged) : MA_OK;
-    });
+  std::shared_ptr<HostJob> job = ha->jobs[set];
+  if (job && (job->mask != mask || taps || std::memcmp(&job->prm, &ctx->prm, sizeof(ma_params_t)) != 0 ||
+              job->timing != ctx->timing || job->accumulate != ctx->accumulate || job->collect != ctx->collect)) {
+    job->wait_all();  // queued ahead under other assumptions than this call's: computed again below, from the staged inputs
+    job.reset();
   }
-  for (auto& t : th) t.join();
-  ctx->pf_batch[set] = nullptr;  // consumed (or used as plain staging): free for the next prefetch
-  for (int k = 0; k < lanes; ++k)
-    if (rc[k] != MA_OK) {
-      ctx->err = "lane " + std::to_string(k) + ": " + ctx->lanes[k]->err;
-      return rc[k];
+  if (!prefetched) ha->uploads[set].reset();
+  if (!job) job = submit_host(ctx, lanes, b, set, prefetched ? ha->uploads[set] : nullptr, mask, taps ? q : nullptr);
+  ha->jobs[set] = job;
+  ha->last_mask = mask;
+  ha->have_mask = true;
+  job->wait_all();
+  if (!ctx->accumulate) ha->times.clear();
+  int rc = MA_OK;
+  for (int k = 0; k < lanes; ++k) {
+    LaneResult const& R = job->res[k];
+    if (R.rc != MA_OK && rc == MA_OK) {
+      ctx->err = "lane " + std::to_string(k) + ": " + R.err;
+      rc = R.rc;
     }
-  return MA_OK;
+    ha->times.insert(ha->times.end(), R.times.begin(), R.times.end());
+    for (int x = 0; x < 8; ++x) ctx->stats[x] += R.stats[x];
+  }
+  if (rc == MA_OK) {
+    bool const verbose = getenv("MA_VERBOSE") != nullptr;
+    auto const t0 = std::chrono::steady_clock::now();
+    if (lanes > 1) {  // (one scatter thread per lane: ~0.7 ms each, side by side)
+      std::vector<std::thread> th;
+      for (int k = 0; k < lanes; ++k) th.emplace_back([&, k]() { lane_deliver(ctx->prm, *job, k, user); });
+      for (auto& t : th) t.join();
+    } else {
+      lane_deliver(ctx->prm, *job, 0, user);
+    }
+    if (verbose)
+      fprintf(stderr, "[microasm] t=%.1f host route: records of %d windows scattered in %.2f ms\n", wall_ms(), b->n_windows,
+              std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+  }
+  ha->jobs[set].reset();
+  ha->uploads[set].reset();
+  ctx->pf_batch[set] = nullptr;  // consumed (or used as plain staging): free for the next prefetch
+  return rc;
 }
 
 }  // namespace
@@ -635,6 +1045,7 @@ int ma_create(const ma_params_t* prm, int device, int memspace, ma_ctx_t** out) 
 
 void ma_destroy(ma_ctx_t* ctx) {
   if (!ctx) return;
+  stop_workers(ctx);  // (the lanes' threads finish what is queued, then end)
   forget_views(ctx);
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
@@ -643,12 +1054,15 @@ void ma_destroy(ma_ctx_t* ctx) {
   ctx->ws_build.release(); ctx->ws_nodes.release(); ctx->ws_clean.release();
   ctx->ws_poa.release(); ctx->ws_aln.release(); ctx->ws_misc.release(); ctx->ws_cx.release(); ctx->ws_gen.release(); ctx->dev_stats.release();
   ctx->pack_aux.release(); ctx->pack_buf.release();
-  if (ctx->pin) (void)hipHostFree(ctx->pin);
-  ctx->pin = nullptr;
-  if (ctx->copy_stream) {
-    (void)hipStreamSynchronize(ctx->copy_stream);
-    (void)hipStreamDestroy(ctx->copy_stream);
+  for (auto& pp : ctx->pin) {
+    if (pp) (void)hipHostFree(pp);
+    pp = nullptr;
   }
+  for (hipStream_t cs : {ctx->copy_stream, ctx->copy_stream2})
+    if (cs) {
+      (void)hipStreamSynchronize(cs);
+      (void)hipStreamDestroy(cs);
+    }
   for (auto& e : ctx->pf_ev)
     if (e) (void)hipEventDestroy(e);
   for (auto& st : ctx->in_sets)
@@ -692,6 +1106,8 @@ int ma_synchronize(ma_ctx_t* ctx) {
 
 int ma_timing_control(ma_ctx_t* ctx, int mode) {
   if (!ctx) return MA_ERR_ARG;
+  drain_host(ctx);  // (the lanes' timers and counters are theirs while a job runs)
+  if (ctx->host_async) static_cast<HostAsync*>(ctx->host_async)->times.clear();
   ctx->timing = mode != 0;
   ctx->accumulate = mode >= 2;
   ctx->collect = mode == 3;
@@ -710,6 +1126,7 @@ int ma_set_streams(ma_ctx_t* ctx, int n) {
 
 int ma_last_stats(ma_ctx_t* ctx, unsigned long long* out, int cap) {
   if (!ctx || !out) return MA_ERR_ARG;
+  drain_host(ctx);
   int n = 0;
   for (; n < cap && n < 8; ++n) {
     out[n] = ctx->stats[n];
@@ -745,6 +1162,14 @@ int ma_last_kernel_times(ma_ctx_t* ctx, const char** names, float* ms, int cap) 
     (void)hipEventElapsedTime(&t, ctx->timers[i].beg, ctx->timers[i].end);
     ms[n] = t;
   }
+  if (ctx->host_async) {  // host route: the lanes' timers were resolved into the jobs that ma_process_batch delivered
+    for (auto const& t : static_cast<HostAsync*>(ctx->host_async)->times) {
+      if (n >= cap) break;
+      names[n] = t.first;
+      ms[n++] = t.second;
+    }
+    return n;
+  }
   for (ma_ctx* ch : ctx->lanes) {  // kernels launched on the child lanes of ma_process_batch
     for (size_t i = 0; i < ch->timers_used && n < cap; ++i, ++n) {
       names[n] = ch->timers[i].name;
@@ -761,7 +1186,8 @@ int ma_last_kernel_times(ma_ctx_t* ctx, const char** names, float* ms, int cap) 
   MA_HIP(ctx, hipSetDevice((ctx)->device));             \
   if (!(ctx)->accumulate) {                             \
     (ctx)->timers_used = 0;                             \
-    for (ma_ctx* _ch : (ctx)->lanes) _ch->timers_used = 0; \
+    if (!(ctx)->host_async)                             \
+      for (ma_ctx* _ch : (ctx)->lanes) _ch->timers_used = 0; \
   }
 
 #define MA_TRY(expr)          \
@@ -869,26 +1295,44 @@ int ma_prefetch_batch(ma_ctx_t* ctx, const ma_batch_t* next) {
   int const set = !ctx->pf_batch[0] ? 0 : (!ctx->pf_batch[1] ? 1 : -1);
   if (set < 0) return MA_OK;  // two batches are waiting already
   if (!ctx->copy_stream) MA_HIP(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
-  if (!ctx->pf_ev[set]) MA_HIP(ctx, hipEventCreateWithFlags(&ctx->pf_ev[set], hipEventDisableTiming));
+  if (!ctx->copy_stream2) MA_HIP(ctx, hipStreamCreateWithFlags(&ctx->copy_stream2, hipStreamNonBlocking));
   int const lanes = host_lanes(ctx, next->n_windows);
-  MA_TRY_RC(ensure_lanes(ctx, lanes));
+  MA_TRY_RC(ensure_workers(ctx, lanes));
+  HostAsync* ha = async_of(ctx);
   std::vector<int> const wb = lane_bounds(next->n_windows, lanes);
   PrefetchViews& pv = views_of(ctx);
   pv.d[set].assign(lanes, DBatch{});
+  auto task = std::make_shared<UploadTask>();
   for (int k = 0; k < lanes; ++k) {
-    if (wb[k + 1] <= wb[k]) continue;
-    int const rc = stage_lane_inputs(ctx->lanes[k], set, next, wb[k], wb[k + 1], ctx->copy_stream, &pv.d[set][k]);
+    if (wb[k + 1] <= wb[k]) {
+      task->lane_end.push_back(task->ops.size());
+      continue;
+    }
+    int const rc = stage_lane_inputs(ctx->lanes[k], set, next, wb[k], wb[k + 1], &task->ops, &pv.d[set][k]);
     if (rc != MA_OK) {
       ctx->err = "prefetch, lane " + std::to_string(k) + ": " + ctx->lanes[k]->err;
       return rc;
     }
+    task->lane_end.push_back(task->ops.size());
   }
-  MA_HIP(ctx, hipEventRecord(ctx->pf_ev[set], ctx->copy_stream));
+  // the copies themselves are the uploader thread's: piece by piece, so that the copy engine's queue stays short
+  if (!ha->uploader.joinable()) ha->uploader = std::thread(uploader_loop, ctx, ha);
+  {
+    std::lock_guard<std::mutex> lk(ha->up_mu);
+    ha->up_q.push_back(task);
+  }
+  ha->up_cv.notify_one();
+  ha->uploads[set] = task;
   ctx->pf_batch[set] = next;
   ctx->pf_sig[set][0] = next->n_windows;
   ctx->pf_sig[set][1] = next->n_reads;
   ctx->pf_sig[set][2] = lanes;
   ctx->pf_seq[set] = ++ctx->pf_counter;
+  // ... and its compute jobs behind whatever the lanes are doing: the call that brings the batch will find the records
+  // waiting (or on their way).  Not in the statistics-gathering mode of the bench (its device counters are per call).
+  ha->jobs[set].reset();
+  if (ha->have_mask && !ctx->collect && !getenv("MA_NO_RUNAHEAD"))
+    ha->jobs[set] = submit_host(ctx, lanes, next, set, task, ha->last_mask, nullptr);
   return MA_OK;
 }
 

@@ -99,8 +99,11 @@ struct ma_ctx {
   hipEvent_t sync_ev = nullptr;  // blocking-sync event: host threads sleep instead of spinning while the stream drains
   // host route (MA_MEM_HOST) of ma_process_batch, per lane: packed result records (pack.hip) and their pinned landing area
   ma::DevBuf pack_aux, pack_buf;
-  void* pin = nullptr;
-  size_t pin_cap = 0;
+  void* pin[2] = {nullptr, nullptr};      // one landing area per input set: a batch's records are read by the caller's
+  size_t pin_cap[2] = {0, 0};             // thread while the lane already computes the next batch
+  size_t last_packed = 0;                 // (lane) bytes of packed records of the lane's last batch: sizes the next landing area
+  void* host_async = nullptr;             // (parent) worker threads + jobs of the host route (api.hip: HostAsync)
+  hipStream_t copy_stream2 = nullptr;     // the pieces of an upload alternate between the two copy streams (api.hip: run_copy_ops)
   ma::InputSet in_sets[2];       // (lane) input staging, double buffered
   // (parent) ma_prefetch_batch: which batch each set of the lanes holds (null: free), in which order they were filled,
   // the event behind the set's uploads, and the stream the uploads of a prefetch run on

@@ -32,8 +32,24 @@ struct PackArgs {
   PackSeg seg[24];
 };
 
+// whole-array copies of k_pack_dense (sizes in bytes, multiples of 4)
+struct DenseCopy {
+  const void* src;
+  void* dst;
+  u32 bytes;
+};
+struct DenseCopies {
+  DenseCopy c[20];
+  u32 n;
+};
+
+// The landing area is pinned HOST memory that the kernels write themselves (the records cross PCIe as the stores of
+// k_pack_copy / k_pack_dense): no copy commands, and one wait for the whole of a lane's results.
 // aux_dev: [2 n + 1] u32 -- per window {record offset in 4-byte words, allele pool bytes in use}, then the total words
-int launch_pack(ma_ctx* ctx, PackArgs const& A, int n, u32* aux_dev, u8** packed_dev, size_t* packed_bytes);
+int launch_pack_sizes(ma_ctx* ctx, PackArgs const& A, int n, u32* aux_dev);
+int launch_pack_dense(ma_ctx* ctx, DenseCopies const& C);
+// records to `out` if they fit in cap_bytes (aux[2 n] * 4 <= cap_bytes: the caller checks the total afterwards)
+int launch_pack_records(ma_ctx* ctx, PackArgs const& A, int n, const u32* aux_dev, u8* out, size_t cap_bytes);
 void unpack_records(PackArgs const& H, const u32* aux, const u8* packed, int n);
 
 }  // namespace ma

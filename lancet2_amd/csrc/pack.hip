@@ -3,6 +3,7 @@
 // them whole was a third of a host batch.  Here the used prefix of every array's window slice is gathered into one packed
 // record per window (k_pack_size -> scan -> k_pack_copy), the records cross PCIe in one copy, and the host scatters them into
 // the caller's arrays (unpack_records).  Bytes the engine never wrote are not transferred, and stay untouched on the host.
+#include <algorithm>
 #include <cstring>
 
 #include "ma_internal.h"
@@ -101,9 +102,10 @@ __device__ __forceinline__ void copy_bytes(u8* dst, const u8* src, u32 bytes, in
   }
 }
 
-__global__ __launch_bounds__(256) void k_pack_copy(PackArgs A, const u32* aux, u8* out, int n) {
+__global__ __launch_bounds__(256) void k_pack_copy(PackArgs A, const u32* aux, u8* out, int n, u32 cap_words) {
   int const w = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (w >= n) return;
+  if (aux[2 * n] > cap_words) return;  // the landing area is too small: the host sees the total, grows it and asks again
   WinUse const u = window_use(A, w);
   u8* dst = out + static_cast<size_t>(aux[2 * w]) * 4u;
   for (u32 s = 0; s < A.nseg; ++s) {
@@ -124,19 +126,33 @@ __global__ __launch_bounds__(256) void k_pack_copy(PackArgs A, const u32* aux, u
   }
 }
 
+// whole arrays (the small per-window ones, and aux itself) into the landing area: 4-byte words, one workgroup row per array
+__global__ __launch_bounds__(256) void k_pack_dense(DenseCopies C) {
+  DenseCopy const& c = C.c[blockIdx.y];
+  u32 const words = c.bytes / 4u;
+  const u32* src = reinterpret_cast<const u32*>(c.src);
+  u32* dst = reinterpret_cast<u32*>(c.dst);
+  for (u32 i = blockIdx.x * 256 + threadIdx.x; i < words; i += gridDim.x * 256) dst[i] = src[i];
+}
+
 }  // namespace
 
-int launch_pack(ma_ctx* ctx, PackArgs const& A, int n, u32* aux_dev, u8** packed_dev, size_t* packed_bytes) {
+int launch_pack_sizes(ma_ctx* ctx, PackArgs const& A, int n, u32* aux_dev) {
   hipLaunchKernelGGL(k_pack_size, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, A, aux_dev, n);
   hipLaunchKernelGGL(k_pack_scan, dim3(1), dim3(1024), 0, ctx->stream, aux_dev, n);
-  u32 total_words = 0;
-  MA_HIP(ctx, hipMemcpyAsync(&total_words, aux_dev + 2 * static_cast<size_t>(n), 4, hipMemcpyDeviceToHost, ctx->stream));
-  MA_HIP(ctx, ma_stream_sync(ctx));
-  size_t const bytes = static_cast<size_t>(total_words) * 4u;
-  MA_HIP(ctx, ctx->pack_buf.reserve(bytes + 256));
-  *packed_dev = ctx->pack_buf.as<u8>();
-  *packed_bytes = bytes;
-  if (bytes) hipLaunchKernelGGL(k_pack_copy, dim3((n + 3) / 4), dim3(256), 0, ctx->stream, A, aux_dev, *packed_dev, n);
+  MA_HIP(ctx, hipGetLastError());
+  return MA_OK;
+}
+
+int launch_pack_dense(ma_ctx* ctx, DenseCopies const& C) {
+  if (C.n) hipLaunchKernelGGL(k_pack_dense, dim3(64, C.n), dim3(256), 0, ctx->stream, C);
+  MA_HIP(ctx, hipGetLastError());
+  return MA_OK;
+}
+
+int launch_pack_records(ma_ctx* ctx, PackArgs const& A, int n, const u32* aux_dev, u8* out, size_t cap_bytes) {
+  u32 const cap_words = static_cast<u32>(std::min<size_t>(cap_bytes / 4u, 0xFFFFFFFFu));
+  hipLaunchKernelGGL(k_pack_copy, dim3((n + 3) / 4), dim3(256), 0, ctx->stream, A, aux_dev, out, n, cap_words);
   MA_HIP(ctx, hipGetLastError());
   return MA_OK;
 }

@@ -934,6 +934,79 @@ def test_prefetched_batches_give_the_same_results():
         eng.close()
 
 
+def test_jobs_queued_ahead_follow_the_call_that_collects_them():
+    """The host route queues a prefetched batch's compute jobs behind the running ones (the lanes are persistent worker
+    threads), assuming the call that brings the batch asks for what the last call asked for.  When it does not -- other
+    optional outputs, the per-read debug taps, kernel timing switched in between -- the queued results are dropped and the
+    batch is computed in the call.  Outputs the caller leaves out stay untouched; counters and kernel timers are per call."""
+    from lancet2_amd.engine import Engine
+    params = capi.default_params(min_k=25, max_k=25)
+    batches = [synth.make_config_batch("C2", 6, first_index=9700), synth.make_config_batch("C3", 4, first_index=9800)]
+    eng = Engine(params)
+    try:
+        want = [eng.process(a_, n_, nr_, debug=True) for a_, n_, nr_ in batches]
+    finally:
+        eng.close()
+    structs = [capi.make_batch_struct(a_, n_, nr_) for a_, n_, nr_ in batches]
+
+    def run(eng, i, leave_out=(), debug=False):
+        arrs, n, nr = batches[i]
+        outs = [capi.alloc_host(capi.gate_out_spec(n)), capi.alloc_host(capi.asm_out_spec(params, n)),
+                capi.alloc_host(capi.var_out_spec(params, n)), capi.alloc_host(capi.geno_out_spec(params, n, nr, debug))]
+        for d_ in outs:
+            for k_ in leave_out:
+                if k_ in d_:
+                    d_[k_].view(np.uint8)[...] = 0x5A
+        kept = [{k_: v_ for k_, v_ in d_.items() if k_ not in leave_out} for d_ in outs]
+        eng.process_device(structs[i], capi.fill_struct(capi.GateOut, kept[0]), capi.fill_struct(capi.AsmOut, kept[1]),
+                           capi.fill_struct(capi.VarOut, kept[2]), capi.fill_struct(capi.GenoOut, kept[3]))
+        g, a, v, q = outs
+        wg, wa, wv, wq = want[i]
+        assert np.array_equal(g["max_approx"], wg["max_approx"]) and np.array_equal(g["max_exact"], wg["max_exact"])
+        for k_ in leave_out:  # nothing was written where the caller passed no array
+            for d_ in outs:
+                if k_ in d_:
+                    assert (d_[k_].view(np.uint8) == 0x5A).all(), k_
+        if not leave_out:
+            bad = compare_asm(params, a, wa, n) + compare_vars(params, v, wv, n)
+            if debug:
+                bad += compare_geno(params, q, wq, n, nr, wv["win_nvars"], arrs["read_win_off"])
+            assert not bad, (i, bad[:6])
+        else:
+            assert np.array_equal(a["win_status"], wa["win_status"]) and np.array_equal(v["win_nvars"], wv["win_nvars"])
+        assert np.array_equal(q["allele_counts"], wq["allele_counts"])
+        assert np.array_equal(q["var_qual"].view(np.uint64), wq["var_qual"].view(np.uint64))
+
+    eng = Engine(params)
+    try:
+        eng.timing_control(1)
+        run(eng, 0)                                   # the first call says what callers ask for
+        t0 = dict(eng.kernel_times())
+        assert t0.get("k_clean", 0) > 0 and t0.get("k_vote", 0) > 0
+        eng.prefetch(structs[1])                      # queued ahead, full outputs
+        run(eng, 1, leave_out=("var_pl", "var_gq", "hap_runs", "comp_cxf", "alt_type"))   # ... but the call wants fewer
+        eng.prefetch(structs[0])                      # queued ahead with the reduced set
+        run(eng, 0)                                   # ... the call wants everything again
+        eng.prefetch(structs[1])
+        run(eng, 1, debug=True)                       # the per-read taps are never computed ahead
+        eng.prefetch(structs[0])
+        eng.timing_control(0)                         # switched while a job is queued: waits for it, the job is then dropped
+        run(eng, 0)
+        assert eng.kernel_times() == []
+        eng.prefetch(structs[1])
+        eng.prefetch(structs[0])
+        run(eng, 1)
+        run(eng, 0)                                   # two jobs queued ahead, collected in order
+        eng.timing_control(1)
+        eng.prefetch(structs[1])
+        run(eng, 1)
+        t1 = dict(eng.kernel_times())                 # the timers of THIS call's batch, not of whatever runs next
+        assert t1.get("k_clean", 0) > 0
+        assert eng.stats()["pairs"] > 0
+    finally:
+        eng.close()
+
+
 def test_device_buffers_need_no_padding_or_alignment():
     """MA_MEM_DEVICE passes the caller's pointers through: the byte arrays (reference, read bases, qualities) sized
     exactly -- without the 64 bytes of padding the host route adds --, at odd addresses, with junk on both sides, give the
