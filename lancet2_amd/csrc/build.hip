@@ -246,9 +246,38 @@ __device__ __forceinline__ bool same_group(const DBatch& b, u32 ra, u32 rb) {
 //     of 64 consecutive reads (one read per lane: the f64 Phred prefix sums are a serial chain per read).
 //     The tile's bases and qualities are contiguous in the batch, so they are staged in LDS with coalesced
 //     loads -- a lane walking its read byte by byte straight from HBM costs one cache-line fetch per byte
-//     once thousands of lanes do it (measured: ~180x read amplification).  Instances that need the general
-//     path are remembered in a per-lane bitmask and appended to the window's slow queue at the end with
-//     one atomic per wave, so that k_insert can hash them with full lanes.
+//     once thousands of lanes do it (measured: ~180x read amplification).  The lane's loop takes FOUR k-mer
+//     positions per trip with every LDS load of the trip unconditional (indices clamped instead of guarded): the 24
+//     byte loads go out together, then the 8 Phred look-ups, and only the sums and the mismatch count run as a
+//     chain.  (One position per trip with guarded loads was 16 dependent LDS round trips per four positions: the
+//     compiler cannot hoist a load out of a branch.)  Instances that need the general path are remembered in a
+//     per-lane bitmask and appended to the window's slow queue at the end with one atomic per wave, so that
+//     k_insert can hash them with full lanes.
+#ifdef MA_PROFILE
+__device__ unsigned long long g_iprof[16];
+#define IPROF_T0() unsigned long long _t0 = __builtin_amdgcn_s_memtime()
+#define IPROF(slot)                                                            \
+  do {                                                                         \
+    __syncthreads();                                                           \
+    unsigned long long _t1 = __builtin_amdgcn_s_memtime();                     \
+    if (threadIdx.x == 0) atomicAdd(&g_iprof[slot], _t1 - _t0);                \
+    _t0 = _t1;                                                                 \
+  } while (0)
+#else
+#define IPROF_T0() do {} while (0)
+#define IPROF(slot) do {} while (0)
+#endif
+#ifdef MA_PROFILE
+#define KPROF(slot)                                                            \
+  do {                                                                         \
+    unsigned long long _t1 = __builtin_amdgcn_s_memtime();                     \
+    if (threadIdx.x == 0) atomicAdd(&g_iprof[slot], _t1 - _t0);                \
+    _t0 = _t1;                                                                 \
+  } while (0)
+#else
+#define KPROF(slot) do {} while (0)
+#endif
+constexpr u32 classify_mask_words(u32 max_read_len) { return (max_read_len + 31) / 32 + 1; }  // per read: slow-instance bits
 __global__ __launch_bounds__(64) void k_classify(DBatch b, GraphWs ws, u32* max_slow, u32 tiles_per_win, u32 tile_cap) {
   extern __shared__ unsigned char lds_build[];
   int const a = blockIdx.x / tiles_per_win;
@@ -259,17 +288,19 @@ __global__ __launch_bounds__(64) void k_classify(DBatch b, GraphWs ws, u32* max_
   u32 const ns = seq_count(b, w);
   u32 const nreads = ns - 1;
   if (tile * 64 >= nreads) return;
+  IPROF_T0();
   u32 const cnt = min(64u, nreads - tile * 64);
   u32* inst_slot = ws.inst_slot + static_cast<size_t>(a) * ws.inst_stride;
   u32* slowq = ws.slowq + static_cast<size_t>(a) * ws.inst_stride;
   u32 const base_idx = b.read_win_off[w] + w;
   // LDS carve
   u32 const ref_cap = (ws.max_ref_len + 8 + 15) & ~15u;
+  u32 const MW = classify_mask_words(ws.max_read_len);
   u8* l_ref = lds_build;
   f64* l_phred = reinterpret_cast<f64*>(lds_build + ref_cap);
   u8* l_bases = lds_build + ref_cap + 2048;
   u8* l_quals = l_bases + tile_cap;
-  u32* l_mask = reinterpret_cast<u32*>(l_quals + tile_cap);  // [kMaskWords][64]
+  u32* l_mask = reinterpret_cast<u32*>(l_quals + tile_cap);  // [64][MW] bit o of read (lane): instance o is slow
   SeqInfo const rsi = seq_info(b, w, 0, k);
   i32 const ref_len = static_cast<i32>(rsi.len);
   {
@@ -279,44 +310,48 @@ __global__ __launch_bounds__(64) void k_classify(DBatch b, GraphWs ws, u32* max_
   for (u32 i = lane; i < 256; i += 64) reinterpret_cast<u64*>(l_phred)[i] = c_phred_bits[i];
   u32 const r0 = b.read_win_off[w] + tile * 64;
   u64 const byte0 = b.read_off[r0], byte1 = b.read_off[r0 + cnt];
-  u64 const al0 = byte0 & ~static_cast<u64>(3);
+  u64 const al0 = byte0 & ~static_cast<u64>(15);
   u64 const total_end = b.read_off[b.n_reads];
   {
-    // 4-byte aligned coalesced copy; the last word is read byte-wise if it would cross the end of the batch
-    u64 const nwords = (byte1 - al0 + 3) >> 2;
-    // four words per lane in flight (one word per trip made this copy 36 % of the kernel: 37 dependent round trips)
+    // coalesced copy in 16-byte words, four per lane and array in flight (one 4-byte word per trip made this copy 36 %
+    // of the kernel, four of them still a third: ~19 dependent round trips to HBM); the last word is read byte-wise if
+    // it would cross the end of the batch
+    u64 const nwords = (byte1 - al0 + 15) >> 4;
     constexpr int kSU = 4;
     for (u64 x0 = lane; x0 < nwords; x0 += 64 * kSU) {
-      u32 vb[kSU], vq[kSU];
+      uint4 vb[kSU], vq[kSU];
 #pragma unroll
       for (int u = 0; u < kSU; ++u) {
-        u64 const x = x0 + 64 * u, at = al0 + 4 * x;
-        vb[u] = vq[u] = 0;
+        u64 const x = x0 + 64 * u, at = al0 + 16 * x;
+        vb[u] = vq[u] = make_uint4(0, 0, 0, 0);
         if (x < nwords) {
-          if (at + 4 <= total_end) {
-            vb[u] = *reinterpret_cast<const u32*>(b.read_bases + at);
-            vq[u] = *reinterpret_cast<const u32*>(b.read_quals + at);
+          if (at + 16 <= total_end) {
+            vb[u] = *reinterpret_cast<const uint4*>(b.read_bases + at);
+            vq[u] = *reinterpret_cast<const uint4*>(b.read_quals + at);
           } else {
+            u32 tb[4] = {0, 0, 0, 0}, tq[4] = {0, 0, 0, 0};
             for (u64 y = 0; at + y < total_end; ++y) {
-              vb[u] |= static_cast<u32>(b.read_bases[at + y]) << (8 * y);
-              vq[u] |= static_cast<u32>(b.read_quals[at + y]) << (8 * y);
+              tb[y >> 2] |= static_cast<u32>(b.read_bases[at + y]) << (8 * (y & 3));
+              tq[y >> 2] |= static_cast<u32>(b.read_quals[at + y]) << (8 * (y & 3));
             }
+            vb[u] = make_uint4(tb[0], tb[1], tb[2], tb[3]);
+            vq[u] = make_uint4(tq[0], tq[1], tq[2], tq[3]);
           }
         }
       }
 #pragma unroll
       for (int u = 0; u < kSU; ++u) {
         u64 const x = x0 + 64 * u;
-        if (x < nwords && 4 * x + 4 <= tile_cap) {
-          reinterpret_cast<u32*>(l_bases)[x] = vb[u];
-          reinterpret_cast<u32*>(l_quals)[x] = vq[u];
+        if (x < nwords && 16 * x + 16 <= tile_cap) {
+          reinterpret_cast<uint4*>(l_bases)[x] = vb[u];
+          reinterpret_cast<uint4*>(l_quals)[x] = vq[u];
         }
       }
     }
   }
-  for (int mw = 0; mw < kMaskWords; ++mw) l_mask[mw * 64 + lane] = 0;
   __syncthreads();
-  bool const hints = b.read_hint != nullptr && rsi.len <= ws.max_ref_len + 8;
+  KPROF(8);
+  bool const hints = b.read_hint != nullptr && rsi.len <= ws.max_ref_len + 8 && ref_len > 0;
   u32 nslow = 0;
   bool all_slow = false;
   u32 s_idx = 0, my_nk = 0;
@@ -335,40 +370,105 @@ __global__ __launch_bounds__(64) void k_classify(DBatch b, GraphWs ws, u32* max_
       i32 const hint = hints ? b.read_hint[r] : MA_NO_HINT;
       bool const use_hint = hint != MA_NO_HINT && hint > -100000 && hint < 100000 && si.nk <= 32u * kMaskWords;
       all_slow = !use_hint;
+      i32 const h0 = use_hint ? hint : 0;
+      u32 const last = si.len - 1, ku = static_cast<u32>(k), nk = si.nk;
+      i32 const rlast = ref_len > 0 ? ref_len - 1 : 0;
+      // does read base i equal the reference base at hint + i?  (loads unconditional, the range test on the result)
+      auto ref_at = [&](u32 i) -> u32 { return l_ref[min(max(h0 + static_cast<i32>(i), 0), rlast)]; };
+      auto in_ref = [&](u32 i) -> bool {
+        i32 const rp = h0 + static_cast<i32>(i);
+        return rp >= 0 && rp < ref_len;
+      };
       f64 lead = 0.0, lag = 0.0;  // prefix[o+k] and prefix[o] of graph.cpp:283-285
       i32 mm = 0;                 // mismatches of read[o, o+k) against ref[hint+o, ...)
-      for (int i = 0; i < k; ++i) {
-        f64 const pe = l_phred[q[i]];
-        lead = (i == 0) ? pe : lead + pe;
-        i32 const rp = hint + i;
-        mm += (use_hint && rp >= 0 && rp < ref_len && s[i] == l_ref[rp]) ? 0 : 1;
-      }
-      for (u32 o = 0; o < si.nk; ++o) {
-        // floor(prefix[o+k] - prefix[o]) == 0  <=>  difference < 1.0 (prefix is non-decreasing)
-        bool const errfree = (lead - lag) < 1.0;
-        u32 word = (errfree ? kInstErrFree : 0u) | (o + 1 == si.nk ? kInstLast : 0u);
-        if (use_hint && mm == 0) {  // FAST: byte-identical to the reference k-mer at hint + o
-          word |= static_cast<u32>(hint + static_cast<i32>(o)) | kInstFast;
-        } else {
-          word |= kInstSlotMask;  // slot filled in by k_insert
-          nslow++;
-          if (use_hint) l_mask[(o >> 5) * 64 + lane] |= 1u << (o & 31);
+      for (u32 i = 0; i < ku; i += 4) {
+        u32 qv[4], sv[4], rv[4];
+#pragma unroll
+        for (u32 j = 0; j < 4; ++j) {
+          u32 const x = min(i + j, last);
+          qv[j] = q[x];
+          sv[j] = s[x];
+          rv[j] = ref_at(x);
         }
-        inst_slot[ibase + o] = word;
-        if (o + 1 < si.nk) {
-          u8 const b_out = s[o], b_in = s[o + k];
-          f64 const pl = l_phred[q[o]];
-          lag = (o == 0) ? pl : lag + pl;
-          lead = lead + l_phred[q[o + k]];
-          if (use_hint) {
-            i32 const rp_out = hint + static_cast<i32>(o), rp_in = hint + static_cast<i32>(o) + k;
-            mm -= (rp_out >= 0 && rp_out < ref_len && b_out == l_ref[rp_out]) ? 0 : 1;
-            mm += (rp_in >= 0 && rp_in < ref_len && b_in == l_ref[rp_in]) ? 0 : 1;
+        f64 pv[4];
+#pragma unroll
+        for (u32 j = 0; j < 4; ++j) pv[j] = l_phred[qv[j]];
+#pragma unroll
+        for (u32 j = 0; j < 4; ++j) {
+          if (i + j < ku) {
+            lead = (i + j == 0) ? pv[j] : lead + pv[j];
+            mm += (use_hint && in_ref(i + j) && sv[j] == rv[j]) ? 0 : 1;
           }
+        }
+      }
+      u32* mw = l_mask + static_cast<u32>(lane) * MW;
+      u32 sacc = 0;
+      for (u32 o = 0; o < nk; o += 4) {
+        u32 qo[4], qi[4], so[4], si4[4], ro[4], ri[4];
+#pragma unroll
+        for (u32 j = 0; j < 4; ++j) {
+          u32 const xo = min(o + j, last), xi = min(o + j + ku, last);
+          qo[j] = q[xo];
+          qi[j] = q[xi];
+          so[j] = s[xo];
+          si4[j] = s[xi];
+          ro[j] = ref_at(xo);
+          ri[j] = ref_at(xi);
+        }
+        f64 pl[4], pi[4];
+#pragma unroll
+        for (u32 j = 0; j < 4; ++j) {
+          pl[j] = l_phred[qo[j]];
+          pi[j] = l_phred[qi[j]];
+        }
+        u32 wd[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (u32 j = 0; j < 4; ++j) {
+          u32 const oo = o + j;
+          if (oo < nk) {
+            // floor(prefix[o+k] - prefix[o]) == 0  <=>  difference < 1.0 (prefix is non-decreasing)
+            bool const errfree = (lead - lag) < 1.0;
+            u32 word = (errfree ? kInstErrFree : 0u) | (oo + 1 == nk ? kInstLast : 0u);
+            if (use_hint && mm == 0) {  // FAST: byte-identical to the reference k-mer at hint + o
+              word |= static_cast<u32>(hint + static_cast<i32>(oo)) | kInstFast;
+            } else {
+              word |= kInstSlotMask;  // slot filled in by k_insert
+              nslow++;
+              sacc |= 1u << (oo & 31u);
+            }
+            wd[j] = word;
+            if (oo + 1 < nk) {
+              lag = (oo == 0) ? pl[j] : lag + pl[j];
+              lead = lead + pi[j];
+              if (use_hint) {
+                mm -= (in_ref(oo) && so[j] == ro[j]) ? 0 : 1;
+                mm += (in_ref(oo + ku) && si4[j] == ri[j]) ? 0 : 1;
+              }
+            }
+          }
+        }
+        // the trip's four words in one store (a lane's words are consecutive; 64 lanes x 4 bytes per store instruction
+        // was 64 separate 4-byte writes)
+        if (o + 4 <= nk) {
+          u32* dst = inst_slot + ibase + o;
+          if ((reinterpret_cast<uintptr_t>(dst) & 15u) == 0) {
+            *reinterpret_cast<uint4*>(dst) = make_uint4(wd[0], wd[1], wd[2], wd[3]);
+          } else {
+            dst[0] = wd[0]; dst[1] = wd[1]; dst[2] = wd[2]; dst[3] = wd[3];
+          }
+        } else {
+#pragma unroll
+          for (u32 j = 0; j < 4; ++j)
+            if (o + j < nk) inst_slot[ibase + o + j] = wd[j];
+        }
+        if (((o + 4) & 31u) == 0 || o + 4 >= nk) {  // (o is a multiple of 4: a mask word fills up exactly at a trip's end)
+          mw[o >> 5] = sacc;
+          sacc = 0;
         }
       }
     }
   }
+  KPROF(9);
   // append this tile's slow instances to the window's queue: one atomic per wave
   u32 inc = nslow;
   for (int d = 1; d < 64; d <<= 1) {
@@ -387,16 +487,18 @@ __global__ __launch_bounds__(64) void k_classify(DBatch b, GraphWs ws, u32* max_
     if (all_slow) {
       for (u32 o = 0; o < my_nk; ++o) slowq[at++] = (s_idx << 12) | o;
     } else {
-      for (int mw = 0; mw < kMaskWords; ++mw) {
-        u32 m = l_mask[mw * 64 + lane];
+      u32 const* mw = l_mask + static_cast<u32>(lane) * MW;
+      for (u32 x = 0; 32 * x < my_nk; ++x) {
+        u32 m = mw[x];
         while (m) {
           u32 const bit = __ffs(m) - 1;
           m &= m - 1;
-          slowq[at++] = (s_idx << 12) | (mw * 32 + bit);
+          slowq[at++] = (s_idx << 12) | (x * 32 + bit);
         }
       }
     }
   }
+  KPROF(10);
 }
 
 // (2) k_insert: reference k-mers, then the slow queue -- one k-mer per lane, hashed from scratch (O(k)), so
@@ -522,20 +624,6 @@ constexpr u32 kSeqWords = 12288;      // the window's read bases as 4-bit codes 
 constexpr u32 kInstTemp = 1u << 26;   // instance word holds a map entry, not yet a table slot (slots are < 2^21);
                                       // gone from the final words, k_rank reuses the bit as kInstFirst
 constexpr u32 kInstDefer = 1u << 25;  // instance waits for the direct path
-#ifdef MA_PROFILE
-__device__ unsigned long long g_iprof[16];
-#define IPROF_T0() unsigned long long _t0 = __builtin_amdgcn_s_memtime()
-#define IPROF(slot)                                                            \
-  do {                                                                         \
-    __syncthreads();                                                           \
-    unsigned long long _t1 = __builtin_amdgcn_s_memtime();                     \
-    if (threadIdx.x == 0) atomicAdd(&g_iprof[slot], _t1 - _t0);                \
-    _t0 = _t1;                                                                 \
-  } while (0)
-#else
-#define IPROF_T0() do {} while (0)
-#define IPROF(slot) do {} while (0)
-#endif
 __global__ __launch_bounds__(kInsT) void k_insert(DBatch b, GraphWs ws) {
   __shared__ u64 l_key[kInsMap];
   __shared__ u32 l_min[kInsMap];  // smallest instance of the id; after pass 2: its table slot | bit 31 "also a reference k-mer"
@@ -1670,8 +1758,8 @@ int run_build_pass(ma_ctx* ctx, const DBatch& b, GraphWs& ws, u32* counters_dev,
   MA_HIP(ctx, hipMemsetAsync(counters_dev, 0, 4, ctx->stream));
   MA_HIP(ctx, hipMemsetAsync(ws.n_slow, 0, 4 * A, ctx->stream));
   u32 const tiles_per_win = std::max<u32>(1, (ws.max_reads + 63) / 64);
-  u32 const tile_cap = (64 * ws.max_read_len + 8 + 15) & ~15u;
-  size_t const lds_c = ((ws.max_ref_len + 8 + 15) & ~15u) + 2048 + 2ull * tile_cap + 4ull * kMaskWords * 64 + 64;
+  u32 const tile_cap = (64 * ws.max_read_len + 32 + 15) & ~15u;
+  size_t const lds_c = ((ws.max_ref_len + 8 + 15) & ~15u) + 2048 + 2ull * tile_cap + 4ull * 64 * classify_mask_words(ws.max_read_len) + 64;
   if (lds_c > 160 * 1024) {
     ctx->err = "ma_assemble_batch: reads too long for the LDS-staged classifier";
     return MA_ERR_PARAM;

@@ -19,4 +19,7 @@ names = ["init+stage", "ref k-mers", "slow pass 1", "table init", "pass 2 insert
 tot = sum(d[:7])
 print({k: round(v, 2) for k, v in eng.kernel_times() if k in ("k_classify", "k_insert")})
 print({n: f"{100.0 * v / tot:.1f}%" for n, v in zip(names, d)})
+cn = ["stage", "lane loop", "slow queue", "-"]
+ct = sum(d[8:12]) or 1
+print("k_classify", {n: f"{100.0 * v / ct:.1f}%" for n, v in zip(cn, d[8:12])}, "mean cycles(100MHz ticks) per tile:", ct / max(1, 2048 * 11))
 eng.close()
