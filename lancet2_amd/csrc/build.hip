@@ -666,21 +666,8 @@ __global__ __launch_bounds__(kInsT) void k_insert(DBatch b, GraphWs ws) {
     const u8* const batch_hi = b.read_bases + b.read_off[b.n_reads];
     u32 const nwords = static_cast<u32>((seq_bytes + 7u) / 8u);
     bool odd = false;
-    for (u32 wd = threadIdx.x; wd < nwords; wd += kInsT) {
-      // aligned 8-byte words; the first / last word of the BATCH may reach outside the caller's buffer (MA_MEM_DEVICE
-      // passes the caller's pointer through: no alignment or padding is promised) and is read byte by byte
-      const u8* const wp = seq_base + static_cast<size_t>(wd) * 8u;
-      uint2 v;
-      if (wp >= batch_lo && wp + 8 <= batch_hi) {
-        v = *reinterpret_cast<const uint2*>(wp);
-      } else {
-        u32 lo4 = 0, hi4 = 0;
-        for (int x = 0; x < 8; ++x) {
-          u32 const byte = (wp + x >= batch_lo && wp + x < batch_hi) ? wp[x] : 0u;
-          if (x < 4) lo4 |= byte << (8 * x); else hi4 |= byte << (8 * (x - 4));
-        }
-        v = make_uint2(lo4, hi4);
-      }
+    const u8* const first_read_byte = b.read_bases + b.read_off[b.read_win_off[w]];
+    auto encode_word = [&](u32 wd, uint2 v) {
       u32 pk = 0;
 #pragma unroll
       for (int x = 0; x < 8; ++x) {
@@ -688,10 +675,45 @@ __global__ __launch_bounds__(kInsT) void k_insert(DBatch b, GraphWs ws) {
         u32 const e = enc_base(static_cast<u8>(byte));
         // (anything but upper-case A/C/G/T/N: a lower-case base would come back from its code in upper case)
         odd = odd || (!(e < 4u ? dev_is_acgt_upper(byte) : byte == 'N') && static_cast<u64>(wd) * 8u + x < seq_bytes &&
-                      seq_base + static_cast<size_t>(wd) * 8u + x >= b.read_bases + b.read_off[b.read_win_off[w]]);
+                      seq_base + static_cast<size_t>(wd) * 8u + x >= first_read_byte);
         pk |= e << (4 * x);
       }
       l_seq[wd] = pk;
+    };
+    // aligned 8-byte words; the first / last word of the BATCH may reach outside the caller's buffer (MA_MEM_DEVICE
+    // passes the caller's pointer through: no alignment or padding is promised) and is read byte by byte.  Everywhere
+    // else (decided once for the window, not per word: a load inside a branch waits for the one before it) four words
+    // per thread are in flight.
+    bool const inside = seq_base >= batch_lo && seq_base + static_cast<size_t>(nwords) * 8u <= batch_hi;
+    if (inside) {
+      constexpr int kWU = 4;
+      for (u32 wd0 = threadIdx.x; wd0 < nwords; wd0 += kInsT * kWU) {
+        uint2 v[kWU];
+#pragma unroll
+        for (int u = 0; u < kWU; ++u) {
+          u32 const wd = min(wd0 + u * kInsT, nwords - 1);
+          v[u] = *reinterpret_cast<const uint2*>(seq_base + static_cast<size_t>(wd) * 8u);
+        }
+#pragma unroll
+        for (int u = 0; u < kWU; ++u)
+          if (wd0 + u * kInsT < nwords) encode_word(wd0 + u * kInsT, v[u]);
+      }
+    } else {
+      for (u32 wd = threadIdx.x; wd < nwords; wd += kInsT) {
+        const u8* const wp = seq_base + static_cast<size_t>(wd) * 8u;
+        uint2 v;
+        if (wp >= batch_lo && wp + 8 <= batch_hi) {
+          v = *reinterpret_cast<const uint2*>(wp);
+        } else {
+          u32 lo4 = 0, hi4 = 0;
+          for (int x = 0; x < 8; ++x) {
+            u32 const byte = (wp + x >= batch_lo && wp + x < batch_hi) ? wp[x] : 0u;
+            if (x < 4) lo4 |= byte << (8 * x); else hi4 |= byte << (8 * (x - 4));
+          }
+          v = make_uint2(lo4, hi4);
+        }
+        encode_word(wd, v);
+      }
     }
     if (odd) l_seq_ok = 0;  // a base that is not A/C/G/T/N: the codes would not give its byte back
     for (u32 sq = 1 + threadIdx.x; sq < ns_all; sq += kInsT) {  // sequence sq >= 1 is read read_win_off[w] + sq - 1
@@ -1458,20 +1480,13 @@ __global__ __launch_bounds__(kBT) void k_rank(DBatch b, GraphWs ws, u32 min_node
     for (int u = 0; u < kRU; ++u) {
       u32 const s = s0 + u * kBT;
       live[u] = s < tcap;
-      ky[u] = live[u] ? keys[s] : 0ull;
-      fi[u] = live[u] ? first[s] : 0u;
-    }
-#pragma unroll
-    for (int u = 0; u < kRU; ++u) {
-      u32 const s = s0 + u * kBT;
-      remove[u] = false;
-      if (!live[u]) continue;
-      slot_node[s] = kNoNode;
-      if (ky[u] == 0) continue;
+      u32 const sc = live[u] ? s : 0u;  // (every load of the trip unconditional: guarded loads go out one at a time)
+      ky[u] = keys[sc];
+      fi[u] = first[sc];
       u32 total = 0;
       bool any = false, all = true;
       for (int i = 0; i < S; ++i) {
-        u32 const c = cnt[static_cast<size_t>(s) * CW + i];
+        u32 const c = cnt[static_cast<size_t>(sc) * CW + i];
         total += c;
         any |= c > 0;
         all &= c <= 1;
@@ -1482,12 +1497,13 @@ __global__ __launch_bounds__(kBT) void k_rank(DBatch b, GraphWs ws, u32 min_node
     for (int u = 0; u < kRU; ++u) {
       u32 const s = s0 + u * kBT;
       if (!live[u]) continue;
+      slot_node[s] = kNoNode;
       if (ky[u] == 0)
         first[s] = 0xFFFFFFFFu;
       else if (remove[u])
         first[s] = fi[u] | 0x80000000u;
       else
-        inst_slot[fi[u]] |= kInstFirst;  // (one slot per instance: no other thread touches this word)
+        atomicOr(&inst_slot[fi[u]], kInstFirst);  // (one slot per instance: no other thread touches this word; no value to wait for)
     }
   }
   __syncthreads();
@@ -1504,19 +1520,34 @@ __global__ __launch_bounds__(kBT) void k_rank(DBatch b, GraphWs ws, u32 min_node
   u64 const win_read_off0 = b.read_off[b.read_win_off[w]];
   int const lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   u32 running = 0;
-  uint4 const none4 = make_uint4(kInstFast, kInstFast, kInstFast, kInstFast);
-  // (the next tile's words are in flight while this tile is scanned: the pass is a chain of load -> block scan otherwise)
-  uint4 nxt4 = 4 * threadIdx.x < ninst ? *reinterpret_cast<const uint4*>(inst_slot + 4 * threadIdx.x) : none4;
-  for (u32 tile0 = 0; tile0 < ninst; tile0 += 4 * kBT) {
-    u32 const ii0 = tile0 + 4 * threadIdx.x;
-    uint4 const v4 = nxt4;  // inst_stride is a multiple of 64 words
-    if (ii0 + 4 * kBT < ninst) nxt4 = *reinterpret_cast<const uint4*>(inst_slot + ii0 + 4 * kBT); else nxt4 = none4;
-    u32 const vv[4] = {v4.x, v4.y, v4.z, v4.w};
+  // 2a. the ranks: 16 consecutive instance words per thread and tile (four 16-byte loads, the next tile's in flight while
+  //     this one is scanned), block scan; a first instance only leaves its index in the window's node list here.  (Writing
+  //     the node's record on the spot -- sequence search, two dependent loads of read fields, the counters -- kept the
+  //     whole workgroup at the tile's barrier for three round trips to HBM, 76 tiles in a row.)
+  u32* node_inst = ws.scratch + nb * 32;  // [nc] instance index of node idx (clean-stage scratch: free during the build)
+  constexpr u32 kWT = 16;
+  u32 const last4 = ninst ? ((ninst - 1) & ~3u) : 0u;
+  auto load16 = [&](u32 ii0, uint4* v) {
+#pragma unroll
+    for (u32 q = 0; q < kWT / 4; ++q) v[q] = *reinterpret_cast<const uint4*>(inst_slot + min(ii0 + 4 * q, last4));  // (clamped: masked below)
+  };
+  uint4 nxt[kWT / 4];
+  load16(kWT * threadIdx.x, nxt);
+  for (u32 tile0 = 0; tile0 < ninst; tile0 += kWT * kBT) {
+    u32 const ii0 = tile0 + kWT * threadIdx.x;
+    uint4 cur[kWT / 4];
+#pragma unroll
+    for (u32 q = 0; q < kWT / 4; ++q) cur[q] = nxt[q];
+    if (tile0 + kWT * kBT < ninst) load16(ii0 + kWT * kBT, nxt);
     u32 fmask = 0;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      u32 const ii = ii0 + j, v = vv[j];
-      if (ii < ninst && !(v & kInstFast) && (v & kInstFirst)) fmask |= 1u << j;
+    for (u32 q = 0; q < kWT / 4; ++q) {
+      u32 const vv[4] = {cur[q].x, cur[q].y, cur[q].z, cur[q].w};
+#pragma unroll
+      for (u32 j2 = 0; j2 < 4; ++j2) {
+        u32 const ii = ii0 + 4 * q + j2, v = vv[j2];
+        if (ii < ninst && !(v & kInstFast) && (v & kInstFirst)) fmask |= 1u << (4 * q + j2);
+      }
     }
     u32 const mine = __popc(fmask);
     u32 inc = mine;
@@ -1535,32 +1566,38 @@ __global__ __launch_bounds__(kBT) void k_rank(DBatch b, GraphWs ws, u32 min_node
     __syncthreads();
     u32 idx = running + before + inc - mine;
     running += tile_total;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      if (!(fmask & (1u << j))) continue;
-      u32 const ii = ii0 + j, v = vv[j];
-      u32 const slot = v & kInstSlotMask;
-      if (idx < ws.nc) {
-        u32 const s = seq_of(sbase, ns, ii);
-        u32 const o = ii - sbase[s];
-        u32 label = 1;  // Label::REFERENCE
-        u32 srcbit = 0, rel_off = 0;
-        if (s > 0) {
-          u32 const r = b.read_win_off[w] + s - 1;
-          label = (b.read_flags[r] & MA_RF_CASE) ? 4u : 2u;  // Label::CASE / Label::CTRL
-          srcbit = 0x80000000u;
-          rel_off = static_cast<u32>(b.read_off[r] - win_read_off0);
-        }
-        slot_node[slot] = idx;
-        for (int i = 0; i < S; ++i) ws.nd_cnt[(nb + idx) * S + i] = cnt[static_cast<size_t>(slot) * CW + i];
-        ws.nd_role[(nb + idx) * 2 + 0] = cnt[static_cast<size_t>(slot) * CW + S];
-        ws.nd_role[(nb + idx) * 2 + 1] = cnt[static_cast<size_t>(slot) * CW + S + 1];
-        ws.nd_src[nb + idx] = srcbit | (rel_off + o);
-        ws.nd_label[nb + idx] = static_cast<u8>(label);
-        ws.nd_sign[nb + idx] = (v & kInstPlus) ? 1 : 0;
-        ws.nd_nedge[nb + idx] = 0;
-      }
+    for (u32 m = fmask; m; m &= m - 1) {
+      if (idx < ws.nc) node_inst[idx] = ii0 + static_cast<u32>(__ffs(m)) - 1u;
       idx++;
+    }
+  }
+  __threadfence_block();
+  __syncthreads();
+  // 2b. the node records, a thread per node: independent chains, as many in flight as there are threads
+  {
+    u32 const nn = min(running, ws.nc);
+    for (u32 idx = threadIdx.x; idx < nn; idx += kBT) {
+      u32 const ii = node_inst[idx];
+      u32 const v = inst_slot[ii];
+      u32 const slot = v & kInstSlotMask;
+      u32 const s = seq_of(sbase, ns, ii);
+      u32 const o = ii - sbase[s];
+      u32 label = 1;  // Label::REFERENCE
+      u32 srcbit = 0, rel_off = 0;
+      if (s > 0) {
+        u32 const r = b.read_win_off[w] + s - 1;
+        label = (b.read_flags[r] & MA_RF_CASE) ? 4u : 2u;  // Label::CASE / Label::CTRL
+        srcbit = 0x80000000u;
+        rel_off = static_cast<u32>(b.read_off[r] - win_read_off0);
+      }
+      slot_node[slot] = idx;
+      for (int i = 0; i < S; ++i) ws.nd_cnt[(nb + idx) * S + i] = cnt[static_cast<size_t>(slot) * CW + i];
+      ws.nd_role[(nb + idx) * 2 + 0] = cnt[static_cast<size_t>(slot) * CW + S];
+      ws.nd_role[(nb + idx) * 2 + 1] = cnt[static_cast<size_t>(slot) * CW + S + 1];
+      ws.nd_src[nb + idx] = srcbit | (rel_off + o);
+      ws.nd_label[nb + idx] = static_cast<u8>(label);
+      ws.nd_sign[nb + idx] = (v & kInstPlus) ? 1 : 0;
+      ws.nd_nedge[nb + idx] = 0;
     }
   }
   u32 const total = running;

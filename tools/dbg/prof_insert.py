@@ -17,7 +17,7 @@ eng.lib.ma_debug_iprof(buf)
 d = [b - a for a, b in zip(base, list(buf))]
 names = ["init+stage", "ref k-mers", "slow pass 1", "table init", "pass 2 inserts", "deferred", "pass 3"]
 tot = sum(d[:7])
-print({k: round(v, 2) for k, v in eng.kernel_times() if k in ("k_classify", "k_insert")})
+print({k: round(v, 2) for k, v in eng.kernel_times()})
 print({n: f"{100.0 * v / tot:.1f}%" for n, v in zip(names, d)})
 cn = ["stage", "lane loop", "slow queue", "-"]
 ct = sum(d[8:12]) or 1
