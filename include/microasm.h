@@ -227,14 +227,19 @@ int ma_annotate_batch(ma_ctx_t* ctx, const ma_batch_t* b, const ma_asm_out_t* as
 int ma_process_batch(ma_ctx_t* ctx, const ma_batch_t* b, const ma_gate_out_t* gate,
                      const ma_asm_out_t* asmb, const ma_var_out_t* vars, const ma_geno_out_t* geno);
 
-/* MA_MEM_HOST only (a no-op otherwise): start uploading the batch the caller will pass to ma_process_batch NEXT, on a copy
- * stream of the context, and return at once -- the staged pipeline of the reference's AsyncWorker (core/async_worker.cpp:
- * 47-110: extract window j + 1 while window j is assembled) at batch granularity:
- *     ma_prefetch_batch(ctx, &batch[j + 1]);  ma_process_batch(ctx, &batch[j], ...);   // upload of j + 1 under the kernels of j
+/* MA_MEM_HOST only (a no-op otherwise): hand over the batch the caller will pass to ma_process_batch NEXT and return at
+ * once -- the staged pipeline of the reference's AsyncWorker (core/async_worker.cpp:47-110: extract window j + 1 while window
+ * j is assembled) at batch granularity:
+ *     ma_prefetch_batch(ctx, &batch[j + 1]);  ma_process_batch(ctx, &batch[j], ...);
+ * The context uploads the batch in the background (an uploader thread, 16 MB pieces) and queues its COMPUTE behind whatever
+ * its lanes are doing: a lane goes from the last kernel of batch j straight to the first of batch j + 1, and
+ * ma_process_batch(j + 1) only waits for the packed records and scatters them into the caller's arrays.  Work that was
+ * queued ahead assumes that the call will ask for the same optional output arrays as the previous ma_process_batch did, with
+ * the same parameters and timing mode; if it does not (or asks for the per-read debug taps), the queued results are dropped
+ * and the batch is computed in the call -- results never depend on whether, or how, a batch was prefetched.
  * `next` and the arrays it points to must stay unchanged until the ma_process_batch call that consumes it (recognised by
  * the struct's address, window and read counts) has returned; the arrays should be page-locked (hipHostMalloc /
- * hipHostRegister), a copy from pageable memory blocks the caller.  At most two batches wait at a time; further calls do
- * nothing.  Results never depend on whether a batch was prefetched. */
+ * hipHostRegister), a copy from pageable memory is slow.  At most two batches wait at a time; further calls do nothing. */
 int ma_prefetch_batch(ma_ctx_t* ctx, const ma_batch_t* next);
 
 /* Kernel timing mode: 0 = off, 1 = reset at every API call (default), 2 = accumulate across calls
