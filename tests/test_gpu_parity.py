@@ -1007,6 +1007,56 @@ def test_jobs_queued_ahead_follow_the_call_that_collects_them():
         eng.close()
 
 
+def test_queued_ahead_jobs_survive_a_change_of_lanes_and_tiny_batches():
+    """The pipelined host route with batches of one and two windows (one lane), an empty window range in a lane, and the
+    number of lanes changed between ma_prefetch_batch and the call that brings the batch (the queued job was split for the
+    old number: it is left alone and the batch is computed for the new one)."""
+    from lancet2_amd.engine import Engine
+    params = capi.default_params(min_k=25, max_k=25)
+    batches = [synth.make_config_batch("C2", 1, first_index=9900), synth.make_config_batch("C2", 2, first_index=9910),
+               synth.make_config_batch("C2", 9, first_index=9920)]
+    eng = Engine(params)
+    try:
+        want = [eng.process(a_, n_, nr_, debug=False) for a_, n_, nr_ in batches]
+    finally:
+        eng.close()
+    structs = [capi.make_batch_struct(a_, n_, nr_) for a_, n_, nr_ in batches]
+
+    def run(eng, i):
+        arrs, n, nr = batches[i]
+        outs = (capi.alloc_host(capi.gate_out_spec(n)), capi.alloc_host(capi.asm_out_spec(params, n)),
+                capi.alloc_host(capi.var_out_spec(params, n)), capi.alloc_host(capi.geno_out_spec(params, n, nr, False)))
+        eng.process_device(structs[i], capi.fill_struct(capi.GateOut, outs[0]), capi.fill_struct(capi.AsmOut, outs[1]),
+                           capi.fill_struct(capi.VarOut, outs[2]), capi.fill_struct(capi.GenoOut, outs[3]))
+        g, a, v, q = outs
+        wg, wa, wv, wq = want[i]
+        assert np.array_equal(g["max_approx"], wg["max_approx"])
+        bad = compare_asm(params, a, wa, n) + compare_vars(params, v, wv, n)
+        assert not bad, (i, bad[:6])
+        assert np.array_equal(q["allele_counts"], wq["allele_counts"])
+
+    eng = Engine(params)
+    try:
+        run(eng, 0)
+        eng.prefetch(structs[1])
+        run(eng, 1)
+        eng.prefetch(structs[0])
+        eng.prefetch(structs[2])
+        run(eng, 0)
+        eng.set_streams(3)            # the job queued for batch 2 was split for one lane
+        run(eng, 2)
+        eng.prefetch(structs[2])      # queued for three lanes ...
+        eng.set_streams(4)            # ... four are asked for: nine windows, lanes of 2-3
+        run(eng, 2)
+        eng.set_streams(8)
+        eng.prefetch(structs[1])      # two windows: one lane whatever was asked for
+        run(eng, 1)
+        eng.prefetch(structs[2])
+        run(eng, 2)
+    finally:
+        eng.close()
+
+
 def test_device_buffers_need_no_padding_or_alignment():
     """MA_MEM_DEVICE passes the caller's pointers through: the byte arrays (reference, read bases, qualities) sized
     exactly -- without the 64 bytes of padding the host route adds --, at odd addresses, with junk on both sides, give the
