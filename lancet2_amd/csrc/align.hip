@@ -975,16 +975,22 @@ template <class Fetch>
 __device__ void align_traceback(GArgs const& A, Fetch fetch, i32 lo, i32 m, i32 best, i32 bi, i32 bj, i32* arec, u32* acig,
                                 bool write) {
   int const MCG = A.prm.max_cigar;
-  u32 ops[64];   // reversed run-length ops, len << 4 | op
-  int nops = 0;
+  u32 ops[64];   // reversed run-length ops, len << 4 | op (private memory: only touched when a run ENDS -- the run in hand
+  int nops = 0;  // lives in registers; one read-modify-write of this array per step was two memory operations per step)
   u32 total_ops = 0;
+  u32 cur_op = 0xFu, cur_len = 0;
+  auto flush_run = [&]() {
+    if (cur_len == 0) return;
+    total_ops++;
+    if (nops < 64) ops[nops++] = (cur_len << 4) | cur_op; else nops = 65;  // overflow marker
+    cur_len = 0;
+  };
   auto push = [&](u32 op) {
-    if (nops > 0 && (ops[nops - 1] & 0xFu) == op && nops <= 64) {
-      ops[nops - 1] += 16u;
-    } else {
-      total_ops++;
-      if (nops < 64) ops[nops++] = (1u << 4) | op; else nops = 65;  // overflow marker
+    if (op != cur_op) {
+      flush_run();
+      cur_op = op;
     }
+    cur_len++;
   };
   i32 i = bi, j = bj;
   int state = 0;
@@ -1012,6 +1018,7 @@ __device__ void align_traceback(GArgs const& A, Fetch fetch, i32 lo, i32 m, i32 
       if (nib & 8u) state = 0;
     }
   }
+  flush_run();
   if (!write) return;
   i32 const qs = i, rs = j, qe = bi, re = bj;
   arec[0] = 1;
@@ -1077,10 +1084,26 @@ __device__ __forceinline__ void dp_pair_store(GArgs const& A, DpPair const& p, c
     return;
   }
   u32 const tbw = A.ws.tb_words;
+  // The walk is a chain of dependent loads, one move nibble per step (~160 steps, ~1 us each from HBM).  A step goes up a
+  // row or stays in it, and leaves its 8-column word only at a gap: the words of the NEXT EIGHT ROWS at the current word
+  // column are fetched together, so the chain is ~20 round trips long instead of ~160.
+  constexpr int kTR = 8;
+  u32 cw[kTR];
+  i32 c_top = -1, c_word = -1;  // cw[r] = word c_word of row c_top - r
   align_traceback(
       A,
       [&](i32 i, i32 t) {
-        u32 const wv = tb[(static_cast<size_t>(i) * tbw + (t >> 3)) * 64 + lane];
+        i32 const wd = t >> 3;
+        if (wd != c_word || i > c_top || i <= c_top - kTR) {
+          c_top = i;
+          c_word = wd;
+#pragma unroll
+          for (int r = 0; r < kTR; ++r) cw[r] = tb[(static_cast<size_t>(max(i - r, 0)) * tbw + wd) * 64 + lane];
+        }
+        i32 const r = c_top - i;
+        u32 wv = cw[0];
+#pragma unroll
+        for (int x = 1; x < kTR; ++x) wv = r == x ? cw[x] : wv;
         return (wv >> (4 * (t & 7))) & 0xFu;
       },
       p.lo, p.m, best, bi, bj, arec, acig, true);
