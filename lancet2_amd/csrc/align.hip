@@ -376,7 +376,8 @@ __device__ __forceinline__ void vote_flush_dp(GArgs const& A, HapIdx ix, int lan
   if (lane == 0) ix.dpbuf[64] = 0;
   __builtin_amdgcn_wave_barrier();
 }
-__device__ __forceinline__ void vote_pair(GArgs const& A, u64 lp, PairId id, HapIdx ix, u16* hist, int lane, i32 m, u32 pre, i32 hint, i32 n);
+__device__ __forceinline__ void vote_pair(GArgs const& A, u64 lp, PairId id, HapIdx ix, u16* hist, int lane, i32 m, u32 pre, i32 hint, i32 n,
+                                          bool shortcut_tried);
 
 #ifndef MA_VOTE_PF
 #define MA_VOTE_PF 2
@@ -536,39 +537,138 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
                   dpbuf_all + wave * 129, hap_amb, dup_pre, sh_cand};
 #endif
   u16* hist = hist_all + static_cast<size_t>(wave) * hist_len;
-  // software pipeline: the next read's plane words (lane l < 3 rwords holds word l) are in flight while the current
-  // read is voted
   u32 const npw = 3u * rwords;
-  auto fetch = [&](u32 ri) -> u32 {
-    return static_cast<u32>(lane) < npw ? A.ws.read_planes[static_cast<size_t>(r0 + ri) * plane_stride(rwords) + lane] : 0u;
-  };
-  // (and its mapping hint: a load per pair that the shortcut would otherwise wait for first thing)
   bool const hinted = A.b.read_hint != nullptr;
-  // kPF reads ahead: a pair that takes the shortcut is done in well under one memory latency
-  constexpr u32 kPF = MA_VOTE_PF;
-  u32 pf[kPF];
-  i32 hf[kPF];
-#pragma unroll
-  for (u32 x = 0; x < kPF; ++x) {
-    u32 const ri = wave + 4u * x;
-    pf[x] = ri < nr ? fetch(ri) : 0u;
-    hf[x] = (hinted && ri < nr) ? A.b.read_hint[r0 + ri] : MA_NO_HINT;
-  }
-  for (u32 ri = wave; ri < nr; ri += 4) {
-    u32 const ra = ri + 4u * kPF;
-    u32 const pn = ra < nr ? fetch(ra) : 0u;
-    i32 const hn = (hinted && ra < nr) ? A.b.read_hint[r0 + ra] : MA_NO_HINT;
-    u64 const p = p0 + ri;
-    if (p >= A.pair0 && p < A.pair0 + A.npairs)
-      vote_pair(A, p - A.pair0, PairId{w, r0 + ri, static_cast<u32>(slot)}, ix, hist, lane,
-                static_cast<i32>(l_roff[ri + 1] - l_roff[ri]), pf[0], hf[0], static_cast<i32>(n));
-#pragma unroll
-    for (u32 x = 0; x + 1 < kPF; ++x) {
-      pf[x] = pf[x + 1];
-      hf[x] = hf[x + 1];
+  if (rwords <= 8 && ix.cand[0] > 0 && !ix.hap_amb && hinted && nr > 0) {
+    // EIGHT reads per trip: the hint shortcut needs a lane per 32 bases -- five lanes of the wave for a 150-base read -- and
+    // two reads in three end there.  Lane 8 g + x holds word x of read g's three planes (reads of up to 256 bases); the
+    // candidate diagonals of all eight reads are tried side by side with 8-lane reductions, every group's first lane
+    // writes its own record.  Only the reads that are left go through the wave-wide vote, one after the other, their
+    // plane words brought into the lane-l-holds-word-l layout by shuffles.  (One read per trip: the shortcut, a third of
+    // this kernel's time, ran on 5 of 64 lanes.)
+    u32 const g = static_cast<u32>(lane) >> 3, x = static_cast<u32>(lane) & 7u;
+    auto group_read = [&](u32 q0) -> u32 { return static_cast<u32>(wave) + 4u * (q0 + g); };
+    auto fetch_words = [&](u32 ri, u32* wl, u32* wh, u32* wb, i32* hn) {
+      bool const ok = ri < nr && x < rwords;
+      const u32* pl = A.ws.read_planes + static_cast<size_t>(r0 + min(ri, nr - 1)) * plane_stride(rwords);
+      u32 const a0 = pl[min(x, rwords - 1)], a1 = pl[rwords + min(x, rwords - 1)], a2 = pl[2 * rwords + min(x, rwords - 1)];
+      *wl = ok ? a0 : 0u;
+      *wh = ok ? a1 : 0u;
+      *wb = ok ? a2 : 0u;
+      *hn = ri < nr ? A.b.read_hint[r0 + ri] : MA_NO_HINT;
+    };
+    u32 nwl, nwh, nwb;
+    i32 nhn;
+    fetch_words(group_read(0), &nwl, &nwh, &nwb, &nhn);
+    for (u32 q0 = 0; static_cast<u32>(wave) + 4u * q0 < nr; q0 += 8) {
+      u32 const ri = group_read(q0);
+      u32 const wl = nwl, wh = nwh, wb = nwb;
+      i32 const hint = nhn;
+      fetch_words(group_read(q0 + 8), &nwl, &nwh, &nwb, &nhn);  // (the next eight reads' words: in flight under this trip)
+      u64 const p = p0 + ri;
+      bool const valid = ri < nr && p >= A.pair0 && p < A.pair0 + A.npairs;
+      i32 const m = valid ? static_cast<i32>(l_roff[ri + 1] - l_roff[ri]) : 0;
+      bool can = valid && m >= SK && m <= 256 && hint != MA_NO_HINT;  // (longer reads: the wave-wide route tries the shortcut itself)
+      bool const tried = can;
+      bool settled = false;
+      u32 const wbad_any = wb;
+      {  // an N in the read: general route (the per-read code leaves its candidate loop at the first in-range candidate)
+        u32 b_ = wbad_any;
+        b_ |= __shfl_xor(b_, 1);
+        b_ |= __shfl_xor(b_, 2);
+        b_ |= __shfl_xor(b_, 4);
+        if (b_ != 0) can = false;
+      }
+      i32 const ncand = ix.cand[0];
+      for (int cx = 0; cx < ncand; ++cx) {
+        if (__ballot(can && !settled) == 0ull) break;
+        i32 const c = hint - ix.cand[1] + ix.cand[2 + cx];
+        bool const inr = can && !settled && !(c < 0 || c + m > n);
+        u32 mism = 0;
+        i32 const i = 32 * static_cast<i32>(x);
+        if (inr && i < m) {
+          i32 const hi = min(m - i, 32);
+          u32 const vmask = hi >= 32 ? 0xFFFFFFFFu : ((1u << hi) - 1u);
+          u32 const hl = plane32(ix.hlo, c + i), hh = plane32(ix.hhi, c + i);
+          mism = __popc(((wl ^ hl) | (wh ^ hh)) & vmask);
+        }
+        mism += __shfl_xor(mism, 1);
+        mism += __shfl_xor(mism, 2);
+        mism += __shfl_xor(mism, 4);
+        i32 const X = static_cast<i32>(mism);
+        if (inr && X <= 2) {
+          i32 const D = static_cast<i32>(ix.dup_pre[c + m - SK + 1]) - static_cast<i32>(ix.dup_pre[c]);
+          i32 const S0 = m - 5 * X;
+          if (D + 22 * X + 10 < m && S0 >= A.prm.min_aln_score && D < 60000) {
+            settled = true;
+            if (x == 0) {
+              size_t const rec = static_cast<size_t>(r0 + ri) * A.prm.max_haps + static_cast<u32>(slot);
+              i32* arec = A.o.aln_rec + rec * 6;
+              u32* acig = A.o.aln_cigar + rec * (1 + A.prm.max_cigar);
+              arec[0] = 1;
+              arec[1] = S0;
+              arec[2] = c;
+              arec[3] = c + m;
+              arec[4] = 0;
+              arec[5] = m;
+              acig[0] = 1;
+              acig[1] = static_cast<u32>(m) << 4;
+              A.ws.centre[p - A.pair0] = 0x7FFFFFFE;
+            }
+          }
+        }
+      }
+      // the reads that are left, one after the other on the whole wave
+      unsigned long long const todo = __ballot(valid && !settled && x == 0);
+      for (u32 gg = 0; gg < 8; ++gg) {
+        if (!((todo >> (8 * gg)) & 1ull)) continue;
+        u32 const src = 8 * gg;
+        u32 const ri_g = static_cast<u32>(__shfl(static_cast<int>(ri), static_cast<int>(src)));
+        i32 const m_g = __shfl(m, static_cast<int>(src));
+        i32 const h_g = __shfl(hint, static_cast<int>(src));
+        bool const tried_g = __shfl(static_cast<int>(tried), static_cast<int>(src)) != 0;
+        // lane l < 3 rwords wants word l % rwords of plane l / rwords: it sits in lane 8 gg + l % rwords
+        u32 const pln = static_cast<u32>(lane) / rwords, wx = static_cast<u32>(lane) % rwords;
+        int const from = static_cast<int>(src + wx);
+        u32 const s0 = __shfl(wl, from), s1 = __shfl(wh, from), s2 = __shfl(wb, from);
+        u32 const pre = static_cast<u32>(lane) < npw ? (pln == 0 ? s0 : (pln == 1 ? s1 : s2)) : 0u;
+        vote_pair(A, p0 + ri_g - A.pair0, PairId{w, r0 + ri_g, static_cast<u32>(slot)}, ix, hist, lane, m_g, pre, h_g, static_cast<i32>(n),
+                  tried_g);
+      }
     }
-    pf[kPF - 1] = pn;
-    hf[kPF - 1] = hn;
+  } else {
+    // software pipeline: the next read's plane words (lane l < 3 rwords holds word l) are in flight while the current
+    // read is voted
+    auto fetch = [&](u32 ri) -> u32 {
+      return static_cast<u32>(lane) < npw ? A.ws.read_planes[static_cast<size_t>(r0 + ri) * plane_stride(rwords) + lane] : 0u;
+    };
+    // (and its mapping hint: a load per pair that the shortcut would otherwise wait for first thing)
+    // kPF reads ahead: a pair that takes the shortcut is done in well under one memory latency
+    constexpr u32 kPF = MA_VOTE_PF;
+    u32 pf[kPF];
+    i32 hf[kPF];
+#pragma unroll
+    for (u32 x = 0; x < kPF; ++x) {
+      u32 const ri = wave + 4u * x;
+      pf[x] = ri < nr ? fetch(ri) : 0u;
+      hf[x] = (hinted && ri < nr) ? A.b.read_hint[r0 + ri] : MA_NO_HINT;
+    }
+    for (u32 ri = wave; ri < nr; ri += 4) {
+      u32 const ra = ri + 4u * kPF;
+      u32 const pn = ra < nr ? fetch(ra) : 0u;
+      i32 const hn = (hinted && ra < nr) ? A.b.read_hint[r0 + ra] : MA_NO_HINT;
+      u64 const p = p0 + ri;
+      if (p >= A.pair0 && p < A.pair0 + A.npairs)
+        vote_pair(A, p - A.pair0, PairId{w, r0 + ri, static_cast<u32>(slot)}, ix, hist, lane,
+                  static_cast<i32>(l_roff[ri + 1] - l_roff[ri]), pf[0], hf[0], static_cast<i32>(n), false);
+#pragma unroll
+      for (u32 x = 0; x + 1 < kPF; ++x) {
+        pf[x] = pf[x + 1];
+        hf[x] = hf[x + 1];
+      }
+      pf[kPF - 1] = pn;
+      hf[kPF - 1] = hn;
+    }
   }
   vote_flush_dp(A, ix, lane);
 #ifdef MA_PROFILE
@@ -584,7 +684,8 @@ __device__ __forceinline__ void write_no_hit(GArgs const& A, PairId id) {
   A.o.aln_rec[(static_cast<size_t>(id.r) * A.prm.max_haps + id.slot) * 6] = 0;
 }
 
-__device__ __forceinline__ void vote_pair(GArgs const& A, u64 lp, PairId id, HapIdx ix, u16* hist, int lane, i32 m, u32 pre, i32 hint, i32 n) {
+__device__ __forceinline__ void vote_pair(GArgs const& A, u64 lp, PairId id, HapIdx ix, u16* hist, int lane, i32 m, u32 pre, i32 hint, i32 n,
+                                          bool shortcut_tried) {
   i32 const nd = m + n + 1;  // (n = the haplotype's length, held by the caller)  // diagonals d in [-m, n] -> hist[d + m]
   i32 const Kr = m - A.prm.min_aln_score - GO > 0 ? (m - A.prm.min_aln_score - GO) / GE : 0;  // reach K of the search region
   const u16* head = ix.head;
@@ -605,7 +706,7 @@ __device__ __forceinline__ void vote_pair(GArgs const& A, u64 lp, PairId id, Hap
   // votes, which is all certificate (I) asks of the vote histogram -- D + 11 X + 10 + 11 X < m makes P0 the unique
   // optimum.  c itself holds >= m - 10 - 11 X >= 4 votes, so it is an anchor and P0 lies in the search region.  A wrong
   // or missing hint only means that no candidate passes and the pair takes the general route: results never depend on it.
-  if (ix.cand[0] > 0 && !ix.hap_amb && m >= SK && m <= 2048) {
+  if (!shortcut_tried && ix.cand[0] > 0 && !ix.hap_amb && m >= SK && m <= 2048) {
     if (hint != MA_NO_HINT) {  // (A.b.read_hint[id.r], fetched by the caller a read ahead)
       for (int x = 0; x < ix.cand[0]; ++x) {
         i32 const c = hint - ix.cand[1] + ix.cand[2 + x];
@@ -950,7 +1051,17 @@ __device__ __forceinline__ void vote_pair(GArgs const& A, u64 lp, PairId id, Hap
   if (ix.dpbuf[64] == 64) vote_flush_dp(A, ix, lane);
   VPROF_ACC(6);
 #ifdef MA_PROFILE
-  if (lane == 0) ix.prof[7] += 1;
+  if (lane == 0) {
+    ix.prof[7] += 1;
+    // (developer census: what keeps pairs on the general route)
+    if (!fast && !nohit) {
+      if (inside && certs && !amb && X >= 3 && X <= 5 && S0 >= ms) atomicAdd(&g_vprof[11], 1ull);
+      else if (inside && certs && !amb && X <= 2) atomicAdd(&g_vprof[12], 1ull);   // vote bound failed
+      else atomicAdd(&g_vprof[13], 1ull);
+    }
+    if (fast) atomicAdd(&g_vprof[10], 1ull);
+    if (nohit) atomicAdd(&g_vprof[9], 1ull);
+  }
 #endif
 }
 
