@@ -1053,7 +1053,7 @@ void ma_destroy(ma_ctx_t* ctx) {
   for (auto& b : ctx->out_stage) b.release();
   ctx->ws_build.release(); ctx->ws_nodes.release(); ctx->ws_clean.release();
   ctx->ws_poa.release(); ctx->ws_aln.release(); ctx->ws_misc.release(); ctx->ws_cx.release(); ctx->ws_gen.release(); ctx->dev_stats.release();
-  ctx->pack_aux.release(); ctx->pack_buf.release();
+  ctx->pack_aux.release();
   for (auto& pp : ctx->pin) {
     if (pp) (void)hipHostFree(pp);
     pp = nullptr;
@@ -1063,8 +1063,6 @@ void ma_destroy(ma_ctx_t* ctx) {
       (void)hipStreamSynchronize(cs);
       (void)hipStreamDestroy(cs);
     }
-  for (auto& e : ctx->pf_ev)
-    if (e) (void)hipEventDestroy(e);
   for (auto& st : ctx->in_sets)
     for (auto& bf : st.bufs) bf.release();
   for (auto& t : ctx->timers) {

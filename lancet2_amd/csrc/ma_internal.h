@@ -98,7 +98,7 @@ struct ma_ctx {
   double hbm_share = 1.0;   // fraction of the device this context plans its workspaces for
   hipEvent_t sync_ev = nullptr;  // blocking-sync event: host threads sleep instead of spinning while the stream drains
   // host route (MA_MEM_HOST) of ma_process_batch, per lane: packed result records (pack.hip) and their pinned landing area
-  ma::DevBuf pack_aux, pack_buf;
+  ma::DevBuf pack_aux;
   void* pin[2] = {nullptr, nullptr};      // one landing area per input set: a batch's records are read by the caller's
   size_t pin_cap[2] = {0, 0};             // thread while the lane already computes the next batch
   size_t last_packed = 0;                 // (lane) bytes of packed records of the lane's last batch: sizes the next landing area
@@ -106,11 +106,10 @@ struct ma_ctx {
   hipStream_t copy_stream2 = nullptr;     // the pieces of an upload alternate between the two copy streams (api.hip: run_copy_ops)
   ma::InputSet in_sets[2];       // (lane) input staging, double buffered
   // (parent) ma_prefetch_batch: which batch each set of the lanes holds (null: free), in which order they were filled,
-  // the event behind the set's uploads, and the stream the uploads of a prefetch run on
+  // and the stream the uploads of a prefetch run on (api.hip: uploader thread)
   const ma_batch_t* pf_batch[2] = {nullptr, nullptr};
   int64_t pf_sig[2][3] = {{0, 0, 0}, {0, 0, 0}};  // n_windows, n_reads, lanes of the prefetched batch
   unsigned long long pf_seq[2] = {0, 0}, pf_counter = 0;
-  hipEvent_t pf_ev[2] = {nullptr, nullptr};
   hipStream_t copy_stream = nullptr;
 
   void tic(const char* name);
