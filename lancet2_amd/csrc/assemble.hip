@@ -4,6 +4,8 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <utility>
+#include <vector>
 
 #include "graph_ws.h"
 
@@ -103,6 +105,245 @@ struct Carver {
 
 }  // namespace
 
+// ---- speculative tail of the k ladder ------------------------------------------------------------------------------------
+// A window whose graph has a cycle (or is too complex, or yields nothing) at k goes on to the next rung; a tandem duplication
+// of 80 bases sends it up a dozen rungs.  One pass of the build + clean kernels per rung costs its fixed latency (~3.5 ms: the
+// slowest window of k_clean, the kernels' minimum durations) however few windows it holds, and the tail of the ladder is a
+// dozen such passes over a few dozen windows.  Once few windows are pending, their NEXT SIX RUNGS are therefore attempted at
+// once: the pending windows are copied into a derived batch, one copy per rung, the derived batch is assembled by this same
+// function (every copy at its one k, k_select_active: win_kfirst), and each window takes the result of the first rung that
+// resolved -- what the rung-by-rung loop would have stopped at.  Rungs beyond it were wasted work, on idle hardware.
+struct SpecDesc {  // one pending window, as the host needs it to lay the derived batch out
+  u32 w, k, gate, ref_len, n_reads, pad_;
+  u64 read_bytes;
+};
+struct SpecVirt {  // one window of the derived batch
+  u32 src_w;       // the window it is a copy of
+  u32 k;           // its rung
+  u32 ref_off;     // where its reference bytes start in the derived batch
+  u32 rwo;         // its first read's index there
+  u64 byte_off;    // its first read byte there
+};
+struct SpecBatch {  // the derived batch's arrays (device, writable)
+  u8* ref_bases;
+  u32* ref_off;
+  u32* read_win_off;
+  u64* read_off;
+  u8* read_bases;
+  u8* read_quals;
+  u32* read_qname_id;
+  u8* read_sample;
+  u8* read_flags;
+  i32* read_hint;
+};
+__global__ void k_spec_describe(DBatch b, const u32* active, u32 n, const u32* win_k, const u32* gate, SpecDesc* out) {
+  u32 const i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  u32 const w = active[i];
+  u32 const r0 = b.read_win_off[w], r1 = b.read_win_off[w + 1];
+  out[i] = SpecDesc{w, win_k[w], gate[w], b.ref_off[w + 1] - b.ref_off[w], r1 - r0, 0u, b.read_off[r1] - b.read_off[r0]};
+}
+__global__ __launch_bounds__(256) void k_spec_gather(DBatch b, const SpecVirt* virt, u32 V, SpecBatch d) {
+  u32 const v = blockIdx.x;
+  SpecVirt const sv = virt[v], nx = virt[v + 1];  // (virt[V] holds the totals)
+  u32 const w = sv.src_w;
+  u32 const ref_len = nx.ref_off - sv.ref_off, nr = nx.rwo - sv.rwo;
+  u64 const nbytes = nx.byte_off - sv.byte_off;
+  const u8* rs = b.ref_bases + b.ref_off[w];
+  for (u32 i = threadIdx.x; i < ref_len; i += 256) d.ref_bases[sv.ref_off + i] = rs[i];
+  u32 const r0 = b.read_win_off[w];
+  u64 const byte0 = b.read_off[r0];
+  for (u32 i = threadIdx.x; i < nr; i += 256) {
+    u32 const r = r0 + i, at = sv.rwo + i;
+    d.read_off[at] = sv.byte_off + (b.read_off[r] - byte0);
+    d.read_qname_id[at] = b.read_qname_id[r];
+    d.read_sample[at] = b.read_sample[r];
+    d.read_flags[at] = b.read_flags[r];
+    if (d.read_hint) d.read_hint[at] = b.read_hint[r];
+  }
+  for (u64 i = threadIdx.x; i < nbytes; i += 256) {
+    d.read_bases[sv.byte_off + i] = b.read_bases[byte0 + i];
+    d.read_quals[sv.byte_off + i] = b.read_quals[byte0 + i];
+  }
+  if (threadIdx.x == 0) {
+    d.ref_off[v] = sv.ref_off;
+    d.read_win_off[v] = sv.rwo;
+    if (v + 1 == V) {
+      d.ref_off[V] = nx.ref_off;
+      d.read_win_off[V] = nx.rwo;
+      d.read_off[nx.rwo] = nx.byte_off;
+    }
+  }
+}
+struct SpecField {  // one output array: bytes per window, in the derived batch's outputs and in the caller's
+  const u8* src;
+  u8* dst;
+  u32 bytes;
+};
+struct SpecFields {
+  SpecField f[13];
+  u32 n;
+};
+// a workgroup per pending window: the first of its copies (rung order) that resolved hands its outputs over
+__global__ __launch_bounds__(256) void k_spec_select(const SpecDesc* desc, const u32* first_virt, const SpecVirt* virt, u32 P,
+                                                     ma_asm_out_t inner, SpecFields F, ma_asm_out_t outer, u32* win_flags, u32* counts) {
+  u32 const p = blockIdx.x;
+  if (p >= P) return;
+  u32 const w = desc[p].w;
+  u32 const v0 = first_virt[p], v1 = first_virt[p + 1];
+  u32 chosen = 0xFFFFFFFFu;
+  for (u32 v = v0; v < v1 && chosen == 0xFFFFFFFFu; ++v)
+    if (inner.win_ncomp[v] > 0 || (inner.win_status[v] & MA_W_TABLE_OVERFLOW)) chosen = v;
+  if (chosen == 0xFFFFFFFFu) {  // none of these rungs: still pending, next time from the last one tried
+    if (threadIdx.x == 0) {
+      outer.win_k[w] = virt[v1 - 1].k;
+      atomicAdd(&counts[0], v1 - v0);   // rungs the rung-by-rung loop would have attempted too
+      atomicAdd(&counts[1], 1u);        // still pending
+    }
+    return;
+  }
+  for (u32 x = 0; x < F.n; ++x) {
+    const u8* s = F.f[x].src + static_cast<size_t>(chosen) * F.f[x].bytes;
+    u8* d = F.f[x].dst + static_cast<size_t>(w) * F.f[x].bytes;
+    if ((F.f[x].bytes & 3u) == 0)
+      for (u32 i = threadIdx.x; i < F.f[x].bytes / 4u; i += 256) reinterpret_cast<u32*>(d)[i] = reinterpret_cast<const u32*>(s)[i];
+    else
+      for (u32 i = threadIdx.x; i < F.f[x].bytes; i += 256) d[i] = s[i];
+  }
+  if (threadIdx.x == 0) {
+    atomicOr(&win_flags[w], 1u);
+    atomicAdd(&counts[0], chosen - v0 + 1u);
+  }
+}
+
+constexpr u32 kSpecPending = 256;  // windows pending at most for the tail to be attempted this way
+constexpr u32 kSpecRungs = 6;      // rungs per round
+
+// `active[0, P)` = the pending windows of the chunk, win_k[w] = the rung each of them would attempt next (k_select_active
+// has just run).  Resolves them as far as kSpecRungs rungs go; *still = how many remain pending.
+int speculate_tail(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& out, const u32* gate_approx, const u32* active, u32 P,
+                   u32* win_flags, u32* counters, u32* still) {
+  ma_params_t const& prm = ctx->prm;
+  // 1. what the pending windows look like
+  MA_HIP(ctx, ctx->spec_data.reserve(sizeof(SpecDesc) * kSpecPending + 4096));
+  SpecDesc* d_desc = ctx->spec_data.as<SpecDesc>();
+  hipLaunchKernelGGL(k_spec_describe, dim3((P + 255) / 256), dim3(256), 0, ctx->stream, b, active, P, out.win_k, gate_approx, d_desc);
+  std::vector<SpecDesc> desc(P);
+  MA_HIP(ctx, hipMemcpyAsync(desc.data(), d_desc, sizeof(SpecDesc) * P, hipMemcpyDeviceToHost, ctx->stream));
+  MA_HIP(ctx, ma_stream_sync(ctx));
+  // 2. the derived batch: every pending window once per rung (the ladder's skip rule for gated k: k_select_active)
+  std::vector<SpecVirt> virt;
+  std::vector<u32> first_virt(P + 1, 0), vk;
+  u32 ref_at = 0, read_at = 0;
+  u64 byte_at = 0;
+  for (u32 p = 0; p < P; ++p) {
+    first_virt[p] = static_cast<u32>(virt.size());
+    u32 k = desc[p].k;
+    for (u32 r = 0; r < kSpecRungs && k <= static_cast<u32>(prm.max_k); ++r) {
+      virt.push_back(SpecVirt{desc[p].w, k, ref_at, read_at, byte_at});
+      vk.push_back(k);
+      ref_at += desc[p].ref_len;
+      read_at += desc[p].n_reads;
+      byte_at += desc[p].read_bytes;
+      k += static_cast<u32>(prm.k_step);
+      if (k <= desc[p].gate) k += ((desc[p].gate - k) / static_cast<u32>(prm.k_step) + 1u) * static_cast<u32>(prm.k_step);
+    }
+  }
+  u32 const V = static_cast<u32>(virt.size());
+  first_virt[P] = V;
+  virt.push_back(SpecVirt{0, 0, ref_at, read_at, byte_at});  // totals
+  // device layout of the derived batch + its bookkeeping arrays
+  Carver probe{nullptr};
+  auto carve = [&](Carver& c, SpecBatch* d, SpecDesc** dd, SpecVirt** dv, u32** dfirst, u32** dk, u32** dgate) {
+    *dd = c.take<SpecDesc>(kSpecPending);
+    *dv = c.take<SpecVirt>(V + 1);
+    *dfirst = c.take<u32>(P + 1);
+    *dk = c.take<u32>(V);
+    *dgate = c.take<u32>(V);
+    d->ref_bases = c.take<u8>(static_cast<size_t>(ref_at) + 128);
+    d->ref_off = c.take<u32>(V + 1);
+    d->read_win_off = c.take<u32>(V + 1);
+    d->read_off = c.take<u64>(static_cast<size_t>(read_at) + 1);
+    d->read_bases = c.take<u8>(byte_at + 128);
+    d->read_quals = c.take<u8>(byte_at + 128);
+    d->read_qname_id = c.take<u32>(static_cast<size_t>(read_at) + 1);
+    d->read_sample = c.take<u8>(static_cast<size_t>(read_at) + 16);
+    d->read_flags = c.take<u8>(static_cast<size_t>(read_at) + 16);
+    d->read_hint = b.read_hint ? c.take<i32>(static_cast<size_t>(read_at) + 1) : nullptr;
+  };
+  SpecBatch sb{};
+  SpecDesc* dd = nullptr;
+  SpecVirt* dv = nullptr;
+  u32 *dfirst = nullptr, *dk = nullptr, *dgate = nullptr;
+  carve(probe, &sb, &dd, &dv, &dfirst, &dk, &dgate);
+  MA_HIP(ctx, ctx->spec_data.reserve(probe.off + 4096));  // (may move the buffer: d_desc is not used again)
+  Carver cv{static_cast<char*>(ctx->spec_data.p)};
+  carve(cv, &sb, &dd, &dv, &dfirst, &dk, &dgate);
+  MA_HIP(ctx, hipMemcpyAsync(dd, desc.data(), sizeof(SpecDesc) * P, hipMemcpyHostToDevice, ctx->stream));
+  MA_HIP(ctx, hipMemcpyAsync(dv, virt.data(), sizeof(SpecVirt) * (V + 1), hipMemcpyHostToDevice, ctx->stream));
+  MA_HIP(ctx, hipMemcpyAsync(dfirst, first_virt.data(), 4ull * (P + 1), hipMemcpyHostToDevice, ctx->stream));
+  MA_HIP(ctx, hipMemcpyAsync(dk, vk.data(), 4ull * V, hipMemcpyHostToDevice, ctx->stream));
+  MA_HIP(ctx, hipMemsetAsync(dgate, 0, 4ull * V, ctx->stream));
+  MA_HIP(ctx, hipMemsetAsync(sb.ref_bases + ref_at, 0, 128, ctx->stream));
+  MA_HIP(ctx, hipMemsetAsync(sb.read_bases + byte_at, 0, 128, ctx->stream));
+  MA_HIP(ctx, hipMemsetAsync(sb.read_quals + byte_at, 0, 128, ctx->stream));
+  hipLaunchKernelGGL(k_spec_gather, dim3(V), dim3(256), 0, ctx->stream, b, dv, V, sb);
+  MA_HIP(ctx, ma_stream_sync(ctx));  // (the host vectors above are the sources of the copies)
+  DBatch d2{};
+  d2.n_windows = static_cast<int>(V);
+  d2.n_reads = read_at;
+  d2.ref_bases = sb.ref_bases; d2.ref_off = sb.ref_off; d2.read_win_off = sb.read_win_off; d2.read_off = sb.read_off;
+  d2.read_bases = sb.read_bases; d2.read_quals = sb.read_quals; d2.read_qname_id = sb.read_qname_id;
+  d2.read_sample = sb.read_sample; d2.read_flags = sb.read_flags; d2.read_hint = sb.read_hint;
+  // 3. its outputs
+  size_t const MC = prm.max_comps, MH = prm.max_haps, ML = prm.max_hap_len, MR = prm.max_runs;
+  ma_asm_out_t o2{};
+  SpecFields F{};
+  {
+    Carver oprobe{nullptr};
+    auto carve_out = [&](Carver& c, ma_asm_out_t* o) {
+      o->win_status = c.take<u32>(V); o->win_k = c.take<u32>(V); o->win_ncomp = c.take<u32>(V);
+      o->comp_anchor = c.take<u32>(V * MC); o->comp_hap0 = c.take<u32>(V * MC); o->comp_nhaps = c.take<u32>(V * MC);
+      o->comp_cx = c.take<u32>(V * MC * 3); o->comp_cxf = c.take<double>(V * MC * 4);
+      o->hap_len = c.take<u32>(V * MH); o->hap_nruns = c.take<u32>(V * MH); o->hap_stats = c.take<double>(V * MH * 6);
+      o->hap_bases = c.take<u8>(V * MH * ML); o->hap_runs = c.take<u32>(V * MH * MR * 2);
+    };
+    carve_out(oprobe, &o2);
+    MA_HIP(ctx, ctx->spec_out.reserve(oprobe.off + 4096));
+    Carver co{static_cast<char*>(ctx->spec_out.p)};
+    carve_out(co, &o2);
+    auto add = [&](const void* src, void* dst, size_t bytes) {
+      if (src && dst) F.f[F.n++] = SpecField{static_cast<const u8*>(src), static_cast<u8*>(dst), static_cast<u32>(bytes)};
+    };
+    add(o2.win_status, out.win_status, 4); add(o2.win_k, out.win_k, 4); add(o2.win_ncomp, out.win_ncomp, 4);
+    add(o2.comp_anchor, out.comp_anchor, 4 * MC); add(o2.comp_hap0, out.comp_hap0, 4 * MC); add(o2.comp_nhaps, out.comp_nhaps, 4 * MC);
+    add(o2.comp_cx, out.comp_cx, 12 * MC); add(o2.comp_cxf, out.comp_cxf, 32 * MC);
+    add(o2.hap_len, out.hap_len, 4 * MH); add(o2.hap_nruns, out.hap_nruns, 4 * MH); add(o2.hap_stats, out.hap_stats, 48 * MH);
+    add(o2.hap_bases, out.hap_bases, MH * ML); add(o2.hap_runs, out.hap_runs, 8 * MH * MR);
+  }
+  // 4. the derived batch through this same stage, every window at its one rung, on workspaces of its own
+  std::swap(ctx->ws_nodes, ctx->spec_nodes);
+  std::swap(ctx->ws_build, ctx->spec_build);
+  ctx->spec_k = dk;
+  int const rc = launch_assemble(ctx, d2, o2, dgate);
+  ctx->spec_k = nullptr;
+  std::swap(ctx->ws_nodes, ctx->spec_nodes);
+  std::swap(ctx->ws_build, ctx->spec_build);
+  MA_TRY_RC(rc);
+  // 5. every pending window takes the first rung that resolved
+  MA_HIP(ctx, hipMemsetAsync(counters, 0, 8, ctx->stream));
+  hipLaunchKernelGGL(k_spec_select, dim3(P), dim3(256), 0, ctx->stream, dd, dfirst, dv, P, o2, F, out, win_flags, counters);
+  u32 host[2] = {0, 0};
+  MA_HIP(ctx, hipMemcpyAsync(host, counters, 8, hipMemcpyDeviceToHost, ctx->stream));
+  MA_HIP(ctx, ma_stream_sync(ctx));
+  ctx->stats[3] += host[0];
+  *still = host[1];
+  if (getenv("MA_VERBOSE"))
+    fprintf(stderr, "[microasm] assemble: ladder tail -- %u pending windows x up to %u rungs = %u attempts at once, %u still pending\n", P,
+            kSpecRungs, V, host[1]);
+  return MA_OK;
+}
+
 int launch_assemble(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& out, const u32* gate_approx) {
   int const n = b.n_windows;
   if (n == 0) return MA_OK;
@@ -122,6 +363,8 @@ int launch_assemble(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& out, const
     ws.rd_flag = c.take<u8>(static_cast<size_t>(b.n_reads) + 16);
   };
   GraphWs ws{};
+  bool const nested = ctx->spec_k != nullptr;  // the nested pass of speculate_tail: every window at its one rung
+  ws.win_kfirst = ctx->spec_k;
   u32 *win_flags = nullptr, *active = nullptr, *counters = nullptr;
   carve_misc(cm, ws, &win_flags, &active, &counters);
   MA_HIP(ctx, ctx->ws_nodes.reserve(cm.off + 4096));
@@ -194,7 +437,7 @@ int launch_assemble(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& out, const
     g.arena = c.take<uint4>(A * g.ac);
   };
 
-  ctx->stats[2] += static_cast<unsigned long long>(n);
+  if (!nested) ctx->stats[2] += static_cast<unsigned long long>(n);
   // Pass 0 runs every window with the planned capacities.  Windows that come back flagged TABLE_OVERFLOW (graph larger
   // than the node array, walk search larger than the arena: the reference has no such limits) are re-assembled from
   // scratch by up to two more passes with 4x / 16x the node capacity and 8x / 64x the search arena -- only they are active, the workspace
@@ -249,8 +492,15 @@ int launch_assemble(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& out, const
         ws.n_active = static_cast<int>(host_cnt[0]);
         ws.active = active;
         if (host_cnt[1] == 0) break;  // every window of the chunk is resolved (graph.cpp:106 loop exit)
+        if (!nested && kpass >= 1 && ws.n_active > 0 && static_cast<u32>(ws.n_active) <= kSpecPending && P.max_k > P.min_k &&
+            !getenv("MA_NO_SPEC")) {
+          // few windows are left on the ladder: their next rungs at once (speculate_tail), until none is pending
+          u32 still = 0;
+          MA_TRY_RC(speculate_tail(ctx, b, out, gate_approx, active, static_cast<u32>(ws.n_active), win_flags, counters + 8, &still));
+          continue;  // (the next k_select_active moves what is still pending to its next rung, or finds the ladder exhausted)
+        }
         if (ws.n_active > 0) {
-          ctx->stats[3] += static_cast<unsigned long long>(ws.n_active);
+          if (!nested) ctx->stats[3] += static_cast<unsigned long long>(ws.n_active);
           MA_TRY_RC(run_count_inst(ctx, b, ws, win0, nwin, counters));
           ws.tc_log2 = tc_log2_alloc;
           ws.mc_log2 = mc_log2_alloc;  // run_build_pass shrinks both to what this attempt needs

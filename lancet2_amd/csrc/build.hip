@@ -129,6 +129,16 @@ __global__ void k_select_active(GraphWs ws, int win0, int nwin, const u32* gate_
   int const w = win0 + i;
   if (ws.win_flags[w] & 1u) return;           // done in an earlier pass
   u32 const last = win_k[w];
+  if (ws.win_kfirst) {  // nested pass of the speculative ladder tail: one rung, chosen by the caller (gate already applied)
+    if (last) {
+      atomicOr(&ws.win_flags[w], 1u);         // its one attempt is over
+      return;
+    }
+    atomicAdd(n_active + 1, 1u);
+    win_k[w] = ws.win_kfirst[w];
+    active[atomicAdd(n_active, 1u)] = static_cast<u32>(w);
+    return;
+  }
   u32 k = last ? last + static_cast<u32>(k_step) : static_cast<u32>(min_k);
   u32 const ga = gate_approx[w];
   if (k <= ga) k += ((ga - k) / static_cast<u32>(k_step) + 1u) * static_cast<u32>(k_step);  // HasExactOrApproxRepeat -> continue

@@ -32,6 +32,7 @@ struct GraphWs {
   int k;                  // the ladder's first k: what a window without a k of its own yet is counted with (capacity planning)
   const u32* win_k;       // [n_windows] the k window w attempts in this pass (0: none yet) -- every window climbs its OWN
                           // ladder, so one pass serves windows at different k (k_select_active)
+  const u32* win_kfirst;  // non-null in the nested pass of the speculative ladder tail: window w is built at this k only
   u64 pk1;   // P^(k-1) mod 2^64
   u64 pinv;  // P^-1   mod 2^64
   int n_active;
