@@ -775,6 +775,46 @@ def test_whole_chain_parity_on_the_harder_bench_shapes(kw, pk):
         assert (wa["win_k"] > 40).any(), wa["win_k"].tolist()
 
 
+def test_ladder_tail_six_rungs_at_a_time_equals_rung_by_rung(monkeypatch):
+    """Once few windows are left on the k ladder their next six rungs are attempted at once (assemble.hip: speculate_tail --
+    the pending windows copied into a derived batch, one copy per rung, each window taking the first rung that resolved).
+    Same bytes and the same attempt count as the pass-per-rung loop (MA_NO_SPEC) and as the oracle: tandem duplications of
+    30 to 110 bases (ladders of 4 to 17 rungs, two rounds of six and more), a window that climbs to the top and stays
+    unresolved, windows that resolve on the first rung, and a ladder with a coarser step."""
+    from lancet2_amd.engine import Engine
+    wins = []
+    for i, dup in enumerate((30, 45, 64, 80, 110, 0, 0, 95)):
+        kw = dict(synth.CONFIGS["C2"])
+        if dup:
+            kw["tandem_dup"] = dup
+        wins.append(synth.make_window(84_000 + i, **kw))
+    arrs, n, nr = synth.pack_batch(wins)
+    for pk in (dict(), dict(min_k=13, max_k=61, k_step=12)):
+        params = capi.default_params(**pk)
+        orc = OracleEngine(params)
+        want = orc.assemble(arrs, n, nr)
+        got = {}
+        for mode in ("spec", "rungs"):
+            if mode == "rungs":
+                monkeypatch.setenv("MA_NO_SPEC", "1")
+            else:
+                monkeypatch.delenv("MA_NO_SPEC", raising=False)
+            eng = Engine(params)
+            try:
+                eng.timing_control(1)
+                a = eng.assemble(arrs, n, nr)
+                got[mode] = (a, eng.stats()["window_attempts"], sum(1 for k_, _ in eng.kernel_times() if k_ == "k_clean"))
+            finally:
+                eng.close()
+        monkeypatch.delenv("MA_NO_SPEC", raising=False)
+        for mode in got:
+            bad = compare_asm(params, got[mode][0], want, n)
+            assert not bad, (pk, mode, bad[:8])
+        assert got["spec"][1] == got["rungs"][1], (pk, got["spec"][1], got["rungs"][1])
+        assert got["spec"][2] < got["rungs"][2], (pk, got["spec"][2], got["rungs"][2])   # fewer passes is the point
+        assert (want["win_k"] > 50).any() and (want["win_k"] <= 31).any(), want["win_k"].tolist()
+
+
 def test_truncated_cigars_are_flagged_not_silent():
     """The alignment records hold max_cigar operations and the scoring epilogue (local_scorer.cpp:166-279) walks the whole
     CIGAR: with a cap that some read's CIGAR exceeds (max_cigar = 4 on indel-dense windows) every window that holds such
