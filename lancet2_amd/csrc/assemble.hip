@@ -216,8 +216,9 @@ __global__ __launch_bounds__(256) void k_spec_select(const SpecDesc* desc, const
   }
 }
 
-constexpr u32 kSpecPending = 256;  // windows pending at most for the tail to be attempted this way
-constexpr u32 kSpecRungs = 6;      // rungs per round
+constexpr u32 kSpecPendingCap = 2048;
+static u32 const kSpecPending = getenv("MA_SPEC_PENDING") ? static_cast<u32>(atoi(getenv("MA_SPEC_PENDING"))) : 256u;  // windows pending at most
+static u32 const kSpecRungs = getenv("MA_SPEC_RUNGS") ? static_cast<u32>(atoi(getenv("MA_SPEC_RUNGS"))) : 6u;          // rungs per round
 
 // `active[0, P)` = the pending windows of the chunk, win_k[w] = the rung each of them would attempt next (k_select_active
 // has just run).  Resolves them as far as kSpecRungs rungs go; *still = how many remain pending.
@@ -225,7 +226,7 @@ int speculate_tail(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& out, const 
                    u32* win_flags, u32* counters, u32* still) {
   ma_params_t const& prm = ctx->prm;
   // 1. what the pending windows look like
-  MA_HIP(ctx, ctx->spec_data.reserve(sizeof(SpecDesc) * kSpecPending + 4096));
+  MA_HIP(ctx, ctx->spec_data.reserve(sizeof(SpecDesc) * kSpecPendingCap + 4096));
   SpecDesc* d_desc = ctx->spec_data.as<SpecDesc>();
   hipLaunchKernelGGL(k_spec_describe, dim3((P + 255) / 256), dim3(256), 0, ctx->stream, b, active, P, out.win_k, gate_approx, d_desc);
   std::vector<SpecDesc> desc(P);
@@ -255,7 +256,7 @@ int speculate_tail(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& out, const 
   // device layout of the derived batch + its bookkeeping arrays
   Carver probe{nullptr};
   auto carve = [&](Carver& c, SpecBatch* d, SpecDesc** dd, SpecVirt** dv, u32** dfirst, u32** dk, u32** dgate) {
-    *dd = c.take<SpecDesc>(kSpecPending);
+    *dd = c.take<SpecDesc>(kSpecPendingCap);
     *dv = c.take<SpecVirt>(V + 1);
     *dfirst = c.take<u32>(P + 1);
     *dk = c.take<u32>(V);
@@ -321,14 +322,15 @@ int speculate_tail(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& out, const 
     add(o2.hap_len, out.hap_len, 4 * MH); add(o2.hap_nruns, out.hap_nruns, 4 * MH); add(o2.hap_stats, out.hap_stats, 48 * MH);
     add(o2.hap_bases, out.hap_bases, MH * ML); add(o2.hap_runs, out.hap_runs, 8 * MH * MR);
   }
-  // 4. the derived batch through this same stage, every window at its one rung, on workspaces of its own
+  // 4. the derived batch through this same stage, every window at its one rung.  The batch-level bookkeeping (flags, active
+  //    list, counters: ws_nodes) gets a buffer of its own; the per-window workspace (ws_build) is the caller's chunk's --
+  //    nothing of it is live between passes, and once the tail is attempted this way the chunk sees no ordinary pass again
+  //    (a second workspace of that size, 20 GB per lane, left the stages that follow nothing to reserve).
   std::swap(ctx->ws_nodes, ctx->spec_nodes);
-  std::swap(ctx->ws_build, ctx->spec_build);
   ctx->spec_k = dk;
   int const rc = launch_assemble(ctx, d2, o2, dgate);
   ctx->spec_k = nullptr;
   std::swap(ctx->ws_nodes, ctx->spec_nodes);
-  std::swap(ctx->ws_build, ctx->spec_build);
   MA_TRY_RC(rc);
   // 5. every pending window takes the first rung that resolved
   MA_HIP(ctx, hipMemsetAsync(counters, 0, 8, ctx->stream));
@@ -492,7 +494,7 @@ int launch_assemble(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& out, const
         ws.n_active = static_cast<int>(host_cnt[0]);
         ws.active = active;
         if (host_cnt[1] == 0) break;  // every window of the chunk is resolved (graph.cpp:106 loop exit)
-        if (!nested && kpass >= 1 && ws.n_active > 0 && static_cast<u32>(ws.n_active) <= kSpecPending && P.max_k > P.min_k &&
+        if (!nested && kpass >= 1 && ws.n_active > 0 && static_cast<u32>(ws.n_active) <= std::min(kSpecPending, kSpecPendingCap) && P.max_k > P.min_k &&
             !getenv("MA_NO_SPEC")) {
           // few windows are left on the ladder: their next rungs at once (speculate_tail), until none is pending
           u32 still = 0;

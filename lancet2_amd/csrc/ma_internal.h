@@ -74,9 +74,9 @@ struct ma_ctx {
   std::vector<ma::DevBuf> out_stage;
   // per-stage workspaces (grow-only, reused across calls)
   ma::DevBuf ws_build, ws_nodes, ws_clean, ws_poa, ws_aln, ws_misc, ws_gen;
-  // speculative tail of the k ladder (assemble.hip: speculate_tail): the derived batch, its outputs and the workspaces of the
+  // speculative tail of the k ladder (assemble.hip: speculate_tail): the derived batch, its outputs and the bookkeeping of the
   // nested pass; spec_k = the rung every window of the nested pass is built at (null outside of it)
-  ma::DevBuf spec_data, spec_out, spec_nodes, spec_build;
+  ma::DevBuf spec_data, spec_out, spec_nodes;
   const uint32_t* spec_k = nullptr;
   // annotation tables (annotate.hip): rebuilt when the GC fraction or max_hap_len changes
   ma::DevBuf ws_cx;
