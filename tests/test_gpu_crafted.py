@@ -106,6 +106,43 @@ def test_capacity_overflow_is_retried_inside_the_library(env, cfg, kw, monkeypat
     assert not bad, "\n".join(bad[:10])
 
 
+def test_capacity_retries_inside_the_ladders_speculative_tail(monkeypatch):
+    """Capacity overflow and the k ladder together: with the node array and the search arena forced small, windows overflow
+    on the first rungs and in the nested pass that attempts the ladder's tail six rungs at a time (assemble.hip:
+    speculate_tail) -- which retries with larger capacities itself, like the outer passes do.  Every window ends on the
+    oracle's k with the oracle's haplotypes and no flag left."""
+    from lancet2_amd.engine import Engine
+    params = capi.default_params()  # the reference's ladder, k = 13 ... 127
+    wins = []
+    for i, dup in enumerate((40, 70, 0, 100, 0, 55)):
+        kw = dict(synth.CONFIGS["C2"])
+        if dup:
+            kw["tandem_dup"] = dup
+        wins.append(synth.make_window(85_000 + i, **kw))
+    arrs, n, nr = synth.pack_batch(wins)
+    orc = OracleEngine(params)
+    wa = orc.assemble(arrs, n, nr)
+    monkeypatch.setenv("MA_NODE_CAP", "700")
+    monkeypatch.setenv("MA_ARENA_CAP", "64")
+    monkeypatch.setenv("MA_NO_CAP_RETRY", "1")
+    eng = Engine(params)
+    try:
+        a1 = eng.assemble(arrs, n, nr)
+    finally:
+        eng.close()
+    assert ((a1["win_status"] & capi.MA_W_TABLE_OVERFLOW) != 0).any(), "the forced capacities do not overflow"
+    monkeypatch.delenv("MA_NO_CAP_RETRY")
+    eng = Engine(params)
+    try:
+        a = eng.assemble(arrs, n, nr)
+    finally:
+        eng.close()
+    assert not (a["win_status"] & capi.MA_W_TABLE_OVERFLOW).any()
+    bad = compare_asm(params, a, wa, n)
+    assert not bad, "\n".join(bad[:10])
+    assert (wa["win_k"] > 50).any()
+
+
 def test_reads_beyond_the_aligner_limit_flag_their_window():
     """reads longer than 608 bases: never a silently truncated alignment, and (since round 3) not a failed batch either --
     the window is assembled, not genotyped, and says so (MA_W_READ_OVERFLOW; the whole story in
