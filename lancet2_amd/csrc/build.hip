@@ -1291,6 +1291,10 @@ __global__ __launch_bounds__(kMmT) void k_mm_lds(DBatch b, GraphWs ws) {
   __shared__ u32 l_set[kMmLdsCap];
   __shared__ u32 l_aux[kMmAux];  // walk: instance bases | run leaders | queue; afterwards: packed u16 support counters
   __shared__ u32 l_qn;
+  // sequence of every 128th instance: an instance's sequence is then a table look-up and a step or two along the instance
+  // bases instead of an 11-step binary search (a chain of dependent LDS reads per general instance, ~20 k per window)
+  constexpr u32 kBlkShift = 7, kBlkCap = 1024;  // windows of up to 128 Ki instances
+  __shared__ u16 l_blk[kBlkCap];
   u32* const l_base = l_aux;
   u16* const l_lead = reinterpret_cast<u16*>(l_aux + kSeqCap);
   u32* const l_queue = l_aux + kSeqCap + kSeqCap / 2;
@@ -1308,6 +1312,7 @@ __global__ __launch_bounds__(kMmT) void k_mm_lds(DBatch b, GraphWs ws) {
   // Windows with more general instances than one set holds (deep samples) take several passes, pass p handling the
   // table slots with slot % npass == p: every key lives in exactly one pass, so each pass is complete in itself.
   u32 const npass = (mode + kMmLdsMax - 1u) / kMmLdsMax;
+  IPROF_T0();
   for (u32 pass = 0; pass < npass; ++pass) {
   __syncthreads();
   for (u32 i = threadIdx.x; i < kMmLdsCap; i += kMmT) l_set[i] = 0;
@@ -1318,10 +1323,22 @@ __global__ __launch_bounds__(kMmT) void k_mm_lds(DBatch b, GraphWs ws) {
     l_lead[s] = static_cast<u16>(lead);
   }
   __syncthreads();
+  bool const blk_ok = ws.win_ninst[w] <= (kBlkCap << kBlkShift);
+  if (blk_ok && pass == 0)
+    for (u32 bk = threadIdx.x; (bk << kBlkShift) < ws.win_ninst[w]; bk += kMmT) l_blk[bk] = static_cast<u16>(seq_of(l_base, ns, bk << kBlkShift));
+  __syncthreads();
+  IPROF(12);  // set init, instance bases, run leaders
   u32 const ninst = ws.win_ninst[w], nref = ninst - ws.win_nread_inst[w];
   // (qname, role, node) of one general instance -> set
   auto const visit_slot = [&](u32 ii, u32 nslot) {
-    u32 const lead = l_lead[seq_of(l_base, ns, ii)];
+    u32 sq;
+    if (blk_ok) {
+      sq = l_blk[ii >> kBlkShift];
+      while (sq + 1 < ns && l_base[sq + 1] <= ii) ++sq;
+    } else {
+      sq = seq_of(l_base, ns, ii);
+    }
+    u32 const lead = l_lead[sq];
     if (npass > 1 && nslot % npass != pass) return;
     u32 const key = ((nslot << 11) | (lead - 1)) + 1u;
     u32 h = (key * 2654435761u) >> 17;  // kMmLdsCap == 1 << 15
@@ -1396,6 +1413,7 @@ __global__ __launch_bounds__(kMmT) void k_mm_lds(DBatch b, GraphWs ws) {
   // The set is not probed any more: its keys are compacted to the front (every thread reads its 32 entries into
   // registers first, so compacting in place is safe) and the rest of the set joins l_aux as counter space -- three
   // or four slot ranges instead of ten, each scanning only the keys.
+  IPROF(13);  // scan + queue + set inserts
   u32 nkeys = 0;
   {
     constexpr u32 kPer = kMmLdsCap / kMmT;  // 32 consecutive entries per thread
@@ -1430,6 +1448,7 @@ __global__ __launch_bounds__(kMmT) void k_mm_lds(DBatch b, GraphWs ws) {
     nkeys = total;
     __syncthreads();
   }
+  IPROF(14);  // key compaction
   // counter space: l_aux, then the free tail of l_set (u32 words, two u16 counters each)
   u32 const tail_words = kMmLdsCap - nkeys;
   u32 const ctr_words = kMmAux + tail_words;
@@ -1459,6 +1478,7 @@ __global__ __launch_bounds__(kMmT) void k_mm_lds(DBatch b, GraphWs ws) {
     }
     __syncthreads();
   }
+  IPROF(15);  // support counters
   }  // pass
 }
 

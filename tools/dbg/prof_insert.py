@@ -21,5 +21,7 @@ print({k: round(v, 2) for k, v in eng.kernel_times()})
 print({n: f"{100.0 * v / tot:.1f}%" for n, v in zip(names, d)})
 cn = ["stage", "lane loop", "slow queue", "-"]
 ct = sum(d[8:12]) or 1
+mt = sum(d[12:16]) or 1
+print("k_mm_lds", {n: f"{100.0 * v / mt:.1f}%" for n, v in zip(["init+bases+leaders", "scan+queue+inserts", "compaction", "support"], d[12:16])})
 print("k_classify", {n: f"{100.0 * v / ct:.1f}%" for n, v in zip(cn, d[8:12])}, "mean cycles(100MHz ticks) per tile:", ct / max(1, 2048 * 11))
 eng.close()
