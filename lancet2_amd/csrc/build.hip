@@ -939,7 +939,12 @@ extern "C" void ma_debug_iprof(unsigned long long* out) { (void)hipMemcpyFromSym
 // (3) k_support: read support of the FAST instances (node.cpp:18-24 + graph.h:102-117), one thread per group
 //     of adjacent reads with equal (qname, role, sample); per-reference-position counters live in LDS.
 constexpr u32 kSupCache = 2048;  // reads per window whose records k_support keeps in LDS
-__global__ __launch_bounds__(kBT) void k_support(DBatch b, GraphWs ws, u32* max_gen, u32 cache_cap) {
+// eight wavefronts per window: a wavefront's turn per group of mates is a chain of LDS look-ups and a round trip for the
+// instance words, ~80 groups in a row with four waves -- twice the waves, half the chain; and the workgroup's LDS is what
+// the counters and the cache need (40 KB: four workgroups, 32 waves per CU; with the old mapping's mask area it was 48 KB
+// and, at four waves each, 12 waves per CU)
+constexpr int kSupT = 512;
+__global__ __launch_bounds__(kSupT) void k_support(DBatch b, GraphWs ws, u32* max_gen, u32 cache_cap) {
   extern __shared__ unsigned char lds_build[];
   __shared__ u32 xs_flag;
   __shared__ u32 gen_count;  // instances routed through the general mate-mer set (sizes that set)
@@ -957,7 +962,7 @@ __global__ __launch_bounds__(kBT) void k_support(DBatch b, GraphWs ws, u32* max_
   u32* l_cnt = reinterpret_cast<u32*>(lds_build + off);
   off += 4u * ws.ref_stride * CW;
   u32* l_mask = reinterpret_cast<u32*>(lds_build + off);
-  off += 4u * max(static_cast<u32>(kMaskWords * kBT), ws.max_reads + 2u);
+  off += 4u * (ws.max_reads + 2u);  // (the group leaders)
   u32* l_xkey = reinterpret_cast<u32*>(lds_build + off);
   off += 4u * kXs;
   u32* l_xgrp = reinterpret_cast<u32*>(lds_build + off);
@@ -973,8 +978,8 @@ __global__ __launch_bounds__(kBT) void k_support(DBatch b, GraphWs ws, u32* max_
   i32* c_hint = reinterpret_cast<i32*>(c_ib + cache_cap);
   bool const cached = cache_cap != 0 && ns <= cache_cap;
   SeqInfo const rsi = seq_info(b, w, 0, k);
-  for (u32 i = threadIdx.x; i < ws.ref_stride * CW; i += kBT) l_cnt[i] = 0;
-  for (u32 i = threadIdx.x; i < kXs; i += kBT) {
+  for (u32 i = threadIdx.x; i < ws.ref_stride * CW; i += kSupT) l_cnt[i] = 0;
+  for (u32 i = threadIdx.x; i < kXs; i += kSupT) {
     l_xkey[i] = 0;
     l_xgrp[i] = 0;
   }
@@ -983,7 +988,7 @@ __global__ __launch_bounds__(kBT) void k_support(DBatch b, GraphWs ws, u32* max_
     gen_count = 0;
   }
   if (cached) {
-    for (u32 sx = 1 + threadIdx.x; sx < ns; sx += kBT) {
+    for (u32 sx = 1 + threadIdx.x; sx < ns; sx += kSupT) {
       u32 const r = b.read_win_off[w] + sx - 1;
       SeqInfo const si = seq_info(b, w, sx, k);
       c_meta[sx] = (b.read_flags[r] & 7u) | (ws.rd_flag[r] ? 8u : 0u) | (static_cast<u32>(b.read_sample[r]) << 8) | (min(si.nk, 0xFFFFu) << 16);
@@ -997,7 +1002,7 @@ __global__ __launch_bounds__(kBT) void k_support(DBatch b, GraphWs ws, u32* max_
   // (X) every (qname, role) key must belong to ONE sample and to ONE run of adjacent reads; otherwise the
   //     adjacent-group shortcut is not the whole story and every group goes through the general set.
   if (hints) {
-    for (u32 s_idx = 1 + threadIdx.x; s_idx < ns; s_idx += kBT) {
+    for (u32 s_idx = 1 + threadIdx.x; s_idx < ns; s_idx += kSupT) {
       u32 const r = b.read_win_off[w] + s_idx - 1;
       if (!(b.read_flags[r] & MA_RF_PASS)) continue;
       u32 const key = ((b.read_qname_id[r] << 1) | ((b.read_flags[r] & MA_RF_CASE) ? 1u : 0u)) + 1u;
@@ -1021,7 +1026,7 @@ __global__ __launch_bounds__(kBT) void k_support(DBatch b, GraphWs ws, u32* max_
   }
   __syncthreads();
   if (hints) {
-    for (u32 s_idx = 1 + threadIdx.x; s_idx < ns; s_idx += kBT) {
+    for (u32 s_idx = 1 + threadIdx.x; s_idx < ns; s_idx += kSupT) {
       u32 const r = b.read_win_off[w] + s_idx - 1;
       if (!(b.read_flags[r] & MA_RF_PASS)) continue;
       bool const leader = !(s_idx > 1 && same_group(b, r, r - 1));
@@ -1050,7 +1055,7 @@ __global__ __launch_bounds__(kBT) void k_support(DBatch b, GraphWs ws, u32* max_
   u32* const l_leaders = l_mask;  // [max_reads + 2] (the per-thread masks of the old mapping lived here)
   if (threadIdx.x == 0) n_leaders = 0;
   __syncthreads();
-  for (u32 s_idx = 1 + threadIdx.x; s_idx < ns; s_idx += kBT) {
+  for (u32 s_idx = 1 + threadIdx.x; s_idx < ns; s_idx += kSupT) {
     u32 const r0 = b.read_win_off[w] + s_idx - 1;
     if (!(b.read_flags[r0] & MA_RF_PASS)) continue;
     if (s_idx > 1 && same_group(b, r0, r0 - 1)) continue;  // not the leader
@@ -1064,7 +1069,7 @@ __global__ __launch_bounds__(kBT) void k_support(DBatch b, GraphWs ws, u32* max_
     u32 const ma_ = c_meta[sa], mb = c_meta[sb];
     return (mb & MA_RF_PASS) && c_qn[sa] == c_qn[sb] && ((ma_ ^ mb) & MA_RF_CASE) == 0 && ((ma_ ^ mb) & 0xFF00u) == 0;
   };
-  for (u32 gi = wave; gi < n_leaders; gi += kBT / 64) {
+  for (u32 gi = wave; gi < n_leaders; gi += kSupT / 64) {
     u32 const s_idx = l_leaders[gi];
     u32 const r0 = b.read_win_off[w] + s_idx - 1;
     u32 gsize = 1;
@@ -1175,7 +1180,7 @@ __global__ __launch_bounds__(kBT) void k_support(DBatch b, GraphWs ws, u32* max_
     atomicMax(max_gen, gen_count);
     if (!lds_ok) atomicMax(max_gen + 1, gen_count);
   }
-  for (u32 i = threadIdx.x; i < rsi.nk * CW; i += kBT) {
+  for (u32 i = threadIdx.x; i < rsi.nk * CW; i += kSupT) {
     u32 const v = l_cnt[i];
     if (v == 0) continue;
     u32 const p = i / CW, x = i % CW;
@@ -1851,14 +1856,14 @@ int run_build_pass(ma_ctx* ctx, const DBatch& b, GraphWs& ws, u32* counters_dev,
   ctx->toc();
   // + per-sequence cache (16 B per read of the busiest window, when that is at most kSupCache reads)
   u32 const sup_cache = ws.max_reads + 2 <= kSupCache ? ws.max_reads + 2 : 0u;
-  size_t const lds_s = 4ull * ws.ref_stride * (S + 2) + 4ull * std::max<size_t>(kMaskWords * kBT, ws.max_reads + 2) + 8ull * kXs + kXs + 64 +
+  size_t const lds_s = 4ull * ws.ref_stride * (S + 2) + 4ull * (ws.max_reads + 2) + 8ull * kXs + kXs + 64 +
                        16ull * sup_cache + 16;
   if (lds_s > 65536)
     MA_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_support), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     static_cast<int>(lds_s)));
   ctx->tic("k_support");
   MA_HIP(ctx, hipMemsetAsync(counters_dev + 1, 0, 8, ctx->stream));
-  hipLaunchKernelGGL(k_support, dim3(ws.n_active), dim3(kBT), lds_s, ctx->stream, b, ws, counters_dev + 1, sup_cache);
+  hipLaunchKernelGGL(k_support, dim3(ws.n_active), dim3(kSupT), lds_s, ctx->stream, b, ws, counters_dev + 1, sup_cache);
   ctx->toc();
   // windows whose general instances fit an LDS set are finished by k_mm_lds; the HBM-resident set only has to
   // hold what the remaining windows routed to it (usually nothing)
