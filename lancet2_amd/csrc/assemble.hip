@@ -19,13 +19,31 @@ int run_clean_pass(ma_ctx* ctx, const DBatch& b, const GraphWs& ws, const ma_asm
 
 namespace {
 
-__global__ void k_init_out(ma_asm_out_t o, u32* win_flags, int n) {
+__global__ void k_init_out(ma_asm_out_t o, u32* win_flags, int n, u32 MC, u32 MH) {
   int const i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   o.win_status[i] = MA_W_NO_HAPLOTYPE;
   o.win_k[i] = 0;
   o.win_ncomp[i] = 0;
   win_flags[i] = 0;
+  // the per-component / per-haplotype records start from zero: slots a window does not use read the same whatever the
+  // buffers held before (the host route copies these small arrays whole)
+  size_t const c0 = static_cast<size_t>(i) * MC, h0 = static_cast<size_t>(i) * MH;
+  for (u32 c = 0; c < MC; ++c) {
+    if (o.comp_anchor) o.comp_anchor[c0 + c] = 0;
+    if (o.comp_hap0) o.comp_hap0[c0 + c] = 0;
+    if (o.comp_nhaps) o.comp_nhaps[c0 + c] = 0;
+    if (o.comp_cx)
+      for (u32 x = 0; x < 3; ++x) o.comp_cx[(c0 + c) * 3 + x] = 0;
+    if (o.comp_cxf)
+      for (u32 x = 0; x < 4; ++x) o.comp_cxf[(c0 + c) * 4 + x] = 0.0;
+  }
+  for (u32 h = 0; h < MH; ++h) {
+    if (o.hap_len) o.hap_len[h0 + h] = 0;
+    if (o.hap_nruns) o.hap_nruns[h0 + h] = 0;
+    if (o.hap_stats)
+      for (u32 x = 0; x < 6; ++x) o.hap_stats[(h0 + h) * 6 + x] = 0.0;
+  }
 }
 
 // The classifier stages a tile of 64 reads (bases + qualities) in LDS: reads of up to kMaxAsmRead bases.  A window that
@@ -375,7 +393,8 @@ int launch_assemble(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& out, const
   ws.win_flags = win_flags;
   ws.num_samples = S;
 
-  hipLaunchKernelGGL(k_init_out, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, out, win_flags, n);
+  hipLaunchKernelGGL(k_init_out, dim3((n + 63) / 64), dim3(64), 0, ctx->stream, out, win_flags, n, static_cast<u32>(P.max_comps),
+                     static_cast<u32>(P.max_haps));
   hipLaunchKernelGGL(k_flag_long_reads, dim3((n + 3) / 4), dim3(256), 0, ctx->stream, b, out, win_flags);
 
   // capacity planning: instance maxima at the smallest k (the largest instance counts)

@@ -1097,6 +1097,62 @@ def test_queued_ahead_jobs_survive_a_change_of_lanes_and_tiny_batches():
         eng.close()
 
 
+@pytest.mark.parametrize("seed", [20261003, 7, 4242])
+def test_host_route_pipeline_under_a_random_sequence_of_calls(seed):
+    """A seeded random walk over what a caller can do with one MA_MEM_HOST context -- prefetch a batch (or the same one
+    twice, or a third while two wait), process a batch that was or was not prefetched, leave optional outputs out, switch
+    the timing mode, change the number of lanes, read counters and timers in between -- against results computed once up
+    front: the lanes' worker threads, the uploader thread and the calling thread must agree whatever the order."""
+    from lancet2_amd.engine import Engine
+    params = capi.default_params(min_k=25, max_k=25)
+    batches = [synth.make_config_batch("C2", 3, first_index=9950), synth.make_config_batch("C3", 5, first_index=9960),
+               synth.make_config_batch("C2", 8, first_index=9970, indel_rate=1e-3), synth.make_config_batch("C2", 1, first_index=9980)]
+    eng = Engine(params)
+    try:
+        want = [eng.process(a_, n_, nr_, debug=False) for a_, n_, nr_ in batches]
+    finally:
+        eng.close()
+    structs = [capi.make_batch_struct(a_, n_, nr_) for a_, n_, nr_ in batches]
+    optional = ("var_pl", "var_gq", "hap_runs", "comp_cx", "alt_length", "hap_stats")
+    rng = np.random.default_rng(seed)
+
+    def run(eng, i, leave_out):
+        arrs, n, nr = batches[i]
+        outs = [capi.alloc_host(capi.gate_out_spec(n)), capi.alloc_host(capi.asm_out_spec(params, n)),
+                capi.alloc_host(capi.var_out_spec(params, n)), capi.alloc_host(capi.geno_out_spec(params, n, nr, False))]
+        kept = [{k_: v_ for k_, v_ in d_.items() if k_ not in leave_out} for d_ in outs]
+        eng.process_device(structs[i], capi.fill_struct(capi.GateOut, kept[0]), capi.fill_struct(capi.AsmOut, kept[1]),
+                           capi.fill_struct(capi.VarOut, kept[2]), capi.fill_struct(capi.GenoOut, kept[3]))
+        g, a, v, q = outs
+        wg, wa, wv, wq = want[i]
+        assert np.array_equal(g["max_approx"], wg["max_approx"]), i
+        assert np.array_equal(a["win_status"], wa["win_status"]) and np.array_equal(v["win_nvars"], wv["win_nvars"]), i
+        assert np.array_equal(a["hap_len"], wa["hap_len"]) and np.array_equal(q["allele_counts"], wq["allele_counts"]), i
+        if not leave_out:
+            bad = compare_asm(params, a, wa, n) + compare_vars(params, v, wv, n)
+            assert not bad, (i, bad[:6])
+
+    eng = Engine(params)
+    try:
+        for step in range(60):
+            op = int(rng.integers(0, 10))
+            i = int(rng.integers(0, len(batches)))
+            if op <= 3:
+                eng.prefetch(structs[i])
+            elif op <= 7:
+                lo = tuple(k_ for k_ in optional if rng.random() < 0.25) if rng.random() < 0.4 else ()
+                run(eng, i, lo)
+            elif op == 8:
+                eng.timing_control(int(rng.integers(0, 3)))
+                eng.kernel_times()
+                eng.stats()
+            else:
+                eng.set_streams(int(rng.integers(0, 5)))
+        run(eng, 2, ())
+    finally:
+        eng.close()
+
+
 def test_device_buffers_need_no_padding_or_alignment():
     """MA_MEM_DEVICE passes the caller's pointers through: the byte arrays (reference, read bases, qualities) sized
     exactly -- without the 64 bytes of padding the host route adds --, at odd addresses, with junk on both sides, give the
