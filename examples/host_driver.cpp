@@ -28,6 +28,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <set>
 #include <mutex>
 #include <random>
 #include <string>
@@ -357,6 +358,7 @@ int main(int argc, char** argv) {
     ma_ctx_t* c2 = nullptr;
     for (auto& c : ctx) { ma_destroy(c); c = nullptr; }
     std::map<int, std::vector<std::string>> redo;  // window -> its records from the larger buffers
+    std::set<int> redone;                            // windows whose re-submission succeeded (possibly with no record)
     if (ma_create(&big, 0, MA_MEM_HOST, &c2) == MA_OK) {
       for (int w : flagged) {
         FlatBatch fb;
@@ -366,10 +368,21 @@ int main(int argc, char** argv) {
         if (ma_process_batch(c2, &fb.view, &o2.gate, &o2.asmb, &o2.vars, &o2.geno) == MA_OK) {
           std::vector<int> still;
           EmitRecords(big, o2, w, 1, &redo[w], &still);
+          redone.insert(w);
+        } else {
+          std::fprintf(stderr, "host_driver: re-submission of window %d failed: %s\n", w, ma_last_error(c2));
         }
       }
       ma_destroy(c2);
+    } else {
+      std::fprintf(stderr, "host_driver: could not create a context with larger output buffers\n");
     }
+    // a flagged window that could not be re-submitted keeps its (truncated) first-pass records, and the run says so
+    for (int w : flagged)
+      if (!redone.count(w)) {
+        std::fprintf(stderr, "host_driver: window %d: output capacity flag, first-pass records written as they are (TRUNCATED)\n", w);
+        rc_all = 6;
+      }
     // splice: the held-back records in window order, a re-submitted window's records in place of its first-pass ones
     int last_w = -1;
     auto flush_redo_upto = [&](int w_excl) {
@@ -383,7 +396,7 @@ int main(int argc, char** argv) {
       int const w = std::atoi(l.c_str());
       if (w != last_w) flush_redo_upto(w);
       last_w = w;
-      if (std::find(flagged.begin(), flagged.end(), w) != flagged.end()) continue;  // replaced
+      if (redone.count(w)) continue;  // replaced by the re-submitted window's records
       std::fprintf(out, "%s\n", l.c_str());
       n_records++;
     }

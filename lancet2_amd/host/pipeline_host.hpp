@@ -705,6 +705,14 @@ struct VariantRecord {
         if (s[a] > 0) return true;
     return false;
   }
+  // the flush-time rule of core/variant_store.cpp:62-66 / :88-92: no ALT support, or every ALT category is REF
+  bool HasNoSupport() const {
+    if (!HasAltSupport()) return true;
+    if (alt_type.empty()) return false;  // categories not filled in (TSV-only callers): the depth rule alone
+    for (int32_t t : alt_type)
+      if (t >= 0) return false;
+    return true;
+  }
   std::string AsLine(Reference const& ref_) const {
     std::string l = ref_.chroms[static_cast<size_t>(chrom)].name + "\t" + std::to_string(pos1) + "\t" + ref + "\t";
     for (size_t a = 0; a < alts.size(); ++a) l += (a ? "," : "") + alts[a];
@@ -742,7 +750,7 @@ class VariantStore {
         ++it;
         continue;
       }
-      if (v.HasAltSupport()) out.push_back(std::move(it->second));
+      if (!v.HasNoSupport()) out.push_back(std::move(it->second));
       it = data_.erase(it);
     }
     return out;  // (std::map iterates in key order: coordinate-sorted already)
@@ -750,7 +758,7 @@ class VariantStore {
   std::vector<VariantRecord> ExtractAll() {
     std::vector<VariantRecord> out;
     for (auto& kv : data_)
-      if (kv.second.HasAltSupport()) out.push_back(std::move(kv.second));
+      if (!kv.second.HasNoSupport()) out.push_back(std::move(kv.second));
     data_.clear();
     return out;
   }
@@ -762,7 +770,7 @@ class VariantStore {
 
 // ---- VCF text (caller/variant_call.cpp:100-520, caller/sample_format_data.cpp:32-98, cli/vcf_header_builder.cpp:28-63) -------
 // The record layout, INFO field and the FORMAT key are the reference's.  Of the 24 FORMAT values the engine's outputs give
-// GT, AD, ADF, ADR, DP, SDFC, PRAD, PANG, PL and GQ; the read-level statistics (RMQ, NPBQ, SB, SCA, FLD, RPCD, BQCD, MQCD, ASMD,
+// GT, AD, ADF, ADR, DP, SB, SDFC, PRAD, PANG, PL and GQ; the read-level statistics (RMQ, NPBQ, SCA, FLD, RPCD, BQCD, MQCD, ASMD,
 // CMLOD, FSSE, AHDD, HSE, PDCV) need per-read data the reference keeps in VariantSupport and are written as missing (".").
 inline constexpr const char* kVcfFormatKey =
     "GT:AD:ADF:ADR:DP:RMQ:NPBQ:SB:SCA:FLD:RPCD:BQCD:MQCD:ASMD:SDFC:PRAD:PANG:CMLOD:FSSE:AHDD:HSE:PDCV:PL:GQ";
@@ -888,16 +896,35 @@ inline std::string AsVcfRecord(VariantRecord const& r, Reference const& ref, std
     char polar[64];
     std::snprintf(polar, sizeof polar, "%.4f:%.4f", static_cast<double>(static_cast<float>(PolarRadius(r.ad[s][0], alt))),
                   static_cast<double>(static_cast<float>(PolarAngle(alt, r.ad[s][0]))));
+    // SB = ln(((rf+1)(ar+1)) / ((rr+1)(af+1))), ALT summed over the non-REF alleles, stored as f32, printed {:.3f}
+    // (caller/variant_support.cpp:197-237, variant_call.cpp:167, sample_format_data.cpp:82): a closed form of ADF / ADR
+    std::string sb = ".";
+    if (s < r.adf.size() && s < r.adr.size() && !r.adf[s].empty() && r.adf[s].size() == r.adr[s].size()) {
+      int af = 0, ar = 0;
+      for (size_t a = 1; a < r.adf[s].size(); ++a) {
+        af += static_cast<int>(r.adf[s][a]);
+        ar += static_cast<int>(r.adr[s][a]);
+      }
+      double const rf1 = static_cast<double>(static_cast<int>(r.adf[s][0]) + 1), rr1 = static_cast<double>(static_cast<int>(r.adr[s][0]) + 1);
+      double const af1 = static_cast<double>(af + 1), ar1 = static_cast<double>(ar + 1);
+      char sbuf[48];
+      std::snprintf(sbuf, sizeof sbuf, "%.3f", static_cast<double>(static_cast<float>(std::log((rf1 * ar1) / (rr1 * af1)))));
+      sb = sbuf;
+    }
     line += "\t" + gt + ":" + join(r.ad[s]) + ":" + (s < r.adf.size() ? join(r.adf[s]) : ".") + ":" +
-            (s < r.adr.size() ? join(r.adr[s]) : ".") + ":" + std::to_string(dp) + ":.:.:.:.:.:.:.:.:.:" + sdfc + ":" + polar +
+            (s < r.adr.size() ? join(r.adr[s]) : ".") + ":" + std::to_string(dp) + ":.:.:" + sb + ":.:.:.:.:.:.:" + sdfc + ":" + polar +
             ":.:.:.:.:.:" + pl + ":" + (s < r.gq.size() ? std::to_string(r.gq[s]) : ".");
   }
   return line;
 }
 
-// the engine's per-window outputs of one batch -> records (what VariantCall / CollectSupportedCalls hand to the store)
+// the engine's per-window outputs of one batch -> records: what VariantBuilder::CollectSupportedCalls hands to the store
+// (core/variant_builder.cpp:184-199).  A genotyped variant WITHOUT ALT support in any sample never becomes a VariantCall there,
+// so it is dropped HERE, before VariantStore::AddVariants: kept, it could replace a supported call of the same CHROM+POS+REF
+// from the overlapping window by having more total coverage, and the flush would then drop both.  `supported_only = false`
+// returns every record (tests; callers that want the raw per-window table).
 inline std::vector<VariantRecord> RecordsOfBatch(const ma_params_t& p, FlatBatch const& fb, const ma_var_out_t& v, const ma_geno_out_t& q,
-                                                 const ma_cx_out_t* cx = nullptr) {
+                                                 const ma_cx_out_t* cx = nullptr, bool supported_only = true) {
   std::vector<VariantRecord> out;
   int const MV = p.max_vars, MA = p.max_alts, S = p.num_samples, NA = MA + 1;
   for (size_t w = 0; w < fb.windows.size(); ++w) {
@@ -933,6 +960,7 @@ inline std::vector<VariantRecord> RecordsOfBatch(const ma_params_t& p, FlatBatch
         r.alt_type.push_back(v.alt_type[vi * MA + a]);
         r.alt_length.push_back(v.alt_length[vi * MA + a]);
       }
+      if (supported_only && !r.HasAltSupport()) continue;  // variant_builder.cpp:189-194
       if (w < fb.sample_cov.size()) r.sample_window_cov = fb.sample_cov[w];
       if (cx) {  // caller/raw_variant.h:43-46, base/sequence_complexity.cpp:462-469
         const int32_t* ci = cx->seq_cx_i + vi * 4;

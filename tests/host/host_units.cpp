@@ -169,6 +169,50 @@ int main() {
     auto const rest = st.ExtractAll();
     CHECK(rest.size() == 1 && rest[0].chrom == 2 && st.Size() == 0);
   }
+  {  // core/variant_builder.cpp:184-199 BEFORE core/variant_store.cpp:20-42: a call without ALT support never reaches the store.
+    // Two overlapping windows report the same CHROM + POS + REF; window 0's call has MORE total coverage but no ALT read,
+    // window 1's has less coverage and ALT support.  Filtering at the flush only, the unsupported call would win the
+    // keep-better-covered rule and the site would vanish from the output.
+    ma_params_t p{};
+    p.max_vars = 2; p.max_alts = 2; p.num_samples = 2; p.max_allele_bytes = 8;
+    FlatBatch fb;
+    fb.windows = {Window{0, 1, 1001, 0}, Window{0, 801, 1801, 1}};
+    int const MV = 2, MA = 2, S = 2, NA = 3;
+    std::vector<uint8_t> pool = {'A', 'T', 0, 0, 0, 0, 0, 0, 'A', 'T', 0, 0, 0, 0, 0, 0};
+    std::vector<uint32_t> win_nvars = {1, 1}, var_pos(2 * MV, 0), var_ref_off(2 * MV, 0), var_ref_len(2 * MV, 1), var_nalts(2 * MV, 1);
+    std::vector<uint32_t> alt_off(2 * MV * MA, 1), alt_len(2 * MV * MA, 1);
+    std::vector<int32_t> alt_type(2 * MV * MA, 0), alt_length(2 * MV * MA, 1);
+    var_pos[0] = 899;          // window 0 starts at 1   -> POS 900
+    var_pos[1 * MV] = 99;      // window 1 starts at 801 -> POS 900
+    std::vector<double> var_qual(2 * MV, 0.0);
+    var_qual[1 * MV] = 33.0;
+    std::vector<uint32_t> counts(2 * MV * S * NA * 2, 0);
+    auto cnt = [&](int w, int s, int al) { return &counts[((static_cast<size_t>(w * MV) * S + s) * NA + al) * 2]; };
+    cnt(0, 0, 0)[0] = 20; cnt(0, 0, 0)[1] = 20; cnt(0, 1, 0)[0] = 30; cnt(0, 1, 0)[1] = 30;   // 100 REF reads, no ALT
+    cnt(1, 0, 0)[0] = 5; cnt(1, 0, 0)[1] = 5; cnt(1, 1, 0)[0] = 6; cnt(1, 1, 0)[1] = 6;       // 22 REF ...
+    cnt(1, 1, 1)[0] = 3; cnt(1, 1, 1)[1] = 2;                                                 // ... and 5 ALT in the tumour
+    ma_var_out_t v{};
+    v.allele_pool = pool.data(); v.win_nvars = win_nvars.data(); v.var_pos = var_pos.data(); v.var_ref_off = var_ref_off.data();
+    v.var_ref_len = var_ref_len.data(); v.var_nalts = var_nalts.data(); v.alt_off = alt_off.data(); v.alt_len = alt_len.data();
+    v.alt_type = alt_type.data(); v.alt_length = alt_length.data();
+    ma_geno_out_t q{};
+    q.var_qual = var_qual.data(); q.allele_counts = counts.data();
+    auto const all = RecordsOfBatch(p, fb, v, q, nullptr, /*supported_only=*/false);
+    CHECK(all.size() == 2 && all[0].TotalCoverage() == 100 && all[1].TotalCoverage() == 27 && !all[0].HasAltSupport());
+    auto const calls = RecordsOfBatch(p, fb, v, q);
+    CHECK(calls.size() == 1 && calls[0].window_index == 1 && calls[0].pos1 == 900 && calls[0].HasAltSupport());
+    VariantStore st;
+    st.AddVariants(calls);
+    auto const out = st.ExtractAll();
+    CHECK(out.size() == 1 && out[0].qual == 33.0 && out[0].ad[1][1] == 5);
+    VariantStore wrong;  // the order this test guards against: the site is lost
+    wrong.AddVariants(all);
+    CHECK(wrong.ExtractAll().empty());
+    // flush-time rule (variant_store.cpp:62-66): ALT depth but every category REF -> not written
+    VariantRecord refonly{0, 10, "A", {"A"}, 1.0, {{3, 2}, {1, 1}}, 0};
+    refonly.alt_type = {-1};
+    CHECK(refonly.HasAltSupport() && refonly.HasNoSupport());
+  }
   {  // VCF text (caller/variant_call.cpp, caller/sample_format_data.cpp:32-98)
     // GL index -> genotype: 0/0 0/1 1/1 0/2 1/2 2/2 0/3 ... (variant_call.cpp:262-290)
     const int want[10][2] = {{0, 0}, {0, 1}, {1, 1}, {0, 2}, {1, 2}, {2, 2}, {0, 3}, {1, 3}, {2, 3}, {3, 3}};
@@ -193,7 +237,9 @@ int main() {
     std::string const line = AsVcfRecord(r, ref, {Tag::CTRL, Tag::CASE}, true);
     CHECK(line.rfind("chr1\t1500\t.\tA\tT,G\t12.35\t.\tCASE;MULTIALLELIC;TYPE=SNV,SNV;LENGTH=1,1\t", 0) == 0);
     CHECK(line.find(std::string("\t") + kVcfFormatKey + "\t0/0:12,0,0:6,0,0:6,0,0:12:") != std::string::npos);
-    CHECK(line.find("\t0/1:9,6,1:5,3,1:4,3,0:16:.:.:.:.:.:.:.:.:.:0.50:") != std::string::npos);
+    // SB (variant_support.cpp:197-237): ln((5+1)(3+0+1) / ((4+1)(3+1+1))) = ln(24/25) = -0.041; sample 0: ln(7*1/(7*1)) = 0
+    CHECK(line.find("\t0/1:9,6,1:5,3,1:4,3,0:16:.:.:-0.041:.:.:.:.:.:.:0.50:") != std::string::npos);
+    CHECK(line.find(":12:.:.:0.000:.:") != std::string::npos);
     CHECK(line.find(":120,0,200,90,210,400:90") != std::string::npos);
     size_t colons = 0;  // 24 FORMAT values per sample
     for (char c : line.substr(line.rfind('\t'))) colons += c == ':';

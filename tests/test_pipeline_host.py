@@ -161,7 +161,7 @@ def test_pipeline_driver_reproduces_the_oracle_with_overlap_duplicates_merged(tm
     params = capi.default_params(min_k=25, max_k=25)
     dt = {"u8": np.uint8, "u32": np.uint32, "u64": np.uint64, "i32": np.int32}
     store = {}
-    n_windows = n_duplicates = 0
+    n_windows = n_duplicates = n_unsupported = 0
     starts = []
     for b in sorted(os.listdir(dump)):
         arrs = {f.rsplit(".", 1)[0]: np.fromfile(str(dump / b / f), dtype=dt[f.rsplit(".", 1)[1]]) for f in os.listdir(dump / b)}
@@ -184,6 +184,11 @@ def test_pipeline_driver_reproduces_the_oracle_with_overlap_duplicates_merged(tm
                 rec = (int(wins[w, 1]) + pos, ref.decode(), ",".join(x.decode() for x in alts), float(q["var_qual"][vi]), ads)
                 key = (rec[0], rec[1])  # one chromosome: CHROM + POS + REF (variant_call.cpp:37)
                 cov = sum(sum(x) for x in ads)
+                # core/variant_builder.cpp:184-199 (CollectSupportedCalls) runs BEFORE the store: a genotyped variant without
+                # ALT support in any sample never becomes a VariantCall, so it cannot shadow a supported duplicate
+                if not any(sum(x[1:]) > 0 for x in ads):
+                    n_unsupported += 1
+                    continue
                 # core/variant_store.cpp:31-42: a duplicate replaces the stored call only if it has MORE total coverage
                 n_duplicates += key in store
                 if key not in store or sum(sum(x) for x in store[key][4]) < cov:
