@@ -420,6 +420,9 @@ int launch_assemble(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& out, const
   if (const char* e = getenv("MA_NODE_CAP")) nc0 = std::max<u32>(256, static_cast<u32>(atoi(e)));  // tests: force the retry passes
   u32 ac0 = 1u << 16;
   if (const char* e = getenv("MA_ARENA_CAP")) ac0 = static_cast<u32>(atoi(e));
+  ws.vc = 256;
+  ws.cg_sc = 1024;
+  ws.pool_cap = 16384;
 
   // per-window workspace footprint -> chunk size
   auto carve_ws = [&](Carver& c, GraphWs& g, size_t A) {
@@ -456,6 +459,29 @@ int launch_assemble(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& out, const
     g.sl_desc = c.take<u32>(A * NC);
     g.scratch = c.take<u32>(A * NC * 32);
     g.arena = c.take<uint4>(A * g.ac);
+    // compact graph (k_clean_chains -> k_clean_tail)
+    size_t const VC = g.vc;
+    g.cg_state = c.take<u32>(A);
+    g.cg_hdr = c.take<u32>(A * kCgHdr);
+    g.cg_cnt = c.take<u32>(A * VC * S);
+    g.cg_role = c.take<u32>(A * VC * 2);
+    g.cg_bsrc = c.take<u32>(A * VC);
+    g.cg_blen = c.take<u32>(A * VC);
+    g.cg_len = c.take<u32>(A * VC);
+    g.cg_comp = c.take<u32>(A * VC);
+    g.cg_label = c.take<u8>(A * VC);
+    g.cg_sign = c.take<u8>(A * VC);
+    g.cg_bsign = c.take<u8>(A * VC);
+    g.cg_nedge = c.take<u8>(A * VC);
+    g.cg_alive = c.take<u8>(A * VC);
+    g.cg_edge = c.take<u32>(A * VC * kCgEdgeCap);
+    g.cg_head = c.take<u32>(A * VC);
+    g.cg_tail = c.take<u32>(A * VC);
+    g.cg_snext = c.take<u32>(A * VC);
+    g.cg_sprev = c.take<u32>(A * VC);
+    g.cg_sdesc = c.take<u32>(A * VC);
+    g.cg_scratch = c.take<u32>(A * static_cast<size_t>(g.cg_sc) * 32);
+    g.cg_pool = c.take<u8>(A * static_cast<size_t>(g.pool_cap));
   };
 
   if (!nested) ctx->stats[2] += static_cast<unsigned long long>(n);

@@ -72,7 +72,12 @@ struct Win {
   u32* tail;
   u32* snext;
   u32* sprev;
-  u32* sdesc;
+  u32* sdesc;         // slice = (start, len, revcomp) of a BASE STRING: sd_make()
+  const u32* bsrc;    // base string of slice s: bit31 = read buffer (else ref), bit30 = the window's string pool; low bits = byte offset
+  const u32* blen;    // its length; null: every base string is an original k-mer (length k)
+  const u8* bsign;    // 1: the bytes are the stored orientation, 0: its reverse complement (a k-mer first seen on the other strand)
+  const u8* pool;     // merged strings written by k_clean_chains (null on the raw graph)
+  u32 ecap;           // edge slots per node in `edge`
   u32* scratch;
   u32* link;  // LDS, 8 KB: component labels, then the chain-following table, then the slice ranks
   bool ranked;  // link holds rank_slices() of the current graph
@@ -83,6 +88,13 @@ struct Win {
   unsigned long long dbg_t[6];
 #endif
 };
+
+// slice descriptor: start (15 bit) | length (15 bit) << 15 | reverse complement << 30
+__device__ __forceinline__ u32 sd_make(u32 st, u32 ln, u32 rc) { return st | (ln << 15) | (rc << 30); }
+__device__ __forceinline__ u32 sd_st(u32 d) { return d & 0x7FFFu; }
+__device__ __forceinline__ u32 sd_ln(u32 d) { return (d >> 15) & 0x7FFFu; }
+__device__ __forceinline__ u32 sd_rc(u32 d) { return (d >> 30) & 1u; }
+__device__ __forceinline__ u32 base_len(const Win& g, u32 s) { return g.blen ? g.blen[s] : static_cast<u32>(g.k); }
 
 __device__ __forceinline__ u32 kind_rev(u32 kind) { return (((kind & 1u) ^ 1u) << 1) | (((kind >> 1) & 1u) ^ 1u); }
 __device__ __forceinline__ u32 mirror_of(u32 self, u32 val) { return (self << 2) | kind_rev(val & 3u); }
@@ -115,11 +127,11 @@ __device__ __forceinline__ u32 nd_confidence(const Win& g, u32 i) {
 }
 
 __device__ __forceinline__ void emplace_edge(Win& g, u32 i, u32 val) {  // node.h:59-64
-  u32* e = g.edge + i * kEdgeCap;
+  u32* e = g.edge + i * g.ecap;
   int const n = g.nedge[i];
   for (int x = 0; x < n; ++x)
     if (e[x] == val) return;
-  if (n >= kEdgeCap) {
+  if (n >= static_cast<int>(g.ecap)) {
     g.flags |= 4u;
     return;
   }
@@ -127,7 +139,7 @@ __device__ __forceinline__ void emplace_edge(Win& g, u32 i, u32 val) {  // node.
   g.nedge[i] = static_cast<u8>(n + 1);
 }
 __device__ __forceinline__ void erase_edge(Win& g, u32 i, u32 val) {  // node.h:66-71
-  u32* e = g.edge + i * kEdgeCap;
+  u32* e = g.edge + i * g.ecap;
   int const n = g.nedge[i];
   for (int x = 0; x < n; ++x)
     if (e[x] == val) {
@@ -137,7 +149,7 @@ __device__ __forceinline__ void erase_edge(Win& g, u32 i, u32 val) {  // node.h:
     }
 }
 __device__ __forceinline__ bool has_self_loop(const Win& g, u32 i) {
-  const u32* e = g.edge + i * kEdgeCap;
+  const u32* e = g.edge + i * g.ecap;
   for (int x = 0; x < g.nedge[i]; ++x)
     if ((e[x] >> 2) == i) return true;
   return false;
@@ -145,7 +157,7 @@ __device__ __forceinline__ bool has_self_loop(const Win& g, u32 i) {
 // FindEdgesInDirection (node.cpp:118-127): count + first match
 __device__ __forceinline__ int edges_in_dir(const Win& g, u32 i, bool dflt, u32* first) {
   u32 const exp_minus = dflt ? (g.sign[i] ? 0u : 1u) : (g.sign[i] ? 1u : 0u);
-  const u32* e = g.edge + i * kEdgeCap;
+  const u32* e = g.edge + i * g.ecap;
   int c = 0;
   for (int x = 0; x < g.nedge[i]; ++x)
     if (((e[x] >> 1) & 1u) == exp_minus) {
@@ -158,7 +170,7 @@ __device__ __forceinline__ int edges_in_dir(const Win& g, u32 i, bool dflt, u32*
 // Graph::RemoveNode (graph.cpp:347-361)
 __device__ __forceinline__ void remove_node(Win& g, u32 i) {
   if (!g.alive[i]) return;
-  const u32* e = g.edge + i * kEdgeCap;
+  const u32* e = g.edge + i * g.ecap;
   for (int x = 0; x < g.nedge[i]; ++x) {
     u32 const d = e[x] >> 2;
     if (d == i) continue;
@@ -201,8 +213,8 @@ __device__ __forceinline__ void slices_reverse(Win& g, u32 node) {  // sequence 
     g.snext[s] = g.sprev[s];
     g.sprev[s] = nx;
     u32 const d = g.sdesc[s];
-    u32 const st = d & 0xFFu, ln = (d >> 8) & 0xFFu, rc = (d >> 16) & 1u;
-    g.sdesc[s] = (static_cast<u32>(g.k) - st - ln) | (ln << 8) | ((rc ^ 1u) << 16);
+    u32 const st = sd_st(d), ln = sd_ln(d), rc = sd_rc(d);
+    g.sdesc[s] = sd_make(base_len(g, s) - st - ln, ln, rc ^ 1u);
     s = nx;
   }
   u32 const h = g.head[node];
@@ -213,14 +225,14 @@ __device__ __forceinline__ void slices_drop_front(Win& g, u32 node, u32 nb) {
   while (nb > 0) {
     u32 const s = g.head[node];
     u32 const d = g.sdesc[s];
-    u32 const st = d & 0xFFu, ln = (d >> 8) & 0xFFu;
+    u32 const st = sd_st(d), ln = sd_ln(d);
     if (ln <= nb) {
       nb -= ln;
       u32 const nx = g.snext[s];
       g.head[node] = nx;
       if (nx != kNoNode) g.sprev[nx] = kNoNode; else g.tail[node] = kNoNode;
     } else {
-      g.sdesc[s] = (st + nb) | ((ln - nb) << 8) | (d & 0x10000u);
+      g.sdesc[s] = sd_make(st + nb, ln - nb, sd_rc(d));
       nb = 0;
     }
   }
@@ -229,14 +241,14 @@ __device__ __forceinline__ void slices_drop_back(Win& g, u32 node, u32 nb) {
   while (nb > 0) {
     u32 const s = g.tail[node];
     u32 const d = g.sdesc[s];
-    u32 const st = d & 0xFFu, ln = (d >> 8) & 0xFFu;
+    u32 const st = sd_st(d), ln = sd_ln(d);
     if (ln <= nb) {
       nb -= ln;
       u32 const pv = g.sprev[s];
       g.tail[node] = pv;
       if (pv != kNoNode) g.snext[pv] = kNoNode; else g.head[node] = kNoNode;
     } else {
-      g.sdesc[s] = st | ((ln - nb) << 8) | (d & 0x10000u);
+      g.sdesc[s] = sd_make(st, ln - nb, sd_rc(d));
       nb = 0;
     }
   }
@@ -286,7 +298,7 @@ __device__ __forceinline__ void merge_node(Win& g, u32 x, u32 b, u32 kind) {
 __device__ __forceinline__ bool is_potential_buddy(const Win& g, u32 src, u32 conn) {
   u32 const nb = conn >> 2;
   if (g.nedge[src] == 1 && g.nedge[nb] == 1) {
-    if ((g.edge[src * kEdgeCap] >> 2) == nb && (g.edge[nb * kEdgeCap] >> 2) == src) return false;
+    if ((g.edge[src * g.ecap] >> 2) == nb && (g.edge[nb * g.ecap] >> 2) == src) return false;
   }
   if (g.nedge[nb] > 2 || g.nedge[nb] == 0 || has_self_loop(g, nb)) return false;
   u32 const expected = mirror_of(src, conn);  // nbour -> src
@@ -334,7 +346,7 @@ __device__ __forceinline__ void compress_node(Win& g, u32 nid, bool dflt, u8* ab
     u32 const mirror = mirror_of(nid, s2o);
     int const nob = g.nedge[ob];
     for (int x = 0; x < nob; ++x) {
-      u32 const o2n = g.edge[ob * kEdgeCap + x];
+      u32 const o2n = g.edge[ob * g.ecap + x];
       if (o2n == mirror) continue;
       u32 const nbd = o2n >> 2;
       u32 const o2n_src_minus = (o2n >> 1) & 1u, o2n_dst_minus = o2n & 1u;
@@ -354,7 +366,7 @@ __device__ __forceinline__ bool is_potential_buddy_f2(const Win& g, u32 src, u32
   u32 const nb = conn >> 2;
   *f2node = kNoNode;
   if (g.nedge[src] == 1 && g.nedge[nb] == 1) {
-    if ((g.edge[src * kEdgeCap] >> 2) == nb && (g.edge[nb * kEdgeCap] >> 2) == src) return false;
+    if ((g.edge[src * g.ecap] >> 2) == nb && (g.edge[nb * g.ecap] >> 2) == src) return false;
   }
   if (g.nedge[nb] > 2 || g.nedge[nb] == 0 || has_self_loop(g, nb)) return false;
   u32 const expected = mirror_of(src, conn);
@@ -386,7 +398,7 @@ __device__ __forceinline__ void compress_node_fast(Win& g, u32 nid, bool dflt, u
   int const S = g.S;
   u32 xe0, xe1;
   {
-    uint2 const ev = *reinterpret_cast<const uint2*>(g.edge + static_cast<size_t>(nid) * kEdgeCap);
+    uint2 const ev = *reinterpret_cast<const uint2*>(g.edge + static_cast<size_t>(nid) * g.ecap);
     xe0 = ev.x;
     xe1 = ev.y;
   }
@@ -413,8 +425,8 @@ __device__ __forceinline__ void compress_node_fast(Win& g, u32 nid, bool dflt, u
   auto flush = [&]() {
     if (!dirty) return;
     g.nedge[nid] = static_cast<u8>(xn);
-    g.edge[static_cast<size_t>(nid) * kEdgeCap] = xe0;
-    g.edge[static_cast<size_t>(nid) * kEdgeCap + 1] = xe1;
+    g.edge[static_cast<size_t>(nid) * g.ecap] = xe0;
+    g.edge[static_cast<size_t>(nid) * g.ecap + 1] = xe1;
     if (xloaded) {
       g.len[nid] = xlen;
       g.label[nid] = static_cast<u8>(xlabel);
@@ -443,7 +455,7 @@ __device__ __forceinline__ void compress_node_fast(Win& g, u32 nid, bool dflt, u
     if (static_cast<i64>(d) == g.source || static_cast<i64>(d) == g.sink) break;
     // ---- batch 1: the record of b, straight from memory (the previous step's stores to it are ordered before) ----
     u32 const bn = g.nedge[d];
-    uint2 const bev = *reinterpret_cast<const uint2*>(g.edge + static_cast<size_t>(d) * kEdgeCap);
+    uint2 const bev = *reinterpret_cast<const uint2*>(g.edge + static_cast<size_t>(d) * g.ecap);
     u32 const be0 = bev.x, be1 = bev.y;
     u32 const bsign = g.sign[d];
     u32 const blen = g.len[d], blabel = g.label[d], bhead = g.head[d], btail = g.tail[d];
@@ -475,7 +487,7 @@ __device__ __forceinline__ void compress_node_fast(Win& g, u32 nid, bool dflt, u
     u32 const fn = f2 >> 2;
     // ---- batch 2: the far neighbour and b's first slice ----
     u32 fnn = g.nedge[fn];
-    uint2 const fev = *reinterpret_cast<const uint2*>(g.edge + static_cast<size_t>(fn) * kEdgeCap);
+    uint2 const fev = *reinterpret_cast<const uint2*>(g.edge + static_cast<size_t>(fn) * g.ecap);
     u32 const bdesc_head = g.sdesc[bhead != kNoNode ? bhead : d];
     // one wait for the whole batch: without this the loads that are only used after the next test are sunk behind it
     asm volatile("" ::"v"(fnn), "v"(fev.x), "v"(fev.y), "v"(bdesc_head));
@@ -502,16 +514,16 @@ __device__ __forceinline__ void compress_node_fast(Win& g, u32 nid, bool dflt, u
     bool const append = kind == 0 || kind == 1;
     bool const rc = kind == 1 || kind == 2;
     if (bhead != kNoNode && bhead == btail) {  // single slice: everything in registers
-      u32 st = bdesc & 0xFFu, ln = (bdesc >> 8) & 0xFFu, rcb = (bdesc >> 16) & 1u;
+      u32 st = sd_st(bdesc), ln = sd_ln(bdesc), rcb = sd_rc(bdesc);
+      u32 const s = bhead;
       if (rc) {
-        st = static_cast<u32>(g.k) - st - ln;
+        st = base_len(g, s) - st - ln;
         rcb ^= 1u;
       }
-      u32 const s = bhead;
       if (ln > K1) {
         if (append) st += K1;
         ln -= K1;
-        g.sdesc[s] = st | (ln << 8) | (rcb << 16);
+        g.sdesc[s] = sd_make(st, ln, rcb);
         if (append) {
           g.snext[xtail] = s;
           g.sprev[s] = xtail;
@@ -596,9 +608,9 @@ __device__ __forceinline__ void compress_node_fast(Win& g, u32 nid, bool dflt, u
         fnn--;
       }
       g.nedge[fn] = static_cast<u8>(fnn);
-      g.edge[static_cast<size_t>(fn) * kEdgeCap] = fe0;
-      g.edge[static_cast<size_t>(fn) * kEdgeCap + 1] = fe1;
-      if (fnn > 2) g.edge[static_cast<size_t>(fn) * kEdgeCap + 2] = fe2;
+      g.edge[static_cast<size_t>(fn) * g.ecap] = fe0;
+      g.edge[static_cast<size_t>(fn) * g.ecap + 1] = fe1;
+      if (fnn > 2) g.edge[static_cast<size_t>(fn) * g.ecap + 2] = fe2;
     }
     CCOUNT(11);
 #ifdef MA_PROFILE
@@ -633,7 +645,7 @@ __device__ __forceinline__ void set_links(Win& g, u32 i, u32 n_edges, u32 e0, u3
 __device__ __forceinline__ void build_links(Win& g) {
   u32 const top = g.n < kLinkCap ? g.n : kLinkCap;
   for (u32 i = lane_id(); i < top; i += 64) {
-    uint2 const ev = *reinterpret_cast<const uint2*>(g.edge + static_cast<size_t>(i) * kEdgeCap);
+    uint2 const ev = *reinterpret_cast<const uint2*>(g.edge + static_cast<size_t>(i) * g.ecap);
     set_links(g, i, g.alive[i] ? g.nedge[i] : 0u, ev.x, ev.y);
   }
   wave_sync_mem();
@@ -666,7 +678,7 @@ __device__ __forceinline__ bool compress_walk_par(Win& g, u32 nid, bool dflt, u8
   int const S = g.S;
   u32 xe0, xe1;
   {
-    uint2 const ev = *reinterpret_cast<const uint2*>(g.edge + static_cast<size_t>(nid) * kEdgeCap);
+    uint2 const ev = *reinterpret_cast<const uint2*>(g.edge + static_cast<size_t>(nid) * g.ecap);
     xe0 = ev.x;
     xe1 = xn == 2 ? ev.y : 0u;
   }
@@ -715,7 +727,7 @@ __device__ __forceinline__ bool compress_walk_par(Win& g, u32 nid, bool dflt, u8
     bool const act = lane < nst;
     u32 const d = act ? (my_cand >> 2) : nid;
     u32 const bn = g.nedge[d];
-    uint2 const bev = *reinterpret_cast<const uint2*>(g.edge + static_cast<size_t>(d) * kEdgeCap);
+    uint2 const bev = *reinterpret_cast<const uint2*>(g.edge + static_cast<size_t>(d) * g.ecap);
     u32 const bsign = g.sign[d];
     u32 const blen = g.len[d], blabel = g.label[d], bhead = g.head[d], btail = g.tail[d];
     u32 const a0 = g.cnt[d * S], a1 = S > 1 ? g.cnt[d * S + 1] : 0u;
@@ -832,16 +844,16 @@ __device__ __forceinline__ bool compress_walk_par(Win& g, u32 nid, bool dflt, u8
     xlen = __builtin_amdgcn_readlane(this_len, r - 1);
     // ---- slices: trim k-1 bases off the joining end, then link the survivors in walk order ----
     {
-      u32 st = bdesc & 0xFFu, ln = (bdesc >> 8) & 0xFFu, rcb = (bdesc >> 16) & 1u;
+      u32 st = sd_st(bdesc), ln = sd_ln(bdesc), rcb = sd_rc(bdesc);
       if (kind == 1 || kind == 2) {
-        st = K - st - ln;
+        st = base_len(g, sl) - st - ln;
         rcb ^= 1u;
       }
       bool const keep = in && ln > K1;
       if (keep) {
         if (append) st += K1;
         ln -= K1;
-        g.sdesc[bhead] = st | (ln << 8) | (rcb << 16);
+        g.sdesc[bhead] = sd_make(st, ln, rcb);
       }
       unsigned long long const kept = __ballot(keep);
       unsigned long long const below = kept & ((1ull << lane) - 1ull), above = kept & ~((2ull << lane) - 1ull);
@@ -885,7 +897,7 @@ __device__ __forceinline__ bool compress_walk_par(Win& g, u32 nid, bool dflt, u8
     {
       u32 const fl = f2_last >> 2;
       u32 fnl = g.nedge[fl];
-      uint2 const fev = *reinterpret_cast<const uint2*>(g.edge + static_cast<size_t>(fl) * kEdgeCap);
+      uint2 const fev = *reinterpret_cast<const uint2*>(g.edge + static_cast<size_t>(fl) * g.ecap);
       u32 fe0 = fev.x, fe1 = fev.y, fe2 = 0;
       u32 const add = mirror_of(nid, s2n_last), del = mirror_of(ob_last, f2_last);
       bool const present = (fnl >= 1 && fe0 == add) || (fnl >= 2 && fe1 == add);
@@ -909,9 +921,9 @@ __device__ __forceinline__ bool compress_walk_par(Win& g, u32 nid, bool dflt, u8
       }
       clean = !present && fnl == fnl_before;
       g.nedge[fl] = static_cast<u8>(fnl);
-      g.edge[static_cast<size_t>(fl) * kEdgeCap] = fe0;
-      g.edge[static_cast<size_t>(fl) * kEdgeCap + 1] = fe1;
-      if (fnl > 2) g.edge[static_cast<size_t>(fl) * kEdgeCap + 2] = fe2;
+      g.edge[static_cast<size_t>(fl) * g.ecap] = fe0;
+      g.edge[static_cast<size_t>(fl) * g.ecap + 1] = fe1;
+      if (fnl > 2) g.edge[static_cast<size_t>(fl) * g.ecap + 2] = fe2;
       set_links(g, fl, fnl, fe0, fe1);
     }
     cand = s2n_last;
@@ -925,8 +937,8 @@ __device__ __forceinline__ bool compress_walk_par(Win& g, u32 nid, bool dflt, u8
     wave_sync_mem();  // the next chunk links its first surviving slice behind this chunk's last one
   }
   if (loaded) {
-    g.edge[static_cast<size_t>(nid) * kEdgeCap] = xe0;
-    g.edge[static_cast<size_t>(nid) * kEdgeCap + 1] = xe1;
+    g.edge[static_cast<size_t>(nid) * g.ecap] = xe0;
+    g.edge[static_cast<size_t>(nid) * g.ecap + 1] = xe1;
     g.len[nid] = xlen;
     g.label[nid] = static_cast<u8>(xlabel);
     g.cnt[nid * S] = X0;
@@ -949,11 +961,11 @@ __device__ __forceinline__ bool may_compress(const Win& g, u32 i) {
   if (static_cast<i64>(i) == g.source || static_cast<i64>(i) == g.sink) return false;
   u32 const xn = g.nedge[i];
   if (xn == 0 || xn > 2) return false;
-  uint2 const ev = *reinterpret_cast<const uint2*>(g.edge + static_cast<size_t>(i) * kEdgeCap);
+  uint2 const ev = *reinterpret_cast<const uint2*>(g.edge + static_cast<size_t>(i) * g.ecap);
   for (u32 x = 0; x < xn; ++x) {
     u32 const nb = (x == 0 ? ev.x : ev.y) >> 2;
     if (g.nedge[nb] != 2) return false;
-    uint2 const ne = *reinterpret_cast<const uint2*>(g.edge + static_cast<size_t>(nb) * kEdgeCap);
+    uint2 const ne = *reinterpret_cast<const uint2*>(g.edge + static_cast<size_t>(nb) * g.ecap);
     bool const via0 = (ne.x >> 2) == i && g.nedge[ne.y >> 2] <= 2;
     bool const via1 = (ne.y >> 2) == i && g.nedge[ne.x >> 2] <= 2;
     if (!via0 && !via1) return false;
@@ -1036,15 +1048,15 @@ __device__ __forceinline__ u32 collect_tips(Win& g, u32 comp, u32* rm) {
 }
 
 // ---- sequence spelling ----
-__device__ __forceinline__ u8 canon_base(const Win& g, u32 o, u32 x) {  // x-th base of node o's canonical k-mer
-  u32 const sv = g.src[o];
-  const u8* p = (sv & 0x80000000u) ? g.readb + (sv & 0x7FFFFFFFu) : g.refb + sv;
-  return g.sign[o] ? p[x] : dev_complement(p[g.k - 1 - x]);
+__device__ __forceinline__ u8 canon_base(const Win& g, u32 o, u32 x) {  // x-th base of slice o's base string
+  u32 const sv = g.bsrc[o];
+  const u8* p = (sv & 0x80000000u) ? g.readb + (sv & 0x3FFFFFFFu) : ((sv & 0x40000000u) ? g.pool + (sv & 0x3FFFFFFFu) : g.refb + sv);
+  return g.bsign[o] ? p[x] : dev_complement(p[base_len(g, o) - 1 - x]);
 }
 __device__ __forceinline__ u8 slice_base(const Win& g, u32 o, u32 d, u32 j) {  // j-th base of slice (o, d)
-  u32 const st = d & 0xFFu, rc = (d >> 16) & 1u;
+  u32 const st = sd_st(d), rc = sd_rc(d);
   u32 const pp = st + j;
-  return rc ? dev_complement(canon_base(g, o, g.k - 1 - pp)) : canon_base(g, o, pp);
+  return rc ? dev_complement(canon_base(g, o, base_len(g, o) - 1 - pp)) : canon_base(g, o, pp);
 }
 // append the oriented sequence of `node` (dflt: stored orientation, else reverse complement) minus its
 // first `skip` bases to out[*pos..], bounded by cap.  Returns false on overflow.
@@ -1103,7 +1115,7 @@ __device__ __forceinline__ bool emit_node_seq(const Win& g, u32 node, bool dflt,
     u32 s = dflt ? g.head[node] : g.tail[node];
     while (s != kNoNode) {
       u32 const mine = dflt ? s + lane : s - lane;  // wraps past 0 when walking backwards: rejected by the bound
-      u32 const nx = mine < g.nc ? (dflt ? g.snext[mine] : g.sprev[mine]) : kNoNode;
+      u32 const nx = mine < g.n ? (dflt ? g.snext[mine] : g.sprev[mine]) : kNoNode;
       bool const linked = nx == (dflt ? mine + 1u : mine - 1u) && (dflt || mine != 0u);
       unsigned long long const m = __ballot(linked);
       u32 const run = m == ~0ull ? 63u : static_cast<u32>(__builtin_ctzll(~m));  // lanes 0 .. run are on the list
@@ -1117,25 +1129,65 @@ __device__ __forceinline__ bool emit_node_seq(const Win& g, u32 node, bool dflt,
   u32 emitted = 0;  // bases of the node spelled by the blocks before this one
   for (u32 b0 = 0; b0 < ns; b0 += 64) {
     u32 const idx = b0 + lane;
-    u32 s = 0, d = 0, ln = 0;
+    u32 s = 0, d = 0, ln = 0, bl = 0, bs = 1;
+    const u8* bp = g.refb;
     if (idx < ns) {
       s = ids[idx];
       d = g.sdesc[s];
-      ln = (d >> 8) & 0xFFu;
+      ln = sd_ln(d);
+      u32 const sv = g.bsrc[s];
+      bp = (sv & 0x80000000u) ? g.readb + (sv & 0x3FFFFFFFu) : ((sv & 0x40000000u) ? g.pool + (sv & 0x3FFFFFFFu) : g.refb + sv);
+      bl = base_len(g, s);
+      bs = g.bsign[s];
     }
-    u32 inc = ln;
+    // j-th base of the slice in ITS orientation: base string position st + j, read backwards and complemented once for a
+    // reverse-complemented slice and once more for a base string stored on the other strand
+    auto base_of = [](const u8* p, u32 blen, u32 bsign, u32 dd, u32 j) -> u8 {
+      u32 pp = sd_st(dd) + j;
+      bool comp = false;
+      if (sd_rc(dd)) {
+        pp = blen - 1 - pp;
+        comp = !comp;
+      }
+      if (!bsign) {
+        pp = blen - 1 - pp;
+        comp = !comp;
+      }
+      u8 const c = p[pp];
+      return comp ? dev_complement(c) : c;
+    };
+    u32 inc = ln, mx = ln;
 #pragma unroll
     for (u32 o = 1; o < 64; o <<= 1) {
       u32 const y = __shfl_up(inc, o, 64);
       if (lane >= o) inc += y;
+      mx = max(mx, static_cast<u32>(__shfl_xor(mx, o, 64)));
     }
     u32 const off = emitted + inc - ln;
-    for (u32 j = 0; j < ln; ++j) {
-      u32 const e = off + j;  // index of this base within the node's oriented sequence
-      if (e < skip) continue;
-      u32 const at = *pos + (e - skip);
-      u8 const base = dflt ? slice_base(g, s, d, j) : dev_complement(slice_base(g, s, d, ln - 1 - j));
-      if (at < cap) out[at] = base; else over = true;
+    if (mx <= 4u) {  // k-mer sized slices (the raw graph: mostly one base each): a lane per slice
+      for (u32 j = 0; j < ln; ++j) {
+        u32 const e = off + j;  // index of this base within the node's oriented sequence
+        if (e < skip) continue;
+        u32 const at = *pos + (e - skip);
+        u8 const base = dflt ? base_of(bp, bl, bs, d, j) : dev_complement(base_of(bp, bl, bs, d, ln - 1 - j));
+        if (at < cap) out[at] = base; else over = true;
+      }
+    } else {  // long slices (merged strings of the compact graph): one slice at a time, a lane per base
+      u32 const cntb = ns - b0 < 64u ? ns - b0 : 64u;
+      for (u32 t = 0; t < cntb; ++t) {
+        u32 const dt = __builtin_amdgcn_readlane(d, t), lt = __builtin_amdgcn_readlane(ln, t), ot = __builtin_amdgcn_readlane(off, t);
+        u32 const blt = __builtin_amdgcn_readlane(bl, t), bst = __builtin_amdgcn_readlane(bs, t);
+        u64 const pa = reinterpret_cast<u64>(bp);
+        u32 const plo = __builtin_amdgcn_readlane(static_cast<u32>(pa), t), phi = __builtin_amdgcn_readlane(static_cast<u32>(pa >> 32), t);
+        const u8* pt = reinterpret_cast<const u8*>((static_cast<u64>(phi) << 32) | plo);
+        for (u32 j = lane; j < lt; j += 64) {
+          u32 const e = ot + j;
+          if (e < skip) continue;
+          u32 const at = *pos + (e - skip);
+          u8 const base = dflt ? base_of(pt, blt, bst, dt, j) : dev_complement(base_of(pt, blt, bst, dt, lt - 1 - j));
+          if (at < cap) out[at] = base; else over = true;
+        }
+      }
     }
     emitted += __shfl(inc, 63, 64);
   }
@@ -1246,7 +1298,7 @@ __device__ __forceinline__ u32 label_components(Win& g, u32* lab, u32* cid, u32 
       u32 const ne = g.nedge[i];
       u32 best = gu;
       for (u32 x = 0; x < ne; ++x) {
-        u32 const v = g.edge[i * kEdgeCap + x] >> 2;
+        u32 const v = g.edge[i * g.ecap + x] >> 2;
         best = min(best, lab[lab[v]]);
       }
       if (best < gu) {
@@ -1287,6 +1339,20 @@ struct CleanArgs {
   ma_params_t prm;
 };
 
+// LDS of the one-wavefront kernels: the shared 8 KB table plus everything that used to be a dynamically indexed local
+// (candidate components, accepted walks, the edge order of EnqueueOutgoingEdges): as private arrays those lived in
+// scratch memory -- an HBM round trip per access of an already serial loop, 1.6 KB per lane.
+constexpr int kMaxCand = 16;
+struct CleanLds {
+  u32 link[kLinkCap];
+  u32 cand_comp[kMaxCand], cand_size[kMaxCand], cand_src[kMaxCand], cand_snk[kMaxCand], cand_soff[kMaxCand], cand_koff[kMaxCand];
+  u32 walk_off[kMaxWalks], walk_len[kMaxWalks], walk_minw[kMaxWalks];
+  int order[kMaxWalks];
+  u32 eq_idx[kEdgeCap], eq_conf[kEdgeCap];
+};
+
+__device__ __forceinline__ void clean_candidates(CleanArgs const& A, Win& g, CleanLds& sh, int a, int w, int ncand, int first_phase, u32 NC);
+
 __global__ __launch_bounds__(64, 4) void k_clean(CleanArgs A) {
   int const a = blockIdx.x;
   u32 const lane = threadIdx.x;
@@ -1294,7 +1360,7 @@ __global__ __launch_bounds__(64, 4) void k_clean(CleanArgs A) {
   int const w = static_cast<int>(ws.active[a]);
   ma_params_t const& P = A.prm;
   size_t const nb = static_cast<size_t>(a) * ws.nc;
-  int const MC = P.max_comps, MH = P.max_haps, ML = P.max_hap_len, MR = P.max_runs;
+  if (ws.cg_state && ws.cg_state[a] != 0u) return;  // k_clean_chains + k_clean_tail have this window
 
   if (ws.win_flags[w] & 4u) {  // build-stage capacity overflow: report and stop retrying
     A.out.win_status[w] = MA_W_TABLE_OVERFLOW | MA_W_NO_HAPLOTYPE;
@@ -1303,7 +1369,8 @@ __global__ __launch_bounds__(64, 4) void k_clean(CleanArgs A) {
     return;
   }
 
-  __shared__ u32 l_link[kLinkCap];
+  __shared__ CleanLds sh;
+  u32* const l_link = sh.link;
   Win g;
   g.link = l_link;
   g.ranked = false;
@@ -1331,6 +1398,11 @@ __global__ __launch_bounds__(64, 4) void k_clean(CleanArgs A) {
   g.snext = ws.sl_next + nb;
   g.sprev = ws.sl_prev + nb;
   g.sdesc = ws.sl_desc + nb;
+  g.bsrc = g.src;
+  g.blen = nullptr;
+  g.bsign = g.sign;
+  g.pool = nullptr;
+  g.ecap = kEdgeCap;
   g.scratch = ws.scratch + nb * 32;
   g.source = g.sink = -1;
   g.flags = 0;
@@ -1352,7 +1424,7 @@ __global__ __launch_bounds__(64, 4) void k_clean(CleanArgs A) {
     g.alive[i] = 1;
     g.head[i] = g.tail[i] = i;
     g.snext[i] = g.sprev[i] = kNoNode;
-    g.sdesc[i] = 0u | (K << 8);
+    g.sdesc[i] = sd_make(0u, K, 0u);
   }
   wave_sync_mem();
 
@@ -1371,9 +1443,12 @@ __global__ __launch_bounds__(64, 4) void k_clean(CleanArgs A) {
   // Candidate = component with source != sink and ref anchor length >= min_anchor_len.
   const u32* refn = ws.ref_node + static_cast<size_t>(a) * ws.ref_stride;
   u32 const n_refk = g.ref_len >= K + 1 ? g.ref_len - K + 1 : 0;
-  constexpr int kMaxCand = 16;
-  u32 cand_comp[kMaxCand], cand_size[kMaxCand], cand_src[kMaxCand], cand_snk[kMaxCand];
-  u32 cand_soff[kMaxCand], cand_koff[kMaxCand];
+  u32* const cand_comp = sh.cand_comp;
+  u32* const cand_size = sh.cand_size;
+  u32* const cand_src = sh.cand_src;
+  u32* const cand_snk = sh.cand_snk;
+  u32* const cand_soff = sh.cand_soff;
+  u32* const cand_koff = sh.cand_koff;
   int ncand = 0;
   {
     // first / last qualifying reference k-mer per component, discovered in reference order
@@ -1451,10 +1526,33 @@ __global__ __launch_bounds__(64, 4) void k_clean(CleanArgs A) {
     }
   }
 
+  CPROF_ACC(2);
+  clean_candidates(A, g, sh, a, w, ncand, 0, NC);
+}
+
+// The candidate components in order (graph.cpp:142-235): PruneComponent, BuildTraversalIndex, HasCycle, complexity gate,
+// MaxFlow::NextPath loop, BuildHaplotypes; then the window's status.  first_phase = 0 on the raw graph; 1 when
+// k_clean_chains has already done the first CompressGraph (the graph in `g` is then the compact one).
+__device__ __forceinline__ void clean_candidates(CleanArgs const& A, Win& g, CleanLds& sh, int a, int w, int ncand, int first_phase, u32 NC) {
+  GraphWs const& ws = A.ws;
+  ma_params_t const& P = A.prm;
+  u32 const lane = threadIdx.x;
+  int const MC = P.max_comps, MH = P.max_haps, ML = P.max_hap_len, MR = P.max_runs;
+  u32 const K = static_cast<u32>(g.k);
+  u32* const l_link = sh.link;
+  u32* const cand_comp = sh.cand_comp;
+  u32* const cand_src = sh.cand_src;
+  u32* const cand_snk = sh.cand_snk;
+  u32* const cand_soff = sh.cand_soff;
+  u32* const cand_koff = sh.cand_koff;
+  CPROF_T0();
+#ifdef MA_PROFILE
+  unsigned long long const t_begin = __builtin_amdgcn_s_memtime();
+  u32 dbg_rounds = 0;
+#endif
   u32 status = 0;
   u32 ncomp_out = 0, slot = 0;
   bool retry = false;
-  CPROF_ACC(2);
 
   for (int ci = 0; ci < ncand && !retry; ++ci) {
     u32 const comp = cand_comp[ci];
@@ -1468,7 +1566,7 @@ __global__ __launch_bounds__(64, 4) void k_clean(CleanArgs A) {
     // compress; remove low coverage; compress; { remove tips; compress } until no tip is left -- written as
     // one loop so that the (large, fully inlined) compression code exists once
 #pragma nounroll
-    for (int phase = 0;; ++phase) {
+    for (int phase = first_phase;; ++phase) {
       if (phase == 1) remove_low_cov(g, comp);
       if (phase >= 2) {
         u32* rm = g.scratch;
@@ -1518,7 +1616,7 @@ __global__ __launch_bounds__(64, 4) void k_clean(CleanArgs A) {
           u32 const i = flat_nodes[f];
           u32 const ne = g.nedge[i];
           for (u32 x = 0; x < ne; ++x) {
-            u32 const e = g.edge[i * kEdgeCap + x];
+            u32 const e = g.edge[i * g.ecap + x];
             if (flat_of[e >> 2] == kNoNode) continue;
             if ((e >> 1) & 1u) c1++; else c0++;
           }
@@ -1551,7 +1649,7 @@ __global__ __launch_bounds__(64, 4) void k_clean(CleanArgs A) {
       u32 const b0 = rstart[f * 2], b1 = rstart[f * 2 + 1];
       u32 k0 = 0, k1 = 0;
       for (u32 x = 0; x < ne; ++x) {
-        u32 const e = g.edge[i * kEdgeCap + x];
+        u32 const e = g.edge[i * g.ecap + x];
         u32 const df = flat_of[e >> 2];
         if (df == kNoNode) continue;
         u32 const ord = b0 + k0 + k1;  // ordinals count the node's edges in list order, whatever their side
@@ -1619,7 +1717,7 @@ __global__ __launch_bounds__(64, 4) void k_clean(CleanArgs A) {
           u32 const self_minus = g.sign[i] ? 0u : 1u;
           u32 const nei = g.nedge[i];
           for (u32 x = 0; x < nei; ++x) {
-            if (((g.edge[i * kEdgeCap + x] >> 1) & 1u) == self_minus) d++; else o++;
+            if (((g.edge[i * g.ecap + x] >> 1) & 1u) == self_minus) d++; else o++;
           }
           ne_l += d + o;
           mx_l = max(mx_l, max(d, o));
@@ -1664,7 +1762,9 @@ __global__ __launch_bounds__(64, 4) void k_clean(CleanArgs A) {
     uint4* arena = ws.arena + static_cast<size_t>(a) * ws.ac;
     u32* walk_pool = stack;  // ordinals of accepted walks, back to back
     u32 walk_pool_cap = 7 * NC, walk_pool_used = 0;
-    u32 walk_off[kMaxWalks], walk_len[kMaxWalks], walk_minw[kMaxWalks];
+    u32* const walk_off = sh.walk_off;
+    u32* const walk_len = sh.walk_len;
+    u32* const walk_minw = sh.walk_minw;
     int nwalks = 0;
     bool hit_limit = false, arena_over = false;
     // The reference's breadth-first search enumerates walk PREFIXES: with b bubbles between source and sink that is
@@ -1725,7 +1825,8 @@ __global__ __launch_bounds__(64, 4) void k_clean(CleanArgs A) {
       auto enqueue = [&](u32 state, u32 parent, u32 pw) {
         u32 const cnt = rcnt[state];
         if (cnt == 0) return;
-        u32 idx[kEdgeCap], conf[kEdgeCap];
+        u32* const idx = sh.eq_idx;
+        u32* const conf = sh.eq_conf;
         u32 const m = cnt < static_cast<u32>(kEdgeCap) ? cnt : static_cast<u32>(kEdgeCap);
         for (u32 x = 0; x < m; ++x) {
           u32 const p = rstart[state] + x;
@@ -1845,7 +1946,7 @@ __global__ __launch_bounds__(64, 4) void k_clean(CleanArgs A) {
     auto conf_at = [&](u32 node) { return have_tab ? l_link[g.n + flat_of[node]] : nd_confidence(g, node); };
     auto total_at = [&](u32 node) { return have_tab ? l_link[g.n + V + flat_of[node]] : nd_total(g, node); };
     // stable sort by MinWeight desc (graph.cpp:876-879)
-    int order[kMaxWalks];
+    int* const order = sh.order;
     for (int i = 0; i < nwalks; ++i) {
       int j = i;
       while (j > 0 && walk_minw[order[j - 1]] < walk_minw[i]) {
@@ -2010,9 +2111,94 @@ __global__ __launch_bounds__(64, 4) void k_clean(CleanArgs A) {
   if (lane == 0) atomicOr(&ws.win_flags[w], 1u);
 }
 
+// The candidate loop on the COMPACT graph k_clean_chains left: a few dozen nodes whose base strings are original k-mers
+// (nodes the first CompressGraph did not touch) or merged strings in the window's pool.
+__global__ __launch_bounds__(64, 4) void k_clean_tail(CleanArgs A) {
+  int const a = blockIdx.x;
+  u32 const lane = threadIdx.x;
+  GraphWs const& ws = A.ws;
+  if (ws.cg_state[a] != 1u) return;
+  int const w = static_cast<int>(ws.active[a]);
+  size_t const nb = static_cast<size_t>(a) * ws.vc;
+  const u32* hdr = ws.cg_hdr + static_cast<size_t>(a) * kCgHdr;
+  __shared__ CleanLds sh;
+  Win g;
+  g.link = sh.link;
+  g.ranked = false;
+  g.refb = A.b.ref_bases + A.b.ref_off[w];
+  g.readb = A.b.read_bases + A.b.read_off[A.b.read_win_off[w]];
+  g.ref_len = A.b.ref_off[w + 1] - A.b.ref_off[w];
+  g.k = win_kmer(ws, w);
+  g.S = ws.num_samples;
+  g.n = hdr[0];
+  g.nc = ws.cg_sc;
+  g.min_node_cov = A.prm.min_node_cov;
+  g.min_anchor_cov = A.prm.min_anchor_cov;
+  g.cnt = ws.cg_cnt + nb * g.S;
+  g.role = ws.cg_role + nb * 2;
+  g.src = ws.cg_bsrc + nb;
+  g.label = ws.cg_label + nb;
+  g.sign = ws.cg_sign + nb;
+  g.nedge = ws.cg_nedge + nb;
+  g.edge = ws.cg_edge + nb * kCgEdgeCap;
+  g.comp = ws.cg_comp + nb;
+  g.len = ws.cg_len + nb;
+  g.alive = ws.cg_alive + nb;
+  g.head = ws.cg_head + nb;
+  g.tail = ws.cg_tail + nb;
+  g.snext = ws.cg_snext + nb;
+  g.sprev = ws.cg_sprev + nb;
+  g.sdesc = ws.cg_sdesc + nb;
+  g.bsrc = ws.cg_bsrc + nb;
+  g.blen = ws.cg_blen + nb;
+  g.bsign = ws.cg_bsign + nb;
+  g.pool = ws.cg_pool + static_cast<size_t>(a) * ws.pool_cap;
+  g.ecap = kCgEdgeCap;
+  g.scratch = ws.cg_scratch + static_cast<size_t>(a) * ws.cg_sc * 32;
+  g.source = g.sink = -1;
+  g.flags = 0;
+#ifdef MA_PROFILE
+  for (int q = 0; q < 6; ++q) g.dbg_t[q] = 0;
+  g.dbg_phase = 0; g.dbg_merges[0] = g.dbg_merges[1] = g.dbg_maxwalk[0] = g.dbg_maxwalk[1] = g.dbg_walks[0] = g.dbg_walks[1] = 0;
+#endif
+  int const ncand = static_cast<int>(hdr[1]);
+  if (lane < static_cast<u32>(ncand)) {
+    const u32* c = hdr + 8 + 6 * lane;
+    sh.cand_comp[lane] = c[0];
+    sh.cand_size[lane] = c[1];
+    sh.cand_src[lane] = c[2];
+    sh.cand_snk[lane] = c[3];
+    sh.cand_soff[lane] = c[4];
+    sh.cand_koff[lane] = c[5];
+  }
+  for (u32 i = lane; i < g.n; i += 64) {
+    g.alive[i] = 1;
+    g.head[i] = g.tail[i] = i;
+    g.snext[i] = g.sprev[i] = kNoNode;
+    g.sdesc[i] = sd_make(0u, g.blen[i], 0u);
+  }
+  wave_sync_mem();
+  clean_candidates(A, g, sh, a, w, ncand, 1, ws.cg_sc);
+}
+
+int run_clean_chains(ma_ctx* ctx, const DBatch& b, const GraphWs& ws, const ma_params_t& prm);  // chains.hip
+
 int run_clean_pass(ma_ctx* ctx, const DBatch& b, const GraphWs& ws, const ma_asm_out_t& out) {
   if (ws.n_active == 0) return MA_OK;
   CleanArgs args{b, ws, out, ctx->prm};
+  static const bool use_chains = !getenv("MA_NO_CHAINS");
+  if (use_chains && ws.cg_state) {
+    // the first CompressGraph of every candidate component as bulk-parallel LDS work, then the rest of the candidate loop
+    // on the few dozen nodes it leaves; windows it does not take (graph beyond its capacities, unusual shapes) keep
+    // cg_state = 0 and go through k_clean from the raw graph
+    MA_HIP(ctx, hipMemsetAsync(ws.cg_state, 0, sizeof(u32) * static_cast<size_t>(ws.n_active), ctx->stream));
+    MA_TRY_RC(run_clean_chains(ctx, b, ws, ctx->prm));
+    ctx->tic("k_clean_tail");
+    hipLaunchKernelGGL(k_clean_tail, dim3(ws.n_active), dim3(64), 0, ctx->stream, args);
+    ctx->toc();
+  } else if (ws.cg_state) {
+    MA_HIP(ctx, hipMemsetAsync(ws.cg_state, 0, sizeof(u32) * static_cast<size_t>(ws.n_active), ctx->stream));
+  }
   ctx->tic("k_clean");
   hipLaunchKernelGGL(k_clean, dim3(ws.n_active), dim3(64), 0, ctx->stream, args);
   ctx->toc();

@@ -88,7 +88,35 @@ struct GraphWs {
   uint4* arena;           // [a][AC]
   u32* win_flags;         // [n_windows] bit0 done, bit1 retry-at-next-k requested
   int num_samples;
+  // ---- compact graph: what the first CompressGraph leaves of the candidate components (k_clean_chains -> k_clean_tail) ----
+  u32 vc;                 // node capacity per window (all candidate components together)
+  u32 cg_sc;              // node stride of the tail's scratch (>= vc: walk pool and search tables scale with it)
+  u32 pool_cap;           // bytes of merged node strings per window
+  u32* cg_state;          // [a] 0: not produced -- k_clean takes the window from the raw graph; 1: produced
+  u32* cg_hdr;            // [a][kCgHdr] n, ncand, then per candidate: comp, size, src, snk, soff, koff (compact ids)
+  u32* cg_cnt;            // [a][vc][S]
+  u32* cg_role;           // [a][vc][2]
+  u32* cg_bsrc;           // [a][vc] base string of the node: nd_src of the original k-mer, or bit30 | offset into cg_pool
+  u32* cg_blen;           // [a][vc] its length
+  u32* cg_len;            // [a][vc]
+  u32* cg_comp;           // [a][vc] candidate's component id
+  u8* cg_label;           // [a][vc]
+  u8* cg_sign;            // [a][vc]
+  u8* cg_bsign;           // [a][vc]
+  u8* cg_nedge;           // [a][vc]
+  u8* cg_alive;           // [a][vc]
+  u32* cg_edge;           // [a][vc][kCgEdgeCap]
+  u32* cg_head;           // [a][vc] slice lists of the tail (slice id = compact node id)
+  u32* cg_tail;
+  u32* cg_snext;
+  u32* cg_sprev;
+  u32* cg_sdesc;
+  u32* cg_scratch;        // [a][32 * cg_sc]
+  u8* cg_pool;            // [a][pool_cap]
 };
+constexpr int kCgEdgeCap = 8;
+constexpr int kCgMaxCand = 15;
+constexpr int kCgHdr = 8 + 6 * 16;
 
 // the k window w is built / cleaned with in the current pass
 __device__ __forceinline__ int win_kmer(GraphWs const& ws, int w) {
