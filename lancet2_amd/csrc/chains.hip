@@ -77,6 +77,7 @@ struct Lds {
   u16* seg_fl;
   u16* cidnode;   // [kVcMax]
   u16* pooloff;   // [kVcMax]
+  u32* bmin;      // [cap / 32] minimum of each 32-entry block of p2n: node << 12 | index
   u32* cand;      // [6 * 16]
   u32* misc;      // [32] counters / flags / wave sums
 };
@@ -139,7 +140,40 @@ __device__ __forceinline__ u32 top_owner(const Lds& L, u32 q) {
   return q;
 }
 
+#ifdef MA_PROFILE
+__device__ unsigned long long g_chprof[16];
+#define CH_T0() unsigned long long _t0 = __builtin_amdgcn_s_memtime()
+#define CH_ACC(slot)                                                      \
+  do {                                                                    \
+    unsigned long long const _t1 = __builtin_amdgcn_s_memtime();          \
+    if (threadIdx.x == 0) atomicAdd(&g_chprof[slot], _t1 - _t0);          \
+    _t0 = _t1;                                                            \
+  } while (0)
+#define CH_SUB0() unsigned long long _s0 = __builtin_amdgcn_s_memtime()
+#define CH_SUB(slot)                                                      \
+  do {                                                                    \
+    unsigned long long const _s1 = __builtin_amdgcn_s_memtime();          \
+    if (threadIdx.x == 0) atomicAdd(&g_chprof[slot], _s1 - _s0);          \
+    _s0 = _s1;                                                            \
+  } while (0)
+#else
+#define CH_T0() do {} while (0)
+#define CH_ACC(slot) do {} while (0)
+#define CH_SUB0() do {} while (0)
+#define CH_SUB(slot) do {} while (0)
+#endif
+
 }  // namespace
+
+#ifdef MA_PROFILE
+extern "C" void ma_debug_chprof(unsigned long long* out, int reset) {
+  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_chprof), sizeof(unsigned long long) * 16);
+  if (reset) {
+    unsigned long long z[16] = {0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_chprof), z, sizeof(z));
+  }
+}
+#endif
 
 __global__ __launch_bounds__(kT) void k_clean_chains(ChainArgs A) {
   extern __shared__ u32 smem[];
@@ -177,6 +211,7 @@ __global__ __launch_bounds__(kT) void k_clean_chains(ChainArgs A) {
     L.seg_fl = reinterpret_cast<u16*>(p); p += kSegCap / 2;
     L.cidnode = reinterpret_cast<u16*>(p); p += kVcMax / 2;
     L.pooloff = reinterpret_cast<u16*>(p); p += kVcMax / 2;
+    L.bmin = p; p += cap / 32;
     L.cand = p; p += 96;
     L.misc = p; p += 32;
   }
@@ -186,6 +221,7 @@ __global__ __launch_bounds__(kT) void k_clean_chains(ChainArgs A) {
 #define PUNT() do { L.misc[M_PUNT] = 1u; } while (0)
 #define BAIL_IF_PUNT() do { __syncthreads(); if (L.misc[M_PUNT]) return; } while (0)
 
+  CH_T0();
   // ---- the raw graph: flags, first two edges inline, the rare third and fourth in a side table ----
   for (u32 i = t; i < n; i += kT) {
     u32 const ne = ws.nd_nedge[nb + i];
@@ -210,6 +246,7 @@ __global__ __launch_bounds__(kT) void k_clean_chains(ChainArgs A) {
   }
   BAIL_IF_PUNT();
 
+  CH_ACC(0);
   // ---- MarkConnectedComponents (graph.cpp:392-463): FastSV hooking + shortcutting on LDS labels ----
   {
     u32* const lab = L.x;
@@ -243,6 +280,7 @@ __global__ __launch_bounds__(kT) void k_clean_chains(ChainArgs A) {
       if (!L.misc[M_CHANGED]) break;
       __syncthreads();
     }
+    CH_ACC(1);
     // component ids in discovery order = rank of the component's smallest node among the roots
     u32 const chunk = (n + kT - 1) / kT, i0 = t * chunk, i1 = min(n, i0 + chunk);
     u32 mine = 0;
@@ -258,6 +296,7 @@ __global__ __launch_bounds__(kT) void k_clean_chains(ChainArgs A) {
   }
   u32 const ncomp = L.misc[M_NCOMP];
 
+  CH_ACC(2);
   // ---- component sizes, FindSource / FindSink (graph.cpp:469-509) for every component at once ----
   const u32* refn = ws.ref_node + static_cast<size_t>(a) * ws.ref_stride;
   u32 const ref_len = A.b.ref_off[w + 1] - A.b.ref_off[w];
@@ -356,6 +395,7 @@ __global__ __launch_bounds__(kT) void k_clean_chains(ChainArgs A) {
   }
   __syncthreads();
 
+  CH_ACC(3);
   // ---- plain / fully plain ----
   for (u32 i = t; i < n; i += kT) {
     u32 const f = L.fl[i];
@@ -374,6 +414,7 @@ __global__ __launch_bounds__(kT) void k_clean_chains(ChainArgs A) {
   }
   BAIL_IF_PUNT();
 
+  CH_ACC(4);
   // ---- chain states: (node, side it leaves by) -> next such state; list ranking by pointer jumping ----
   {
     u32* const st = L.x;  // state << 12 | hops
@@ -411,6 +452,7 @@ __global__ __launch_bounds__(kT) void k_clean_chains(ChainArgs A) {
       if (t == 0) PUNT();  // a ring of fully plain nodes never settles
     }
     BAIL_IF_PUNT();
+    CH_ACC(5);
     // position 0 = the end with the smaller node index
     for (u32 i = t; i < n; i += kT) {
       if (!(L.fl[i] & F_INI)) continue;
@@ -426,6 +468,7 @@ __global__ __launch_bounds__(kT) void k_clean_chains(ChainArgs A) {
     }
     BAIL_IF_PUNT();
   }
+  CH_ACC(6);
   // ---- segment table ----
   {
     u32 const chunk = (n + kT - 1) / kT, i0 = t * chunk, i1 = min(n, i0 + chunk);
@@ -503,6 +546,7 @@ __global__ __launch_bounds__(kT) void k_clean_chains(ChainArgs A) {
   }
   u32 const G = L.misc[M_G];
 
+  CH_ACC(7);
   // ---- per-node values (per-sample counts, two role counts) as u16; blocks, absorbers, rewrite times ----
   u16* const val = reinterpret_cast<u16*>(L.x);
   for (u32 i = t; i < n; i += kT) {
@@ -520,10 +564,29 @@ __global__ __launch_bounds__(kT) void k_clean_chains(ChainArgs A) {
   }
   BAIL_IF_PUNT();
 
+  CH_ACC(8);
   // ---- the interval process: one group of VL lanes per segment ----
+  // Whose turn it is: CompressGraph visits nodes in index order, so the next walker of a segment is the remaining single
+  // with the smallest node index -- among those whose turn can do anything: an interior single always absorbs one side;
+  // position 0 (m - 1) only if L (R) is a buddy, otherwise its turn is a no-op whenever it comes and it can be left out
+  // for good.  Every remaining candidate has a larger index than the last walker (or it would have walked first), so no
+  // clock is needed; a tip end's turn comes when its index is smaller than that minimum, and ends the segment.
+  // The minimum over the shrinking interval [a..b] is a range query: minima of the 32-entry blocks of p2n are prepared
+  // once, a query reads the two partial blocks and the block minima in between (m / 128 + 16 trips instead of m / 4).
   {
-    u32 const VL = NV <= 4u ? 4u : (NV <= 8u ? 8u : 16u);
-    u32 const v = t & (VL - 1u), gid = t / VL, ngroups = kT / VL;
+    u32* const bmin = L.bmin;
+    for (u32 bq = t; bq < (n + 31u) / 32u; bq += kT) {
+      u32 best = 0xFFFFFFFFu;
+      for (u32 q = 0; q < 32u; ++q) {
+        u32 const idx = bq * 32u + q;
+        if (idx < n) best = min(best, (static_cast<u32>(L.p2n[idx]) << 12) | idx);
+      }
+      bmin[bq] = best;  // (entries of p2n beyond the last segment are stale: such a block is never inside a query)
+    }
+    __syncthreads();
+    u32 const VL = NV <= 4u ? 4u : (NV <= 8u ? 8u : 16u), GW = 64u / VL;
+    u32 const v = t & (VL - 1u), q_ = t / VL, ngroups = kT / VL;
+    u32 const gid = (q_ % GW) * 4u + q_ / GW;  // consecutive segments on different wavefronts
     bool const vlane = v < NV;
     auto grp_min = [&](u32 x) {
       for (u32 o = 1; o < VL; o <<= 1) x = min(x, static_cast<u32>(__shfl_xor(x, o, 64)));
@@ -533,8 +596,8 @@ __global__ __launch_bounds__(kT) void k_clean_chains(ChainArgs A) {
       u32 const base = L.seg_base[gg], m = L.seg_m[gg], nl = L.seg_l[gg], nr = L.seg_r[gg], sfl = L.seg_fl[gg];
       i32 a_ = 0, b_ = static_cast<i32>(m) - 1;   // remaining singles [a_..b_]
       i32 lbn = -1, rbn = -1;                      // owners of the blocks at the L / R end
-      i32 clock = -1;
       bool tip_l = (sfl & SF_TIPL) != 0, tip_r = (sfl & SF_TIPR) != 0;
+      i32 const elig_lo = ((sfl & SF_BL) && m > 1u) ? 0 : 1, elig_hi = static_cast<i32>(m) - (((sfl & SF_BR) && m > 1u) ? 1 : 2);
       // running state of the walker whose turn it is
       u32 s = 0, len_a = 0, lab = 0, steps = 0;
       auto absorb = [&](u32 walker, u32 unit, bool single) {
@@ -547,39 +610,90 @@ __global__ __launch_bounds__(kT) void k_clean_chains(ChainArgs A) {
         u32 const av = vlane ? val[unit * VS + v] : 0u;
         len_a += sz;  // node.cpp:91: the walker's length AFTER the merge
         s = div_floor(__umul24(s, len_a) + __umul24(av, len_b), len_a + len_b);
-        lab |= (L.fl[unit] >> F_LABEL_SH) & 7u;
+        lab |= L.fl[unit];
         if (v == 0) L.abs[unit] = static_cast<u16>(walker);
         ++steps;
+      };
+      // a run of `cnt` singles at positions p0, p0 + dir, ...: node ids, values and labels of eight of them are fetched
+      // together (the loads do not depend on the running averages), so that the serial chain per step is multiply-add,
+      // estimate, remainder, fix-up
+      auto step1 = [&](u32 av) {
+        len_a += 1u;
+        u32 const den = len_a + K, num = __umul24(s, len_a) + __umul24(av, K);
+        u32 qq = static_cast<u32>(static_cast<float>(num) * __builtin_amdgcn_rcpf(static_cast<float>(den)));
+        i32 const rem = static_cast<i32>(num - __umul24(qq, den));
+        if (rem < 0) --qq;
+        else if (static_cast<u32>(rem) >= den) ++qq;
+        s = qq;
+      };
+      auto absorb_run = [&](u32 walker, i32 p0, i32 cnt, i32 dir) {
+        i32 c0 = 0;
+        i32 const pb = static_cast<i32>(base) + p0;
+        for (; c0 + 8 <= cnt; c0 += 8) {
+          u32 ids[8], av[8];
+#pragma unroll
+          for (i32 q = 0; q < 8; ++q) ids[q] = L.p2n[pb + (c0 + q) * dir];
+#pragma unroll
+          for (i32 q = 0; q < 8; ++q) {
+            av[q] = vlane ? val[ids[q] * VS + v] : 0u;
+            lab |= L.fl[ids[q]];  // (label bits picked out once the turn is over)
+          }
+          if (v == 0) {
+#pragma unroll
+            for (i32 q = 0; q < 8; ++q) L.abs[ids[q]] = static_cast<u16>(walker);
+          }
+#pragma unroll
+          for (i32 q = 0; q < 8; ++q) step1(av[q]);
+        }
+        for (; c0 < cnt; ++c0) {
+          u32 const id = L.p2n[pb + c0 * dir];
+          u32 const av = vlane ? val[id * VS + v] : 0u;
+          lab |= L.fl[id];
+          if (v == 0) L.abs[id] = static_cast<u16>(walker);
+          step1(av);
+        }
+        steps += static_cast<u32>(cnt);
       };
       auto begin_turn = [&](u32 x) {
         s = vlane ? val[x * VS + v] : 0u;
         len_a = K;
-        lab = (L.fl[x] >> F_LABEL_SH) & 7u;
+        lab = L.fl[x];
       };
       auto stamp = [&](u32 node, u32 slot, u32 walker, u32 pass) {
         if (v == 0) atomicMax(&L.key[node], (((walker << 13) | (pass << 12) | steps) << 1) | slot);
       };
-      while (true) {
+      // min over p2n[base + lo .. base + hi] as id << 12 | (index - base)
+      auto range_min = [&](i32 lo, i32 hi) {
         u32 best = 0xFFFFFFFFu;
-        for (i32 p = a_ + static_cast<i32>(v); p <= b_; p += static_cast<i32>(VL)) {
-          u32 const id = L.p2n[base + p];
-          if (static_cast<i32>(id) > clock) best = min(best, (id << 12) | static_cast<u32>(p));
+        if (lo > hi) return best;
+        u32 const g0 = base + static_cast<u32>(lo), g1 = base + static_cast<u32>(hi);
+        u32 const h_end = min(g1, g0 | 31u);  // head: up to the end of g0's block
+        for (u32 i = g0 + v; i <= h_end; i += VL) best = min(best, (static_cast<u32>(L.p2n[i]) << 12) | i);
+        if (h_end < g1) {
+          u32 const b0 = (h_end + 1u) >> 5, b1 = (g1 + 1u) >> 5;  // full blocks [b0, b1)
+          for (u32 bq = b0 + v; bq < b1; bq += VL) best = min(best, bmin[bq]);
+          for (u32 i = max(b1 << 5, h_end + 1u) + v; i <= g1; i += VL) best = min(best, (static_cast<u32>(L.p2n[i]) << 12) | i);
         }
         best = grp_min(best);
+        return best == 0xFFFFFFFFu ? best : ((best & ~0xFFFu) | ((best & 0xFFFu) - base));
+      };
+      while (true) {
+        CH_SUB0();
+        u32 const best = range_min(max(a_, elig_lo), min(b_, elig_hi));
+        CH_SUB(12);
         u32 who = 0, bid = best >> 12;
         bool have = best != 0xFFFFFFFFu;
-        if (tip_l && static_cast<i32>(nl) > clock && (!have || nl < bid)) {
+        if (tip_l && (!have || nl < bid)) {
           who = 1;
           bid = nl;
           have = true;
         }
-        if (tip_r && static_cast<i32>(nr) > clock && (!have || nr < bid)) {
+        if (tip_r && (!have || nr < bid)) {
           who = 2;
           bid = nr;
           have = true;
         }
         if (!have) break;
-        clock = static_cast<i32>(bid);
         if (who != 0) {
           // a tip end swallows every unit of the segment, nearest first
           u32 const T = bid;
@@ -588,17 +702,17 @@ __global__ __launch_bounds__(kT) void k_clean_chains(ChainArgs A) {
           steps = 0;
           if (who == 1) {
             if (a_ > 0) absorb(T, static_cast<u32>(lbn), false);
-            for (i32 p = a_; p <= b_; ++p) absorb(T, L.p2n[base + p], true);
+            if (b_ >= a_) absorb_run(T, a_, b_ - a_ + 1, 1);
             if (b_ < static_cast<i32>(m) - 1) absorb(T, static_cast<u32>(rbn), false);
           } else {
             if (b_ < static_cast<i32>(m) - 1) absorb(T, static_cast<u32>(rbn), false);
-            for (i32 p = b_; p >= a_; --p) absorb(T, L.p2n[base + p], true);
+            if (b_ >= a_) absorb_run(T, b_, b_ - a_ + 1, -1);
             if (a_ > 0) absorb(T, static_cast<u32>(lbn), false);
           }
           if (vlane) val[T * VS + v] = static_cast<u16>(s);
           if (v == 0) {
             u32 f = L.fl[T] & ~(F_SIDEL | (7u << F_LABEL_SH));
-            f |= lab << F_LABEL_SH;
+            f |= lab & (7u << F_LABEL_SH);
             // position -1 (L) / m (R); its one edge faces the segment: that is its R side / L side
             if (who == 1 ? (side_t == 0u) : (side_t == 1u)) f |= F_SIDEL;
             L.fl[T] = static_cast<u16>(f);
@@ -631,7 +745,7 @@ __global__ __launch_bounds__(kT) void k_clean_chains(ChainArgs A) {
           if (!opp_ok) continue;
           steps = 0;
           if (right) {
-            for (i32 p = j + 1; p <= b_; ++p) absorb(x, L.p2n[base + p], true);
+            if (b_ > j) absorb_run(x, j + 1, b_ - j, 1);
             if (b_ < static_cast<i32>(m) - 1) absorb(x, static_cast<u32>(rbn), false);
             stamp(x, side_slot(L, x, side_r), x, pass);
             stamp(nr, (sfl >> SF_SLOTR_SH) & 3u, x, pass);
@@ -639,7 +753,7 @@ __global__ __launch_bounds__(kT) void k_clean_chains(ChainArgs A) {
             rbn = static_cast<i32>(x);
             hi = static_cast<i32>(m) - 1;
           } else {
-            for (i32 p = j - 1; p >= a_; --p) absorb(x, L.p2n[base + p], true);
+            if (j > a_) absorb_run(x, j - 1, j - a_, -1);
             if (a_ > 0) absorb(x, static_cast<u32>(lbn), false);
             stamp(x, side_slot(L, x, side_l), x, pass);
             stamp(nl, (sfl >> SF_SLOTL_SH) & 3u, x, pass);
@@ -650,23 +764,24 @@ __global__ __launch_bounds__(kT) void k_clean_chains(ChainArgs A) {
           if (pass == 0) walked_f = true;
           walked_any = true;
         }
-        if (walked_any) {
-          if (lbn == static_cast<i32>(x) && rbn == static_cast<i32>(x)) {  // x holds the whole segment
-            a_ = static_cast<i32>(m);
-            b_ = static_cast<i32>(m) - 1;
-            rbn = -1;
-          }
-          if (vlane) val[x * VS + v] = static_cast<u16>(s);
-          if (v == 0) {
-            L.fl[x] = static_cast<u16>((fx & ~(7u << F_LABEL_SH)) | (lab << F_LABEL_SH));
-            L.blk[x] = static_cast<u32>(lo + 1) | (static_cast<u32>(hi + 1) << 16);
-          }
+        CH_SUB(13);
+        if (!walked_any) break;  // (cannot happen: every candidate's turn absorbs a side)
+        if (lbn == static_cast<i32>(x) && rbn == static_cast<i32>(x)) {  // x holds the whole segment
+          a_ = static_cast<i32>(m);
+          b_ = static_cast<i32>(m) - 1;
+          rbn = -1;
+        }
+        if (vlane) val[x * VS + v] = static_cast<u16>(s);
+        if (v == 0) {
+          L.fl[x] = static_cast<u16>((fx & ~(7u << F_LABEL_SH)) | (lab & (7u << F_LABEL_SH)));
+          L.blk[x] = static_cast<u32>(lo + 1) | (static_cast<u32>(hi + 1) << 16);
         }
       }
     }
   }
   __syncthreads();
 
+  CH_ACC(9);
   // ---- the compact graph ----
   u32 V = 0;
   {
@@ -774,6 +889,7 @@ __global__ __launch_bounds__(kT) void k_clean_chains(ChainArgs A) {
 #pragma unroll
     for (u32 x = 0; x < 4; ++x) ws.cg_edge[(vb + t) * kCgEdgeCap + x] = out_e[x];
   }
+  CH_ACC(10);
   // leaf bytes -> pool
   {
     const u8* refb = A.b.ref_bases + A.b.ref_off[w];
@@ -808,32 +924,51 @@ __global__ __launch_bounds__(kT) void k_clean_chains(ChainArgs A) {
       }
       pool[L.pooloff[L.cid[y]] + static_cast<u32>(idx)] = comp ? dev_complement(base) : base;
     };
+    auto src_of = [&](u32 q) -> const u8* {
+      u32 const sv = ws.nd_src[nb + q];
+      return (sv & 0x80000000u) ? readb + (sv & 0x7FFFFFFFu) : refb + sv;
+    };
+    // an absorbed k-mer leaves one base
     for (u32 q = t; q < n; q += kT) {
       u32 const f = L.fl[q];
-      if ((f >> F_CAND_SH) == 15u) continue;
+      if ((f >> F_CAND_SH) == 15u || L.abs[q] == kNone16) continue;
       u32 const bk = L.blk[q];
-      bool const owns = (bk >> 16) > (bk & 0xFFFFu);
-      if (!owns && L.abs[q] == kNone16) continue;  // an untouched node keeps its original k-mer
-      u32 const sv = ws.nd_src[nb + q];
-      const u8* p = (sv & 0x80000000u) ? readb + (sv & 0x7FFFFFFFu) : refb + sv;
+      if ((bk >> 16) > (bk & 0xFFFFu)) continue;  // a block: its bytes travel with its owner's
+      const u8* p = src_of(q);
       bool const plus = (f & F_SIGN) != 0;
-      auto canon = [&](u32 xx) -> u8 { return plus ? p[xx] : dev_complement(p[K1 - xx]); };
-      if (owns) {
-        i32 const PP = static_cast<i32>(prepend_count(q));
-        for (u32 i = 0; i < K; ++i) place(q, PP + static_cast<i32>(i), canon(i), false);
-      } else {
-        u32 const y = L.abs[q];
-        bool const right = pos1(q) > pos1(y);
-        u32 const sy = right ? (sideL(y) ^ 1u) : sideL(y);
-        u32 const j = (right ? sideL(q) : (sideL(q) ^ 1u)) ^ 1u;
-        bool const rc = sy != j, append = sy == 0u;
-        i32 const d = right ? static_cast<i32>(pos1(q) - pos1(y)) : static_cast<i32>(pos1(y) - pos1(q));
-        i32 const PP = static_cast<i32>(prepend_count(y));
-        u8 const base = append ? (rc ? canon(0) : canon(K1)) : (rc ? canon(K1) : canon(0));
-        place(y, append ? PP + static_cast<i32>(K) + d - 1 : PP - d, base, rc);
-      }
+      u32 const y = L.abs[q];
+      bool const right = pos1(q) > pos1(y);
+      u32 const sy = right ? (sideL(y) ^ 1u) : sideL(y);
+      u32 const j = (right ? sideL(q) : (sideL(q) ^ 1u)) ^ 1u;
+      bool const rc = sy != j, append = sy == 0u;
+      i32 const d = right ? static_cast<i32>(pos1(q) - pos1(y)) : static_cast<i32>(pos1(y) - pos1(q));
+      i32 const PP = static_cast<i32>(prepend_count(y));
+      u32 const xx = (append != rc) ? K1 : 0u;  // append: last base of the oriented k-mer, prepend: first; rc flips which canonical base that is
+      u8 const base = plus ? p[xx] : dev_complement(p[K1 - xx]);
+      place(y, append ? PP + static_cast<i32>(K) + d - 1 : PP - d, base, rc);
+    }
+    // an owner's k-mer: (owner, byte) pairs over all threads
+    for (u32 it = t; it < V * K; it += kT) {
+      u32 const q = L.cidnode[it / K], i = it % K;
+      u32 const bk = L.blk[q];
+      if ((bk >> 16) <= (bk & 0xFFFFu)) continue;
+      const u8* p = src_of(q);
+      u8 const base = (L.fl[q] & F_SIGN) ? p[i] : dev_complement(p[K1 - i]);
+      place(q, static_cast<i32>(prepend_count(q)) + static_cast<i32>(i), base, false);
+    }
+    // (nested owners are not in cidnode: they are not alive)
+    for (u32 q = t; q < n; q += kT) {
+      u32 const f = L.fl[q];
+      if ((f >> F_CAND_SH) == 15u || L.abs[q] == kNone16) continue;
+      u32 const bk = L.blk[q];
+      if ((bk >> 16) <= (bk & 0xFFFFu)) continue;
+      const u8* p = src_of(q);
+      bool const plus = (f & F_SIGN) != 0;
+      i32 const PP = static_cast<i32>(prepend_count(q));
+      for (u32 i = 0; i < K; ++i) place(q, PP + static_cast<i32>(i), plus ? p[i] : dev_complement(p[K1 - i]), false);
     }
   }
+  CH_ACC(11);
   if (t == 0) {
     hdr[0] = V;
     hdr[1] = ncand;
@@ -857,7 +992,7 @@ int run_clean_chains(ma_ctx* ctx, const DBatch& b, const GraphWs& ws, const ma_p
   u32 const S = static_cast<u32>(ws.num_samples);
   u32 const xw = std::max<u32>(2u, (S + 2u + 1u) / 2u);
   auto lds_bytes = [&](u32 cap) {
-    size_t words = static_cast<size_t>(cap) * (3 + xw) + static_cast<size_t>(cap) * 3 /* six u16 arrays */ + kXeCap * 2 + (kSegCap / 2) * 5 + kVcMax + 96 + 32;
+    size_t words = static_cast<size_t>(cap) * (3 + xw) + static_cast<size_t>(cap) * 3 /* six u16 arrays */ + kXeCap * 2 + (kSegCap / 2) * 5 + kVcMax + 96 + 32 + cap / 32;
     return words * 4;
   };
   static bool attr_set = false;
