@@ -78,6 +78,9 @@ struct Win {
   const u8* bsign;    // 1: the bytes are the stored orientation, 0: its reverse complement (a k-mer first seen on the other strand)
   const u8* pool;     // merged strings written by k_clean_chains (null on the raw graph)
   u32 ecap;           // edge slots per node in `edge`
+  u32 link_cap;       // u32 words behind `link`
+  uint4* arena;       // search arena of MaxFlow::NextPath
+  u32 ac;             // its capacity (records)
   u32* scratch;
   u32* link;  // LDS, 8 KB: component labels, then the chain-following table, then the slice ranks
   bool ranked;  // link holds rank_slices() of the current graph
@@ -634,7 +637,7 @@ __device__ __forceinline__ void compress_node_fast(Win& g, u32 nid, bool dflt, u
 constexpr u32 kLinkCap = 2048;  // nodes covered (2 x u16 each = the kernel's 8 KB of LDS)
 constexpr u32 kNoLink = 0xFFFFu;
 __device__ __forceinline__ void set_links(Win& g, u32 i, u32 n_edges, u32 e0, u32 e1) {
-  if (i >= kLinkCap) return;
+  if (i >= g.link_cap) return;
   u16* next = reinterpret_cast<u16*>(g.link);
 #pragma unroll
   for (u32 j = 0; j < 2; ++j) {
@@ -643,7 +646,7 @@ __device__ __forceinline__ void set_links(Win& g, u32 i, u32 n_edges, u32 e0, u3
   }
 }
 __device__ __forceinline__ void build_links(Win& g) {
-  u32 const top = g.n < kLinkCap ? g.n : kLinkCap;
+  u32 const top = g.n < g.link_cap ? g.n : g.link_cap;
   for (u32 i = lane_id(); i < top; i += 64) {
     uint2 const ev = *reinterpret_cast<const uint2*>(g.edge + static_cast<size_t>(i) * g.ecap);
     set_links(g, i, g.alive[i] ? g.nedge[i] : 0u, ev.x, ev.y);
@@ -714,7 +717,7 @@ __device__ __forceinline__ bool compress_walk_par(Win& g, u32 nid, bool dflt, u8
       while (true) {
         my_st = lane == nst ? st : my_st;
         ++nst;
-        if (nst == 64 || (st >> 1) >= kLinkCap) break;
+        if (nst == 64 || (st >> 1) >= g.link_cap) break;
         u32 const nx = __builtin_amdgcn_readfirstlane(static_cast<u32>(next[st]));
         if (nx == kNoLink) break;
         st = nx;
@@ -1403,6 +1406,9 @@ __global__ __launch_bounds__(64, 4) void k_clean(CleanArgs A) {
   g.bsign = g.sign;
   g.pool = nullptr;
   g.ecap = kEdgeCap;
+  g.link_cap = kLinkCap;
+  g.arena = ws.arena + static_cast<size_t>(a) * ws.ac;
+  g.ac = ws.ac;
   g.scratch = ws.scratch + nb * 32;
   g.source = g.sink = -1;
   g.flags = 0;
@@ -1553,6 +1559,7 @@ __device__ __forceinline__ void clean_candidates(CleanArgs const& A, Win& g, Cle
   u32 status = 0;
   u32 ncomp_out = 0, slot = 0;
   bool retry = false;
+  bool const compact = first_phase != 0;
 
   for (int ci = 0; ci < ncand && !retry; ++ci) {
     u32 const comp = cand_comp[ci];
@@ -1759,7 +1766,8 @@ __device__ __forceinline__ void clean_candidates(CleanArgs const& A, Win& g, Cle
     CPROF_ACC(8);
     // ---- BuildHaplotypes: MaxFlow::NextPath loop (max_flow.cpp:162-280, graph.cpp:846-891) ----
     for (u32 e = 0; e < E; ++e) traversed[e] = 0;
-    uint4* arena = ws.arena + static_cast<size_t>(a) * ws.ac;
+    uint4* const arena = g.arena;
+    u32 const arena_cap = g.ac;
     u32* walk_pool = stack;  // ordinals of accepted walks, back to back
     u32 walk_pool_cap = 7 * NC, walk_pool_used = 0;
     u32* const walk_off = sh.walk_off;
@@ -1774,7 +1782,7 @@ __device__ __forceinline__ void clean_candidates(CleanArgs const& A, Win& g, Cle
     // folded into those two as a multiplicity, which is all that is needed to know how many entries the reference
     // would have popped (its 2^20-visit cap, max_flow.h:69).  Same walks, arena use linear in the graph.
     u32* rep = l_link;  // [state][2]: arena index of the representatives in the level being built
-    bool const fold = 5u * V <= kLinkCap;
+    bool const fold = 5u * V <= g.link_cap;
     // Node::Confidence (f64 arithmetic) of every node of the component, once: the search asks for it per outgoing
     // edge of every popped entry
     if (fold) {
@@ -1805,7 +1813,7 @@ __device__ __forceinline__ void clean_candidates(CleanArgs const& A, Win& g, Cle
               arena[r1].w = 0x80000000u | min((arena[r1].w & 0x7FFFFFFFu) + mult, 0x40000000u);
               return;
             }
-            if (an >= ws.ac) {
+            if (an >= arena_cap) {
               arena_over = true;
               return;
             }
@@ -1813,9 +1821,9 @@ __device__ __forceinline__ void clean_candidates(CleanArgs const& A, Win& g, Cle
             arena[an++] = make_uint4(ord, st, parent, 0x80000000u | mult);
             return;
           }
-          if (an < ws.ac) rep[st * 2] = an;
+          if (an < arena_cap) rep[st * 2] = an;
         }
-        if (an >= ws.ac) {
+        if (an >= arena_cap) {
           arena_over = true;
           return;
         }
@@ -1894,6 +1902,10 @@ __device__ __forceinline__ void clean_candidates(CleanArgs const& A, Win& g, Cle
       // reconstruct (max_flow.cpp:42-54) into the pool, reversed to source->sink order
       u32 wl = 0;
       for (u32 i = static_cast<u32>(best); i != kNoParent; i = arena[i].z) wl++;
+      if (compact && nwalks < kMaxWalks && walk_pool_used + wl > walk_pool_cap) {
+        g.flags |= 4u;  // the compact graph's smaller pool: k_clean has the window again
+        break;
+      }
       if (nwalks >= kMaxWalks || walk_pool_used + wl > walk_pool_cap) {
         status |= MA_W_HAP_OVERFLOW;
         break;
@@ -1920,6 +1932,8 @@ __device__ __forceinline__ void clean_candidates(CleanArgs const& A, Win& g, Cle
       walk_pool_used += wl;
     }
     CPROF_ACC(9);
+    if (compact && arena_over) g.flags |= 4u;
+    if (g.flags & 4u) break;
     if (arena_over) status |= MA_W_TABLE_OVERFLOW;
     if (arena_over && nwalks == 0) {
       // "no walk" cannot be told from "walk not reached before the arena filled up" (the reference allows 2^20
@@ -1931,11 +1945,11 @@ __device__ __forceinline__ void clean_candidates(CleanArgs const& A, Win& g, Cle
     if (hit_limit) status |= MA_W_BFS_LIMIT;
     if (nwalks == 0) continue;  // graph.cpp:225
 
-    g.ranked = g.n <= kLinkCap;  // 2048 slices x (distance, last slice) = the 8 KB of LDS
+    g.ranked = g.n <= g.link_cap;  // (distance, last slice) per slice
     if (g.ranked) rank_slices(g);
     // Node::Confidence and the total coverage of the component's nodes, behind the slice ranks: every walk asks for
     // both at every node it passes
-    bool const have_tab = g.ranked && g.n + 2u * V <= kLinkCap;
+    bool const have_tab = g.ranked && g.n + 2u * V <= g.link_cap;
     if (have_tab) {
       for (u32 f = lane; f < V; f += 64) {
         l_link[g.n + f] = nd_confidence(g, flat_nodes[f]);
@@ -2082,6 +2096,12 @@ __device__ __forceinline__ void clean_candidates(CleanArgs const& A, Win& g, Cle
     ncomp_out++;
   }
 
+  if ((g.flags & 4u) && compact) {
+    // a capacity of the compact route (edge slots, search arena, walk pool): nothing is reported from here, k_clean --
+    // launched behind this kernel -- assembles the window from the raw graph, which nobody has touched
+    if (lane == 0) ws.cg_state[a] = 0u;
+    return;
+  }
   if (g.flags & 4u) {
     A.out.win_status[w] = MA_W_TABLE_OVERFLOW | MA_W_NO_HAPLOTYPE;
     A.out.win_ncomp[w] = 0;
@@ -2112,15 +2132,33 @@ __device__ __forceinline__ void clean_candidates(CleanArgs const& A, Win& g, Cle
 }
 
 // The candidate loop on the COMPACT graph k_clean_chains left: a few dozen nodes whose base strings are original k-mers
-// (nodes the first CompressGraph did not touch) or merged strings in the window's pool.
+// (nodes the first CompressGraph did not touch) or merged strings in the window's pool.  kLds: the whole graph, the
+// traversal index, the search arena and every work list live in LDS (graphs of up to kTailV nodes: all but the deepest
+// windows); otherwise the same code runs on the arrays in HBM.  Capacities of this route that a window outgrows (edge
+// slots, arena, walk pool) hand it to k_clean, never to the caller.
+constexpr u32 kTailV = 128;       // nodes of the LDS image
+constexpr u32 kTailArena = 640;   // search records
+constexpr u32 kTailLink = 1024;
+struct TailLds {
+  u32 cnt[kTailV * kMaxSamples], role[kTailV * 2], bsrc[kTailV], blen[kTailV], len[kTailV], comp[kTailV];
+  u32 edge[kTailV * kCgEdgeCap];
+  u32 head[kTailV], tail[kTailV], snext[kTailV], sprev[kTailV], sdesc[kTailV];
+  u8 label[kTailV], sign[kTailV], bsign[kTailV], nedge[kTailV], alive[kTailV];
+  u32 scratch[32 * kTailV];
+  uint4 arena[kTailArena];
+};
+
+template <bool kLds>
 __global__ __launch_bounds__(64, 4) void k_clean_tail(CleanArgs A) {
   int const a = blockIdx.x;
   u32 const lane = threadIdx.x;
   GraphWs const& ws = A.ws;
   if (ws.cg_state[a] != 1u) return;
+  const u32* hdr = ws.cg_hdr + static_cast<size_t>(a) * kCgHdr;
+  u32 const V = hdr[0];
+  if ((V <= kTailV) != kLds) return;  // the other instantiation's window
   int const w = static_cast<int>(ws.active[a]);
   size_t const nb = static_cast<size_t>(a) * ws.vc;
-  const u32* hdr = ws.cg_hdr + static_cast<size_t>(a) * kCgHdr;
   __shared__ CleanLds sh;
   Win g;
   g.link = sh.link;
@@ -2130,33 +2168,90 @@ __global__ __launch_bounds__(64, 4) void k_clean_tail(CleanArgs A) {
   g.ref_len = A.b.ref_off[w + 1] - A.b.ref_off[w];
   g.k = win_kmer(ws, w);
   g.S = ws.num_samples;
-  g.n = hdr[0];
-  g.nc = ws.cg_sc;
+  g.n = V;
   g.min_node_cov = A.prm.min_node_cov;
   g.min_anchor_cov = A.prm.min_anchor_cov;
-  g.cnt = ws.cg_cnt + nb * g.S;
-  g.role = ws.cg_role + nb * 2;
-  g.src = ws.cg_bsrc + nb;
-  g.label = ws.cg_label + nb;
-  g.sign = ws.cg_sign + nb;
-  g.nedge = ws.cg_nedge + nb;
-  g.edge = ws.cg_edge + nb * kCgEdgeCap;
-  g.comp = ws.cg_comp + nb;
-  g.len = ws.cg_len + nb;
-  g.alive = ws.cg_alive + nb;
-  g.head = ws.cg_head + nb;
-  g.tail = ws.cg_tail + nb;
-  g.snext = ws.cg_snext + nb;
-  g.sprev = ws.cg_sprev + nb;
-  g.sdesc = ws.cg_sdesc + nb;
-  g.bsrc = ws.cg_bsrc + nb;
-  g.blen = ws.cg_blen + nb;
-  g.bsign = ws.cg_bsign + nb;
   g.pool = ws.cg_pool + static_cast<size_t>(a) * ws.pool_cap;
   g.ecap = kCgEdgeCap;
-  g.scratch = ws.cg_scratch + static_cast<size_t>(a) * ws.cg_sc * 32;
   g.source = g.sink = -1;
   g.flags = 0;
+  u32 NC;
+  if constexpr (kLds) {
+    __shared__ TailLds tl;
+    int const S = g.S;
+    for (u32 i = lane; i < V * static_cast<u32>(S); i += 64) tl.cnt[i] = ws.cg_cnt[nb * S + i];
+    for (u32 i = lane; i < V * 2u; i += 64) tl.role[i] = ws.cg_role[nb * 2 + i];
+    for (u32 i = lane; i < V * kCgEdgeCap; i += 64) tl.edge[i] = ws.cg_edge[nb * kCgEdgeCap + i];
+    for (u32 i = lane; i < V; i += 64) {
+      tl.bsrc[i] = ws.cg_bsrc[nb + i];
+      u32 const bl = ws.cg_blen[nb + i];
+      tl.blen[i] = bl;
+      tl.len[i] = ws.cg_len[nb + i];
+      tl.comp[i] = ws.cg_comp[nb + i];
+      tl.label[i] = ws.cg_label[nb + i];
+      tl.sign[i] = ws.cg_sign[nb + i];
+      tl.bsign[i] = ws.cg_bsign[nb + i];
+      tl.nedge[i] = ws.cg_nedge[nb + i];
+      tl.alive[i] = 1;
+      tl.head[i] = tl.tail[i] = i;
+      tl.snext[i] = tl.sprev[i] = kNoNode;
+      tl.sdesc[i] = sd_make(0u, bl, 0u);
+    }
+    g.cnt = tl.cnt;
+    g.role = tl.role;
+    g.src = tl.bsrc;
+    g.label = tl.label;
+    g.sign = tl.sign;
+    g.nedge = tl.nedge;
+    g.edge = tl.edge;
+    g.comp = tl.comp;
+    g.len = tl.len;
+    g.alive = tl.alive;
+    g.head = tl.head;
+    g.tail = tl.tail;
+    g.snext = tl.snext;
+    g.sprev = tl.sprev;
+    g.sdesc = tl.sdesc;
+    g.bsrc = tl.bsrc;
+    g.blen = tl.blen;
+    g.bsign = tl.bsign;
+    g.scratch = tl.scratch;
+    g.arena = tl.arena;
+    g.ac = kTailArena;
+    g.link_cap = kTailLink;
+    NC = kTailV;
+  } else {
+    g.cnt = ws.cg_cnt + nb * g.S;
+    g.role = ws.cg_role + nb * 2;
+    g.src = ws.cg_bsrc + nb;
+    g.label = ws.cg_label + nb;
+    g.sign = ws.cg_sign + nb;
+    g.nedge = ws.cg_nedge + nb;
+    g.edge = ws.cg_edge + nb * kCgEdgeCap;
+    g.comp = ws.cg_comp + nb;
+    g.len = ws.cg_len + nb;
+    g.alive = ws.cg_alive + nb;
+    g.head = ws.cg_head + nb;
+    g.tail = ws.cg_tail + nb;
+    g.snext = ws.cg_snext + nb;
+    g.sprev = ws.cg_sprev + nb;
+    g.sdesc = ws.cg_sdesc + nb;
+    g.bsrc = ws.cg_bsrc + nb;
+    g.blen = ws.cg_blen + nb;
+    g.bsign = ws.cg_bsign + nb;
+    g.scratch = ws.cg_scratch + static_cast<size_t>(a) * ws.cg_sc * 32;
+    g.arena = ws.arena + static_cast<size_t>(a) * ws.ac;
+    g.ac = ws.ac;
+    g.link_cap = kTailLink;
+    NC = ws.cg_sc;
+    for (u32 i = lane; i < g.n; i += 64) {
+      g.alive[i] = 1;
+      g.head[i] = g.tail[i] = i;
+      g.snext[i] = g.sprev[i] = kNoNode;
+      g.sdesc[i] = sd_make(0u, g.blen[i], 0u);
+    }
+  }
+  g.nc = NC;
 #ifdef MA_PROFILE
   for (int q = 0; q < 6; ++q) g.dbg_t[q] = 0;
   g.dbg_phase = 0; g.dbg_merges[0] = g.dbg_merges[1] = g.dbg_maxwalk[0] = g.dbg_maxwalk[1] = g.dbg_walks[0] = g.dbg_walks[1] = 0;
@@ -2171,14 +2266,8 @@ __global__ __launch_bounds__(64, 4) void k_clean_tail(CleanArgs A) {
     sh.cand_soff[lane] = c[4];
     sh.cand_koff[lane] = c[5];
   }
-  for (u32 i = lane; i < g.n; i += 64) {
-    g.alive[i] = 1;
-    g.head[i] = g.tail[i] = i;
-    g.snext[i] = g.sprev[i] = kNoNode;
-    g.sdesc[i] = sd_make(0u, g.blen[i], 0u);
-  }
   wave_sync_mem();
-  clean_candidates(A, g, sh, a, w, ncand, 1, ws.cg_sc);
+  clean_candidates(A, g, sh, a, w, ncand, 1, NC);
 }
 
 int run_clean_chains(ma_ctx* ctx, const DBatch& b, const GraphWs& ws, const ma_params_t& prm);  // chains.hip
@@ -2194,7 +2283,8 @@ int run_clean_pass(ma_ctx* ctx, const DBatch& b, const GraphWs& ws, const ma_asm
     MA_HIP(ctx, hipMemsetAsync(ws.cg_state, 0, sizeof(u32) * static_cast<size_t>(ws.n_active), ctx->stream));
     MA_TRY_RC(run_clean_chains(ctx, b, ws, ctx->prm));
     ctx->tic("k_clean_tail");
-    hipLaunchKernelGGL(k_clean_tail, dim3(ws.n_active), dim3(64), 0, ctx->stream, args);
+    hipLaunchKernelGGL(k_clean_tail<true>, dim3(ws.n_active), dim3(64), 0, ctx->stream, args);
+    hipLaunchKernelGGL(k_clean_tail<false>, dim3(ws.n_active), dim3(64), 0, ctx->stream, args);
     ctx->toc();
   } else if (ws.cg_state) {
     MA_HIP(ctx, hipMemsetAsync(ws.cg_state, 0, sizeof(u32) * static_cast<size_t>(ws.n_active), ctx->stream));
