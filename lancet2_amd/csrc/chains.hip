@@ -818,6 +818,7 @@ __global__ __launch_bounds__(kT) void k_clean_chains(ChainArgs A) {
     } else if (t < V) {
       L.pooloff[t] = static_cast<u16>(off);
     }
+    if (t == 0) L.misc[M_POOL] = total;
     BAIL_IF_PUNT();
   }
   size_t const vb = static_cast<size_t>(a) * ws.vc;
@@ -972,6 +973,7 @@ __global__ __launch_bounds__(kT) void k_clean_chains(ChainArgs A) {
   if (t == 0) {
     hdr[0] = V;
     hdr[1] = ncand;
+    hdr[2] = L.misc[M_POOL];  // bytes of merged strings in the pool
     for (u32 q = 0; q < ncand; ++q) {
       u32* c = hdr + 8 + 6 * q;
       c[0] = q + 1u;

@@ -78,6 +78,11 @@ struct Win {
   const u8* bsign;    // 1: the bytes are the stored orientation, 0: its reverse complement (a k-mer first seen on the other strand)
   const u8* pool;     // merged strings written by k_clean_chains (null on the raw graph)
   u32 ecap;           // edge slots per node in `edge`
+  bool lds;           // every array the lanes cooperate through lives in LDS
+  u32 ek;             // scratch layout: the four per-edge arrays hold ek * nc entries each, the walk pool wk * nc
+  u32 wk;
+  u32* pieces;        // (LDS kernels) piece table of the walk being spelled: [0] = count, then two words per piece
+  u32 piece_cap;
   u32 link_cap;       // u32 words behind `link`
   uint4* arena;       // search arena of MaxFlow::NextPath
   u32 ac;             // its capacity (records)
@@ -184,7 +189,14 @@ __device__ __forceinline__ void remove_node(Win& g, u32 i) {
 }
 
 // lanes of the wave cooperate on index ranges; stores of one lane are made visible to the others here
-__device__ __forceinline__ void wave_sync_mem() { __threadfence_block(); }
+// lanes of the wave cooperate through memory: a lane's stores must have landed before another lane's loads.  On the LDS
+// image that only means "LDS operations issued so far are done" (the LDS unit serves a wave in order anyway); with work
+// lists in HBM it is a fence -- which also waits for every outstanding store to HBM to be acknowledged (~2 us a time:
+// haplotype bases, run records), so the LDS kernels must not use it.
+__device__ __forceinline__ void wave_sync_mem(bool lds_only) {
+  if (lds_only) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  else __threadfence_block();
+}
 __device__ __forceinline__ u32 lane_id() { return threadIdx.x; }
 // append the indices i (in increasing order) whose flag is set to list[]: 64 indices per ballot
 __device__ __forceinline__ void ordered_append(bool flag, u32 i, u32* list, u32& count) {
@@ -204,7 +216,7 @@ __device__ __forceinline__ void remove_low_cov(Win& g, u32 comp) {
       flag = nd_all_singletons(g, i) || nd_total(g, i) < g.min_node_cov;
     ordered_append(flag, i, rm, nrm);
   }
-  wave_sync_mem();
+  wave_sync_mem(g.lds);
   for (u32 x = 0; x < nrm; ++x) remove_node(g, rm[x]);
 }
 
@@ -651,7 +663,7 @@ __device__ __forceinline__ void build_links(Win& g) {
     uint2 const ev = *reinterpret_cast<const uint2*>(g.edge + static_cast<size_t>(i) * g.ecap);
     set_links(g, i, g.alive[i] ? g.nedge[i] : 0u, ev.x, ev.y);
   }
-  wave_sync_mem();
+  wave_sync_mem(g.lds);
 }
 
 // floor(num / den) for num < 2^32 with m = floor(2^32 / den): the estimate mulhi(num, m) is q - 1 or q
@@ -937,7 +949,7 @@ __device__ __forceinline__ bool compress_walk_par(Win& g, u32 nid, bool dflt, u8
       settled = neg_r && clean;
       break;  // the exit below fences
     }
-    wave_sync_mem();  // the next chunk links its first surviving slice behind this chunk's last one
+    wave_sync_mem(g.lds);  // the next chunk links its first surviving slice behind this chunk's last one
   }
   if (loaded) {
     g.edge[static_cast<size_t>(nid) * g.ecap] = xe0;
@@ -951,7 +963,7 @@ __device__ __forceinline__ bool compress_walk_par(Win& g, u32 nid, bool dflt, u8
     g.head[nid] = xhead;
     g.tail[nid] = xtail;
     set_links(g, nid, 0u, 0u, 0u);  // several slices now: no lane-parallel walk passes through it
-    wave_sync_mem();
+    wave_sync_mem(g.lds);
   }
   return settled;
 }
@@ -981,7 +993,7 @@ __device__ __forceinline__ void compress_graph(Win& g, u32 comp) {
   TSTAMP(tg0);
   u8* absorbed = reinterpret_cast<u8*>(g.scratch + g.nc);
   for (u32 i = lane_id(); i < g.n; i += 64) absorbed[i] = 0;
-  wave_sync_mem();
+  wave_sync_mem(g.lds);
   if (g.S <= 2) build_links(g);
   TSTAMP(tg2);
   TACC(5, tg0, tg2);
@@ -1022,7 +1034,7 @@ __device__ __forceinline__ void compress_graph(Win& g, u32 comp) {
     }
     any_generic |= ab == 1;
   }
-  wave_sync_mem();
+  wave_sync_mem(g.lds);
   if (__ballot(any_generic))
     for (u32 i = 0; i < g.n; ++i)
       if (absorbed[i] == 1) remove_node(g, i);
@@ -1046,7 +1058,7 @@ __device__ __forceinline__ u32 collect_tips(Win& g, u32 comp, u32* rm) {
     }
     ordered_append(flag, i, rm, nrm);
   }
-  wave_sync_mem();
+  wave_sync_mem(g.lds);
   return nrm;
 }
 
@@ -1080,7 +1092,7 @@ __device__ __forceinline__ void rank_slices(Win& g) {
     bool const fwd = nx != kNoNode && nx < g.n && g.sprev[nx] == i;
     rank[i] = fwd ? ((1u << 16) | nx) : i;
   }
-  wave_sync_mem();
+  wave_sync_mem(g.lds);
   while (true) {
     bool changed = false;
     for (u32 i = lane; i < g.n; i += 64) {
@@ -1091,7 +1103,7 @@ __device__ __forceinline__ void rank_slices(Win& g) {
         changed = true;
       }
     }
-    wave_sync_mem();
+    wave_sync_mem(g.lds);
     if (!__ballot(changed)) break;
   }
 }
@@ -1127,7 +1139,7 @@ __device__ __forceinline__ bool emit_node_seq(const Win& g, u32 node, bool dflt,
       s = static_cast<u32>(__builtin_amdgcn_readlane(static_cast<int>(nx), static_cast<int>(run)));
     }
   }
-  wave_sync_mem();
+  wave_sync_mem(g.lds);
   bool over = false;
   u32 emitted = 0;  // bases of the node spelled by the blocks before this one
   for (u32 b0 = 0; b0 < ns; b0 += 64) {
@@ -1195,7 +1207,7 @@ __device__ __forceinline__ bool emit_node_seq(const Win& g, u32 node, bool dflt,
     emitted += __shfl(inc, 63, 64);
   }
   *pos += emitted > skip ? emitted - skip : 0u;
-  wave_sync_mem();
+  wave_sync_mem(g.lds);
   return __ballot(over) == 0;
 }
 
@@ -1216,7 +1228,7 @@ struct OnlineStats {  // base/compute_stats.h:75-125
 // ascending sort of a short list kept in the window's scratch: up to 64 values are ranked in registers (lane l counts
 // the values that sort before its own; equal values keep their order) instead of shuffling them through memory
 __device__ __forceinline__ void isort_u32(u32* v, u32 n);
-__device__ __forceinline__ void sort_small_u32(u32* v, u32 n) {
+__device__ __forceinline__ void sort_small_u32(u32* v, u32 n, bool lds_only) {
   if (n > 64) {
     isort_u32(v, n);
     return;
@@ -1228,9 +1240,9 @@ __device__ __forceinline__ void sort_small_u32(u32* v, u32 n) {
     u32 const y = __builtin_amdgcn_readlane(x, j);
     rank += (y < x || (y == x && j < lane)) ? 1u : 0u;
   }
-  wave_sync_mem();  // every lane has read before any lane writes
+  wave_sync_mem(lds_only);  // every lane has read before any lane writes
   if (lane < n) v[rank] = x;
-  wave_sync_mem();
+  wave_sync_mem(lds_only);
 }
 __device__ __forceinline__ void isort_u32(u32* v, u32 n) {
   for (u32 i = 1; i < n; ++i) {
@@ -1277,9 +1289,18 @@ extern "C" void ma_debug_cprof(unsigned long long* out, int reset) {
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_cprof), z, sizeof(z));
   }
 }
+#define CSUB_T0() unsigned long long _u0 = __builtin_amdgcn_s_memtime()
+#define CSUB_ACC(slot)                                                        \
+  do {                                                                        \
+    unsigned long long _u1 = __builtin_amdgcn_s_memtime();                    \
+    if (threadIdx.x == 0) atomicAdd(&g_cprof[slot], _u1 - _u0);               \
+    _u0 = _u1;                                                                \
+  } while (0)
 #else
 #define CPROF_T0() do {} while (0)
 #define CPROF_ACC(slot) do {} while (0)
+#define CSUB_T0() do {} while (0)
+#define CSUB_ACC(slot) do {} while (0)
 #endif
 
 // MarkConnectedComponents (graph.cpp:392-463), lane-parallel; returns the number of components.  `lab` is working
@@ -1288,7 +1309,7 @@ extern "C" void ma_debug_cprof(unsigned long long* out, int reset) {
 __device__ __forceinline__ u32 label_components(Win& g, u32* lab, u32* cid, u32 lane) {
   u32 ncomp_all = 0;
   for (u32 i = lane; i < g.n; i += 64) lab[i] = i;
-  wave_sync_mem();
+  wave_sync_mem(g.lds);
   // FastSV-style hooking (Zhang, Azad, Hu 2020): lab[] is a forest of pointers towards smaller indices;
   // every edge hooks the parent of one end (and the end itself) onto the grandparent of the other, then
   // every node shortcuts to its grandparent.  At the fixed point every tree is a star rooted at the
@@ -1310,7 +1331,7 @@ __device__ __forceinline__ u32 label_components(Win& g, u32* lab, u32* cid, u32 
         changed = true;
       }
     }
-    wave_sync_mem();
+    wave_sync_mem(g.lds);
     for (u32 i = lane; i < g.n; i += 64) {
       u32 const pu = lab[i];
       u32 const gu = lab[pu];
@@ -1319,7 +1340,7 @@ __device__ __forceinline__ u32 label_components(Win& g, u32* lab, u32* cid, u32 
         changed = true;
       }
     }
-    wave_sync_mem();
+    wave_sync_mem(g.lds);
     if (!__ballot(changed)) break;
   }
   for (u32 base = 0; base < g.n; base += 64) {
@@ -1329,9 +1350,9 @@ __device__ __forceinline__ u32 label_components(Win& g, u32* lab, u32* cid, u32 
     if (root) cid[i] = ncomp_all + 1 + static_cast<u32>(__popcll(m & ((1ull << lane) - 1ull)));
     ncomp_all += static_cast<u32>(__popcll(m));
   }
-  wave_sync_mem();
+  wave_sync_mem(g.lds);
   for (u32 i = lane; i < g.n; i += 64) g.comp[i] = cid[lab[i]];
-  wave_sync_mem();
+  wave_sync_mem(g.lds);
   return ncomp_all;
 }
 
@@ -1346,15 +1367,18 @@ struct CleanArgs {
 // (candidate components, accepted walks, the edge order of EnqueueOutgoingEdges): as private arrays those lived in
 // scratch memory -- an HBM round trip per access of an already serial loop, 1.6 KB per lane.
 constexpr int kMaxCand = 16;
-struct CleanLds {
-  u32 link[kLinkCap];
+template <u32 kLink>
+struct CleanLdsT {
+  u32 link[kLink];
   u32 cand_comp[kMaxCand], cand_size[kMaxCand], cand_src[kMaxCand], cand_snk[kMaxCand], cand_soff[kMaxCand], cand_koff[kMaxCand];
   u32 walk_off[kMaxWalks], walk_len[kMaxWalks], walk_minw[kMaxWalks];
   int order[kMaxWalks];
   u32 eq_idx[kEdgeCap], eq_conf[kEdgeCap];
 };
 
-__device__ __forceinline__ void clean_candidates(CleanArgs const& A, Win& g, CleanLds& sh, int a, int w, int ncand, int first_phase, u32 NC);
+using CleanLds = CleanLdsT<kLinkCap>;
+template <class SH>
+__device__ __forceinline__ void clean_candidates(CleanArgs const& A, Win& g, SH& sh, int a, int w, int ncand, int first_phase, u32 NC);
 
 __global__ __launch_bounds__(64, 4) void k_clean(CleanArgs A) {
   int const a = blockIdx.x;
@@ -1406,6 +1430,11 @@ __global__ __launch_bounds__(64, 4) void k_clean(CleanArgs A) {
   g.bsign = g.sign;
   g.pool = nullptr;
   g.ecap = kEdgeCap;
+  g.lds = false;
+  g.ek = 4;
+  g.wk = 7;
+  g.pieces = nullptr;
+  g.piece_cap = 0;
   g.link_cap = kLinkCap;
   g.arena = ws.arena + static_cast<size_t>(a) * ws.ac;
   g.ac = ws.ac;
@@ -1432,7 +1461,7 @@ __global__ __launch_bounds__(64, 4) void k_clean(CleanArgs A) {
     g.snext[i] = g.sprev[i] = kNoNode;
     g.sdesc[i] = sd_make(0u, K, 0u);
   }
-  wave_sync_mem();
+  wave_sync_mem(g.lds);
 
   CPROF_ACC(0);
   // ---- MarkConnectedComponents (graph.cpp:392-463): ids in discovery order over canonical order ----
@@ -1466,7 +1495,7 @@ __global__ __launch_bounds__(64, 4) void k_clean(CleanArgs A) {
       last_off[c] = 0;         // maximum (only read when first_off exists)
       csize[c] = 0;
     }
-    wave_sync_mem();
+    wave_sync_mem(g.lds);
     // neighbouring indices mostly share a component: one atomic per distinct component of the 64, issued by the
     // group's first lane, instead of 64 atomics queueing on one address
     for (u32 base = 0; base < g.n; base += 64) {
@@ -1498,7 +1527,7 @@ __global__ __launch_bounds__(64, 4) void k_clean(CleanArgs A) {
         rem &= ~m;
       }
     }
-    wave_sync_mem();
+    wave_sync_mem(g.lds);
     for (u32 c = 1; c <= ncomp_all; ++c) {
       if (first_off[c] == kNoNode) continue;
       u32 const so = first_off[c], ko = last_off[c];
@@ -1539,7 +1568,8 @@ __global__ __launch_bounds__(64, 4) void k_clean(CleanArgs A) {
 // The candidate components in order (graph.cpp:142-235): PruneComponent, BuildTraversalIndex, HasCycle, complexity gate,
 // MaxFlow::NextPath loop, BuildHaplotypes; then the window's status.  first_phase = 0 on the raw graph; 1 when
 // k_clean_chains has already done the first CompressGraph (the graph in `g` is then the compact one).
-__device__ __forceinline__ void clean_candidates(CleanArgs const& A, Win& g, CleanLds& sh, int a, int w, int ncand, int first_phase, u32 NC) {
+template <class SH>
+__device__ __forceinline__ void clean_candidates(CleanArgs const& A, Win& g, SH& sh, int a, int w, int ncand, int first_phase, u32 NC) {
   GraphWs const& ws = A.ws;
   ma_params_t const& P = A.prm;
   u32 const lane = threadIdx.x;
@@ -1595,13 +1625,14 @@ __device__ __forceinline__ void clean_candidates(CleanArgs const& A, Win& g, Cle
     u32* flat_nodes = g.scratch + 2 * NC;
     u32* rstart = g.scratch + 3 * NC;    // [2V]
     u32* rcnt = g.scratch + 5 * NC;      // [2V]
-    u32* adj_state = g.scratch + 7 * NC;   // [E]
-    u32* adj_ord = g.scratch + 11 * NC;    // [E]
-    u32* ord_src = g.scratch + 15 * NC;    // [E] source node of ordinal
-    u32* ord_val = g.scratch + 19 * NC;    // [E] dst<<2|kind of ordinal
-    u8* traversed = reinterpret_cast<u8*>(g.scratch + 23 * NC);  // [E]
-    u8* color = reinterpret_cast<u8*>(g.scratch + 24 * NC);      // [2V]
-    u32* stack = g.scratch + 25 * NC;      // DFS frames (2 u32 each) / walk pool afterwards
+    u32 const EK = g.ek;
+    u32* adj_state = g.scratch + 7 * NC;              // [E <= EK * NC]
+    u32* adj_ord = g.scratch + (7 + EK) * NC;         // [E]
+    u32* ord_src = g.scratch + (7 + 2 * EK) * NC;     // [E] source node of ordinal
+    u32* ord_val = g.scratch + (7 + 3 * EK) * NC;     // [E] dst<<2|kind of ordinal
+    u8* traversed = reinterpret_cast<u8*>(g.scratch + (7 + 4 * EK) * NC);  // [E]
+    u8* color = reinterpret_cast<u8*>(g.scratch + (8 + 4 * EK) * NC);      // [2V]
+    u32* stack = g.scratch + (9 + 4 * EK) * NC;       // DFS frames (2 u32 each) / walk pool afterwards
     u32 V = 0, E = 0;
     for (u32 base = 0; base < g.n; base += 64) {
       u32 const i = base + lane;
@@ -1611,7 +1642,7 @@ __device__ __forceinline__ void clean_candidates(CleanArgs const& A, Win& g, Cle
       if (in) flat_nodes[V + __popcll(m & ((1ull << lane) - 1ull))] = i;
       V += static_cast<u32>(__popcll(m));
     }
-    wave_sync_mem();
+    wave_sync_mem(g.lds);
     // one lane per node: edge counts per strand side, then the two prefix sums of the reference's loops in one --
     // a state's block starts where the edges of the nodes before it end, and so do the node's edge ordinals
     {
@@ -1644,9 +1675,9 @@ __device__ __forceinline__ void clean_candidates(CleanArgs const& A, Win& g, Cle
         carry += __shfl(incl, 63, 64);
       }
       E = carry;
-      wave_sync_mem();
+      wave_sync_mem(g.lds);
     }
-    if (E > 4 * NC || 2 * V > 2 * NC) {
+    if (E > EK * NC || 2 * V > 2 * NC || 4u * V + 4u > g.wk * NC) {
       g.flags |= 4u;
       break;
     }
@@ -1667,7 +1698,7 @@ __device__ __forceinline__ void clean_candidates(CleanArgs const& A, Win& g, Cle
         adj_ord[slot] = ord;
       }
     }
-    wave_sync_mem();
+    wave_sync_mem(g.lds);
     u32 const src_state = flat_of[g.source] * 2 + (g.sign[g.source] ? 0u : 1u);
     u32 const snk_flat = flat_of[g.sink];
 
@@ -1769,7 +1800,7 @@ __device__ __forceinline__ void clean_candidates(CleanArgs const& A, Win& g, Cle
     uint4* const arena = g.arena;
     u32 const arena_cap = g.ac;
     u32* walk_pool = stack;  // ordinals of accepted walks, back to back
-    u32 walk_pool_cap = 7 * NC, walk_pool_used = 0;
+    u32 walk_pool_cap = g.wk * NC, walk_pool_used = 0;
     u32* const walk_off = sh.walk_off;
     u32* const walk_len = sh.walk_len;
     u32* const walk_minw = sh.walk_minw;
@@ -1787,7 +1818,7 @@ __device__ __forceinline__ void clean_candidates(CleanArgs const& A, Win& g, Cle
     // edge of every popped entry
     if (fold) {
       for (u32 f = lane; f < V; f += 64) l_link[4u * V + f] = nd_confidence(g, flat_nodes[f]);
-      wave_sync_mem();
+      wave_sync_mem(g.lds);
     }
     while (true) {
       u32 an = 0, head = 0;
@@ -1795,7 +1826,7 @@ __device__ __forceinline__ void clean_candidates(CleanArgs const& A, Win& g, Cle
       u64 build_total = 0;         // reference entries (multiplicities) of the level being built
       if (fold) {
         for (u32 x = lane; x < 4u * V; x += 64) rep[x] = kNoNode;
-        wave_sync_mem();
+        wave_sync_mem(g.lds);
       }
       // w of an arena record: bit 31 = the walk has crossed a not yet traversed edge, bits 0-30 = multiplicity
       auto push = [&](u32 ord, u32 st, u32 parent, u32 flag, u32 mult) {
@@ -1946,6 +1977,7 @@ __device__ __forceinline__ void clean_candidates(CleanArgs const& A, Win& g, Cle
     if (nwalks == 0) continue;  // graph.cpp:225
 
     g.ranked = g.n <= g.link_cap;  // (distance, last slice) per slice
+    CSUB_T0();
     if (g.ranked) rank_slices(g);
     // Node::Confidence and the total coverage of the component's nodes, behind the slice ranks: every walk asks for
     // both at every node it passes
@@ -1955,7 +1987,7 @@ __device__ __forceinline__ void clean_candidates(CleanArgs const& A, Win& g, Cle
         l_link[g.n + f] = nd_confidence(g, flat_nodes[f]);
         l_link[g.n + V + f] = nd_total(g, flat_nodes[f]);
       }
-      wave_sync_mem();
+      wave_sync_mem(g.lds);
     }
     auto conf_at = [&](u32 node) { return have_tab ? l_link[g.n + flat_of[node]] : nd_confidence(g, node); };
     auto total_at = [&](u32 node) { return have_tab ? l_link[g.n + V + flat_of[node]] : nd_total(g, node); };
@@ -1975,6 +2007,7 @@ __device__ __forceinline__ void clean_candidates(CleanArgs const& A, Win& g, Cle
     }
     size_t const cidx = static_cast<size_t>(w) * MC + ncomp_out;
     u32 const hap0 = slot;
+    CSUB_ACC(11);
     // REF haplotype (graph.cpp:902-924)
     {
       u32* confs = g.scratch;  // reuse
@@ -1987,8 +2020,8 @@ __device__ __forceinline__ void clean_candidates(CleanArgs const& A, Win& g, Cle
         if (is_ref) confs[ncf + __popcll(m & ((1ull << lane) - 1ull))] = nd_confidence(g, i);
         ncf += static_cast<u32>(__popcll(m));
       }
-      wave_sync_mem();
-      sort_small_u32(confs, ncf);
+      wave_sync_mem(g.lds);
+      sort_small_u32(confs, ncf, g.lds);
       u32 const wgt = ncf == 0 ? 1u : median_sorted(confs, ncf);
       size_t const hi = static_cast<size_t>(w) * MH + slot;
       u32 len = anchor_len;
@@ -1996,8 +2029,20 @@ __device__ __forceinline__ void clean_candidates(CleanArgs const& A, Win& g, Cle
         status |= MA_W_LEN_OVERFLOW;
         len = ML;
       }
-      for (u32 x = lane; x < len; x += 64) A.out.hap_bases[hi * ML + x] = ref_anchor[x];
-      wave_sync_mem();
+      for (u32 x0 = 0; x0 < len; x0 += 512) {  // eight loads in flight, then eight stores (the compiler cannot tell that
+        u8 tmp[8];                              // the two buffers do not overlap and would wait for every byte)
+#pragma unroll
+        for (u32 q = 0; q < 8; ++q) {
+          u32 const x = x0 + q * 64 + lane;
+          tmp[q] = x < len ? ref_anchor[x] : 0;
+        }
+#pragma unroll
+        for (u32 q = 0; q < 8; ++q) {
+          u32 const x = x0 + q * 64 + lane;
+          if (x < len) A.out.hap_bases[hi * ML + x] = tmp[q];
+        }
+      }
+      wave_sync_mem(g.lds);
       A.out.hap_len[hi] = len;
       A.out.hap_nruns[hi] = 1;
       A.out.hap_runs[(hi * MR) * 2 + 0] = wgt;
@@ -2005,6 +2050,7 @@ __device__ __forceinline__ void clean_candidates(CleanArgs const& A, Win& g, Cle
       for (int x = 0; x < 6; ++x) A.out.hap_stats[hi * 6 + x] = 0.0;
       slot++;
     }
+    CSUB_ACC(12);
     f64 max_alt_cv = -1.0;
     bool has_alt = false;
     for (int oi = 0; oi < nwalks; ++oi) {
@@ -2018,9 +2064,105 @@ __device__ __forceinline__ void clean_candidates(CleanArgs const& A, Win& g, Cle
       u32* covs = g.scratch;  // node coverages in walk order
       u32 ncov = 0, pos = 0, nruns = 0;
       bool ok = true, runs_ok = true;
+      CSUB_ACC(15);
       // BuildSequence (max_flow.cpp:64-113)
       u32 const wl = walk_len[wi];
       const u32* wo = walk_pool + walk_off[wi];
+      if (g.lds) {
+        // The whole walk at once (every base string is in the LDS pool, stored orientation): a lane per node works out
+        // where the node's bases go (prefix sum of the lengths each node contributes) and turns its slice list into
+        // PIECES -- (first source byte, direction, complement, length, output offset) -- then the pieces are copied one
+        // after the other, a lane per base.  Was: a call per node with its own scans, list look-up and fences.
+        u32* const pieces = g.pieces;
+        if (lane == 0) pieces[0] = 0;
+        wave_sync_mem(true);
+        u32 carry = 0;
+        bool pover = false;
+        for (u32 t0 = 0; t0 <= wl; t0 += 64) {
+          u32 const tt = t0 + lane;
+          bool const on = tt <= wl;
+          u32 node = 0, clen = 0, skip = 0;
+          bool dfl = true;
+          if (on) {
+            if (tt == 0) {
+              u32 const e0 = ord_val[wo[0]];
+              node = ord_src[wo[0]];
+              dfl = ((e0 >> 1) & 1u) == 0u;  // walk[0].SrcSign() == PLUS
+            } else {
+              u32 const e = ord_val[wo[tt - 1]];
+              node = e >> 2;
+              dfl = (e & 1u) == 0u;          // conn.DstSign() == PLUS
+              skip = K - 1;
+            }
+            u32 const ln = g.len[node];
+            clen = ln > skip ? ln - skip : 0u;
+          }
+          u32 inc = clen;
+#pragma unroll
+          for (u32 o = 1; o < 64; o <<= 1) {
+            u32 const y = __shfl_up(inc, o, 64);
+            if (lane >= o) inc += y;
+          }
+          if (on) {
+            covs[tt] = total_at(node);
+            if (static_cast<int>(tt) < MR) {
+              A.out.hap_runs[(hi * MR + tt) * 2 + 0] = conf_at(node);
+              A.out.hap_runs[(hi * MR + tt) * 2 + 1] = clen;
+            } else {
+              runs_ok = false;
+            }
+            u32 o = carry + inc - clen;
+            u32 sidx = dfl ? g.head[node] : g.tail[node];
+            while (sidx != kNoNode) {
+              u32 const d = g.sdesc[sidx], st = sd_st(d), ln = sd_ln(d), rc = sd_rc(d);
+              u32 const bl = g.blen[sidx], po = g.bsrc[sidx] & 0x3FFFFFFFu;
+              u32 const nx = dfl ? g.snext[sidx] : g.sprev[sidx];
+              if (skip >= ln) {
+                skip -= ln;
+              } else {
+                u32 const j0 = skip, take = ln - skip;
+                skip = 0;
+                // j-th base of the slice as the walk reads it: forwards  rc ? comp(B[bl-1-st-j]) : B[st+j],
+                //                                             backwards rc ? B[bl-st-ln+j] : comp(B[st+ln-1-j])
+                bool const back = dfl ? (rc != 0u) : (rc == 0u);  // source index runs downwards, bases complemented
+                u32 const idx0 = dfl ? (rc ? bl - 1u - st - j0 : st + j0) : (rc ? bl - st - ln + j0 : st + ln - 1u - j0);
+                u32 const at = atomicAdd(&pieces[0], 1u);
+                if (at < g.piece_cap && o + take <= 0xFFFFu) {
+                  pieces[1 + 2 * at] = (po + idx0) | (back ? 0x80000000u : 0u);
+                  pieces[2 + 2 * at] = take | (o << 16);
+                } else {
+                  pover = true;
+                }
+                o += take;
+              }
+              sidx = nx;
+            }
+          }
+          carry += __shfl(inc, 63, 64);
+        }
+        pos = carry;
+        ncov = wl + 1u;
+        nruns = wl + 1u;
+        wave_sync_mem(true);
+        if (__ballot(pover)) {
+          g.flags |= 4u;  // more slices than the piece table holds: k_clean has the window again
+          break;
+        }
+        u32 const np = pieces[0];
+        const u8* const lp = g.pool;
+        bool over = false;
+        for (u32 q = 0; q < np; ++q) {
+          u32 const w0 = pieces[1 + 2 * q], w1 = pieces[2 + 2 * q];
+          u32 const src = w0 & 0x3FFFFFFFu, ln = w1 & 0xFFFFu, o = w1 >> 16;
+          bool const back = (w0 >> 31) != 0u;
+          for (u32 j = lane; j < ln; j += 64) {
+            u8 const c = lp[back ? src - j : src + j];
+            u32 const at = o + j;
+            if (at < static_cast<u32>(ML)) hb[at] = back ? dev_complement(c) : c; else over = true;
+          }
+        }
+        ok = __ballot(over) == 0;
+      } else {
       {
         u32 const e0 = ord_val[wo[0]];
         u32 const sn = ord_src[wo[0]];
@@ -2047,6 +2189,8 @@ __device__ __forceinline__ void clean_candidates(CleanArgs const& A, Win& g, Cle
         } else runs_ok = false;
         nruns++;
       }
+      }
+      CSUB_ACC(13);
       // dedup by sequence against kept haplotypes of this component and the ref anchor (graph.cpp:883-887)
       bool dup = false;
       if (ok) {
@@ -2063,6 +2207,7 @@ __device__ __forceinline__ void clean_candidates(CleanArgs const& A, Win& g, Cle
       if (!ok || !runs_ok) status |= MA_W_LEN_OVERFLOW;
       A.out.hap_len[hi] = pos < static_cast<u32>(ML) ? pos : static_cast<u32>(ML);
       A.out.hap_nruns[hi] = nruns < static_cast<u32>(MR) ? nruns : static_cast<u32>(MR);
+      CSUB_ACC(14);
       // Path::Finalize (path.cpp:39-70)
       OnlineStats st;
       for (u32 x = 0; x < ncov; ++x) st.add(static_cast<f64>(covs[x]));
@@ -2070,7 +2215,7 @@ __device__ __forceinline__ void clean_candidates(CleanArgs const& A, Win& g, Cle
       f64 const total = mean * static_cast<f64>(st.n);
       f64 cv = 0.0, qcv = 0.0;
       if (mean > 0.0) cv = sdv / mean;
-      sort_small_u32(covs, ncov);
+      sort_small_u32(covs, ncov, g.lds);
       f64 const med = static_cast<f64>(median_sorted(covs, ncov));
       if (ncov >= 4) {
         f64 const q1 = static_cast<f64>(covs[ncov / 4]), q3 = static_cast<f64>(covs[(ncov * 3) / 4]);
@@ -2137,15 +2282,21 @@ __device__ __forceinline__ void clean_candidates(CleanArgs const& A, Win& g, Cle
 // windows); otherwise the same code runs on the arrays in HBM.  Capacities of this route that a window outgrows (edge
 // slots, arena, walk pool) hand it to k_clean, never to the caller.
 constexpr u32 kTailV = 128;       // nodes of the LDS image
-constexpr u32 kTailArena = 640;   // search records
-constexpr u32 kTailLink = 1024;
+constexpr u32 kTailArena = 320;   // search records
+constexpr u32 kTailLink = 640;
+constexpr u32 kTailS = 4;         // samples
+constexpr u32 kTailEk = 2, kTailWk = 5;
+constexpr u32 kTailPieces = 255;  // slices of one walk
+constexpr u32 kTailPool = 5120;   // bytes of base strings (merged strings + the k-mers of untouched nodes)
 struct TailLds {
-  u32 cnt[kTailV * kMaxSamples], role[kTailV * 2], bsrc[kTailV], blen[kTailV], len[kTailV], comp[kTailV];
+  u32 cnt[kTailV * kTailS], role[kTailV * 2], bsrc[kTailV], blen[kTailV], len[kTailV], comp[kTailV];
   u32 edge[kTailV * kCgEdgeCap];
   u32 head[kTailV], tail[kTailV], snext[kTailV], sprev[kTailV], sdesc[kTailV];
   u8 label[kTailV], sign[kTailV], bsign[kTailV], nedge[kTailV], alive[kTailV];
-  u32 scratch[32 * kTailV];
+  u32 scratch[(9 + 4 * kTailEk + kTailWk) * kTailV];
   uint4 arena[kTailArena];
+  u32 pool[kTailPool / 4];
+  u32 pieces[1 + 2 * kTailPieces];
 };
 
 template <bool kLds>
@@ -2155,11 +2306,13 @@ __global__ __launch_bounds__(64, 4) void k_clean_tail(CleanArgs A) {
   GraphWs const& ws = A.ws;
   if (ws.cg_state[a] != 1u) return;
   const u32* hdr = ws.cg_hdr + static_cast<size_t>(a) * kCgHdr;
-  u32 const V = hdr[0];
-  if ((V <= kTailV) != kLds) return;  // the other instantiation's window
+  u32 const V = hdr[0], pool_used = hdr[2];
+  u32 const kk = static_cast<u32>(win_kmer(ws, static_cast<int>(ws.active[a])));
+  bool const fits = V <= kTailV && pool_used + 4u + V * kk <= kTailPool && static_cast<u32>(ws.num_samples) <= kTailS;
+  if (fits != kLds) return;  // the other instantiation's window
   int const w = static_cast<int>(ws.active[a]);
   size_t const nb = static_cast<size_t>(a) * ws.vc;
-  __shared__ CleanLds sh;
+  __shared__ CleanLdsT<kTailLink> sh;
   Win g;
   g.link = sh.link;
   g.ranked = false;
@@ -2173,6 +2326,7 @@ __global__ __launch_bounds__(64, 4) void k_clean_tail(CleanArgs A) {
   g.min_anchor_cov = A.prm.min_anchor_cov;
   g.pool = ws.cg_pool + static_cast<size_t>(a) * ws.pool_cap;
   g.ecap = kCgEdgeCap;
+  g.lds = kLds;
   g.source = g.sink = -1;
   g.flags = 0;
   u32 NC;
@@ -2215,7 +2369,35 @@ __global__ __launch_bounds__(64, 4) void k_clean_tail(CleanArgs A) {
     g.bsrc = tl.bsrc;
     g.blen = tl.blen;
     g.bsign = tl.bsign;
+    // every base string into LDS: the merged strings as they are, the k-mers of untouched nodes in their stored
+    // orientation -- spelling a haplotype then never waits for HBM (one round trip per slice, ~20 slices a walk)
+    {
+      u8* const lp = reinterpret_cast<u8*>(tl.pool);
+      const u32* gp = reinterpret_cast<const u32*>(g.pool);
+      for (u32 i = lane; i < (pool_used + 3u) / 4u; i += 64) tl.pool[i] = gp[i];
+      u32 nsingle = 0;
+      for (u32 i0 = 0; i0 < V; i0 += 64) {
+        u32 const i = i0 + lane;
+        u32 const sv = i < V ? tl.bsrc[i] : 0x40000000u;
+        bool const single = !(sv & 0x40000000u);
+        unsigned long long const m = __ballot(single);
+        if (single) {
+          u32 const off = ((pool_used + 3u) & ~3u) + (nsingle + static_cast<u32>(__popcll(m & ((1ull << lane) - 1ull)))) * kk;
+          const u8* p = (sv & 0x80000000u) ? g.readb + (sv & 0x3FFFFFFFu) : g.refb + sv;
+          bool const plus = tl.bsign[i] != 0;
+          for (u32 x = 0; x < kk; ++x) lp[off + x] = plus ? p[x] : dev_complement(p[kk - 1u - x]);
+          tl.bsrc[i] = 0x40000000u | off;
+          tl.bsign[i] = 1;
+        }
+        nsingle += static_cast<u32>(__popcll(m));
+      }
+      g.pool = lp;
+    }
     g.scratch = tl.scratch;
+    g.pieces = tl.pieces;
+    g.piece_cap = kTailPieces;
+    g.ek = kTailEk;
+    g.wk = kTailWk;
     g.arena = tl.arena;
     g.ac = kTailArena;
     g.link_cap = kTailLink;
@@ -2240,6 +2422,10 @@ __global__ __launch_bounds__(64, 4) void k_clean_tail(CleanArgs A) {
     g.blen = ws.cg_blen + nb;
     g.bsign = ws.cg_bsign + nb;
     g.scratch = ws.cg_scratch + static_cast<size_t>(a) * ws.cg_sc * 32;
+    g.pieces = nullptr;
+    g.piece_cap = 0;
+    g.ek = 4;
+    g.wk = 7;
     g.arena = ws.arena + static_cast<size_t>(a) * ws.ac;
     g.ac = ws.ac;
     g.link_cap = kTailLink;
@@ -2266,7 +2452,7 @@ __global__ __launch_bounds__(64, 4) void k_clean_tail(CleanArgs A) {
     sh.cand_soff[lane] = c[4];
     sh.cand_koff[lane] = c[5];
   }
-  wave_sync_mem();
+  wave_sync_mem(g.lds);
   clean_candidates(A, g, sh, a, w, ncand, 1, NC);
 }
 
