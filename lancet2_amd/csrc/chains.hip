@@ -84,8 +84,9 @@ struct Lds {
 
 // seg_fl bits
 constexpr u32 SF_BL = 1u, SF_BR = 2u, SF_TIPL = 4u, SF_TIPR = 8u, SF_SLOTL_SH = 4, SF_SLOTR_SH = 6, SF_DML = 1u << 8, SF_DMR = 1u << 9;
+constexpr u32 SF_DESC = 1u << 10;  // some node index is smaller than its left neighbour's (else: ascending along the segment)
 // misc words
-constexpr int M_PUNT = 0, M_XE = 1, M_CHANGED = 2, M_NCOMP = 3, M_NCAND = 4, M_G = 5, M_V = 6, M_POOL = 7, M_WSUM = 8;  // wsum: 4 words
+constexpr int M_PUNT = 0, M_XE = 1, M_NCOMP = 3, M_NCAND = 4, M_G = 5, M_V = 6, M_POOL = 7, M_WSUM = 8, M_CHANGED = 12;  // wsum: 4 words, changed: 2 words
 
 __device__ __forceinline__ u32 kind_rev(u32 kind) { return (((kind & 1u) ^ 1u) << 1) | (((kind >> 1) & 1u) ^ 1u); }
 
@@ -223,26 +224,40 @@ __global__ __launch_bounds__(kT) void k_clean_chains(ChainArgs A) {
 
   CH_T0();
   // ---- the raw graph: flags, first two edges inline, the rare third and fourth in a side table ----
-  for (u32 i = t; i < n; i += kT) {
-    u32 const ne = ws.nd_nedge[nb + i];
-    uint4 const ev = *reinterpret_cast<const uint4*>(ws.nd_edge + (nb + i) * kEdgeCap);
-    u32 e1 = ne > 1 ? ev.y : 0u;
-    if (ne > 4u) PUNT();
-    if (ne > 2u) {
-      u32 const idx = atomicAdd(&L.misc[M_XE], 1u);
-      if (idx >= kXeCap) {
-        PUNT();
-      } else {
-        L.xe[idx * 4 + 0] = static_cast<u16>(ev.y);
-        L.xe[idx * 4 + 1] = static_cast<u16>(ev.z);
-        L.xe[idx * 4 + 2] = static_cast<u16>(ne > 3 ? ev.w : 0u);
-      }
-      e1 = idx;
+  for (u32 base = 0; base < n; base += 8 * kT) {  // eight nodes per thread: their loads in flight together
+    u32 ne_[8], sg_[8], lb_[8];
+    uint4 ev_[8];
+#pragma unroll
+    for (u32 q = 0; q < 8; ++q) {
+      u32 const i = base + q * kT + t, ic = i < n ? i : 0u;
+      ne_[q] = ws.nd_nedge[nb + ic];
+      sg_[q] = ws.nd_sign[nb + ic];
+      lb_[q] = ws.nd_label[nb + ic];
+      ev_[q] = *reinterpret_cast<const uint4*>(ws.nd_edge + (nb + ic) * kEdgeCap);
     }
-    L.e2[i] = (ne > 0 ? (ev.x & 0xFFFFu) : 0u) | (e1 << 16);
-    L.fl[i] = static_cast<u16>((ne > 4u ? 0u : ne) | (ws.nd_sign[nb + i] ? F_SIGN : 0u) | (static_cast<u32>(ws.nd_label[nb + i] & 7u) << F_LABEL_SH) |
-                               (15u << F_CAND_SH));
-    L.x[i] = i;  // FastSV label
+#pragma unroll
+    for (u32 q = 0; q < 8; ++q) {
+      u32 const i = base + q * kT + t;
+      if (i >= n) continue;
+      u32 const ne = ne_[q];
+      uint4 const ev = ev_[q];
+      u32 e1 = ne > 1 ? ev.y : 0u;
+      if (ne > 4u) PUNT();
+      if (ne > 2u) {
+        u32 const idx = atomicAdd(&L.misc[M_XE], 1u);
+        if (idx >= kXeCap) {
+          PUNT();
+        } else {
+          L.xe[idx * 4 + 0] = static_cast<u16>(ev.y);
+          L.xe[idx * 4 + 1] = static_cast<u16>(ev.z);
+          L.xe[idx * 4 + 2] = static_cast<u16>(ne > 3 ? ev.w : 0u);
+        }
+        e1 = idx;
+      }
+      L.e2[i] = (ne > 0 ? (ev.x & 0xFFFFu) : 0u) | (e1 << 16);
+      L.fl[i] = static_cast<u16>((ne > 4u ? 0u : ne) | (sg_[q] ? F_SIGN : 0u) | ((lb_[q] & 7u) << F_LABEL_SH) | (15u << F_CAND_SH));
+      L.x[i] = i;  // FastSV label
+    }
   }
   BAIL_IF_PUNT();
 
@@ -250,35 +265,71 @@ __global__ __launch_bounds__(kT) void k_clean_chains(ChainArgs A) {
   // ---- MarkConnectedComponents (graph.cpp:392-463): FastSV hooking + shortcutting on LDS labels ----
   {
     u32* const lab = L.x;
+    // Eight nodes per thread and trip: the loads of a level (label, parent's label, neighbours' labels, their parents')
+    // are in flight together -- a node at a time every trip was five dependent LDS round trips.
     for (int round = 0; round < 64; ++round) {
-      if (t == 0) L.misc[M_CHANGED] = 0;
+      bool hooked = false;
+      for (u32 base = 0; base < n; base += 8 * kT) {
+        u32 ic[8], pu[8], gu[8], ev[8], ne[8], a0[8], a1[8];
+        bool ok[8];
+#pragma unroll
+        for (u32 q = 0; q < 8; ++q) {
+          u32 const i = base + q * kT + t;
+          ok[q] = i < n;
+          ic[q] = ok[q] ? i : 0u;
+          pu[q] = lab[ic[q]];
+          ev[q] = L.e2[ic[q]];
+          ne[q] = ok[q] ? (L.fl[ic[q]] & F_NE) : 0u;
+        }
+#pragma unroll
+        for (u32 q = 0; q < 8; ++q) {
+          gu[q] = lab[pu[q]];
+          a0[q] = lab[ne[q] >= 1u ? ((ev[q] & 0xFFFFu) >> 2) : ic[q]];
+          a1[q] = lab[ne[q] == 2u ? (ev[q] >> 18) : ic[q]];
+        }
+#pragma unroll
+        for (u32 q = 0; q < 8; ++q) {
+          a0[q] = lab[a0[q]];
+          a1[q] = lab[a1[q]];
+        }
+#pragma unroll
+        for (u32 q = 0; q < 8; ++q) {
+          u32 best = min(gu[q], min(a0[q], a1[q]));  // (a node without that edge contributed lab[lab[i]] = gu or larger)
+          if (ne[q] > 2u)
+            for (u32 x = 1; x < ne[q]; ++x) best = min(best, lab[lab[edge_at(L, ic[q], x) >> 2]]);
+          if (ok[q] && best < gu[q]) {
+            atomicMin(&lab[pu[q]], best);
+            atomicMin(&lab[ic[q]], best);
+            hooked = true;
+          }
+        }
+      }
+      if (hooked) L.misc[M_CHANGED + (round & 1)] = 1u;
       __syncthreads();
+      if (t == 0) L.misc[M_CHANGED + ((round + 1) & 1)] = 0;  // (read again only after the next round's second barrier)
       bool changed = false;
-      for (u32 i = t; i < n; i += kT) {
-        u32 const pu = lab[i], gu = lab[pu], ne = L.fl[i] & F_NE;
-        u32 best = gu;
-        for (u32 x = 0; x < ne; ++x) {
-          u32 const v = edge_at(L, i, x) >> 2;
-          best = min(best, lab[lab[v]]);
+      for (u32 base = 0; base < n; base += 8 * kT) {
+        u32 ic[8], pu[8], gu[8];
+        bool ok[8];
+#pragma unroll
+        for (u32 q = 0; q < 8; ++q) {
+          u32 const i = base + q * kT + t;
+          ok[q] = i < n;
+          ic[q] = ok[q] ? i : 0u;
+          pu[q] = lab[ic[q]];
         }
-        if (best < gu) {
-          atomicMin(&lab[pu], best);
-          atomicMin(&lab[i], best);
-          changed = true;
-        }
+#pragma unroll
+        for (u32 q = 0; q < 8; ++q) gu[q] = lab[pu[q]];
+#pragma unroll
+        for (u32 q = 0; q < 8; ++q)
+          if (ok[q] && gu[q] < pu[q]) {
+            lab[ic[q]] = gu[q];
+            changed = true;
+          }
       }
+      if (changed) L.misc[M_CHANGED + (round & 1)] = 1u;
       __syncthreads();
-      for (u32 i = t; i < n; i += kT) {
-        u32 const pu = lab[i], gu = lab[pu];
-        if (gu < pu) {
-          lab[i] = gu;
-          changed = true;
-        }
-      }
-      if (changed) L.misc[M_CHANGED] = 1u;
-      __syncthreads();
-      if (!L.misc[M_CHANGED]) break;
-      __syncthreads();
+      if (!L.misc[M_CHANGED + (round & 1)]) break;
     }
     CH_ACC(1);
     // component ids in discovery order = rank of the component's smallest node among the roots
@@ -311,15 +362,27 @@ __global__ __launch_bounds__(kT) void k_clean_chains(ChainArgs A) {
     }
     __syncthreads();
     for (u32 i = t; i < n; i += kT) atomicAdd(&csize[L.a1[i]], 1u);
-    for (u32 r = t; r < n_refk; r += kT) {
-      u32 const nd = refn[r];
-      if (nd == kNoNode) continue;
-      u32 tot = 0;
-      for (int s = 0; s < S; ++s) tot += ws.nd_cnt[(nb + nd) * S + s];
-      if (tot < P.min_anchor_cov) continue;
-      u32 const c = L.a1[nd];
-      atomicMin(&first_off[c], r);
-      atomicMax(&last_off[c], r);
+    for (u32 base = 0; base < n_refk; base += 8 * kT) {
+      u32 nd_[8], tot_[8];
+#pragma unroll
+      for (u32 q = 0; q < 8; ++q) {
+        u32 const r = base + q * kT + t;
+        nd_[q] = r < n_refk ? refn[r] : kNoNode;
+      }
+#pragma unroll
+      for (u32 q = 0; q < 8; ++q) {
+        tot_[q] = 0;
+        if (nd_[q] != kNoNode)
+          for (int s = 0; s < S; ++s) tot_[q] += ws.nd_cnt[(nb + nd_[q]) * S + s];
+      }
+#pragma unroll
+      for (u32 q = 0; q < 8; ++q) {
+        u32 const r = base + q * kT + t;
+        if (nd_[q] == kNoNode || tot_[q] < P.min_anchor_cov) continue;
+        u32 const c = L.a1[nd_[q]];
+        atomicMin(&first_off[c], r);
+        atomicMax(&last_off[c], r);
+      }
     }
     __syncthreads();
     // candidates in component order, then stable by size descending (graph.cpp:441 made canonical)
@@ -425,31 +488,47 @@ __global__ __launch_bounds__(kT) void k_clean_chains(ChainArgs A) {
         st[2 * i + j] = (L.fl[nx] & F_INI) ? (((2 * nx + (e & 1u)) << 12) | 1u) : ((2 * i + j) << 12);
       }
     }
-    bool done = false;
-    for (int round = 0; round < 16; ++round) {
-      if (t == 0) L.misc[M_CHANGED] = 0;
+    // In-place, unsynchronised jumps are safe (a state's word is read and written whole, and only ever moves further along
+    // its chain): one barrier a round, ceil(log2 n) + 1 rounds settle every path; a ring of plain nodes never does.
+    int rounds = 2;
+    while ((1u << (rounds - 1)) < n) ++rounds;
+    for (int round = 0; round < rounds; ++round) {
       __syncthreads();
-      bool changed = false;
-      for (u32 i = t; i < n; i += kT) {
-        if (!(L.fl[i] & F_INI)) continue;
-        for (u32 j = 0; j < 2; ++j) {
-          u32 const v = st[2 * i + j], n1 = v >> 12, v2 = st[n1], n2 = v2 >> 12;
-          if (n2 != n1) {
-            st[2 * i + j] = (n2 << 12) | ((v & 0xFFFu) + (v2 & 0xFFFu));
-            changed = true;
-          }
+      for (u32 base = 0; base < n; base += 8 * kT) {
+        u32 va[8], vb[8], wa[8], wb[8];
+        bool ok[8];
+        u32 ic[8];
+#pragma unroll
+        for (u32 q = 0; q < 8; ++q) {
+          u32 const i = base + q * kT + t;
+          ok[q] = i < n && (L.fl[i < n ? i : 0u] & F_INI);
+          ic[q] = ok[q] ? i : 0u;
+        }
+#pragma unroll
+        for (u32 q = 0; q < 8; ++q) {
+          va[q] = ok[q] ? st[2 * ic[q]] : 0u;
+          vb[q] = ok[q] ? st[2 * ic[q] + 1] : 0u;
+        }
+#pragma unroll
+        for (u32 q = 0; q < 8; ++q) {
+          wa[q] = st[va[q] >> 12];
+          wb[q] = st[vb[q] >> 12];
+        }
+#pragma unroll
+        for (u32 q = 0; q < 8; ++q) {
+          if (!ok[q]) continue;
+          if ((wa[q] >> 12) != (va[q] >> 12)) st[2 * ic[q]] = (wa[q] & ~0xFFFu) | ((va[q] & 0xFFFu) + (wa[q] & 0xFFFu));
+          if ((wb[q] >> 12) != (vb[q] >> 12)) st[2 * ic[q] + 1] = (wb[q] & ~0xFFFu) | ((vb[q] & 0xFFFu) + (wb[q] & 0xFFFu));
         }
       }
-      if (changed) L.misc[M_CHANGED] = 1u;
-      __syncthreads();
-      if (!L.misc[M_CHANGED]) {
-        done = true;
-        break;
-      }
-      __syncthreads();
     }
-    if (!done) {
-      if (t == 0) PUNT();  // a ring of fully plain nodes never settles
+    __syncthreads();
+    for (u32 i = t; i < n; i += kT) {
+      if (!(L.fl[i] & F_INI)) continue;
+      for (u32 j = 0; j < 2; ++j) {
+        u32 const n1 = st[2 * i + j] >> 12;
+        if ((st[n1] >> 12) != n1) PUNT();  // not at a terminal state yet: a ring
+      }
     }
     BAIL_IF_PUNT();
     CH_ACC(5);
@@ -543,24 +622,48 @@ __global__ __launch_bounds__(kT) void k_clean_chains(ChainArgs A) {
       L.seg_fl[gg] = static_cast<u16>(fl);
     }
     BAIL_IF_PUNT();
+    // node indices ascending along the segment (k-mers enter the graph left to right: the reference backbone always is)?
+    // then the minimum of any interval is its left end and the walker search below needs no range query
+    for (u32 i = t; i < n; i += kT) {
+      if (!(L.fl[i] & F_INI)) continue;
+      u32 const gg = L.segi[i], pos = L.a1[i] - 1u;
+      if (pos + 1u < L.seg_m[gg] && L.p2n[L.seg_base[gg] + pos + 1u] < i) atomicOr(reinterpret_cast<u32*>(L.seg_fl) + (gg >> 1), (gg & 1u) ? (SF_DESC << 16) : SF_DESC);
+    }
+    __syncthreads();
   }
   u32 const G = L.misc[M_G];
 
   CH_ACC(7);
   // ---- per-node values (per-sample counts, two role counts) as u16; blocks, absorbers, rewrite times ----
   u16* const val = reinterpret_cast<u16*>(L.x);
-  for (u32 i = t; i < n; i += kT) {
-    bool const in = (L.fl[i] >> F_CAND_SH) != 15u;
-    for (u32 v = 0; v < VS; ++v) {
-      u32 c = 0;
-      if (in && v < NV) c = v < static_cast<u32>(S) ? ws.nd_cnt[(nb + i) * S + v] : ws.nd_role[(nb + i) * 2 + (v - S)];
-      if (c > 0xFFFFu) PUNT();
-      val[i * VS + v] = static_cast<u16>(c);
+  for (u32 base = 0; base < n; base += 4 * kT) {
+    u32 cv[4][16];
+#pragma unroll
+    for (u32 q = 0; q < 4; ++q) {
+      u32 const i = base + q * kT + t, ic = i < n ? i : 0u;
+#pragma unroll
+      for (u32 v = 0; v < 16; ++v) {
+        cv[q][v] = 0;
+        if (v < NV) cv[q][v] = v < static_cast<u32>(S) ? ws.nd_cnt[(nb + ic) * S + v] : ws.nd_role[(nb + ic) * 2 + (v - S)];
+      }
     }
-    L.abs[i] = static_cast<u16>(kNone16);
-    u32 const p1 = (L.fl[i] & F_INI) ? L.a1[i] : 0u;
-    L.blk[i] = p1 | (p1 << 16);
-    L.key[i] = 0;
+#pragma unroll
+    for (u32 q = 0; q < 4; ++q) {
+      u32 const i = base + q * kT + t;
+      if (i >= n) continue;
+      bool const in = (L.fl[i] >> F_CAND_SH) != 15u;
+#pragma unroll
+      for (u32 v = 0; v < 16; ++v) {
+        if (v >= VS) continue;
+        u32 const c = in ? cv[q][v] : 0u;
+        if (c > 0xFFFFu) PUNT();
+        val[i * VS + v] = static_cast<u16>(c);
+      }
+      L.abs[i] = static_cast<u16>(kNone16);
+      u32 const p1 = (L.fl[i] & F_INI) ? L.a1[i] : 0u;
+      L.blk[i] = p1 | (p1 << 16);
+      L.key[i] = 0;
+    }
   }
   BAIL_IF_PUNT();
 
@@ -679,7 +782,9 @@ __global__ __launch_bounds__(kT) void k_clean_chains(ChainArgs A) {
       };
       while (true) {
         CH_SUB0();
-        u32 const best = range_min(max(a_, elig_lo), min(b_, elig_hi));
+        i32 const qlo = max(a_, elig_lo), qhi = min(b_, elig_hi);
+        u32 const best = (sfl & SF_DESC) ? range_min(qlo, qhi)
+                                         : (qlo <= qhi ? ((static_cast<u32>(L.p2n[base + qlo]) << 12) | static_cast<u32>(qlo)) : 0xFFFFFFFFu);
         CH_SUB(12);
         u32 who = 0, bid = best >> 12;
         bool have = best != 0xFFFFFFFFu;
@@ -1002,18 +1107,15 @@ int run_clean_chains(ma_ctx* ctx, const DBatch& b, const GraphWs& ws, const ma_p
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_clean_chains), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  // two launches: the LDS image of the common case leaves room for three workgroups per CU; graphs beyond it (deep
-  // panels, 2.5 kb windows) get a whole CU's LDS.  A workgroup whose window is not in its launch's range returns at once.
-  u32 caps[2] = {1536u, 0u};
-  for (u32 c = 4096; c >= 2048; c -= 256)
-    if (lds_bytes(c) <= 160 * 1024 - 1024) {
-      caps[1] = c;
-      break;
-    }
+  // three launches by graph size: LDS is handed out in coarse granules, so the image of the common case is cut to fit
+  // THREE workgroups per CU with room to spare (1472 nodes: 51.9 KB; at 1536 nodes only two fitted and the kernel took
+  // 2.18 instead of 1.58 ms), the next class two per CU, the deepest windows one.  A workgroup whose window belongs to
+  // another launch returns at once (0.02 ms per launch).
+  u32 caps[3] = {1472u, 2304u, 4096u};
   if (const char* e = getenv("MA_CHAINS_CAP")) caps[0] = static_cast<u32>(atoi(e)) / 64u * 64u;
   u32 lo = 0;
-  for (int l = 0; l < 2; ++l) {
-    if (caps[l] <= lo) continue;
+  for (int l = 0; l < 3; ++l) {
+    if (caps[l] <= lo || lds_bytes(caps[l]) > 160 * 1024) continue;
     ChainArgs args{b, ws, prm, caps[l], lo, xw};
     ctx->tic("k_clean_chains");
     hipLaunchKernelGGL(k_clean_chains, dim3(ws.n_active), dim3(kT), lds_bytes(caps[l]), ctx->stream, args);

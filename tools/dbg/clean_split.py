@@ -20,4 +20,5 @@ acc = {}
 for k, v in eng.kernel_times():
     acc[k] = acc.get(k, 0.0) + v
 print({k: round(v, 3) for k, v in acc.items()})
+print("clean launches:", [(k, round(v, 3)) for k, v in eng.kernel_times() if "clean" in k])
 eng.close()
