@@ -94,6 +94,7 @@ struct Win {
 #ifdef MA_PROFILE
   u32 dbg_phase, dbg_merges[2], dbg_maxwalk[2], dbg_walks[2];
   unsigned long long dbg_t[6];
+  unsigned long long dbg_ph[16];
 #endif
 };
 
@@ -1271,6 +1272,7 @@ __device__ __forceinline__ u32 median_sorted(const u32* v, u32 n) {  // compute_
   do {                                                                        \
     unsigned long long _t1 = __builtin_amdgcn_s_memtime();                    \
     if (threadIdx.x == 0) atomicAdd(&g_cprof[slot], _t1 - _t0);               \
+    g.dbg_ph[slot] += _t1 - _t0;                                              \
     _t0 = _t1;                                                                \
   } while (0)
 extern "C" void ma_debug_cwin(unsigned long long* out, int n) {
@@ -1443,6 +1445,7 @@ __global__ __launch_bounds__(64, 4) void k_clean(CleanArgs A) {
   g.flags = 0;
 #ifdef MA_PROFILE
   for (int q = 0; q < 6; ++q) g.dbg_t[q] = 0;
+  for (int q = 0; q < 16; ++q) g.dbg_ph[q] = 0;
   g.dbg_phase = 0; g.dbg_merges[0] = g.dbg_merges[1] = g.dbg_maxwalk[0] = g.dbg_maxwalk[1] = g.dbg_walks[0] = g.dbg_walks[1] = 0;
 #endif
   u32 const NC = ws.nc;
@@ -1819,6 +1822,35 @@ __device__ __forceinline__ void clean_candidates(CleanArgs const& A, Win& g, SH&
     if (fold) {
       for (u32 f = lane; f < V; f += 64) l_link[4u * V + f] = nd_confidence(g, flat_nodes[f]);
       wave_sync_mem(g.lds);
+      // EnqueueOutgoingEdges sorts a state's edges by the destination's Confidence (stable, descending) every time the
+      // state is popped; the confidences do not change during the search, so each state's block is sorted ONCE, a lane
+      // per state (the cycle check and the metrics above have read it in list order already)
+      for (u32 stt = lane; stt < 2u * V; stt += 64) {
+        u32 const c = rcnt[stt], b0 = rstart[stt];
+        for (u32 x = 1; x < c; ++x) {
+          u32 const as = adj_state[b0 + x], ao = adj_ord[b0 + x], cf = l_link[4u * V + (as >> 1)];
+          u32 j = x;
+          while (j > 0 && l_link[4u * V + (adj_state[b0 + j - 1] >> 1)] < cf) {
+            adj_state[b0 + j] = adj_state[b0 + j - 1];
+            adj_ord[b0 + j] = adj_ord[b0 + j - 1];
+            --j;
+          }
+          adj_state[b0 + j] = as;
+          adj_ord[b0 + j] = ao;
+        }
+      }
+      wave_sync_mem(g.lds);
+    }
+    // Small graphs (every pruned component of the bench): (state, ordinal) of an edge in one word, (start, count) of a
+    // state in one word, the traversed flags as bits in registers -- a popped entry then costs a handful of dependent
+    // look-ups instead of some twenty-five
+    bool const fastq = fold && E <= 128u && E <= NC && 2u * V < 0x10000u;
+    u32* const adjp = g.scratch;  // [E] (the list area is free between pruning and haplotype emission)
+    unsigned long long trav0 = 0, trav1 = 0;
+    if (fastq) {
+      for (u32 x = lane; x < E; x += 64) adjp[x] = adj_state[x] | (adj_ord[x] << 16);
+      for (u32 stt = lane; stt < 2u * V; stt += 64) rcnt[stt] = rstart[stt] | (rcnt[stt] << 16);
+      wave_sync_mem(g.lds);
     }
     while (true) {
       u32 an = 0, head = 0;
@@ -1888,7 +1920,34 @@ __device__ __forceinline__ void clean_candidates(CleanArgs const& A, Win& g, SH&
             if (arena_over) return;
           }
       };
-      enqueue(src_state, kNoParent, 1u);
+      auto is_trav = [&](u32 ord) { return ((ord < 64u ? trav0 : trav1) >> (ord & 63u)) & 1ull; };
+      auto enqueue_fast = [&](u32 state, u32 parent, u32 pw) {
+        u32 const rs = rcnt[state], cnt = rs >> 16, b0 = rs & 0xFFFFu;
+        if (cnt == 0) return;
+        u32 const pflag = pw >> 31, mult = pw & 0x7FFFFFFFu;
+        if (cnt == 1) {
+          u32 const ap = adjp[b0], ord = ap >> 16;
+          push(ord, ap & 0xFFFFu, parent, pflag | (is_trav(ord) ? 0u : 1u), mult);
+          return;
+        }
+        u32 const m = cnt < 8u ? cnt : 8u;  // (a state of the bidirected graph has at most four edges)
+        u32 aps[8];
+#pragma unroll
+        for (u32 x = 0; x < 8; ++x) aps[x] = adjp[b0 + (x < m ? x : 0u)];
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+          for (u32 x = 0; x < 8; ++x) {
+            if (x >= m) continue;
+            u32 const ord = aps[x] >> 16;
+            bool const trav = is_trav(ord) != 0;
+            if (trav != (pass == 1)) continue;
+            push(ord, aps[x] & 0xFFFFu, parent, pflag | (trav ? 0u : 1u), mult);
+            if (arena_over) return;
+          }
+        }
+      };
+      if (fastq) enqueue_fast(src_state, kNoParent, 1u); else enqueue(src_state, kNoParent, 1u);
       u64 pops_before = 0, lvl_total = build_total;  // reference pops before / inside the level being popped
       u32 lvl_end = an;
       build_total = 0;
@@ -1919,6 +1978,60 @@ __device__ __forceinline__ void clean_candidates(CleanArgs const& A, Win& g, SH&
           enter_level();
           if (hit_limit || undecided) break;
         }
+        if (fastq && lvl_end - head <= 64u) {
+          // The whole level at once: a lane per entry fetches the entry, its state's block and (up to) the two edges most
+          // states have -- three dependent look-ups per LEVEL -- and the entries are then popped in order out of
+          // registers; what stays serial per popped entry is the fold bookkeeping of push().
+          u32 const nlev = lvl_end - head;
+          u32 my_st = 0, my_w = 0, my_cnt = 0, my_a0 = 0, my_a1 = 0, my_b0 = 0;
+          if (lane < nlev) {
+            uint4 const e = arena[head + lane];
+            my_st = e.y;
+            my_w = e.w;
+            u32 const rs = rcnt[e.y];
+            my_cnt = rs >> 16;
+            my_b0 = rs & 0xFFFFu;
+            my_a0 = adjp[my_b0];                         // (entry 0 of a block that may be empty: any word of the table)
+            my_a1 = adjp[my_b0 + (my_cnt > 1u ? 1u : 0u)];
+          }
+          bool stop = false;
+          for (u32 x = 0; x < nlev; ++x) {
+            u32 const ai = head + x;
+            u32 const y = __builtin_amdgcn_readlane(my_st, x), ww = __builtin_amdgcn_readlane(my_w, x);
+            if ((y >> 1) == snk_flat) {
+              if (!(ww >> 31)) continue;
+              best = ai;
+              stop = true;
+              break;
+            }
+            u32 const cnt = __builtin_amdgcn_readlane(my_cnt, x);
+            if (cnt == 0) continue;
+            u32 const pflag = ww >> 31, mult = ww & 0x7FFFFFFFu;
+            if (cnt <= 2u) {
+              u32 const a0 = __builtin_amdgcn_readlane(my_a0, x), a1 = __builtin_amdgcn_readlane(my_a1, x);
+              bool const t0 = is_trav(a0 >> 16) != 0;
+              if (cnt == 1u) {
+                push(a0 >> 16, a0 & 0xFFFFu, ai, pflag | (t0 ? 0u : 1u), mult);
+              } else {
+                bool const t1 = is_trav(a1 >> 16) != 0;
+                // new edges first, each class in confidence order: only (old, new) swaps the two
+                u32 const f0 = (t0 && !t1) ? a1 : a0, f1 = (t0 && !t1) ? a0 : a1;
+                bool const ft0 = (t0 && !t1) ? t1 : t0, ft1 = (t0 && !t1) ? t0 : t1;
+                push(f0 >> 16, f0 & 0xFFFFu, ai, pflag | (ft0 ? 0u : 1u), mult);
+                if (!arena_over) push(f1 >> 16, f1 & 0xFFFFu, ai, pflag | (ft1 ? 0u : 1u), mult);
+              }
+            } else {
+              enqueue_fast(y, ai, ww);
+            }
+            if (arena_over) {
+              stop = true;
+              break;
+            }
+          }
+          head = lvl_end;
+          if (stop) break;
+          continue;
+        }
         u32 const ai = head++;
         uint4 const wn = arena[ai];
         if ((wn.y >> 1) == snk_flat) {
@@ -1926,7 +2039,7 @@ __device__ __forceinline__ void clean_candidates(CleanArgs const& A, Win& g, SH&
           best = ai;
           break;
         }
-        enqueue(wn.y, ai, wn.w);
+        if (fastq) enqueue_fast(wn.y, ai, wn.w); else enqueue(wn.y, ai, wn.w);
       }
       if (undecided) arena_over = true;  // reported as a capacity failure below
       if (best < 0) break;
@@ -1945,17 +2058,26 @@ __device__ __forceinline__ void clean_candidates(CleanArgs const& A, Win& g, SH&
       {
         u32 pos = wl;
         for (u32 i = static_cast<u32>(best); i != kNoParent; i = arena[i].z) {
-          walk_pool[off + --pos] = arena[i].x;
-          traversed[arena[i].x] = 1;
+          u32 const ord = arena[i].x;
+          walk_pool[off + --pos] = ord;
+          if (fastq) {
+            if (ord < 64u) trav0 |= 1ull << ord; else trav1 |= 1ull << (ord & 63u);
+          } else {
+            traversed[ord] = 1;
+          }
         }
       }
-      // MinWeight over the walk's nodes (path.cpp:34-37)
+      wave_sync_mem(g.lds);
+      // MinWeight over the walk's nodes (path.cpp:34-37): a lane per edge, the source node on lane 0 as well
       auto conf_of = [&](u32 node) { return fold ? l_link[4u * V + flat_of[node]] : nd_confidence(g, node); };
-      u32 mw = conf_of(ord_src[walk_pool[off]]);
-      for (u32 x = 0; x < wl; ++x) {
-        u32 const cf = conf_of(ord_val[walk_pool[off + x]] >> 2);
-        mw = mw < cf ? mw : cf;
+      u32 mw = 0xFFFFFFFFu;
+      for (u32 x = lane; x < wl; x += 64) {
+        u32 const ordx = walk_pool[off + x];
+        mw = min(mw, conf_of(ord_val[ordx] >> 2));
+        if (x == 0) mw = min(mw, conf_of(ord_src[ordx]));
       }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) mw = min(mw, static_cast<u32>(__shfl_xor(mw, o)));
       walk_off[nwalks] = off;
       walk_len[nwalks] = wl;
       walk_minw[nwalks] = mw;
@@ -2262,7 +2384,8 @@ __device__ __forceinline__ void clean_candidates(CleanArgs const& A, Win& g, SH&
   if (w < 4096) {
     g_cwin[w * 4 + 0] = __builtin_amdgcn_s_memtime() - t_begin;
     g_cwin[w * 4 + 1] = g.n;
-    if (w < 4096) for (int q = 0; q < 6; ++q) g_ctime[w * 6 + q] = g.dbg_t[q];
+    if (w < 4096) for (int q = 0; q < 5; ++q) g_ctime[w * 6 + q] = g.dbg_ph[6 + q];
+    if (w < 4096) g_ctime[w * 6 + 5] = slot;
     if (w < 4096) { g_cmerge[w*8+0]=g.dbg_merges[0]; g_cmerge[w*8+1]=g.dbg_merges[1]; g_cmerge[w*8+2]=g.dbg_maxwalk[0]; g_cmerge[w*8+3]=g.dbg_maxwalk[1]; g_cmerge[w*8+4]=g.dbg_walks[0]; g_cmerge[w*8+5]=g.dbg_walks[1]; g_cmerge[w*8+6]=g.n; }
     g_cwin[w * 4 + 2] = dbg_rounds;
     g_cwin[w * 4 + 3] = static_cast<unsigned long long>(ncand);
@@ -2281,25 +2404,35 @@ __device__ __forceinline__ void clean_candidates(CleanArgs const& A, Win& g, SH&
 // traversal index, the search arena and every work list live in LDS (graphs of up to kTailV nodes: all but the deepest
 // windows); otherwise the same code runs on the arrays in HBM.  Capacities of this route that a window outgrows (edge
 // slots, arena, walk pool) hand it to k_clean, never to the caller.
-constexpr u32 kTailV = 128;       // nodes of the LDS image
-constexpr u32 kTailArena = 320;   // search records
-constexpr u32 kTailLink = 640;
-constexpr u32 kTailS = 4;         // samples
-constexpr u32 kTailEk = 2, kTailWk = 5;
-constexpr u32 kTailPieces = 255;  // slices of one walk
-constexpr u32 kTailPool = 5120;   // bytes of base strings (merged strings + the k-mers of untouched nodes)
-struct TailLds {
-  u32 cnt[kTailV * kTailS], role[kTailV * 2], bsrc[kTailV], blen[kTailV], len[kTailV], comp[kTailV];
-  u32 edge[kTailV * kCgEdgeCap];
-  u32 head[kTailV], tail[kTailV], snext[kTailV], sprev[kTailV], sdesc[kTailV];
-  u8 label[kTailV], sign[kTailV], bsign[kTailV], nedge[kTailV], alive[kTailV];
-  u32 scratch[(9 + 4 * kTailEk + kTailWk) * kTailV];
-  uint4 arena[kTailArena];
-  u32 pool[kTailPool / 4];
-  u32 pieces[1 + 2 * kTailPieces];
+// Two LDS images: most compact graphs have a few dozen nodes (bench: 40 on average, 95 at most) and fit the small one,
+// of which seven share a CU; the large one takes four.  The kernel is latency bound with one wavefront per window, so the
+// windows in flight per CU set its speed.
+struct TailSmall {
+  static constexpr u32 V = 64, Arena = 192, Link = 320, S = 2, Ek = 2, Wk = 5, Pieces = 127, Pool = 3072;
 };
+struct TailLarge {
+  static constexpr u32 V = 128, Arena = 320, Link = 640, S = 4, Ek = 2, Wk = 5, Pieces = 255, Pool = 5120;
+};
+struct TailHbm {  // (sizes unused: the arrays stay in HBM)
+  static constexpr u32 V = 1, Arena = 1, Link = 640, S = 1, Ek = 1, Wk = 1, Pieces = 1, Pool = 4;
+};
+template <class C>
+struct TailLdsT {
+  u32 cnt[C::V * C::S], role[C::V * 2], bsrc[C::V], blen[C::V], len[C::V], comp[C::V];
+  u32 edge[C::V * kCgEdgeCap];
+  u32 head[C::V], tail[C::V], snext[C::V], sprev[C::V], sdesc[C::V];
+  u8 label[C::V], sign[C::V], bsign[C::V], nedge[C::V], alive[C::V];
+  u32 scratch[(9 + 4 * C::Ek + C::Wk) * C::V];
+  uint4 arena[C::Arena];
+  u32 pool[C::Pool / 4];
+  u32 pieces[1 + 2 * C::Pieces];
+};
+template <class C>
+__device__ __forceinline__ bool tail_fits(u32 V, u32 pool_used, u32 kk, int S) {
+  return V <= C::V && pool_used + 4u + V * kk <= C::Pool && static_cast<u32>(S) <= C::S;
+}
 
-template <bool kLds>
+template <class C, bool kLds>
 __global__ __launch_bounds__(64, 4) void k_clean_tail(CleanArgs A) {
   int const a = blockIdx.x;
   u32 const lane = threadIdx.x;
@@ -2308,11 +2441,13 @@ __global__ __launch_bounds__(64, 4) void k_clean_tail(CleanArgs A) {
   const u32* hdr = ws.cg_hdr + static_cast<size_t>(a) * kCgHdr;
   u32 const V = hdr[0], pool_used = hdr[2];
   u32 const kk = static_cast<u32>(win_kmer(ws, static_cast<int>(ws.active[a])));
-  bool const fits = V <= kTailV && pool_used + 4u + V * kk <= kTailPool && static_cast<u32>(ws.num_samples) <= kTailS;
-  if (fits != kLds) return;  // the other instantiation's window
+  // the smallest image that holds the window
+  int const cls = tail_fits<TailSmall>(V, pool_used, kk, ws.num_samples) ? 0 : (tail_fits<TailLarge>(V, pool_used, kk, ws.num_samples) ? 1 : 2);
+  constexpr int kMine = !kLds ? 2 : (C::V == TailSmall::V ? 0 : 1);
+  if (cls != kMine) return;  // another instantiation's window
   int const w = static_cast<int>(ws.active[a]);
   size_t const nb = static_cast<size_t>(a) * ws.vc;
-  __shared__ CleanLdsT<kTailLink> sh;
+  __shared__ CleanLdsT<C::Link> sh;
   Win g;
   g.link = sh.link;
   g.ranked = false;
@@ -2331,7 +2466,7 @@ __global__ __launch_bounds__(64, 4) void k_clean_tail(CleanArgs A) {
   g.flags = 0;
   u32 NC;
   if constexpr (kLds) {
-    __shared__ TailLds tl;
+    __shared__ TailLdsT<C> tl;
     int const S = g.S;
     for (u32 i = lane; i < V * static_cast<u32>(S); i += 64) tl.cnt[i] = ws.cg_cnt[nb * S + i];
     for (u32 i = lane; i < V * 2u; i += 64) tl.role[i] = ws.cg_role[nb * 2 + i];
@@ -2395,13 +2530,13 @@ __global__ __launch_bounds__(64, 4) void k_clean_tail(CleanArgs A) {
     }
     g.scratch = tl.scratch;
     g.pieces = tl.pieces;
-    g.piece_cap = kTailPieces;
-    g.ek = kTailEk;
-    g.wk = kTailWk;
+    g.piece_cap = C::Pieces;
+    g.ek = C::Ek;
+    g.wk = C::Wk;
     g.arena = tl.arena;
-    g.ac = kTailArena;
-    g.link_cap = kTailLink;
-    NC = kTailV;
+    g.ac = C::Arena;
+    g.link_cap = C::Link;
+    NC = C::V;
   } else {
     g.cnt = ws.cg_cnt + nb * g.S;
     g.role = ws.cg_role + nb * 2;
@@ -2428,7 +2563,7 @@ __global__ __launch_bounds__(64, 4) void k_clean_tail(CleanArgs A) {
     g.wk = 7;
     g.arena = ws.arena + static_cast<size_t>(a) * ws.ac;
     g.ac = ws.ac;
-    g.link_cap = kTailLink;
+    g.link_cap = C::Link;
     NC = ws.cg_sc;
     for (u32 i = lane; i < g.n; i += 64) {
       g.alive[i] = 1;
@@ -2440,6 +2575,7 @@ __global__ __launch_bounds__(64, 4) void k_clean_tail(CleanArgs A) {
   g.nc = NC;
 #ifdef MA_PROFILE
   for (int q = 0; q < 6; ++q) g.dbg_t[q] = 0;
+  for (int q = 0; q < 16; ++q) g.dbg_ph[q] = 0;
   g.dbg_phase = 0; g.dbg_merges[0] = g.dbg_merges[1] = g.dbg_maxwalk[0] = g.dbg_maxwalk[1] = g.dbg_walks[0] = g.dbg_walks[1] = 0;
 #endif
   int const ncand = static_cast<int>(hdr[1]);
@@ -2469,8 +2605,13 @@ int run_clean_pass(ma_ctx* ctx, const DBatch& b, const GraphWs& ws, const ma_asm
     MA_HIP(ctx, hipMemsetAsync(ws.cg_state, 0, sizeof(u32) * static_cast<size_t>(ws.n_active), ctx->stream));
     MA_TRY_RC(run_clean_chains(ctx, b, ws, ctx->prm));
     ctx->tic("k_clean_tail");
-    hipLaunchKernelGGL(k_clean_tail<true>, dim3(ws.n_active), dim3(64), 0, ctx->stream, args);
-    hipLaunchKernelGGL(k_clean_tail<false>, dim3(ws.n_active), dim3(64), 0, ctx->stream, args);
+    hipLaunchKernelGGL((k_clean_tail<TailSmall, true>), dim3(ws.n_active), dim3(64), 0, ctx->stream, args);
+    ctx->toc();
+    ctx->tic("k_clean_tail");
+    hipLaunchKernelGGL((k_clean_tail<TailLarge, true>), dim3(ws.n_active), dim3(64), 0, ctx->stream, args);
+    ctx->toc();
+    ctx->tic("k_clean_tail");
+    hipLaunchKernelGGL((k_clean_tail<TailHbm, false>), dim3(ws.n_active), dim3(64), 0, ctx->stream, args);
     ctx->toc();
   } else if (ws.cg_state) {
     MA_HIP(ctx, hipMemsetAsync(ws.cg_state, 0, sizeof(u32) * static_cast<size_t>(ws.n_active), ctx->stream));

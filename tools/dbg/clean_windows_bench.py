@@ -28,6 +28,6 @@ nodes = np.array([buf[4 * i + 1] for i in range(n)])
 print("windows", n, "ticks: mean %.0f  p50 %.0f  p90 %.0f  p99 %.0f  max %.0f" % (t.mean(), *np.percentile(t, [50, 90, 99]), t.max()))
 order = np.argsort(-t)
 for i in list(order[:12]) + list(order[n // 2:n // 2 + 3]):
-    print("win %4d (str %d) ticks %9d nodes %5d comps %3d cands %2d | compress: filter %8d follow %8d tests %8d apply %8d total %8d" %
-          ((i, int((10_000 + i) % 8 == 7), int(t[i]), nodes[i], buf[4 * i + 2], buf[4 * i + 3]) + tuple(tb[6 * i + q] for q in range(5))))
+    print("win %4d (str %d) ticks %9d nodes %5d rounds %3d cands %2d | tips %8d index %8d cyc+cx %8d maxflow %8d emit %8d haps %3d" %
+          ((i, int((10_000 + i) % 8 == 7), int(t[i]), nodes[i], buf[4 * i + 2], buf[4 * i + 3]) + tuple(tb[6 * i + q] for q in range(6))))
 eng.close()
