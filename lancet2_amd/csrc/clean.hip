@@ -1844,9 +1844,9 @@ __device__ __forceinline__ void clean_candidates(CleanArgs const& A, Win& g, SH&
     // Small graphs (every pruned component of the bench): (state, ordinal) of an edge in one word, (start, count) of a
     // state in one word, the traversed flags as bits in registers -- a popped entry then costs a handful of dependent
     // look-ups instead of some twenty-five
-    bool const fastq = fold && E <= 128u && E <= NC && 2u * V < 0x10000u;
-    u32* const adjp = g.scratch;  // [E] (the list area is free between pruning and haplotype emission)
-    unsigned long long trav0 = 0, trav1 = 0;
+    bool const fastq = fold && E <= 256u && 2u * V < 0x10000u;
+    u32* const adjp = adj_state;  // packed in place (nothing reads the plain table after the cycle check)
+    unsigned long long trav0 = 0, trav1 = 0, trav2 = 0, trav3 = 0;
     if (fastq) {
       for (u32 x = lane; x < E; x += 64) adjp[x] = adj_state[x] | (adj_ord[x] << 16);
       for (u32 stt = lane; stt < 2u * V; stt += 64) rcnt[stt] = rstart[stt] | (rcnt[stt] << 16);
@@ -1920,7 +1920,7 @@ __device__ __forceinline__ void clean_candidates(CleanArgs const& A, Win& g, SH&
             if (arena_over) return;
           }
       };
-      auto is_trav = [&](u32 ord) { return ((ord < 64u ? trav0 : trav1) >> (ord & 63u)) & 1ull; };
+      auto is_trav = [&](u32 ord) { return ((ord < 128u ? (ord < 64u ? trav0 : trav1) : (ord < 192u ? trav2 : trav3)) >> (ord & 63u)) & 1ull; };
       auto enqueue_fast = [&](u32 state, u32 parent, u32 pw) {
         u32 const rs = rcnt[state], cnt = rs >> 16, b0 = rs & 0xFFFFu;
         if (cnt == 0) return;
@@ -2061,7 +2061,8 @@ __device__ __forceinline__ void clean_candidates(CleanArgs const& A, Win& g, SH&
           u32 const ord = arena[i].x;
           walk_pool[off + --pos] = ord;
           if (fastq) {
-            if (ord < 64u) trav0 |= 1ull << ord; else trav1 |= 1ull << (ord & 63u);
+            unsigned long long const bit = 1ull << (ord & 63u);
+            if (ord < 64u) trav0 |= bit; else if (ord < 128u) trav1 |= bit; else if (ord < 192u) trav2 |= bit; else trav3 |= bit;
           } else {
             traversed[ord] = 1;
           }
