@@ -44,7 +44,7 @@ STAGE_OF = {"gate_kernel": "gate",
             "k_count_inst": "build", "k_classify": "build", "k_insert": "build", "k_support": "build",
             "k_mm_lds": "build", "k_mm_insert": "build", "k_count": "build", "k_rank": "build", "k_edges": "build",
             "k_edge_sort": "build",
-            "k_clean": "clean",
+            "k_clean": "clean", "k_clean_chains": "clean", "k_clean_tail": "clean",
             "k_msa": "poa", "k_msa_band": "poa",
             "k_read_planes": "genotype", "k_plan": "genotype", "k_vote": "genotype", "k_dp_scatter": "genotype", "k_align_reg": "genotype",
             "k_align_wave": "genotype", "k_align_gen": "genotype", "k_assign": "genotype", "k_evidence": "genotype",
@@ -70,6 +70,7 @@ def parse():
     ap.add_argument("--config", default="C3",
                     help="C3 = WGS-shaped tumour/normal 60x/30x (the workload BASELINE.json's metric is quoted on); "
                          "C2 = chr22-shaped 30x/30x (configs[1]); C4, C5")
+    ap.add_argument("--c4-windows", type=int, default=512, help="distinct deep-panel windows of the also.c4_panel leg (0 = skip)")
     ap.add_argument("--no-also", action="store_true", help="skip the secondary measurements (k cascade, other config, host path)")
     ap.add_argument("--cpu-windows", type=int, default=64, help="oracle sample for cpu_baseline (0 = skip)")
     ap.add_argument("--no-cpu", action="store_true")
@@ -367,6 +368,11 @@ def main():
     if other and world == 1 and not args.no_also:
         also_arrs = make_windows(other, min(distinct, 1024), first, args.str_every, workers)
         long_arrs = make_windows(args.config, min(distinct, 512), first, args.str_every, workers, over=dict(read_len=250))
+    c4_arrs = c5_arrs = None
+    if world == 1 and not args.no_also and args.config == "C3":
+        # BASELINE.json configs[3] and [4]: the deep panel at full depth (500x/500x, 50 bp indels) and the three-sample mode
+        c4_arrs = make_windows("C4", min(distinct, args.c4_windows), first, 0, workers) if args.c4_windows > 0 else None
+        c5_arrs = make_windows("C5", min(distinct, 2048), first, args.str_every, workers)
     t_gen = time.perf_counter() - t_gen
     cpu = cpu_mt = None
     if world == 1 and not args.no_cpu and args.cpu_windows > 0:
@@ -590,18 +596,21 @@ def main():
                              "assembled_fraction": round(c_asm, 4)}
         ceng.close()
         # (2) the other WGS-shaped config, and the headline's windows sequenced 2 x 250
-        def device_leg(batch, label):
+        def device_leg(batch, label, leg_params=None, max_windows=None, kernels=False):
+            lp = leg_params or params
             o_arrs, o_n0, o_nr0 = batch
-            o_arrs, o_n, o_nr = synth.tile_batch(o_arrs, o_n0, o_nr0, max(1, min(args.windows, n) // o_n0))
+            o_arrs, o_n, o_nr = synth.tile_batch(o_arrs, o_n0, o_nr0, max(1, min(args.windows, n, max_windows or args.windows) // o_n0))
             o_dbatch = to_dev(o_arrs)
             o_b = capi.make_batch_struct(o_dbatch, o_n, o_nr)
-            o_q = dev_alloc(capi.geno_out_spec(params, o_n, o_nr, debug=False))
+            o_q = dev_alloc(capi.geno_out_spec(lp, o_n, o_nr, debug=False))
             o_qs = capi.fill_struct(capi.GenoOut, o_q)
-            oeng = Engine(params, device=local_rank, memspace=capi.MA_MEM_DEVICE)
+            oeng = Engine(lp, device=local_rank, memspace=capi.MA_MEM_DEVICE)
             oeng.set_stream(stream.cuda_stream)
             oeng.timing_control(0)
             oeng.process_device(o_b, gs, as_, vs, o_qs)
             barrier()
+            if kernels:
+                oeng.timing_control(2)
             t_o = time.perf_counter()
             for _ in range(2):
                 oeng.process_device(o_b, gs, as_, vs, o_qs)
@@ -609,16 +618,33 @@ def main():
             dt_o = time.perf_counter() - t_o
             ost = a["win_status"].view(torch.int32).cpu().numpy().view(np.uint32)[:o_n]
             o_asm = float(((ost & capi.MA_W_NO_HAPLOTYPE) == 0).mean())
+            res = {"workload": label, "value": round(2 * o_n * o_asm / dt_o, 2), "unit": "assembled windows/s", "steps": 2,
+                   "submitted_windows_per_s": round(2 * o_n / dt_o, 2), "assembled_fraction": round(o_asm, 4),
+                   "windows_per_step": o_n, "distinct_windows": o_n0, "reads_per_window": round(o_nr / o_n, 1)}
+            if kernels:
+                acc = {}
+                for kname, ms in oeng.kernel_times():
+                    acc[kname] = acc.get(kname, 0.0) + ms / 2
+                res["kernel_ms_per_step"] = {k_: round(v_, 3) for k_, v_ in sorted(acc.items(), key=lambda kv: -kv[1])}
+                flagged = ost & ~np.uint32(capi.MA_W_NO_HAPLOTYPE | capi.MA_W_BFS_LIMIT)
+                res["windows_with_capacity_flag"] = int((flagged != 0).sum())
+                res["windows_at_traversal_limit"] = int(((ost & capi.MA_W_BFS_LIMIT) != 0).sum())
             oeng.close()
             del o_dbatch, o_q
-            return {"workload": label, "value": round(2 * o_n * o_asm / dt_o, 2), "unit": "assembled windows/s", "steps": 2,
-                    "submitted_windows_per_s": round(2 * o_n / dt_o, 2), "assembled_fraction": round(o_asm, 4),
-                    "windows_per_step": o_n, "distinct_windows": o_n0, "reads_per_window": round(o_nr / o_n, 1)}
+            return res
 
         if also_arrs is not None:
             also["other_config"] = device_leg(also_arrs, WORKLOADS[other])
         if long_arrs is not None:
             also["reads_2x250"] = device_leg(long_arrs, WORKLOADS[args.config] + " -- sequenced as 2 x 250 bp reads")
+        if c4_arrs is not None:  # every window distinct (no tiling): 7.6 k reads a window
+            also["c4_panel"] = device_leg(c4_arrs, WORKLOADS["C4"], max_windows=c4_arrs[1], kernels=True)
+        if c5_arrs is not None:
+            p5 = capi.default_params(min_k=25, max_k=25)
+            p5.num_samples = 3
+            # the output structs of the headline (two samples) are large enough for the assembly / variant arrays; the
+            # genotype arrays are allocated per leg from the leg's own parameters
+            also["c5_three_samples"] = device_leg(c5_arrs, WORKLOADS["C5"], leg_params=p5, kernels=True)
         # (3) host path: caller-owned PINNED host buffers through MA_MEM_HOST -- the library stages inputs through HBM and
         #     copies every fixed-stride output array back (PCIe both ways inside the timed region).  One feeder = one
         #     context, nothing overlaps; two feeders = two contexts on the same device, each on its own host thread (what

@@ -1955,21 +1955,24 @@ __device__ __forceinline__ void clean_candidates(CleanArgs const& A, Win& g, SH&
       bool undecided = false;
       u64 const limit = static_cast<u64>(P.bfs_limit);
       i64 best = -1;
+      bool straddle = false;  // the cap falls inside the level being popped, which holds a qualifying arrival
       auto enter_level = [&]() {  // the reference stops at its (limit + 1)-th pop: does that fall into this level?
         if (pops_before + lvl_total <= limit) return;
         if (pops_before < limit) {
           // it falls inside; if no entry of the level qualifies the reference pops them all and gives up, otherwise
-          // the answer depends on positions the folding has not kept
+          // the question is whether the first qualifying arrival comes before the cap: its exact position in the
+          // reference's (unfolded) queue is worked out once it is found (arrival_rank below)
           for (u32 x = head; x < lvl_end; ++x) {
             uint4 const e = arena[x];
-            if ((e.y >> 1) == snk_flat && (e.w >> 31)) undecided = true;
+            if ((e.y >> 1) == snk_flat && (e.w >> 31)) straddle = true;
           }
         }
-        if (!undecided) hit_limit = true;
+        if (!straddle) hit_limit = true;
       };
       enter_level();
       while (head < an && !arena_over && !hit_limit && !undecided) {
         if (head == lvl_end) {
+          if (straddle) break;  // (the arrival the level promised was not found: cannot happen)
           pops_before += lvl_total;
           lvl_total = build_total;
           build_total = 0;
@@ -2040,6 +2043,103 @@ __device__ __forceinline__ void clean_candidates(CleanArgs const& A, Win& g, SH&
           break;
         }
         if (fastq) enqueue_fast(wn.y, ai, wn.w); else enqueue(wn.y, ai, wn.w);
+      }
+      if (straddle && best < 0) undecided = true;
+      if (straddle && best >= 0) {
+        // Position of the arrival inside its level of the REFERENCE's queue.  Entries of a level come in the order of their
+        // parents, children of one parent in enqueue order; the number of entries that precede the arrival's ancestor A_i
+        // in level i, per state, is B_i[s'] = sum over s of B_(i-1)[s] x edges(s -> s')  (every entry before A_(i-1)
+        // expands into all its edges; sink entries into none)  +  the siblings enqueued before A_i.  The arrival is the
+        // (sum of B_d)-th entry of its level; the reference reaches it iff that is below the pops the cap leaves.
+        u32 depth = 0;
+        for (u32 i = static_cast<u32>(best); i != kNoParent; i = arena[i].z) depth++;
+        if (walk_pool_used + depth + 4u * V > walk_pool_cap) {
+          undecided = true;
+        } else {
+          u32* const chain = walk_pool + walk_pool_used;  // arena indices, level 0 first
+          {
+            u32 pos = depth;
+            for (u32 i = static_cast<u32>(best); i != kNoParent; i = arena[i].z) chain[--pos] = i;
+          }
+          u32* bcur = walk_pool + walk_pool_cap - 4u * V;
+          u32* bnxt = bcur + 2u * V;
+          constexpr u32 kSat = 1u << 22;
+          auto block_of = [&](u32 stt, u32* b0, u32* cnt) {
+            if (fastq) {
+              u32 const rs = rcnt[stt];
+              *b0 = rs & 0xFFFFu;
+              *cnt = rs >> 16;
+            } else {
+              *b0 = rstart[stt];
+              *cnt = rcnt[stt];
+            }
+          };
+          auto edge_of = [&](u32 p, u32* dst, u32* ord) {
+            if (fastq) {
+              u32 const ap = adjp[p];
+              *dst = ap & 0xFFFFu;
+              *ord = ap >> 16;
+            } else {
+              *dst = adj_state[p];
+              *ord = adj_ord[p];
+            }
+          };
+          auto trav_of = [&](u32 ord) { return fastq ? (is_trav(ord) != 0) : (traversed[ord] != 0); };
+          for (u32 x = lane; x < 2u * V; x += 64) bcur[x] = 0;
+          wave_sync_mem(g.lds);
+          u32 parent_state = src_state;
+          for (u32 lv = 0; lv < depth; ++lv) {
+            uint4 const A_ = arena[chain[lv]];
+            if (lv > 0) {
+              for (u32 x = lane; x < 2u * V; x += 64) bnxt[x] = 0;
+              wave_sync_mem(g.lds);
+              for (u32 stt = lane; stt < 2u * V; stt += 64) {
+                u32 const c = bcur[stt];
+                if (c == 0 || (stt >> 1) == snk_flat) continue;
+                u32 b0, cnt;
+                block_of(stt, &b0, &cnt);
+                for (u32 x = 0; x < cnt; ++x) {
+                  u32 dst, ord;
+                  edge_of(b0 + x, &dst, &ord);
+                  atomicAdd(&bnxt[dst], c);
+                }
+              }
+              wave_sync_mem(g.lds);
+              for (u32 x = lane; x < 2u * V; x += 64) bnxt[x] = min(bnxt[x], kSat);
+              wave_sync_mem(g.lds);
+              u32* const tsw = bcur;
+              bcur = bnxt;
+              bnxt = tsw;
+            }
+            // siblings enqueued before A_: new edges first, each class in confidence order (the blocks are sorted)
+            {
+              u32 b0, cnt;
+              block_of(parent_state, &b0, &cnt);
+              bool found = false;
+              for (int pass = 0; pass < 2 && !found; ++pass)
+                for (u32 x = 0; x < cnt && !found; ++x) {
+                  u32 dst, ord;
+                  edge_of(b0 + x, &dst, &ord);
+                  if (trav_of(ord) != (pass == 1)) continue;
+                  if (ord == A_.x) found = true;
+                  else if (lane == 0) bcur[dst] = min(bcur[dst] + 1u, kSat);
+                }
+              wave_sync_mem(g.lds);
+            }
+            parent_state = A_.y;
+          }
+          u64 rank = 0;
+          for (u32 x0 = 0; x0 < 2u * V; x0 += 64) {
+            u32 vv = x0 + lane < 2u * V ? bcur[x0 + lane] : 0u;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) vv += static_cast<u32>(__shfl_xor(vv, o));
+            rank += vv;
+          }
+          if (pops_before + rank >= limit) {  // the reference's (limit + 1)-th pop comes first: it gives up
+            best = -1;
+            hit_limit = true;
+          }
+        }
       }
       if (undecided) arena_over = true;  // reported as a capacity failure below
       if (best < 0) break;

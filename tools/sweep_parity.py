@@ -33,6 +33,8 @@ CASES = [("C2", 96, 70_000, {}, dict(min_k=25, max_k=25)), ("C3", 32, 71_000, {}
          ("C3", 16, 89_000, dict(tandem_dup=40), {}), ("C3", 16, 90_000, dict(tandem_dup=70, softclip_frac=0.03), {}),
          ("C3", 12, 88_000, dict(dup_len=150, low_complexity=60, softclip_frac=0.03, n_frac=0.01, str_unit=b"CA"), {})]
 shift = int(sys.argv[1]) if len(sys.argv) > 1 else 0  # other windows of the same shapes
+if len(sys.argv) > 2 and sys.argv[2] == "c4":  # the deep panel at full depth: 32 windows of 500x/500x, 50 bp indels
+    CASES = [("C4", 32, 91_000, {}, dict(min_k=25, max_k=25))]
 tot = 0
 for cfg, nwin, first, kw, pk in CASES:
     first += shift
