@@ -420,9 +420,9 @@ int launch_assemble(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& out, const
   if (const char* e = getenv("MA_NODE_CAP")) nc0 = std::max<u32>(256, static_cast<u32>(atoi(e)));  // tests: force the retry passes
   u32 ac0 = 1u << 16;
   if (const char* e = getenv("MA_ARENA_CAP")) ac0 = static_cast<u32>(atoi(e));
-  ws.vc = 256;
-  ws.cg_sc = 1024;
-  ws.pool_cap = 16384;
+  ws.vc = 2048;
+  ws.cg_sc = 2048;
+  ws.pool_cap = 49152;
 
   // per-window workspace footprint -> chunk size
   auto carve_ws = [&](Carver& c, GraphWs& g, size_t A) {

@@ -34,12 +34,9 @@ namespace {
 
 constexpr int kT = 256;          // threads per window
 constexpr u32 kNone16 = 0xFFFFu;
-constexpr u32 kXeCap = 64;       // nodes with three or four edges
-constexpr u32 kSegCap = 256;     // segments per window
-constexpr u32 kVcMax = 256;      // compact nodes per window (GraphWs::vc <= this)
 
 // node flags (u16)
-constexpr u32 F_NE = 7u;          // [2:0] edges (<= 4)
+constexpr u32 F_NE = 7u;          // [2:0] edges: 0, 1, 2 or 3 = three to eight (the count is in the node's side-table entry)
 constexpr u32 F_SIGN = 1u << 3;   // Kmer sign (1 = PLUS)
 constexpr u32 F_LABEL_SH = 4;     // [6:4] label
 constexpr u32 F_PLAIN = 1u << 7;
@@ -56,6 +53,9 @@ struct ChainArgs {
   u32 cap;    // nodes the LDS image holds
   u32 n_lo;   // windows with n_lo < n <= cap are this launch's
   u32 xw;     // u32 words per node of the X region (>= 2)
+  u32 xe_cap;   // nodes with three or four edges
+  u32 seg_cap;  // segments per window (even)
+  u32 cl_cap;   // compact nodes the alive list holds (even)
 };
 
 struct Lds {
@@ -69,14 +69,13 @@ struct Lds {
   u16* cid;     // [cap] compact id
   u32* blk;     // [cap] block of an owner: (lo + 1) | (hi + 1) << 16
   u32* key;     // [cap] time of the last edge rewrite << 1 | slot
-  u16* xe;      // [kXeCap * 4]
+  u16* xe;      // [kXeCap * 8] edges 1 .. 7 of a node with three to eight edges, [7] = their number
   u16* seg_base;  // [kSegCap]
   u16* seg_m;
   u16* seg_l;
   u16* seg_r;
   u16* seg_fl;
-  u16* cidnode;   // [kVcMax]
-  u16* pooloff;   // [kVcMax]
+  u16* cl;        // [cl_cap] compact id -> node, when the compact graph is that small
   u32* bmin;      // [cap / 32] minimum of each 32-entry block of p2n: node << 12 | index
   u32* cand;      // [6 * 16]
   u32* misc;      // [32] counters / flags / wave sums
@@ -94,7 +93,12 @@ __device__ __forceinline__ u32 edge_at(const Lds& L, u32 i, u32 x) {
   u32 const v = L.e2[i];
   if (x == 0) return v & 0xFFFFu;
   if ((L.fl[i] & F_NE) <= 2u) return v >> 16;
-  return L.xe[(v >> 16) * 4u + (x - 1u)];
+  return L.xe[(v >> 16) * 8u + (x - 1u)];
+}
+// number of edges of node i
+__device__ __forceinline__ u32 node_ne(const Lds& L, u32 i) {
+  u32 const c = L.fl[i] & F_NE;
+  return c <= 2u ? c : L.xe[(L.e2[i] >> 16) * 8u + 7u];
 }
 // the edge of a PLAIN node on side s (src_minus == s)
 __device__ __forceinline__ u32 side_edge(const Lds& L, u32 i, u32 s) {
@@ -185,7 +189,7 @@ __global__ __launch_bounds__(kT) void k_clean_chains(ChainArgs A) {
   int const w = static_cast<int>(ws.active[a]);
   u32 const n = ws.n_nodes[a];
   if ((ws.win_flags[w] & 4u) || n <= A.n_lo || n > A.cap || n == 0) return;  // not this launch's (k_clean reports overflows)
-  u32 const cap = A.cap, xw = A.xw;
+  u32 const cap = A.cap, xw = A.xw, kXeCap = A.xe_cap, kSegCap = A.seg_cap;
   int const S = ws.num_samples;
   u32 const NV = static_cast<u32>(S) + 2u, VS = 2u * xw;  // values per node, u16 stride of the value table
   u32 const K = static_cast<u32>(win_kmer(ws, w)), K1 = K - 1u;
@@ -204,14 +208,13 @@ __global__ __launch_bounds__(kT) void k_clean_chains(ChainArgs A) {
     L.p2n = reinterpret_cast<u16*>(p); p += cap / 2;
     L.abs = reinterpret_cast<u16*>(p); p += cap / 2;
     L.cid = reinterpret_cast<u16*>(p); p += cap / 2;
-    L.xe = reinterpret_cast<u16*>(p); p += kXeCap * 2;
+    L.xe = reinterpret_cast<u16*>(p); p += kXeCap * 4;
     L.seg_base = reinterpret_cast<u16*>(p); p += kSegCap / 2;
     L.seg_m = reinterpret_cast<u16*>(p); p += kSegCap / 2;
     L.seg_l = reinterpret_cast<u16*>(p); p += kSegCap / 2;
     L.seg_r = reinterpret_cast<u16*>(p); p += kSegCap / 2;
     L.seg_fl = reinterpret_cast<u16*>(p); p += kSegCap / 2;
-    L.cidnode = reinterpret_cast<u16*>(p); p += kVcMax / 2;
-    L.pooloff = reinterpret_cast<u16*>(p); p += kVcMax / 2;
+    L.cl = reinterpret_cast<u16*>(p); p += A.cl_cap / 2;
     L.bmin = p; p += cap / 32;
     L.cand = p; p += 96;
     L.misc = p; p += 32;
@@ -219,8 +222,8 @@ __global__ __launch_bounds__(kT) void k_clean_chains(ChainArgs A) {
   u32* const csize = reinterpret_cast<u32*>(L.segi);
   if (t < 32) L.misc[t] = 0;
   __syncthreads();
-#define PUNT() do { L.misc[M_PUNT] = 1u; } while (0)
-#define BAIL_IF_PUNT() do { __syncthreads(); if (L.misc[M_PUNT]) return; } while (0)
+#define PUNT() do { L.misc[M_PUNT] = static_cast<u32>(__LINE__); } while (0)
+#define BAIL_IF_PUNT() do { __syncthreads(); if (L.misc[M_PUNT]) { if (threadIdx.x == 0) ws.cg_hdr[static_cast<size_t>(a) * kCgHdr + 3] = L.misc[M_PUNT]; return; } } while (0)
 
   CH_T0();
   // ---- the raw graph: flags, first two edges inline, the rare third and fourth in a side table ----
@@ -242,20 +245,28 @@ __global__ __launch_bounds__(kT) void k_clean_chains(ChainArgs A) {
       u32 const ne = ne_[q];
       uint4 const ev = ev_[q];
       u32 e1 = ne > 1 ? ev.y : 0u;
-      if (ne > 4u) PUNT();
+      if (ne > 8u) PUNT();
       if (ne > 2u) {
         u32 const idx = atomicAdd(&L.misc[M_XE], 1u);
         if (idx >= kXeCap) {
           PUNT();
         } else {
-          L.xe[idx * 4 + 0] = static_cast<u16>(ev.y);
-          L.xe[idx * 4 + 1] = static_cast<u16>(ev.z);
-          L.xe[idx * 4 + 2] = static_cast<u16>(ne > 3 ? ev.w : 0u);
+          L.xe[idx * 8 + 0] = static_cast<u16>(ev.y);
+          L.xe[idx * 8 + 1] = static_cast<u16>(ev.z);
+          L.xe[idx * 8 + 2] = static_cast<u16>(ev.w);
+          if (ne > 4u && ne <= 8u) {  // rare (deep panels): the second quad
+            uint4 const ev2 = *reinterpret_cast<const uint4*>(ws.nd_edge + (nb + i) * kEdgeCap + 4);
+            L.xe[idx * 8 + 3] = static_cast<u16>(ev2.x);
+            L.xe[idx * 8 + 4] = static_cast<u16>(ev2.y);
+            L.xe[idx * 8 + 5] = static_cast<u16>(ev2.z);
+            L.xe[idx * 8 + 6] = static_cast<u16>(ev2.w);
+          }
+          L.xe[idx * 8 + 7] = static_cast<u16>(ne);
         }
         e1 = idx;
       }
       L.e2[i] = (ne > 0 ? (ev.x & 0xFFFFu) : 0u) | (e1 << 16);
-      L.fl[i] = static_cast<u16>((ne > 4u ? 0u : ne) | (sg_[q] ? F_SIGN : 0u) | ((lb_[q] & 7u) << F_LABEL_SH) | (15u << F_CAND_SH));
+      L.fl[i] = static_cast<u16>((ne > 2u ? 3u : ne) | (sg_[q] ? F_SIGN : 0u) | ((lb_[q] & 7u) << F_LABEL_SH) | (15u << F_CAND_SH));
       L.x[i] = i;  // FastSV label
     }
   }
@@ -295,8 +306,10 @@ __global__ __launch_bounds__(kT) void k_clean_chains(ChainArgs A) {
 #pragma unroll
         for (u32 q = 0; q < 8; ++q) {
           u32 best = min(gu[q], min(a0[q], a1[q]));  // (a node without that edge contributed lab[lab[i]] = gu or larger)
-          if (ne[q] > 2u)
-            for (u32 x = 1; x < ne[q]; ++x) best = min(best, lab[lab[edge_at(L, ic[q], x) >> 2]]);
+          if (ne[q] > 2u) {
+            u32 const nq = node_ne(L, ic[q]);
+            for (u32 x = 1; x < nq; ++x) best = min(best, lab[lab[edge_at(L, ic[q], x) >> 2]]);
+          }
           if (ok[q] && best < gu[q]) {
             atomicMin(&lab[pu[q]], best);
             atomicMin(&lab[ic[q]], best);
@@ -894,42 +907,28 @@ __global__ __launch_bounds__(kT) void k_clean_chains(ChainArgs A) {
     u32 mine = 0;
     for (u32 i = i0; i < i1; ++i) mine += ((L.fl[i] >> F_CAND_SH) != 15u && L.abs[i] == kNone16) ? 1u : 0u;
     u32 c = block_excl_scan(L, mine, &V);
-    if (V > ws.vc || V > kVcMax) {
+    if (V > ws.vc) {
       if (t == 0) PUNT();
     } else {
       for (u32 i = i0; i < i1; ++i)
         if ((L.fl[i] >> F_CAND_SH) != 15u && L.abs[i] == kNone16) {
-          L.cid[i] = static_cast<u16>(c);
-          L.cidnode[c] = static_cast<u16>(i);
-          ++c;
+          if (c < A.cl_cap) L.cl[c] = static_cast<u16>(i);
+          L.cid[i] = static_cast<u16>(c++);
         }
     }
     BAIL_IF_PUNT();
   }
-  // merged strings: one pool region per top-level owner
-  u32 my_node = 0, my_len = K;
-  bool my_owns = false;
-  {
-    if (t < V) {
-      my_node = L.cidnode[t];
-      u32 const bk = L.blk[my_node];
-      my_owns = (bk >> 16) > (bk & 0xFFFFu);
-      if (my_owns) my_len = K1 + ((bk >> 16) - (bk & 0xFFFFu) + 1u);
-    }
-    u32 total = 0;
-    u32 const off = block_excl_scan(L, my_owns ? my_len : 0u, &total);
-    if (total > ws.pool_cap || total > 0xFFFFu) {
-      if (t == 0) PUNT();
-    } else if (t < V) {
-      L.pooloff[t] = static_cast<u16>(off);
-    }
-    if (t == 0) L.misc[M_POOL] = total;
-    BAIL_IF_PUNT();
-  }
   size_t const vb = static_cast<size_t>(a) * ws.vc;
   u8* const pool = ws.cg_pool + static_cast<size_t>(a) * ws.pool_cap;
-  if (t < V) {
-    u32 const i = my_node, f = L.fl[i], ci = f >> F_CAND_SH;
+  bool const listed = V <= A.cl_cap;  // a thread per alive node when the list holds them all, else a sweep over the nodes
+  for (u32 it = t; it < (listed ? V : n); it += kT) {
+    u32 const i = listed ? static_cast<u32>(L.cl[it]) : it;
+    u32 const f = L.fl[i], ci = f >> F_CAND_SH;
+    if (ci == 15u || L.abs[i] != kNone16) continue;
+    u32 const t = L.cid[i];  // (shadows the thread index: the record's slot)
+    u32 const bk0 = L.blk[i];
+    bool const my_owns = (bk0 >> 16) > (bk0 & 0xFFFFu);
+    u32 const my_len = my_owns ? K1 + ((bk0 >> 16) - (bk0 & 0xFFFFu) + 1u) : K;
     for (int s = 0; s < S; ++s) ws.cg_cnt[(vb + t) * S + s] = val[i * VS + s];
     ws.cg_role[(vb + t) * 2] = val[i * VS + S];
     ws.cg_role[(vb + t) * 2 + 1] = val[i * VS + S + 1];
@@ -937,14 +936,14 @@ __global__ __launch_bounds__(kT) void k_clean_chains(ChainArgs A) {
     ws.cg_sign[vb + t] = (f & F_SIGN) ? 1 : 0;
     ws.cg_len[vb + t] = my_len;
     ws.cg_comp[vb + t] = ci + 1u;
-    ws.cg_bsrc[vb + t] = my_owns ? (0x40000000u | L.pooloff[t]) : ws.nd_src[nb + i];
+    ws.cg_bsrc[vb + t] = my_owns ? 0x40000000u : ws.nd_src[nb + i];  // (an owner's pool offset is filled in below)
     ws.cg_blen[vb + t] = my_len;
     ws.cg_bsign[vb + t] = my_owns ? 1 : ((f & F_SIGN) ? 1 : 0);
     // edges: content from the final adjacency of the segments, order from the last rewrite
-    u32 const ne = f & F_NE;
-    u32 out_e[4] = {0, 0, 0, 0};
+    u32 const ne = node_ne(L, i);
+    u32 out_e[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-    for (u32 x = 0; x < 4; ++x) {
+    for (u32 x = 0; x < 8; ++x) {
       if (x >= ne) continue;
       u32 const e = edge_at(L, i, x), d = e >> 2, sm = (e >> 1) & 1u;
       u32 ne_w = e;
@@ -993,9 +992,37 @@ __global__ __launch_bounds__(kT) void k_clean_chains(ChainArgs A) {
     }
     ws.cg_nedge[vb + t] = static_cast<u8>(ne);
 #pragma unroll
-    for (u32 x = 0; x < 4; ++x) ws.cg_edge[(vb + t) * kCgEdgeCap + x] = out_e[x];
+    for (u32 x = 0; x < 8; ++x)
+      if (x < 4u || ne > 4u) ws.cg_edge[(vb + t) * kCgEdgeCap + x] = out_e[x];
   }
   CH_ACC(10);
+  // merged strings: one pool region per top-level owner, in node order; the offset lives where the rewrite time did
+  {
+    __syncthreads();
+    u32 const chunk = (n + kT - 1) / kT, i0 = t * chunk, i1 = min(n, i0 + chunk);
+    auto owner_len = [&](u32 i) -> u32 {
+      if ((L.fl[i] >> F_CAND_SH) == 15u || L.abs[i] != kNone16) return 0u;
+      u32 const bk = L.blk[i];
+      return (bk >> 16) > (bk & 0xFFFFu) ? K1 + ((bk >> 16) - (bk & 0xFFFFu) + 1u) : 0u;
+    };
+    u32 mine = 0;
+    for (u32 i = i0; i < i1; ++i) mine += owner_len(i);
+    u32 total = 0;
+    u32 off = block_excl_scan(L, mine, &total);
+    if (total > ws.pool_cap || total > 0x3FFFFFFFu) {
+      if (t == 0) PUNT();
+    } else {
+      for (u32 i = i0; i < i1; ++i) {
+        u32 const ln = owner_len(i);
+        if (ln == 0) continue;
+        L.key[i] = off;
+        ws.cg_bsrc[vb + L.cid[i]] = 0x40000000u | off;
+        off += ln;
+      }
+    }
+    if (t == 0) L.misc[M_POOL] = total;
+    BAIL_IF_PUNT();
+  }
   // leaf bytes -> pool
   {
     const u8* refb = A.b.ref_bases + A.b.ref_off[w];
@@ -1028,7 +1055,7 @@ __global__ __launch_bounds__(kT) void k_clean_chains(ChainArgs A) {
         comp ^= rc;
         y = z;
       }
-      pool[L.pooloff[L.cid[y]] + static_cast<u32>(idx)] = comp ? dev_complement(base) : base;
+      pool[L.key[y] + static_cast<u32>(idx)] = comp ? dev_complement(base) : base;
     };
     auto src_of = [&](u32 q) -> const u8* {
       u32 const sv = ws.nd_src[nb + q];
@@ -1053,19 +1080,21 @@ __global__ __launch_bounds__(kT) void k_clean_chains(ChainArgs A) {
       u8 const base = plus ? p[xx] : dev_complement(p[K1 - xx]);
       place(y, append ? PP + static_cast<i32>(K) + d - 1 : PP - d, base, rc);
     }
-    // an owner's k-mer: (owner, byte) pairs over all threads
-    for (u32 it = t; it < V * K; it += kT) {
-      u32 const q = L.cidnode[it / K], i = it % K;
-      u32 const bk = L.blk[q];
-      if ((bk >> 16) <= (bk & 0xFFFFu)) continue;
-      const u8* p = src_of(q);
-      u8 const base = (L.fl[q] & F_SIGN) ? p[i] : dev_complement(p[K1 - i]);
-      place(q, static_cast<i32>(prepend_count(q)) + static_cast<i32>(i), base, false);
+    // a top-level owner's k-mer: (owner, byte) pairs over all threads when the alive list holds the graph
+    if (listed) {
+      for (u32 it = t; it < V * K; it += kT) {
+        u32 const q = L.cl[it / K], i = it % K;
+        u32 const bk = L.blk[q];
+        if ((bk >> 16) <= (bk & 0xFFFFu)) continue;
+        const u8* p = src_of(q);
+        u8 const base = (L.fl[q] & F_SIGN) ? p[i] : dev_complement(p[K1 - i]);
+        place(q, static_cast<i32>(prepend_count(q)) + static_cast<i32>(i), base, false);
+      }
     }
-    // (nested owners are not in cidnode: they are not alive)
+    // nested owners (and every owner when there is no list): a thread per owner
     for (u32 q = t; q < n; q += kT) {
       u32 const f = L.fl[q];
-      if ((f >> F_CAND_SH) == 15u || L.abs[q] == kNone16) continue;
+      if ((f >> F_CAND_SH) == 15u || (listed && L.abs[q] == kNone16)) continue;
       u32 const bk = L.blk[q];
       if ((bk >> 16) <= (bk & 0xFFFFu)) continue;
       const u8* p = src_of(q);
@@ -1099,7 +1128,8 @@ int run_clean_chains(ma_ctx* ctx, const DBatch& b, const GraphWs& ws, const ma_p
   u32 const S = static_cast<u32>(ws.num_samples);
   u32 const xw = std::max<u32>(2u, (S + 2u + 1u) / 2u);
   auto lds_bytes = [&](u32 cap) {
-    size_t words = static_cast<size_t>(cap) * (3 + xw) + static_cast<size_t>(cap) * 3 /* six u16 arrays */ + kXeCap * 2 + (kSegCap / 2) * 5 + kVcMax + 96 + 32 + cap / 32;
+    u32 const kXeCap = cap <= 1472u ? 64u : cap / 8u, kSegCap = cap <= 1472u ? 256u : cap / 4u;
+    size_t words = static_cast<size_t>(cap) * (3 + xw) + static_cast<size_t>(cap) * 3 /* six u16 arrays */ + kXeCap * 4 + (kSegCap / 2) * 5 + 96 + 32 + cap / 32 + (cap <= 1472u ? 256u : cap / 4u) / 2;
     return words * 4;
   };
   static bool attr_set = false;
@@ -1116,7 +1146,7 @@ int run_clean_chains(ma_ctx* ctx, const DBatch& b, const GraphWs& ws, const ma_p
   u32 lo = 0;
   for (int l = 0; l < 3; ++l) {
     if (caps[l] <= lo || lds_bytes(caps[l]) > 160 * 1024) continue;
-    ChainArgs args{b, ws, prm, caps[l], lo, xw};
+    ChainArgs args{b, ws, prm, caps[l], lo, xw, caps[l] <= 1472u ? 64u : caps[l] / 8u, caps[l] <= 1472u ? 256u : caps[l] / 4u, caps[l] <= 1472u ? 256u : caps[l] / 4u};
     ctx->tic("k_clean_chains");
     hipLaunchKernelGGL(k_clean_chains, dim3(ws.n_active), dim3(kT), lds_bytes(caps[l]), ctx->stream, args);
     ctx->toc();

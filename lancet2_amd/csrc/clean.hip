@@ -26,6 +26,9 @@
 // Loops over the nodes of a component (traversal index, complexity metrics, confidence tables) run one lane per node;
 // a loop that walks global memory serially costs a memory round trip per iteration and a kernel of one wavefront per
 // window lasts as long as its slowest window.
+#include <algorithm>
+#include <vector>
+
 #include "graph_ws.h"
 
 namespace ma {
@@ -79,6 +82,7 @@ struct Win {
   const u8* pool;     // merged strings written by k_clean_chains (null on the raw graph)
   u32 ecap;           // edge slots per node in `edge`
   bool lds;           // every array the lanes cooperate through lives in LDS
+  u32 dbg_why;        // (diagnostics) source line of the capacity that made the compact route give the window up
   u32 ek;             // scratch layout: the four per-edge arrays hold ek * nc entries each, the walk pool wk * nc
   u32 wk;
   u32* pieces;        // (LDS kernels) piece table of the walk being spelled: [0] = count, then two words per piece
@@ -142,6 +146,7 @@ __device__ __forceinline__ void emplace_edge(Win& g, u32 i, u32 val) {  // node.
     if (e[x] == val) return;
   if (n >= static_cast<int>(g.ecap)) {
     g.flags |= 4u;
+    g.dbg_why = __LINE__;
     return;
   }
   e[n] = val;
@@ -1443,6 +1448,7 @@ __global__ __launch_bounds__(64, 4) void k_clean(CleanArgs A) {
   g.scratch = ws.scratch + nb * 32;
   g.source = g.sink = -1;
   g.flags = 0;
+  g.dbg_why = 0;
 #ifdef MA_PROFILE
   for (int q = 0; q < 6; ++q) g.dbg_t[q] = 0;
   for (int q = 0; q < 16; ++q) g.dbg_ph[q] = 0;
@@ -1682,6 +1688,7 @@ __device__ __forceinline__ void clean_candidates(CleanArgs const& A, Win& g, SH&
     }
     if (E > EK * NC || 2 * V > 2 * NC || 4u * V + 4u > g.wk * NC) {
       g.flags |= 4u;
+      g.dbg_why = __LINE__;
       break;
     }
     for (u32 f = lane; f < V; f += 64) {
@@ -1815,12 +1822,19 @@ __device__ __forceinline__ void clean_candidates(CleanArgs const& A, Win& g, SH&
     // earliest overall and, if that one has not crossed a new edge yet, the earliest that has.  The others are
     // folded into those two as a multiplicity, which is all that is needed to know how many entries the reference
     // would have popped (its 2^20-visit cap, max_flow.h:69).  Same walks, arena use linear in the graph.
-    u32* rep = l_link;  // [state][2]: arena index of the representatives in the level being built
-    bool const fold = 5u * V <= g.link_cap;
+    // rep [state][2] (arena index of the representatives in the level being built) + Confidence of every node: in the LDS
+    // table when the component fits it, else behind the walk pool (deep panels keep components of many hundred nodes
+    // after pruning: searched UNFOLDED they ran into the reference's 2^20-pop cap one HBM round trip at a time -- seconds
+    // per window).  The last 4 V words of the pool are the work area of arrival_rank.
+    bool const fold_lds = 5u * V <= g.link_cap;
+    bool const fold = fold_lds || 9u * V + 64u <= walk_pool_cap;
+    u32* const ftab = fold_lds ? l_link : walk_pool + (walk_pool_cap - 9u * V);
+    if (fold && !fold_lds) walk_pool_cap -= 9u * V;
+    u32* rep = ftab;
     // Node::Confidence (f64 arithmetic) of every node of the component, once: the search asks for it per outgoing
     // edge of every popped entry
     if (fold) {
-      for (u32 f = lane; f < V; f += 64) l_link[4u * V + f] = nd_confidence(g, flat_nodes[f]);
+      for (u32 f = lane; f < V; f += 64) ftab[4u * V + f] = nd_confidence(g, flat_nodes[f]);
       wave_sync_mem(g.lds);
       // EnqueueOutgoingEdges sorts a state's edges by the destination's Confidence (stable, descending) every time the
       // state is popped; the confidences do not change during the search, so each state's block is sorted ONCE, a lane
@@ -1828,9 +1842,9 @@ __device__ __forceinline__ void clean_candidates(CleanArgs const& A, Win& g, SH&
       for (u32 stt = lane; stt < 2u * V; stt += 64) {
         u32 const c = rcnt[stt], b0 = rstart[stt];
         for (u32 x = 1; x < c; ++x) {
-          u32 const as = adj_state[b0 + x], ao = adj_ord[b0 + x], cf = l_link[4u * V + (as >> 1)];
+          u32 const as = adj_state[b0 + x], ao = adj_ord[b0 + x], cf = ftab[4u * V + (as >> 1)];
           u32 j = x;
-          while (j > 0 && l_link[4u * V + (adj_state[b0 + j - 1] >> 1)] < cf) {
+          while (j > 0 && ftab[4u * V + (adj_state[b0 + j - 1] >> 1)] < cf) {
             adj_state[b0 + j] = adj_state[b0 + j - 1];
             adj_ord[b0 + j] = adj_ord[b0 + j - 1];
             --j;
@@ -1844,12 +1858,19 @@ __device__ __forceinline__ void clean_candidates(CleanArgs const& A, Win& g, SH&
     // Small graphs (every pruned component of the bench): (state, ordinal) of an edge in one word, (start, count) of a
     // state in one word, the traversed flags as bits in registers -- a popped entry then costs a handful of dependent
     // look-ups instead of some twenty-five
-    bool const fastq = fold && E <= 256u && 2u * V < 0x10000u;
-    u32* const adjp = adj_state;  // packed in place (nothing reads the plain table after the cycle check)
-    unsigned long long trav0 = 0, trav1 = 0, trav2 = 0, trav3 = 0;
+    // Where the packed tables live: the LDS kernels pack them in place (their scratch IS LDS); the HBM kernels copy them
+    // behind the fold tables when the component fits the LDS table, so that the search itself never leaves LDS (the
+    // arena only takes fire-and-forget stores and one lane-parallel read per level).  Otherwise: the plain search.
+    u32 const tab_words = 2u * V + E + (E + 31u) / 32u;
+    bool const tabs_in_link = !g.lds && fold_lds && 5u * V + tab_words <= g.link_cap;
+    bool const fastq = fold && (g.lds || tabs_in_link) && E < 0x10000u && 2u * V < 0x10000u && (!g.lds || (E + 31u) / 32u <= NC);
+    u32* const rs_tab = tabs_in_link ? l_link + 5u * V : rcnt;            // [2V] start | count << 16
+    u32* const adjp = tabs_in_link ? l_link + 7u * V : adj_state;         // [E]  state | ordinal << 16
+    u32* const trav_w = tabs_in_link ? l_link + 7u * V + E : g.scratch;   // [E / 32] traversed flags (the list area is free here)
     if (fastq) {
       for (u32 x = lane; x < E; x += 64) adjp[x] = adj_state[x] | (adj_ord[x] << 16);
-      for (u32 stt = lane; stt < 2u * V; stt += 64) rcnt[stt] = rstart[stt] | (rcnt[stt] << 16);
+      for (u32 stt = lane; stt < 2u * V; stt += 64) rs_tab[stt] = rstart[stt] | (rcnt[stt] << 16);
+      for (u32 x = lane; x < (E + 31u) / 32u; x += 64) trav_w[x] = 0;
       wave_sync_mem(g.lds);
     }
     while (true) {
@@ -1901,7 +1922,7 @@ __device__ __forceinline__ void clean_candidates(CleanArgs const& A, Win& g, SH&
         u32 const m = cnt < static_cast<u32>(kEdgeCap) ? cnt : static_cast<u32>(kEdgeCap);
         for (u32 x = 0; x < m; ++x) {
           u32 const p = rstart[state] + x;
-          u32 const cf = fold ? l_link[4u * V + (adj_state[p] >> 1)] : nd_confidence(g, flat_nodes[adj_state[p] >> 1]);
+          u32 const cf = fold ? ftab[4u * V + (adj_state[p] >> 1)] : nd_confidence(g, flat_nodes[adj_state[p] >> 1]);
           u32 j = x;
           while (j > 0 && conf[j - 1] < cf) {
             conf[j] = conf[j - 1];
@@ -1920,9 +1941,9 @@ __device__ __forceinline__ void clean_candidates(CleanArgs const& A, Win& g, SH&
             if (arena_over) return;
           }
       };
-      auto is_trav = [&](u32 ord) { return ((ord < 128u ? (ord < 64u ? trav0 : trav1) : (ord < 192u ? trav2 : trav3)) >> (ord & 63u)) & 1ull; };
+      auto is_trav = [&](u32 ord) { return (trav_w[ord >> 5] >> (ord & 31u)) & 1u; };
       auto enqueue_fast = [&](u32 state, u32 parent, u32 pw) {
-        u32 const rs = rcnt[state], cnt = rs >> 16, b0 = rs & 0xFFFFu;
+        u32 const rs = rs_tab[state], cnt = rs >> 16, b0 = rs & 0xFFFFu;
         if (cnt == 0) return;
         u32 const pflag = pw >> 31, mult = pw & 0x7FFFFFFFu;
         if (cnt == 1) {
@@ -1986,16 +2007,17 @@ __device__ __forceinline__ void clean_candidates(CleanArgs const& A, Win& g, SH&
           // states have -- three dependent look-ups per LEVEL -- and the entries are then popped in order out of
           // registers; what stays serial per popped entry is the fold bookkeeping of push().
           u32 const nlev = lvl_end - head;
-          u32 my_st = 0, my_w = 0, my_cnt = 0, my_a0 = 0, my_a1 = 0, my_b0 = 0;
+          u32 my_st = 0, my_w = 0, my_cnt = 0, my_a0 = 0, my_a1 = 0, my_b0 = 0, my_t = 0;
           if (lane < nlev) {
             uint4 const e = arena[head + lane];
             my_st = e.y;
             my_w = e.w;
-            u32 const rs = rcnt[e.y];
+            u32 const rs = rs_tab[e.y];
             my_cnt = rs >> 16;
             my_b0 = rs & 0xFFFFu;
             my_a0 = adjp[my_b0];                         // (entry 0 of a block that may be empty: any word of the table)
             my_a1 = adjp[my_b0 + (my_cnt > 1u ? 1u : 0u)];
+            my_t = (my_cnt >= 1u ? is_trav(my_a0 >> 16) : 0u) | ((my_cnt >= 2u ? is_trav(my_a1 >> 16) : 0u) << 1);
           }
           bool stop = false;
           for (u32 x = 0; x < nlev; ++x) {
@@ -2012,11 +2034,12 @@ __device__ __forceinline__ void clean_candidates(CleanArgs const& A, Win& g, SH&
             u32 const pflag = ww >> 31, mult = ww & 0x7FFFFFFFu;
             if (cnt <= 2u) {
               u32 const a0 = __builtin_amdgcn_readlane(my_a0, x), a1 = __builtin_amdgcn_readlane(my_a1, x);
-              bool const t0 = is_trav(a0 >> 16) != 0;
+              u32 const tb = __builtin_amdgcn_readlane(my_t, x);
+              bool const t0 = (tb & 1u) != 0;
               if (cnt == 1u) {
                 push(a0 >> 16, a0 & 0xFFFFu, ai, pflag | (t0 ? 0u : 1u), mult);
               } else {
-                bool const t1 = is_trav(a1 >> 16) != 0;
+                bool const t1 = (tb & 2u) != 0;
                 // new edges first, each class in confidence order: only (old, new) swaps the two
                 u32 const f0 = (t0 && !t1) ? a1 : a0, f1 = (t0 && !t1) ? a0 : a1;
                 bool const ft0 = (t0 && !t1) ? t1 : t0, ft1 = (t0 && !t1) ? t0 : t1;
@@ -2053,7 +2076,7 @@ __device__ __forceinline__ void clean_candidates(CleanArgs const& A, Win& g, SH&
         // (sum of B_d)-th entry of its level; the reference reaches it iff that is below the pops the cap leaves.
         u32 depth = 0;
         for (u32 i = static_cast<u32>(best); i != kNoParent; i = arena[i].z) depth++;
-        if (walk_pool_used + depth + 4u * V > walk_pool_cap) {
+        if (walk_pool_used + depth + (fold_lds ? 4u * V : 0u) > walk_pool_cap) {
           undecided = true;
         } else {
           u32* const chain = walk_pool + walk_pool_used;  // arena indices, level 0 first
@@ -2061,12 +2084,12 @@ __device__ __forceinline__ void clean_candidates(CleanArgs const& A, Win& g, SH&
             u32 pos = depth;
             for (u32 i = static_cast<u32>(best); i != kNoParent; i = arena[i].z) chain[--pos] = i;
           }
-          u32* bcur = walk_pool + walk_pool_cap - 4u * V;
+          u32* bcur = fold_lds ? walk_pool + walk_pool_cap - 4u * V : ftab + 5u * V;
           u32* bnxt = bcur + 2u * V;
           constexpr u32 kSat = 1u << 22;
           auto block_of = [&](u32 stt, u32* b0, u32* cnt) {
             if (fastq) {
-              u32 const rs = rcnt[stt];
+              u32 const rs = rs_tab[stt];
               *b0 = rs & 0xFFFFu;
               *cnt = rs >> 16;
             } else {
@@ -2148,6 +2171,7 @@ __device__ __forceinline__ void clean_candidates(CleanArgs const& A, Win& g, SH&
       for (u32 i = static_cast<u32>(best); i != kNoParent; i = arena[i].z) wl++;
       if (compact && nwalks < kMaxWalks && walk_pool_used + wl > walk_pool_cap) {
         g.flags |= 4u;  // the compact graph's smaller pool: k_clean has the window again
+        g.dbg_why = __LINE__;
         break;
       }
       if (nwalks >= kMaxWalks || walk_pool_used + wl > walk_pool_cap) {
@@ -2161,8 +2185,7 @@ __device__ __forceinline__ void clean_candidates(CleanArgs const& A, Win& g, SH&
           u32 const ord = arena[i].x;
           walk_pool[off + --pos] = ord;
           if (fastq) {
-            unsigned long long const bit = 1ull << (ord & 63u);
-            if (ord < 64u) trav0 |= bit; else if (ord < 128u) trav1 |= bit; else if (ord < 192u) trav2 |= bit; else trav3 |= bit;
+            if (lane == 0) trav_w[ord >> 5] |= 1u << (ord & 31u);
           } else {
             traversed[ord] = 1;
           }
@@ -2170,7 +2193,7 @@ __device__ __forceinline__ void clean_candidates(CleanArgs const& A, Win& g, SH&
       }
       wave_sync_mem(g.lds);
       // MinWeight over the walk's nodes (path.cpp:34-37): a lane per edge, the source node on lane 0 as well
-      auto conf_of = [&](u32 node) { return fold ? l_link[4u * V + flat_of[node]] : nd_confidence(g, node); };
+      auto conf_of = [&](u32 node) { return fold ? ftab[4u * V + flat_of[node]] : nd_confidence(g, node); };
       u32 mw = 0xFFFFFFFFu;
       for (u32 x = lane; x < wl; x += 64) {
         u32 const ordx = walk_pool[off + x];
@@ -2186,7 +2209,10 @@ __device__ __forceinline__ void clean_candidates(CleanArgs const& A, Win& g, SH&
       walk_pool_used += wl;
     }
     CPROF_ACC(9);
-    if (compact && arena_over) g.flags |= 4u;
+    if (compact && arena_over) {
+      g.flags |= 4u;
+      g.dbg_why = __LINE__;
+    }
     if (g.flags & 4u) break;
     if (arena_over) status |= MA_W_TABLE_OVERFLOW;
     if (arena_over && nwalks == 0) {
@@ -2369,6 +2395,7 @@ __device__ __forceinline__ void clean_candidates(CleanArgs const& A, Win& g, SH&
         wave_sync_mem(true);
         if (__ballot(pover)) {
           g.flags |= 4u;  // more slices than the piece table holds: k_clean has the window again
+          g.dbg_why = __LINE__;
           break;
         }
         u32 const np = pieces[0];
@@ -2467,7 +2494,10 @@ __device__ __forceinline__ void clean_candidates(CleanArgs const& A, Win& g, SH&
   if ((g.flags & 4u) && compact) {
     // a capacity of the compact route (edge slots, search arena, walk pool): nothing is reported from here, k_clean --
     // launched behind this kernel -- assembles the window from the raw graph, which nobody has touched
-    if (lane == 0) ws.cg_state[a] = 0u;
+    if (lane == 0) {
+      ws.cg_state[a] = 0u;
+      ws.cg_hdr[static_cast<size_t>(a) * kCgHdr + 3] = 100000u + g.dbg_why;
+    }
     return;
   }
   if (g.flags & 4u) {
@@ -2514,8 +2544,9 @@ struct TailSmall {
 struct TailLarge {
   static constexpr u32 V = 128, Arena = 320, Link = 640, S = 4, Ek = 2, Wk = 5, Pieces = 255, Pool = 5120;
 };
-struct TailHbm {  // (sizes unused: the arrays stay in HBM)
-  static constexpr u32 V = 1, Arena = 1, Link = 640, S = 1, Ek = 1, Wk = 1, Pieces = 1, Pool = 4;
+struct TailHbm {  // the arrays stay in HBM (components of up to a thousand nodes: deep panels); the LDS table is large enough
+  // for the fold tables AND the packed search tables of such a component, so that the search itself runs out of LDS
+  static constexpr u32 V = 1, Arena = 1, Link = 12288, S = 1, Ek = 1, Wk = 1, Pieces = 1, Pool = 4;
 };
 template <class C>
 struct TailLdsT {
@@ -2565,6 +2596,7 @@ __global__ __launch_bounds__(64, 4) void k_clean_tail(CleanArgs A) {
   g.lds = kLds;
   g.source = g.sink = -1;
   g.flags = 0;
+  g.dbg_why = 0;
   u32 NC;
   if constexpr (kLds) {
     __shared__ TailLdsT<C> tl;
@@ -2716,6 +2748,27 @@ int run_clean_pass(ma_ctx* ctx, const DBatch& b, const GraphWs& ws, const ma_asm
     ctx->toc();
   } else if (ws.cg_state) {
     MA_HIP(ctx, hipMemsetAsync(ws.cg_state, 0, sizeof(u32) * static_cast<size_t>(ws.n_active), ctx->stream));
+  }
+  if (use_chains && ws.cg_state && getenv("MA_VERBOSE")) {  // which windows fall through to k_clean, and how large they are
+    std::vector<u32> st(ws.n_active), nn(ws.n_active), hd(static_cast<size_t>(ws.n_active) * kCgHdr);
+    (void)hipMemcpyAsync(st.data(), ws.cg_state, 4 * st.size(), hipMemcpyDeviceToHost, ctx->stream);
+    (void)hipMemcpyAsync(nn.data(), ws.n_nodes, 4 * nn.size(), hipMemcpyDeviceToHost, ctx->stream);
+    (void)hipMemcpyAsync(hd.data(), ws.cg_hdr, 4 * hd.size(), hipMemcpyDeviceToHost, ctx->stream);
+    (void)hipStreamSynchronize(ctx->stream);
+    u32 fall = 0, fall_big = 0, nmax = 0, vmax = 0;
+    std::string why;
+    for (int i = 0; i < ws.n_active; ++i) {
+      nmax = std::max(nmax, nn[i]);
+      if (st[i] == 0) {
+        fall++;
+        fall_big += nn[i] > 4096u;
+        if (fall <= 12) why += " " + std::to_string(hd[static_cast<size_t>(i) * kCgHdr + 3]);
+      } else {
+        vmax = std::max(vmax, hd[static_cast<size_t>(i) * kCgHdr]);
+      }
+    }
+    fprintf(stderr, "[microasm] clean: %d attempts, %u left to k_clean (%u of them beyond 4096 nodes), largest graph %u nodes, largest compact graph %u; reasons (source lines; 100000+ = tail):%s\n",
+            ws.n_active, fall, fall_big, nmax, vmax, why.c_str());
   }
   ctx->tic("k_clean");
   hipLaunchKernelGGL(k_clean, dim3(ws.n_active), dim3(64), 0, ctx->stream, args);

@@ -10,7 +10,8 @@ from lancet2_amd import capi  # noqa: E402
 from lancet2_amd import engine as E  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
-arrs, nw, nr = bench.make_windows("C3", n, 10_000, 8, 8)
+cfg = sys.argv[2] if len(sys.argv) > 2 else "C3"
+arrs, nw, nr = bench.make_windows(cfg, n, 10_000, 8 if cfg != "C4" else 0, 8)
 eng = E.Engine(capi.default_params(min_k=25, max_k=25))
 eng.set_streams(1)
 eng.process(arrs, nw, nr)
