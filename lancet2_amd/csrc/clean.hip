@@ -2730,7 +2730,7 @@ int run_clean_chains(ma_ctx* ctx, const DBatch& b, const GraphWs& ws, const ma_p
 int run_clean_pass(ma_ctx* ctx, const DBatch& b, const GraphWs& ws, const ma_asm_out_t& out) {
   if (ws.n_active == 0) return MA_OK;
   CleanArgs args{b, ws, out, ctx->prm};
-  static const bool use_chains = !getenv("MA_NO_CHAINS");
+  bool const use_chains = !getenv("MA_NO_CHAINS");  // (read per call: the tests switch routes inside one process)
   if (use_chains && ws.cg_state) {
     // the first CompressGraph of every candidate component as bulk-parallel LDS work, then the rest of the candidate loop
     // on the few dozen nodes it leaves; windows it does not take (graph beyond its capacities, unusual shapes) keep
