@@ -392,7 +392,7 @@ def main():
 
     from lancet2_amd import capi, synth
     from lancet2_amd.engine import Engine
-    from lancet2_amd.stamp import csrc_sha16
+    from lancet2_amd.stamp import build_stamp, csrc_sha16
 
     params = capi.default_params(min_k=25, max_k=25)  # BASELINE config: k = 25 (single attempt)
     params.num_samples = num_samples
@@ -531,7 +531,13 @@ def main():
     dom = max(agg.items(), key=lambda kv: kv[1][0])[0] if agg else None
     roof = roof_valu = None
     prof = {}
-    for cand in ("r3_pmc_per_kernel.json", "r2_pmc_per_kernel.json"):
+    def prof_is_stale(stamp):  # the counters were taken from another build than the one this run times
+        now = build_stamp()
+        if stamp.get("lib_sha16") and now.get("lib_sha16"):
+            return stamp["lib_sha16"] != now["lib_sha16"]
+        return stamp.get("csrc_sha16") != now["csrc_sha16"]
+
+    for cand in ("r4_pmc_per_kernel.json", "r3_pmc_per_kernel.json", "r2_pmc_per_kernel.json"):
         tpath = os.path.join(REPO, "profiles", cand)
         if os.path.exists(tpath):
             try:
@@ -553,7 +559,7 @@ def main():
                 "traffic_source": prof.get("_file") if pk else None,
                 # the PMC passes are a separate run of this command (rocprofv3 --pmc cannot share a run with the timing);
                 # stale = the kernel sources have changed since those passes were taken
-                "traffic_stale": (prof.get("_stamp", {}).get("csrc_sha16") != csrc_sha16()) if pk else None,
+                "traffic_stale": prof_is_stale(prof.get("_stamp", {})) if pk else None,
                 "avg_launch_ms": round(avg_ms, 4), "launches_per_step": launches_per_step,
                 "algorithmic_bytes_per_launch": int(bytes_per_launch),
                 "note": "achieved = the WHOLE stage's SURVEY 8(d) bytes per launch / this kernel's mean launch time "
@@ -564,7 +570,7 @@ def main():
             roof_valu = {"bound": "valu", "kernel": dom, "achieved": round(av / 1e12, 3), "peak": round(VALU_PEAK_LANE_OPS / 1e12, 1),
                          "unit": "T lane-ops/s", "frac": round(av / VALU_PEAK_LANE_OPS, 4),
                          "valu_insts_per_launch": pk["valu_insts_per_launch"], "source": prof.get("_file"),
-                         "stale": prof.get("_stamp", {}).get("csrc_sha16") != csrc_sha16(),
+                         "stale": prof_is_stale(prof.get("_stamp", {})),
                          "note": "SQ_INSTS_VALU (wave instructions, committed PMC pass of this command) x 64 lanes / this run's "
                                  "mean launch time; peak = 256 CU x 4 SIMD x 32 lanes x 2.4 GHz"}
 
@@ -761,6 +767,7 @@ def main():
             "step_algorithmic": {"MB_per_step": round(step_bytes / 1e6, 1),
                                  "GB_per_s": round(step_bytes / (elapsed / args.steps) / 1e9, 1),
                                  "frac_of_hbm_peak": round(step_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 5)},
+            "build": build_stamp(),  # what this run loaded: tools/pmc_per_kernel.py stamps the counters of a PMC pass with it
             "kernel_ms_per_step": kernel_ms_per_step, "stages": stages,
             "work": {"pairs_per_window": round(pairs_w, 1), "dp_pairs_per_window": round(dp_w, 1),
                      "dp_pairs_by_region_width": {k_: round(stats.get(k_, 0) / steps / n, 2)

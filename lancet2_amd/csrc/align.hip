@@ -1513,7 +1513,10 @@ __global__ __launch_bounds__(256) void k_dp_scatter(GArgs A, u32 ndp, u32* out, 
 }
 
 // waves per SIMD the register allocator is asked to keep (it otherwise spends registers on scheduling freedom)
-__host__ __device__ constexpr int reg_waves(int w) { return w <= 49 ? 4 : (w <= 65 ? 3 : (w <= 97 ? 2 : 1)); }
+#ifndef MA_RW49
+#define MA_RW49 3
+#endif
+__host__ __device__ constexpr int reg_waves(int w) { return w <= 49 ? MA_RW49 : (w <= 65 ? 3 : (w <= 97 ? 2 : 1)); }
 // the body of one width class: `group` = the class's 64-pair group this wavefront owns
 template <int W, int WLO>
 __device__ __forceinline__ void align_reg_body(GArgs const& A, u32 seg_words, u32 const group, u32* lds) {
@@ -2265,11 +2268,11 @@ int launch_genotype(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& a, const m
         }
         // two register classes of the same register budget, side by side in one launch (k_align_reg2) when both fit the
         // traceback workspace whole
-        if (!wave && cls < kNumReg && reg_waves(reg_width(cls)) == 4 && !getenv("MA_NO_PAIR")) {
+        if (!wave && cls < kNumReg && reg_waves(reg_width(cls)) == MA_RW49 && !getenv("MA_NO_PAIR")) {
           int c2 = -1;
           for (int c = cls + 1; c < kNumReg; ++c) {
             if (class_n(c) == 0) continue;
-            if (!class_wave(c) && reg_waves(reg_width(c)) == 4) c2 = c;
+            if (!class_wave(c) && reg_waves(reg_width(c)) == MA_RW49) c2 = c;
             break;
           }
           if (c2 >= 0) {

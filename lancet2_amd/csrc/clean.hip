@@ -1387,7 +1387,7 @@ using CleanLds = CleanLdsT<kLinkCap>;
 template <class SH>
 __device__ __forceinline__ void clean_candidates(CleanArgs const& A, Win& g, SH& sh, int a, int w, int ncand, int first_phase, u32 NC);
 
-__global__ __launch_bounds__(64, 4) void k_clean(CleanArgs A) {
+__global__ __launch_bounds__(64, 2) void k_clean(CleanArgs A) {  // (the rare route: registers rather than occupancy, no spills)
   int const a = blockIdx.x;
   u32 const lane = threadIdx.x;
   GraphWs const& ws = A.ws;
@@ -2565,7 +2565,7 @@ __device__ __forceinline__ bool tail_fits(u32 V, u32 pool_used, u32 kk, int S) {
 }
 
 template <class C, bool kLds>
-__global__ __launch_bounds__(64, 4) void k_clean_tail(CleanArgs A) {
+__global__ __launch_bounds__(64, 2) void k_clean_tail(CleanArgs A) {
   int const a = blockIdx.x;
   u32 const lane = threadIdx.x;
   GraphWs const& ws = A.ws;

@@ -16,3 +16,19 @@ def csrc_sha16():
         h.update(os.path.basename(f).encode())
         h.update(open(f, "rb").read())
     return h.hexdigest()[:16]
+
+
+def lib_sha16():
+    """hash of the built library bench.py / the profiler actually load (None if it is not built)"""
+    path = os.path.join(REPO, "lancet2_amd", "libmicroasm.so")
+    if not os.path.exists(path):
+        return None
+    h = hashlib.sha256()
+    with open(path, "rb") as fh:
+        for chunk in iter(lambda: fh.read(1 << 20), b""):
+            h.update(chunk)
+    return h.hexdigest()[:16]
+
+
+def build_stamp():
+    return {"csrc_sha16": csrc_sha16(), "lib_sha16": lib_sha16()}

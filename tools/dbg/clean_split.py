@@ -9,6 +9,8 @@ import bench  # noqa: E402
 from lancet2_amd import capi  # noqa: E402
 from lancet2_amd import engine as E  # noqa: E402
 
+if os.environ.get("MA_LIB"):
+    capi.LIB_PATH = os.path.join(capi.REPO, "lancet2_amd", os.environ["MA_LIB"])
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 cfg = sys.argv[2] if len(sys.argv) > 2 else "C3"
 arrs, nw, nr = bench.make_windows(cfg, n, 10_000, 8 if cfg != "C4" else 0, 8)

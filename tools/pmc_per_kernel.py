@@ -54,7 +54,15 @@ def main():
     out["_note"] = ("FETCH_SIZE x 1024 x 2 (gfx950 read correction) + WRITE_SIZE x 1024; SQ_INSTS_VALU wave instructions; "
                     "averaged per launch; three separate --pmc passes of `python3 bench.py --steps 2 --no-cpu --no-also`")
     # provenance: bench.py marks these figures stale when the kernel sources it runs are not the ones profiled here
-    out["_stamp"] = {"csrc_sha16": csrc_sha16(), "command": "python3 bench.py --steps 2 --no-cpu --no-also --gen-workers 1"}
+    # provenance = what the PROFILED run loaded (the `build` object of its own JSON line, argv[5] = that run's log), not what
+    # the sources look like when this script runs afterwards
+    stamp = {"csrc_sha16": csrc_sha16()}
+    if len(sys.argv) > 5 and os.path.exists(sys.argv[5]):
+        for line in open(sys.argv[5]):
+            if line.startswith('{"metric"'):
+                stamp = json.loads(line).get("build", stamp)
+    stamp["command"] = "python3 bench.py --steps 2 --no-cpu --no-also --gen-workers 1"
+    out["_stamp"] = stamp
     json.dump(out, open(sys.argv[4], "w"), indent=1, sort_keys=True)
     for k, v in out.items():
         if not k.startswith("_"):
