@@ -108,6 +108,61 @@ def units_per_step(stage, st):
     return st["assembled"]
 
 
+def pipeline_extract_leg(genome_len=200_000, depths=(30, 60), seed=0x5EED):
+    """builds examples/pipeline_driver.cpp with g++, writes a random genome + two coordinate-sorted SAM files (150-base paired
+    reads, plain 150M alignments) and times the extract stage on them: the driver prints each stage's busy time"""
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which("g++") is None:
+        raise RuntimeError("no g++")
+    d = tempfile.mkdtemp(prefix="ma_extract_")
+    try:
+        exe = os.path.join(d, "pipeline_driver")
+        lib = os.path.join(REPO, "lancet2_amd")
+        subprocess.check_call(["g++", "-std=c++17", "-O2", os.path.join(REPO, "examples", "pipeline_driver.cpp"), "-I", os.path.join(REPO, "include"),
+                               "-L", lib, "-lmicroasm", f"-Wl,-rpath,{lib}", "-Wl,--allow-shlib-undefined", "-DLANCET2_AMD_WITH_ZLIB", "-lz",
+                               "-lpthread", "-o", exe])
+        rng = np.random.default_rng(seed)
+        genome = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, genome_len)]
+        with open(os.path.join(d, "ref.fa"), "w") as f:
+            f.write(">chr1\n" + bytes(genome).decode() + "\n")
+        nreads = 0
+        for name, depth in zip(("normal", "tumor"), depths):
+            npairs = genome_len * depth // 300
+            starts = np.sort(rng.integers(0, genome_len - 550, npairs))
+            qual = "I" * 150
+            recs = []
+            for i, s0 in enumerate(starts):
+                s1 = int(s0) + 250 + int(rng.integers(0, 150))
+                recs.append((int(s0), f"{name[0]}{i}", 0x63, s1))
+                recs.append((s1, f"{name[0]}{i}", 0x93, int(s0)))
+            recs.sort()
+            with open(os.path.join(d, name + ".sam"), "w") as f:
+                f.write("@HD\tVN:1.6\tSO:coordinate\n@SQ\tSN:chr1\tLN:%d\n" % genome_len)
+                for pos0, qn, flag, mate in recs:
+                    f.write(f"{qn}\t{flag}\tchr1\t{pos0 + 1}\t60\t150M\t=\t{mate + 1}\t{mate - pos0}\t{bytes(genome[pos0:pos0 + 150]).decode()}\t{qual}\tMD:Z:150\n")
+            nreads += len(recs)
+        t0 = time.perf_counter()
+        r = subprocess.run([exe, "--reference", os.path.join(d, "ref.fa"), "--normal", os.path.join(d, "normal.sam"), "--tumor",
+                            os.path.join(d, "tumor.sam"), "--no-active-region", "--extract-only"], capture_output=True, text=True)
+        wall = time.perf_counter() - t0
+        m = re.search(r"extract ([0-9.]+) s busy \(([0-9.]+) windows/s tiled, ([0-9.]+) shipped/s\)", r.stderr)
+        if r.returncode != 0 or not m:
+            raise RuntimeError("pipeline_driver --extract-only: " + r.stderr[-200:])
+        nwin = int(re.search(r"pipeline_driver: (\d+) windows", r.stderr).group(1))
+        return {"value": float(m.group(3)), "unit": "windows/s handed to the engine by the extract stage", "busy_s": float(m.group(1)),
+                "collector_threads": int(m.group(4)), "windows_per_cpu_second": round(nwin / max(float(m.group(5)), 1e-9), 1),
+                "windows": nwin, "reads": nreads, "reads_per_window": round(nreads * 1.25 / max(nwin, 1), 1),
+                "wall_s_incl_sam_parsing": round(wall, 2),
+                "note": "examples/pipeline_driver.cpp --extract-only --no-active-region on a random %d kb genome, %dx/%dx, SAM text; "
+                        "the engine takes ~200 k windows/s: the extract stage, not the GPU, bounds a deployment unless it gets "
+                        "hundreds of cores (the reference runs one collector per worker, pipeline_executor.cpp:174-197)" % (genome_len // 1000, depths[1], depths[0])}
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
 # ---- synthetic windows ---------------------------------------------------------------------------------------------
 NOHINT_EVERY = 50  # set from --nohint-every before any window is made (module global: the pool workers are forked)
 HARD_EVERY, SOFTCLIP, NFRAC = 16, 0.03, 0.01  # likewise (--hard-every, --softclip, --nfrac)
@@ -651,6 +706,13 @@ def main():
             # the output structs of the headline (two samples) are large enough for the assembly / variant arrays; the
             # genotype arrays are allocated per leg from the leg's own parameters
             also["c5_three_samples"] = device_leg(c5_arrs, WORKLOADS["C5"], leg_params=p5, kernels=True)
+        # (2b) the host shell's EXTRACT stage alone (examples/pipeline_driver.cpp --extract-only): window tiling,
+        #      gates, read collection with the reference's filters / downsampling / comparator, Flatten -- how many windows
+        #      per second ONE extract thread can hand the engine, on a synthetic 60x/30x genome read from SAM text
+        try:
+            also["pipeline_extract"] = pipeline_extract_leg()
+        except Exception as exc:  # (no g++ / zlib on the box: not part of the metric)
+            also["pipeline_extract"] = {"error": str(exc)[:200]}
         # (3) host path: caller-owned PINNED host buffers through MA_MEM_HOST -- the library stages inputs through HBM and
         #     copies every fixed-stride output array back (PCIe both ways inside the timed region).  One feeder = one
         #     context, nothing overlaps; two feeders = two contexts on the same device, each on its own host thread (what

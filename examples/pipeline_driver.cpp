@@ -12,6 +12,8 @@
 //       -Wl,--allow-shlib-undefined -DLANCET2_AMD_WITH_ZLIB -lz -lpthread -o pipeline_driver
 //   ./pipeline_driver --reference ref.fa --normal n.sam --tumor t.sam --region chr1:1-20000 --out calls.tsv
 // Flags follow the reference CLI (cli/cli_interface.cpp:203-303) where the engine has the knob.
+#include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <deque>
 #include <mutex>
@@ -150,7 +152,15 @@ void DumpBatch(const std::string& dir, FlatBatch const& fb) {
 AlignmentSource LoadAlignments(const std::string& path, Reference const& ref) {
   bool const bam = path.size() > 4 && path.substr(path.size() - 4) == ".bam";
 #ifdef LANCET2_AMD_WITH_ZLIB
-  if (bam) return AlignmentSource::LoadBam(path, ref);
+  if (bam) {
+    // a .bai next to the file: region-indexed access (only the blocks of the regions asked for are read and inflated);
+    // without one the whole file is read once
+    for (std::string const& bai : {path + ".bai", path.substr(0, path.size() - 4) + ".bai"}) {
+      std::ifstream probe(bai, std::ios::binary);
+      if (probe && !getenv("PIPELINE_NO_INDEX")) return AlignmentSource::OpenIndexedBam(path, bai, ref);
+    }
+    return AlignmentSource::LoadBam(path, ref);
+  }
 #else
   if (bam) throw std::runtime_error("built without zlib (-DLANCET2_AMD_WITH_ZLIB -lz): BAM input is not available");
 #endif
@@ -164,12 +174,14 @@ int main(int argc, char** argv) {
   for (int i = 0; i < argc; ++i) command_line += std::string(i ? " " : "") + argv[i];
   double gc_frac = 0.41;  // --genome-gc-bias of the reference CLI: background GC of the LongdustQ null model
   std::vector<std::string> normals, tumors, regions;
+  std::string bed_path;
   WindowBuilder::Params wp;
   ReadCollector::Params rp;
   ma_params_t prm;
   ma_default_params(&prm);
   bool no_active_region = false, extract_only = false;
   int batch_windows = 512;
+  int extract_threads = static_cast<int>(std::min(8u, std::max(1u, std::thread::hardware_concurrency())));
   for (int i = 1; i < argc; ++i) {
     std::string const a = argv[i];
     auto next = [&]() -> const char* { return i + 1 < argc ? argv[++i] : ""; };
@@ -177,6 +189,7 @@ int main(int argc, char** argv) {
     else if (a == "--normal" || a == "-n") normals.emplace_back(next());
     else if (a == "--tumor" || a == "-t") tumors.emplace_back(next());
     else if (a == "--region" || a == "-R") regions.emplace_back(next());
+    else if (a == "--bed-file" || a == "-b") bed_path = next();  // cli_interface.cpp: regions from a BED file (core/bed_parser.cpp)
     else if (a == "--out" || a == "-o") out_path = next();
     else if (a == "--out-vcf") vcf_path = next();  // VCF text instead of the TSV lines (adds the SEQ_CX / GRAPH_CX annotation)
     else if (a == "--genome-gc-bias") gc_frac = std::atof(next());
@@ -192,6 +205,7 @@ int main(int argc, char** argv) {
     else if (a == "--extract-pairs") rp.extract_pairs = true;
     else if (a == "--no-active-region") no_active_region = true;
     else if (a == "--batch-windows") batch_windows = std::max(1, std::atoi(next()));
+    else if (a == "--extract-threads") extract_threads = std::max(1, std::atoi(next()));  // (the reference: -T, one collector per worker)
     else if (a == "--dump") dump_dir = next();
     else if (a == "--extract-only") extract_only = true;  // stage 1 alone (with --dump): no device needed
     else { std::fprintf(stderr, "pipeline_driver: unknown option %s\n", a.c_str()); return 2; }
@@ -218,8 +232,18 @@ int main(int argc, char** argv) {
   if (wp.window_length + 1 > static_cast<uint32_t>(prm.max_hap_len) - 16) prm.max_hap_len = 3072;  // -w 2500 (cli maximum)
 
   WindowBuilder wb(&ref, wp);
-  if (regions.empty()) wb.AddAllReferenceRegions();
+  std::vector<RegionSpec> bed_regions;
+  if (!bed_path.empty()) {
+    try {
+      bed_regions = ParseBedFile(bed_path, [&](std::string const& c) { return ref.Find(c) >= 0; });
+    } catch (std::exception const& e) {
+      std::fprintf(stderr, "pipeline_driver: %s\n", e.what());
+      return 2;
+    }
+  }
+  if (regions.empty() && bed_regions.empty()) wb.AddAllReferenceRegions();
   for (auto const& r : regions) wb.AddRegion(r);
+  for (auto const& r : bed_regions) wb.AddRegion(r);
   std::vector<Window> const windows = wb.BuildWindows();
 
   ma_ctx_t* ctx = nullptr;
@@ -232,15 +256,66 @@ int main(int argc, char** argv) {
 
   Channel<Job> to_engine(3), to_flush(3);
   size_t n_skipped[5] = {0, 0, 0, 0, 0};
+  // busy time of each stage (what it spends on its own work, not waiting for its neighbours): windows / busy second is the
+  // rate the stage could sustain alone -- the slowest of the three bounds the pipeline
+  using Clock = std::chrono::steady_clock;
+  auto secs = [](Clock::duration d) { return std::chrono::duration<double>(d).count(); };
+  double busy_extract = 0.0, busy_engine = 0.0, busy_flush = 0.0;
+  size_t n_shipped = 0;
+  auto const t_start = Clock::now();
   // ---- stage 1: extract ----
+  // N worker threads take windows off a shared counter (gates + read collection, each with its own ReadCollector and its own
+  // handle on an indexed BAM, as the reference's workers have: async_worker.h:45); one assembler thread appends their
+  // results to the batches IN WINDOW ORDER, so the batches do not depend on N.
+  struct Slot {
+    std::atomic<int> ready{0};
+    WindowStatus st = WindowStatus::RUN;
+    ReadCollector::Result rc;
+  };
+  std::vector<Slot> slots(windows.size());
+  std::atomic<size_t> next_window{0}, consumed{0};
+  constexpr size_t kRunAhead = 4096;  // windows collected but not yet batched (bounds the memory held in slots)
+  std::vector<double> worker_busy(static_cast<size_t>(extract_threads), 0.0);
+  std::vector<std::thread> workers;
+  for (int t = 0; t < extract_threads; ++t)
+    workers.emplace_back([&, t] {
+      std::vector<SampleInfo> mine = samples;
+      std::vector<AlignmentSource> clones;
+#ifdef LANCET2_AMD_WITH_ZLIB
+      clones.reserve(mine.size());
+      for (auto& sm : mine)
+        if (sm.source->indexed() && t > 0) {
+          clones.push_back(sm.source->CloneIndexed());
+          sm.source = &clones.back();
+        }
+#endif
+      ReadCollector collector(rp, mine);
+      while (true) {
+        size_t const i = next_window.fetch_add(1);
+        if (i >= windows.size()) break;
+        while (i > consumed.load(std::memory_order_acquire) + kRunAhead) std::this_thread::yield();
+        auto const t0 = Clock::now();
+        Window const& w = windows[i];
+        std::string_view const seq(ref.chroms[static_cast<size_t>(w.chrom)].seq.data() + (w.start1 - 1), w.Length());
+        Slot& sl = slots[i];
+        sl.st = PreReadGate(seq, prm.max_k, no_active_region, collector.Samples(), w);
+        if (sl.st == WindowStatus::RUN) {
+          sl.rc = collector.CollectRegion(w);
+          if (CrossSampleMeanCoverage(sl.rc.samples, w.Length()) < static_cast<double>(prm.min_anchor_cov)) sl.st = WindowStatus::SKIPPED_ANCHOR_COVERAGE;
+        }
+        worker_busy[static_cast<size_t>(t)] += secs(Clock::now() - t0);
+        sl.ready.store(1, std::memory_order_release);
+      }
+    });
   std::thread extract([&] {
-    ReadCollector collector(rp, samples);
     auto fresh = [] { Job j; j.batch = std::make_unique<FlatBatch>(); return j; };
     Job cur = fresh();
     size_t n_dumped = 0;
     auto ship = [&] {
       if (cur.batch->windows.empty()) return;
+      auto const ts = Clock::now();
       cur.batch->Seal();
+      busy_extract += secs(Clock::now() - ts);  // (the Push below may wait for the engine: not this stage's time)
       if (!dump_dir.empty()) {
         char sub[64];
         std::snprintf(sub, sizeof sub, "/batch_%04zu", n_dumped++);
@@ -252,17 +327,20 @@ int main(int argc, char** argv) {
       to_engine.Push(std::move(cur));
       cur = fresh();
     };
-    for (Window const& w : windows) {
-      std::string_view const seq(ref.chroms[static_cast<size_t>(w.chrom)].seq.data() + (w.start1 - 1), w.Length());
-      WindowStatus st = PreReadGate(seq, prm.max_k, no_active_region, collector.Samples(), w);
-      ReadCollector::Result rc;
-      if (st == WindowStatus::RUN) {
-        rc = collector.CollectRegion(w);
-        if (CrossSampleMeanCoverage(rc.samples, w.Length()) < static_cast<double>(prm.min_anchor_cov)) st = WindowStatus::SKIPPED_ANCHOR_COVERAGE;
+    for (size_t i = 0; i < windows.size(); ++i) {
+      Slot& sl = slots[i];
+      while (!sl.ready.load(std::memory_order_acquire)) std::this_thread::yield();
+      auto const t0 = Clock::now();
+      Window const& w = windows[i];
+      n_skipped[static_cast<int>(sl.st)]++;
+      if (sl.st == WindowStatus::RUN) {
+        std::string_view const seq(ref.chroms[static_cast<size_t>(w.chrom)].seq.data() + (w.start1 - 1), w.Length());
+        cur.batch->Add(w, seq, sl.rc.reads, &sl.rc.samples);
+        n_shipped++;
       }
-      n_skipped[static_cast<int>(st)]++;
-      if (st != WindowStatus::RUN) continue;
-      cur.batch->Add(w, seq, rc.reads, &rc.samples);
+      sl.rc = ReadCollector::Result();  // release the reads
+      consumed.store(i + 1, std::memory_order_release);
+      busy_extract += secs(Clock::now() - t0);
       if (static_cast<int>(cur.batch->windows.size()) >= batch_windows) ship();
     }
     ship();
@@ -275,12 +353,14 @@ int main(int argc, char** argv) {
       if (extract_only) continue;
       Job* nxt = nullptr;
       if (to_engine.Peek(&nxt)) ma_prefetch_batch(ctx, &nxt->batch->view);  // uploads under this batch's kernels
+      auto const t0 = Clock::now();
       j.out = std::make_unique<Outputs>();
       j.out->Allocate(prm, j.batch->view.n_windows);
       j.rc = ma_process_batch(ctx, &j.batch->view, &j.out->gate, &j.out->asmb, &j.out->vars, &j.out->geno);
       if (j.rc == MA_OK && !vcf_path.empty())  // INFO SEQ_CX / GRAPH_CX (core/variant_builder.cpp:159-160)
         j.rc = ma_annotate_batch(ctx, &j.batch->view, &j.out->asmb, &j.out->vars, gc_frac, &j.out->cx);
       if (j.rc != MA_OK) j.err = ma_last_error(ctx);
+      busy_engine += secs(Clock::now() - t0);
       to_flush.Push(std::move(j));
     }
     to_flush.Close();
@@ -313,6 +393,7 @@ int main(int argc, char** argv) {
       // pipeline_executor.cpp:215-252: the flush lags the last window done by NUM_BUFFER_WINDOWS = 100 windows, so that a
       // call can still be replaced by a better covered duplicate from a window that overlaps its own (batches finish in
       // window order here; windows the gates skipped count as done)
+      auto const tf = Clock::now();
       store.AddVariants(RecordsOfBatch(prm, *j.batch, j.out->vars, j.out->geno, as_vcf ? &j.out->cx : nullptr));
       size_t const done_upto = j.batch->windows.back().genome_index + 1;
       constexpr size_t kBufferWindows = 100;
@@ -325,9 +406,13 @@ int main(int argc, char** argv) {
         n_assembled += (st & MA_W_NO_HAPLOTYPE) ? 0 : 1;
         n_flagged += (st & ~static_cast<uint32_t>(MA_W_NO_HAPLOTYPE | MA_W_BFS_LIMIT)) ? 1 : 0;
       }
+      busy_flush += secs(Clock::now() - tf);
     }
+    auto const tf = Clock::now();
     write(store.ExtractAll());
+    busy_flush += secs(Clock::now() - tf);
   }
+  for (auto& t : workers) t.join();
   extract.join();
   engine.join();
   if (ctx) ma_destroy(ctx);
@@ -336,5 +421,27 @@ int main(int argc, char** argv) {
                "pipeline_driver: %zu windows (%zu N-only, %zu max-k repeat, %zu inactive, %zu below anchor coverage), %zu assembled, "
                "%zu with a capacity flag, %zu records\n",
                windows.size(), n_skipped[1], n_skipped[2], n_skipped[3], n_skipped[4], n_assembled, n_flagged, n_records);
+  double const wall = secs(Clock::now() - t_start);
+  size_t blocks = 0;
+  bool any_indexed = false;
+#ifdef LANCET2_AMD_WITH_ZLIB
+  for (auto const& src : sources) {
+    blocks += src.blocks_inflated();
+    any_indexed = any_indexed || src.indexed();
+  }
+#endif
+  auto rate = [](size_t nn, double t) { return t > 0.0 ? static_cast<double>(nn) / t : 0.0; };
+  double collect_cpu = 0.0, collect_max = 0.0;
+  for (double b : worker_busy) {
+    collect_cpu += b;
+    collect_max = std::max(collect_max, b);
+  }
+  busy_extract += collect_max;  // the stage's span: its slowest collector + the ordered batching
+  std::fprintf(stderr,
+               "pipeline_driver: stages -- extract %.3f s busy (%.0f windows/s tiled, %.0f shipped/s) with %d collector thread(s), %.3f cpu-s of collection, engine %.3f s busy (%.0f windows/s), "
+               "flush %.3f s busy (%.0f windows/s); wall %.3f s (%.0f shipped windows/s)%s\n",
+               busy_extract, rate(windows.size(), busy_extract), rate(n_shipped, busy_extract), extract_threads, collect_cpu, busy_engine, rate(n_shipped, busy_engine),
+               busy_flush, rate(n_shipped, busy_flush), wall, rate(n_shipped, wall),
+               any_indexed ? (std::string("; indexed BAM: ") + std::to_string(blocks) + " BGZF blocks inflated").c_str() : "");
   return rc_all;
 }

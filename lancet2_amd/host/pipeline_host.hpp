@@ -23,6 +23,7 @@
 #include <fstream>
 #include <functional>
 #include <map>
+#include <memory>
 #include <optional>
 #include <random>
 #include <sstream>
@@ -123,11 +124,179 @@ inline std::vector<CigarUnit> ParseCigar(std::string_view s) {
   return out;
 }
 
+#ifdef LANCET2_AMD_WITH_ZLIB
+// ---- region-indexed BAM access without htslib: BGZF virtual offsets + the BAI index (SAM specification 4.1, 5.2) ---------
+// What core/read_collector.cpp:106-204 gets from htslib's iterators: only the blocks that hold a region's records are read
+// and inflated -- the whole file no longer has to fit in memory.
+class BgzfFile {
+ public:
+  explicit BgzfFile(const std::string& path) : f_(std::fopen(path.c_str(), "rb")) {
+    if (!f_) throw std::runtime_error("cannot open " + path);
+  }
+  ~BgzfFile() {
+    if (f_) std::fclose(f_);
+  }
+  BgzfFile(BgzfFile const&) = delete;
+  BgzfFile& operator=(BgzfFile const&) = delete;
+  void Seek(uint64_t voff) {
+    if (!have_ || (voff >> 16) != coff_) Load(voff >> 16);
+    pos_ = static_cast<size_t>(voff & 0xFFFFu);
+  }
+  // virtual offset of the next byte Read() returns
+  uint64_t Tell() {
+    while (have_ && pos_ >= block_.size() && !eof_) Load(next_);
+    return (coff_ << 16) | pos_;
+  }
+  bool Read(void* dst, size_t n) {
+    auto* out = static_cast<unsigned char*>(dst);
+    while (n > 0) {
+      if (!have_) Load(0);
+      while (pos_ >= block_.size()) {
+        if (eof_) return false;
+        Load(next_);
+      }
+      size_t const take = std::min(n, block_.size() - pos_);
+      std::memcpy(out, block_.data() + pos_, take);
+      out += take;
+      pos_ += take;
+      n -= take;
+    }
+    return true;
+  }
+  size_t blocks_inflated() const { return blocks_; }
+
+ private:
+  void Load(uint64_t coff) {
+    have_ = true;
+    coff_ = coff;
+    pos_ = 0;
+    block_.clear();
+    unsigned char h[12];
+    if (fseeko(f_, static_cast<off_t>(coff), SEEK_SET) != 0 || std::fread(h, 1, 12, f_) != 12) {
+      eof_ = true;
+      next_ = coff;
+      return;
+    }
+    if (h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || !(h[3] & 4)) throw std::runtime_error("not a BGZF block");
+    size_t const xlen = h[10] | (static_cast<size_t>(h[11]) << 8);
+    std::vector<unsigned char> extra(xlen);
+    if (std::fread(extra.data(), 1, xlen, f_) != xlen) throw std::runtime_error("truncated BGZF block");
+    size_t bsize = 0;
+    for (size_t p = 0; p + 4 <= xlen;) {
+      size_t const slen = extra[p + 2] | (static_cast<size_t>(extra[p + 3]) << 8);
+      if (extra[p] == 'B' && extra[p + 1] == 'C' && slen == 2) bsize = (extra[p + 4] | (static_cast<size_t>(extra[p + 5]) << 8)) + 1;
+      p += 4 + slen;
+    }
+    if (bsize < 12 + xlen + 8) throw std::runtime_error("BGZF block without a BC field");
+    size_t const clen = bsize - 12 - xlen - 8;
+    std::vector<unsigned char> cdata(clen + 8);
+    if (std::fread(cdata.data(), 1, clen + 8, f_) != clen + 8) throw std::runtime_error("truncated BGZF block");
+    uint32_t isize;
+    std::memcpy(&isize, cdata.data() + clen + 4, 4);
+    block_.resize(isize);
+    if (isize > 0) {
+      z_stream zs{};
+      if (inflateInit2(&zs, -15) != Z_OK) throw std::runtime_error("zlib init failed");
+      zs.next_in = cdata.data();
+      zs.avail_in = static_cast<uInt>(clen);
+      zs.next_out = block_.data();
+      zs.avail_out = isize;
+      int const rc = inflate(&zs, Z_FINISH);
+      inflateEnd(&zs);
+      if (rc != Z_STREAM_END) throw std::runtime_error("zlib inflate failed on a BGZF block");
+    }
+    next_ = coff + bsize;
+    eof_ = false;
+    ++blocks_;
+  }
+  FILE* f_ = nullptr;
+  bool have_ = false, eof_ = false;
+  uint64_t coff_ = 0, next_ = 0;
+  std::vector<unsigned char> block_;
+  size_t pos_ = 0, blocks_ = 0;
+};
+
+class BamIndex {  // .bai: per reference the binning index (bin -> chunks of virtual offsets) and the 16 kb linear index
+ public:
+  using Chunk = std::pair<uint64_t, uint64_t>;
+  static BamIndex Load(const std::string& path) {
+    std::ifstream in(path, std::ios::binary);
+    if (!in) throw std::runtime_error("cannot open index " + path);
+    std::vector<unsigned char> d((std::istreambuf_iterator<char>(in)), std::istreambuf_iterator<char>());
+    size_t at = 0;
+    auto need = [&](size_t n) {
+      if (at + n > d.size()) throw std::runtime_error("truncated BAI " + path);
+    };
+    auto rd32 = [&]() { need(4); int32_t v; std::memcpy(&v, d.data() + at, 4); at += 4; return v; };
+    auto rdu32 = [&]() { need(4); uint32_t v; std::memcpy(&v, d.data() + at, 4); at += 4; return v; };
+    auto rd64 = [&]() { need(8); uint64_t v; std::memcpy(&v, d.data() + at, 8); at += 8; return v; };
+    need(4);
+    if (std::memcmp(d.data(), "BAI\1", 4) != 0) throw std::runtime_error(path + " is not a BAI index");
+    at = 4;
+    BamIndex ix;
+    int32_t const n_ref = rd32();
+    ix.refs_.resize(static_cast<size_t>(n_ref));
+    for (auto& r : ix.refs_) {
+      int32_t const n_bin = rd32();
+      for (int32_t b = 0; b < n_bin; ++b) {
+        uint32_t const bin = rdu32();
+        int32_t const n_chunk = rd32();
+        auto& v = r.bins[bin];
+        for (int32_t c = 0; c < n_chunk; ++c) {
+          uint64_t const beg = rd64(), end = rd64();
+          if (bin != 37450u) v.emplace_back(beg, end);  // (the pseudo-bin carries file statistics, not chunks)
+        }
+      }
+      int32_t const n_intv = rd32();
+      r.linear.resize(static_cast<size_t>(n_intv));
+      for (auto& o : r.linear) o = rd64();
+    }
+    return ix;
+  }
+  // chunks that may hold records overlapping [beg0, end0) of reference rid, sorted, overlapping ones merged
+  std::vector<Chunk> Query(int rid, int64_t beg0, int64_t end0) const {
+    std::vector<Chunk> out;
+    if (rid < 0 || static_cast<size_t>(rid) >= refs_.size() || end0 <= beg0) return out;
+    Ref const& r = refs_[static_cast<size_t>(rid)];
+    beg0 = std::max<int64_t>(beg0, 0);
+    int64_t const e = end0 - 1;
+    size_t const w = static_cast<size_t>(beg0 >> 14);
+    uint64_t const min_off = r.linear.empty() ? 0 : r.linear[std::min(w, r.linear.size() - 1)];
+    auto add = [&](uint32_t bin) {
+      auto it = r.bins.find(bin);
+      if (it == r.bins.end()) return;
+      for (auto const& c : it->second)
+        if (c.second > min_off) out.push_back(c);
+    };
+    add(0);
+    for (int64_t k = 1 + (beg0 >> 26); k <= 1 + (e >> 26); ++k) add(static_cast<uint32_t>(k));
+    for (int64_t k = 9 + (beg0 >> 23); k <= 9 + (e >> 23); ++k) add(static_cast<uint32_t>(k));
+    for (int64_t k = 73 + (beg0 >> 20); k <= 73 + (e >> 20); ++k) add(static_cast<uint32_t>(k));
+    for (int64_t k = 585 + (beg0 >> 17); k <= 585 + (e >> 17); ++k) add(static_cast<uint32_t>(k));
+    for (int64_t k = 4681 + (beg0 >> 14); k <= 4681 + (e >> 14); ++k) add(static_cast<uint32_t>(k));
+    std::sort(out.begin(), out.end());
+    std::vector<Chunk> merged;
+    for (auto const& c : out) {
+      if (!merged.empty() && c.first <= merged.back().second) merged.back().second = std::max(merged.back().second, c.second);
+      else merged.push_back(c);
+    }
+    return merged;
+  }
+
+ private:
+  struct Ref {
+    std::map<uint32_t, std::vector<Chunk>> bins;
+    std::vector<uint64_t> linear;
+  };
+  std::vector<Ref> refs_;
+};
+#endif
+
 // One sample's alignments, coordinate-sorted, in memory.  ForRegion visits the records that overlap chrom:start1-end1
 // (1-based, closed -- the region syntax the reference hands to htslib), in file order.
 class AlignmentSource {
  public:
-  std::vector<SamRecord> recs;
+  std::vector<SamRecord> recs;  // whole-file mode (SAM text, BAM without an index); empty in indexed mode
 
   void Finish(size_t n_chroms) {
     std::stable_sort(recs.begin(), recs.end(), [](SamRecord const& a, SamRecord const& b) {
@@ -144,6 +313,39 @@ class AlignmentSource {
   }
   template <class F>
   void ForRegion(int chrom, int64_t start1, int64_t end1, F&& fn) const {
+#ifdef LANCET2_AMD_WITH_ZLIB
+    if (bgzf_) {  // indexed BAM: the index names the chunks, only their blocks are read; same records, same order
+      if (chrom < 0 || static_cast<size_t>(chrom) >= chrom_rid_.size() || chrom_rid_[static_cast<size_t>(chrom)] < 0) return;
+      int const rid = chrom_rid_[static_cast<size_t>(chrom)];
+      int64_t const s0 = start1 - 1, e0 = end1;
+      std::vector<unsigned char> buf;
+      for (auto const& ck : index_->Query(rid, s0, e0)) {
+        bgzf_->Seek(ck.first);
+        bool done = false;
+        while (!done && bgzf_->Tell() < ck.second) {
+          int32_t block = 0;
+          if (!bgzf_->Read(&block, 4) || block < 32) break;
+          buf.resize(static_cast<size_t>(block));
+          if (!bgzf_->Read(buf.data(), buf.size())) break;
+          int32_t r_rid, r_pos;
+          std::memcpy(&r_rid, buf.data(), 4);
+          std::memcpy(&r_pos, buf.data() + 4, 4);
+          if (r_rid != rid) {
+            if (r_rid > rid || r_rid < 0) done = true;
+            continue;
+          }
+          if (r_pos >= e0) {
+            done = true;  // coordinate-sorted: nothing further in this chunk (or any later one) overlaps
+            continue;
+          }
+          SamRecord rec = DecodeBamRecord(buf.data(), buf.size(), ref_map_);
+          if (rec.pos0 + rec.RefSpan() > s0) fn(rec);
+        }
+        if (done) break;
+      }
+      return;
+    }
+#endif
     if (chrom < 0 || static_cast<size_t>(chrom) + 1 >= begin_.size()) return;
     size_t const lo = begin_[static_cast<size_t>(chrom)], hi = begin_[static_cast<size_t>(chrom) + 1];
     int64_t const s0 = start1 - 1, e0 = end1;  // half-open [s0, e0)
@@ -198,6 +400,65 @@ class AlignmentSource {
     return src;
   }
 
+  // one BAM alignment record (SAM specification 4.2; `b` points behind its block_size field)
+  static SamRecord DecodeBamRecord(const unsigned char* b, size_t block, std::vector<int> const& ref_map) {
+    static const char* kSeq = "=ACMGRSVTWYHKDBN";
+    static const char* kOps = "MIDNSHP=X";
+    auto rd32 = [&](size_t at) { int32_t v; std::memcpy(&v, b + at, 4); return v; };
+    int32_t const n_ref = static_cast<int32_t>(ref_map.size());
+    SamRecord r;
+    int32_t const rid = rd32(0), pos = rd32(4);
+    uint8_t const l_read_name = b[8];
+    r.mapq = b[9];
+    uint16_t n_cigar, flag;
+    std::memcpy(&n_cigar, b + 12, 2);
+    std::memcpy(&flag, b + 14, 2);
+    int32_t const l_seq = rd32(16), mrid = rd32(20), mpos = rd32(24), tlen = rd32(28);
+    r.flag = flag;
+    r.chrom = rid >= 0 && rid < n_ref ? ref_map[static_cast<size_t>(rid)] : -1;
+    r.pos0 = pos;
+    r.mate_chrom = mrid >= 0 && mrid < n_ref ? ref_map[static_cast<size_t>(mrid)] : -1;
+    r.mate_pos0 = mpos;
+    r.tlen = tlen;
+    size_t p = 32;
+    r.qname.assign(reinterpret_cast<const char*>(b + p), l_read_name ? l_read_name - 1u : 0u);
+    p += l_read_name;
+    for (uint16_t c = 0; c < n_cigar; ++c) {
+      uint32_t v;
+      std::memcpy(&v, b + p + 4u * c, 4);
+      r.cigar.push_back({(v & 15u) < 9 ? kOps[v & 15u] : '?', v >> 4});
+    }
+    p += 4u * n_cigar;
+    r.seq.resize(static_cast<size_t>(l_seq));
+    for (int32_t i = 0; i < l_seq; ++i) r.seq[static_cast<size_t>(i)] = kSeq[(b[p + static_cast<size_t>(i) / 2] >> (i % 2 ? 0 : 4)) & 15];
+    p += static_cast<size_t>(l_seq + 1) / 2;
+    r.qual.assign(b + p, b + p + l_seq);
+    p += static_cast<size_t>(l_seq);
+    while (p + 3 <= block) {  // auxiliary fields: only MD:Z and the presence of SA matter here
+      char const t0 = static_cast<char>(b[p]), t1 = static_cast<char>(b[p + 1]), ty = static_cast<char>(b[p + 2]);
+      p += 3;
+      size_t len = 0;
+      if (ty == 'Z' || ty == 'H') {
+        len = std::strlen(reinterpret_cast<const char*>(b + p)) + 1;
+        if (t0 == 'M' && t1 == 'D') {
+          r.md.assign(reinterpret_cast<const char*>(b + p));
+          r.has_md = true;
+        }
+        if (t0 == 'S' && t1 == 'A') r.has_sa = true;
+      } else if (ty == 'A' || ty == 'c' || ty == 'C') len = 1;
+      else if (ty == 's' || ty == 'S') len = 2;
+      else if (ty == 'i' || ty == 'I' || ty == 'f') len = 4;
+      else if (ty == 'B') {
+        char const sub = static_cast<char>(b[p]);
+        int32_t const cnt = rd32(p + 1);
+        size_t const es = (sub == 'c' || sub == 'C') ? 1 : ((sub == 's' || sub == 'S') ? 2 : 4);
+        len = 5 + es * static_cast<size_t>(cnt);
+      } else break;
+      p += len;
+    }
+    return r;
+  }
+
 #ifdef LANCET2_AMD_WITH_ZLIB
   // BAM: BGZF blocks are gzip members; the payload is the BAM record stream of the SAM specification, section 4.2
   static AlignmentSource LoadBam(const std::string& path, Reference const& ref) {
@@ -238,74 +499,68 @@ class AlignmentSource {
       ref_map[static_cast<size_t>(i)] = ref.Find(std::string_view(reinterpret_cast<const char*>(raw.data() + at), static_cast<size_t>(l_name - 1)));
       at += static_cast<size_t>(l_name) + 4;
     }
-    static const char* kSeq = "=ACMGRSVTWYHKDBN";
-    static const char* kOps = "MIDNSHP=X";
     AlignmentSource src;
     while (at + 4 <= raw.size()) {
       int32_t const block = rd32(at);
       size_t const b = at + 4;
       at = b + static_cast<size_t>(block);
       if (at > raw.size()) break;
-      SamRecord r;
-      int32_t const rid = rd32(b), pos = rd32(b + 4);
-      uint8_t const l_read_name = raw[b + 8];
-      r.mapq = raw[b + 9];
-      uint16_t n_cigar, flag;
-      std::memcpy(&n_cigar, raw.data() + b + 12, 2);
-      std::memcpy(&flag, raw.data() + b + 14, 2);
-      int32_t const l_seq = rd32(b + 16), mrid = rd32(b + 20), mpos = rd32(b + 24), tlen = rd32(b + 28);
-      r.flag = flag;
-      r.chrom = rid >= 0 && rid < n_ref ? ref_map[static_cast<size_t>(rid)] : -1;
-      r.pos0 = pos;
-      r.mate_chrom = mrid >= 0 && mrid < n_ref ? ref_map[static_cast<size_t>(mrid)] : -1;
-      r.mate_pos0 = mpos;
-      r.tlen = tlen;
-      size_t p = b + 32;
-      r.qname.assign(reinterpret_cast<const char*>(raw.data() + p), l_read_name ? l_read_name - 1u : 0u);
-      p += l_read_name;
-      for (uint16_t c = 0; c < n_cigar; ++c) {
-        uint32_t v;
-        std::memcpy(&v, raw.data() + p + 4u * c, 4);
-        r.cigar.push_back({(v & 15u) < 9 ? kOps[v & 15u] : '?', v >> 4});
-      }
-      p += 4u * n_cigar;
-      r.seq.resize(static_cast<size_t>(l_seq));
-      for (int32_t i = 0; i < l_seq; ++i) r.seq[static_cast<size_t>(i)] = kSeq[(raw[p + static_cast<size_t>(i) / 2] >> (i % 2 ? 0 : 4)) & 15];
-      p += static_cast<size_t>(l_seq + 1) / 2;
-      r.qual.assign(raw.data() + p, raw.data() + p + l_seq);
-      p += static_cast<size_t>(l_seq);
-      while (p + 3 <= at) {  // auxiliary fields: only MD:Z and the presence of SA matter here
-        char const t0 = static_cast<char>(raw[p]), t1 = static_cast<char>(raw[p + 1]), ty = static_cast<char>(raw[p + 2]);
-        p += 3;
-        size_t len = 0;
-        if (ty == 'Z' || ty == 'H') {
-          len = std::strlen(reinterpret_cast<const char*>(raw.data() + p)) + 1;
-          if (t0 == 'M' && t1 == 'D') {
-            r.md.assign(reinterpret_cast<const char*>(raw.data() + p));
-            r.has_md = true;
-          }
-          if (t0 == 'S' && t1 == 'A') r.has_sa = true;
-        } else if (ty == 'A' || ty == 'c' || ty == 'C') len = 1;
-        else if (ty == 's' || ty == 'S') len = 2;
-        else if (ty == 'i' || ty == 'I' || ty == 'f') len = 4;
-        else if (ty == 'B') {
-          char const sub = static_cast<char>(raw[p]);
-          int32_t const cnt = rd32(p + 1);
-          size_t const es = (sub == 'c' || sub == 'C') ? 1 : ((sub == 's' || sub == 'S') ? 2 : 4);
-          len = 5 + es * static_cast<size_t>(cnt);
-        } else break;
-        p += len;
-      }
-      src.recs.push_back(std::move(r));
+      src.recs.push_back(DecodeBamRecord(raw.data() + b, static_cast<size_t>(block), ref_map));
     }
     src.Finish(ref.chroms.size());
     return src;
   }
+  // BAM + .bai: header only; records are fetched per region (ForRegion)
+  static AlignmentSource OpenIndexedBam(const std::string& path, const std::string& bai_path, Reference const& ref) {
+    AlignmentSource src;
+    src.index_ = std::make_shared<BamIndex>(BamIndex::Load(bai_path));
+    src.path_ = path;
+    src.bgzf_ = std::make_shared<BgzfFile>(path);
+    BgzfFile& f = *src.bgzf_;
+    char magic[4];
+    int32_t l_text = 0, n_ref = 0;
+    if (!f.Read(magic, 4) || std::memcmp(magic, "BAM\1", 4) != 0 || !f.Read(&l_text, 4)) throw std::runtime_error(path + " is not a BAM file");
+    std::vector<char> text(static_cast<size_t>(l_text));
+    if (l_text > 0 && !f.Read(text.data(), text.size())) throw std::runtime_error("truncated BAM header in " + path);
+    if (!f.Read(&n_ref, 4)) throw std::runtime_error("truncated BAM header in " + path);
+    src.ref_map_.assign(static_cast<size_t>(n_ref), -1);
+    src.chrom_rid_.assign(ref.chroms.size(), -1);
+    for (int32_t i = 0; i < n_ref; ++i) {
+      int32_t l_name = 0, l_ref = 0;
+      if (!f.Read(&l_name, 4)) throw std::runtime_error("truncated BAM header in " + path);
+      std::string name(static_cast<size_t>(l_name), '\0');
+      if (!f.Read(name.data(), name.size()) || !f.Read(&l_ref, 4)) throw std::runtime_error("truncated BAM header in " + path);
+      if (!name.empty() && name.back() == '\0') name.pop_back();
+      int const c = ref.Find(name);
+      src.ref_map_[static_cast<size_t>(i)] = c;
+      if (c >= 0) src.chrom_rid_[static_cast<size_t>(c)] = i;
+    }
+    return src;
+  }
+  // a second handle on the same indexed file for another extract thread (the BGZF reader is stateful; the index is shared)
+  AlignmentSource CloneIndexed() const {
+    AlignmentSource c;
+    c.index_ = index_;
+    c.path_ = path_;
+    c.bgzf_ = std::make_shared<BgzfFile>(path_);
+    c.ref_map_ = ref_map_;
+    c.chrom_rid_ = chrom_rid_;
+    return c;
+  }
+  bool indexed() const { return bgzf_ != nullptr; }
+  size_t blocks_inflated() const { return bgzf_ ? bgzf_->blocks_inflated() : 0; }
 #endif
 
  private:
   std::vector<size_t> begin_;
   int64_t max_span_ = 1;
+#ifdef LANCET2_AMD_WITH_ZLIB
+  std::shared_ptr<BgzfFile> bgzf_;
+  std::shared_ptr<BamIndex> index_;
+  std::string path_;
+  std::vector<int> ref_map_;    // BAM reference id -> chromosome of the FASTA (-1: not in it)
+  std::vector<int> chrom_rid_;  // and back
+#endif
 };
 
 // ---- windows -----------------------------------------------------------------------------------------------------------
@@ -340,6 +595,39 @@ struct Window {
   uint64_t Length() const { return end1 - start1 + 1; }
 };
 
+// core/bed_parser.cpp:27-96: exactly three tab-separated columns per line, '#' lines and empty lines skipped, the chromosome must
+// be in the reference; the two numbers go into the region span AS THEY ARE (the reference does not shift BED's 0-based start)
+inline std::vector<RegionSpec> ParseBedFile(const std::string& path, std::function<bool(std::string const&)> const& chrom_known) {
+  std::ifstream in(path);
+  if (!in) throw std::runtime_error("Could not open bed file: " + path);
+  std::vector<RegionSpec> out;
+  std::string line;
+  size_t line_num = 0;
+  while (std::getline(in, line)) {
+    line_num++;
+    if (line.empty() || line[0] == '#') continue;
+    std::vector<std::string> tok;
+    size_t p = 0;
+    while (true) {
+      size_t const t = line.find('\t', p);
+      tok.push_back(line.substr(p, t == std::string::npos ? std::string::npos : t - p));
+      if (t == std::string::npos) break;
+      p = t + 1;
+    }
+    if (tok.size() != 3) throw std::runtime_error("Invalid bed line with " + std::to_string(tok.size()) + " columns at line number " + std::to_string(line_num));
+    char *e1 = nullptr, *e2 = nullptr;
+    long long const a = std::strtoll(tok[1].c_str(), &e1, 10), b = std::strtoll(tok[2].c_str(), &e2, 10);
+    if (tok[1].empty() || tok[2].empty() || *e1 != '\0' || *e2 != '\0') throw std::runtime_error("Could not parse line " + std::to_string(line_num) + " in bed: " + path);
+    if (!chrom_known(tok[0])) throw std::runtime_error("Could not find chrom " + tok[0] + " from bed file line " + std::to_string(line_num) + " in reference");
+    RegionSpec r;
+    r.chrom = tok[0];
+    r.start = static_cast<uint64_t>(a);
+    r.end = static_cast<uint64_t>(b);
+    out.push_back(r);
+  }
+  return out;
+}
+
 class WindowBuilder {
  public:
   struct Params {  // core/window_builder.h:19-38
@@ -347,6 +635,7 @@ class WindowBuilder {
   };
   WindowBuilder(Reference const* ref, Params p) : ref_(ref), prm_(p) {}
   void AddRegion(const std::string& spec) { regions_.push_back(RegionSpec::Parse(spec)); }
+  void AddRegion(RegionSpec const& r) { regions_.push_back(r); }  // (a BED line: core/window_builder.cpp:70-74)
   static bool ShouldExcludeChrom(std::string_view c) {  // window_builder.cpp:41-53
     auto starts = [&](std::string_view p) { return c.substr(0, p.size()) == p; };
     auto ends = [&](std::string_view s) { return c.size() >= s.size() && c.substr(c.size() - s.size()) == s; };

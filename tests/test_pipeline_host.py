@@ -245,8 +245,9 @@ def test_pipeline_driver_reproduces_the_oracle_with_overlap_duplicates_merged(tm
     assert somatic >= 2  # the tumour-only SNVs at 1001 and 3101
 
 
-def sam_to_bam(sam_path, bam_path):
-    """a minimal BAM writer (SAM spec 4.2; BGZF blocks = gzip members with the BC extra field): fixture for LoadBam"""
+def sam_to_bam(sam_path, bam_path, with_index=False, block_bytes=60000):
+    """a minimal BAM writer (SAM spec 4.2; BGZF blocks = gzip members with the BC extra field): fixture for LoadBam.
+    with_index: also writes bam_path + ".bai" (SAM spec 5.2: binning index + 16 kb linear index over virtual offsets)"""
     import struct
     import zlib
     refs, recs = [], []
@@ -265,6 +266,7 @@ def sam_to_bam(sam_path, bam_path):
         out += struct.pack("<i", len(nm) + 1) + nm.encode() + b"\0" + struct.pack("<i", ln)
     code = {c: i for i, c in enumerate("=ACMGRSVTWYHKDBN")}
     ops = {c: i for i, c in enumerate("MIDNSHP=X")}
+    rec_at = []  # (uncompressed offset, reference id, start, end) of every record, for the index
     for f in recs:
         qn, flag, rn, pos, mapq, cig, rnext, pnext, tlen, seq, qual = f[:11]
         cigar, num = [], ""
@@ -285,17 +287,63 @@ def sam_to_bam(sam_path, bam_path):
         for tag in f[11:]:
             if tag[3] == "Z":
                 body += tag[:2].encode() + b"Z" + tag[5:].encode() + b"\0"
+        span = sum(n >> 4 for n in cigar if (n & 15) in (0, 2, 3, 7, 8)) or 1
+        rec_at.append((len(out), rid, int(pos) - 1, int(pos) - 1 + span))
         out += struct.pack("<i", len(body)) + body
+    cstart = []
     with open(bam_path, "wb") as fh:
         def block(data):
+            cstart.append(fh.tell())
             comp = zlib.compressobj(6, zlib.DEFLATED, -15)
             cdata = comp.compress(bytes(data)) + comp.flush()
             bsize = len(cdata) + 25
             fh.write(b"\x1f\x8b\x08\x04\0\0\0\0\0\xff\x06\0BC\x02\0" + struct.pack("<H", bsize) + cdata +
                      struct.pack("<II", zlib.crc32(bytes(data)) & 0xFFFFFFFF, len(data)))
-        for i in range(0, len(out), 60000):
-            block(out[i:i + 60000])
+        for i in range(0, len(out), block_bytes):
+            block(out[i:i + block_bytes])
         block(b"")
+    if not with_index:
+        return len(cstart)
+
+    def voff(u):  # (a record may start in one block and end in the next: BGZF allows it)
+        return (cstart[u // block_bytes] << 16) | (u % block_bytes)
+
+    def reg2bin(beg, end):
+        end -= 1
+        for shift, base in ((14, 4681), (17, 585), (20, 73), (23, 9), (26, 1)):
+            if beg >> shift == end >> shift:
+                return base + (beg >> shift)
+        return 0
+
+    bins = [dict() for _ in refs]
+    lin = [dict() for _ in refs]
+    for k, (u, rid, beg, end) in enumerate(rec_at):
+        if rid < 0:
+            continue
+        v0, v1 = voff(u), voff(rec_at[k + 1][0] if k + 1 < len(rec_at) else len(out))
+        ch = bins[rid].setdefault(reg2bin(beg, end), [])
+        if ch and ch[-1][1] == v0:
+            ch[-1][1] = v1
+        else:
+            ch.append([v0, v1])
+        for w in range(beg >> 14, ((end - 1) >> 14) + 1):
+            lin[rid][w] = min(lin[rid].get(w, v0), v0)
+    bai = bytearray(b"BAI\1" + struct.pack("<i", len(refs)))
+    for rid in range(len(refs)):
+        bai += struct.pack("<i", len(bins[rid]))
+        for b_, chunks in sorted(bins[rid].items()):
+            bai += struct.pack("<Ii", b_, len(chunks))
+            for v0, v1 in chunks:
+                bai += struct.pack("<QQ", v0, v1)
+        n_intv = (max(lin[rid]) + 1) if lin[rid] else 0
+        bai += struct.pack("<i", n_intv)
+        last = 0
+        for w in range(n_intv):
+            last = lin[rid].get(w, last)
+            bai += struct.pack("<Q", last)
+    with open(bam_path + ".bai", "wb") as fh:
+        fh.write(bytes(bai))
+    return len(cstart)
 
 
 def test_bam_and_sam_sources_feed_identical_batches(tmp_path):
@@ -318,3 +366,67 @@ def test_bam_and_sam_sources_feed_identical_batches(tmp_path):
     assert dumps["sam"].keys() == dumps["bam"].keys() and len(dumps["sam"]) >= 22
     for k in dumps["sam"]:
         assert dumps["sam"][k] == dumps["bam"][k], k
+
+
+def test_indexed_bam_reads_only_the_blocks_of_the_region(tmp_path):
+    """BAM + .bai (BGZF virtual offsets, binning + linear index; no htslib): for whole-genome and sub-region runs the extract
+    stage flattens byte-identical batches from SAM text, from the BAM read whole, and from the BAM through its index -- and
+    for a sub-region the indexed run inflates a fraction of the file's blocks (core/read_collector.cpp:106-204 iterates
+    htslib regions; round 3 loaded the whole file)."""
+    exe = driver(tmp_path)
+    write_fixture(str(tmp_path))
+    nblocks = {}
+    for name in ("normal", "tumor"):
+        nblocks[name] = sam_to_bam(str(tmp_path / (name + ".sam")), str(tmp_path / (name + ".bam")), with_index=True, block_bytes=6000)
+
+    def run(ext, region, tag, env=None):
+        d = tmp_path / ("dump_" + tag)
+        d.mkdir()
+        e = dict(os.environ)
+        e.update(env or {})
+        r = subprocess.run([exe, "--reference", str(tmp_path / "ref.fa"), "--normal", str(tmp_path / ("normal." + ext)),
+                            "--tumor", str(tmp_path / ("tumor." + ext)), "--batch-windows", "4", "--dump", str(d), "--extract-only"] +
+                           (["--region", region] if region else []), capture_output=True, text=True, env=e)
+        assert r.returncode == 0, r.stderr
+        files = {(b, f): open(d / b / f, "rb").read() for b in sorted(os.listdir(d)) for f in sorted(os.listdir(d / b))}
+        return files, r.stderr
+
+    for region, tag in ((None, "all"), ("chr1:2400-3900", "sub"), ("chr1:1-900", "head"), ("chr1:5200-6000", "tail")):
+        sam, _ = run("sam", region, tag + "_sam")
+        whole, _ = run("bam", region, tag + "_whole", {"PIPELINE_NO_INDEX": "1"})
+        idx, log = run("bam", region, tag + "_idx")
+        assert sam.keys() == whole.keys() == idx.keys() and len(sam) >= 11, (tag, len(sam), len(idx))
+        for k in sam:
+            assert sam[k] == whole[k] == idx[k], (tag, k)
+        assert "indexed BAM" in log and "extract" in log and "windows/s" in log, log
+        inflated = int(log.split("indexed BAM: ")[1].split(" BGZF")[0])
+        if tag == "sub":  # ~1.5 kb of a 6 kb genome: well under the whole file (re-reads of a block by neighbouring windows count)
+            assert 0 < inflated < (nblocks["normal"] + nblocks["tumor"]) * 3, (inflated, nblocks)
+
+
+def test_bed_file_gives_the_regions(tmp_path):
+    """--bed-file (core/bed_parser.cpp:27-96): three tab-separated columns, the span taken as it is; the same windows as the
+    equivalent --region arguments; a malformed line is an error."""
+    exe = driver(tmp_path)
+    write_fixture(str(tmp_path))
+    bed = tmp_path / "targets.bed"
+    bed.write_text("# panel\nchr1\t1000\t2400\n\nchr1\t4000\t5200\n")
+    outs = {}
+    for tag, extra in (("bed", ["--bed-file", str(bed)]), ("regions", ["--region", "chr1:1000-2400", "--region", "chr1:4000-5200"])):
+        d = tmp_path / ("dump_" + tag)
+        d.mkdir()
+        r = subprocess.run([exe, "--reference", str(tmp_path / "ref.fa"), "--normal", str(tmp_path / "normal.sam"),
+                            "--tumor", str(tmp_path / "tumor.sam"), "--batch-windows", "4", "--dump", str(d), "--extract-only"] + extra,
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        outs[tag] = {(b, f): open(d / b / f, "rb").read() for b in sorted(os.listdir(d)) for f in sorted(os.listdir(d / b))}
+    assert outs["bed"] == outs["regions"] and len(outs["bed"]) >= 11
+    bad = tmp_path / "bad.bed"
+    bad.write_text("chr1\t100\n")
+    r = subprocess.run([exe, "--reference", str(tmp_path / "ref.fa"), "--normal", str(tmp_path / "normal.sam"), "--bed-file", str(bad),
+                        "--extract-only"], capture_output=True, text=True)
+    assert r.returncode == 2 and "Invalid bed line with 2 columns at line number 1" in r.stderr, r.stderr
+    bad.write_text("chrZ\t100\t200\n")
+    r = subprocess.run([exe, "--reference", str(tmp_path / "ref.fa"), "--normal", str(tmp_path / "normal.sam"), "--bed-file", str(bad),
+                        "--extract-only"], capture_output=True, text=True)
+    assert r.returncode == 2 and "Could not find chrom chrZ" in r.stderr, r.stderr
