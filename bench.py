@@ -148,7 +148,7 @@ def pipeline_extract_leg(genome_len=200_000, depths=(30, 60), seed=0x5EED):
         r = subprocess.run([exe, "--reference", os.path.join(d, "ref.fa"), "--normal", os.path.join(d, "normal.sam"), "--tumor",
                             os.path.join(d, "tumor.sam"), "--no-active-region", "--extract-only"], capture_output=True, text=True)
         wall = time.perf_counter() - t0
-        m = re.search(r"extract ([0-9.]+) s busy \(([0-9.]+) windows/s tiled, ([0-9.]+) shipped/s\)", r.stderr)
+        m = re.search(r"extract ([0-9.]+) s busy \(([0-9.]+) windows/s tiled, ([0-9.]+) shipped/s\) with (\d+) collector thread\(s\), ([0-9.]+) cpu-s", r.stderr)
         if r.returncode != 0 or not m:
             raise RuntimeError("pipeline_driver --extract-only: " + r.stderr[-200:])
         nwin = int(re.search(r"pipeline_driver: (\d+) windows", r.stderr).group(1))
