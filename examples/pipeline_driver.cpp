@@ -181,7 +181,7 @@ int main(int argc, char** argv) {
   ma_default_params(&prm);
   bool no_active_region = false, extract_only = false;
   int batch_windows = 512;
-  int extract_threads = static_cast<int>(std::min(8u, std::max(1u, std::thread::hardware_concurrency())));
+  int extract_threads = static_cast<int>(std::min(4u, std::max(1u, std::thread::hardware_concurrency())));
   for (int i = 1; i < argc; ++i) {
     std::string const a = argv[i];
     auto next = [&]() -> const char* { return i + 1 < argc ? argv[++i] : ""; };
@@ -293,7 +293,7 @@ int main(int argc, char** argv) {
       while (true) {
         size_t const i = next_window.fetch_add(1);
         if (i >= windows.size()) break;
-        while (i > consumed.load(std::memory_order_acquire) + kRunAhead) std::this_thread::yield();
+        while (i > consumed.load(std::memory_order_acquire) + kRunAhead) std::this_thread::sleep_for(std::chrono::microseconds(200));
         auto const t0 = Clock::now();
         Window const& w = windows[i];
         std::string_view const seq(ref.chroms[static_cast<size_t>(w.chrom)].seq.data() + (w.start1 - 1), w.Length());
@@ -329,7 +329,7 @@ int main(int argc, char** argv) {
     };
     for (size_t i = 0; i < windows.size(); ++i) {
       Slot& sl = slots[i];
-      while (!sl.ready.load(std::memory_order_acquire)) std::this_thread::yield();
+      while (!sl.ready.load(std::memory_order_acquire)) std::this_thread::sleep_for(std::chrono::microseconds(50));  // (no spinning: the collectors need the cores)
       auto const t0 = Clock::now();
       Window const& w = windows[i];
       n_skipped[static_cast<int>(sl.st)]++;
