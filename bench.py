@@ -761,7 +761,7 @@ def main():
                            capi.fill_struct(capi.VarOut, outs[2]), capi.fill_struct(capi.GenoOut, outs[3]))
                 return h_in, outs, structs, capi.make_batch_struct(h_in, hn, h_nr)
 
-            def host_leg(n_feeders, steps_each=5, prefetch=True):
+            def host_leg(n_feeders, steps_each=5, prefetch=True, drain=False):
                 os.environ["MA_HBM_SHARE"] = str(round(0.9 / n_feeders, 3))
                 feeders = [make_feeder() for _ in range(n_feeders)]
                 engs = [Engine(params, device=local_rank, memspace=capi.MA_MEM_HOST) for _ in range(n_feeders)]
@@ -777,6 +777,16 @@ def main():
                     # steady state of a stream of batches: the pipeline is primed before the clock starts (as the warm-up
                     # steps of the headline are) and EVERY timed step uploads one batch and processes one -- the last
                     # step's upload is of a batch nobody processes, so that uploads and steps stay one to one
+                    if drain:
+                        # from an IDLE pipeline to a fully drained one: nothing is uploaded or queued before the clock
+                        # starts, nothing is left in flight when it stops; every batch counted was delivered inside it
+                        start.wait()
+                        e_.prefetch(f_[3])
+                        for it in range(steps_each):
+                            if it + 1 < steps_each:
+                                e_.prefetch(f_[3])
+                            e_.process_device(f_[3], *f_[2])
+                        return
                     if prefetch:
                         e_.prefetch(f_[3])
                         e_.prefetch(f_[3])
@@ -808,6 +818,10 @@ def main():
                                          "its slice and brings back packed records of what it wrote; the next batch is uploaded "
                                          "under this batch's kernels (ma_prefetch_batch); submitted windows/s, PCIe both ways "
                                          "inside the timed region")
+            also["host_path"]["timing"] = "steady state over 5 batches: one batch uploaded and computing when the clock starts, one still in flight when it stops"
+            also["host_path_start_to_drain"] = host_leg(1, steps_each=20, drain=True)
+            also["host_path_start_to_drain"]["note"] = ("the same route timed from an idle pipeline to a drained one over 20 batches: "
+                                                        "every counted batch was uploaded, computed and delivered inside the clock")
             also["host_path_no_prefetch"] = host_leg(1, prefetch=False)
             also["host_path_no_prefetch"]["note"] = "the same without ma_prefetch_batch: upload, kernels and download of a batch in turn"
             also["host_path_2_feeders"] = host_leg(2)

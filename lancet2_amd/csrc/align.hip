@@ -2083,7 +2083,7 @@ int launch_genotype(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& a, const m
   size_t const NR = static_cast<size_t>(b.n_reads);
   int const MH = P.max_haps, MV = P.max_vars, MCG = P.max_cigar;
   if (P.max_hap_len + SK > 65000 || P.max_hap_len * 2 > kIdxCap * 2) {
-    ctx->err = "max_hap_len too large for the 16-bit seed index";
+    ma_set_err(ctx, "max_hap_len too large for the 16-bit seed index");
     return MA_ERR_PARAM;
   }
   GArgs A{};
@@ -2108,7 +2108,7 @@ int launch_genotype(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& a, const m
     u32 const mr = mr2[0];
     rwords_all = (mr2[1] + 31) / 32 + 2;
     if (3u * rwords_all > 64u) {  // (cannot happen: k_max_reads leaves the windows with longer reads out)
-      ctx->err = "ma_genotype_batch: read planes do not fit a wavefront";
+      ma_set_err(ctx, "ma_genotype_batch: read planes do not fit a wavefront");
       return MA_ERR_PARAM;
     }
     u64 want = static_cast<u64>(mr) * 8 + 1024;
@@ -2227,7 +2227,7 @@ int launch_genotype(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& a, const m
         acc += cnt[4 + k];
       }
       if (acc != ndp) {
-        ctx->err = "read aligner: DP pairs per width class do not add up";
+        ma_set_err(ctx, "read aligner: DP pairs per width class do not add up");
         return MA_ERR_HIP;
       }
       ctx->tic("k_dp_scatter");
@@ -2321,7 +2321,7 @@ int launch_genotype(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& a, const m
           A.ws.gen_row = ctx->ws_gen.as<u32>();
         }
         if (tb_per_group > tb_cap) {
-          ctx->err = "read aligner: traceback tile of one pair group exceeds the workspace";
+          ma_set_err(ctx, "read aligner: traceback tile of one pair group exceeds the workspace");
           return MA_ERR_NOMEM;
         }
         u32 const per_group = wave ? 1u : 64u;  // pairs per workgroup

@@ -1,6 +1,7 @@
 // C-ABI entry points of libmicroasm.so (see include/microasm.h).  No CPU fallback: every entry
 // point fails with MA_ERR_NO_DEVICE when there is no HIP device.
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <cstring>
@@ -277,7 +278,7 @@ int process_in_lanes(ma_ctx* ctx, int lanes, const DBatch& d, const ma_gate_out_
   for (auto& t : th) t.join();
   for (int k = 0; k < lanes; ++k) {
     if (rc[k] != MA_OK) {
-      ctx->err = "lane " + std::to_string(k) + ": " + ctx->lanes[k]->err;
+      ma_set_err(ctx, "lane " + std::to_string(k) + ": " + ma_get_err(ctx->lanes[k]));
       return rc[k];
     }
     MA_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->lanes[k]->lane_done, 0));
@@ -400,7 +401,7 @@ int run_copy_ops(ma_ctx* owner, hipStream_t stream, hipStream_t stream2, std::ve
   hipStream_t const st[2] = {stream, stream2 ? stream2 : stream};
   size_t queued = 0;
   static int const dbg_skip = getenv("MA_DEBUG_SKIP_UPLOAD") ? atoi(getenv("MA_DEBUG_SKIP_UPLOAD")) : 0;  // developer experiment:
-  static int dbg_calls = 0;                                                                                // the buffers keep what
+  static std::atomic<int> dbg_calls{0};                                                                                // the buffers keep what
   if (dbg_skip > 0 && ++dbg_calls > dbg_skip) {
     for (size_t g = 0; g < group_end.size(); ++g) group_done(g);
     return MA_OK;
@@ -597,7 +598,7 @@ int lane_compute(ma_ctx* ch, HostJob& job, int k) {
   if (job.upload) {
     job.upload->wait_lane(static_cast<size_t>(k));
     if (job.upload->rc != MA_OK) {
-      ch->err = "upload: " + job.upload->err;
+      ma_set_err(ch, "upload: " + job.upload->err);
       return job.upload->rc;
     }
     d = job.staged[k];
@@ -778,7 +779,7 @@ void lane_worker(ma_ctx* ch, LaneQueue* lq, int k) {
     LaneResult& R = job->res[k];
     R.rc = job->wb[k + 1] > job->wb[k] ? lane_compute(ch, *job, k) : MA_OK;
     if (R.rc != MA_OK) {
-      R.err = ch->err;
+      R.err = ma_get_err(ch);
       (void)hipStreamSynchronize(ch->stream);  // whatever was queued before the error is done before the buffers are reused
     }
     {
@@ -830,7 +831,7 @@ void uploader_loop(ma_ctx* ctx, HostAsync* ha) {
     {
       std::lock_guard<std::mutex> lk(t->mu);
       t->rc = rc;
-      if (rc != MA_OK) t->err = ctx->err;
+      if (rc != MA_OK) t->err = ma_get_err(ctx);
       t->done = true;
     }
     t->cv.notify_all();
@@ -973,7 +974,7 @@ int process_host(ma_ctx* ctx, int lanes, const ma_batch_t* b, const ma_gate_out_
   for (int k = 0; k < lanes; ++k) {
     LaneResult const& R = job->res[k];
     if (R.rc != MA_OK && rc == MA_OK) {
-      ctx->err = "lane " + std::to_string(k) + ": " + R.err;
+      ma_set_err(ctx, "lane " + std::to_string(k) + ": " + R.err);
       rc = R.rc;
     }
     ha->times.insert(ha->times.end(), R.times.begin(), R.times.end());
@@ -1082,7 +1083,13 @@ void ma_destroy(ma_ctx_t* ctx) {
   delete ctx;
 }
 
-const char* ma_last_error(const ma_ctx_t* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+const char* ma_last_error(const ma_ctx_t* ctx) {
+  if (!ctx) return "null context";
+  // a copy per calling thread: the context's string may be rewritten by a worker thread while the caller reads it
+  static thread_local std::string copy;
+  copy = ma_get_err(const_cast<ma_ctx_t*>(ctx));
+  return copy.c_str();
+}
 
 int ma_set_stream(ma_ctx_t* ctx, void* s) {
   if (!ctx) return MA_ERR_ARG;
@@ -1309,7 +1316,7 @@ int ma_prefetch_batch(ma_ctx_t* ctx, const ma_batch_t* next) {
     }
     int const rc = stage_lane_inputs(ctx->lanes[k], set, next, wb[k], wb[k + 1], &task->ops, &pv.d[set][k]);
     if (rc != MA_OK) {
-      ctx->err = "prefetch, lane " + std::to_string(k) + ": " + ctx->lanes[k]->err;
+      ma_set_err(ctx, "prefetch, lane " + std::to_string(k) + ": " + ma_get_err(ctx->lanes[k]));
       return rc;
     }
     task->lane_end.push_back(task->ops.size());

@@ -1836,7 +1836,7 @@ int run_build_pass(ma_ctx* ctx, const DBatch& b, GraphWs& ws, u32* counters_dev,
   u32 const tile_cap = (64 * ws.max_read_len + 32 + 15) & ~15u;
   size_t const lds_c = ((ws.max_ref_len + 8 + 15) & ~15u) + 2048 + 2ull * tile_cap + 4ull * 64 * classify_mask_words(ws.max_read_len) + 64;
   if (lds_c > 160 * 1024) {
-    ctx->err = "ma_assemble_batch: reads too long for the LDS-staged classifier";
+    ma_set_err(ctx, "ma_assemble_batch: reads too long for the LDS-staged classifier");
     return MA_ERR_PARAM;
   }
   if (lds_c > 65536)

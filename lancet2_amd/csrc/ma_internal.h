@@ -5,6 +5,7 @@
 
 #include <cstdint>
 #include <cstdio>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -68,7 +69,8 @@ struct ma_ctx {
   int memspace = MA_MEM_HOST;
   hipStream_t stream = nullptr;
   hipStream_t own_stream = nullptr;  // created by ma_create (non-blocking); `stream` points here until ma_set_stream
-  std::string err;
+  std::string err;     // last error: written through ma_set_err (worker threads of the host route write it too)
+  std::mutex err_mu;
   // staging for MA_MEM_HOST
   ma::DevBuf in_stage[10];
   std::vector<ma::DevBuf> out_stage;
@@ -120,11 +122,21 @@ struct ma_ctx {
   void toc();
 };
 
+// the error string of a context is shared by the caller's thread, the uploader and the lane workers of the host route
+inline void ma_set_err(ma_ctx* c, std::string m) {
+  std::lock_guard<std::mutex> g(c->err_mu);
+  c->err = std::move(m);
+}
+inline std::string ma_get_err(ma_ctx* c) {
+  std::lock_guard<std::mutex> g(c->err_mu);
+  return c->err;
+}
+
 #define MA_HIP(ctx, call)                                                              \
   do {                                                                                 \
     hipError_t _e = (call);                                                            \
     if (_e != hipSuccess) {                                                            \
-      (ctx)->err = std::string(#call) + ": " + hipGetErrorString(_e);                  \
+      ma_set_err((ctx), std::string(#call) + ": " + hipGetErrorString(_e));             \
       return MA_ERR_HIP;                                                               \
     }                                                                                  \
   } while (0)

@@ -2477,6 +2477,7 @@ __global__ __launch_bounds__(kT, 2) void k_msa(MsaArgs A) {
             ST.pending = 1;
             ST.filled = 0;
             atomicAdd(ws.pending_ctr, 1u);
+            atomicAdd(ws.pending_ctr + 1, 1u);  // ... at a RETRIED tier: worth a band round of its own (see launch_msa)
             ST.nvars = nvars;
             ST.pool = pool;
             ST.var_overflow = overflow ? 1u : 0u;
@@ -2981,11 +2982,11 @@ int launch_msa(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& a, const ma_var
   if (n == 0) return MA_OK;
   ma_params_t const& P = ctx->prm;
   if (P.max_haps > 16) {
-    ctx->err = "ma_msa_batch: max_haps > 16 not supported (16-bit haplotype label masks)";
+    ma_set_err(ctx, "ma_msa_batch: max_haps > 16 not supported (16-bit haplotype label masks)");
     return MA_ERR_PARAM;
   }
   if (P.max_hap_len > 4096) {
-    ctx->err = "ma_msa_batch: max_hap_len > 4096 not supported (256 lanes x 16 columns)";
+    ma_set_err(ctx, "ma_msa_batch: max_hap_len > 4096 not supported (256 lanes x 16 columns)");
     return MA_ERR_PARAM;
   }
   PoaWs ws{};
@@ -3021,7 +3022,7 @@ int launch_msa(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& a, const ma_var
   while (poa_lds_bytes(pn, max_len) > 159 * 1024 && pn > max_len + 32) pn -= 8;
   size_t const lds = poa_lds_bytes(pn, max_len);
   if (lds > 160 * 1024) {
-    ctx->err = "ma_msa_batch: haplotypes too long for the LDS-resident POA graph";
+    ma_set_err(ctx, "ma_msa_batch: haplotypes too long for the LDS-resident POA graph");
     return MA_ERR_PARAM;
   }
   ws.pn = pn;
@@ -3044,6 +3045,7 @@ int launch_msa(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& a, const ma_var
   // split mode: a band round is launched while at least this many windows wait for a fill; fewer finish inside k_msa
   u32 const min_pending = getenv("MA_POA_MIN_PENDING") ? static_cast<u32>(atoi(getenv("MA_POA_MIN_PENDING"))) : 256u;
   bool const verbose = getenv("MA_VERBOSE") != nullptr;
+  bool const no_retry_rounds = getenv("MA_POA_NO_RETRY_ROUNDS") != nullptr;  // (A/B: round 3's rule)
   ws.img_words = static_cast<u32>((lds + 3) / 4);
   ws.code_cells = (static_cast<size_t>(pn + 2) * (max_len + 16) + 7) & ~size_t(7);
   if (ws.code_cells * 2 < static_cast<size_t>(P.max_haps) * (2 * max_len + 8) + 64)  // raw-allele scratch lives in the codes
@@ -3100,12 +3102,17 @@ int launch_msa(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& a, const ma_var
         ctx->tic("k_msa");
         hipLaunchKernelGGL(kern, dim3(nwin), dim3(kT), lds, ctx->stream, args);
         ctx->toc();
-        u32 pending = 0;
-        MA_HIP(ctx, hipMemcpyAsync(&pending, ws.pending_ctr, 4, hipMemcpyDeviceToHost, ctx->stream));
-        MA_HIP(ctx, hipMemsetAsync(ws.pending_ctr, 0, 4, ctx->stream));
+        u32 pend2[2] = {0, 0};
+        MA_HIP(ctx, hipMemcpyAsync(pend2, ws.pending_ctr, 8, hipMemcpyDeviceToHost, ctx->stream));
+        MA_HIP(ctx, hipMemsetAsync(ws.pending_ctr, 0, 8, ctx->stream));
         MA_HIP(ctx, ma_stream_sync(ctx));
+        u32 const pending = pend2[0], pending_retry = pend2[1];
         if (pending == 0) break;
-        if (pending < min_pending || r + 1 >= max_rounds) {
+        // Few windows left: finish them inside k_msa -- unless some of them wait at a RETRIED tier (their 128-column fill
+        // failed its certificate: long indels, e.g. the 30-80 base duplications that only assemble further up the k ladder).
+        // In-kernel those cost a 256-column fill on one wavefront, or the row-synchronous full fill, per window in turn
+        // (12 ms for the slowest window of the ladder workload); a band round costs ~1 ms however few windows it holds.
+        if ((pending < min_pending && (pending_retry == 0 || no_retry_rounds)) || r + 1 >= max_rounds) {
           args.round = r + 1;
           args.finish = 1;
           ctx->tic("k_msa");

@@ -15,9 +15,10 @@ from lancet2_amd.engine import Engine  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("n", nargs="?", type=int, default=2048)
 ap.add_argument("--str-every", type=int, default=8)
+ap.add_argument("--cascade", action="store_true", help="the reference default ladder k = 13 ... 127 instead of k = 25")
 a = ap.parse_args()
 arrs, n, nr = bench.make_windows("C3", a.n, 10_000, a.str_every, 8)
-eng = Engine(capi.default_params(min_k=25, max_k=25))
+eng = Engine(capi.default_params() if a.cascade else capi.default_params(min_k=25, max_k=25))
 eng.set_streams(1)
 g, asm, v, q = eng.process(arrs, n, nr, debug=False)
 eng.timing_control(1)
