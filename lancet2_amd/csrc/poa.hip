@@ -70,6 +70,7 @@ struct PoaWs {
   u32 row_slots;     // stored rows per window
   u32 use_band;      // try the banded fills first (see launch_msa: MA_POA_BAND)
   u32 tier0;         // columns per lane of the first band tier: 1 / 2 / 4 = 64 / 128 / 256 columns (MA_POA_TIER0)
+  u32 no_wide_start; // (A/B) every alignment starts at tier0, whatever its length
   u32* tier_stats;   // [8] fills per tier 64/128/256 + (at 4) failed certificates per tier; null unless MA_VERBOSE
   u32* pending_ctr;  // split mode: windows that yielded in the current k_msa launch
   u32 no_direct;     // MA_POA_NO_DIRECT: every alignment goes through a fill (tests: the shortcut changes nothing)
@@ -2158,7 +2159,13 @@ __global__ __launch_bounds__(kT, 2) void k_msa(MsaArgs A) {
               ST.V = V;
               ST.cw = cw;
               // first band tier (columns per lane: 64 / 128 / 256 columns), 0 = full fill only
-              u32 const t0 = ws.tier0;
+              // a haplotype that is much longer or shorter than the component's backbone (its first sequence, the REF
+              // anchor) carries an indel of at least that size: the 128-column band cannot hold its path, so it starts at the
+              // 256-column tier instead of failing the narrow certificate first (a round, i.e. a fill's latency, saved;
+              // the tiers are exact, the result is the same)
+              u32 const Lref = A.a.hap_len[static_cast<size_t>(w) * MH + hap0];
+              u32 const dl = L > Lref ? L - Lref : Lref - L;
+              u32 const t0 = (ws.tier0 < 4u && dl > 48u && !ws.no_wide_start) ? 4u : ws.tier0;
               ST.band = (ws.use_band && L >= 400 && static_cast<size_t>(V + 1) * 256 <= ws.code_cells) ? t0 : 0u;
             }
           }
@@ -3041,6 +3048,7 @@ int launch_msa(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& a, const ma_var
   {
     int const t0 = getenv("MA_POA_TIER0") ? atoi(getenv("MA_POA_TIER0")) : MA_POA_TIER0;
     ws.tier0 = (t0 == 1 || t0 == 2) ? static_cast<u32>(t0) : 4u;
+    ws.no_wide_start = getenv("MA_POA_NO_WIDE_START") ? 1u : 0u;
   }
   // split mode: a band round is launched while at least this many windows wait for a fill; fewer finish inside k_msa
   u32 const min_pending = getenv("MA_POA_MIN_PENDING") ? static_cast<u32>(atoi(getenv("MA_POA_MIN_PENDING"))) : 256u;
@@ -3125,11 +3133,11 @@ int launch_msa(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& a, const ma_var
         if (ws.lean) {
           if (ws.tier0 == 1) band(k_msa_band<1, true>);
           else if (ws.tier0 == 2) band(k_msa_band<2, true>);
-          if (ws.tier0 == 4 || r > 0) band(k_msa_band<4, true>);
+          band(k_msa_band<4, true>);  // (retried fills, and haplotypes that start wide)
         } else {
           if (ws.tier0 == 1) band(k_msa_band<1, false>);
           else if (ws.tier0 == 2) band(k_msa_band<2, false>);
-          if (ws.tier0 == 4 || r > 0) band(k_msa_band<4, false>);
+          band(k_msa_band<4, false>);
         }
         ctx->toc();
       }
