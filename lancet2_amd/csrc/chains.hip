@@ -56,6 +56,7 @@ struct ChainArgs {
   u32 xe_cap;   // nodes with three or four edges
   u32 seg_cap;  // segments per window (even)
   u32 cl_cap;   // compact nodes the alive list holds (even)
+  u32 stop;     // (developer A/B) leave after phase `stop`: the window then takes the raw route; 0 = run to the end
 };
 
 struct Lds {
@@ -153,6 +154,7 @@ __device__ unsigned long long g_chprof[16];
     unsigned long long const _t1 = __builtin_amdgcn_s_memtime();          \
     if (threadIdx.x == 0) atomicAdd(&g_chprof[slot], _t1 - _t0);          \
     _t0 = _t1;                                                            \
+    if (A.stop == (slot) + 1u) return;                                    \
   } while (0)
 #define CH_SUB0() unsigned long long _s0 = __builtin_amdgcn_s_memtime()
 #define CH_SUB(slot)                                                      \
@@ -163,7 +165,7 @@ __device__ unsigned long long g_chprof[16];
   } while (0)
 #else
 #define CH_T0() do {} while (0)
-#define CH_ACC(slot) do {} while (0)
+#define CH_ACC(slot) do { if (A.stop == (slot) + 1u) return; } while (0)
 #define CH_SUB0() do {} while (0)
 #define CH_SUB(slot) do {} while (0)
 #endif
@@ -749,17 +751,27 @@ __global__ __launch_bounds__(kT) void k_clean_chains(ChainArgs A) {
           u32 ids[8], av[8];
 #pragma unroll
           for (i32 q = 0; q < 8; ++q) ids[q] = L.p2n[pb + (c0 + q) * dir];
+          float rr[8];
 #pragma unroll
           for (i32 q = 0; q < 8; ++q) {
-            av[q] = vlane ? val[ids[q] * VS + v] : 0u;
+            av[q] = __umul24(vlane ? val[ids[q] * VS + v] : 0u, K);  // the absorbed k-mer's share of the numerator
             lab |= L.fl[ids[q]];  // (label bits picked out once the turn is over)
+            rr[q] = __builtin_amdgcn_rcpf(static_cast<float>(len_a + static_cast<u32>(q) + 1u + K));
           }
           if (v == 0) {
 #pragma unroll
             for (i32 q = 0; q < 8; ++q) L.abs[ids[q]] = static_cast<u16>(walker);
           }
+          // the serial chain: multiply-add, estimate, remainder, fix-up -- nothing else depends on the running average
 #pragma unroll
-          for (i32 q = 0; q < 8; ++q) step1(av[q]);
+          for (i32 q = 0; q < 8; ++q) {
+            len_a += 1u;
+            u32 const den = len_a + K, num = __umul24(s, len_a) + av[q];
+            u32 qq = static_cast<u32>(static_cast<float>(num) * rr[q]);
+            i32 const rem = static_cast<i32>(num - __umul24(qq, den));
+            qq += rem < 0 ? 0xFFFFFFFFu : (static_cast<u32>(rem) >= den ? 1u : 0u);
+            s = qq;
+          }
         }
         for (; c0 < cnt; ++c0) {
           u32 const id = L.p2n[pb + c0 * dir];
@@ -1146,7 +1158,8 @@ int run_clean_chains(ma_ctx* ctx, const DBatch& b, const GraphWs& ws, const ma_p
   u32 lo = 0;
   for (int l = 0; l < 3; ++l) {
     if (caps[l] <= lo || lds_bytes(caps[l]) > 160 * 1024) continue;
-    ChainArgs args{b, ws, prm, caps[l], lo, xw, caps[l] <= 1472u ? 64u : caps[l] / 8u, caps[l] <= 1472u ? 256u : caps[l] / 4u, caps[l] <= 1472u ? 256u : caps[l] / 4u};
+    ChainArgs args{b, ws, prm, caps[l], lo, xw, caps[l] <= 1472u ? 64u : caps[l] / 8u, caps[l] <= 1472u ? 256u : caps[l] / 4u, caps[l] <= 1472u ? 256u : caps[l] / 4u,
+                   getenv("MA_CHAINS_STOP") ? static_cast<u32>(atoi(getenv("MA_CHAINS_STOP"))) : 0u};
     ctx->tic("k_clean_chains");
     hipLaunchKernelGGL(k_clean_chains, dim3(ws.n_active), dim3(kT), lds_bytes(caps[l]), ctx->stream, args);
     ctx->toc();
