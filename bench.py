@@ -714,8 +714,9 @@ def main():
             also["other_config"] = device_leg(also_arrs, WORKLOADS[other])
         if long_arrs is not None:
             also["reads_2x250"] = device_leg(long_arrs, WORKLOADS[args.config] + " -- sequenced as 2 x 250 bp reads")
-        if c4_arrs is not None:  # every window distinct (no tiling): 7.6 k reads a window
-            also["c4_panel"] = device_leg(c4_arrs, WORKLOADS["C4"], max_windows=c4_arrs[1], kernels=True)
+        if c4_arrs is not None:  # 7.1 k reads a window; a panel has ~10 k windows: 2048 per step (512 distinct, tiled)
+            also["c4_panel"] = device_leg(c4_arrs, WORKLOADS["C4"], max_windows=max(c4_arrs[1], 2048), kernels=True)
+            also["c4_panel_512"] = device_leg(c4_arrs, WORKLOADS["C4"] + " -- 512 windows per step, every one distinct", max_windows=c4_arrs[1])
         if c5_arrs is not None:
             p5 = capi.default_params(min_k=25, max_k=25)
             p5.num_samples = 3
