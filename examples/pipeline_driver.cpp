@@ -270,7 +270,7 @@ int main(int argc, char** argv) {
   struct Slot {
     std::atomic<int> ready{0};
     WindowStatus st = WindowStatus::RUN;
-    ReadCollector::Result rc;
+    std::unique_ptr<FlatBatch> flat;  // the window's reads as the batch holds them (flattened on the collector's thread)
   };
   std::vector<Slot> slots(windows.size());
   std::atomic<size_t> next_window{0}, consumed{0};
@@ -300,8 +300,13 @@ int main(int argc, char** argv) {
         Slot& sl = slots[i];
         sl.st = PreReadGate(seq, prm.max_k, no_active_region, collector.Samples(), w);
         if (sl.st == WindowStatus::RUN) {
-          sl.rc = collector.CollectRegion(w);
-          if (CrossSampleMeanCoverage(sl.rc.samples, w.Length()) < static_cast<double>(prm.min_anchor_cov)) sl.st = WindowStatus::SKIPPED_ANCHOR_COVERAGE;
+          ReadCollector::Result const rc = collector.CollectRegion(w);
+          if (CrossSampleMeanCoverage(rc.samples, w.Length()) < static_cast<double>(prm.min_anchor_cov)) {
+            sl.st = WindowStatus::SKIPPED_ANCHOR_COVERAGE;
+          } else {
+            sl.flat = std::make_unique<FlatBatch>();
+            sl.flat->Add(w, seq, rc.reads, &rc.samples);
+          }
         }
         worker_busy[static_cast<size_t>(t)] += secs(Clock::now() - t0);
         sl.ready.store(1, std::memory_order_release);
@@ -331,14 +336,12 @@ int main(int argc, char** argv) {
       Slot& sl = slots[i];
       while (!sl.ready.load(std::memory_order_acquire)) std::this_thread::sleep_for(std::chrono::microseconds(50));  // (no spinning: the collectors need the cores)
       auto const t0 = Clock::now();
-      Window const& w = windows[i];
       n_skipped[static_cast<int>(sl.st)]++;
       if (sl.st == WindowStatus::RUN) {
-        std::string_view const seq(ref.chroms[static_cast<size_t>(w.chrom)].seq.data() + (w.start1 - 1), w.Length());
-        cur.batch->Add(w, seq, sl.rc.reads, &sl.rc.samples);
+        cur.batch->Append(*sl.flat);
         n_shipped++;
       }
-      sl.rc = ReadCollector::Result();  // release the reads
+      sl.flat.reset();
       consumed.store(i + 1, std::memory_order_release);
       busy_extract += secs(Clock::now() - t0);
       if (static_cast<int>(cur.batch->windows.size()) >= batch_windows) ship();

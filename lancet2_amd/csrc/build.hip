@@ -226,6 +226,7 @@ __device__ __forceinline__ bool canon_plus(const u8* s, int k) {
 constexpr int kMaskWords = 10;  // fast-path bitmask covers reads with <= 320 k-mers
 constexpr u32 kMmLdsCap = 32768;              // entries of the LDS mate-mer set of k_mm_lds
 constexpr u32 kMmLdsMax = kMmLdsCap * 7 / 8;  // general instances per window it accepts (distinct keys are fewer)
+constexpr u32 kMmRunMax = 32;  // longest run of one (qname, role) in a window that k_mm_lds takes in chunks
 
 struct BuildLds {
   u8* ref;        // [max_ref_len + 8]
@@ -944,7 +945,7 @@ constexpr u32 kSupCache = 2048;  // reads per window whose records k_support kee
 // the counters and the cache need (40 KB: four workgroups, 32 waves per CU; with the old mapping's mask area it was 48 KB
 // and, at four waves each, 12 waves per CU)
 constexpr int kSupT = 512;
-__global__ __launch_bounds__(kSupT) void k_support(DBatch b, GraphWs ws, u32* max_gen, u32 cache_cap) {
+__global__ __launch_bounds__(kSupT) void k_support(DBatch b, GraphWs ws, u32* max_gen, u32 cache_cap, u32 xs_log2) {
   extern __shared__ unsigned char lds_build[];
   __shared__ u32 xs_flag;
   __shared__ u32 gen_count;  // instances routed through the general mate-mer set (sizes that set)
@@ -963,12 +964,14 @@ __global__ __launch_bounds__(kSupT) void k_support(DBatch b, GraphWs ws, u32* ma
   off += 4u * ws.ref_stride * CW;
   u32* l_mask = reinterpret_cast<u32*>(lds_build + off);
   off += 4u * (ws.max_reads + 2u);  // (the group leaders)
+  // (qname, role) table of check (X): a power of two above the busiest window's read count (1024 entries up to 1022 reads)
+  u32 const xs_cap = 1u << xs_log2, xs_shift = 32u - xs_log2;
   u32* l_xkey = reinterpret_cast<u32*>(lds_build + off);
-  off += 4u * kXs;
+  off += 4u * xs_cap;
   u32* l_xgrp = reinterpret_cast<u32*>(lds_build + off);
-  off += 4u * kXs;
+  off += 4u * xs_cap;
   u8* l_xsmp = lds_build + off;
-  off = (off + kXs + 15u) & ~15u;
+  off = (off + xs_cap + 15u) & ~15u;
   // Per-sequence records for the group loop below (it was 95 % of this kernel: every group re-read flags, names, samples,
   // offsets, hints and instance bases of its reads from HBM, ten dependent round trips per group).
   //   c_meta: flags (bits 0-2) | general-path-hit flag of k_insert (bit 3) | sample << 8 | k-mer count << 16
@@ -979,7 +982,7 @@ __global__ __launch_bounds__(kSupT) void k_support(DBatch b, GraphWs ws, u32* ma
   bool const cached = cache_cap != 0 && ns <= cache_cap;
   SeqInfo const rsi = seq_info(b, w, 0, k);
   for (u32 i = threadIdx.x; i < ws.ref_stride * CW; i += kSupT) l_cnt[i] = 0;
-  for (u32 i = threadIdx.x; i < kXs; i += kSupT) {
+  for (u32 i = threadIdx.x; i < xs_cap; i += kSupT) {
     l_xkey[i] = 0;
     l_xgrp[i] = 0;
   }
@@ -1006,9 +1009,9 @@ __global__ __launch_bounds__(kSupT) void k_support(DBatch b, GraphWs ws, u32* ma
       u32 const r = b.read_win_off[w] + s_idx - 1;
       if (!(b.read_flags[r] & MA_RF_PASS)) continue;
       u32 const key = ((b.read_qname_id[r] << 1) | ((b.read_flags[r] & MA_RF_CASE) ? 1u : 0u)) + 1u;
-      u32 h = (key * 2654435761u) >> 22;  // kXs == 1024
+      u32 h = (key * 2654435761u) >> xs_shift;
       bool done = false;
-      for (u32 probe = 0; probe < kXs && !done; ++probe) {
+      for (u32 probe = 0; probe < xs_cap && !done; ++probe) {
         u32 cur = l_xkey[h];
         if (cur == 0) {
           u32 const old = atomicCAS(&l_xkey[h], 0u, key);
@@ -1019,7 +1022,7 @@ __global__ __launch_bounds__(kSupT) void k_support(DBatch b, GraphWs ws, u32* ma
           }
           cur = old;
         }
-        if (cur == key) done = true; else h = (h + 1) & (kXs - 1);
+        if (cur == key) done = true; else h = (h + 1) & (xs_cap - 1);
       }
       if (!done) xs_flag = 1;  // table full: be conservative
     }
@@ -1031,8 +1034,8 @@ __global__ __launch_bounds__(kSupT) void k_support(DBatch b, GraphWs ws, u32* ma
       if (!(b.read_flags[r] & MA_RF_PASS)) continue;
       bool const leader = !(s_idx > 1 && same_group(b, r, r - 1));
       u32 const key = ((b.read_qname_id[r] << 1) | ((b.read_flags[r] & MA_RF_CASE) ? 1u : 0u)) + 1u;
-      u32 h = (key * 2654435761u) >> 22;
-      for (u32 probe = 0; probe < kXs; ++probe) {
+      u32 h = (key * 2654435761u) >> xs_shift;
+      for (u32 probe = 0; probe < xs_cap; ++probe) {
         u32 const cur = l_xkey[h];
         if (cur == key) {
           if (l_xsmp[h] != b.read_sample[r]) xs_flag = 1;
@@ -1040,8 +1043,18 @@ __global__ __launch_bounds__(kSupT) void k_support(DBatch b, GraphWs ws, u32* ma
           break;
         }
         if (cur == 0) break;
-        h = (h + 1) & (kXs - 1);
+        h = (h + 1) & (xs_cap - 1);
       }
+    }
+  }
+  // (k_mm_lds takes a window of more than kSeqCap sequences in chunks cut between two runs of one (qname, role): no run
+  //  may be longer than kMmRunMax there -- same adjacency test as its leader walk)
+  if (hints && ns > kSeqCap) {
+    for (u32 s_idx = 1 + kMmRunMax + threadIdx.x; s_idx < ns; s_idx += kSupT) {
+      u32 const r = b.read_win_off[w] + s_idx - 1;
+      u32 j = 0;
+      while (j < kMmRunMax && same_group(b, r - j, r - j - 1)) ++j;
+      if (j == kMmRunMax) xs_flag = 1;
     }
   }
   __syncthreads();
@@ -1175,7 +1188,8 @@ __global__ __launch_bounds__(kSupT) void k_support(DBatch b, GraphWs ws, u32* ma
   if (threadIdx.x == 0) {
     // Windows whose (qname, role) keys each map to ONE run of adjacent reads (xs_flag == 0) and whose general
     // instances fit the LDS set are finished by k_mm_lds; the others need the HBM-resident set (max_gen[1]).
-    bool const lds_ok = !all_generic && ns <= kSeqCap && gen_count <= 4u * kMmLdsMax && ws.tc_log2 <= 20;  // <= 4 passes
+    // (up to four passes over the set for a window that fits the LDS tables; a deeper one goes chunk by chunk)
+    bool const lds_ok = !all_generic && (ns > kSeqCap || gen_count <= 4u * kMmLdsMax) && ws.tc_log2 <= 20;
     ws.mm_mode[a] = gen_count | (lds_ok ? 0u : 0x80000000u);
     atomicMax(max_gen, gen_count);
     if (!lds_ok) atomicMax(max_gen + 1, gen_count);
@@ -1316,36 +1330,70 @@ __global__ __launch_bounds__(kMmT) void k_mm_lds(DBatch b, GraphWs ws) {
   u32 const r_base = b.read_win_off[w];
   // Windows with more general instances than one set holds (deep samples) take several passes, pass p handling the
   // table slots with slot % npass == p: every key lives in exactly one pass, so each pass is complete in itself.
-  u32 const npass = (mode + kMmLdsMax - 1u) / kMmLdsMax;
+  // Windows with more sequences than the LDS tables hold (deep panels: 7 k reads) go through them in CHUNKS of up to
+  // kSeqCap - 1 consecutive sequences cut between two runs: a key names its run's leader, so the keys of two chunks are
+  // disjoint and every chunk is complete in itself as well (k_support: no run longer than kMmRunMax in such a window).
+  __shared__ u32 l_chunk[4];  // s_lo, s_hi of the chunk, its general instances
+  u32 const ninst = ws.win_ninst[w], nref = ninst - ws.win_nread_inst[w];
+  bool const chunked = ns > kSeqCap;
   IPROF_T0();
+  for (u32 s_lo = 0; s_lo < ns;) {
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    u32 e = ns;
+    if (chunked) {
+      e = min(s_lo + kSeqCap - 1u - kMmRunMax, ns);
+      while (e < ns && same_group(b, r_base + e - 1, r_base + e - 2)) ++e;  // (e >= 2 here)
+    }
+    l_chunk[0] = e;
+    l_chunk[1] = 0;
+  }
+  __syncthreads();
+  u32 const s_hi = l_chunk[0], nsc = s_hi - s_lo, s_one = max(s_lo, 1u);
+  u32 const i_lo = s_lo == 0 ? 0u : ws.seq_inst_base[base_idx + s_lo];
+  u32 const i_hi = s_hi < ns ? ws.seq_inst_base[base_idx + s_hi] : ninst;
+  u32 cgen = mode;
+  if (chunked) {  // the chunk's general instances (sizes its passes)
+    u32 mine = 0;
+    for (u32 ii = max(i_lo, nref) + threadIdx.x; ii < i_hi; ii += kMmT)
+      mine += (inst_slot[ii] & (kInstErrFree | kInstGen)) == (kInstErrFree | kInstGen);
+    for (u32 o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o, 64);
+    if ((threadIdx.x & 63u) == 0 && mine) atomicAdd(&l_chunk[1], mine);
+    __syncthreads();
+    cgen = l_chunk[1];
+  }
+  u32 const npass = (cgen + kMmLdsMax - 1u) / kMmLdsMax;
   for (u32 pass = 0; pass < npass; ++pass) {
   __syncthreads();
   for (u32 i = threadIdx.x; i < kMmLdsCap; i += kMmT) l_set[i] = 0;
-  for (u32 s = threadIdx.x; s < ns; s += kMmT) {
-    l_base[s] = ws.seq_inst_base[base_idx + s];
+  for (u32 sr = threadIdx.x; sr < nsc; sr += kMmT) {
+    u32 const s = s_lo + sr;
+    l_base[sr] = ws.seq_inst_base[base_idx + s];
     u32 lead = s;  // sequence s >= 1 is read r_base + s - 1; its run's leader
-    while (lead > 1 && same_group(b, r_base + lead - 1, r_base + lead - 2)) --lead;
-    l_lead[s] = static_cast<u16>(lead);
+    while (lead > s_one && same_group(b, r_base + lead - 1, r_base + lead - 2)) --lead;
+    l_lead[sr] = static_cast<u16>(lead - min(lead, s_one));  // relative to the chunk's first read
   }
   __syncthreads();
-  bool const blk_ok = ws.win_ninst[w] <= (kBlkCap << kBlkShift);
+  u32 blk_shift = kBlkShift;
+  while (blk_shift < 10 && i_hi - i_lo > (kBlkCap << blk_shift)) ++blk_shift;  // (a chunk of 2 k reads: 258 k instances)
+  bool const blk_ok = i_hi - i_lo <= (kBlkCap << blk_shift);
   if (blk_ok && pass == 0)
-    for (u32 bk = threadIdx.x; (bk << kBlkShift) < ws.win_ninst[w]; bk += kMmT) l_blk[bk] = static_cast<u16>(seq_of(l_base, ns, bk << kBlkShift));
+    for (u32 bk = threadIdx.x; (bk << blk_shift) < i_hi - i_lo; bk += kMmT)
+      l_blk[bk] = static_cast<u16>(seq_of(l_base, nsc, i_lo + (bk << blk_shift)));
   __syncthreads();
   IPROF(12);  // set init, instance bases, run leaders
-  u32 const ninst = ws.win_ninst[w], nref = ninst - ws.win_nread_inst[w];
   // (qname, role, node) of one general instance -> set
   auto const visit_slot = [&](u32 ii, u32 nslot) {
     u32 sq;
     if (blk_ok) {
-      sq = l_blk[ii >> kBlkShift];
-      while (sq + 1 < ns && l_base[sq + 1] <= ii) ++sq;
+      sq = l_blk[(ii - i_lo) >> blk_shift];
+      while (sq + 1 < nsc && l_base[sq + 1] <= ii) ++sq;
     } else {
-      sq = seq_of(l_base, ns, ii);
+      sq = seq_of(l_base, nsc, ii);
     }
     u32 const lead = l_lead[sq];
     if (npass > 1 && nslot % npass != pass) return;
-    u32 const key = ((nslot << 11) | (lead - 1)) + 1u;
+    u32 const key = ((nslot << 11) | lead) + 1u;
     u32 h = (key * 2654435761u) >> 17;  // kMmLdsCap == 1 << 15
     for (u32 probe = 0; probe < kMmLdsCap; ++probe) {
       u32 cur = l_set[h];
@@ -1365,10 +1413,10 @@ __global__ __launch_bounds__(kMmT) void k_mm_lds(DBatch b, GraphWs ws) {
   constexpr int kU = 4;           // independent loads in flight per thread
   constexpr u32 kChunk = kMmT * 16;
   u32 const lane = threadIdx.x & 63u;
-  for (u32 c0 = nref; c0 < ninst; c0 += kChunk) {
+  for (u32 c0 = max(i_lo, nref); c0 < i_hi; c0 += kChunk) {
     if (threadIdx.x == 0) l_qn = 0;
     __syncthreads();
-    u32 const c1 = min(c0 + kChunk, ninst);
+    u32 const c1 = min(c0 + kChunk, i_hi);
     for (u32 i0 = c0 + threadIdx.x; i0 < c1 + kMmT * kU; i0 += kMmT * kU) {  // whole wavefronts reach the ballots
       u32 v[kU];
 #pragma unroll
@@ -1467,7 +1515,7 @@ __global__ __launch_bounds__(kMmT) void k_mm_lds(DBatch b, GraphWs ws) {
       u32 const key = l_set[i];
       u32 const nslot = (key - 1u) >> 11;
       if (nslot < s0 || nslot - s0 >= slots_per_pass) continue;
-      u32 const r = r_base + ((key - 1u) & 2047u);
+      u32 const r = r_base + s_one - 1u + ((key - 1u) & 2047u);
       u32 sample = b.read_sample[r];
       if (sample >= static_cast<u32>(S)) sample = S - 1;
       u32 const role = (b.read_flags[r] & MA_RF_CASE) ? 1u : 0u;
@@ -1485,6 +1533,8 @@ __global__ __launch_bounds__(kMmT) void k_mm_lds(DBatch b, GraphWs ws) {
   }
   IPROF(15);  // support counters
   }  // pass
+  s_lo = s_hi;
+  }  // chunk
 }
 
 // low-coverage pruning (graph.cpp:363-390 with component 0 == everything, no anchors yet) and
@@ -1859,14 +1909,19 @@ int run_build_pass(ma_ctx* ctx, const DBatch& b, GraphWs& ws, u32* counters_dev,
   ctx->toc();
   // + per-sequence cache (16 B per read of the busiest window, when that is at most kSupCache reads)
   u32 const sup_cache = ws.max_reads + 2 <= kSupCache ? ws.max_reads + 2 : 0u;
-  size_t const lds_s = 4ull * ws.ref_stride * (S + 2) + 4ull * (ws.max_reads + 2) + 8ull * kXs + kXs + 64 +
-                       16ull * sup_cache + 16;
+  u32 xs_log2 = 10;  // check (X)'s table: above the busiest window's read count (every read could bring a name of its own)
+  while ((1u << xs_log2) < ws.max_reads + 2 && xs_log2 < 14) ++xs_log2;
+  auto const sup_lds = [&](u32 lg) {
+    return 4ull * ws.ref_stride * (S + 2) + 4ull * (ws.max_reads + 2) + 9ull * (size_t(1) << lg) + 64 + 16ull * sup_cache + 16;
+  };
+  while (xs_log2 > 10 && sup_lds(xs_log2) > 159u * 1024u) --xs_log2;  // (a table that fills up sends the window down the general route)
+  size_t const lds_s = sup_lds(xs_log2);
   if (lds_s > 65536)
     MA_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_support), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     static_cast<int>(lds_s)));
   ctx->tic("k_support");
   MA_HIP(ctx, hipMemsetAsync(counters_dev + 1, 0, 8, ctx->stream));
-  hipLaunchKernelGGL(k_support, dim3(ws.n_active), dim3(kSupT), lds_s, ctx->stream, b, ws, counters_dev + 1, sup_cache);
+  hipLaunchKernelGGL(k_support, dim3(ws.n_active), dim3(kSupT), lds_s, ctx->stream, b, ws, counters_dev + 1, sup_cache, xs_log2);
   ctx->toc();
   // windows whose general instances fit an LDS set are finished by k_mm_lds; the HBM-resident set only has to
   // hold what the remaining windows routed to it (usually nothing)

@@ -2919,8 +2919,10 @@ struct DescView {
 // Split mode: the banded fill (tier CW: 64 CW columns) of every window whose pending alignment is at that tier, one
 // wavefront per window.  Only the state block is staged in LDS (instead of the graph's 77 KB), so a CU holds 16-32
 // windows and the dependent instruction chains of the row recurrence overlap across them.
-template <int CW, bool LEAN>
-__global__ __launch_bounds__(64, CW == 1 ? 8 : (CW == 2 ? 6 : 4)) void k_msa_band(MsaArgs A) {
+// One launch serves every tier: the wavefront takes the tier its window waits at (a launch per tier cost each tier's
+// slowest window in turn -- and a tier with three windows still cost a fill's latency).
+template <bool LEAN>
+__global__ __launch_bounds__(64, 4) void k_msa_band(MsaArgs A) {
   int const lane = threadIdx.x;
   int const lw = blockIdx.x;
   int const w = A.win0 + lw;
@@ -2930,7 +2932,7 @@ __global__ __launch_bounds__(64, CW == 1 ? 8 : (CW == 2 ? 6 : 4)) void k_msa_ban
   u32* const img = reinterpret_cast<u32*>(ws.img) + static_cast<size_t>(lw) * ws.img_words;
   {
     const WgState* pst = reinterpret_cast<const WgState*>(img);
-    if (pst->done || !pst->pending || pst->filled || pst->band != static_cast<u32>(CW)) return;
+    if (pst->done || !pst->pending || pst->filled || pst->band == 0) return;
   }
   u32 const PN = ws.pn;
   GL const full = poa_carve(PN, ws.max_l);
@@ -2960,15 +2962,22 @@ __global__ __launch_bounds__(64, CW == 1 ? 8 : (CW == 2 ? 6 : 4)) void k_msa_ban
   u16* const codes = ws.codes + static_cast<size_t>(lw) * ws.code_cells;
   i32* const rows = ws.rows + static_cast<size_t>(lw) * ws.row_cells;
   i32* const hlast = ws.hlast + static_cast<size_t>(lw) * (PN + 8);
-  if constexpr (LEAN)
-    poa_fill_lean<CW>(g, ws.w_stride, ws.code_cells, codes, rows, hlast, V, L, lane, seq, edge0, kStBytes + 16, &ST.edge_max);
-  else
-    poa_fill_band<CW>(g, ws.w_stride, ws.code_cells, codes, rows, hlast, V, L, lane, seq, &ST.edge_max);
+  u32 const tier = __builtin_amdgcn_readfirstlane(ST.band);
+  auto const fill = [&](auto cw) {
+    constexpr int CW = decltype(cw)::value;
+    if constexpr (LEAN)
+      poa_fill_lean<CW>(g, ws.w_stride, ws.code_cells, codes, rows, hlast, V, L, lane, seq, edge0, kStBytes + 16, &ST.edge_max);
+    else
+      poa_fill_band<CW>(g, ws.w_stride, ws.code_cells, codes, rows, hlast, V, L, lane, seq, &ST.edge_max);
+  };
+  if (tier == 1) fill(std::integral_constant<int, 1>{});
+  else if (tier == 2) fill(std::integral_constant<int, 2>{});
+  else fill(std::integral_constant<int, 4>{});
   __syncthreads();
   if (lane == 0) {
     reinterpret_cast<WgState*>(img)->edge_max = ST.edge_max;
     reinterpret_cast<WgState*>(img)->filled = 1;
-    if (ws.tier_stats) atomicAdd(&ws.tier_stats[CW == 1 ? 0 : (CW == 2 ? 1 : 2)], 1u);
+    if (ws.tier_stats) atomicAdd(&ws.tier_stats[tier == 1 ? 0 : (tier == 2 ? 1 : 2)], 1u);
   }
 }
 
@@ -3130,15 +3139,8 @@ int launch_msa(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& a, const ma_var
         }
         ctx->tic("k_msa_band");
         auto band = [&](auto kfn) { hipLaunchKernelGGL(kfn, dim3(nwin), dim3(64), band_lds, ctx->stream, args); };
-        if (ws.lean) {
-          if (ws.tier0 == 1) band(k_msa_band<1, true>);
-          else if (ws.tier0 == 2) band(k_msa_band<2, true>);
-          band(k_msa_band<4, true>);  // (retried fills, and haplotypes that start wide)
-        } else {
-          if (ws.tier0 == 1) band(k_msa_band<1, false>);
-          else if (ws.tier0 == 2) band(k_msa_band<2, false>);
-          band(k_msa_band<4, false>);
-        }
+        if (ws.lean) band(k_msa_band<true>);  // (first tiers, retried fills and haplotypes that start wide alike)
+        else band(k_msa_band<false>);
         ctx->toc();
       }
     }

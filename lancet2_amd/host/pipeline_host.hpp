@@ -933,9 +933,13 @@ struct FlatBatch {
     ref_bases.insert(ref_bases.end(), ref_seq.begin(), ref_seq.end());
     ref_off.push_back(static_cast<uint32_t>(ref_bases.size()));
     std::unordered_map<std::string_view, uint32_t> names;  // (qname, role) de-duplication needs names only within a window
+    names.reserve(reads.size());
     for (Read const& r : reads) {
       read_bases.insert(read_bases.end(), r.seq.begin(), r.seq.end());
-      for (uint8_t q : r.qual) read_quals.push_back(q == 0xFF ? 0 : q);
+      size_t const q0 = read_quals.size();
+      read_quals.insert(read_quals.end(), r.qual.begin(), r.qual.end());
+      for (size_t q = q0; q < read_quals.size(); ++q)
+        if (read_quals[q] == 0xFF) read_quals[q] = 0;
       read_off.push_back(read_bases.size());
       read_qname_id.push_back(names.emplace(r.qname, static_cast<uint32_t>(names.size())).first->second);
       read_sample.push_back(static_cast<uint8_t>(r.sample_index));
@@ -946,6 +950,24 @@ struct FlatBatch {
       read_hint.push_back(hint > INT32_MIN && hint < INT32_MAX ? static_cast<int32_t>(hint) : MA_NO_HINT);
     }
     read_win_off.push_back(static_cast<uint32_t>(read_qname_id.size()));
+  }
+  // Appends the windows of another (unsealed) batch -- what Add() on their reads would have appended: the extract stage's
+  // workers flatten each window on their own thread, the ordered assembler only copies.
+  void Append(FlatBatch const& o) {
+    uint32_t const rb = static_cast<uint32_t>(ref_bases.size()), nr = static_cast<uint32_t>(read_qname_id.size());
+    uint64_t const qb = read_bases.size();
+    windows.insert(windows.end(), o.windows.begin(), o.windows.end());
+    sample_cov.insert(sample_cov.end(), o.sample_cov.begin(), o.sample_cov.end());
+    ref_bases.insert(ref_bases.end(), o.ref_bases.begin(), o.ref_bases.end());
+    read_bases.insert(read_bases.end(), o.read_bases.begin(), o.read_bases.end());
+    read_quals.insert(read_quals.end(), o.read_quals.begin(), o.read_quals.end());
+    read_sample.insert(read_sample.end(), o.read_sample.begin(), o.read_sample.end());
+    read_flags.insert(read_flags.end(), o.read_flags.begin(), o.read_flags.end());
+    read_qname_id.insert(read_qname_id.end(), o.read_qname_id.begin(), o.read_qname_id.end());
+    read_hint.insert(read_hint.end(), o.read_hint.begin(), o.read_hint.end());
+    for (size_t i = 1; i < o.ref_off.size(); ++i) ref_off.push_back(rb + o.ref_off[i]);
+    for (size_t i = 1; i < o.read_off.size(); ++i) read_off.push_back(qb + o.read_off[i]);
+    for (size_t i = 1; i < o.read_win_off.size(); ++i) read_win_off.push_back(nr + o.read_win_off[i]);
   }
   void Seal() {
     size_t const rb = ref_bases.size(), qb = read_bases.size();
