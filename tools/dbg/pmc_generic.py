@@ -13,6 +13,7 @@ root = sys.argv[1]
 pat = re.compile(sys.argv[2]) if len(sys.argv) > 2 else None
 tot = defaultdict(lambda: defaultdict(float))
 disp = defaultdict(set)
+dur = defaultdict(dict)  # kernel -> dispatch -> ns (when the csv carries the dispatch's timestamps)
 for path in glob.glob(root + "/**/*counter_collection.csv", recursive=True):
     with open(path) as fh:
         for row in csv.DictReader(fh):
@@ -22,6 +23,14 @@ for path in glob.glob(root + "/**/*counter_collection.csv", recursive=True):
                 continue
             tot[name][row["Counter_Name"]] += float(row["Counter_Value"])
             disp[name].add(row["Dispatch_Id"])
+            if row.get("Start_Timestamp") and row.get("End_Timestamp"):
+                dur[name][row["Dispatch_Id"]] = float(row["End_Timestamp"]) - float(row["Start_Timestamp"])
 for name in sorted(tot, key=lambda k: -tot[k].get("SQ_WAVE_CYCLES", 0.0)):
     n = max(len(disp[name]), 1)
-    print(f"{name:20s} launches {n:4d} " + " ".join(f"{c}={v / n:.4g}" for c, v in sorted(tot[name].items())))
+    extra = ""
+    if dur[name]:
+        ns = sum(dur[name].values()) / len(dur[name])
+        extra = f" avg_ms={ns / 1e6:.3f}"
+        if "SQ_BUSY_CU_CYCLES" in tot[name] and ns > 0:  # mean number of CUs with a wave on them while the kernel runs (2.4 GHz)
+            extra += f" busy_CUs={tot[name]['SQ_BUSY_CU_CYCLES'] / n / (ns * 2.4):.1f}"
+    print(f"{name:20s} launches {n:4d} " + " ".join(f"{c}={v / n:.4g}" for c, v in sorted(tot[name].items())) + extra)

@@ -20,7 +20,7 @@ grep -h "^{\"metric\"" $O/pmc_SQ_INSTS_VALU.log | tail -1 > $O/${T}_pmc_bench_un
 python3 tools/dbg/pmc_generic.py $O/pmc_sq > $O/${T}_pmc_sq_per_kernel.txt 2>&1
 # achieved occupancy and L2 hit rate, each in a pass of its own (a pass that asks for too much aborts the profiler)
 cd /tmp
-timeout 600 rocprofv3 --pmc SQ_LEVEL_WAVES SQ_BUSY_CU_CYCLES --kernel-trace --output-format csv -d $O/pmc_occ -- $B > $O/pmc_occ.log 2>&1
+timeout 600 rocprofv3 --pmc SQ_BUSY_CU_CYCLES --kernel-trace --output-format csv -d $O/pmc_occ -- $B > $O/pmc_occ.log 2>&1
 timeout 600 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d $O/pmc_l2 -- $B > $O/pmc_l2.log 2>&1
 cd $R
 python3 tools/dbg/pmc_generic.py $O/pmc_occ > $O/${T}_pmc_occupancy_per_kernel.txt 2>&1
