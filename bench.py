@@ -46,7 +46,7 @@ STAGE_OF = {"gate_kernel": "gate",
             "k_edge_sort": "build",
             "k_clean": "clean", "k_clean_chains": "clean", "k_clean_tail": "clean",
             "k_msa": "poa", "k_msa_band": "poa",
-            "k_read_planes": "genotype", "k_plan": "genotype", "k_vote": "genotype", "k_dp_scatter": "genotype", "k_align_reg": "genotype",
+            "k_read_planes": "genotype", "k_plan": "genotype", "k_vote": "genotype", "k_dp_scatter": "genotype", "k_align_reg": "genotype", "k_align_tb": "genotype",
             "k_align_wave": "genotype", "k_align_gen": "genotype", "k_assign": "genotype", "k_evidence": "genotype",
             "k_qual": "genotype"}
 
@@ -624,7 +624,7 @@ def main():
         sname = STAGE_OF.get(dom, "other")
         bytes_per_launch = stage_bytes_step.get(sname, 0) / max(launches_per_step, 1)
         ach = bytes_per_launch / (avg_ms * 1e-3) / 1e9
-        pk = prof.get(dom, {})
+        pk = prof.get(dom) or next((v for k, v in prof.items() if k.startswith(dom) and isinstance(v, dict)), {})  # (k_align_reg -> k_align_reg2p)
         roof = {"bound": "hbm", "kernel": dom, "stage": sname, "achieved": round(ach, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(ach / HBM_PEAK_GBS, 6), "traffic": pk.get("bytes_per_launch"),
                 "traffic_source": prof.get("_file") if pk else None,

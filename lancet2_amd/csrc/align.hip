@@ -1182,8 +1182,9 @@ __device__ __forceinline__ DpPair dp_pair_load(GArgs const& A, u32 li) {
   p.active = p.m >= SK && p.n >= SK && static_cast<u32>(p.m) + 1 <= A.ws.tb_rows;
   return p;
 }
-__device__ __forceinline__ void dp_pair_store(GArgs const& A, DpPair const& p, const u32* tb, int lane, i32 best, i32 bi,
-                                              i32 bj) {
+// the record of one DP pair: no hit, or the traceback through `fetch` (see align_traceback)
+template <class Fetch>
+__device__ __forceinline__ void dp_pair_finish(GArgs const& A, DpPair const& p, Fetch fetch, i32 best, i32 bi, i32 bj) {
   if (!p.live) return;
   size_t const rec = static_cast<size_t>(p.id.r) * A.prm.max_haps + p.id.slot;
   i32* arec = A.o.aln_rec + rec * 6;
@@ -1194,6 +1195,10 @@ __device__ __forceinline__ void dp_pair_store(GArgs const& A, DpPair const& p, c
     acig[0] = 0;
     return;
   }
+  align_traceback(A, fetch, p.lo, p.m, best, bi, bj, arec, acig, true);
+}
+__device__ __forceinline__ void dp_pair_store(GArgs const& A, DpPair const& p, const u32* tb, int lane, i32 best, i32 bi,
+                                              i32 bj) {
   u32 const tbw = A.ws.tb_words;
   // The walk is a chain of dependent loads, one move nibble per step (~160 steps, ~1 us each from HBM).  A step goes up a
   // row or stays in it, and leaves its 8-column word only at a gap: the words of the NEXT EIGHT ROWS at the current word
@@ -1201,8 +1206,8 @@ __device__ __forceinline__ void dp_pair_store(GArgs const& A, DpPair const& p, c
   constexpr int kTR = 8;
   u32 cw[kTR];
   i32 c_top = -1, c_word = -1;  // cw[r] = word c_word of row c_top - r
-  align_traceback(
-      A,
+  dp_pair_finish(
+      A, p,
       [&](i32 i, i32 t) {
         i32 const wd = t >> 3;
         if (wd != c_word || i > c_top || i <= c_top - kTR) {
@@ -1217,7 +1222,7 @@ __device__ __forceinline__ void dp_pair_store(GArgs const& A, DpPair const& p, c
         for (int x = 1; x < kTR; ++x) wv = r == x ? cw[x] : wv;
         return (wv >> (4 * (t & 7))) & 0xFu;
       },
-      p.lo, p.m, best, bi, bj, arec, acig, true);
+      best, bi, bj);
 }
 
 // ---- overlap DP over a WIDE region: one wavefront per pair ----
@@ -1698,6 +1703,304 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(reg_waves(W2
     B.ws.tb = c2.tb;
     align_reg_body<W2, WLO2>(B, seg_words, blockIdx.x - n1, lds);
   }
+}
+
+
+// ---- two pairs per lane: the register kernel's lean row body on packed 16-bit halves --------------------------------------
+// A lane of align_reg_body spends ~22 vector instructions per cell on values that fit 16 bits.  Here a lane owns TWO pairs
+// (lo half: pair 128 g + lane, hi half: pair 128 g + 64 + lane) and the row body runs on v_pk_add / sub / max_i16: ~24
+// instructions per cell of BOTH pairs.  What has no packed form is rearranged: the four decisions of a cell (diagonal vs
+// gap, E vs F, E opened, F opened) are the SIGN BITS of four packed differences, shifted into four bit planes of 16 cells
+// each (plane word: lo half pair A's cells, hi half pair B's) -- the traceback reads a cell's four bits back from the planes;
+// the substitution score comes from match bits (one per nibble of the XOR of read base and haplotype codes) through a packed
+// multiply-add.  Only rows without walls or N in any of the wavefront's 128 haplotype segments have this form: a group that
+// holds such a code anywhere falls back to align_reg_body for its two halves (the DP list is sorted by "region can reach a
+// haplotype end", so those groups are few).  Cell rules, tie rules, end cells and outputs are align_reg_body's.
+typedef short v2s16 __attribute__((ext_vector_type(2)));
+typedef unsigned short v2u16 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2u16 pk_u(u32 x) { return __builtin_bit_cast(v2u16, x); }
+__device__ __forceinline__ u32 pk_add(u32 a, u32 b) { return __builtin_bit_cast(u32, static_cast<v2u16>(pk_u(a) + pk_u(b))); }
+__device__ __forceinline__ u32 pk_sub(u32 a, u32 b) { return __builtin_bit_cast(u32, static_cast<v2u16>(pk_u(a) - pk_u(b))); }
+__device__ __forceinline__ u32 pk_mul(u32 a, u32 b) { return __builtin_bit_cast(u32, static_cast<v2u16>(pk_u(a) * pk_u(b))); }
+__device__ __forceinline__ u32 pk_max(u32 a, u32 b) {
+  return __builtin_bit_cast(u32, __builtin_elementwise_max(__builtin_bit_cast(v2s16, a), __builtin_bit_cast(v2s16, b)));
+}
+__device__ __forceinline__ u32 pk_shr(u32 a, u32 n) {
+  v2u16 const sh = {static_cast<unsigned short>(n), static_cast<unsigned short>(n)};
+  return __builtin_bit_cast(u32, static_cast<v2u16>(pk_u(a) >> sh));
+}
+__host__ __device__ constexpr u32 pk2(i32 v) { return (static_cast<u32>(v) & 0xFFFFu) | (static_cast<u32>(v) << 16); }
+__device__ __forceinline__ u32 pk_of(i32 lo16, i32 hi16) { return (static_cast<u32>(lo16) & 0xFFFFu) | (static_cast<u32>(hi16) << 16); }
+__device__ __forceinline__ i32 pk_lo(u32 x) { return static_cast<i16>(x & 0xFFFFu); }
+__device__ __forceinline__ i32 pk_hi(u32 x) { return static_cast<i32>(x) >> 16; }
+__host__ __device__ constexpr u32 reg_pk_words(int w) { return 4u * ((static_cast<u32>(w) + 15u) / 16u); }  // plane words per row and lane
+
+// plane rows of a 128-pair group (two 64-pair tiles side by side: row stride 2 x tb_words x 64 words)
+__device__ __forceinline__ u32* pk_group_rows(GArgs const& A, u32 group) {
+  return A.ws.tb + static_cast<size_t>(group) * A.ws.tb_rows * (static_cast<size_t>(2u * A.ws.tb_words) * 64);
+}
+template <int W, int WLO>
+__device__ __forceinline__ bool align_reg_body_pk(GArgs const& A, u32 seg_words, u32 const group, u32* lds) {
+  constexpr int WD = W;
+  constexpr int NW = (WD + 7) / 8;    // segment words per row
+  constexpr int NB = (WD + 15) / 16;  // 16-cell blocks of decision planes per row
+  constexpr i32 GOE = GO + GE;
+  int const lane = threadIdx.x;
+  u32* const SEGA = lds;  // [seg_words][64] each
+  u32* const SEGB = lds + static_cast<size_t>(seg_words) * 64;
+  DpPair const PA = dp_pair_load(A, group * 128u + lane);
+  DpPair const PB = dp_pair_load(A, group * 128u + 64u + lane);
+  i32 const wrA = PA.active ? PA.wr : 0, wrB = PB.active ? PB.wr : 0;
+  i32 const mA = PA.active ? PA.m : 0, mB = PB.active ? PB.m : 0;
+  i32 mmax = max(mA, mB);
+  for (int off = 32; off > 0; off >>= 1) mmax = max(mmax, __shfl_xor(mmax, off));
+  u32 spec = 0;
+  auto const build = [&](DpPair const& P, u32* SEG) {
+    if (!P.active) return;
+    i32 const seglen = P.m + WD;
+    for (i32 wd = 0; wd * 8 < seglen + 8; ++wd) {
+      u32 pk = 0;
+      for (int x = 0; x < 8; ++x) {
+        i32 const hbidx = P.lo + wd * 8 + x;
+        u32 const e = hbidx == -1 ? 6u : ((hbidx < -1 || hbidx >= P.n) ? 7u : enc_base(P.hb[hbidx]));
+        pk |= e << (4 * x);
+      }
+      if (static_cast<u32>(wd) < seg_words) SEG[static_cast<size_t>(wd) * 64 + lane] = pk;
+      // (only the columns k_vote's "region can reach a haplotype end" looked at -- [lo, lo + m + W + 8) -- count: the cells read
+      //  none beyond lo + m + W - 2, and the last word's spare columns would send three groups in four down the general body)
+      i32 const keep = seglen + 8 - wd * 8;
+      spec |= keep >= 8 ? pk : (pk & ((1u << (4 * keep)) - 1u));
+    }
+  };
+  build(PA, SEGA);
+  build(PB, SEGB);
+  if (__ballot((spec & 0x44444444u) != 0) != 0) return false;  // a wall or an N somewhere: the general body
+
+  u32 H[WD + 1], F[WD + 1];  // previous row, biased as in align_reg_body: H - (GO + GE), F - GE; lo half pair A, hi half pair B
+#pragma unroll
+  for (int t = 0; t <= WD; ++t) {
+    i32 const jA = PA.lo + t, jB = PB.lo + t;
+    i32 const hA = (t < wrA && jA >= 0 && jA <= PA.n) ? 0 : NEGR;
+    i32 const hB = (t < wrB && jB >= 0 && jB <= PB.n) ? 0 : NEGR;
+    H[t] = pk_of(hA - GOE, hB - GOE);
+    F[t] = pk2(NEGR - GE);
+  }
+  u32 const wrp = static_cast<u32>(wrA) | (static_cast<u32>(wrB) << 16);
+  u32 const tbw = A.ws.tb_words;                              // words per row of a 64-pair tile; a group owns two such tiles
+  size_t const rs = static_cast<size_t>(2u * tbw) * 64;       // row stride of the group's plane rows
+  u32* const tb = pk_group_rows(A, group);
+  i32 bestA = NEGR, biA = -1, bjA = -1, bestB = NEGR, biB = -1, bjB = -1;
+  for (i32 i = 1; i <= mmax; ++i) {
+    u32 const qA = i <= mA ? enc_base(PA.rb[i - 1]) : 4u, qB = i <= mB ? enc_base(PB.rb[i - 1]) : 4u;
+    // substitution scores biased by GO + GE: mismatch (or N in the read) per half, and what a match adds to it
+    i32 const smA = (qA > 3 ? -1 : -4) + GOE, smB = (qB > 3 ? -1 : -4) + GOE;
+    u32 const smis = pk_of(smA, smB), delta = pk_of(GOE + 1 - smA, GOE + 1 - smB);
+    u32 const qrA = (qA > 3 ? 15u : qA) * 0x11111111u, qrB = (qB > 3 ? 15u : qB) * 0x11111111u;
+    // match bits of the row's cells: nibble t of zz[] holds pair A's bit (bit 0) and pair B's (bit 1)
+    u32 const wbase = static_cast<u32>(i - 1) >> 3, sh = (static_cast<u32>(i - 1) & 7u) * 4u;
+    u32 zz[NW];
+    {
+      u32 pa = SEGA[static_cast<size_t>(wbase) * 64 + lane], pb = SEGB[static_cast<size_t>(wbase) * 64 + lane];
+#pragma unroll
+      for (int k = 0; k < NW; ++k) {
+        u32 const na = SEGA[static_cast<size_t>(wbase + k + 1) * 64 + lane], nb = SEGB[static_cast<size_t>(wbase + k + 1) * 64 + lane];
+        u32 const xa = (sh ? ((pa >> sh) | (na << (32u - sh))) : pa) ^ qrA;
+        u32 const xb = (sh ? ((pb >> sh) | (nb << (32u - sh))) : pb) ^ qrB;
+        u32 const oa = xa | (xa >> 1) | (xa >> 2) | (xa >> 3), ob = xb | (xb >> 1) | (xb >> 2) | (xb >> 3);
+        zz[k] = (~oa & 0x11111111u) | ((~ob & 0x11111111u) << 1);
+        pa = na;
+        pb = nb;
+      }
+    }
+    u32 dhm = H[0];                  // H(i-1, diagonal) - GOE; afterwards carried over from the cell before
+    u32 lhm = pk2(NEGR - GOE);       // H(i, t-1) - GOE
+    u32 lem = pk2(NEGR - GE);        // E(i, t-1) - GE
+    u32 acc1 = 0, acc2 = 0, acc3 = 0, acc4 = 0, hlast = 0;
+    u32* const tbrow = tb + static_cast<size_t>(i) * rs + lane;
+#pragma unroll
+    for (int t = 0; t < WD; ++t) {
+      u32 const uph = H[t + 1], upf = F[t + 1];
+      u32 const c = (zz[t >> 3] >> (4 * (t & 7))) & 3u;
+      u32 const mbit = (c * 0x8001u) & 0x00010001u;
+      u32 const sb = pk_add(smis, pk_mul(mbit, delta));
+      u32 const dg = pk_add(dhm, sb);
+      u32 const e = pk_max(lhm, lem), f = pk_max(uph, upf);
+      u32 const h = pk_max(dg, pk_max(e, f));
+      // sign bits: E extended (eo < ee), F extended (fo < fe), F beats E (e < f), a gap beats the diagonal (dg < h)
+      u32 const d1 = pk_sub(lhm, lem), d2 = pk_sub(uph, upf), d3 = pk_sub(e, f), d4 = pk_sub(dg, h);
+      acc1 = pk_shr(acc1, 1) | (d1 & 0x80008000u);
+      acc2 = pk_shr(acc2, 1) | (d2 & 0x80008000u);
+      acc3 = pk_shr(acc3, 1) | (d3 & 0x80008000u);
+      acc4 = pk_shr(acc4, 1) | (d4 & 0x80008000u);
+      u32 hm = pk_sub(h, pk2(GOE)), fm = pk_sub(f, pk2(GE));
+      lem = pk_sub(e, pk2(GE));
+      if (t > WLO) {  // first cell outside a narrower region of either pair: minus infinity
+        u32 const x = wrp ^ pk2(t);
+        u32 const ne = __builtin_bit_cast(u32, __builtin_elementwise_min(pk_u(x), pk_u(0x00010001u)));
+        u32 const msk = pk_sub(ne, 0x00010001u);  // 0xFFFF in the halves whose wr == t
+        hm = (hm & ~msk) | (pk2(NEGR - GOE) & msk);
+        fm = (fm & ~msk) | (pk2(NEGR - GE) & msk);
+      }
+      H[t] = hm;
+      F[t] = fm;
+      lhm = hm;
+      dhm = uph;
+      hlast = h;
+      if ((t & 15) == 15 || t == WD - 1) {
+        constexpr int kb = 0;
+        (void)kb;
+        u32 const fin = 15u - static_cast<u32>(t & 15);  // a partial last block: right-align its bits
+        u32* const q = tbrow + static_cast<size_t>((t >> 4) * 4) * 64;
+        q[0] = fin ? pk_shr(acc1, fin) : acc1;
+        q[64] = fin ? pk_shr(acc2, fin) : acc2;
+        q[128] = fin ? pk_shr(acc3, fin) : acc3;
+        q[192] = fin ? pk_shr(acc4, fin) : acc4;
+        acc1 = acc2 = acc3 = acc4 = 0;
+      }
+    }
+    // end cell (i, n) for i < m: the last cell of the row is column n iff the region reaches it (see align_reg_body)
+    {
+      i32 const lhA = pk_lo(hlast), lhB = pk_hi(hlast);
+      if (i < mA && i + PA.lo + wrA - 1 >= PA.n && i + PA.lo <= PA.n && lhA >= bestA) {
+        bestA = lhA;
+        biA = i;
+        bjA = PA.n;
+      }
+      if (i < mB && i + PB.lo + wrB - 1 >= PB.n && i + PB.lo <= PB.n && lhB >= bestB) {
+        bestB = lhB;
+        biB = i;
+        bjB = PB.n;
+      }
+    }
+    // end cells (m, j) of a pair whose last row this is: left to right, smaller j wins ties, row m beats earlier rows on ties
+    if (i == mA || i == mB) {
+      bool const isA = i == mA, isB = i == mB;
+      bool firstA = true, firstB = true;
+#pragma unroll
+      for (int t = 0; t < WD; ++t) {
+        i32 const hA = pk_lo(H[t]) + GOE, hB = pk_hi(H[t]) + GOE;
+        i32 const jA = i + PA.lo + t, jB = i + PB.lo + t;
+        if (isA && t < wrA && jA >= 0 && jA <= PA.n) {
+          if (hA > bestA || (firstA && hA == bestA)) {
+            bestA = hA;
+            biA = i;
+            bjA = jA;
+          }
+          if (hA >= bestA) firstA = false;
+        }
+        if (isB && t < wrB && jB >= 0 && jB <= PB.n) {
+          if (hB > bestB || (firstB && hB == bestB)) {
+            bestB = hB;
+            biB = i;
+            bjB = jB;
+          }
+          if (hB >= bestB) firstB = false;
+        }
+      }
+    }
+  }
+  // What the walk back needs goes into row 0 of the group's plane rows (the fill writes rows 1 ... m): the tracebacks are
+  // chains of dependent loads, ~20 round trips a pair -- in k_align_tb2, at full occupancy, they no longer hold this
+  // kernel's registers (two wavefronts per SIMD) while they wait.
+  {
+    u32* const q = tb + lane;
+    q[0] = 1u;  // plane layout (0: the group took the general body, which walks back itself)
+    q[64] = static_cast<u32>(bestA);
+    q[128] = static_cast<u32>(biA);
+    q[192] = static_cast<u32>(bjA);
+    q[256] = static_cast<u32>(bestB);
+    q[320] = static_cast<u32>(biB);
+    q[384] = static_cast<u32>(bjB);
+  }
+  return true;
+}
+
+// k_align_reg2 with two pairs per lane.  The DP list of a class is sorted "cannot reach a haplotype end" first: those pairs go
+// through the packed body in groups of 128 (segments 0 and 1: class 1, class 2), the others through align_reg_body in groups of
+// 64 (segments 2 and 3) -- side by side in one launch, every workgroup one group.  (A packed group that falls back walks its two
+// halves one after the other: with the wall pairs inside the packed groups, three groups in four did, and the launch lasted two
+// general bodies in a row.)
+struct RegSeg {
+  u32 dp0, dp_n, tb_words, gen_w, units;
+  u32* tb;
+};
+struct RegPlan { RegSeg seg[4]; };
+__device__ __forceinline__ void reg_seg_apply(GArgs& A, RegSeg const& sg) {
+  A.dp0 = sg.dp0;
+  A.dp_n = sg.dp_n;
+  A.ws.tb_words = sg.tb_words;
+  A.ws.gen_w = sg.gen_w;
+  A.ws.tb = sg.tb;
+}
+template <int W1, int WLO1, int W2, int WLO2>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 8))) void k_align_reg2p(GArgs A, RegPlan pl, u32 seg_words) {
+  extern __shared__ u32 lds[];
+  static_assert(reg_waves(W1) == reg_waves(W2), "same register budget");
+  u32 unit = blockIdx.x;
+  int sg = 0;
+  while (sg < 3 && unit >= pl.seg[sg].units) unit -= pl.seg[sg++].units;
+  reg_seg_apply(A, pl.seg[sg]);
+  if (sg == 0) {
+    if (!align_reg_body_pk<W1, WLO1>(A, seg_words, unit, lds)) {
+      pk_group_rows(A, unit)[threadIdx.x] = 0u;
+      for (u32 hf = 0; hf < 2; ++hf) align_reg_body<W1, WLO1>(A, seg_words, 2u * unit + hf, lds);
+    }
+  } else if (sg == 1) {
+    if (!align_reg_body_pk<W2, WLO2>(A, seg_words, unit, lds)) {
+      pk_group_rows(A, unit)[threadIdx.x] = 0u;
+      for (u32 hf = 0; hf < 2; ++hf) align_reg_body<W2, WLO2>(A, seg_words, 2u * unit + hf, lds);
+    }
+  } else if (sg == 2) {
+    align_reg_body<W1, WLO1>(A, seg_words, unit, lds);
+  } else {
+    align_reg_body<W2, WLO2>(A, seg_words, unit, lds);
+  }
+}
+
+// the walks back of k_align_reg2p's packed groups: one wavefront per 64 pairs (workgroup 2 g + h: half h of group g), a lane per pair;
+// a cell's four decision bits come from the planes of its 16-cell block, the blocks of the next eight rows fetched together
+__global__ __launch_bounds__(64) void k_align_tb2(GArgs A, RegPlan pl) {
+  u32 g = blockIdx.x >> 1;
+  u32 const half = blockIdx.x & 1u;
+  int const sg = g >= pl.seg[0].units ? 1 : 0;
+  if (sg) g -= pl.seg[0].units;
+  reg_seg_apply(A, pl.seg[sg]);
+  int const lane = threadIdx.x;
+  const u32* const tb = pk_group_rows(A, g);
+  if (tb[lane] != 1u) return;  // (the same for every lane of a group)
+  DpPair const P = dp_pair_load(A, g * 128u + half * 64u + lane);
+  size_t const rs = static_cast<size_t>(2u * A.ws.tb_words) * 64;
+  i32 const best = static_cast<i32>(tb[(1 + 3 * half) * 64 + lane]), bi = static_cast<i32>(tb[(2 + 3 * half) * 64 + lane]),
+            bj = static_cast<i32>(tb[(3 + 3 * half) * 64 + lane]);
+  constexpr int kTR = 8;
+  u32 cw[kTR][4];
+  i32 c_top = -1, c_blk = -1;
+  dp_pair_finish(
+      A, P,
+      [&](i32 ri, i32 t) {
+        i32 const blk = t >> 4;
+        if (blk != c_blk || ri > c_top || ri <= c_top - kTR) {
+          c_top = ri;
+          c_blk = blk;
+#pragma unroll
+          for (int r = 0; r < kTR; ++r)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) cw[r][k] = tb[static_cast<size_t>(max(ri - r, 0)) * rs + static_cast<size_t>(blk * 4 + k) * 64 + lane];
+        }
+        i32 const r = c_top - ri;
+        u32 w1 = cw[0][0], w2 = cw[0][1], w3 = cw[0][2], w4 = cw[0][3];
+#pragma unroll
+        for (int x = 1; x < kTR; ++x) {
+          w1 = r == x ? cw[x][0] : w1;
+          w2 = r == x ? cw[x][1] : w2;
+          w3 = r == x ? cw[x][2] : w3;
+          w4 = r == x ? cw[x][3] : w4;
+        }
+        u32 const shb = half * 16u + (static_cast<u32>(t) & 15u);
+        u32 const s1 = (w1 >> shb) & 1u, s2 = (w2 >> shb) & 1u, s3 = (w3 >> shb) & 1u, s4 = (w4 >> shb) & 1u;
+        return (s4 ? (s3 ? 2u : 1u) : 0u) | (s1 ? 0u : 4u) | (s2 ? 0u : 8u);
+      },
+      best, bi, bj);
 }
 
 // ---- scoring epilogue ----
@@ -2278,6 +2581,55 @@ int launch_genotype(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& a, const m
           if (c2 >= 0) {
             u32 const n1 = cls_n, n2 = class_n(c2);
             u32 const gw2 = class_w(c2);
+            bool const pk = !getenv("MA_ALIGN_NO_PK");
+            if (pk) {
+              // two pairs per lane (k_align_reg2p): the pairs that cannot reach a haplotype end in packed groups of 128 (two
+              // 64-pair tiles, wide enough for the plane rows), the others in groups of 64 through the general body
+              u32 const tw[2] = {std::max<u32>((gw + 7) / 8, reg_pk_words(static_cast<int>(gw)) / 2),
+                                 std::max<u32>((gw2 + 7) / 8, reg_pk_words(static_cast<int>(gw2)) / 2)};
+              u32 const gws[2] = {gw, gw2};
+              int const cc[2] = {cls, c2};
+              RegPlan pl{};
+              size_t off = 0;  // bytes into the traceback workspace
+              for (int sgi = 0; sgi < 4; ++sgi) {
+                int const x = sgi & 1;
+                bool const packed = sgi < 2;
+                u32 const n = cnt[4 + 2 * cc[x] + (packed ? 0 : 1)];
+                u32 const per = packed ? 128u : 64u;
+                RegSeg& sg = pl.seg[sgi];
+                sg.dp0 = kb.b[2 * cc[x] + (packed ? 0 : 1)];
+                sg.dp_n = n;
+                sg.tb_words = tw[x];
+                sg.gen_w = gws[x];
+                sg.units = (n + per - 1) / per;
+                sg.tb = A.ws.tb + off / 4;
+                off += static_cast<size_t>(sg.units) * ws.tb_rows * tw[x] * per * 4;
+              }
+              u32 const units = pl.seg[0].units + pl.seg[1].units + pl.seg[2].units + pl.seg[3].units;
+              if (off <= tb_cap && units > 0) {
+                ctx->stats[4 + (c2 < 2 ? 0 : (c2 < 4 ? 1 : 2))] += n2;
+                u32 const segw = (max_read_len + gw2 + 7) / 8 + 3;
+                size_t const lds_reg = static_cast<size_t>(segw) * 512;
+                ctx->tic("k_align_reg");
+                if (cls == 0 && c2 == 1)
+                  hipLaunchKernelGGL((k_align_reg2p<reg_width(0), 0, reg_width(1), reg_width(0)>), dim3(units), dim3(64), lds_reg, ctx->stream,
+                                     A, pl, segw);
+                else if (cls == 0 && c2 == 2)
+                  hipLaunchKernelGGL((k_align_reg2p<reg_width(0), 0, reg_width(2), reg_width(1)>), dim3(units), dim3(64), lds_reg, ctx->stream,
+                                     A, pl, segw);
+                else
+                  hipLaunchKernelGGL((k_align_reg2p<reg_width(1), reg_width(0), reg_width(2), reg_width(1)>), dim3(units), dim3(64), lds_reg,
+                                     ctx->stream, A, pl, segw);
+                ctx->toc();
+                if (pl.seg[0].units + pl.seg[1].units > 0) {
+                  ctx->tic("k_align_tb");
+                  hipLaunchKernelGGL(k_align_tb2, dim3(2 * (pl.seg[0].units + pl.seg[1].units)), dim3(64), 0, ctx->stream, A, pl);
+                  ctx->toc();
+                }
+                cls = c2;
+                continue;
+              }
+            }
             u32 const tw1 = (gw + 7) / 8, tw2 = (gw2 + 7) / 8;
             size_t const tpg1 = static_cast<size_t>(ws.tb_rows) * tw1 * 64 * 4, tpg2 = static_cast<size_t>(ws.tb_rows) * tw2 * 64 * 4;
             u32 const ng1 = (n1 + 63) / 64, ng2 = (n2 + 63) / 64;
