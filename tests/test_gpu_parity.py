@@ -775,6 +775,33 @@ def test_whole_chain_parity_on_the_harder_bench_shapes(kw, pk):
         assert (wa["win_k"] > 40).any(), wa["win_k"].tolist()
 
 
+def test_packed_two_pairs_per_lane_aligner_is_the_one_pair_aligner(monkeypatch):
+    """MA_ALIGN_PK=1: the two busiest register classes of the read aligner run two pairs per lane on packed 16-bit halves
+    (align.hip: k_align_reg2p -- decisions as bit planes, walks back in k_align_tb2) for the pairs whose region cannot reach a
+    haplotype end, the general body beside them for the others.  Same records as the oracle, on WGS-shaped windows with
+    tandem repeats, soft clips and N bases; the timing names prove the route was taken."""
+    from lancet2_amd.engine import Engine
+    monkeypatch.setenv("MA_ALIGN_PK", "1")
+    monkeypatch.setenv("MA_NO_REROUTE", "1")  # (a class of a few hundred pairs would go to the wavefront kernel: no two classes to pair)
+    params = capi.default_params(min_k=25, max_k=25)
+    arrs, n, nr = synth.make_config_batch("C3", 12, first_index=86_000, softclip_frac=0.05, n_frac=0.03)
+    orc = OracleEngine(params)
+    wa = orc.assemble(arrs, n, nr)
+    wv = orc.msa(arrs, n, nr, wa)
+    wq = orc.genotype(arrs, n, nr, wa, wv)
+    eng = Engine(params)
+    try:
+        eng.timing_control(1)
+        g, a, v, q = eng.process(arrs, n, nr, debug=True)
+        names = {k for k, _ in eng.kernel_times()}
+    finally:
+        eng.close()
+    assert "k_align_tb" in names, sorted(names)
+    bad = compare_asm(params, a, wa, n) + compare_vars(params, v, wv, n)
+    bad += compare_geno(params, q, wq, n, nr, wv["win_nvars"], arrs["read_win_off"])
+    assert not bad, "\n".join(bad[:12])
+
+
 def test_ladder_tail_six_rungs_at_a_time_equals_rung_by_rung(monkeypatch):
     """Once few windows are left on the k ladder their next six rungs are attempted at once (assemble.hip: speculate_tail --
     the pending windows copied into a derived batch, one copy per rung, each window taking the first rung that resolved).
