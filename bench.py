@@ -705,6 +705,10 @@ def main():
                 res["kernel_ms_per_step"] = {k_: round(v_, 3) for k_, v_ in sorted(acc.items(), key=lambda kv: -kv[1])}
                 flagged = ost & ~np.uint32(capi.MA_W_NO_HAPLOTYPE | capi.MA_W_BFS_LIMIT)
                 res["windows_with_capacity_flag"] = int((flagged != 0).sum())
+                res["capacity_flags"] = {nm: int(((ost & np.uint32(getattr(capi, nm))) != 0).sum())
+                                         for nm in ("MA_W_HAP_OVERFLOW", "MA_W_LEN_OVERFLOW", "MA_W_TABLE_OVERFLOW", "MA_W_VAR_OVERFLOW",
+                                                    "MA_W_CIGAR_OVERFLOW", "MA_W_READ_OVERFLOW")
+                                         if ((ost & np.uint32(getattr(capi, nm))) != 0).any()}
                 res["windows_at_traversal_limit"] = int(((ost & capi.MA_W_BFS_LIMIT) != 0).sum())
             oeng.close()
             del o_dbatch, o_q
