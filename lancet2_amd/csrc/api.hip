@@ -6,6 +6,7 @@
 #include <condition_variable>
 #include <cstring>
 #include <deque>
+#include <functional>
 #include <memory>
 #include <mutex>
 #include <new>
@@ -243,6 +244,63 @@ int run_lane(ma_ctx* ch, hipEvent_t start, const DBatch& full, int w0, int w1, u
   return MA_OK;
 }
 
+// The lanes of the device route run on PERSISTENT threads (one per lane, parked on a condition variable between calls): a call
+// hands them its closure and waits for the last of them -- no thread is created or joined per call (round 3 did both, 4 x ~40 us
+// and a first-touch of the HIP runtime's per-thread state on every call).
+struct DevLanePool {
+  std::mutex mu;
+  std::condition_variable cv_go, cv_done;
+  std::vector<std::thread> th;
+  std::function<void(int)> fn;
+  unsigned long long gen = 0;
+  int active = 0, pending = 0;
+  bool stop = false;
+  void ensure(int n) {
+    while (static_cast<int>(th.size()) < n) {
+      int const k = static_cast<int>(th.size());
+      th.emplace_back([this, k] {
+        unsigned long long seen = 0;
+        for (;;) {
+          std::function<void(int)> f;
+          {
+            std::unique_lock<std::mutex> lk(mu);
+            cv_go.wait(lk, [&] { return stop || (gen != seen && k < active); });
+            if (stop) return;
+            seen = gen;
+            f = fn;
+          }
+          f(k);
+          {
+            std::lock_guard<std::mutex> lk(mu);
+            if (--pending == 0) cv_done.notify_all();
+          }
+        }
+      });
+    }
+  }
+  void run(int n, std::function<void(int)> f) {
+    ensure(n);
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      fn = std::move(f);
+      active = n;
+      pending = n;
+      ++gen;
+    }
+    cv_go.notify_all();
+    std::unique_lock<std::mutex> lk(mu);
+    cv_done.wait(lk, [&] { return pending == 0; });
+  }
+  ~DevLanePool() {
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      stop = true;
+    }
+    cv_go.notify_all();
+    for (auto& t : th) t.join();
+  }
+};
+
 int process_in_lanes(ma_ctx* ctx, int lanes, const DBatch& d, const ma_gate_out_t& g, const ma_asm_out_t& a,
                      const ma_var_out_t& v, const ma_geno_out_t& q) {
   while (static_cast<int>(ctx->lanes.size()) < lanes) {
@@ -264,7 +322,6 @@ int process_in_lanes(ma_ctx* ctx, int lanes, const DBatch& d, const ma_gate_out_
   MA_HIP(ctx, hipEventRecord(ctx->lane_done, ctx->stream));  // inputs (and staging copies) are ready after this
   MA_HIP(ctx, ma_stream_sync(ctx));
   std::vector<int> rc(lanes, MA_OK);
-  std::vector<std::thread> th;
   for (int k = 0; k < lanes; ++k) {
     ma_ctx* ch = ctx->lanes[k];
     ch->prm = ctx->prm;
@@ -273,9 +330,11 @@ int process_in_lanes(ma_ctx* ctx, int lanes, const DBatch& d, const ma_gate_out_
     ch->collect = ctx->collect;
     if (!ch->accumulate) ch->timers_used = 0;
     ch->hbm_share = ctx->hbm_share / lanes;
-    th.emplace_back([&, k, ch]() { rc[k] = run_lane(ch, ctx->lane_done, d, wb[k], wb[k + 1], rb[k], rb[k + 1], g, a, v, q, k); });
   }
-  for (auto& t : th) t.join();
+  if (!ctx->dev_pool) ctx->dev_pool = new DevLanePool();
+  static_cast<DevLanePool*>(ctx->dev_pool)->run(lanes, [&](int k) {
+    rc[k] = run_lane(ctx->lanes[k], ctx->lane_done, d, wb[k], wb[k + 1], rb[k], rb[k + 1], g, a, v, q, k);
+  });
   for (int k = 0; k < lanes; ++k) {
     if (rc[k] != MA_OK) {
       ma_set_err(ctx, "lane " + std::to_string(k) + ": " + ma_get_err(ctx->lanes[k]));
@@ -1047,6 +1106,8 @@ int ma_create(const ma_params_t* prm, int device, int memspace, ma_ctx_t** out) 
 void ma_destroy(ma_ctx_t* ctx) {
   if (!ctx) return;
   stop_workers(ctx);  // (the lanes' threads finish what is queued, then end)
+  delete static_cast<DevLanePool*>(ctx->dev_pool);
+  ctx->dev_pool = nullptr;
   forget_views(ctx);
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);

@@ -109,6 +109,7 @@ struct ma_ctx {
   size_t pin_cap[2] = {0, 0};             // thread while the lane already computes the next batch
   size_t last_packed = 0;                 // (lane) bytes of packed records of the lane's last batch: sizes the next landing area
   void* host_async = nullptr;             // (parent) worker threads + jobs of the host route (api.hip: HostAsync)
+  void* dev_pool = nullptr;               // (parent) the lanes' worker threads of the device route (api.hip: DevLanePool)
   hipStream_t copy_stream2 = nullptr;     // the pieces of an upload alternate between the two copy streams (api.hip: run_copy_ops)
   ma::InputSet in_sets[2];       // (lane) input staging, double buffered
   // (parent) ma_prefetch_batch: which batch each set of the lanes holds (null: free), in which order they were filled,
