@@ -411,7 +411,15 @@ int launch_assemble(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& out, const
 
   ws.tc_log2 = std::max(10, ceil_log2(static_cast<u64>(max_inst) * 4 / 3 + 16));
   ws.mc_log2 = std::max(10, ceil_log2(static_cast<u64>(max_read_inst) * 4 / 3 + 16));
-  int const tc_log2_alloc = ws.tc_log2, mc_log2_alloc = ws.mc_log2;
+  // The k-mer table of a window is planned for its INSTANCES (every one could be a k-mer of its own).  A deep window (0.9 M
+  // instances in a 2000x panel) holds some 40 k distinct k-mers: planned by instances its table is 2^21 slots = 67 MB, a lane's
+  // share of the build budget holds 200 such windows and the lane pays the clean stage's latency once per chunk.  The first
+  // pass therefore plans a quarter of the instances; a window whose table does fill up is flagged like any other capacity and
+  // re-assembled by the retry passes, which plan the full table.
+  int const tc_full = ws.tc_log2, mc_log2_alloc = ws.mc_log2;
+  int tc_first = max_inst > 400000 ? std::max(17, ceil_log2(static_cast<u64>(max_inst) / 4 + 16)) : tc_full;
+  if (const char* e = getenv("MA_TC_FIRST")) tc_first = std::max(10, atoi(e));  // tests: force the table retry
+  tc_first = std::min(tc_first, tc_full);
   ws.inst_stride = (max_inst + 63) & ~63u;
   ws.ref_stride = (max_refk + 63) & ~63u;
   ws.max_ref_len = max_refk + static_cast<u32>(P.min_k) + 8;  // longest reference window (+ slack)
@@ -436,8 +444,7 @@ int launch_assemble(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& out, const
     g.n_slow = c.take<u32>(A);
     g.mm_mode = c.take<u32>(A);
     g.win_tc = c.take<u32>(A);
-    g.mm_key = c.take<u64>(A * mcap);
-    g.mm_min = c.take<u32>(A * mcap);
+    (void)mcap;  // (the HBM mate-mer set is reserved by run_build_pass when a window needs it: ma_ctx::ws_mm)
     g.n_nodes = c.take<u32>(A);
     g.nd_cnt = c.take<u32>(A * NC * S);
     g.nd_role = c.take<u32>(A * NC * 2);
@@ -492,6 +499,7 @@ int launch_assemble(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& out, const
   // than 16 edges on a node, a traversal cap the folded search cannot place: DESIGN.md section 7).
   for (int pass = 0; pass < 3; ++pass) {
     u32 const grow = pass == 0 ? 1u : (pass == 1 ? 4u : 16u);
+    int const tc_log2_alloc = pass == 0 ? tc_first : tc_full;
     ws.nc = nc0 * grow;
     // the arena of the last pass holds what the reference's own cap allows: 2^20 pops (max_flow.h:69), a few pushes each
     // (components of more than ~400 nodes search unfolded, clean.hip)

@@ -1949,6 +1949,11 @@ int run_build_pass(ma_ctx* ctx, const DBatch& b, GraphWs& ws, u32* counters_dev,
     while ((size_t(1) << mc) < static_cast<size_t>(max_gen[1]) * 4 / 3 + 16) ++mc;
     ws.mc_log2 = mc < mc_log2_alloc ? mc : mc_log2_alloc;
     size_t const mcap = size_t(1) << ws.mc_log2;
+    // (reserved here, when a window of the chunk needs it -- windows without mapping hints, names in separate runs: the set was
+    //  a quarter of every window's planned workspace and is not touched at all on the usual route)
+    MA_HIP(ctx, ctx->ws_mm.reserve(A * mcap * 12 + 256));
+    ws.mm_key = ctx->ws_mm.as<u64>();
+    ws.mm_min = reinterpret_cast<u32*>(ws.mm_key + A * mcap);
     MA_HIP(ctx, hipMemsetAsync(ws.mm_key, 0, A * mcap * 8, ctx->stream));
     MA_HIP(ctx, hipMemsetAsync(ws.mm_min, 0xFF, A * mcap * 4, ctx->stream));
     ctx->tic("k_mm_insert");

@@ -71,7 +71,10 @@ def test_maximum_window_size_end_to_end():
 
 
 @pytest.mark.parametrize("env,cfg,kw", [({"MA_ARENA_CAP": "48"}, "C2", dict(snv_rate=1e-2, indel_rate=2e-3)),
-                                         ({"MA_NODE_CAP": "512", "MA_ARENA_CAP": "256"}, "C4", dict(depths=(200, 200)))])
+                                         ({"MA_NODE_CAP": "512", "MA_ARENA_CAP": "256"}, "C4", dict(depths=(200, 200))),
+                                         # the k-mer table: a first pass planned too small (what deep windows get by design: a
+                                         # quarter of their instances), the retry passes plan the full table
+                                         ({"MA_TC_FIRST": "11"}, "C2", dict(snv_rate=1e-2, indel_rate=2e-3))])
 def test_capacity_overflow_is_retried_inside_the_library(env, cfg, kw, monkeypatch):
     """The reference has one capacity (2^20 BFS visits); the engine's node array and search arena are sized per batch.
     With the capacities forced far too low, a single pass leaves windows flagged TABLE_OVERFLOW (shown with
