@@ -108,7 +108,7 @@ def units_per_step(stage, st):
     return st["assembled"]
 
 
-def pipeline_extract_leg(genome_len=200_000, depths=(30, 60), seed=0x5EED, threads=(1, 0)):
+def pipeline_extract_leg(genome_len=600_000, depths=(30, 60), seed=0x5EED, threads=(1, 0)):
     """builds examples/pipeline_driver.cpp with g++, writes a random genome + two coordinate-sorted SAM files (150-base paired
     reads, plain 150M alignments) and times the extract stage on them: the driver prints each stage's busy time"""
     import re

@@ -181,7 +181,7 @@ int main(int argc, char** argv) {
   ma_default_params(&prm);
   bool no_active_region = false, extract_only = false;
   int batch_windows = 512;
-  int extract_threads = static_cast<int>(std::min(4u, std::max(1u, std::thread::hardware_concurrency())));
+  int extract_threads = static_cast<int>(std::min(8u, std::max(1u, std::thread::hardware_concurrency())));
   for (int i = 1; i < argc; ++i) {
     std::string const a = argv[i];
     auto next = [&]() -> const char* { return i + 1 < argc ? argv[++i] : ""; };
