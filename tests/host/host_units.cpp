@@ -169,6 +169,37 @@ int main() {
     auto const rest = st.ExtractAll();
     CHECK(rest.size() == 1 && rest[0].chrom == 2 && st.Size() == 0);
   }
+  {  // FlatBatch::Append (the extract stage's workers flatten a window each, the ordered assembler appends): the batch is the
+    // one that Add() on the same windows in the same order builds -- arrays, offsets, per-window name ids and coverage.
+    auto mk = [](const char* qn, const char* seq, uint8_t q0, int64_t start0, uint16_t flag, Tag tag, size_t sidx, uint32_t clip) {
+      Read r;
+      r.qname = qn; r.seq = seq; r.qual.assign(r.seq.size(), q0); r.start0 = start0; r.chrom = 0; r.flag = flag; r.tag = tag;
+      r.sample_index = sidx; r.leading_clip = clip; r.passes = q0 != 7;
+      return r;
+    };
+    std::vector<Read> r0 = {mk("a", "ACGTAC", 30, 104, 0x63, Tag::CTRL, 0, 0), mk("a", "TTGACA", 0xFF, 180, 0x93, Tag::CTRL, 0, 2),
+                            mk("b", "GGGTTT", 7, 150, 0x10, Tag::CASE, 1, 0)};
+    std::vector<Read> r1 = {};
+    std::vector<Read> r2 = {mk("b", "CATCAT", 20, 905, 0, Tag::CASE, 1, 1), mk("c", "AAAAAC", 25, 950, 0x10, Tag::CTRL, 0, 0)};
+    std::vector<SampleInfo> si(2);
+    si[0].sampled_bases = 1200; si[1].sampled_bases = 600;
+    Window const w0{0, 101, 1101, 0}, w1{0, 501, 1501, 1}, w2{0, 901, 1901, 2};
+    std::string const ref(1001, 'A');
+    FlatBatch serial;
+    serial.Add(w0, ref, r0, &si); serial.Add(w1, ref, r1, &si); serial.Add(w2, ref, r2, &si);
+    FlatBatch pieces;
+    for (auto const& pr : {std::make_pair(&w0, &r0), std::make_pair(&w1, &r1), std::make_pair(&w2, &r2)}) {
+      FlatBatch one;
+      one.Add(*pr.first, ref, *pr.second, &si);
+      pieces.Append(one);
+    }
+    CHECK(serial.ref_bases == pieces.ref_bases && serial.read_bases == pieces.read_bases && serial.read_quals == pieces.read_quals);
+    CHECK(serial.read_sample == pieces.read_sample && serial.read_flags == pieces.read_flags && serial.read_hint == pieces.read_hint);
+    CHECK(serial.ref_off == pieces.ref_off && serial.read_off == pieces.read_off && serial.read_win_off == pieces.read_win_off);
+    CHECK(serial.read_qname_id == pieces.read_qname_id && serial.sample_cov == pieces.sample_cov && serial.windows.size() == 3);
+    CHECK(serial.read_win_off == (std::vector<uint32_t>{0, 3, 3, 5}) && serial.read_qname_id == (std::vector<uint32_t>{0, 0, 1, 0, 1}));
+    CHECK(serial.read_quals[6] == 0 && serial.read_hint[0] == 4 && serial.read_hint[1] == 78);  // 0xFF qualities -> 0; hint = start - window start - clip
+  }
   {  // core/variant_builder.cpp:184-199 BEFORE core/variant_store.cpp:20-42: a call without ALT support never reaches the store.
     // Two overlapping windows report the same CHROM + POS + REF; window 0's call has MORE total coverage but no ALT read,
     // window 1's has less coverage and ALT support.  Filtering at the flush only, the unsupported call would win the
