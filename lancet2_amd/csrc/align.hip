@@ -1847,8 +1847,6 @@ __device__ __forceinline__ bool align_reg_body_pk(GArgs const& A, u32 seg_words,
       dhm = uph;
       hlast = h;
       if ((t & 15) == 15 || t == WD - 1) {
-        constexpr int kb = 0;
-        (void)kb;
         u32 const fin = 15u - static_cast<u32>(t & 15);  // a partial last block: right-align its bits
         u32* const q = tbrow + static_cast<size_t>((t >> 4) * 4) * 64;
         q[0] = fin ? pk_shr(acc1, fin) : acc1;
