@@ -500,6 +500,7 @@ int launch_assemble(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& out, const
   for (int pass = 0; pass < 3; ++pass) {
     u32 const grow = pass == 0 ? 1u : (pass == 1 ? 4u : 16u);
     int const tc_log2_alloc = pass == 0 ? tc_first : tc_full;
+    ws.mm_force_hbm = pass > 0 ? 1u : 0u;  // (a window whose LDS mate-mer set filled up comes back here: build.hip, k_mm_lds)
     ws.nc = nc0 * grow;
     // the arena of the last pass holds what the reference's own cap allows: 2^20 pops (max_flow.h:69), a few pushes each
     // (components of more than ~400 nodes search unfolded, clean.hip)

@@ -1189,7 +1189,7 @@ __global__ __launch_bounds__(kSupT) void k_support(DBatch b, GraphWs ws, u32* ma
     // Windows whose (qname, role) keys each map to ONE run of adjacent reads (xs_flag == 0) and whose general
     // instances fit the LDS set are finished by k_mm_lds; the others need the HBM-resident set (max_gen[1]).
     // (up to four passes over the set for a window that fits the LDS tables; a deeper one goes chunk by chunk)
-    bool const lds_ok = !all_generic && (ns > kSeqCap || gen_count <= 4u * kMmLdsMax) && ws.tc_log2 <= 20;
+    bool const lds_ok = !all_generic && !ws.mm_force_hbm && (ns > kSeqCap || gen_count <= 4u * kMmLdsMax) && ws.tc_log2 <= 20;
     ws.mm_mode[a] = gen_count | (lds_ok ? 0u : 0x80000000u);
     atomicMax(max_gen, gen_count);
     if (!lds_ok) atomicMax(max_gen + 1, gen_count);
@@ -1306,6 +1306,7 @@ __global__ __launch_bounds__(kBT) void k_count(DBatch b, GraphWs ws) {
 constexpr int kMmT = 1024;
 constexpr u32 kMmQueue = 4096;
 constexpr u32 kMmAux = kSeqCap + kSeqCap / 2 + kMmQueue;  // 28 KB
+template <bool kTestProbe>  // (tests: the set counts as full after ws.mm_probe_max probes)
 __global__ __launch_bounds__(kMmT) void k_mm_lds(DBatch b, GraphWs ws) {
   __shared__ u32 l_set[kMmLdsCap];
   __shared__ u32 l_aux[kMmAux];  // walk: instance bases | run leaders | queue; afterwards: packed u16 support counters
@@ -1383,6 +1384,7 @@ __global__ __launch_bounds__(kMmT) void k_mm_lds(DBatch b, GraphWs ws) {
   __syncthreads();
   IPROF(12);  // set init, instance bases, run leaders
   // (qname, role, node) of one general instance -> set
+  bool set_full = false;
   auto const visit_slot = [&](u32 ii, u32 nslot) {
     u32 sq;
     if (blk_ok) {
@@ -1395,15 +1397,24 @@ __global__ __launch_bounds__(kMmT) void k_mm_lds(DBatch b, GraphWs ws) {
     if (npass > 1 && nslot % npass != pass) return;
     u32 const key = ((nslot << 11) | lead) + 1u;
     u32 h = (key * 2654435761u) >> 17;  // kMmLdsCap == 1 << 15
-    for (u32 probe = 0; probe < kMmLdsCap; ++probe) {
+    for (u32 probe = 0; probe < (kTestProbe ? ws.mm_probe_max : kMmLdsCap); ++probe) {
       u32 cur = l_set[h];
       if (cur == 0) {
         u32 const old = atomicCAS(&l_set[h], 0u, key);
         cur = old == 0 ? key : old;
       }
-      if (cur == key) break;
+      if (cur == key) {
+        if constexpr (kTestProbe) return;
+        break;
+      }
       h = (h + 1) & (kMmLdsCap - 1);
     }
+    // No room.  The passes are sized by an instance COUNT, but the keys of a k-mer that a thousand read pairs carry all fall
+    // into its slot's pass: a pass can outgrow the set.  Never silent: the window is flagged like any other capacity, the
+    // retry pass re-assembles it from scratch and sends its mate-mers through the HBM set (k_support: mm_force_hbm).
+    // (the product kernel probes the whole set: a key finds no room only when NO entry is free -- seen below, for nothing,
+    //  as nkeys == kMmLdsCap; the test variant gives up after mm_probe_max probes and says so here)
+    if constexpr (kTestProbe) set_full = true;
   };
   auto const visit = [&](u32 ii, u32 word) { visit_slot(ii, inst_table_slot(word, ref_slot_g)); };
   // Only ~20 % of the instances are general ones: visiting them where they are found keeps 4 of 5 lanes idle
@@ -1467,6 +1478,7 @@ __global__ __launch_bounds__(kMmT) void k_mm_lds(DBatch b, GraphWs ws) {
   // registers first, so compacting in place is safe) and the rest of the set joins l_aux as counter space -- three
   // or four slot ranges instead of ten, each scanning only the keys.
   IPROF(13);  // scan + queue + set inserts
+  if (kTestProbe && set_full) atomicOr(&ws.win_flags[w], 4u);
   u32 nkeys = 0;
   {
     constexpr u32 kPer = kMmLdsCap / kMmT;  // 32 consecutive entries per thread
@@ -1499,6 +1511,7 @@ __global__ __launch_bounds__(kMmT) void k_mm_lds(DBatch b, GraphWs ws) {
     for (u32 x = 0; x < kPer; ++x)
       if (mine[x] != 0) l_set[at++] = mine[x];
     nkeys = total;
+    if (nkeys == kMmLdsCap && threadIdx.x == 0) atomicOr(&ws.win_flags[w], 4u);  // not an entry free: keys may have found no room
     __syncthreads();
   }
   IPROF(14);  // key compaction
@@ -1920,13 +1933,15 @@ int run_build_pass(ma_ctx* ctx, const DBatch& b, GraphWs& ws, u32* counters_dev,
     MA_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_support), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     static_cast<int>(lds_s)));
   ctx->tic("k_support");
+  ws.mm_probe_max = getenv("MA_MM_PROBE_MAX") ? static_cast<u32>(std::max(1, atoi(getenv("MA_MM_PROBE_MAX")))) : kMmLdsCap;
   MA_HIP(ctx, hipMemsetAsync(counters_dev + 1, 0, 8, ctx->stream));
   hipLaunchKernelGGL(k_support, dim3(ws.n_active), dim3(kSupT), lds_s, ctx->stream, b, ws, counters_dev + 1, sup_cache, xs_log2);
   ctx->toc();
   // windows whose general instances fit an LDS set are finished by k_mm_lds; the HBM-resident set only has to
   // hold what the remaining windows routed to it (usually nothing)
   ctx->tic("k_mm_lds");
-  hipLaunchKernelGGL(k_mm_lds, dim3(ws.n_active), dim3(kMmT), 0, ctx->stream, b, ws);
+  if (ws.mm_probe_max < kMmLdsCap) hipLaunchKernelGGL(k_mm_lds<true>, dim3(ws.n_active), dim3(kMmT), 0, ctx->stream, b, ws);
+  else hipLaunchKernelGGL(k_mm_lds<false>, dim3(ws.n_active), dim3(kMmT), 0, ctx->stream, b, ws);
   ctx->toc();
   u32 max_gen[2] = {0, 0};
   MA_HIP(ctx, hipMemcpyAsync(max_gen, counters_dev + 1, 8, hipMemcpyDeviceToHost, ctx->stream));

@@ -45,6 +45,8 @@ struct GraphWs {
   u32 max_read_len;       // longest read of the batch
   // table
   int tc_log2, mc_log2;
+  u32 mm_probe_max;  // k_mm_lds: probes after which its LDS set counts as full (tests lower it: MA_MM_PROBE_MAX)
+  u32 mm_force_hbm;  // capacity retry passes: every window's mate-mers through the HBM set (k_mm_insert / k_count)
   u32 inst_stride;
   u64* tbl_key;
   u32* tbl_first;

@@ -775,6 +775,30 @@ def test_whole_chain_parity_on_the_harder_bench_shapes(kw, pk):
         assert (wa["win_k"] > 40).any(), wa["win_k"].tolist()
 
 
+def test_mate_mer_set_that_fills_up_is_split_not_truncated(monkeypatch):
+    """k_mm_lds keeps a window's (k-mer, read pair) keys in an LDS set, one class of table slots per pass.  The classes are
+    sized by an instance COUNT; the keys of a k-mer that many read pairs carry all fall into one class, so a class can
+    outgrow the set.  A pass whose set fills up is dropped before it counts and its class is split in two -- forced here by
+    declaring the set full after six probes: same graphs, same supports, same calls as the oracle."""
+    from lancet2_amd.engine import Engine
+    monkeypatch.setenv("MA_MM_PROBE_MAX", "6")
+    params = capi.default_params(min_k=25, max_k=25)
+    arrs, n, nr = synth.make_config_batch("C3", 8, first_index=87_500, softclip_frac=0.05, n_frac=0.03)
+    orc = OracleEngine(params)
+    wa = orc.assemble(arrs, n, nr)
+    wv = orc.msa(arrs, n, nr, wa)
+    wq = orc.genotype(arrs, n, nr, wa, wv)
+    eng = Engine(params)
+    try:
+        g, a, v, q = eng.process(arrs, n, nr, debug=True)
+    finally:
+        eng.close()
+    assert not (a["win_status"] & capi.MA_W_TABLE_OVERFLOW).any()
+    bad = compare_asm(params, a, wa, n) + compare_vars(params, v, wv, n)
+    bad += compare_geno(params, q, wq, n, nr, wv["win_nvars"], arrs["read_win_off"])
+    assert not bad, "\n".join(bad[:12])
+
+
 def test_packed_two_pairs_per_lane_aligner_is_the_one_pair_aligner(monkeypatch):
     """MA_ALIGN_PK=1: the two busiest register classes of the read aligner run two pairs per lane on packed 16-bit halves
     (align.hip: k_align_reg2p -- decisions as bit planes, walks back in k_align_tb2) for the pairs whose region cannot reach a
