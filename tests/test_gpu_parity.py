@@ -778,8 +778,9 @@ def test_whole_chain_parity_on_the_harder_bench_shapes(kw, pk):
 def test_mate_mer_set_that_fills_up_is_split_not_truncated(monkeypatch):
     """k_mm_lds keeps a window's (k-mer, read pair) keys in an LDS set, one class of table slots per pass.  The classes are
     sized by an instance COUNT; the keys of a k-mer that many read pairs carry all fall into one class, so a class can
-    outgrow the set.  A pass whose set fills up is dropped before it counts and its class is split in two -- forced here by
-    declaring the set full after six probes: same graphs, same supports, same calls as the oracle."""
+    outgrow the set.  A window whose set fills up is flagged like any other capacity and the retry pass sends its mate-mers
+    through the HBM set -- forced here by declaring the set full after six probes: same graphs, same supports, same calls as
+    the oracle, no flag left."""
     from lancet2_amd.engine import Engine
     monkeypatch.setenv("MA_MM_PROBE_MAX", "6")
     params = capi.default_params(min_k=25, max_k=25)
