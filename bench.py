@@ -270,8 +270,10 @@ def make_windows(config, count, first, str_every, workers, indices=None, over=No
 _START = None  # multi-worker baseline: every worker finishes synthesising its windows before any of them is timed
 
 
-def _oracle_chunk(job):
-    """One worker of the CPU baseline: the whole path (oracle) over `count` windows starting at `first`."""
+def _oracle_chunk(job, keep=True):
+    """One worker of the CPU baseline: the whole path (oracle) over `count` windows starting at `first` (or over the windows
+    a list names).  keep: the oracle's outputs come back too -- they are what `parity_sample` checks the engine's outputs
+    for the very same windows against after the timed region (the checker role; never the thing measured)."""
     config, first, count, num_samples, str_every = job
     sys.path.insert(0, os.path.join(REPO, "tests"))
     from harness import OracleEngine
@@ -285,11 +287,16 @@ def _oracle_chunk(job):
         except Exception:
             pass
     t0 = time.perf_counter()
-    orc.gate(sub, sn, snr)
+    og = orc.gate(sub, sn, snr)
     oa = orc.assemble(sub, sn, snr)
     ov = orc.msa(sub, sn, snr, oa)
-    orc.genotype(sub, sn, snr, oa, ov, debug=False)
-    return sn, time.perf_counter() - t0
+    oq = orc.genotype(sub, sn, snr, oa, ov, debug=False)
+    dt = time.perf_counter() - t0
+    kept = None
+    if keep:
+        kept = {"config": config, "windows": list(first) if isinstance(first, (list, tuple)) else list(range(first, first + sn)),
+                "gate": og, "asm": oa, "var": ov, "geno": oq}
+    return sn, dt, kept
 
 
 def effective_cores():
@@ -336,7 +343,8 @@ def cpu_baselines(args, num_samples):
         os.environ["MA_ORACLE_LIB"] = native
     flags = "-O3 -march=native" if native else "-O2 (portable build: the native one did not build)"
     n1 = args.cpu_windows
-    sn, ct = _oracle_chunk((args.config, 10_000, n1, num_samples, args.str_every))
+    sn, ct, kept1 = _oracle_chunk((args.config, 10_000, n1, num_samples, args.str_every))
+    kept = [kept1]
     cpu = {"value": round(sn / ct, 3), "unit": "windows/s", "cores": 1, "kind": "port",
            "sample": f"the first {sn} windows of the same {args.config} workload through the metric's path (gate, assembly, "
                      f"POA/variants, genotyping; oracle built {flags}, 1 thread, {ct:.1f} s)"}
@@ -362,11 +370,71 @@ def cpu_baselines(args, num_samples):
     _START = None
     tot = sum(r[0] for r in res)
     slowest = max(r[1] for r in res)  # workers run concurrently; input synthesis (Python) is not timed
+    kept += [r[2] for r in res]
     cpu_mt = {"value": round(tot / slowest, 3), "unit": "windows/s", "cores": cores, "kind": "port",
               "sample": f"{tot} windows, one oracle process per usable core ({cores} x {per} windows; affinity mask cut to "
                         f"the cgroup quota, os.cpu_count() = {os.cpu_count()}), slowest worker {slowest:.1f} s"}
+    # (iii) BASELINE.json configs[3]: a few deep-panel windows (7 k reads each; incl. windows whose LDS mate-mer set fills up
+    #       and windows that end at the reference's traversal cap), one oracle process per window, each on one thread
+    cpu_c4 = None
+    if args.c4_windows > 0 and args.config == "C3" and not args.no_also:
+        c4_idx = [i for i in C4_PARITY_WINDOWS if i < 10_000 + args.c4_windows]
+        if c4_idx:
+            jobs = [("C4", [i], 0, 2, 0) for i in c4_idx]
+            with ctx.Pool(min(cores, len(jobs))) as pool:
+                res4 = pool.map(_oracle_chunk, jobs, chunksize=1)
+            kept += [r[2] for r in res4]
+            t4 = sum(r[1] for r in res4)
+            cpu_c4 = {"value": round(len(res4) / t4, 4), "unit": "windows/s", "cores": 1, "kind": "port",
+                      "sample": f"{len(res4)} deep-panel windows of the c4_panel leg (indices {c4_idx}), one oracle process per "
+                                f"window run side by side, value = windows / sum of the per-window times ({t4:.1f} s of CPU)"}
     os.environ.pop("MA_ORACLE_LIB", None)
-    return cpu, cpu_mt
+    return cpu, cpu_mt, cpu_c4, kept
+
+
+# deep-panel windows the parity sample covers (indices of the c4_panel leg's seeded windows): the two whose LDS mate-mer set
+# fills up (the retry pass re-assembles them through the HBM set), windows that end at the reference's 2^20-pop traversal cap,
+# windows over the caller's default haplotype caps, ordinary ones
+C4_PARITY_WINDOWS = [10_488,                            # LDS mate-mer set fills up in the first pass (tools/dbg/c4_flags.py)
+                     10_007, 10_011, 10_012, 10_016,    # end at the traversal cap
+                     10_056, 10_098,                    # traversal cap AND more haplotypes than the default cap of 16
+                     10_000, 10_002, 10_022]            # ordinary deep windows
+
+
+def parity_check(kept, config, first, lp, n, out_dev):
+    """The engine's outputs for the windows the cpu_baseline legs ran the oracle on, against the oracle's (gate, assembly,
+    variants, allele counts / PL / GQ bit for bit, QUAL within 1e-9).  out_dev = (gate, asm, var, geno) dicts of device
+    byte tensors of a batch of `n` windows whose window j is the seeded window first + j of `config`.
+    -> (windows checked, mismatch strings)"""
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    from harness import compare_asm, compare_geno_calls, compare_vars
+    from lancet2_amd import capi
+    specs = (capi.gate_out_spec(n), capi.asm_out_spec(lp, n), capi.var_out_spec(lp, n), capi.geno_out_spec(lp, n, 0, debug=False))
+
+    def rows(dev, spec, w0, cnt):
+        got = {}
+        for key, (dt, sz) in spec.items():
+            per = sz // n * np.dtype(dt).itemsize
+            got[key] = dev[key][w0 * per:(w0 + cnt) * per].cpu().numpy().view(dt)
+        return got
+
+    checked, bad = 0, []
+    for kp in kept:
+        if kp is None or kp["config"] != config:
+            continue
+        wins = kp["windows"]
+        runs = [(wins[0] - first, len(wins))] if wins == list(range(wins[0], wins[0] + len(wins))) else [(w - first, 1) for w in wins]
+        if any(w0 < 0 or w0 + cnt > n for w0, cnt in runs):
+            continue
+        cnt_all = len(wins)
+        got = [{k_: np.concatenate([rows(dev, spec, w0, cnt)[k_] for w0, cnt in runs]) for k_ in spec} for dev, spec in zip(out_dev, specs)]
+        here = [] if np.array_equal(got[0]["max_approx"], kp["gate"]["max_approx"]) and \
+            np.array_equal(got[0]["max_exact"], kp["gate"]["max_exact"]) else ["repeat gate differs"]
+        here += compare_asm(lp, got[1], kp["asm"], cnt_all) + compare_vars(lp, got[2], kp["var"], cnt_all)
+        here += compare_geno_calls(got[3], kp["geno"])
+        bad += [f"{config} windows {wins[0]}..{wins[-1]}: {m}" for m in here[:4]]
+        checked += cnt_all
+    return checked, bad
 
 
 def count_gpus_sysfs():
@@ -445,9 +513,10 @@ def main():
         c4_arrs = make_windows("C4", min(distinct, args.c4_windows), first, 0, workers) if args.c4_windows > 0 else None
         c5_arrs = make_windows("C5", min(distinct, 2048), first, args.str_every, workers)
     t_gen = time.perf_counter() - t_gen
-    cpu = cpu_mt = None
+    cpu = cpu_mt = cpu_c4 = None
+    kept = []
     if world == 1 and not args.no_cpu and args.cpu_windows > 0:
-        cpu, cpu_mt = cpu_baselines(args, num_samples)
+        cpu, cpu_mt, cpu_c4, kept = cpu_baselines(args, num_samples)
 
     import torch
     import torch.distributed as dist
@@ -517,6 +586,16 @@ def main():
     elapsed = time.perf_counter() - t0
     ktimes = eng.kernel_times()
     stats = eng.stats()
+    # ---- parity sample: the outputs of the LAST timed step for the windows the cpu_baseline legs ran the oracle on ----
+    parity = None
+    if kept and world == 1:
+        pc, pbad = parity_check(kept, args.config, first, params, n, (g, a, v, q))
+        parity = {"windows": pc, "mismatches": len(pbad), "c4_windows": 0,
+                  "checked": "repeat gate, haplotypes / weights / statistics (f64 bit patterns), variants and alleles, allele counts, "
+                             "PL / GQ: equal; QUAL within 1e-9 -- engine outputs of the last timed step vs the oracle's for the "
+                             "same windows (the cpu_baseline legs' own outputs)"}
+        if pbad:
+            parity["first_mismatches"] = pbad[:6]
     # SEQ_CX / GRAPH_CX annotation of the batch's variants (a "next" row: not part of the metric's
     # path) -- timed on its own, after the timed region, and reported beside it
     eng.timing_control(0)
@@ -673,7 +752,7 @@ def main():
                              "assembled_fraction": round(c_asm, 4)}
         ceng.close()
         # (2) the other WGS-shaped config, and the headline's windows sequenced 2 x 250
-        def device_leg(batch, label, leg_params=None, max_windows=None, kernels=False):
+        def device_leg(batch, label, leg_params=None, max_windows=None, kernels=False, parity_config=None):
             lp = leg_params or params
             o_arrs, o_n0, o_nr0 = batch
             o_arrs, o_n, o_nr = synth.tile_batch(o_arrs, o_n0, o_nr0, max(1, min(args.windows, n, max_windows or args.windows) // o_n0))
@@ -710,6 +789,13 @@ def main():
                                                     "MA_W_CIGAR_OVERFLOW", "MA_W_READ_OVERFLOW")
                                          if ((ost & np.uint32(getattr(capi, nm))) != 0).any()}
                 res["windows_at_traversal_limit"] = int(((ost & capi.MA_W_BFS_LIMIT) != 0).sum())
+            if parity_config and kept and parity is not None:  # the oracle ran some of this leg's windows too (cpu_baselines)
+                pc, pbad = parity_check(kept, parity_config, first, lp, o_n, (g, a, v, o_q))
+                res["parity_sample"] = {"windows": pc, "mismatches": len(pbad)}
+                parity["c4_windows"] += pc
+                parity["mismatches"] += len(pbad)
+                if pbad:
+                    parity.setdefault("first_mismatches", []).extend(pbad[:6])
             oeng.close()
             del o_dbatch, o_q
             return res
@@ -719,7 +805,9 @@ def main():
         if long_arrs is not None:
             also["reads_2x250"] = device_leg(long_arrs, WORKLOADS[args.config] + " -- sequenced as 2 x 250 bp reads")
         if c4_arrs is not None:  # 7.1 k reads a window; a panel has ~10 k windows: 2048 per step (512 distinct, tiled)
-            also["c4_panel"] = device_leg(c4_arrs, WORKLOADS["C4"], max_windows=max(c4_arrs[1], 2048), kernels=True)
+            also["c4_panel"] = device_leg(c4_arrs, WORKLOADS["C4"], max_windows=max(c4_arrs[1], 2048), kernels=True, parity_config="C4")
+            if cpu_c4:
+                also["c4_panel"]["cpu_baseline"] = cpu_c4
             also["c4_panel_512"] = device_leg(c4_arrs, WORKLOADS["C4"] + " -- 512 windows per step, every one distinct", max_windows=c4_arrs[1])
         if c5_arrs is not None:
             p5 = capi.default_params(min_k=25, max_k=25)
@@ -861,6 +949,7 @@ def main():
                        "sharding": "static, one process per GPU, no collective",
                        "input_synthesis_s": round(t_gen, 1)},
             "roofline": roof, "roofline_valu": roof_valu, "cpu_baseline": cpu, "cpu_baseline_all_cores": cpu_mt,
+            "parity_sample": parity,
             "step_algorithmic": {"MB_per_step": round(step_bytes / 1e6, 1),
                                  "GB_per_s": round(step_bytes / (elapsed / args.steps) / 1e9, 1),
                                  "frac_of_hbm_peak": round(step_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 5)},
@@ -882,6 +971,8 @@ def main():
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+    if rank == 0 and parity and parity["mismatches"]:
+        sys.exit(3)  # a fast step whose results differ from the oracle's is not a result
 
 
 if __name__ == "__main__":

@@ -1887,6 +1887,251 @@ __global__ __launch_bounds__(kBT) void k_edge_sort(GraphWs ws) {
   }
 }
 
+// k_graph: k_rank + k_edges + k_edge_sort for the common window in ONE workgroup-per-window kernel that streams the
+// instance words ONCE (the three kernels streamed them twice, marked first instances in them with atomics, and went through
+// HBM for the slot -> node map, the edge slots' 0xFF initialisation and the order keys).
+//   * ranking without the instance stream: a survivor's rank is the number of survivors with a smaller FIRST instance, and
+//     the table already holds every slot's first instance -- a bitmap over the instance indices (one bit per survivor's first
+//     instance, 4 KB per 32 Ki instances), a prefix count per bitmap word, rank = prefix + popcount below the bit;
+//   * slot -> node and reference position -> node stay in LDS (u16) for the edge pass;
+//   * edges: one coalesced walk over consecutive instance words (16-byte loads); the distinct directed edges go into an LDS set
+//     probed from hash(SOURCE NODE) only, so that all edges of a node sit in one run of occupied entries: an edge's place in
+//     its node's list (EmplaceEdge order = order of first occurrence, node.h:59-64) is the number of that run's entries with
+//     the same source and a smaller order key -- no per-node counters, no order keys in HBM, no sort kernel.
+// LDS: 16 KB + 1 KB + 2 B per reference k-mer + max(ranking area, 8 B x kGrSet) = ~69 KB: two workgroups per CU.
+// A window this kernel does not take (table of more than 8192 slots, an edge set that fills up) is left untouched for
+// k_rank / k_edges / k_edge_sort, which skip the windows marked done here.
+constexpr int kGrT = 1024;
+constexpr u32 kGrSlots = 8192;   // table slots per window (k_insert's direct map: 6144 entries -> 8192 slots)
+constexpr u32 kGrSet = 6144;     // entries of the edge set
+constexpr u32 kGrProbe = 384;    // longest run of occupied entries a lookup walks before the window is handed back
+constexpr u32 kGrNone = 0xFFFFu;
+constexpr u32 kGrEmpty = 0xFFFFFFFFu;
+__host__ __device__ inline u32 graph_lds_bytes(u32 inst_stride, u32 ref_stride) {
+  u32 const nw = (inst_stride + 31u) / 32u + 1u;
+  u32 const rank_area = 4u * nw + 2u * nw + 4u * kSeqCap + 64u;
+  u32 const set_area = 8u * kGrSet;
+  return 2u * kGrSlots + kGrSlots / 8u + ((2u * ref_stride + 15u) & ~15u) + ((rank_area > set_area ? rank_area : set_area) + 15u & ~15u) + 64u;
+}
+__global__ __launch_bounds__(kGrT) void k_graph(DBatch b, GraphWs ws, u32 min_node_cov) {
+  extern __shared__ unsigned char lds_build[];
+  __shared__ u32 sh[kGrT / 64];
+  __shared__ u32 l_fail;
+  int const a = blockIdx.x;
+  int const w = static_cast<int>(ws.active[a]);
+  int const S = ws.num_samples, CW = S + 2;
+  int const tcl = tbl_log2(ws);
+  u32 const tcap = 1u << ws.win_tc[a];
+  u32 const ninst = ws.win_ninst[w], nref = ninst - ws.win_nread_inst[w];
+  u32 const nw = (ws.inst_stride + 31u) / 32u + 1u;
+  if (threadIdx.x == 0) ws.gr_done[a] = 0;
+  if ((ws.win_flags[w] & 4u) || tcap > kGrSlots || ninst > ws.inst_stride || ws.nc > 32768u) return;  // (uniform)
+  const u64* keys = ws.tbl_key + (static_cast<size_t>(a) << tcl);
+  const u32* first = ws.tbl_first + (static_cast<size_t>(a) << tcl);
+  const u32* cnt = ws.tbl_cnt + (static_cast<size_t>(a) << tcl) * CW;
+  const u32* inst_slot = ws.inst_slot + static_cast<size_t>(a) * ws.inst_stride;
+  const u32* ref_slot_g = ws.ref_slot + static_cast<size_t>(a) * ws.ref_stride;
+  size_t const nb = static_cast<size_t>(a) * ws.nc;
+  // LDS carve
+  u16* l_node = reinterpret_cast<u16*>(lds_build);                        // [kGrSlots] slot -> node
+  u32* l_sign = reinterpret_cast<u32*>(lds_build + 2u * kGrSlots);        // [kGrSlots / 32] node -> stored sign is PLUS
+  u16* l_refn = reinterpret_cast<u16*>(lds_build + 2u * kGrSlots + kGrSlots / 8u);  // [ref_stride] reference position -> node
+  unsigned char* area = lds_build + 2u * kGrSlots + kGrSlots / 8u + ((2u * ws.ref_stride + 15u) & ~15u);
+  u32* l_bits = reinterpret_cast<u32*>(area);                 // ranking: [nw] first instances of the survivors
+  u32* l_base = l_bits + nw;                                  //          [kSeqCap] instance bases of the sequences
+  u16* l_pref = reinterpret_cast<u16*>(l_base + kSeqCap);     //          [nw] survivors before the bitmap word
+  u32* l_key = reinterpret_cast<u32*>(area);                  // edges:   [kGrSet] src << 15 | dst << 2 | kind
+  u32* l_ok = l_key + kGrSet;                                 //          [kGrSet] order key of the first occurrence
+  int const lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  u32 const ns = seq_count(b, w);
+  u32 const base_idx = b.read_win_off[w] + w;
+
+  for (u32 i = threadIdx.x; i < nw; i += kGrT) l_bits[i] = 0;
+  for (u32 i = threadIdx.x; i < kGrSlots / 2u; i += kGrT) reinterpret_cast<u32*>(l_node)[i] = 0xFFFFFFFFu;
+  for (u32 i = threadIdx.x; i < kGrSlots / 32u; i += kGrT) l_sign[i] = 0;
+  const u32* sbase = stage_seq_bases(ws.seq_inst_base + base_idx, ns, l_base);
+  if (threadIdx.x == 0) l_fail = 0;
+  __syncthreads();
+  // ---- 1. survivors of RemoveLowCovNodes(0) (graph.cpp:363-390; node.cpp:38-42): their first instances into the bitmap ----
+  constexpr u32 kPer = kGrSlots / kGrT;  // 8 slots per thread, every load of the trip in flight together
+  u32 fi[kPer];
+  u32 surv = 0;
+#pragma unroll
+  for (u32 j = 0; j < kPer; ++j) {
+    u32 const s = threadIdx.x + j * kGrT;
+    u32 const sc = s < tcap ? s : 0u;
+    u64 const ky = keys[sc];
+    fi[j] = first[sc];
+    u32 total = 0;
+    bool any = false, all = true;
+    for (int i = 0; i < S; ++i) {
+      u32 const c = cnt[static_cast<size_t>(sc) * CW + i];
+      total += c;
+      any |= c > 0;
+      all &= c <= 1;
+    }
+    bool const remove = (any && all) || total < min_node_cov;
+    if (s < tcap && ky != 0 && !remove && fi[j] < ninst) surv |= 1u << j;
+  }
+#pragma unroll
+  for (u32 j = 0; j < kPer; ++j)
+    if (surv & (1u << j)) atomicOr(&l_bits[fi[j] >> 5], 1u << (fi[j] & 31u));
+  __syncthreads();
+  // ---- 2. survivors before every bitmap word (block scan over the words' popcounts) ----
+  u32 total_nodes;
+  {
+    u32 const per = (nw + kGrT - 1u) / kGrT;
+    u32 const w0 = threadIdx.x * per;
+    u32 mine = 0;
+    for (u32 x = 0; x < per; ++x)
+      if (w0 + x < nw) mine += __popc(l_bits[w0 + x]);
+    u32 inc = mine;
+    for (int d = 1; d < 64; d <<= 1) {
+      u32 const y = __shfl_up(inc, d);
+      if (lane >= d) inc += y;
+    }
+    if (lane == 63) sh[wave] = inc;
+    __syncthreads();
+    u32 before = 0, tot = 0;
+    for (int x = 0; x < kGrT / 64; ++x) {
+      u32 const t = sh[x];
+      if (x < wave) before += t;
+      tot += t;
+    }
+    total_nodes = tot;
+    u32 run = before + inc - mine;
+    if (tot < 65535u)
+      for (u32 x = 0; x < per; ++x)
+        if (w0 + x < nw) {
+          l_pref[w0 + x] = static_cast<u16>(run);
+          run += __popc(l_bits[w0 + x]);
+        }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) ws.n_nodes[a] = total_nodes;
+  if (total_nodes >= ws.nc || total_nodes >= 65535u) {  // capacity exceeded: flagged (k_rank's rule), the retry passes grow it
+    if (threadIdx.x == 0) {
+      atomicOr(&ws.win_flags[w], 4u);
+      ws.gr_done[a] = 1;
+    }
+    return;
+  }
+  // ---- 3. node records, a thread per survivor (k_rank 2b) ----
+  u64 const win_read_off0 = b.read_off[b.read_win_off[w]];
+#pragma unroll
+  for (u32 j = 0; j < kPer; ++j) {
+    if (!(surv & (1u << j))) continue;
+    u32 const s = threadIdx.x + j * kGrT, ii = fi[j];
+    u32 const idx = l_pref[ii >> 5] + __popc(l_bits[ii >> 5] & ((1u << (ii & 31u)) - 1u));
+    l_node[s] = static_cast<u16>(idx);
+    u32 const v = inst_slot[ii];
+    u32 const sq = seq_of(sbase, ns, ii);
+    u32 const o = ii - sbase[sq];
+    u32 label = 1, srcbit = 0, rel_off = 0;  // Label::REFERENCE
+    if (sq > 0) {
+      u32 const r = b.read_win_off[w] + sq - 1;
+      label = (b.read_flags[r] & MA_RF_CASE) ? 4u : 2u;  // Label::CASE / Label::CTRL
+      srcbit = 0x80000000u;
+      rel_off = static_cast<u32>(b.read_off[r] - win_read_off0);
+    }
+    for (int i = 0; i < S; ++i) ws.nd_cnt[(nb + idx) * S + i] = cnt[static_cast<size_t>(s) * CW + i];
+    ws.nd_role[(nb + idx) * 2 + 0] = cnt[static_cast<size_t>(s) * CW + S];
+    ws.nd_role[(nb + idx) * 2 + 1] = cnt[static_cast<size_t>(s) * CW + S + 1];
+    ws.nd_src[nb + idx] = srcbit | (rel_off + o);
+    ws.nd_label[nb + idx] = static_cast<u8>(label);
+    ws.nd_sign[nb + idx] = (v & kInstPlus) ? 1 : 0;
+    ws.nd_nedge[nb + idx] = 0;
+    if (v & kInstPlus) atomicOr(&l_sign[idx >> 5], 1u << (idx & 31u));
+  }
+  __syncthreads();  // (also: the ranking area is dead from here on)
+  // mRefNodeIds (graph.cpp:264-267): node of every reference k-mer, kNoNode when pruned
+  SeqInfo const rsi = seq_info(b, w, 0, win_kmer(ws, w));
+  u32* refn = ws.ref_node + static_cast<size_t>(a) * ws.ref_stride;
+  for (u32 p = threadIdx.x; p < ws.ref_stride; p += kGrT) {
+    u32 nd = kGrNone;
+    if (p < rsi.nk) nd = l_node[ref_slot_g[p] & (kGrSlots - 1u)];
+    l_refn[p] = static_cast<u16>(nd);
+    refn[p] = nd == kGrNone ? kNoNode : nd;
+  }
+  for (u32 i = threadIdx.x; i < kGrSet; i += kGrT) {
+    l_key[i] = kGrEmpty;
+    l_ok[i] = 0xFFFFFFFFu;
+  }
+  __syncthreads();
+  // ---- 4. an edge and its mirror per (k+1)-mer whose two k-mers survive (graph.cpp:333-337), distinct ones into the set ----
+  auto const h0_of = [&](u32 src) -> u32 { return __umulhi(src * 2654435761u, kGrSet); };
+  auto const set_insert = [&](u32 src, u32 val, u32 okey) {
+    u32 const key = (src << 15) | val;
+    u32 h = h0_of(src);
+    for (u32 probe = 0; probe < kGrProbe; ++probe) {
+      u32 cur = l_key[h];
+      if (cur == kGrEmpty) {
+        u32 const old = atomicCAS(&l_key[h], kGrEmpty, key);
+        cur = old == kGrEmpty ? key : old;
+      }
+      if (cur == key) {
+        atomicMin(&l_ok[h], okey);
+        return;
+      }
+      h = h + 1u == kGrSet ? 0u : h + 1u;
+    }
+    l_fail = 1;
+  };
+  auto const node_of = [&](u32 wd) -> u32 {
+    return (wd & kInstFast) ? l_refn[min(wd & kInstSlotMask, ws.ref_stride - 1u)] : l_node[wd & (kGrSlots - 1u)];
+  };
+  u32 const last = ninst > 0 ? ninst - 1 : 0;
+  u32 const last4 = last & ~3u;
+  // four consecutive (k+1)-mers per thread and trip: one 16-byte load + the neighbour's first word (the next trip's in flight)
+  for (u32 i0 = 4u * threadIdx.x; i0 < last; i0 += 4u * kGrT) {
+    uint4 const q4 = *reinterpret_cast<const uint4*>(inst_slot + min(i0, last4));
+    u32 nxt = __shfl_down(q4.x, 1);
+    if (lane == 63) nxt = inst_slot[min(i0 + 4u, last)];
+    u32 const wd[5] = {q4.x, q4.y, q4.z, q4.w, nxt};
+#pragma unroll
+    for (u32 j = 0; j < 4; ++j) {
+      u32 const ii = i0 + j;
+      u32 const wa = wd[j], wb = wd[j + 1];
+      if (ii >= last || (wa & kInstLast)) continue;
+      // both k-mers are reference nodes at consecutive positions: the reference's own edge, inserted (with a smaller order
+      // key) by the reference sequence itself
+      if (ii >= nref && (wa & kInstFast) && (wb & kInstFast) && (wb & kInstSlotMask) == (wa & kInstSlotMask) + 1) continue;
+      u32 const na = node_of(wa), nbn = node_of(wb);
+      if (na == kGrNone || nbn == kGrNone) continue;
+      // edge kind from the STORED signs of both nodes (graph.cpp:333-336)
+      u32 const sa_minus = ((l_sign[na >> 5] >> (na & 31u)) & 1u) ^ 1u, sb_minus = ((l_sign[nbn >> 5] >> (nbn & 31u)) & 1u) ^ 1u;
+      u32 const fwd = (sa_minus << 1) | sb_minus;                 // MakeFwdEdgeKind(sA, sB)
+      u32 const rev = ((sb_minus ^ 1u) << 1) | (sa_minus ^ 1u);   // RevEdgeKind(fwd) seen from B
+      set_insert(na, (nbn << 2) | fwd, 2u * ii);
+      set_insert(nbn, (na << 2) | rev, 2u * ii + 1u);
+    }
+  }
+  __syncthreads();
+  if (l_fail) return;  // (gr_done stays 0: the three general kernels redo this window from the table)
+  // ---- 5. every distinct edge to its place in its node's list ----
+  bool over = false;
+  for (u32 i = threadIdx.x; i < kGrSet; i += kGrT) {
+    u32 const key = l_key[i];
+    if (key == kGrEmpty) continue;
+    u32 const src = key >> 15, myok = l_ok[i];
+    u32 r = 0, m = 0, h = h0_of(src);
+    for (u32 probe = 0; probe < kGrSet; ++probe) {
+      u32 const kk = l_key[h];
+      if (kk == kGrEmpty) break;
+      if ((kk >> 15) == src) {
+        ++m;
+        r += l_ok[h] < myok;
+      }
+      h = h + 1u == kGrSet ? 0u : h + 1u;
+    }
+    if (r < static_cast<u32>(kEdgeCap)) ws.nd_edge[(nb + src) * kEdgeCap + r] = key & 0x7FFFu;
+    if (r == 0) ws.nd_nedge[nb + src] = static_cast<u8>(min(m, static_cast<u32>(kEdgeCap)));
+    over |= m > static_cast<u32>(kEdgeCap);  // more than kEdgeCap distinct edges at one node
+  }
+  if (over) atomicOr(&ws.win_flags[w], 4u);
+  if (threadIdx.x == 0) ws.gr_done[a] = 1;
+}
+
 // ---- host side: one k attempt of the build stage for the active windows ----
 int run_build_pass(ma_ctx* ctx, const DBatch& b, GraphWs& ws, u32* counters_dev, int tc_log2_alloc) {
   if (ws.n_active == 0) return MA_OK;

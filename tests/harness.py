@@ -216,6 +216,20 @@ def compare_geno(p, got, want, n, nr, win_nvars, read_win_off):
     return bad
 
 
+def compare_geno_calls(got, want):
+    """The call-level outputs of the genotype stage (what a caller that does not ask for the debug taps gets): allele
+    depths, PL, GQ equal; QUAL within 1e-9."""
+    bad = []
+    for key in ("allele_counts", "var_pl", "var_gq"):
+        if not np.array_equal(got[key], want[key]):
+            i = np.nonzero(got[key] != want[key])[0][:8]
+            bad.append(f"{key} differs at {i.tolist()}: got {got[key][i].tolist()} want {want[key][i].tolist()}")
+    dq = np.abs(got["var_qual"] - want["var_qual"]).max() if len(want["var_qual"]) else 0.0
+    if not dq <= 1e-9:
+        bad.append(f"var_qual max abs diff {dq}")
+    return bad
+
+
 SEQCX_FLOAT_TOL = 1e-5  # north_star's floating-point tolerance; the integer features must be equal
 
 
