@@ -65,8 +65,8 @@ __global__ __launch_bounds__(256) void k_flag_long_reads(DBatch b, ma_asm_out_t 
 // Workload statistics for bench.py's algorithmic-byte model; launched only in ma_timing_control mode 3.
 __global__ __launch_bounds__(256) void k_workload_stats(GraphWs ws, unsigned long long* acc) {
   int const a = blockIdx.x;
-  const u64* keys = ws.tbl_key + (static_cast<size_t>(a) << ws.tc_log2);
-  u32 const slots = 1u << ws.win_tc[a];
+  const u64* keys = ws.tbl_key + (static_cast<size_t>(a) << tbl_log2(ws));
+  u32 const slots = ws.win_nslots[a];
   u32 cnt = 0;
   for (u32 i = threadIdx.x; i < slots; i += 256) cnt += keys[i] != 0;
   __shared__ u32 sh[256];
@@ -433,6 +433,7 @@ int launch_assemble(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& out, const
   ws.pool_cap = 49152;
 
   // per-window workspace footprint -> chunk size
+  size_t mm_share = 0;  // bytes of the mate-mer pool per window of the chunk (set per pass below)
   auto carve_ws = [&](Carver& c, GraphWs& g, size_t A) {
     size_t const tcap = size_t(1) << g.tc_log2, mcap = size_t(1) << g.mc_log2, NC = g.nc;
     g.tbl_key = c.take<u64>(A * tcap);
@@ -443,8 +444,19 @@ int launch_assemble(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& out, const
     g.slowq = c.take<u32>(A * g.inst_stride);
     g.n_slow = c.take<u32>(A);
     g.mm_mode = c.take<u32>(A);
-    g.win_tc = c.take<u32>(A);
-    (void)mcap;  // (the HBM mate-mer set is reserved by run_build_pass when a window needs it: ma_ctx::ws_mm)
+    g.win_nslots = c.take<u32>(A);
+    g.slow_id = c.take<u64>(A * g.inst_stride);
+    g.gr_done = c.take<u32>(A);
+    // HBM-resident mate-mer sets: a pool the windows that need one carve theirs out of (k_support).  A full set per window
+    // when every window will need one (no mapping hints; capacity retries route every mate-mer through it), a token share
+    // otherwise -- the pool is part of the chunk's budgeted workspace either way (round 4 reserved it on demand, outside the
+    // budget: tens of GB for a chunk of deep windows without hints)
+    g.mm_off = c.take<unsigned long long>(A);
+    g.mm_log2 = c.take<u32>(A);
+    g.mm_pool_used = c.take<unsigned long long>(1);
+    g.mm_pool_bytes = static_cast<unsigned long long>(A) * mm_share;
+    g.mm_pool = c.take<u8>(g.mm_pool_bytes + 256);
+    (void)mcap;
     g.n_nodes = c.take<u32>(A);
     g.nd_cnt = c.take<u32>(A * NC * S);
     g.nd_role = c.take<u32>(A * NC * 2);
@@ -501,6 +513,11 @@ int launch_assemble(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& out, const
     u32 const grow = pass == 0 ? 1u : (pass == 1 ? 4u : 16u);
     int const tc_log2_alloc = pass == 0 ? tc_first : tc_full;
     ws.mm_force_hbm = pass > 0 ? 1u : 0u;  // (a window whose LDS mate-mer set filled up comes back here: build.hip, k_mm_lds)
+    {
+      size_t const full = ((size_t(12) << mc_log2_alloc) + 255) & ~size_t(255);
+      mm_share = (b.read_hint == nullptr || pass > 0) ? full : std::min<size_t>(full, size_t(256) << 10);
+      if (const char* e = pass == 0 ? getenv("MA_MM_POOL_KB") : nullptr) mm_share = static_cast<size_t>(atoi(e)) << 10;  // tests: a pool that runs out
+    }
     ws.nc = nc0 * grow;
     // the arena of the last pass holds what the reference's own cap allows: 2^20 pops (max_flow.h:69), a few pushes each
     // (components of more than ~400 nodes search unfolded, clean.hip)

@@ -171,9 +171,12 @@ __device__ __forceinline__ const u32* stage_seq_bases(const u32* gbase, u32 ns, 
   return l_base;
 }
 
-__device__ __forceinline__ u32 table_insert(u64* keys, u32 mask, u64 id) {
+// (flags: the window's flag word -- once the table has been found full (bit 2) nobody probes all of it again: a first pass that
+//  plans a quarter of a deep window's instances makes "full" an expected event, and every id without room walked 2^18 slots)
+__device__ __forceinline__ u32 table_insert(u64* keys, u32 mask, u64 id, const u32* flags) {
   u32 slot = static_cast<u32>(id) & mask;
   for (u32 probe = 0; probe <= mask; ++probe) {
+    if ((probe & 255u) == 255u && (*reinterpret_cast<const volatile u32*>(flags) & 4u)) return kNoNode;
     u64 cur = keys[slot];
     if (cur == id) return slot;
     if (cur == 0) {
@@ -289,6 +292,10 @@ __device__ unsigned long long g_iprof[16];
 #define KPROF(slot) do {} while (0)
 #endif
 constexpr u32 classify_mask_words(u32 max_read_len) { return (max_read_len + 31) / 32 + 1; }  // per read: slow-instance bits
+// slow-queue item: [11:0] offset of the k-mer in its sequence, [28:12] sequence, [29] last k-mer of its sequence, [30] error-free,
+// [31] canonical == as-seen (set by k_insert once it has hashed the k-mer) -- everything k_insert needs to write the instance
+// word without reading it first
+constexpr u32 kQPlus = 1u << 31, kQErrFree = 1u << 30, kQLast = 1u << 29, kQSeqMask = 0x1FFFFu;
 __global__ __launch_bounds__(64) void k_classify(DBatch b, GraphWs ws, u32* max_slow, u32 tiles_per_win, u32 tile_cap) {
   extern __shared__ unsigned char lds_build[];
   int const a = blockIdx.x / tiles_per_win;
@@ -312,6 +319,7 @@ __global__ __launch_bounds__(64) void k_classify(DBatch b, GraphWs ws, u32* max_
   u8* l_bases = lds_build + ref_cap + 2048;
   u8* l_quals = l_bases + tile_cap;
   u32* l_mask = reinterpret_cast<u32*>(l_quals + tile_cap);  // [64][MW] bit o of read (lane): instance o is slow
+  u32* l_emask = l_mask + 64u * MW;                           // [64][MW] bit o: instance o is error-free
   SeqInfo const rsi = seq_info(b, w, 0, k);
   i32 const ref_len = static_cast<i32>(rsi.len);
   {
@@ -413,7 +421,8 @@ __global__ __launch_bounds__(64) void k_classify(DBatch b, GraphWs ws, u32* max_
         }
       }
       u32* mw = l_mask + static_cast<u32>(lane) * MW;
-      u32 sacc = 0;
+      u32* ew = l_emask + static_cast<u32>(lane) * MW;
+      u32 sacc = 0, eacc = 0;
       for (u32 o = 0; o < nk; o += 4) {
         u32 qo[4], qi[4], so[4], si4[4], ro[4], ri[4];
 #pragma unroll
@@ -440,6 +449,7 @@ __global__ __launch_bounds__(64) void k_classify(DBatch b, GraphWs ws, u32* max_
             // floor(prefix[o+k] - prefix[o]) == 0  <=>  difference < 1.0 (prefix is non-decreasing)
             bool const errfree = (lead - lag) < 1.0;
             u32 word = (errfree ? kInstErrFree : 0u) | (oo + 1 == nk ? kInstLast : 0u);
+            eacc |= (errfree ? 1u : 0u) << (oo & 31u);
             if (use_hint && mm == 0) {  // FAST: byte-identical to the reference k-mer at hint + o
               word |= static_cast<u32>(hint + static_cast<i32>(oo)) | kInstFast;
             } else {
@@ -474,7 +484,8 @@ __global__ __launch_bounds__(64) void k_classify(DBatch b, GraphWs ws, u32* max_
         }
         if (((o + 4) & 31u) == 0 || o + 4 >= nk) {  // (o is a multiple of 4: a mask word fills up exactly at a trip's end)
           mw[o >> 5] = sacc;
-          sacc = 0;
+          ew[o >> 5] = eacc;
+          sacc = eacc = 0;
         }
       }
     }
@@ -495,17 +506,16 @@ __global__ __launch_bounds__(64) void k_classify(DBatch b, GraphWs ws, u32* max_
   qbase = __shfl(qbase, 0);
   u32 at = qbase + inc - nslow;
   if (nslow) {
-    if (all_slow) {
-      for (u32 o = 0; o < my_nk; ++o) slowq[at++] = (s_idx << 12) | o;
-    } else {
-      u32 const* mw = l_mask + static_cast<u32>(lane) * MW;
-      for (u32 x = 0; 32 * x < my_nk; ++x) {
-        u32 m = mw[x];
-        while (m) {
-          u32 const bit = __ffs(m) - 1;
-          m &= m - 1;
-          slowq[at++] = (s_idx << 12) | (x * 32 + bit);
-        }
+    u32 const* mw = l_mask + static_cast<u32>(lane) * MW;
+    u32 const* ew = l_emask + static_cast<u32>(lane) * MW;
+    for (u32 x = 0; 32 * x < my_nk; ++x) {
+      u32 m = all_slow ? 0xFFFFFFFFu : mw[x];
+      u32 const e = ew[x];
+      if (32 * x + 32 > my_nk) m &= (1u << (my_nk - 32 * x)) - 1u;
+      while (m) {
+        u32 const bit = __ffs(m) - 1, o = x * 32 + bit;
+        m &= m - 1;
+        slowq[at++] = (s_idx << 12) | o | (((e >> bit) & 1u) ? kQErrFree : 0u) | (o + 1 == my_nk ? kQLast : 0u);
       }
     }
   }
@@ -629,37 +639,43 @@ __device__ __forceinline__ u64 kmer_id_lds(const u32* l_seq, u32 p, int k, bool*
 // k_mm_lds), each distinct k-mer goes into it once, and a last pass hands every instance its table slot.  k-mers that
 // do not fit the map (deep samples) are deferred and take the direct path with its atomics.
 constexpr int kInsT = 1024;
-constexpr u32 kInsMap = 6144;         // LDS map entries (48 KB of ids + 24 KB of first instances: two workgroups per CU)
-constexpr u32 kInsEntryMask = 8191;   // an instance word carries its map entry in 13 bits
-constexpr u32 kSeqWords = 12288;      // the window's read bases as 4-bit codes in LDS: 48 KB = 98 304 bases
-constexpr u32 kInstTemp = 1u << 26;   // instance word holds a map entry, not yet a table slot (slots are < 2^21);
-                                      // gone from the final words, k_rank reuses the bit as kInstFirst
-constexpr u32 kInstDefer = 1u << 25;  // instance waits for the direct path
+constexpr u32 kInsMap = 6144;         // LDS map entries (48 KB of ids + 24 KB of first instances)
+constexpr u32 kSeqWords = 16376;      // the window's read bases as 4-bit codes in LDS: 131 008 bases (+ 8 words of slack)
+constexpr u32 kInsArea = 12u * kInsMap;  // 73 728 B: the staged bases + sequence starts, THEN the map (two workgroups per CU)
+static_assert(4u * (kSeqWords + 8u) + 4u * kSeqCap <= kInsArea, "k_insert: the staging area must fit the map's");
+// Round 5: the kernel runs in two phases that share ONE 72 KB LDS area.  Phase A stages the window's read bases and
+// hashes every slow k-mer (ids to HBM, coalesced, each thread reading back only what it wrote itself); phase B builds the
+// map from the ids.  With the map and the staged bases side by side the kernel held 139 KB: one workgroup, four waves
+// per SIMD, per CU -- and every phase of it is a chain of round trips that wants more waves in flight.  The queue items
+// carry the instance's error-free / last bits (k_classify) and its canonical bit (phase A), so an instance word is
+// WRITTEN once, with its final table slot -- the LDS map's entry, which is what the table is copied out from -- and
+// never read: the old passes read and rewrote every slow instance's word twice (two 64-byte sectors per 4-byte word).
 __global__ __launch_bounds__(kInsT) void k_insert(DBatch b, GraphWs ws) {
-  __shared__ u64 l_key[kInsMap];
-  __shared__ u32 l_min[kInsMap];  // smallest instance of the id; after pass 2: its table slot | bit 31 "also a reference k-mer"
-  __shared__ u32 l_seq[kSeqWords + 8];  // (+ slack: the packed identity reads five words from a k-mer's first)
-  __shared__ u32 l_rpos[kSeqCap], l_ibase[kSeqCap];  // staged windows: per sequence, first base in l_seq and first instance
+  __shared__ __align__(16) unsigned char l_area[kInsArea];
   __shared__ u32 l_nmap, l_ndef, l_seq_ok;
+  u32* const l_seq = reinterpret_cast<u32*>(l_area);                               // phase A: [kSeqWords + 8]
+  u32* const l_rpos = reinterpret_cast<u32*>(l_area + 4u * (kSeqWords + 8u));      //          [kSeqCap] first base of a sequence in l_seq
+  u64* const l_key = reinterpret_cast<u64*>(l_area);                               // phase B: [kInsMap]
+  u32* const l_min = reinterpret_cast<u32*>(l_area + 8u * kInsMap);                //          [kInsMap] smallest instance of the id
   int const a = blockIdx.x;
   int const w = static_cast<int>(ws.active[a]);
   int const k = win_kmer(ws, w);
-  u64* keys = ws.tbl_key + (static_cast<size_t>(a) << ws.tc_log2);
-  u32* first = ws.tbl_first + (static_cast<size_t>(a) << ws.tc_log2);
+  int const tcl = tbl_log2(ws);
+  u64* keys = ws.tbl_key + (static_cast<size_t>(a) << tcl);
+  u32* first = ws.tbl_first + (static_cast<size_t>(a) << tcl);
   u32* inst_slot = ws.inst_slot + static_cast<size_t>(a) * ws.inst_stride;
-  const u32* slowq = ws.slowq + static_cast<size_t>(a) * ws.inst_stride;
+  u32* slowq = ws.slowq + static_cast<size_t>(a) * ws.inst_stride;
+  u64* ids = ws.slow_id + static_cast<size_t>(a) * ws.inst_stride;
   u32* ref_slot_g = ws.ref_slot + static_cast<size_t>(a) * ws.ref_stride;
   u32 const base_idx = b.read_win_off[w] + w;
+  u32 const r_first = b.read_win_off[w];
   SeqInfo const rsi = seq_info(b, w, 0, k);
   u32 const nq = ws.n_slow[a];
   IPROF_T0();
-  for (u32 i = threadIdx.x; i < kInsMap; i += kInsT) {
-    l_key[i] = 0;
-    l_min[i] = 0xFFFFFFFFu;
-  }
-  // The slow pass hashes ~16 k k-mers per window straight from the read bytes: chains of dependent HBM round trips per
-  // instance were 73 % of this kernel.  The window's read bases are therefore staged in LDS first (4 bit per base, aligned
-  // 8-byte loads) whenever they fit and hold nothing but A/C/G/T/N; deeper or odd windows hash from HBM as before.
+  // ================= phase A: ids =================
+  // The slow pass hashes ~16 k k-mers per window: straight from the read bytes that was a chain of dependent HBM round trips
+  // per instance.  The window's read bases are staged in LDS first (4 bit per base, aligned 8-byte loads) whenever they fit
+  // and hold nothing but A/C/G/T/N; deeper or odd windows hash from HBM.
   const u8* const seq_base = [&]() {
     const u8* const first_byte = b.read_bases + b.read_off[b.read_win_off[w]];
     return first_byte - (reinterpret_cast<uintptr_t>(first_byte) & 7u);
@@ -726,15 +742,68 @@ __global__ __launch_bounds__(kInsT) void k_insert(DBatch b, GraphWs ws) {
         encode_word(wd, v);
       }
     }
+    for (u32 wd = nwords + threadIdx.x; wd < nwords + 8u; wd += kInsT) l_seq[wd] = 0;  // (the packed identity reads five words)
     if (odd) l_seq_ok = 0;  // a base that is not A/C/G/T/N: the codes would not give its byte back
-    for (u32 sq = 1 + threadIdx.x; sq < ns_all; sq += kInsT) {  // sequence sq >= 1 is read read_win_off[w] + sq - 1
+    for (u32 sq = 1 + threadIdx.x; sq < ns_all; sq += kInsT)  // sequence sq >= 1 is read read_win_off[w] + sq - 1
       l_rpos[sq] = static_cast<u32>((b.read_bases + b.read_off[b.read_win_off[w] + sq - 1]) - seq_base);
-      l_ibase[sq] = ws.seq_inst_base[base_idx + sq];
-    }
     __syncthreads();
   }
   bool const staged = l_seq_ok != 0;
-  IPROF(0);  // init + staging
+  IPROF(0);  // staging
+  {  // reference k-mers (graph.cpp:264-267): instance index == reference position; ids[p]
+    const u8* s = b.ref_bases + rsi.off;
+    for (u32 p = threadIdx.x; p < rsi.nk; p += kInsT) {
+      bool plus;
+      ids[p] = kmer_id(s + p, k, &plus);
+      inst_slot[p] = (plus ? kInstPlus : 0u) | (p + 1 == rsi.nk ? kInstLast : 0u);  // (its slot: phase B)
+    }
+  }
+  // slow queue: ids[nk + x]; the item gets its canonical bit.  Four independent chains per thread.
+  constexpr int kIU = 4;
+  for (u32 x0 = threadIdx.x; x0 < nq; x0 += kInsT * kIU) {
+    u32 item[kIU];
+    u64 off[kIU], id[kIU];
+    bool live[kIU], plus[kIU];
+#pragma unroll
+    for (int u = 0; u < kIU; ++u) {
+      u32 const x = x0 + u * kInsT;
+      live[u] = x < nq;
+      item[u] = live[u] ? slowq[x] : 0u;
+    }
+#pragma unroll
+    for (int u = 0; u < kIU; ++u) {
+      u32 const s_idx = (item[u] >> 12) & kQSeqMask, o = item[u] & 0xFFFu;
+      if (staged) {  // (slow instances come from reads: s_idx >= 1)
+        off[u] = live[u] ? l_rpos[s_idx] + o : 0u;  // position in l_seq
+      } else {
+        SeqInfo const si = seq_info(b, w, live[u] ? s_idx : 0u, k);
+        off[u] = si.off + o;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < kIU; ++u) {
+      id[u] = 1;
+      plus[u] = true;
+      if (live[u])
+        id[u] = staged ? kmer_id_lds(l_seq, static_cast<u32>(off[u]), k, &plus[u]) : kmer_id(b.read_bases + off[u], k, &plus[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < kIU; ++u) {
+      if (!live[u]) continue;
+      u32 const x = x0 + u * kInsT;
+      ids[rsi.nk + x] = id[u];
+      slowq[x] = item[u] | (plus[u] ? kQPlus : 0u);
+    }
+  }
+  __threadfence_block();
+  __syncthreads();  // the staged bases are dead: the area becomes the map
+  IPROF(1);  // ids
+  // ================= phase B: the map =================
+  for (u32 i = threadIdx.x; i < kInsMap; i += kInsT) {
+    l_key[i] = 0;
+    l_min[i] = 0xFFFFFFFFu;
+  }
+  __syncthreads();
   // map entry of an id (kNoNode: no room along this probe sequence -- then there never will be for this id)
   auto map_entry = [&](u64 id) -> u32 {
     u32 e = static_cast<u32>(id >> 32) % kInsMap;
@@ -751,111 +820,103 @@ __global__ __launch_bounds__(kInsT) void k_insert(DBatch b, GraphWs ws) {
     }
     return kNoNode;
   };
-  // ---- pass 1: every k-mer into the map; its instance word temporarily names the map entry ----
-  {  // (A) reference k-mers (graph.cpp:264-267): instance index == reference position
-    const u8* s = b.ref_bases + rsi.off;
-    for (u32 p = threadIdx.x; p < rsi.nk; p += kInsT) {
-      bool plus;
-      u64 const id = kmer_id(s + p, k, &plus);
-      u32 const e = map_entry(id);
-      u32 const flags = (plus ? kInstPlus : 0u) | (p + 1 == rsi.nk ? kInstLast : 0u);
-      if (e != kNoNode) {
-        atomicMin(&l_min[e], p);
-        inst_slot[p] = e | kInstTemp | flags;
-      } else {
-        atomicAdd(&l_ndef, 1u);
-        inst_slot[p] = kInstDefer | flags;
-      }
+  auto map_find = [&](u64 id) -> u32 {  // (an id that found no room within 64 probes is not found within 64 either)
+    u32 e = static_cast<u32>(id >> 32) % kInsMap;
+    for (u32 probe = 0; probe < 64; ++probe) {
+      u64 const cur = l_key[e];
+      if (cur == id) return e;
+      if (cur == 0) return kNoNode;
+      e = e + 1 == kInsMap ? 0u : e + 1;
+    }
+    return kNoNode;
+  };
+  // When every id finds room in the LDS map (always, except in deep samples) the map IS the table: slot = map entry, keys and
+  // first instances are copied out with coalesced stores below, and every instance word can be written here and now.  The
+  // words are written on that assumption; the rare window that needs the HBM table rewrites them (the general route below).
+  for (u32 p = threadIdx.x; p < rsi.nk; p += kInsT) {
+    u32 const e = map_entry(ids[p]);
+    if (e != kNoNode) {
+      atomicMin(&l_min[e], p);
+      inst_slot[p] |= e;  // (flags from phase A, written by this same thread)
+      ref_slot_g[p] = e;
+    } else {
+      atomicAdd(&l_ndef, 1u);
     }
   }
-  IPROF(1);  // reference k-mers
-  // (B) slow queue.  Every instance is a chain of dependent HBM round trips (queue entry -> sequence record -> instance
-  // word -> k-mer bytes) and this pass was 73 % of the kernel with one instance in flight per thread: four independent
-  // chains per thread now, the LDS map only touched once all four ids are known.
-  constexpr int kIU = 4;
+  __syncthreads();  // a later instance of a reference k-mer sees a reference position as its id's minimum
+  IPROF(2);  // reference k-mers
+  auto const word_flags = [](u32 item) -> u32 {
+    return ((item & kQPlus) ? kInstPlus : 0u) | ((item & kQErrFree) ? kInstErrFree : 0u) | ((item & kQLast) ? kInstLast : 0u);
+  };
   for (u32 x0 = threadIdx.x; x0 < nq; x0 += kInsT * kIU) {
-    u32 item[kIU], inst[kIU], keep[kIU];
-    u64 off[kIU], id[kIU];
-    bool live[kIU], plus[kIU];
+    u32 item[kIU], inst[kIU];
+    u64 id[kIU];
+    bool live[kIU];
 #pragma unroll
     for (int u = 0; u < kIU; ++u) {
       u32 const x = x0 + u * kInsT;
       live[u] = x < nq;
       item[u] = live[u] ? slowq[x] : 0u;
+      id[u] = live[u] ? ids[rsi.nk + x] : 1ull;
     }
 #pragma unroll
-    for (int u = 0; u < kIU; ++u) {
-      u32 const s_idx = item[u] >> 12, o = item[u] & 0xFFFu;
-      if (staged) {  // (slow instances come from reads: s_idx >= 1)
-        inst[u] = live[u] ? l_ibase[s_idx] + o : 0u;
-        off[u] = live[u] ? l_rpos[s_idx] + o : 0u;  // position in l_seq
-      } else {
-        SeqInfo const si = seq_info(b, w, live[u] ? s_idx : 0u, k);
-        inst[u] = live[u] ? ws.seq_inst_base[base_idx + s_idx] + o : 0u;
-        off[u] = si.off + o;
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < kIU; ++u) {
-      keep[u] = live[u] ? inst_slot[inst[u]] & (kInstErrFree | kInstLast) : 0u;
-      id[u] = 1;
-      plus[u] = true;
-      if (live[u])
-        id[u] = staged ? kmer_id_lds(l_seq, static_cast<u32>(off[u]), k, &plus[u]) : kmer_id(b.read_bases + off[u], k, &plus[u]);
-    }
+    for (int u = 0; u < kIU; ++u)
+      inst[u] = live[u] ? ws.seq_inst_base[base_idx + ((item[u] >> 12) & kQSeqMask)] + (item[u] & 0xFFFu) : 0u;
 #pragma unroll
     for (int u = 0; u < kIU; ++u) {
       if (!live[u]) continue;
       u32 const e = map_entry(id[u]);
       if (e != kNoNode) {
-        atomicMin(&l_min[e], inst[u]);
-        inst_slot[inst[u]] = e | kInstTemp | (plus[u] ? kInstPlus : 0u) | keep[u];
+        u32 const before = atomicMin(&l_min[e], inst[u]);
+        inst_slot[inst[u]] = e | word_flags(item[u]);
+        // the k-mer is also a reference k-mer <=> the smallest instance of its id is a reference position
+        if ((item[u] & kQErrFree) && before < rsi.nk) ws.rd_flag[r_first + ((item[u] >> 12) & kQSeqMask) - 1] = 1;
       } else {
         atomicAdd(&l_ndef, 1u);
-        inst_slot[inst[u]] = kInstDefer | (plus[u] ? kInstPlus : 0u) | keep[u];
       }
     }
   }
   __syncthreads();
-  IPROF(2);  // slow queue, pass 1
-  // ---- the table: as many slots as the distinct k-mers need (the stride tc_log2 is sized for the busiest window;
-  //      nothing re-hashes later: every stage goes through the slot in the instance word) ----
-  // When every id found room in the LDS map (always, except in deep samples) the map IS the table: slot = map entry, keys
-  // and first instances copied out with coalesced stores -- re-hashing the ids into an HBM table with one atomicCAS each
-  // (scattered, one round trip per probe) was a quarter of this kernel.  Nothing downstream probes by key: every stage goes
-  // through the slot in the instance word.
-  bool const direct_map = l_ndef == 0 && (1u << ws.tc_log2) >= kInsMap;
-  u32 tcw = 10;
-  while (tcw < static_cast<u32>(ws.tc_log2) && (1u << tcw) < (direct_map ? kInsMap : (l_nmap + l_ndef) * 4u / 3u + 16u)) ++tcw;
-  u32 const mask = (1u << tcw) - 1;
+  IPROF(3);  // slow queue
+  // ---- the table: as many slots as the distinct k-mers need (the stride is sized for the busiest window; nothing re-hashes
+  //      later: every stage goes through the slot in the instance word) ----
+  bool const direct_map = l_ndef == 0 && (1u << tcl) >= kInsMap;
+  u32 nslots = kInsMap;
+  if (!direct_map) {
+    u32 tcw = 10;
+    while (tcw < static_cast<u32>(tcl) && (1u << tcw) < (l_nmap + l_ndef) * 4u / 3u + 16u) ++tcw;
+    nslots = 1u << tcw;
+  }
+  u32 const mask = nslots - 1;  // (general route only: a power of two there)
   {
     int const CW = ws.num_samples + 2;
-    u32* cnt = ws.tbl_cnt + (static_cast<size_t>(a) << ws.tc_log2) * CW;
-    for (u32 i = threadIdx.x; i <= mask; i += kInsT) {
-      u64 const id = (direct_map && i < kInsMap) ? l_key[i] : 0ull;
+    u32* cnt = ws.tbl_cnt + (static_cast<size_t>(a) << tcl) * CW;
+    for (u32 i = threadIdx.x; i < nslots; i += kInsT) {
+      u64 const id = direct_map ? l_key[i] : 0ull;
       keys[i] = id;
       first[i] = id ? l_min[i] : 0x7F7F7F7Fu;  // (0x7F7F7F7F > any instance)
     }
-    for (u32 i = threadIdx.x; i < (mask + 1u) * CW; i += kInsT) cnt[i] = 0;
-    if (threadIdx.x == 0) ws.win_tc[a] = tcw;
-    __syncthreads();
+    for (u32 i = threadIdx.x; i < nslots * CW; i += kInsT) cnt[i] = 0;
+    if (threadIdx.x == 0) ws.win_nslots[a] = nslots;
   }
-  IPROF(3);  // table initialisation
-  // ---- pass 2: every distinct k-mer of the map into the HBM table, once ----
+  IPROF(4);  // table initialisation
+  if (direct_map) return;
+  // ================= general route: an HBM table (deep samples; a table stride below the map's size) =================
+  __syncthreads();
+  // every distinct k-mer of the map into the HBM table, once; l_min[e] becomes its slot | bit 31 "also a reference k-mer"
   for (u32 e = threadIdx.x; e < kInsMap; e += kInsT) {
     u64 const id = l_key[e];
     if (id == 0) continue;
-    u32 const slot = direct_map ? e : table_insert(keys, mask, id);
+    u32 const slot = table_insert(keys, mask, id, &ws.win_flags[w]);
     u32 const fi = l_min[e];
-    if (slot == kNoNode) atomicOr(&ws.win_flags[w], 4u);  // table full (cannot happen with the capacity planning)
-    else if (!direct_map) first[slot] = fi;  // plain store: ids of the map never take the direct path
+    if (slot == kNoNode) atomicOr(&ws.win_flags[w], 4u);  // table full: the first pass plans a quarter of a deep window's instances (assemble.hip); the retry passes plan the full table
+    else first[slot] = fi;  // plain store: ids of the map never take the direct path
     l_min[e] = (slot == kNoNode ? 0x7FFFFFFFu : (slot & kInstSlotMask)) | (fi < rsi.nk ? 0x80000000u : 0u);
   }
-  IPROF(4);  // pass 2: table inserts
-  // deferred instances (ids without room in the map): the direct path, reference k-mers first
-  bool const any_def = l_ndef != 0;
+  __syncthreads();
+  // ids without room in the map go straight to the table: the direct path, reference k-mers first
   auto direct_insert = [&](u64 id, u32 inst, u32* old_first) -> u32 {
-    u32 const slot = table_insert(keys, mask, id);
+    u32 const slot = table_insert(keys, mask, id, &ws.win_flags[w]);
     *old_first = 0xFFFFFFFFu;
     if (slot == kNoNode) {
       atomicOr(&ws.win_flags[w], 4u);
@@ -864,74 +925,42 @@ __global__ __launch_bounds__(kInsT) void k_insert(DBatch b, GraphWs ws) {
     *old_first = atomicMin(&first[slot], inst);
     return slot & kInstSlotMask;
   };
-  if (any_def) {
-    __syncthreads();
-    const u8* s = b.ref_bases + rsi.off;
-    for (u32 p = threadIdx.x; p < rsi.nk; p += kInsT) {
-      u32 const word = inst_slot[p];
-      if (!(word & kInstDefer)) continue;
-      bool plus;
-      u64 const id = kmer_id(s + p, k, &plus);
-      u32 of;
-      u32 const fin = direct_insert(id, p, &of) | (word & (kInstPlus | kInstLast));
-      inst_slot[p] = fin;
-      ref_slot_g[p] = fin & kInstSlotMask;
-    }
-    __syncthreads();  // a later instance of a reference k-mer sees a reference position as the minimum
-    for (u32 x = threadIdx.x; x < nq; x += kInsT) {
-      u32 const item = slowq[x];
-      u32 const s_idx = item >> 12, o = item & 0xFFFu;
-      u32 const inst = ws.seq_inst_base[base_idx + s_idx] + o;
-      u32 const word = inst_slot[inst];
-      if (!(word & kInstDefer)) continue;
-      SeqInfo const si = seq_info(b, w, s_idx, k);
-      bool plus;
-      u64 const id = kmer_id(b.read_bases + si.off + o, k, &plus);
-      u32 of;
-      inst_slot[inst] = direct_insert(id, inst, &of) | (word & (kInstPlus | kInstLast | kInstErrFree));
-      if ((word & kInstErrFree) && of < rsi.nk) ws.rd_flag[b.read_win_off[w] + s_idx - 1] = 1;
-    }
-  }
-  __syncthreads();
-  IPROF(5);  // deferred ids
-  // ---- pass 3: instance words get their table slot; reads with a general-path k-mer that is a reference node ----
   for (u32 p = threadIdx.x; p < rsi.nk; p += kInsT) {
-    u32 const word = inst_slot[p];
-    if (!(word & kInstTemp)) continue;
-    u32 const slot = l_min[word & kInsEntryMask] & 0x7FFFFFFFu;
-    u32 const fin = (slot == 0x7FFFFFFFu ? 0u : slot) | (word & (kInstPlus | kInstLast));
-    inst_slot[p] = fin;
-    ref_slot_g[p] = fin & kInstSlotMask;
+    u64 const id = ids[p];
+    u32 const e = map_find(id);
+    u32 slot, of;
+    if (e != kNoNode) {
+      slot = l_min[e] & 0x7FFFFFFFu;
+      slot = slot == 0x7FFFFFFFu ? 0u : slot;
+    } else {
+      slot = direct_insert(id, p, &of);
+    }
+    inst_slot[p] = (inst_slot[p] & (kInstPlus | kInstLast)) | slot;
+    ref_slot_g[p] = slot;
   }
-  // (four instances in flight per thread, like pass 1: queue entry -> [sequence record ->] instance word was three
-  //  dependent round trips per instance, seventeen instances per thread)
-  u32 const r_first = b.read_win_off[w];
-  for (u32 x0 = threadIdx.x; x0 < nq; x0 += kInsT * kIU) {
-    u32 item[kIU], inst[kIU], word[kIU];
-    bool live[kIU];
-#pragma unroll
-    for (int u = 0; u < kIU; ++u) {
-      u32 const x = x0 + u * kInsT;
-      live[u] = x < nq;
-      item[u] = live[u] ? slowq[x] : 0u;
+  __syncthreads();  // a later instance of a reference k-mer sees a reference position as the minimum
+  for (u32 x = threadIdx.x; x < nq; x += kInsT) {
+    u32 const item = slowq[x];
+    u64 const id = ids[rsi.nk + x];
+    u32 const s_idx = (item >> 12) & kQSeqMask;
+    u32 const inst = ws.seq_inst_base[base_idx + s_idx] + (item & 0xFFFu);
+    u32 const e = map_find(id);
+    u32 slot;
+    bool isref;
+    if (e != kNoNode) {
+      u32 const sv = l_min[e];
+      slot = sv & 0x7FFFFFFFu;
+      slot = slot == 0x7FFFFFFFu ? 0u : slot;
+      isref = (sv >> 31) != 0;
+    } else {
+      u32 of;
+      slot = direct_insert(id, inst, &of);
+      isref = of < rsi.nk;
     }
-#pragma unroll
-    for (int u = 0; u < kIU; ++u) {
-      u32 const s_idx = item[u] >> 12, o = item[u] & 0xFFFu;
-      inst[u] = !live[u] ? 0u : (staged ? l_ibase[s_idx] : ws.seq_inst_base[base_idx + s_idx]) + o;
-    }
-#pragma unroll
-    for (int u = 0; u < kIU; ++u) word[u] = live[u] ? inst_slot[inst[u]] : 0u;
-#pragma unroll
-    for (int u = 0; u < kIU; ++u) {
-      if (!live[u] || !(word[u] & kInstTemp)) continue;  // direct path: finished above
-      u32 const sv = l_min[word[u] & kInsEntryMask], slot = sv & 0x7FFFFFFFu;
-      inst_slot[inst[u]] = (slot == 0x7FFFFFFFu ? 0u : slot) | (word[u] & (kInstPlus | kInstLast | kInstErrFree));
-      // the k-mer is also a reference k-mer <=> the smallest instance of its id is a reference position
-      if ((word[u] & kInstErrFree) && (sv >> 31)) ws.rd_flag[r_first + (item[u] >> 12) - 1] = 1;
-    }
+    inst_slot[inst] = slot | word_flags(item);
+    if ((item & kQErrFree) && isref) ws.rd_flag[r_first + s_idx - 1] = 1;
   }
-  IPROF(6);  // pass 3
+  IPROF(5);  // general route
 }
 #ifdef MA_PROFILE
 extern "C" void ma_debug_iprof(unsigned long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_iprof), sizeof(unsigned long long) * 16); }
@@ -954,7 +983,7 @@ __global__ __launch_bounds__(kSupT) void k_support(DBatch b, GraphWs ws, u32* ma
   int const w = static_cast<int>(ws.active[a]);
   int const k = win_kmer(ws, w);
   int const S = ws.num_samples, CW = S + 2;
-  u32* gcnt = ws.tbl_cnt + (static_cast<size_t>(a) << ws.tc_log2) * CW;
+  u32* gcnt = ws.tbl_cnt + (static_cast<size_t>(a) << tbl_log2(ws)) * CW;
   u32* inst_slot = ws.inst_slot + static_cast<size_t>(a) * ws.inst_stride;
   const u32* ref_slot_g = ws.ref_slot + static_cast<size_t>(a) * ws.ref_stride;
   u32 const ns = seq_count(b, w);
@@ -1189,10 +1218,26 @@ __global__ __launch_bounds__(kSupT) void k_support(DBatch b, GraphWs ws, u32* ma
     // Windows whose (qname, role) keys each map to ONE run of adjacent reads (xs_flag == 0) and whose general
     // instances fit the LDS set are finished by k_mm_lds; the others need the HBM-resident set (max_gen[1]).
     // (up to four passes over the set for a window that fits the LDS tables; a deeper one goes chunk by chunk)
-    bool const lds_ok = !all_generic && !ws.mm_force_hbm && (ns > kSeqCap || gen_count <= 4u * kMmLdsMax) && ws.tc_log2 <= 20;
+    bool const lds_ok = !all_generic && !ws.mm_force_hbm && (ns > kSeqCap || gen_count <= 4u * kMmLdsMax) && tbl_log2(ws) <= 20;
     ws.mm_mode[a] = gen_count | (lds_ok ? 0u : 0x80000000u);
     atomicMax(max_gen, gen_count);
-    if (!lds_ok) atomicMax(max_gen + 1, gen_count);
+    ws.mm_log2[a] = 0;
+    if (!lds_ok && gen_count) {
+      // the window's HBM-resident set: 12 bytes per entry at a load of 3/4, carved out of the chunk's pool.  A pool that is
+      // used up is a capacity like any other: the window is flagged and the retry pass, whose pool holds a full set per
+      // window, re-assembles it.
+      atomicMax(max_gen + 1, gen_count);
+      u32 lg = 10;
+      while (lg < 31u && (1ull << lg) < static_cast<u64>(gen_count) * 4u / 3u + 16u) ++lg;
+      unsigned long long const bytes = ((12ull << lg) + 255ull) & ~255ull;
+      unsigned long long const at = atomicAdd(ws.mm_pool_used, bytes);
+      if (at + bytes <= ws.mm_pool_bytes) {
+        ws.mm_off[a] = at;
+        ws.mm_log2[a] = lg;
+      } else {
+        atomicOr(&ws.win_flags[w], 4u);
+      }
+    }
   }
   for (u32 i = threadIdx.x; i < rsi.nk * CW; i += kSupT) {
     u32 const v = l_cnt[i];
@@ -1215,16 +1260,22 @@ __device__ __forceinline__ u32 inst_table_slot(u32 word, const u32* ref_slot_g) 
 __global__ __launch_bounds__(kBT) void k_mm_insert(DBatch b, GraphWs ws) {
   __shared__ u32 l_base[kSeqCap];
   int const a = blockIdx.x;
-  if (!(ws.mm_mode[a] & 0x80000000u)) return;  // done by k_mm_lds
+  if (!(ws.mm_mode[a] & 0x80000000u) || ws.mm_log2[a] == 0) return;  // done by k_mm_lds / no set (flagged)
   int const w = static_cast<int>(ws.active[a]);
-  u32 const mask = (1u << ws.mc_log2) - 1;
-  u64* keys = ws.mm_key + (static_cast<size_t>(a) << ws.mc_log2);
-  u32* mins = ws.mm_min + (static_cast<size_t>(a) << ws.mc_log2);
+  u32 const mlg = ws.mm_log2[a];
+  u32 const mask = (1u << mlg) - 1;
+  u64* keys = reinterpret_cast<u64*>(ws.mm_pool + ws.mm_off[a]);
+  u32* mins = reinterpret_cast<u32*>(keys + (size_t(1) << mlg));
   const u32* inst_slot = ws.inst_slot + static_cast<size_t>(a) * ws.inst_stride;
   const u32* ref_slot_g = ws.ref_slot + static_cast<size_t>(a) * ws.ref_stride;
   u32 const ns = seq_count(b, w);
   u32 const base_idx = b.read_win_off[w] + w;
   const u32* sbase = stage_seq_bases(ws.seq_inst_base + base_idx, ns, l_base);
+  // the set is the workgroup's own: it clears it itself (16-byte stores; the region is 256-byte aligned)
+  for (u32 i = threadIdx.x; i < (1u << mlg) / 2u; i += kBT) reinterpret_cast<uint4*>(keys)[i] = make_uint4(0, 0, 0, 0);
+  for (u32 i = threadIdx.x; i < (1u << mlg) / 4u; i += kBT)
+    reinterpret_cast<uint4*>(mins)[i] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+  __threadfence_block();
   __syncthreads();
   u32 const ninst = ws.win_ninst[w], nref = ninst - ws.win_nread_inst[w];
   for (u32 ii = nref + threadIdx.x; ii < ninst; ii += kBT) {
@@ -1255,13 +1306,14 @@ __global__ __launch_bounds__(kBT) void k_mm_insert(DBatch b, GraphWs ws) {
 __global__ __launch_bounds__(kBT) void k_count(DBatch b, GraphWs ws) {
   __shared__ u32 l_base[kSeqCap];
   int const a = blockIdx.x;
-  if (!(ws.mm_mode[a] & 0x80000000u)) return;  // done by k_mm_lds
+  if (!(ws.mm_mode[a] & 0x80000000u) || ws.mm_log2[a] == 0) return;  // done by k_mm_lds / no set (flagged)
   int const w = static_cast<int>(ws.active[a]);
   int const S = ws.num_samples, CW = S + 2;
-  u32 const mask = (1u << ws.mc_log2) - 1;
-  const u64* keys = ws.mm_key + (static_cast<size_t>(a) << ws.mc_log2);
-  const u32* mins = ws.mm_min + (static_cast<size_t>(a) << ws.mc_log2);
-  u32* cnt = ws.tbl_cnt + (static_cast<size_t>(a) << ws.tc_log2) * CW;
+  u32 const mlg = ws.mm_log2[a];
+  u32 const mask = (1u << mlg) - 1;
+  const u64* keys = reinterpret_cast<const u64*>(ws.mm_pool + ws.mm_off[a]);
+  const u32* mins = reinterpret_cast<const u32*>(keys + (size_t(1) << mlg));
+  u32* cnt = ws.tbl_cnt + (static_cast<size_t>(a) << tbl_log2(ws)) * CW;
   const u32* inst_slot = ws.inst_slot + static_cast<size_t>(a) * ws.inst_stride;
   const u32* ref_slot_g = ws.ref_slot + static_cast<size_t>(a) * ws.ref_stride;
   u32 const ns = seq_count(b, w);
@@ -1323,7 +1375,7 @@ __global__ __launch_bounds__(kMmT) void k_mm_lds(DBatch b, GraphWs ws) {
   if ((mode & 0x80000000u) || mode == 0) return;
   int const w = static_cast<int>(ws.active[a]);
   int const S = ws.num_samples, CW = S + 2;
-  u32* cnt = ws.tbl_cnt + (static_cast<size_t>(a) << ws.tc_log2) * CW;
+  u32* cnt = ws.tbl_cnt + (static_cast<size_t>(a) << tbl_log2(ws)) * CW;
   const u32* inst_slot = ws.inst_slot + static_cast<size_t>(a) * ws.inst_stride;
   const u32* ref_slot_g = ws.ref_slot + static_cast<size_t>(a) * ws.ref_stride;
   u32 const ns = seq_count(b, w);
@@ -1520,7 +1572,7 @@ __global__ __launch_bounds__(kMmT) void k_mm_lds(DBatch b, GraphWs ws) {
   u32 const ctr_words = kMmAux + tail_words;
   auto const ctr = [&](u32 wd) -> u32& { return wd < kMmAux ? l_aux[wd] : l_set[nkeys + (wd - kMmAux)]; };
   u32 const slots_per_pass = (2u * ctr_words) / static_cast<u32>(CW);
-  u32 const tcap = 1u << ws.win_tc[a];
+  u32 const tcap = ws.win_nslots[a];
   for (u32 s0 = 0; s0 < tcap; s0 += slots_per_pass) {
     for (u32 i = threadIdx.x; i < ctr_words; i += kMmT) ctr(i) = 0;
     __syncthreads();
@@ -1561,11 +1613,13 @@ __global__ __launch_bounds__(kRankT) void k_rank(DBatch b, GraphWs ws, u32 min_n
   int const a = blockIdx.x;
   int const w = static_cast<int>(ws.active[a]);
   int const S = ws.num_samples, CW = S + 2;
-  u32 const tcap = 1u << ws.win_tc[a];  // slots this window uses (k_insert)
-  const u64* keys = ws.tbl_key + (static_cast<size_t>(a) << ws.tc_log2);
-  u32* first = ws.tbl_first + (static_cast<size_t>(a) << ws.tc_log2);
-  u32* slot_node = ws.slot_node + (static_cast<size_t>(a) << ws.tc_log2);
-  const u32* cnt = ws.tbl_cnt + (static_cast<size_t>(a) << ws.tc_log2) * CW;
+  u32 const tcap = ws.win_nslots[a];  // slots this window uses (k_insert)
+  int const tcl = tbl_log2(ws);
+  if (ws.gr_done[a]) return;  // k_graph took this window
+  const u64* keys = ws.tbl_key + (static_cast<size_t>(a) << tcl);
+  u32* first = ws.tbl_first + (static_cast<size_t>(a) << tcl);
+  u32* slot_node = ws.slot_node + (static_cast<size_t>(a) << tcl);
+  const u32* cnt = ws.tbl_cnt + (static_cast<size_t>(a) << tcl) * CW;
   u32* inst_slot = ws.inst_slot + static_cast<size_t>(a) * ws.inst_stride;
   size_t const nb = static_cast<size_t>(a) * ws.nc;
 
@@ -1753,8 +1807,8 @@ __global__ __launch_bounds__(kEdT) void k_edges(DBatch b, GraphWs ws) {
   __shared__ u32 l_fail;
   int const a = blockIdx.x;
   int const w = static_cast<int>(ws.active[a]);
-  if (ws.win_flags[w] & 4u) return;
-  const u32* slot_node = ws.slot_node + (static_cast<size_t>(a) << ws.tc_log2);
+  if ((ws.win_flags[w] & 4u) || ws.gr_done[a]) return;
+  const u32* slot_node = ws.slot_node + (static_cast<size_t>(a) << tbl_log2(ws));
   const u32* inst_slot = ws.inst_slot + static_cast<size_t>(a) * ws.inst_stride;
   const u32* refn = ws.ref_node + static_cast<size_t>(a) * ws.ref_stride;
   size_t const nb = static_cast<size_t>(a) * ws.nc;
@@ -1855,6 +1909,7 @@ __global__ __launch_bounds__(kEdT) void k_edges(DBatch b, GraphWs ws) {
 
 __global__ __launch_bounds__(kBT) void k_edge_sort(GraphWs ws) {
   int const a = blockIdx.x;
+  if (ws.gr_done[a]) return;
   size_t const nb = static_cast<size_t>(a) * ws.nc;
   u32 const n = min(ws.n_nodes[a], ws.nc);
   for (u32 i = threadIdx.x; i < n; i += kBT) {
@@ -1921,11 +1976,11 @@ __global__ __launch_bounds__(kGrT) void k_graph(DBatch b, GraphWs ws, u32 min_no
   int const w = static_cast<int>(ws.active[a]);
   int const S = ws.num_samples, CW = S + 2;
   int const tcl = tbl_log2(ws);
-  u32 const tcap = 1u << ws.win_tc[a];
+  u32 const tcap = ws.win_nslots[a];
   u32 const ninst = ws.win_ninst[w], nref = ninst - ws.win_nread_inst[w];
   u32 const nw = (ws.inst_stride + 31u) / 32u + 1u;
   if (threadIdx.x == 0) ws.gr_done[a] = 0;
-  if ((ws.win_flags[w] & 4u) || tcap > kGrSlots || ninst > ws.inst_stride || ws.nc > 32768u) return;  // (uniform)
+  if ((ws.win_flags[w] & 4u) || tcap > kGrSlots || ninst > ws.inst_stride) return;  // (uniform)
   const u64* keys = ws.tbl_key + (static_cast<size_t>(a) << tcl);
   const u32* first = ws.tbl_first + (static_cast<size_t>(a) << tcl);
   const u32* cnt = ws.tbl_cnt + (static_cast<size_t>(a) << tcl) * CW;
@@ -2000,7 +2055,7 @@ __global__ __launch_bounds__(kGrT) void k_graph(DBatch b, GraphWs ws, u32 min_no
     }
     total_nodes = tot;
     u32 run = before + inc - mine;
-    if (tot < 65535u)
+    if (tot <= kGrSlots)
       for (u32 x = 0; x < per; ++x)
         if (w0 + x < nw) {
           l_pref[w0 + x] = static_cast<u16>(run);
@@ -2009,7 +2064,8 @@ __global__ __launch_bounds__(kGrT) void k_graph(DBatch b, GraphWs ws, u32 min_no
     __syncthreads();
   }
   if (threadIdx.x == 0) ws.n_nodes[a] = total_nodes;
-  if (total_nodes >= ws.nc || total_nodes >= 65535u) {  // capacity exceeded: flagged (k_rank's rule), the retry passes grow it
+  if (total_nodes < ws.nc && total_nodes > kGrSlots) return;  // node indices beyond the packed edge key: the general kernels
+  if (total_nodes >= ws.nc) {  // capacity exceeded: flagged (k_rank's rule), the retry passes grow it
     if (threadIdx.x == 0) {
       atomicOr(&ws.win_flags[w], 4u);
       ws.gr_done[a] = 1;
@@ -2083,7 +2139,8 @@ __global__ __launch_bounds__(kGrT) void k_graph(DBatch b, GraphWs ws, u32 min_no
   u32 const last = ninst > 0 ? ninst - 1 : 0;
   u32 const last4 = last & ~3u;
   // four consecutive (k+1)-mers per thread and trip: one 16-byte load + the neighbour's first word (the next trip's in flight)
-  for (u32 i0 = 4u * threadIdx.x; i0 < last; i0 += 4u * kGrT) {
+  for (u32 t0 = 0; t0 < last; t0 += 4u * kGrT) {  // (whole wavefronts reach the shuffle: the trip count is the workgroup's)
+    u32 const i0 = t0 + 4u * threadIdx.x;
     uint4 const q4 = *reinterpret_cast<const uint4*>(inst_slot + min(i0, last4));
     u32 nxt = __shfl_down(q4.x, 1);
     if (lane == 63) nxt = inst_slot[min(i0 + 4u, last)];
@@ -2135,14 +2192,20 @@ __global__ __launch_bounds__(kGrT) void k_graph(DBatch b, GraphWs ws, u32 min_no
 // ---- host side: one k attempt of the build stage for the active windows ----
 int run_build_pass(ma_ctx* ctx, const DBatch& b, GraphWs& ws, u32* counters_dev, int tc_log2_alloc) {
   if (ws.n_active == 0) return MA_OK;
-  size_t const A = ws.n_active;
   int const S = ws.num_samples;
-  // (1) classify (no table traffic) -> how many k-mers need the table at most
-  MA_HIP(ctx, hipMemsetAsync(counters_dev, 0, 4, ctx->stream));
+  // Round 5: NO host round trip inside a k attempt.  The table stride follows from the busiest window's slow instances
+  // (counters_dev[0], k_classify) and is worked out by the kernels themselves (graph_ws.h: tbl_log2); the windows that need an
+  // HBM-resident mate-mer set take theirs from the chunk's pool on the device (k_support).  The host used to read both
+  // numbers back -- the stream drained twice per pass, per lane, per chunk, per rung of the ladder.
+  size_t const A = ws.n_active;
+  ws.tc_log2 = tc_log2_alloc;
+  ws.max_slow = counters_dev;
+  MA_HIP(ctx, hipMemsetAsync(counters_dev, 0, 12, ctx->stream));  // max_slow, max_gen[2]
   MA_HIP(ctx, hipMemsetAsync(ws.n_slow, 0, 4 * A, ctx->stream));
+  MA_HIP(ctx, hipMemsetAsync(ws.mm_pool_used, 0, 8, ctx->stream));
   u32 const tiles_per_win = std::max<u32>(1, (ws.max_reads + 63) / 64);
   u32 const tile_cap = (64 * ws.max_read_len + 32 + 15) & ~15u;
-  size_t const lds_c = ((ws.max_ref_len + 8 + 15) & ~15u) + 2048 + 2ull * tile_cap + 4ull * 64 * classify_mask_words(ws.max_read_len) + 64;
+  size_t const lds_c = ((ws.max_ref_len + 8 + 15) & ~15u) + 2048 + 2ull * tile_cap + 2 * 4ull * 64 * classify_mask_words(ws.max_read_len) + 64;
   if (lds_c > 160 * 1024) {
     ma_set_err(ctx, "ma_assemble_batch: reads too long for the LDS-staged classifier");
     return MA_ERR_PARAM;
@@ -2154,13 +2217,6 @@ int run_build_pass(ma_ctx* ctx, const DBatch& b, GraphWs& ws, u32* counters_dev,
   hipLaunchKernelGGL(k_classify, dim3(ws.n_active * tiles_per_win), dim3(64), lds_c, ctx->stream, b, ws, counters_dev,
                      tiles_per_win, tile_cap);
   ctx->toc();
-  u32 max_slow = 0;
-  MA_HIP(ctx, hipMemcpyAsync(&max_slow, counters_dev, 4, hipMemcpyDeviceToHost, ctx->stream));
-  MA_HIP(ctx, ma_stream_sync(ctx));
-  int tc = 10;
-  while ((size_t(1) << tc) < (static_cast<size_t>(max_slow) + ws.ref_stride) * 4 / 3 + 16) ++tc;
-  ws.tc_log2 = tc < tc_log2_alloc ? tc : tc_log2_alloc;
-  int const mc_log2_alloc = ws.mc_log2;
   // (k_insert initialises the slots each window uses: no table-wide memsets)
   ctx->tic("k_insert");
   hipLaunchKernelGGL(k_insert, dim3(ws.n_active), dim3(kInsT), 0, ctx->stream, b, ws);
@@ -2179,21 +2235,28 @@ int run_build_pass(ma_ctx* ctx, const DBatch& b, GraphWs& ws, u32* counters_dev,
                                     static_cast<int>(lds_s)));
   ctx->tic("k_support");
   ws.mm_probe_max = getenv("MA_MM_PROBE_MAX") ? static_cast<u32>(std::max(1, atoi(getenv("MA_MM_PROBE_MAX")))) : kMmLdsCap;
-  MA_HIP(ctx, hipMemsetAsync(counters_dev + 1, 0, 8, ctx->stream));
   hipLaunchKernelGGL(k_support, dim3(ws.n_active), dim3(kSupT), lds_s, ctx->stream, b, ws, counters_dev + 1, sup_cache, xs_log2);
   ctx->toc();
-  // windows whose general instances fit an LDS set are finished by k_mm_lds; the HBM-resident set only has to
-  // hold what the remaining windows routed to it (usually nothing)
+  // windows whose general instances fit an LDS set are finished by k_mm_lds; the HBM-resident sets only hold what the
+  // remaining windows routed to them (usually nothing: both kernels then leave at their first test)
   ctx->tic("k_mm_lds");
   if (ws.mm_probe_max < kMmLdsCap) hipLaunchKernelGGL(k_mm_lds<true>, dim3(ws.n_active), dim3(kMmT), 0, ctx->stream, b, ws);
   else hipLaunchKernelGGL(k_mm_lds<false>, dim3(ws.n_active), dim3(kMmT), 0, ctx->stream, b, ws);
   ctx->toc();
-  u32 max_gen[2] = {0, 0};
-  MA_HIP(ctx, hipMemcpyAsync(max_gen, counters_dev + 1, 8, hipMemcpyDeviceToHost, ctx->stream));
-  MA_HIP(ctx, ma_stream_sync(ctx));
-  if (getenv("MA_VERBOSE")) {
+  ctx->tic("k_mm_insert");
+  hipLaunchKernelGGL(k_mm_insert, dim3(ws.n_active), dim3(kBT), 0, ctx->stream, b, ws);
+  ctx->toc();
+  ctx->tic("k_count");
+  hipLaunchKernelGGL(k_count, dim3(ws.n_active), dim3(kBT), 0, ctx->stream, b, ws);
+  ctx->toc();
+  if (getenv("MA_VERBOSE")) {  // (diagnostics only: this does wait for the stream)
     std::vector<u32> mm(A);
+    u32 max_gen[2] = {0, 0};
+    unsigned long long used = 0;
+    MA_HIP(ctx, ma_stream_sync(ctx));
     MA_HIP(ctx, hipMemcpy(mm.data(), ws.mm_mode, 4 * A, hipMemcpyDeviceToHost));
+    MA_HIP(ctx, hipMemcpy(max_gen, counters_dev + 1, 8, hipMemcpyDeviceToHost));
+    MA_HIP(ctx, hipMemcpy(&used, ws.mm_pool_used, 8, hipMemcpyDeviceToHost));
     size_t nfb = 0, big = 0;
     u64 tot = 0;
     for (u32 v : mm) {
@@ -2201,26 +2264,18 @@ int run_build_pass(ma_ctx* ctx, const DBatch& b, GraphWs& ws, u32* counters_dev,
       big += (v & 0x7FFFFFFFu) > kMmLdsMax;
       tot += v & 0x7FFFFFFFu;
     }
-    fprintf(stderr, "[ma] mate-mer sets: %zu windows, %zu need the HBM set (%zu by size), mean general instances %.0f, max %u / %u\n",
-            A, nfb, big, static_cast<double>(tot) / static_cast<double>(A), max_gen[0], max_gen[1]);
+    fprintf(stderr, "[ma] mate-mer sets: %zu windows, %zu need the HBM set (%zu by size), mean general instances %.0f, max %u / %u; pool %.1f of %.1f MB\n",
+            A, nfb, big, static_cast<double>(tot) / static_cast<double>(A), max_gen[0], max_gen[1], used / 1048576.0, ws.mm_pool_bytes / 1048576.0);
   }
-  if (max_gen[1] > 0) {
-    int mc = 10;
-    while ((size_t(1) << mc) < static_cast<size_t>(max_gen[1]) * 4 / 3 + 16) ++mc;
-    ws.mc_log2 = mc < mc_log2_alloc ? mc : mc_log2_alloc;
-    size_t const mcap = size_t(1) << ws.mc_log2;
-    // (reserved here, when a window of the chunk needs it -- windows without mapping hints, names in separate runs: the set was
-    //  a quarter of every window's planned workspace and is not touched at all on the usual route)
-    MA_HIP(ctx, ctx->ws_mm.reserve(A * mcap * 12 + 256));
-    ws.mm_key = ctx->ws_mm.as<u64>();
-    ws.mm_min = reinterpret_cast<u32*>(ws.mm_key + A * mcap);
-    MA_HIP(ctx, hipMemsetAsync(ws.mm_key, 0, A * mcap * 8, ctx->stream));
-    MA_HIP(ctx, hipMemsetAsync(ws.mm_min, 0xFF, A * mcap * 4, ctx->stream));
-    ctx->tic("k_mm_insert");
-    hipLaunchKernelGGL(k_mm_insert, dim3(ws.n_active), dim3(kBT), 0, ctx->stream, b, ws);
-    ctx->toc();
-    ctx->tic("k_count");
-    hipLaunchKernelGGL(k_count, dim3(ws.n_active), dim3(kBT), 0, ctx->stream, b, ws);
+  // node records + edges: k_graph for the common window (table of at most 8192 slots), the three general kernels for the rest
+  MA_HIP(ctx, hipMemsetAsync(ws.gr_done, 0, 4 * A, ctx->stream));
+  size_t const lds_g = graph_lds_bytes(ws.inst_stride, ws.ref_stride);
+  if (lds_g <= 80u * 1024u && !getenv("MA_NO_GRAPH_FUSE")) {
+    if (lds_g > 65536)
+      MA_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_graph), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      static_cast<int>(lds_g)));
+    ctx->tic("k_graph");
+    hipLaunchKernelGGL(k_graph, dim3(ws.n_active), dim3(kGrT), lds_g, ctx->stream, b, ws, static_cast<u32>(ctx->prm.min_node_cov));
     ctx->toc();
   }
   ctx->tic("k_rank");

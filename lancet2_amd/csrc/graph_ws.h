@@ -44,7 +44,9 @@ struct GraphWs {
   u32 max_reads;          // most reads of any window of the batch
   u32 max_read_len;       // longest read of the batch
   // table
-  int tc_log2, mc_log2;
+  int tc_log2, mc_log2;   // ALLOCATED strides (log2): the table stride an attempt uses is tbl_log2(ws), sized on the device
+  const u32* max_slow;    // [1] device: most slow-path instances of any window of this attempt (k_classify) -- what sizes the
+                          //     table stride; read by the kernels themselves, so the host never waits for it
   u32 mm_probe_max;  // k_mm_lds: probes after which its LDS set counts as full (tests lower it: MA_MM_PROBE_MAX)
   u32 mm_force_hbm;  // capacity retry passes: every window's mate-mers through the HBM set (k_mm_insert / k_count)
   u32 inst_stride;
@@ -55,10 +57,18 @@ struct GraphWs {
   u32* slowq;             // [a][inst_stride] (seq << 12 | offset) of the instances that need the hash table
   u32* n_slow;            // [a]
   u32* mm_mode;           // [a] general mate-mer instances of the window; bit31: needs the HBM-resident set
-  u32* win_tc;            // [a] log2 of the table slots this window uses (<= tc_log2, the stride)
+  u32* win_nslots;        // [a] table slots this window uses (<= the stride; 6144 = k_insert's LDS map copied out, else a power of two)
+  u64* slow_id;           // [a][inst_stride] k_insert: node ids of the reference k-mers, then of the slow queue's entries
+  u32* gr_done;           // [a] 1: k_graph produced the window's node records and edges (k_rank / k_edges / k_edge_sort skip it)
   u8* rd_flag;            // [n_reads] general-path k-mer of this read hit a reference node
-  u64* mm_key;
-  u32* mm_min;
+  // HBM-resident mate-mer sets (windows without mapping hints, names in separate runs, capacity retries): carved out of a
+  // pool by the windows that need one (k_support: one atomicAdd), so that nothing is reserved per window on the usual route and
+  // the host never has to learn how many windows need how much
+  u8* mm_pool;
+  unsigned long long mm_pool_bytes;
+  unsigned long long* mm_pool_used;  // [1] device bump pointer
+  unsigned long long* mm_off;        // [a] the window's set: byte offset into mm_pool (keys u64[cap], then minima u32[cap])
+  u32* mm_log2;                      // [a] log2 of its capacity
   // compact graph (per active slot, NC nodes)
   u32 nc;                 // node capacity per window
   u32* slot_node;         // [a][TC] slot -> node idx (kNoNode if pruned) 
@@ -126,6 +136,15 @@ __device__ __forceinline__ int win_kmer(GraphWs const& ws, int w) {
   return k ? static_cast<int>(k) : ws.k;
 }
 
+
+// table stride of this attempt (log2): the host's old formula -- slots for the busiest window's slow instances + reference
+// k-mers at a load of 3/4, at least 2^10, at most what was allocated -- evaluated where max_slow lives
+__device__ __forceinline__ int tbl_log2(GraphWs const& ws) {
+  u32 const need = (ws.max_slow[0] + ws.ref_stride) / 3u * 4u + 32u;
+  int tc = 32 - __clz(static_cast<int>(need - 1u));
+  tc = tc < 10 ? 10 : tc;
+  return tc < ws.tc_log2 ? tc : ws.tc_log2;
+}
 
 __device__ __forceinline__ u64 dev_fmix64(u64 x) {
   x ^= x >> 33;

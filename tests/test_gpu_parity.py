@@ -1324,3 +1324,79 @@ def test_traversal_limit_is_the_references(bfs_limit):
     if bfs_limit <= 40:  # the cap was meant to bite: the reference's answer is not the uncapped one
         full = OracleEngine(capi.default_params(min_k=25, max_k=25)).assemble(arrs, n, nr)
         assert not (np.array_equal(full["win_status"], wa["win_status"]) and np.array_equal(full["comp_nhaps"], wa["comp_nhaps"]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg,nwin,first,kw,pk", [
+    ("C3", 12, 93_000, dict(softclip_frac=0.05, n_frac=0.03), dict(min_k=25, max_k=25)),
+    ("C3", 8, 93_100, dict(tandem_dup=45), {}),                       # the k ladder: every rung through both routes
+    ("C5", 6, 93_200, {}, dict(min_k=25, max_k=25, num_samples=3)),
+    ("C2", 6, 93_300, dict(W=2501), dict(min_k=25, max_k=25, max_hap_len=4096)),  # -w 2500: 2477 reference k-mers
+])
+def test_fused_graph_kernel_equals_the_three_general_kernels(cfg, nwin, first, kw, pk, monkeypatch):
+    """Round 5: k_graph (survivor ranks from a bitmap of first instances, slot -> node in LDS, the window's distinct edges in an
+    LDS set probed by source node, an edge's place read off its run) against k_rank + k_edges + k_edge_sort (MA_NO_GRAPH_FUSE=1):
+    the same assembly outputs, both equal to the oracle's; the timing names prove which route ran."""
+    from lancet2_amd.engine import Engine
+    params = capi.default_params(**pk)
+    arrs, n, nr = synth.make_config_batch(cfg, nwin, first_index=first, **kw)
+    orc = OracleEngine(params)
+    wa = orc.assemble(arrs, n, nr)
+    wv = orc.msa(arrs, n, nr, wa)
+    wq = orc.genotype(arrs, n, nr, wa, wv)
+    for fused in (True, False):
+        if fused:
+            monkeypatch.delenv("MA_NO_GRAPH_FUSE", raising=False)
+        else:
+            monkeypatch.setenv("MA_NO_GRAPH_FUSE", "1")
+        eng = Engine(params)
+        try:
+            eng.timing_control(1)
+            g, a, v, q = eng.process(arrs, n, nr, debug=True)
+            times = {}
+            for k_, ms in eng.kernel_times():
+                times[k_] = times.get(k_, 0.0) + ms
+        finally:
+            eng.close()
+        assert ("k_graph" in times) == fused, sorted(times)
+        if fused and kw.get("W", 1001) <= 1001:  # the general kernels only leave at their first test (a 2.5 kb window holds more
+            # distinct k-mers than k_insert's LDS map: its table has 16 k slots and the general kernels take it)
+            assert times["k_rank"] + times["k_edges"] + times["k_edge_sort"] < times["k_graph"], times
+        bad = compare_asm(params, a, wa, n) + compare_vars(params, v, wv, n)
+        bad += compare_geno(params, q, wq, n, nr, wv["win_nvars"], arrs["read_win_off"])
+        assert not bad, f"fused={fused}\n" + "\n".join(bad[:12])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pool_kb", ["1", "4096", None])
+def test_hbm_mate_mer_sets_come_out_of_a_budgeted_pool(pool_kb, monkeypatch):
+    """Windows without mapping hints route every mate-mer through an HBM-resident set; each window carves its set out of the
+    chunk's pool on the device (k_support), so the host never learns -- or waits for -- how many windows need how much.  A pool
+    that runs out (MA_MM_POOL_KB: 1 KB and 4 MB per window of the chunk; the default without hints is a full set per window)
+    is a capacity like any other: the window is flagged and re-assembled by the retry pass, whose pool holds a full set per
+    window.  Same results as the oracle, no flag left."""
+    from lancet2_amd.engine import Engine
+    if pool_kb:
+        monkeypatch.setenv("MA_MM_POOL_KB", pool_kb)
+    params = capi.default_params(min_k=25, max_k=25)
+    arrs, n, nr = synth.make_config_batch("C3", 6, first_index=94_000)
+    arrs = dict(arrs)
+    arrs["read_hint"] = np.full_like(arrs["read_hint"], capi.MA_NO_HINT)
+    orc = OracleEngine(params)
+    wa = orc.assemble(arrs, n, nr)
+    wv = orc.msa(arrs, n, nr, wa)
+    wq = orc.genotype(arrs, n, nr, wa, wv)
+    eng = Engine(params)
+    try:
+        eng.timing_control(1)
+        g, a, v, q = eng.process(arrs, n, nr, debug=True)
+        times = {}
+        for k_, ms in eng.kernel_times():
+            times[k_] = times.get(k_, 0.0) + ms
+    finally:
+        eng.close()
+    assert times.get("k_mm_insert", 0) > 0 and times.get("k_count", 0) > 0, times
+    assert not (a["win_status"] & capi.MA_W_TABLE_OVERFLOW).any()
+    bad = compare_asm(params, a, wa, n) + compare_vars(params, v, wv, n)
+    bad += compare_geno(params, q, wq, n, nr, wv["win_nvars"], arrs["read_win_off"])
+    assert not bad, "\n".join(bad[:12])
