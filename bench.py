@@ -43,7 +43,7 @@ STR_UNITS = (b"A", b"CA", b"CAG", b"GATA", b"TTTCC", b"AGGGTT")
 STAGE_OF = {"gate_kernel": "gate",
             "k_count_inst": "build", "k_classify": "build", "k_insert": "build", "k_support": "build",
             "k_mm_lds": "build", "k_mm_insert": "build", "k_count": "build", "k_rank": "build", "k_edges": "build",
-            "k_edge_sort": "build",
+            "k_edge_sort": "build", "k_graph": "build", "k_graph_gen": "build", "k_mm_q": "build", "k_mm_hbm": "build",
             "k_clean": "clean", "k_clean_chains": "clean", "k_clean_tail": "clean",
             "k_msa": "poa", "k_msa_band": "poa",
             "k_read_planes": "genotype", "k_plan": "genotype", "k_vote": "genotype", "k_dp_scatter": "genotype", "k_align_reg": "genotype", "k_align_tb": "genotype",

@@ -268,7 +268,7 @@ __device__ __forceinline__ bool same_group(const DBatch& b, u32 ra, u32 rb) {
 //     per-lane bitmask and appended to the window's slow queue at the end with one atomic per wave, so that
 //     k_insert can hash them with full lanes.
 #ifdef MA_PROFILE
-__device__ unsigned long long g_iprof[16];
+__device__ unsigned long long g_iprof[32];
 #define IPROF_T0() unsigned long long _t0 = __builtin_amdgcn_s_memtime()
 #define IPROF(slot)                                                            \
   do {                                                                         \
@@ -281,6 +281,8 @@ __device__ unsigned long long g_iprof[16];
 #define IPROF_T0() do {} while (0)
 #define IPROF(slot) do {} while (0)
 #endif
+// a barrier that is also a phase mark of the profile build
+#define IPROF_SYNC(slot) do { __syncthreads(); IPROF(slot); } while (0)
 #ifdef MA_PROFILE
 #define KPROF(slot)                                                            \
   do {                                                                         \
@@ -640,21 +642,35 @@ __device__ __forceinline__ u64 kmer_id_lds(const u32* l_seq, u32 p, int k, bool*
 // do not fit the map (deep samples) are deferred and take the direct path with its atomics.
 constexpr int kInsT = 1024;
 constexpr u32 kInsMap = 6144;         // LDS map entries (48 KB of ids + 24 KB of first instances)
+constexpr u32 kInsProbe = 1024;       // probes before an id counts as homeless (only a map without a free entry gets there)
 constexpr u32 kSeqWords = 16376;      // the window's read bases as 4-bit codes in LDS: 131 008 bases (+ 8 words of slack)
-constexpr u32 kInsArea = 12u * kInsMap;  // 73 728 B: the staged bases + sequence starts, THEN the map (two workgroups per CU)
-static_assert(4u * (kSeqWords + 8u) + 4u * kSeqCap <= kInsArea, "k_insert: the staging area must fit the map's");
-// Round 5: the kernel runs in two phases that share ONE 72 KB LDS area.  Phase A stages the window's read bases and
-// hashes every slow k-mer (ids to HBM, coalesced, each thread reading back only what it wrote itself); phase B builds the
-// map from the ids.  With the map and the staged bases side by side the kernel held 139 KB: one workgroup, four waves
-// per SIMD, per CU -- and every phase of it is a chain of round trips that wants more waves in flight.  The queue items
-// carry the instance's error-free / last bits (k_classify) and its canonical bit (phase A), so an instance word is
-// WRITTEN once, with its final table slot -- the LDS map's entry, which is what the table is copied out from -- and
-// never read: the old passes read and rewrote every slow instance's word twice (two 64-byte sectors per 4-byte word).
+constexpr u32 kStageSeqs = 1024;      // sequences whose first base / first instance phase A keeps in LDS
+constexpr u32 kInsArea = 12u * kInsMap;  // 73 728 B: the staged bases + sequence records, THEN the map (two workgroups per CU)
+static_assert(4u * (kSeqWords + 8u) + 8u * kStageSeqs <= kInsArea, "k_insert: the staging area must fit the map's");
+// four ASCII bases -> four 2-bit codes in the low bits of each byte, and whether all four are upper-case A/C/G/T: the byte a
+// code stands for is 0x41 + 2 c0 + 6 c1 + 11 c0 c1 (A 0x41, C 0x43, G 0x47, T 0x54) -- byte lanes never carry into each other
+__device__ __forceinline__ u32 swar_codes4(u32 v, bool* all_acgt) {
+  u32 x = (v >> 1) & 0x03030303u;          // A 0, C 1, T 2, G 3
+  x ^= (x >> 1) & 0x01010101u;             // A 0, C 1, G 2, T 3
+  u32 const c0 = x & 0x01010101u, c1 = (x >> 1) & 0x01010101u;
+  u32 const expect = 0x41414141u + 2u * c0 + 6u * c1 + 11u * (c0 & c1);
+  *all_acgt = v == expect;
+  return x;
+}
+// Round 5: the kernel runs in two phases that share ONE 72 KB LDS area.  Phase A stages the window's read bases and hashes
+// every slow k-mer: one 16-byte record per k-mer -- id, instance index + flags, sequence -- written to HBM with coalesced
+// stores; phase B builds the map from the records (each thread reads back what it wrote itself: one coalesced load per k-mer,
+// no gather).  With the map and the staged bases side by side the kernel held 139 KB: one workgroup, four waves per SIMD,
+// per CU -- and every phase of it is a chain of round trips that wants more waves in flight.  The records carry the instance's
+// error-free / last bits (k_classify) and its canonical bit, so an instance word is WRITTEN once, with its final table slot --
+// the LDS map's entry, which is what the table is copied out from -- and never read: the old passes read and rewrote every
+// slow instance's word twice (two 64-byte sectors per 4-byte word).
 __global__ __launch_bounds__(kInsT) void k_insert(DBatch b, GraphWs ws) {
   __shared__ __align__(16) unsigned char l_area[kInsArea];
   __shared__ u32 l_nmap, l_ndef, l_seq_ok;
   u32* const l_seq = reinterpret_cast<u32*>(l_area);                               // phase A: [kSeqWords + 8]
-  u32* const l_rpos = reinterpret_cast<u32*>(l_area + 4u * (kSeqWords + 8u));      //          [kSeqCap] first base of a sequence in l_seq
+  u32* const l_rpos = reinterpret_cast<u32*>(l_area + 4u * (kSeqWords + 8u));      //          [kStageSeqs] first base of a sequence in l_seq
+  u32* const l_ibase = l_rpos + kStageSeqs;                                        //          [kStageSeqs] its first instance
   u64* const l_key = reinterpret_cast<u64*>(l_area);                               // phase B: [kInsMap]
   u32* const l_min = reinterpret_cast<u32*>(l_area + 8u * kInsMap);                //          [kInsMap] smallest instance of the id
   int const a = blockIdx.x;
@@ -664,15 +680,16 @@ __global__ __launch_bounds__(kInsT) void k_insert(DBatch b, GraphWs ws) {
   u64* keys = ws.tbl_key + (static_cast<size_t>(a) << tcl);
   u32* first = ws.tbl_first + (static_cast<size_t>(a) << tcl);
   u32* inst_slot = ws.inst_slot + static_cast<size_t>(a) * ws.inst_stride;
-  u32* slowq = ws.slowq + static_cast<size_t>(a) * ws.inst_stride;
-  u64* ids = ws.slow_id + static_cast<size_t>(a) * ws.inst_stride;
+  const u32* slowq = ws.slowq + static_cast<size_t>(a) * ws.inst_stride;
+  uint4* recs = ws.slow_rec + static_cast<size_t>(a) * ws.inst_stride;  // [reference k-mers | slow queue]
   u32* ref_slot_g = ws.ref_slot + static_cast<size_t>(a) * ws.ref_stride;
   u32 const base_idx = b.read_win_off[w] + w;
   u32 const r_first = b.read_win_off[w];
   SeqInfo const rsi = seq_info(b, w, 0, k);
   u32 const nq = ws.n_slow[a];
+  constexpr u32 kInstIdx = (1u << 29) - 1u;  // record word z: instance index | kQLast | kQErrFree | kQPlus
   IPROF_T0();
-  // ================= phase A: ids =================
+  // ================= phase A: one record per k-mer =================
   // The slow pass hashes ~16 k k-mers per window: straight from the read bytes that was a chain of dependent HBM round trips
   // per instance.  The window's read bases are staged in LDS first (4 bit per base, aligned 8-byte loads) whenever they fit
   // and hold nothing but A/C/G/T/N; deeper or odd windows hash from HBM.
@@ -682,7 +699,7 @@ __global__ __launch_bounds__(kInsT) void k_insert(DBatch b, GraphWs ws) {
   }();
   u64 const seq_bytes = static_cast<u64>((b.read_bases + b.read_off[b.read_win_off[w + 1]]) - seq_base);
   u32 const ns_all = seq_count(b, w);
-  bool const stage = nq > 0 && seq_bytes <= static_cast<u64>(kSeqWords) * 8u && ns_all <= kSeqCap;
+  bool const stage = nq > 0 && seq_bytes <= static_cast<u64>(kSeqWords) * 8u && ns_all <= kStageSeqs;
   if (threadIdx.x == 0) {
     l_nmap = l_ndef = 0;
     l_seq_ok = stage ? 1u : 0u;
@@ -695,6 +712,15 @@ __global__ __launch_bounds__(kInsT) void k_insert(DBatch b, GraphWs ws) {
     bool odd = false;
     const u8* const first_read_byte = b.read_bases + b.read_off[b.read_win_off[w]];
     auto encode_word = [&](u32 wd, uint2 v) {
+      bool ok_lo, ok_hi;
+      u32 const xl = swar_codes4(v.x, &ok_lo), xh = swar_codes4(v.y, &ok_hi);
+      if (ok_lo && ok_hi) {  // eight upper-case A/C/G/T (all but one word in a few hundred): bytes -> nibbles
+        u32 yl = (xl | (xl >> 4)) & 0x00FF00FFu, yh = (xh | (xh >> 4)) & 0x00FF00FFu;
+        yl = (yl | (yl >> 8)) & 0xFFFFu;
+        yh = (yh | (yh >> 8)) & 0xFFFFu;
+        l_seq[wd] = yl | (yh << 16);
+        return;
+      }
       u32 pk = 0;
 #pragma unroll
       for (int x = 0; x < 8; ++x) {
@@ -744,24 +770,26 @@ __global__ __launch_bounds__(kInsT) void k_insert(DBatch b, GraphWs ws) {
     }
     for (u32 wd = nwords + threadIdx.x; wd < nwords + 8u; wd += kInsT) l_seq[wd] = 0;  // (the packed identity reads five words)
     if (odd) l_seq_ok = 0;  // a base that is not A/C/G/T/N: the codes would not give its byte back
-    for (u32 sq = 1 + threadIdx.x; sq < ns_all; sq += kInsT)  // sequence sq >= 1 is read read_win_off[w] + sq - 1
+    for (u32 sq = 1 + threadIdx.x; sq < ns_all; sq += kInsT) {  // sequence sq >= 1 is read read_win_off[w] + sq - 1
       l_rpos[sq] = static_cast<u32>((b.read_bases + b.read_off[b.read_win_off[w] + sq - 1]) - seq_base);
+      l_ibase[sq] = ws.seq_inst_base[base_idx + sq];
+    }
     __syncthreads();
   }
   bool const staged = l_seq_ok != 0;
   IPROF(0);  // staging
-  {  // reference k-mers (graph.cpp:264-267): instance index == reference position; ids[p]
+  {  // reference k-mers (graph.cpp:264-267): instance index == reference position; recs[p]
     const u8* s = b.ref_bases + rsi.off;
     for (u32 p = threadIdx.x; p < rsi.nk; p += kInsT) {
       bool plus;
-      ids[p] = kmer_id(s + p, k, &plus);
-      inst_slot[p] = (plus ? kInstPlus : 0u) | (p + 1 == rsi.nk ? kInstLast : 0u);  // (its slot: phase B)
+      u64 const id = kmer_id(s + p, k, &plus);
+      recs[p] = make_uint4(static_cast<u32>(id), static_cast<u32>(id >> 32), p | (plus ? kQPlus : 0u) | (p + 1 == rsi.nk ? kQLast : 0u), 0u);
     }
   }
-  // slow queue: ids[nk + x]; the item gets its canonical bit.  Four independent chains per thread.
+  // slow queue: recs[nk + x].  Four independent chains per thread.
   constexpr int kIU = 4;
   for (u32 x0 = threadIdx.x; x0 < nq; x0 += kInsT * kIU) {
-    u32 item[kIU];
+    u32 item[kIU], inst[kIU];
     u64 off[kIU], id[kIU];
     bool live[kIU], plus[kIU];
 #pragma unroll
@@ -775,9 +803,11 @@ __global__ __launch_bounds__(kInsT) void k_insert(DBatch b, GraphWs ws) {
       u32 const s_idx = (item[u] >> 12) & kQSeqMask, o = item[u] & 0xFFFu;
       if (staged) {  // (slow instances come from reads: s_idx >= 1)
         off[u] = live[u] ? l_rpos[s_idx] + o : 0u;  // position in l_seq
+        inst[u] = live[u] ? l_ibase[s_idx] + o : 0u;
       } else {
         SeqInfo const si = seq_info(b, w, live[u] ? s_idx : 0u, k);
         off[u] = si.off + o;
+        inst[u] = live[u] ? ws.seq_inst_base[base_idx + s_idx] + o : 0u;
       }
     }
 #pragma unroll
@@ -790,24 +820,24 @@ __global__ __launch_bounds__(kInsT) void k_insert(DBatch b, GraphWs ws) {
 #pragma unroll
     for (int u = 0; u < kIU; ++u) {
       if (!live[u]) continue;
-      u32 const x = x0 + u * kInsT;
-      ids[rsi.nk + x] = id[u];
-      slowq[x] = item[u] | (plus[u] ? kQPlus : 0u);
+      recs[rsi.nk + x0 + u * kInsT] = make_uint4(static_cast<u32>(id[u]), static_cast<u32>(id[u] >> 32),
+                                                 inst[u] | (item[u] & (kQErrFree | kQLast)) | (plus[u] ? kQPlus : 0u),
+                                                 (item[u] >> 12) & kQSeqMask);
     }
   }
   __threadfence_block();
   __syncthreads();  // the staged bases are dead: the area becomes the map
-  IPROF(1);  // ids
+  IPROF(1);  // records
   // ================= phase B: the map =================
   for (u32 i = threadIdx.x; i < kInsMap; i += kInsT) {
     l_key[i] = 0;
     l_min[i] = 0xFFFFFFFFu;
   }
   __syncthreads();
-  // map entry of an id (kNoNode: no room along this probe sequence -- then there never will be for this id)
+  // map entry of an id (kNoNode: no room -- the map has not an entry free within kInsProbe of the id's place, and never will)
   auto map_entry = [&](u64 id) -> u32 {
     u32 e = static_cast<u32>(id >> 32) % kInsMap;
-    for (u32 probe = 0; probe < 64; ++probe) {
+    for (u32 probe = 0; probe < kInsProbe; ++probe) {
       u64 cur = l_key[e];
       if (cur == 0) {
         unsigned long long const old = atomicCAS(reinterpret_cast<unsigned long long*>(&l_key[e]), 0ull,
@@ -820,9 +850,9 @@ __global__ __launch_bounds__(kInsT) void k_insert(DBatch b, GraphWs ws) {
     }
     return kNoNode;
   };
-  auto map_find = [&](u64 id) -> u32 {  // (an id that found no room within 64 probes is not found within 64 either)
+  auto map_find = [&](u64 id) -> u32 {  // (an id that found no room within kInsProbe probes is not found within them either)
     u32 e = static_cast<u32>(id >> 32) % kInsMap;
-    for (u32 probe = 0; probe < 64; ++probe) {
+    for (u32 probe = 0; probe < kInsProbe; ++probe) {
       u64 const cur = l_key[e];
       if (cur == id) return e;
       if (cur == 0) return kNoNode;
@@ -830,14 +860,19 @@ __global__ __launch_bounds__(kInsT) void k_insert(DBatch b, GraphWs ws) {
     }
     return kNoNode;
   };
+  auto const word_flags = [](u32 z) -> u32 {
+    return ((z & kQPlus) ? kInstPlus : 0u) | ((z & kQErrFree) ? kInstErrFree : 0u) | ((z & kQLast) ? kInstLast : 0u);
+  };
+  auto const rec_id = [](uint4 const& r) -> u64 { return static_cast<u64>(r.x) | (static_cast<u64>(r.y) << 32); };
   // When every id finds room in the LDS map (always, except in deep samples) the map IS the table: slot = map entry, keys and
   // first instances are copied out with coalesced stores below, and every instance word can be written here and now.  The
   // words are written on that assumption; the rare window that needs the HBM table rewrites them (the general route below).
   for (u32 p = threadIdx.x; p < rsi.nk; p += kInsT) {
-    u32 const e = map_entry(ids[p]);
+    uint4 const rc = recs[p];
+    u32 const e = map_entry(rec_id(rc));
     if (e != kNoNode) {
       atomicMin(&l_min[e], p);
-      inst_slot[p] |= e;  // (flags from phase A, written by this same thread)
+      inst_slot[p] = e | word_flags(rc.z);
       ref_slot_g[p] = e;
     } else {
       atomicAdd(&l_ndef, 1u);
@@ -845,32 +880,25 @@ __global__ __launch_bounds__(kInsT) void k_insert(DBatch b, GraphWs ws) {
   }
   __syncthreads();  // a later instance of a reference k-mer sees a reference position as its id's minimum
   IPROF(2);  // reference k-mers
-  auto const word_flags = [](u32 item) -> u32 {
-    return ((item & kQPlus) ? kInstPlus : 0u) | ((item & kQErrFree) ? kInstErrFree : 0u) | ((item & kQLast) ? kInstLast : 0u);
-  };
   for (u32 x0 = threadIdx.x; x0 < nq; x0 += kInsT * kIU) {
-    u32 item[kIU], inst[kIU];
-    u64 id[kIU];
+    uint4 rc[kIU];
     bool live[kIU];
 #pragma unroll
     for (int u = 0; u < kIU; ++u) {
       u32 const x = x0 + u * kInsT;
       live[u] = x < nq;
-      item[u] = live[u] ? slowq[x] : 0u;
-      id[u] = live[u] ? ids[rsi.nk + x] : 1ull;
+      rc[u] = recs[rsi.nk + (live[u] ? x : 0u)];
     }
-#pragma unroll
-    for (int u = 0; u < kIU; ++u)
-      inst[u] = live[u] ? ws.seq_inst_base[base_idx + ((item[u] >> 12) & kQSeqMask)] + (item[u] & 0xFFFu) : 0u;
 #pragma unroll
     for (int u = 0; u < kIU; ++u) {
       if (!live[u]) continue;
-      u32 const e = map_entry(id[u]);
+      u32 const e = map_entry(rec_id(rc[u]));
       if (e != kNoNode) {
-        u32 const before = atomicMin(&l_min[e], inst[u]);
-        inst_slot[inst[u]] = e | word_flags(item[u]);
+        u32 const inst = rc[u].z & kInstIdx;
+        u32 const before = atomicMin(&l_min[e], inst);
+        inst_slot[inst] = e | word_flags(rc[u].z);
         // the k-mer is also a reference k-mer <=> the smallest instance of its id is a reference position
-        if ((item[u] & kQErrFree) && before < rsi.nk) ws.rd_flag[r_first + ((item[u] >> 12) & kQSeqMask) - 1] = 1;
+        if ((rc[u].z & kQErrFree) && before < rsi.nk) ws.rd_flag[r_first + rc[u].w - 1] = 1;
       } else {
         atomicAdd(&l_ndef, 1u);
       }
@@ -926,25 +954,23 @@ __global__ __launch_bounds__(kInsT) void k_insert(DBatch b, GraphWs ws) {
     return slot & kInstSlotMask;
   };
   for (u32 p = threadIdx.x; p < rsi.nk; p += kInsT) {
-    u64 const id = ids[p];
-    u32 const e = map_find(id);
+    uint4 const rc = recs[p];
+    u32 const e = map_find(rec_id(rc));
     u32 slot, of;
     if (e != kNoNode) {
       slot = l_min[e] & 0x7FFFFFFFu;
       slot = slot == 0x7FFFFFFFu ? 0u : slot;
     } else {
-      slot = direct_insert(id, p, &of);
+      slot = direct_insert(rec_id(rc), p, &of);
     }
-    inst_slot[p] = (inst_slot[p] & (kInstPlus | kInstLast)) | slot;
+    inst_slot[p] = word_flags(rc.z) | slot;
     ref_slot_g[p] = slot;
   }
   __syncthreads();  // a later instance of a reference k-mer sees a reference position as the minimum
   for (u32 x = threadIdx.x; x < nq; x += kInsT) {
-    u32 const item = slowq[x];
-    u64 const id = ids[rsi.nk + x];
-    u32 const s_idx = (item >> 12) & kQSeqMask;
-    u32 const inst = ws.seq_inst_base[base_idx + s_idx] + (item & 0xFFFu);
-    u32 const e = map_find(id);
+    uint4 const rc = recs[rsi.nk + x];
+    u32 const inst = rc.z & kInstIdx;
+    u32 const e = map_find(rec_id(rc));
     u32 slot;
     bool isref;
     if (e != kNoNode) {
@@ -954,18 +980,25 @@ __global__ __launch_bounds__(kInsT) void k_insert(DBatch b, GraphWs ws) {
       isref = (sv >> 31) != 0;
     } else {
       u32 of;
-      slot = direct_insert(id, inst, &of);
+      slot = direct_insert(rec_id(rc), inst, &of);
       isref = of < rsi.nk;
     }
-    inst_slot[inst] = slot | word_flags(item);
-    if ((item & kQErrFree) && isref) ws.rd_flag[r_first + s_idx - 1] = 1;
+    inst_slot[inst] = slot | word_flags(rc.z);
+    if ((rc.z & kQErrFree) && isref) ws.rd_flag[r_first + rc.w - 1] = 1;
   }
   IPROF(5);  // general route
 }
 #ifdef MA_PROFILE
-extern "C" void ma_debug_iprof(unsigned long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_iprof), sizeof(unsigned long long) * 16); }
+extern "C" void ma_debug_iprof(unsigned long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_iprof), sizeof(unsigned long long) * 32); }
 #endif
 
+// edge-queue entry: instance index (22 bits) and the two instance words cut down to what names their node -- FAST bit + 20 bits
+// of table slot / reference position (k_graph only takes windows of at most 8192 slots and 2^18 instances)
+__device__ __forceinline__ u32 edge_word(u32 word) { return ((word & kInstFast) ? (1u << 20) : 0u) | (word & 0xFFFFFu); }
+__device__ __forceinline__ uint2 edge_pack(u32 ii, u32 wa, u32 wb) {
+  u32 const ca = edge_word(wa), cb = edge_word(wb);
+  return make_uint2((ii & 0x3FFFFFu) | (ca << 22), (ca >> 10) | (cb << 11));
+}
 // (3) k_support: read support of the FAST instances (node.cpp:18-24 + graph.h:102-117), one thread per group
 //     of adjacent reads with equal (qname, role, sample); per-reference-position counters live in LDS.
 constexpr u32 kSupCache = 2048;  // reads per window whose records k_support keeps in LDS
@@ -978,6 +1011,8 @@ __global__ __launch_bounds__(kSupT) void k_support(DBatch b, GraphWs ws, u32* ma
   extern __shared__ unsigned char lds_build[];
   __shared__ u32 xs_flag;
   __shared__ u32 gen_count;  // instances routed through the general mate-mer set (sizes that set)
+  __shared__ u32 genq_n;     // queue mode: keys written to the window's general-instance queue so far
+  __shared__ u32 edgeq_n;    // (k+1)-mers written to the window's edge queue so far
   __shared__ u32 n_leaders;
   int const a = blockIdx.x;
   int const w = static_cast<int>(ws.active[a]);
@@ -1018,6 +1053,8 @@ __global__ __launch_bounds__(kSupT) void k_support(DBatch b, GraphWs ws, u32* ma
   if (threadIdx.x == 0) {
     xs_flag = 0;
     gen_count = 0;
+    genq_n = 0;
+    edgeq_n = 0;
   }
   if (cached) {
     for (u32 sx = 1 + threadIdx.x; sx < ns; sx += kSupT) {
@@ -1088,6 +1125,19 @@ __global__ __launch_bounds__(kSupT) void k_support(DBatch b, GraphWs ws, u32* ma
   }
   __syncthreads();
   bool const all_generic = !hints || xs_flag != 0;
+  // Round 5, QUEUE MODE (every window whose (qname, role) keys are runs of adjacent reads and whose sequences fit an 11-bit
+  // leader index -- all but deep panels and windows without hints): a general instance's mate-mer KEY (table slot << 11 |
+  // run leader) is appended to the window's queue right here, where its word is in a register anyway; k_mm_q builds the LDS set
+  // from the queue.  k_mm_lds found the general instances by streaming all of the window's instance words again (311 KB per
+  // window for 31 KB of keys) and needed a GEN bit written back into each of them (a scattered 4-byte store per instance).
+  // The queue is the slow queue's memory: k_insert is done with it.
+  bool const qmode = !all_generic && !ws.mm_force_hbm && ns <= kSeqCap && tbl_log2(ws) <= 20;
+  u32* const genq = ws.slowq + static_cast<size_t>(a) * ws.inst_stride;
+  // EDGE QUEUE: the (k+1)-mers of the reads that are not the reference's own edges (both k-mers FAST at consecutive reference
+  // positions: 7 of 8) -- instance index and both words packed into 8 bytes (edge_pack), into the memory k_insert's records lived in.  k_graph
+  // builds the window's edges from this queue and the reference's own words: after k_classify has written the instance words
+  // this kernel is the only one that streams them.
+  uint2* const edgeq = reinterpret_cast<uint2*>(ws.slow_rec + static_cast<size_t>(a) * ws.inst_stride);
 
   // One WAVEFRONT per group of mates, a lane per k-mer: the instance words of a read are read coalesced, the offsets
   // of the first mate that were counted are one ballot per 64 k-mers (kept in scalar registers), and the second mate
@@ -1183,12 +1233,41 @@ __global__ __launch_bounds__(kSupT) void k_support(DBatch b, GraphWs ws, u32* ma
         u32 const o = ob + lane;
         u32 const word = have_pre ? (gm == 0 ? (ob == 0 ? pre00 : pre01) : (ob == 0 ? pre10 : pre11))
                                   : (o < si.nk ? inst_slot[ibase + o] : 0u);
+        {
+          u32 const dn = __shfl_down(word, 1, 64);
+          u32 first_next;  // the word at offset ob + 64 (the neighbour of lane 63's)
+          if (have_pre) first_next = ob == 0 ? __shfl(gm == 0 ? pre01 : pre11, 0, 64) : 0u;
+          else first_next = ob + 64 < si.nk ? inst_slot[ibase + ob + 64] : 0u;
+          u32 const nextw = lane == 63 ? first_next : dn;
+          bool const pair = o + 1 < si.nk && !((word & kInstFast) && (nextw & kInstFast) &&
+                                               (nextw & kInstSlotMask) == (word & kInstSlotMask) + 1u);
+          unsigned long long const em = __ballot(pair);
+          if (em) {
+            u32 eb = 0;
+            if (lane == 0) eb = atomicAdd(&edgeq_n, static_cast<u32>(__popcll(em)));
+            eb = __shfl(eb, 0, 64);
+            if (pair) edgeq[eb + static_cast<u32>(__popcll(em & ((1ull << lane) - 1ull)))] = edge_pack(ibase + o, word, nextw);
+          }
+        }
         bool const ef = (word & kInstErrFree) != 0;
         bool const to_gen = ef && (generic || !(word & kInstFast));
-        if (to_gen) inst_slot[ibase + o] = word | kInstGen;  // exact handling by the mate-mer set kernels
-        wave_gen += static_cast<u32>(__popcll(__ballot(to_gen)));
-        bool const fast = ef && !to_gen;
         u32 const p = word & kInstSlotMask;
+        unsigned long long const gmask = __ballot(to_gen);
+        if (qmode) {
+          if (gmask) {
+            u32 qb = 0;
+            if (lane == 0) qb = atomicAdd(&genq_n, static_cast<u32>(__popcll(gmask)));
+            qb = __shfl(qb, 0, 64);
+            if (to_gen) {
+              u32 const nslot = (word & kInstFast) ? ref_slot_g[p] : p;
+              genq[qb + static_cast<u32>(__popcll(gmask & ((1ull << lane) - 1ull)))] = ((nslot << 11) | (s_idx - 1u)) + 1u;
+            }
+          }
+        } else if (to_gen) {
+          inst_slot[ibase + o] = word | kInstGen;  // exact handling by the mate-mer set kernels
+        }
+        wave_gen += static_cast<u32>(__popcll(gmask));
+        bool const fast = ef && !to_gen;
         bool dup = false;
         if (gm == 1 && nk0 > 0 && fast) {  // did the first member count this reference position?
           i64 const o0 = static_cast<i64>(p) - hint0;
@@ -1219,10 +1298,11 @@ __global__ __launch_bounds__(kSupT) void k_support(DBatch b, GraphWs ws, u32* ma
     // instances fit the LDS set are finished by k_mm_lds; the others need the HBM-resident set (max_gen[1]).
     // (up to four passes over the set for a window that fits the LDS tables; a deeper one goes chunk by chunk)
     bool const lds_ok = !all_generic && !ws.mm_force_hbm && (ns > kSeqCap || gen_count <= 4u * kMmLdsMax) && tbl_log2(ws) <= 20;
-    ws.mm_mode[a] = gen_count | (lds_ok ? 0u : 0x80000000u);
+    ws.n_edgeq[a] = edgeq_n;
+    ws.mm_mode[a] = qmode ? (gen_count | 0x40000000u) : (gen_count | (lds_ok ? 0u : 0x80000000u));  // bit 30: k_mm_q, bit 31: HBM set
     atomicMax(max_gen, gen_count);
     ws.mm_log2[a] = 0;
-    if (!lds_ok && gen_count) {
+    if (!qmode && !lds_ok && gen_count) {
       // the window's HBM-resident set: 12 bytes per entry at a load of 3/4, carved out of the chunk's pool.  A pool that is
       // used up is a capacity like any other: the window is flagged and the retry pass, whose pool holds a full set per
       // window, re-assembles it.
@@ -1257,9 +1337,7 @@ __device__ __forceinline__ u32 inst_table_slot(u32 word, const u32* ref_slot_g) 
 // k_mm_insert / k_count / k_rank / k_edges walk the window's instance words in FLAT order (lane i reads
 // word base + i: coalesced); the read of an instance is recovered from the per-sequence instance bases
 // only for the few instances that need it.
-__global__ __launch_bounds__(kBT) void k_mm_insert(DBatch b, GraphWs ws) {
-  __shared__ u32 l_base[kSeqCap];
-  int const a = blockIdx.x;
+__device__ __forceinline__ void mm_hbm_insert(DBatch const& b, GraphWs const& ws, int a, u32* l_base) {
   if (!(ws.mm_mode[a] & 0x80000000u) || ws.mm_log2[a] == 0) return;  // done by k_mm_lds / no set (flagged)
   int const w = static_cast<int>(ws.active[a]);
   u32 const mlg = ws.mm_log2[a];
@@ -1303,9 +1381,7 @@ __global__ __launch_bounds__(kBT) void k_mm_insert(DBatch b, GraphWs ws) {
   }
 }
 
-__global__ __launch_bounds__(kBT) void k_count(DBatch b, GraphWs ws) {
-  __shared__ u32 l_base[kSeqCap];
-  int const a = blockIdx.x;
+__device__ __forceinline__ void mm_hbm_count(DBatch const& b, GraphWs const& ws, int a, u32* l_base) {
   if (!(ws.mm_mode[a] & 0x80000000u) || ws.mm_log2[a] == 0) return;  // done by k_mm_lds / no set (flagged)
   int const w = static_cast<int>(ws.active[a]);
   int const S = ws.num_samples, CW = S + 2;
@@ -1348,6 +1424,18 @@ __global__ __launch_bounds__(kBT) void k_count(DBatch b, GraphWs ws) {
   }
 }
 
+// the HBM-resident mate-mer set of the windows that need one (no mapping hints, names in separate runs, capacity retries):
+// build it, then count through it -- one workgroup per such window does both
+__global__ __launch_bounds__(kBT) void k_mm_hbm(DBatch b, GraphWs ws) {
+  __shared__ u32 l_base[kSeqCap];
+  int const a = blockIdx.x;
+  if (!(ws.mm_mode[a] & 0x80000000u) || ws.mm_log2[a] == 0) return;  // done by k_mm_q / k_mm_lds, or no set (flagged)
+  mm_hbm_insert(b, ws, a, l_base);
+  __threadfence_block();
+  __syncthreads();
+  mm_hbm_count(b, ws, a, l_base);
+}
+
 // k_mm_lds: the general mate-mer set (graph.h:102-117) and its read support (node.cpp:18-24) for one window, entirely
 // in LDS.  k_mm_insert / k_count keep a (slot, qname, role) set per window in HBM: ~12 k random 128-byte-line
 // accesses per window and pass (profiles/: 8-10 GB of traffic per launch for ~0.6 GB of useful bytes).  When every
@@ -1372,7 +1460,7 @@ __global__ __launch_bounds__(kMmT) void k_mm_lds(DBatch b, GraphWs ws) {
   u32* const l_queue = l_aux + kSeqCap + kSeqCap / 2;
   int const a = blockIdx.x;
   u32 const mode = ws.mm_mode[a];
-  if ((mode & 0x80000000u) || mode == 0) return;
+  if ((mode & 0xC0000000u) || mode == 0) return;  // HBM set / queue mode (k_mm_q) / nothing to do
   int const w = static_cast<int>(ws.active[a]);
   int const S = ws.num_samples, CW = S + 2;
   u32* cnt = ws.tbl_cnt + (static_cast<size_t>(a) << tbl_log2(ws)) * CW;
@@ -1602,15 +1690,146 @@ __global__ __launch_bounds__(kMmT) void k_mm_lds(DBatch b, GraphWs ws) {
   }  // chunk
 }
 
+// k_mm_q: the mate-mer set and its read support from the window's KEY QUEUE (k_support, queue mode).  Same set, same
+// compaction, same packed counters as k_mm_lds -- without the walk over the instance words, the instance bases, run leaders
+// and block table that walk needed (30 KB of LDS), and in two sizes: a 16 k-entry set (76 KB: two workgroups per CU) for the
+// windows with up to 14 k general instances -- the usual WGS window has 8 k --, a 32 k-entry set for the rest, which take
+// as many passes over slot classes as their keys need (a pass re-reads the queue: 4 bytes per key).
+template <int kCapLog2>
+__global__ __launch_bounds__(kMmT) void k_mm_q(DBatch b, GraphWs ws) {
+  constexpr u32 kCap = 1u << kCapLog2, kMax = kCap * 7u / 8u;
+  constexpr u32 kAux = kCapLog2 == 14 ? 3072u : 7168u;
+  __shared__ u32 l_set[kCap];
+  __shared__ u32 l_aux[kAux];  // packed u16 support counters (+ the free tail of the set)
+  __shared__ u32 l_full;
+  int const a = blockIdx.x;
+  u32 const mode = ws.mm_mode[a];
+  if ((mode & 0xC0000000u) != 0x40000000u) return;
+  u32 const gen = mode & 0x3FFFFFFFu;
+  if (gen == 0) return;
+  int const w = static_cast<int>(ws.active[a]);
+  int const S = ws.num_samples, CW = S + 2;
+  u32* cnt = ws.tbl_cnt + (static_cast<size_t>(a) << tbl_log2(ws)) * CW;
+  const u32* genq = ws.slowq + static_cast<size_t>(a) * ws.inst_stride;
+  u32 const r_base = b.read_win_off[w];
+  u32 const lane = threadIdx.x & 63u;
+  u32 const pmax = min(ws.mm_probe_max, kCap);
+  u32 const npass = (gen + kMax - 1u) / kMax;
+  if (threadIdx.x == 0) l_full = 0;
+  IPROF_T0();
+  for (u32 pass = 0; pass < npass; ++pass) {
+    __syncthreads();
+    for (u32 i = threadIdx.x; i < kCap; i += kMmT) l_set[i] = 0;
+    IPROF_SYNC(22);  // set init
+    constexpr int kU = 4;
+    for (u32 q0 = threadIdx.x; q0 < gen; q0 += kMmT * kU) {
+      u32 key[kU];
+#pragma unroll
+      for (int u = 0; u < kU; ++u) key[u] = q0 + u * kMmT < gen ? genq[q0 + u * kMmT] : 0u;
+#pragma unroll
+      for (int u = 0; u < kU; ++u) {
+        if (key[u] == 0 || (npass > 1 && ((key[u] - 1u) >> 11) % npass != pass)) continue;
+        u32 h = (key[u] * 2654435761u) >> (32 - kCapLog2);
+        bool placed = false;
+        for (u32 probe = 0; probe < pmax; ++probe) {
+          u32 cur = l_set[h];
+          if (cur == 0) {
+            u32 const old = atomicCAS(&l_set[h], 0u, key[u]);
+            cur = old == 0 ? key[u] : old;
+          }
+          if (cur == key[u]) {
+            placed = true;
+            break;
+          }
+          h = (h + 1) & (kCap - 1);
+          if ((probe & 127u) == 127u && l_full) break;  // somebody has found the set full: the window is redone anyway
+        }
+        // No room.  The passes are sized by a key COUNT, but the keys of a k-mer that a thousand read pairs carry all fall into
+        // its slot's pass: a pass can outgrow the set.  Never silent: the window is flagged like any other capacity, the retry
+        // pass re-assembles it from scratch and sends its mate-mers through the HBM set (k_support: mm_force_hbm).
+        if (!placed) l_full = 1;
+      }
+    }
+    IPROF_SYNC(23);  // queue -> set
+    // The set is not probed any more: its keys are compacted to the front (every thread reads its entries into registers
+    // first, so compacting in place is safe) and the rest of the set joins l_aux as counter space.
+    u32 nkeys = 0;
+    {
+      constexpr u32 kPer = kCap / kMmT;
+      u32 mine[kPer];
+      u32 cntk = 0;
+#pragma unroll
+      for (u32 x = 0; x < kPer; ++x) {
+        mine[x] = l_set[threadIdx.x * kPer + x];
+        cntk += mine[x] != 0;
+      }
+      __syncthreads();
+      u32 inc = cntk;
+#pragma unroll
+      for (u32 o = 1; o < 64; o <<= 1) {
+        u32 const y = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += y;
+      }
+      if (lane == 63) l_aux[threadIdx.x >> 6] = inc;
+      __syncthreads();
+      u32 woff = 0, total = 0;
+      for (u32 k = 0; k < kMmT / 64; ++k) {
+        u32 const t = l_aux[k];
+        if (k < (threadIdx.x >> 6)) woff += t;
+        total += t;
+      }
+      __syncthreads();
+      u32 at = woff + inc - cntk;
+#pragma unroll
+      for (u32 x = 0; x < kPer; ++x)
+        if (mine[x] != 0) l_set[at++] = mine[x];
+      nkeys = total;
+    }
+    IPROF_SYNC(24);  // compaction
+    // Read support: one count per key, for the leader's sample and role -- accumulated in LDS as packed u16 (a slot has at most
+    // 2047 names) for a range of slots at a time and added to the window's table in index order.
+    u32 const tail_words = kCap - nkeys;
+    u32 const ctr_words = kAux + tail_words;
+    auto const ctr = [&](u32 wd) -> u32& { return wd < kAux ? l_aux[wd] : l_set[nkeys + (wd - kAux)]; };
+    u32 const slots_per_pass = (2u * ctr_words) / static_cast<u32>(CW);
+    u32 const tcap = ws.win_nslots[a];
+    for (u32 s0 = 0; s0 < tcap; s0 += slots_per_pass) {
+      for (u32 i = threadIdx.x; i < ctr_words; i += kMmT) ctr(i) = 0;
+      __syncthreads();
+      for (u32 i = threadIdx.x; i < nkeys; i += kMmT) {
+        u32 const key = l_set[i];
+        u32 const nslot = (key - 1u) >> 11;
+        if (nslot < s0 || nslot - s0 >= slots_per_pass) continue;
+        u32 const r = r_base + ((key - 1u) & 2047u);  // the run's leader: sequence (key & 2047) + 1 is read r_base + that
+        u32 sample = b.read_sample[r];
+        if (sample >= static_cast<u32>(S)) sample = S - 1;
+        u32 const role = (b.read_flags[r] & MA_RF_CASE) ? 1u : 0u;
+        u32 const i1 = (nslot - s0) * CW + sample, i2 = (nslot - s0) * CW + S + role;
+        atomicAdd(&ctr(i1 >> 1), 1u << ((i1 & 1u) * 16u));
+        atomicAdd(&ctr(i2 >> 1), 1u << ((i2 & 1u) * 16u));
+      }
+      __syncthreads();
+      u32 const nc = min(slots_per_pass, tcap - s0) * CW;
+      for (u32 j = threadIdx.x; j < nc; j += kMmT) {
+        u32 const c = (ctr(j >> 1) >> ((j & 1u) * 16u)) & 0xFFFFu;
+        if (c) atomicAdd(&cnt[static_cast<size_t>(s0) * CW + j], c);  // no return value: the wave does not wait for it
+      }
+      __syncthreads();
+    }
+    IPROF(25);  // support counters
+  }
+  __syncthreads();
+  if (l_full && threadIdx.x == 0) atomicOr(&ws.win_flags[w], 4u);
+}
+
 // low-coverage pruning (graph.cpp:363-390 with component 0 == everything, no anchors yet) and
 // canonical ranking of the survivors by first-insertion order.
 // sixteen wavefronts per window: the table pass and the node records are chains of round trips to HBM per thread, the
 // ranking scan a chain of tiles -- four times the threads, a quarter of the chain (0.48 -> 0.39 ms per 2048 windows)
 constexpr int kRankT = 1024;
-__global__ __launch_bounds__(kRankT) void k_rank(DBatch b, GraphWs ws, u32 min_node_cov) {
+__device__ __forceinline__ void rank_window(DBatch const& b, GraphWs const& ws, u32 min_node_cov, int a) {
   __shared__ u32 sh[kRankT / 64];
   __shared__ u32 l_base[kSeqCap];
-  int const a = blockIdx.x;
   int const w = static_cast<int>(ws.active[a]);
   int const S = ws.num_samples, CW = S + 2;
   u32 const tcap = ws.win_nslots[a];  // slots this window uses (k_insert)
@@ -1800,12 +2019,11 @@ constexpr int kEdT = 1024;
 constexpr u32 kEdgeSet = 8192;    // 64 KB of keys + order keys and 8 KB of counters: TWO workgroups per CU (16 k entries made it
 constexpr u32 kEdgeNodes = 8192;  // one, and the lanes' copies of this kernel queued behind each other); fuller windows insert directly
 constexpr u32 kEdgeEmpty = 0xFFFFFFFFu;
-__global__ __launch_bounds__(kEdT) void k_edges(DBatch b, GraphWs ws) {
+__device__ __forceinline__ void edges_window(DBatch const& b, GraphWs const& ws, int a) {
   __shared__ u32 l_key[kEdgeSet];
   __shared__ u32 l_min[kEdgeSet];
   __shared__ u8 l_deg[kEdgeNodes];
   __shared__ u32 l_fail;
-  int const a = blockIdx.x;
   int const w = static_cast<int>(ws.active[a]);
   if ((ws.win_flags[w] & 4u) || ws.gr_done[a]) return;
   const u32* slot_node = ws.slot_node + (static_cast<size_t>(a) << tbl_log2(ws));
@@ -1907,12 +2125,10 @@ __global__ __launch_bounds__(kEdT) void k_edges(DBatch b, GraphWs ws) {
   }
 }
 
-__global__ __launch_bounds__(kBT) void k_edge_sort(GraphWs ws) {
-  int const a = blockIdx.x;
-  if (ws.gr_done[a]) return;
+__device__ __forceinline__ void edge_sort_window(GraphWs const& ws, int a) {
   size_t const nb = static_cast<size_t>(a) * ws.nc;
   u32 const n = min(ws.n_nodes[a], ws.nc);
-  for (u32 i = threadIdx.x; i < n; i += kBT) {
+  for (u32 i = threadIdx.x; i < n; i += kEdT) {
     u32* ed = ws.nd_edge + (nb + i) * kEdgeCap;
     u32* ek = ws.nd_ekey + (nb + i) * kEdgeCap;
     u32 v[kEdgeCap], kk[kEdgeCap];
@@ -1939,6 +2155,24 @@ __global__ __launch_bounds__(kBT) void k_edge_sort(GraphWs ws) {
     }
     for (int e = 0; e < m; ++e) ed[e] = v[e];
     ws.nd_nedge[nb + i] = static_cast<u8>(m);
+  }
+}
+
+// the general route of the graph records: low-coverage pruning + ranking, edges, edge order from the table and the instance
+// words in HBM -- for the windows k_graph does not take (a table beyond 8192 slots: deep panels, 2.5 kb windows; an edge set
+// that filled up).  A few hundred workgroups walk the batch's windows and skip the ones marked done.
+static_assert(kRankT == kEdT, "k_graph_gen runs the three phases with one workgroup size");
+__global__ __launch_bounds__(kRankT) void k_graph_gen(DBatch b, GraphWs ws, u32 min_node_cov) {
+  for (int a = blockIdx.x; a < ws.n_active; a += gridDim.x) {
+    if (ws.gr_done[a]) continue;  // k_graph took this window
+    rank_window(b, ws, min_node_cov, a);
+    __threadfence_block();
+    __syncthreads();
+    edges_window(b, ws, a);
+    __threadfence_block();
+    __syncthreads();
+    edge_sort_window(ws, a);
+    __syncthreads();
   }
 }
 
@@ -1980,7 +2214,7 @@ __global__ __launch_bounds__(kGrT) void k_graph(DBatch b, GraphWs ws, u32 min_no
   u32 const ninst = ws.win_ninst[w], nref = ninst - ws.win_nread_inst[w];
   u32 const nw = (ws.inst_stride + 31u) / 32u + 1u;
   if (threadIdx.x == 0) ws.gr_done[a] = 0;
-  if ((ws.win_flags[w] & 4u) || tcap > kGrSlots || ninst > ws.inst_stride) return;  // (uniform)
+  if ((ws.win_flags[w] & 4u) || tcap > kGrSlots || ninst > ws.inst_stride || ninst >= (1u << 22)) return;  // (uniform)
   const u64* keys = ws.tbl_key + (static_cast<size_t>(a) << tcl);
   const u32* first = ws.tbl_first + (static_cast<size_t>(a) << tcl);
   const u32* cnt = ws.tbl_cnt + (static_cast<size_t>(a) << tcl) * CW;
@@ -2006,6 +2240,7 @@ __global__ __launch_bounds__(kGrT) void k_graph(DBatch b, GraphWs ws, u32 min_no
   for (u32 i = threadIdx.x; i < kGrSlots / 32u; i += kGrT) l_sign[i] = 0;
   const u32* sbase = stage_seq_bases(ws.seq_inst_base + base_idx, ns, l_base);
   if (threadIdx.x == 0) l_fail = 0;
+  IPROF_T0();
   __syncthreads();
   // ---- 1. survivors of RemoveLowCovNodes(0) (graph.cpp:363-390; node.cpp:38-42): their first instances into the bitmap ----
   constexpr u32 kPer = kGrSlots / kGrT;  // 8 slots per thread, every load of the trip in flight together
@@ -2031,7 +2266,7 @@ __global__ __launch_bounds__(kGrT) void k_graph(DBatch b, GraphWs ws, u32 min_no
 #pragma unroll
   for (u32 j = 0; j < kPer; ++j)
     if (surv & (1u << j)) atomicOr(&l_bits[fi[j] >> 5], 1u << (fi[j] & 31u));
-  __syncthreads();
+  IPROF_SYNC(16);  // table pass
   // ---- 2. survivors before every bitmap word (block scan over the words' popcounts) ----
   u32 total_nodes;
   {
@@ -2061,8 +2296,8 @@ __global__ __launch_bounds__(kGrT) void k_graph(DBatch b, GraphWs ws, u32 min_no
           l_pref[w0 + x] = static_cast<u16>(run);
           run += __popc(l_bits[w0 + x]);
         }
-    __syncthreads();
   }
+  IPROF_SYNC(17);  // ranks
   if (threadIdx.x == 0) ws.n_nodes[a] = total_nodes;
   if (total_nodes < ws.nc && total_nodes > kGrSlots) return;  // node indices beyond the packed edge key: the general kernels
   if (total_nodes >= ws.nc) {  // capacity exceeded: flagged (k_rank's rule), the retry passes grow it
@@ -2099,7 +2334,7 @@ __global__ __launch_bounds__(kGrT) void k_graph(DBatch b, GraphWs ws, u32 min_no
     ws.nd_nedge[nb + idx] = 0;
     if (v & kInstPlus) atomicOr(&l_sign[idx >> 5], 1u << (idx & 31u));
   }
-  __syncthreads();  // (also: the ranking area is dead from here on)
+  IPROF_SYNC(18);  // node records
   // mRefNodeIds (graph.cpp:264-267): node of every reference k-mer, kNoNode when pruned
   SeqInfo const rsi = seq_info(b, w, 0, win_kmer(ws, w));
   u32* refn = ws.ref_node + static_cast<size_t>(a) * ws.ref_stride;
@@ -2113,7 +2348,7 @@ __global__ __launch_bounds__(kGrT) void k_graph(DBatch b, GraphWs ws, u32 min_no
     l_key[i] = kGrEmpty;
     l_ok[i] = 0xFFFFFFFFu;
   }
-  __syncthreads();
+  IPROF_SYNC(19);  // reference nodes, set init
   // ---- 4. an edge and its mirror per (k+1)-mer whose two k-mers survive (graph.cpp:333-337), distinct ones into the set ----
   auto const h0_of = [&](u32 src) -> u32 { return __umulhi(src * 2654435761u, kGrSet); };
   auto const set_insert = [&](u32 src, u32 val, u32 okey) {
@@ -2133,37 +2368,36 @@ __global__ __launch_bounds__(kGrT) void k_graph(DBatch b, GraphWs ws, u32 min_no
     }
     l_fail = 1;
   };
-  auto const node_of = [&](u32 wd) -> u32 {
-    return (wd & kInstFast) ? l_refn[min(wd & kInstSlotMask, ws.ref_stride - 1u)] : l_node[wd & (kGrSlots - 1u)];
+  auto const node_of = [&](u32 c) -> u32 {  // c: edge_word() of an instance word
+    return (c >> 20) ? l_refn[min(c & 0xFFFFFu, ws.ref_stride - 1u)] : l_node[c & (kGrSlots - 1u)];
   };
-  u32 const last = ninst > 0 ? ninst - 1 : 0;
-  u32 const last4 = last & ~3u;
-  // four consecutive (k+1)-mers per thread and trip: one 16-byte load + the neighbour's first word (the next trip's in flight)
-  for (u32 t0 = 0; t0 < last; t0 += 4u * kGrT) {  // (whole wavefronts reach the shuffle: the trip count is the workgroup's)
-    u32 const i0 = t0 + 4u * threadIdx.x;
-    uint4 const q4 = *reinterpret_cast<const uint4*>(inst_slot + min(i0, last4));
-    u32 nxt = __shfl_down(q4.x, 1);
-    if (lane == 63) nxt = inst_slot[min(i0 + 4u, last)];
-    u32 const wd[5] = {q4.x, q4.y, q4.z, q4.w, nxt};
+  auto const add_edge = [&](u32 ii, u32 ca, u32 cb) {
+    u32 const na = node_of(ca), nbn = node_of(cb);
+    if (na == kGrNone || nbn == kGrNone) return;
+    // edge kind from the STORED signs of both nodes (graph.cpp:333-336)
+    u32 const sa_minus = ((l_sign[na >> 5] >> (na & 31u)) & 1u) ^ 1u, sb_minus = ((l_sign[nbn >> 5] >> (nbn & 31u)) & 1u) ^ 1u;
+    u32 const fwd = (sa_minus << 1) | sb_minus;                 // MakeFwdEdgeKind(sA, sB)
+    u32 const rev = ((sb_minus ^ 1u) << 1) | (sa_minus ^ 1u);   // RevEdgeKind(fwd) seen from B
+    set_insert(na, (nbn << 2) | fwd, 2u * ii);
+    set_insert(nbn, (na << 2) | rev, 2u * ii + 1u);
+  };
+  // the reference's own (k+1)-mers (instance index == reference position), then the reads' from k_support's edge queue: the
+  // ones that are not the reference's own edges again -- one in eight
+  for (u32 p = threadIdx.x; p + 1 < nref; p += kGrT) add_edge(p, edge_word(inst_slot[p]), edge_word(inst_slot[p + 1]));
+  {
+    const uint2* edgeq = reinterpret_cast<const uint2*>(ws.slow_rec + static_cast<size_t>(a) * ws.inst_stride);
+    u32 const neq = ws.n_edgeq[a];
+    constexpr int kU = 4;
+    for (u32 q0 = threadIdx.x; q0 < neq; q0 += kGrT * kU) {
+      uint2 e[kU];
 #pragma unroll
-    for (u32 j = 0; j < 4; ++j) {
-      u32 const ii = i0 + j;
-      u32 const wa = wd[j], wb = wd[j + 1];
-      if (ii >= last || (wa & kInstLast)) continue;
-      // both k-mers are reference nodes at consecutive positions: the reference's own edge, inserted (with a smaller order
-      // key) by the reference sequence itself
-      if (ii >= nref && (wa & kInstFast) && (wb & kInstFast) && (wb & kInstSlotMask) == (wa & kInstSlotMask) + 1) continue;
-      u32 const na = node_of(wa), nbn = node_of(wb);
-      if (na == kGrNone || nbn == kGrNone) continue;
-      // edge kind from the STORED signs of both nodes (graph.cpp:333-336)
-      u32 const sa_minus = ((l_sign[na >> 5] >> (na & 31u)) & 1u) ^ 1u, sb_minus = ((l_sign[nbn >> 5] >> (nbn & 31u)) & 1u) ^ 1u;
-      u32 const fwd = (sa_minus << 1) | sb_minus;                 // MakeFwdEdgeKind(sA, sB)
-      u32 const rev = ((sb_minus ^ 1u) << 1) | (sa_minus ^ 1u);   // RevEdgeKind(fwd) seen from B
-      set_insert(na, (nbn << 2) | fwd, 2u * ii);
-      set_insert(nbn, (na << 2) | rev, 2u * ii + 1u);
+      for (int u = 0; u < kU; ++u) e[u] = edgeq[min(q0 + u * kGrT, neq - 1u)];
+#pragma unroll
+      for (int u = 0; u < kU; ++u)
+        if (q0 + u * kGrT < neq) add_edge(e[u].x & 0x3FFFFFu, (e[u].x >> 22) | ((e[u].y & 0x7FFu) << 10), e[u].y >> 11);
     }
   }
-  __syncthreads();
+  IPROF_SYNC(20);  // edge pass
   if (l_fail) return;  // (gr_done stays 0: the three general kernels redo this window from the table)
   // ---- 5. every distinct edge to its place in its node's list ----
   bool over = false;
@@ -2187,6 +2421,7 @@ __global__ __launch_bounds__(kGrT) void k_graph(DBatch b, GraphWs ws, u32 min_no
   }
   if (over) atomicOr(&ws.win_flags[w], 4u);
   if (threadIdx.x == 0) ws.gr_done[a] = 1;
+  IPROF(21);  // edge lists
 }
 
 // ---- host side: one k attempt of the build stage for the active windows ----
@@ -2239,15 +2474,17 @@ int run_build_pass(ma_ctx* ctx, const DBatch& b, GraphWs& ws, u32* counters_dev,
   ctx->toc();
   // windows whose general instances fit an LDS set are finished by k_mm_lds; the HBM-resident sets only hold what the
   // remaining windows routed to them (usually nothing: both kernels then leave at their first test)
-  ctx->tic("k_mm_lds");
-  if (ws.mm_probe_max < kMmLdsCap) hipLaunchKernelGGL(k_mm_lds<true>, dim3(ws.n_active), dim3(kMmT), 0, ctx->stream, b, ws);
-  else hipLaunchKernelGGL(k_mm_lds<false>, dim3(ws.n_active), dim3(kMmT), 0, ctx->stream, b, ws);
+  ctx->tic("k_mm_q");
+  hipLaunchKernelGGL(k_mm_q<14>, dim3(ws.n_active), dim3(kMmT), 0, ctx->stream, b, ws);
   ctx->toc();
-  ctx->tic("k_mm_insert");
-  hipLaunchKernelGGL(k_mm_insert, dim3(ws.n_active), dim3(kBT), 0, ctx->stream, b, ws);
-  ctx->toc();
-  ctx->tic("k_count");
-  hipLaunchKernelGGL(k_count, dim3(ws.n_active), dim3(kBT), 0, ctx->stream, b, ws);
+  if (ws.max_reads + 1u > kSeqCap) {  // (the scan route is for windows of more sequences than a key's leader index names)
+    ctx->tic("k_mm_lds");
+    if (ws.mm_probe_max < kMmLdsCap) hipLaunchKernelGGL(k_mm_lds<true>, dim3(ws.n_active), dim3(kMmT), 0, ctx->stream, b, ws);
+    else hipLaunchKernelGGL(k_mm_lds<false>, dim3(ws.n_active), dim3(kMmT), 0, ctx->stream, b, ws);
+    ctx->toc();
+  }
+  ctx->tic("k_mm_hbm");
+  hipLaunchKernelGGL(k_mm_hbm, dim3(ws.n_active), dim3(kBT), 0, ctx->stream, b, ws);
   ctx->toc();
   if (getenv("MA_VERBOSE")) {  // (diagnostics only: this does wait for the stream)
     std::vector<u32> mm(A);
@@ -2261,8 +2498,8 @@ int run_build_pass(ma_ctx* ctx, const DBatch& b, GraphWs& ws, u32* counters_dev,
     u64 tot = 0;
     for (u32 v : mm) {
       nfb += v >> 31;
-      big += (v & 0x7FFFFFFFu) > kMmLdsMax;
-      tot += v & 0x7FFFFFFFu;
+      big += (v & 0x3FFFFFFFu) > kMmLdsMax;
+      tot += v & 0x3FFFFFFFu;
     }
     fprintf(stderr, "[ma] mate-mer sets: %zu windows, %zu need the HBM set (%zu by size), mean general instances %.0f, max %u / %u; pool %.1f of %.1f MB\n",
             A, nfb, big, static_cast<double>(tot) / static_cast<double>(A), max_gen[0], max_gen[1], used / 1048576.0, ws.mm_pool_bytes / 1048576.0);
@@ -2278,15 +2515,9 @@ int run_build_pass(ma_ctx* ctx, const DBatch& b, GraphWs& ws, u32* counters_dev,
     hipLaunchKernelGGL(k_graph, dim3(ws.n_active), dim3(kGrT), lds_g, ctx->stream, b, ws, static_cast<u32>(ctx->prm.min_node_cov));
     ctx->toc();
   }
-  ctx->tic("k_rank");
-  hipLaunchKernelGGL(k_rank, dim3(ws.n_active), dim3(kRankT), 0, ctx->stream, b, ws,
+  ctx->tic("k_graph_gen");
+  hipLaunchKernelGGL(k_graph_gen, dim3(std::min<u32>(static_cast<u32>(ws.n_active), 512u)), dim3(kRankT), 0, ctx->stream, b, ws,
                      static_cast<u32>(ctx->prm.min_node_cov));
-  ctx->toc();
-  ctx->tic("k_edges");
-  hipLaunchKernelGGL(k_edges, dim3(ws.n_active), dim3(kEdT), 0, ctx->stream, b, ws);
-  ctx->toc();
-  ctx->tic("k_edge_sort");
-  hipLaunchKernelGGL(k_edge_sort, dim3(ws.n_active), dim3(kBT), 0, ctx->stream, ws);
   ctx->toc();
   MA_HIP(ctx, hipGetLastError());
   return MA_OK;

@@ -1335,7 +1335,8 @@ def test_traversal_limit_is_the_references(bfs_limit):
 ])
 def test_fused_graph_kernel_equals_the_three_general_kernels(cfg, nwin, first, kw, pk, monkeypatch):
     """Round 5: k_graph (survivor ranks from a bitmap of first instances, slot -> node in LDS, the window's distinct edges in an
-    LDS set probed by source node, an edge's place read off its run) against k_rank + k_edges + k_edge_sort (MA_NO_GRAPH_FUSE=1):
+    LDS set probed by source node, an edge's place read off its run, the reads' (k+1)-mers from k_support's edge queue) against
+    the general route k_graph_gen = rank + edges + edge sort from the instance words (MA_NO_GRAPH_FUSE=1):
     the same assembly outputs, both equal to the oracle's; the timing names prove which route ran."""
     from lancet2_amd.engine import Engine
     params = capi.default_params(**pk)
@@ -1361,7 +1362,7 @@ def test_fused_graph_kernel_equals_the_three_general_kernels(cfg, nwin, first, k
         assert ("k_graph" in times) == fused, sorted(times)
         if fused and kw.get("W", 1001) <= 1001:  # the general kernels only leave at their first test (a 2.5 kb window holds more
             # distinct k-mers than k_insert's LDS map: its table has 16 k slots and the general kernels take it)
-            assert times["k_rank"] + times["k_edges"] + times["k_edge_sort"] < times["k_graph"], times
+            assert times["k_graph_gen"] < times["k_graph"], times
         bad = compare_asm(params, a, wa, n) + compare_vars(params, v, wv, n)
         bad += compare_geno(params, q, wq, n, nr, wv["win_nvars"], arrs["read_win_off"])
         assert not bad, f"fused={fused}\n" + "\n".join(bad[:12])
@@ -1381,7 +1382,7 @@ def test_hbm_mate_mer_sets_come_out_of_a_budgeted_pool(pool_kb, monkeypatch):
     params = capi.default_params(min_k=25, max_k=25)
     arrs, n, nr = synth.make_config_batch("C3", 6, first_index=94_000)
     arrs = dict(arrs)
-    arrs["read_hint"] = np.full_like(arrs["read_hint"], capi.MA_NO_HINT)
+    arrs.pop("read_hint")  # a batch without the array: every window takes the all-generic route
     orc = OracleEngine(params)
     wa = orc.assemble(arrs, n, nr)
     wv = orc.msa(arrs, n, nr, wa)
@@ -1395,7 +1396,7 @@ def test_hbm_mate_mer_sets_come_out_of_a_budgeted_pool(pool_kb, monkeypatch):
             times[k_] = times.get(k_, 0.0) + ms
     finally:
         eng.close()
-    assert times.get("k_mm_insert", 0) > 0 and times.get("k_count", 0) > 0, times
+    assert times.get("k_mm_hbm", 0) > 0.05, times  # (an empty launch takes ~0.006 ms)
     assert not (a["win_status"] & capi.MA_W_TABLE_OVERFLOW).any()
     bad = compare_asm(params, a, wa, n) + compare_vars(params, v, wv, n)
     bad += compare_geno(params, q, wq, n, nr, wv["win_nvars"], arrs["read_win_off"])
