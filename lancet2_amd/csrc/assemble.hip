@@ -448,6 +448,7 @@ int launch_assemble(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& out, const
     g.slow_rec = c.take<uint4>(A * g.inst_stride);
     g.gr_done = c.take<u32>(A);
     g.n_edgeq = c.take<u32>(A);
+    g.n_genq = c.take<u32>(A);
     // HBM-resident mate-mer sets: a pool the windows that need one carve theirs out of (k_support).  A full set per window
     // when every window will need one (no mapping hints; capacity retries route every mate-mer through it), a token share
     // otherwise -- the pool is part of the chunk's budgeted workspace either way (round 4 reserved it on demand, outside the

@@ -665,7 +665,7 @@ __device__ __forceinline__ u32 swar_codes4(u32 v, bool* all_acgt) {
 // error-free / last bits (k_classify) and its canonical bit, so an instance word is WRITTEN once, with its final table slot --
 // the LDS map's entry, which is what the table is copied out from -- and never read: the old passes read and rewrote every
 // slow instance's word twice (two 64-byte sectors per 4-byte word).
-__global__ __launch_bounds__(kInsT) void k_insert(DBatch b, GraphWs ws) {
+__global__ __launch_bounds__(kInsT) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_insert(DBatch b, GraphWs ws) {
   __shared__ __align__(16) unsigned char l_area[kInsArea];
   __shared__ u32 l_nmap, l_ndef, l_seq_ok;
   u32* const l_seq = reinterpret_cast<u32*>(l_area);                               // phase A: [kSeqWords + 8]
@@ -992,6 +992,7 @@ __global__ __launch_bounds__(kInsT) void k_insert(DBatch b, GraphWs ws) {
 extern "C" void ma_debug_iprof(unsigned long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_iprof), sizeof(unsigned long long) * 32); }
 #endif
 
+constexpr u32 kGrSlots = 6144;   // table slots per window k_graph takes (= k_insert's direct map; a multiple of 1024)
 // edge-queue entry: instance index (22 bits) and the two instance words cut down to what names their node -- FAST bit + 20 bits
 // of table slot / reference position (k_graph only takes windows of at most 8192 slots and 2^18 instances)
 __device__ __forceinline__ u32 edge_word(u32 word) { return ((word & kInstFast) ? (1u << 20) : 0u) | (word & 0xFFFFFu); }
@@ -1010,6 +1011,7 @@ constexpr int kSupT = 512;
 __global__ __launch_bounds__(kSupT) void k_support(DBatch b, GraphWs ws, u32* max_gen, u32 cache_cap, u32 xs_log2) {
   extern __shared__ unsigned char lds_build[];
   __shared__ u32 xs_flag;
+  __shared__ u32 any_big;    // some group of mates holds more k-mers than a wavefront's dedup table takes
   __shared__ u32 gen_count;  // instances routed through the general mate-mer set (sizes that set)
   __shared__ u32 genq_n;     // queue mode: keys written to the window's general-instance queue so far
   __shared__ u32 edgeq_n;    // (k+1)-mers written to the window's edge queue so far
@@ -1024,8 +1026,11 @@ __global__ __launch_bounds__(kSupT) void k_support(DBatch b, GraphWs ws, u32* ma
   u32 const ns = seq_count(b, w);
   u32 const base_idx = b.read_win_off[w] + w;
   u32 off = 0;
-  u32* l_cnt = reinterpret_cast<u32*>(lds_build + off);
-  off += 4u * ws.ref_stride * CW;
+  u32* l_cnt = reinterpret_cast<u32*>(lds_build + off);  // packed u16 counters [ref_stride][CW] (a position is covered by < 65536 reads)
+  u32 const cnt_words = (ws.ref_stride * CW + 1u) / 2u;
+  off += 4u * cnt_words;
+  u32* l_dd = reinterpret_cast<u32*>(lds_build + off);   // [kSupT / 64][1 << dd_log2] per-wavefront dedup tables (below)
+  off += 4u * (kSupT / 64u) << ws.dd_log2;
   u32* l_mask = reinterpret_cast<u32*>(lds_build + off);
   off += 4u * (ws.max_reads + 2u);  // (the group leaders)
   // (qname, role) table of check (X): a power of two above the busiest window's read count (1024 entries up to 1022 reads)
@@ -1045,13 +1050,15 @@ __global__ __launch_bounds__(kSupT) void k_support(DBatch b, GraphWs ws, u32* ma
   i32* c_hint = reinterpret_cast<i32*>(c_ib + cache_cap);
   bool const cached = cache_cap != 0 && ns <= cache_cap;
   SeqInfo const rsi = seq_info(b, w, 0, k);
-  for (u32 i = threadIdx.x; i < ws.ref_stride * CW; i += kSupT) l_cnt[i] = 0;
+  for (u32 i = threadIdx.x; i < cnt_words; i += kSupT) l_cnt[i] = 0;
+  for (u32 i = threadIdx.x; i < (kSupT / 64u) << ws.dd_log2; i += kSupT) l_dd[i] = 0;
   for (u32 i = threadIdx.x; i < xs_cap; i += kSupT) {
     l_xkey[i] = 0;
     l_xgrp[i] = 0;
   }
   if (threadIdx.x == 0) {
-    xs_flag = 0;
+    xs_flag = ns > 65535u ? 1u : 0u;  // (the packed position counters hold 16 bits: such a window takes the general route)
+    any_big = 0;
     gen_count = 0;
     genq_n = 0;
     edgeq_n = 0;
@@ -1133,6 +1140,14 @@ __global__ __launch_bounds__(kSupT) void k_support(DBatch b, GraphWs ws, u32* ma
   // The queue is the slow queue's memory: k_insert is done with it.
   bool const qmode = !all_generic && !ws.mm_force_hbm && ns <= kSeqCap && tbl_log2(ws) <= 20;
   u32* const genq = ws.slowq + static_cast<size_t>(a) * ws.inst_stride;
+  // DEDUP MODE.  A key names its run's leader, and a run is one group of mates -- handled by ONE wavefront, right here.  So
+  // the set over the window's keys is a union of per-group sets, and a group's set (its reads' general instances, a few
+  // dozen, at most the k-mers of two reads) fits a table of the wavefront's own: 512 entries tagged with the group's number
+  // (no clearing between groups).  The first instance of a (table slot, group) emits slot << 4 | sample << 1 | role, and
+  // what the queue then holds is one entry per COUNT: k_graph adds them up in LDS while it reads the table -- no window-wide
+  // set (20 k keys per window into a 16 k / 32 k-entry LDS set: the slowest kernel of the build stage), no kernel of its own.
+  // For the windows k_graph takes (ws.graph_fused, a table of at most kGrSlots slots) whose groups all fit their table.
+  u32 const dd_cap = 1u << ws.dd_log2;
   // EDGE QUEUE: the (k+1)-mers of the reads that are not the reference's own edges (both k-mers FAST at consecutive reference
   // positions: 7 of 8) -- instance index and both words packed into 8 bytes (edge_pack), into the memory k_insert's records lived in.  k_graph
   // builds the window's edges from this queue and the reference's own words: after k_classify has written the instance words
@@ -1152,9 +1167,16 @@ __global__ __launch_bounds__(kSupT) void k_support(DBatch b, GraphWs ws, u32* ma
     if (!(b.read_flags[r0] & MA_RF_PASS)) continue;
     if (s_idx > 1 && same_group(b, r0, r0 - 1)) continue;  // not the leader
     l_leaders[atomicAdd(&n_leaders, 1u)] = s_idx;
+    if (qmode) {  // k-mers of the whole group against the dedup table's capacity (3/4 full at most)
+      u32 tot = 0;
+      for (u32 j = 0; s_idx + j < ns && (j == 0 || same_group(b, r0, r0 + j)); ++j) tot += seq_info(b, w, s_idx + j, k).nk;
+      if (tot > dd_cap / 4u * 3u) any_big = 1;
+    }
   }
   __syncthreads();
+  bool const qdedup = qmode && ws.graph_fused && !any_big && ws.win_nslots[a] <= kGrSlots;
   u32 const wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+  u32* const dd = l_dd + (wave << ws.dd_log2);
   u32 wave_gen = 0;
   // (sequence sa, sb of this window in one group: same_group() on the cached records)
   auto same_group_c = [&](u32 sa, u32 sb) {
@@ -1253,7 +1275,37 @@ __global__ __launch_bounds__(kSupT) void k_support(DBatch b, GraphWs ws, u32* ma
         bool const to_gen = ef && (generic || !(word & kInstFast));
         u32 const p = word & kInstSlotMask;
         unsigned long long const gmask = __ballot(to_gen);
-        if (qmode) {
+        if (qdedup) {
+          if (gmask) {
+            u32 const nslot = to_gen ? ((word & kInstFast) ? ref_slot_g[p] : p) : 0u;
+            bool won = false;
+            if (to_gen) {  // first of its (table slot, group)?  entry = slot << 11 | tag; an entry with another tag is free
+              u32 const tag = gi + 1u, mine = (nslot << 11) | tag;
+              u32 h = (nslot * 2654435761u) >> (32u - ws.dd_log2);
+              for (;;) {
+                u32 cur = dd[h];
+                if ((cur & 0x7FFu) != tag) {
+                  u32 const old = atomicCAS(&dd[h], cur, mine);
+                  if (old == cur) {
+                    won = true;
+                    break;
+                  }
+                  cur = old;
+                  if ((cur & 0x7FFu) != tag) continue;  // (not reachable: only this group's lanes write the table now)
+                }
+                if (cur == mine) break;  // counted already
+                h = (h + 1u) & (dd_cap - 1u);
+              }
+            }
+            unsigned long long const wm = __ballot(won);
+            if (wm) {
+              u32 qb = 0;
+              if (lane == 0) qb = atomicAdd(&genq_n, static_cast<u32>(__popcll(wm)));
+              qb = __shfl(qb, 0, 64);
+              if (won) genq[qb + static_cast<u32>(__popcll(wm & ((1ull << lane) - 1ull)))] = (nslot << 4) | (smp << 1) | role;
+            }
+          }
+        } else if (qmode) {
           if (gmask) {
             u32 qb = 0;
             if (lane == 0) qb = atomicAdd(&genq_n, static_cast<u32>(__popcll(gmask)));
@@ -1285,8 +1337,9 @@ __global__ __launch_bounds__(kSupT) void k_support(DBatch b, GraphWs ws, u32* ma
             if (static_cast<int>(ob >> 6) == x) m0[x] = cm;
         }
         if (fast && !dup) {
-          atomicAdd(&l_cnt[p * CW + smp], 1u);
-          atomicAdd(&l_cnt[p * CW + S + role], 1u);
+          u32 const i1 = p * CW + smp, i2 = p * CW + S + role;
+          atomicAdd(&l_cnt[i1 >> 1], 1u << ((i1 & 1u) * 16u));
+          atomicAdd(&l_cnt[i2 >> 1], 1u << ((i2 & 1u) * 16u));
         }
       }
     }
@@ -1299,7 +1352,9 @@ __global__ __launch_bounds__(kSupT) void k_support(DBatch b, GraphWs ws, u32* ma
     // (up to four passes over the set for a window that fits the LDS tables; a deeper one goes chunk by chunk)
     bool const lds_ok = !all_generic && !ws.mm_force_hbm && (ns > kSeqCap || gen_count <= 4u * kMmLdsMax) && tbl_log2(ws) <= 20;
     ws.n_edgeq[a] = edgeq_n;
-    ws.mm_mode[a] = qmode ? (gen_count | 0x40000000u) : (gen_count | (lds_ok ? 0u : 0x80000000u));  // bit 30: k_mm_q, bit 31: HBM set
+    ws.n_genq[a] = (qmode || qdedup) ? genq_n : 0u;
+    // bit 29: counts queued for k_graph (dedup mode), bit 30: keys queued for k_mm_q, bit 31: HBM set; else k_mm_lds
+    ws.mm_mode[a] = qdedup ? (gen_count | 0x20000000u) : qmode ? (gen_count | 0x40000000u) : (gen_count | (lds_ok ? 0u : 0x80000000u));
     atomicMax(max_gen, gen_count);
     ws.mm_log2[a] = 0;
     if (!qmode && !lds_ok && gen_count) {
@@ -1320,7 +1375,7 @@ __global__ __launch_bounds__(kSupT) void k_support(DBatch b, GraphWs ws, u32* ma
     }
   }
   for (u32 i = threadIdx.x; i < rsi.nk * CW; i += kSupT) {
-    u32 const v = l_cnt[i];
+    u32 const v = (l_cnt[i >> 1] >> ((i & 1u) * 16u)) & 0xFFFFu;
     if (v == 0) continue;
     u32 const p = i / CW, x = i % CW;
     atomicAdd(&gcnt[static_cast<size_t>(ref_slot_g[p]) * CW + x], v);
@@ -1460,7 +1515,7 @@ __global__ __launch_bounds__(kMmT) void k_mm_lds(DBatch b, GraphWs ws) {
   u32* const l_queue = l_aux + kSeqCap + kSeqCap / 2;
   int const a = blockIdx.x;
   u32 const mode = ws.mm_mode[a];
-  if ((mode & 0xC0000000u) || mode == 0) return;  // HBM set / queue mode (k_mm_q) / nothing to do
+  if ((mode & 0xE0000000u) || mode == 0) return;  // HBM set / queued for k_mm_q or k_graph / nothing to do
   int const w = static_cast<int>(ws.active[a]);
   int const S = ws.num_samples, CW = S + 2;
   u32* cnt = ws.tbl_cnt + (static_cast<size_t>(a) << tbl_log2(ws)) * CW;
@@ -1697,15 +1752,15 @@ __global__ __launch_bounds__(kMmT) void k_mm_lds(DBatch b, GraphWs ws) {
 // as many passes over slot classes as their keys need (a pass re-reads the queue: 4 bytes per key).
 template <int kCapLog2>
 __global__ __launch_bounds__(kMmT) void k_mm_q(DBatch b, GraphWs ws) {
-  constexpr u32 kCap = 1u << kCapLog2, kMax = kCap * 7u / 8u;
+  constexpr u32 kCap = 1u << kCapLog2, kMax = kCap * 5u / 8u;  // (a pass fills the set to 5/8: linear probing at 7/8 walks dozens of entries per key)
   constexpr u32 kAux = kCapLog2 == 14 ? 3072u : 7168u;
   __shared__ u32 l_set[kCap];
   __shared__ u32 l_aux[kAux];  // packed u16 support counters (+ the free tail of the set)
   __shared__ u32 l_full;
   int const a = blockIdx.x;
   u32 const mode = ws.mm_mode[a];
-  if ((mode & 0xC0000000u) != 0x40000000u) return;
-  u32 const gen = mode & 0x3FFFFFFFu;
+  if ((mode & 0xE0000000u) != 0x40000000u) return;
+  u32 const gen = mode & 0x1FFFFFFFu;
   if (gen == 0) return;
   int const w = static_cast<int>(ws.active[a]);
   int const S = ws.num_samples, CW = S + 2;
@@ -2191,18 +2246,24 @@ __global__ __launch_bounds__(kRankT) void k_graph_gen(DBatch b, GraphWs ws, u32 
 // A window this kernel does not take (table of more than 8192 slots, an edge set that fills up) is left untouched for
 // k_rank / k_edges / k_edge_sort, which skip the windows marked done here.
 constexpr int kGrT = 1024;
-constexpr u32 kGrSlots = 8192;   // table slots per window (k_insert's direct map: 6144 entries -> 8192 slots)
 constexpr u32 kGrSet = 6144;     // entries of the edge set
 constexpr u32 kGrProbe = 384;    // longest run of occupied entries a lookup walks before the window is handed back
 constexpr u32 kGrNone = 0xFFFFu;
 constexpr u32 kGrEmpty = 0xFFFFFFFFu;
-__host__ __device__ inline u32 graph_lds_bytes(u32 inst_stride, u32 ref_stride) {
+__host__ __device__ inline u32 graph_area_bytes(u32 inst_stride, int S) {
   u32 const nw = (inst_stride + 31u) / 32u + 1u;
   u32 const rank_area = 4u * nw + 2u * nw + 4u * kSeqCap + 64u;
   u32 const set_area = 8u * kGrSet;
-  return 2u * kGrSlots + kGrSlots / 8u + ((2u * ref_stride + 15u) & ~15u) + ((rank_area > set_area ? rank_area : set_area) + 15u & ~15u) + 64u;
+  u32 const ctr_area = 2u * kGrSlots * static_cast<u32>(S + 2);
+  u32 m = rank_area > set_area ? rank_area : set_area;
+  m = m > ctr_area ? m : ctr_area;
+  return (m + 15u) & ~15u;
 }
-__global__ __launch_bounds__(kGrT) void k_graph(DBatch b, GraphWs ws, u32 min_node_cov) {
+__host__ __device__ inline u32 graph_lds_bytes(u32 inst_stride, u32 ref_stride, int S) {
+  return 2u * kGrSlots + kGrSlots / 8u + ((2u * ref_stride + 15u) & ~15u) + graph_area_bytes(inst_stride, S) + 64u;
+}
+// (eight waves per SIMD = two workgroups per CU: 64 VGPRs)
+__global__ __launch_bounds__(kGrT) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_graph(DBatch b, GraphWs ws, u32 min_node_cov) {
   extern __shared__ unsigned char lds_build[];
   __shared__ u32 sh[kGrT / 64];
   __shared__ u32 l_fail;
@@ -2217,7 +2278,7 @@ __global__ __launch_bounds__(kGrT) void k_graph(DBatch b, GraphWs ws, u32 min_no
   if ((ws.win_flags[w] & 4u) || tcap > kGrSlots || ninst > ws.inst_stride || ninst >= (1u << 22)) return;  // (uniform)
   const u64* keys = ws.tbl_key + (static_cast<size_t>(a) << tcl);
   const u32* first = ws.tbl_first + (static_cast<size_t>(a) << tcl);
-  const u32* cnt = ws.tbl_cnt + (static_cast<size_t>(a) << tcl) * CW;
+  u32* cnt = ws.tbl_cnt + (static_cast<size_t>(a) << tcl) * CW;
   const u32* inst_slot = ws.inst_slot + static_cast<size_t>(a) * ws.inst_stride;
   const u32* ref_slot_g = ws.ref_slot + static_cast<size_t>(a) * ws.ref_stride;
   size_t const nb = static_cast<size_t>(a) * ws.nc;
@@ -2235,15 +2296,38 @@ __global__ __launch_bounds__(kGrT) void k_graph(DBatch b, GraphWs ws, u32 min_no
   u32 const ns = seq_count(b, w);
   u32 const base_idx = b.read_win_off[w] + w;
 
-  for (u32 i = threadIdx.x; i < nw; i += kGrT) l_bits[i] = 0;
   for (u32 i = threadIdx.x; i < kGrSlots / 2u; i += kGrT) reinterpret_cast<u32*>(l_node)[i] = 0xFFFFFFFFu;
   for (u32 i = threadIdx.x; i < kGrSlots / 32u; i += kGrT) l_sign[i] = 0;
-  const u32* sbase = stage_seq_bases(ws.seq_inst_base + base_idx, ns, l_base);
   if (threadIdx.x == 0) l_fail = 0;
   IPROF_T0();
-  __syncthreads();
+  // ---- 0. the general instances' read support (k_support's dedup mode queued one entry per count: table slot << 4 |
+  //         sample << 1 | role): added up here as packed u16 (a k-mer has at most 2047 groups of mates) ----
+  u32* const l_ctr = reinterpret_cast<u32*>(area);  // [tcap * CW / 2]
+  u32 const n_cnt = (ws.mm_mode[a] & 0xE0000000u) == 0x20000000u ? ws.n_genq[a] : 0u;
+  if (n_cnt) {
+    u32 const ctr_words = (tcap * static_cast<u32>(CW) + 1u) / 2u;
+    for (u32 i = threadIdx.x; i < ctr_words; i += kGrT) l_ctr[i] = 0;
+    __syncthreads();
+    const u32* genq = ws.slowq + static_cast<size_t>(a) * ws.inst_stride;
+    constexpr int kQU = 4;
+    for (u32 q0 = threadIdx.x; q0 < n_cnt; q0 += kGrT * kQU) {
+      u32 e[kQU];
+#pragma unroll
+      for (int u = 0; u < kQU; ++u) e[u] = genq[min(q0 + u * kGrT, n_cnt - 1u)];
+#pragma unroll
+      for (int u = 0; u < kQU; ++u) {
+        if (q0 + u * kGrT >= n_cnt) continue;
+        u32 const sl = min(e[u] >> 4, tcap - 1u);
+        u32 const i1 = sl * CW + ((e[u] >> 1) & 7u), i2 = sl * CW + S + (e[u] & 1u);
+        atomicAdd(&l_ctr[i1 >> 1], 1u << ((i1 & 1u) * 16u));
+        atomicAdd(&l_ctr[i2 >> 1], 1u << ((i2 & 1u) * 16u));
+      }
+    }
+    __syncthreads();
+  }
+  IPROF(22);  // counts
   // ---- 1. survivors of RemoveLowCovNodes(0) (graph.cpp:363-390; node.cpp:38-42): their first instances into the bitmap ----
-  constexpr u32 kPer = kGrSlots / kGrT;  // 8 slots per thread, every load of the trip in flight together
+  constexpr u32 kPer = kGrSlots / kGrT;  // 6 slots per thread, every load of the trip in flight together
   u32 fi[kPer];
   u32 surv = 0;
 #pragma unroll
@@ -2253,16 +2337,33 @@ __global__ __launch_bounds__(kGrT) void k_graph(DBatch b, GraphWs ws, u32 min_no
     u64 const ky = keys[sc];
     fi[j] = first[sc];
     u32 total = 0;
-    bool any = false, all = true;
-    for (int i = 0; i < S; ++i) {
-      u32 const c = cnt[static_cast<size_t>(sc) * CW + i];
-      total += c;
-      any |= c > 0;
-      all &= c <= 1;
+    bool any = false, all = true, touched = false;
+    for (int i = 0; i < CW; ++i) {
+      u32 c = cnt[static_cast<size_t>(sc) * CW + i];
+      if (n_cnt) {  // + the counts queued for this slot; the table row gets the sum (the node records and any general route read it)
+        u32 const x = sc * CW + i;
+        u32 const add = (l_ctr[x >> 1] >> ((x & 1u) * 16u)) & 0xFFFFu;
+        if (add && s < tcap) {
+          c += add;
+          cnt[static_cast<size_t>(sc) * CW + i] = c;
+          touched = true;
+        }
+      }
+      if (i < S) {
+        total += c;
+        any |= c > 0;
+        all &= c <= 1;
+      }
     }
+    (void)touched;
     bool const remove = (any && all) || total < min_node_cov;
     if (s < tcap && ky != 0 && !remove && fi[j] < ninst) surv |= 1u << j;
   }
+  __threadfence_block();
+  __syncthreads();  // the counters are dead: their area becomes the ranking area
+  for (u32 i = threadIdx.x; i < nw; i += kGrT) l_bits[i] = 0;
+  const u32* sbase = stage_seq_bases(ws.seq_inst_base + base_idx, ns, l_base);
+  __syncthreads();
 #pragma unroll
   for (u32 j = 0; j < kPer; ++j)
     if (surv & (1u << j)) atomicOr(&l_bits[fi[j] >> 5], 1u << (fi[j] & 31u));
@@ -2340,7 +2441,7 @@ __global__ __launch_bounds__(kGrT) void k_graph(DBatch b, GraphWs ws, u32 min_no
   u32* refn = ws.ref_node + static_cast<size_t>(a) * ws.ref_stride;
   for (u32 p = threadIdx.x; p < ws.ref_stride; p += kGrT) {
     u32 nd = kGrNone;
-    if (p < rsi.nk) nd = l_node[ref_slot_g[p] & (kGrSlots - 1u)];
+    if (p < rsi.nk) nd = l_node[min(ref_slot_g[p], kGrSlots - 1u)];
     l_refn[p] = static_cast<u16>(nd);
     refn[p] = nd == kGrNone ? kNoNode : nd;
   }
@@ -2369,7 +2470,7 @@ __global__ __launch_bounds__(kGrT) void k_graph(DBatch b, GraphWs ws, u32 min_no
     l_fail = 1;
   };
   auto const node_of = [&](u32 c) -> u32 {  // c: edge_word() of an instance word
-    return (c >> 20) ? l_refn[min(c & 0xFFFFFu, ws.ref_stride - 1u)] : l_node[c & (kGrSlots - 1u)];
+    return (c >> 20) ? l_refn[min(c & 0xFFFFFu, ws.ref_stride - 1u)] : l_node[min(c & 0xFFFFFu, kGrSlots - 1u)];
   };
   auto const add_edge = [&](u32 ii, u32 ca, u32 cb) {
     u32 const na = node_of(ca), nbn = node_of(cb);
@@ -2456,12 +2557,19 @@ int run_build_pass(ma_ctx* ctx, const DBatch& b, GraphWs& ws, u32* counters_dev,
   ctx->tic("k_insert");
   hipLaunchKernelGGL(k_insert, dim3(ws.n_active), dim3(kInsT), 0, ctx->stream, b, ws);
   ctx->toc();
+  // k_graph takes the common window (and then k_support queues that window's read-support counts for it)
+  size_t const lds_g = graph_lds_bytes(ws.inst_stride, ws.ref_stride, S);
+  ws.graph_fused = (lds_g <= 120u * 1024u && !getenv("MA_NO_GRAPH_FUSE")) ? 1u : 0u;
+  // a wavefront's dedup table: the k-mers of two reads of the longest length at a load of 3/4 at most
+  ws.dd_log2 = 9;
+  while ((1u << ws.dd_log2) / 4u * 3u < 2u * ws.max_read_len && ws.dd_log2 < 12) ++ws.dd_log2;
   // + per-sequence cache (16 B per read of the busiest window, when that is at most kSupCache reads)
   u32 const sup_cache = ws.max_reads + 2 <= kSupCache ? ws.max_reads + 2 : 0u;
   u32 xs_log2 = 10;  // check (X)'s table: above the busiest window's read count (every read could bring a name of its own)
   while ((1u << xs_log2) < ws.max_reads + 2 && xs_log2 < 14) ++xs_log2;
   auto const sup_lds = [&](u32 lg) {
-    return 4ull * ws.ref_stride * (S + 2) + 4ull * (ws.max_reads + 2) + 9ull * (size_t(1) << lg) + 64 + 16ull * sup_cache + 16;
+    return 2ull * ws.ref_stride * (S + 2) + 4 + (size_t(4 * (kSupT / 64)) << ws.dd_log2) + 4ull * (ws.max_reads + 2) + 9ull * (size_t(1) << lg) + 64 +
+           16ull * sup_cache + 16;
   };
   while (xs_log2 > 10 && sup_lds(xs_log2) > 159u * 1024u) --xs_log2;  // (a table that fills up sends the window down the general route)
   size_t const lds_s = sup_lds(xs_log2);
@@ -2498,16 +2606,15 @@ int run_build_pass(ma_ctx* ctx, const DBatch& b, GraphWs& ws, u32* counters_dev,
     u64 tot = 0;
     for (u32 v : mm) {
       nfb += v >> 31;
-      big += (v & 0x3FFFFFFFu) > kMmLdsMax;
-      tot += v & 0x3FFFFFFFu;
+      big += (v & 0x1FFFFFFFu) > kMmLdsMax;
+      tot += v & 0x1FFFFFFFu;
     }
     fprintf(stderr, "[ma] mate-mer sets: %zu windows, %zu need the HBM set (%zu by size), mean general instances %.0f, max %u / %u; pool %.1f of %.1f MB\n",
             A, nfb, big, static_cast<double>(tot) / static_cast<double>(A), max_gen[0], max_gen[1], used / 1048576.0, ws.mm_pool_bytes / 1048576.0);
   }
   // node records + edges: k_graph for the common window (table of at most 8192 slots), the three general kernels for the rest
   MA_HIP(ctx, hipMemsetAsync(ws.gr_done, 0, 4 * A, ctx->stream));
-  size_t const lds_g = graph_lds_bytes(ws.inst_stride, ws.ref_stride);
-  if (lds_g <= 80u * 1024u && !getenv("MA_NO_GRAPH_FUSE")) {
+  if (ws.graph_fused) {
     if (lds_g > 65536)
       MA_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_graph), hipFuncAttributeMaxDynamicSharedMemorySize,
                                       static_cast<int>(lds_g)));

@@ -59,6 +59,9 @@ struct GraphWs {
   u32* mm_mode;           // [a] general mate-mer instances of the window; bit31: needs the HBM-resident set
   u32* win_nslots;        // [a] table slots this window uses (<= the stride; 6144 = k_insert's LDS map copied out, else a power of two)
   uint4* slow_rec;        // [a][inst_stride] k_insert: one record per reference k-mer, then per slow-queue entry: id, instance | flags, sequence
+  u32 graph_fused;        // k_graph runs in this attempt (then k_support may queue a window's read-support counts for it)
+  u32 dd_log2;            // log2 of the entries of a wavefront's dedup table in k_support
+  u32* n_genq;            // [a] entries of the window's key / count queue (k_support; the queue lives where slowq did)
   u32* n_edgeq;           // [a] entries of the window's edge queue (k_support; the queue lives where slow_rec did)
   u32* gr_done;           // [a] 1: k_graph produced the window's node records and edges (k_rank / k_edges / k_edge_sort skip it)
   u8* rd_flag;            // [n_reads] general-path k-mer of this read hit a reference node
