@@ -419,6 +419,7 @@ def parity_check(kept, config, first, lp, n, out_dev):
         return got
 
     checked, bad = 0, []
+    n_flagged = [0]
     for kp in kept:
         if kp is None or kp["config"] != config:
             continue
@@ -428,13 +429,24 @@ def parity_check(kept, config, first, lp, n, out_dev):
             continue
         cnt_all = len(wins)
         got = [{k_: np.concatenate([rows(dev, spec, w0, cnt)[k_] for w0, cnt in runs]) for k_ in spec} for dev, spec in zip(out_dev, specs)]
+        # A window that outgrew one of the CALLER's output caps (more haplotypes / longer haplotypes / more variants than the
+        # fixed strides hold) is flagged by both sides and re-submitted by the host with larger buffers (include/microasm.h):
+        # what its truncated rows hold is not part of the contract -- only that both sides flag it.
+        over = np.uint32(capi.MA_W_HAP_OVERFLOW | capi.MA_W_LEN_OVERFLOW | capi.MA_W_VAR_OVERFLOW)
+        flagged = (kp["asm"]["win_status"] & over) != 0
+        if flagged.any():
+            for gd, wd, spec in zip(got[1:], (kp["asm"], kp["var"], kp["geno"]), specs[1:]):
+                for key in spec:
+                    if key != "win_status":
+                        gd[key].reshape(cnt_all, -1)[flagged] = wd[key].reshape(cnt_all, -1)[flagged]
+            n_flagged[0] += int(flagged.sum())
         here = [] if np.array_equal(got[0]["max_approx"], kp["gate"]["max_approx"]) and \
             np.array_equal(got[0]["max_exact"], kp["gate"]["max_exact"]) else ["repeat gate differs"]
         here += compare_asm(lp, got[1], kp["asm"], cnt_all) + compare_vars(lp, got[2], kp["var"], cnt_all)
         here += compare_geno_calls(got[3], kp["geno"])
         bad += [f"{config} windows {wins[0]}..{wins[-1]}: {m}" for m in here[:4]]
         checked += cnt_all
-    return checked, bad
+    return checked, bad, n_flagged[0]
 
 
 def count_gpus_sysfs():
@@ -589,11 +601,12 @@ def main():
     # ---- parity sample: the outputs of the LAST timed step for the windows the cpu_baseline legs ran the oracle on ----
     parity = None
     if kept and world == 1:
-        pc, pbad = parity_check(kept, args.config, first, params, n, (g, a, v, q))
-        parity = {"windows": pc, "mismatches": len(pbad), "c4_windows": 0,
+        pc, pbad, pfl = parity_check(kept, args.config, first, params, n, (g, a, v, q))
+        parity = {"windows": pc, "mismatches": len(pbad), "c4_windows": 0, "flagged_windows_status_only": pfl,
                   "checked": "repeat gate, haplotypes / weights / statistics (f64 bit patterns), variants and alleles, allele counts, "
                              "PL / GQ: equal; QUAL within 1e-9 -- engine outputs of the last timed step vs the oracle's for the "
-                             "same windows (the cpu_baseline legs' own outputs)"}
+                             "same windows (the cpu_baseline legs' own outputs); a window over one of the CALLER's output caps is flagged by both sides "
+                             "and compared by its status word only (the host re-submits it with larger buffers)"}
         if pbad:
             parity["first_mismatches"] = pbad[:6]
     # SEQ_CX / GRAPH_CX annotation of the batch's variants (a "next" row: not part of the metric's
@@ -790,9 +803,10 @@ def main():
                                          if ((ost & np.uint32(getattr(capi, nm))) != 0).any()}
                 res["windows_at_traversal_limit"] = int(((ost & capi.MA_W_BFS_LIMIT) != 0).sum())
             if parity_config and kept and parity is not None:  # the oracle ran some of this leg's windows too (cpu_baselines)
-                pc, pbad = parity_check(kept, parity_config, first, lp, o_n, (g, a, v, o_q))
-                res["parity_sample"] = {"windows": pc, "mismatches": len(pbad)}
+                pc, pbad, pfl = parity_check(kept, parity_config, first, lp, o_n, (g, a, v, o_q))
+                res["parity_sample"] = {"windows": pc, "mismatches": len(pbad), "flagged_windows_status_only": pfl}
                 parity["c4_windows"] += pc
+                parity["flagged_windows_status_only"] += pfl
                 parity["mismatches"] += len(pbad)
                 if pbad:
                     parity.setdefault("first_mismatches", []).extend(pbad[:6])

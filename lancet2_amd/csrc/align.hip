@@ -387,6 +387,9 @@ __device__ __forceinline__ void vote_pair(GArgs const& A, u64 lp, PairId id, Hap
 // bought with a half-size seed index, costs more in longer bucket chains than it hides)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_vote(GArgs A, u32 hist_len, u32 rwords, u32 ml_eff) {
   extern __shared__ u32 lds_vote[];
+#ifdef MA_PROFILE
+  unsigned long long const k_tstart = __builtin_amdgcn_s_memtime();
+#endif
   u32 const item = A.ws.vote_wg[blockIdx.x];
   int const w = item / A.prm.max_haps, slot = item % A.prm.max_haps;
   u32 const mask = A.ws.win_slotmask[w];
@@ -524,6 +527,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
   __shared__ unsigned long long sh_prof[4][8];
   if (lane < 8) sh_prof[wave][lane] = 0;
   unsigned long long const k_t0 = __builtin_amdgcn_s_memtime();
+  if (threadIdx.x == 0) atomicAdd(&g_vprof[15], k_t0 - k_tstart);  // workgroup set-up: planes, seed index, repeat flags, prefix counts
   u32 hap_amb = 0;
   for (u32 x = lane; x < pw; x += 64) hap_amb |= hbad[x];
   hap_amb = __ballot(hap_amb != 0) ? 1u : 0u;

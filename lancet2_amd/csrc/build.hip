@@ -837,7 +837,12 @@ __global__ __launch_bounds__(kInsT) __attribute__((amdgpu_waves_per_eu(8, 8))) v
   // map entry of an id (kNoNode: no room -- the map has not an entry free within kInsProbe of the id's place, and never will)
   auto map_entry = [&](u64 id) -> u32 {
     u32 e = static_cast<u32>(id >> 32) % kInsMap;
-    for (u32 probe = 0; probe < kInsProbe; ++probe) {
+    // (a map that is all but full -- deep samples: 40 k distinct k-mers -- turns every further id away after 64 probes: each of
+    //  a deep window's 200 k instances walking 1024 occupied entries was 0.4 s of this kernel per 2048 windows.  An id turned
+    //  away here may still sit further along its probe sequence, put there while the map had room: the general route looks
+    //  every id up with the full limit and folds every instance into the table's first-instance minimum itself.)
+    u32 const lim = *reinterpret_cast<volatile u32*>(&l_nmap) + 64u >= kInsMap ? 64u : kInsProbe;
+    for (u32 probe = 0; probe < lim; ++probe) {
       u64 cur = l_key[e];
       if (cur == 0) {
         unsigned long long const old = atomicCAS(reinterpret_cast<unsigned long long*>(&l_key[e]), 0ull,
@@ -959,7 +964,7 @@ __global__ __launch_bounds__(kInsT) __attribute__((amdgpu_waves_per_eu(8, 8))) v
     u32 slot, of;
     if (e != kNoNode) {
       slot = l_min[e] & 0x7FFFFFFFu;
-      slot = slot == 0x7FFFFFFFu ? 0u : slot;
+      if (slot == 0x7FFFFFFFu) slot = 0u; else atomicMin(&first[slot], p);
     } else {
       slot = direct_insert(rec_id(rc), p, &of);
     }
@@ -976,7 +981,7 @@ __global__ __launch_bounds__(kInsT) __attribute__((amdgpu_waves_per_eu(8, 8))) v
     if (e != kNoNode) {
       u32 const sv = l_min[e];
       slot = sv & 0x7FFFFFFFu;
-      slot = slot == 0x7FFFFFFFu ? 0u : slot;
+      if (slot == 0x7FFFFFFFu) slot = 0u; else atomicMin(&first[slot], inst);
       isref = (sv >> 31) != 0;
     } else {
       u32 of;
@@ -1530,6 +1535,8 @@ __global__ __launch_bounds__(kMmT) void k_mm_lds(DBatch b, GraphWs ws) {
   // kSeqCap - 1 consecutive sequences cut between two runs: a key names its run's leader, so the keys of two chunks are
   // disjoint and every chunk is complete in itself as well (k_support: no run longer than kMmRunMax in such a window).
   __shared__ u32 l_chunk[4];  // s_lo, s_hi of the chunk, its general instances
+  constexpr u32 kMmWork = 48;
+  __shared__ u32 l_wl[kMmWork], l_wn, l_witem, l_sfull;
   u32 const ninst = ws.win_ninst[w], nref = ninst - ws.win_nread_inst[w];
   bool const chunked = ns > kSeqCap;
   IPROF_T0();
@@ -1558,9 +1565,29 @@ __global__ __launch_bounds__(kMmT) void k_mm_lds(DBatch b, GraphWs ws) {
     __syncthreads();
     cgen = l_chunk[1];
   }
-  u32 const npass = (cgen + kMmLdsMax - 1u) / kMmLdsMax;
-  for (u32 pass = 0; pass < npass; ++pass) {
+  // The chunk's slot classes (modulus << 16 | residue), a work list: a class whose keys fill the set -- the passes are sized
+  // by an instance COUNT, but the keys of a k-mer that a thousand read pairs carry all fall into its slot's class -- is split
+  // in two and redone before anything of it was counted.  (Round 4 flagged such a window and the retry pass re-assembled it
+  // from scratch with an HBM-resident set: two of the bench's 512 deep-panel windows, a fifth of that leg's step.)
   __syncthreads();
+  if (threadIdx.x == 0) {
+    u32 const np0 = min(max((cgen + kMmLdsMax - 1u) / kMmLdsMax, 1u), 16u);
+    for (u32 p = 0; p < np0; ++p) l_wl[p] = (np0 << 16) | p;
+    l_wn = cgen ? np0 : 0u;
+  }
+  __syncthreads();
+  u32 chunk_items = 0;
+  for (;;) {
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    l_sfull = 0;
+    l_witem = l_wn ? l_wl[--l_wn] : 0u;
+  }
+  __syncthreads();
+  u32 const witem = l_witem;
+  if (witem == 0) break;
+  bool const first_item = chunk_items++ == 0;  // (the chunk's block table is built once)
+  u32 const npass = witem >> 16, pass = witem & 0xFFFFu;
   for (u32 i = threadIdx.x; i < kMmLdsCap; i += kMmT) l_set[i] = 0;
   for (u32 sr = threadIdx.x; sr < nsc; sr += kMmT) {
     u32 const s = s_lo + sr;
@@ -1573,7 +1600,7 @@ __global__ __launch_bounds__(kMmT) void k_mm_lds(DBatch b, GraphWs ws) {
   u32 blk_shift = kBlkShift;
   while (blk_shift < 10 && i_hi - i_lo > (kBlkCap << blk_shift)) ++blk_shift;  // (a chunk of 2 k reads: 258 k instances)
   bool const blk_ok = i_hi - i_lo <= (kBlkCap << blk_shift);
-  if (blk_ok && pass == 0)
+  if (blk_ok && first_item)
     for (u32 bk = threadIdx.x; (bk << blk_shift) < i_hi - i_lo; bk += kMmT)
       l_blk[bk] = static_cast<u16>(seq_of(l_base, nsc, i_lo + (bk << blk_shift)));
   __syncthreads();
@@ -1673,7 +1700,7 @@ __global__ __launch_bounds__(kMmT) void k_mm_lds(DBatch b, GraphWs ws) {
   // registers first, so compacting in place is safe) and the rest of the set joins l_aux as counter space -- three
   // or four slot ranges instead of ten, each scanning only the keys.
   IPROF(13);  // scan + queue + set inserts
-  if (kTestProbe && set_full) atomicOr(&ws.win_flags[w], 4u);
+  if (kTestProbe && set_full) l_sfull = 1;
   u32 nkeys = 0;
   {
     constexpr u32 kPer = kMmLdsCap / kMmT;  // 32 consecutive entries per thread
@@ -1706,8 +1733,20 @@ __global__ __launch_bounds__(kMmT) void k_mm_lds(DBatch b, GraphWs ws) {
     for (u32 x = 0; x < kPer; ++x)
       if (mine[x] != 0) l_set[at++] = mine[x];
     nkeys = total;
-    if (nkeys == kMmLdsCap && threadIdx.x == 0) atomicOr(&ws.win_flags[w], 4u);  // not an entry free: keys may have found no room
     __syncthreads();
+  }
+  if (nkeys == kMmLdsCap || l_sfull) {  // not an entry free (or, in the test build, a probe sequence cut short): keys may have found no room
+    if (npass < 8192u) {
+      if (threadIdx.x == 0 && l_wn + 2u <= kMmWork) {
+        l_wl[l_wn++] = ((2u * npass) << 16) | pass;
+        l_wl[l_wn++] = ((2u * npass) << 16) | (pass + npass);
+      } else if (threadIdx.x == 0) {
+        atomicOr(&ws.win_flags[w], 4u);
+      }
+    } else if (threadIdx.x == 0) {
+      atomicOr(&ws.win_flags[w], 4u);  // one table slot alone holds more keys than the set: the retry pass's HBM set takes the window
+    }
+    continue;
   }
   IPROF(14);  // key compaction
   // counter space: l_aux, then the free tail of l_set (u32 words, two u16 counters each)
