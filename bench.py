@@ -98,6 +98,34 @@ def survey_bytes(stage, st):
     return 0
 
 
+def kernel_bytes(kname, st):
+    """DESIGN.md section 4, column "alg. bytes / window": what ONE kernel has to read and write per window (per k attempt for the
+    build / clean kernels, per assembled window behind the assembler) when each of its inputs is read once and each of its
+    outputs written once.  Ns slow-path instances, Ne (k+1)-mers of reads queued for the edge builder, Nc read-support counts
+    queued, Nn nodes after the first low-coverage pass, slots = table slots per window (k_insert's direct map), P pairs,
+    Pdp pairs that run the DP, m read length.  None: no formula (helper kernels)."""
+    W, R, B, S = st["W"], st["R"], st["B"], st["S"]
+    Ni, Ns, Ne, Nc, Nn = st["N_inst"], st["N_slow"], st["N_edgeq"], st["N_cntq"], st["N_nodes"]
+    H, L, m, P, Pdp = st["H"], st["L"], st["m"], st["P"], st["P_dp"]
+    slots, CW = 6144, S + 2
+    table = {
+        "gate_kernel": W + 8,
+        "k_classify": 2 * B + 12 * R + W + 4 * Ni + 4 * Ns,
+        "k_insert": W + B + 4 * Ns + 2 * 16 * (Ns + W) + 4 * (Ns + W) + (12 + 4 * CW) * slots,
+        "k_support": 4 * Ni + 13 * R + 8 * Ne + 4 * Nc + 4 * CW * W,
+        "k_graph": (12 + 4 * CW) * slots + 4 * Nc + 8 * Ne + 8 * W + (4 * S + 8 + 4 + 4) * Nn + 8 * Nn,
+        "k_clean_chains": (4 * S + 8 + 4 + 4 + 16) * Nn + 4000,
+        "k_clean_tail": 4000 + H * L + 64 * H,
+        "k_msa": H * L + max(H - 1, 0) * 2 * 77_000 + 16 * (L + st["var_bases"]),
+        "k_msa_band": max(H - 1, 0) * (128 + 14) * (L + 1),
+        "k_read_planes": B + 12 * (m / 32 + 2) * R,
+        "k_vote": P * (12 * (m / 32 + 2) + 4 + 32) + H * L,
+        "k_align_reg": Pdp * (2 * m + 45 / 2 * (m + 1) + 68),
+        "k_assign": R * (2 * m + H * (24 + 68)) + R * st["max_vars"],
+    }
+    return table.get(kname)
+
+
 def units_per_step(stage, st):
     """how many times a stage's per-window figure is paid per step: k attempts for build/clean, assembled windows
     for the stages behind the assembler"""
@@ -662,6 +690,9 @@ def main():
               N_inst=wstats.get("kmer_instances", 0) / attempts, N_raw=wstats.get("distinct_kmers", 0) / attempts,
               H=H, L=L, L_ref=L, var_bases=var_bases, n_cigar=params.max_cigar,
               attempts_per_step=stats.get("window_attempts", 0) / steps, assembled=assembled)
+    st.update(N_slow=wstats.get("slow_instances", 0) / attempts, N_edgeq=wstats.get("edge_queue", 0) / attempts,
+              N_cntq=wstats.get("count_queue", 0) / attempts, N_nodes=wstats.get("nodes_after_lowcov", 0) / attempts,
+              m=read_len, P=pairs_w * n / max(assembled, 1), P_dp=dp_w * n / max(assembled, 1), max_vars=params.max_vars)
     stage_bytes_step = {s: survey_bytes(s, st) * units_per_step(s, st) for s in ("gate", "build", "clean", "poa", "genotype")}
 
     # the metric counts ASSEMBLED windows: those that pass the repeat gate, yield haplotypes and run POA and
@@ -700,7 +731,7 @@ def main():
             return stamp["lib_sha16"] != now["lib_sha16"]
         return stamp.get("csrc_sha16") != now["csrc_sha16"]
 
-    for cand in ("r4_pmc_per_kernel.json", "r3_pmc_per_kernel.json", "r2_pmc_per_kernel.json"):
+    for cand in ("r5_pmc_per_kernel.json", "r4_pmc_per_kernel.json", "r3_pmc_per_kernel.json", "r2_pmc_per_kernel.json"):
         tpath = os.path.join(REPO, "profiles", cand)
         if os.path.exists(tpath):
             try:
@@ -714,7 +745,8 @@ def main():
         avg_ms = tot_ms / launches
         launches_per_step = launches / args.steps
         sname = STAGE_OF.get(dom, "other")
-        bytes_per_launch = stage_bytes_step.get(sname, 0) / max(launches_per_step, 1)
+        own = kernel_bytes(dom, st)
+        bytes_per_launch = (own * units_per_step(sname, st) if own is not None else stage_bytes_step.get(sname, 0)) / max(launches_per_step, 1)
         ach = bytes_per_launch / (avg_ms * 1e-3) / 1e9
         pk = prof.get(dom) or next((v for k, v in prof.items() if k.startswith(dom) and isinstance(v, dict)), {})  # (k_align_reg -> k_align_reg2p)
         roof = {"bound": "hbm", "kernel": dom, "stage": sname, "achieved": round(ach, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -725,8 +757,9 @@ def main():
                 "traffic_stale": prof_is_stale(prof.get("_stamp", {})) if pk else None,
                 "avg_launch_ms": round(avg_ms, 4), "launches_per_step": launches_per_step,
                 "algorithmic_bytes_per_launch": int(bytes_per_launch),
-                "note": "achieved = the WHOLE stage's SURVEY 8(d) bytes per launch / this kernel's mean launch time "
-                        "(HIP events on the launch stream); intermediates (traceback tiles etc.) are not counted"}
+                "note": "achieved = this kernel's OWN algorithmic bytes per launch (bench.py: kernel_bytes = DESIGN.md section 4's per-window "
+                        "figure x the units one launch processes) / its mean launch time (HIP events on the launch stream); "
+                        "roofline_top5 has the same for the five kernels with the most summed time"}
         if pk.get("valu_insts_per_launch"):
             lane_ops = pk["valu_insts_per_launch"] * 64.0
             av = lane_ops / (avg_ms * 1e-3)
@@ -736,6 +769,39 @@ def main():
                          "stale": prof_is_stale(prof.get("_stamp", {})),
                          "note": "SQ_INSTS_VALU (wave instructions, committed PMC pass of this command) x 64 lanes / this run's "
                                  "mean launch time; peak = 256 CU x 4 SIMD x 32 lanes x 2.4 GHz"}
+
+    # ---- the five kernels with the most summed time, each priced with its OWN algorithmic bytes (kernel_bytes), beside what the
+    #      committed PMC passes measured for it (traffic, vector instructions, share of wave cycles parked on a wait) ----
+    sq = {}
+    try:
+        sq = json.load(open(os.path.join(REPO, "profiles", "r5_pmc_sq_per_kernel.json")))
+    except Exception:
+        sq = {}
+    top5 = []
+    for kname, (tot_ms, launches) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:5]:
+        per_win = kernel_bytes(kname, st)
+        sname = STAGE_OF.get(kname, "other")
+        units = units_per_step(sname, st)
+        lps = launches / args.steps
+        avg_ms = tot_ms / launches
+        ent = {"kernel": kname, "stage": sname, "avg_launch_ms": round(avg_ms, 4), "launches_per_step": lps,
+               "ms_per_step_summed_over_lanes": round(tot_ms / args.steps, 3)}
+        if per_win is not None:
+            bpl = per_win * units / max(lps, 1)
+            ent.update(algorithmic_bytes_per_window=int(per_win), algorithmic_bytes_per_launch=int(bpl),
+                       achieved_GBps=round(bpl / (avg_ms * 1e-3) / 1e9, 2), frac_of_hbm_peak=round(bpl / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5))
+        pk = prof.get(kname) or next((v_ for k_, v_ in prof.items() if k_.startswith(kname) and isinstance(v_, dict)), {})
+        if pk:
+            ent.update(traffic_bytes_per_launch=pk.get("bytes_per_launch"), valu_insts_per_launch=pk.get("valu_insts_per_launch"),
+                       counters_stale=prof_is_stale(prof.get("_stamp", {})), counters_source=prof.get("_file"))
+            if pk.get("valu_insts_per_launch"):
+                ent["valu_frac"] = round(pk["valu_insts_per_launch"] * 64.0 / (avg_ms * 1e-3) / VALU_PEAK_LANE_OPS, 4)
+            if pk.get("bytes_per_launch") and per_win is not None:
+                ent["traffic_over_algorithmic"] = round(pk["bytes_per_launch"] / max(bpl, 1), 2)
+        sk = sq.get(kname) or next((v_ for k_, v_ in sq.items() if k_.startswith(kname) and isinstance(v_, dict)), {})
+        if sk.get("SQ_WAVE_CYCLES"):
+            ent["wait_any_share"] = round(sk.get("SQ_WAIT_ANY", 0) / sk["SQ_WAVE_CYCLES"], 3)
+        top5.append(ent)
 
     # ---- secondary measurements (never `value`) ----
     also = {}
@@ -962,7 +1028,7 @@ def main():
                        "windows_with_capacity_overflow": overflowed, "haplotypes_per_assembled_window": round(H, 2),
                        "sharding": "static, one process per GPU, no collective",
                        "input_synthesis_s": round(t_gen, 1)},
-            "roofline": roof, "roofline_valu": roof_valu, "cpu_baseline": cpu, "cpu_baseline_all_cores": cpu_mt,
+            "roofline": roof, "roofline_valu": roof_valu, "roofline_top5": top5, "cpu_baseline": cpu, "cpu_baseline_all_cores": cpu_mt,
             "parity_sample": parity,
             "step_algorithmic": {"MB_per_step": round(step_bytes / 1e6, 1),
                                  "GB_per_s": round(step_bytes / (elapsed / args.steps) / 1e9, 1),

@@ -244,7 +244,7 @@ int ma_prefetch_batch(ma_ctx_t* ctx, const ma_batch_t* next);
 
 /* Kernel timing mode: 0 = off, 1 = reset at every API call (default), 2 = accumulate across calls
  * until ma_timing_control is called again (used by bench.py to time kernels over the timed region), 3 = as 2 and
- * one extra small kernel per k attempt gathers the workload statistics ma_last_stats reports in out[8..11]
+ * one extra small kernel per k attempt gathers the workload statistics ma_last_stats reports in out[8..13]
  * (bench.py runs one untimed step in this mode). */
 int ma_timing_control(ma_ctx_t* ctx, int mode);
 
@@ -262,8 +262,9 @@ int ma_set_streams(ma_ctx_t* ctx, int n);
  *   out[0] read x haplotype pairs seen by ma_genotype_batch      out[1] pairs that needed the DP
  *   out[2] windows passed to ma_assemble_batch                   out[3] k attempts x windows assembled
  *   out[4..7] DP pairs by region width: <= 41, <= 65, <= 129 diagonals, wider (any-width kernel)
- *   out[8..11] (timing mode 3 only) distinct k-mers, nodes after the first low-coverage pass, k-mer instances on the
- *              hash-table path, k-mer instances -- each summed over the window attempts
+ *   out[8..13] (timing mode 3 only) distinct k-mers, nodes after the first low-coverage pass, k-mer instances on the
+ *              hash-table path, k-mer instances, (k+1)-mers of reads queued for the edge builder, read-support counts
+ *              queued -- each summed over the window attempts
  * Used by bench.py to price the kernels' algorithmic HBM bytes.  Returns the number of entries written. */
 int ma_last_stats(ma_ctx_t* ctx, unsigned long long* out, int cap);
 

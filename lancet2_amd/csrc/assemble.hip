@@ -81,6 +81,8 @@ __global__ __launch_bounds__(256) void k_workload_stats(GraphWs ws, unsigned lon
     atomicAdd(&acc[1], static_cast<unsigned long long>(ws.n_nodes[a]));      // nodes that survive the first low-coverage pass
     atomicAdd(&acc[2], static_cast<unsigned long long>(ws.n_slow[a]));       // k-mer instances that took the hash-table path
     atomicAdd(&acc[3], static_cast<unsigned long long>(ws.win_ninst[ws.active[a]]));  // k-mer instances (N_inst)
+    atomicAdd(&acc[4], static_cast<unsigned long long>(ws.n_edgeq[a]));      // the reads' (k+1)-mers queued for k_graph
+    atomicAdd(&acc[5], static_cast<unsigned long long>(ws.n_genq[a]));       // read-support counts / keys queued (k_support)
   }
 }
 

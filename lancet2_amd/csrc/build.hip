@@ -1790,13 +1790,12 @@ __global__ __launch_bounds__(kMmT) void k_mm_lds(DBatch b, GraphWs ws) {
 // windows with up to 14 k general instances -- the usual WGS window has 8 k --, a 32 k-entry set for the rest, which take
 // as many passes over slot classes as their keys need (a pass re-reads the queue: 4 bytes per key).
 template <int kCapLog2>
-__global__ __launch_bounds__(kMmT) void k_mm_q(DBatch b, GraphWs ws) {
+__device__ __forceinline__ void mm_q_window(DBatch const& b, GraphWs const& ws, int const a) {
   constexpr u32 kCap = 1u << kCapLog2, kMax = kCap * 5u / 8u;  // (a pass fills the set to 5/8: linear probing at 7/8 walks dozens of entries per key)
   constexpr u32 kAux = kCapLog2 == 14 ? 3072u : 7168u;
   __shared__ u32 l_set[kCap];
   __shared__ u32 l_aux[kAux];  // packed u16 support counters (+ the free tail of the set)
   __shared__ u32 l_full;
-  int const a = blockIdx.x;
   u32 const mode = ws.mm_mode[a];
   if ((mode & 0xE0000000u) != 0x40000000u) return;
   u32 const gen = mode & 0x1FFFFFFFu;
@@ -1914,6 +1913,15 @@ __global__ __launch_bounds__(kMmT) void k_mm_q(DBatch b, GraphWs ws) {
   }
   __syncthreads();
   if (l_full && threadIdx.x == 0) atomicOr(&ws.win_flags[w], 4u);
+}
+// (a few hundred workgroups walk the batch: since the dedup mode this is the route of the few windows whose groups of mates do
+//  not fit a wavefront's table, or that k_graph does not take)
+template <int kCapLog2>
+__global__ __launch_bounds__(kMmT) void k_mm_q(DBatch b, GraphWs ws) {
+  for (int a = blockIdx.x; a < ws.n_active; a += gridDim.x) {
+    mm_q_window<kCapLog2>(b, ws, a);
+    __syncthreads();
+  }
 }
 
 // low-coverage pruning (graph.cpp:363-390 with component 0 == everything, no anchors yet) and
@@ -2622,7 +2630,7 @@ int run_build_pass(ma_ctx* ctx, const DBatch& b, GraphWs& ws, u32* counters_dev,
   // windows whose general instances fit an LDS set are finished by k_mm_lds; the HBM-resident sets only hold what the
   // remaining windows routed to them (usually nothing: both kernels then leave at their first test)
   ctx->tic("k_mm_q");
-  hipLaunchKernelGGL(k_mm_q<14>, dim3(ws.n_active), dim3(kMmT), 0, ctx->stream, b, ws);
+  hipLaunchKernelGGL(k_mm_q<14>, dim3(std::min<u32>(static_cast<u32>(ws.n_active), 512u)), dim3(kMmT), 0, ctx->stream, b, ws);
   ctx->toc();
   if (ws.max_reads + 1u > kSeqCap) {  // (the scan route is for windows of more sequences than a key's leader index names)
     ctx->tic("k_mm_lds");

@@ -182,9 +182,7 @@ extern "C" void ma_debug_chprof(unsigned long long* out, int reset) {
 }
 #endif
 
-__global__ __launch_bounds__(kT) void k_clean_chains(ChainArgs A) {
-  extern __shared__ u32 smem[];
-  int const a = blockIdx.x;
+__device__ __forceinline__ void chains_window(ChainArgs const& A, int const a, u32* smem) {
   u32 const t = threadIdx.x, lane = t & 63u;
   GraphWs const& ws = A.ws;
   ma_params_t const& P = A.prm;
@@ -1136,6 +1134,21 @@ __global__ __launch_bounds__(kT) void k_clean_chains(ChainArgs A) {
 #undef BAIL_IF_PUNT
 }
 
+// One workgroup per window for the common size class; the two larger classes (2.5 kb windows, deep panels: 81 / 144 KB of
+// LDS) are launched as a few hundred workgroups that walk the batch -- two thousand workgroups that each claim most of a CU's
+// LDS only to find that their window belongs to another launch held the lane up behind the other lanes' kernels.
+__global__ __launch_bounds__(kT) void k_clean_chains(ChainArgs A) {
+  extern __shared__ u32 smem[];
+  chains_window(A, static_cast<int>(blockIdx.x), smem);
+}
+__global__ __launch_bounds__(kT) void k_clean_chains_walk(ChainArgs A) {
+  extern __shared__ u32 smem[];
+  for (int a = blockIdx.x; a < A.ws.n_active; a += gridDim.x) {
+    chains_window(A, a, smem);
+    __syncthreads();
+  }
+}
+
 int run_clean_chains(ma_ctx* ctx, const DBatch& b, const GraphWs& ws, const ma_params_t& prm) {
   u32 const S = static_cast<u32>(ws.num_samples);
   u32 const xw = std::max<u32>(2u, (S + 2u + 1u) / 2u);
@@ -1144,11 +1157,9 @@ int run_clean_chains(ma_ctx* ctx, const DBatch& b, const GraphWs& ws, const ma_p
     size_t words = static_cast<size_t>(cap) * (3 + xw) + static_cast<size_t>(cap) * 3 /* six u16 arrays */ + kXeCap * 4 + (kSegCap / 2) * 5 + 96 + 32 + cap / 32 + (cap <= 1472u ? 256u : cap / 4u) / 2;
     return words * 4;
   };
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_clean_chains), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
+  // (per call, like every other launch of more than 64 KB: the attribute belongs to the device the context runs on)
+  MA_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_clean_chains), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  MA_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_clean_chains_walk), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   // three launches by graph size: LDS is handed out in coarse granules, so the image of the common case is cut to fit
   // THREE workgroups per CU with room to spare (1472 nodes: 51.9 KB; at 1536 nodes only two fitted and the kernel took
   // 2.18 instead of 1.58 ms), the next class two per CU, the deepest windows one.  A workgroup whose window belongs to
@@ -1161,7 +1172,10 @@ int run_clean_chains(ma_ctx* ctx, const DBatch& b, const GraphWs& ws, const ma_p
     ChainArgs args{b, ws, prm, caps[l], lo, xw, caps[l] <= 1472u ? 64u : caps[l] / 8u, caps[l] <= 1472u ? 256u : caps[l] / 4u, caps[l] <= 1472u ? 256u : caps[l] / 4u,
                    getenv("MA_CHAINS_STOP") ? static_cast<u32>(atoi(getenv("MA_CHAINS_STOP"))) : 0u};
     ctx->tic("k_clean_chains");
-    hipLaunchKernelGGL(k_clean_chains, dim3(ws.n_active), dim3(kT), lds_bytes(caps[l]), ctx->stream, args);
+    if (l == 0)
+      hipLaunchKernelGGL(k_clean_chains, dim3(ws.n_active), dim3(kT), lds_bytes(caps[l]), ctx->stream, args);
+    else
+      hipLaunchKernelGGL(k_clean_chains_walk, dim3(std::min<u32>(static_cast<u32>(ws.n_active), 256u)), dim3(kT), lds_bytes(caps[l]), ctx->stream, args);
     ctx->toc();
     lo = caps[l];
   }

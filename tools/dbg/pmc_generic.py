@@ -10,7 +10,8 @@ import sys
 from collections import defaultdict
 
 root = sys.argv[1]
-pat = re.compile(sys.argv[2]) if len(sys.argv) > 2 else None
+pat = re.compile(sys.argv[2]) if len(sys.argv) > 2 and sys.argv[2] != "-" else None
+json_out = sys.argv[3] if len(sys.argv) > 3 else None  # also write {kernel: {counter: mean per launch}}
 tot = defaultdict(lambda: defaultdict(float))
 disp = defaultdict(set)
 dur = defaultdict(dict)  # kernel -> dispatch -> ns (when the csv carries the dispatch's timestamps)
@@ -34,3 +35,7 @@ for name in sorted(tot, key=lambda k: -tot[k].get("SQ_WAVE_CYCLES", 0.0)):
         if "SQ_BUSY_CU_CYCLES" in tot[name] and ns > 0:  # mean number of CUs with a wave on them while the kernel runs (2.4 GHz)
             extra += f" busy_CUs={tot[name]['SQ_BUSY_CU_CYCLES'] / n / (ns * 2.4):.1f}"
     print(f"{name:20s} launches {n:4d} " + " ".join(f"{c}={v / n:.4g}" for c, v in sorted(tot[name].items())) + extra)
+
+if json_out:
+    import json
+    json.dump({name: {c: v / max(len(disp[name]), 1) for c, v in tot[name].items()} for name in tot}, open(json_out, "w"), indent=1, sort_keys=True)
