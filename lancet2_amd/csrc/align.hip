@@ -97,6 +97,13 @@ struct AlnWs {
   u64* ev_key;         // [n][ev_cap]
   u32* ev_min;         // [n][ev_cap]
   u8* asg_allele;      // [n_reads * MV] (internal copy when the caller passes NULL)
+  // alignment records, COMPACT: one per planned (read, haplotype) pair, indexed by the global pair index
+  // pair_off[w] + (rank of the haplotype slot among the window's aligned slots) * reads of the window + read -- the reads of
+  // one (window, haplotype) are consecutive, so a wavefront of k_assign (a lane per read) loads 64 records as one run.
+  // (Round 4 kept them in the caller's fixed-stride layout [read][max_haps]: 1.5 KB between two lanes' records, 8 GB of
+  //  workspace touched a sector at a time.)  The caller's debug taps aln_rec / aln_cigar are filled from these (k_tap_records).
+  i32* rec;            // [pairs][6]  hit, score, rs, re, qs, qe
+  u32* cig;            // [pairs][1 + max_cigar]  op count, ops
 };
 
 struct GArgs {
@@ -111,6 +118,9 @@ struct GArgs {
   u32 dp0;       // first dp_list entry of this DP launch
   u32 dp_n;      // entries of this DP launch
 };
+
+__device__ __forceinline__ i32* rec_at(AlnWs const& ws, u64 gp) { return ws.rec + gp * 6; }
+__device__ __forceinline__ u32* cig_at(AlnWs const& ws, ma_params_t const& prm, u64 gp) { return ws.cig + gp * (1 + prm.max_cigar); }
 
 // A read's three bit planes live in one wavefront (k_vote / k_align_*: a lane per word): 608 bases at most.  A window
 // that holds a longer read is not genotyped and says so (MA_W_READ_OVERFLOW) -- the batch goes on without it.
@@ -606,9 +616,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
           if (D + 22 * X + 10 < m && S0 >= A.prm.min_aln_score && D < 60000) {
             settled = true;
             if (x == 0) {
-              size_t const rec = static_cast<size_t>(r0 + ri) * A.prm.max_haps + static_cast<u32>(slot);
-              i32* arec = A.o.aln_rec + rec * 6;
-              u32* acig = A.o.aln_cigar + rec * (1 + A.prm.max_cigar);
+              i32* arec = rec_at(A.ws, p);
+              u32* acig = cig_at(A.ws, A.prm, p);
               arec[0] = 1;
               arec[1] = S0;
               arec[2] = c;
@@ -684,8 +693,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
 
 // "no alignment": the hit flag of the pair's record is cleared explicitly (every reader tests it before anything else),
 // so the multi-GB internal record arrays need no memset per batch.
-__device__ __forceinline__ void write_no_hit(GArgs const& A, PairId id) {
-  A.o.aln_rec[(static_cast<size_t>(id.r) * A.prm.max_haps + id.slot) * 6] = 0;
+__device__ __forceinline__ void write_no_hit(GArgs const& A, u64 lp) {
+  rec_at(A.ws, A.pair0 + lp)[0] = 0;
 }
 
 __device__ __forceinline__ void vote_pair(GArgs const& A, u64 lp, PairId id, HapIdx ix, u16* hist, int lane, i32 m, u32 pre, i32 hint, i32 n,
@@ -734,9 +743,8 @@ __device__ __forceinline__ void vote_pair(GArgs const& A, u64 lp, PairId id, Hap
         i32 const S0 = m - 5 * X;
         if (D + 22 * X + 10 < m && S0 >= A.prm.min_aln_score && D < 60000) {
           if (lane == 0) {
-            size_t const rec = static_cast<size_t>(id.r) * A.prm.max_haps + id.slot;
-            i32* arec = A.o.aln_rec + rec * 6;
-            u32* acig = A.o.aln_cigar + rec * (1 + A.prm.max_cigar);
+            i32* arec = rec_at(A.ws, A.pair0 + lp);
+            u32* acig = cig_at(A.ws, A.prm, A.pair0 + lp);
             arec[0] = 1;
             arec[1] = S0;
             arec[2] = c;
@@ -922,7 +930,7 @@ __device__ __forceinline__ void vote_pair(GArgs const& A, u64 lp, PairId id, Hap
   if (best == 0 || dhi < 0) {  // no shared 11-mer, or only stray ones that anchor no chain: no hit
     if (lane == 0) {
       A.ws.centre[lp] = 0x7FFFFFFF;
-      write_no_hit(A, id);
+      write_no_hit(A, lp);
     }
     return;
   }
@@ -1010,11 +1018,10 @@ __device__ __forceinline__ void vote_pair(GArgs const& A, u64 lp, PairId id, Hap
   if (lane == 0) {
     if (nohit) {
       A.ws.centre[lp] = 0x7FFFFFFF;  // no alignment
-      write_no_hit(A, id);
+      write_no_hit(A, lp);
     } else if (fast) {
-      size_t const rec = static_cast<size_t>(id.r) * A.prm.max_haps + id.slot;
-      i32* arec = A.o.aln_rec + rec * 6;
-      u32* acig = A.o.aln_cigar + rec * (1 + A.prm.max_cigar);
+      i32* arec = rec_at(A.ws, A.pair0 + lp);
+      u32* acig = cig_at(A.ws, A.prm, A.pair0 + lp);
       arec[0] = 1;
       arec[1] = S0;
       arec[2] = c + qs;
@@ -1159,6 +1166,7 @@ __device__ void align_traceback(GArgs const& A, Fetch fetch, i32 lo, i32 m, i32 
 // one DP pair of a launch: its sequences and its search region
 struct DpPair {
   PairId id;
+  u64 gp;  // global pair index (its record's place)
   i32 m, n, lo, wr;
   const u8* rb;
   const u8* hb;
@@ -1169,6 +1177,7 @@ __device__ __forceinline__ DpPair dp_pair_load(GArgs const& A, u32 li) {
   p.live = li < A.dp_n;
   if (!p.live) return p;
   u64 const lp = A.ws.dp_list[A.dp0 + li];
+  p.gp = A.pair0 + lp;
   {
     u32 const pr = A.ws.pair_read[lp];
     p.id.r = pr & 0x7FFFFFFu;
@@ -1190,9 +1199,8 @@ __device__ __forceinline__ DpPair dp_pair_load(GArgs const& A, u32 li) {
 template <class Fetch>
 __device__ __forceinline__ void dp_pair_finish(GArgs const& A, DpPair const& p, Fetch fetch, i32 best, i32 bi, i32 bj) {
   if (!p.live) return;
-  size_t const rec = static_cast<size_t>(p.id.r) * A.prm.max_haps + p.id.slot;
-  i32* arec = A.o.aln_rec + rec * 6;
-  u32* acig = A.o.aln_cigar + rec * (1 + A.prm.max_cigar);
+  i32* arec = rec_at(A.ws, p.gp);
+  u32* acig = cig_at(A.ws, A.prm, p.gp);
   bool const hit = p.active && bi >= 0 && best >= A.prm.min_aln_score;
   if (!hit) {
     for (int x = 0; x < 6; ++x) arec[x] = 0;
@@ -1270,9 +1278,8 @@ __global__ __launch_bounds__(64) void k_align_wave(GArgs A, u32 nchunk_alloc) {
   const u8* rb = A.b.read_bases + ro;
   i32 const lo = A.ws.centre[lp];
   i32 const wr = static_cast<i32>(A.ws.band_w[lp] & 0xFFFFu);
-  size_t const rec = static_cast<size_t>(id.r) * A.prm.max_haps + id.slot;
-  i32* arec = A.o.aln_rec + rec * 6;
-  u32* acig = A.o.aln_cigar + rec * (1 + A.prm.max_cigar);
+  i32* arec = rec_at(A.ws, A.pair0 + lp);
+  u32* acig = cig_at(A.ws, A.prm, A.pair0 + lp);
   bool const active = m >= SK && n >= SK && static_cast<u32>(m) + 1 <= A.ws.tb_rows;
   if (!active) {
     if (lane < 6) arec[lane] = 0;
@@ -2137,6 +2144,25 @@ __device__ __forceinline__ u64 ev_key_of(u32 var, u32 sample, u32 allele, u32 qn
           (static_cast<u64>(qname) << 1)) + 1ull;
 }
 
+// the caller's debug taps (fixed stride [read][max_haps]; cleared by the launcher): every hit's record copied to its place
+__global__ __launch_bounds__(256) void k_tap_records(GArgs A, u64 total_pairs) {
+  u64 const gp = static_cast<u64>(blockIdx.x) * 256 + threadIdx.x;
+  if (gp >= total_pairs) return;
+  const i32* ar = rec_at(A.ws, gp);
+  if (!ar[0]) return;
+  PairId const id = pair_decode(A, gp);
+  size_t const rec = static_cast<size_t>(id.r) * A.prm.max_haps + id.slot;
+  if (A.o.aln_rec)
+    for (int x = 0; x < 6; ++x) A.o.aln_rec[rec * 6 + x] = ar[x];
+  if (A.o.aln_cigar) {
+    const u32* cg = cig_at(A.ws, A.prm, gp);
+    u32 const nops = min(cg[0], static_cast<u32>(A.prm.max_cigar));
+    u32* out = A.o.aln_cigar + rec * (1 + A.prm.max_cigar);
+    out[0] = cg[0];
+    for (u32 x = 0; x < nops; ++x) out[1 + x] = cg[1 + x];
+  }
+}
+
 // AssignReadToAlleles (genotyper.cpp:269-321): one lane per read
 __global__ __launch_bounds__(64) void k_assign(GArgs A) {
   i64 const r = static_cast<i64>(blockIdx.x) * 64 + threadIdx.x;
@@ -2145,14 +2171,24 @@ __global__ __launch_bounds__(64) void k_assign(GArgs A) {
   int const MH = P.max_haps, MV = P.max_vars, MA = P.max_alts, MCG = P.max_cigar, S = P.num_samples;
   int const w = static_cast<int>(A.ws.read_win[r]);  // (k_plan)
   u8* asg = A.ws.asg_allele + static_cast<size_t>(r) * MV;
-  for (int v = 0; v < MV; ++v) asg[v] = 255;
-  if (A.o.asg_allele)
-    for (int v = 0; v < MV; ++v) A.o.asg_allele[static_cast<size_t>(r) * MV + v] = 255;
+  // ("unassigned" for every variant slot: 16 bytes per store -- 64 one-byte stores per lane were most of this kernel's writes)
+  auto fill255 = [&](u8* dst) {
+    if ((MV & 15) == 0 && (reinterpret_cast<uintptr_t>(dst) & 15u) == 0) {
+      for (int v = 0; v < MV; v += 16) *reinterpret_cast<uint4*>(dst + v) = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+    } else {
+      for (int v = 0; v < MV; ++v) dst[v] = 255;
+    }
+  };
+  fill255(asg);
+  if (A.o.asg_allele) fill255(A.o.asg_allele + static_cast<size_t>(r) * MV);
   if (A.o.asg_score)
     for (int v = 0; v < MV; ++v) A.o.asg_score[static_cast<size_t>(r) * MV + v] = 0.0;
   u32 const nv = A.v.win_nvars[w];
   u32 const mask = A.ws.win_slotmask[w];
   if (nv == 0 || mask == 0) return;
+  // the records of this read: pair_off[w] + (rank of the haplotype's slot) * reads of the window + the read's place in it
+  u32 const r0w = A.b.read_win_off[w], nrw = A.b.read_win_off[w + 1] - r0w;
+  u64 const gp_read = A.ws.pair_off[w] + (static_cast<u64>(r) - r0w);
   u64 const ro = A.b.read_off[r];
   u32 const rlen = static_cast<u32>(A.b.read_off[r + 1] - ro);
   const u8* rb = A.b.read_bases + ro;
@@ -2173,10 +2209,11 @@ __global__ __launch_bounds__(64) void k_assign(GArgs A) {
       bool have_best = false;
       Scored bestsc{};
       for (u32 h = 0; h < nh; ++h) {  // alignments in haplotype order (all_alns)
-        size_t const rec = static_cast<size_t>(r) * MH + hap0 + h;
-        const i32* ar = A.o.aln_rec + rec * 6;
+        u64 const gp = gp_read + static_cast<u64>(__popc(mask & ((1u << (hap0 + h)) - 1u))) * nrw;
+        if (!(mask & (1u << (hap0 + h)))) continue;  // (not aligned: no record)
+        const i32* ar = rec_at(A.ws, gp);
         if (!ar[0]) continue;
-        const u32* cgp = A.o.aln_cigar + rec * (1 + MCG);
+        const u32* cgp = cig_at(A.ws, A.prm, gp);
         Cig cg{cgp + 1, min(cgp[0], static_cast<u32>(MCG))};
         // the record holds max_cigar operations; the reference scores the whole CIGAR: never silently
         if (cgp[0] > static_cast<u32>(MCG)) atomicOr(&A.a.win_status[w], static_cast<u32>(MA_W_CIGAR_OVERFLOW));
@@ -2441,9 +2478,6 @@ int launch_genotype(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& a, const m
     ws.ev_key = reinterpret_cast<u64*>(take(8ull * n * ws.ev_cap));
     ws.ev_min = reinterpret_cast<u32*>(take(4ull * n * ws.ev_cap));
     ws.asg_allele = reinterpret_cast<u8*>(take(NR * MV + 16));
-    // internal alignment records when the caller does not want the debug taps
-    if (!o_in.aln_rec) A.o.aln_rec = reinterpret_cast<i32*>(take(4ull * NR * MH * 6));
-    if (!o_in.aln_cigar) A.o.aln_cigar = reinterpret_cast<u32*>(take(4ull * NR * MH * (1 + MCG)));
     return off;
   };
   size_t const fixed = carve_fixed(nullptr);
@@ -2476,6 +2510,10 @@ int launch_genotype(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& a, const m
   u32 const max_read_len = plan_counters[0], n_vote_wg = plan_counters[2];
 
   ctx->stats[0] += total_pairs;
+  // the compact alignment records: 24 + 4 (1 + max_cigar) bytes per planned pair
+  MA_HIP(ctx, ctx->ws_mm.reserve((total_pairs + 64) * (24ull + 4ull * (1 + MCG)) + 512));
+  ws.rec = ctx->ws_mm.as<i32>();
+  ws.cig = reinterpret_cast<u32*>(reinterpret_cast<char*>(ctx->ws_mm.p) + (((total_pairs + 64) * 24ull + 255ull) & ~255ull));
   if (total_pairs > 0) {
     ws.tb_rows = max_read_len + 1;
     // LDS of k_align_wave: two i32 rows of w + 2 cells, the haplotype codes of the region and the read's codes
@@ -2721,6 +2759,11 @@ int launch_genotype(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& a, const m
       }
       A = Avote;
     }
+  }
+  if ((o_in.aln_rec || o_in.aln_cigar) && total_pairs > 0) {
+    ctx->tic("k_tap_records");
+    hipLaunchKernelGGL(k_tap_records, dim3(static_cast<u32>((total_pairs + 255) / 256)), dim3(256), 0, ctx->stream, A, total_pairs);
+    ctx->toc();
   }
   ctx->tic("k_assign");
   hipLaunchKernelGGL(k_assign, dim3(static_cast<u32>((NR + 63) / 64)), dim3(64), 0, ctx->stream, A);
