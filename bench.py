@@ -136,7 +136,7 @@ def units_per_step(stage, st):
     return st["assembled"]
 
 
-def pipeline_extract_leg(genome_len=600_000, depths=(30, 60), seed=0x5EED, threads=(1, 0)):
+def pipeline_extract_leg(genome_len=2_400_000, depths=(30, 60), seed=0x5EED, threads=(1, -1)):
     """builds examples/pipeline_driver.cpp with g++, writes a random genome + two coordinate-sorted SAM files (150-base paired
     reads, plain 150M alignments) and times the extract stage on them: the driver prints each stage's busy time"""
     import re
@@ -173,7 +173,7 @@ def pipeline_extract_leg(genome_len=600_000, depths=(30, 60), seed=0x5EED, threa
                     f.write(f"{qn}\t{flag}\tchr1\t{pos0 + 1}\t60\t150M\t=\t{mate + 1}\t{mate - pos0}\t{bytes(genome[pos0:pos0 + 150]).decode()}\t{qual}\tMD:Z:150\n")
             nreads += len(recs)
         best = None
-        for nthreads in threads:  # one collector thread, then the driver's default (min(8, cores))
+        for nthreads in [effective_cores() if t_ < 0 else t_ for t_ in threads]:  # one collector thread, then one per usable core
             t0 = time.perf_counter()
             r = subprocess.run([exe, "--reference", os.path.join(d, "ref.fa"), "--normal", os.path.join(d, "normal.sam"), "--tumor",
                                 os.path.join(d, "tumor.sam"), "--no-active-region", "--extract-only"] +
@@ -194,17 +194,19 @@ def pipeline_extract_leg(genome_len=600_000, depths=(30, 60), seed=0x5EED, threa
 def _parse_extract(r, wall, nreads, genome_len, depths):
     import re
     if True:
-        m = re.search(r"extract ([0-9.]+) s busy \(([0-9.]+) windows/s tiled, ([0-9.]+) shipped/s\) with (\d+) collector thread\(s\), ([0-9.]+) cpu-s", r.stderr)
+        m = re.search(r"extract ([0-9.]+) s busy \(([0-9.]+) windows/s tiled, ([0-9.]+) shipped/s\) with (\d+) collector thread\(s\), ([0-9.]+) cpu-s of collection, ([0-9.]+) s of ordered batching", r.stderr)
         if r.returncode != 0 or not m:
             raise RuntimeError("pipeline_driver --extract-only: " + r.stderr[-200:])
         nwin = int(re.search(r"pipeline_driver: (\d+) windows", r.stderr).group(1))
         return {"value": float(m.group(3)), "unit": "windows/s handed to the engine by the extract stage", "busy_s": float(m.group(1)),
                 "collector_threads": int(m.group(4)), "windows_per_cpu_second": round(nwin / max(float(m.group(5)), 1e-9), 1),
+                "ordered_batching_s": float(m.group(6)),
                 "windows": nwin, "reads": nreads, "reads_per_window": round(nreads * 1.25 / max(nwin, 1), 1),
                 "wall_s_incl_sam_parsing": round(wall, 2),
                 "note": "examples/pipeline_driver.cpp --extract-only --no-active-region on a random %d kb genome, %dx/%dx, SAM text; "
-                        "the engine takes ~200 k windows/s: the extract stage, not the GPU, bounds a deployment unless it gets "
-                        "hundreds of cores (the reference runs one collector per worker, pipeline_executor.cpp:174-197)" % (genome_len // 1000, depths[1], depths[0])}
+                        "one collector thread, then one per usable core (the reference runs one collector per worker, "
+                        "pipeline_executor.cpp:174-197); the stage's span = max(slowest collector, ordered batching thread); the engine "
+                        "takes ~250 k submitted windows/s" % (genome_len // 1000, depths[1], depths[0])}
 
 
 # ---- synthetic windows ---------------------------------------------------------------------------------------------

@@ -12,6 +12,8 @@
 //       -Wl,--allow-shlib-undefined -DLANCET2_AMD_WITH_ZLIB -lz -lpthread -o pipeline_driver
 //   ./pipeline_driver --reference ref.fa --normal n.sam --tumor t.sam --region chr1:1-20000 --out calls.tsv
 // Flags follow the reference CLI (cli/cli_interface.cpp:203-303) where the engine has the knob.
+#include <malloc.h>
+
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
@@ -170,6 +172,13 @@ AlignmentSource LoadAlignments(const std::string& path, Reference const& ref) {
 }  // namespace
 
 int main(int argc, char** argv) {
+  // The extract stage allocates a window's flat arrays (100-200 KB each) on its collector threads and frees them on the batching
+  // thread.  glibc serves blocks of that size with mmap / munmap -- a system call, fresh page faults and the process-wide
+  // address-space lock per array, which is what kept eight collectors from being faster than one.  From the heap arenas
+  // (one per thread) the same blocks are recycled without leaving user space.  (The reference links mimalloc for the same reason.)
+  mallopt(M_MMAP_THRESHOLD, 1 << 30);
+  mallopt(M_TRIM_THRESHOLD, 1 << 30);
+  mallopt(M_TOP_PAD, 64 << 20);
   std::string ref_path, out_path, dump_dir, vcf_path, command_line;
   for (int i = 0; i < argc; ++i) command_line += std::string(i ? " " : "") + argv[i];
   double gc_frac = 0.41;  // --genome-gc-bias of the reference CLI: background GC of the LongdustQ null model
@@ -179,7 +188,7 @@ int main(int argc, char** argv) {
   ReadCollector::Params rp;
   ma_params_t prm;
   ma_default_params(&prm);
-  bool no_active_region = false, extract_only = false;
+  bool no_active_region = false, extract_only = false, collect_reads = false;
   int batch_windows = 512;
   int extract_threads = static_cast<int>(std::min(8u, std::max(1u, std::thread::hardware_concurrency())));
   for (int i = 1; i < argc; ++i) {
@@ -207,6 +216,7 @@ int main(int argc, char** argv) {
     else if (a == "--batch-windows") batch_windows = std::max(1, std::atoi(next()));
     else if (a == "--extract-threads") extract_threads = std::max(1, std::atoi(next()));  // (the reference: -T, one collector per worker)
     else if (a == "--dump") dump_dir = next();
+    else if (a == "--collect-reads") collect_reads = true;  // the reference-shaped collector (a Read per alignment) instead of CollectFlat
     else if (a == "--extract-only") extract_only = true;  // stage 1 alone (with --dump): no device needed
     else { std::fprintf(stderr, "pipeline_driver: unknown option %s\n", a.c_str()); return 2; }
   }
@@ -300,12 +310,20 @@ int main(int argc, char** argv) {
         Slot& sl = slots[i];
         sl.st = PreReadGate(seq, prm.max_k, no_active_region, collector.Samples(), w);
         if (sl.st == WindowStatus::RUN) {
-          ReadCollector::Result const rc = collector.CollectRegion(w);
-          if (CrossSampleMeanCoverage(rc.samples, w.Length()) < static_cast<double>(prm.min_anchor_cov)) {
-            sl.st = WindowStatus::SKIPPED_ANCHOR_COVERAGE;
+          // the window's reads straight into its flat arrays (ReadCollector::CollectFlat); the reference-shaped path -- a Read
+          // per alignment, then FlatBatch::Add -- when the options need it (--extract-pairs) or --collect-reads asks for it
+          auto flat = std::make_unique<FlatBatch>();
+          if (!collect_reads && collector.CollectFlat(w, seq, flat.get())) {
+            if (CrossSampleMeanCoverage(collector.Samples(), w.Length()) < static_cast<double>(prm.min_anchor_cov)) sl.st = WindowStatus::SKIPPED_ANCHOR_COVERAGE;
+            else sl.flat = std::move(flat);
           } else {
-            sl.flat = std::make_unique<FlatBatch>();
-            sl.flat->Add(w, seq, rc.reads, &rc.samples);
+            ReadCollector::Result const rc = collector.CollectRegion(w);
+            if (CrossSampleMeanCoverage(rc.samples, w.Length()) < static_cast<double>(prm.min_anchor_cov)) {
+              sl.st = WindowStatus::SKIPPED_ANCHOR_COVERAGE;
+            } else {
+              sl.flat = std::move(flat);
+              sl.flat->Add(w, seq, rc.reads, &rc.samples);
+            }
           }
         }
         worker_busy[static_cast<size_t>(t)] += secs(Clock::now() - t0);
@@ -313,12 +331,21 @@ int main(int argc, char** argv) {
       }
     });
   std::thread extract([&] {
-    auto fresh = [] { Job j; j.batch = std::make_unique<FlatBatch>(); return j; };
+    size_t hint_bases = 0, hint_reads = 0, hint_ref = 0;  // the last batch's sizes: the next one's arrays are reserved whole
+    auto fresh = [&] {
+      Job j;
+      j.batch = std::make_unique<FlatBatch>();
+      if (hint_reads) j.batch->Reserve(static_cast<size_t>(batch_windows), hint_ref, hint_reads, hint_bases);
+      return j;
+    };
     Job cur = fresh();
     size_t n_dumped = 0;
     auto ship = [&] {
       if (cur.batch->windows.empty()) return;
       auto const ts = Clock::now();
+      hint_bases = cur.batch->read_bases.size() + cur.batch->read_bases.size() / 16;
+      hint_reads = cur.batch->read_qname_id.size() + cur.batch->read_qname_id.size() / 16;
+      hint_ref = cur.batch->ref_bases.size() + 64;
       cur.batch->Seal();
       busy_extract += secs(Clock::now() - ts);  // (the Push below may wait for the engine: not this stage's time)
       if (!dump_dir.empty()) {
@@ -439,11 +466,12 @@ int main(int argc, char** argv) {
     collect_cpu += b;
     collect_max = std::max(collect_max, b);
   }
-  busy_extract += collect_max;  // the stage's span: its slowest collector + the ordered batching
+  double const busy_batching = busy_extract;
+  busy_extract = std::max(busy_batching, collect_max);  // the stage's span: collectors and the ordered batching thread run side by side
   std::fprintf(stderr,
-               "pipeline_driver: stages -- extract %.3f s busy (%.0f windows/s tiled, %.0f shipped/s) with %d collector thread(s), %.3f cpu-s of collection, engine %.3f s busy (%.0f windows/s), "
+               "pipeline_driver: stages -- extract %.3f s busy (%.0f windows/s tiled, %.0f shipped/s) with %d collector thread(s), %.3f cpu-s of collection, %.3f s of ordered batching, engine %.3f s busy (%.0f windows/s), "
                "flush %.3f s busy (%.0f windows/s); wall %.3f s (%.0f shipped windows/s)%s\n",
-               busy_extract, rate(windows.size(), busy_extract), rate(n_shipped, busy_extract), extract_threads, collect_cpu, busy_engine, rate(n_shipped, busy_engine),
+               busy_extract, rate(windows.size(), busy_extract), rate(n_shipped, busy_extract), extract_threads, collect_cpu, busy_batching, busy_engine, rate(n_shipped, busy_engine),
                busy_flush, rate(n_shipped, busy_flush), wall, rate(n_shipped, wall),
                any_indexed ? (std::string("; indexed BAM: ") + std::to_string(blocks) + " BGZF blocks inflated").c_str() : "");
   return rc_all;

@@ -1180,6 +1180,7 @@ __global__ __launch_bounds__(kSupT) void k_support(DBatch b, GraphWs ws, u32* ma
   }
   __syncthreads();
   bool const qdedup = qmode && ws.graph_fused && !any_big && ws.win_nslots[a] <= kGrSlots;
+  IPROF_T0();
   u32 const wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
   u32* const dd = l_dd + (wave << ws.dd_log2);
   u32 wave_gen = 0;
@@ -1350,7 +1351,7 @@ __global__ __launch_bounds__(kSupT) void k_support(DBatch b, GraphWs ws, u32* ma
     }
   }
   if (lane == 0 && wave_gen) atomicAdd(&gen_count, wave_gen);
-  __syncthreads();
+  IPROF_SYNC(27);  // group loop
   if (threadIdx.x == 0) {
     // Windows whose (qname, role) keys each map to ONE run of adjacent reads (xs_flag == 0) and whose general
     // instances fit the LDS set are finished by k_mm_lds; the others need the HBM-resident set (max_gen[1]).
@@ -1385,6 +1386,7 @@ __global__ __launch_bounds__(kSupT) void k_support(DBatch b, GraphWs ws, u32* ma
     u32 const p = i / CW, x = i % CW;
     atomicAdd(&gcnt[static_cast<size_t>(ref_slot_g[p]) * CW + x], v);
   }
+  IPROF(28);  // flush of the position counters
 }
 
 __device__ __forceinline__ u64 mm_key_of(u32 slot, u32 qname, u32 role) {

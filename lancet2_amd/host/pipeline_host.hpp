@@ -33,6 +33,7 @@
 #include <unordered_map>
 #include <unordered_set>
 #include <utility>
+#include <deque>
 #include <vector>
 
 #include "../../include/microasm.h"
@@ -885,9 +886,18 @@ class ReadCollector {
       sinfo.sampled_reads = sampled;
       sinfo.sampled_bases = bases;
     }
-    std::sort(out.begin(), out.end(), CompareReadsByPriority);
+    std::stable_sort(out.begin(), out.end(), CompareReadsByPriority);  // (ties -- the reference's std::sort leaves them unspecified -- in arrival order)
     return {std::move(out), samples_};
   }
+
+  // The same window, flattened straight into `out` (what CollectRegion + FlatBatch::Add append), without materialising a Read
+  // per alignment: the kept alignments are REFERENCES to the source's records (whole-file sources; an indexed source's records
+  // are copied once into a per-call arena), sorted as references, and every output array is sized before it is filled.  The
+  // reference-shaped path above costs ~3000 allocations per 60x/30x window (three strings and a vector per read, the hash
+  // sets of both passes) and was what bounded the extract stage at ~0.5 ms of one core per window; tests/host/host_units.cpp
+  // holds the two paths to byte-identical batches.  Returns false when the window's options need the general path
+  // (extract_pairs: out-of-region mates).
+  bool CollectFlat(Window const& w, std::string_view ref_seq, struct FlatBatch* out);
 
  private:
   Params prm_;
@@ -969,6 +979,11 @@ struct FlatBatch {
     for (size_t i = 1; i < o.read_off.size(); ++i) read_off.push_back(qb + o.read_off[i]);
     for (size_t i = 1; i < o.read_win_off.size(); ++i) read_win_off.push_back(nr + o.read_win_off[i]);
   }
+  void Reserve(size_t n_win, size_t n_ref, size_t n_reads, size_t n_bases) {  // (Append then never re-allocates and copies what it holds)
+    windows.reserve(n_win); sample_cov.reserve(n_win); ref_off.reserve(n_win + 1); read_win_off.reserve(n_win + 1);
+    ref_bases.reserve(n_ref + 64); read_bases.reserve(n_bases + 64); read_quals.reserve(n_bases + 64);
+    read_sample.reserve(n_reads); read_flags.reserve(n_reads); read_qname_id.reserve(n_reads); read_hint.reserve(n_reads); read_off.reserve(n_reads + 1);
+  }
   void Seal() {
     size_t const rb = ref_bases.size(), qb = read_bases.size();
     ref_bases.resize(rb + 64, 0);
@@ -988,6 +1003,129 @@ struct FlatBatch {
     view.read_hint = read_hint.data();
   }
 };
+
+inline bool ReadCollector::CollectFlat(Window const& w, std::string_view ref_seq, FlatBatch* out) {
+  if (prm_.extract_pairs) return false;
+  struct Ref {
+    const SamRecord* rec;
+    uint64_t qh;
+    uint32_t sample;  // position in samples_
+    uint32_t order;   // arrival order (ties of the comparator)
+  };
+  std::vector<Ref> kept;
+  std::deque<SamRecord> arena;  // an indexed source hands out temporaries
+  double const max_sample_bases = prm_.max_sample_cov * static_cast<double>(w.Length());
+  int64_t const s1 = static_cast<int64_t>(w.start1), e1 = static_cast<int64_t>(w.end1);
+  size_t total_bases = 0;
+  for (size_t si = 0; si < samples_.size(); ++si) {
+    SampleInfo& sinfo = samples_[si];
+    size_t const first = kept.size();
+    uint64_t n_reads = 0, n_bases = 0;
+#ifdef LANCET2_AMD_WITH_ZLIB
+    bool const own = sinfo.source->indexed();
+#else
+    bool const own = false;
+#endif
+    sinfo.source->ForRegion(w.chrom, s1, e1, [&](SamRecord const& a) {
+      if (Filtered(a)) return;
+      const SamRecord* p = &a;
+      if (own) {
+        arena.push_back(a);
+        p = &arena.back();
+      }
+      n_reads += 1;
+      n_bases += a.seq.size();
+      kept.push_back(Ref{p, HashQname(a.qname), static_cast<uint32_t>(si), static_cast<uint32_t>(kept.size())});
+    });
+    double const bases_per_read = static_cast<double>(n_bases) / static_cast<double>(std::max<uint64_t>(n_reads, 1));
+    uint64_t const max_reads = static_cast<uint64_t>(std::ceil(max_sample_bases / bases_per_read));
+    uint64_t const sampled = std::min(n_reads, max_reads);
+    if (sampled < n_reads) {  // coverage-capped: the same shuffle of the name hashes, the same kept set (read_collector.cpp:147-216)
+      std::vector<uint64_t> hashes;
+      hashes.reserve(n_reads);
+      for (size_t i = first; i < kept.size(); ++i) hashes.push_back(kept[i].qh);
+      std::shuffle(hashes.begin(), hashes.end(), std::mt19937_64{0});
+      std::unordered_set<uint64_t> keep(hashes.begin(), hashes.begin() + static_cast<long>(sampled));
+      size_t at = first;
+      for (size_t i = first; i < kept.size(); ++i)
+        if (keep.count(kept[i].qh)) kept[at++] = kept[i];
+      kept.resize(at);
+    }
+    uint64_t bases = 0;
+    for (size_t i = first; i < kept.size(); ++i) bases += kept[i].rec->seq.size();
+    sinfo.sampled_reads = sampled;
+    sinfo.sampled_bases = bases;
+    total_bases += bases;
+  }
+  // read_collector.cpp:42-53: filter-pass status > sample tag > sample name > qname > chrom > position (> arrival)
+  std::sort(kept.begin(), kept.end(), [&](Ref const& l, Ref const& r) {
+    bool const lp = l.rec->mapq >= 20, rp = r.rec->mapq >= 20;
+    if (lp != rp) return static_cast<int>(lp) > static_cast<int>(rp);
+    if (l.sample != r.sample) {
+      SampleInfo const &ls = samples_[l.sample], &rs = samples_[r.sample];
+      if (ls.tag != rs.tag) return static_cast<uint8_t>(ls.tag) < static_cast<uint8_t>(rs.tag);
+      if (ls.name != rs.name) return ls.name < rs.name;
+    }
+    if (l.qh != r.qh || l.rec->qname != r.rec->qname) return l.rec->qname < r.rec->qname;
+    if (l.rec->chrom != r.rec->chrom) return l.rec->chrom < r.rec->chrom;
+    if (l.rec->pos0 != r.rec->pos0) return l.rec->pos0 < r.rec->pos0;
+    return l.order < r.order;
+  });
+  // ---- what FlatBatch::Add appends ----
+  FlatBatch& fb = *out;
+  fb.windows.push_back(w);
+  fb.sample_cov.emplace_back();
+  for (auto const& sm : samples_) fb.sample_cov.back().push_back(static_cast<double>(sm.sampled_bases) / static_cast<double>(w.Length()));
+  fb.ref_bases.insert(fb.ref_bases.end(), ref_seq.begin(), ref_seq.end());
+  fb.ref_off.push_back(static_cast<uint32_t>(fb.ref_bases.size()));
+  size_t const nr = kept.size(), b0 = fb.read_bases.size(), r0 = fb.read_qname_id.size();
+  fb.read_bases.resize(b0 + total_bases);
+  fb.read_quals.resize(b0 + total_bases);
+  fb.read_off.reserve(fb.read_off.size() + nr);
+  fb.read_qname_id.resize(r0 + nr);
+  fb.read_sample.resize(r0 + nr);
+  fb.read_flags.resize(r0 + nr);
+  fb.read_hint.resize(r0 + nr);
+  // names -> ids in order of first appearance: open addressing on the name hash, the name itself compared on a hit
+  size_t cap = 16;
+  while (cap < 2 * nr + 2) cap <<= 1;
+  std::vector<uint32_t> table(cap, 0xFFFFFFFFu);  // index into kept of the name's first appearance
+  std::vector<uint32_t> id_of(nr);
+  uint32_t n_names = 0;
+  size_t at = b0;
+  for (size_t i = 0; i < nr; ++i) {
+    SamRecord const& a = *kept[i].rec;
+    std::memcpy(fb.read_bases.data() + at, a.seq.data(), a.seq.size());
+    uint8_t* q = fb.read_quals.data() + at;
+    for (size_t x = 0; x < a.qual.size(); ++x) q[x] = a.qual[x] == 0xFF ? 0 : a.qual[x];
+    at += a.seq.size();
+    fb.read_off.push_back(at);
+    size_t h = static_cast<size_t>(kept[i].qh * 0x9E3779B97F4A7C15ull >> 20) & (cap - 1);
+    uint32_t id;
+    for (;;) {
+      uint32_t const e = table[h];
+      if (e == 0xFFFFFFFFu) {
+        table[h] = static_cast<uint32_t>(i);
+        id = n_names++;
+        break;
+      }
+      if (kept[e].qh == kept[i].qh && kept[e].rec->qname == a.qname) {
+        id = id_of[e];
+        break;
+      }
+      h = (h + 1) & (cap - 1);
+    }
+    id_of[i] = id;
+    fb.read_qname_id[r0 + i] = id;
+    SampleInfo const& sm = samples_[kept[i].sample];
+    fb.read_sample[r0 + i] = static_cast<uint8_t>(sm.index);
+    fb.read_flags[r0 + i] = static_cast<uint8_t>((a.mapq >= 20 ? MA_RF_PASS : 0) | (sm.tag == Tag::CASE ? MA_RF_CASE : 0) | ((a.flag & 0x10) ? MA_RF_REV : 0));
+    int64_t const hint = a.chrom == w.chrom ? a.pos0 - static_cast<int64_t>(w.start1 - 1) - static_cast<int64_t>(a.LeadingSoftClip()) : INT64_MIN;
+    fb.read_hint[r0 + i] = hint > INT32_MIN && hint < INT32_MAX ? static_cast<int32_t>(hint) : MA_NO_HINT;
+  }
+  fb.read_win_off.push_back(static_cast<uint32_t>(fb.read_qname_id.size()));
+  return true;
+}
 
 // ---- the store between the workers and the output (core/variant_store.cpp) ---------------------------------------------------
 struct VariantRecord {

@@ -146,6 +146,24 @@ int main() {
     CHECK(r1.samples[0].sampled_reads == 201);          // ceil(20 020 / 100) of the 800 passing reads
     CHECK(r1.reads.size() >= 201 && r1.reads.size() <= 402);
     CHECK(CrossSampleMeanCoverage(r1.samples, w.Length()) > 19.0);
+    // CollectFlat: the same window straight into flat arrays -- byte for byte what CollectRegion + FlatBatch::Add append,
+    // in the coverage-capped case (above) and in the uncapped one, with a second sample of the other tag beside the first
+    for (double cap : {20.0, 1000.0}) {
+      ReadCollector::Params pc;
+      pc.max_sample_cov = cap;
+      ReadCollector ca(pc, {{"s", Tag::CASE, &src, 0, 0, 0}, {"n", Tag::CTRL, &src, 0, 0, 0}});
+      ReadCollector cb(pc, {{"s", Tag::CASE, &src, 0, 0, 0}, {"n", Tag::CTRL, &src, 0, 0, 0}});
+      std::string const seq(w.Length(), 'A');
+      auto const rr = ca.CollectRegion(w);
+      FlatBatch fa, fbb;
+      fa.Add(w, seq, rr.reads, &rr.samples);
+      CHECK(cb.CollectFlat(w, seq, &fbb));
+      CHECK(fa.read_bases == fbb.read_bases && fa.read_quals == fbb.read_quals && fa.read_off == fbb.read_off);
+      CHECK(fa.read_qname_id == fbb.read_qname_id && fa.read_sample == fbb.read_sample && fa.read_flags == fbb.read_flags);
+      CHECK(fa.read_hint == fbb.read_hint && fa.read_win_off == fbb.read_win_off && fa.ref_bases == fbb.ref_bases && fa.ref_off == fbb.ref_off);
+      CHECK(fa.sample_cov == fbb.sample_cov && !fa.read_qname_id.empty());
+      CHECK(ca.Samples()[0].sampled_bases == cb.Samples()[0].sampled_bases && ca.Samples()[1].sampled_reads == cb.Samples()[1].sampled_reads);
+    }
   }
   {  // gates (variant_builder.cpp:107-132)
     std::vector<SampleInfo> none;

@@ -31,4 +31,5 @@ print("k_graph", {n: f"{100.0 * v / gt:.1f}%" for n, v in zip(["table pass", "ra
 qt = sum(d[22:26]) or 1
 print("k_mm_q", {n: f"{100.0 * v / qt:.1f}%" for n, v in zip(["set init", "queue -> set", "compaction", "support"], d[22:26])})
 eng.close()
+print("k_support (after its set-up)", {n: round(v / 2048.0) for n, v in zip(["group loop", "flush"], d[27:29])})
 print("raw ticks per workgroup (100 MHz?):", {i: round(v / 2048.0, 1) for i, v in enumerate(d) if v})

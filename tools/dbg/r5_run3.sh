@@ -1,3 +1,3 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/r5b
-timeout 900 python tools/prof_phases.py 2048 bench > gpurun_out/r5b/prof_phases.txt 2>&1
+timeout 600 python tools/dbg/prof_insert.py > gpurun_out/r5b/prof.txt 2>&1
