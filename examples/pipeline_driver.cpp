@@ -286,6 +286,9 @@ int main(int argc, char** argv) {
   std::atomic<size_t> next_window{0}, consumed{0};
   constexpr size_t kRunAhead = 4096;  // windows collected but not yet batched (bounds the memory held in slots)
   std::vector<double> worker_busy(static_cast<size_t>(extract_threads), 0.0);
+  std::atomic<bool> worker_failed{false};
+  std::exception_ptr worker_error;
+  std::mutex worker_mu;
   std::vector<std::thread> workers;
   for (int t = 0; t < extract_threads; ++t)
     workers.emplace_back([&, t] {
@@ -303,6 +306,12 @@ int main(int argc, char** argv) {
       while (true) {
         size_t const i = next_window.fetch_add(1);
         if (i >= windows.size()) break;
+        if (worker_failed.load(std::memory_order_acquire)) {  // another collector hit a corrupt input: hand over empty slots, stop
+          slots[i].st = WindowStatus::SKIPPED_NONLY_REF_BASES;
+          slots[i].ready.store(1, std::memory_order_release);
+          continue;
+        }
+        try {
         while (i > consumed.load(std::memory_order_acquire) + kRunAhead) std::this_thread::sleep_for(std::chrono::microseconds(200));
         auto const t0 = Clock::now();
         Window const& w = windows[i];
@@ -328,6 +337,16 @@ int main(int argc, char** argv) {
         }
         worker_busy[static_cast<size_t>(t)] += secs(Clock::now() - t0);
         sl.ready.store(1, std::memory_order_release);
+        } catch (...) {  // (a BGZF / BAI / BAM decoding error surfaces lazily, on this thread: keep the first one for main())
+          {
+            std::lock_guard<std::mutex> g(worker_mu);
+            if (!worker_error) worker_error = std::current_exception();
+          }
+          worker_failed.store(true, std::memory_order_release);
+          slots[i].st = WindowStatus::SKIPPED_NONLY_REF_BASES;
+          slots[i].flat.reset();
+          slots[i].ready.store(1, std::memory_order_release);
+        }
       }
     });
   std::thread extract([&] {
@@ -447,6 +466,16 @@ int main(int argc, char** argv) {
   engine.join();
   if (ctx) ma_destroy(ctx);
   if (out != stdout) std::fclose(out);
+  if (worker_error) {  // a collector thread's decoding error: the driver's own message and exit code, not std::terminate
+    try {
+      std::rethrow_exception(worker_error);
+    } catch (std::exception const& e) {
+      std::fprintf(stderr, "pipeline_driver: reading the alignments failed: %s\n", e.what());
+    } catch (...) {
+      std::fprintf(stderr, "pipeline_driver: reading the alignments failed\n");
+    }
+    return 5;
+  }
   std::fprintf(stderr,
                "pipeline_driver: %zu windows (%zu N-only, %zu max-k repeat, %zu inactive, %zu below anchor coverage), %zu assembled, "
                "%zu with a capacity flag, %zu records\n",

@@ -185,6 +185,7 @@ class BgzfFile {
     size_t bsize = 0;
     for (size_t p = 0; p + 4 <= xlen;) {
       size_t const slen = extra[p + 2] | (static_cast<size_t>(extra[p + 3]) << 8);
+      if (p + 4 + slen > xlen) throw std::runtime_error("corrupt BGZF block: extra subfield beyond the extra field");
       if (extra[p] == 'B' && extra[p + 1] == 'C' && slen == 2) bsize = (extra[p + 4] | (static_cast<size_t>(extra[p + 5]) << 8)) + 1;
       p += 4 + slen;
     }
@@ -194,6 +195,7 @@ class BgzfFile {
     if (std::fread(cdata.data(), 1, clen + 8, f_) != clen + 8) throw std::runtime_error("truncated BGZF block");
     uint32_t isize;
     std::memcpy(&isize, cdata.data() + clen + 4, 4);
+    if (isize > 65536u) throw std::runtime_error("corrupt BGZF block: more than 64 KiB of payload");
     block_.resize(isize);
     if (isize > 0) {
       z_stream zs{};
@@ -422,6 +424,10 @@ class AlignmentSource {
     r.mate_pos0 = mpos;
     r.tlen = tlen;
     size_t p = 32;
+    // every length comes from the file: a truncated or corrupt record must not send the decoder past its block
+    if (block < 32 || l_seq < 0 ||
+        32 + static_cast<size_t>(l_read_name) + 4u * static_cast<size_t>(n_cigar) + (static_cast<size_t>(l_seq) + 1) / 2 + static_cast<size_t>(l_seq) > block)
+      throw std::runtime_error("corrupt BAM record: its fields do not fit its block");
     r.qname.assign(reinterpret_cast<const char*>(b + p), l_read_name ? l_read_name - 1u : 0u);
     p += l_read_name;
     for (uint16_t c = 0; c < n_cigar; ++c) {
@@ -440,9 +446,11 @@ class AlignmentSource {
       p += 3;
       size_t len = 0;
       if (ty == 'Z' || ty == 'H') {
-        len = std::strlen(reinterpret_cast<const char*>(b + p)) + 1;
+        const void* const nul = std::memchr(b + p, 0, block - p);
+        if (!nul) break;  // unterminated string: nothing further can be trusted
+        len = static_cast<size_t>(static_cast<const unsigned char*>(nul) - (b + p)) + 1;
         if (t0 == 'M' && t1 == 'D') {
-          r.md.assign(reinterpret_cast<const char*>(b + p));
+          r.md.assign(reinterpret_cast<const char*>(b + p), len - 1);
           r.has_md = true;
         }
         if (t0 == 'S' && t1 == 'A') r.has_sa = true;
@@ -450,11 +458,14 @@ class AlignmentSource {
       else if (ty == 's' || ty == 'S') len = 2;
       else if (ty == 'i' || ty == 'I' || ty == 'f') len = 4;
       else if (ty == 'B') {
+        if (p + 5 > block) break;
         char const sub = static_cast<char>(b[p]);
         int32_t const cnt = rd32(p + 1);
+        if (cnt < 0) break;
         size_t const es = (sub == 'c' || sub == 'C') ? 1 : ((sub == 's' || sub == 'S') ? 2 : 4);
         len = 5 + es * static_cast<size_t>(cnt);
       } else break;
+      if (len > block - p) break;
       p += len;
     }
     return r;

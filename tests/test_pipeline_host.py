@@ -245,7 +245,7 @@ def test_pipeline_driver_reproduces_the_oracle_with_overlap_duplicates_merged(tm
     assert somatic >= 2  # the tumour-only SNVs at 1001 and 3101
 
 
-def sam_to_bam(sam_path, bam_path, with_index=False, block_bytes=60000):
+def sam_to_bam(sam_path, bam_path, with_index=False, block_bytes=60000, corrupt_record=None):
     """a minimal BAM writer (SAM spec 4.2; BGZF blocks = gzip members with the BC extra field): fixture for LoadBam.
     with_index: also writes bam_path + ".bai" (SAM spec 5.2: binning index + 16 kb linear index over virtual offsets)"""
     import struct
@@ -280,7 +280,8 @@ def sam_to_bam(sam_path, bam_path, with_index=False, block_bytes=60000):
         packed = bytearray((len(seq) + 1) // 2)
         for i, ch in enumerate(seq):
             packed[i // 2] |= code[ch] << (0 if i % 2 else 4)
-        body = struct.pack("<iiBBHHHiiii", rid, int(pos) - 1, len(qn) + 1, int(mapq), 4680, len(cigar), int(flag), len(seq),
+        l_seq = len(seq) if corrupt_record != len(rec_at) else (1 << 20)  # (a length field that lies about its block)
+        body = struct.pack("<iiBBHHHiiii", rid, int(pos) - 1, len(qn) + 1, int(mapq), 4680, len(cigar), int(flag), l_seq,
                            mrid, int(pnext) - 1, int(tlen))
         body += qn.encode() + b"\0" + b"".join(struct.pack("<I", c) for c in cigar) + bytes(packed)
         body += bytes(ord(c) - 33 for c in qual)
@@ -430,3 +431,18 @@ def test_bed_file_gives_the_regions(tmp_path):
     r = subprocess.run([exe, "--reference", str(tmp_path / "ref.fa"), "--normal", str(tmp_path / "normal.sam"), "--bed-file", str(bad),
                         "--extract-only"], capture_output=True, text=True)
     assert r.returncode == 2 and "Could not find chrom chrZ" in r.stderr, r.stderr
+
+
+def test_corrupt_bam_record_ends_the_run_with_a_message_not_a_crash(tmp_path):
+    """A record whose l_seq lies about its block (truncated / corrupt BAM): the decoder checks every file-supplied length against
+    the block, and the error -- raised lazily on a collector thread in indexed mode -- reaches main(): the driver's own message
+    and exit code instead of an out-of-bounds read or std::terminate."""
+    exe = driver(tmp_path)
+    write_fixture(str(tmp_path))
+    sam_to_bam(str(tmp_path / "normal.sam"), str(tmp_path / "normal.bam"), with_index=True, block_bytes=6000)
+    sam_to_bam(str(tmp_path / "tumor.sam"), str(tmp_path / "tumor.bam"), with_index=True, block_bytes=6000, corrupt_record=40)
+    r = subprocess.run([exe, "--reference", str(tmp_path / "ref.fa"), "--normal", str(tmp_path / "normal.bam"), "--tumor",
+                        str(tmp_path / "tumor.bam"), "--region", "chr1:1-6000", "--extract-only", "--extract-threads", "3"],
+                       capture_output=True, text=True)
+    assert r.returncode == 5, (r.returncode, r.stderr[-400:])
+    assert "corrupt BAM record" in r.stderr
