@@ -56,8 +56,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--windows", type=int, default=8192, help="windows per step per GPU")
-    ap.add_argument("--distinct", type=int, default=8192, help="distinct synthetic windows (tiled to --windows if fewer)")
+    ap.add_argument("--windows", type=int, default=16384, help="windows per step per GPU (round 5: 16384 -- a whole-genome run holds "
+                                                               "~3 M windows; rounds 1-4 stepped 8192 at a time)")
+    ap.add_argument("--distinct", type=int, default=16384, help="distinct synthetic windows (tiled to --windows if fewer)")
     ap.add_argument("--str-every", type=int, default=8, help="every n-th window carries a short tandem repeat (0 = none)")
     ap.add_argument("--nohint-every", type=int, default=50,
                     help="every n-th read pair arrives without a mapping hint (unmapped / rescued mates); 0 = every read hinted")
