@@ -76,6 +76,7 @@ def parse():
     ap.add_argument("--cpu-windows", type=int, default=64, help="oracle sample for cpu_baseline (0 = skip)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--gen-workers", type=int, default=0, help="processes that synthesise windows (0 = min(16, cores))")
+    ap.add_argument("--gen-only", action="store_true", help="synthesise the windows (into MA_BENCH_CACHE) and exit: no GPU is touched")
     return ap.parse_args()
 
 
@@ -285,6 +286,18 @@ def make_windows(config, count, first, str_every, workers, indices=None, over=No
     import multiprocessing as mp
     per = 32
     over = over or {}
+    # MA_BENCH_CACHE=<dir>: the synthesised batch is kept there (tools/r5_measure.sh: the profiler passes run the same command
+    # seven times, each of which would otherwise synthesise its windows in ONE process -- forked pools do not survive rocprofv3)
+    cache = os.environ.get("MA_BENCH_CACHE")
+    cpath = None
+    if cache:
+        import hashlib
+        key = repr((config, count, first, str_every, None if indices is None else list(indices), sorted(over.items()), NOHINT_EVERY,
+                    HARD_EVERY, SOFTCLIP, NFRAC))
+        cpath = os.path.join(cache, "batch_" + hashlib.sha256(key.encode()).hexdigest()[:16] + ".npz")
+        if os.path.exists(cpath):
+            z = np.load(cpath)
+            return {k_: z[k_] for k_ in z.files if k_ not in ("_n", "_nr")}, int(z["_n"]), int(z["_nr"])
     if indices is None:
         jobs = [(config, first + o, min(per, count - o), str_every, over) for o in range(0, count, per)]
     else:
@@ -295,7 +308,11 @@ def make_windows(config, count, first, str_every, workers, indices=None, over=No
     else:
         with mp.get_context("fork").Pool(workers) as pool:
             parts = pool.map(_gen_chunk, jobs, chunksize=1)
-    return concat_batches(parts)
+    res = concat_batches(parts)
+    if cpath:
+        os.makedirs(cache, exist_ok=True)
+        np.savez(cpath, _n=res[1], _nr=res[2], **res[0])
+    return res
 
 
 _START = None  # multi-worker baseline: every worker finishes synthesising its windows before any of them is timed
@@ -556,6 +573,9 @@ def main():
         c4_arrs = make_windows("C4", min(distinct, args.c4_windows), first, 0, workers) if args.c4_windows > 0 else None
         c5_arrs = make_windows("C5", min(distinct, 2048), first, args.str_every, workers)
     t_gen = time.perf_counter() - t_gen
+    if args.gen_only:
+        print(json.dumps({"synthesised_windows": n0, "s": round(t_gen, 1), "cache": os.environ.get("MA_BENCH_CACHE")}))
+        return
     cpu = cpu_mt = cpu_c4 = None
     kept = []
     if world == 1 and not args.no_cpu and args.cpu_windows > 0:

@@ -7,6 +7,9 @@ T=${1:-r5_final}
 O=$R/gpurun_out/$T
 rm -rf $O && mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
+# the windows are synthesised ONCE (16 processes) and kept: every profiler pass below loads them
+export MA_BENCH_CACHE=/tmp/ma_bench_cache
+python3 $R/bench.py --no-cpu --no-also --gen-only > $O/gen.log 2>&1
 B="python3 $R/bench.py --steps 2 --no-cpu --no-also --gen-workers 1"
 for c in FETCH_SIZE WRITE_SIZE SQ_INSTS_VALU; do
   timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_$c -- $B > $O/pmc_$c.log 2>&1
