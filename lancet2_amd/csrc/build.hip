@@ -641,12 +641,8 @@ __device__ __forceinline__ u64 kmer_id_lds(const u32* l_seq, u32 p, int k, bool*
 // k_mm_lds), each distinct k-mer goes into it once, and a last pass hands every instance its table slot.  k-mers that
 // do not fit the map (deep samples) are deferred and take the direct path with its atomics.
 constexpr int kInsT = 1024;
-constexpr u32 kInsMap = 6144;         // LDS map entries (48 KB of ids + 24 KB of first instances)
 constexpr u32 kInsProbe = 1024;       // probes before an id counts as homeless (only a map without a free entry gets there)
-constexpr u32 kSeqWords = 16376;      // the window's read bases as 4-bit codes in LDS: 131 008 bases (+ 8 words of slack)
-constexpr u32 kStageSeqs = 1024;      // sequences whose first base / first instance phase A keeps in LDS
-constexpr u32 kInsArea = 12u * kInsMap;  // 73 728 B: the staged bases + sequence records, THEN the map (two workgroups per CU)
-static_assert(4u * (kSeqWords + 8u) + 8u * kStageSeqs <= kInsArea, "k_insert: the staging area must fit the map's");
+constexpr u32 kInsMapA = 6144, kInsStageA = 1024;  // LDS map entries (48 KB of ids + 24 KB of first instances); staged sequences
 // four ASCII bases -> four 2-bit codes in the low bits of each byte, and whether all four are upper-case A/C/G/T: the byte a
 // code stands for is 0x41 + 2 c0 + 6 c1 + 11 c0 c1 (A 0x41, C 0x43, G 0x47, T 0x54) -- byte lanes never carry into each other
 __device__ __forceinline__ u32 swar_codes4(u32 v, bool* all_acgt) {
@@ -665,15 +661,17 @@ __device__ __forceinline__ u32 swar_codes4(u32 v, bool* all_acgt) {
 // error-free / last bits (k_classify) and its canonical bit, so an instance word is WRITTEN once, with its final table slot --
 // the LDS map's entry, which is what the table is copied out from -- and never read: the old passes read and rewrote every
 // slow instance's word twice (two 64-byte sectors per 4-byte word).
-__global__ __launch_bounds__(kInsT) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_insert(DBatch b, GraphWs ws) {
-  __shared__ __align__(16) unsigned char l_area[kInsArea];
+template <u32 kInsMap, u32 kStageSeqs>
+__device__ __forceinline__ void insert_window(DBatch const& b, GraphWs const& ws, int const a, unsigned char* l_area) {
+  constexpr u32 kInsArea = 12u * kInsMap;  // the staged bases + sequence records, THEN the map
+  constexpr u32 kSeqWords = (kInsArea - 8u * kStageSeqs) / 4u - 8u;  // read bases as 4-bit codes: 131 008 / 262 080 bases (+ 8 words of slack)
+  static_assert(4u * (kSeqWords + 8u) + 8u * kStageSeqs <= kInsArea, "k_insert: the staging area must fit the map's");
   __shared__ u32 l_nmap, l_ndef, l_seq_ok;
   u32* const l_seq = reinterpret_cast<u32*>(l_area);                               // phase A: [kSeqWords + 8]
   u32* const l_rpos = reinterpret_cast<u32*>(l_area + 4u * (kSeqWords + 8u));      //          [kStageSeqs] first base of a sequence in l_seq
   u32* const l_ibase = l_rpos + kStageSeqs;                                        //          [kStageSeqs] its first instance
   u64* const l_key = reinterpret_cast<u64*>(l_area);                               // phase B: [kInsMap]
   u32* const l_min = reinterpret_cast<u32*>(l_area + 8u * kInsMap);                //          [kInsMap] smallest instance of the id
-  int const a = blockIdx.x;
   int const w = static_cast<int>(ws.active[a]);
   int const k = win_kmer(ws, w);
   int const tcl = tbl_log2(ws);
@@ -829,11 +827,6 @@ __global__ __launch_bounds__(kInsT) __attribute__((amdgpu_waves_per_eu(8, 8))) v
   __syncthreads();  // the staged bases are dead: the area becomes the map
   IPROF(1);  // records
   // ================= phase B: the map =================
-  for (u32 i = threadIdx.x; i < kInsMap; i += kInsT) {
-    l_key[i] = 0;
-    l_min[i] = 0xFFFFFFFFu;
-  }
-  __syncthreads();
   // map entry of an id (kNoNode: no room -- the map has not an entry free within kInsProbe of the id's place, and never will)
   auto map_entry = [&](u64 id) -> u32 {
     u32 e = static_cast<u32>(id >> 32) % kInsMap;
@@ -869,71 +862,120 @@ __global__ __launch_bounds__(kInsT) __attribute__((amdgpu_waves_per_eu(8, 8))) v
     return ((z & kQPlus) ? kInstPlus : 0u) | ((z & kQErrFree) ? kInstErrFree : 0u) | ((z & kQLast) ? kInstLast : 0u);
   };
   auto const rec_id = [](uint4 const& r) -> u64 { return static_cast<u64>(r.x) | (static_cast<u64>(r.y) << 32); };
+  int const CW = ws.num_samples + 2;
+  u32* cnt = ws.tbl_cnt + (static_cast<size_t>(a) << tcl) * CW;
   // When every id finds room in the LDS map (always, except in deep samples) the map IS the table: slot = map entry, keys and
-  // first instances are copied out with coalesced stores below, and every instance word can be written here and now.  The
-  // words are written on that assumption; the rare window that needs the HBM table rewrites them (the general route below).
-  for (u32 p = threadIdx.x; p < rsi.nk; p += kInsT) {
-    uint4 const rc = recs[p];
-    u32 const e = map_entry(rec_id(rc));
-    if (e != kNoNode) {
-      atomicMin(&l_min[e], p);
-      inst_slot[p] = e | word_flags(rc.z);
-      ref_slot_g[p] = e;
-    } else {
-      atomicAdd(&l_ndef, 1u);
+  // first instances are copied out with coalesced stores, and every instance word is written here and now with its final slot.
+  // ONE map pass over the ids of class `cls` of `ncls` (the id's low bits; one class = everything): map from scratch, the
+  // reference k-mers, then the slow queue; slot = cls * kInsMap + map entry.  Returns with l_ndef = ids that found no room.
+  auto map_pass = [&](u32 ncls, u32 cls) {
+    __syncthreads();
+    for (u32 i = threadIdx.x; i < kInsMap; i += kInsT) {
+      l_key[i] = 0;
+      l_min[i] = 0xFFFFFFFFu;
     }
-  }
-  __syncthreads();  // a later instance of a reference k-mer sees a reference position as its id's minimum
-  IPROF(2);  // reference k-mers
-  for (u32 x0 = threadIdx.x; x0 < nq; x0 += kInsT * kIU) {
-    uint4 rc[kIU];
-    bool live[kIU];
-#pragma unroll
-    for (int u = 0; u < kIU; ++u) {
-      u32 const x = x0 + u * kInsT;
-      live[u] = x < nq;
-      rc[u] = recs[rsi.nk + (live[u] ? x : 0u)];
-    }
-#pragma unroll
-    for (int u = 0; u < kIU; ++u) {
-      if (!live[u]) continue;
-      u32 const e = map_entry(rec_id(rc[u]));
+    if (threadIdx.x == 0) l_nmap = 0;
+    __syncthreads();
+    u32 const sbase = cls * kInsMap;
+    for (u32 p = threadIdx.x; p < rsi.nk; p += kInsT) {
+      uint4 const rc = recs[p];
+      if (ncls > 1 && (rc.x & 0xFFFFu) % ncls != cls) continue;
+      u32 const e = map_entry(rec_id(rc));
       if (e != kNoNode) {
-        u32 const inst = rc[u].z & kInstIdx;
-        u32 const before = atomicMin(&l_min[e], inst);
-        inst_slot[inst] = e | word_flags(rc[u].z);
-        // the k-mer is also a reference k-mer <=> the smallest instance of its id is a reference position
-        if ((rc[u].z & kQErrFree) && before < rsi.nk) ws.rd_flag[r_first + rc[u].w - 1] = 1;
+        atomicMin(&l_min[e], p);
+        inst_slot[p] = (sbase + e) | word_flags(rc.z);
+        ref_slot_g[p] = sbase + e;
       } else {
         atomicAdd(&l_ndef, 1u);
       }
     }
+    __syncthreads();  // a later instance of a reference k-mer sees a reference position as its id's minimum
+    for (u32 x0 = threadIdx.x; x0 < nq; x0 += kInsT * kIU) {
+      uint4 rc[kIU];
+      bool live[kIU];
+#pragma unroll
+      for (int u = 0; u < kIU; ++u) {
+        u32 const x = x0 + u * kInsT;
+        live[u] = x < nq;
+        rc[u] = recs[rsi.nk + (live[u] ? x : 0u)];
+      }
+#pragma unroll
+      for (int u = 0; u < kIU; ++u) {
+        if (!live[u] || (ncls > 1 && (rc[u].x & 0xFFFFu) % ncls != cls)) continue;
+        u32 const e = map_entry(rec_id(rc[u]));
+        if (e != kNoNode) {
+          u32 const inst = rc[u].z & kInstIdx;
+          u32 const before = atomicMin(&l_min[e], inst);
+          inst_slot[inst] = (sbase + e) | word_flags(rc[u].z);
+          // the k-mer is also a reference k-mer <=> the smallest instance of its id is a reference position
+          if ((rc[u].z & kQErrFree) && before < rsi.nk) ws.rd_flag[r_first + rc[u].w - 1] = 1;
+        } else {
+          atomicAdd(&l_ndef, 1u);
+        }
+      }
+    }
+    __syncthreads();
+  };
+  auto copy_out = [&](u32 cls) {  // the map as slots [cls * kInsMap, (cls + 1) * kInsMap) of the window's table
+    for (u32 i = threadIdx.x; i < kInsMap; i += kInsT) {
+      u64 const id = l_key[i];
+      keys[cls * kInsMap + i] = id;
+      first[cls * kInsMap + i] = id ? l_min[i] : 0x7F7F7F7Fu;  // (0x7F7F7F7F > any instance)
+    }
+  };
+  map_pass(1, 0);
+  IPROF(3);  // the map
+  if (l_ndef == 0 && (1u << tcl) >= kInsMap) {  // the usual case
+    copy_out(0);
+    for (u32 i = threadIdx.x; i < kInsMap * CW; i += kInsT) cnt[i] = 0;
+    if (threadIdx.x == 0) ws.win_nslots[a] = kInsMap;
+    IPROF(4);  // table out
+    return;
   }
-  __syncthreads();
-  IPROF(3);  // slow queue
-  // ---- the table: as many slots as the distinct k-mers need (the stride is sized for the busiest window; nothing re-hashes
-  //      later: every stage goes through the slot in the instance word) ----
-  bool const direct_map = l_ndef == 0 && (1u << tcl) >= kInsMap;
-  u32 nslots = kInsMap;
-  if (!direct_map) {
+  // More distinct k-mers than the map holds (large k: an error spoils k k-mers -- the tail of the k ladder; long reads; 2.5 kb
+  // windows): the ids are split into 2 or 4 CLASSES and the map is filled, and copied out as its own range of table slots,
+  // once per class -- the records are read again, nothing goes through an HBM hash table.  (l_ndef counts the INSTANCES that
+  // found no room -- a few per distinct id: a generous estimate of the classes it takes.)
+  {
+    u32 const ndef0 = l_ndef;
+    u32 ncls = ndef0 <= 2u * kInsMap ? 2u : (ndef0 <= 8u * kInsMap ? 4u : 0u);
+    bool tried = false;
+    if (ncls && ndef0 && (1u << tcl) >= ncls * kInsMap) {
+      tried = true;
+      __syncthreads();
+      if (threadIdx.x == 0) l_ndef = 0;
+      for (u32 cls = 0; cls < ncls; ++cls) {
+        map_pass(ncls, cls);
+        if (l_ndef != 0) break;  // (uniform: read after the pass's last barrier)
+        copy_out(cls);
+      }
+      if (l_ndef == 0) {
+        for (u32 i = threadIdx.x; i < ncls * kInsMap * CW; i += kInsT) cnt[i] = 0;
+        if (threadIdx.x == 0) ws.win_nslots[a] = ncls * kInsMap;
+        return;
+      }
+    }
+    if (tried) {  // (a class outgrew the map after all) the general route below continues from the state of ONE pass over everything
+      __syncthreads();
+      if (threadIdx.x == 0) l_ndef = 0;
+      map_pass(1, 0);
+    }
+  }
+  // ---- the HBM table: as many slots as the distinct k-mers need (the stride is sized for the busiest window; nothing
+  //      re-hashes later: every stage goes through the slot in the instance word) ----
+  u32 nslots;
+  {
     u32 tcw = 10;
     while (tcw < static_cast<u32>(tcl) && (1u << tcw) < (l_nmap + l_ndef) * 4u / 3u + 16u) ++tcw;
     nslots = 1u << tcw;
   }
-  u32 const mask = nslots - 1;  // (general route only: a power of two there)
-  {
-    int const CW = ws.num_samples + 2;
-    u32* cnt = ws.tbl_cnt + (static_cast<size_t>(a) << tcl) * CW;
-    for (u32 i = threadIdx.x; i < nslots; i += kInsT) {
-      u64 const id = direct_map ? l_key[i] : 0ull;
-      keys[i] = id;
-      first[i] = id ? l_min[i] : 0x7F7F7F7Fu;  // (0x7F7F7F7F > any instance)
-    }
-    for (u32 i = threadIdx.x; i < nslots * CW; i += kInsT) cnt[i] = 0;
-    if (threadIdx.x == 0) ws.win_nslots[a] = nslots;
+  u32 const mask = nslots - 1;
+  for (u32 i = threadIdx.x; i < nslots; i += kInsT) {
+    keys[i] = 0ull;
+    first[i] = 0x7F7F7F7Fu;
   }
-  IPROF(4);  // table initialisation
-  if (direct_map) return;
+  for (u32 i = threadIdx.x; i < nslots * CW; i += kInsT) cnt[i] = 0;
+  if (threadIdx.x == 0) ws.win_nslots[a] = nslots;
   // ================= general route: an HBM table (deep samples; a table stride below the map's size) =================
   __syncthreads();
   // every distinct k-mer of the map into the HBM table, once; l_min[e] becomes its slot | bit 31 "also a reference k-mer"
@@ -992,6 +1034,10 @@ __global__ __launch_bounds__(kInsT) __attribute__((amdgpu_waves_per_eu(8, 8))) v
     if ((rc.z & kQErrFree) && isref) ws.rd_flag[r_first + rc.w - 1] = 1;
   }
   IPROF(5);  // general route
+}
+__global__ __launch_bounds__(kInsT) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_insert(DBatch b, GraphWs ws) {
+  __shared__ __align__(16) unsigned char l_area[12u * kInsMapA];
+  insert_window<kInsMapA, kInsStageA>(b, ws, static_cast<int>(blockIdx.x), l_area);
 }
 #ifdef MA_PROFILE
 extern "C" void ma_debug_iprof(unsigned long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_iprof), sizeof(unsigned long long) * 32); }
