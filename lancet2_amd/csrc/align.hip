@@ -395,7 +395,10 @@ __device__ __forceinline__ void vote_pair(GArgs const& A, u64 lp, PairId id, Hap
 // waves per SIMD the registers are held to (96 VGPRs): five workgroups per CU, as many as their LDS allows -- the
 // kernel spends most of its life waiting for LDS and memory, one more resident workgroup in four is worth 13 % (a sixth,
 // bought with a half-size seed index, costs more in longer bucket chains than it hides)
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_vote(GArgs A, u32 hist_len, u32 rwords, u32 ml_eff) {
+#ifndef MA_VOTE_WAVES
+#define MA_VOTE_WAVES 5
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MA_VOTE_WAVES, 8))) void k_vote(GArgs A, u32 hist_len, u32 rwords, u32 ml_eff) {
   extern __shared__ u32 lds_vote[];
 #ifdef MA_PROFILE
   unsigned long long const k_tstart = __builtin_amdgcn_s_memtime();
