@@ -2624,9 +2624,10 @@ int launch_genotype(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& a, const m
           if (c2 >= 0) {
             u32 const n1 = cls_n, n2 = class_n(c2);
             u32 const gw2 = class_w(c2);
-            // (opt-in: 36 % fewer vector instructions and 0.2-0.7 ms less single-lane, but at two wavefronts per SIMD it gives the
-            //  other lanes' kernels less room -- with four lanes the step is 0.2 ms LONGER)
-            bool const pk = getenv("MA_ALIGN_PK") && atoi(getenv("MA_ALIGN_PK")) != 0;
+            // (36 % fewer vector instructions.  Round 4 left it opt-in: the four-lane step was no shorter.  Round 5's step is bound
+            //  by the throughput kernels' CU time, and the packed launch now buys +1.7 % (A/B on one box, twice); MA_ALIGN_PK=0
+            //  is the one-pair-per-lane launch)
+            bool const pk = !(getenv("MA_ALIGN_PK") && atoi(getenv("MA_ALIGN_PK")) == 0);
             if (pk) {
               // two pairs per lane (k_align_reg2p): the pairs that cannot reach a haplotype end in packed groups of 128 (two
               // 64-pair tiles, wide enough for the plane rows), the others in groups of 64 through the general body

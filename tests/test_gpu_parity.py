@@ -800,13 +800,14 @@ def test_mate_mer_set_that_fills_up_is_split_not_truncated(monkeypatch):
     assert not bad, "\n".join(bad[:12])
 
 
-def test_packed_two_pairs_per_lane_aligner_is_the_one_pair_aligner(monkeypatch):
+@pytest.mark.parametrize("pk", ["1", "0"])
+def test_packed_two_pairs_per_lane_aligner_is_the_one_pair_aligner(pk, monkeypatch):
     """MA_ALIGN_PK=1: the two busiest register classes of the read aligner run two pairs per lane on packed 16-bit halves
     (align.hip: k_align_reg2p -- decisions as bit planes, walks back in k_align_tb2) for the pairs whose region cannot reach a
     haplotype end, the general body beside them for the others.  Same records as the oracle, on WGS-shaped windows with
     tandem repeats, soft clips and N bases; the timing names prove the route was taken."""
     from lancet2_amd.engine import Engine
-    monkeypatch.setenv("MA_ALIGN_PK", "1")
+    monkeypatch.setenv("MA_ALIGN_PK", pk)  # (round 5: the packed launch is the default; "0" keeps the one-pair launch covered)
     monkeypatch.setenv("MA_NO_REROUTE", "1")  # (a class of a few hundred pairs would go to the wavefront kernel: no two classes to pair)
     params = capi.default_params(min_k=25, max_k=25)
     arrs, n, nr = synth.make_config_batch("C3", 12, first_index=86_000, softclip_frac=0.05, n_frac=0.03)
@@ -821,7 +822,7 @@ def test_packed_two_pairs_per_lane_aligner_is_the_one_pair_aligner(monkeypatch):
         names = {k for k, _ in eng.kernel_times()}
     finally:
         eng.close()
-    assert "k_align_tb" in names, sorted(names)
+    assert ("k_align_tb" in names) == (pk == "1"), sorted(names)
     bad = compare_asm(params, a, wa, n) + compare_vars(params, v, wv, n)
     bad += compare_geno(params, q, wq, n, nr, wv["win_nvars"], arrs["read_win_off"])
     assert not bad, "\n".join(bad[:12])

@@ -1,0 +1,8 @@
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out/r5b
+timeout 1200 python -m pytest tests -m gpu -x -q 2>&1 | tail -15 > gpurun_out/r5b/gpu_tests.txt
+if grep -q failed gpurun_out/r5b/gpu_tests.txt; then exit 0; fi
+export MA_BENCH_CACHE=/tmp/mbc
+python3 bench.py --no-cpu --no-also --gen-only > /dev/null 2>&1
+MA_STREAMS=1 python3 bench.py --steps 3 --no-cpu --no-also 2>/dev/null | tail -1 > gpurun_out/r5b/bench_1lane.json
+python3 bench.py --steps 4 --no-cpu --no-also 2>/dev/null | tail -1 > gpurun_out/r5b/bench.json
