@@ -1402,3 +1402,37 @@ def test_hbm_mate_mer_sets_come_out_of_a_budgeted_pool(pool_kb, monkeypatch):
     bad = compare_asm(params, a, wa, n) + compare_vars(params, v, wv, n)
     bad += compare_geno(params, q, wq, n, nr, wv["win_nvars"], arrs["read_win_off"])
     assert not bad, "\n".join(bad[:12])
+
+
+@pytest.mark.gpu
+def test_deep_window_whose_lds_mate_mer_set_fills_is_split_in_place(monkeypatch):
+    """The bench's deep-panel window 10488 (7 k reads): one slot class of k_mm_lds's scan route holds more (k-mer, read pair)
+    keys than the 32 k-entry LDS set -- the PRODUCTION detection (not an entry free after the pass), not the test build's probe
+    cap.  Round 4 flagged the window and the retry pass re-assembled it through the HBM set; round 5 splits the class in two and
+    redoes it before anything of it was counted.  With the capacity retries switched off the window must come out unflagged
+    and identical to the oracle."""
+    import sys
+    sys.path.insert(0, capi.REPO)
+    import bench
+    from lancet2_amd.engine import Engine
+    monkeypatch.setenv("MA_NO_CAP_RETRY", "1")
+    arrs, n, nr = bench._gen_chunk(("C4", [10_488, 10_000], 0, 0))
+    params = capi.default_params(min_k=25, max_k=25)
+    orc = OracleEngine(params)
+    wa = orc.assemble(arrs, n, nr)
+    wv = orc.msa(arrs, n, nr, wa)
+    wq = orc.genotype(arrs, n, nr, wa, wv)
+    eng = Engine(params)
+    try:
+        eng.timing_control(1)
+        g, a, v, q = eng.process(arrs, n, nr, debug=True)
+        times = {}
+        for k_, ms in eng.kernel_times():
+            times[k_] = times.get(k_, 0.0) + ms
+    finally:
+        eng.close()
+    assert times.get("k_mm_lds", 0) > 0.1, times  # (the scan route: more sequences than a key's leader index names)
+    assert not (a["win_status"] & capi.MA_W_TABLE_OVERFLOW).any(), a["win_status"].tolist()
+    bad = compare_asm(params, a, wa, n) + compare_vars(params, v, wv, n)
+    bad += compare_geno(params, q, wq, n, nr, wv["win_nvars"], arrs["read_win_off"])
+    assert not bad, "\n".join(bad[:12])

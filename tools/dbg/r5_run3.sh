@@ -1,3 +1,3 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/r5b
-MA_VERBOSE=1 timeout 600 python tools/dbg/cascade_passes.py 2048 > gpurun_out/r5b/cascade.txt 2>&1
+timeout 900 python -m pytest tests -m gpu -x -q -k "set_fills_is_split" 2>&1 | tail -8 > gpurun_out/r5b/t.txt
