@@ -102,8 +102,8 @@ struct AlnWs {
   // one (window, haplotype) are consecutive, so a wavefront of k_assign (a lane per read) loads 64 records as one run.
   // (Round 4 kept them in the caller's fixed-stride layout [read][max_haps]: 1.5 KB between two lanes' records, 8 GB of
   //  workspace touched a sector at a time.)  The caller's debug taps aln_rec / aln_cigar are filled from these (k_tap_records).
-  i32* rec;            // [pairs][6]  hit, score, rs, re, qs, qe
-  u32* cig;            // [pairs][1 + max_cigar]  op count, ops
+  i32* rec;            // [pairs][8]  packed record (rec_store)
+  u32* cig;            // [pairs][1 + max_cigar]  op count, ops -- written for DP pairs only, read when a CIGAR has more than four operations
 };
 
 struct GArgs {
@@ -119,8 +119,18 @@ struct GArgs {
   u32 dp_n;      // entries of this DP launch
 };
 
-__device__ __forceinline__ i32* rec_at(AlnWs const& ws, u64 gp) { return ws.rec + gp * 6; }
+// A pair's record is 32 bytes: [0] score, [1] rs | re << 16, [2] qs | qe << 16 (haplotype and read coordinates are below 2^16),
+// [3] number of CIGAR operations (0: no alignment), [4..7] the first four operations -- a certificate pair is `S? M S?`, and 94 %
+// of the pairs are certificate pairs.  Longer CIGARs (DP pairs) are ALSO in the side array cig[pair][1 + max_cigar]; nobody
+// touches a pair's side slot otherwise (round 4 wrote 24 + 8 bytes into a 24-byte record and a 68-byte slot per pair).
+constexpr u32 kRecWords = 8;
+__device__ __forceinline__ u32* rec_at(AlnWs const& ws, u64 gp) { return reinterpret_cast<u32*>(ws.rec) + gp * kRecWords; }
 __device__ __forceinline__ u32* cig_at(AlnWs const& ws, ma_params_t const& prm, u64 gp) { return ws.cig + gp * (1 + prm.max_cigar); }
+__device__ __forceinline__ void rec_store(u32* r, i32 score, i32 rs, i32 re, i32 qs, i32 qe, u32 nops, u32 o0, u32 o1, u32 o2, u32 o3) {
+  reinterpret_cast<uint4*>(r)[0] = make_uint4(static_cast<u32>(score), static_cast<u32>(rs) | (static_cast<u32>(re) << 16),
+                                              static_cast<u32>(qs) | (static_cast<u32>(qe) << 16), nops);
+  reinterpret_cast<uint4*>(r)[1] = make_uint4(o0, o1, o2, o3);
+}
 
 // A read's three bit planes live in one wavefront (k_vote / k_align_*: a lane per word): 608 bases at most.  A window
 // that holds a longer read is not genotyped and says so (MA_W_READ_OVERFLOW) -- the batch goes on without it.
@@ -619,16 +629,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MA_VOTE_WAV
           if (D + 22 * X + 10 < m && S0 >= A.prm.min_aln_score && D < 60000) {
             settled = true;
             if (x == 0) {
-              i32* arec = rec_at(A.ws, p);
-              u32* acig = cig_at(A.ws, A.prm, p);
-              arec[0] = 1;
-              arec[1] = S0;
-              arec[2] = c;
-              arec[3] = c + m;
-              arec[4] = 0;
-              arec[5] = m;
-              acig[0] = 1;
-              acig[1] = static_cast<u32>(m) << 4;
+              rec_store(rec_at(A.ws, p), S0, c, c + m, 0, m, 1u, static_cast<u32>(m) << 4, 0u, 0u, 0u);
               A.ws.centre[p - A.pair0] = 0x7FFFFFFE;
             }
           }
@@ -697,7 +698,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MA_VOTE_WAV
 // "no alignment": the hit flag of the pair's record is cleared explicitly (every reader tests it before anything else),
 // so the multi-GB internal record arrays need no memset per batch.
 __device__ __forceinline__ void write_no_hit(GArgs const& A, u64 lp) {
-  rec_at(A.ws, A.pair0 + lp)[0] = 0;
+  rec_at(A.ws, A.pair0 + lp)[3] = 0;
 }
 
 __device__ __forceinline__ void vote_pair(GArgs const& A, u64 lp, PairId id, HapIdx ix, u16* hist, int lane, i32 m, u32 pre, i32 hint, i32 n,
@@ -746,16 +747,7 @@ __device__ __forceinline__ void vote_pair(GArgs const& A, u64 lp, PairId id, Hap
         i32 const S0 = m - 5 * X;
         if (D + 22 * X + 10 < m && S0 >= A.prm.min_aln_score && D < 60000) {
           if (lane == 0) {
-            i32* arec = rec_at(A.ws, A.pair0 + lp);
-            u32* acig = cig_at(A.ws, A.prm, A.pair0 + lp);
-            arec[0] = 1;
-            arec[1] = S0;
-            arec[2] = c;
-            arec[3] = c + m;
-            arec[4] = 0;
-            arec[5] = m;
-            acig[0] = 1;
-            acig[1] = static_cast<u32>(m) << 4;
+            rec_store(rec_at(A.ws, A.pair0 + lp), S0, c, c + m, 0, m, 1u, static_cast<u32>(m) << 4, 0u, 0u, 0u);
             A.ws.centre[lp] = 0x7FFFFFFE;
           }
           return;
@@ -1023,20 +1015,23 @@ __device__ __forceinline__ void vote_pair(GArgs const& A, u64 lp, PairId id, Hap
       A.ws.centre[lp] = 0x7FFFFFFF;  // no alignment
       write_no_hit(A, lp);
     } else if (fast) {
-      i32* arec = rec_at(A.ws, A.pair0 + lp);
-      u32* acig = cig_at(A.ws, A.prm, A.pair0 + lp);
-      arec[0] = 1;
-      arec[1] = S0;
-      arec[2] = c + qs;
-      arec[3] = c + qe;
-      arec[4] = qs;
-      arec[5] = qe;
       // BuildCigar (genotyper.cpp:45-69): S(qs) + core + S(m - qe); ops: 0 M, 4 S
+      u32 o[3] = {0u, 0u, 0u};
       u32 nc = 0;
-      if (qs > 0) acig[1 + nc++] = (static_cast<u32>(qs) << 4) | 4u;
-      acig[1 + nc++] = static_cast<u32>(qe - qs) << 4;
-      if (qe < m) acig[1 + nc++] = (static_cast<u32>(m - qe) << 4) | 4u;
-      acig[0] = nc;
+      u32 const ops_s = (static_cast<u32>(qs) << 4) | 4u, ops_m = static_cast<u32>(qe - qs) << 4, ops_e = (static_cast<u32>(m - qe) << 4) | 4u;
+      if (qs > 0) {
+        o[0] = ops_s;
+        o[1] = ops_m;
+        nc = 2;
+      } else {
+        o[0] = ops_m;
+        nc = 1;
+      }
+      if (qe < m) {
+        if (nc == 1) o[1] = ops_e; else o[2] = ops_e;
+        ++nc;
+      }
+      rec_store(rec_at(A.ws, A.pair0 + lp), S0, c + qs, c + qe, qs, qe, nc, o[0], o[1], o[2], 0u);
       A.ws.centre[lp] = 0x7FFFFFFE;
     } else {
       // width class of the region; can a row of the kernel's window reach column 0 or n (+ the 7 columns the last
@@ -1097,8 +1092,7 @@ namespace {
 // prefer opening a gap) + BuildCigar (genotyper.cpp:45-69).  fetch(i, t) returns the move nibble of cell (i, j),
 // t = j - i - lo: bits 0-1 source of H (0 diagonal, 1 E, 2 F), bit 2 E opened here, bit 3 F opened here.
 template <class Fetch>
-__device__ void align_traceback(GArgs const& A, Fetch fetch, i32 lo, i32 m, i32 best, i32 bi, i32 bj, i32* arec, u32* acig,
-                                bool write) {
+__device__ void align_traceback(GArgs const& A, Fetch fetch, i32 lo, i32 m, i32 best, i32 bi, i32 bj, u64 gp, bool write) {
   int const MCG = A.prm.max_cigar;
   u32 ops[64];   // reversed run-length ops, len << 4 | op (private memory: only touched when a run ENDS -- the run in hand
   int nops = 0;  // lives in registers; one read-modify-write of this array per step was two memory operations per step)
@@ -1146,16 +1140,16 @@ __device__ void align_traceback(GArgs const& A, Fetch fetch, i32 lo, i32 m, i32 
   flush_run();
   if (!write) return;
   i32 const qs = i, rs = j, qe = bi, re = bj;
-  arec[0] = 1;
-  arec[1] = best;
-  arec[2] = rs;
-  arec[3] = re;
-  arec[4] = qs;
-  arec[5] = qe;
+  u32* const acig = cig_at(A.ws, A.prm, gp);
   // BuildCigar (genotyper.cpp:45-69): S(qs) + core + S(qlen - qe); ops were collected reversed
   u32 ncig = 0, widx = 0;
+  u32 o0 = 0, o1 = 0, o2 = 0, o3 = 0;  // the first four operations: inline in the record
   auto emit = [&](u32 v) {
     if (static_cast<int>(widx) < MCG) acig[1 + widx] = v;
+    o0 = widx == 0 ? v : o0;
+    o1 = widx == 1 ? v : o1;
+    o2 = widx == 2 ? v : o2;
+    o3 = widx == 3 ? v : o3;
     widx++;
     ncig++;
   };
@@ -1163,7 +1157,9 @@ __device__ void align_traceback(GArgs const& A, Fetch fetch, i32 lo, i32 m, i32 
   int const kept = nops > 64 ? 64 : nops;
   for (int x = kept - 1; x >= 0; --x) emit(ops[x]);
   if (qe < m) emit((static_cast<u32>(m - qe) << 4) | 4u);
-  acig[0] = (nops > 64) ? (total_ops + (qs > 0) + (qe < m)) : ncig;
+  u32 const count = (nops > 64) ? (total_ops + (qs > 0) + (qe < m)) : ncig;
+  acig[0] = count;
+  rec_store(rec_at(A.ws, gp), best, rs, re, qs, qe, count, o0, o1, o2, o3);
 }
 
 // one DP pair of a launch: its sequences and its search region
@@ -1202,15 +1198,12 @@ __device__ __forceinline__ DpPair dp_pair_load(GArgs const& A, u32 li) {
 template <class Fetch>
 __device__ __forceinline__ void dp_pair_finish(GArgs const& A, DpPair const& p, Fetch fetch, i32 best, i32 bi, i32 bj) {
   if (!p.live) return;
-  i32* arec = rec_at(A.ws, p.gp);
-  u32* acig = cig_at(A.ws, A.prm, p.gp);
   bool const hit = p.active && bi >= 0 && best >= A.prm.min_aln_score;
   if (!hit) {
-    for (int x = 0; x < 6; ++x) arec[x] = 0;
-    acig[0] = 0;
+    rec_at(A.ws, p.gp)[3] = 0;
     return;
   }
-  align_traceback(A, fetch, p.lo, p.m, best, bi, bj, arec, acig, true);
+  align_traceback(A, fetch, p.lo, p.m, best, bi, bj, p.gp, true);
 }
 __device__ __forceinline__ void dp_pair_store(GArgs const& A, DpPair const& p, const u32* tb, int lane, i32 best, i32 bi,
                                               i32 bj) {
@@ -1281,12 +1274,10 @@ __global__ __launch_bounds__(64) void k_align_wave(GArgs A, u32 nchunk_alloc) {
   const u8* rb = A.b.read_bases + ro;
   i32 const lo = A.ws.centre[lp];
   i32 const wr = static_cast<i32>(A.ws.band_w[lp] & 0xFFFFu);
-  i32* arec = rec_at(A.ws, A.pair0 + lp);
-  u32* acig = cig_at(A.ws, A.prm, A.pair0 + lp);
+  u64 const gp = A.pair0 + lp;
   bool const active = m >= SK && n >= SK && static_cast<u32>(m) + 1 <= A.ws.tb_rows;
   if (!active) {
-    if (lane < 6) arec[lane] = 0;
-    if (lane == 0) acig[0] = 0;
+    if (lane == 0) rec_at(A.ws, gp)[3] = 0;
     return;
   }
   u32 const GW = A.ws.gen_w;
@@ -1408,8 +1399,7 @@ __global__ __launch_bounds__(64) void k_align_wave(GArgs A, u32 nchunk_alloc) {
   if (!settled) run(lo, wr);
   bool const hit = bi >= 0 && best >= A.prm.min_aln_score;
   if (!hit) {
-    if (lane < 6) arec[lane] = 0;
-    if (lane == 0) acig[0] = 0;
+    if (lane == 0) rec_at(A.ws, gp)[3] = 0;
     return;
   }
   // the traceback is a serial walk; every lane follows it (uniform loads), lane 0 writes the record
@@ -1421,7 +1411,7 @@ __global__ __launch_bounds__(64) void k_align_wave(GArgs A, u32 nchunk_alloc) {
         return static_cast<u32>(((q[0] >> sh) & 1ull) | (((q[1] >> sh) & 1ull) << 1) | (((q[2] >> sh) & 1ull) << 2) |
                                 (((q[3] >> sh) & 1ull) << 3));
       },
-      nlo, m, best, bi, bj, arec, acig, lane == 0);
+      nlo, m, best, bi, bj, gp, lane == 0);
 }
 
 // ---- last resort: a region no LDS row holds (more than ~7000 diagonals); one lane per pair, the (H,F) row in HBM ----
@@ -2151,18 +2141,26 @@ __device__ __forceinline__ u64 ev_key_of(u32 var, u32 sample, u32 allele, u32 qn
 __global__ __launch_bounds__(256) void k_tap_records(GArgs A, u64 total_pairs) {
   u64 const gp = static_cast<u64>(blockIdx.x) * 256 + threadIdx.x;
   if (gp >= total_pairs) return;
-  const i32* ar = rec_at(A.ws, gp);
-  if (!ar[0]) return;
+  const u32* r = rec_at(A.ws, gp);
+  uint4 const h = *reinterpret_cast<const uint4*>(r);
+  if (h.w == 0) return;
   PairId const id = pair_decode(A, gp);
   size_t const rec = static_cast<size_t>(id.r) * A.prm.max_haps + id.slot;
-  if (A.o.aln_rec)
-    for (int x = 0; x < 6; ++x) A.o.aln_rec[rec * 6 + x] = ar[x];
+  if (A.o.aln_rec) {
+    i32* out = A.o.aln_rec + rec * 6;
+    out[0] = 1;
+    out[1] = static_cast<i32>(h.x);
+    out[2] = static_cast<i32>(h.y & 0xFFFFu);
+    out[3] = static_cast<i32>(h.y >> 16);
+    out[4] = static_cast<i32>(h.z & 0xFFFFu);
+    out[5] = static_cast<i32>(h.z >> 16);
+  }
   if (A.o.aln_cigar) {
-    const u32* cg = cig_at(A.ws, A.prm, gp);
-    u32 const nops = min(cg[0], static_cast<u32>(A.prm.max_cigar));
+    const u32* ops = h.w <= 4u ? r + 4 : cig_at(A.ws, A.prm, gp) + 1;
+    u32 const nops = min(h.w, static_cast<u32>(A.prm.max_cigar));
     u32* out = A.o.aln_cigar + rec * (1 + A.prm.max_cigar);
-    out[0] = cg[0];
-    for (u32 x = 0; x < nops; ++x) out[1 + x] = cg[1 + x];
+    out[0] = h.w;
+    for (u32 x = 0; x < nops; ++x) out[1 + x] = ops[x];
   }
 }
 
@@ -2214,12 +2212,12 @@ __global__ __launch_bounds__(64) void k_assign(GArgs A) {
       for (u32 h = 0; h < nh; ++h) {  // alignments in haplotype order (all_alns)
         u64 const gp = gp_read + static_cast<u64>(__popc(mask & ((1u << (hap0 + h)) - 1u))) * nrw;
         if (!(mask & (1u << (hap0 + h)))) continue;  // (not aligned: no record)
-        const i32* ar = rec_at(A.ws, gp);
-        if (!ar[0]) continue;
-        const u32* cgp = cig_at(A.ws, A.prm, gp);
-        Cig cg{cgp + 1, min(cgp[0], static_cast<u32>(MCG))};
+        const u32* rp = rec_at(A.ws, gp);
+        uint4 const ah = *reinterpret_cast<const uint4*>(rp);  // score, rs | re << 16, qs | qe << 16, operations
+        if (!ah.w) continue;
+        Cig cg{ah.w <= 4u ? rp + 4 : cig_at(A.ws, A.prm, gp) + 1, min(ah.w, static_cast<u32>(MCG))};
         // the record holds max_cigar operations; the reference scores the whole CIGAR: never silently
-        if (cgp[0] > static_cast<u32>(MCG)) atomicOr(&A.a.win_status[w], static_cast<u32>(MA_W_CIGAR_OVERFLOW));
+        if (ah.w > static_cast<u32>(MCG)) atomicOr(&A.a.win_status[w], static_cast<u32>(MA_W_CIGAR_OVERFLOW));
         // ExtractHapBounds (genotyper.cpp:329-352)
         i32 vstart, vlen;
         u32 allele;
@@ -2234,10 +2232,10 @@ __global__ __launch_bounds__(64) void k_assign(GArgs A) {
           vlen = static_cast<i32>(A.v.alt_len[vi * MA + (al - 1)]);
           allele = al;
         }
-        i32 const rs = ar[2], re = ar[3];
+        i32 const rs = static_cast<i32>(ah.y & 0xFFFFu), re = static_cast<i32>(ah.y >> 16);
         if (!((vstart + vlen) > rs && vstart < re)) continue;  // OverlapsAlignment (:360-362)
         const u8* hap = A.a.hap_bases + (static_cast<size_t>(w) * MH + hap0 + h) * P.max_hap_len;
-        Scored sc = score_at_variant(cg, ar[1], rs, re, rb, rq, rlen, hap, vstart, vlen);
+        Scored sc = score_at_variant(cg, static_cast<i32>(ah.x), rs, re, rb, rq, rlen, hap, vstart, vlen);
         sc.allele = allele;
         if (have_best && sc.combined() <= bestsc.combined()) continue;  // first wins ties
         bestsc = sc;
@@ -2513,10 +2511,10 @@ int launch_genotype(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& a, const m
   u32 const max_read_len = plan_counters[0], n_vote_wg = plan_counters[2];
 
   ctx->stats[0] += total_pairs;
-  // the compact alignment records: 24 + 4 (1 + max_cigar) bytes per planned pair
-  MA_HIP(ctx, ctx->ws_mm.reserve((total_pairs + 64) * (24ull + 4ull * (1 + MCG)) + 512));
+  // the compact alignment records: 32 bytes per planned pair (+ a side slot of 4 (1 + max_cigar) bytes that only DP pairs touch)
+  MA_HIP(ctx, ctx->ws_mm.reserve((total_pairs + 64) * (32ull + 4ull * (1 + MCG)) + 512));
   ws.rec = ctx->ws_mm.as<i32>();
-  ws.cig = reinterpret_cast<u32*>(reinterpret_cast<char*>(ctx->ws_mm.p) + (((total_pairs + 64) * 24ull + 255ull) & ~255ull));
+  ws.cig = reinterpret_cast<u32*>(reinterpret_cast<char*>(ctx->ws_mm.p) + (((total_pairs + 64) * 32ull + 255ull) & ~255ull));
   if (total_pairs > 0) {
     ws.tb_rows = max_read_len + 1;
     // LDS of k_align_wave: two i32 rows of w + 2 cells, the haplotype codes of the region and the read's codes
