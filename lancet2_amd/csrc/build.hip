@@ -933,14 +933,17 @@ __device__ __forceinline__ void insert_window(DBatch const& b, GraphWs const& ws
     return;
   }
   // More distinct k-mers than the map holds (large k: an error spoils k k-mers -- the tail of the k ladder; long reads; 2.5 kb
-  // windows): the ids are split into 2 or 4 CLASSES and the map is filled, and copied out as its own range of table slots,
-  // once per class -- the records are read again, nothing goes through an HBM hash table.  (l_ndef counts the INSTANCES that
-  // found no room -- a few per distinct id: a generous estimate of the classes it takes.)
+  // windows; deep panels: 40 k distinct k-mers): the ids are split into 2 ... 16 CLASSES and the map is filled, and copied out as
+  // its own range of table slots, once per class -- the records are read again (coalesced), nothing goes through an HBM hash
+  // table (a deep window's 200 k slow instances through HBM compare-and-swaps took 22 ms of a workgroup).  l_ndef counts the
+  // INSTANCES that found no room, a few per distinct id: the first guess is a class per ~3700 ids at four instances per id; a
+  // class that still outgrows the map doubles the number of classes.
   {
     u32 const ndef0 = l_ndef;
-    u32 ncls = ndef0 <= 2u * kInsMap ? 2u : (ndef0 <= 8u * kInsMap ? 4u : 0u);
+    u32 ncls = 2;
+    while (ncls < 16u && (kInsMap + ndef0 / 4u) > ncls * (kInsMap * 6u / 10u)) ncls *= 2u;
     bool tried = false;
-    if (ncls && ndef0 && (1u << tcl) >= ncls * kInsMap) {
+    while (ndef0 && ncls <= 16u && (1u << tcl) >= ncls * kInsMap) {
       tried = true;
       __syncthreads();
       if (threadIdx.x == 0) l_ndef = 0;
@@ -954,8 +957,9 @@ __device__ __forceinline__ void insert_window(DBatch const& b, GraphWs const& ws
         if (threadIdx.x == 0) ws.win_nslots[a] = ncls * kInsMap;
         return;
       }
+      ncls *= 2u;
     }
-    if (tried) {  // (a class outgrew the map after all) the general route below continues from the state of ONE pass over everything
+    if (tried) {  // (the classes outgrew the map after all) the general route below continues from the state of ONE pass over everything
       __syncthreads();
       if (threadIdx.x == 0) l_ndef = 0;
       map_pass(1, 0);
