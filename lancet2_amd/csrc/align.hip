@@ -358,7 +358,7 @@ struct HapIdx {
   u32 rwords;
   u32* dpbuf;       // this wave's pending DP pairs: [64] + count at [64] + their keys at [65 .. 129)
   u32 hap_amb;      // the haplotype holds a base that is not A/C/G/T
-  const u16* dup_pre;  // [n + 1] number of repeated (kCodeDup) 11-mers starting before position j
+  const u16* dup_pre;  // [n + 1] sum of (occurrences - 1) of the 11-mers starting before position j (k_vote's set-up)
   const i32* cand;     // hint shortcut: [0] number of candidate shifts (0: off), [1] anchor, [2 ..] shifts
 #ifdef MA_PROFILE
   unsigned long long* prof;  // this wave's phase cycle counters
@@ -492,20 +492,37 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MA_VOTE_WAV
   }
   __syncthreads();
   int const wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  // dup_pre[j] = repeated 11-mers starting before j (for the hint shortcut's vote bound)
+  // dup_pre[j] = sum over the haplotype positions j' < j of (occurrences of the 11-mer at j' in the haplotype - 1): the votes
+  // that matching those positions exactly casts on OTHER diagonals (for the hint shortcuts' vote bounds; a position whose
+  // 11-mer is unique adds nothing).  sh_mmax = the most occurrences of any 11-mer: what a read 11-mer that is NOT the
+  // haplotype's own at its place can vote at most.
   __shared__ u32 sh_dup[4];
+  __shared__ u32 sh_mmax;
   __shared__ i32 sh_cand[12];
+  if (threadIdx.x == 0) sh_mmax = 1;
+  __syncthreads();
+  u32 running = 0;  // (the same in every thread)
   {
-    u32 running = 0;
     for (u32 j0 = 0; j0 <= n; j0 += 256) {
       u32 const j = j0 + threadIdx.x;
-      bool const f = j + SK <= n && code[j] != 0xFFFFFFFFu && (code[j] & kCodeDup);
-      unsigned long long const bal = __ballot(f);
-      if (lane == 0) sh_dup[wave] = static_cast<u32>(__popcll(bal));
+      u32 extra = 0;
+      if (j + SK <= n && code[j] != 0xFFFFFFFFu && (code[j] & kCodeDup)) {
+        u32 const cd = code[j];
+        u32 cnt = 0;
+        for (u32 x = head[((cd & ~kCodeDup) * 2654435761u) >> (32 - 12)]; x != 0xFFFFu && cnt < 255u; x = next[x]) cnt += same_code(code[x], cd);
+        extra = cnt > 0 ? cnt - 1u : 0u;
+        atomicMax(&sh_mmax, cnt);
+      }
+      u32 inc = extra;
+      for (int d = 1; d < 64; d <<= 1) {
+        u32 const y = __shfl_up(inc, d);
+        if (lane >= d) inc += y;
+      }
+      if (lane == 63) sh_dup[wave] = inc;
       __syncthreads();
       u32 before = running;
       for (int x = 0; x < wave; ++x) before += sh_dup[x];
-      if (j <= n) dup_pre[j] = static_cast<u16>(min(before + static_cast<u32>(__popcll(bal & ((1ull << lane) - 1ull))), 65535u));
+      if (j <= n) dup_pre[j] = static_cast<u16>(min(before + inc - extra, 65535u));
       running += sh_dup[0] + sh_dup[1] + sh_dup[2] + sh_dup[3];
       __syncthreads();
     }
@@ -515,7 +532,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MA_VOTE_WAV
   if (threadIdx.x == 0) {
     int nc = 0;
     sh_cand[0] = 0;
-    if (A.b.read_hint && !(A.prm.aln_tier & 2)) {
+    if (A.b.read_hint && !(A.prm.aln_tier & 2) && running < 60000u) {  // (a 16-bit prefix sum that saturated bounds nothing)
       ma_params_t const& P = A.prm;
       for (u32 c = 0; c < A.a.win_ncomp[w]; ++c) {
         size_t const ci = static_cast<size_t>(w) * P.max_comps + c;
@@ -546,6 +563,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MA_VOTE_WAV
     sh_cand[0] = nc;
   }
   __syncthreads();
+#if defined(MA_VOTE_STOP) && MA_VOTE_STOP == 1  // (developer timing build, tools/dbg/vote_phases.sh: the set-up alone; results invalid)
+  return;
+#endif
 #ifdef MA_PROFILE
   __shared__ unsigned long long sh_prof[4][8];
   if (lane < 8) sh_prof[wave][lane] = 0;
@@ -607,17 +627,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MA_VOTE_WAV
         if (b_ != 0) can = false;
       }
       i32 const ncand = ix.cand[0];
+      i32 const mmax = static_cast<i32>(sh_mmax);
       for (int cx = 0; cx < ncand; ++cx) {
         if (__ballot(can && !settled) == 0ull) break;
         i32 const c = hint - ix.cand[1] + ix.cand[2 + cx];
-        bool const inr = can && !settled && !(c < 0 || c + m > n);
+        // the read inside the haplotype on this diagonal -- or overhanging ONE of its ends by o bases (rows [qs, qe) overlap)
+        i32 const o_left = c < 0 ? -c : 0, o_right = c + m > n ? c + m - n : 0;
+        i32 const qs = o_left, qe = m - o_right;
+        bool const inr = can && !settled && o_left == 0 && o_right == 0;
+        bool const ovr = can && !settled && ((o_left == 0) != (o_right == 0)) && qe - qs >= SK && A.prm.max_cigar >= 2;
         u32 mism = 0;
         i32 const i = 32 * static_cast<i32>(x);
-        if (inr && i < m) {
-          i32 const hi = min(m - i, 32);
-          u32 const vmask = hi >= 32 ? 0xFFFFFFFFu : ((1u << hi) - 1u);
-          u32 const hl = plane32(ix.hlo, c + i), hh = plane32(ix.hhi, c + i);
-          mism = __popc(((wl ^ hl) | (wh ^ hh)) & vmask);
+        if ((inr || ovr) && i < m) {
+          i32 const lo = max(qs - i, 0), hi = min(qe - i, 32);  // overlap bits of this word: [lo, hi)
+          if (hi > lo) {
+            u32 const vmask = (hi >= 32 ? 0xFFFFFFFFu : ((1u << hi) - 1u)) & ~((1u << lo) - 1u);
+            i32 const hp = c + i + lo;  // >= 0
+            u32 const hl = plane32(ix.hlo, hp) << lo, hh = plane32(ix.hhi, hp) << lo;
+            mism = __popc(((wl ^ hl) | (wh ^ hh)) & vmask);
+          }
         }
         mism += __shfl_xor(mism, 1);
         mism += __shfl_xor(mism, 2);
@@ -633,10 +661,38 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MA_VOTE_WAV
               A.ws.centre[p - A.pair0] = 0x7FFFFFFE;
             }
           }
+        } else if (ovr && X <= 2) {
+          // Certificate (II) without the seed index (round 5; timing builds put 83 % of this kernel into the wave-wide route and
+          // a quarter of the pairs there only because the read hangs over a haplotype end).  With L0 = qe - qs overlap rows,
+          // X <= 2 mismatches and nothing ambiguous, diagonal c holds >= L0 - 10 - 11 X votes.  Every vote NOT on c comes from
+          // a read 11-mer that (a) lies in the overlap and equals the haplotype's own 11-mer at its place -- it votes elsewhere
+          // once per further occurrence of that 11-mer: D in total, from the prefix sums of (occurrences - 1) -- or (b) overlaps a
+          // mismatch (<= 11 X positions) or the overhang (o positions): at most mmax votes each, mmax = the most occurrences of
+          // any 11-mer of the haplotype.  So V_off <= U = D + (11 X + o + 10) mmax.  If L0 - 10 - 11 X > U, c is the strictly
+          // most-voted diagonal -- the one the wave-wide route would examine -- and an anchor; if moreover 11 S0 > 6 m + 50 + 5 U,
+          // its certificate (II) holds with the true V_off <= U: the same record, without the votes.  Anything else takes the
+          // wave-wide route as before.
+          i32 const L0 = qe - qs, o = o_left + o_right;
+          i32 const D = static_cast<i32>(ix.dup_pre[c + qe - SK + 1]) - static_cast<i32>(ix.dup_pre[c + qs]);
+          i32 const U = D + (11 * X + o + 10) * mmax;
+          i32 const S0 = L0 - 5 * X;
+          if (S0 >= A.prm.min_aln_score && L0 - 10 - 11 * X > U && 11 * S0 > 6 * m + 50 + 5 * U && D < 60000 && mmax < 255) {
+            settled = true;
+            if (x == 0) {
+              u32 const ops_m = static_cast<u32>(L0) << 4;
+              if (qs > 0) rec_store(rec_at(A.ws, p), S0, c + qs, c + qe, qs, qe, 2u, (static_cast<u32>(qs) << 4) | 4u, ops_m, 0u, 0u);
+              else rec_store(rec_at(A.ws, p), S0, c + qs, c + qe, qs, qe, 2u, ops_m, (static_cast<u32>(m - qe) << 4) | 4u, 0u, 0u);
+              A.ws.centre[p - A.pair0] = 0x7FFFFFFE;
+            }
+          }
         }
       }
       // the reads that are left, one after the other on the whole wave
+#if defined(MA_VOTE_STOP) && MA_VOTE_STOP == 2  // (developer timing build: the shortcut trips without the wave-wide route; results invalid)
+      unsigned long long const todo = 0ull;
+#else
       unsigned long long const todo = __ballot(valid && !settled && x == 0);
+#endif
       for (u32 gg = 0; gg < 8; ++gg) {
         if (!((todo >> (8 * gg)) & 1ull)) continue;
         u32 const src = 8 * gg;
