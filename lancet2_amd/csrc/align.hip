@@ -256,8 +256,10 @@ __device__ PairId pair_decode(GArgs const& A, u64 p) {
   return id;
 }
 
-#ifdef MA_PROFILE
+#if defined(MA_PROFILE) || defined(MA_PROFILE_TRIPS)
 __device__ unsigned long long g_vprof[16];
+#endif
+#ifdef MA_PROFILE
 #define VPROF_T0() unsigned long long _t0 = __builtin_amdgcn_s_memtime()
 #define VPROF_ACC(slot)                                                       \
   do {                                                                        \
@@ -396,6 +398,81 @@ __device__ __forceinline__ void vote_flush_dp(GArgs const& A, HapIdx ix, int lan
   if (lane == 0) ix.dpbuf[64] = 0;
   __builtin_amdgcn_wave_barrier();
 }
+// "no alignment": the hit flag of the pair's record is cleared explicitly (every reader tests it before anything else),
+// so the multi-GB internal record arrays need no memset per batch.
+__device__ __forceinline__ void write_no_hit(GArgs const& A, u64 lp) {
+  rec_at(A.ws, A.pair0 + lp)[3] = 0;
+}
+
+// What the votes of one pair come to, decided by ONE lane (vote_pair's lane 0; the first lane of a read's group in k_vote's
+// eight-reads-per-trip vote): the gapless certificates (I) / (II) write the record, (III) writes "no alignment", everything
+// else is prepared for the DP kernels -- the return value is then the pair's (width class, wall) key, for the caller to queue.
+// c = the most-voted diagonal, [vmin, vmax] the extreme anchor diagonals, K the reach, X / amb the mismatches / ambiguous
+// bases of the gapless path on c, v2 the runner-up's votes, v_off the votes not on c.  (The reasoning is with vote_pair.)
+constexpr u32 kVoteFast = 0xFFFFFFFEu, kVoteNoHit = 0xFFFFFFFFu;
+__device__ __forceinline__ u32 vote_settle(GArgs const& A, u64 lp, PairId id, i32 m, i32 n, i32 c, i32 vmin, i32 vmax, i32 K, i32 X, bool amb,
+                                           bool ramb, bool hap_amb, i32 v2, i32 v_off, u32 vfar8, u32 vfar16, u32 vfar24) {
+  i32 const ms = A.prm.min_aln_score;
+  i32 const r_lo = vmin - K;
+  u32 const r_w = static_cast<u32>(vmax - vmin + 2 * K + 1);
+  i32 const o_left = c < 0 ? -c : 0, o_right = c + m > n ? c + m - n : 0;
+  bool const inside = o_left == 0 && o_right == 0;
+  i32 const qs = o_left, qe = m - o_right;  // overlap rows [qs, qe)
+  i32 const S0 = (qe - qs) - 5 * X;
+  bool const certs = !(A.prm.aln_tier & 2);
+  bool const ok_common = certs && !amb && X <= 2 && S0 >= ms && m < (1 << 27);
+  bool const fast_in = inside && ok_common && v2 + 10 + 11 * X < m;
+  bool const fast_ov = !inside && (o_left == 0 || o_right == 0) && ok_common && !ramb && !hap_amb &&
+                       11 * S0 > 6 * m + 50 + 5 * v_off && A.prm.max_cigar >= 2;
+  i32 const L0 = qe - qs, lmax = min(m, L0 + K + (o_left ? vmax - c : c - vmin));
+  bool const nohit = certs && !inside && (o_left == 0 || o_right == 0) && !ramb && !hap_amb && S0 < ms && L0 - 14 < ms &&
+                     6 * lmax + 50 + 5 * v_off < 11 * ms;
+  if (nohit) {
+    A.ws.centre[lp] = 0x7FFFFFFF;  // no alignment
+    write_no_hit(A, lp);
+    return kVoteNoHit;
+  }
+  if (fast_in || fast_ov) {
+    // BuildCigar (genotyper.cpp:45-69): S(qs) + core + S(m - qe); ops: 0 M, 4 S
+    u32 o[3] = {0u, 0u, 0u};
+    u32 nc = 0;
+    u32 const ops_s = (static_cast<u32>(qs) << 4) | 4u, ops_m = static_cast<u32>(qe - qs) << 4, ops_e = (static_cast<u32>(m - qe) << 4) | 4u;
+    if (qs > 0) {
+      o[0] = ops_s;
+      o[1] = ops_m;
+      nc = 2;
+    } else {
+      o[0] = ops_m;
+      nc = 1;
+    }
+    if (qe < m) {
+      if (nc == 1) o[1] = ops_e; else o[2] = ops_e;
+      ++nc;
+    }
+    rec_store(rec_at(A.ws, A.pair0 + lp), S0, c + qs, c + qe, qs, qe, nc, o[0], o[1], o[2], 0u);
+    A.ws.centre[lp] = 0x7FFFFFFE;
+    return kVoteFast;
+  }
+  // width class of the region; can a row of the kernel's window reach column 0 or n (+ the 7 columns the last
+  // segment word carries beyond it)?  k_align_reg picks its row body per wavefront, so the two kinds are kept apart
+  int cls = kNumReg;
+  if (!(A.prm.aln_tier & 1))
+    for (cls = 0; cls < kNumReg && r_w > static_cast<u32>(reg_width(cls)); ++cls) {}
+  if (cls == kNumReg) cls = r_w <= kWaveSmallW ? kClsWaveS : (r_w <= A.ws.wave_big_w ? kClsWaveB : kClsGlobal);
+  i32 const kw = cls < kNumReg ? reg_width(cls) : static_cast<i32>(r_w);
+  u32 const wall = (r_lo >= 0 && r_lo + kw + m + 8 <= n) ? 0u : 1u;
+  u32 const key = static_cast<u32>(cls) * 2u + wall;
+  if (cls == kClsGlobal) atomicMax(&A.ws.dp_count[40], r_w);
+  if (cls == kClsWaveB) atomicMax(&A.ws.dp_count[41], r_w);
+  if (cls >= kNumReg)
+    A.ws.vote_aux[lp] = static_cast<u64>(static_cast<u32>(c - r_lo) & 0xFFFFu) | (static_cast<u64>(min(vfar8, 65535u)) << 16) |
+                        (static_cast<u64>(min(vfar16, 65535u)) << 32) | (static_cast<u64>(min(vfar24, 65535u)) << 48);
+  A.ws.centre[lp] = r_lo;
+  A.ws.band_w[lp] = r_w | (key << 16);
+  A.ws.pair_read[lp] = id.r | (id.slot << 27);
+  return key;
+}
+
 __device__ __forceinline__ void vote_pair(GArgs const& A, u64 lp, PairId id, HapIdx ix, u16* hist, int lane, i32 m, u32 pre, i32 hint, i32 n,
                                           bool shortcut_tried);
 
@@ -410,7 +487,7 @@ __device__ __forceinline__ void vote_pair(GArgs const& A, u64 lp, PairId id, Hap
 #endif
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MA_VOTE_WAVES, 8))) void k_vote(GArgs A, u32 hist_len, u32 rwords, u32 ml_eff) {
   extern __shared__ u32 lds_vote[];
-#ifdef MA_PROFILE
+#if defined(MA_PROFILE) || defined(MA_PROFILE_TRIPS)
   unsigned long long const k_tstart = __builtin_amdgcn_s_memtime();
 #endif
   u32 const item = A.ws.vote_wg[blockIdx.x];
@@ -434,14 +511,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MA_VOTE_WAV
   u32* rplanes_all = hbad + pw;                            // [4 waves][3][rwords]
   u32* dpbuf_all = rplanes_all + 12 * rwords;              // [4 waves][129]
   u16* dup_pre = reinterpret_cast<u16*>(dpbuf_all + 4 * 129);  // [ML + 2]
-  u32* l_roff = reinterpret_cast<u32*>(dup_pre + ((ML + 4) & ~1u));  // [nr + 1] read byte offsets relative to the window's first read
+  u16* l_rlen = dup_pre + ((ML + 4) & ~1u);  // [nr] read lengths (<= kMaxGenoRead)
+  // [4 waves][left_cap] the reads a wave's eight-reads-per-trip pass leaves to the wave-wide route (bit 15: hint shortcut tried)
+  u32 const left_cap = (nr + 3u) / 4u + 10u;
+  u16* l_left_all = l_rlen + ((nr + 3u) & ~1u);
   size_t const hi = static_cast<size_t>(w) * A.prm.max_haps + slot;
   u32 const n = A.a.hap_len[hi];
   const u8* hb = A.a.hap_bases + hi * A.prm.max_hap_len;
   for (u32 x = threadIdx.x; x < kIdxCap / 2; x += 256) reinterpret_cast<u32*>(head)[x] = 0xFFFFFFFFu;
   for (u32 x = threadIdx.x; x < 4 * hist_len / 2; x += 256) reinterpret_cast<u32*>(hist_all)[x] = 0;
-  u64 const roff0 = A.b.read_off[r0];
-  for (u32 x = threadIdx.x; x <= nr; x += 256) l_roff[x] = static_cast<u32>(A.b.read_off[r0 + x] - roff0);
+  for (u32 x = threadIdx.x; x < nr; x += 256) l_rlen[x] = static_cast<u16>(A.b.read_off[r0 + x + 1] - A.b.read_off[r0 + x]);
   if (threadIdx.x < 4) dpbuf_all[threadIdx.x * 129 + 64] = 0;
   // haplotype bases -> three bit planes (one coalesced byte load per base, wave ballots)
   for (u32 j0 = 0; j0 < pw * 32; j0 += 256) {
@@ -583,10 +662,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MA_VOTE_WAV
   HapIdx const ix{head, next, code, hlo, hhi, hbad, rplanes_all + static_cast<size_t>(wave) * 3 * rwords, rwords,
                   dpbuf_all + wave * 129, hap_amb, dup_pre, sh_cand};
 #endif
+#ifdef MA_PROFILE_TRIPS  // (developer build: where a trip of eight reads spends its time -- [0] candidates [1] group vote [2] wave-wide route)
+  unsigned long long const k_t0 = __builtin_amdgcn_s_memtime();
+  if (threadIdx.x == 0) atomicAdd(&g_vprof[15], k_t0 - k_tstart);
+  unsigned long long tp0 = 0, tp1 = 0, tp2 = 0, tp3 = 0, tp4 = 0, tq0 = 0, tq1 = 0, tq2 = 0, tq3 = 0;
+#define TRIP_STAMP(v) unsigned long long const v = __builtin_amdgcn_s_memtime()
+#else
+#define TRIP_STAMP(v) do {} while (0)
+#endif
   u16* hist = hist_all + static_cast<size_t>(wave) * hist_len;
   u32 const npw = 3u * rwords;
   bool const hinted = A.b.read_hint != nullptr;
-  if (rwords <= 8 && ix.cand[0] > 0 && !ix.hap_amb && hinted && nr > 0) {
+  u16* l_left = l_left_all + static_cast<size_t>(wave) * left_cap;
+  u32 nleft = 0;  // (wave-uniform)
+  bool const grouped = rwords <= 8 && ix.cand[0] > 0 && !ix.hap_amb && hinted && nr > 0 && nr < 32768u;
+  if (grouped) {
     // EIGHT reads per trip: the hint shortcut needs a lane per 32 bases -- five lanes of the wave for a 150-base read -- and
     // two reads in three end there.  Lane 8 g + x holds word x of read g's three planes (reads of up to 256 bases); the
     // candidate diagonals of all eight reads are tried side by side with 8-lane reductions, every group's first lane
@@ -614,20 +704,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MA_VOTE_WAV
       fetch_words(group_read(q0 + 8), &nwl, &nwh, &nwb, &nhn);  // (the next eight reads' words: in flight under this trip)
       u64 const p = p0 + ri;
       bool const valid = ri < nr && p >= A.pair0 && p < A.pair0 + A.npairs;
-      i32 const m = valid ? static_cast<i32>(l_roff[ri + 1] - l_roff[ri]) : 0;
+      i32 const m = valid ? static_cast<i32>(l_rlen[ri]) : 0;
       bool can = valid && m >= SK && m <= 256 && hint != MA_NO_HINT;  // (longer reads: the wave-wide route tries the shortcut itself)
       bool const tried = can;
       bool settled = false;
-      u32 const wbad_any = wb;
+      bool read_n;
       {  // an N in the read: general route (the per-read code leaves its candidate loop at the first in-range candidate)
-        u32 b_ = wbad_any;
+        u32 b_ = wb;
         b_ |= __shfl_xor(b_, 1);
         b_ |= __shfl_xor(b_, 2);
         b_ |= __shfl_xor(b_, 4);
-        if (b_ != 0) can = false;
+        read_n = b_ != 0;
+        if (read_n) can = false;
       }
       i32 const ncand = ix.cand[0];
       i32 const mmax = static_cast<i32>(sh_mmax);
+      TRIP_STAMP(ts0);
       for (int cx = 0; cx < ncand; ++cx) {
         if (__ballot(can && !settled) == 0ull) break;
         i32 const c = hint - ix.cand[1] + ix.cand[2 + cx];
@@ -687,74 +779,271 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MA_VOTE_WAV
           }
         }
       }
-      // the reads that are left, one after the other on the whole wave
+      TRIP_STAMP(ts1);
+      TRIP_STAMP(ts2);
+      // the reads that are left go on this wave's list: the wave-wide route runs in a loop of its own below (inlined into this
+      // loop it shared the trip's registers: the prefetched words were reloaded from scratch behind a vmcnt(0) every trip)
 #if defined(MA_VOTE_STOP) && MA_VOTE_STOP == 2  // (developer timing build: the shortcut trips without the wave-wide route; results invalid)
       unsigned long long const todo = 0ull;
 #else
       unsigned long long const todo = __ballot(valid && !settled && x == 0);
 #endif
-      for (u32 gg = 0; gg < 8; ++gg) {
-        if (!((todo >> (8 * gg)) & 1ull)) continue;
-        u32 const src = 8 * gg;
-        u32 const ri_g = static_cast<u32>(__shfl(static_cast<int>(ri), static_cast<int>(src)));
-        i32 const m_g = __shfl(m, static_cast<int>(src));
-        i32 const h_g = __shfl(hint, static_cast<int>(src));
-        bool const tried_g = __shfl(static_cast<int>(tried), static_cast<int>(src)) != 0;
-        // lane l < 3 rwords wants word l % rwords of plane l / rwords: it sits in lane 8 gg + l % rwords
-        u32 const pln = static_cast<u32>(lane) / rwords, wx = static_cast<u32>(lane) % rwords;
-        int const from = static_cast<int>(src + wx);
-        u32 const s0 = __shfl(wl, from), s1 = __shfl(wh, from), s2 = __shfl(wb, from);
-        u32 const pre = static_cast<u32>(lane) < npw ? (pln == 0 ? s0 : (pln == 1 ? s1 : s2)) : 0u;
-        vote_pair(A, p0 + ri_g - A.pair0, PairId{w, r0 + ri_g, static_cast<u32>(slot)}, ix, hist, lane, m_g, pre, h_g, static_cast<i32>(n),
-                  tried_g);
-      }
+      if ((todo >> lane) & 1ull)
+        l_left[nleft + static_cast<u32>(__popcll(todo & ((1ull << lane) - 1ull)))] = static_cast<u16>(ri | (tried ? 0x8000u : 0u));
+      nleft += static_cast<u32>(__popcll(todo));
+#ifdef MA_PROFILE_TRIPS
+      tp0 += ts2 - ts0;
+      tp3 += 1;
+#endif
     }
-  } else {
-    // software pipeline: the next read's plane words (lane l < 3 rwords holds word l) are in flight while the current
-    // read is voted
+    __builtin_amdgcn_wave_barrier();
+  }
+#ifndef MA_NO_GROUP_VOTE
+  if (grouped && nleft > 0 && static_cast<i32>(n) >= SK) {
+    // ---- the UNANIMOUS vote, eight listed reads side by side (round 5) ---------------------------------------------------
+    // What is listed -- reads without a usable hint, with more than two mismatches, with an indel, or hanging far over a
+    // haplotype end: 28 % of the pairs -- took the wave-wide route one after the other, 83 % of this kernel's time.  Nine in
+    // ten of those votes are unanimous: every 11-mer that is found lies on ONE diagonal and none of them is a repeat.  That
+    // case needs no histogram.  Lane 8 g + x holds word x of listed read g's planes again; the group's eight lanes look up
+    // CONTIGUOUS runs of their read's positions (one 64-bit window per plane and lane, two shuffles each -- the kernel is
+    // bound by the CU's LDS pipe, every one of its 20 waves gathering from the seed index: LDS instructions are what a trip
+    // costs), eight positions at a time: their bucket heads, then their first entries, are independent accesses in flight,
+    // and the longer bucket chains of all eight advance together.  The group keeps the count and the extreme diagonals; when
+    // the vote is unanimous (or empty) its first lane settles the pair exactly as vote_pair's unanimous branch does: best =
+    // the count, no runner-up, no vote off c, anchors = {c} iff the count reaches kMinChainVotes.  A repeat, a second
+    // diagonal or an N keeps the read on the list for the wave-wide route.  (Run inside the trips above, on the two or
+    // three unsettled reads of each trip with the other groups' lanes idle, this vote cost as much as the route it replaces.)
+    u32 const g = static_cast<u32>(lane) >> 3, x = static_cast<u32>(lane) & 7u;
+    int const gl = lane & ~7;
+    u32 const nA = nleft;
+    u32 nB = 0;
+    auto fetch_item = [&](u32 q, u32* wl, u32* wh, u32* wb, u32* it) {
+      u32 const idx = q + g;
+      bool const ok = idx < nA;
+      u32 const e = ok ? l_left[idx] : 0u;
+      const u32* pl = A.ws.read_planes + static_cast<size_t>(r0 + (e & 0x7FFFu)) * plane_stride(rwords);
+      u32 const xx = min(x, rwords - 1);
+      u32 const a0 = pl[xx], a1 = pl[rwords + xx], a2 = pl[2 * rwords + xx];
+      bool const okw = ok && x < rwords;
+      *wl = okw ? a0 : 0u;
+      *wh = okw ? a1 : 0u;
+      *wb = okw ? a2 : 0u;
+      *it = ok ? (e | 0x10000u) : 0u;
+    };
+    u32 nwl, nwh, nwb, nit;
+    fetch_item(0, &nwl, &nwh, &nwb, &nit);
+    for (u32 q = 0; q < nA; q += 8) {
+      TRIP_STAMP(tg0);
+      u32 const wl = nwl, wh = nwh, it = nit;
+      u32 bad = nwb;
+      fetch_item(q + 8, &nwl, &nwh, &nwb, &nit);  // (the next eight listed reads: in flight under this trip)
+      bad |= __shfl_xor(bad, 1);
+      bad |= __shfl_xor(bad, 2);
+      bad |= __shfl_xor(bad, 4);
+      bool const valid = (it & 0x10000u) != 0u;
+      u32 const ri = it & 0x7FFFu;
+      u64 const p = p0 + ri;
+      i32 const m = valid ? static_cast<i32>(l_rlen[ri]) : 0;
+      bool const gv = valid && bad == 0u && m >= SK;  // (m <= 32 (rwords - 2) <= 192 here)
+      // this lane's run of positions: [s, s + pr) of the read's np = m - 10
+      i32 const np = m - SK + 1;
+      i32 const pr = gv ? (np + 7) / 8 : 0;
+      i32 const s = static_cast<i32>(x) * pr;
+      u32 const off = static_cast<u32>(s) & 31u;
+      int const k = gl + (s >> 5);  // (s <= 7 * 23: the window's two words sit in lanes gl + k, gl + k + 1 <= gl + 6)
+      u64 const lo64 = static_cast<u64>(static_cast<u32>(__shfl(static_cast<int>(wl), k))) | (static_cast<u64>(static_cast<u32>(__shfl(static_cast<int>(wl), k + 1))) << 32);
+      u64 const hi64 = static_cast<u64>(static_cast<u32>(__shfl(static_cast<int>(wh), k))) | (static_cast<u64>(static_cast<u32>(__shfl(static_cast<int>(wh), k + 1))) << 32);
+      u32 cnt = 0;
+      i32 dmin = 0x7FFFFFFF, dmax = -0x7FFFFFFF;
+      u32 multi = 0;
+      for (i32 t0 = 0; t0 < 24; t0 += 8) {
+        if (__ballot(t0 < pr && s + t0 < np) == 0ull) break;
+        u32 cdv[8], jv[8], ev[8];
+        u32 pend = 0;
+#pragma unroll
+        for (int tt = 0; tt < 8; ++tt) {
+          i32 const t = t0 + tt;
+          u32 const sh = off + static_cast<u32>(t);  // <= 31 + 22: eleven more bits stay inside the window
+          cdv[tt] = (static_cast<u32>(lo64 >> sh) & 0x7FFu) | ((static_cast<u32>(hi64 >> sh) & 0x7FFu) << 11);
+          jv[tt] = (t < pr && s + t < np) ? head[(cdv[tt] * 2654435761u) >> (32 - 12)] : 0xFFFFu;
+        }
+#pragma unroll
+        for (int tt = 0; tt < 8; ++tt) ev[tt] = jv[tt] != 0xFFFFu ? code[jv[tt]] : 0u;
+#pragma unroll
+        for (int tt = 0; tt < 8; ++tt)
+          if (jv[tt] != 0xFFFFu && !same_code(ev[tt], cdv[tt])) pend |= 1u << tt;
+        while (pend != 0) {  // (buckets shared with other 11-mers)
+#pragma unroll
+          for (int tt = 0; tt < 8; ++tt)
+            if (pend & (1u << tt)) jv[tt] = next[jv[tt]];
+#pragma unroll
+          for (int tt = 0; tt < 8; ++tt)
+            if ((pend & (1u << tt)) && jv[tt] != 0xFFFFu) ev[tt] = code[jv[tt]];
+#pragma unroll
+          for (int tt = 0; tt < 8; ++tt)
+            if ((pend & (1u << tt)) && (jv[tt] == 0xFFFFu || same_code(ev[tt], cdv[tt]))) pend &= ~(1u << tt);
+        }
+#pragma unroll
+        for (int tt = 0; tt < 8; ++tt) {
+          if (jv[tt] != 0xFFFFu) {
+            i32 const d = static_cast<i32>(jv[tt]) - (s + t0 + tt);
+            ++cnt;
+            dmin = min(dmin, d);
+            dmax = max(dmax, d);
+            multi |= ev[tt] & kCodeDup;
+          }
+        }
+      }
+      TRIP_STAMP(tgA);
+#pragma unroll
+      for (int o = 1; o < 8; o <<= 1) {
+        cnt += __shfl_xor(cnt, o);
+        dmin = min(dmin, __shfl_xor(dmin, o));
+        dmax = max(dmax, __shfl_xor(dmax, o));
+        multi |= __shfl_xor(multi, o);
+      }
+      bool const unan = gv && multi == 0 && (cnt == 0 || dmin == dmax);
+      bool const anchored = unan && cnt >= kMinChainVotes;
+      // mismatches of the gapless path on c = dmin (vote_pair's rule: only when the read is inside or overhangs ONE end)
+      i32 const c = anchored ? dmin : 0;
+      i32 const o_left = c < 0 ? -c : 0, o_right = c + m > static_cast<i32>(n) ? c + m - static_cast<i32>(n) : 0;
+      i32 const qs = o_left, qe = m - o_right;
+      u32 mism = 0;
+      {
+        i32 const i = 32 * static_cast<i32>(x);
+        if (anchored && (o_left == 0 || o_right == 0) && i < m) {
+          i32 const lo = max(qs - i, 0), hi = min(qe - i, 32);  // overlap bits of this word: [lo, hi)
+          if (hi > lo) {
+            u32 const vmask = (hi >= 32 ? 0xFFFFFFFFu : ((1u << hi) - 1u)) & ~((1u << lo) - 1u);
+            i32 const hp = c + i + lo;  // >= 0
+            u32 const hl = plane32(ix.hlo, hp) << lo, hh = plane32(ix.hhi, hp) << lo;
+            mism = __popc(((wl ^ hl) | (wh ^ hh)) & vmask);
+          }
+        }
+      }
+      mism += __shfl_xor(mism, 1);
+      mism += __shfl_xor(mism, 2);
+      mism += __shfl_xor(mism, 4);
+      TRIP_STAMP(tgB);
+      u32 act = kVoteNoHit;
+      if (unan && x == 0) {
+        u64 const lp = p - A.pair0;
+        if (!anchored) {  // no shared 11-mer, or fewer than a chain needs: no hit
+          A.ws.centre[lp] = 0x7FFFFFFF;
+          write_no_hit(A, lp);
+        } else {
+          i32 const K = m - A.prm.min_aln_score - GO > 0 ? (m - A.prm.min_aln_score - GO) / GE : 0;
+          act = vote_settle(A, lp, PairId{w, r0 + ri, static_cast<u32>(slot)}, m, static_cast<i32>(n), c, c, c, K, static_cast<i32>(mism), false,
+                            false, false, 0, 0, 0u, 0u, 0u);
+        }
+      }
+      TRIP_STAMP(tgC);
+      // the DP pairs of this trip (at most eight) into the wave's buffer: it holds < 64 on entry
+      unsigned long long const dpm = __ballot(act < kVoteFast);
+      if (dpm != 0ull) {
+        u32 const ndp = static_cast<u32>(__popcll(dpm));
+        if (ix.dpbuf[64] + ndp > 64u) vote_flush_dp(A, ix, lane);
+        u32 const base = ix.dpbuf[64];
+        __builtin_amdgcn_wave_barrier();
+        if (act < kVoteFast) {
+          u32 const at = base + static_cast<u32>(__popcll(dpm & ((1ull << lane) - 1ull)));
+          ix.dpbuf[at] = static_cast<u32>(p - A.pair0);
+          ix.dpbuf[65 + at] = act;
+        }
+        if (lane == 0) ix.dpbuf[64] = base + ndp;
+        __builtin_amdgcn_wave_barrier();
+        if (ix.dpbuf[64] == 64u) vote_flush_dp(A, ix, lane);
+      }
+      // what stays listed (compacted in place: nB <= q, and the entries up to q + 15 have been read)
+      unsigned long long const stay = __ballot(valid && !unan && x == 0);
+      if ((stay >> lane) & 1ull) l_left[nB + static_cast<u32>(__popcll(stay & ((1ull << lane) - 1ull)))] = static_cast<u16>(it & 0xFFFFu);
+      nB += static_cast<u32>(__popcll(stay));
+#ifdef MA_PROFILE_TRIPS
+      TRIP_STAMP(tgD);
+      tp1 += tgD - tg0;
+      tq0 += tgA - tg0;
+      tq1 += tgB - tgA;
+      tq2 += tgC - tgB;
+      tq3 += tgD - tgC;
+      tp4 += 1;
+#endif
+    }
+    __builtin_amdgcn_wave_barrier();
+    nleft = nB;
+  }
+#endif
+#if defined(MA_VOTE_STOP) && MA_VOTE_STOP == 3  // (developer timing build: no wave-wide route after the group vote; results invalid)
+  nleft = 0;
+#endif
+  {
+    // ---- the wave-wide route: the listed reads (or, without the trips, all of this wave's reads), one after the other ----
+    // software pipeline: the next reads' plane words (lane l < 3 rwords holds word l) and mapping hints are in flight while
+    // the current read is voted -- kPF reads ahead
+    TRIP_STAMP(tw0);
+    u32 const nloop = grouped ? nleft : (nr > static_cast<u32>(wave) ? (nr - static_cast<u32>(wave) + 3u) / 4u : 0u);
+    auto item = [&](u32 idx) -> u32 {  // read index, bit 31: the hint shortcut was tried
+      if (!grouped) return static_cast<u32>(wave) + 4u * idx;
+      u32 const e = l_left[idx];
+      return (e & 0x7FFFu) | ((e >> 15) << 31);
+    };
     auto fetch = [&](u32 ri) -> u32 {
       return static_cast<u32>(lane) < npw ? A.ws.read_planes[static_cast<size_t>(r0 + ri) * plane_stride(rwords) + lane] : 0u;
     };
-    // (and its mapping hint: a load per pair that the shortcut would otherwise wait for first thing)
-    // kPF reads ahead: a pair that takes the shortcut is done in well under one memory latency
     constexpr u32 kPF = MA_VOTE_PF;
-    u32 pf[kPF];
+    u32 pf[kPF], it[kPF];
     i32 hf[kPF];
 #pragma unroll
     for (u32 x = 0; x < kPF; ++x) {
-      u32 const ri = wave + 4u * x;
-      pf[x] = ri < nr ? fetch(ri) : 0u;
-      hf[x] = (hinted && ri < nr) ? A.b.read_hint[r0 + ri] : MA_NO_HINT;
+      it[x] = x < nloop ? item(x) : 0u;
+      u32 const ri = it[x] & 0x7FFFFFFFu;
+      pf[x] = x < nloop ? fetch(ri) : 0u;
+      hf[x] = (hinted && x < nloop) ? A.b.read_hint[r0 + ri] : MA_NO_HINT;
     }
-    for (u32 ri = wave; ri < nr; ri += 4) {
-      u32 const ra = ri + 4u * kPF;
-      u32 const pn = ra < nr ? fetch(ra) : 0u;
-      i32 const hn = (hinted && ra < nr) ? A.b.read_hint[r0 + ra] : MA_NO_HINT;
+    for (u32 idx = 0; idx < nloop; ++idx) {
+      u32 const ia = idx + kPF;
+      u32 const itn = ia < nloop ? item(ia) : 0u;
+      u32 const pn = ia < nloop ? fetch(itn & 0x7FFFFFFFu) : 0u;
+      i32 const hn = (hinted && ia < nloop) ? A.b.read_hint[r0 + (itn & 0x7FFFFFFFu)] : MA_NO_HINT;
+      u32 const ri = it[0] & 0x7FFFFFFFu;
       u64 const p = p0 + ri;
       if (p >= A.pair0 && p < A.pair0 + A.npairs)
         vote_pair(A, p - A.pair0, PairId{w, r0 + ri, static_cast<u32>(slot)}, ix, hist, lane,
-                  static_cast<i32>(l_roff[ri + 1] - l_roff[ri]), pf[0], hf[0], static_cast<i32>(n), false);
+                  static_cast<i32>(l_rlen[ri]), pf[0], hf[0], static_cast<i32>(n), (it[0] >> 31) != 0u);
 #pragma unroll
       for (u32 x = 0; x + 1 < kPF; ++x) {
         pf[x] = pf[x + 1];
         hf[x] = hf[x + 1];
+        it[x] = it[x + 1];
       }
       pf[kPF - 1] = pn;
       hf[kPF - 1] = hn;
+      it[kPF - 1] = itn;
     }
+#ifdef MA_PROFILE_TRIPS
+    TRIP_STAMP(tw1);
+    tp2 += tw1 - tw0;
+#endif
   }
   vote_flush_dp(A, ix, lane);
+#ifdef MA_PROFILE_TRIPS
+  if (lane == 0) {
+    atomicAdd(&g_vprof[0], tp0);
+    atomicAdd(&g_vprof[1], tp1);
+    atomicAdd(&g_vprof[2], tp2);
+    atomicAdd(&g_vprof[7], tp3);
+    atomicAdd(&g_vprof[8], tp4);
+    atomicAdd(&g_vprof[3], tq0);
+    atomicAdd(&g_vprof[4], tq1);
+    atomicAdd(&g_vprof[5], tq2);
+    atomicAdd(&g_vprof[6], tq3);
+    atomicAdd(&g_vprof[14], __builtin_amdgcn_s_memtime() - k_t0);
+  }
+#endif
 #ifdef MA_PROFILE
   __builtin_amdgcn_wave_barrier();
   if (lane < 8) atomicAdd(&g_vprof[lane], sh_prof[wave][lane]);
   if (lane == 0) atomicAdd(&g_vprof[14], __builtin_amdgcn_s_memtime() - k_t0);
 #endif
-}
-
-// "no alignment": the hit flag of the pair's record is cleared explicitly (every reader tests it before anything else),
-// so the multi-GB internal record arrays need no memset per batch.
-__device__ __forceinline__ void write_no_hit(GArgs const& A, u64 lp) {
-  rec_at(A.ws, A.pair0 + lp)[3] = 0;
 }
 
 __device__ __forceinline__ void vote_pair(GArgs const& A, u64 lp, PairId id, HapIdx ix, u16* hist, int lane, i32 m, u32 pre, i32 hint, i32 n,
@@ -989,11 +1278,9 @@ __device__ __forceinline__ void vote_pair(GArgs const& A, u64 lp, PairId id, Hap
   // ---- search region (oracle/align.cpp rule 3) ---------------------------------
   // cost(P) = m - score(P): every read row costs >= 0 and a gap shifting the diagonal by s costs >= 12 + 3 s, so a hit
   // (score >= min_aln_score) through a seed on diagonal d stays within [d - K, d + K]: R = [vmin - K, vmax + K].
-  i32 const ms = A.prm.min_aln_score;
+  [[maybe_unused]] i32 const ms = A.prm.min_aln_score;
   i32 const K = Kr;
   i32 const vmin = dlo - m, vmax = dhi - m;
-  i32 const r_lo = vmin - K;
-  u32 const r_w = static_cast<u32>(vmax - vmin + 2 * K + 1);
   // ---- gapless certificates ------------------------------------------------------------------------
   // P0 = the gapless path on the most-voted diagonal c (read rows [qs, qe) against haplotype columns [rs, re)),
   // X its mismatches, S0 = (qe - qs) - 5 X.  Scores: match +1, mismatch -4, a gap of length L costs 12 + 3 L.
@@ -1027,7 +1314,7 @@ __device__ __forceinline__ void vote_pair(GArgs const& A, u64 lp, PairId id, Hap
   // In cases (I)/(II) (score, rs, re, qs, qe, CIGAR) is written without running the DP, in case (III) the
   // record stays "no alignment"; everything else goes to the DP kernels.
   i32 const o_left = c < 0 ? -c : 0, o_right = c + m > n ? c + m - n : 0;
-  bool const inside = o_left == 0 && o_right == 0;
+  [[maybe_unused]] bool const inside = o_left == 0 && o_right == 0;
   i32 const qs = o_left, qe = m - o_right;  // overlap rows [qs, qe)
   u32 mism = 0, amb = 0, ramb = 0;
   if (qe - qs > 0 && (o_left == 0 || o_right == 0)) {
@@ -1055,61 +1342,14 @@ __device__ __forceinline__ void vote_pair(GArgs const& A, u64 lp, PairId id, Hap
   }
   VPROF_ACC(5);
   i32 const X = static_cast<i32>(mism);
-  i32 const S0 = (qe - qs) - 5 * X;
   i32 const v_off = static_cast<i32>(vtot) - static_cast<i32>(best);
-  bool const certs = !(A.prm.aln_tier & 2);
-  bool const ok_common = certs && !amb && X <= 2 && S0 >= ms && m < (1 << 27);
-  bool const fast_in = inside && ok_common && static_cast<i32>(v2) + 10 + 11 * X < m;
-  bool const fast_ov = !inside && (o_left == 0 || o_right == 0) && ok_common && !ramb && !ix.hap_amb &&
-                       11 * S0 > 6 * m + 50 + 5 * v_off && A.prm.max_cigar >= 2;
-  bool const fast = fast_in || fast_ov;
-  i32 const L0 = qe - qs, lmax = min(m, L0 + K + (o_left ? vmax - c : c - vmin));
-  bool const nohit = certs && !inside && (o_left == 0 || o_right == 0) && !ramb && !ix.hap_amb && S0 < ms && L0 - 14 < ms &&
-                     6 * lmax + 50 + 5 * v_off < 11 * ms;
+  u32 act = kVoteNoHit;
   if (lane == 0) {
-    if (nohit) {
-      A.ws.centre[lp] = 0x7FFFFFFF;  // no alignment
-      write_no_hit(A, lp);
-    } else if (fast) {
-      // BuildCigar (genotyper.cpp:45-69): S(qs) + core + S(m - qe); ops: 0 M, 4 S
-      u32 o[3] = {0u, 0u, 0u};
-      u32 nc = 0;
-      u32 const ops_s = (static_cast<u32>(qs) << 4) | 4u, ops_m = static_cast<u32>(qe - qs) << 4, ops_e = (static_cast<u32>(m - qe) << 4) | 4u;
-      if (qs > 0) {
-        o[0] = ops_s;
-        o[1] = ops_m;
-        nc = 2;
-      } else {
-        o[0] = ops_m;
-        nc = 1;
-      }
-      if (qe < m) {
-        if (nc == 1) o[1] = ops_e; else o[2] = ops_e;
-        ++nc;
-      }
-      rec_store(rec_at(A.ws, A.pair0 + lp), S0, c + qs, c + qe, qs, qe, nc, o[0], o[1], o[2], 0u);
-      A.ws.centre[lp] = 0x7FFFFFFE;
-    } else {
-      // width class of the region; can a row of the kernel's window reach column 0 or n (+ the 7 columns the last
-      // segment word carries beyond it)?  k_align_reg picks its row body per wavefront, so the two kinds are kept apart
-      int cls = kNumReg;
-      if (!(A.prm.aln_tier & 1))
-        for (cls = 0; cls < kNumReg && r_w > static_cast<u32>(reg_width(cls)); ++cls) {}
-      if (cls == kNumReg) cls = r_w <= kWaveSmallW ? kClsWaveS : (r_w <= A.ws.wave_big_w ? kClsWaveB : kClsGlobal);
-      i32 const kw = cls < kNumReg ? reg_width(cls) : static_cast<i32>(r_w);
-      u32 const wall = (r_lo >= 0 && r_lo + kw + m + 8 <= n) ? 0u : 1u;
-      u32 const key = static_cast<u32>(cls) * 2u + wall;
-      if (cls == kClsGlobal) atomicMax(&A.ws.dp_count[40], r_w);
-      if (cls == kClsWaveB) atomicMax(&A.ws.dp_count[41], r_w);
-      if (cls >= kNumReg)
-        A.ws.vote_aux[lp] = static_cast<u64>(static_cast<u32>(c - r_lo) & 0xFFFFu) | (static_cast<u64>(min(vfar8, 65535u)) << 16) |
-                            (static_cast<u64>(min(vfar16, 65535u)) << 32) | (static_cast<u64>(min(vfar24, 65535u)) << 48);
-      A.ws.centre[lp] = r_lo;
-      A.ws.band_w[lp] = r_w | (key << 16);
-      A.ws.pair_read[lp] = id.r | (id.slot << 27);
+    act = vote_settle(A, lp, id, m, n, c, vmin, vmax, K, X, amb != 0, ramb != 0, ix.hap_amb != 0, static_cast<i32>(v2), v_off, vfar8, vfar16, vfar24);
+    if (act < kVoteFast) {  // a DP pair: act is its (width class, wall) key
       u32 const at = ix.dpbuf[64]++;
       ix.dpbuf[at] = static_cast<u32>(lp);
-      ix.dpbuf[65 + at] = key;
+      ix.dpbuf[65 + at] = act;
     }
   }
   __builtin_amdgcn_wave_barrier();
@@ -1119,18 +1359,19 @@ __device__ __forceinline__ void vote_pair(GArgs const& A, u64 lp, PairId id, Hap
   if (lane == 0) {
     ix.prof[7] += 1;
     // (developer census: what keeps pairs on the general route)
-    if (!fast && !nohit) {
-      if (inside && certs && !amb && X >= 3 && X <= 5 && S0 >= ms) atomicAdd(&g_vprof[11], 1ull);
-      else if (inside && certs && !amb && X <= 2) atomicAdd(&g_vprof[12], 1ull);   // vote bound failed
+    if (act < kVoteFast) {
+      i32 const S0 = (qe - qs) - 5 * X;
+      if (inside && !amb && X >= 3 && X <= 5 && S0 >= ms) atomicAdd(&g_vprof[11], 1ull);
+      else if (inside && !amb && X <= 2) atomicAdd(&g_vprof[12], 1ull);   // vote bound failed
       else atomicAdd(&g_vprof[13], 1ull);
     }
-    if (fast) atomicAdd(&g_vprof[10], 1ull);
-    if (nohit) atomicAdd(&g_vprof[9], 1ull);
+    if (act == kVoteFast) atomicAdd(&g_vprof[10], 1ull);
+    if (act == kVoteNoHit) atomicAdd(&g_vprof[9], 1ull);
   }
 #endif
 }
 
-#ifdef MA_PROFILE
+#if defined(MA_PROFILE) || defined(MA_PROFILE_TRIPS)
 }  // namespace
 }  // namespace ma
 extern "C" void ma_debug_vprof(unsigned long long* out, int reset) {
@@ -2602,7 +2843,9 @@ int launch_genotype(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& a, const m
     u32 const pw_host = (ml_eff + 31) / 32 + 2;
     u32 const rwords = rwords_all;  // == (max_read_len + 31) / 32 + 2
     size_t const lds_vote = 4ull * ml_eff + 2ull * kIdxCap + 2ull * ((ml_eff + 1) & ~1) + 8ull * hist_len +
-                            12ull * pw_host + 48ull * rwords + 4ull * 4 * 129 + 2ull * (ml_eff + 6) + 4ull * (plan_counters[1] + 2) + 64;
+                            12ull * pw_host + 48ull * rwords + 4ull * 4 * 129 + 2ull * (ml_eff + 6) + 2ull * (plan_counters[1] + 4) +
+                            8ull * ((plan_counters[1] + 3) / 4 + 10) + 64;
+    if (getenv("MA_VOTE_DEBUG")) fprintf(stderr, "k_vote: %zu B of LDS (ml_eff %u, max reads %u, hist_len %u, rwords %u), %u workgroups\n", lds_vote, ml_eff, plan_counters[1], hist_len, rwords, n_vote_wg);
     if (lds_vote > 65536)
       MA_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_vote), hipFuncAttributeMaxDynamicSharedMemorySize,
                                       static_cast<int>(lds_vote)));

@@ -1,0 +1,10 @@
+# Developer tool: one k_vote iteration on the GPU box -- aligner parity tests, the trip-level profile (libmicroasm_prof.so built
+# -DMA_PROFILE_TRIPS for align.hip) and the single-lane / four-lane bench.
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out/r5b
+timeout 900 python -m pytest tests -m gpu -x -q -k "align or geno or vote or parity" 2>&1 | tail -5 > gpurun_out/r5b/gpu_tests_align.txt
+python3 tools/prof_phases.py 4096 bench 2>&1 | tail -2 > gpurun_out/r5b/vprof.txt
+export MA_BENCH_CACHE=/tmp/mbc
+python3 bench.py --no-cpu --no-also --gen-only > /dev/null 2>&1
+MA_STREAMS=1 python3 bench.py --steps 3 --no-cpu --no-also 2>/dev/null | tail -1 > gpurun_out/r5b/bench_1lane.json
+python3 bench.py --steps 4 --no-cpu --no-also 2>/dev/null | tail -1 > gpurun_out/r5b/bench.json
