@@ -379,6 +379,24 @@ __device__ __forceinline__ u32 plane32(const u32* pl, u32 i) {
 // index entry == read code?  Bit 31 of an entry flags "this 11-mer occurs more than once in the haplotype".
 constexpr u32 kCodeDup = 0x80000000u;
 __device__ __forceinline__ bool same_code(u32 entry, u32 cd) { return ((entry ^ cd) & ~kCodeDup) == 0; }
+// All-reduce over the eight lanes 8 g .. 8 g + 7 of a wave (k_vote: one read per group) on the DPP path: lane ^ 1 and
+// lane ^ 2 inside the quad, then the mirror image inside the half row (lane i <-> 7 - i: the other quad).  No LDS traffic --
+// the kernel is bound by the CU's LDS pipe and __shfl_xor is a ds_bpermute.  (All 64 lanes must be active.)
+template <class Op>
+__device__ __forceinline__ u32 grp8_reduce(u32 v, Op op) {
+  v = op(v, static_cast<u32>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0xB1, 0xF, 0xF, false)));   // quad_perm [1,0,3,2]
+  v = op(v, static_cast<u32>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x4E, 0xF, 0xF, false)));   // quad_perm [2,3,0,1]
+  v = op(v, static_cast<u32>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x141, 0xF, 0xF, false)));  // row_half_mirror
+  return v;
+}
+__device__ __forceinline__ u32 grp8_sum(u32 v) { return grp8_reduce(v, [](u32 a, u32 b) { return a + b; }); }
+__device__ __forceinline__ u32 grp8_or(u32 v) { return grp8_reduce(v, [](u32 a, u32 b) { return a | b; }); }
+__device__ __forceinline__ i32 grp8_min(i32 v) {
+  return static_cast<i32>(grp8_reduce(static_cast<u32>(v), [](u32 a, u32 b) { return static_cast<u32>(min(static_cast<i32>(a), static_cast<i32>(b))); }));
+}
+__device__ __forceinline__ i32 grp8_max(i32 v) {
+  return static_cast<i32>(grp8_reduce(static_cast<u32>(v), [](u32 a, u32 b) { return static_cast<u32>(max(static_cast<i32>(a), static_cast<i32>(b))); }));
+}
 // append this wave's buffered DP pairs to the global list: one atomic per 64 pairs
 __device__ __forceinline__ void vote_flush_dp(GArgs const& A, HapIdx ix, int lane) {
   u32 const cnt = ix.dpbuf[64];
@@ -710,10 +728,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MA_VOTE_WAV
       bool settled = false;
       bool read_n;
       {  // an N in the read: general route (the per-read code leaves its candidate loop at the first in-range candidate)
-        u32 b_ = wb;
-        b_ |= __shfl_xor(b_, 1);
-        b_ |= __shfl_xor(b_, 2);
-        b_ |= __shfl_xor(b_, 4);
+        u32 const b_ = grp8_or(wb);
         read_n = b_ != 0;
         if (read_n) can = false;
       }
@@ -739,10 +754,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MA_VOTE_WAV
             mism = __popc(((wl ^ hl) | (wh ^ hh)) & vmask);
           }
         }
-        mism += __shfl_xor(mism, 1);
-        mism += __shfl_xor(mism, 2);
-        mism += __shfl_xor(mism, 4);
-        i32 const X = static_cast<i32>(mism);
+        i32 const X = static_cast<i32>(grp8_sum(mism));
         if (inr && X <= 2) {
           i32 const D = static_cast<i32>(ix.dup_pre[c + m - SK + 1]) - static_cast<i32>(ix.dup_pre[c]);
           i32 const S0 = m - 5 * X;
@@ -837,9 +849,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MA_VOTE_WAV
       u32 const wl = nwl, wh = nwh, it = nit;
       u32 bad = nwb;
       fetch_item(q + 8, &nwl, &nwh, &nwb, &nit);  // (the next eight listed reads: in flight under this trip)
-      bad |= __shfl_xor(bad, 1);
-      bad |= __shfl_xor(bad, 2);
-      bad |= __shfl_xor(bad, 4);
+      bad = grp8_or(bad);
       bool const valid = (it & 0x10000u) != 0u;
       u32 const ri = it & 0x7FFFu;
       u64 const p = p0 + ri;
@@ -856,52 +866,86 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MA_VOTE_WAV
       u32 cnt = 0;
       i32 dmin = 0x7FFFFFFF, dmax = -0x7FFFFFFF;
       u32 multi = 0;
+      // (the loop is bound by VALU issue -- ~60 instructions per lane and position in its first form, five waves per SIMD:
+      //  every load below is unconditional with a harmless address, every update a select, the 64-bit shifts one per batch)
+#if defined(MA_VOTE_STOP) && MA_VOTE_STOP == 4  // (developer timing build: the group vote without its lookups; results invalid)
+      i32 const nrun = 0;
+#else
+      i32 const nrun = min(pr, np - s);  // this lane's positions: t < nrun (<= 0: none)
+#endif
       for (i32 t0 = 0; t0 < 24; t0 += 8) {
-        if (__ballot(t0 < pr && s + t0 < np) == 0ull) break;
+        i32 const nact = nrun - t0;
+        if (__ballot(nact > 0) == 0ull) break;
+        u32 const shb = off + static_cast<u32>(t0);  // <= 31 + 16; bits shb + tt .. shb + tt + 10 <= 63 for every position of the run
+        u32 const wlo = static_cast<u32>(lo64 >> shb), whi = static_cast<u32>(hi64 >> shb);
         u32 cdv[8], jv[8], ev[8];
+#pragma unroll
+        for (int tt = 0; tt < 8; ++tt) {
+          cdv[tt] = ((wlo >> tt) & 0x7FFu) | (((whi >> tt) & 0x7FFu) << 11);
+          jv[tt] = head[(cdv[tt] * 2654435761u) >> (32 - 12)];
+        }
+#pragma unroll
+        for (int tt = 0; tt < 8; ++tt) {
+          jv[tt] = tt < nact ? jv[tt] : 0xFFFFu;
+          ev[tt] = code[jv[tt] != 0xFFFFu ? jv[tt] : 0u];
+        }
         u32 pend = 0;
+        u32 bmin = 0xFFFFFFFFu, bmax = 0u;  // extremes of j + 8 - tt over this batch's first-probe hits
 #pragma unroll
         for (int tt = 0; tt < 8; ++tt) {
-          i32 const t = t0 + tt;
-          u32 const sh = off + static_cast<u32>(t);  // <= 31 + 22: eleven more bits stay inside the window
-          cdv[tt] = (static_cast<u32>(lo64 >> sh) & 0x7FFu) | ((static_cast<u32>(hi64 >> sh) & 0x7FFu) << 11);
-          jv[tt] = (t < pr && s + t < np) ? head[(cdv[tt] * 2654435761u) >> (32 - 12)] : 0xFFFFu;
+          bool const have = jv[tt] != 0xFFFFu, same = same_code(ev[tt], cdv[tt]);
+          bool const hit = have && same;
+          pend |= (have && !same) ? (1u << tt) : 0u;
+          u32 const vb = jv[tt] + static_cast<u32>(8 - tt);
+          bmin = min(bmin, hit ? vb : 0xFFFFFFFFu);
+          bmax = max(bmax, hit ? vb : 0u);
+          cnt += hit ? 1u : 0u;
+          multi |= hit ? ev[tt] : 0u;  // (only bit 31 is looked at)
         }
-#pragma unroll
-        for (int tt = 0; tt < 8; ++tt) ev[tt] = jv[tt] != 0xFFFFu ? code[jv[tt]] : 0u;
-#pragma unroll
-        for (int tt = 0; tt < 8; ++tt)
-          if (jv[tt] != 0xFFFFu && !same_code(ev[tt], cdv[tt])) pend |= 1u << tt;
-        while (pend != 0) {  // (buckets shared with other 11-mers)
-#pragma unroll
-          for (int tt = 0; tt < 8; ++tt)
-            if (pend & (1u << tt)) jv[tt] = next[jv[tt]];
-#pragma unroll
-          for (int tt = 0; tt < 8; ++tt)
-            if ((pend & (1u << tt)) && jv[tt] != 0xFFFFu) ev[tt] = code[jv[tt]];
-#pragma unroll
-          for (int tt = 0; tt < 8; ++tt)
-            if ((pend & (1u << tt)) && (jv[tt] == 0xFFFFu || same_code(ev[tt], cdv[tt]))) pend &= ~(1u << tt);
+        if (bmax != 0u) {
+          i32 const base = s + t0 + 8;
+          dmin = min(dmin, static_cast<i32>(bmin) - base);
+          dmax = max(dmax, static_cast<i32>(bmax) - base);
         }
+        // Buckets shared with other 11-mers (one probe in ten): every lane walks ITS pending chains one after the other --
+        // a handful of LDS instructions for the wave.  (All eight positions in lock step issued sixteen, mostly empty, per
+        // chain step.)
+#if defined(MA_VOTE_STOP) && MA_VOTE_STOP == 5  // (developer timing build: first probes only; results invalid)
+        pend = 0;
+#endif
+        while (pend != 0) {
+          u32 const tt = static_cast<u32>(__builtin_ctz(pend));
+          pend &= pend - 1u;
+          u32 j = jv[0], cd = cdv[0];
 #pragma unroll
-        for (int tt = 0; tt < 8; ++tt) {
-          if (jv[tt] != 0xFFFFu) {
-            i32 const d = static_cast<i32>(jv[tt]) - (s + t0 + tt);
+          for (u32 k = 1; k < 8; ++k) {
+            j = tt == k ? jv[k] : j;
+            cd = tt == k ? cdv[k] : cd;
+          }
+          u32 e = 0;
+          do {
+            j = next[j];
+            if (j == 0xFFFFu) break;
+            e = code[j];
+          } while (!same_code(e, cd));
+          if (j != 0xFFFFu) {
+            i32 const d = static_cast<i32>(j) - (s + t0 + static_cast<i32>(tt));
             ++cnt;
             dmin = min(dmin, d);
             dmax = max(dmax, d);
-            multi |= ev[tt] & kCodeDup;
+            multi |= e;
           }
         }
       }
+      multi &= kCodeDup;
       TRIP_STAMP(tgA);
-#pragma unroll
-      for (int o = 1; o < 8; o <<= 1) {
-        cnt += __shfl_xor(cnt, o);
-        dmin = min(dmin, __shfl_xor(dmin, o));
-        dmax = max(dmax, __shfl_xor(dmax, o));
-        multi |= __shfl_xor(multi, o);
-      }
+      cnt = grp8_sum(cnt);
+#if defined(MA_VOTE_STOP) && MA_VOTE_STOP == 6  // (developer timing build: the lookups run, every listed read is then called 'no shared 11-mer'; results invalid)
+      if (cnt != 0x12345678u) cnt = 0;
+#endif
+      dmin = grp8_min(dmin);
+      dmax = grp8_max(dmax);
+      multi = grp8_or(multi);
       bool const unan = gv && multi == 0 && (cnt == 0 || dmin == dmax);
       bool const anchored = unan && cnt >= kMinChainVotes;
       // mismatches of the gapless path on c = dmin (vote_pair's rule: only when the read is inside or overhangs ONE end)
@@ -921,9 +965,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MA_VOTE_WAV
           }
         }
       }
-      mism += __shfl_xor(mism, 1);
-      mism += __shfl_xor(mism, 2);
-      mism += __shfl_xor(mism, 4);
+      mism = grp8_sum(mism);
       TRIP_STAMP(tgB);
       u32 act = kVoteNoHit;
       if (unan && x == 0) {
@@ -937,6 +979,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MA_VOTE_WAV
                             false, false, 0, 0, 0u, 0u, 0u);
         }
       }
+#if defined(MA_VOTE_STOP) && MA_VOTE_STOP == 7  // (developer timing build: the group vote's DP pairs are not queued; results invalid)
+      act = kVoteFast;
+#endif
       TRIP_STAMP(tgC);
       // the DP pairs of this trip (at most eight) into the wave's buffer: it holds < 64 on entry
       unsigned long long const dpm = __ballot(act < kVoteFast);
@@ -972,7 +1017,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MA_VOTE_WAV
     nleft = nB;
   }
 #endif
-#if defined(MA_VOTE_STOP) && MA_VOTE_STOP == 3  // (developer timing build: no wave-wide route after the group vote; results invalid)
+#if defined(MA_VOTE_STOP) && MA_VOTE_STOP >= 3  // (developer timing builds: no wave-wide route after the group vote; results invalid)
   nleft = 0;
 #endif
   {
@@ -1024,7 +1069,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MA_VOTE_WAV
     tp2 += tw1 - tw0;
 #endif
   }
-  vote_flush_dp(A, ix, lane);
+  // What the four waves still buffer goes out together: ONE returning atomic per workgroup and one per key present.  (A
+  // flush per wave put ~1.5 M atomics per step on the one cache line of dp_count -- each wave's handful of pairs, its
+  // returning add and three or four key counts -- and the kernel, timing builds say, spent 2 of its 5.6 ms queueing for
+  // that line.)
+  {
+    __shared__ u32 sh_kh[36];
+    __shared__ u32 sh_dpbase;
+    if (threadIdx.x < 36) sh_kh[threadIdx.x] = 0;
+    __syncthreads();
+    u32 const c0 = dpbuf_all[64], c1 = dpbuf_all[129 + 64], c2 = dpbuf_all[2 * 129 + 64], c3 = dpbuf_all[3 * 129 + 64];
+    u32 const total = c0 + c1 + c2 + c3;
+    if (total != 0) {  // (workgroup-uniform)
+      u32 const mine = wave == 0 ? c0 : (wave == 1 ? c1 : (wave == 2 ? c2 : c3));
+      u32 const before = wave == 0 ? 0u : (wave == 1 ? c0 : (wave == 2 ? c0 + c1 : c0 + c1 + c2));
+      bool const have = static_cast<u32>(lane) < mine;
+      u32 const entry = have ? dpbuf_all[wave * 129 + lane] : 0u;
+      if (have) atomicAdd(&sh_kh[dpbuf_all[wave * 129 + 65 + lane]], 1u);
+      if (threadIdx.x == 0) sh_dpbase = atomicAdd(A.ws.dp_count, total);
+      __syncthreads();
+      if (have) A.ws.dp_list[sh_dpbase + before + static_cast<u32>(lane)] = entry;
+      if (threadIdx.x < 36 && sh_kh[threadIdx.x] != 0) atomicAdd(&A.ws.dp_count[4 + threadIdx.x], sh_kh[threadIdx.x]);
+    }
+  }
 #ifdef MA_PROFILE_TRIPS
   if (lane == 0) {
     atomicAdd(&g_vprof[0], tp0);

@@ -4,7 +4,7 @@ cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/r5b
 export MA_BENCH_CACHE=/tmp/mbc
 python3 bench.py --no-cpu --no-also --gen-only > /dev/null 2>&1
-for lib in libmicroasm.so libmicroasm_vs1.so libmicroasm_vs2.so libmicroasm_vs3.so; do
+for lib in ${VOTE_LIBS:-libmicroasm.so libmicroasm_vs1.so libmicroasm_vs2.so libmicroasm_vs3.so}; do
   MA_LIB=$PWD/lancet2_amd/$lib MA_STREAMS=1 python3 - >> gpurun_out/r5b/vote_phases.txt 2>/dev/null <<PY
 import sys, json, subprocess, os
 r = subprocess.run([sys.executable, "bench.py", "--steps", "2", "--no-cpu", "--no-also"], capture_output=True, text=True)
