@@ -277,73 +277,69 @@ __device__ unsigned long long g_vprof[16];
 // words per read record: three planes of rwords words, padded to whole 128-byte lines (full-line stores, one or two
 // aligned lines per fetch)
 __host__ __device__ constexpr u32 plane_stride(u32 rwords) { return (3u * rwords + 31u) & ~31u; }
-constexpr int kPlaneReadsPerWave = 16;  // (one read per wavefront would make the workgroup launch rate the bottleneck)
+// A lane per (read, 32-base word): 32 bytes in as dwords (any alignment), three plane words out.  G = 8 / 16 / 32 lanes per
+// read (the power of two that holds rwords); four ASCII bases become four 2-bit codes per dword operation (swar below), an
+// all-A/C/G/T dword -- all but one in a few hundred -- needs nothing else, anything else is encoded byte by byte with
+// enc_base.  (Round 5; the first form packed one read per wavefront and trip -- a byte per lane, nine ballots and an LDS
+// round per 64 bases, 17 reads in series: 2.2 ms per 16384 windows for 2.6 GB of traffic.)
+__device__ __forceinline__ u32 nib4(u32 c) {  // bit 0 of each of the four bytes -> bits 0..3
+  u32 const y = (c | (c >> 7)) & 0x00030003u;
+  return (y | (y >> 14)) & 0xFu;
+}
+template <u32 G>
 __global__ __launch_bounds__(256) void k_read_planes(GArgs A, u32 rwords) {
-  extern __shared__ u32 lds_pl[];  // [4 waves][3 rwords]: the words are collected here and leave as ONE coalesced store per read
-  int const lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  u32* mine = lds_pl + wave * 3u * rwords;
-  i64 const r_begin = (static_cast<i64>(blockIdx.x) * 4 + wave) * kPlaneReadsPerWave;
-  i64 const r_end = min(r_begin + kPlaneReadsPerWave, A.b.n_reads);
-  // the loop would be a chain of HBM round trips (offset -> bases -> store): the wave's 17 read offsets are fetched at once,
-  // one per lane, and the first 256 bases of the next TWO reads are in flight while this one is packed
-  constexpr int kPre = 4;
-  u64 my_off = 0;
-  if (lane <= kPlaneReadsPerWave && r_begin + lane <= A.b.n_reads) my_off = A.b.read_off[r_begin + lane];
-  auto off_of = [&](int x) -> u64 {  // x uniform: read r_begin + x
-    u32 const lo = static_cast<u32>(__builtin_amdgcn_readlane(static_cast<int>(static_cast<u32>(my_off)), x));
-    u32 const hi = static_cast<u32>(__builtin_amdgcn_readlane(static_cast<int>(static_cast<u32>(my_off >> 32)), x));
-    return (static_cast<u64>(hi) << 32) | lo;
-  };
-  u32 cur[kPre], nxt[kPre], nxt2[kPre];
-  i32 m_cur = 0, m_nxt = 0, m_nxt2 = 0;
-  auto fetch = [&](i64 r, u32 (&pre)[kPre], i32* mm) {
-    int const x = static_cast<int>(r - r_begin);
-    u64 const ro = off_of(x);
-    *mm = static_cast<i32>(off_of(x + 1) - ro);
-    if (*mm > static_cast<i32>(rwords - 2) * 32) *mm = 0;  // a read of a window that is not genotyped (MA_W_READ_OVERFLOW)
-    const u8* rb = A.b.read_bases + ro;
+  i64 const r = static_cast<i64>(blockIdx.x) * (256 / G) + threadIdx.x / G;
+  u32 const x = threadIdx.x % G;
+  if (r >= A.b.n_reads || x >= rwords) return;
+  u64 const ro = A.b.read_off[r];
+  i32 m = static_cast<i32>(A.b.read_off[r + 1] - ro);
+  if (m > static_cast<i32>(rwords - 2) * 32) m = 0;  // a read of a window that is not genotyped (MA_W_READ_OVERFLOW)
+  i32 const nb = min(max(m - 32 * static_cast<i32>(x), 0), 32);
+  u32 lo = 0, hi = 0, bad = 0;
+  if (nb > 0) {
+    const u8* rb = A.b.read_bases + ro + 32u * x;
+    u32 v[8];
 #pragma unroll
-    for (int q = 0; q < kPre; ++q) pre[q] = lane + 64 * q < *mm ? rb[lane + 64 * q] : 0u;
-  };
-#pragma unroll
-  for (int x = 0; x < kPre; ++x) cur[x] = nxt[x] = nxt2[x] = 0;
-  if (r_begin < r_end) fetch(r_begin, cur, &m_cur);
-  if (r_begin + 1 < r_end) fetch(r_begin + 1, nxt, &m_nxt);
-  for (i64 r = r_begin; r < r_end; ++r) {
-    if (r + 2 < r_end) fetch(r + 2, nxt2, &m_nxt2);
-    i32 const m = m_cur;
-    const u8* rb = A.b.read_bases + off_of(static_cast<int>(r - r_begin));
-    for (i32 i0 = 0; i0 < static_cast<i32>(rwords) * 32; i0 += 64) {
-      i32 const i = i0 + lane;
-      int const t = i0 >> 6;
-      u32 byte = 0;
-      if (t < kPre) {
-#pragma unroll
-        for (int x = 0; x < kPre; ++x) byte = t == x ? cur[x] : byte;
-      } else if (i < m) {
-        byte = rb[i];
-      }
-      u32 const e = i < m ? enc_base(static_cast<u8>(byte)) : 0u;
-      unsigned long long const blo = __ballot(e & 1u), bhi = __ballot(e & 2u), bbad = __ballot(e > 3u);
-      if (lane < 2 && static_cast<u32>(i0 >> 5) + lane < rwords) {
-        u32 const wd = (i0 >> 5) + lane;
-        mine[wd] = static_cast<u32>(blo >> (32 * lane));
-        mine[rwords + wd] = static_cast<u32>(bhi >> (32 * lane));
-        mine[2 * rwords + wd] = static_cast<u32>(bbad >> (32 * lane));
+    for (int q = 0; q < 8; ++q) {
+      i32 const rem = nb - 4 * q;
+      v[q] = 0x41414141u;  // (past the read's end: 'A' -- code 0, nothing flagged)
+      if (rem >= 4) {
+        __builtin_memcpy(&v[q], rb + 4 * q, 4);
+      } else if (rem > 0) {  // the read's last bytes: nothing behind them is touched (the caller's buffer may end there)
+        u32 t = 0x41414141u;
+        for (i32 y = 0; y < rem; ++y) t = (t & ~(0xFFu << (8 * y))) | (static_cast<u32>(rb[4 * q + y]) << (8 * y));
+        v[q] = t;
       }
     }
-    __builtin_amdgcn_wave_barrier();
-    u32* out = A.ws.read_planes + static_cast<size_t>(r) * plane_stride(rwords);
-    for (u32 x = lane; x < plane_stride(rwords); x += 64) out[x] = x < 3u * rwords ? mine[x] : 0u;
-    __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int x = 0; x < kPre; ++x) {
-      cur[x] = nxt[x];
-      nxt[x] = nxt2[x];
+    for (int q = 0; q < 8; ++q) {
+      u32 c = (v[q] >> 1) & 0x03030303u;  // A 0, C 1, T 2, G 3
+      c ^= (c >> 1) & 0x01010101u;        // A 0, C 1, G 2, T 3
+      u32 const c0 = c & 0x01010101u, c1 = (c >> 1) & 0x01010101u;
+      // the byte a code stands for: 0x41 ^ 0x02 c0 ^ 0x06 c1 ^ 0x11 c0 c1 (A 0x41, C 0x43, G 0x47, T 0x54), shifts and xors only
+      u32 const both = c0 & c1;
+      u32 const expect = 0x41414141u ^ (c0 << 1) ^ (c1 << 1) ^ (c1 << 2) ^ both ^ (both << 4);
+      u32 l4 = nib4(c0), h4 = nib4(c1), b4 = 0;
+      if (v[q] != expect) {  // lower case, N, anything else: enc_base's rule, byte by byte
+        l4 = h4 = 0;
+#pragma unroll
+        for (int y = 0; y < 4; ++y) {
+          u32 const e = enc_base(static_cast<u8>((v[q] >> (8 * y)) & 0xFFu));
+          l4 |= (e & 1u) << y;
+          h4 |= ((e >> 1) & 1u) << y;
+          b4 |= (e > 3u ? 1u : 0u) << y;
+        }
+      }
+      lo |= l4 << (4 * q);
+      hi |= h4 << (4 * q);
+      bad |= b4 << (4 * q);
     }
-    m_cur = m_nxt;
-    m_nxt = m_nxt2;
   }
+  u32* out = A.ws.read_planes + static_cast<size_t>(r) * plane_stride(rwords);
+  out[x] = lo;
+  out[rwords + x] = hi;
+  out[2 * rwords + x] = bad;
+  for (u32 y = 3 * rwords + x; y < plane_stride(rwords); y += rwords) out[y] = 0u;  // (the stride's padding reads as zero)
 }
 
 // ---- seed vote: one workgroup per (window, haplotype), one wave per read ----
@@ -2859,8 +2855,9 @@ int launch_genotype(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& a, const m
   if (o_in.aln_cigar) MA_HIP(ctx, hipMemsetAsync(A.o.aln_cigar, 0, 4ull * NR * MH * (1 + MCG), ctx->stream));
 
   ctx->tic("k_read_planes");
-  hipLaunchKernelGGL(k_read_planes, dim3(static_cast<u32>((NR + 4 * kPlaneReadsPerWave - 1) / (4 * kPlaneReadsPerWave))), dim3(256),
-                     4 * 3 * rwords_all * 4, ctx->stream, A, rwords_all);
+  if (rwords_all <= 8) hipLaunchKernelGGL(k_read_planes<8>, dim3(static_cast<u32>((NR + 31) / 32)), dim3(256), 0, ctx->stream, A, rwords_all);
+  else if (rwords_all <= 16) hipLaunchKernelGGL(k_read_planes<16>, dim3(static_cast<u32>((NR + 15) / 16)), dim3(256), 0, ctx->stream, A, rwords_all);
+  else hipLaunchKernelGGL(k_read_planes<32>, dim3(static_cast<u32>((NR + 7) / 8)), dim3(256), 0, ctx->stream, A, rwords_all);
   ctx->toc();
   ctx->tic("k_plan");
   hipLaunchKernelGGL(k_plan, dim3((n + 127) / 128), dim3(128), 0, ctx->stream, A);
