@@ -997,6 +997,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MA_VOTE_WAV
       }
       // what stays listed (compacted in place: nB <= q, and the entries up to q + 15 have been read)
       unsigned long long const stay = __ballot(valid && !unan && x == 0);
+#ifdef MA_PROFILE_TRIPS  // (census of what stays listed: a repeat / two or more diagonals without a repeat / not voted here at all)
+      if (lane == 0) {
+        atomicAdd(&g_vprof[9], static_cast<unsigned long long>(__popcll(__ballot(valid && gv && multi != 0 && x == 0))));
+        atomicAdd(&g_vprof[10], static_cast<unsigned long long>(__popcll(__ballot(valid && gv && multi == 0 && !unan && x == 0))));
+        atomicAdd(&g_vprof[11], static_cast<unsigned long long>(__popcll(__ballot(valid && !gv && x == 0))));
+      }
+#endif
       if ((stay >> lane) & 1ull) l_left[nB + static_cast<u32>(__popcll(stay & ((1ull << lane) - 1ull)))] = static_cast<u16>(it & 0xFFFFu);
       nB += static_cast<u32>(__popcll(stay));
 #ifdef MA_PROFILE_TRIPS
