@@ -425,10 +425,9 @@ __device__ __forceinline__ void write_no_hit(GArgs const& A, u64 lp) {
 // bases of the gapless path on c, v2 the runner-up's votes, v_off the votes not on c.  (The reasoning is with vote_pair.)
 constexpr u32 kVoteFast = 0xFFFFFFFEu, kVoteNoHit = 0xFFFFFFFFu;
 __device__ __forceinline__ u32 vote_settle(GArgs const& A, u64 lp, PairId id, i32 m, i32 n, i32 c, i32 vmin, i32 vmax, i32 K, i32 X, bool amb,
-                                           bool ramb, bool hap_amb, i32 v2, i32 v_off, u32 vfar8, u32 vfar16, u32 vfar24) {
+                                           bool ramb, bool hap_amb, i32 v2, i32 v_off, u32 vfar8, u32 vfar16, u32 vfar24,
+                                           i32 lb_other = -(1 << 20), i32 n_amb = 0) {
   i32 const ms = A.prm.min_aln_score;
-  i32 const r_lo = vmin - K;
-  u32 const r_w = static_cast<u32>(vmax - vmin + 2 * K + 1);
   i32 const o_left = c < 0 ? -c : 0, o_right = c + m > n ? c + m - n : 0;
   bool const inside = o_left == 0 && o_right == 0;
   i32 const qs = o_left, qe = m - o_right;  // overlap rows [qs, qe)
@@ -467,6 +466,50 @@ __device__ __forceinline__ u32 vote_settle(GArgs const& A, u64 lp, PairId id, i3
     A.ws.centre[lp] = 0x7FFFFFFE;
     return kVoteFast;
   }
+  // ---- the DP's region, narrowed EXACTLY (round 5) --------------------------------------------------------------------
+  // Rule 3 sizes R = [vmin - K, vmax + K] for the weakest alignment that counts (score min_aln_score).  The DP's answer --
+  // the optimum inside R with the canonical ties -- is known to score at least S_lb whenever some overlap alignment inside
+  // [vmin, vmax] is: the gapless path P0 on c (S0), or the caller's one-gap path between two voted diagonals (lb_other).
+  // With nothing ambiguous in read or haplotype:
+  //   (a) a path of score >= S_lb has gaps of total length <= K' = (m - S_lb - 12) / 3: it stays within K' diagonals of
+  //       any diagonal it visits;
+  //   (b) with L paired rows, x mismatches and g gaps it scores <= L - 5 x - 15 g and holds >= L - 10 (g + 1) - 11 x >=
+  //       S_lb - 10 - 6 (m - S_lb) / 5 exact 11-mers -- at least kMinChainVotes of them once 11 S_lb >= 70 + 6 m -- all on its
+  //       own diagonals, which lie within K' <= K of each other: every voted diagonal of the path is an ANCHOR, so the path
+  //       visits [vmin, vmax] and lies inside R' = [vmin - K', vmax + K'];
+  //   (c) every optimal path inside R, and every optimal-or-tied prefix of one (prefix + the path's suffix is such a path),
+  //       therefore lies inside R': the cells the end-cell choice and the traceback compare hold the same H / E / F in the
+  //       DP over R' as over R, every other cell at most what it held -- the same end cell, the same moves, the same record.
+  // The kernels' cost is rows x the width class of the region: 39 + spread columns become 2 K' + 1 + spread.
+  //   (d) rows that NO path inside the region can pair are paid by every path: a region whose largest diagonal is D < 0
+  //       clips >= -D rows at the read's start, one that ends past the haplotype's end likewise at its end.  They come off
+  //       the rows a path can pair in (b) -- with the full K, before anything is narrowed -- and off the gap budget in (a),
+  //       which may then be re-applied to the narrower region: a read hanging 65 bases over a haplotype end with one
+  //       mismatch (11 S0 <= 6 m + 50, no certificate) has K' = 17 by (a) alone and 0 with the 64 rows it cannot pair.
+  i32 Kn = K;
+  {
+    i32 s_lb = lb_other;
+    // (an N in the READ -- n_amb of them, none in the haplotype: X counts it as a mismatch, so S0 only underestimates P0; a
+    //  path pairs at most n_amb of them at cost 2 each, and each spoils 11 of its 11-mers: 45 n_amb more in (b)'s condition)
+    if ((o_left == 0 || o_right == 0) && qe - qs > 0 && c >= vmin && c <= vmax) s_lb = max(s_lb, S0);
+    i32 const clip0 = max(0, -(vmax + K)) + max(0, vmin - K + m - n);
+    if (certs && !hap_amb && (ramb || !amb) && 11 * s_lb >= 70 + 6 * (m - clip0) + 45 * n_amb) {
+      Kn = min(K, max(0, (m - s_lb - GO) / GE));
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        i32 const clip = max(0, -(vmax + Kn)) + max(0, vmin - Kn + m - n);
+        Kn = min(Kn, max(0, (m - s_lb - clip - GO) / GE));
+      }
+    }
+  }
+#ifdef MA_DP_HIST  // (developer build: how wide are the DP regions?  dp_count[24 ..])
+  if (!(fast_in || fast_ov || nohit)) {
+    u32 const w = static_cast<u32>(vmax - vmin + 2 * Kn + 1);
+    atomicAdd(&A.ws.dp_count[24 + (w <= 5 ? 0 : w <= 9 ? 1 : w <= 13 ? 2 : w <= 17 ? 3 : w <= 25 ? 4 : w <= 33 ? 5 : w <= 41 ? 6 : 7)], 1u);
+  }
+#endif
+  i32 const r_lo = vmin - Kn;
+  u32 const r_w = static_cast<u32>(vmax - vmin + 2 * Kn + 1);
   // width class of the region; can a row of the kernel's window reach column 0 or n (+ the 7 columns the last
   // segment word carries beyond it)?  k_align_reg picks its row body per wavefront, so the two kinds are kept apart
   int cls = kNumReg;
@@ -1213,6 +1256,7 @@ __device__ __forceinline__ void vote_pair(GArgs const& A, u64 lp, PairId id, Hap
   // -- no histogram update, no arg-max, no clearing.  Everything else takes the histogram path below.
   u32 nvotes = 0;  // this lane's votes; summed over the wave further down
   u32 best = 0, v2 = 0;
+  i32 d2 = 0x7FFFFFFF;  // the runner-up diagonal (histogram path only; ties: the smaller)
   i32 bd = 0x7FFFFFFF;
   i32 dlo = 0x7FFFFFFF, dhi = -1;  // extreme diagonals that received a vote (histogram index: diagonal + m)
   u32 vfar8 = 0, vfar16 = 0, vfar24 = 0;  // votes further than 8 / 16 / 24 diagonals from the most-voted one
@@ -1319,14 +1363,25 @@ __device__ __forceinline__ void vote_pair(GArgs const& A, u64 lp, PairId id, Hap
     VPROF_ACC(2);
     // second best (any other diagonal), then restore the all-zero histogram
     walk([&](i32 d) {
-      if (d != bd) v2 = max(v2, static_cast<u32>(hist[d]));
+      if (d != bd) {
+        u32 const v = hist[d];
+        if (v > v2 || (v == v2 && d < d2)) {
+          v2 = v;
+          d2 = d;
+        }
+      }
       u32 const far = static_cast<u32>(d > bd ? d - bd : bd - d);  // every visit is one vote
       vfar8 += far > 8u;
       vfar16 += far > 16u;
       vfar24 += far > 24u;
     });
     for (int off = 32; off > 0; off >>= 1) {
-      v2 = max(v2, __shfl_xor(v2, off));
+      u32 const ov = __shfl_xor(v2, off);
+      i32 const od = __shfl_xor(d2, off);
+      if (ov > v2 || (ov == v2 && od < d2)) {
+        v2 = ov;
+        d2 = od;
+      }
       vfar8 += __shfl_xor(vfar8, off);
       vfar16 += __shfl_xor(vfar16, off);
       vfar24 += __shfl_xor(vfar24, off);
@@ -1386,12 +1441,13 @@ __device__ __forceinline__ void vote_pair(GArgs const& A, u64 lp, PairId id, Hap
   i32 const o_left = c < 0 ? -c : 0, o_right = c + m > n ? c + m - n : 0;
   [[maybe_unused]] bool const inside = o_left == 0 && o_right == 0;
   i32 const qs = o_left, qe = m - o_right;  // overlap rows [qs, qe)
-  u32 mism = 0, amb = 0, ramb = 0;
+  u32 mism = 0, amb = 0, ramb = 0, namb = 0;
   if (qe - qs > 0 && (o_left == 0 || o_right == 0)) {
     for (i32 i = 32 * lane; i < m; i += 32 * 64) {  // 32 bases per lane: XOR of the bit planes
       i32 const lo = max(qs - i, 0), hi = min(qe - i, 32);  // overlap bits of this word: [lo, hi)
       u32 const rb_bad = rbad[i >> 5];
       ramb |= rb_bad;  // bits past the read's end are zero
+      namb += __popc(rb_bad);
       if (hi > lo) {
         u32 const valid = (hi >= 32 ? 0xFFFFFFFFu : ((1u << hi) - 1u)) & ~((1u << lo) - 1u);
         // haplotype bits aligned to read bit 0 of this word: haplotype position c + i + b for bit b >= lo
@@ -1411,11 +1467,49 @@ __device__ __forceinline__ void vote_pair(GArgs const& A, u64 lp, PairId id, Hap
     vtot += __shfl_xor(vtot, off);
   }
   VPROF_ACC(5);
+  if (ramb != 0)  // (wave-uniform after the reduction; one read in a hundred)
+    for (int off = 32; off > 0; off >>= 1) namb += __shfl_xor(namb, off);
   i32 const X = static_cast<i32>(mism);
   i32 const v_off = static_cast<i32>(vtot) - static_cast<i32>(best);
+  // ---- a ONE-GAP alignment between the two most-voted diagonals: a lower bound for the DP's optimum (vote_settle narrows the
+  // region with it).  The read lies inside the haplotype on both; rows [0, t) on the first diagonal up to its first
+  // mismatch, then the gap, the rest on the second: for B > A a deletion of s = B - A columns (all rows paired), for B < A an
+  // insertion of s rows.  Tried both ways round -- ANY such path's score is a valid bound, the better one is taken.
+  i32 lb_two = -(1 << 20);
+  if (v2 > 0 && d2 != 0x7FFFFFFF && m <= 2048 && !ramb && !ix.hap_amb && !(A.prm.aln_tier & 2)) {  // (wave-uniform)
+    i32 const c2 = d2 - m;
+    if (c >= 0 && c + m <= n && c2 >= 0 && c2 + m <= n && c >= vmin && c <= vmax && c2 >= vmin && c2 <= vmax) {
+      i32 const i = 32 * lane;
+      u32 xa = 0, xb = 0;
+      if (i < m) {
+        u32 const valid = m - i >= 32 ? 0xFFFFFFFFu : ((1u << (m - i)) - 1u);
+        u32 const rl = rlo[i >> 5], rh = rhi[i >> 5];
+        xa = ((rl ^ plane32(ix.hlo, c + i)) | (rh ^ plane32(ix.hhi, c + i))) & valid;
+        xb = ((rl ^ plane32(ix.hlo, c2 + i)) | (rh ^ plane32(ix.hhi, c2 + i))) & valid;
+      }
+      auto one_gap = [&](u32 first, u32 second, i32 a, i32 b) -> i32 {
+        unsigned long long const fm = __ballot(first != 0);
+        i32 t = m;
+        if (fm != 0ull) {
+          int const l0 = __builtin_ctzll(fm);
+          t = 32 * l0 + __shfl(first ? __builtin_ctz(first) : 0, l0);
+        }
+        i32 const sgap = b > a ? b - a : a - b;
+        i32 const start = b > a ? t : t + sgap;  // the first row on the second diagonal
+        if (start > m) return -(1 << 20);
+        i32 const rel = start - i;
+        u32 const from = rel <= 0 ? 0xFFFFFFFFu : (rel >= 32 ? 0u : ~((1u << rel) - 1u));
+        u32 xs = __popc(second & from);
+        for (int off = 32; off > 0; off >>= 1) xs += __shfl_xor(xs, off);
+        return (b > a ? m : m - sgap) - 5 * static_cast<i32>(xs) - (GO + GE * sgap);
+      };
+      lb_two = max(one_gap(xa, xb, c, c2), one_gap(xb, xa, c2, c));
+    }
+  }
   u32 act = kVoteNoHit;
   if (lane == 0) {
-    act = vote_settle(A, lp, id, m, n, c, vmin, vmax, K, X, amb != 0, ramb != 0, ix.hap_amb != 0, static_cast<i32>(v2), v_off, vfar8, vfar16, vfar24);
+    act = vote_settle(A, lp, id, m, n, c, vmin, vmax, K, X, amb != 0, ramb != 0, ix.hap_amb != 0, static_cast<i32>(v2), v_off, vfar8, vfar16, vfar24,
+                      lb_two, static_cast<i32>(namb));
     if (act < kVoteFast) {  // a DP pair: act is its (width class, wall) key
       u32 const at = ix.dpbuf[64]++;
       ix.dpbuf[at] = static_cast<u32>(lp);
@@ -1865,27 +1959,51 @@ __global__ __launch_bounds__(64) void k_align_gen(GArgs A) {
 // and its left neighbour, so whatever the cells t > wr compute never reaches a cell of the region, and only the
 // positions t in (WLO, W) carry the test.
 constexpr i32 NEGR = -20000;
-// DP list sorted by key = class * 2 + wall (order inside a key never affects a result: every pair is independent)
+// DP list sorted by key = class * 2 + wall and, inside a key, by the region's width in steps of eight cells (the order never
+// affects a result: every pair is independent; the DP kernels walk a row only as far as the widest region of a group)
 struct KeyBase { u32 b[kNumKeys]; };
-__global__ __launch_bounds__(256) void k_dp_scatter(GArgs A, u32 ndp, u32* out, u32* fill, KeyBase kb) {
-  // one global atomic per key and WORKGROUP, all keys at once: the pairs take their places inside the workgroup's
+constexpr int kSubKeys = kNumKeys * 8;
+__device__ __forceinline__ u32 dp_subkey(u32 bw) {  // band_w: width | key << 16
+  u32 const key = bw >> 16, w = bw & 0xFFFFu;
+  return key * 8u + (key < 2u * kNumReg ? min(7u, (max(w, 1u) - 1u) >> 3) : 0u);
+}
+__global__ __launch_bounds__(256) void k_dp_subcount(GArgs A, u32 ndp, u32* sub) {
+  __shared__ u32 l_cnt[kSubKeys];
+  for (u32 x = threadIdx.x; x < kSubKeys; x += 256) l_cnt[x] = 0;
+  __syncthreads();
+  u32 const li = blockIdx.x * 256u + threadIdx.x;
+  if (li < ndp) atomicAdd(&l_cnt[dp_subkey(A.ws.band_w[A.ws.dp_list[li]])], 1u);
+  __syncthreads();
+  for (u32 x = threadIdx.x; x < kSubKeys; x += 256)
+    if (l_cnt[x]) atomicAdd(&sub[x], l_cnt[x]);
+}
+__global__ __launch_bounds__(256) void k_dp_scatter(GArgs A, u32 ndp, u32* out, u32* fill, const u32* sub, KeyBase kb) {
+  // one global atomic per (key, width step) and WORKGROUP, all at once: the pairs take their places inside the workgroup's
   // share through LDS counters (a returning global atomic per key and wavefront, one key after the other, kept this
   // kernel waiting on a handful of contended addresses for its whole life)
-  __shared__ u32 l_cnt[kNumKeys], l_base[kNumKeys];
+  __shared__ u32 l_cnt[kSubKeys], l_base[kSubKeys], l_start[kSubKeys];
   u32 const li = blockIdx.x * 256u + threadIdx.x;
   bool const live = li < ndp;
-  if (threadIdx.x < kNumKeys) l_cnt[threadIdx.x] = 0;
+  for (u32 x = threadIdx.x; x < kSubKeys; x += 256) l_cnt[x] = 0;
+  if (threadIdx.x < kNumKeys) {  // where each width step of this key starts
+    u32 at = kb.b[threadIdx.x];
+    for (u32 y = 0; y < 8; ++y) {
+      l_start[threadIdx.x * 8u + y] = at;
+      at += sub[threadIdx.x * 8u + y];
+    }
+  }
   __syncthreads();
   u32 lp = 0, key = 0, pos = 0;
   if (live) {
     lp = A.ws.dp_list[li];
-    key = A.ws.band_w[lp] >> 16;
+    key = dp_subkey(A.ws.band_w[lp]);
     pos = atomicAdd(&l_cnt[key], 1u);
   }
   __syncthreads();
-  if (threadIdx.x < kNumKeys && l_cnt[threadIdx.x]) l_base[threadIdx.x] = atomicAdd(&fill[threadIdx.x], l_cnt[threadIdx.x]);
+  for (u32 x = threadIdx.x; x < kSubKeys; x += 256)
+    if (l_cnt[x]) l_base[x] = atomicAdd(&fill[x], l_cnt[x]);
   __syncthreads();
-  if (live) out[kb.b[key] + l_base[key] + pos] = lp;
+  if (live) out[l_start[key] + l_base[key] + pos] = lp;
 }
 
 // waves per SIMD the register allocator is asked to keep (it otherwise spends registers on scheduling freedom)
@@ -1904,8 +2022,12 @@ __device__ __forceinline__ void align_reg_body(GArgs const& A, u32 seg_words, u3
   i32 const m = P.m, n = P.n, lo = P.lo;
   i32 const wr = P.active ? P.wr : 0;
   i32 const mrows = P.active ? m : 0;
-  i32 mmax = mrows;
-  for (int off = 32; off > 0; off >>= 1) mmax = max(mmax, __shfl_xor(mmax, off));
+  i32 mmax = mrows, wlim = wr;
+  for (int off = 32; off > 0; off >>= 1) {
+    mmax = max(mmax, __shfl_xor(mmax, off));
+    wlim = max(wlim, __shfl_xor(wlim, off));
+  }
+  wlim = __builtin_amdgcn_readfirstlane((wlim + 7) & ~7);  // rows are walked in chunks of eight cells up to the group's widest region
 
   // packed previous row, BIASED by what the next row subtracts anyway: lo16 = H - (GO + GE), hi16 = F - GE; HF[WD] = sentinel
   u32 HF[WD + 1];
@@ -1968,7 +2090,10 @@ __device__ __forceinline__ void align_reg_body(GArgs const& A, u32 seg_words, u3
         i32 dhm = static_cast<i16>(HF[0] & 0xFFFFu);  // H(i-1, diag) - GOE; afterwards carried over from the cell before
         i32 lhm = NEGR - GOE;                          // H(i, t-1) - GOE
 #pragma unroll
-        for (int t = 0; t < WD; ++t) {
+        for (int t0 = 0; t0 < WD; t0 += 8) {
+         if (WD > 49 || t0 < wlim) {  // (the wide classes are walked whole: the chunk tests cost them registers)
+#pragma unroll
+        for (int t = t0; t < (t0 + 8 < WD ? t0 + 8 : WD); ++t) {
           u32 const up = HF[t + 1];
           i32 const uhm = static_cast<i16>(up & 0xFFFFu), ufm = static_cast<i32>(up) >> 16;
           i32 sb;
@@ -2011,6 +2136,8 @@ __device__ __forceinline__ void align_reg_body(GArgs const& A, u32 seg_words, u3
           } else if (t == WD - 1) {
             tbrow[static_cast<size_t>(t >> 3) * 64] = word >> (4 * (7 - (t & 7)));
           }
+        }
+         }
         }
       };
       if (__ballot(any_special != 0) != 0) row(std::true_type{}); else row(std::false_type{});
@@ -2124,7 +2251,14 @@ __device__ __forceinline__ bool align_reg_body_pk(GArgs const& A, u32 seg_words,
   i32 const wrA = PA.active ? PA.wr : 0, wrB = PB.active ? PB.wr : 0;
   i32 const mA = PA.active ? PA.m : 0, mB = PB.active ? PB.m : 0;
   i32 mmax = max(mA, mB);
-  for (int off = 32; off > 0; off >>= 1) mmax = max(mmax, __shfl_xor(mmax, off));
+  i32 wlim = max(wrA, wrB);
+  for (int off = 32; off > 0; off >>= 1) {
+    mmax = max(mmax, __shfl_xor(mmax, off));
+    wlim = max(wlim, __shfl_xor(wlim, off));
+  }
+  // Rows are walked in chunks of eight cells up to the widest region of the group's 128 pairs (the DP list is sorted by
+  // width inside a class: k_dp_scatter): the regions k_vote narrows are a few cells wide, the class's row is 33 to 49.
+  wlim = __builtin_amdgcn_readfirstlane((wlim + 7) & ~7);
   u32 spec = 0;
   auto const build = [&](DpPair const& P, u32* SEG) {
     if (!P.active) return;
@@ -2189,7 +2323,10 @@ __device__ __forceinline__ bool align_reg_body_pk(GArgs const& A, u32 seg_words,
     u32 acc1 = 0, acc2 = 0, acc3 = 0, acc4 = 0, hlast = 0;
     u32* const tbrow = tb + static_cast<size_t>(i) * rs + lane;
 #pragma unroll
-    for (int t = 0; t < WD; ++t) {
+    for (int t0 = 0; t0 < WD; t0 += 8) {
+     if (WD > 49 || t0 < wlim) {  // (the wide classes are walked whole: the chunk tests cost them registers)
+#pragma unroll
+    for (int t = t0; t < (t0 + 8 < WD ? t0 + 8 : WD); ++t) {
       u32 const uph = H[t + 1], upf = F[t + 1];
       u32 const c = (zz[t >> 3] >> (4 * (t & 7))) & 3u;
       u32 const mbit = (c * 0x8001u) & 0x00010001u;
@@ -2217,7 +2354,7 @@ __device__ __forceinline__ bool align_reg_body_pk(GArgs const& A, u32 seg_words,
       lhm = hm;
       dhm = uph;
       hlast = h;
-      if ((t & 15) == 15 || t == WD - 1) {
+      if ((t & 15) == 15 || t == WD - 1 || (WD <= 49 && (t & 15) == 7 && t + 1 >= wlim)) {
         u32 const fin = 15u - static_cast<u32>(t & 15);  // a partial last block: right-align its bits
         u32* const q = tbrow + static_cast<size_t>((t >> 4) * 4) * 64;
         q[0] = fin ? pk_shr(acc1, fin) : acc1;
@@ -2226,6 +2363,8 @@ __device__ __forceinline__ bool align_reg_body_pk(GArgs const& A, u32 seg_words,
         q[192] = fin ? pk_shr(acc4, fin) : acc4;
         acc1 = acc2 = acc3 = acc4 = 0;
       }
+    }
+     }
     }
     // end cell (i, n) for i < m: the last cell of the row is column n iff the region reaches it (see align_reg_body)
     {
@@ -2904,11 +3043,13 @@ int launch_genotype(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& a, const m
     ws.tb = ctx->ws_misc.as<u32>();
     ws.vote_aux = reinterpret_cast<u64*>(reinterpret_cast<char*>(ctx->ws_misc.p) + tb_cap);
     ws.centre = reinterpret_cast<i32*>(ws.vote_aux + pairs_chunk + 16);
-    ws.pair_read = reinterpret_cast<u32*>(ws.centre) + 4 * (pairs_chunk + 16) + 256;  // behind centre / band_w / dp_list / dp_count+sorted
+    ws.pair_read = reinterpret_cast<u32*>(ws.centre) + 4 * (pairs_chunk + 16) + 640;  // behind centre / band_w / dp_list / dp_count+sorted
     ws.band_w = reinterpret_cast<u32*>(ws.centre + pairs_chunk + 16);
     ws.dp_list = ws.band_w + pairs_chunk + 16;
     ws.dp_count = ws.dp_list + pairs_chunk + 16;
-    u32* const dp_sorted = ws.dp_count + 128;  // [pairs_chunk] the DP list sorted by key (k_dp_scatter)
+    u32* const dp_sorted = ws.dp_count + 512;  // [pairs_chunk] the DP list sorted by key (k_dp_scatter); dp_count: [0, 128) counters, [128, 128 + kSubKeys) pairs per
+                                               // (key, width step), [288, 288 + kSubKeys) k_dp_scatter's fill counters
+    static_assert(128 + kSubKeys <= 288 && 288 + kSubKeys <= 512, "dp_count layout");
     u32 const ml_eff = std::min<u32>(static_cast<u32>(P.max_hap_len), (std::max<u32>(plan_counters[3], 64u) + 31u) & ~31u);
     u32 const hist_len = ((max_read_len + ml_eff + 2 + 1) & ~1u);
     u32 const pw_host = (ml_eff + 31) / 32 + 2;
@@ -2923,7 +3064,7 @@ int launch_genotype(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& a, const m
     for (u64 p0 = 0; p0 < total_pairs; p0 += pairs_chunk) {
       A.pair0 = p0;
       A.npairs = static_cast<u32>(std::min<u64>(pairs_chunk, total_pairs - p0));
-      MA_HIP(ctx, hipMemsetAsync(ws.dp_count, 0, 4 * 128, ctx->stream));
+      MA_HIP(ctx, hipMemsetAsync(ws.dp_count, 0, 4 * 512, ctx->stream));
       ctx->tic("k_vote");
       hipLaunchKernelGGL(k_vote, dim3(n_vote_wg), dim3(256), lds_vote, ctx->stream, A, hist_len, rwords, ml_eff);
       ctx->toc();
@@ -2933,6 +3074,13 @@ int launch_genotype(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& a, const m
       u32 const ndp = cnt[0];
       ctx->stats[1] += ndp;
       if (ndp == 0) continue;
+      if (getenv("MA_VOTE_DEBUG")) {
+        fprintf(stderr, "k_vote: %u DP pairs of %u; by (class, wall):", ndp, A.npairs);
+        for (int k = 0; k < kNumKeys; ++k) fprintf(stderr, " %u", cnt[4 + k]);
+        fprintf(stderr, "; region widths <= 5 9 13 17 25 33 41 more (MA_DP_HIST builds):");
+        for (int k = 0; k < 8; ++k) fprintf(stderr, " %u", cnt[24 + k]);
+        fprintf(stderr, "\n");
+      }
       GArgs const Avote = A;
       KeyBase kb{};
       u32 acc = 0;
@@ -2945,8 +3093,9 @@ int launch_genotype(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& a, const m
         return MA_ERR_HIP;
       }
       ctx->tic("k_dp_scatter");
+      hipLaunchKernelGGL(k_dp_subcount, dim3((ndp + 255) / 256), dim3(256), 0, ctx->stream, A, ndp, ws.dp_count + 128);
       hipLaunchKernelGGL(k_dp_scatter, dim3((ndp + 255) / 256), dim3(256), 0, ctx->stream, A, ndp, dp_sorted,
-                         ws.dp_count + 64, kb);
+                         ws.dp_count + 288, ws.dp_count + 128, kb);
       ctx->toc();
       A.ws.dp_list = dp_sorted;
       auto class_n = [&](int c) { return cnt[4 + 2 * c] + cnt[4 + 2 * c + 1]; };
@@ -2989,26 +3138,36 @@ int launch_genotype(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& a, const m
             if (!class_wave(c) && reg_waves(reg_width(c)) == MA_RW49) c2 = c;
             break;
           }
-          if (c2 >= 0) {
-            u32 const n1 = cls_n, n2 = class_n(c2);
-            u32 const gw2 = class_w(c2);
+          // (all three 49-register classes in use -- the narrowed regions fill the first: it runs alone, the other two side by
+          //  side, two full launches instead of a full one and a sparse one)
+          if (cls == 0 && c2 == 1 && class_n(2) != 0 && !class_wave(2) && reg_waves(reg_width(2)) == MA_RW49) c2 = -1;
+          // (a class without a partner still takes the packed launch, beside an EMPTY neighbour class: with the regions
+          //  narrowed there are pairs in all three classes, and the third fell back to one pair per lane)
+          bool const pk_env = !(getenv("MA_ALIGN_PK") && atoi(getenv("MA_ALIGN_PK")) == 0);
+          bool const solo = c2 < 0 && pk_env;
+          int const lo_c = solo ? (cls == 0 ? 0 : cls - 1) : cls, hi_c = solo ? (cls == 0 ? 1 : cls) : c2;
+          if (c2 >= 0 || solo) {
+            u32 const n1 = cls_n, n2 = solo ? 0u : class_n(c2);
+            u32 const gw2 = solo ? class_w(hi_c) : class_w(c2);
             // (36 % fewer vector instructions.  Round 4 left it opt-in: the four-lane step was no shorter.  Round 5's step is bound
             //  by the throughput kernels' CU time, and the packed launch now buys +1.7 % (A/B on one box, twice); MA_ALIGN_PK=0
             //  is the one-pair-per-lane launch)
-            bool const pk = !(getenv("MA_ALIGN_PK") && atoi(getenv("MA_ALIGN_PK")) == 0);
+            bool const pk = pk_env;
             if (pk) {
               // two pairs per lane (k_align_reg2p): the pairs that cannot reach a haplotype end in packed groups of 128 (two
               // 64-pair tiles, wide enough for the plane rows), the others in groups of 64 through the general body
-              u32 const tw[2] = {std::max<u32>((gw + 7) / 8, reg_pk_words(static_cast<int>(gw)) / 2),
+              u32 const gwl = solo ? class_w(lo_c) : gw;
+              u32 const tw[2] = {std::max<u32>((gwl + 7) / 8, reg_pk_words(static_cast<int>(gwl)) / 2),
                                  std::max<u32>((gw2 + 7) / 8, reg_pk_words(static_cast<int>(gw2)) / 2)};
-              u32 const gws[2] = {gw, gw2};
-              int const cc[2] = {cls, c2};
+              u32 const gws[2] = {gwl, gw2};
+              int const cc[2] = {lo_c, hi_c};
+              bool const live[2] = {!solo || lo_c == cls, !solo || hi_c == cls};
               RegPlan pl{};
               size_t off = 0;  // bytes into the traceback workspace
               for (int sgi = 0; sgi < 4; ++sgi) {
                 int const x = sgi & 1;
                 bool const packed = sgi < 2;
-                u32 const n = cnt[4 + 2 * cc[x] + (packed ? 0 : 1)];
+                u32 const n = live[x] ? cnt[4 + 2 * cc[x] + (packed ? 0 : 1)] : 0u;
                 u32 const per = packed ? 128u : 64u;
                 RegSeg& sg = pl.seg[sgi];
                 sg.dp0 = kb.b[2 * cc[x] + (packed ? 0 : 1)];
@@ -3021,14 +3180,14 @@ int launch_genotype(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& a, const m
               }
               u32 const units = pl.seg[0].units + pl.seg[1].units + pl.seg[2].units + pl.seg[3].units;
               if (off <= tb_cap && units > 0) {
-                ctx->stats[4 + (c2 < 2 ? 0 : (c2 < 4 ? 1 : 2))] += n2;
+                if (!solo) ctx->stats[4 + (c2 < 2 ? 0 : (c2 < 4 ? 1 : 2))] += n2;
                 u32 const segw = (max_read_len + gw2 + 7) / 8 + 3;
                 size_t const lds_reg = static_cast<size_t>(segw) * 512;
                 ctx->tic("k_align_reg");
-                if (cls == 0 && c2 == 1)
+                if (lo_c == 0 && hi_c == 1)
                   hipLaunchKernelGGL((k_align_reg2p<reg_width(0), 0, reg_width(1), reg_width(0)>), dim3(units), dim3(64), lds_reg, ctx->stream,
                                      A, pl, segw);
-                else if (cls == 0 && c2 == 2)
+                else if (lo_c == 0 && hi_c == 2)
                   hipLaunchKernelGGL((k_align_reg2p<reg_width(0), 0, reg_width(2), reg_width(1)>), dim3(units), dim3(64), lds_reg, ctx->stream,
                                      A, pl, segw);
                 else
@@ -3040,10 +3199,11 @@ int launch_genotype(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& a, const m
                   hipLaunchKernelGGL(k_align_tb2, dim3(2 * (pl.seg[0].units + pl.seg[1].units)), dim3(64), 0, ctx->stream, A, pl);
                   ctx->toc();
                 }
-                cls = c2;
+                if (!solo) cls = c2;
                 continue;
               }
             }
+            if (!solo) {  // (a lone class without room for the packed tiles: one pair per lane below)
             u32 const tw1 = (gw + 7) / 8, tw2 = (gw2 + 7) / 8;
             size_t const tpg1 = static_cast<size_t>(ws.tb_rows) * tw1 * 64 * 4, tpg2 = static_cast<size_t>(ws.tb_rows) * tw2 * 64 * 4;
             u32 const ng1 = (n1 + 63) / 64, ng2 = (n2 + 63) / 64;
@@ -3069,6 +3229,7 @@ int launch_genotype(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& a, const m
               ctx->toc();
               cls = c2;
               continue;
+            }
             }
           }
         }

@@ -1139,6 +1139,8 @@ void ma_destroy(ma_ctx_t* ctx) {
     if (cs) (void)hipStreamDestroy(cs);
   }
   if (ctx->lane_done) (void)hipEventDestroy(ctx->lane_done);
+  if (ctx->hi_ev) (void)hipEventDestroy(ctx->hi_ev);
+  if (ctx->hi_stream) (void)hipStreamDestroy(ctx->hi_stream);
   if (ctx->sync_ev) (void)hipEventDestroy(ctx->sync_ev);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
   delete ctx;

@@ -2993,7 +2993,34 @@ extern "C" void ma_debug_prof(unsigned long long* out, int reset) {
 }
 #endif
 
+static int launch_msa_on_stream(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& a, const ma_var_out_t& o);
+// The POA rounds of a lane are short launches of few, long-lived wavefronts (one per window): next to another lane's
+// throughput kernel -- thousands of workgroups queued for every wave slot -- each of their launches waits for slots like
+// everybody else, 29 times per lane-step.  They run on a stream of the greatest priority instead: the dispatcher takes
+// their workgroups first, which costs the throughput kernels a few slots and takes the POA's chain of launches off the
+// step's critical path.  (MA_POA_PRIORITY=0: the lane's own stream, as before.)
 int launch_msa(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& a, const ma_var_out_t& o) {
+  static bool const use_hi = !(getenv("MA_POA_PRIORITY") && atoi(getenv("MA_POA_PRIORITY")) == 0);
+  if (!use_hi || b.n_windows == 0) return launch_msa_on_stream(ctx, b, a, o);
+  if (!ctx->hi_stream) {
+    int least = 0, greatest = 0;
+    MA_HIP(ctx, hipDeviceGetStreamPriorityRange(&least, &greatest));
+    MA_HIP(ctx, hipStreamCreateWithPriority(&ctx->hi_stream, hipStreamNonBlocking, greatest));
+    MA_HIP(ctx, hipEventCreateWithFlags(&ctx->hi_ev, hipEventDisableTiming));
+  }
+  hipStream_t const mine = ctx->stream;
+  MA_HIP(ctx, hipEventRecord(ctx->hi_ev, mine));
+  MA_HIP(ctx, hipStreamWaitEvent(ctx->hi_stream, ctx->hi_ev, 0));
+  ctx->stream = ctx->hi_stream;
+  int const rc = launch_msa_on_stream(ctx, b, a, o);
+  ctx->stream = mine;
+  if (hipEventRecord(ctx->hi_ev, ctx->hi_stream) != hipSuccess || hipStreamWaitEvent(mine, ctx->hi_ev, 0) != hipSuccess) {
+    ma_set_err(ctx, "ma_msa_batch: joining the POA stream failed");
+    return rc != MA_OK ? rc : MA_ERR_HIP;
+  }
+  return rc;
+}
+static int launch_msa_on_stream(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& a, const ma_var_out_t& o) {
   int const n = b.n_windows;
   if (n == 0) return MA_OK;
   ma_params_t const& P = ctx->prm;
