@@ -1467,8 +1467,10 @@ __device__ __forceinline__ void vote_pair(GArgs const& A, u64 lp, PairId id, Hap
     vtot += __shfl_xor(vtot, off);
   }
   VPROF_ACC(5);
-  if (ramb != 0)  // (wave-uniform after the reduction; one read in a hundred)
-    for (int off = 32; off > 0; off >>= 1) namb += __shfl_xor(namb, off);
+  if (ramb != 0) {  // (wave-uniform after the reduction; one read in a hundred)
+    for (int off = m <= 256 ? 4 : 32; off > 0; off >>= 1) namb += __shfl_xor(namb, off);
+    namb = static_cast<u32>(__builtin_amdgcn_readfirstlane(static_cast<int>(namb)));
+  }
   i32 const X = static_cast<i32>(mism);
   i32 const v_off = static_cast<i32>(vtot) - static_cast<i32>(best);
   // ---- a ONE-GAP alignment between the two most-voted diagonals: a lower bound for the DP's optimum (vote_settle narrows the
@@ -1500,7 +1502,8 @@ __device__ __forceinline__ void vote_pair(GArgs const& A, u64 lp, PairId id, Hap
         i32 const rel = start - i;
         u32 const from = rel <= 0 ? 0xFFFFFFFFu : (rel >= 32 ? 0u : ~((1u << rel) - 1u));
         u32 xs = __popc(second & from);
-        for (int off = 32; off > 0; off >>= 1) xs += __shfl_xor(xs, off);
+        for (int off = m <= 256 ? 4 : 32; off > 0; off >>= 1) xs += __shfl_xor(xs, off);  // (words live in lanes < m / 32)
+        xs = static_cast<u32>(__builtin_amdgcn_readfirstlane(static_cast<int>(xs)));
         return (b > a ? m : m - sgap) - 5 * static_cast<i32>(xs) - (GO + GE * sgap);
       };
       lb_two = max(one_gap(xa, xb, c, c2), one_gap(xb, xa, c2, c));
@@ -2308,6 +2311,7 @@ __device__ __forceinline__ bool align_reg_body_pk(GArgs const& A, u32 seg_words,
       u32 pa = SEGA[static_cast<size_t>(wbase) * 64 + lane], pb = SEGB[static_cast<size_t>(wbase) * 64 + lane];
 #pragma unroll
       for (int k = 0; k < NW; ++k) {
+        if (WD <= 49 && 8 * k >= wlim) break;  // (cells the row is not walked to)
         u32 const na = SEGA[static_cast<size_t>(wbase + k + 1) * 64 + lane], nb = SEGB[static_cast<size_t>(wbase + k + 1) * 64 + lane];
         u32 const xa = (sh ? ((pa >> sh) | (na << (32u - sh))) : pa) ^ qrA;
         u32 const xb = (sh ? ((pb >> sh) | (nb << (32u - sh))) : pb) ^ qrB;

@@ -1,0 +1,9 @@
+# Developer tool: the whole GPU suite + smoke + the parity sweeps (what profiles/r5_final_gpu_tests.txt and r5_sweep_* hold)
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out/r5g
+timeout 1200 python -m pytest tests -m gpu -q 2>&1 | tail -6 > gpurun_out/r5g/r5_final_gpu_tests.txt
+python -c "import __graft_entry__ as g; g.smoke()" >> gpurun_out/r5g/r5_final_gpu_tests.txt 2>&1
+timeout 1500 python3 tools/sweep_parity.py 0 > gpurun_out/r5g/r5_sweep_parity.txt 2>&1
+timeout 1500 python3 tools/sweep_parity.py 1000 > gpurun_out/r5g/r5_sweep_parity_shift1000.txt 2>&1
+timeout 900 python3 tools/sweep_parity.py 0 c4 > gpurun_out/r5g/r5_sweep_parity_c4.txt 2>&1
+timeout 600 python3 tools/sweep_poa.py > gpurun_out/r5g/r5_sweep_poa.txt 2>&1
