@@ -54,8 +54,8 @@ STAGE_OF = {"gate_kernel": "gate",
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--windows", type=int, default=16384, help="windows per step per GPU (round 5: 16384 -- a whole-genome run holds "
                                                                "~3 M windows; rounds 1-4 stepped 8192 at a time)")
     ap.add_argument("--distinct", type=int, default=16384, help="distinct synthetic windows (tiled to --windows if fewer)")
