@@ -158,3 +158,52 @@ def test_long_reads_and_long_indels():
     want, _ = _run(params, cases, wins)
     rec = want["aln_rec"].reshape(-1, 6)
     assert (rec[:, 0] > 0).sum() > 150 and (rec[:, 0] == 0).sum() > 20
+
+
+def test_pairs_whose_dp_region_the_vote_narrows():
+    """Round 5: k_vote narrows a DP pair's region from a lower bound of its optimum (align.hip: vote_settle) -- the gapless
+    path on the most-voted diagonal, a one-gap path between the two most-voted diagonals, minus the rows no path can pair,
+    reads with N -- and the kernels fill only the chunks of a row that the widest region of a group reaches.  The flavours
+    that take each of those routes, and the ones that must NOT be narrowed (soft-clipped ends: an optimum below what the
+    anchor argument needs), against the oracle's full region; tiers 2 / 3 of _run are the same engine without the
+    narrowing."""
+    params = capi.default_params(min_k=25, max_k=25, max_hap_len=2048)
+    rng = np.random.default_rng(909 + SWEEP)
+    cases, wins = [], []
+    for m in (150, 101, 250):
+        hap = rand_dna(rng, 1100)
+        alt1 = hap[:500] + hap[502:]                      # 2-base deletion: two diagonals 2 apart
+        alt2 = hap[:640] + rand_dna(rng, 1) + hap[640:]   # 1-base insertion
+        alt3 = hap[:560] + hap[567:]                      # 7-base deletion
+        reads = []
+        for src, site in ((alt1, 500), (alt2, 640), (alt3, 560)):
+            for off in range(6, m - 4, max(m // 12, 1)):  # the indel 6 bases from the read's start ... 4 from its end
+                reads.append(mutate(rng, src[site - off: site - off + m], sub=float(rng.choice([0.0, 0.0, 0.01]))))
+        for x in (3, 4, 6, 9, 12, 15):                    # mismatches only: S0 = m - 5 x is the bound
+            st = int(rng.integers(50, 900))
+            b = bytearray(hap[st: st + m])
+            for p in rng.choice(m, size=x, replace=False):
+                b[p] = BASES[(BASES.index(bytes([b[p]])) + 1) % 4]
+            reads.append(bytes(b))
+        for o in (52, 58, 63, 64, 66, 69, 70, 71, 75):   # hanging over an end by o bases, with and without a mismatch
+            if o >= m - 30:
+                continue
+            left = rand_dna(rng, o) + hap[: m - o]
+            right = hap[len(hap) - (m - o):] + rand_dna(rng, o)
+            reads += [left, right, mutate(rng, left, sub=0.01), mutate(rng, right, sub=0.01)]
+        for _ in range(8):                                # an N and an indel / a few mismatches
+            st = int(rng.integers(380, 520))
+            b = bytearray(mutate(rng, alt1[st: st + m], sub=0.01))
+            b[int(rng.integers(0, len(b)))] = ord("N")
+            reads.append(bytes(b))
+        for clip in (8, 14, 20, 26, 34):                  # soft-clipped ends: adapter-like bases the mapper clipped
+            st = int(rng.integers(50, 900))
+            reads.append(hap[st: st + m - clip] + rand_dna(rng, clip))
+            reads.append(rand_dna(rng, clip) + hap[st + clip: st + m])
+        c, w = _window([hap, alt1, alt2, alt3], reads)
+        cases.append(c)
+        wins.append(w)
+    want, kt = _run(params, cases, wins)
+    rec = want["aln_rec"].reshape(-1, 6)
+    assert (rec[:, 0] > 0).sum() > 400 and (rec[:, 0] == 0).sum() > 20
+    assert kt.get("k_align_reg", 0.0) > 0.0
