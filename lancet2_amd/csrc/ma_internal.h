@@ -103,6 +103,7 @@ struct ma_ctx {
   hipEvent_t lane_done = nullptr;
   hipStream_t hi_stream = nullptr;  // a lane's POA rounds run here, at the greatest stream priority (poa.hip: launch_msa)
   hipEvent_t hi_ev = nullptr;
+  bool hi_failed = false;
   double hbm_share = 1.0;   // fraction of the device this context plans its workspaces for
   hipEvent_t sync_ev = nullptr;  // blocking-sync event: host threads sleep instead of spinning while the stream drains
   // host route (MA_MEM_HOST) of ma_process_batch, per lane: packed result records (pack.hip) and their pinned landing area

@@ -3002,12 +3002,18 @@ static int launch_msa_on_stream(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t
 int launch_msa(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& a, const ma_var_out_t& o) {
   static bool const use_hi = !(getenv("MA_POA_PRIORITY") && atoi(getenv("MA_POA_PRIORITY")) == 0);
   if (!use_hi || b.n_windows == 0) return launch_msa_on_stream(ctx, b, a, o);
-  if (!ctx->hi_stream) {
+  if (!ctx->hi_stream && !ctx->hi_failed) {  // (a device without stream priorities: the lane's own stream, no error)
     int least = 0, greatest = 0;
-    MA_HIP(ctx, hipDeviceGetStreamPriorityRange(&least, &greatest));
-    MA_HIP(ctx, hipStreamCreateWithPriority(&ctx->hi_stream, hipStreamNonBlocking, greatest));
-    MA_HIP(ctx, hipEventCreateWithFlags(&ctx->hi_ev, hipEventDisableTiming));
+    if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess ||
+        hipStreamCreateWithPriority(&ctx->hi_stream, hipStreamNonBlocking, greatest) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->hi_ev, hipEventDisableTiming) != hipSuccess) {
+      (void)hipGetLastError();
+      if (ctx->hi_stream) (void)hipStreamDestroy(ctx->hi_stream);
+      ctx->hi_stream = nullptr;
+      ctx->hi_failed = true;
+    }
   }
+  if (!ctx->hi_stream) return launch_msa_on_stream(ctx, b, a, o);
   hipStream_t const mine = ctx->stream;
   MA_HIP(ctx, hipEventRecord(ctx->hi_ev, mine));
   MA_HIP(ctx, hipStreamWaitEvent(ctx->hi_stream, ctx->hi_ev, 0));
