@@ -903,7 +903,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MA_VOTE_WAV
       u64 const lo64 = static_cast<u64>(static_cast<u32>(__shfl(static_cast<int>(wl), k))) | (static_cast<u64>(static_cast<u32>(__shfl(static_cast<int>(wl), k + 1))) << 32);
       u64 const hi64 = static_cast<u64>(static_cast<u32>(__shfl(static_cast<int>(wh), k))) | (static_cast<u64>(static_cast<u32>(__shfl(static_cast<int>(wh), k + 1))) << 32);
       u32 cnt = 0;
+      // this lane's extreme diagonals and the votes ON each (two diagonals without a repeat are settled here too: below)
       i32 dmin = 0x7FFFFFFF, dmax = -0x7FFFFFFF;
+      u32 clo = 0, chi = 0;
+      auto add_votes = [&](i32 dl, u32 nl, i32 dh, u32 nh) {  // nl votes on dl <= dh, nh on dh (the same votes when dl == dh)
+        if (dl < dmin) {
+          dmin = dl;
+          clo = nl;
+        } else if (dl == dmin) {
+          clo += nl;
+        }
+        if (dh > dmax) {
+          dmax = dh;
+          chi = nh;
+        } else if (dh == dmax) {
+          chi += nh;
+        }
+      };
       u32 multi = 0;
       // (the loop is bound by VALU issue -- ~60 instructions per lane and position in its first form, five waves per SIMD:
       //  every load below is unconditional with a harmless address, every update a select, the 64-bit shifts one per batch)
@@ -928,23 +944,34 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MA_VOTE_WAV
           jv[tt] = tt < nact ? jv[tt] : 0xFFFFu;
           ev[tt] = code[jv[tt] != 0xFFFFu ? jv[tt] : 0u];
         }
-        u32 pend = 0;
+        u32 pend = 0, hits = 0, cntb = 0;
         u32 bmin = 0xFFFFFFFFu, bmax = 0u;  // extremes of j + 8 - tt over this batch's first-probe hits
 #pragma unroll
         for (int tt = 0; tt < 8; ++tt) {
           bool const have = jv[tt] != 0xFFFFu, same = same_code(ev[tt], cdv[tt]);
           bool const hit = have && same;
           pend |= (have && !same) ? (1u << tt) : 0u;
+          hits |= hit ? (1u << tt) : 0u;
           u32 const vb = jv[tt] + static_cast<u32>(8 - tt);
           bmin = min(bmin, hit ? vb : 0xFFFFFFFFu);
           bmax = max(bmax, hit ? vb : 0u);
-          cnt += hit ? 1u : 0u;
+          cntb += hit ? 1u : 0u;
           multi |= hit ? ev[tt] : 0u;  // (only bit 31 is looked at)
+        }
+        cnt += cntb;
+        u32 nlo = cntb, nhi = cntb;
+        if (__ballot(bmax != 0u && bmin != bmax) != 0ull) {  // a lane whose eight positions straddle the indel: votes per extreme
+          nlo = nhi = 0;
+#pragma unroll
+          for (int tt = 0; tt < 8; ++tt) {
+            u32 const vb = jv[tt] + static_cast<u32>(8 - tt);
+            nlo += ((hits >> tt) & 1u) && vb == bmin ? 1u : 0u;
+            nhi += ((hits >> tt) & 1u) && vb == bmax ? 1u : 0u;
+          }
         }
         if (bmax != 0u) {
           i32 const base = s + t0 + 8;
-          dmin = min(dmin, static_cast<i32>(bmin) - base);
-          dmax = max(dmax, static_cast<i32>(bmax) - base);
+          add_votes(static_cast<i32>(bmin) - base, nlo, static_cast<i32>(bmax) - base, nhi);
         }
         // Buckets shared with other 11-mers (one probe in ten): every lane walks ITS pending chains one after the other --
         // a handful of LDS instructions for the wave.  (All eight positions in lock step issued sixteen, mostly empty, per
@@ -970,8 +997,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MA_VOTE_WAV
           if (j != 0xFFFFu) {
             i32 const d = static_cast<i32>(j) - (s + t0 + static_cast<i32>(tt));
             ++cnt;
-            dmin = min(dmin, d);
-            dmax = max(dmax, d);
+            add_votes(d, 1u, d, 1u);
             multi |= e;
           }
         }
@@ -982,13 +1008,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MA_VOTE_WAV
 #if defined(MA_VOTE_STOP) && MA_VOTE_STOP == 6  // (developer timing build: the lookups run, every listed read is then called 'no shared 11-mer'; results invalid)
       if (cnt != 0x12345678u) cnt = 0;
 #endif
+      i32 const lmin = dmin, lmax = dmax;
       dmin = grp8_min(dmin);
       dmax = grp8_max(dmax);
       multi = grp8_or(multi);
       bool const unan = gv && multi == 0 && (cnt == 0 || dmin == dmax);
-      bool const anchored = unan && cnt >= kMinChainVotes;
-      // mismatches of the gapless path on c = dmin (vote_pair's rule: only when the read is inside or overhangs ONE end)
-      i32 const c = anchored ? dmin : 0;
+      // TWO diagonals, no repeat (a read across an indel of the other allele, both sides long enough to vote): what the
+      // histogram route would find is two counters -- na votes on da = dmin, nb on db = dmax, nothing else (every vote
+      // is on one of the group's two extremes iff the votes on them add up to all of them).  Most-voted diagonal, ties to
+      // the smaller; runner-up = the other; anchors: a diagonal with >= kMinChainVotes votes within reach K of it.
+      u32 const na = grp8_sum(lmin == dmin ? clo : (lmax == dmin ? chi : 0u));
+      u32 const nb = grp8_sum(lmax == dmax ? chi : (lmin == dmax ? clo : 0u));
+      bool const two = gv && multi == 0 && cnt != 0 && dmin != dmax && na + nb == cnt;
+      i32 const Kq = m - A.prm.min_aln_score - GO > 0 ? (m - A.prm.min_aln_score - GO) / GE : 0;
+      bool const near2 = two && dmax - dmin <= Kq;
+      bool const ancA = two && na + (near2 ? nb : 0u) >= kMinChainVotes, ancB = two && nb + (near2 ? na : 0u) >= kMinChainVotes;
+      bool const anchored = (unan && cnt >= kMinChainVotes) || ancA || ancB;
+      // mismatches of the gapless path on the most-voted diagonal c (vote_pair's rule: only when the read is inside or
+      // overhangs ONE end)
+      i32 const c2 = two ? (na >= nb ? dmax : dmin) : 0;  // the runner-up
+      i32 const c = anchored ? (two ? (na >= nb ? dmin : dmax) : dmin) : 0;
       i32 const o_left = c < 0 ? -c : 0, o_right = c + m > static_cast<i32>(n) ? c + m - static_cast<i32>(n) : 0;
       i32 const qs = o_left, qe = m - o_right;
       u32 mism = 0;
@@ -1005,17 +1044,47 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MA_VOTE_WAV
         }
       }
       mism = grp8_sum(mism);
+      // the one-gap lower bound between the two diagonals (see vote_pair), on the group's eight words
+      i32 lb_two = -(1 << 20);
+      i32 const vmin2 = ancA ? dmin : dmax, vmax2 = ancB ? dmax : dmin;  // extreme anchors of a two-diagonal vote
+      if (__ballot(two && anchored) != 0ull) {
+        bool const okc = two && anchored && c >= 0 && c + m <= static_cast<i32>(n) && c2 >= 0 && c2 + m <= static_cast<i32>(n) &&
+                         c >= vmin2 && c <= vmax2 && c2 >= vmin2 && c2 <= vmax2;
+        i32 const i = 32 * static_cast<i32>(x);
+        u32 xa = 0, xb = 0;
+        if (okc && i < m) {
+          u32 const vmask = m - i >= 32 ? 0xFFFFFFFFu : ((1u << (m - i)) - 1u);
+          xa = ((wl ^ plane32(ix.hlo, c + i)) | (wh ^ plane32(ix.hhi, c + i))) & vmask;
+          xb = ((wl ^ plane32(ix.hlo, c2 + i)) | (wh ^ plane32(ix.hhi, c2 + i))) & vmask;
+        }
+        auto one_gap = [&](u32 first, u32 second, i32 a, i32 b) -> i32 {
+          i32 const t = min(m, grp8_min(first ? i + static_cast<i32>(__builtin_ctz(first)) : 0x7FFFFFFF));
+          i32 const sgap = b > a ? b - a : a - b;
+          i32 const start = b > a ? t : t + sgap;  // the first row on the second diagonal
+          i32 const rel = start - i;
+          u32 const from = rel <= 0 ? 0xFFFFFFFFu : (rel >= 32 ? 0u : ~((1u << rel) - 1u));
+          i32 const xs = static_cast<i32>(grp8_sum(static_cast<u32>(__popc(second & from))));
+          return start > m ? -(1 << 20) : (b > a ? m : m - sgap) - 5 * xs - (GO + GE * sgap);
+        };
+        i32 const g1 = one_gap(xa, xb, c, c2), g2 = one_gap(xb, xa, c2, c);
+        if (okc) lb_two = max(g1, g2);
+      }
       TRIP_STAMP(tgB);
       u32 act = kVoteNoHit;
-      if (unan && x == 0) {
+      if ((unan || two) && x == 0) {
         u64 const lp = p - A.pair0;
         if (!anchored) {  // no shared 11-mer, or fewer than a chain needs: no hit
           A.ws.centre[lp] = 0x7FFFFFFF;
           write_no_hit(A, lp);
-        } else {
-          i32 const K = m - A.prm.min_aln_score - GO > 0 ? (m - A.prm.min_aln_score - GO) / GE : 0;
-          act = vote_settle(A, lp, PairId{w, r0 + ri, static_cast<u32>(slot)}, m, static_cast<i32>(n), c, c, c, K, static_cast<i32>(mism), false,
+        } else if (unan) {
+          act = vote_settle(A, lp, PairId{w, r0 + ri, static_cast<u32>(slot)}, m, static_cast<i32>(n), c, c, c, Kq, static_cast<i32>(mism), false,
                             false, false, 0, 0, 0u, 0u, 0u);
+        } else {
+          u32 const v2 = min(na, nb);
+          u32 const far = static_cast<u32>(dmax - dmin);
+          act = vote_settle(A, lp, PairId{w, r0 + ri, static_cast<u32>(slot)}, m, static_cast<i32>(n), c, vmin2, vmax2, Kq, static_cast<i32>(mism),
+                            false, false, false, static_cast<i32>(v2), static_cast<i32>(v2), far > 8u ? v2 : 0u, far > 16u ? v2 : 0u,
+                            far > 24u ? v2 : 0u, lb_two);
         }
       }
 #if defined(MA_VOTE_STOP) && MA_VOTE_STOP == 7  // (developer timing build: the group vote's DP pairs are not queued; results invalid)
@@ -1039,11 +1108,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MA_VOTE_WAV
         if (ix.dpbuf[64] == 64u) vote_flush_dp(A, ix, lane);
       }
       // what stays listed (compacted in place: nB <= q, and the entries up to q + 15 have been read)
-      unsigned long long const stay = __ballot(valid && !unan && x == 0);
+      unsigned long long const stay = __ballot(valid && !(unan || two) && x == 0);
 #ifdef MA_PROFILE_TRIPS  // (census of what stays listed: a repeat / two or more diagonals without a repeat / not voted here at all)
       if (lane == 0) {
         atomicAdd(&g_vprof[9], static_cast<unsigned long long>(__popcll(__ballot(valid && gv && multi != 0 && x == 0))));
-        atomicAdd(&g_vprof[10], static_cast<unsigned long long>(__popcll(__ballot(valid && gv && multi == 0 && !unan && x == 0))));
+        atomicAdd(&g_vprof[10], static_cast<unsigned long long>(__popcll(__ballot(valid && gv && multi == 0 && !unan && !two && x == 0))));
         atomicAdd(&g_vprof[11], static_cast<unsigned long long>(__popcll(__ballot(valid && !gv && x == 0))));
       }
 #endif
