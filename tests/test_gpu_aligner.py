@@ -180,7 +180,7 @@ def test_pairs_whose_dp_region_the_vote_narrows():
             for off in range(6, m - 4, max(m // 12, 1)):  # the indel 6 bases from the read's start ... 4 from its end
                 reads.append(mutate(rng, src[site - off: site - off + m], sub=float(rng.choice([0.0, 0.0, 0.01]))))
         for x in (3, 4, 6, 9, 12, 15):                    # mismatches only: S0 = m - 5 x is the bound
-            st = int(rng.integers(50, 900))
+            st = int(rng.integers(50, len(hap) - m - 1))
             b = bytearray(hap[st: st + m])
             for p in rng.choice(m, size=x, replace=False):
                 b[p] = BASES[(BASES.index(bytes([b[p]])) + 1) % 4]
@@ -197,7 +197,7 @@ def test_pairs_whose_dp_region_the_vote_narrows():
             b[int(rng.integers(0, len(b)))] = ord("N")
             reads.append(bytes(b))
         for clip in (8, 14, 20, 26, 34):                  # soft-clipped ends: adapter-like bases the mapper clipped
-            st = int(rng.integers(50, 900))
+            st = int(rng.integers(50, len(hap) - m - 1))
             reads.append(hap[st: st + m - clip] + rand_dna(rng, clip))
             reads.append(rand_dna(rng, clip) + hap[st + clip: st + m])
         c, w = _window([hap, alt1, alt2, alt3], reads)
