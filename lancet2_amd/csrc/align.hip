@@ -2743,6 +2743,27 @@ __global__ __launch_bounds__(256) void k_tap_records(GArgs A, u64 total_pairs) {
   }
 }
 
+// The evidence table of a window: [ev_cap] slots are reserved for every window (the largest one sizes them), a window uses
+// the first ev_slots() of its own -- a power of two holding 1.5 x (its reads x its variants) keys, every read files at most
+// one key per variant -- and only those are cleared per batch: 1-2 k of the 8 k slots on the whole-genome workload (the two
+// whole-array memsets were 1.6 GB per step of 16384 windows, 2.3 ms of fill kernels).
+__device__ __forceinline__ u32 ev_slots(u32 nrw, u32 nv, u32 cap_max) {
+  u64 const need = static_cast<u64>(nrw) * nv * 3u / 2u + 16u;
+  if (need >= cap_max) return cap_max;
+  u32 const c = 1u << (32 - __builtin_clz(static_cast<u32>(need) - 1u));
+  return min(max(c, 64u), cap_max);
+}
+__global__ __launch_bounds__(256) void k_ev_clear(GArgs A) {
+  int const w = blockIdx.x;
+  u32 const nv = A.v.win_nvars[w];
+  if (nv == 0 || A.ws.win_slotmask[w] == 0) return;  // (k_assign / k_evidence leave at the same test)
+  u32 const cap = ev_slots(A.b.read_win_off[w + 1] - A.b.read_win_off[w], nv, A.ws.ev_cap);
+  u64* evk = A.ws.ev_key + static_cast<size_t>(w) * A.ws.ev_cap;
+  u32* evm = A.ws.ev_min + static_cast<size_t>(w) * A.ws.ev_cap;
+  for (u32 x = threadIdx.x; x < cap / 2; x += 256) reinterpret_cast<uint4*>(evk)[x] = make_uint4(0u, 0u, 0u, 0u);
+  for (u32 x = threadIdx.x; x < cap / 4; x += 256) reinterpret_cast<uint4*>(evm)[x] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+}
+
 // AssignReadToAlleles (genotyper.cpp:269-321): one lane per read
 __global__ __launch_bounds__(64) void k_assign(GArgs A) {
   i64 const r = static_cast<i64>(blockIdx.x) * 64 + threadIdx.x;
@@ -2752,18 +2773,19 @@ __global__ __launch_bounds__(64) void k_assign(GArgs A) {
   int const w = static_cast<int>(A.ws.read_win[r]);  // (k_plan)
   u8* asg = A.ws.asg_allele + static_cast<size_t>(r) * MV;
   // ("unassigned" for every variant slot: 16 bytes per store -- 64 one-byte stores per lane were most of this kernel's writes)
-  auto fill255 = [&](u8* dst) {
+  auto fill255 = [&](u8* dst, int cnt) {
     if ((MV & 15) == 0 && (reinterpret_cast<uintptr_t>(dst) & 15u) == 0) {
-      for (int v = 0; v < MV; v += 16) *reinterpret_cast<uint4*>(dst + v) = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+      for (int v = 0; v < cnt; v += 16) *reinterpret_cast<uint4*>(dst + v) = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
     } else {
-      for (int v = 0; v < MV; ++v) dst[v] = 255;
+      for (int v = 0; v < cnt; ++v) dst[v] = 255;
     }
   };
-  fill255(asg);
-  if (A.o.asg_allele) fill255(A.o.asg_allele + static_cast<size_t>(r) * MV);
+  u32 const nv = A.v.win_nvars[w];
+  // (the internal copy is read by k_evidence alone, for the window's nv variants: a window has one to three, the array 64 slots)
+  fill255(asg, min(MV, static_cast<int>((nv + 15u) & ~15u)));
+  if (A.o.asg_allele) fill255(A.o.asg_allele + static_cast<size_t>(r) * MV, MV);
   if (A.o.asg_score)
     for (int v = 0; v < MV; ++v) A.o.asg_score[static_cast<size_t>(r) * MV + v] = 0.0;
-  u32 const nv = A.v.win_nvars[w];
   u32 const mask = A.ws.win_slotmask[w];
   if (nv == 0 || mask == 0) return;
   // the records of this read: pair_off[w] + (rank of the haplotype's slot) * reads of the window + the read's place in it
@@ -2777,7 +2799,7 @@ __global__ __launch_bounds__(64) void k_assign(GArgs A) {
   u32 const qn = A.b.read_qname_id[r];
   u64* evk = A.ws.ev_key + static_cast<size_t>(w) * A.ws.ev_cap;
   u32* evm = A.ws.ev_min + static_cast<size_t>(w) * A.ws.ev_cap;
-  u32 const evmask = A.ws.ev_cap - 1;
+  u32 const evmask = ev_slots(nrw, nv, A.ws.ev_cap) - 1;
 
   for (u32 c = 0; c < A.a.win_ncomp[w]; ++c) {
     size_t const ci = static_cast<size_t>(w) * P.max_comps + c;
@@ -2860,7 +2882,7 @@ __global__ __launch_bounds__(64) void k_evidence(GArgs A) {
   u32 const rev = (A.b.read_flags[r] & MA_RF_REV) ? 1u : 0u;
   const u64* evk = A.ws.ev_key + static_cast<size_t>(w) * A.ws.ev_cap;
   const u32* evm = A.ws.ev_min + static_cast<size_t>(w) * A.ws.ev_cap;
-  u32 const evmask = A.ws.ev_cap - 1;
+  u32 const evmask = ev_slots(A.b.read_win_off[w + 1] - A.b.read_win_off[w], nv, A.ws.ev_cap) - 1;
   u32 const rloc = static_cast<u32>(r - A.b.read_win_off[w]);
   for (u32 v = 0; v < nv; ++v) {
     u32 const al = asg[v];
@@ -3064,8 +3086,6 @@ int launch_genotype(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& a, const m
   MA_HIP(ctx, ctx->ws_aln.reserve(fixed + 4096));
   carve_fixed(static_cast<char*>(ctx->ws_aln.p));
   MA_HIP(ctx, hipMemsetAsync(ws.counters, 0, 64, ctx->stream));
-  MA_HIP(ctx, hipMemsetAsync(ws.ev_key, 0, 8ull * n * ws.ev_cap, ctx->stream));
-  MA_HIP(ctx, hipMemsetAsync(ws.ev_min, 0xFF, 4ull * n * ws.ev_cap, ctx->stream));
   MA_HIP(ctx, hipMemsetAsync(A.o.allele_counts, 0,
                              4ull * n * MV * P.num_samples * (P.max_alts + 1) * 2, ctx->stream));
   // every planned pair gets its hit flag written (a record, or an explicit "no alignment"): only the caller's debug
@@ -3081,6 +3101,7 @@ int launch_genotype(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& a, const m
   ctx->tic("k_plan");
   hipLaunchKernelGGL(k_plan, dim3((n + 127) / 128), dim3(128), 0, ctx->stream, A);
   hipLaunchKernelGGL(k_plan_reads, dim3((n + 3) / 4), dim3(256), 0, ctx->stream, A);
+  hipLaunchKernelGGL(k_ev_clear, dim3(n), dim3(256), 0, ctx->stream, A);  // (after k_plan: it reads the windows' slot masks)
   hipLaunchKernelGGL(k_scan_pairs, dim3(1), dim3(1024), 0, ctx->stream, ws.pair_off, n);
   ctx->toc();
   u64 total_pairs = 0;
