@@ -2993,6 +2993,27 @@ extern "C" void ma_debug_prof(unsigned long long* out, int reset) {
 }
 #endif
 
+// longest haplotype that is aligned and the most alignments of any window (what launch_msa sizes the graph and its rounds by)
+__global__ __launch_bounds__(256) void k_msa_maxima(ma_asm_out_t a, int n, u32 max_haps, u32 max_comps, u32* out) {
+  int const w = blockIdx.x * 256 + threadIdx.x;
+  u32 ml = 0, al = 0;
+  if (w < n && !(a.win_status[w] & MA_W_NO_HAPLOTYPE)) {
+    for (u32 c = 0; c < a.win_ncomp[w]; ++c) {
+      size_t const ci = static_cast<size_t>(w) * max_comps + c;
+      u32 const nh = a.comp_nhaps[ci], h0 = a.comp_hap0[ci];
+      for (u32 h = 0; h < nh; ++h) ml = max(ml, a.hap_len[static_cast<size_t>(w) * max_haps + h0 + h]);
+      al += nh > 1 ? nh - 1 : 0;
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    ml = max(ml, __shfl_xor(ml, off));
+    al = max(al, __shfl_xor(al, off));
+  }
+  if ((threadIdx.x & 63) == 0) {
+    if (ml) atomicMax(&out[0], ml);
+    if (al) atomicMax(&out[1], al);
+  }
+}
 static int launch_msa_on_stream(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& a, const ma_var_out_t& o);
 // The POA rounds of a lane are short launches of few, long-lived wavefronts (one per window): next to another lane's
 // throughput kernel -- thousands of workgroups queued for every wave slot -- each of their launches waits for slots like
@@ -3042,24 +3063,18 @@ static int launch_msa_on_stream(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t
   // longest haplotype of the batch decides the DP width and the LDS graph capacity (one small D2H)
   u32 max_len = 0, rounds = 1;  // rounds: split mode, 1 + the most alignments of any window
   {
-    size_t const cnt = static_cast<size_t>(n) * P.max_haps;
-    std::vector<u32> hl(cnt), st(n), nc(n), h0(static_cast<size_t>(n) * P.max_comps), nh(static_cast<size_t>(n) * P.max_comps);
-    MA_HIP(ctx, hipMemcpyAsync(hl.data(), a.hap_len, cnt * 4, hipMemcpyDeviceToHost, ctx->stream));
-    MA_HIP(ctx, hipMemcpyAsync(st.data(), a.win_status, 4ull * n, hipMemcpyDeviceToHost, ctx->stream));
-    MA_HIP(ctx, hipMemcpyAsync(nc.data(), a.win_ncomp, 4ull * n, hipMemcpyDeviceToHost, ctx->stream));
-    MA_HIP(ctx, hipMemcpyAsync(h0.data(), a.comp_hap0, 4ull * n * P.max_comps, hipMemcpyDeviceToHost, ctx->stream));
-    MA_HIP(ctx, hipMemcpyAsync(nh.data(), a.comp_nhaps, 4ull * n * P.max_comps, hipMemcpyDeviceToHost, ctx->stream));
+    // (on the device: the five arrays used to come back whole -- 0.3 MB per lane into pageable memory, staged copies and a
+    //  host loop in front of every lane's POA rounds -- for two numbers)
+    MA_HIP(ctx, ctx->ws_poa.reserve(4096));
+    u32* mx = static_cast<u32*>(ctx->ws_poa.p);
+    MA_HIP(ctx, hipMemsetAsync(mx, 0, 8, ctx->stream));
+    hipLaunchKernelGGL(k_msa_maxima, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, a, n, static_cast<u32>(P.max_haps),
+                       static_cast<u32>(P.max_comps), mx);
+    u32 got[2] = {0, 0};
+    MA_HIP(ctx, hipMemcpyAsync(got, mx, 8, hipMemcpyDeviceToHost, ctx->stream));
     MA_HIP(ctx, ma_stream_sync(ctx));
-    for (int w = 0; w < n; ++w) {
-      if (st[w] & MA_W_NO_HAPLOTYPE) continue;
-      u32 alignments = 0;
-      for (u32 c = 0; c < nc[w]; ++c) {
-        size_t const ci = static_cast<size_t>(w) * P.max_comps + c;
-        for (u32 h = 0; h < nh[ci]; ++h) max_len = std::max(max_len, hl[static_cast<size_t>(w) * P.max_haps + h0[ci] + h]);
-        alignments += nh[ci] > 1 ? nh[ci] - 1 : 0;
-      }
-      rounds = std::max(rounds, alignments + 1);
-    }
+    max_len = got[0];
+    rounds = std::max<u32>(1u, got[1] + 1u);
   }
   max_len = std::max<u32>(max_len, 16);
   ws.max_l = max_len;
