@@ -578,7 +578,9 @@ int launch_assemble(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& out, const
         }
         if (ws.n_active > 0) {
           if (!nested) ctx->stats[3] += static_cast<unsigned long long>(ws.n_active);
-          MA_TRY_RC(run_count_inst(ctx, b, ws, win0, nwin, counters));
+          // (a single rung: every window is attempted at the k the capacity planning above counted it at -- the per-sequence
+          //  instance bases and the windows' totals are already there)
+          if (nested || P.min_k != P.max_k) MA_TRY_RC(run_count_inst(ctx, b, ws, win0, nwin, counters));
           ws.tc_log2 = tc_log2_alloc;
           ws.mc_log2 = mc_log2_alloc;  // run_build_pass shrinks both to what this attempt needs
           MA_TRY_RC(run_build_pass(ctx, b, ws, counters + 12, tc_log2_alloc));
