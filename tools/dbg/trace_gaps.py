@@ -13,6 +13,7 @@ for f in glob.glob(d + "/**/*memory_copy_trace.csv", recursive=True):
 ks.sort()
 t0 = ks[0][0]
 tail = float(sys.argv[2]) if len(sys.argv) > 2 else 300.0  # analyse the last `tail` ms
+thr = float(sys.argv[3]) if len(sys.argv) > 3 else 0.2       # report gaps longer than this (ms)
 tend = max(e for _, e, _ in ks)
 lo = tend - int(tail * 1e6)
 cur_s, cur_e = None, None
@@ -33,8 +34,14 @@ for s, e, nm in ks:
     last_name = nm
 busy += cur_e - cur_s
 print("window %.1f ms, kernels busy (union) %.1f ms, idle %.1f ms" % ((tend - lo) / 1e6, busy / 1e6, (tend - lo - busy) / 1e6))
+import collections
+agg = collections.Counter()
 for a, b, n1, n2 in gaps:
-    if b - a > 200_000:
+    agg[(n1[:28], n2[:28])] += b - a
+for (n1, n2), v in agg.most_common(25):
+    print("  idle %.2f ms in all between %s -> %s" % (v / 1e6, n1, n2))
+for a, b, n1, n2 in gaps:
+    if b - a > thr * 1e6:
         print("  gap %.2f ms at t=%.1f ms: after %s, before %s" % ((b - a) / 1e6, (a - lo) / 1e6, n1, n2))
 big = [(s, e, dr, sz) for s, e, dr, sz in cs if e >= lo and sz > (1 << 20)]
 tot = {}
