@@ -56,7 +56,7 @@ def run(engs, steps_each):
     return dt * 1e3 / total
 
 
-os.environ["MA_HBM_SHARE"] = "0.5"
+os.environ["MA_HBM_SHARE"] = os.environ.get("MA_HBM_SHARE", "0.5")
 engs = [setup(), setup()]
 one = run(engs[:1], 2 * K)
 two = run(engs, K)
