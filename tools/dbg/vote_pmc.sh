@@ -13,4 +13,4 @@ timeout 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VM
   --kernel-trace --output-format csv -d $O/pmc_b -- $B > $O/pmc_b.log 2>&1
 timeout 600 rocprofv3 --pmc SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_LDS_MEM_VIOLATIONS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_FLAT SQ_INST_CYCLES_SALU SQ_THREAD_CYCLES_VALU \
   --kernel-trace --output-format csv -d $O/pmc_c -- $B > $O/pmc_c.log 2>&1
-for p in a b c; do python3 tools/dbg/pmc_generic.py $O/pmc_$p "k_vote|k_align_reg|k_support|k_classify|k_msa" > $O/vote_pmc_$p.txt 2>&1; tail -3 $O/pmc_$p.log >> $O/vote_pmc_$p.txt; rm -rf $O/pmc_$p; done
+for p in a b c; do python3 tools/dbg/pmc_generic.py $O/pmc_$p "${PMC_KERNELS:-k_vote|k_align_reg|k_support|k_classify|k_msa}" > $O/vote_pmc_$p.txt 2>&1; tail -3 $O/pmc_$p.log >> $O/vote_pmc_$p.txt; rm -rf $O/pmc_$p; done
