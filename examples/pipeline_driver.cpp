@@ -176,9 +176,10 @@ int main(int argc, char** argv) {
   // thread.  glibc serves blocks of that size with mmap / munmap -- a system call, fresh page faults and the process-wide
   // address-space lock per array, which is what kept eight collectors from being faster than one.  From the heap arenas
   // (one per thread) the same blocks are recycled without leaving user space.  (The reference links mimalloc for the same reason.)
-  mallopt(M_MMAP_THRESHOLD, 1 << 30);
-  mallopt(M_TRIM_THRESHOLD, 1 << 30);
-  mallopt(M_TOP_PAD, 64 << 20);
+  // (64-bit glibc caps M_MMAP_THRESHOLD at HEAP_MAX_SIZE / 2 = 32 MiB and REJECTS anything larger, leaving the 128 KiB default
+  //  in force -- ADVICE r5; the flat arrays are far below 32 MiB)
+  if (mallopt(M_MMAP_THRESHOLD, 32 << 20) != 1 || mallopt(M_TRIM_THRESHOLD, 1 << 30) != 1 || mallopt(M_TOP_PAD, 64 << 20) != 1)
+    std::fprintf(stderr, "pipeline_driver: mallopt rejected a setting; large arrays fall back to mmap (slower, still correct)\n");
   std::string ref_path, out_path, dump_dir, vcf_path, command_line;
   for (int i = 0; i < argc; ++i) command_line += std::string(i ? " " : "") + argv[i];
   double gc_frac = 0.41;  // --genome-gc-bias of the reference CLI: background GC of the LongdustQ null model
@@ -234,8 +235,13 @@ int main(int argc, char** argv) {
     name = name.substr(0, name.find_last_of('.'));
     samples.push_back({name, tag, nullptr, 0, 0, 0});
   };
-  for (auto const& p : normals) add_sample(p, Tag::CTRL);
-  for (auto const& p : tumors) add_sample(p, Tag::CASE);
+  try {  // (an eager source -- SAM text, an unindexed BAM -- is decoded here: a corrupt record ends the run as it does on a collector thread)
+    for (auto const& p : normals) add_sample(p, Tag::CTRL);
+    for (auto const& p : tumors) add_sample(p, Tag::CASE);
+  } catch (std::exception const& e) {
+    std::fprintf(stderr, "pipeline_driver: %s\n", e.what());
+    return 5;
+  }
   for (size_t i = 0; i < samples.size(); ++i) samples[i].source = &sources[i];
   prm.num_samples = static_cast<int32_t>(samples.size());
   prm.case_ctrl_mode = (!normals.empty() && !tumors.empty()) ? 1 : 0;  // read_collector.cpp:88-94

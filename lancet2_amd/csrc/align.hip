@@ -3225,16 +3225,19 @@ int launch_genotype(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& a, const m
         }
         // two register classes of the same register budget, side by side in one launch (k_align_reg2) when both fit the
         // traceback workspace whole
-        if (!wave && cls < kNumReg && reg_waves(reg_width(cls)) == MA_RW49 && !getenv("MA_NO_PAIR")) {
+        // (only the classes of at most 49 cells have a paired / packed instantiation: class 3 -- 65 cells -- shares
+        //  reg_waves() == 3 with them when MA_RW49 is 3 and must NOT be taken for one of them)
+        auto pair_class = [&](int c) { return c < kNumReg && reg_width(c) <= 49; };
+        if (!wave && pair_class(cls) && !getenv("MA_NO_PAIR")) {
           int c2 = -1;
           for (int c = cls + 1; c < kNumReg; ++c) {
             if (class_n(c) == 0) continue;
-            if (!class_wave(c) && reg_waves(reg_width(c)) == MA_RW49) c2 = c;
+            if (!class_wave(c) && pair_class(c)) c2 = c;
             break;
           }
           // (all three 49-register classes in use -- the narrowed regions fill the first: it runs alone, the other two side by
           //  side, two full launches instead of a full one and a sparse one)
-          if (cls == 0 && c2 == 1 && class_n(2) != 0 && !class_wave(2) && reg_waves(reg_width(2)) == MA_RW49) c2 = -1;
+          if (cls == 0 && c2 == 1 && class_n(2) != 0 && !class_wave(2)) c2 = -1;
           // (a class without a partner still takes the packed launch, beside an EMPTY neighbour class: with the regions
           //  narrowed there are pairs in all three classes, and the third fell back to one pair per lane)
           bool const pk_env = !(getenv("MA_ALIGN_PK") && atoi(getenv("MA_ALIGN_PK")) == 0);
@@ -3273,6 +3276,10 @@ int launch_genotype(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& a, const m
                 off += static_cast<size_t>(sg.units) * ws.tb_rows * tw[x] * per * 4;
               }
               u32 const units = pl.seg[0].units + pl.seg[1].units + pl.seg[2].units + pl.seg[3].units;
+              if (hi_c > 2 || lo_c >= hi_c || gwl > static_cast<u32>(reg_width(lo_c)) || gw2 > static_cast<u32>(reg_width(hi_c))) {
+                ma_set_err(ctx, "read aligner: a width class without a packed instantiation reached the packed launch");
+                return MA_ERR_HIP;
+              }
               if (off <= tb_cap && units > 0) {
                 if (!solo) ctx->stats[4 + (c2 < 2 ? 0 : (c2 < 4 ? 1 : 2))] += n2;
                 u32 const segw = (max_read_len + gw2 + 7) / 8 + 3;

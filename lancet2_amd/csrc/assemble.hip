@@ -579,8 +579,11 @@ int launch_assemble(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& out, const
         if (ws.n_active > 0) {
           if (!nested) ctx->stats[3] += static_cast<unsigned long long>(ws.n_active);
           // (a single rung: every window is attempted at the k the capacity planning above counted it at -- the per-sequence
-          //  instance bases and the windows' totals are already there)
-          if (nested || P.min_k != P.max_k) MA_TRY_RC(run_count_inst(ctx, b, ws, win0, nwin, counters));
+          //  instance bases and the windows' totals are already there.  INVARIANT the skip rests on: the planning
+          //  call counted EVERY window at min_k == max_k == this k; seq_inst_base / win_ninst live in the misc carve that no
+          //  chunk, capacity-retry pass or k_reset_overflowed writes (those reset node / table / arena state only).  Whoever
+          //  changes win_k handling or moves those arrays must drop the skip; MA_RECOUNT_INST=1 recounts on every pass)
+          if (nested || P.min_k != P.max_k || getenv("MA_RECOUNT_INST")) MA_TRY_RC(run_count_inst(ctx, b, ws, win0, nwin, counters));
           ws.tc_log2 = tc_log2_alloc;
           ws.mc_log2 = mc_log2_alloc;  // run_build_pass shrinks both to what this attempt needs
           MA_TRY_RC(run_build_pass(ctx, b, ws, counters + 12, tc_log2_alloc));

@@ -389,6 +389,9 @@ class AlignmentSource {
         for (char c : f[10]) r.qual.push_back(static_cast<uint8_t>(c - 33));
       else
         r.qual.assign(r.seq.size(), 0xFF);
+      // (SAM spec: QUAL is '*' or as long as SEQ.  Everything downstream sizes the quality array by SEQ -- a longer QUAL would
+      //  be written past it -- so a record that breaks the rule ends the run like a corrupt BAM record does)
+      if (r.qual.size() != r.seq.size()) throw std::runtime_error("corrupt SAM record: QUAL and SEQ differ in length (" + r.qname + ")");
       for (size_t i = 11; i < f.size(); ++i) {
         if (f[i].substr(0, 5) == "MD:Z:") {
           r.md = std::string(f[i].substr(5));
@@ -1108,7 +1111,9 @@ inline bool ReadCollector::CollectFlat(Window const& w, std::string_view ref_seq
     SamRecord const& a = *kept[i].rec;
     std::memcpy(fb.read_bases.data() + at, a.seq.data(), a.seq.size());
     uint8_t* q = fb.read_quals.data() + at;
-    for (size_t x = 0; x < a.qual.size(); ++x) q[x] = a.qual[x] == 0xFF ? 0 : a.qual[x];
+    size_t const nq = std::min(a.qual.size(), a.seq.size());  // (the arrays are sized by SEQ; the parsers reject a mismatch)
+    for (size_t x = 0; x < nq; ++x) q[x] = a.qual[x] == 0xFF ? 0 : a.qual[x];
+    for (size_t x = nq; x < a.seq.size(); ++x) q[x] = 0;
     at += a.seq.size();
     fb.read_off.push_back(at);
     size_t h = static_cast<size_t>(kept[i].qh * 0x9E3779B97F4A7C15ull >> 20) & (cap - 1);

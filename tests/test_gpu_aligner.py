@@ -207,3 +207,47 @@ def test_pairs_whose_dp_region_the_vote_narrows():
     rec = want["aln_rec"].reshape(-1, 6)
     assert (rec[:, 0] > 0).sum() > 400 and (rec[:, 0] == 0).sum() > 20
     assert kt.get("k_align_reg", 0.0) > 0.0
+
+
+def test_more_than_4096_pairs_in_the_65_cell_class():
+    """width class 3 (regions of 50-65 cells) shares reg_waves() == 3 with the classes of <= 49 cells, and the
+    packed / paired launch took it for one of them once it held more than 4096 DP pairs (below that the class is rerouted to the
+    wavefront kernel): its pairs ran through a 49-cell row body.  180-base reads have K = 29, i.e. regions of 59 + spread cells
+    whenever the region is not narrowed: reads whose last 80 bases are foreign (an optimum of ~100 -- too poor for the anchor
+    argument, so tier 0 keeps the full region) and, with the certificates off (tier 2), every read."""
+    from lancet2_amd.engine import Engine
+    params = capi.default_params(min_k=25, max_k=25, max_hap_len=2048)
+    rng = np.random.default_rng(6565 + SWEEP)
+    cases, wins = [], []
+    for _ in range(16):
+        hap = rand_dna(rng, 900)
+        alt = hap[:450] + hap[453:]
+        reads = []
+        for i in range(300):
+            st = int(rng.integers(0, len(hap) - 181))
+            src = hap if i & 1 else alt
+            if i % 3 == 0:
+                reads.append(src[st: st + 100] + rand_dna(rng, 80))
+            elif i % 3 == 1:
+                reads.append(rand_dna(rng, 80) + src[st + 80: st + 180])
+            else:
+                reads.append(mutate(rng, src[st: st + 180], sub=0.03))
+        c, w = _window([hap, alt], reads)
+        cases.append(c)
+        wins.append(w)
+    asm, var = handmade_annotation_case(params, cases)
+    arrs, n, nr = synth.pack_batch(wins)
+    want = OracleEngine(params).genotype(arrs, n, nr, asm, var)
+    for tier in (0, 2):
+        p = capi.default_params(**{f: getattr(params, f) for f, _ in capi.Params._fields_})
+        p.aln_tier = tier
+        eng = Engine(p)
+        try:
+            got = eng.genotype(arrs, n, nr, asm, var)
+            st = eng.stats()
+            kt = dict(eng.kernel_times())
+        finally:
+            eng.close()
+        assert st["dp_w65"] > 4096 and "k_align_reg" in kt, (tier, st, kt)
+        bad = compare_geno(params, got, want, n, nr, var["win_nvars"], arrs["read_win_off"])
+        assert not bad, f"aln_tier {tier}:\n" + "\n".join(bad[:20])

@@ -446,3 +446,22 @@ def test_corrupt_bam_record_ends_the_run_with_a_message_not_a_crash(tmp_path):
                        capture_output=True, text=True)
     assert r.returncode == 5, (r.returncode, r.stderr[-400:])
     assert "corrupt BAM record" in r.stderr
+
+
+def test_sam_record_with_qual_longer_than_seq_is_rejected(tmp_path):
+    """CollectFlat sizes the window's quality array by SEQ and copied QUAL at its own length -- a SAM record whose
+    QUAL is longer than SEQ (or SEQ '*' with a QUAL) wrote past the array.  The SAM parser now rejects such a record the way the
+    BAM decoder rejects a lying length field: message + exit code, no out-of-bounds write."""
+    exe = driver(tmp_path)
+    write_fixture(str(tmp_path))
+    lines = open(tmp_path / "tumor.sam").read().split("\n")
+    k = [i for i, ln in enumerate(lines) if ln and ln[0] != "@"][40]
+    f = lines[k].split("\t")
+    f[10] = f[10] + "I" * 5000
+    lines[k] = "\t".join(f)
+    (tmp_path / "tumor_bad.sam").write_text("\n".join(lines))
+    r = subprocess.run([exe, "--reference", str(tmp_path / "ref.fa"), "--normal", str(tmp_path / "normal.sam"), "--tumor",
+                        str(tmp_path / "tumor_bad.sam"), "--region", "chr1:1-6000", "--extract-only", "--extract-threads", "3"],
+                       capture_output=True, text=True)
+    assert r.returncode == 5, (r.returncode, r.stderr[-400:])
+    assert "corrupt SAM record" in r.stderr
