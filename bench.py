@@ -75,7 +75,17 @@ def parse():
     ap.add_argument("--no-also", action="store_true", help="skip the secondary measurements (k cascade, other config, host path)")
     ap.add_argument("--cpu-windows", type=int, default=64, help="oracle sample for cpu_baseline (0 = skip)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--parity-windows", type=int, default=16,
+                    help="N > 1 only (at N = 1 the cpu_baseline legs' windows are the parity sample): rank 0 runs the oracle on this many "
+                         "of ITS OWN windows before the GPU is initialised and checks the engine's outputs of the last timed step "
+                         "against them (0 = skip)")
     ap.add_argument("--gen-workers", type=int, default=0, help="processes that synthesise windows (0 = min(16, cores))")
+    ap.add_argument("--oversubscribe", action="store_true",
+                    help="rehearsal of the N > 1 launch path on a box with fewer GPUs than ranks: every rank runs on device "
+                         "(rank mod GPUs present), each planning its workspaces for its share of the HBM, and the barrier / "
+                         "max-over-ranks go through gloo (RCCL cannot put two ranks on one device).  The line says so "
+                         "(`oversubscribed`): it exercises the launcher, the sharding and the rank plumbing -- it is NOT a scaling "
+                         "measurement")
     ap.add_argument("--gen-only", action="store_true", help="synthesise the windows (into MA_BENCH_CACHE) and exit: no GPU is touched")
     return ap.parse_args()
 
@@ -119,7 +129,10 @@ def kernel_bytes(kname, st):
         "k_clean_chains": (4 * S + 8 + 4 + 4 + 16) * Nn + 4000,
         "k_clean_tail": 4000 + H * L + 64 * H,
         "k_msa": H * L + max(H - 1, 0) * 2 * 77_000 + 16 * (L + st["var_bases"]),
-        "k_msa_band": max(H - 1, 0) * (128 + 14) * (L + 1),
+        # the banded fills that actually RAN (statistics step: band cells and fills per assembled window): one code byte
+        # written per band cell, a 14-byte row descriptor and the haplotype read per fill -- half of the alignments are
+        # written down in closed form and never reach this kernel (rounds 3-5 billed every alignment a full 128-column band)
+        "k_msa_band": st.get("poa_band_cells", 0.0) + st.get("poa_band_fills", 0.0) * (14 * (L + 1) + L),
         "k_read_planes": B + 12 * (m / 32 + 2) * R,
         "k_vote": P * (12 * (m / 32 + 2) + 4 + 32) + H * L,
         "k_align_reg": Pdp * (2 * m + 45 / 2 * (m + 1) + 68),
@@ -449,7 +462,7 @@ C4_PARITY_WINDOWS = [10_488,                            # LDS mate-mer set fills
                      10_000, 10_002, 10_022]            # ordinary deep windows
 
 
-def parity_check(kept, config, first, lp, n, out_dev):
+def parity_check(kept, config, first, lp, n, out_dev, row_of=None):
     """The engine's outputs for the windows the cpu_baseline legs ran the oracle on, against the oracle's (gate, assembly,
     variants, allele counts / PL / GQ bit for bit, QUAL within 1e-9).  out_dev = (gate, asm, var, geno) dicts of device
     byte tensors of a batch of `n` windows whose window j is the seeded window first + j of `config`.
@@ -472,7 +485,10 @@ def parity_check(kept, config, first, lp, n, out_dev):
         if kp is None or kp["config"] != config:
             continue
         wins = kp["windows"]
-        runs = [(wins[0] - first, len(wins))] if wins == list(range(wins[0], wins[0] + len(wins))) else [(w - first, 1) for w in wins]
+        if row_of is None:  # batch row of seeded window w (a sharded rank holds every world-th window: main() passes its map)
+            runs = [(wins[0] - first, len(wins))] if wins == list(range(wins[0], wins[0] + len(wins))) else [(w - first, 1) for w in wins]
+        else:
+            runs = [(row_of(w), 1) for w in wins]
         if any(w0 < 0 or w0 + cnt > n for w0, cnt in runs):
             continue
         cnt_all = len(wins)
@@ -523,7 +539,7 @@ def spawn_ranks(args):
     Nothing in THIS process touches a GPU or imports torch (tests/test_bench_launcher.py checks both)."""
     import socket
     have = count_gpus_sysfs()
-    if have is not None and have < args.gpus:
+    if have is not None and have < args.gpus and not getattr(args, "oversubscribe", False):
         print(json.dumps({"error": f"--gpus {args.gpus} but this node exposes {have} GPU(s)"}))
         return 2
     s = socket.socket()
@@ -580,6 +596,8 @@ def main():
     kept = []
     if world == 1 and not args.no_cpu and args.cpu_windows > 0:
         cpu, cpu_mt, cpu_c4, kept = cpu_baselines(args, num_samples)
+    elif world > 1 and rank == 0 and args.parity_windows > 0:  # the checker on a few of rank 0's own windows (never timed)
+        kept = [_oracle_chunk((args.config, mine[:min(args.parity_windows, len(mine))], 0, num_samples, args.str_every))[2]]
 
     import torch
     import torch.distributed as dist
@@ -587,11 +605,18 @@ def main():
     if not torch.cuda.is_available():
         print(json.dumps({"error": "no GPU: the engine has no CPU fallback"}))
         sys.exit(2)
+    oversub = bool(args.oversubscribe and world > 1)
+    if oversub:  # (device_count() does not initialise the GPU on this image)
+        local_rank = local_rank % max(1, torch.cuda.device_count())
+        os.environ["MA_HBM_SHARE"] = str(round(0.9 / world, 3))  # the ranks share one device's HBM
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if oversub:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=dev)
 
     from lancet2_amd import capi, synth
     from lancet2_amd.engine import Engine
@@ -651,8 +676,9 @@ def main():
     stats = eng.stats()
     # ---- parity sample: the outputs of the LAST timed step for the windows the cpu_baseline legs ran the oracle on ----
     parity = None
-    if kept and world == 1:
-        pc, pbad, pfl = parity_check(kept, args.config, first, params, n, (g, a, v, q))
+    if kept:
+        row_of = None if world == 1 else (lambda w_: (w_ - first - rank) // world)
+        pc, pbad, pfl = parity_check(kept, args.config, first, params, n, (g, a, v, q), row_of=row_of)
         parity = {"windows": pc, "mismatches": len(pbad), "c4_windows": 0, "flagged_windows_status_only": pfl,
                   "checked": "repeat gate, haplotypes / weights / statistics (f64 bit patterns), variants and alleles, allele counts, "
                              "PL / GQ: equal; QUAL within 1e-9 -- engine outputs of the last timed step vs the oracle's for the "
@@ -674,10 +700,17 @@ def main():
     annot_k = {}
     for name, ms in eng.kernel_times():
         annot_k[name] = annot_k.get(name, 0.0) + ms / max(args.steps, 1)
+    rank_windows = None
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if oversub else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        # which seeded windows each rank ran (first / last / count + a checksum of the indices): rank 0's line shows the shards
+        mine_t = torch.tensor([mine[0], mine[-1], len(mine), sum(mine) % (1 << 31)], dtype=torch.int64, device="cpu" if oversub else dev)
+        gathered = [torch.zeros_like(mine_t) for _ in range(world)]
+        dist.all_gather(gathered, mine_t)
+        rank_windows = [{"rank": r_, "first": int(g_[0]), "last": int(g_[1]), "count": int(g_[2]), "index_sum_mod_2_31": int(g_[3])}
+                        for r_, g_ in enumerate(gathered)]
 
     # ---- workload statistics from the inputs, the results and the engine's counters ----
     status = a["win_status"].view(torch.int32).cpu().numpy().view(np.uint32)
@@ -716,6 +749,8 @@ def main():
     st.update(N_slow=wstats.get("slow_instances", 0) / attempts, N_edgeq=wstats.get("edge_queue", 0) / attempts,
               N_cntq=wstats.get("count_queue", 0) / attempts, N_nodes=wstats.get("nodes_after_lowcov", 0) / attempts,
               m=read_len, P=pairs_w * n / max(assembled, 1), P_dp=dp_w * n / max(assembled, 1), max_vars=params.max_vars)
+    st.update(poa_band_cells=wstats.get("poa_band_cells", 0) / max(assembled, 1),
+              poa_band_fills=wstats.get("poa_band_fills", 0) / max(assembled, 1))
     stage_bytes_step = {s: survey_bytes(s, st) * units_per_step(s, st) for s in ("gate", "build", "clean", "poa", "genotype")}
 
     # the metric counts ASSEMBLED windows: those that pass the repeat gate, yield haplotypes and run POA and
@@ -754,7 +789,7 @@ def main():
             return stamp["lib_sha16"] != now["lib_sha16"]
         return stamp.get("csrc_sha16") != now["csrc_sha16"]
 
-    for cand in ("r5_pmc_per_kernel.json", "r4_pmc_per_kernel.json", "r3_pmc_per_kernel.json", "r2_pmc_per_kernel.json"):
+    for cand in ("r6_pmc_per_kernel.json", "r5_pmc_per_kernel.json", "r4_pmc_per_kernel.json", "r3_pmc_per_kernel.json", "r2_pmc_per_kernel.json"):
         tpath = os.path.join(REPO, "profiles", cand)
         if os.path.exists(tpath):
             try:
@@ -780,8 +815,14 @@ def main():
                 "traffic_stale": prof_is_stale(prof.get("_stamp", {})) if pk else None,
                 "avg_launch_ms": round(avg_ms, 4), "launches_per_step": launches_per_step,
                 "algorithmic_bytes_per_launch": int(bytes_per_launch),
+                # SURVEY 8(d) as written: the STAGE's algorithmic bytes per step / the summed time of the stage's kernels
+                "frac_survey": stages.get(sname, {}).get("frac_of_hbm_peak"),
+                "survey_stage_MB_per_step": stages.get(sname, {}).get("algorithmic_MB_per_step"),
+                "survey_stage_kernel_ms_per_step": stages.get(sname, {}).get("kernel_ms_per_step"),
                 "note": "achieved = this kernel's OWN algorithmic bytes per launch (bench.py: kernel_bytes = DESIGN.md section 4's per-window "
                         "figure x the units one launch processes) / its mean launch time (HIP events on the launch stream); "
+                        "frac_survey = SURVEY 8(d)'s per-window bytes of the kernel's STAGE x the stage's units per step / the summed "
+                        "time of the stage's kernels / peak (what `stages` lists for every stage); "
                         "roofline_top5 has the same for the five kernels with the most summed time"}
         if pk.get("valu_insts_per_launch"):
             lane_ops = pk["valu_insts_per_launch"] * 64.0
@@ -797,7 +838,7 @@ def main():
     #      committed PMC passes measured for it (traffic, vector instructions, share of wave cycles parked on a wait) ----
     sq = {}
     try:
-        sq = json.load(open(os.path.join(REPO, "profiles", "r5_pmc_sq_per_kernel.json")))
+        sq = json.load(open(os.path.join(REPO, "profiles", "r6_pmc_sq_per_kernel.json")))
     except Exception:
         sq = {}
     top5 = []
@@ -825,6 +866,49 @@ def main():
         if sk.get("SQ_WAVE_CYCLES"):
             ent["wait_any_share"] = round(sk.get("SQ_WAIT_ANY", 0) / sk["SQ_WAVE_CYCLES"], 3)
         top5.append(ent)
+
+    # ---- GCUPS of the two DP stages: cells of the statistics step / the summed time of the
+    #      kernels that compute them in the timed region; beside it the vector lane-operations each cell cost (committed
+    #      SQ_INSTS_VALU pass of this command) -- the VALU roofline is what bounds integer DP on this chip, not MFMA ----
+    def pmc_insts_per_step(prefixes):
+        """wave-level VALU instructions per step of every profiled kernel whose name starts with one of `prefixes`"""
+        steps_prof = prof.get("_stamp", {}).get("steps_profiled", 5)  # 2 timed + 2 warm-up + 1 statistics step
+        tot, found = 0.0, False
+        for k_, v_ in prof.items():
+            if isinstance(v_, dict) and not k_.startswith("_") and k_.startswith(tuple(prefixes)) and v_.get("valu_insts_per_launch"):
+                tot += v_["valu_insts_per_launch"] * v_.get("launches", 0)
+                found = True
+        return tot / steps_prof if found else None
+
+    def gcups_entry(cells, knames, what, extra_kernels=()):
+        ms = sum(agg[k_][0] for k_ in knames if k_ in agg) / args.steps
+        if cells <= 0 or ms <= 0:
+            return None
+        ent = {"cells_per_step": int(cells), "cells": what, "kernels": [k_ for k_ in knames if k_ in agg],
+               "kernel_ms_per_step_summed_over_lanes": round(ms, 3), "GCUPS": round(cells / (ms * 1e-3) / 1e9, 1)}
+        if extra_kernels:
+            ms2 = ms + sum(agg[k_][0] for k_ in extra_kernels if k_ in agg) / args.steps
+            ent["GCUPS_incl_" + "_".join(k_.replace("k_", "") for k_ in extra_kernels if k_ in agg)] = round(cells / (ms2 * 1e-3) / 1e9, 1)
+        insts = pmc_insts_per_step(knames)
+        if insts:
+            ent.update(valu_lane_ops_per_cell=round(insts * 64.0 / cells, 1),
+                       valu_frac_of_peak=round(insts * 64.0 / (ms * 1e-3) / VALU_PEAK_LANE_OPS, 4),
+                       valu_peak_T_lane_ops_per_s=round(VALU_PEAK_LANE_OPS / 1e12, 1),
+                       counters_source=prof.get("_file"), counters_stale=prof_is_stale(prof.get("_stamp", {})))
+        return ent
+
+    gcups = {
+        "read_aligner": gcups_entry(wstats.get("aln_dp_cells", 0), ("k_align_reg", "k_align_wave", "k_align_gen"),
+                                    "rows x region width of every read x haplotype pair that ran the DP (a19); the kernels compute "
+                                    "their width class's cells in chunks of eight up to the widest region of a group", ("k_align_tb",)),
+        "poa_band": gcups_entry(wstats.get("poa_band_cells", 0), ("k_msa_band", "k_poa"),
+                                "rows x band columns of every banded haplotype <-> graph fill that ran (a18); alignments written "
+                                "down in closed form have no cells"),
+        "poa_alignments_per_step": wstats.get("poa_alignments", 0), "poa_closed_form_per_step": wstats.get("poa_direct_alignments", 0),
+        "poa_band_fills_per_step": wstats.get("poa_band_fills", 0), "poa_full_fill_cells_per_step": wstats.get("poa_full_cells", 0),
+        "dp_pairs_per_step": wstats.get("dp_pairs", 0),
+        "note": "GCUPS = 1e9 cell updates per second of kernel time; under concurrent lanes the kernels' times are stretched by sharing "
+                "the chip (profiles/*_bench_single_lane.json has the unshared times)"}
 
     # ---- secondary measurements (never `value`) ----
     also = {}
@@ -1050,8 +1134,11 @@ def main():
                        "repeat_gated_fraction": round(gated / n, 4),
                        "windows_with_capacity_overflow": overflowed, "haplotypes_per_assembled_window": round(H, 2),
                        "sharding": "static, one process per GPU, no collective",
+                       "rank_windows": rank_windows,
+                       "oversubscribed": (f"REHEARSAL: {world} ranks share {torch.cuda.device_count()} device(s), gloo barrier -- exercises "
+                                          "the launch / sharding path, not a scaling measurement") if oversub else None,
                        "input_synthesis_s": round(t_gen, 1)},
-            "roofline": roof, "roofline_valu": roof_valu, "roofline_top5": top5, "cpu_baseline": cpu, "cpu_baseline_all_cores": cpu_mt,
+            "roofline": roof, "roofline_valu": roof_valu, "roofline_top5": top5, "gcups": gcups, "cpu_baseline": cpu, "cpu_baseline_all_cores": cpu_mt,
             "parity_sample": parity,
             "step_algorithmic": {"MB_per_step": round(step_bytes / 1e6, 1),
                                  "GB_per_s": round(step_bytes / (elapsed / args.steps) / 1e9, 1),

@@ -265,6 +265,10 @@ int ma_set_streams(ma_ctx_t* ctx, int n);
  *   out[8..13] (timing mode 3 only) distinct k-mers, nodes after the first low-coverage pass, k-mer instances on the
  *              hash-table path, k-mer instances, (k+1)-mers of reads queued for the edge builder, read-support counts
  *              queued -- each summed over the window attempts
+ *   out[14..19] (timing mode 3 only) DP cells: [14] cells of the read aligner's DP regions (rows x region width, summed over
+ *              the pairs that ran the DP), [15] cells of the POA's banded fills (rows x band columns), [16] banded fills,
+ *              [17] cells of the POA's full fills (rows x haplotype length), [18] haplotype <-> graph alignments,
+ *              [19] alignments written down in closed form (no fill) -- what bench.py's `gcups` block divides the kernel times by
  * Used by bench.py to price the kernels' algorithmic HBM bytes.  Returns the number of entries written. */
 int ma_last_stats(ma_ctx_t* ctx, unsigned long long* out, int cap);
 

@@ -2039,15 +2039,29 @@ __device__ __forceinline__ u32 dp_subkey(u32 bw) {  // band_w: width | key << 16
   u32 const key = bw >> 16, w = bw & 0xFFFFu;
   return key * 8u + (key < 2u * kNumReg ? min(7u, (max(w, 1u) - 1u) >> 3) : 0u);
 }
-__global__ __launch_bounds__(256) void k_dp_subcount(GArgs A, u32 ndp, u32* sub) {
+// cells: (ma_timing_control mode 3 only, else null) += rows x region width of every DP pair -- the cells of the regions the
+// DP is defined on (the kernels compute a class's width, in chunks of eight cells up to the widest region of a group)
+__global__ __launch_bounds__(256) void k_dp_subcount(GArgs A, u32 ndp, u32* sub, unsigned long long* cells) {
   __shared__ u32 l_cnt[kSubKeys];
+  __shared__ unsigned long long l_cells;
   for (u32 x = threadIdx.x; x < kSubKeys; x += 256) l_cnt[x] = 0;
+  if (threadIdx.x == 0) l_cells = 0;
   __syncthreads();
   u32 const li = blockIdx.x * 256u + threadIdx.x;
-  if (li < ndp) atomicAdd(&l_cnt[dp_subkey(A.ws.band_w[A.ws.dp_list[li]])], 1u);
+  if (li < ndp) {
+    u32 const lp = A.ws.dp_list[li];
+    u32 const bw = A.ws.band_w[lp];
+    atomicAdd(&l_cnt[dp_subkey(bw)], 1u);
+    if (cells) {
+      u32 const r = A.ws.pair_read[lp] & 0x7FFFFFFu;
+      u64 const m = A.b.read_off[r + 1] - A.b.read_off[r];
+      atomicAdd(&l_cells, static_cast<unsigned long long>(m) * (bw & 0xFFFFu));
+    }
+  }
   __syncthreads();
   for (u32 x = threadIdx.x; x < kSubKeys; x += 256)
     if (l_cnt[x]) atomicAdd(&sub[x], l_cnt[x]);
+  if (cells && threadIdx.x == 0 && l_cells) atomicAdd(&cells[6], l_cells);
 }
 __global__ __launch_bounds__(256) void k_dp_scatter(GArgs A, u32 ndp, u32* out, u32* fill, const u32* sub, KeyBase kb) {
   // one global atomic per (key, width step) and WORKGROUP, all at once: the pairs take their places inside the workgroup's
@@ -3187,7 +3201,9 @@ int launch_genotype(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& a, const m
         return MA_ERR_HIP;
       }
       ctx->tic("k_dp_scatter");
-      hipLaunchKernelGGL(k_dp_subcount, dim3((ndp + 255) / 256), dim3(256), 0, ctx->stream, A, ndp, ws.dp_count + 128);
+      unsigned long long* dstats = nullptr;
+      MA_TRY_RC(ma_dev_stats(ctx, &dstats));
+      hipLaunchKernelGGL(k_dp_subcount, dim3((ndp + 255) / 256), dim3(256), 0, ctx->stream, A, ndp, ws.dp_count + 128, dstats);
       hipLaunchKernelGGL(k_dp_scatter, dim3((ndp + 255) / 256), dim3(256), 0, ctx->stream, A, ndp, dp_sorted,
                          ws.dp_count + 288, ws.dp_count + 128, kb);
       ctx->toc();

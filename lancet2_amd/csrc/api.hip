@@ -1204,19 +1204,19 @@ int ma_last_stats(ma_ctx_t* ctx, unsigned long long* out, int cap) {
   // entries 8..13: device-side workload statistics (mode 3 only; zero otherwise)
   auto add_dev = [&](ma_ctx* c) -> int {
     if (!c->dev_stats.p || !c->dev_stats_clean) return MA_OK;
-    unsigned long long h[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long h[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     MA_HIP(c, hipSetDevice(c->device));
     MA_HIP(c, ma_stream_sync(c));
     MA_HIP(c, hipMemcpy(h, c->dev_stats.p, sizeof(h), hipMemcpyDeviceToHost));
-    for (int x = 0; x < 6 && 8 + x < cap; ++x) out[8 + x] += h[x];
+    for (int x = 0; x < 12 && 8 + x < cap; ++x) out[8 + x] += h[x];
     return MA_OK;
   };
   if (cap > 8) {
-    for (int x = 8; x < cap && x < 14; ++x) out[x] = 0;
+    for (int x = 8; x < cap && x < 20; ++x) out[x] = 0;
     if (add_dev(ctx) != MA_OK) return MA_ERR_HIP;
     for (ma_ctx* ch : ctx->lanes)
       if (add_dev(ch) != MA_OK) return MA_ERR_HIP;
-    n = cap < 14 ? cap : 14;
+    n = cap < 20 ? cap : 20;
   }
   return n;
 }

@@ -588,13 +588,9 @@ int launch_assemble(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& out, const
           ws.mc_log2 = mc_log2_alloc;  // run_build_pass shrinks both to what this attempt needs
           MA_TRY_RC(run_build_pass(ctx, b, ws, counters + 12, tc_log2_alloc));
           if (ctx->collect) {
-            MA_HIP(ctx, ctx->dev_stats.reserve(64));
-            if (!ctx->dev_stats_clean) {
-              MA_HIP(ctx, hipMemsetAsync(ctx->dev_stats.p, 0, 64, ctx->stream));
-              ctx->dev_stats_clean = true;
-            }
-            hipLaunchKernelGGL(k_workload_stats, dim3(ws.n_active), dim3(256), 0, ctx->stream, ws,
-                               ctx->dev_stats.as<unsigned long long>());
+            unsigned long long* acc = nullptr;
+            MA_TRY_RC(ma_dev_stats(ctx, &acc));
+            hipLaunchKernelGGL(k_workload_stats, dim3(ws.n_active), dim3(256), 0, ctx->stream, ws, acc);
           }
           MA_TRY_RC(run_clean_pass(ctx, b, ws, out));
         }

@@ -92,7 +92,8 @@ struct ma_ctx {
   bool accumulate = false;
   unsigned long long stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // see ma_last_stats
   bool collect = false;          // ma_timing_control mode 3: also gather the workload statistics (device side)
-  ma::DevBuf dev_stats;          // [8] u64 accumulated by k_workload_stats
+  ma::DevBuf dev_stats;          // [kDevStats] u64: [0..5] k_workload_stats, [6] DP cells of the read aligner's regions,
+                                 // [7] POA band cells, [8] band fills, [9] cells of full fills, [10] POA alignments, [11] closed-form ones
   bool dev_stats_clean = false;
   // ma_process_batch splits a batch into `n_lanes` contiguous window ranges that run concurrently on child
   // contexts (own stream + workspaces): the stages have complementary bottlenecks (latency-bound graph
@@ -144,6 +145,20 @@ inline std::string ma_get_err(ma_ctx* c) {
       return MA_ERR_HIP;                                                               \
     }                                                                                  \
   } while (0)
+
+// ma_timing_control mode 3: the device-side statistics block (zeroed once per statistics region); null when not collecting
+constexpr int kDevStats = 16;
+inline int ma_dev_stats(ma_ctx* ctx, unsigned long long** out) {
+  *out = nullptr;
+  if (!ctx->collect) return MA_OK;
+  MA_HIP(ctx, ctx->dev_stats.reserve(sizeof(unsigned long long) * kDevStats));
+  if (!ctx->dev_stats_clean) {
+    MA_HIP(ctx, hipMemsetAsync(ctx->dev_stats.p, 0, sizeof(unsigned long long) * kDevStats, ctx->stream));
+    ctx->dev_stats_clean = true;
+  }
+  *out = ctx->dev_stats.as<unsigned long long>();
+  return MA_OK;
+}
 
 // Wait for the context's stream without burning a host core: one process per GPU and up to three lane threads per
 // process would otherwise spin on hipStreamSynchronize (8 GPUs: 24 busy cores for nothing).

@@ -48,6 +48,7 @@ namespace {
 constexpr int kPE = 4;        // in / out edges and aligned nodes kept per POA node
 constexpr int kT = 256;       // threads per window
 constexpr u32 kSlowCap = 256; // rows with a cached predecessor-row list
+constexpr u32 kMaxSeq = 32;   // haplotypes per component: the per-edge label masks are 16 bit (common kernel) or 32 bit (LAB32)
 constexpr i32 kNegInf = static_cast<i32>(0x80000000u) + 1024;
 constexpr i32 M_ = 0, N_ = -6, G_ = -6, E_ = -2, Q_ = -26, C_ = -1;  // msa_builder.h:72-77
 
@@ -72,10 +73,14 @@ struct PoaWs {
   u32 tier0;         // columns per lane of the first band tier: 1 / 2 / 4 = 64 / 128 / 256 columns (MA_POA_TIER0)
   u32 no_wide_start; // (A/B) every alignment starts at tier0, whatever its length
   u32* tier_stats;   // [8] fills per tier 64/128/256 + (at 4) failed certificates per tier; null unless MA_VERBOSE
+  unsigned long long* dstats;  // ma_timing_control mode 3 (else null): [7] band cells, [8] band fills, [9] full-fill cells,
+                               // [10] alignments, [11] closed-form alignments (ma_internal.h: dev_stats)
   u32* pending_ctr;  // split mode: windows that yielded in the current k_msa launch
   u32 no_direct;     // MA_POA_NO_DIRECT: every alignment goes through a fill (tests: the shortcut changes nothing)
   u32 raw_cap;       // MA_POA_RAW_CAP: bytes per haplotype of the bubble walk's LDS scratch (tests: forces the HBM route)
   u32 lean;          // band tiers run poa_fill_lean (default) / poa_fill_band (MA_POA_LEAN=0; same codes, tested)
+  u32 lab32;         // this pass runs the kernels with 32-bit label masks (components of 17 .. 32 haplotypes)
+  u32 pass;          // 0: every window; 1: only windows whose components all hold <= 16 haplotypes; 2: only the others
   size_t code_cells; // u16 per window
   size_t row_cells;  // i32 per window
   u16* codes;
@@ -98,7 +103,7 @@ struct LdsArr {
 
 struct WgState {
   u32 nn, nseq, nrank, overflow;
-  i32 seq_first[16];
+  i32 seq_first[kMaxSeq];
   u32 mode, V, L, cw, naln, nslow;
   u32 band, band_fail;  // band tier of this alignment's current attempt (columns per lane, 0 = full fill) / its traceback ran off the band
   u32 filled;           // split mode: k_msa_band has filled the pending alignment at tier `band`
@@ -120,8 +125,9 @@ struct WgState {
   u32 nvars, pool, var_overflow;
   // thread 0's per-haplotype state of the bubble walk: dynamically indexed arrays, which as locals live in scratch memory
   // (an HBM round trip per access of a serial walk)
-  i32 xa_active[16], xa_alt_of[16];
-  u32 xa_hap_pos[16], xa_starts[16], xa_rawlen[16], xa_grp_rep[16], xa_glo[16], xa_ghi[16], xa_ordg[16], xa_rank_of_grp[16];
+  i32 xa_active[kMaxSeq], xa_alt_of[kMaxSeq];
+  u32 xa_hap_pos[kMaxSeq], xa_starts[kMaxSeq], xa_rawlen[kMaxSeq], xa_grp_rep[kMaxSeq], xa_glo[kMaxSeq], xa_ghi[kMaxSeq], xa_ordg[kMaxSeq],
+      xa_rank_of_grp[kMaxSeq];
 };
 #define ST (*reinterpret_cast<WgState*>(ma_lds))
 constexpr u32 kStBytes = (sizeof(WgState) + 15u) & ~15u;
@@ -129,7 +135,20 @@ constexpr u32 kStBytes = (sizeof(WgState) + 15u) & ~15u;
 struct GL {  // LDS layout of one window's POA graph + scratch
   u32 pn;
   LdsArr<u8> nchar, nin, nout, nal;
-  LdsArr<u16> in_tail, out_head, out_lab, al, rank2node, node2rank;
+  LdsArr<u16> in_tail, out_head, al, rank2node, node2rank;
+  // per-edge haplotype label masks: u16 (components of <= 16 haplotypes: the common kernel) or u32 (LAB32 kernels: <= 32).
+  // lab32 is a template constant of the kernel that carves the view, so the accessors fold to one width.
+  u32 lab32;
+  u32 out_lab_off;
+  __device__ __forceinline__ u32 lab(u32 i) const {
+    return lab32 ? *reinterpret_cast<u32*>(&ma_lds[out_lab_off + 4u * i]) : static_cast<u32>(*reinterpret_cast<u16*>(&ma_lds[out_lab_off + 2u * i]));
+  }
+  __device__ __forceinline__ void lab_set(u32 i, u32 v) const {
+    if (lab32) *reinterpret_cast<u32*>(&ma_lds[out_lab_off + 4u * i]) = v;
+    else *reinterpret_cast<u16*>(&ma_lds[out_lab_off + 2u * i]) = static_cast<u16>(v);
+  }
+  __device__ __forceinline__ void lab_or(u32 i, u32 v) const { lab_set(i, lab(i) | v); }
+  __device__ __forceinline__ u32 max_seq() const { return lab32 ? 32u : 16u; }
   LdsArr<u16> npos;  // backbone coordinate of a node (guides the DP band): reference index, or the neighbour's + 1
   // scratch, alignment phase
   LdsArr<u32> rowinfo;
@@ -145,16 +164,17 @@ struct GL {  // LDS layout of one window's POA graph + scratch
   __device__ __forceinline__ u32 uword(const void* p) const { return *static_cast<const u32*>(p); }
 };
 
-__host__ __device__ inline size_t poa_lds_bytes(u32 pn, u32 ml) {
-  size_t const graph = size_t(42) * pn;
+__host__ __device__ inline size_t poa_lds_bytes(u32 pn, u32 ml, u32 lab32) {
+  size_t const graph = size_t(lab32 ? 50 : 42) * pn;
   size_t const s_aln = size_t(12) * (pn + 2) + 8 * kSlowCap + size_t(4) * (pn + ml + 2);
   size_t const s_topo = size_t(10) * pn;
   return kStBytes + graph + (s_aln > s_topo ? s_aln : s_topo) + 16;
 }
 
-__device__ __forceinline__ GL poa_carve(u32 PN, u32 ML) {
+__device__ __forceinline__ GL poa_carve(u32 PN, u32 ML, u32 lab32) {
   GL g;
   g.pn = PN;
+  g.lab32 = lab32;
   u32 o = kStBytes;
   g.nchar.off = o;
   g.nin.off = o + PN;
@@ -163,9 +183,9 @@ __device__ __forceinline__ GL poa_carve(u32 PN, u32 ML) {
   o += 4 * PN;
   g.in_tail.off = o;
   g.out_head.off = o + 8 * PN;
-  g.out_lab.off = o + 16 * PN;
-  g.al.off = o + 24 * PN;
-  o += 32 * PN;
+  g.out_lab_off = o + 16 * PN;
+  g.al.off = o + (lab32 ? 32 : 24) * PN;
+  o += (lab32 ? 40 : 32) * PN;
   g.rank2node.off = o;
   g.node2rank.off = o + 2 * PN;
   g.npos.off = o + 4 * PN;
@@ -206,11 +226,11 @@ __device__ __forceinline__ i32 pg_add_node(GL const& g, u8 ch, u32 pos) {
 }
 // spoa::Graph::AddEdge (weights dropped).  Also used lane-parallel by the graph update: there every
 // call touches the out-list of a distinct tail and the in-list of a distinct head.
-__device__ __forceinline__ void pg_add_edge(GL const& g, u32 tail, u32 head, u16 lab) {
+__device__ __forceinline__ void pg_add_edge(GL const& g, u32 tail, u32 head, u32 lab) {
   u32 const no = g.nout[tail];
   for (u32 x = 0; x < no; ++x)
     if (g.out_head[tail * kPE + x] == head) {
-      g.out_lab[tail * kPE + x] |= lab;
+      g.lab_or(tail * kPE + x, lab);
       return;
     }
   u32 const ni = g.nin[head];
@@ -219,7 +239,7 @@ __device__ __forceinline__ void pg_add_edge(GL const& g, u32 tail, u32 head, u16
     return;
   }
   g.out_head[tail * kPE + no] = static_cast<u16>(head);
-  g.out_lab[tail * kPE + no] = lab;
+  g.lab_set(tail * kPE + no, lab);
   g.nout[tail] = static_cast<u8>(no + 1);
   g.in_tail[head * kPE + ni] = static_cast<u16>(tail);
   g.nin[head] = static_cast<u8>(ni + 1);
@@ -228,7 +248,7 @@ __device__ __forceinline__ i32 pg_add_sequence(GL const& g, const u8* seq, u32 b
   if (begin >= end) return -1;
   i32 prev = -1;
   u32 const first = ST.nn;
-  u16 const lab = static_cast<u16>(1u << ST.nseq);
+  u32 const lab = 1u << ST.nseq;
   for (u32 i = begin; i < end; ++i) {
     i32 const cur = pg_add_node(g, seq[i], i);  // unaligned stretch: its own index is as good a guess as any
     if (ST.overflow) return -1;
@@ -239,7 +259,7 @@ __device__ __forceinline__ i32 pg_add_sequence(GL const& g, const u8* seq, u32 b
 }
 __device__ __forceinline__ i32 pg_successor(GL const& g, u32 node, u32 label) {  // spoa::Graph::Node::Successor
   for (int x = 0; x < g.nout[node]; ++x)
-    if (g.out_lab[node * kPE + x] & (1u << label)) return static_cast<i32>(g.out_head[node * kPE + x]);
+    if (g.lab(node * kPE + x) & (1u << label)) return static_cast<i32>(g.out_head[node * kPE + x]);
   return -1;
 }
 // spoa::Graph::TopologicalSort, run by wave 0 (marks / ignored are zeroed by the caller).
@@ -1737,13 +1757,34 @@ __device__ void poa_fill_lean(G const& g, u32 const w_stride, size_t const plane
 
   u32 info = g.rowinfo[1];
   __builtin_amdgcn_s_waitcnt(0);  // (the same for the loads above: nothing in flight when the loop is entered)
+#ifdef MA_PROFILE
+  unsigned long long t_lean = 0, t_gen = 0, n_gen = 0;
+  unsigned long long const t_fill0 = __builtin_amdgcn_s_memtime();
+#endif
   for (u32 i = 1; i <= V; ++i) {
     u32 const cur = info;
     if (i < V) info = g.rowinfo[i + 1];  // the next row's descriptor: a scalar load, a row ahead
+#ifdef MA_PROFILE
+    unsigned long long const q0 = __builtin_amdgcn_s_memtime();
+#endif
     if (__builtin_expect((cur & RI_LEAN) != 0, 1)) row_lean(cur);
     else row_gen(i, cur);
+#ifdef MA_PROFILE
+    unsigned long long const q1 = __builtin_amdgcn_s_memtime();
+    if (cur & RI_LEAN) t_lean += q1 - q0; else { t_gen += q1 - q0; n_gen++; }
+#endif
     cp += BW;
   }
+#ifdef MA_PROFILE
+  if (lane == 0) {  // (s_memtime ticks: 100 MHz) [8] lean rows' time, [9] other rows' time, [10] other rows, [11] fills, [12] rows, [13] whole fills
+    atomicAdd(&g_prof[8], t_lean);
+    atomicAdd(&g_prof[9], t_gen);
+    atomicAdd(&g_prof[10], n_gen);
+    atomicAdd(&g_prof[11], 1ull);
+    atomicAdd(&g_prof[12], static_cast<unsigned long long>(V));
+    atomicAdd(&g_prof[13], __builtin_amdgcn_s_memtime() - t_fill0);
+  }
+#endif
   for (int off = 32; off > 0; off >>= 1) edge = max(edge, __shfl_xor(edge, off));
   if (lane == 0) *edge_out = edge;
 }
@@ -2047,8 +2088,19 @@ struct MsaArgs {
   u32 finish;  // split mode: last launch -- every fill still to do runs inside k_msa (no more yields)
 };
 
-template <int CWMAX>
-__global__ __launch_bounds__(kT, 2) void k_msa(MsaArgs A) {
+// A batch with a component of more than 16 haplotypes runs in two passes (launch_msa): the common kernels over the windows
+// that fit 16-bit label masks, the LAB32 kernels -- 8 more bytes of LDS per node: one workgroup per CU -- over the few that do not.
+__device__ __forceinline__ bool poa_window_skipped(MsaArgs const& A, int w) {
+  if ((A.a.win_status[w] & MA_W_NO_HAPLOTYPE) || A.a.win_ncomp[w] == 0) return true;
+  if (A.ws.pass == 0) return false;
+  bool wide = false;
+  u32 const nc = A.a.win_ncomp[w];
+  for (u32 c = 0; c < nc; ++c) wide = wide || A.a.comp_nhaps[static_cast<size_t>(w) * A.prm.max_comps + c] > 16;
+  return wide != (A.ws.pass == 2);
+}
+
+template <int CWMAX, bool LAB32>
+__global__ __launch_bounds__(kT, LAB32 ? 1 : 2) void k_msa(MsaArgs A) {
   int const tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   int const lw = blockIdx.x;
   int const w = A.win0 + lw;
@@ -2062,8 +2114,9 @@ __global__ __launch_bounds__(kT, 2) void k_msa(MsaArgs A) {
     if (tid == 0) A.o.win_nvars[w] = 0;
     return;
   }
+  if (poa_window_skipped(A, w)) return;  // the other pass's window
   u32 const PN = ws.pn;
-  GL const g = poa_carve(PN, ws.max_l);
+  GL const g = poa_carve(PN, ws.max_l, LAB32 ? 1u : 0u);
   u16* const codes = ws.codes + static_cast<size_t>(lw) * ws.code_cells;
   i32* const rows = ws.rows + static_cast<size_t>(lw) * ws.row_cells;
   i32* const hlast = ws.hlast + static_cast<size_t>(lw) * (PN + 8);
@@ -2071,7 +2124,7 @@ __global__ __launch_bounds__(kT, 2) void k_msa(MsaArgs A) {
   // the code area in HBM beyond that (every byte thread 0 reads back from HBM is a round trip of its serial walk)
   u8* const raw_hbm = reinterpret_cast<u8*>(codes);
   u8* const raw_lds = &ma_lds[g.rowinfo.off];
-  u32 const raw_lds_room = (static_cast<u32>(poa_lds_bytes(PN, ws.max_l)) - 16u - g.rowinfo.off) / 16u;  // bytes per haplotype
+  u32 const raw_lds_room = (static_cast<u32>(poa_lds_bytes(PN, ws.max_l, LAB32 ? 1u : 0u)) - 16u - g.rowinfo.off) / g.max_seq();  // bytes per haplotype
   u32 const raw_lds_cap = ws.raw_cap ? min(ws.raw_cap, raw_lds_room) : raw_lds_room;
 
   // Split mode: the banded fill of an alignment runs in k_msa_band (one wavefront per window, a dozen windows per
@@ -2133,7 +2186,7 @@ __global__ __launch_bounds__(kT, 2) void k_msa(MsaArgs A) {
     u32 const hap0 = A.a.comp_hap0[ci], nh = A.a.comp_nhaps[ci];
     if (tid == 0 && !rc) {
       ST.nn = ST.nseq = ST.nrank = 0;
-      ST.overflow = nh > 16 ? 1u : 0u;  // label masks are 16 bit
+      ST.overflow = nh > g.max_seq() ? 1u : 0u;  // label masks are 16 / 32 bit (launch_msa sends wider components to the LAB32 pass)
     }
     u32 const h_start = rc ? ST.h_cur : 0u;
     for (u32 h = h_start; h < nh; ++h) {
@@ -2180,7 +2233,7 @@ __global__ __launch_bounds__(kT, 2) void k_msa(MsaArgs A) {
       if (mode == 0) continue;
       if (mode == 1) {
         // first sequence of the component: a linear chain whose topological order is the identity
-        u16 const lab = static_cast<u16>(1u << ST.nseq);
+        u32 const lab = 1u << ST.nseq;
         for (u32 i = tid; i < L; i += kT) {
           g.nchar[i] = seq[i];
           g.nin[i] = i > 0 ? 1 : 0;
@@ -2188,7 +2241,7 @@ __global__ __launch_bounds__(kT, 2) void k_msa(MsaArgs A) {
           g.nal[i] = 0;
           g.in_tail[i * kPE] = static_cast<u16>(i - 1);
           g.out_head[i * kPE] = static_cast<u16>(i + 1);
-          g.out_lab[i * kPE] = lab;
+          g.lab_set(i * kPE, lab);
           g.rank2node[i] = static_cast<u16>(i);
           g.node2rank[i] = static_cast<u16>(i);
           g.npos[i] = static_cast<u16>(i);
@@ -2272,6 +2325,10 @@ __global__ __launch_bounds__(kT, 2) void k_msa(MsaArgs A) {
             if (tid == 0) ST.naln = total;
           }
         }
+      }
+      if (ws.dstats && tid == 0 && !rh) {
+        atomicAdd(&ws.dstats[10], 1ull);
+        if (direct) atomicAdd(&ws.dstats[11], 1ull);
       }
       if (!direct) {
       if (!rh) {
@@ -2386,6 +2443,14 @@ __global__ __launch_bounds__(kT, 2) void k_msa(MsaArgs A) {
         u32 tier = ST.band;
         if (!filled && tier != kTierIn) tier = 0;  // inside this kernel: the narrow tier or the full fill
         if (!filled) {
+          if (ws.dstats && tid == 0) {
+            if (tier) {
+              atomicAdd(&ws.dstats[7], static_cast<unsigned long long>(V) * (64u * tier));
+              atomicAdd(&ws.dstats[8], 1ull);
+            } else {
+              atomicAdd(&ws.dstats[9], static_cast<unsigned long long>(V) * L);
+            }
+          }
           if (tier) {
             if (tid == 0) ST.band_fail = 0;
             if (wave == 0) {
@@ -2507,7 +2572,7 @@ __global__ __launch_bounds__(kT, 2) void k_msa(MsaArgs A) {
           ST.nseq++;
         }
       } else {
-        u16 const lab = static_cast<u16>(1u << ST.nseq);
+        u32 const lab = 1u << ST.nseq;
         // entries that carry a sequence position, compacted in path order
         u32 nv = 0;
         {
@@ -2652,9 +2717,9 @@ __global__ __launch_bounds__(kT, 2) void k_msa(MsaArgs A) {
     if (tid == 0 && ST.overflow) overflow = true;
     u32 const ns = ST.nseq;
     u32 const nn = ST.nn;
-    i32(&active)[16] = ST.xa_active;
-    u32(&hap_pos)[16] = ST.xa_hap_pos;
-    u32(&starts)[16] = ST.xa_starts;
+    i32(&active)[kMaxSeq] = ST.xa_active;
+    u32(&hap_pos)[kMaxSeq] = ST.xa_hap_pos;
+    u32(&starts)[kMaxSeq] = ST.xa_starts;
     u32 ref_pos = 0;
     i32 prev_match = -1;
     bool x_init = false;
@@ -2698,7 +2763,7 @@ __global__ __launch_bounds__(kT, 2) void k_msa(MsaArgs A) {
         }
         u8* pl = A.o.allele_pool + static_cast<size_t>(w) * MP;
         u32 const acap_hbm = 2 * ws.max_l + 8;  // raw allele strings: [ns][acap]
-        u32(&rawlen)[16] = ST.xa_rawlen;
+        u32(&rawlen)[kMaxSeq] = ST.xa_rawlen;
         auto converged = [&]() {
           for (u32 s = 1; s < ns; ++s)
             if (active[s] != active[0]) return false;
@@ -2740,8 +2805,8 @@ __global__ __launch_bounds__(kT, 2) void k_msa(MsaArgs A) {
               }
           }
           // group identical non-REF alleles (CreateNormalizedBubble); alt_of[s] = group id or -1
-          i32(&alt_of)[16] = ST.xa_alt_of;
-          u32(&grp_rep)[16] = ST.xa_grp_rep;
+          i32(&alt_of)[kMaxSeq] = ST.xa_alt_of;
+          u32(&grp_rep)[kMaxSeq] = ST.xa_grp_rep;
           u32 ngrp = 0;
           for (u32 s = 1; s < ns; ++s) {
             alt_of[s] = -1;
@@ -2759,8 +2824,8 @@ __global__ __launch_bounds__(kT, 2) void k_msa(MsaArgs A) {
           if (ngrp == 0) continue;
           // NormalizeVcfParsimony (variant_bubble.cpp:89-116): trims act on views [lo, hi) of the raw strings
           u32 rlo = 0, rhi = rawlen[0];
-          u32(&glo)[16] = ST.xa_glo;
-          u32(&ghi)[16] = ST.xa_ghi;
+          u32(&glo)[kMaxSeq] = ST.xa_glo;
+          u32(&ghi)[kMaxSeq] = ST.xa_ghi;
           for (u32 gi = 0; gi < ngrp; ++gi) {
             glo[gi] = 0;
             ghi[gi] = rawlen[grp_rep[gi]];
@@ -2786,7 +2851,7 @@ __global__ __launch_bounds__(kT, 2) void k_msa(MsaArgs A) {
             start_pos += init_len - (rhi - rlo);
           }
           // AssembleMultiallelicVariant: ALTs sorted by sequence (variant_extractor.cpp:229)
-          u32(&ordg)[16] = ST.xa_ordg;
+          u32(&ordg)[kMaxSeq] = ST.xa_ordg;
           for (u32 gi = 0; gi < ngrp; ++gi) {
             u32 jx = gi;
             while (jx > 0 && bytes_cmp(raw + grp_rep[ordg[jx - 1]] * acap + glo[ordg[jx - 1]], ghi[ordg[jx - 1]] - glo[ordg[jx - 1]],
@@ -2815,7 +2880,7 @@ __global__ __launch_bounds__(kT, 2) void k_msa(MsaArgs A) {
             A.o.var_hap_allele[vi * MH + hx] = 0;
             A.o.var_hap_start[vi * MH + hx] = 0;
           }
-          u32(&rank_of_grp)[16] = ST.xa_rank_of_grp;
+          u32(&rank_of_grp)[kMaxSeq] = ST.xa_rank_of_grp;
           for (u32 ai = 0; ai < ngrp; ++ai) {
             u32 const gi = ordg[ai];
             rank_of_grp[gi] = ai;
@@ -2849,7 +2914,7 @@ __global__ __launch_bounds__(kT, 2) void k_msa(MsaArgs A) {
         if (v + 1 < nn) {
           u32 const no = g.nout[v];
           for (u32 x = 0; x < no; ++x)
-            if (g.out_head[v * kPE + x] == v + 1 && (g.out_lab[v * kPE + x] & allmask) == allmask) ok = true;
+            if (g.out_head[v * kPE + x] == v + 1 && (g.lab(v * kPE + x) & allmask) == allmask) ok = true;
         }
         unsigned long long const m = __ballot(ok);
         u32 const cnt = m == ~0ull ? 64u : static_cast<u32>(__builtin_ctzll(~m));
@@ -2928,14 +2993,14 @@ __global__ __launch_bounds__(64, 4) void k_msa_band(MsaArgs A) {
   int const w = A.win0 + lw;
   ma_params_t const& P = A.prm;
   PoaWs const& ws = A.ws;
-  if ((A.a.win_status[w] & MA_W_NO_HAPLOTYPE) || A.a.win_ncomp[w] == 0) return;
+  if (poa_window_skipped(A, w)) return;
   u32* const img = reinterpret_cast<u32*>(ws.img) + static_cast<size_t>(lw) * ws.img_words;
   {
     const WgState* pst = reinterpret_cast<const WgState*>(img);
     if (pst->done || !pst->pending || pst->filled || pst->band == 0) return;
   }
   u32 const PN = ws.pn;
-  GL const full = poa_carve(PN, ws.max_l);
+  GL const full = poa_carve(PN, ws.max_l, ws.lab32);
   for (u32 i = lane; i < kStBytes / 4; i += 64) reinterpret_cast<u32*>(ma_lds)[i] = img[i];
   const u8* const ib = reinterpret_cast<const u8*>(img);
   DescView g;
@@ -2978,6 +3043,10 @@ __global__ __launch_bounds__(64, 4) void k_msa_band(MsaArgs A) {
     reinterpret_cast<WgState*>(img)->edge_max = ST.edge_max;
     reinterpret_cast<WgState*>(img)->filled = 1;
     if (ws.tier_stats) atomicAdd(&ws.tier_stats[tier == 1 ? 0 : (tier == 2 ? 1 : 2)], 1u);
+    if (ws.dstats) {
+      atomicAdd(&ws.dstats[7], static_cast<unsigned long long>(V) * (64u * tier));
+      atomicAdd(&ws.dstats[8], 1ull);
+    }
   }
 }
 
@@ -2996,22 +3065,30 @@ extern "C" void ma_debug_prof(unsigned long long* out, int reset) {
 // longest haplotype that is aligned and the most alignments of any window (what launch_msa sizes the graph and its rounds by)
 __global__ __launch_bounds__(256) void k_msa_maxima(ma_asm_out_t a, int n, u32 max_haps, u32 max_comps, u32* out) {
   int const w = blockIdx.x * 256 + threadIdx.x;
-  u32 ml = 0, al = 0;
+  // out[0] / out[1]: over all windows; out[2]: most haplotypes of any component; out[3]: longest haplotype of a window
+  // that holds such a wide component (sizes the LAB32 pass)
+  u32 ml = 0, al = 0, mh = 0, mlw = 0;
   if (w < n && !(a.win_status[w] & MA_W_NO_HAPLOTYPE)) {
     for (u32 c = 0; c < a.win_ncomp[w]; ++c) {
       size_t const ci = static_cast<size_t>(w) * max_comps + c;
       u32 const nh = a.comp_nhaps[ci], h0 = a.comp_hap0[ci];
       for (u32 h = 0; h < nh; ++h) ml = max(ml, a.hap_len[static_cast<size_t>(w) * max_haps + h0 + h]);
       al += nh > 1 ? nh - 1 : 0;
+      mh = max(mh, nh);
     }
+    if (mh > 16) mlw = ml;
   }
   for (int off = 32; off > 0; off >>= 1) {
     ml = max(ml, __shfl_xor(ml, off));
     al = max(al, __shfl_xor(al, off));
+    mh = max(mh, __shfl_xor(mh, off));
+    mlw = max(mlw, __shfl_xor(mlw, off));
   }
   if ((threadIdx.x & 63) == 0) {
     if (ml) atomicMax(&out[0], ml);
     if (al) atomicMax(&out[1], al);
+    if (mh) atomicMax(&out[2], mh);
+    if (mlw) atomicMax(&out[3], mlw);
   }
 }
 static int launch_msa_on_stream(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& a, const ma_var_out_t& o);
@@ -3047,44 +3124,60 @@ int launch_msa(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& a, const ma_var
   }
   return rc;
 }
+static int launch_msa_pass(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& a, const ma_var_out_t& o, u32 max_len, u32 rounds,
+                           u32 lab32, u32 pass);
 static int launch_msa_on_stream(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& a, const ma_var_out_t& o) {
   int const n = b.n_windows;
   if (n == 0) return MA_OK;
   ma_params_t const& P = ctx->prm;
-  if (P.max_haps > 16) {
-    ma_set_err(ctx, "ma_msa_batch: max_haps > 16 not supported (16-bit haplotype label masks)");
+  if (P.max_haps > static_cast<int>(kMaxSeq)) {
+    ma_set_err(ctx, "ma_msa_batch: max_haps > 32 not supported (32-bit haplotype label masks)");
     return MA_ERR_PARAM;
   }
   if (P.max_hap_len > 4096) {
     ma_set_err(ctx, "ma_msa_batch: max_hap_len > 4096 not supported (256 lanes x 16 columns)");
     return MA_ERR_PARAM;
   }
-  PoaWs ws{};
   // longest haplotype of the batch decides the DP width and the LDS graph capacity (one small D2H)
-  u32 max_len = 0, rounds = 1;  // rounds: split mode, 1 + the most alignments of any window
+  u32 got[4] = {0, 0, 0, 0};
   {
     // (on the device: the five arrays used to come back whole -- 0.3 MB per lane into pageable memory, staged copies and a
-    //  host loop in front of every lane's POA rounds -- for two numbers)
+    //  host loop in front of every lane's POA rounds -- for a few numbers)
     MA_HIP(ctx, ctx->ws_poa.reserve(4096));
     u32* mx = static_cast<u32*>(ctx->ws_poa.p);
-    MA_HIP(ctx, hipMemsetAsync(mx, 0, 8, ctx->stream));
+    MA_HIP(ctx, hipMemsetAsync(mx, 0, 16, ctx->stream));
     hipLaunchKernelGGL(k_msa_maxima, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, a, n, static_cast<u32>(P.max_haps),
                        static_cast<u32>(P.max_comps), mx);
-    u32 got[2] = {0, 0};
-    MA_HIP(ctx, hipMemcpyAsync(got, mx, 8, hipMemcpyDeviceToHost, ctx->stream));
+    MA_HIP(ctx, hipMemcpyAsync(got, mx, 16, hipMemcpyDeviceToHost, ctx->stream));
     MA_HIP(ctx, ma_stream_sync(ctx));
-    max_len = got[0];
-    rounds = std::max<u32>(1u, got[1] + 1u);
   }
+  u32 const rounds = std::max<u32>(1u, got[1] + 1u);  // split mode: 1 + the most alignments of any window
+  bool const any_wide = got[2] > 16 && !getenv("MA_POA_NO_LAB32");  // (knob for tests: wide components stay flagged, as in round 5)
+  if (getenv("MA_POA_FORCE_LAB32")) return launch_msa_pass(ctx, b, a, o, got[0], rounds, 1u, 0u);  // tests: every window through LAB32
+  // The reference has no cap on the haplotypes of a component (cbdg/graph.cpp:846-924, caller/msa_builder.cpp:29-42); the
+  // engine's is the caller's max_haps <= 32.  Components of up to 16 haplotypes take the common kernels (16-bit label masks,
+  // two workgroups per CU); a window with a wider component takes the LAB32 kernels in a pass of its own.
+  MA_TRY_RC(launch_msa_pass(ctx, b, a, o, got[0], rounds, 0u, any_wide ? 1u : 0u));
+  if (any_wide) MA_TRY_RC(launch_msa_pass(ctx, b, a, o, std::max(got[3], 16u), rounds, 1u, 2u));
+  return MA_OK;
+}
+static int launch_msa_pass(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& a, const ma_var_out_t& o, u32 max_len, u32 rounds,
+                           u32 const lab32, u32 const pass) {
+  int const n = b.n_windows;
+  ma_params_t const& P = ctx->prm;
+  PoaWs ws{};
+  MA_TRY_RC(ma_dev_stats(ctx, &ws.dstats));
+  ws.lab32 = lab32;
+  ws.pass = pass;
   max_len = std::max<u32>(max_len, 16);
   ws.max_l = max_len;
   u32 pn = max_len + std::max<u32>(256, max_len / 4);
   if (const char* e = getenv("MA_POA_NODE_CAP")) pn = static_cast<u32>(atoi(e));
   pn = std::min<u32>((pn + 7) & ~7u, 65000);
   // two workgroups per CU when the graph fits in 80 KB of LDS, one otherwise
-  while (poa_lds_bytes(pn, max_len) > 80 * 1024 && pn > max_len + 128) pn -= 8;
-  while (poa_lds_bytes(pn, max_len) > 159 * 1024 && pn > max_len + 32) pn -= 8;
-  size_t const lds = poa_lds_bytes(pn, max_len);
+  while (!lab32 && poa_lds_bytes(pn, max_len, lab32) > 80 * 1024 && pn > max_len + 128) pn -= 8;
+  while (poa_lds_bytes(pn, max_len, lab32) > 159 * 1024 && pn > max_len + 32) pn -= 8;
+  size_t const lds = poa_lds_bytes(pn, max_len, lab32);
   if (lds > 160 * 1024) {
     ma_set_err(ctx, "ma_msa_batch: haplotypes too long for the LDS-resident POA graph");
     return MA_ERR_PARAM;
@@ -3128,7 +3221,8 @@ static int launch_msa_on_stream(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t
   if (getenv("MA_VERBOSE"))
     fprintf(stderr, "[microasm] msa: %d windows, %.2f MB/window, budget %.1f GB -> chunks of %d (pn %u, max_len %u, lds %zu)\n", n,
             per_window / 1048576.0, budget / 1073741824.0, chunk, pn, max_len, lds);
-  auto kern = max_len <= 1024 ? k_msa<4> : (max_len <= 2048 ? k_msa<8> : k_msa<16>);
+  auto kern = lab32 ? (max_len <= 1024 ? k_msa<4, true> : (max_len <= 2048 ? k_msa<8, true> : k_msa<16, true>))
+                    : (max_len <= 1024 ? k_msa<4, false> : (max_len <= 2048 ? k_msa<8, false> : k_msa<16, false>));
   MA_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   static_cast<int>(lds)));
   for (int win0 = 0; win0 < n; win0 += chunk) {

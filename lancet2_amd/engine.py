@@ -91,10 +91,11 @@ class Engine:
 
     def stats(self):
         """Work counters of include/microasm.h:ma_last_stats."""
-        buf = (C.c_ulonglong * 14)()
-        n = self.lib.ma_last_stats(self.h, buf, 14)
+        buf = (C.c_ulonglong * 20)()
+        n = self.lib.ma_last_stats(self.h, buf, 20)
         keys = ("pairs", "dp_pairs", "windows", "window_attempts", "dp_w41", "dp_w65", "dp_w129", "dp_wide",
-                "distinct_kmers", "nodes_after_lowcov", "slow_instances", "kmer_instances", "edge_queue", "count_queue")
+                "distinct_kmers", "nodes_after_lowcov", "slow_instances", "kmer_instances", "edge_queue", "count_queue",
+                "aln_dp_cells", "poa_band_cells", "poa_band_fills", "poa_full_cells", "poa_alignments", "poa_direct_alignments")
         return {k: int(buf[i]) for i, k in enumerate(keys) if i < n}
 
     # ---- host-array convenience (MA_MEM_HOST): numpy in, numpy out ----

@@ -62,6 +62,7 @@ def main():
             if line.startswith('{"metric"'):
                 stamp = json.loads(line).get("build", stamp)
     stamp["command"] = "python3 bench.py --steps 2 --no-cpu --no-also --gen-workers 1"
+    stamp["steps_profiled"] = 5  # 2 timed + 2 warm-up + 1 statistics step: what `launches` counts
     out["_stamp"] = stamp
     json.dump(out, open(sys.argv[4], "w"), indent=1, sort_keys=True)
     for k, v in out.items():
