@@ -2099,10 +2099,13 @@ __device__ __forceinline__ bool poa_window_skipped(MsaArgs const& A, int w) {
   return wide != (A.ws.pass == 2);
 }
 
+// One window's POA up to its next banded fill (returns kMsaYield: the LDS block is saved, the pending alignment's descriptors
+// are in the image) or to its end (kMsaDone).  `resume`: continue from the image after a fill.  Runs as the body of k_msa
+// (host-counted rounds, MA_POA_SCHED=0) and as the G job of the persistent kernel k_poa.
+constexpr u32 kMsaDone = 0, kMsaYield = 1;
 template <int CWMAX, bool LAB32>
-__global__ __launch_bounds__(kT, LAB32 ? 1 : 2) void k_msa(MsaArgs A) {
+__device__ __forceinline__ u32 msa_window(MsaArgs const& A, int const lw, bool const resume_in) {
   int const tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  int const lw = blockIdx.x;
   int const w = A.win0 + lw;
   ma_params_t const& P = A.prm;
   PoaWs const& ws = A.ws;
@@ -2112,9 +2115,9 @@ __global__ __launch_bounds__(kT, LAB32 ? 1 : 2) void k_msa(MsaArgs A) {
   u32 const ncomp = (A.a.win_status[w] & MA_W_NO_HAPLOTYPE) ? 0u : A.a.win_ncomp[w];
   if (ncomp == 0) {
     if (tid == 0) A.o.win_nvars[w] = 0;
-    return;
+    return kMsaDone;
   }
-  if (poa_window_skipped(A, w)) return;  // the other pass's window
+  if (poa_window_skipped(A, w)) return kMsaDone;  // the other pass's window
   u32 const PN = ws.pn;
   GL const g = poa_carve(PN, ws.max_l, LAB32 ? 1u : 0u);
   u16* const codes = ws.codes + static_cast<size_t>(lw) * ws.code_cells;
@@ -2136,8 +2139,8 @@ __global__ __launch_bounds__(kT, LAB32 ? 1 : 2) void k_msa(MsaArgs A) {
 #ifdef MA_PROFILE
   unsigned long long const t_in = __builtin_amdgcn_s_memtime();
 #endif
-  if (A.round > 0) {
-    if (reinterpret_cast<const WgState*>(img)->done) return;
+  if (resume_in) {
+    if (reinterpret_cast<const WgState*>(img)->done) return kMsaDone;
     {  // 16 bytes per thread and load, four loads in flight (img_words is a multiple of 64, the image 256-byte aligned)
       const uint4* src = reinterpret_cast<const uint4*>(img);
       uint4* dst = reinterpret_cast<uint4*>(ma_lds);
@@ -2934,7 +2937,10 @@ __global__ __launch_bounds__(kT, LAB32 ? 1 : 2) void k_msa(MsaArgs A) {
       for (u32 i = tid; i < nq; i += kT) dst[i] = src[i];
     }
     PROF_ACC(14);  // image save
-    return;
+    // (k_poa publishes the window to another workgroup right after this: every wavefront's stores have to be out of its
+    //  own queue before thread 0's device-scope release -- a workgroup-scope barrier alone does not wait for them)
+    __builtin_amdgcn_s_waitcnt(0);
+    return kMsaYield;
   }
   if (tid == 0) {
     A.o.win_nvars[w] = nvars;
@@ -2948,6 +2954,12 @@ __global__ __launch_bounds__(kT, LAB32 ? 1 : 2) void k_msa(MsaArgs A) {
     __syncthreads();
     for (u32 i = tid; i < kStBytes / 4; i += kT) img[i] = reinterpret_cast<const u32*>(ma_lds)[i];
   }
+  return kMsaDone;
+}
+
+template <int CWMAX, bool LAB32>
+__global__ __launch_bounds__(kT, LAB32 ? 1 : 2) void k_msa(MsaArgs A) {
+  (void)msa_window<CWMAX, LAB32>(A, static_cast<int>(blockIdx.x), A.round > 0);
 }
 
 // The row descriptors of a pending alignment, read straight from the window's LDS image in HBM: every access is
@@ -2986,22 +2998,20 @@ struct DescView {
 // windows and the dependent instruction chains of the row recurrence overlap across them.
 // One launch serves every tier: the wavefront takes the tier its window waits at (a launch per tier cost each tier's
 // slowest window in turn -- and a tier with three windows still cost a fill's latency).
+// The banded fill of window lw's pending alignment by ONE wavefront (`lane` = its lane index): the body of k_msa_band
+// (host-counted rounds) and the F job of the persistent kernel k_poa.  Nothing of the window is staged in LDS -- the state
+// block's few fields and the row descriptors come straight from the image in HBM -- so any wavefront of any workgroup can
+// run it; lut_off = 256 bytes of LDS of the wavefront's own for poa_fill_lean's code table.
 template <bool LEAN>
-__global__ __launch_bounds__(64, 4) void k_msa_band(MsaArgs A) {
-  int const lane = threadIdx.x;
-  int const lw = blockIdx.x;
+__device__ __forceinline__ bool band_job(MsaArgs const& A, int const lw, int const lane, u32 const lut_off) {
   int const w = A.win0 + lw;
   ma_params_t const& P = A.prm;
   PoaWs const& ws = A.ws;
-  if (poa_window_skipped(A, w)) return;
   u32* const img = reinterpret_cast<u32*>(ws.img) + static_cast<size_t>(lw) * ws.img_words;
-  {
-    const WgState* pst = reinterpret_cast<const WgState*>(img);
-    if (pst->done || !pst->pending || pst->filled || pst->band == 0) return;
-  }
+  WgState* const pst = reinterpret_cast<WgState*>(img);
+  if (pst->done || !pst->pending || pst->filled || pst->band == 0) return false;
   u32 const PN = ws.pn;
   GL const full = poa_carve(PN, ws.max_l, ws.lab32);
-  for (u32 i = lane; i < kStBytes / 4; i += 64) reinterpret_cast<u32*>(ma_lds)[i] = img[i];
   const u8* const ib = reinterpret_cast<const u8*>(img);
   DescView g;
   g.rowinfo.base = reinterpret_cast<const u32*>(ib + full.rowinfo.off);
@@ -3012,14 +3022,11 @@ __global__ __launch_bounds__(64, 4) void k_msa_band(MsaArgs A) {
   g.rank2node.base = reinterpret_cast<const u16*>(ib + full.rank2node.off);
   g.node2rank.base = reinterpret_cast<const u16*>(ib + full.node2rank.off);
   g.in_tail.base = reinterpret_cast<const u16*>(ib + full.in_tail.off);
-  __builtin_amdgcn_s_waitcnt(0);
-  __builtin_amdgcn_wave_barrier();
-  __syncthreads();
-  // (what comes out of LDS counts as divergent: without the readfirstlanes the haplotype's address sits in vector
+  // (what comes out of a vector load counts as divergent: without the readfirstlanes the haplotype's address sits in vector
   //  registers and every "scalar" load of the fill turns into a vector load)
-  u32 const c_cur = __builtin_amdgcn_readfirstlane(ST.c_cur), h_cur = __builtin_amdgcn_readfirstlane(ST.h_cur);
-  u32 const V = __builtin_amdgcn_readfirstlane(ST.V), L = __builtin_amdgcn_readfirstlane(ST.L);
-  i32 const edge0 = __builtin_amdgcn_readfirstlane(ST.edge0);
+  u32 const c_cur = __builtin_amdgcn_readfirstlane(pst->c_cur), h_cur = __builtin_amdgcn_readfirstlane(pst->h_cur);
+  u32 const V = __builtin_amdgcn_readfirstlane(pst->V), L = __builtin_amdgcn_readfirstlane(pst->L);
+  i32 const edge0 = __builtin_amdgcn_readfirstlane(pst->edge0);
   size_t const ci = static_cast<size_t>(w) * P.max_comps + c_cur;
   u32 const hap0 = __builtin_amdgcn_readfirstlane(A.a.comp_hap0[ci]);
   size_t const hi = static_cast<size_t>(w) * P.max_haps + hap0 + h_cur;
@@ -3027,25 +3034,190 @@ __global__ __launch_bounds__(64, 4) void k_msa_band(MsaArgs A) {
   u16* const codes = ws.codes + static_cast<size_t>(lw) * ws.code_cells;
   i32* const rows = ws.rows + static_cast<size_t>(lw) * ws.row_cells;
   i32* const hlast = ws.hlast + static_cast<size_t>(lw) * (PN + 8);
-  u32 const tier = __builtin_amdgcn_readfirstlane(ST.band);
+  u32 const tier = __builtin_amdgcn_readfirstlane(pst->band);
   auto const fill = [&](auto cw) {
     constexpr int CW = decltype(cw)::value;
     if constexpr (LEAN)
-      poa_fill_lean<CW>(g, ws.w_stride, ws.code_cells, codes, rows, hlast, V, L, lane, seq, edge0, kStBytes + 16, &ST.edge_max);
+      poa_fill_lean<CW>(g, ws.w_stride, ws.code_cells, codes, rows, hlast, V, L, lane, seq, edge0, lut_off, &pst->edge_max);
     else
-      poa_fill_band<CW>(g, ws.w_stride, ws.code_cells, codes, rows, hlast, V, L, lane, seq, &ST.edge_max);
+      poa_fill_band<CW>(g, ws.w_stride, ws.code_cells, codes, rows, hlast, V, L, lane, seq, &pst->edge_max);
   };
   if (tier == 1) fill(std::integral_constant<int, 1>{});
   else if (tier == 2) fill(std::integral_constant<int, 2>{});
   else fill(std::integral_constant<int, 4>{});
-  __syncthreads();
   if (lane == 0) {
-    reinterpret_cast<WgState*>(img)->edge_max = ST.edge_max;
-    reinterpret_cast<WgState*>(img)->filled = 1;
+    pst->filled = 1;
     if (ws.tier_stats) atomicAdd(&ws.tier_stats[tier == 1 ? 0 : (tier == 2 ? 1 : 2)], 1u);
     if (ws.dstats) {
       atomicAdd(&ws.dstats[7], static_cast<unsigned long long>(V) * (64u * tier));
       atomicAdd(&ws.dstats[8], 1ull);
+    }
+  }
+  return true;
+}
+
+template <bool LEAN>
+__global__ __launch_bounds__(64, 4) void k_msa_band(MsaArgs A) {
+  int const lw = blockIdx.x;
+  if (poa_window_skipped(A, A.win0 + lw)) return;
+  (void)band_job<LEAN>(A, lw, static_cast<int>(threadIdx.x), 16u);
+}
+
+// ---- the persistent POA kernel: device-side scheduling instead of host-counted rounds (round 6) ----------------------------
+// Rounds 3-5 ran the POA as rounds the HOST counted: k_msa over every window of the chunk (restore the LDS image, work up to the
+// next fill, save), one 8-byte read-back, k_msa_band over every window, again -- 17 + 12 launches and ~30 stream
+// synchronisations per lane-step, every round as long as its slowest window, the later rounds (third / fourth alignments,
+// retried tiers) nearly empty but a fill's latency each.  k_poa is ONE launch per chunk: its workgroups loop over queues in HBM
+// until every window is done --
+//   G jobs (a whole workgroup, the window's POA graph in LDS): msa_window up to the window's next banded fill, which it posts
+//          as an F job (fresh windows come off a counter, windows whose fill is done off the G queue);
+//   F jobs (ONE wavefront each, up to four side by side in a workgroup): band_job, then the window goes back on the G queue.
+// Fills are taken first (they are the long jobs: the graph phases of other windows run while they are in flight).
+// Windows hand over through HBM (the LDS image, the decision codes).  **Every hand-over stays inside one XCD**: the chip's
+// eight XCDs have an L2 each, and a device-scope release / acquire on this chip is a write-back of the whole L2 plus an
+// invalidation of it (buffer_wbl2 sc1 / buffer_inv sc1) -- the first version, with __threadfence() around every queue
+// operation, ran the stage 2.6x SLOWER than the host rounds and slowed the other lanes' kernels with it.  A window belongs to
+// the XCD of the workgroup that started it (s_getreg XCC_ID): its F and G jobs go through that XCD's queues and are taken by
+// that XCD's workgroups only, so producer and consumer share one coherent L2 and a hand-over costs: the producer's stores out
+// of its queues (s_waitcnt vmcnt(0), every wavefront, before the slot is published), the consumer's vector L1 invalidated
+// (buffer_inv sc0) -- and its SCALAR cache (s_dcache_inv), which the fill's descriptor loads go through and no fence covers.
+// Fresh windows come off one global counter, so the XCDs balance themselves.  A workgroup leaves when no window is left to
+// start and its XCD has more workgroups than open windows.  (MA_POA_XCD=0: one domain for the whole chip, device-scope fences.)
+constexpr u32 kPoaDoms = 16;
+struct PoaDom {  // one per XCD, a cache line of its own
+  u32 f_head, f_tail, g_head, g_tail;
+  u32 n_open;     // windows started here and not finished
+  u32 n_workers;  // workgroups of this XCD in the loop
+  u32 seen;       // workgroups that ever registered here, windows started here (MA_VERBOSE prints them)
+  u32 started;
+  u32 pad[24];
+};
+struct PoaSched {
+  u32 fresh;  // next window that has not been started
+  u32 pad[31];
+  PoaDom dom[kPoaDoms];
+};
+constexpr u32 kQEmpty = 0xFFFFFFFFu;
+__device__ __forceinline__ u32 ld_dev(u32* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_dev(u32* p, u32 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// multi-producer / multi-consumer ring: a slot is reserved by the counter, published by its value (kQEmpty = not yet / taken).
+// The caller has made the job's data visible BEFORE the push (poa_release) and makes it readable AFTER the pop (poa_acquire).
+__device__ __forceinline__ void q_push(u32* tail, u32* buf, u32 mask, u32 id) {
+  u32 const t = atomicAdd(tail, 1u);
+  u32* const slot = buf + (t & mask);
+  while (ld_dev(slot) != kQEmpty) __builtin_amdgcn_s_sleep(2);  // (the ring holds every window at once: practically never)
+  st_dev(slot, id);
+}
+__device__ __forceinline__ u32 q_pop(u32* head, u32* tail, u32* buf, u32 mask, u32 maxn, u32* out) {
+  for (;;) {
+    u32 const h = ld_dev(head), t = ld_dev(tail);
+    if (static_cast<i32>(t - h) <= 0) return 0;
+    u32 const n = min(maxn, t - h);
+    if (atomicCAS(head, h, h + n) != h) continue;
+    for (u32 k = 0; k < n; ++k) {
+      u32* const slot = buf + ((h + k) & mask);
+      u32 v;
+      while ((v = ld_dev(slot)) == kQEmpty) __builtin_amdgcn_s_sleep(1);  // reserved, about to be published
+      out[k] = v;
+      st_dev(slot, kQEmpty);
+    }
+    return n;
+  }
+}
+// producer side, EVERY wavefront that wrote: its stores have left its queues (they are in the XCD's L2) ...
+__device__ __forceinline__ void poa_release(bool device_scope) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_s_waitcnt(0);
+  if (device_scope) __threadfence();  // ... and, with one domain for the whole chip, written back for the other XCDs
+}
+// consumer side, every wavefront that is going to read: nothing stale in the vector L1 or in the scalar cache
+__device__ __forceinline__ void poa_acquire(bool device_scope) {
+  if (device_scope) __threadfence();
+  asm volatile("buffer_inv sc0\n\ts_dcache_inv\n\ts_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+template <int CWMAX, bool LAB32>
+__global__ __launch_bounds__(kT, LAB32 ? 1 : 2) void k_poa(MsaArgs A, PoaSched* S, u32* fq_all, u32* gq_all, u32 qcap, u32 nwin, u32 xcd_local, u32 policy_min_fills) {
+  __shared__ u32 sh_job[8];  // [0] kind: 0 nothing right now, 1 fresh window, 2 window back from its fill, 3 fills, 4 leave; [1] count; [2..5] windows
+  int const tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // HW_REG_XCC_ID (id 20), bits [3:0]: the XCD this workgroup runs on
+  u32 const dom_id = xcd_local ? (static_cast<u32>(__builtin_amdgcn_s_getreg(20 | (3 << 11))) & (kPoaDoms - 1u)) : 0u;
+  PoaDom* const D = &S->dom[dom_id];
+  u32* const fq = fq_all + static_cast<size_t>(dom_id) * qcap;
+  u32* const gq = gq_all + static_cast<size_t>(dom_id) * qcap;
+  u32 const qmask = qcap - 1u;
+  bool const dev_scope = !xcd_local;
+  if (tid == 0) {
+    atomicAdd(&D->n_workers, 1u);
+    atomicAdd(&D->seen, 1u);
+  }
+  for (;;) {
+    __syncthreads();  // (the previous job's last LDS reads)
+    if (tid == 0) {
+      u32 kind = 0, cnt = 0, ids[4] = {0, 0, 0, 0};
+      // A fill occupies its wavefront for ~0.5 ms and the whole workgroup waits for it: fills are taken when there is a
+      // workgroup's worth of them (four) -- or nothing else to do; until then windows that came back from their fill go first
+      // (they are the furthest along: the batch's critical path is its windows with three or four alignments), then fresh ones.
+      u32 const f_avail = ld_dev(&D->f_tail) - ld_dev(&D->f_head);
+      if (static_cast<i32>(f_avail) >= static_cast<i32>(policy_min_fills)) cnt = q_pop(&D->f_head, &D->f_tail, fq, qmask, 4u, ids);
+      if (cnt) {
+        kind = 3;
+      } else if (q_pop(&D->g_head, &D->g_tail, gq, qmask, 1u, ids)) {
+        kind = 2;
+        cnt = 1;
+      } else if (ld_dev(&S->fresh) >= nwin && (cnt = q_pop(&D->f_head, &D->f_tail, fq, qmask, 4u, ids)) != 0) {
+        kind = 3;  // (no window left to start: whatever fills there are)
+      } else {
+        bool more = ld_dev(&S->fresh) < nwin;
+        if (more) {
+          u32 const f = atomicAdd(&S->fresh, 1u);
+          if (f < nwin) {
+            kind = 1;
+            cnt = 1;
+            ids[0] = f;
+            atomicAdd(&D->n_open, 1u);
+            atomicAdd(&D->started, 1u);
+          } else {
+            more = false;
+          }
+        }
+        if (!kind && !more) {  // no window left to start: leave once this XCD has more workgroups than open windows
+          u32 const open = ld_dev(&D->n_open);
+          if (ld_dev(&D->n_workers) > open) {
+            if (atomicSub(&D->n_workers, 1u) > open) kind = 4; else atomicAdd(&D->n_workers, 1u);
+          }
+        }
+      }
+      sh_job[0] = kind;
+      sh_job[1] = cnt;
+      for (u32 k = 0; k < 4; ++k) sh_job[2 + k] = ids[k];
+    }
+    __syncthreads();
+    u32 const kind = sh_job[0], cnt = sh_job[1];
+    if (kind == 4) break;
+    if (kind == 0) {
+      __builtin_amdgcn_s_sleep(64);
+      continue;
+    }
+    if (kind == 3) {
+      if (static_cast<u32>(wave) < cnt) {
+        int const lw = static_cast<int>(__builtin_amdgcn_readfirstlane(sh_job[2 + wave]));
+        poa_acquire(dev_scope);  // the image another workgroup saved
+        (void)band_job<true>(A, lw, lane, static_cast<u32>(wave) * 256u);
+        poa_release(dev_scope);  // codes, stored rows, last column, edge maximum, the image's `filled`
+        if (lane == 0) q_push(&D->g_tail, gq, qmask, static_cast<u32>(lw));
+      }
+      continue;
+    }
+    int const lw = static_cast<int>(sh_job[2]);
+    if (kind == 2) poa_acquire(dev_scope);  // the fill's outputs
+    u32 const st = msa_window<CWMAX, LAB32>(A, lw, kind == 2);
+    if (st == kMsaYield) poa_release(dev_scope);  // the image (every wavefront wrote a part)
+    __syncthreads();
+    if (tid == 0) {
+      if (st == kMsaYield) q_push(&D->f_tail, fq, qmask, static_cast<u32>(lw));
+      else atomicSub(&D->n_open, 1u);
     }
   }
 }
@@ -3217,7 +3389,13 @@ static int launch_msa_pass(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& a, 
   size_t budget = stage_budget(0.30, ctx->ws_poa.cap, size_t(24) << 30, ctx->hbm_share);
   if (const char* e = getenv("MA_WS_GB")) budget = static_cast<size_t>(atoi(e)) << 30;
   int const chunk = static_cast<int>(std::max<size_t>(1, std::min<size_t>(n, budget / per_window)));
-  MA_HIP(ctx, ctx->ws_poa.reserve(per_window * static_cast<size_t>(chunk) + 8192));
+  // MA_POA_SCHED: 1 (default) = the persistent kernel k_poa schedules the windows on the device; 0 = rounds 3-5's host-counted
+  // rounds of k_msa / k_msa_band (same device code: msa_window, band_job; same results, tested)
+  bool const sched = ws.split && ws.lean && !(getenv("MA_POA_SCHED") && atoi(getenv("MA_POA_SCHED")) == 0);
+  u32 qcap = 64;
+  while (qcap < static_cast<u32>(chunk)) qcap <<= 1;
+  MA_HIP(ctx, ctx->ws_poa.reserve(per_window * static_cast<size_t>(chunk) + 8192 + 2 * sizeof(u32) * qcap * kPoaDoms + sizeof(PoaSched)));
+  u32 const xcd_local = (getenv("MA_POA_XCD") && atoi(getenv("MA_POA_XCD")) == 0) ? 0u : 1u;
   if (getenv("MA_VERBOSE"))
     fprintf(stderr, "[microasm] msa: %d windows, %.2f MB/window, budget %.1f GB -> chunks of %d (pn %u, max_len %u, lds %zu)\n", n,
             per_window / 1048576.0, budget / 1073741824.0, chunk, pn, max_len, lds);
@@ -3225,6 +3403,20 @@ static int launch_msa_pass(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& a, 
                     : (max_len <= 1024 ? k_msa<4, false> : (max_len <= 2048 ? k_msa<8, false> : k_msa<16, false>));
   MA_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   static_cast<int>(lds)));
+  auto pkern = lab32 ? (max_len <= 1024 ? k_poa<4, true> : (max_len <= 2048 ? k_poa<8, true> : k_poa<16, true>))
+                     : (max_len <= 1024 ? k_poa<4, false> : (max_len <= 2048 ? k_poa<8, false> : k_poa<16, false>));
+  if (sched)
+    MA_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(pkern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    static_cast<int>(lds)));
+  // workgroups of the persistent kernel: what the chip holds at once (two per CU while the graph fits 80 KB of LDS; a lane
+  // that runs beside others may be told to take one -- MA_POA_WGS_PER_CU -- and leave the other half of every CU's LDS to them)
+  int n_cu = 256;
+  {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess && prop.multiProcessorCount > 0) n_cu = prop.multiProcessorCount;
+  }
+  int wgs_per_cu = lds > 80 * 1024 ? 1 : 2;
+  if (const char* e = getenv("MA_POA_WGS_PER_CU")) wgs_per_cu = std::max(1, std::min(wgs_per_cu, atoi(e)));
   for (int win0 = 0; win0 < n; win0 += chunk) {
     int const nwin = std::min(chunk, n - win0);
     char* base = static_cast<char*>(ctx->ws_poa.p);
@@ -3243,7 +3435,28 @@ static int launch_msa_pass(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& a, 
       MA_HIP(ctx, hipMemsetAsync(ctr, 0, 64, ctx->stream));
     }
     MsaArgs args{b, a, o, ws, P, win0, 0u, 0u};
-    if (!ws.split) {
+    if (sched) {
+      char* qb = reinterpret_cast<char*>(ws.pending_ctr) + 256;
+      PoaSched* const S = reinterpret_cast<PoaSched*>(qb);
+      u32* const fq = reinterpret_cast<u32*>(qb + sizeof(PoaSched));
+      u32* const gq = fq + static_cast<size_t>(qcap) * kPoaDoms;
+      u32 const grid = static_cast<u32>(std::min(nwin, n_cu * wgs_per_cu));
+      MA_HIP(ctx, hipMemsetAsync(S, 0, sizeof(PoaSched), ctx->stream));
+      MA_HIP(ctx, hipMemsetAsync(fq, 0xFF, 2 * sizeof(u32) * qcap * kPoaDoms, ctx->stream));
+      ctx->tic("k_poa");
+      hipLaunchKernelGGL(pkern, dim3(grid), dim3(kT), lds, ctx->stream, args, S, fq, gq, qcap, static_cast<u32>(nwin), xcd_local,
+                         static_cast<u32>(getenv("MA_POA_MIN_FILLS") ? atoi(getenv("MA_POA_MIN_FILLS")) : 4));
+      ctx->toc();
+      if (verbose) {
+        PoaSched hs;
+        MA_HIP(ctx, hipMemcpyAsync(&hs, S, sizeof(hs), hipMemcpyDeviceToHost, ctx->stream));
+        MA_HIP(ctx, ma_stream_sync(ctx));
+        fprintf(stderr, "[microasm] k_poa: %u workgroups, %d windows; per XCD (workgroups / windows started):", grid, nwin);
+        for (u32 x = 0; x < kPoaDoms; ++x)
+          if (hs.dom[x].seen) fprintf(stderr, " %u: %u / %u", x, hs.dom[x].seen, hs.dom[x].started);
+        fprintf(stderr, "\n");
+      }
+    } else if (!ws.split) {
       args.finish = 1;
       ctx->tic("k_msa");
       hipLaunchKernelGGL(kern, dim3(nwin), dim3(kT), lds, ctx->stream, args);

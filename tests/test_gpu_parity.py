@@ -183,8 +183,9 @@ def test_msa_parity_band_tiers(tier0, min_pending, monkeypatch):
     from lancet2_amd.engine import Engine
     monkeypatch.setenv("MA_POA_TIER0", tier0)
     monkeypatch.setenv("MA_POA_NO_DIRECT", "1")  # every alignment takes a fill
-    if min_pending is not None:
+    if min_pending is not None:  # (round 6: the host-counted rounds are MA_POA_SCHED=0; None = the persistent kernel k_poa)
         monkeypatch.setenv("MA_POA_MIN_PENDING", min_pending)
+        monkeypatch.setenv("MA_POA_SCHED", "0")
     params = capi.default_params(min_k=25, max_k=25)
     for cfg, nwin, kw in (("C2", 5, {}), ("C2", 3, dict(big_indel=60)), ("C2", 3, dict(snv_rate=8e-3, indel_rate=2e-3)),
                           ("C2", 2, dict(W=1700))):
@@ -199,6 +200,44 @@ def test_msa_parity_band_tiers(tier0, min_pending, monkeypatch):
             eng.close()
         bad = compare_vars(params, got, want, n)
         assert not bad, (cfg, kw, "\n".join(bad[:20]))
+
+
+@pytest.mark.parametrize("sched,wgs", [("1", None), ("1", "1"), ("0", None)])
+def test_msa_persistent_kernel_on_a_batch_that_overfills_the_chip(sched, wgs, monkeypatch):
+    """Round 6: k_poa schedules the windows on the device (fresh windows off a counter, fills and resumed windows through two
+    queues in HBM, windows handed from workgroup to workgroup through their LDS image).  1536 windows -- three times what the
+    chip holds at once, so workgroups take window after window and fills of many windows are in flight while others are
+    resumed -- with every alignment through a fill (no closed forms) and indels that fail the first tier: the variants of all
+    1536 equal the oracle's for the 96 distinct windows they are copies of; two workgroups per CU, one, and the host-counted
+    rounds (MA_POA_SCHED=0) alike."""
+    from lancet2_amd.engine import Engine
+    monkeypatch.setenv("MA_POA_SCHED", sched)
+    monkeypatch.setenv("MA_POA_NO_DIRECT", "1")
+    if wgs:
+        monkeypatch.setenv("MA_POA_WGS_PER_CU", wgs)
+    params = capi.default_params(min_k=25, max_k=25)
+    parts = [synth.make_config_batch("C2", 48, first_index=8100), synth.make_config_batch("C2", 24, first_index=8300, big_indel=60),
+             synth.make_config_batch("C3", 24, first_index=8400, snv_rate=8e-3, indel_rate=2e-3)]
+    import bench
+    arrs0, n0, nr0 = bench.concat_batches(parts)
+    orc = OracleEngine(params)
+    asm0 = orc.assemble(arrs0, n0, nr0)
+    want0 = orc.msa(arrs0, n0, nr0, asm0)
+    times = 16
+    arrs, n, nr = synth.tile_batch(arrs0, n0, nr0, times)
+    asm = {k: np.tile(v, times) for k, v in asm0.items()}
+    want = {k: np.tile(v, times) for k, v in want0.items()}
+    eng = Engine(params)
+    try:
+        for _ in range(2):  # (a second call reuses the workspace: stale queue slots / images must not matter)
+            got = eng.msa(arrs, n, nr, asm)
+            bad = compare_vars(params, got, want, n)
+            assert not bad, "\n".join(bad[:20])
+        kt = dict(eng.kernel_times())
+    finally:
+        eng.close()
+    assert ("k_poa" in kt) == (sched == "1"), kt
+    assert want0["win_nvars"].sum() > 100
 
 
 @pytest.mark.parametrize("lean,raw_cap", [("0", None), ("1", "4"), ("1", "40")])
