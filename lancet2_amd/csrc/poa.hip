@@ -394,6 +394,8 @@ __device__ __forceinline__ i32 col0_f(u32 d) { return G_ + E_ * static_cast<i32>
 __device__ __forceinline__ i32 col0_h(u32 d) { return max(col0_o(d), col0_f(d)); }
 
 #ifdef MA_PROFILE
+__device__ unsigned long long g_prof2[16];  // k_poa: [0] ticks scheduling (thread 0), [1] G jobs, [2] F phases (workgroup), [3] idle, [4..7] F phases of
+                                            // 1 / 2 / 3 / 4 fills, [8] G jobs, [9] idle polls, [10] whole kernel per workgroup
 __device__ unsigned long long g_prof[16];
 #define PROF_T0() unsigned long long _t0 = __builtin_amdgcn_s_memtime()
 #define PROF_ACC(slot)                                                        \
@@ -1392,9 +1394,10 @@ __device__ void poa_fill_lean(G const& g, u32 const w_stride, size_t const plane
   u8* cp = codes + static_cast<size_t>(BW) + static_cast<u32>(CW) * lane;  // this lane's code bytes of row 1
 
   // ---- the straight-line row ----
-  auto row_lean = [&](u32 const info) __attribute__((always_inline)) {
+  auto row_lean = [&](u32 const info, auto col0_tag) __attribute__((always_inline)) {
+    constexpr bool kCol0 = decltype(col0_tag)::value;  // two straight-line bodies: the ordinary row pays nothing for column 0
     u32 const nch = info & 0xFFu;
-    if (info & RI_SLIDE) {
+    if (!kCol0 && (info & RI_SLIDE)) {
       // lane 0's columns leave the window: exits
       i32 dm = H1[0];
 #pragma unroll
@@ -1410,11 +1413,19 @@ __device__ void poa_fill_lean(G const& g, u32 const w_stride, size_t const plane
       j0 += CW;
       load_sc_in();
     }
-    // vertical + diagonal part (lane 0 has nothing to its left: the fill value)
-    i32 hd = wave_shr1(H1[CW - 1], kNegInf);
+    // A row whose window starts at column 1 (info[31:16] = depth + 1, never together with a slide): column 0 is lane 0's left
+    // neighbour -- H(i, 0) = h0 and H(i - 1, 0) in closed form of the depth, no E / Q -- and enters the row's prefix maxima
+    // with the keys h0 - 1, h0 - 2 (jr = -1).  Every other row: nothing to the left of lane 0 (the fill values).
+    u32 const d1 = info >> 16;
+    constexpr bool col0 = kCol0;
+    i32 const h0 = col0 ? col0_h(d1 - 1u) : kNegInf;
+    i32 const hd0 = col0 ? col0_h(d1 - 2u) : kNegInf;  // (the FAST predecessor's depth is one less)
+    i32 const s10 = col0 ? h0 - 1 : NEG, s20 = col0 ? h0 - 2 : NEG;
+    // vertical + diagonal part
+    i32 hd = wave_shr1(H1[CW - 1], hd0);
     i32 ff[CW], oo[CW], hmv[CW], hh[CW], hv[CW], a1r[CW], a2r[CW];
     u32 acc[CW];  // the sign bits of each column, most significant first
-    i32 run1 = NEG, run2 = NEG;
+    i32 run1 = lane0 ? s10 : NEG, run2 = lane0 ? s20 : NEG;
 #pragma unroll
     for (int c = 0; c < CW; ++c) {
       i32 const ph = H1[c];
@@ -1436,15 +1447,16 @@ __device__ void poa_fill_lean(G const& g, u32 const w_stride, size_t const plane
     }
     // prefix maxima over the window
     i32 const inc1 = wave_incl_max(run1, NEG), inc2 = wave_incl_max(run2, NEG);
-    i32 s1 = wave_shr1(inc1, NEG), s2 = wave_shr1(inc2, NEG);
+    i32 s1 = wave_shr1(inc1, s10), s2 = wave_shr1(inc2, s20);
     i32 ee[CW], qq[CW];
+    bool const no_left = lane0 && !col0;
 #pragma unroll
     for (int c = 0; c < CW; ++c) {
       i32 q = s1 + cq[c];
       i32 e = max(s2 + ce[c], q + (G_ + 1));
-      if (c == 0) {  // nothing to the left of the window's first column
-        q = lane0 ? kNegInf : q;
-        e = lane0 ? kNegInf : e;
+      if (c == 0) {  // nothing to the left of the window's first column (unless it is column 0)
+        q = no_left ? kNegInf : q;
+        e = no_left ? kNegInf : e;
       }
       s1 = max(s1, a1r[c]);
       s2 = max(s2, a2r[c]);
@@ -1452,8 +1464,9 @@ __device__ void poa_fill_lean(G const& g, u32 const w_stride, size_t const plane
       qq[c] = q;
       hh[c] = max(hh[c], max(e, q));
     }
-    // the column to the left of this lane's first one (lane 0: values that make eB = qB = false, see above)
-    i32 hl = wave_shr1(hh[CW - 1], kNegInf), el = wave_shr1(ee[CW - 1], kNegInf - 64), ql = wave_shr1(qq[CW - 1], kNegInf - 64);
+    // the column to the left of this lane's first one (lane 0: column 0's H, or the fill value; E / Q values that make
+    // eB = qB = false either way, see above)
+    i32 hl = wave_shr1(hh[CW - 1], h0), el = wave_shr1(ee[CW - 1], kNegInf - 64), ql = wave_shr1(qq[CW - 1], kNegInf - 64);
     // decision codes: five more sign bits per column, then the table
     u32 code = 0;
 #pragma unroll
@@ -1767,8 +1780,12 @@ __device__ void poa_fill_lean(G const& g, u32 const w_stride, size_t const plane
 #ifdef MA_PROFILE
     unsigned long long const q0 = __builtin_amdgcn_s_memtime();
 #endif
-    if (__builtin_expect((cur & RI_LEAN) != 0, 1)) row_lean(cur);
-    else row_gen(i, cur);
+    if (__builtin_expect((cur & RI_LEAN) != 0, 1)) {
+      if (__builtin_expect((cur >> 16) == 0, 1)) row_lean(cur, std::false_type{});
+      else row_lean(cur, std::true_type{});
+    } else {
+      row_gen(i, cur);
+    }
 #ifdef MA_PROFILE
     unsigned long long const q1 = __builtin_amdgcn_s_memtime();
     if (cur & RI_LEAN) t_lean += q1 - q0; else { t_gen += q1 - q0; n_gen++; }
@@ -2058,14 +2075,21 @@ __device__ __forceinline__ void band_flags(GL const& g, u32 V, u32 cwb, int tid)
   i32 e0 = kNegInf;
   for (u32 i = 1 + tid; i <= V; i += kT) {
     u32 info = g.rowinfo[i] & ~(RI_LEAN | RI_SLIDE);
+    if (info & RI_FAST) info &= 0xFFFFu;  // (a retried tier: the depth a column-0 lean row carried in its upper half)
     u32 const j0 = g.rowj0[i];
     if (j0 > 1) e0 = max(e0, col0_h(g.rowdepth[i]));
     if (i >= 2 && cwb) {
       u32 const jp = g.rowj0[i - 1];
-      if ((info & RI_FAST) && !(info & RI_STORE) && j0 > 1 && (j0 == jp || j0 == jp + cwb) &&
-          g.nout[g.rank2node[i - 1]] != 0) {
-        info |= RI_LEAN;
-        if (j0 != jp) info |= RI_SLIDE;
+      if ((info & RI_FAST) && !(info & RI_STORE) && g.nout[g.rank2node[i - 1]] != 0) {
+        if (j0 > 1 && (j0 == jp || j0 == jp + cwb)) {
+          info = (info & 0xFFFFu) | RI_LEAN;
+          if (j0 != jp) info |= RI_SLIDE;
+        } else if (j0 == 1 && jp == 1) {
+          // (round 6) the window starts at column 1, like the previous row's: column 0 -- closed form of the row's depth --
+          // is lane 0's left neighbour.  Bits [31:16] (free in a FAST row) carry depth + 1; the ~64 first rows of every
+          // alignment took the any-shape row body for this alone (4200 cycles a row against 850)
+          info = (info & 0xFFFFu) | RI_LEAN | ((static_cast<u32>(g.rowdepth[i]) + 1u) << 16);
+        }
       }
     }
     g.rowinfo[i] = info;
@@ -3086,11 +3110,12 @@ __global__ __launch_bounds__(64, 4) void k_msa_band(MsaArgs A) {
 constexpr u32 kPoaDoms = 16;
 struct PoaDom {  // one per XCD, a cache line of its own
   u32 f_head, f_tail, g_head, g_tail;
+  u32 h_head, h_tail;  // fills of windows that are past their first alignment: taken first (the batch's critical path)
   u32 n_open;     // windows started here and not finished
   u32 n_workers;  // workgroups of this XCD in the loop
   u32 seen;       // workgroups that ever registered here, windows started here (MA_VERBOSE prints them)
   u32 started;
-  u32 pad[24];
+  u32 pad[22];
 };
 struct PoaSched {
   u32 fresh;  // next window that has not been started
@@ -3138,7 +3163,8 @@ __device__ __forceinline__ void poa_acquire(bool device_scope) {
 }
 
 template <int CWMAX, bool LAB32>
-__global__ __launch_bounds__(kT, LAB32 ? 1 : 2) void k_poa(MsaArgs A, PoaSched* S, u32* fq_all, u32* gq_all, u32 qcap, u32 nwin, u32 xcd_local, u32 policy_min_fills) {
+__global__ __launch_bounds__(kT, LAB32 ? 1 : 2) void k_poa(MsaArgs A, PoaSched* S, u32* fq_all, u32* gq_all, u32* hq_all, u32 qcap, u32 nwin,
+                                                           u32 xcd_local, u32 policy_min_fills) {
   __shared__ u32 sh_job[8];  // [0] kind: 0 nothing right now, 1 fresh window, 2 window back from its fill, 3 fills, 4 leave; [1] count; [2..5] windows
   int const tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // HW_REG_XCC_ID (id 20), bits [3:0]: the XCD this workgroup runs on
@@ -3146,12 +3172,20 @@ __global__ __launch_bounds__(kT, LAB32 ? 1 : 2) void k_poa(MsaArgs A, PoaSched* 
   PoaDom* const D = &S->dom[dom_id];
   u32* const fq = fq_all + static_cast<size_t>(dom_id) * qcap;
   u32* const gq = gq_all + static_cast<size_t>(dom_id) * qcap;
+  u32* const hq = hq_all + static_cast<size_t>(dom_id) * qcap;
   u32 const qmask = qcap - 1u;
   bool const dev_scope = !xcd_local;
   if (tid == 0) {
     atomicAdd(&D->n_workers, 1u);
     atomicAdd(&D->seen, 1u);
   }
+#ifdef MA_PROFILE
+  unsigned long long pt = __builtin_amdgcn_s_memtime();
+  unsigned long long const pt_begin = pt;
+#define KPOA_ACC(slot) do { unsigned long long const _n = __builtin_amdgcn_s_memtime(); if (tid == 0) atomicAdd(&g_prof2[slot], _n - pt); pt = _n; } while (0)
+#else
+#define KPOA_ACC(slot) do {} while (0)
+#endif
   for (;;) {
     __syncthreads();  // (the previous job's last LDS reads)
     if (tid == 0) {
@@ -3159,14 +3193,19 @@ __global__ __launch_bounds__(kT, LAB32 ? 1 : 2) void k_poa(MsaArgs A, PoaSched* 
       // A fill occupies its wavefront for ~0.5 ms and the whole workgroup waits for it: fills are taken when there is a
       // workgroup's worth of them (four) -- or nothing else to do; until then windows that came back from their fill go first
       // (they are the furthest along: the batch's critical path is its windows with three or four alignments), then fresh ones.
-      u32 const f_avail = ld_dev(&D->f_tail) - ld_dev(&D->f_head);
-      if (static_cast<i32>(f_avail) >= static_cast<i32>(policy_min_fills)) cnt = q_pop(&D->f_head, &D->f_tail, fq, qmask, 4u, ids);
+      auto pop_fills = [&]() {  // later alignments first
+        u32 n = q_pop(&D->h_head, &D->h_tail, hq, qmask, 4u, ids);
+        if (n < 4u) n += q_pop(&D->f_head, &D->f_tail, fq, qmask, 4u - n, ids + n);
+        return n;
+      };
+      u32 const f_avail = (ld_dev(&D->f_tail) - ld_dev(&D->f_head)) + (ld_dev(&D->h_tail) - ld_dev(&D->h_head));
+      if (static_cast<i32>(f_avail) >= static_cast<i32>(policy_min_fills)) cnt = pop_fills();
       if (cnt) {
         kind = 3;
       } else if (q_pop(&D->g_head, &D->g_tail, gq, qmask, 1u, ids)) {
         kind = 2;
         cnt = 1;
-      } else if (ld_dev(&S->fresh) >= nwin && (cnt = q_pop(&D->f_head, &D->f_tail, fq, qmask, 4u, ids)) != 0) {
+      } else if (ld_dev(&S->fresh) >= nwin && (cnt = pop_fills()) != 0) {
         kind = 3;  // (no window left to start: whatever fills there are)
       } else {
         bool more = ld_dev(&S->fresh) < nwin;
@@ -3195,9 +3234,14 @@ __global__ __launch_bounds__(kT, LAB32 ? 1 : 2) void k_poa(MsaArgs A, PoaSched* 
     }
     __syncthreads();
     u32 const kind = sh_job[0], cnt = sh_job[1];
+    KPOA_ACC(0);
     if (kind == 4) break;
     if (kind == 0) {
       __builtin_amdgcn_s_sleep(64);
+      KPOA_ACC(3);
+#ifdef MA_PROFILE
+      if (tid == 0) atomicAdd(&g_prof2[9], 1ull);
+#endif
       continue;
     }
     if (kind == 3) {
@@ -3208,6 +3252,11 @@ __global__ __launch_bounds__(kT, LAB32 ? 1 : 2) void k_poa(MsaArgs A, PoaSched* 
         poa_release(dev_scope);  // codes, stored rows, last column, edge maximum, the image's `filled`
         if (lane == 0) q_push(&D->g_tail, gq, qmask, static_cast<u32>(lw));
       }
+#ifdef MA_PROFILE
+      __syncthreads();
+      KPOA_ACC(2);
+      if (tid == 0) atomicAdd(&g_prof2[3 + cnt], 1ull);
+#endif
       continue;
     }
     int const lw = static_cast<int>(sh_job[2]);
@@ -3216,15 +3265,34 @@ __global__ __launch_bounds__(kT, LAB32 ? 1 : 2) void k_poa(MsaArgs A, PoaSched* 
     if (st == kMsaYield) poa_release(dev_scope);  // the image (every wavefront wrote a part)
     __syncthreads();
     if (tid == 0) {
-      if (st == kMsaYield) q_push(&D->f_tail, fq, qmask, static_cast<u32>(lw));
-      else atomicSub(&D->n_open, 1u);
+      if (st == kMsaYield) {
+        // (the state block is still in LDS: which alignment of the window is this?)
+        bool const later = ST.c_cur > 0 || ST.h_cur > 1 || ST.band > A.ws.tier0;
+        if (later) q_push(&D->h_tail, hq, qmask, static_cast<u32>(lw)); else q_push(&D->f_tail, fq, qmask, static_cast<u32>(lw));
+      } else {
+        atomicSub(&D->n_open, 1u);
+      }
     }
+    KPOA_ACC(1);
+#ifdef MA_PROFILE
+    if (tid == 0) atomicAdd(&g_prof2[8], 1ull);
+#endif
   }
+#ifdef MA_PROFILE
+  if (tid == 0) atomicAdd(&g_prof2[10], __builtin_amdgcn_s_memtime() - pt_begin);
+#endif
 }
 
 }  // namespace
 
 #ifdef MA_PROFILE
+extern "C" void ma_debug_prof2(unsigned long long* out, int reset) {
+  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prof2), sizeof(unsigned long long) * 16);
+  if (reset) {
+    unsigned long long z[16] = {0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_prof2), z, sizeof(z));
+  }
+}
 extern "C" void ma_debug_prof(unsigned long long* out, int reset) {
   (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prof), sizeof(unsigned long long) * 16);
   if (reset) {
@@ -3394,7 +3462,7 @@ static int launch_msa_pass(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& a, 
   bool const sched = ws.split && ws.lean && !(getenv("MA_POA_SCHED") && atoi(getenv("MA_POA_SCHED")) == 0);
   u32 qcap = 64;
   while (qcap < static_cast<u32>(chunk)) qcap <<= 1;
-  MA_HIP(ctx, ctx->ws_poa.reserve(per_window * static_cast<size_t>(chunk) + 8192 + 2 * sizeof(u32) * qcap * kPoaDoms + sizeof(PoaSched)));
+  MA_HIP(ctx, ctx->ws_poa.reserve(per_window * static_cast<size_t>(chunk) + 8192 + 3 * sizeof(u32) * qcap * kPoaDoms + sizeof(PoaSched)));
   u32 const xcd_local = (getenv("MA_POA_XCD") && atoi(getenv("MA_POA_XCD")) == 0) ? 0u : 1u;
   if (getenv("MA_VERBOSE"))
     fprintf(stderr, "[microasm] msa: %d windows, %.2f MB/window, budget %.1f GB -> chunks of %d (pn %u, max_len %u, lds %zu)\n", n,
@@ -3440,12 +3508,13 @@ static int launch_msa_pass(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& a, 
       PoaSched* const S = reinterpret_cast<PoaSched*>(qb);
       u32* const fq = reinterpret_cast<u32*>(qb + sizeof(PoaSched));
       u32* const gq = fq + static_cast<size_t>(qcap) * kPoaDoms;
+      u32* const hq = gq + static_cast<size_t>(qcap) * kPoaDoms;
       u32 const grid = static_cast<u32>(std::min(nwin, n_cu * wgs_per_cu));
       MA_HIP(ctx, hipMemsetAsync(S, 0, sizeof(PoaSched), ctx->stream));
-      MA_HIP(ctx, hipMemsetAsync(fq, 0xFF, 2 * sizeof(u32) * qcap * kPoaDoms, ctx->stream));
+      MA_HIP(ctx, hipMemsetAsync(fq, 0xFF, 3 * sizeof(u32) * qcap * kPoaDoms, ctx->stream));
+      u32 const min_fills = static_cast<u32>(getenv("MA_POA_MIN_FILLS") ? atoi(getenv("MA_POA_MIN_FILLS")) : 16);
       ctx->tic("k_poa");
-      hipLaunchKernelGGL(pkern, dim3(grid), dim3(kT), lds, ctx->stream, args, S, fq, gq, qcap, static_cast<u32>(nwin), xcd_local,
-                         static_cast<u32>(getenv("MA_POA_MIN_FILLS") ? atoi(getenv("MA_POA_MIN_FILLS")) : 4));
+      hipLaunchKernelGGL(pkern, dim3(grid), dim3(kT), lds, ctx->stream, args, S, fq, gq, hq, qcap, static_cast<u32>(nwin), xcd_local, min_fills);
       ctx->toc();
       if (verbose) {
         PoaSched hs;

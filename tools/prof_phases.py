@@ -26,6 +26,7 @@ eng.set_streams(1)
 eng.process(arrs, nw, nr)
 buf = (C.c_ulonglong * 16)()
 for sym, names in (("ma_debug_chprof", ["load", "fastsv", "number", "anchors+cands", "classify", "states+jump", "positions", "segtable", "values", "simulate", "compact", "records", "strings", "sim_scan", "sim_turn", "x14", "x15"]), ("ma_debug_cprof", ["init", "components", "anchors", "compress1", "lowcov", "compress2", "tips", "trav_index", "cycle+cx", "maxflow", "emit", "e_rank+tables", "e_refhap", "e_buildseq", "e_dedup", "e_finalize+misc"]), ("ma_debug_vprof", ["encode", "vote", "argmax", "second", "clear", "mismatch", "emit", "pairs", "shortcut", "shortcut_hits", "shortcut_miss", "x11", "x12", "x13", "wave_total", "wg_setup(thread 0)"]),
+                   ("ma_debug_prof2", ["sched", "G_jobs", "F_phases", "idle", "F1", "F2", "F3", "F4", "n_G", "n_idle_polls", "wg_total"]),
                    ("ma_debug_prof", ["prep", "fill", "end+traceback", "add_alignment", "toposort", "extract", "first_seq", "img_restore", "fill_pre", "fill_barrier", "fill_post", "rows_generic", "rows", "band_fallbacks", "img_save"])):
     fn = getattr(eng.lib, sym, None)
     if fn is None:
@@ -35,6 +36,7 @@ eng.timing_control(1)
 eng.process(arrs, nw, nr)
 print({k: round(v, 2) for k, v in eng.kernel_times()})
 for sym, names in (("ma_debug_chprof", ["load", "fastsv", "number", "anchors+cands", "classify", "states+jump", "positions", "segtable", "values", "simulate", "compact", "records", "strings", "sim_scan", "sim_turn", "x14", "x15"]), ("ma_debug_cprof", ["init", "components", "anchors", "compress1", "lowcov", "compress2", "tips", "trav_index", "cycle+cx", "maxflow", "emit", "e_rank+tables", "e_refhap", "e_buildseq", "e_dedup", "e_finalize+misc"]), ("ma_debug_vprof", ["encode", "vote", "argmax", "second", "clear", "mismatch", "emit", "pairs", "shortcut", "shortcut_hits", "shortcut_miss", "x11", "x12", "x13", "wave_total", "wg_setup(thread 0)"]),
+                   ("ma_debug_prof2", ["sched", "G_jobs", "F_phases", "idle", "F1", "F2", "F3", "F4", "n_G", "n_idle_polls", "wg_total"]),
                    ("ma_debug_prof", ["prep", "fill", "end+traceback", "add_alignment", "toposort", "extract", "first_seq", "img_restore", "fill_pre", "fill_barrier", "fill_post", "rows_generic", "rows", "band_fallbacks", "img_save"])):
     fn = getattr(eng.lib, sym, None)
     if fn is None:
