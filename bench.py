@@ -45,7 +45,7 @@ STAGE_OF = {"gate_kernel": "gate",
             "k_mm_lds": "build", "k_mm_insert": "build", "k_count": "build", "k_rank": "build", "k_edges": "build",
             "k_edge_sort": "build", "k_graph": "build", "k_graph_gen": "build", "k_mm_q": "build", "k_mm_hbm": "build",
             "k_clean": "clean", "k_clean_chains": "clean", "k_clean_tail": "clean",
-            "k_msa": "poa", "k_msa_band": "poa",
+            "k_msa": "poa", "k_msa_band": "poa", "k_poa": "poa",
             "k_read_planes": "genotype", "k_plan": "genotype", "k_vote": "genotype", "k_dp_scatter": "genotype", "k_align_reg": "genotype", "k_align_tb": "genotype",
             "k_align_wave": "genotype", "k_align_gen": "genotype", "k_assign": "genotype", "k_evidence": "genotype",
             "k_qual": "genotype"}
@@ -133,6 +133,11 @@ def kernel_bytes(kname, st):
         # written per band cell, a 14-byte row descriptor and the haplotype read per fill -- half of the alignments are
         # written down in closed form and never reach this kernel (rounds 3-5 billed every alignment a full 128-column band)
         "k_msa_band": st.get("poa_band_cells", 0.0) + st.get("poa_band_fills", 0.0) * (14 * (L + 1) + L),
+        # the persistent kernel (round 6) = the graph phases + the fills in one launch: haplotypes and variant records as k_msa,
+        # a code byte written and read back per band cell, per fill the 14-byte row descriptors and one save + restore of the
+        # window's LDS image (77 KB) -- not one per window and round
+        "k_poa": H * L + 16 * (L + st["var_bases"]) + 2 * st.get("poa_band_cells", 0.0) +
+                 st.get("poa_band_fills", 0.0) * (14 * (L + 1) + L + 2 * 77_000),
         "k_read_planes": B + 12 * (m / 32 + 2) * R,
         "k_vote": P * (12 * (m / 32 + 2) + 4 + 32) + H * L,
         "k_align_reg": Pdp * (2 * m + 45 / 2 * (m + 1) + 68),
@@ -938,7 +943,7 @@ def main():
                              "assembled_fraction": round(c_asm, 4)}
         ceng.close()
         # (2) the other WGS-shaped config, and the headline's windows sequenced 2 x 250
-        def device_leg(batch, label, leg_params=None, max_windows=None, kernels=False, parity_config=None):
+        def device_leg(batch, label, leg_params=None, max_windows=None, kernels=False, parity_config=None, resubmit=False):
             lp = leg_params or params
             o_arrs, o_n0, o_nr0 = batch
             o_arrs, o_n, o_nr = synth.tile_batch(o_arrs, o_n0, o_nr0, max(1, min(args.windows, n, max_windows or args.windows) // o_n0))
@@ -951,14 +956,54 @@ def main():
             oeng.timing_control(0)
             oeng.process_device(o_b, gs, as_, vs, o_qs)
             barrier()
+            # Windows that outgrew one of the CALLER's output caps (fixed strides: max_haps, max_hap_len, max_vars) are flagged;
+            # the host re-submits them on a context with larger buffers, as examples/host_driver.cpp does (max_haps 32,
+            # max_hap_len 4096, max_vars 256).  The flagged set of the warm-up step -- the steps run the same windows -- is
+            # gathered into a batch of its own, and every timed step runs it right behind the main batch: the leg's time
+            # includes the re-submission.
+            redo = None
+            if resubmit:
+                wst = a["win_status"].view(torch.int32).cpu().numpy().view(np.uint32)[:o_n]
+                capm = np.uint32(capi.MA_W_HAP_OVERFLOW | capi.MA_W_LEN_OVERFLOW | capi.MA_W_VAR_OVERFLOW)
+                fl = np.nonzero((wst & capm) != 0)[0]
+                if len(fl):
+                    parts = [synth.slice_batch(o_arrs, o_n, int(w_), int(w_) + 1) for w_ in fl]
+                    r_arrs, r_n, r_nr = concat_batches(parts)
+                    big = capi.default_params(**{f_: getattr(lp, f_) for f_, _ in capi.Params._fields_})
+                    big.max_haps, big.max_hap_len, big.max_vars, big.max_allele_bytes, big.max_runs = 32, 4096, 256, 16384, 512
+                    r_db = to_dev(r_arrs)
+                    r_out = [dev_alloc(capi.gate_out_spec(r_n)), dev_alloc(capi.asm_out_spec(big, r_n)),
+                             dev_alloc(capi.var_out_spec(big, r_n)), dev_alloc(capi.geno_out_spec(big, r_n, r_nr, debug=False))]
+                    r_structs = (capi.make_batch_struct(r_db, r_n, r_nr), capi.fill_struct(capi.GateOut, r_out[0]),
+                                 capi.fill_struct(capi.AsmOut, r_out[1]), capi.fill_struct(capi.VarOut, r_out[2]),
+                                 capi.fill_struct(capi.GenoOut, r_out[3]))
+                    os.environ["MA_HBM_SHARE"] = "0.15"  # a second context beside the leg's: a small share of the HBM
+                    reng = Engine(big, device=local_rank, memspace=capi.MA_MEM_DEVICE)
+                    os.environ.pop("MA_HBM_SHARE", None)
+                    # (on a stream of its own: the spare context works beside the main one -- the next batch's kernels run
+                    #  while the few re-submitted windows go through their serial deep-window searches; barrier() waits for both)
+                    r_stream = torch.cuda.Stream(dev)
+                    reng.set_stream(r_stream.cuda_stream)
+                    reng.timing_control(0)
+                    reng.process_device(*r_structs)
+                    barrier()
+                    redo = (reng, r_structs, r_out, r_n, fl, r_db, r_stream)
             if kernels:
                 oeng.timing_control(2)
             t_o = time.perf_counter()
             for _ in range(2):
                 oeng.process_device(o_b, gs, as_, vs, o_qs)
+                if redo:
+                    redo[0].process_device(*redo[1])
             barrier()
             dt_o = time.perf_counter() - t_o
-            ost = a["win_status"].view(torch.int32).cpu().numpy().view(np.uint32)[:o_n]
+            ost = a["win_status"].view(torch.int32).cpu().numpy().view(np.uint32)[:o_n].copy()
+            n_redone = 0
+            if redo:  # the re-submitted windows' status words replace their first-pass ones
+                rst = redo[2][1]["win_status"].view(torch.int32).cpu().numpy().view(np.uint32)[:redo[3]]
+                ost[redo[4]] = rst
+                n_redone = int(redo[3])
+                redo[0].close()
             o_asm = float(((ost & capi.MA_W_NO_HAPLOTYPE) == 0).mean())
             res = {"workload": label, "value": round(2 * o_n * o_asm / dt_o, 2), "unit": "assembled windows/s", "steps": 2,
                    "submitted_windows_per_s": round(2 * o_n / dt_o, 2), "assembled_fraction": round(o_asm, 4),
@@ -975,6 +1020,8 @@ def main():
                                                     "MA_W_CIGAR_OVERFLOW", "MA_W_READ_OVERFLOW")
                                          if ((ost & np.uint32(getattr(capi, nm))) != 0).any()}
                 res["windows_at_traversal_limit"] = int(((ost & capi.MA_W_BFS_LIMIT) != 0).sum())
+                if resubmit:
+                    res["windows_resubmitted_with_larger_buffers"] = n_redone
             if parity_config and kept and parity is not None:  # the oracle ran some of this leg's windows too (cpu_baselines)
                 pc, pbad, pfl = parity_check(kept, parity_config, first, lp, o_n, (g, a, v, o_q))
                 res["parity_sample"] = {"windows": pc, "mismatches": len(pbad), "flagged_windows_status_only": pfl}
@@ -992,7 +1039,8 @@ def main():
         if long_arrs is not None:
             also["reads_2x250"] = device_leg(long_arrs, WORKLOADS[args.config] + " -- sequenced as 2 x 250 bp reads")
         if c4_arrs is not None:  # 7.1 k reads a window; a panel has ~10 k windows: 2048 per step (512 distinct, tiled)
-            also["c4_panel"] = device_leg(c4_arrs, WORKLOADS["C4"], max_windows=max(c4_arrs[1], 2048), kernels=True, parity_config="C4")
+            also["c4_panel"] = device_leg(c4_arrs, WORKLOADS["C4"], max_windows=max(c4_arrs[1], 2048), kernels=True, parity_config="C4",
+                                          resubmit=True)
             if cpu_c4:
                 also["c4_panel"]["cpu_baseline"] = cpu_c4
             also["c4_panel_512"] = device_leg(c4_arrs, WORKLOADS["C4"] + " -- 512 windows per step, every one distinct", max_windows=c4_arrs[1])

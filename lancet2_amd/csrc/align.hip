@@ -2923,28 +2923,43 @@ __global__ __launch_bounds__(64) void k_evidence(GArgs A) {
 // K (K + 1) / 2 genotypes in VCF order; the same sequential f64 operations as the reference, lgamma from the device
 // math library (the PLs are integers: a last-ulp difference in lgamma moves one only when it sits within ~1e-12 of a
 // rounding boundary).  Writes the PLs (optional) and returns PL[0/0]; *gq = second-smallest PL, capped at 99.
-__device__ u32 genotype_pls(const u32* cnt2, int K, u32* pl_out, u32* gq) {
+// Round 6: every alpha is one of THREE values whatever the allele (background only / + half / + all of the main mass), so the
+// 2 K lgamma calls inside every one of the 2 G genotype evaluations collapse to 3 K + 3 terms computed once -- term_j[k] is the
+// very difference lgamma(c[k] + alpha) - lgamma(alpha) the reference adds up, added up in the reference's order: the same bits,
+// a seventh of the calls.  KM = 5 (max_alts <= 4, the default): everything unrolled, the tables in registers -- the rolled
+// version kept c[] and a frame for the inlined lgamma in scratch (214 spilled VGPRs, 692 bytes per lane).
+template <int KM>
+__device__ __forceinline__ u32 genotype_pls(const u32* cnt2, int K, u32* pl_out, u32* gq) {
   constexpr f64 kBackgroundError = 0.005, kOverdispersion = 0.01, kAlphaFloor = 1e-6;
-  constexpr int kMaxK = 16;
   f64 const precision = (1.0 - kOverdispersion) / kOverdispersion;
   f64 const main_mass = 1.0 - kBackgroundError;
   f64 const cap = 4294967295.0 / 2.0, ln_ten = 2.302585092994045684017991454684364208;
-  f64 c[kMaxK];
-  for (int k = 0; k < K; ++k) c[k] = static_cast<f64>(cnt2[2 * k] + cnt2[2 * k + 1]);
+  f64 const mu0 = kBackgroundError / K;
+  f64 al[3];
+  al[0] = fmax(kAlphaFloor, mu0 * precision);
+  al[1] = fmax(kAlphaFloor, (mu0 + main_mass / 2.0) * precision);
+  al[2] = fmax(kAlphaFloor, (mu0 + main_mass) * precision);
+  f64 lg[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) lg[j] = lgamma(al[j]);
+  f64 c[KM], term[3][KM];
+#pragma unroll
+  for (int k = 0; k < KM; ++k) {
+    c[k] = k < K ? static_cast<f64>(cnt2[2 * k] + cnt2[2 * k + 1]) : 0.0;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) term[j][k] = k < K ? lgamma(c[k] + al[j]) - lg[j] : 0.0;
+  }
   auto loglk = [&](int a, int b) {
     f64 log_prob = 0.0, alpha_sum = 0.0, count_alpha_sum = 0.0;
-    for (int k = 0; k < K; ++k) {
-      f64 mu = kBackgroundError / K;
-      if (a == b) {
-        if (k == a) mu += main_mass;
-      } else {
-        if (k == a) mu += main_mass / 2.0;
-        if (k == b) mu += main_mass / 2.0;
+#pragma unroll
+    for (int k = 0; k < KM; ++k) {
+      if (k < K) {
+        bool const hom = a == b && k == a, het = a != b && (k == a || k == b);
+        f64 const alpha = hom ? al[2] : (het ? al[1] : al[0]);
+        log_prob += hom ? term[2][k] : (het ? term[1][k] : term[0][k]);
+        alpha_sum += alpha;
+        count_alpha_sum += c[k] + alpha;
       }
-      f64 const alpha = fmax(kAlphaFloor, mu * precision);
-      log_prob += lgamma(c[k] + alpha) - lgamma(alpha);
-      alpha_sum += alpha;
-      count_alpha_sum += c[k] + alpha;
     }
     return log_prob + (lgamma(alpha_sum) - lgamma(count_alpha_sum));
   };
@@ -2974,8 +2989,8 @@ __device__ u32 genotype_pls(const u32* cnt2, int K, u32* pl_out, u32* gq) {
 // case/control mode, otherwise the largest PL[0/0] over the samples with evidence
 // kWithPl = false: case / control mode without the PL / GQ outputs -- the genotype likelihoods (f64 lgamma, 128 VGPRs and
 // a scratch frame) are compiled out of the kernel the somatic path launches
-template <bool kWithPl>
-__global__ void k_qual(GArgs A) {
+template <bool kWithPl, int KM>
+__global__ __launch_bounds__(256) void k_qual(GArgs A) {
   i64 const tix = static_cast<i64>(blockIdx.x) * blockDim.x + threadIdx.x;
   ma_params_t const& P = A.prm;
   int const MV = P.max_vars, NA = P.max_alts + 1, S = P.num_samples, G = NA * (NA + 1) / 2;
@@ -2998,7 +3013,7 @@ __global__ void k_qual(GArgs A) {
     for (int s = 0; s < S; ++s) {
       if (cov(s, false) + cov(s, true) == 0) continue;  // evidence.Find(sample) == nullptr: missing support
       u32 gq = 0;
-      u32 const pl0 = genotype_pls(cnt + static_cast<size_t>(s) * NA * 2, K,
+      u32 const pl0 = genotype_pls<KM>(cnt + static_cast<size_t>(s) * NA * 2, K,
                                    A.o.var_pl ? A.o.var_pl + (static_cast<size_t>(idx) * S + s) * G : nullptr, &gq);
       if (A.o.var_gq) A.o.var_gq[static_cast<size_t>(idx) * S + s] = gq;
       qual = fmax(qual, static_cast<f64>(pl0));
@@ -3428,7 +3443,7 @@ int launch_genotype(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& a, const m
     if (A.o.var_pl) MA_HIP(ctx, hipMemsetAsync(A.o.var_pl, 0, 4ull * n * MV * P.num_samples * Gq, ctx->stream));
     if (A.o.var_gq) MA_HIP(ctx, hipMemsetAsync(A.o.var_gq, 0, 4ull * n * MV * P.num_samples, ctx->stream));
     bool const with_pl = !P.case_ctrl_mode || A.o.var_pl || A.o.var_gq;
-    auto kq = with_pl ? k_qual<true> : k_qual<false>;
+    auto kq = with_pl ? (NAq <= 5 ? k_qual<true, 5> : k_qual<true, 16>) : k_qual<false, 5>;
     hipLaunchKernelGGL(kq, dim3(static_cast<u32>((static_cast<size_t>(n) * MV + 255) / 256)), dim3(256), 0, ctx->stream, A);
   }
   ctx->toc();
