@@ -156,7 +156,7 @@ def units_per_step(stage, st):
     return st["assembled"]
 
 
-def pipeline_extract_leg(genome_len=2_400_000, depths=(30, 60), seed=0x5EED, threads=(1, -1)):
+def pipeline_extract_leg(genome_len=2_400_000, depths=(30, 60), seed=0x5EED, threads=(1, -1), cxx_flags=()):
     """builds examples/pipeline_driver.cpp with g++, writes a random genome + two coordinate-sorted SAM files (150-base paired
     reads, plain 150M alignments) and times the extract stage on them: the driver prints each stage's busy time"""
     import re
@@ -169,9 +169,9 @@ def pipeline_extract_leg(genome_len=2_400_000, depths=(30, 60), seed=0x5EED, thr
     try:
         exe = os.path.join(d, "pipeline_driver")
         lib = os.path.join(REPO, "lancet2_amd")
-        subprocess.check_call(["g++", "-std=c++17", "-O2", os.path.join(REPO, "examples", "pipeline_driver.cpp"), "-I", os.path.join(REPO, "include"),
+        subprocess.check_call(["g++", "-std=c++17", "-O3", os.path.join(REPO, "examples", "pipeline_driver.cpp"), "-I", os.path.join(REPO, "include"),
                                "-L", lib, "-lmicroasm", f"-Wl,-rpath,{lib}", "-Wl,--allow-shlib-undefined", "-DLANCET2_AMD_WITH_ZLIB", "-lz",
-                               "-lpthread", "-o", exe])
+                               "-lpthread", "-o", exe] + list(cxx_flags))
         rng = np.random.default_rng(seed)
         genome = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, genome_len)]
         with open(os.path.join(d, "ref.fa"), "w") as f:

@@ -271,6 +271,16 @@ int main(int argc, char** argv) {
   }
 
   Channel<Job> to_engine(3), to_flush(3);
+  // batches whose records are flushed go back to the extract stage with their arrays' memory (a fresh batch is 300 MB of
+  // pages to fault in, on the copying threads: a quarter of the stage's time)
+  std::mutex pool_mu;
+  std::vector<std::unique_ptr<FlatBatch>> batch_pool;
+  auto recycle = [&](std::unique_ptr<FlatBatch> b) {
+    if (!b) return;
+    b->Clear();
+    std::lock_guard<std::mutex> g(pool_mu);
+    if (batch_pool.size() < 6) batch_pool.push_back(std::move(b));
+  };
   size_t n_skipped[5] = {0, 0, 0, 0, 0};
   // busy time of each stage (what it spends on its own work, not waiting for its neighbours): windows / busy second is the
   // rate the stage could sustain alone -- the slowest of the three bounds the pipeline
@@ -295,6 +305,35 @@ int main(int argc, char** argv) {
   std::atomic<bool> worker_failed{false};
   std::exception_ptr worker_error;
   std::mutex worker_mu;
+  // Round 6: the ordered thread no longer copies the windows' arrays into the batch (43 us of ONE thread per window: the stage's
+  // bound at 23-30 k windows/s whatever the number of collectors).  It appends a window's scalars (FlatBatch::PlaceHeader), and
+  // when a batch is closed and sized its windows are copied into their places by whoever has a hand free -- the collectors
+  // between two windows, the ordered thread while it waits.
+  struct CopyTask {
+    FlatBatch* dst = nullptr;
+    std::unique_ptr<FlatBatch> src;
+    FlatBatch::Place place{};
+    std::atomic<size_t>* left = nullptr;
+  };
+  std::mutex copy_mu;
+  std::deque<CopyTask> copy_q;
+  std::atomic<size_t> copy_pending{0};
+  std::atomic<bool> extract_done{false};
+  auto serve_copy = [&]() -> bool {
+    if (copy_pending.load(std::memory_order_acquire) == 0) return false;
+    CopyTask t;
+    {
+      std::lock_guard<std::mutex> g(copy_mu);
+      if (copy_q.empty()) return false;
+      t = std::move(copy_q.front());
+      copy_q.pop_front();
+    }
+    copy_pending.fetch_sub(1, std::memory_order_acq_rel);
+    t.dst->CopyPlaced(*t.src, t.place);
+    t.src.reset();
+    t.left->fetch_sub(1, std::memory_order_acq_rel);
+    return true;
+  };
   std::vector<std::thread> workers;
   for (int t = 0; t < extract_threads; ++t)
     workers.emplace_back([&, t] {
@@ -310,8 +349,13 @@ int main(int argc, char** argv) {
 #endif
       ReadCollector collector(rp, mine);
       while (true) {
-        size_t const i = next_window.fetch_add(1);
-        if (i >= windows.size()) break;
+        if (serve_copy()) continue;  // a closed batch waits for its windows' arrays: those first
+        size_t const i = next_window.load() < windows.size() ? next_window.fetch_add(1) : windows.size();
+        if (i >= windows.size()) {
+          if (extract_done.load(std::memory_order_acquire)) break;
+          std::this_thread::sleep_for(std::chrono::microseconds(50));
+          continue;
+        }
         if (worker_failed.load(std::memory_order_acquire)) {  // another collector hit a corrupt input: hand over empty slots, stop
           slots[i].st = WindowStatus::SKIPPED_NONLY_REF_BASES;
           slots[i].ready.store(1, std::memory_order_release);
@@ -359,15 +403,37 @@ int main(int argc, char** argv) {
     size_t hint_bases = 0, hint_reads = 0, hint_ref = 0;  // the last batch's sizes: the next one's arrays are reserved whole
     auto fresh = [&] {
       Job j;
-      j.batch = std::make_unique<FlatBatch>();
+      {
+        std::lock_guard<std::mutex> g(pool_mu);
+        if (!batch_pool.empty()) {
+          j.batch = std::move(batch_pool.back());
+          batch_pool.pop_back();
+        }
+      }
+      if (!j.batch) j.batch = std::make_unique<FlatBatch>();
       if (hint_reads) j.batch->Reserve(static_cast<size_t>(batch_windows), hint_ref, hint_reads, hint_bases);
       return j;
     };
     Job cur = fresh();
     size_t n_dumped = 0;
+    std::vector<CopyTask> staged;  // the current batch's windows, in order
     auto ship = [&] {
       if (cur.batch->windows.empty()) return;
       auto const ts = Clock::now();
+      cur.batch->SizeForPlaced();
+      std::atomic<size_t> left{staged.size()};
+      {
+        std::lock_guard<std::mutex> g(copy_mu);
+        for (auto& t : staged) {
+          t.dst = cur.batch.get();
+          t.left = &left;
+          copy_q.push_back(std::move(t));
+        }
+      }
+      copy_pending.fetch_add(staged.size(), std::memory_order_acq_rel);
+      staged.clear();
+      while (left.load(std::memory_order_acquire) != 0)
+        if (!serve_copy()) std::this_thread::yield();
       hint_bases = cur.batch->read_bases.size() + cur.batch->read_bases.size() / 16;
       hint_reads = cur.batch->read_qname_id.size() + cur.batch->read_qname_id.size() / 16;
       hint_ref = cur.batch->ref_bases.size() + 64;
@@ -390,7 +456,10 @@ int main(int argc, char** argv) {
       auto const t0 = Clock::now();
       n_skipped[static_cast<int>(sl.st)]++;
       if (sl.st == WindowStatus::RUN) {
-        cur.batch->Append(*sl.flat);
+        CopyTask t;
+        t.place = cur.batch->PlaceHeader(*sl.flat);
+        t.src = std::move(sl.flat);
+        staged.push_back(std::move(t));
         n_shipped++;
       }
       sl.flat.reset();
@@ -399,13 +468,17 @@ int main(int argc, char** argv) {
       if (static_cast<int>(cur.batch->windows.size()) >= batch_windows) ship();
     }
     ship();
+    extract_done.store(true, std::memory_order_release);
     to_engine.Close();
   });
   // ---- stage 2: engine ----
   std::thread engine([&] {
     Job j;
     while (to_engine.Pop(&j)) {
-      if (extract_only) continue;
+      if (extract_only) {
+        recycle(std::move(j.batch));
+        continue;
+      }
       Job* nxt = nullptr;
       if (to_engine.Peek(&nxt)) ma_prefetch_batch(ctx, &nxt->batch->view);  // uploads under this batch's kernels
       auto const t0 = Clock::now();
@@ -462,6 +535,7 @@ int main(int argc, char** argv) {
         n_flagged += (st & ~static_cast<uint32_t>(MA_W_NO_HAPLOTYPE | MA_W_BFS_LIMIT)) ? 1 : 0;
       }
       busy_flush += secs(Clock::now() - tf);
+      recycle(std::move(j.batch));
     }
     auto const tf = Clock::now();
     write(store.ExtractAll());

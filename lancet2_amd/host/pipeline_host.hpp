@@ -941,8 +941,29 @@ inline double CrossSampleMeanCoverage(std::vector<SampleInfo> const& samples, ui
 }
 
 // ---- Flatten: windows + collected reads -> ma_batch_t ------------------------------------------------------------------------
+// A vector whose resize() does not zero what it adds: the big byte arrays (100-200 KB per window, 400 MB per batch) are sized
+// first and filled right after -- value-initialising them was a memset of every byte in front of the memcpy that overwrites it.
+template <class T>
+struct NoInitAlloc : std::allocator<T> {
+  template <class U>
+  struct rebind { using other = NoInitAlloc<U>; };
+  NoInitAlloc() = default;
+  template <class U>
+  NoInitAlloc(NoInitAlloc<U> const&) {}
+  template <class U, class... A>
+  void construct(U* p_, A&&... a) {
+    if constexpr (sizeof...(A) == 0) ::new (static_cast<void*>(p_)) U;
+    else ::new (static_cast<void*>(p_)) U(std::forward<A>(a)...);
+  }
+};
+#ifdef MA_BYTEVEC_STD  // (A/B knob of tools/dbg/extract_ab.py)
+using ByteVec = std::vector<uint8_t>;
+#else
+using ByteVec = std::vector<uint8_t, NoInitAlloc<uint8_t>>;
+#endif
 struct FlatBatch {
-  std::vector<uint8_t> ref_bases, read_bases, read_quals, read_sample, read_flags;
+  ByteVec ref_bases, read_bases, read_quals;
+  std::vector<uint8_t> read_sample, read_flags;
   std::vector<uint32_t> ref_off{0}, read_win_off{0}, read_qname_id;
   std::vector<uint64_t> read_off{0};
   std::vector<int32_t> read_hint;
@@ -992,6 +1013,59 @@ struct FlatBatch {
     for (size_t i = 1; i < o.ref_off.size(); ++i) ref_off.push_back(rb + o.ref_off[i]);
     for (size_t i = 1; i < o.read_off.size(); ++i) read_off.push_back(qb + o.read_off[i]);
     for (size_t i = 1; i < o.read_win_off.size(); ++i) read_win_off.push_back(nr + o.read_win_off[i]);
+  }
+  // The same, in two steps, for the extract stage's ordered thread (round 6: its Append() -- 200 KB copied per window on ONE
+  // thread -- bounded the whole stage at ~30 k windows/s whatever the number of collectors): PlaceHeader() appends only the
+  // window's scalars and returns where its arrays go; once the batch is closed SizeForPlaced() sizes the arrays (no zero-fill
+  // of the big ones) and any thread copies a window into its place with CopyPlaced() -- disjoint ranges, no locks.
+  struct Place {
+    size_t ref0, read0;
+    uint64_t base0;
+  };
+  Place PlaceHeader(FlatBatch const& o) {  // o holds ONE window (what CollectFlat / Add produce)
+    Place const pl{placed_ref_, placed_reads_, placed_bases_};
+    windows.insert(windows.end(), o.windows.begin(), o.windows.end());
+    sample_cov.insert(sample_cov.end(), o.sample_cov.begin(), o.sample_cov.end());
+    placed_ref_ += o.ref_bases.size();
+    placed_reads_ += o.read_qname_id.size();
+    placed_bases_ += o.read_bases.size();
+    ref_off.push_back(static_cast<uint32_t>(placed_ref_));
+    read_win_off.push_back(static_cast<uint32_t>(placed_reads_));
+    return pl;
+  }
+  void SizeForPlaced() {
+    ref_bases.resize(placed_ref_);
+    read_bases.resize(placed_bases_);
+    read_quals.resize(placed_bases_);
+    read_sample.resize(placed_reads_);
+    read_flags.resize(placed_reads_);
+    read_qname_id.resize(placed_reads_);
+    read_hint.resize(placed_reads_);
+    read_off.resize(placed_reads_ + 1);
+    read_off[0] = 0;
+  }
+  void CopyPlaced(FlatBatch const& o, Place const& pl) {
+    if (!o.ref_bases.empty()) std::memcpy(ref_bases.data() + pl.ref0, o.ref_bases.data(), o.ref_bases.size());
+    size_t const nr = o.read_qname_id.size();
+    if (nr == 0) return;
+    std::memcpy(read_bases.data() + pl.base0, o.read_bases.data(), o.read_bases.size());
+    std::memcpy(read_quals.data() + pl.base0, o.read_quals.data(), o.read_quals.size());
+    std::memcpy(read_sample.data() + pl.read0, o.read_sample.data(), nr);
+    std::memcpy(read_flags.data() + pl.read0, o.read_flags.data(), nr);
+    std::memcpy(read_qname_id.data() + pl.read0, o.read_qname_id.data(), nr * sizeof(uint32_t));
+    std::memcpy(read_hint.data() + pl.read0, o.read_hint.data(), nr * sizeof(int32_t));
+    for (size_t i = 1; i <= nr; ++i) read_off[pl.read0 + i] = pl.base0 + o.read_off[i];
+  }
+  size_t placed_ref_ = 0, placed_reads_ = 0;
+  uint64_t placed_bases_ = 0;
+  // back to an empty batch that KEEPS its arrays' memory: a recycled batch does not fault 300 MB of fresh pages in again
+  void Clear() {
+    ref_bases.clear(); read_bases.clear(); read_quals.clear(); read_sample.clear(); read_flags.clear();
+    ref_off.assign(1, 0); read_win_off.assign(1, 0); read_off.assign(1, 0);
+    read_qname_id.clear(); read_hint.clear(); windows.clear(); sample_cov.clear();
+    placed_ref_ = placed_reads_ = 0;
+    placed_bases_ = 0;
+    view = ma_batch_t{};
   }
   void Reserve(size_t n_win, size_t n_ref, size_t n_reads, size_t n_bases) {  // (Append then never re-allocates and copies what it holds)
     windows.reserve(n_win); sample_cov.reserve(n_win); ref_off.reserve(n_win + 1); read_win_off.reserve(n_win + 1);

@@ -211,6 +211,22 @@ int main() {
       one.Add(*pr.first, ref, *pr.second, &si);
       pieces.Append(one);
     }
+    {  // round 6: the same batch placed in two steps (headers in order, arrays copied afterwards in ANY order)
+      FlatBatch placed;
+      std::vector<std::pair<std::unique_ptr<FlatBatch>, FlatBatch::Place>> todo;
+      for (auto const& pr : {std::make_pair(&w0, &r0), std::make_pair(&w1, &r1), std::make_pair(&w2, &r2)}) {
+        auto one = std::make_unique<FlatBatch>();
+        one->Add(*pr.first, ref, *pr.second, &si);
+        FlatBatch::Place const pl = placed.PlaceHeader(*one);
+        todo.emplace_back(std::move(one), pl);
+      }
+      placed.SizeForPlaced();
+      for (size_t i = todo.size(); i-- > 0;) placed.CopyPlaced(*todo[i].first, todo[i].second);
+      CHECK(serial.ref_bases == placed.ref_bases && serial.read_bases == placed.read_bases && serial.read_quals == placed.read_quals);
+      CHECK(serial.read_sample == placed.read_sample && serial.read_flags == placed.read_flags && serial.read_hint == placed.read_hint);
+      CHECK(serial.ref_off == placed.ref_off && serial.read_off == placed.read_off && serial.read_win_off == placed.read_win_off);
+      CHECK(serial.read_qname_id == placed.read_qname_id && serial.sample_cov == placed.sample_cov && placed.windows.size() == 3);
+    }
     CHECK(serial.ref_bases == pieces.ref_bases && serial.read_bases == pieces.read_bases && serial.read_quals == pieces.read_quals);
     CHECK(serial.read_sample == pieces.read_sample && serial.read_flags == pieces.read_flags && serial.read_hint == pieces.read_hint);
     CHECK(serial.ref_off == pieces.ref_off && serial.read_off == pieces.read_off && serial.read_win_off == pieces.read_win_off);
