@@ -76,7 +76,9 @@ typedef struct ma_params {
   int32_t min_aln_score;                 /* 80 (minimap2 min_dp_max default) */
   /* engine caps (outputs are fixed-stride; overflow sets a status bit) */
   int32_t max_comps;                     /* components kept per window (default 4) */
-  int32_t max_haps;                      /* haplotype slots per window, REF included (default 16) */
+  int32_t max_haps;                      /* haplotype slots per window, REF included (default 16, at most 32: a component of
+                                            17 .. 32 haplotypes takes the POA's 32-bit-label kernels; the reference has no cap,
+                                            cbdg/graph.cpp:846-924 -- beyond 32 the window is flagged MA_W_HAP_OVERFLOW) */
   int32_t max_hap_len;                   /* bytes per haplotype slot (default 2048) */
   int32_t max_runs;                      /* (weight,nbases) runs per haplotype (default 256) */
   int32_t max_vars;                      /* variants per window (default 64) */

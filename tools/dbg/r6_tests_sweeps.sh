@@ -10,4 +10,4 @@ timeout 600 python3 tools/sweep_poa.py > gpurun_out/r6g/r6_sweep_poa.txt 2>&1
 timeout 600 python3 tools/sweep_poa.py 500 > gpurun_out/r6g/r6_sweep_poa_shift500.txt 2>&1
 MA_POA_SCHED=0 timeout 600 python3 tools/sweep_poa.py > gpurun_out/r6g/r6_sweep_poa_host_rounds.txt 2>&1
 for s in 1 2 3 4; do MA_SWEEP_SEED=$s timeout 600 python3 -m pytest tests/test_gpu_aligner.py -x -q -m gpu 2>&1 | tail -2; done > gpurun_out/r6g/r6_aligner_seeds.txt 2>&1
-tail -3 gpurun_out/r6g/*.txt
+for f in gpurun_out/r6g/*.txt; do tail -n 2 $f; done
