@@ -392,24 +392,45 @@ __global__ __launch_bounds__(64) void k_classify(DBatch b, GraphWs ws, u32* max_
       bool const use_hint = hint != MA_NO_HINT && hint > -100000 && hint < 100000 && si.nk <= 32u * kMaskWords;
       all_slow = !use_hint;
       i32 const h0 = use_hint ? hint : 0;
-      u32 const last = si.len - 1, ku = static_cast<u32>(k), nk = si.nk;
-      i32 const rlast = ref_len > 0 ? ref_len - 1 : 0;
-      // does read base i equal the reference base at hint + i?  (loads unconditional, the range test on the result)
-      auto ref_at = [&](u32 i) -> u32 { return l_ref[min(max(h0 + static_cast<i32>(i), 0), rlast)]; };
+      u32 const ku = static_cast<u32>(k), nk = si.nk;
       auto in_ref = [&](u32 i) -> bool {
         i32 const rp = h0 + static_cast<i32>(i);
         return rp >= 0 && rp < ref_len;
       };
       f64 lead = 0.0, lag = 0.0;  // prefix[o+k] and prefix[o] of graph.cpp:283-285
       i32 mm = 0;                 // mismatches of read[o, o+k) against ref[hint+o, ...)
+      // Round 6: FOUR bytes per LDS load.  The lane loop was bound by the LDS pipeline, not by latency: 24 one-byte loads per
+      // trip of four positions, each lane at its own read's offset (150 bytes apart: bank conflicts) -- ~2100 cycles per
+      // trip with seven wavefronts on a CU.  A stream of consecutive bytes at ANY offset is one aligned dword per trip and a
+      // byte-align with the previous one (v_alignbyte); the reference stream, whose offset is the read's hint and may leave
+      // the staged window on either side, takes two clamped dwords per trip (a byte that is in range always comes from an
+      // unclamped index; what lies outside is never looked at: in_ref()).  16 LDS loads per trip instead of 32.
+      u32 const* const lds32 = reinterpret_cast<u32 const*>(lds_build);
+      u32 const q_byte0 = static_cast<u32>(q - lds_build), s_byte0 = static_cast<u32>(s - lds_build);
+      i32 const ref_words_m1 = static_cast<i32>(ref_cap >> 2) - 1;
+      // bytes [byte, byte + 4) of the staged tile: `prev` = the aligned dword that holds `byte` (kept from the trip before)
+      auto next4 = [&](u32 byte, u32& prev) -> u32 {
+        u32 const nxt = lds32[(byte >> 2) + 1u];
+        u32 const v = __builtin_amdgcn_alignbyte(nxt, prev, byte & 3u);
+        prev = nxt;
+        return v;
+      };
+      auto ref4 = [&](i32 pos) -> u32 {  // reference bytes at window positions [pos, pos + 4)
+        i32 const wi = pos >> 2;
+        u32 const w0 = lds32[static_cast<u32>(min(max(wi, 0), ref_words_m1))], w1 = lds32[static_cast<u32>(min(max(wi + 1, 0), ref_words_m1))];
+        return __builtin_amdgcn_alignbyte(w1, w0, static_cast<u32>(pos) & 3u);
+      };
       for (u32 i = 0; i < ku; i += 4) {
         u32 qv[4], sv[4], rv[4];
+        {
+          u32 pq = lds32[(q_byte0 + i) >> 2], ps = lds32[(s_byte0 + i) >> 2];
+          u32 const q4 = next4(q_byte0 + i, pq), s4 = next4(s_byte0 + i, ps), r4 = ref4(h0 + static_cast<i32>(i));
 #pragma unroll
-        for (u32 j = 0; j < 4; ++j) {
-          u32 const x = min(i + j, last);
-          qv[j] = q[x];
-          sv[j] = s[x];
-          rv[j] = ref_at(x);
+          for (u32 j = 0; j < 4; ++j) {
+            qv[j] = (q4 >> (8 * j)) & 0xFFu;
+            sv[j] = (s4 >> (8 * j)) & 0xFFu;
+            rv[j] = (r4 >> (8 * j)) & 0xFFu;
+          }
         }
         f64 pv[4];
 #pragma unroll
@@ -425,17 +446,22 @@ __global__ __launch_bounds__(64) void k_classify(DBatch b, GraphWs ws, u32* max_
       u32* mw = l_mask + static_cast<u32>(lane) * MW;
       u32* ew = l_emask + static_cast<u32>(lane) * MW;
       u32 sacc = 0, eacc = 0;
+      u32 pqo = lds32[q_byte0 >> 2], pqi = lds32[(q_byte0 + ku) >> 2], pso = lds32[s_byte0 >> 2], psi = lds32[(s_byte0 + ku) >> 2];
       for (u32 o = 0; o < nk; o += 4) {
         u32 qo[4], qi[4], so[4], si4[4], ro[4], ri[4];
+        {
+          u32 const qo4 = next4(q_byte0 + o, pqo), qi4 = next4(q_byte0 + o + ku, pqi);
+          u32 const so4 = next4(s_byte0 + o, pso), si44 = next4(s_byte0 + o + ku, psi);
+          u32 const ro4 = ref4(h0 + static_cast<i32>(o)), ri4 = ref4(h0 + static_cast<i32>(o + ku));
 #pragma unroll
-        for (u32 j = 0; j < 4; ++j) {
-          u32 const xo = min(o + j, last), xi = min(o + j + ku, last);
-          qo[j] = q[xo];
-          qi[j] = q[xi];
-          so[j] = s[xo];
-          si4[j] = s[xi];
-          ro[j] = ref_at(xo);
-          ri[j] = ref_at(xi);
+          for (u32 j = 0; j < 4; ++j) {
+            qo[j] = (qo4 >> (8 * j)) & 0xFFu;
+            qi[j] = (qi4 >> (8 * j)) & 0xFFu;
+            so[j] = (so4 >> (8 * j)) & 0xFFu;
+            si4[j] = (si44 >> (8 * j)) & 0xFFu;
+            ro[j] = (ro4 >> (8 * j)) & 0xFFu;
+            ri[j] = (ri4 >> (8 * j)) & 0xFFu;
+          }
         }
         f64 pl[4], pi[4];
 #pragma unroll
