@@ -298,13 +298,21 @@ constexpr u32 classify_mask_words(u32 max_read_len) { return (max_read_len + 31)
 // [31] canonical == as-seen (set by k_insert once it has hashed the k-mer) -- everything k_insert needs to write the instance
 // word without reading it first
 constexpr u32 kQPlus = 1u << 31, kQErrFree = 1u << 30, kQLast = 1u << 29, kQSeqMask = 0x1FFFFu;
-__global__ __launch_bounds__(64) void k_classify(DBatch b, GraphWs ws, u32* max_slow, u32 tiles_per_win, u32 tile_cap) {
+// Round 6: TWO wavefronts per tile.  The tile's 22 KB of staged reads allowed 1.75 wavefronts per SIMD, each a serial chain
+// per read (~170 vector instructions per trip of four positions): 0.15 instructions per SIMD and cycle.  Both wavefronts map a
+// lane to a read; wavefront 0 takes the k-mer positions below `split` (half of the longest read's, a multiple of 32: the
+// mask words of the two halves are disjoint), wavefront 1 the rest -- after a pre-pass that adds the read's Phred values up
+// to `split` + k in the reference's order (prefix sums are sequential by definition: the same additions, the same bits) and
+// counts the mismatches of the window it starts at.  Twice the wavefronts on the same LDS, 65 % of the chain.
+constexpr u32 kClsT = 128;
+__global__ __launch_bounds__(kClsT) void k_classify(DBatch b, GraphWs ws, u32* max_slow, u32 tiles_per_win, u32 tile_cap) {
   extern __shared__ unsigned char lds_build[];
   int const a = blockIdx.x / tiles_per_win;
   u32 const tile = blockIdx.x % tiles_per_win;
   int const w = static_cast<int>(ws.active[a]);
   int const k = win_kmer(ws, w);
-  int const lane = threadIdx.x;
+  int const lane = threadIdx.x & 63;
+  u32 const half = threadIdx.x >> 6;  // which wavefront of the tile
   u32 const ns = seq_count(b, w);
   u32 const nreads = ns - 1;
   if (tile * 64 >= nreads) return;
@@ -326,9 +334,9 @@ __global__ __launch_bounds__(64) void k_classify(DBatch b, GraphWs ws, u32* max_
   i32 const ref_len = static_cast<i32>(rsi.len);
   {
     const u8* s = b.ref_bases + rsi.off;
-    for (u32 i = lane; i < rsi.len && i < ws.max_ref_len + 8; i += 64) l_ref[i] = s[i];
+    for (u32 i = threadIdx.x; i < rsi.len && i < ws.max_ref_len + 8; i += kClsT) l_ref[i] = s[i];
   }
-  for (u32 i = lane; i < 256; i += 64) reinterpret_cast<u64*>(l_phred)[i] = c_phred_bits[i];
+  for (u32 i = threadIdx.x; i < 256; i += kClsT) reinterpret_cast<u64*>(l_phred)[i] = c_phred_bits[i];
   u32 const r0 = b.read_win_off[w] + tile * 64;
   u64 const byte0 = b.read_off[r0], byte1 = b.read_off[r0 + cnt];
   u64 const al0 = byte0 & ~static_cast<u64>(15);
@@ -339,11 +347,11 @@ __global__ __launch_bounds__(64) void k_classify(DBatch b, GraphWs ws, u32* max_
     // it would cross the end of the batch
     u64 const nwords = (byte1 - al0 + 15) >> 4;
     constexpr int kSU = 4;
-    for (u64 x0 = lane; x0 < nwords; x0 += 64 * kSU) {
+    for (u64 x0 = threadIdx.x; x0 < nwords; x0 += kClsT * kSU) {
       uint4 vb[kSU], vq[kSU];
 #pragma unroll
       for (int u = 0; u < kSU; ++u) {
-        u64 const x = x0 + 64 * u, at = al0 + 16 * x;
+        u64 const x = x0 + kClsT * u, at = al0 + 16 * x;
         vb[u] = vq[u] = make_uint4(0, 0, 0, 0);
         if (x < nwords) {
           if (at + 16 <= total_end) {
@@ -362,7 +370,7 @@ __global__ __launch_bounds__(64) void k_classify(DBatch b, GraphWs ws, u32* max_
       }
 #pragma unroll
       for (int u = 0; u < kSU; ++u) {
-        u64 const x = x0 + 64 * u;
+        u64 const x = x0 + kClsT * u;
         if (x < nwords && 16 * x + 16 <= tile_cap) {
           reinterpret_cast<uint4*>(l_bases)[x] = vb[u];
           reinterpret_cast<uint4*>(l_quals)[x] = vq[u];
@@ -376,15 +384,22 @@ __global__ __launch_bounds__(64) void k_classify(DBatch b, GraphWs ws, u32* max_
   u32 nslow = 0;
   bool all_slow = false;
   u32 s_idx = 0, my_nk = 0;
+  // this wavefront's k-mer positions of every read: [o_begin, o_end)
+  u32 const nk_longest = ws.max_read_len >= static_cast<u32>(k) ? ws.max_read_len - static_cast<u32>(k) + 1u : 1u;
+  u32 const split = max(32u, (nk_longest / 2u + 16u) & ~31u);
+  u32 my_begin = 0, read_nk = 0;
   if (lane < static_cast<int>(cnt)) {
     s_idx = 1 + tile * 64 + lane;
     SeqInfo const si = seq_info(b, w, s_idx, k);
     u32 const r = r0 + lane;
-    ws.rd_flag[r] = 0;
+    if (half == 0) ws.rd_flag[r] = 0;
     u64 const rel = si.off - al0;
     bool const fits = rel + si.len <= tile_cap;  // always true: tile_cap covers 64 reads of the longest length
-    if (si.nk != 0 && fits) {
-      my_nk = si.nk;
+    u32 const o_begin = half ? split : 0u, o_end = half ? si.nk : min(si.nk, split);
+    if (si.nk != 0 && fits && o_begin < o_end) {
+      my_nk = o_end;
+      my_begin = o_begin;
+      read_nk = si.nk;
       const u8* s = l_bases + rel;
       const u8* q = l_quals + rel;
       u32 const ibase = ws.seq_inst_base[base_idx + s_idx];
@@ -420,11 +435,25 @@ __global__ __launch_bounds__(64) void k_classify(DBatch b, GraphWs ws, u32* max_
         u32 const w0 = lds32[static_cast<u32>(min(max(wi, 0), ref_words_m1))], w1 = lds32[static_cast<u32>(min(max(wi + 1, 0), ref_words_m1))];
         return __builtin_amdgcn_alignbyte(w1, w0, static_cast<u32>(pos) & 3u);
       };
+      // wavefront 1's pre-pass: prefix[o_begin] by the same sequential additions the reference's prefix array is made of
+      // (the loop below then carries on from prefix[o_begin + k] and the mismatch count of the window at o_begin)
+      if (o_begin) {
+        u32 pq = lds32[q_byte0 >> 2];
+        for (u32 i = 0; i < o_begin; i += 4) {  // (o_begin is a multiple of 32)
+          u32 const q4 = next4(q_byte0 + i, pq);
+          f64 pv[4];
+#pragma unroll
+          for (u32 j = 0; j < 4; ++j) pv[j] = l_phred[(q4 >> (8 * j)) & 0xFFu];
+#pragma unroll
+          for (u32 j = 0; j < 4; ++j) lag = (i + j == 0) ? pv[j] : lag + pv[j];
+        }
+        lead = lag;
+      }
       for (u32 i = 0; i < ku; i += 4) {
         u32 qv[4], sv[4], rv[4];
         {
-          u32 pq = lds32[(q_byte0 + i) >> 2], ps = lds32[(s_byte0 + i) >> 2];
-          u32 const q4 = next4(q_byte0 + i, pq), s4 = next4(s_byte0 + i, ps), r4 = ref4(h0 + static_cast<i32>(i));
+          u32 pq = lds32[(q_byte0 + o_begin + i) >> 2], ps = lds32[(s_byte0 + o_begin + i) >> 2];
+          u32 const q4 = next4(q_byte0 + o_begin + i, pq), s4 = next4(s_byte0 + o_begin + i, ps), r4 = ref4(h0 + static_cast<i32>(o_begin + i));
 #pragma unroll
           for (u32 j = 0; j < 4; ++j) {
             qv[j] = (q4 >> (8 * j)) & 0xFFu;
@@ -438,16 +467,17 @@ __global__ __launch_bounds__(64) void k_classify(DBatch b, GraphWs ws, u32* max_
 #pragma unroll
         for (u32 j = 0; j < 4; ++j) {
           if (i + j < ku) {
-            lead = (i + j == 0) ? pv[j] : lead + pv[j];
-            mm += (use_hint && in_ref(i + j) && sv[j] == rv[j]) ? 0 : 1;
+            lead = (o_begin + i + j == 0) ? pv[j] : lead + pv[j];
+            mm += (use_hint && in_ref(o_begin + i + j) && sv[j] == rv[j]) ? 0 : 1;
           }
         }
       }
       u32* mw = l_mask + static_cast<u32>(lane) * MW;
       u32* ew = l_emask + static_cast<u32>(lane) * MW;
       u32 sacc = 0, eacc = 0;
-      u32 pqo = lds32[q_byte0 >> 2], pqi = lds32[(q_byte0 + ku) >> 2], pso = lds32[s_byte0 >> 2], psi = lds32[(s_byte0 + ku) >> 2];
-      for (u32 o = 0; o < nk; o += 4) {
+      u32 pqo = lds32[(q_byte0 + o_begin) >> 2], pqi = lds32[(q_byte0 + o_begin + ku) >> 2], pso = lds32[(s_byte0 + o_begin) >> 2],
+          psi = lds32[(s_byte0 + o_begin + ku) >> 2];
+      for (u32 o = o_begin; o < o_end; o += 4) {
         u32 qo[4], qi[4], so[4], si4[4], ro[4], ri[4];
         {
           u32 const qo4 = next4(q_byte0 + o, pqo), qi4 = next4(q_byte0 + o + ku, pqi);
@@ -473,7 +503,7 @@ __global__ __launch_bounds__(64) void k_classify(DBatch b, GraphWs ws, u32* max_
 #pragma unroll
         for (u32 j = 0; j < 4; ++j) {
           u32 const oo = o + j;
-          if (oo < nk) {
+          if (oo < o_end) {
             // floor(prefix[o+k] - prefix[o]) == 0  <=>  difference < 1.0 (prefix is non-decreasing)
             bool const errfree = (lead - lag) < 1.0;
             u32 word = (errfree ? kInstErrFree : 0u) | (oo + 1 == nk ? kInstLast : 0u);
@@ -498,7 +528,7 @@ __global__ __launch_bounds__(64) void k_classify(DBatch b, GraphWs ws, u32* max_
         }
         // the trip's four words in one store (a lane's words are consecutive; 64 lanes x 4 bytes per store instruction
         // was 64 separate 4-byte writes)
-        if (o + 4 <= nk) {
+        if (o + 4 <= o_end) {
           u32* dst = inst_slot + ibase + o;
           if ((reinterpret_cast<uintptr_t>(dst) & 15u) == 0) {
             *reinterpret_cast<uint4*>(dst) = make_uint4(wd[0], wd[1], wd[2], wd[3]);
@@ -508,9 +538,9 @@ __global__ __launch_bounds__(64) void k_classify(DBatch b, GraphWs ws, u32* max_
         } else {
 #pragma unroll
           for (u32 j = 0; j < 4; ++j)
-            if (o + j < nk) inst_slot[ibase + o + j] = wd[j];
+            if (o + j < o_end) inst_slot[ibase + o + j] = wd[j];
         }
-        if (((o + 4) & 31u) == 0 || o + 4 >= nk) {  // (o is a multiple of 4: a mask word fills up exactly at a trip's end)
+        if (((o + 4) & 31u) == 0 || o + 4 >= o_end) {  // (o is a multiple of 4: a mask word fills up exactly at a trip's end)
           mw[o >> 5] = sacc;
           ew[o >> 5] = eacc;
           sacc = eacc = 0;
@@ -536,14 +566,14 @@ __global__ __launch_bounds__(64) void k_classify(DBatch b, GraphWs ws, u32* max_
   if (nslow) {
     u32 const* mw = l_mask + static_cast<u32>(lane) * MW;
     u32 const* ew = l_emask + static_cast<u32>(lane) * MW;
-    for (u32 x = 0; 32 * x < my_nk; ++x) {
+    for (u32 x = my_begin >> 5; 32 * x < my_nk; ++x) {  // (this wavefront's positions [my_begin, my_nk): whole mask words)
       u32 m = all_slow ? 0xFFFFFFFFu : mw[x];
       u32 const e = ew[x];
       if (32 * x + 32 > my_nk) m &= (1u << (my_nk - 32 * x)) - 1u;
       while (m) {
         u32 const bit = __ffs(m) - 1, o = x * 32 + bit;
         m &= m - 1;
-        slowq[at++] = (s_idx << 12) | o | (((e >> bit) & 1u) ? kQErrFree : 0u) | (o + 1 == my_nk ? kQLast : 0u);
+        slowq[at++] = (s_idx << 12) | o | (((e >> bit) & 1u) ? kQErrFree : 0u) | (o + 1 == read_nk ? kQLast : 0u);
       }
     }
   }
@@ -2675,7 +2705,7 @@ int run_build_pass(ma_ctx* ctx, const DBatch& b, GraphWs& ws, u32* counters_dev,
     MA_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_classify), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     static_cast<int>(lds_c)));
   ctx->tic("k_classify");
-  hipLaunchKernelGGL(k_classify, dim3(ws.n_active * tiles_per_win), dim3(64), lds_c, ctx->stream, b, ws, counters_dev,
+  hipLaunchKernelGGL(k_classify, dim3(ws.n_active * tiles_per_win), dim3(kClsT), lds_c, ctx->stream, b, ws, counters_dev,
                      tiles_per_win, tile_cap);
   ctx->toc();
   // (k_insert initialises the slots each window uses: no table-wide memsets)
