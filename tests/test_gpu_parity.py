@@ -202,18 +202,20 @@ def test_msa_parity_band_tiers(tier0, min_pending, monkeypatch):
         assert not bad, (cfg, kw, "\n".join(bad[:20]))
 
 
-@pytest.mark.parametrize("sched,wgs", [("1", None), ("1", "1"), ("0", None)])
+@pytest.mark.parametrize("sched,wgs", [("1", None), ("1", "1"), ("0", None), ("1", "xcd0")])
 def test_msa_persistent_kernel_on_a_batch_that_overfills_the_chip(sched, wgs, monkeypatch):
     """Round 6: k_poa schedules the windows on the device (fresh windows off a counter, fills and resumed windows through two
     queues in HBM, windows handed from workgroup to workgroup through their LDS image).  1536 windows -- three times what the
     chip holds at once, so workgroups take window after window and fills of many windows are in flight while others are
     resumed -- with every alignment through a fill (no closed forms) and indels that fail the first tier: the variants of all
-    1536 equal the oracle's for the 96 distinct windows they are copies of; two workgroups per CU, one, and the host-counted
-    rounds (MA_POA_SCHED=0) alike."""
+    1536 equal the oracle's for the 96 distinct windows they are copies of; two workgroups per CU, one, the host-counted
+    rounds (MA_POA_SCHED=0) and the single-domain variant with device-scope fences (MA_POA_XCD=0) alike."""
     from lancet2_amd.engine import Engine
     monkeypatch.setenv("MA_POA_SCHED", sched)
     monkeypatch.setenv("MA_POA_NO_DIRECT", "1")
-    if wgs:
+    if wgs == "xcd0":  # one scheduling domain for the whole chip, device-scope fences around every hand-over (MA_POA_XCD=0)
+        monkeypatch.setenv("MA_POA_XCD", "0")
+    elif wgs:
         monkeypatch.setenv("MA_POA_WGS_PER_CU", wgs)
     params = capi.default_params(min_k=25, max_k=25)
     parts = [synth.make_config_batch("C2", 48, first_index=8100), synth.make_config_batch("C2", 24, first_index=8300, big_indel=60),
