@@ -1001,10 +1001,15 @@ def main():
                 import queue
                 import threading
                 redo_q = queue.Queue()
+                redo_err = []
 
                 def redo_worker():
                     while redo_q.get() is not None:
-                        redo[0].process_device(*redo[1])
+                        try:
+                            if not redo_err:
+                                redo[0].process_device(*redo[1])
+                        except Exception as exc:  # (raised again on the main thread below)
+                            redo_err.append(exc)
 
                 redo_th = threading.Thread(target=redo_worker)
                 redo_th.start()
@@ -1016,6 +1021,8 @@ def main():
             if redo:
                 redo_q.put(None)
                 redo_th.join()
+                if redo_err:
+                    raise redo_err[0]
             barrier()
             dt_o = time.perf_counter() - t_o
             ost = a["win_status"].view(torch.int32).cpu().numpy().view(np.uint32)[:o_n].copy()
