@@ -947,7 +947,14 @@ def main():
                              "assembled_fraction": round(c_asm, 4)}
         ceng.close()
         # (2) the other WGS-shaped config, and the headline's windows sequenced 2 x 250
-        def device_leg(batch, label, leg_params=None, max_windows=None, kernels=False, parity_config=None, resubmit=False, steps=2):
+        def device_leg(batch, label, **kw):
+            # a secondary measurement must never cost the headline its line: an error becomes the leg's entry
+            try:
+                return device_leg_run(batch, label, **kw)
+            except Exception as exc:
+                return {"workload": label, "error": repr(exc)[:300]}
+
+        def device_leg_run(batch, label, leg_params=None, max_windows=None, kernels=False, parity_config=None, resubmit=False, steps=2):
             lp = leg_params or params
             o_arrs, o_n0, o_nr0 = batch
             o_arrs, o_n, o_nr = synth.tile_batch(o_arrs, o_n0, o_nr0, max(1, min(args.windows, n, max_windows or args.windows) // o_n0))
