@@ -4,16 +4,17 @@
 // kNW with convex gaps 0/-6/-6,-2/-26,-1: caller/msa_builder.h:72-89) and the caller::VariantSet
 // constructor (caller/variant_extractor.cpp:24-233, variant_bubble.cpp:16-116, raw_variant.cpp:44-77).
 //
-// Two kernels per alignment round (launch_msa):
-//  * k_msa -- one workgroup of 256 threads (4 wavefronts) per window; its components and haplotypes are processed one
-//    after another.  The POA graph (node chars, in/out adjacency with 16-bit ids, per-edge haplotype label masks,
-//    aligned-node rings, rank <-> node maps) lives in LDS (~42 B per node).  The kernel is a coroutine: when the next
-//    haplotype <-> graph alignment is ready for the DP it writes the row descriptors, saves its whole LDS block to HBM
-//    and returns; the next launch restores the block and continues after the fill (best end cell, certificate,
-//    traceback, graph update, toposort, variants).
-//  * k_msa_band -- ONE wavefront per window fills a 256-column band around every row's backbone coordinate
-//    (poa_fill_band), reading the descriptors straight from the saved block: sixteen windows per CU instead of two.
-//    The band is exact by certificate (see poa_fill_band) or the alignment is redone with the full fill.
+// One persistent kernel per chunk of windows (launch_msa -> k_poa, round 6), two kinds of jobs scheduled on the device:
+//  * G jobs (msa_window) -- one workgroup of 256 threads (4 wavefronts) works on a window; its components and haplotypes are
+//    processed one after another.  The POA graph (node chars, in/out adjacency with 16-bit ids, per-edge haplotype label
+//    masks, aligned-node rings, rank <-> node maps) lives in LDS (~42 B per node).  msa_window is a coroutine: when the next
+//    haplotype <-> graph alignment is ready for the DP it writes the row descriptors, saves its LDS block to HBM and
+//    returns; the workgroup that takes the window after its fill restores the block and continues (best end cell,
+//    certificate, traceback, graph update, toposort, variants).
+//  * F jobs (band_job) -- ONE wavefront fills a band of 64 / 128 / 256 columns around every row's backbone coordinate
+//    (poa_fill_lean / poa_fill_band), reading the descriptors straight from the saved block.  The band is exact by
+//    certificate (see poa_fill_band) or the alignment is redone with the next tier, at last with the full fill.
+//  (k_msa / k_msa_band run the same two bodies as rounds the host counts: MA_POA_SCHED=0, the scheduling of rounds 3-5.)
 //  * Full fill (poa_fill<CW>, fallback and MA_POA_BAND=0): row-synchronous, all 256 lanes work on ONE DP row, lane l
 //    owns CW consecutive columns; the horizontal gap chains (E, Q) are closed with two prefix maxima over the row
 //    (DPP scans + one LDS exchange across the wave boundaries); the previous two rows stay in registers.  A row is
@@ -2168,7 +2169,9 @@ __device__ __forceinline__ u32 msa_window(MsaArgs const& A, int const lw, bool c
     {  // 16 bytes per thread and load, four loads in flight (img_words is a multiple of 64, the image 256-byte aligned)
       const uint4* src = reinterpret_cast<const uint4*>(img);
       uint4* dst = reinterpret_cast<uint4*>(ma_lds);
-      u32 const nq = ws.img_words / 4u;
+      // (the block's last array, the alignment path buffer `aln`, is scratch before the fill -- the list of slow rows -- and
+      //  written afresh by the traceback after it: neither saved nor restored, 9 of the block's 80 KB)
+      u32 const nq = min(ws.img_words / 4u, (g.aln.off + 15u) / 16u);
       for (u32 i0 = tid; i0 < nq; i0 += 4u * kT) {
         uint4 v[4];
 #pragma unroll
@@ -2957,7 +2960,7 @@ __device__ __forceinline__ u32 msa_window(MsaArgs const& A, int const lw, bool c
     {
       uint4* dst = reinterpret_cast<uint4*>(img);
       const uint4* src = reinterpret_cast<const uint4*>(ma_lds);
-      u32 const nq = ws.img_words / 4u;
+      u32 const nq = min(ws.img_words / 4u, (g.aln.off + 15u) / 16u);
       for (u32 i = tid; i < nq; i += kT) dst[i] = src[i];
     }
     PROF_ACC(14);  // image save
