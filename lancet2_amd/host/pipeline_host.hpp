@@ -1018,6 +1018,7 @@ struct FlatBatch {
   // thread -- bounded the whole stage at ~30 k windows/s whatever the number of collectors): PlaceHeader() appends only the
   // window's scalars and returns where its arrays go; once the batch is closed SizeForPlaced() sizes the arrays (no zero-fill
   // of the big ones) and any thread copies a window into its place with CopyPlaced() -- disjoint ranges, no locks.
+  // (A batch is built EITHER this way or with Add() / Append(): the placed sizes below are counted by PlaceHeader() alone.)
   struct Place {
     size_t ref0, read0;
     uint64_t base0;
