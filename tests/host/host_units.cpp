@@ -226,6 +226,24 @@ int main() {
       CHECK(serial.read_sample == placed.read_sample && serial.read_flags == placed.read_flags && serial.read_hint == placed.read_hint);
       CHECK(serial.ref_off == placed.ref_off && serial.read_off == placed.read_off && serial.read_win_off == placed.read_win_off);
       CHECK(serial.read_qname_id == placed.read_qname_id && serial.sample_cov == placed.sample_cov && placed.windows.size() == 3);
+      // a recycled batch (Clear() keeps the arrays' memory): built again from two of the windows it equals a fresh one
+      placed.Seal();
+      placed.Clear();
+      CHECK(placed.windows.empty() && placed.read_bases.empty() && placed.ref_off == (std::vector<uint32_t>{0}) && placed.view.n_windows == 0);
+      FlatBatch fresh2;
+      fresh2.Add(w2, ref, r2, &si); fresh2.Add(w0, ref, r0, &si);
+      std::vector<std::pair<std::unique_ptr<FlatBatch>, FlatBatch::Place>> again;
+      for (auto const& pr : {std::make_pair(&w2, &r2), std::make_pair(&w0, &r0)}) {
+        auto one = std::make_unique<FlatBatch>();
+        one->Add(*pr.first, ref, *pr.second, &si);
+        FlatBatch::Place const pl = placed.PlaceHeader(*one);
+        again.emplace_back(std::move(one), pl);
+      }
+      placed.SizeForPlaced();
+      for (auto const& t : again) placed.CopyPlaced(*t.first, t.second);
+      CHECK(fresh2.read_bases == placed.read_bases && fresh2.read_quals == placed.read_quals && fresh2.read_off == placed.read_off);
+      CHECK(fresh2.read_win_off == placed.read_win_off && fresh2.ref_off == placed.ref_off && fresh2.read_hint == placed.read_hint);
+      CHECK(fresh2.read_qname_id == placed.read_qname_id && fresh2.read_flags == placed.read_flags && fresh2.ref_bases == placed.ref_bases);
     }
     CHECK(serial.ref_bases == pieces.ref_bases && serial.read_bases == pieces.read_bases && serial.read_quals == pieces.read_quals);
     CHECK(serial.read_sample == pieces.read_sample && serial.read_flags == pieces.read_flags && serial.read_hint == pieces.read_hint);
