@@ -169,7 +169,7 @@ def pipeline_extract_leg(genome_len=2_400_000, depths=(30, 60), seed=0x5EED, thr
     try:
         exe = os.path.join(d, "pipeline_driver")
         lib = os.path.join(REPO, "lancet2_amd")
-        subprocess.check_call(["g++", "-std=c++17", "-O3", os.path.join(REPO, "examples", "pipeline_driver.cpp"), "-I", os.path.join(REPO, "include"),
+        subprocess.check_call(["g++", "-std=c++17", "-O3", "-march=native", os.path.join(REPO, "examples", "pipeline_driver.cpp"), "-I", os.path.join(REPO, "include"),
                                "-L", lib, "-lmicroasm", f"-Wl,-rpath,{lib}", "-Wl,--allow-shlib-undefined", "-DLANCET2_AMD_WITH_ZLIB", "-lz",
                                "-lpthread", "-o", exe] + list(cxx_flags))
         rng = np.random.default_rng(seed)

@@ -417,42 +417,69 @@ int main(int argc, char** argv) {
     Job cur = fresh();
     size_t n_dumped = 0;
     std::vector<CopyTask> staged;  // the current batch's windows, in order
+    // A closed batch is NOT waited for: its copy tasks are queued and the thread goes on with the next batch's headers; the
+    // batches whose copies are through are sealed and handed to the engine in order whenever this thread comes by (waiting
+    // at every close put most of a batch's 512 copies on this one thread: the collectors only look between two windows).
+    struct Pending {
+      Job job;
+      std::unique_ptr<std::atomic<size_t>> left;
+    };
+    std::deque<Pending> pending;
+    auto flush_ready = [&](bool wait_all) {
+      while (!pending.empty()) {
+        if (pending.front().left->load(std::memory_order_acquire) != 0) {
+          if (!wait_all) return;
+          if (!serve_copy()) std::this_thread::yield();
+          continue;
+        }
+        auto const ts = Clock::now();
+        Job j = std::move(pending.front().job);
+        pending.pop_front();
+        j.batch->Seal();
+        busy_extract += secs(Clock::now() - ts);  // (the Push below may wait for the engine: not this stage's time)
+        if (!dump_dir.empty()) {
+          char sub[64];
+          std::snprintf(sub, sizeof sub, "/batch_%04zu", n_dumped++);
+          std::string const d = dump_dir + sub;
+          std::string const cmd = "mkdir -p '" + d + "'";
+          if (std::system(cmd.c_str()) != 0) std::exit(4);
+          DumpBatch(d, *j.batch);
+        }
+        to_engine.Push(std::move(j));
+      }
+    };
     auto ship = [&] {
       if (cur.batch->windows.empty()) return;
       auto const ts = Clock::now();
       cur.batch->SizeForPlaced();
-      std::atomic<size_t> left{staged.size()};
+      hint_bases = cur.batch->read_bases.size() + cur.batch->read_bases.size() / 16;
+      hint_reads = cur.batch->read_qname_id.size() + cur.batch->read_qname_id.size() / 16;
+      hint_ref = cur.batch->ref_bases.size() + 64;
+      auto left = std::make_unique<std::atomic<size_t>>(staged.size());
       {
         std::lock_guard<std::mutex> g(copy_mu);
         for (auto& t : staged) {
           t.dst = cur.batch.get();
-          t.left = &left;
+          t.left = left.get();
           copy_q.push_back(std::move(t));
         }
       }
       copy_pending.fetch_add(staged.size(), std::memory_order_acq_rel);
       staged.clear();
-      while (left.load(std::memory_order_acquire) != 0)
-        if (!serve_copy()) std::this_thread::yield();
-      hint_bases = cur.batch->read_bases.size() + cur.batch->read_bases.size() / 16;
-      hint_reads = cur.batch->read_qname_id.size() + cur.batch->read_qname_id.size() / 16;
-      hint_ref = cur.batch->ref_bases.size() + 64;
-      cur.batch->Seal();
-      busy_extract += secs(Clock::now() - ts);  // (the Push below may wait for the engine: not this stage's time)
-      if (!dump_dir.empty()) {
-        char sub[64];
-        std::snprintf(sub, sizeof sub, "/batch_%04zu", n_dumped++);
-        std::string const d = dump_dir + sub;
-        std::string const cmd = "mkdir -p '" + d + "'";
-        if (std::system(cmd.c_str()) != 0) std::exit(4);
-        DumpBatch(d, *cur.batch);
-      }
-      to_engine.Push(std::move(cur));
+      pending.push_back(Pending{std::move(cur), std::move(left)});
+      busy_extract += secs(Clock::now() - ts);
       cur = fresh();
+      flush_ready(false);
     };
     for (size_t i = 0; i < windows.size(); ++i) {
       Slot& sl = slots[i];
-      while (!sl.ready.load(std::memory_order_acquire)) std::this_thread::sleep_for(std::chrono::microseconds(50));  // (no spinning: the collectors need the cores)
+      while (!sl.ready.load(std::memory_order_acquire)) {  // (no spinning: the collectors need the cores)
+        flush_ready(false);
+        auto const tc = Clock::now();
+        bool const copied = serve_copy();
+        if (copied) busy_extract += secs(Clock::now() - tc);
+        else std::this_thread::sleep_for(std::chrono::microseconds(50));
+      }
       auto const t0 = Clock::now();
       n_skipped[static_cast<int>(sl.st)]++;
       if (sl.st == WindowStatus::RUN) {
@@ -468,6 +495,7 @@ int main(int argc, char** argv) {
       if (static_cast<int>(cur.batch->windows.size()) >= batch_windows) ship();
     }
     ship();
+    flush_ready(true);
     extract_done.store(true, std::memory_order_release);
     to_engine.Close();
   });

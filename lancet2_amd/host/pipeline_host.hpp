@@ -1098,8 +1098,15 @@ inline bool ReadCollector::CollectFlat(Window const& w, std::string_view ref_seq
   struct Ref {
     const SamRecord* rec;
     uint64_t qh;
+    uint64_t qpre;    // the name's first eight bytes, big-endian, zero-padded: its order is the names' order while it differs
     uint32_t sample;  // position in samples_
     uint32_t order;   // arrival order (ties of the comparator)
+  };
+  auto name_prefix = [](std::string const& q) {
+    uint64_t v = 0;
+    size_t const n = std::min<size_t>(q.size(), 8);
+    for (size_t i = 0; i < n; ++i) v |= static_cast<uint64_t>(static_cast<unsigned char>(q[i])) << (56 - 8 * i);
+    return v;
   };
   std::vector<Ref> kept;
   std::deque<SamRecord> arena;  // an indexed source hands out temporaries
@@ -1124,7 +1131,7 @@ inline bool ReadCollector::CollectFlat(Window const& w, std::string_view ref_seq
       }
       n_reads += 1;
       n_bases += a.seq.size();
-      kept.push_back(Ref{p, HashQname(a.qname), static_cast<uint32_t>(si), static_cast<uint32_t>(kept.size())});
+      kept.push_back(Ref{p, HashQname(a.qname), name_prefix(a.qname), static_cast<uint32_t>(si), static_cast<uint32_t>(kept.size())});
     });
     double const bases_per_read = static_cast<double>(n_bases) / static_cast<double>(std::max<uint64_t>(n_reads, 1));
     uint64_t const max_reads = static_cast<uint64_t>(std::ceil(max_sample_bases / bases_per_read));
@@ -1155,6 +1162,9 @@ inline bool ReadCollector::CollectFlat(Window const& w, std::string_view ref_seq
       if (ls.tag != rs.tag) return static_cast<uint8_t>(ls.tag) < static_cast<uint8_t>(rs.tag);
       if (ls.name != rs.name) return ls.name < rs.name;
     }
+    // (names: bytes compare as unsigned chars, a proper prefix sorts first -- what the zero-padded big-endian prefix orders by
+    //  while it differs; the 5 500 comparisons of a window's sort were string comparisons, most of the collector's time)
+    if (l.qpre != r.qpre) return l.qpre < r.qpre;
     if (l.qh != r.qh || l.rec->qname != r.rec->qname) return l.rec->qname < r.rec->qname;
     if (l.rec->chrom != r.rec->chrom) return l.rec->chrom < r.rec->chrom;
     if (l.rec->pos0 != r.rec->pos0) return l.rec->pos0 < r.rec->pos0;
