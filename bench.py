@@ -709,6 +709,26 @@ def main():
     annot_k = {}
     for name, ms in eng.kernel_times():
         annot_k[name] = annot_k.get(name, 0.0) + ms / max(args.steps, 1)
+    # ---- the measured device-copy ceiling SURVEY 8(d) asks for beside the 8 TB/s vendor figure: 1 GiB copied device to
+    #      device (read + write = 2 GiB of HBM traffic per copy), after the timed region, torch events on torch's stream ----
+    copy_ceiling = None
+    try:
+        cbytes = 1 << 30
+        csrc_t = torch.empty(cbytes, dtype=torch.uint8, device=dev).fill_(7)
+        cdst_t = torch.empty(cbytes, dtype=torch.uint8, device=dev)
+        for _ in range(3):
+            cdst_t.copy_(csrc_t)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            cdst_t.copy_(csrc_t)
+        e1.record()
+        torch.cuda.synchronize()
+        copy_ceiling = round(2.0 * cbytes * 10 / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1)
+        del csrc_t, cdst_t
+    except Exception as ex:  # reported, never fatal: the ceiling is context for the roofline, not part of the metric
+        copy_ceiling = None
+        sys.stderr.write("bench: device-copy ceiling not measured: %r\n" % (ex,))
     rank_windows = None
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if oversub else dev)
@@ -785,7 +805,8 @@ def main():
         gbs = ab / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
         stages[s] = {"kernel_ms_per_step": round(ms, 3), "algorithmic_MB_per_step": round(ab / 1e6, 1),
                      "MB_per_window": round(survey_bytes(s, st) / 1e6, 4), "GB_per_s": round(gbs, 1),
-                     "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 5)}
+                     "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 5),
+                     "frac_of_copy_ceiling": round(gbs / copy_ceiling, 5) if copy_ceiling else None}
     step_bytes = sum(stage_bytes_step.values())
 
     # ---- dominant kernel: HBM roofline by its stage's SURVEY 8(d) bytes, and a VALU roofline from the PMC pass ----
@@ -826,6 +847,10 @@ def main():
                 "algorithmic_bytes_per_launch": int(bytes_per_launch),
                 # SURVEY 8(d) as written: the STAGE's algorithmic bytes per step / the summed time of the stage's kernels
                 "frac_survey": stages.get(sname, {}).get("frac_of_hbm_peak"),
+                # the same two against what a plain device-to-device copy of 1 GiB reaches on this GPU (read + write counted)
+                "copy_ceiling_GBps": copy_ceiling,
+                "frac_of_copy_ceiling": round(ach / copy_ceiling, 6) if copy_ceiling else None,
+                "frac_survey_of_copy_ceiling": stages.get(sname, {}).get("frac_of_copy_ceiling"),
                 "survey_stage_MB_per_step": stages.get(sname, {}).get("algorithmic_MB_per_step"),
                 "survey_stage_kernel_ms_per_step": stages.get(sname, {}).get("kernel_ms_per_step"),
                 "note": "achieved = this kernel's OWN algorithmic bytes per launch (bench.py: kernel_bytes = DESIGN.md section 4's per-window "
@@ -1225,7 +1250,9 @@ def main():
             "parity_sample": parity,
             "step_algorithmic": {"MB_per_step": round(step_bytes / 1e6, 1),
                                  "GB_per_s": round(step_bytes / (elapsed / args.steps) / 1e9, 1),
-                                 "frac_of_hbm_peak": round(step_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 5)},
+                                 "frac_of_hbm_peak": round(step_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 5),
+                                 "copy_ceiling_GBps": copy_ceiling,
+                                 "frac_of_copy_ceiling": round(step_bytes / (elapsed / args.steps) / 1e9 / copy_ceiling, 5) if copy_ceiling else None},
             "build": build_stamp(),  # what this run loaded: tools/pmc_per_kernel.py stamps the counters of a PMC pass with it
             "kernel_ms_per_step": kernel_ms_per_step, "stages": stages,
             "work": {"pairs_per_window": round(pairs_w, 1), "dp_pairs_per_window": round(dp_w, 1),
