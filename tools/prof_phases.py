@@ -44,4 +44,10 @@ for sym, names in (("ma_debug_chprof", ["load", "fastsv", "number", "anchors+can
     fn(buf, 0)
     vals = list(buf)[:len(names)]
     print(sym, {k: v for k, v in zip(names, vals)})
+fn = getattr(eng.lib, "ma_debug_vhist", None)
+if fn is not None:  # k_vote: how long its workgroups live (buckets of 131072 clock ticks)
+    hb = (C.c_ulonglong * 40)()
+    fn(hb, 0)
+    h = list(hb)
+    print("k_vote workgroup lifetimes, buckets of 131072 ticks:", h[:32], "longest", h[32] >> 24, "item", h[32] & 0xFFFFFF, "mean", h[33] // max(h[34], 1), "count", h[34])
 eng.close()
