@@ -1115,7 +1115,7 @@ void ma_destroy(ma_ctx_t* ctx) {
   for (auto& b : ctx->out_stage) b.release();
   ctx->ws_build.release(); ctx->ws_nodes.release(); ctx->ws_clean.release();
   ctx->spec_data.release(); ctx->spec_out.release(); ctx->spec_nodes.release();
-  ctx->ws_poa.release(); ctx->ws_aln.release(); ctx->ws_misc.release(); ctx->ws_cx.release(); ctx->ws_gen.release(); ctx->ws_mm.release(); ctx->dev_stats.release();
+  ctx->ws_aln.release(); ctx->ws_misc.release(); ctx->ws_cx.release(); ctx->ws_gen.release(); ctx->ws_mm.release(); ctx->dev_stats.release();
   ctx->pack_aux.release();
   for (auto& pp : ctx->pin) {
     if (pp) (void)hipHostFree(pp);

@@ -544,7 +544,9 @@ int launch_assemble(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& out, const
       carve_ws(probe, tmp, 1);
     }
     size_t const per_window = probe.off + 4096;
-    size_t budget = stage_budget(0.30, ctx->ws_build.cap, size_t(24) << 30, ctx->hbm_share);
+    // (0.60 of the device for this stage AND the POA stage, which works in the same arena afterwards -- poa.hip; until round 6
+    //  each had 0.30 of its own and a lane's 4096 windows of the headline workload went through both in two chunks)
+    size_t budget = stage_budget(0.60, ctx->ws_build.cap, size_t(48) << 30, ctx->hbm_share);
     if (const char* e = getenv("MA_WS_GB")) budget = static_cast<size_t>(atoi(e)) << 30;
     int chunk = static_cast<int>(std::max<size_t>(1, std::min<size_t>(n, budget / per_window)));
     MA_HIP(ctx, ctx->ws_build.reserve(per_window * static_cast<size_t>(chunk)));

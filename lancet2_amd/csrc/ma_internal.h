@@ -75,7 +75,7 @@ struct ma_ctx {
   ma::DevBuf in_stage[10];
   std::vector<ma::DevBuf> out_stage;
   // per-stage workspaces (grow-only, reused across calls)
-  ma::DevBuf ws_build, ws_nodes, ws_clean, ws_poa, ws_aln, ws_misc, ws_gen, ws_mm;
+  ma::DevBuf ws_build, ws_nodes, ws_clean, ws_aln, ws_misc, ws_gen, ws_mm;  // (ws_build: the assembly stage's arena, then the POA stage's)
   // speculative tail of the k ladder (assemble.hip: speculate_tail): the derived batch, its outputs and the bookkeeping of the
   // nested pass; spec_k = the rung every window of the nested pass is built at (null outside of it)
   ma::DevBuf spec_data, spec_out, spec_nodes;

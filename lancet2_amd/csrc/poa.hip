@@ -82,8 +82,18 @@ struct PoaWs {
   u32 lean;          // band tiers run poa_fill_lean (default) / poa_fill_band (MA_POA_LEAN=0; same codes, tested)
   u32 lab32;         // this pass runs the kernels with 32-bit label masks (components of 17 .. 32 haplotypes)
   u32 pass;          // 0: every window; 1: only windows whose components all hold <= 16 haplotypes; 2: only the others
-  size_t code_cells; // u16 per window
-  size_t row_cells;  // i32 per window
+  size_t code_cells; // bytes per decision-code plane of a window's OWN area: band fills ((pn + 2) rows x 256 columns at most)
+  size_t row_cells;  // i32 per window: row_slots stored rows x 3 matrices x band_stride
+  // The full row-synchronous fill (the last tier: an alignment whose 256-column band failed its certificate) needs whole
+  // rows -- (pn + 2) x (max_len + 16) code bytes per plane, row_slots x 3 x w_stride stored cells: 10 MB per window of
+  // 1 kb haplotypes where the band tiers need 2.7 -- and begins and ends inside one G job: its areas belong to the
+  // WORKGROUP that runs it (k_poa: one per resident workgroup; the host-counted rounds: one per window, as before).
+  u16* fcodes;
+  i32* frows;
+  size_t fcode_cells;   // bytes per plane
+  size_t frow_cells;    // i32
+  u32 full_by_worker;   // 1: fcodes / frows are indexed by blockIdx.x, 0: by the window
+  u32 band_stride;      // i32 per stored row and matrix in the band fills (256: the widest tier)
   u16* codes;
   i32* rows;
   i32* hlast;        // [w][pn + 8] H(i, L)
@@ -820,7 +830,7 @@ __device__ __forceinline__ void poa_fill(GL const& g, PoaWs const& ws, u16* code
       // decision codes, row-major byte planes: one store of the wave covers 64 * CW contiguous bytes
       u8* const cp = reinterpret_cast<u8*>(codes) + static_cast<size_t>(i) * W + static_cast<size_t>(gl) * CW;
       store_code_bytes<CW>(cp, cd, 0);
-      if (!fast) store_code_bytes<CW>(cp + ws.code_cells, cd, 6);
+      if (!fast) store_code_bytes<CW>(cp + ws.fcode_cells, cd, 6);
       if (store) {
         u32 const slot = g.rowslot[i];
         i32* rb = rows + static_cast<size_t>(slot) * 3 * ws.w_stride + static_cast<size_t>(gl) * CW;
@@ -2145,8 +2155,11 @@ __device__ __forceinline__ u32 msa_window(MsaArgs const& A, int const lw, bool c
   if (poa_window_skipped(A, w)) return kMsaDone;  // the other pass's window
   u32 const PN = ws.pn;
   GL const g = poa_carve(PN, ws.max_l, LAB32 ? 1u : 0u);
-  u16* const codes = ws.codes + static_cast<size_t>(lw) * ws.code_cells;
+  u16* const codes = reinterpret_cast<u16*>(reinterpret_cast<u8*>(ws.codes) + static_cast<size_t>(lw) * ws.code_cells * 2);
   i32* const rows = ws.rows + static_cast<size_t>(lw) * ws.row_cells;
+  size_t const fslot = ws.full_by_worker ? static_cast<size_t>(blockIdx.x) : static_cast<size_t>(lw);
+  u16* const fcodes = reinterpret_cast<u16*>(reinterpret_cast<u8*>(ws.fcodes) + fslot * ws.fcode_cells * 2);
+  i32* const frows = ws.frows + fslot * ws.frow_cells;
   i32* const hlast = ws.hlast + static_cast<size_t>(lw) * (PN + 8);
   // raw-allele scratch of the bubble walk: the alignment scratch in LDS (free by then) while a bubble's alleles fit,
   // the code area in HBM beyond that (every byte thread 0 reads back from HBM is a round trip of its serial walk)
@@ -2235,7 +2248,7 @@ __device__ __forceinline__ u32 msa_window(MsaArgs const& A, int const lw, bool c
             u32 const V = ST.nrank;
             u32 const cw = L <= 1024 ? 4u : (L <= 1536 ? 6u : (L <= 2048 ? 8u : (L <= 3072 ? 12u : 16u)));
             u32 const nl = (L + cw - 1) / cw;
-            if (L > 4096 || V > PN || static_cast<size_t>(V + 1) * nl * cw > ws.code_cells) {
+            if (L > 4096 || V > PN || static_cast<size_t>(V + 1) * nl * cw > ws.fcode_cells) {
               ST.overflow = 1;
             } else {
               mode = 2;
@@ -2485,23 +2498,23 @@ __device__ __forceinline__ u32 msa_window(MsaArgs const& A, int const lw, bool c
             if (tid == 0) ST.band_fail = 0;
             if (wave == 0) {
               if (ws.lean)
-                poa_fill_lean<static_cast<int>(kTierIn)>(g, ws.w_stride, ws.code_cells, codes, rows, hlast, V, L, lane, seq,
+                poa_fill_lean<static_cast<int>(kTierIn)>(g, ws.band_stride, ws.code_cells, codes, rows, hlast, V, L, lane, seq,
                                                          ST.edge0, g.aln.off, &ST.edge_max);
               else
-                poa_fill_band<static_cast<int>(kTierIn)>(g, ws.w_stride, ws.code_cells, codes, rows, hlast, V, L, lane, seq,
+                poa_fill_band<static_cast<int>(kTierIn)>(g, ws.band_stride, ws.code_cells, codes, rows, hlast, V, L, lane, seq,
                                                          &ST.edge_max);
             }
           } else {
             if (cw == 4) {
-              poa_fill<4>(g, ws, codes, rows, hlast, V, L, tid, seq);
+              poa_fill<4>(g, ws, fcodes, frows, hlast, V, L, tid, seq);
             } else if constexpr (CWMAX > 4) {
               if (cw == 6) {
-                poa_fill<6>(g, ws, codes, rows, hlast, V, L, tid, seq);
+                poa_fill<6>(g, ws, fcodes, frows, hlast, V, L, tid, seq);
               } else if (cw == 8) {
-                poa_fill<8>(g, ws, codes, rows, hlast, V, L, tid, seq);
+                poa_fill<8>(g, ws, fcodes, frows, hlast, V, L, tid, seq);
               } else if constexpr (CWMAX > 8) {
-                if (cw == 12) poa_fill<12>(g, ws, codes, rows, hlast, V, L, tid, seq);
-                else poa_fill<16>(g, ws, codes, rows, hlast, V, L, tid, seq);
+                if (cw == 12) poa_fill<12>(g, ws, fcodes, frows, hlast, V, L, tid, seq);
+                else poa_fill<16>(g, ws, fcodes, frows, hlast, V, L, tid, seq);
               }
             }
           }
@@ -2553,7 +2566,8 @@ __device__ __forceinline__ u32 msa_window(MsaArgs const& A, int const lw, bool c
         bool const certified = !tier || (ST.best_row != 0xFFFFFFFFu && ST.best - 32 > ST.edge_max);
         if (wave == 0 && certified) {
           u32 const br = ST.best_row;
-          u32 const naln = poa_traceback(g, codes, ws.code_cells, cw, V, L, br == 0xFFFFFFFFu ? 0u : br, br != 0xFFFFFFFFu, lane, 64u * tier);
+          u32 const naln = poa_traceback(g, tier ? codes : fcodes, tier ? ws.code_cells : ws.fcode_cells, cw, V, L, br == 0xFFFFFFFFu ? 0u : br,
+                                         br != 0xFFFFFFFFu, lane, 64u * tier);
           if (lane == 0) ST.naln = naln;
         }
         __syncthreads();
@@ -3058,16 +3072,16 @@ __device__ __forceinline__ bool band_job(MsaArgs const& A, int const lw, int con
   u32 const hap0 = __builtin_amdgcn_readfirstlane(A.a.comp_hap0[ci]);
   size_t const hi = static_cast<size_t>(w) * P.max_haps + hap0 + h_cur;
   const u8* seq = A.a.hap_bases + hi * P.max_hap_len;
-  u16* const codes = ws.codes + static_cast<size_t>(lw) * ws.code_cells;
+  u16* const codes = reinterpret_cast<u16*>(reinterpret_cast<u8*>(ws.codes) + static_cast<size_t>(lw) * ws.code_cells * 2);
   i32* const rows = ws.rows + static_cast<size_t>(lw) * ws.row_cells;
   i32* const hlast = ws.hlast + static_cast<size_t>(lw) * (PN + 8);
   u32 const tier = __builtin_amdgcn_readfirstlane(pst->band);
   auto const fill = [&](auto cw) {
     constexpr int CW = decltype(cw)::value;
     if constexpr (LEAN)
-      poa_fill_lean<CW>(g, ws.w_stride, ws.code_cells, codes, rows, hlast, V, L, lane, seq, edge0, lut_off, &pst->edge_max);
+      poa_fill_lean<CW>(g, ws.band_stride, ws.code_cells, codes, rows, hlast, V, L, lane, seq, edge0, lut_off, &pst->edge_max);
     else
-      poa_fill_band<CW>(g, ws.w_stride, ws.code_cells, codes, rows, hlast, V, L, lane, seq, &pst->edge_max);
+      poa_fill_band<CW>(g, ws.band_stride, ws.code_cells, codes, rows, hlast, V, L, lane, seq, &pst->edge_max);
   };
   if (tier == 1) fill(std::integral_constant<int, 1>{});
   else if (tier == 2) fill(std::integral_constant<int, 2>{});
@@ -3165,9 +3179,42 @@ __device__ __forceinline__ void poa_acquire(bool device_scope) {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
+// The order in which k_poa starts a chunk's windows: most alignments first.  A launch lasts at least as long as its longest
+// window -- alignments are a chain (graph phase, fill, graph phase, ...) -- and a window with three of them that starts when the
+// others are through holds the launch, and every CU's LDS, for itself.  Counting sort by the number of alignments (33 buckets;
+// the order inside a bucket does not matter: windows are independent, every window's result is its own).
+__global__ __launch_bounds__(1024) void k_poa_order(MsaArgs A, u32* order, u32 nwin) {
+  __shared__ u32 cnt[34];
+  if (threadIdx.x < 34) cnt[threadIdx.x] = 0;
+  __syncthreads();
+  auto bucket_of = [&](u32 lw) {
+    int const w = A.win0 + static_cast<int>(lw);
+    if (poa_window_skipped(A, w)) return 33u;  // (returns at once: last)
+    u32 al = 0;
+    u32 const nc = A.a.win_ncomp[w];
+    for (u32 c = 0; c < nc; ++c) {
+      u32 const nh = A.a.comp_nhaps[static_cast<size_t>(w) * A.prm.max_comps + c];
+      al += nh > 1 ? nh - 1 : 0;
+    }
+    return 32u - min(al, 32u);
+  };
+  for (u32 lw = threadIdx.x; lw < nwin; lw += 1024) atomicAdd(&cnt[bucket_of(lw)], 1u);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    u32 run = 0;
+    for (u32 x = 0; x < 34; ++x) {
+      u32 const c = cnt[x];
+      cnt[x] = run;
+      run += c;
+    }
+  }
+  __syncthreads();
+  for (u32 lw = threadIdx.x; lw < nwin; lw += 1024) order[atomicAdd(&cnt[bucket_of(lw)], 1u)] = lw;
+}
+
 template <int CWMAX, bool LAB32>
 __global__ __launch_bounds__(kT, LAB32 ? 1 : 2) void k_poa(MsaArgs A, PoaSched* S, u32* fq_all, u32* gq_all, u32* hq_all, u32 qcap, u32 nwin,
-                                                           u32 xcd_local, u32 policy_min_fills) {
+                                                           u32 xcd_local, u32 policy_min_fills, const u32* order) {
   __shared__ u32 sh_job[8];  // [0] kind: 0 nothing right now, 1 fresh window, 2 window back from its fill, 3 fills, 4 leave; [1] count; [2..5] windows
   int const tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // HW_REG_XCC_ID (id 20), bits [3:0]: the XCD this workgroup runs on
@@ -3217,7 +3264,7 @@ __global__ __launch_bounds__(kT, LAB32 ? 1 : 2) void k_poa(MsaArgs A, PoaSched* 
           if (f < nwin) {
             kind = 1;
             cnt = 1;
-            ids[0] = f;
+            ids[0] = order ? order[f] : f;  // (k_poa_order: the windows with the most alignments start first)
             atomicAdd(&D->n_open, 1u);
             atomicAdd(&D->started, 1u);
           } else {
@@ -3386,8 +3433,8 @@ static int launch_msa_on_stream(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t
   {
     // (on the device: the five arrays used to come back whole -- 0.3 MB per lane into pageable memory, staged copies and a
     //  host loop in front of every lane's POA rounds -- for a few numbers)
-    MA_HIP(ctx, ctx->ws_poa.reserve(4096));
-    u32* mx = static_cast<u32*>(ctx->ws_poa.p);
+    MA_HIP(ctx, ctx->ws_build.reserve(4096));
+    u32* mx = static_cast<u32*>(ctx->ws_build.p);
     MA_HIP(ctx, hipMemsetAsync(mx, 0, 16, ctx->stream));
     hipLaunchKernelGGL(k_msa_maxima, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, a, n, static_cast<u32>(P.max_haps),
                        static_cast<u32>(P.max_comps), mx);
@@ -3430,9 +3477,10 @@ static int launch_msa_pass(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& a, 
   ws.row_slots = pn / 2;
   // MA_POA_BAND: 2 (default) = 256-column banded fill in its own kernel (k_msa_band), 1 = banded fill inside k_msa,
   // 0 = full row-synchronous fill only.  Results are identical (the band is certified or redone in full).
+  // (3, for tests: the persistent kernel with every alignment through the full fill -- its per-workgroup areas)
   int const band_mode = getenv("MA_POA_BAND") ? atoi(getenv("MA_POA_BAND")) : 2;
-  ws.use_band = band_mode != 0 ? 1u : 0u;
-  ws.split = band_mode == 2 ? 1u : 0u;
+  ws.use_band = (band_mode != 0 && band_mode != 3) ? 1u : 0u;
+  ws.split = band_mode >= 2 ? 1u : 0u;
   ws.no_direct = getenv("MA_POA_NO_DIRECT") ? 1u : 0u;
   ws.raw_cap = getenv("MA_POA_RAW_CAP") ? static_cast<u32>(atoi(getenv("MA_POA_RAW_CAP"))) : 0u;
   ws.lean = (getenv("MA_POA_LEAN") && atoi(getenv("MA_POA_LEAN")) == 0) ? 0u : 1u;
@@ -3448,37 +3496,23 @@ static int launch_msa_pass(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& a, 
   bool const verbose = getenv("MA_VERBOSE") != nullptr;
   bool const no_retry_rounds = getenv("MA_POA_NO_RETRY_ROUNDS") != nullptr;  // (A/B: round 3's rule)
   ws.img_words = static_cast<u32>((lds + 3) / 4);
-  ws.code_cells = (static_cast<size_t>(pn + 2) * (max_len + 16) + 7) & ~size_t(7);
+  // A window's own areas hold what the band tiers write (at most 256 columns per row: 2.7 MB per window of 1 kb haplotypes);
+  // the full fill's whole-row areas (10 MB) belong to whoever runs it -- see PoaWs.
+  ws.band_stride = 256;
+  ws.code_cells = (static_cast<size_t>(pn + 2) * 256 + 7) & ~size_t(7);
   if (ws.code_cells * 2 < static_cast<size_t>(P.max_haps) * (2 * max_len + 8) + 64)  // raw-allele scratch lives in the codes
     ws.code_cells = (static_cast<size_t>(P.max_haps) * (2 * max_len + 8) / 2 + 64 + 7) & ~size_t(7);
-  ws.row_cells = static_cast<size_t>(ws.row_slots) * 3 * ws.w_stride;
+  ws.row_cells = static_cast<size_t>(ws.row_slots) * 3 * ws.band_stride;
+  ws.fcode_cells = (static_cast<size_t>(pn + 2) * (max_len + 16) + 7) & ~size_t(7);
+  ws.frow_cells = static_cast<size_t>(ws.row_slots) * 3 * ws.w_stride;
+  size_t const full_bytes = ((ws.fcode_cells * 2 + 255) & ~size_t(255)) + ((ws.frow_cells * 4 + 255) & ~size_t(255));
 
   size_t const img_bytes = ws.split ? ((static_cast<size_t>(ws.img_words) * 4 + 255) & ~size_t(255)) : 0;
   ws.img_words = static_cast<u32>(ws.split ? img_bytes / 4 : ws.img_words);
-  size_t const per_window = ws.code_cells * 2 + ws.row_cells * 4 + (static_cast<size_t>(pn) + 8) * 4 + img_bytes;
-  (void)rounds;
-  size_t budget = stage_budget(0.30, ctx->ws_poa.cap, size_t(24) << 30, ctx->hbm_share);
-  if (const char* e = getenv("MA_WS_GB")) budget = static_cast<size_t>(atoi(e)) << 30;
-  int const chunk = static_cast<int>(std::max<size_t>(1, std::min<size_t>(n, budget / per_window)));
   // MA_POA_SCHED: 1 (default) = the persistent kernel k_poa schedules the windows on the device; 0 = rounds 3-5's host-counted
   // rounds of k_msa / k_msa_band (same device code: msa_window, band_job; same results, tested)
   bool const sched = ws.split && ws.lean && !(getenv("MA_POA_SCHED") && atoi(getenv("MA_POA_SCHED")) == 0);
-  u32 qcap = 64;
-  while (qcap < static_cast<u32>(chunk)) qcap <<= 1;
-  MA_HIP(ctx, ctx->ws_poa.reserve(per_window * static_cast<size_t>(chunk) + 8192 + 3 * sizeof(u32) * qcap * kPoaDoms + sizeof(PoaSched)));
-  u32 const xcd_local = (getenv("MA_POA_XCD") && atoi(getenv("MA_POA_XCD")) == 0) ? 0u : 1u;
-  if (getenv("MA_VERBOSE"))
-    fprintf(stderr, "[microasm] msa: %d windows, %.2f MB/window, budget %.1f GB -> chunks of %d (pn %u, max_len %u, lds %zu)\n", n,
-            per_window / 1048576.0, budget / 1073741824.0, chunk, pn, max_len, lds);
-  auto kern = lab32 ? (max_len <= 1024 ? k_msa<4, true> : (max_len <= 2048 ? k_msa<8, true> : k_msa<16, true>))
-                    : (max_len <= 1024 ? k_msa<4, false> : (max_len <= 2048 ? k_msa<8, false> : k_msa<16, false>));
-  MA_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  static_cast<int>(lds)));
-  auto pkern = lab32 ? (max_len <= 1024 ? k_poa<4, true> : (max_len <= 2048 ? k_poa<8, true> : k_poa<16, true>))
-                     : (max_len <= 1024 ? k_poa<4, false> : (max_len <= 2048 ? k_poa<8, false> : k_poa<16, false>));
-  if (sched)
-    MA_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(pkern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    static_cast<int>(lds)));
+  ws.full_by_worker = sched ? 1u : 0u;
   // workgroups of the persistent kernel: what the chip holds at once (two per CU while the graph fits 80 KB of LDS; a lane
   // that runs beside others may be told to take one -- MA_POA_WGS_PER_CU -- and leave the other half of every CU's LDS to them)
   int n_cu = 256;
@@ -3488,9 +3522,39 @@ static int launch_msa_pass(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& a, 
   }
   int wgs_per_cu = lds > 80 * 1024 ? 1 : 2;
   if (const char* e = getenv("MA_POA_WGS_PER_CU")) wgs_per_cu = std::max(1, std::min(wgs_per_cu, atoi(e)));
+  size_t const per_window = ws.code_cells * 2 + ws.row_cells * 4 + (static_cast<size_t>(pn) + 8) * 4 + img_bytes + (sched ? 0 : full_bytes);
+  (void)rounds;
+  // The POA stage works in the ASSEMBLY stage's workspace: a lane runs its stages one after the other, and what the assembly
+  // kernels leave there is dead once the haplotypes are in the caller's buffers (ma_asm_out_t).  One arena for both instead of
+  // two that are never in use together: the assembly stage plans with twice the share it had (assemble.hip).
+  size_t budget = stage_budget(0.30, ctx->ws_build.cap, size_t(24) << 30, ctx->hbm_share);
+  if (const char* e = getenv("MA_WS_GB")) budget = static_cast<size_t>(atoi(e)) << 30;
+  // the persistent kernel's workgroups (each with a full-fill area of its own): what the chip holds, what the batch can use,
+  // and no more than half the stage's memory
+  size_t const max_workers = sched ? std::max<size_t>(1, std::min<size_t>(std::min<size_t>(n, static_cast<size_t>(n_cu) * wgs_per_cu),
+                                                                        budget / 2 / full_bytes)) : 0;
+  size_t const fixed_bytes = max_workers * full_bytes;
+  int const chunk = static_cast<int>(std::max<size_t>(1, std::min<size_t>(n, (budget > fixed_bytes ? budget - fixed_bytes : 0) / per_window)));
+  u32 qcap = 64;
+  while (qcap < static_cast<u32>(chunk)) qcap <<= 1;
+  MA_HIP(ctx, ctx->ws_build.reserve(per_window * static_cast<size_t>(chunk) + fixed_bytes + 16384 + 3 * sizeof(u32) * qcap * kPoaDoms +
+                                  sizeof(PoaSched) + sizeof(u32) * qcap));
+  u32 const xcd_local = (getenv("MA_POA_XCD") && atoi(getenv("MA_POA_XCD")) == 0) ? 0u : 1u;
+  if (getenv("MA_VERBOSE"))
+    fprintf(stderr, "[microasm] msa: %d windows, %.2f MB/window + %zu full-fill areas of %.2f MB, budget %.1f GB -> chunks of %d (pn %u, max_len %u, lds %zu)\n",
+            n, per_window / 1048576.0, max_workers, full_bytes / 1048576.0, budget / 1073741824.0, chunk, pn, max_len, lds);
+  auto kern = lab32 ? (max_len <= 1024 ? k_msa<4, true> : (max_len <= 2048 ? k_msa<8, true> : k_msa<16, true>))
+                    : (max_len <= 1024 ? k_msa<4, false> : (max_len <= 2048 ? k_msa<8, false> : k_msa<16, false>));
+  MA_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  static_cast<int>(lds)));
+  auto pkern = lab32 ? (max_len <= 1024 ? k_poa<4, true> : (max_len <= 2048 ? k_poa<8, true> : k_poa<16, true>))
+                     : (max_len <= 1024 ? k_poa<4, false> : (max_len <= 2048 ? k_poa<8, false> : k_poa<16, false>));
+  if (sched)
+    MA_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(pkern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    static_cast<int>(lds)));
   for (int win0 = 0; win0 < n; win0 += chunk) {
     int const nwin = std::min(chunk, n - win0);
-    char* base = static_cast<char*>(ctx->ws_poa.p);
+    char* base = static_cast<char*>(ctx->ws_build.p);
     size_t const csz = (static_cast<size_t>(nwin) * ws.code_cells * 2 + 255) & ~size_t(255);
     size_t const rsz = (static_cast<size_t>(nwin) * ws.row_cells * 4 + 255) & ~size_t(255);
     ws.codes = reinterpret_cast<u16*>(base);
@@ -3498,8 +3562,15 @@ static int launch_msa_pass(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& a, 
     ws.hlast = reinterpret_cast<i32*>(base + csz + rsz);
     size_t const hsz = (static_cast<size_t>(nwin) * (pn + 8) * 4 + 255) & ~size_t(255);
     ws.img = reinterpret_cast<u8*>(base + csz + rsz + hsz);
-    {  // counters behind the image area: [0] pending windows of the current launch, [8..15] tier statistics
-      u32* ctr = reinterpret_cast<u32*>(base + csz + rsz + hsz + static_cast<size_t>(nwin) * img_bytes);
+    // the full fill's areas: one per workgroup of the persistent kernel, one per window for the host-counted rounds
+    size_t const n_full = sched ? max_workers : static_cast<size_t>(nwin);
+    size_t const isz = (static_cast<size_t>(nwin) * img_bytes + 255) & ~size_t(255);
+    size_t const fcsz = (n_full * ws.fcode_cells * 2 + 255) & ~size_t(255);
+    size_t const frsz = (n_full * ws.frow_cells * 4 + 255) & ~size_t(255);
+    ws.fcodes = reinterpret_cast<u16*>(base + csz + rsz + hsz + isz);
+    ws.frows = reinterpret_cast<i32*>(base + csz + rsz + hsz + isz + fcsz);
+    {  // counters behind the areas: [0] pending windows of the current launch, [8..15] tier statistics
+      u32* ctr = reinterpret_cast<u32*>(base + csz + rsz + hsz + isz + fcsz + frsz);
       ctr = reinterpret_cast<u32*>((reinterpret_cast<uintptr_t>(ctr) + 255) & ~uintptr_t(255));
       ws.pending_ctr = ctr;
       ws.tier_stats = verbose ? ctr + 8 : nullptr;
@@ -3512,12 +3583,16 @@ static int launch_msa_pass(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& a, 
       u32* const fq = reinterpret_cast<u32*>(qb + sizeof(PoaSched));
       u32* const gq = fq + static_cast<size_t>(qcap) * kPoaDoms;
       u32* const hq = gq + static_cast<size_t>(qcap) * kPoaDoms;
-      u32 const grid = static_cast<u32>(std::min(nwin, n_cu * wgs_per_cu));
+      u32 const grid = static_cast<u32>(std::min<size_t>(static_cast<size_t>(nwin), max_workers));
       MA_HIP(ctx, hipMemsetAsync(S, 0, sizeof(PoaSched), ctx->stream));
       MA_HIP(ctx, hipMemsetAsync(fq, 0xFF, 3 * sizeof(u32) * qcap * kPoaDoms, ctx->stream));
       u32 const min_fills = static_cast<u32>(getenv("MA_POA_MIN_FILLS") ? atoi(getenv("MA_POA_MIN_FILLS")) : 16);
+      static bool const by_work = !(getenv("MA_POA_ORDER") && atoi(getenv("MA_POA_ORDER")) == 0);  // (0: window order, as before)
+      u32* const order = by_work ? hq + static_cast<size_t>(qcap) * kPoaDoms : nullptr;
+      if (order) hipLaunchKernelGGL(k_poa_order, dim3(1), dim3(1024), 0, ctx->stream, args, order, static_cast<u32>(nwin));
       ctx->tic("k_poa");
-      hipLaunchKernelGGL(pkern, dim3(grid), dim3(kT), lds, ctx->stream, args, S, fq, gq, hq, qcap, static_cast<u32>(nwin), xcd_local, min_fills);
+      hipLaunchKernelGGL(pkern, dim3(grid), dim3(kT), lds, ctx->stream, args, S, fq, gq, hq, qcap, static_cast<u32>(nwin), xcd_local, min_fills,
+                         static_cast<const u32*>(order));
       ctx->toc();
       if (verbose) {
         PoaSched hs;

@@ -242,6 +242,41 @@ def test_msa_persistent_kernel_on_a_batch_that_overfills_the_chip(sched, wgs, mo
     assert want0["win_nvars"].sum() > 100
 
 
+def test_msa_full_fill_inside_the_persistent_kernel(monkeypatch):
+    """A window's own code / stored-row areas hold what the band tiers write (256 columns per row at most); the full
+    row-synchronous fill -- the last tier -- takes whole-row areas that belong to the WORKGROUP of k_poa that runs it.
+    MA_POA_BAND=3: k_poa with every alignment through the full fill, on 768 windows (more than the 512 workgroups: an area
+    serves window after window) of three shapes -- the variants equal the oracle's."""
+    from lancet2_amd.engine import Engine
+    monkeypatch.setenv("MA_POA_BAND", "3")
+    monkeypatch.setenv("MA_POA_NO_DIRECT", "1")
+    params = capi.default_params(min_k=25, max_k=25)
+    parts = [synth.make_config_batch("C2", 24, first_index=8600), synth.make_config_batch("C2", 12, first_index=8700, big_indel=60),
+             synth.make_config_batch("C3", 12, first_index=8800, snv_rate=8e-3, indel_rate=2e-3)]
+    import bench
+    arrs0, n0, nr0 = bench.concat_batches(parts)
+    orc = OracleEngine(params)
+    asm0 = orc.assemble(arrs0, n0, nr0)
+    want0 = orc.msa(arrs0, n0, nr0, asm0)
+    times = 16
+    arrs, n, nr = synth.tile_batch(arrs0, n0, nr0, times)
+    asm = {k: np.tile(v, times) for k, v in asm0.items()}
+    want = {k: np.tile(v, times) for k, v in want0.items()}
+    eng = Engine(params)
+    try:
+        eng.timing_control(3)  # (collect the device-side work counters too)
+        got = eng.msa(arrs, n, nr, asm)
+        bad = compare_vars(params, got, want, n)
+        assert not bad, "\n".join(bad[:20])
+        kt = dict(eng.kernel_times())
+        st = eng.stats()
+    finally:
+        eng.close()
+    assert "k_poa" in kt, kt
+    assert st["poa_full_cells"] > 0 and st["poa_band_fills"] == 0, st
+    assert want0["win_nvars"].sum() > 50
+
+
 @pytest.mark.parametrize("lean,raw_cap", [("0", None), ("1", "4"), ("1", "40")])
 def test_msa_parity_lean_fill_and_bubble_scratch(lean, raw_cap, monkeypatch):
     """poa_fill_lean (default) against poa_fill_band (MA_POA_LEAN=0): same decision codes, so the same variants; and the
