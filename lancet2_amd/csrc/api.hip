@@ -1435,8 +1435,13 @@ int ma_process_batch(ma_ctx_t* ctx, const ma_batch_t* b, const ma_gate_out_t* ga
   // before HIP starts gets four (+2 %).
   // (read once: the variable only means something if it was set before HIP started)
   static int const hwq = getenv("GPU_MAX_HW_QUEUES") ? atoi(getenv("GPU_MAX_HW_QUEUES")) : 4;
+  // Round 6, since a lane's windows go through every stage in ONE chunk: with a single k (no ladder) TWO lanes of 8192 windows
+  // beat four of 4096 (274 against 268 k windows/s on the headline workload; 2 / 3 / 4 / 5 / 6 lanes: 274 / 269 / 268 / 257 /
+  // 256) -- every launch has a tail and a latency floor that twice the windows amortise, and two lanes still overlap one
+  // stage's tail with another's body.  The ladder's many small rungs want the four (145 against 140 k).
+  bool const single_k = ctx->prm.min_k == ctx->prm.max_k;
   int lanes = ctx->n_lanes > 0 ? ctx->n_lanes
-                               : (d.n_windows >= 8192 && hwq >= 6 ? 4 : (d.n_windows >= 6144 ? 3 : (d.n_windows >= 2048 ? 2 : 1)));
+                               : (d.n_windows >= 8192 && hwq >= 6 ? (single_k ? 2 : 4) : (d.n_windows >= 6144 ? 3 : (d.n_windows >= 2048 ? 2 : 1)));
   if (const char* e = getenv("MA_STREAMS")) lanes = atoi(e) > 0 ? atoi(e) : lanes;
   if (lanes > d.n_windows / 2) lanes = d.n_windows / 2 > 0 ? d.n_windows / 2 : 1;
   if (lanes > 8) lanes = 8;

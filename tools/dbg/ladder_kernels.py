@@ -14,7 +14,7 @@ from lancet2_amd import capi  # noqa: E402
 from lancet2_amd.engine import Engine  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
-arrs, nw, nr = bench.make_windows("C3", n, 10_000, 8, 1)
+arrs, nw, nr = bench.make_windows("C3", n, 10_000, 8, 16)
 dev = torch.device("cuda", 0)
 d = {k: torch.from_numpy(v.view(np.uint8) if v.dtype != np.uint8 else v).to(dev) for k, v in arrs.items()}
 b = capi.make_batch_struct(d, nw, nr)
