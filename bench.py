@@ -814,10 +814,9 @@ def main():
     roof = roof_valu = None
     prof = {}
     def prof_is_stale(stamp):  # the counters were taken from another build than the one this run times
-        now = build_stamp()
-        if stamp.get("lib_sha16") and now.get("lib_sha16"):
-            return stamp["lib_sha16"] != now["lib_sha16"]
-        return stamp.get("csrc_sha16") != now["csrc_sha16"]
+        # by the kernel SOURCES: two builds of the same sources differ as files (hipcc's fat binaries are not reproducible bit
+        # for bit), so the library's own hash -- kept in the stamps for the record -- says nothing about a fresh build
+        return stamp.get("csrc_sha16") != build_stamp()["csrc_sha16"]
 
     for cand in ("r6_pmc_per_kernel.json", "r5_pmc_per_kernel.json", "r4_pmc_per_kernel.json", "r3_pmc_per_kernel.json", "r2_pmc_per_kernel.json"):
         tpath = os.path.join(REPO, "profiles", cand)
