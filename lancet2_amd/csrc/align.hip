@@ -39,6 +39,10 @@
 
 #include "ma_internal.h"
 
+// workgroups of the DP kernels in the order heaviest first (0: list order, as until round 6 -- developer A/B builds)
+#ifndef MA_REG_ORDER
+#define MA_REG_ORDER 1
+#endif
 namespace ma {
 
 namespace {
@@ -1794,8 +1798,9 @@ __device__ __forceinline__ i32 wave_excl_prefix_max(i32 x) {  // max over the la
 __global__ __launch_bounds__(64) void k_align_wave(GArgs A, u32 nchunk_alloc) {
   extern __shared__ u32 lds[];
   int const lane = threadIdx.x;
-  u32 const pi = blockIdx.x;
-  if (pi >= A.dp_n) return;
+  if (blockIdx.x >= A.dp_n) return;
+  // (the class's list is sorted by width step: the widest regions -- the longest workgroups -- start first)
+  u32 const pi = MA_REG_ORDER ? A.dp_n - 1u - blockIdx.x : blockIdx.x;
   u64 const lp = A.ws.dp_list[A.dp0 + pi];
   u32 const pr_ = A.ws.pair_read[lp];
   PairId const id{static_cast<int>(A.ws.read_win[pr_ & 0x7FFFFFFu]), pr_ & 0x7FFFFFFu, pr_ >> 27};
@@ -2260,7 +2265,7 @@ __device__ __forceinline__ void align_reg_body(GArgs const& A, u32 seg_words, u3
 template <int W, int WLO>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(reg_waves(W), 8))) void k_align_reg(GArgs A, u32 seg_words) {
   extern __shared__ u32 lds[];
-  align_reg_body<W, WLO>(A, seg_words, blockIdx.x, lds);
+  align_reg_body<W, WLO>(A, seg_words, MA_REG_ORDER ? gridDim.x - 1u - blockIdx.x : blockIdx.x, lds);  // (the widest groups first)
 }
 
 // Two width classes in one launch (the first n1 workgroups are class 1's groups): a launch lasts its 150 dependent rows
@@ -2531,9 +2536,20 @@ template <int W1, int WLO1, int W2, int WLO2>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 8))) void k_align_reg2p(GArgs A, RegPlan pl, u32 seg_words) {
   extern __shared__ u32 lds[];
   static_assert(reg_waves(W1) == reg_waves(W2), "same register budget");
+  // the heaviest groups first: the wider class before the narrower, packed groups (128 pairs) before the others, and -- the DP
+  // list of a class is sorted by width step -- a segment's last groups before its first: the launch ends with its cheapest
+  // workgroups (MA_REG_ORDER=0 at build time: in list order, as until round 6)
   u32 unit = blockIdx.x;
   int sg = 0;
-  while (sg < 3 && unit >= pl.seg[sg].units) unit -= pl.seg[sg++].units;
+  if (MA_REG_ORDER) {
+    constexpr int ord[4] = {1, 0, 3, 2};
+    int oi = 0;
+    while (oi < 3 && unit >= pl.seg[ord[oi]].units) unit -= pl.seg[ord[oi++]].units;
+    sg = ord[oi];
+    unit = pl.seg[sg].units - 1u - unit;
+  } else {
+    while (sg < 3 && unit >= pl.seg[sg].units) unit -= pl.seg[sg++].units;
+  }
   reg_seg_apply(A, pl.seg[sg]);
   if (sg == 0) {
     if (!align_reg_body_pk<W1, WLO1>(A, seg_words, unit, lds)) {
