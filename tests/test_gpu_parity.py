@@ -82,6 +82,46 @@ def test_repeat_gate_parity_window_lengths(mm):
     assert int(want["max_approx"][-1]) >= 60
 
 
+@pytest.mark.parametrize("mm", [0, 1, 2, 3])
+def test_repeat_gate_two_diagonals_per_lane(mm):
+    """Round 6: the gate walks TWO diagonals per lane in packed 16-bit halves (diagonal d + 1 is one position shorter than d
+    and is fed mismatches past its end).  Every window length from 2 to 72 and around the workgroup's strides (256 lanes x 2
+    diagonals), periodic sequences (every diagonal a long run), repeats that end on the window's last base, homopolymers, and
+    bytes that are not upper-case ACGT (N, lower case: the gate compares bytes) -- equal to the oracle for every budget."""
+    from lancet2_amd.engine import Engine
+    rng = np.random.default_rng(4100 + mm)
+    wins = []
+    for W in list(range(2, 73)) + [255, 256, 257, 511, 512, 513, 514, 1023, 1024, 1025, 1026, 2559]:
+        kind = W % 5
+        if kind == 0:
+            ref = np.frombuffer((b"ACGGT" * (W // 5 + 1))[:W], dtype=np.uint8).copy()          # period 5
+        elif kind == 1:
+            ref = np.full(W, ord("A"), dtype=np.uint8)                                          # homopolymer
+        else:
+            ref = synth.BASES[rng.integers(0, 4, W)].copy()
+            if W >= 24:  # a repeat whose second copy ends on the window's last base, with `mm` substitutions
+                L = min(W // 2 - 1, 40)
+                ref[W - L:] = ref[1:1 + L]
+                for x in rng.choice(L, size=min(mm, L), replace=False):
+                    ref[W - L + x] = ord("A") if ref[W - L + x] != ord("A") else ord("C")
+            if kind == 3 and W >= 8:
+                ref[rng.integers(0, W, 3)] = ord("N")
+            if kind == 4 and W >= 8:
+                idx = rng.integers(0, W, 4)
+                ref[idx] = ref[idx] | 0x20  # lower case
+        wins.append(dict(ref=ref, reads=[]))
+    arrs, n, nr = synth.pack_batch(wins)
+    params = capi.default_params(max_mismatch=mm)
+    want = OracleEngine(params).gate(arrs, n, nr)
+    eng = Engine(params)
+    try:
+        got = eng.gate(arrs, n, nr)
+    finally:
+        eng.close()
+    assert np.array_equal(got["max_approx"], want["max_approx"]), [(i, int(a), int(b)) for i, (a, b) in enumerate(zip(got["max_approx"], want["max_approx"])) if a != b][:10]
+    assert np.array_equal(got["max_exact"], want["max_exact"]), [(i, int(a), int(b)) for i, (a, b) in enumerate(zip(got["max_exact"], want["max_exact"])) if a != b][:10]
+
+
 from harness import compare_asm  # noqa: E402
 
 
