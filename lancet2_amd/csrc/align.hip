@@ -149,14 +149,14 @@ __global__ __launch_bounds__(256) void k_max_reads(DBatch b, u32* win_status, u3
 #pragma unroll
   for (int d = 32; d > 0; d >>= 1) ml = max(ml, static_cast<u32>(__shfl_xor(ml, d, 64)));
   if (lane != 0) return;
-  atomicMax(out, b.read_win_off[w + 1] - b.read_win_off[w]);
+  atomic_max_lazy(out, b.read_win_off[w + 1] - b.read_win_off[w]);
   // (a window the assembler skipped for its reads keeps that flag: it has no haplotypes to genotype)
   u32 const st = win_status[w] & ~static_cast<u32>(MA_W_CIGAR_OVERFLOW);
   if (ml > kMaxGenoRead) {
     win_status[w] = st | static_cast<u32>(MA_W_READ_OVERFLOW);
   } else {
     win_status[w] = (st & MA_W_NO_HAPLOTYPE) ? st : (st & ~static_cast<u32>(MA_W_READ_OVERFLOW));
-    atomicMax(out + 1, ml);
+    atomic_max_lazy(out + 1, ml);
   }
 }
 
@@ -179,7 +179,7 @@ __global__ void k_plan(GArgs A) {
       }
     }
   }
-  if (hl) atomicMax(&A.ws.counters[3], hl);  // longest haplotype that is aligned: sizes k_vote's LDS
+  if (hl) atomic_max_lazy(&A.ws.counters[3], hl);  // longest haplotype that is aligned: sizes k_vote's LDS
   A.ws.win_slotmask[w] = mask;
   if (mask) {  // dense work list: a (window, slot) grid would leave most workgroups (and whole XCDs) empty
     u32 at = atomicAdd(&A.ws.counters[2], static_cast<u32>(__popc(mask)));
@@ -187,7 +187,7 @@ __global__ void k_plan(GArgs A) {
   }
   u32 const nr = A.b.read_win_off[w + 1] - A.b.read_win_off[w];
   A.ws.pair_off[w] = static_cast<u64>(nr) * __popc(mask);  // counts; scanned below
-  atomicMax(&A.ws.counters[1], nr);
+  atomic_max_lazy(&A.ws.counters[1], nr);
 }
 
 // The per-read part of the plan, one wavefront per window (a thread per window walking its 600 reads was 600 dependent
@@ -211,7 +211,7 @@ __global__ __launch_bounds__(256) void k_plan_reads(GArgs A) {
   }
   if (lane == 0) {
     A.ws.win_case[w] = cm;
-    if (ml && !(A.a.win_status[w] & MA_W_READ_OVERFLOW)) atomicMax(&A.ws.counters[0], ml);
+    if (ml && !(A.a.win_status[w] & MA_W_READ_OVERFLOW)) atomic_max_lazy(&A.ws.counters[0], ml);
   }
 }
 
@@ -523,8 +523,8 @@ __device__ __forceinline__ u32 vote_settle(GArgs const& A, u64 lp, PairId id, i3
   i32 const kw = cls < kNumReg ? reg_width(cls) : static_cast<i32>(r_w);
   u32 const wall = (r_lo >= 0 && r_lo + kw + m + 8 <= n) ? 0u : 1u;
   u32 const key = static_cast<u32>(cls) * 2u + wall;
-  if (cls == kClsGlobal) atomicMax(&A.ws.dp_count[40], r_w);
-  if (cls == kClsWaveB) atomicMax(&A.ws.dp_count[41], r_w);
+  if (cls == kClsGlobal) atomic_max_lazy(&A.ws.dp_count[40], r_w);
+  if (cls == kClsWaveB) atomic_max_lazy(&A.ws.dp_count[41], r_w);
   if (cls >= kNumReg)
     A.ws.vote_aux[lp] = static_cast<u64>(static_cast<u32>(c - r_lo) & 0xFFFFu) | (static_cast<u64>(min(vfar8, 65535u)) << 16) |
                         (static_cast<u64>(min(vfar16, 65535u)) << 32) | (static_cast<u64>(min(vfar24, 65535u)) << 48);

@@ -108,12 +108,14 @@ __global__ __launch_bounds__(kBT) void k_count_inst(DBatch b, GraphWs ws, int wi
     read_inst = running - refk;
     ws.win_ninst[w] = running;
     ws.win_nread_inst[w] = read_inst;
-    atomicMax(&maxima[0], running);
-    atomicMax(&maxima[1], read_inst);
-    atomicMax(&maxima[2], refk);
-    atomicMax(&maxima[3], ns - 1);
+    atomic_max_lazy(&maxima[0], running);
+    atomic_max_lazy(&maxima[1], read_inst);
+    atomic_max_lazy(&maxima[2], refk);
+    atomic_max_lazy(&maxima[3], ns - 1);
   }
-  if (max_len) atomicMax(&maxima[4], max_len);
+  // (one report per wavefront, not one per thread: every thread of every window used to send its longest read)
+  for (int off = 32; off > 0; off >>= 1) max_len = max(max_len, static_cast<u32>(__shfl_xor(max_len, off)));
+  if ((threadIdx.x & 63) == 0 && max_len) atomic_max_lazy(&maxima[4], max_len);
 }
 
 // ---- choose the windows of this pass and the k each of them attempts (graph.cpp:106-120) ----
@@ -559,7 +561,7 @@ __global__ __launch_bounds__(kClsT) void k_classify(DBatch b, GraphWs ws, u32* m
   u32 qbase = 0;
   if (lane == 0 && wave_total) {
     qbase = atomicAdd(&ws.n_slow[a], wave_total);
-    atomicMax(max_slow, qbase + wave_total);
+    atomic_max_lazy(max_slow, qbase + wave_total);
   }
   qbase = __shfl(qbase, 0);
   u32 at = qbase + inc - nslow;
@@ -1467,13 +1469,13 @@ __global__ __launch_bounds__(kSupT) void k_support(DBatch b, GraphWs ws, u32* ma
     ws.n_genq[a] = (qmode || qdedup) ? genq_n : 0u;
     // bit 29: counts queued for k_graph (dedup mode), bit 30: keys queued for k_mm_q, bit 31: HBM set; else k_mm_lds
     ws.mm_mode[a] = qdedup ? (gen_count | 0x20000000u) : qmode ? (gen_count | 0x40000000u) : (gen_count | (lds_ok ? 0u : 0x80000000u));
-    atomicMax(max_gen, gen_count);
+    atomic_max_lazy(max_gen, gen_count);
     ws.mm_log2[a] = 0;
     if (!qmode && !lds_ok && gen_count) {
       // the window's HBM-resident set: 12 bytes per entry at a load of 3/4, carved out of the chunk's pool.  A pool that is
       // used up is a capacity like any other: the window is flagged and the retry pass, whose pool holds a full set per
       // window, re-assembles it.
-      atomicMax(max_gen + 1, gen_count);
+      atomic_max_lazy(max_gen + 1, gen_count);
       u32 lg = 10;
       while (lg < 31u && (1ull << lg) < static_cast<u64>(gen_count) * 4u / 3u + 16u) ++lg;
       unsigned long long const bytes = ((12ull << lg) + 255ull) & ~255ull;

@@ -3375,10 +3375,10 @@ __global__ __launch_bounds__(256) void k_msa_maxima(ma_asm_out_t a, int n, u32 m
     mlw = max(mlw, __shfl_xor(mlw, off));
   }
   if ((threadIdx.x & 63) == 0) {
-    if (ml) atomicMax(&out[0], ml);
-    if (al) atomicMax(&out[1], al);
-    if (mh) atomicMax(&out[2], mh);
-    if (mlw) atomicMax(&out[3], mlw);
+    if (ml) atomic_max_lazy(&out[0], ml);
+    if (al) atomic_max_lazy(&out[1], al);
+    if (mh) atomic_max_lazy(&out[2], mh);
+    if (mlw) atomic_max_lazy(&out[3], mlw);
   }
 }
 static int launch_msa_on_stream(ma_ctx* ctx, const DBatch& b, const ma_asm_out_t& a, const ma_var_out_t& o);
