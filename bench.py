@@ -576,11 +576,14 @@ def main():
 
     # ---- everything that forks happens before the GPU is initialised ----
     distinct = min(args.distinct, args.windows)
-    # static sharding of ONE seeded window list over the ranks: window i -> rank i mod G (lancet2_amd/shard.py);
+    # static sharding of ONE seeded window list over the ranks: block b of 32 windows -> rank b mod G (lancet2_amd/shard.py);
     # with one rank these are the windows 10 000 ... 10 000 + distinct - 1
     from lancet2_amd.shard import shard_indices
     first = 10_000
-    mine = [first + i for i in shard_indices(distinct * world, rank, world)]
+    # (dealt out in blocks of the workload's period: every 8th / 16th / 32nd window is of a difficult kind -- window i -> rank
+    #  i mod G alone would hand rank 7 of 8 every tandem-repeat window and rank 0 none; 32 = the longest period)
+    shard_block = 32 if distinct % 32 == 0 else 1
+    mine = [first + i for i in shard_indices(distinct * world, rank, world, shard_block)]
     t_gen = time.perf_counter()
     arrs0, n0, nr0 = make_windows(args.config, distinct, first, args.str_every, workers, indices=mine)
     also_arrs = long_arrs = None
@@ -686,7 +689,8 @@ def main():
     # ---- parity sample: the outputs of the LAST timed step for the windows the cpu_baseline legs ran the oracle on ----
     parity = None
     if kept:
-        row_of = None if world == 1 else (lambda w_: (w_ - first - rank) // world)
+        mine_row = {w_: j_ for j_, w_ in enumerate(mine)}
+        row_of = None if world == 1 else (lambda w_: mine_row[w_])
         pc, pbad, pfl = parity_check(kept, args.config, first, params, n, (g, a, v, q), row_of=row_of)
         parity = {"windows": pc, "mismatches": len(pbad), "c4_windows": 0, "flagged_windows_status_only": pfl,
                   "checked": "repeat gate, haplotypes / weights / statistics (f64 bit patterns), variants and alleles, allele counts, "
@@ -783,10 +787,16 @@ def main():
     stage_bytes_step = {s: survey_bytes(s, st) * units_per_step(s, st) for s in ("gate", "build", "clean", "poa", "genotype")}
 
     # the metric counts ASSEMBLED windows: those that pass the repeat gate, yield haplotypes and run POA and
-    # genotyping too -- every rank holds the same mix, so rank 0's assembled fraction stands for all
+    # genotyping too -- counted on every rank and added up (the ranks' shards hold the same mix: blocks of the workload's
+    # period; the sum does not depend on that)
     total_windows = n * args.steps * world
     wps_all = total_windows / elapsed
-    asm_wps = assembled * args.steps * world / elapsed
+    assembled_all = assembled * world
+    if world > 1:
+        t_asm = torch.tensor([assembled], dtype=torch.int64, device="cpu" if oversub else dev)
+        dist.all_reduce(t_asm, op=dist.ReduceOp.SUM)
+        assembled_all = int(t_asm.item())
+    asm_wps = assembled_all * args.steps / elapsed
 
     # ---- per-kernel / per-stage times ----
     agg = {}
@@ -1237,7 +1247,7 @@ def main():
                        "soft_clipped_reads": args.softclip, "reads_with_N": args.nfrac,
                        "reads_without_hint": f"every {args.nohint_every}th read pair" if args.nohint_every else "none",
                        "reads_per_window": round(R, 1),
-                       "assembled_fraction": round(assembled / n, 4),
+                       "assembled_fraction": round(assembled_all / (n * world), 4),
                        "repeat_gated_fraction": round(gated / n, 4),
                        "windows_with_capacity_overflow": overflowed, "haplotypes_per_assembled_window": round(H, 2),
                        "sharding": "static, one process per GPU, no collective",

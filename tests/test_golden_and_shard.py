@@ -77,6 +77,23 @@ def test_shard_indices_cover_every_window_once():
         assert shard.merge_shards(per_rank, n, world) == [f"w{i}" for i in range(n)]
 
 
+def test_shard_indices_in_blocks_keep_a_periodic_mix():
+    """bench.py's window list has a difficult window of one kind at every 8th index, of another at every 16th, ...: dealt out
+    one by one (i mod G) rank 7 of 8 would hold every tandem-repeat window and rank 0 none.  In blocks of the period every
+    rank holds the same number of each kind; the blocks still cover every window once and merge_shards inverts them."""
+    for n, world, block in ((64 * 8, 8, 32), (32 * 6, 2, 32), (100, 4, 32), (10, 2, 3)):
+        shards = [shard.shard_indices(n, r, world, block) for r in range(world)]
+        assert sorted(i for sh in shards for i in sh) == list(range(n))
+        per_rank = [[f"w{i}" for i in sh] for sh in shards]
+        assert shard.merge_shards(per_rank, n, world, block) == [f"w{i}" for i in range(n)]
+    shards = [shard.shard_indices(32 * 8 * 4, r, 8, 32) for r in range(8)]
+    for sh in shards:  # the same mix on every rank
+        assert len(sh) == 128
+        assert sum(1 for i in sh if i % 8 == 7) == 16 and sum(1 for i in sh if i % 16 == 3) == 8 and sum(1 for i in sh if i % 32 == 13) == 4
+    one_by_one = shard.shard_indices(32 * 8 * 4, 7, 8)  # (what block = 1 does to such a list)
+    assert all(i % 8 == 7 for i in one_by_one)
+
+
 def _gloo_worker(rank, world, port, q):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"

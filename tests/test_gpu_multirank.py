@@ -2,7 +2,7 @@
 ranks through the same launcher parent the driver's multi-GPU tier relies on (torch.distributed.run as a child of a
 process that never touched the GPU), both ranks run on device 0 with half of the HBM planned each, gloo carries the
 barrier and the max-over-ranks.  Checked: rank 0's line says n_gpus 2, the ranks ran DISJOINT shards of one seeded
-window list (window i -> rank i mod 2, lancet2_amd/shard.py; core/pipeline_executor.cpp:174-197 is the reference's
+window list (blocks of 32 windows, block b -> rank b mod 2, lancet2_amd/shard.py; core/pipeline_executor.cpp:174-197 is the reference's
 worker model), and the engine's outputs for a sample of rank 0's own windows equal the oracle's."""
 import json
 import os
@@ -28,11 +28,16 @@ def test_two_ranks_rehearsed_on_one_device():
     assert out["config"]["oversubscribed"]
     rw = out["config"]["rank_windows"]
     assert [x["rank"] for x in rw] == [0, 1]
-    # one seeded list 10000 ... 10000 + 2047, window i -> rank i mod 2: disjoint, interleaved, complete
-    assert (rw[0]["first"], rw[0]["last"], rw[0]["count"]) == (10_000, 10_000 + 2046, 1024)
-    assert (rw[1]["first"], rw[1]["last"], rw[1]["count"]) == (10_001, 10_000 + 2047, 1024)
-    assert rw[0]["index_sum_mod_2_31"] == sum(range(10_000, 10_000 + 2048, 2)) % (1 << 31)
-    assert rw[1]["index_sum_mod_2_31"] == sum(range(10_001, 10_000 + 2048, 2)) % (1 << 31)
+    # one seeded list 10000 ... 10000 + 2047, dealt out in blocks of 32 windows (the period of the workload's difficult
+    # windows: every rank gets the same mix), block b -> rank b mod 2: disjoint, interleaved, complete
+    from lancet2_amd.shard import shard_indices
+    want = [[10_000 + i for i in shard_indices(2048, r, 2, 32)] for r in range(2)]
+    assert want[0][:33] == list(range(10_000, 10_032)) + [10_064] and sorted(want[0] + want[1]) == list(range(10_000, 12_048))
+    for r in range(2):
+        assert (rw[r]["first"], rw[r]["last"], rw[r]["count"]) == (want[r][0], want[r][-1], 1024)
+        assert rw[r]["index_sum_mod_2_31"] == sum(want[r]) % (1 << 31)
     assert out["config"]["windows_per_step_per_gpu"] == 1024
+    # the metric counts the windows BOTH ranks assembled (added up over the ranks, not rank 0's share times two)
+    assert 0.6 < out["config"]["assembled_fraction"] < 0.9, out["config"]["assembled_fraction"]
     ps = out["parity_sample"]
     assert ps["windows"] == 8 and ps["mismatches"] == 0, ps
